@@ -1,0 +1,267 @@
+# coding=utf-8
+"""bench.py — aggregated edges/s + HBM roofline of the GCN propagation (segment-sum) hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload products|arxiv|cora|tiny]
+
+A "step" is one pass of the hot path over the whole graph: out = A_hat @ h with the GCN-normalised adjacency
+(weighted gather - scale - segment-sum into destination nodes, the implicit self-loop term included; h is the
+[N, F] float32 feature matrix, resident in HBM before the timed region) — i.e. tfg.layers.GCN(use_kernel=False,
+use_bias=False) on the cached plan.  Default workload: the ogbn-products-shaped graph BASELINE.json's target is
+quoted on (N = 2.4 M, E = 123 M, F = 100).
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the SAME graph is sharded by destination-node range,
+halo source rows are exchanged as an all-to-all-v over RCCL and overlapped with the local-edge pass
+("scaling": "strong").
+
+Prints ONE JSON line (rank 0). `roofline` prices the dominant kernel (seg_reduce_kernel) with ALGORITHMIC bytes
+(SURVEY.md §8d): B_alg = E_agg*(4F + 8) + N*4F + 4(N+1), E_agg = E + N, against the 8 TB/s HBM3E peak.
+`cpu_baseline` times the C restatement of the reference path (oracle/tfg_oracle.c, "port") on the host cores over
+a bounded sample of the same workload.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12   # MI355X HBM3E peak, B/s (MI355X_MICROARCH.md)
+
+
+def parse_args():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--workload", default="products")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--extras", action="store_true", help="also time GEMM+aggregation layers (GCN/SAGE/GAT)")
+    p.add_argument("--seed", type=int, default=0)
+    return p.parse_args()
+
+
+def b_alg(e_agg, n, f, weighted=True):
+    return e_agg * (4 * f + 4 + (4 if weighted else 0)) + n * 4 * f + 4 * (n + 1)
+
+
+def cpu_baseline(x_np, ei_np, w_np, self_coef_np, n, f, budget_edges):
+    """C port of gather -> gcn_mapper -> unsorted_segment_sum (oracle/tfg_oracle.c), all host cores, on the
+    destination rows [0, n_s) of the same graph (full source range, so the gather locality is the job's)."""
+    lib_path = os.path.join(ROOT, "oracle", "libtfg_oracle.so")
+    lib = ctypes.CDLL(lib_path)
+    fn = lib.tfgo_aggregate_coo_f32
+    fn.restype = ctypes.c_int
+    cores = os.cpu_count() or 1
+    e_total = ei_np.shape[1]
+    frac = min(1.0, float(budget_edges) / max(e_total, 1))
+    n_s = max(1, int(n * frac))
+    keep = ei_np[0] < n_s
+    diag = np.arange(n_s, dtype=np.int32)            # the appended self-loop edges (add_diag, gcn.py:77)
+    row = np.ascontiguousarray(np.concatenate([ei_np[0][keep], diag]))
+    col = np.ascontiguousarray(np.concatenate([ei_np[1][keep], diag]))
+    w = np.ascontiguousarray(np.concatenate([w_np[keep], self_coef_np[:n_s]]))
+    out = np.empty((n_s, f), dtype=np.float32)
+    P = ctypes.c_void_p
+
+    def run():
+        rc = fn(P(x_np.ctypes.data), ctypes.c_int64(f), P(row.ctypes.data), P(col.ctypes.data), P(w.ctypes.data),
+                ctypes.c_int64(row.shape[0]), ctypes.c_int64(n_s), ctypes.c_int64(n), ctypes.c_int64(f),
+                ctypes.c_int(0), P(out.ctypes.data), ctypes.c_int64(f), ctypes.c_int(cores))
+        assert rc == 0
+
+    run()  # warm
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        run()
+        reps += 1
+        if time.perf_counter() - t0 > 10.0:
+            break
+    dt = (time.perf_counter() - t0) / reps
+    return {"value": row.shape[0] / dt, "unit": "edges/s", "cores": cores, "kind": "port",
+            "sample": "dst rows [0,{}) of the same graph: {} edges x F={} , full source range, {:.2f} s per pass, "
+                      "tfgo_aggregate_coo_f32 (OpenMP, {} threads)".format(n_s, int(row.shape[0]), f, dt, cores)}, out, n_s
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus {} but WORLD_SIZE={}".format(args.gpus, world))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node {} bench.py --gpus {}".format(
+            args.gpus, args.gpus))
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local_rank)
+
+    import tf_geometric_amd as tfg
+    from tf_geometric_amd import synthetic
+    from tf_geometric_amd import _lib as L
+    from tf_geometric_amd.nn.conv.gcn import gcn_norm_adj
+
+    L.require_gpu()
+    n, e_req, f = synthetic.WORKLOADS[args.workload]
+    ei_np = synthetic.synthetic_edges(n, e_req, seed=args.seed)
+    e = int(ei_np.shape[1])
+    x_np = synthetic.synthetic_features(n, f, seed=args.seed + 1)
+    w_np = np.ones(e, dtype=np.float32)      # Graph default edge_weight (data/graph.py:53-56)
+
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl")
+        from tf_geometric_amd.dist.sharded import ShardedGraph
+        t0 = time.perf_counter()
+        sg = ShardedGraph.from_global(ei_np, n, edge_weight=None, group=dist.group.WORLD)
+        sg.build_gcn_norm()
+        x_local = L.as_f32(x_np[sg.own_lo:sg.own_hi])
+        torch.cuda.synchronize()
+        plan_s = time.perf_counter() - t0
+
+        def step():
+            return sg.gcn_propagate(x_local)
+
+        def barrier():
+            dist.barrier()
+    else:
+        t0 = time.perf_counter()
+        ei = L.as_i32(ei_np)
+        adj = tfg.SparseMatrix(ei, None, [n, n])
+        cache = {}
+        normed = gcn_norm_adj(adj, cache=cache)
+        x = L.as_f32(x_np)
+        out = torch.empty((n, f), dtype=torch.float32, device=x.device)
+        torch.cuda.synchronize()
+        plan_s = time.perf_counter() - t0
+        from tf_geometric_amd.plan import segment_reduce
+
+        def step():
+            return segment_reduce(normed.plan, x, L.SUM, w_csr=normed.w_csr, self_coef=normed.self_coef, out=out)
+
+        def barrier():
+            pass
+
+    for _ in range(args.warmup):
+        res = step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        res = step()
+    ev1.record()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    ev_ms = ev0.elapsed_time(ev1) / args.steps
+
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+        t = torch.tensor([ev_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ev_ms = float(t.item())
+
+    ms_per_step = wall * 1e3 / args.steps
+    e_agg = e + n
+    line = {
+        "metric": "aggregated edges/sec + achieved HBM GB/s, GCN layer",
+        "value": e * args.steps / wall,
+        "unit": "edges/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "strong" if world > 1 else "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "{}-shaped GCN propagation A_hat@h (weighted segment-sum + implicit self-loops): "
+                               "N={} E={} F={}".format(args.workload, n, e, f),
+                   "nodes": n, "edges": e, "features": f, "edges_aggregated": e_agg,
+                   "partition": "single GPU" if world == 1 else "dst-range x{} + RCCL halo all-to-all-v".format(world)},
+        "plan_build_s": plan_s,
+    }
+
+    if rank == 0 and world == 1:
+        bytes_alg = b_alg(e_agg, n, f, weighted=True)
+        achieved = bytes_alg / (ev_ms * 1e-3)
+        line["roofline"] = {"bound": "hbm", "kernel": "seg_reduce_kernel<4,32,1,sum,weighted>",
+                            "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                            "frac": achieved / HBM_PEAK, "traffic": None,
+                            "algorithmic_bytes_per_launch": bytes_alg, "kernel_ms": ev_ms,
+                            "bytes_per_edge": 4 * f + 8}
+        if not args.no_cpu_baseline:
+            budget = {"products": 24_000_000}.get(args.workload, e)
+            base, cpu_out, n_s = cpu_baseline(x_np, ei_np, normed_w_host(normed, ei_np, n),
+                                              normed.self_coef.cpu().numpy(), n, f, budget)
+            line["cpu_baseline"] = base
+            gpu_rows = res[:n_s].cpu().numpy()
+            line["parity_vs_cpu_port_max_abs_err"] = float(np.abs(gpu_rows - cpu_out).max())
+            line["speedup_vs_cpu_baseline"] = line["value"] / base["value"]
+    if args.extras and world == 1 and rank == 0:
+        line["extras"] = extras(tfg, L, synthetic, x, ei, n, e, f, cache)
+    if rank == 0:
+        print(json.dumps(line))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+def normed_w_host(normed, ei_np, n):
+    """GCN-normalised weights in the caller's edge order for the CPU leg (so both legs do the same arithmetic)."""
+    w_csr = normed.w_csr.cpu().numpy()
+    perm = normed.plan.perm.cpu().numpy()
+    w = np.empty_like(w_csr)
+    w[perm] = w_csr
+    return w
+
+
+def _time(fn, steps=10, warmup=3):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / steps
+
+
+def extras(tfg, L, synthetic, x, ei, n, e, f, cache):
+    """Whole-layer timings on the same graph (ms): GEMM + aggregation through the layer API."""
+    res = {}
+    w1 = torch.ones(e, dtype=torch.float32, device=x.device)
+    gcn = tfg.layers.GCN(256, activation=tfg.relu)
+    res["gcn_layer_F{}_to_256_ms".format(f)] = _time(lambda: gcn([x, ei], cache=cache))
+    sage = tfg.layers.MeanGraphSage(256)
+    res["mean_sage_layer_units256_ms"] = _time(lambda: sage([x, ei, w1], cache=cache))
+    mp = tfg.layers.MaxPoolGraphSage(64)
+    res["maxpool_sage_layer_units64_ms"] = _time(lambda: mp([x, ei, w1], cache=cache))
+    gat = tfg.layers.GAT(64, attention_units=8, num_heads=8, activation=tfg.relu)
+    res["gat_layer_H8_A8_U64_ms"] = _time(lambda: gat([x, ei], cache=cache))
+    from tf_geometric_amd.plan import gemm_bias_act
+    k = L.as_f32(synthetic.glorot_uniform(f, 256))
+    ms = _time(lambda: gemm_bias_act(x, k))
+    res["gemm_{}x{}x256_ms".format(n, f)] = ms
+    res["gemm_tflops"] = 2.0 * n * f * 256 / (ms * 1e-3) / 1e12
+    return res
+
+
+if __name__ == "__main__":
+    main()

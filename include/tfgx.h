@@ -1,0 +1,197 @@
+/*
+ * tfgx — C ABI of the MI355X (gfx950) message-passing backend for tf_geometric.
+ *
+ * The reference (tf_geometric 0.1.7) is pure Python: it has no FFI of its own.  Its hot path
+ * bottoms out in TensorFlow / tf_sparse ops; each entry point below replaces the ops named in
+ * its comment (reference file:line, relative to /root/reference).  A binding for the reference
+ * (ctypes today, a tf.load_op_library shim where TensorFlow exists) is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller unless it says "host";
+ *   - nothing is allocated here: outputs and workspaces are caller buffers;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), except
+ *     tfgx_build_csr_by_dst, which synchronises once to report bad indices;
+ *   - return value: 0 = ok, otherwise a TFGX_ERR_* code; text via tfgx_last_error();
+ *   - results are deterministic (no floating-point atomics anywhere);
+ *   - index convention of the reference: edge_index[0] = row = DESTINATION (aggregating node),
+ *     edge_index[1] = col = SOURCE (neighbour whose features are gathered)
+ *     (tf_geometric/nn/kernel/map_reduce.py:60-70).
+ *   - all features float32 row-major, all indices int32 (tf_geometric/data/graph.py:22-23),
+ *     E < 2^31; element offsets are 64-bit inside the kernels.
+ */
+#ifndef TFGX_H
+#define TFGX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* tfgx_stream_t; /* hipStream_t */
+
+enum {
+    TFGX_OK = 0,
+    TFGX_ERR_INVALID_ARG = 1,  /* null pointer / negative size / unsupported combination */
+    TFGX_ERR_INDEX = 2,        /* an edge endpoint is outside [0, n): TF-CPU raises InvalidArgumentError here */
+    TFGX_ERR_WORKSPACE = 3,    /* workspace too small */
+    TFGX_ERR_HIP = 4           /* a HIP runtime call failed */
+};
+
+enum { TFGX_SUM = 0, TFGX_MEAN = 1, TFGX_MAX = 2 };
+enum { TFGX_ACT_NONE = 0, TFGX_ACT_RELU = 1 };
+enum { TFGX_NORM_BOTH = 0, TFGX_NORM_LEFT = 1, TFGX_NORM_RIGHT = 2 };
+
+int tfgx_version(void);
+const char* tfgx_last_error(void); /* host string, thread-local, valid until the next failing call */
+
+/* ---------------------------------------------------------------------------------------------
+ * Plan: CSR-by-destination.  Replaces the per-call scatter of tf.math.unsorted_segment_* (and the
+ * TF1 path's tf.argsort + gathers, tf_geometric/nn/kernel/segment.py:7-11).  Built once per graph
+ * and cached like the reference caches its normalised adjacency (nn/conv/gcn.py:125-128).
+ *   row_ptr[n_dst+1], col_sorted[E], perm[E]:  CSR position i holds original edge perm[i];
+ *   the sort is STABLE, so edges of one destination keep their original relative order.
+ * ------------------------------------------------------------------------------------------- */
+size_t tfgx_csr_plan_workspace_bytes(int64_t n_dst, int64_t E);
+int tfgx_build_csr_by_dst(const int32_t* row, const int32_t* col, int64_t E, int64_t n_dst, int64_t n_src,
+                          int32_t* row_ptr, int32_t* col_sorted, int32_t* perm,
+                          void* workspace, size_t workspace_bytes, tfgx_stream_t stream);
+
+/* dst[i, :] = src[perm[i], :]  (edge attributes into CSR order); width floats per edge */
+int tfgx_permute_rows_f32(const float* src, const int32_t* perm, int64_t E, int64_t width, float* dst,
+                          tfgx_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Gather - scale - segment reduce.  Replaces, fused and without materialising [E,F]:
+ *   tf.gather(x, col)                               nn/kernel/map_reduce.py:63, nn/conv/graph_sage.py:36
+ *   gcn_mapper (neighbor_x * w[:,None])             nn/conv/gcn.py:221-222
+ *   tf.math.unsorted_segment_sum / _mean / _max     nn/kernel/map_reduce.py:16, :28, :41
+ *   tf_sparse SparseMatrix.matmul / @               nn/conv/gcn.py:280, nn/conv/gat.py:89
+ *   sum_updater, "+ bias", activation               map_reduce.py:19-20, gcn.py:284-288
+ * out[r,:] = act( combine( reduce_{i in [rb[r*s], re[r*s])} w[i]*x[col[i],:]  (+ self_coef[r]*x[r,:]) )
+ *                 (+ add_x[r,:]) (+ bias) )
+ * Empty destination: 0 (sum, mean), -FLT_MAX (max) — TF semantics.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct tfgx_reduce_args {
+    const int32_t* row_begin; /* row r spans CSR positions [row_begin[r*rp_stride], row_end[r*rp_stride]) */
+    const int32_t* row_end;   /* plain CSR: row_begin=row_ptr, row_end=row_ptr+1, rp_stride=1 */
+    int64_t rp_stride;
+    const int32_t* col;       /* source row of x per CSR position */
+    const float* w;           /* per CSR position, or NULL (unweighted: identity_mapper) */
+    int64_t n_dst;
+    const float* x;           /* [n_src, ldx] */
+    int64_t ldx;
+    int64_t F;                /* columns reduced */
+    float* out;               /* [n_dst, ldo] */
+    int64_t ldo;
+    int32_t op;               /* TFGX_SUM | TFGX_MEAN | TFGX_MAX */
+    int32_t act;              /* TFGX_ACT_* applied last */
+    int32_t accumulate;       /* 1: combine with the values already in out (sum/mean: add, max: max) — the
+                                 second pass of a local/halo split plan; epilogue terms are applied after */
+    int32_t reserved;
+    const float* self_coef;   /* [n_dst] or NULL: an implicit edge (r, r) of weight self_coef[r] appended after
+                                 the row's edges (SparseMatrix.add_diag, nn/conv/gcn.py:72,77,98) */
+    const float* bias;        /* [F] or NULL */
+    const float* add_x;       /* [n_dst, ld_add] or NULL: sum_updater's "x +" */
+    int64_t ld_add;
+    const int32_t* mean_count;/* [n_dst] or NULL: divisor for TFGX_MEAN (NULL: row_end-row_begin); <1 -> 1 */
+} tfgx_reduce_args;
+
+int tfgx_segment_reduce_f32(const tfgx_reduce_args* args /* host */, tfgx_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * GCN normalisation (nn/conv/gcn.py:32-130), on the CSR plan.
+ *   tfgx_segment_weight_sum_f32 : deg[r] = sum_{i in row r} w[i] (+ diag)     SparseMatrix.segment_sum(axis=-1) :80
+ *   tfgx_gcn_norm_edges_f32     : w_out[i], self_coef[r] per norm mode        :62-119
+ * The added diagonal (add_diag(fill)) is kept implicit as self_coef (see tfgx_reduce_args).
+ *   BOTH : renorm -> deg incl. fill; w' = dis[r]*w*disc[c], self = dis[r]*fill*disc[r];
+ *          !renorm -> deg excl. fill; self = fill                            :74-98
+ *   LEFT : w' = w/deg[r], self = fill/deg[r]   (deg incl. fill if add_self_loop)   :71-72,101-109
+ *   RIGHT: w' = w/deg[c], self = fill/deg[r]   (row degrees, as the reference)     :111-119
+ * row_deg must already contain the diagonal where the mode says so (pass diag to weight_sum).
+ * col_deg: column-side degrees for sym=False, or NULL to reuse row_deg (sym=True, :85-86).
+ * ------------------------------------------------------------------------------------------- */
+int tfgx_segment_weight_sum_f32(const int32_t* row_ptr, const float* w /* or NULL = ones */, int64_t n,
+                                float diag, float* deg, tfgx_stream_t stream);
+int tfgx_gcn_norm_edges_f32(const int32_t* row_ptr, const int32_t* col, const float* w /* or NULL */,
+                            int64_t n, const float* row_deg, const float* col_deg /* or NULL */,
+                            int32_t norm_mode, float fill, int32_t add_self_loop, int32_t renorm,
+                            float* w_out /* [E] */, float* self_coef /* [n] */, tfgx_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Edge softmax grouped by destination (nn/kernel/segment.py:26-33; SparseMatrix.segment_softmax(axis=-1),
+ * nn/conv/gat.py:83-84).  score/out are [E, H]; if perm != NULL they are in the CALLER's edge order
+ * (CSR position i <-> edge perm[i]), else in CSR order.
+ * ------------------------------------------------------------------------------------------- */
+int tfgx_edge_softmax_f32(const int32_t* row_ptr, const int32_t* perm /* or NULL */, const float* score,
+                          int64_t H, int64_t n_dst, float* out, tfgx_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused GAT attention (nn/conv/gat.py:56-89 + :112): per destination r and head h, over the row's edges
+ * plus (add_self_loop) the appended edge (r,r):
+ *   s_e = <Q[r,h,:], K[c_e,h,:]> / scale ; a_e = exp(s_e - max) / (sum exp(s - max) + 1e-8)
+ *   out[r, h*dv : (h+1)*dv] = sum_e a_e * V[c_e, h*dv : (h+1)*dv]   (+ bias, act)
+ * One pass (online softmax); neither [E,A] gathers nor the [2,H*E] virtual graph are materialised.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct tfgx_gat_args {
+    const int32_t* row_ptr;
+    const int32_t* col;
+    int64_t n_dst;
+    const float* q; int64_t ldq;   /* [n_dst, H*d]  */
+    const float* k; int64_t ldk;   /* [n_src, H*d]  */
+    const float* v; int64_t ldv;   /* [n_src, H*dv] */
+    float* out; int64_t ldo;       /* [n_dst, H*dv] */
+    int32_t H, d, dv;
+    int32_t add_self_loop;         /* utils/graph_utils.py:350-366 (appended last) */
+    float scale;                   /* sqrt(d) (gat.py:78) */
+    int32_t act;
+    const float* bias;             /* [H*dv] or NULL */
+} tfgx_gat_args;
+
+int tfgx_gat_fused_f32(const tfgx_gat_args* args /* host */, tfgx_stream_t stream);
+
+/* out[r, j] = (1/H) * sum_h in[r, h*U + j]  (+ bias[j], act)   — gat.py:114-120, split_value_heads=False */
+int tfgx_head_mean_f32(const float* in, int64_t ld_in, int64_t n, int32_t H, int32_t U, const float* bias,
+                       int32_t act, float* out, int64_t ldo, tfgx_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Dense GEMM beside the path: C = act(A[M,K] @ B[K,N] + bias) with fp32-input MFMA
+ * (x @ kernel: nn/conv/gcn.py:272, nn/conv/gat.py:52,61,70, nn/conv/graph_sage.py:43-44).
+ * Bitwise a k-ordered fp32 FMA chain per output element.
+ * ------------------------------------------------------------------------------------------- */
+int tfgx_gemm_bias_act_f32(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias,
+                           int32_t act, float* C, int64_t ldc, int64_t M, int64_t K, int64_t N,
+                           tfgx_stream_t stream);
+
+/* h = h * rsqrt(max(sum(h^2), 1e-12)) per row, in place (tf.nn.l2_normalize, graph_sage.py:58) */
+int tfgx_l2_normalize_rows_f32(float* h, int64_t ld, int64_t n, int64_t F, tfgx_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Destination-range sharding + halo exchange support (no counterpart in the reference).
+ *   tfgx_gather_rows_f32   : pack rows x[idx[i], :] -> out[i, :]   (send side of the halo all-to-all-v)
+ *   tfgx_halo_mark         : flags[c] = 1 for every source c of the slice outside [own_lo, own_hi)
+ *   tfgx_halo_compact      : halo_ids = sorted ids with flags set; pos[c] = its rank; *n_halo (device int32)
+ *   tfgx_halo_remap_cols   : col -> local source-table index: own rows first, then halo rows
+ *   tfgx_split_local_halo  : stable per-row partition into [local | halo] edges; row_ptr2 has 2n+1 entries:
+ *                            local part of row r = [rp2[2r], rp2[2r+1]), halo part = [rp2[2r+1], rp2[2r+2])
+ * ------------------------------------------------------------------------------------------- */
+int tfgx_gather_rows_f32(const float* x, int64_t ldx, const int32_t* idx, int64_t M, int64_t F,
+                         float* out, int64_t ldo, tfgx_stream_t stream);
+size_t tfgx_halo_workspace_bytes(int64_t n_global);
+int tfgx_halo_mark(const int32_t* col, int64_t E, int32_t own_lo, int32_t own_hi, int64_t n_global,
+                   int32_t* flags /* [n_global], zeroed here */, tfgx_stream_t stream);
+int tfgx_halo_compact(const int32_t* flags, int64_t n_global, int32_t* pos /* [n_global] */,
+                      int32_t* halo_ids /* [n_global] capacity */, int32_t* n_halo /* device [1] */,
+                      void* workspace, size_t workspace_bytes, tfgx_stream_t stream);
+int tfgx_halo_remap_cols(const int32_t* col, int64_t E, int32_t own_lo, int32_t own_hi, const int32_t* pos,
+                         int32_t n_own, int32_t* col_local, tfgx_stream_t stream);
+int tfgx_split_local_halo(const int32_t* row_ptr, const int32_t* col_local, const float* w /* or NULL */,
+                          int64_t n_dst, int64_t E, int32_t n_own,
+                          int32_t* row_ptr2 /* [2*n_dst+1] */, int32_t* col_out, float* w_out /* or NULL */,
+                          tfgx_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TFGX_H */

@@ -1,0 +1,423 @@
+# coding=utf-8
+"""
+CPU oracle for the tf_geometric message-passing hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``tf_geometric_amd/`` may import this
+module: it is the checker for ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py``, never the thing that is shipped or timed
+as the product.
+
+PARITY UNPINNED.  The reference (/root/reference, tf_geometric 0.1.7) ships no
+tests, golden vectors or fixtures for this path, and its
+arithmetic lives in two un-vendored third-party packages that are not
+installable here: ``tensorflow`` (>=1.15,<2 or >=2.4.0, setup.py:33-38) and
+``tf_sparse >= 0.0.17`` (setup.py:25).  This file therefore restates the
+reference's *own* Python line by line (each function cites the file:line it
+follows) and restates the published semantics of the TF / tf_sparse ops at the
+call sites:
+
+  * tf.gather(params, idx)                      -> params[idx]
+  * tf.math.unsorted_segment_sum(d, ids, n)     -> zeros(n) then out[ids[i]] += d[i]; empty segment = 0
+  * tf.math.unsorted_segment_mean(d, ids, n)    -> segment_sum / max(count, 1); empty segment = 0
+  * tf.math.unsorted_segment_max(d, ids, n)     -> empty segment = numeric_limits<float>::lowest()
+  * tf.nn.l2_normalize(x, axis, eps=1e-12)      -> x * rsqrt(max(sum(x**2), eps))
+  * tf_sparse.SparseMatrix(index, value, shape) -> COO matrix, duplicate entries are summed by matmul
+  * SparseMatrix.segment_sum(axis=-1 | 0)       -> row sums | column sums of the values
+  * SparseMatrix.add_diag(c)                    -> A + c*I  (restated as N appended (i,i,c) entries:
+                                                   identical under matmul / segment_sum)
+  * SparseMatrix.segment_softmax(axis=-1)       -> nn/kernel/segment.py:26-33 grouped by row
+  * SparseMatrix.dropout(rate, training=False)  -> identity
+
+What pins it instead (tests/test_oracle.py): hand-derived known answers on the
+reference's own example graphs (tutorial_intro.py:24-30, datasets/synthetic.py:
+47-66), an independent second implementation (torch CPU index_add_ /
+scatter_reduce and the C restatement oracle/tfg_oracle.c), and algebraic
+properties (edge-order permutation invariance, duplicate edges sum, linearity).
+
+Two accumulation modes: ``acc=np.float64`` (default; the "true" value the fp32
+implementations are compared with under 1e-5 + 1e-5*|ref|) and
+``acc=np.float32`` (op-for-op fp32, what TF-CPU computes).
+"""
+import numpy as np
+
+FLT_LOWEST = np.float32(-3.4028234663852886e38)  # std::numeric_limits<float>::lowest()
+
+
+# ----------------------------------------------------------------------------
+# segment ops  (TF semantics restated; callers: nn/kernel/map_reduce.py:15-42)
+# ----------------------------------------------------------------------------
+
+def _as2d(data):
+    data = np.asarray(data)
+    if data.ndim == 1:
+        return data[:, None], True
+    return data, False
+
+
+def unsorted_segment_sum(data, segment_ids, num_segments, acc=np.float64):
+    """tf.math.unsorted_segment_sum as used at nn/kernel/map_reduce.py:16."""
+    data, squeeze = _as2d(data)
+    ids = np.asarray(segment_ids).astype(np.int64)
+    if ids.size and (ids.min() < 0 or ids.max() >= num_segments):
+        raise ValueError("segment id out of range")  # TF-CPU raises InvalidArgumentError
+    out = np.zeros((num_segments, data.shape[1]), dtype=acc)
+    if ids.size:
+        order = np.argsort(ids, kind="stable")
+        sid = ids[order]
+        starts = np.flatnonzero(np.concatenate(([True], sid[1:] != sid[:-1])))
+        red = np.add.reduceat(data[order].astype(acc), starts, axis=0)
+        out[sid[starts]] = red
+    out = out.astype(np.float32) if data.dtype == np.float32 else out
+    return out[:, 0] if squeeze else out
+
+
+def segment_count(index, num_segments=None):
+    """nn/kernel/segment.py:36-40."""
+    index = np.asarray(index)
+    if num_segments is None:
+        num_segments = int(index.max()) + 1
+    return np.bincount(index.astype(np.int64), minlength=num_segments).astype(index.dtype)
+
+
+def unsorted_segment_mean(data, segment_ids, num_segments, acc=np.float64):
+    """tf.math.unsorted_segment_mean as used at nn/kernel/map_reduce.py:28: sum / max(count, 1)."""
+    data2, squeeze = _as2d(data)
+    s = unsorted_segment_sum(np.asarray(data2, dtype=acc), segment_ids, num_segments, acc=acc)
+    cnt = np.bincount(np.asarray(segment_ids).astype(np.int64), minlength=num_segments)
+    out = (s / np.maximum(cnt, 1)[:, None].astype(acc)).astype(np.float32)
+    return out[:, 0] if squeeze else out
+
+
+def unsorted_segment_max(data, segment_ids, num_segments):
+    """tf.math.unsorted_segment_max as used at nn/kernel/map_reduce.py:41 and
+    nn/kernel/segment.py:27; an empty segment holds float32 lowest()."""
+    data, squeeze = _as2d(data)
+    ids = np.asarray(segment_ids).astype(np.int64)
+    out = np.full((num_segments, data.shape[1]), FLT_LOWEST, dtype=np.float32)
+    if ids.size:
+        order = np.argsort(ids, kind="stable")
+        sid = ids[order]
+        starts = np.flatnonzero(np.concatenate(([True], sid[1:] != sid[:-1])))
+        red = np.maximum.reduceat(data[order].astype(np.float32), starts, axis=0)
+        out[sid[starts]] = red
+    return out[:, 0] if squeeze else out
+
+
+def segment_softmax(data, segment_ids, num_segments, acc=np.float64):
+    """nn/kernel/segment.py:26-33 line by line."""
+    data = np.asarray(data, dtype=np.float32)
+    ids = np.asarray(segment_ids).astype(np.int64)
+    max_values = unsorted_segment_max(data, ids, num_segments)            # :27
+    gathered_max = max_values[ids]                                         # :28
+    ex = np.exp((data - gathered_max).astype(acc))                         # :29
+    denom = unsorted_segment_sum(ex, ids, num_segments, acc=acc) + 1e-8    # :30
+    score = ex / denom[ids]                                                # :31-32
+    return score.astype(np.float32)
+
+
+# ----------------------------------------------------------------------------
+# mappers / reducers / updaters  (nn/kernel/map_reduce.py:7-42, nn/conv/gcn.py:221-222)
+# ----------------------------------------------------------------------------
+
+def identity_mapper(repeated_x, neighbor_x, edge_weight=None):
+    return neighbor_x                                                      # map_reduce.py:7-8
+
+
+def neighbor_count_mapper(repeated_x, neighbor_x, edge_weight=None):
+    return np.ones([neighbor_x.shape[0], 1], dtype=np.float32)            # map_reduce.py:11-12
+
+
+def gcn_mapper(repeated_x, neighbor_x, edge_weight=None):
+    return neighbor_x * np.asarray(edge_weight)[:, None]                   # gcn.py:221-222 (None -> error)
+
+
+def sum_reducer(neighbor_msg, node_index, num_nodes=None, acc=np.float64):
+    return unsorted_segment_sum(neighbor_msg, node_index, num_nodes, acc=acc)   # :15-16
+
+
+def mean_reducer(neighbor_msg, node_index, num_nodes=None, acc=np.float64):
+    return unsorted_segment_mean(neighbor_msg, node_index, num_nodes, acc=acc)  # :27-28
+
+
+def max_reducer(neighbor_msg, node_index, num_nodes=None, acc=None):
+    if num_nodes is None:
+        num_nodes = int(np.max(node_index)) + 1                            # :38-40
+    return unsorted_segment_max(neighbor_msg, node_index, num_nodes)       # :41
+
+
+def sum_updater(x, reduced_neighbor_msg):
+    return x + reduced_neighbor_msg                                        # :19-20
+
+
+def identity_updater(x, reduced_neighbor_msg):
+    return reduced_neighbor_msg                                            # :23-24
+
+
+def aggregate_neighbors(x, edge_index, edge_weight=None, mapper=identity_mapper,
+                        reducer=sum_reducer, updater=sum_updater, num_nodes=None, acc=np.float64):
+    """nn/kernel/map_reduce.py:45-73 line by line."""
+    x = np.asarray(x, dtype=np.float32)
+    edge_index = np.asarray(edge_index)
+    # :57 `tf.shape(edge_index)[0] == 0` — true only for a 0-row tensor, i.e. "no edges" given as []
+    if edge_index.shape[0] == 0 or edge_index.size == 0:
+        return x
+    row, col = edge_index[0], edge_index[1]                                # :60
+    repeated_x = x[row]                                                    # :62
+    neighbor_x = x[col]                                                    # :63
+    msg = mapper(repeated_x, neighbor_x, edge_weight=edge_weight)          # :65
+    if num_nodes is None:
+        num_nodes = x.shape[0]                                             # :67-68
+    reduced = reducer(np.asarray(msg, dtype=np.float32), row, num_nodes=num_nodes, acc=acc)  # :70
+    return updater(x, reduced).astype(np.float32)                          # :71
+
+
+# ----------------------------------------------------------------------------
+# tf_sparse.SparseMatrix surface used by the path (restated, see header)
+# ----------------------------------------------------------------------------
+
+def add_self_loop_edge(edge_index, num_nodes, edge_weight=None, fill_weight=1.0):
+    """utils/graph_utils.py:350-366: APPEND N diagonal edges after the input edges."""
+    diag = np.stack([np.arange(num_nodes, dtype=np.int32)] * 2, axis=0)
+    ei = np.concatenate([np.asarray(edge_index, dtype=np.int32).reshape(2, -1), diag], axis=1)
+    if edge_weight is not None:
+        ew = np.concatenate([np.asarray(edge_weight, dtype=np.float32),
+                             np.full([num_nodes], fill_weight, dtype=np.float32)])
+    else:
+        ew = None
+    return ei, ew
+
+
+def spmm(index, value, shape, h, acc=np.float64):
+    """SparseMatrix(index, value, shape) @ h : out[r] = sum_{e: row_e = r} value_e * h[col_e]."""
+    row, col = np.asarray(index[0]).astype(np.int64), np.asarray(index[1]).astype(np.int64)
+    h = np.asarray(h, dtype=np.float32)
+    msg = h[col].astype(acc) * np.asarray(value, dtype=np.float32).astype(acc)[:, None]
+    return unsorted_segment_sum(msg, row, shape[0], acc=acc).astype(np.float32)
+
+
+def _remove_inf_and_nan(x):
+    return np.where(np.isinf(x) | np.isnan(x), np.zeros_like(x), x)       # gcn.py:23-29
+
+
+def gcn_norm_adj(edge_index, edge_weight, num_nodes, norm="both", add_self_loop=True, sym=True,
+                 renorm=True, improved=False, acc=np.float64):
+    """nn/conv/gcn.py:32-130 for a square adjacency (non-square forbids add_self_loop/sym, :65-69).
+    Returns (index [2,E'], value [E'] float32) of the normalised adjacency, self-loops appended."""
+    ei = np.asarray(edge_index, dtype=np.int32).reshape(2, -1)
+    E = ei.shape[1]
+    w = np.ones([E], dtype=np.float32) if edge_weight is None else np.asarray(edge_weight, dtype=np.float32)
+    fill = 2.0 if improved else 1.0                                        # :62
+    N = num_nodes
+
+    def add_diag(ei_, w_):
+        ei2, w2 = add_self_loop_edge(ei_, N, w_, fill_weight=fill)
+        return ei2, w2
+
+    def row_sum(ei_, w_):
+        return unsorted_segment_sum(w_.astype(acc), ei_[0], N, acc=acc)
+
+    def col_sum(ei_, w_):
+        return unsorted_segment_sum(w_.astype(acc), ei_[1], N, acc=acc)
+
+    with np.errstate(divide="ignore", invalid="ignore"):
+        if add_self_loop and norm != "both":
+            ei, w = add_diag(ei, w)                                        # :71-72
+        if norm == "both":
+            if add_self_loop and renorm:
+                ei, w = add_diag(ei, w)                                    # :76-77
+            row_deg = row_sum(ei, w)                                       # :80
+            rdis = _remove_inf_and_nan(np.power(row_deg, -0.5))            # :81-82
+            if sym:
+                cdis = rdis                                                # :85-86
+            else:
+                cdis = _remove_inf_and_nan(np.power(col_sum(ei, w), -0.5))  # :88-91
+            nw = rdis[ei[0]] * w.astype(acc) * cdis[ei[1]]                 # :94
+            if add_self_loop and not renorm:
+                ei, nw = add_self_loop_edge(ei, N, nw.astype(np.float32), fill_weight=fill)  # :97-98
+        elif norm == "left":
+            rinv = _remove_inf_and_nan(np.power(row_sum(ei, w), -1.0))     # :103-105
+            nw = rinv[ei[0]] * w.astype(acc)                               # :109
+        elif norm == "right":
+            # quirk kept: "col_deg" is segment_sum(axis=-1), i.e. ROW sums (:113), applied on columns (:119)
+            cinv = _remove_inf_and_nan(np.power(row_sum(ei, w), -1.0))
+            nw = w.astype(acc) * cinv[ei[1]]
+        else:
+            raise Exception("wrong GCN norm type: {}".format(norm))        # :122
+    return ei, np.asarray(nw, dtype=np.float32)
+
+
+def _act(name_or_fn, h):
+    if name_or_fn is None:
+        return h
+    if callable(name_or_fn):
+        return name_or_fn(h)
+    if name_or_fn == "relu":
+        return np.maximum(h, 0)
+    raise ValueError(name_or_fn)
+
+
+def matmul(a, b, acc=np.float64):
+    return (np.asarray(a, dtype=np.float32).astype(acc) @ np.asarray(b, dtype=np.float32).astype(acc)).astype(np.float32)
+
+
+def gcn(x, edge_index, edge_weight, kernel, bias=None, activation=None, norm="both", add_self_loop=True,
+        sym=True, renorm=True, improved=False, acc=np.float64):
+    """nn/conv/gcn.py:225-290 (inference: dropout is identity, num_or_size_splits does not change the result)."""
+    x = np.asarray(x, dtype=np.float32)
+    N = x.shape[0]
+    ei, nw = gcn_norm_adj(edge_index, edge_weight, N, norm, add_self_loop, sym, renorm, improved, acc=acc)  # :260
+    h = x if kernel is None else matmul(x, kernel, acc)                   # :266-272
+    h = spmm(ei, nw, (N, N), h, acc=acc)                                   # :280
+    if bias is not None:
+        h = h + np.asarray(bias, dtype=np.float32)                         # :284-285
+    return _act(activation, h).astype(np.float32)                          # :287-288
+
+
+def l2_normalize(h, eps=1e-12):
+    """tf.nn.l2_normalize(h, axis=-1)."""
+    h = np.asarray(h, dtype=np.float64)
+    return (h / np.sqrt(np.maximum((h * h).sum(-1, keepdims=True), eps))).astype(np.float32)
+
+
+def gat(x, edge_index, query_kernel, query_bias, query_activation, key_kernel, key_bias, key_activation,
+        kernel, bias=None, activation=None, num_heads=1, split_value_heads=True, acc=np.float64):
+    """nn/conv/gat.py:13-122 line by line (inference)."""
+    x = np.asarray(x, dtype=np.float32)
+    N = x.shape[0]
+    ei, _ = add_self_loop_edge(edge_index, N)                              # :43
+    row, col = ei[0], ei[1]                                                # :45
+    Q = matmul(x, query_kernel, acc) + np.asarray(query_bias, np.float32)  # :52-53
+    Q = _act(query_activation, Q)[row]                                     # :54-56
+    K = matmul(x, key_kernel, acc) + np.asarray(key_bias, np.float32)      # :61-62
+    K = _act(key_activation, K)[col]                                       # :63-65
+    V = matmul(x, kernel, acc)                                             # :70
+    H = num_heads
+    Q_ = np.concatenate(np.split(Q, H, axis=-1), axis=0)                   # :73
+    K_ = np.concatenate(np.split(K, H, axis=-1), axis=0)                   # :74
+    idx_ = np.concatenate([ei + i * N for i in range(H)], axis=1)          # :76
+    scale = np.sqrt(np.float32(Q_.shape[-1]))                              # :78
+    score_ = ((Q_.astype(acc) * K_.astype(acc)).sum(-1) / scale).astype(np.float32)  # :79
+    N_ = N * H                                                             # :82
+    att_ = segment_softmax(score_, idx_[0], N_, acc=acc)                   # :83-84
+    V_ = np.concatenate(np.split(V, H, axis=-1), axis=0)                   # :87
+    h_ = spmm(idx_, att_, (N_, N_), V_, acc=acc)                           # :89
+    if split_value_heads:
+        h = np.concatenate(np.split(h_, H, axis=0), axis=-1)               # :112
+    else:
+        h = (np.add.reduce(np.stack(np.split(h_.astype(acc), H, axis=0)), axis=0) / H).astype(np.float32)  # :114
+    if bias is not None:
+        h = h + np.asarray(bias, np.float32)                               # :116-117
+    return _act(activation, h).astype(np.float32)                          # :119-120
+
+
+def _sage_combine(from_x, from_neigh, bias, activation, concat, normalize):
+    h = np.concatenate([from_x, from_neigh], axis=1) if concat else from_x + from_neigh
+    if bias is not None:
+        h = h + np.asarray(bias, np.float32)
+    h = _act(activation, h)
+    if normalize:
+        h = l2_normalize(h)
+    return h.astype(np.float32)
+
+
+def _sage_reduce(x, edge_index, edge_weight, reducer, acc):
+    x = np.asarray(x, np.float32)
+    N = x.shape[0]
+    row, col = np.asarray(edge_index[0]), np.asarray(edge_index[1])
+    neighbor_x = x[col]
+    if edge_weight is not None:
+        neighbor_x = gcn_mapper(None, neighbor_x, edge_weight)
+    return reducer(neighbor_x, row, num_nodes=N, acc=acc)
+
+
+def mean_graph_sage(x, edge_index, edge_weight, self_kernel, neighbor_kernel, bias=None, activation=None,
+                    concat=True, normalize=False, acc=np.float64):
+    """nn/conv/graph_sage.py:9-60."""
+    red = _sage_reduce(x, edge_index, edge_weight, mean_reducer, acc)      # :34-41
+    return _sage_combine(matmul(x, self_kernel, acc), matmul(red, neighbor_kernel, acc),
+                         bias, activation, concat, normalize)              # :43-58
+
+
+def sum_graph_sage(x, edge_index, edge_weight, self_kernel, neighbor_kernel, bias=None, activation=None,
+                   concat=True, normalize=False, acc=np.float64):
+    """nn/conv/graph_sage.py:64-115."""
+    red = _sage_reduce(x, edge_index, edge_weight, sum_reducer, acc)       # :89-96
+    return _sage_combine(matmul(x, self_kernel, acc), matmul(red, neighbor_kernel, acc),
+                         bias, activation, concat, normalize)
+
+
+def gcn_graph_sage(x, edge_index, edge_weight, kernel, bias=None, activation=None, normalize=False,
+                   cache=None, acc=np.float64):
+    """nn/conv/graph_sage.py:118-161 incl. its quirks: a given edge_weight is replaced by ones (:139-140)
+    and `cache` lands in gcn_norm_edge's `renorm` slot (:142 vs gcn.py:180): cache=None -> renorm=False
+    (falsy), a non-empty dict -> renorm=True, an EMPTY dict -> falsy -> renorm=False."""
+    x = np.asarray(x, np.float32)
+    N = x.shape[0]
+    E = np.asarray(edge_index).shape[1]
+    if edge_weight is not None:
+        edge_weight = np.ones([E], np.float32)
+    renorm = bool(cache)
+    ei, nw = gcn_norm_adj(edge_index, edge_weight, N, renorm=renorm, improved=False, acc=acc)
+    red = spmm(ei, nw, (N, N), x, acc=acc)                                 # :143-150
+    h = matmul(red, kernel, acc)                                           # :152
+    if bias is not None:
+        h = h + np.asarray(bias, np.float32)
+    h = _act(activation, h)
+    if normalize:
+        h = l2_normalize(h)
+    return h.astype(np.float32)
+
+
+def _pool_graph_sage(x, edge_index, edge_weight, self_kernel, neighbor_mlp_kernel, neighbor_kernel,
+                     neighbor_mlp_bias, bias, activation, concat, normalize, reducer, acc):
+    x = np.asarray(x, np.float32)
+    N = x.shape[0]
+    E = np.asarray(edge_index).shape[1]
+    if edge_weight is not None:
+        edge_weight = np.ones([E], np.float32)                             # :190-191 / :253-254
+    row, col = np.asarray(edge_index[0]), np.asarray(edge_index[1])
+    neighbor_x = gcn_mapper(None, x[col], edge_weight)                     # :197 / :260 (None -> raises)
+    h = matmul(neighbor_x, neighbor_mlp_kernel, acc)                       # per-EDGE GEMM, as the reference
+    if neighbor_mlp_bias is not None:
+        h = h + np.asarray(neighbor_mlp_bias, np.float32)
+    h = _act(activation, h)
+    red = reducer(h.astype(np.float32), row, num_nodes=N, acc=acc)
+    return _sage_combine(matmul(x, self_kernel, acc), matmul(red, neighbor_kernel, acc),
+                         bias, activation, concat, normalize)
+
+
+def mean_pool_graph_sage(x, edge_index, edge_weight, self_kernel, neighbor_mlp_kernel, neighbor_kernel,
+                         neighbor_mlp_bias=None, bias=None, activation=None, concat=True, normalize=False,
+                         acc=np.float64):
+    """nn/conv/graph_sage.py:164-225."""
+    return _pool_graph_sage(x, edge_index, edge_weight, self_kernel, neighbor_mlp_kernel, neighbor_kernel,
+                            neighbor_mlp_bias, bias, activation, concat, normalize, mean_reducer, acc)
+
+
+def max_pool_graph_sage(x, edge_index, edge_weight, self_kernel, neighbor_mlp_kernel, neighbor_kernel,
+                        neighbor_mlp_bias=None, bias=None, activation=None, concat=True, normalize=False,
+                        acc=np.float64):
+    """nn/conv/graph_sage.py:228-287."""
+    return _pool_graph_sage(x, edge_index, edge_weight, self_kernel, neighbor_mlp_kernel, neighbor_kernel,
+                            neighbor_mlp_bias, bias, activation, concat, normalize, max_reducer, acc)
+
+
+# ----------------------------------------------------------------------------
+# synthetic inputs — shared by tests, smoke and bench
+# ----------------------------------------------------------------------------
+
+def synthetic_edges(num_nodes, num_edges, seed=0):
+    """E/2 uniform pairs, self pairs dropped, both directions emitted in the reference's to_directed order
+    (all (a,b) then all (b,a), utils/graph_utils.py:186-190); duplicates allowed (they sum)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    half = num_edges // 2
+    a = rng.integers(0, num_nodes, size=half, dtype=np.int32)
+    b = rng.integers(0, num_nodes, size=half, dtype=np.int32)
+    keep = a != b
+    a, b = a[keep], b[keep]
+    return np.stack([np.concatenate([a, b]), np.concatenate([b, a])]).astype(np.int32)
+
+
+def glorot_uniform(rng, fan_in, fan_out):
+    limit = np.sqrt(6.0 / (fan_in + fan_out))
+    return rng.uniform(-limit, limit, size=(fan_in, fan_out)).astype(np.float32)

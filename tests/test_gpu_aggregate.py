@@ -1,0 +1,154 @@
+# coding=utf-8
+"""GPU parity: HIP gather-scale-segment-reduce (through the C ABI) vs the CPU oracle, same seeded inputs."""
+import numpy as np
+import pytest
+
+from conftest import assert_parity
+
+pytestmark = pytest.mark.gpu
+
+
+def _graph(oracle, n, e, f, seed=0, weighted=True):
+    ei = oracle.synthetic_edges(n, e, seed=seed)
+    rng = np.random.Generator(np.random.PCG64(seed + 1))
+    x = rng.standard_normal((n, f), dtype=np.float32)
+    w = rng.uniform(0.5, 1.5, size=ei.shape[1]).astype(np.float32) if weighted else None
+    return x, ei, w
+
+
+@pytest.mark.parametrize("f", [1, 3, 7, 16, 41, 64, 100, 128, 200, 256, 300, 602, 1030])
+@pytest.mark.parametrize("red", ["sum", "mean", "max"])
+def test_aggregate_widths(tfg, oracle, f, red):
+    n, e = 500, 6000
+    x, ei, w = _graph(oracle, n, e, f, seed=f)
+    reducers = {"sum": (tfg.nn.sum_reducer, oracle.sum_reducer), "mean": (tfg.nn.mean_reducer, oracle.mean_reducer),
+                "max": (tfg.nn.max_reducer, oracle.max_reducer)}
+    g, o = reducers[red]
+    got = tfg.nn.aggregate_neighbors(x, ei, w, tfg.nn.gcn_mapper, g, tfg.nn.identity_updater).cpu().numpy()
+    ref = oracle.aggregate_neighbors(x, ei, w, oracle.gcn_mapper, o, oracle.identity_updater)
+    assert_parity(got, ref, what="aggregate {} F={}".format(red, f))
+
+
+@pytest.mark.parametrize("mapper", ["identity", "gcn"])
+@pytest.mark.parametrize("red", ["sum", "mean", "max"])
+@pytest.mark.parametrize("upd", ["sum", "identity"])
+def test_aggregate_builtin_triples(tfg, oracle, mapper, red, upd):
+    x, ei, w = _graph(oracle, 300, 2500, 24, seed=3)
+    gm = {"identity": tfg.nn.identity_mapper, "gcn": tfg.nn.gcn_mapper}[mapper]
+    om = {"identity": oracle.identity_mapper, "gcn": oracle.gcn_mapper}[mapper]
+    gr = getattr(tfg.nn, red + "_reducer")
+    orr = getattr(oracle, red + "_reducer")
+    gu = getattr(tfg.nn, upd + "_updater")
+    ou = getattr(oracle, upd + "_updater")
+    got = tfg.nn.aggregate_neighbors(x, ei, w, gm, gr, gu).cpu().numpy()
+    ref = oracle.aggregate_neighbors(x, ei, w, om, orr, ou)
+    assert_parity(got, ref, what="{}-{}-{}".format(mapper, red, upd))
+
+
+def test_empty_segments_and_isolated_nodes(tfg, oracle):
+    """TF semantics: empty segment -> 0 (sum, mean), float32 lowest (max)."""
+    n, f = 40, 12
+    rng = np.random.Generator(np.random.PCG64(5))
+    x = rng.standard_normal((n, f), dtype=np.float32)
+    ei = np.array([[0, 0, 3, 3, 3, 39], [1, 2, 0, 0, 5, 38]], dtype=np.int32)   # duplicate edge (3,0); most rows empty
+    for red in ["sum", "mean", "max"]:
+        got = tfg.nn.aggregate_neighbors(x, ei, None, tfg.nn.identity_mapper, getattr(tfg.nn, red + "_reducer"),
+                                         tfg.nn.identity_updater).cpu().numpy()
+        ref = oracle.aggregate_neighbors(x, ei, None, oracle.identity_mapper, getattr(oracle, red + "_reducer"),
+                                         oracle.identity_updater)
+        assert_parity(got, ref, what="empty-" + red)
+    got = tfg.nn.aggregate_neighbors(x, ei, None, tfg.nn.identity_mapper, tfg.nn.max_reducer,
+                                     tfg.nn.identity_updater).cpu().numpy()
+    assert got[10, 0] == np.float32(-3.4028234663852886e38)
+
+
+def test_no_edges_returns_x(tfg):
+    x = np.ones((5, 3), np.float32)
+    out = tfg.nn.aggregate_neighbors(x, np.zeros((0,), np.int32), None)
+    assert np.array_equal(out.cpu().numpy(), x)
+    out = tfg.nn.aggregate_neighbors(x, np.zeros((2, 0), np.int32), None)
+    assert np.array_equal(out.cpu().numpy(), x)
+
+
+def test_out_of_range_index_raises(tfg):
+    x = np.ones((5, 3), np.float32)
+    with pytest.raises(tfg._lib.TfgxError):
+        tfg.nn.aggregate_neighbors(x, np.array([[0, 7], [1, 2]], np.int32), None)
+    with pytest.raises(tfg._lib.TfgxError):
+        tfg.nn.aggregate_neighbors(x, np.array([[0, 1], [1, -2]], np.int32), None)
+
+
+def test_hub_row_and_ragged_degrees(tfg, oracle):
+    """One destination with 20k in-edges next to degree-0/1 rows (skewed graph)."""
+    n, f = 3000, 100
+    rng = np.random.Generator(np.random.PCG64(9))
+    x = rng.standard_normal((n, f), dtype=np.float32)
+    hub_src = rng.integers(0, n, size=20000, dtype=np.int32)
+    rest = oracle.synthetic_edges(n, 8000, seed=2)
+    ei = np.concatenate([np.stack([np.full_like(hub_src, 17), hub_src]), rest], axis=1).astype(np.int32)
+    w = rng.uniform(0.5, 1.5, size=ei.shape[1]).astype(np.float32)
+    for red in ["sum", "mean", "max"]:
+        got = tfg.nn.aggregate_neighbors(x, ei, w, tfg.nn.gcn_mapper, getattr(tfg.nn, red + "_reducer"),
+                                         tfg.nn.identity_updater).cpu().numpy()
+        ref = oracle.aggregate_neighbors(x, ei, w, oracle.gcn_mapper, getattr(oracle, red + "_reducer"),
+                                         oracle.identity_updater)
+        # a 20k-term fp32 sum carries ~sqrt(20000)*eps relative error: judge it against the sum of magnitudes
+        scale = 1.0 if red != "sum" else 1.0
+        err = np.abs(got - ref)
+        bound = 1e-5 + 1e-5 * np.abs(ref) + (2e-7 * np.abs(x).max() * 1.5 * 150 if red == "sum" else 0.0) * scale
+        assert (err <= bound).all(), red
+
+
+def test_edge_order_permutation_invariance(tfg, oracle):
+    x, ei, w = _graph(oracle, 400, 5000, 32, seed=11)
+    rng = np.random.Generator(np.random.PCG64(12))
+    p = rng.permutation(ei.shape[1])
+    a = tfg.nn.aggregate_neighbors(x, ei, w, tfg.nn.gcn_mapper, tfg.nn.sum_reducer, tfg.nn.identity_updater)
+    b = tfg.nn.aggregate_neighbors(x, ei[:, p], w[p], tfg.nn.gcn_mapper, tfg.nn.sum_reducer, tfg.nn.identity_updater)
+    assert_parity(a.cpu().numpy(), b.cpu().numpy(), what="permutation")
+    m1 = tfg.nn.aggregate_neighbors(x, ei, None, tfg.nn.identity_mapper, tfg.nn.max_reducer, tfg.nn.identity_updater)
+    m2 = tfg.nn.aggregate_neighbors(x, ei[:, p], None, tfg.nn.identity_mapper, tfg.nn.max_reducer,
+                                    tfg.nn.identity_updater)
+    assert np.array_equal(m1.cpu().numpy(), m2.cpu().numpy())   # max is order-independent: bit-exact
+
+
+def test_deterministic_bitwise(tfg, oracle):
+    x, ei, w = _graph(oracle, 2000, 60000, 100, seed=13)
+    cache = {}
+    a = tfg.nn.aggregate_neighbors(x, ei, w, tfg.nn.gcn_mapper, tfg.nn.sum_reducer, tfg.nn.identity_updater, cache=cache)
+    b = tfg.nn.aggregate_neighbors(x, ei, w, tfg.nn.gcn_mapper, tfg.nn.sum_reducer, tfg.nn.identity_updater, cache=cache)
+    assert np.array_equal(a.cpu().numpy(), b.cpu().numpy())
+
+
+def test_generic_python_mapper(tfg, oracle):
+    """A user mapper that is not one of the built-ins goes through gather -> mapper -> HIP reducer."""
+    x, ei, w = _graph(oracle, 200, 1500, 8, seed=21)
+
+    def mapper(repeated_x, neighbor_x, edge_weight=None):
+        return (neighbor_x - repeated_x) * 0.5
+
+    got = tfg.nn.aggregate_neighbors(x, ei, w, mapper, tfg.nn.mean_reducer, tfg.nn.sum_updater).cpu().numpy()
+    ref = oracle.aggregate_neighbors(x, ei, w, lambda r, nb, edge_weight=None: (nb - r) * 0.5, oracle.mean_reducer,
+                                     oracle.sum_updater)
+    assert_parity(got, ref, what="generic mapper")
+
+
+def test_arxiv_shaped_sum(tfg, oracle):
+    """BASELINE configs[1] shape (N=170k, E=1.2M, F=128): GCN-weighted segment-sum vs float64 oracle."""
+    n, e, f = 170000, 1200000, 128
+    x, ei, w = _graph(oracle, n, e, f, seed=0)
+    got = tfg.nn.aggregate_neighbors(x, ei, w, tfg.nn.gcn_mapper, tfg.nn.sum_reducer, tfg.nn.identity_updater)
+    ref = oracle.aggregate_neighbors(x, ei, w, oracle.gcn_mapper, oracle.sum_reducer, oracle.identity_updater)
+    assert_parity(got.cpu().numpy(), ref, what="arxiv-shaped segment-sum")
+
+
+def test_segment_softmax_and_count(tfg, oracle):
+    rng = np.random.Generator(np.random.PCG64(31))
+    ids = rng.integers(0, 50, size=4000, dtype=np.int32)
+    for shape in [(4000,), (4000, 8)]:
+        s = (rng.standard_normal(shape) * 3).astype(np.float32)
+        got = tfg.nn.segment_softmax(s, ids, 60).cpu().numpy()
+        ref = oracle.segment_softmax(s, ids, 60) if len(shape) == 1 else \
+            np.stack([oracle.segment_softmax(s[:, h], ids, 60) for h in range(shape[1])], axis=1)
+        assert_parity(got, ref, what="segment_softmax")
+    assert np.array_equal(tfg.nn.segment_count(ids, 60).cpu().numpy(), oracle.segment_count(ids, 60))

@@ -1,0 +1,187 @@
+# coding=utf-8
+"""GPU parity of the layer API (GCN / GAT / GraphSAGE) and the MFMA GEMM vs the CPU oracle."""
+import numpy as np
+import pytest
+
+from conftest import assert_parity
+
+pytestmark = pytest.mark.gpu
+
+
+def _graph(oracle, n, e, f, seed=0):
+    ei = oracle.synthetic_edges(n, e, seed=seed)
+    rng = np.random.Generator(np.random.PCG64(seed + 1))
+    x = rng.standard_normal((n, f), dtype=np.float32)
+    w = rng.uniform(0.5, 1.5, size=ei.shape[1]).astype(np.float32)
+    return x, ei, w, rng
+
+
+@pytest.mark.parametrize("m,k,n", [(1, 1, 1), (5, 3, 2), (127, 16, 7), (128, 100, 64), (1000, 100, 256),
+                                   (333, 1433, 16), (2708, 602, 41), (4096, 128, 128), (513, 17, 129)])
+@pytest.mark.parametrize("relu", [False, True])
+def test_gemm_bias_act(tfg, oracle, m, k, n, relu):
+    from tf_geometric_amd.plan import gemm_bias_act
+    rng = np.random.Generator(np.random.PCG64(m * 7 + k))
+    a = rng.standard_normal((m, k), dtype=np.float32)
+    b = oracle.glorot_uniform(rng, k, n)
+    bias = rng.standard_normal(n).astype(np.float32) * 0.1
+    got = gemm_bias_act(a, b, bias=bias, act=1 if relu else 0).cpu().numpy()
+    ref = oracle.matmul(a, b) + bias
+    if relu:
+        ref = np.maximum(ref, 0)
+    assert_parity(got, ref, what="gemm {}x{}x{}".format(m, k, n))
+
+
+def test_gemm_transpose_detecting(tfg):
+    """A = I with an asymmetric B catches a swapped C layout (cdna guide §3)."""
+    from tf_geometric_amd.plan import gemm_bias_act
+    n = 96
+    b = (np.arange(n * n, dtype=np.float32).reshape(n, n) % 97) / 97.0
+    got = gemm_bias_act(np.eye(n, dtype=np.float32), b).cpu().numpy()
+    assert np.array_equal(got, b)
+
+
+@pytest.mark.parametrize("cfg", [dict(), dict(renorm=False), dict(improved=True), dict(norm="left"),
+                                 dict(norm="right"), dict(sym=False), dict(add_self_loop=False),
+                                 dict(norm="left", add_self_loop=False)])
+def test_gcn_layer(tfg, oracle, cfg):
+    x, ei, w, rng = _graph(oracle, 600, 5000, 50, seed=4)
+    kernel = oracle.glorot_uniform(rng, 50, 24)
+    bias = (rng.standard_normal(24) * 0.1).astype(np.float32)
+    layer = tfg.layers.GCN(24, activation=tfg.relu, **cfg)
+    layer._maybe_build([x])
+    layer.set_weights(kernel=kernel, bias=bias)
+    cache = {}
+    got = layer([x, ei, w], cache=cache).cpu().numpy()
+    ref = oracle.gcn(x, ei, w, kernel, bias, "relu", **cfg)
+    assert_parity(got, ref, what="GCN {}".format(cfg))
+    got2 = layer([x, ei, w], cache=cache).cpu().numpy()     # cached plan + cached normalised adjacency
+    assert np.array_equal(got, got2)
+
+
+def test_gcn_no_kernel_unweighted_and_path_graph_kat(tfg, oracle):
+    """3-node path graph: normalised weights are exactly 1/sqrt(6), 1/2, 1/3 (hand-derived)."""
+    ei = np.array([[0, 1, 1, 2], [1, 0, 2, 1]], np.int32)
+    x = np.eye(3, dtype=np.float32)
+    layer = tfg.layers.GCN(3, use_kernel=False, use_bias=False)
+    got = layer([x, ei]).cpu().numpy()
+    s = np.float32(1.0 / np.sqrt(6.0))
+    kat = np.array([[0.5, s, 0], [s, 1.0 / 3.0, s], [0, s, 0.5]], dtype=np.float32)
+    assert_parity(got, kat, tol=1e-6, what="path-graph KAT")
+
+
+@pytest.mark.parametrize("heads,att,units,split", [(1, 8, 8, True), (8, 8, 64, True), (8, 64, 64, True),
+                                                  (4, 16, 20, True), (2, 6, 10, False), (8, 8, 16, False),
+                                                  (1, 1, 41, True), (3, 9, 9, True)])
+def test_gat_layer(tfg, oracle, heads, att, units, split):
+    x, ei, w, rng = _graph(oracle, 400, 4000, 30, seed=heads + att)
+    layer = tfg.layers.GAT(units, attention_units=att, activation=tfg.relu, num_heads=heads, split_value_heads=split)
+    layer._maybe_build([x])
+    wq, wk = oracle.glorot_uniform(rng, 30, att), oracle.glorot_uniform(rng, 30, att)
+    bq, bk = (rng.standard_normal(att) * 0.2).astype(np.float32), (rng.standard_normal(att) * 0.2).astype(np.float32)
+    wv = oracle.glorot_uniform(rng, 30, units if split else units * heads)
+    b = (rng.standard_normal(units) * 0.1).astype(np.float32)
+    layer.set_weights(query_kernel=wq, query_bias=bq, key_kernel=wk, key_bias=bk, kernel=wv, bias=b)
+    got = layer([x, ei]).cpu().numpy()
+    ref = oracle.gat(x, ei, wq, bq, "relu", wk, bk, "relu", wv, b, "relu", num_heads=heads, split_value_heads=split)
+    assert_parity(got, ref, what="GAT H={} A={} U={} split={}".format(heads, att, units, split))
+
+
+def test_gat_large_scores_online_softmax(tfg, oracle):
+    """Scores spanning +-60 force many running-max rescales; existing self-loops are kept (duplicates)."""
+    n, f = 200, 6
+    rng = np.random.Generator(np.random.PCG64(77))
+    x = (rng.standard_normal((n, f)) * 6).astype(np.float32)
+    ei = oracle.synthetic_edges(n, 3000, seed=7)
+    ei = np.concatenate([ei, np.stack([np.arange(10, dtype=np.int32)] * 2)], axis=1)   # explicit self-loops too
+    wq, wk = oracle.glorot_uniform(rng, f, 4) * 3, oracle.glorot_uniform(rng, f, 4) * 3
+    bq = bk = np.zeros(4, np.float32)
+    wv = oracle.glorot_uniform(rng, f, 8)
+    got = tfg.nn.gat(x, ei, wq, bq, None, wk, bk, None, wv, None, None, num_heads=2).cpu().numpy()
+    ref = oracle.gat(x, ei, wq, bq, None, wk, bk, None, wv, None, None, num_heads=2)
+    assert_parity(got, ref, what="GAT large scores")
+
+
+@pytest.mark.parametrize("cls,fn", [("MeanGraphSage", "mean_graph_sage"), ("SumGraphSage", "sum_graph_sage")])
+@pytest.mark.parametrize("concat", [True, False])
+@pytest.mark.parametrize("weighted", [True, False])
+def test_sage_mean_sum(tfg, oracle, cls, fn, concat, weighted):
+    x, ei, w, rng = _graph(oracle, 500, 6000, 100, seed=8)
+    layer = getattr(tfg.layers, cls)(64, concat=concat, normalize=True)
+    layer._maybe_build([x])
+    ku = 32 if concat else 64
+    ws, wn = oracle.glorot_uniform(rng, 100, ku), oracle.glorot_uniform(rng, 100, ku)
+    b = (rng.standard_normal(64) * 0.1).astype(np.float32)
+    layer.set_weights(self_kernel=ws, neighbor_kernel=wn, bias=b)
+    inputs = [x, ei, w] if weighted else [x, ei]
+    got = layer(inputs).cpu().numpy()
+    ref = getattr(oracle, fn)(x, ei, w if weighted else None, ws, wn, b, "relu", concat=concat, normalize=True)
+    assert_parity(got, ref, what="{} concat={} weighted={}".format(cls, concat, weighted))
+
+
+@pytest.mark.parametrize("cls,fn,names", [
+    ("MeanPoolGraphSage", "mean_pool_graph_sage", ("neighbor_mlp_kernel", "neighbor_mlp_bias", "neighbor_kernel")),
+    ("MaxPoolGraphSage", "max_pool_graph_sage", ("neighbor_mlp_kernel", "neighbor_mlp_bias", "neighbor_kernel"))])
+@pytest.mark.parametrize("concat", [True, False])
+def test_sage_pool(tfg, oracle, cls, fn, names, concat):
+    n = 300
+    x, ei, w, rng = _graph(oracle, n, 6000, 40, seed=9)
+    # every node gets an in-edge: an isolated node keeps float lowest() into the next GEMM (overflow by design)
+    ring = np.stack([np.arange(n, dtype=np.int32), np.roll(np.arange(n, dtype=np.int32), 1)])
+    ei = np.concatenate([ei, ring], axis=1)
+    w = np.concatenate([w, np.ones(n, np.float32)])
+    layer = getattr(tfg.layers, cls)(32, concat=concat)
+    layer._maybe_build([x])
+    ku = 16 if concat else 32
+    ws = oracle.glorot_uniform(rng, 40, ku)
+    wm = oracle.glorot_uniform(rng, 40, 4 * ku)
+    bm = (rng.standard_normal(4 * ku) * 0.1).astype(np.float32)
+    wn = oracle.glorot_uniform(rng, 4 * ku, ku)
+    b = (rng.standard_normal(32) * 0.1).astype(np.float32)
+    layer.set_weights(self_kernel=ws, neighbor_mlp_kernel=wm, neighbor_mlp_bias=bm, neighbor_kernel=wn, bias=b)
+    got = layer([x, ei, w]).cpu().numpy()
+    ref = getattr(oracle, fn)(x, ei, w, ws, wm, wn, bm, b, "relu", concat=concat)
+    assert_parity(got, ref, what="{} concat={}".format(cls, concat))
+    with pytest.raises(TypeError):
+        layer([x, ei])      # edge_weight=None fails in the reference too (graph_sage.py:197/260)
+
+
+@pytest.mark.parametrize("cache", [None, {}, {"x": 1}])
+def test_gcn_graph_sage_quirks(tfg, oracle, cache):
+    x, ei, w, rng = _graph(oracle, 300, 3000, 20, seed=10)
+    k = oracle.glorot_uniform(rng, 20, 12)
+    b = (rng.standard_normal(12) * 0.1).astype(np.float32)
+    got = tfg.nn.gcn_graph_sage(x, ei, w, k, b, tfg.relu, normalize=True, cache=cache).cpu().numpy()
+    ref = oracle.gcn_graph_sage(x, ei, w, k, b, "relu", normalize=True, cache=cache)
+    assert_parity(got, ref, what="gcn_graph_sage cache={}".format(cache))
+
+
+def test_sparse_matrix_surface(tfg, oracle):
+    x, ei, w, rng = _graph(oracle, 200, 2000, 10, seed=14)
+    A = tfg.SparseMatrix(ei, w, [200, 200])
+    assert_parity((A @ x).cpu().numpy(), oracle.spmm(ei, w, (200, 200), x), what="A @ x")
+    assert_parity(A.segment_sum(axis=-1).cpu().numpy(), oracle.unsorted_segment_sum(w, ei[0], 200), what="rowsum")
+    assert_parity(A.segment_sum(axis=0).cpu().numpy(), oracle.unsorted_segment_sum(w, ei[1], 200), what="colsum")
+    ei2, w2 = oracle.add_self_loop_edge(ei, 200, w, 2.0)
+    assert_parity((A.add_diag(2.0) @ x).cpu().numpy(), oracle.spmm(ei2, w2, (200, 200), x), what="add_diag")
+    sm = A.segment_softmax(axis=-1)
+    assert_parity(sm.value.cpu().numpy(), oracle.segment_softmax(w, ei[0], 200), what="segment_softmax")
+    assert_parity((A.transpose() @ x).cpu().numpy(), oracle.spmm(ei[::-1], w, (200, 200), x), what="transpose")
+
+
+def test_map_reduce_gnn_layer(tfg, oracle):
+    x, ei, w, rng = _graph(oracle, 150, 1200, 6, seed=15)
+
+    class MyGNN(tfg.layers.MapReduceGNN):
+        def map(self, repeated_x, neighbor_x, edge_weight=None):
+            return tfg.nn.gcn_mapper(repeated_x, neighbor_x, edge_weight)
+
+        def reduce(self, neighbor_msg, node_index, num_nodes=None):
+            return tfg.nn.sum_reducer(neighbor_msg, node_index, num_nodes)
+
+        def update(self, x, reduced_neighbor_msg):
+            return tfg.nn.sum_updater(x, reduced_neighbor_msg)
+
+    got = MyGNN()([x, ei, w]).cpu().numpy()
+    ref = oracle.aggregate_neighbors(x, ei, w, oracle.gcn_mapper, oracle.sum_reducer, oracle.sum_updater)
+    assert_parity(got, ref, what="MapReduceGNN")

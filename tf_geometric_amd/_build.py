@@ -1,0 +1,51 @@
+# coding=utf-8
+"""Builds tf_geometric_amd/lib/libtfgx.so (the C-ABI HIP library, gfx950 only) in-tree with hipcc."""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_DIR = os.path.join(_HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libtfgx.so")
+OBJ_DIR = os.path.join(LIB_DIR, "obj")
+SOURCES = ["tfgx_plan.hip", "tfgx_reduce.hip", "tfgx_norm.hip", "tfgx_attn.hip", "tfgx_gemm.hip", "tfgx_misc.hip"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def _newer(a, b):
+    return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    deps = [os.path.join(CSRC, "tfgx_common.h"), os.path.join(_HERE, "..", "include", "tfgx.h")]
+    jobs = []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
+        if force or _newer(s, o) or any(_newer(d, o) for d in deps):
+            jobs.append((s, o))
+
+    def compile_one(job):
+        s, o = job
+        cmd = [HIPCC] + FLAGS + ["-c", s, "-o", o]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    with ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as ex:
+        list(ex.map(compile_one, jobs))
+    objs = [os.path.join(OBJ_DIR, s.replace(".hip", ".o")) for s in SOURCES]
+    if force or jobs or not os.path.exists(LIB_PATH):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,165 @@
+# coding=utf-8
+"""ctypes binding of the C ABI declared in include/tfgx.h (libtfgx.so, hand-written HIP for gfx950).
+
+There is NO CPU fallback: if the library is missing, or there is no GPU, every operator raises.
+PyTorch is used only as plumbing: device memory (torch.Tensor), streams, torch.distributed.
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libtfgx.so")
+
+SUM, MEAN, MAX = 0, 1, 2
+ACT_NONE, ACT_RELU = 0, 1
+NORM_BOTH, NORM_LEFT, NORM_RIGHT = 0, 1, 2
+NORM_MODES = {"both": NORM_BOTH, "left": NORM_LEFT, "right": NORM_RIGHT}
+
+c_i32p = ctypes.c_void_p
+c_f32p = ctypes.c_void_p
+
+
+class TfgxError(RuntimeError):
+    pass
+
+
+class ReduceArgs(ctypes.Structure):
+    """struct tfgx_reduce_args (include/tfgx.h)."""
+    _fields_ = [
+        ("row_begin", ctypes.c_void_p), ("row_end", ctypes.c_void_p), ("rp_stride", ctypes.c_int64),
+        ("col", ctypes.c_void_p), ("w", ctypes.c_void_p), ("n_dst", ctypes.c_int64),
+        ("x", ctypes.c_void_p), ("ldx", ctypes.c_int64), ("F", ctypes.c_int64),
+        ("out", ctypes.c_void_p), ("ldo", ctypes.c_int64),
+        ("op", ctypes.c_int32), ("act", ctypes.c_int32), ("accumulate", ctypes.c_int32), ("reserved", ctypes.c_int32),
+        ("self_coef", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("add_x", ctypes.c_void_p),
+        ("ld_add", ctypes.c_int64), ("mean_count", ctypes.c_void_p),
+    ]
+
+
+class GatArgs(ctypes.Structure):
+    """struct tfgx_gat_args (include/tfgx.h)."""
+    _fields_ = [
+        ("row_ptr", ctypes.c_void_p), ("col", ctypes.c_void_p), ("n_dst", ctypes.c_int64),
+        ("q", ctypes.c_void_p), ("ldq", ctypes.c_int64),
+        ("k", ctypes.c_void_p), ("ldk", ctypes.c_int64),
+        ("v", ctypes.c_void_p), ("ldv", ctypes.c_int64),
+        ("out", ctypes.c_void_p), ("ldo", ctypes.c_int64),
+        ("H", ctypes.c_int32), ("d", ctypes.c_int32), ("dv", ctypes.c_int32), ("add_self_loop", ctypes.c_int32),
+        ("scale", ctypes.c_float), ("act", ctypes.c_int32), ("bias", ctypes.c_void_p),
+    ]
+
+
+# name -> (restype, argtypes); this table is checked against include/tfgx.h by tests/test_abi.py
+_I64, _I32, _F32, _P, _SZ = ctypes.c_int64, ctypes.c_int32, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
+SIGNATURES = {
+    "tfgx_version": (ctypes.c_int, []),
+    "tfgx_last_error": (ctypes.c_char_p, []),
+    "tfgx_csr_plan_workspace_bytes": (_SZ, [_I64, _I64]),
+    "tfgx_build_csr_by_dst": (ctypes.c_int, [_P, _P, _I64, _I64, _I64, _P, _P, _P, _P, _SZ, _P]),
+    "tfgx_permute_rows_f32": (ctypes.c_int, [_P, _P, _I64, _I64, _P, _P]),
+    "tfgx_segment_reduce_f32": (ctypes.c_int, [ctypes.POINTER(ReduceArgs), _P]),
+    "tfgx_segment_weight_sum_f32": (ctypes.c_int, [_P, _P, _I64, _F32, _P, _P]),
+    "tfgx_gcn_norm_edges_f32": (ctypes.c_int, [_P, _P, _P, _I64, _P, _P, _I32, _F32, _I32, _I32, _P, _P, _P]),
+    "tfgx_edge_softmax_f32": (ctypes.c_int, [_P, _P, _P, _I64, _I64, _P, _P]),
+    "tfgx_gat_fused_f32": (ctypes.c_int, [ctypes.POINTER(GatArgs), _P]),
+    "tfgx_head_mean_f32": (ctypes.c_int, [_P, _I64, _I64, _I32, _I32, _P, _I32, _P, _I64, _P]),
+    "tfgx_gemm_bias_act_f32": (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I32, _P, _I64, _I64, _I64, _I64, _P]),
+    "tfgx_l2_normalize_rows_f32": (ctypes.c_int, [_P, _I64, _I64, _I64, _P]),
+    "tfgx_gather_rows_f32": (ctypes.c_int, [_P, _I64, _P, _I64, _I64, _P, _I64, _P]),
+    "tfgx_halo_workspace_bytes": (_SZ, [_I64]),
+    "tfgx_halo_mark": (ctypes.c_int, [_P, _I64, _I32, _I32, _I64, _P, _P]),
+    "tfgx_halo_compact": (ctypes.c_int, [_P, _I64, _P, _P, _P, _P, _SZ, _P]),
+    "tfgx_halo_remap_cols": (ctypes.c_int, [_P, _I64, _I32, _I32, _P, _I32, _P, _P]),
+    "tfgx_split_local_halo": (ctypes.c_int, [_P, _P, _P, _I64, _I64, _I32, _P, _P, _P, _P]),
+}
+
+_lib = None
+
+
+def load_library():
+    """Load libtfgx.so and bind every entry point of include/tfgx.h. Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TfgxError(
+            "tf_geometric_amd: HIP library {} is missing. Build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.".format(LIB_PATH))
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load_library().tfgx_last_error()
+        raise TfgxError("{} failed with code {}: {}".format(what or "tfgx call", rc, (msg or b"").decode()))
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise TfgxError("tf_geometric_amd needs an AMD GPU (gfx950 / MI355X); torch.cuda.is_available() is False "
+                        "and there is no CPU fallback.")
+    return load_library()
+
+
+def device():
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def as_f32(x, dev=None):
+    """numpy / list / torch -> contiguous float32 tensor on the GPU (float64 is down-cast as data/graph.py:79-86)."""
+    dev = dev or device()
+    if isinstance(x, torch.Tensor):
+        t = x.detach()
+    else:
+        t = torch.from_numpy(np.ascontiguousarray(np.asarray(x)))
+    if t.dtype != torch.float32:
+        t = t.to(torch.float32)
+    if t.device != dev:
+        t = t.to(dev)
+    if t.dim() >= 2 and t.stride(-1) != 1:
+        t = t.contiguous()
+    if t.dim() == 1 and not t.is_contiguous():
+        t = t.contiguous()
+    return t
+
+
+def as_i32(x, dev=None):
+    dev = dev or device()
+    if isinstance(x, torch.Tensor):
+        t = x.detach()
+    else:
+        t = torch.from_numpy(np.ascontiguousarray(np.asarray(x)))
+    if t.dtype != torch.int32:
+        t = t.to(torch.int32)          # data/graph.py:59-66: edge_index is cast to int32
+    if t.device != dev:
+        t = t.to(dev)
+    return t.contiguous()
+
+
+def row_major_2d(t):
+    """Return (tensor, leading dimension) for a 2-D float32 tensor whose rows are dense."""
+    assert t.dim() == 2
+    if t.stride(1) != 1 or (t.shape[0] > 1 and t.stride(0) < t.shape[1]):
+        t = t.contiguous()
+    ld = t.stride(0) if t.shape[0] > 1 else max(t.shape[1], 1)
+    return t, ld

@@ -1,0 +1,307 @@
+// GAT edge attention on the CSR-by-destination plan.
+//
+//   tfgx_edge_softmax_f32 : tf_geometric/nn/kernel/segment.py:26-33 (segment_softmax) and
+//                           SparseMatrix.segment_softmax(axis=-1) at nn/conv/gat.py:83-84.
+//   tfgx_gat_fused_f32    : nn/conv/gat.py:56 (gather Q by row), :65 (gather K by col), :73-79 (per-head
+//                           scores), :83-84 (softmax), :87-89 (att @ V), :112 (head concat), :116-120.
+//                           One pass per destination row with an online softmax; the reference's [E',A]
+//                           gathers, the [2, H*E'] virtual edge index and the [H*E'] score vector are
+//                           never materialised.
+//   tfgx_head_mean_f32    : nn/conv/gat.py:114 (split_value_heads=False).
+//
+// Fused kernel mapping: a group of G lanes owns one destination row; lane -> VEC consecutive columns of
+// the H*dv-wide value row, hence one head.  Every lane of a head computes that head's score redundantly
+// (the K loads of a head's lanes hit the same address and coalesce), so the online-softmax state
+// (m, l, acc[VEC]) is lane-private and no cross-lane traffic is needed beyond the col broadcast.
+#include "tfgx_common.h"
+#include <cfloat>
+
+namespace tfgx {
+namespace {
+
+// ---------------------------------------------------------------- edge softmax (standalone)
+__global__ __launch_bounds__(kBlock) void edge_softmax_kernel(const int32_t* __restrict__ row_ptr,
+                                                              const int32_t* __restrict__ perm,
+                                                              const float* __restrict__ score, int H, int64_t n_dst,
+                                                              float* __restrict__ out)
+{
+    int64_t t = blockIdx.x * int64_t(kBlock) + threadIdx.x;
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    const int64_t total = n_dst * H;
+    for (; t < total; t += stride) {
+        const int64_t r = t / H;
+        const int h = int(t - r * H);
+        const int s = row_ptr[r], e = row_ptr[r + 1];
+        float m = -FLT_MAX;
+        for (int i = s; i < e; ++i) {
+            const int64_t eid = perm ? perm[i] : i;
+            m = fmaxf(m, score[eid * H + h]);
+        }
+        float d = 0.0f;
+        for (int i = s; i < e; ++i) {
+            const int64_t eid = perm ? perm[i] : i;
+            d += expf(score[eid * H + h] - m);
+        }
+        d += 1e-8f;
+        for (int i = s; i < e; ++i) {
+            const int64_t eid = perm ? perm[i] : i;
+            out[eid * H + h] = expf(score[eid * H + h] - m) / d;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- fused GAT
+template <int VEC> struct VecT;
+template <> struct VecT<1> { using type = float; };
+template <> struct VecT<2> { using type = float2; };
+template <> struct VecT<4> { using type = float4; };
+
+template <int VEC>
+__device__ __forceinline__ void load_vec(const float* p, float (&v)[VEC])
+{
+    using T = typename VecT<VEC>::type;
+    const T t = *reinterpret_cast<const T*>(p);
+    if constexpr (VEC == 1) { v[0] = t; }
+    if constexpr (VEC == 2) { v[0] = t.x; v[1] = t.y; }
+    if constexpr (VEC == 4) { v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+}
+template <int VEC>
+__device__ __forceinline__ void store_vec(float* p, const float (&v)[VEC])
+{
+    using T = typename VecT<VEC>::type;
+    T t;
+    if constexpr (VEC == 1) { t = v[0]; }
+    if constexpr (VEC == 2) { t.x = v[0]; t.y = v[1]; }
+    if constexpr (VEC == 4) { t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3]; }
+    *reinterpret_cast<T*>(p) = t;
+}
+
+struct GArgs {
+    const int32_t* row_ptr;
+    const int32_t* col;
+    int64_t n_dst;
+    const float* q; int64_t ldq;
+    const float* k; int64_t ldk;
+    const float* v; int64_t ldv;
+    float* out; int64_t ldo;
+    int32_t H, d, dv, W;  // W = H*dv
+    int32_t add_self_loop;
+    float scale;
+    int32_t act;
+    const float* bias;
+    int32_t kvec;         // 1: K/Q head slices are 16-byte aligned and d % 4 == 0
+};
+
+// D > 0: compile-time head width (Q slice lives in registers); D == 0: runtime d, Q re-read (cache-hot)
+template <int D>
+__device__ __forceinline__ float head_dot(const float (&qreg)[D > 0 ? D : 1], const float* __restrict__ qp,
+                                          const float* __restrict__ kp, int d, int kvec)
+{
+    float s = 0.0f;
+    if constexpr (D == 0) {
+        for (int t = 0; t < d; ++t) s = fmaf(qp[t], kp[t], s);
+    } else if constexpr (D % 4 == 0) {
+        if (kvec) {
+#pragma unroll
+            for (int t = 0; t < D; t += 4) {
+                const float4 kk = *reinterpret_cast<const float4*>(kp + t);
+                s = fmaf(qreg[t], kk.x, s);
+                s = fmaf(qreg[t + 1], kk.y, s);
+                s = fmaf(qreg[t + 2], kk.z, s);
+                s = fmaf(qreg[t + 3], kk.w, s);
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < D; ++t) s = fmaf(qreg[t], kp[t], s);
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < D; ++t) s = fmaf(qreg[t], kp[t], s);
+    }
+    return s;
+}
+
+template <int VEC, int G, int D>
+__global__ __launch_bounds__(kBlock) void gat_fused_kernel(const GArgs a)
+{
+    constexpr int ROWS_PER_BLOCK = kBlock / G;
+    constexpr int UNROLL = 4;
+    const int lane = threadIdx.x % G;
+    const int grp = threadIdx.x / G;
+    const int c_raw = (blockIdx.y * G + lane) * VEC;
+    const bool cvalid = c_raw < a.W;
+    const int coff = cvalid ? c_raw : (a.W - VEC);
+    const int head = coff / a.dv;
+    const int hoff = head * a.d;
+
+    for (int64_t r = int64_t(blockIdx.x) * ROWS_PER_BLOCK + grp; r < a.n_dst;
+         r += int64_t(gridDim.x) * ROWS_PER_BLOCK) {
+        const int s = a.row_ptr[r], e = a.row_ptr[r + 1];
+        const float* qp = a.q + r * a.ldq + hoff;
+        float qreg[D > 0 ? D : 1];
+        if constexpr (D > 0) {
+#pragma unroll
+            for (int t = 0; t < D; ++t) qreg[t] = qp[t];
+        }
+        float m = -FLT_MAX, l = 0.0f;
+        float acc[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] = 0.0f;
+
+        auto step = [&](float sc, const float (&vv)[VEC]) {
+            const float mn = fmaxf(m, sc);
+            const float corr = expf(m - mn);
+            const float p = expf(sc - mn);
+            l = fmaf(l, corr, p);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc[i] = fmaf(acc[i], corr, p * vv[i]);
+            m = mn;
+        };
+
+        for (int base = s; base < e; base += G) {
+            const int mine = base + lane;
+            const int cj = (mine < e) ? a.col[mine] : 0;
+            const int cnt = min(G, e - base);
+            int j = 0;
+            for (; j + UNROLL <= cnt; j += UNROLL) {
+                float sc[UNROLL];
+                float vv[UNROLL][VEC];
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) {
+                    const int c = __shfl(cj, j + u, G);
+                    sc[u] = head_dot<D>(qreg, qp, a.k + int64_t(c) * a.ldk + hoff, a.d, a.kvec) / a.scale;
+                    load_vec<VEC>(a.v + int64_t(c) * a.ldv + coff, vv[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) step(sc[u], vv[u]);
+            }
+            for (; j < cnt; ++j) {
+                const int c = __shfl(cj, j, G);
+                const float sc = head_dot<D>(qreg, qp, a.k + int64_t(c) * a.ldk + hoff, a.d, a.kvec) / a.scale;
+                float vv[VEC];
+                load_vec<VEC>(a.v + int64_t(c) * a.ldv + coff, vv);
+                step(sc, vv);
+            }
+        }
+        if (a.add_self_loop) {  // the appended (r, r) edge comes last (graph_utils.py:350-366)
+            const float sc = head_dot<D>(qreg, qp, a.k + r * a.ldk + hoff, a.d, a.kvec) / a.scale;
+            float vv[VEC];
+            load_vec<VEC>(a.v + r * a.ldv + coff, vv);
+            step(sc, vv);
+        }
+        if (cvalid) {
+            const float den = l + 1e-8f;   // segment.py:30
+            float res[VEC];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                float o = acc[i] / den;
+                if (a.bias) o += a.bias[coff + i];
+                res[i] = apply_act(o, a.act);
+            }
+            store_vec<VEC>(a.out + r * a.ldo + coff, res);
+        }
+    }
+}
+
+template <int VEC, int G>
+int launch_gat_d(const GArgs& a, hipStream_t stream)
+{
+    constexpr int ROWS_PER_BLOCK = kBlock / G;
+    dim3 grid(grid_for(a.n_dst, ROWS_PER_BLOCK, 1 << 20), (a.W + G * VEC - 1) / (G * VEC), 1);
+    dim3 block(kBlock, 1, 1);
+    switch (a.d) {
+        case 1: gat_fused_kernel<VEC, G, 1><<<grid, block, 0, stream>>>(a); break;
+        case 2: gat_fused_kernel<VEC, G, 2><<<grid, block, 0, stream>>>(a); break;
+        case 4: gat_fused_kernel<VEC, G, 4><<<grid, block, 0, stream>>>(a); break;
+        case 8: gat_fused_kernel<VEC, G, 8><<<grid, block, 0, stream>>>(a); break;
+        case 16: gat_fused_kernel<VEC, G, 16><<<grid, block, 0, stream>>>(a); break;
+        default: gat_fused_kernel<VEC, G, 0><<<grid, block, 0, stream>>>(a); break;
+    }
+    TFGX_LAUNCH_CHECK("gat_fused_kernel");
+    return TFGX_OK;
+}
+
+template <int VEC>
+int launch_gat(const GArgs& a, hipStream_t stream)
+{
+    const int lanes = (a.W + VEC - 1) / VEC;
+    if (lanes <= 8) return launch_gat_d<VEC, 8>(a, stream);
+    if (lanes <= 16) return launch_gat_d<VEC, 16>(a, stream);
+    if (lanes <= 32) return launch_gat_d<VEC, 32>(a, stream);
+    return launch_gat_d<VEC, 64>(a, stream);  // wider rows tile over grid.y
+}
+
+__global__ __launch_bounds__(kBlock) void head_mean_kernel(const float* __restrict__ in, int64_t ld_in, int64_t n,
+                                                           int H, int U, const float* __restrict__ bias, int act,
+                                                           float* __restrict__ out, int64_t ldo)
+{
+    int64_t t = blockIdx.x * int64_t(kBlock) + threadIdx.x;
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    const int64_t total = n * U;
+    for (; t < total; t += stride) {
+        const int64_t r = t / U;
+        const int j = int(t - r * U);
+        float s = 0.0f;
+        for (int h = 0; h < H; ++h) s += in[r * ld_in + int64_t(h) * U + j];  // tf.add_n order (gat.py:114)
+        s = s / float(H);
+        if (bias) s += bias[j];
+        out[r * ldo + j] = apply_act(s, act);
+    }
+}
+
+inline bool aligned_to(const void* p, size_t al) { return (reinterpret_cast<uintptr_t>(p) % al) == 0; }
+
+}  // namespace
+}  // namespace tfgx
+
+using namespace tfgx;
+
+extern "C" int tfgx_edge_softmax_f32(const int32_t* row_ptr, const int32_t* perm, const float* score, int64_t H,
+                                     int64_t n_dst, float* out, tfgx_stream_t stream)
+{
+    TFGX_REQUIRE(H >= 1 && n_dst >= 0, "bad H / n_dst");
+    if (n_dst == 0) return TFGX_OK;
+    TFGX_REQUIRE(row_ptr != nullptr, "row_ptr is null");
+    edge_softmax_kernel<<<grid_for(n_dst * H, kBlock), kBlock, 0, as_stream(stream)>>>(row_ptr, perm, score,
+                                                                                      int(H), n_dst, out);
+    TFGX_LAUNCH_CHECK("edge_softmax_kernel");
+    return TFGX_OK;
+}
+
+extern "C" int tfgx_gat_fused_f32(const tfgx_gat_args* p, tfgx_stream_t stream_)
+{
+    TFGX_REQUIRE(p != nullptr, "args is null");
+    TFGX_REQUIRE(p->H >= 1 && p->d >= 1 && p->dv >= 1 && p->n_dst >= 0, "bad H / d / dv / n_dst");
+    TFGX_REQUIRE(p->scale > 0.0f, "scale must be positive");
+    if (p->n_dst == 0) return TFGX_OK;
+    TFGX_REQUIRE(p->row_ptr && p->q && p->k && p->v && p->out, "null pointer");
+    const int64_t W = int64_t(p->H) * p->dv, A = int64_t(p->H) * p->d;
+    TFGX_REQUIRE(p->ldq >= A && p->ldk >= A && p->ldv >= W && p->ldo >= W, "leading dimension too small");
+    GArgs a;
+    a.row_ptr = p->row_ptr; a.col = p->col; a.n_dst = p->n_dst;
+    a.q = p->q; a.ldq = p->ldq; a.k = p->k; a.ldk = p->ldk; a.v = p->v; a.ldv = p->ldv;
+    a.out = p->out; a.ldo = p->ldo; a.H = p->H; a.d = p->d; a.dv = p->dv; a.W = int32_t(W);
+    a.add_self_loop = p->add_self_loop; a.scale = p->scale; a.act = p->act; a.bias = p->bias;
+    a.kvec = (p->d % 4 == 0) && (p->ldk % 4 == 0) && aligned_to(p->k, 16);
+    hipStream_t stream = as_stream(stream_);
+    auto ok = [&](int vec) {
+        const size_t al = sizeof(float) * vec;
+        return (p->dv % vec == 0) && (p->ldv % vec == 0) && (p->ldo % vec == 0) && aligned_to(p->v, al) &&
+               aligned_to(p->out, al);
+    };
+    if (ok(4)) return launch_gat<4>(a, stream);
+    if (ok(2)) return launch_gat<2>(a, stream);
+    return launch_gat<1>(a, stream);
+}
+
+extern "C" int tfgx_head_mean_f32(const float* in, int64_t ld_in, int64_t n, int32_t H, int32_t U,
+                                  const float* bias, int32_t act, float* out, int64_t ldo, tfgx_stream_t stream)
+{
+    TFGX_REQUIRE(n >= 0 && H >= 1 && U >= 1, "bad size");
+    if (n == 0) return TFGX_OK;
+    TFGX_REQUIRE(in && out && ld_in >= int64_t(H) * U && ldo >= U, "bad pointer / leading dimension");
+    head_mean_kernel<<<grid_for(n * U, kBlock), kBlock, 0, as_stream(stream)>>>(in, ld_in, n, H, U, bias, act, out,
+                                                                               ldo);
+    TFGX_LAUNCH_CHECK("head_mean_kernel");
+    return TFGX_OK;
+}

@@ -1,0 +1,209 @@
+// Row utilities and destination-range sharding helpers.
+//   tfgx_l2_normalize_rows_f32 : tf.nn.l2_normalize(h, axis=-1) (tf_geometric/nn/conv/graph_sage.py:58)
+//   tfgx_gather_rows_f32       : send-side pack of the halo all-to-all-v (no counterpart in the reference,
+//                                which replicates the whole graph per GPU: demo/demo_distributed_gcn.py:38-57)
+//   tfgx_halo_* / tfgx_split_local_halo : per-rank plan for a destination-range shard
+#include "tfgx_common.h"
+#include <hipcub/hipcub.hpp>
+
+namespace tfgx {
+namespace {
+
+__global__ __launch_bounds__(kBlock) void l2_normalize_kernel(float* __restrict__ h, int64_t ld, int64_t n, int F)
+{
+    const int lane = threadIdx.x & 63;
+    int64_t r = (blockIdx.x * int64_t(kBlock) + threadIdx.x) >> 6;
+    const int64_t stride = (int64_t(gridDim.x) * kBlock) >> 6;
+    for (; r < n; r += stride) {
+        float* row = h + r * ld;
+        float ss = 0.0f;
+        for (int j = lane; j < F; j += 64) ss = fmaf(row[j], row[j], ss);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        const float inv = 1.0f / sqrtf(fmaxf(ss, 1e-12f));
+        for (int j = lane; j < F; j += 64) row[j] *= inv;
+    }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void gather_rows_kernel(const float* __restrict__ x, int64_t ldx,
+                                                             const int32_t* __restrict__ idx, int64_t M, int F,
+                                                             float* __restrict__ out, int64_t ldo)
+{
+    const int per_row = F / VEC;
+    int64_t t = blockIdx.x * int64_t(kBlock) + threadIdx.x;
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    const int64_t total = M * per_row;
+    for (; t < total; t += stride) {
+        const int64_t i = t / per_row;
+        const int j = int(t - i * per_row) * VEC;
+        const float* src = x + int64_t(idx[i]) * ldx + j;
+        float* dst = out + i * ldo + j;
+        if constexpr (VEC == 4) *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(src);
+        else *dst = *src;
+    }
+}
+
+__global__ void halo_mark_kernel(const int32_t* __restrict__ col, int64_t E, int32_t lo, int32_t hi,
+                                 int32_t* __restrict__ flags)
+{
+    int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (; i < E; i += stride) {
+        const int32_t c = col[i];
+        if (c < lo || c >= hi) flags[c] = 1;   // benign race: every writer stores the same value
+    }
+}
+
+__global__ void halo_scatter_kernel(const int32_t* __restrict__ flags, const int32_t* __restrict__ pos, int64_t n,
+                                    int32_t* __restrict__ halo_ids, int32_t* __restrict__ n_halo)
+{
+    int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (; i < n; i += stride) {
+        if (flags[i]) halo_ids[pos[i]] = static_cast<int32_t>(i);
+        if (i == n - 1) *n_halo = pos[i] + (flags[i] ? 1 : 0);
+    }
+}
+
+__global__ void halo_remap_kernel(const int32_t* __restrict__ col, int64_t E, int32_t lo, int32_t hi,
+                                  const int32_t* __restrict__ pos, int32_t n_own, int32_t* __restrict__ col_local)
+{
+    int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (; i < E; i += stride) {
+        const int32_t c = col[i];
+        col_local[i] = (c >= lo && c < hi) ? (c - lo) : (n_own + pos[c]);
+    }
+}
+
+// stable per-row partition into [local | halo]; one thread per destination row (plan time only)
+__global__ void split_local_halo_kernel(const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col_local,
+                                        const float* __restrict__ w, int64_t n_dst, int32_t n_own,
+                                        int32_t* __restrict__ row_ptr2, int32_t* __restrict__ col_out,
+                                        float* __restrict__ w_out)
+{
+    int64_t r = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (; r < n_dst; r += stride) {
+        const int s = row_ptr[r], e = row_ptr[r + 1];
+        int nloc = 0;
+        for (int i = s; i < e; ++i) nloc += (col_local[i] < n_own);
+        int pl = s, ph = s + nloc;
+        for (int i = s; i < e; ++i) {
+            const int32_t c = col_local[i];
+            const int dst = (c < n_own) ? pl++ : ph++;
+            col_out[dst] = c;
+            if (w_out) w_out[dst] = w[i];
+        }
+        row_ptr2[2 * r] = s;
+        row_ptr2[2 * r + 1] = s + nloc;
+        if (r == n_dst - 1) row_ptr2[2 * n_dst] = e;
+    }
+}
+
+inline bool aligned_to(const void* p, size_t al) { return (reinterpret_cast<uintptr_t>(p) % al) == 0; }
+
+}  // namespace
+}  // namespace tfgx
+
+using namespace tfgx;
+
+extern "C" int tfgx_l2_normalize_rows_f32(float* h, int64_t ld, int64_t n, int64_t F, tfgx_stream_t stream)
+{
+    TFGX_REQUIRE(n >= 0 && F >= 1 && ld >= F, "bad size");
+    if (n == 0) return TFGX_OK;
+    TFGX_REQUIRE(h != nullptr, "null pointer");
+    l2_normalize_kernel<<<grid_for(n * 64, kBlock), kBlock, 0, as_stream(stream)>>>(h, ld, n, int(F));
+    TFGX_LAUNCH_CHECK("l2_normalize_kernel");
+    return TFGX_OK;
+}
+
+extern "C" int tfgx_gather_rows_f32(const float* x, int64_t ldx, const int32_t* idx, int64_t M, int64_t F,
+                                    float* out, int64_t ldo, tfgx_stream_t stream)
+{
+    TFGX_REQUIRE(M >= 0 && F >= 1 && ldx >= F && ldo >= F, "bad size");
+    if (M == 0) return TFGX_OK;
+    TFGX_REQUIRE(x && idx && out, "null pointer");
+    const bool v4 = (F % 4 == 0) && (ldx % 4 == 0) && (ldo % 4 == 0) && aligned_to(x, 16) && aligned_to(out, 16);
+    if (v4)
+        gather_rows_kernel<4><<<grid_for(M * (F / 4), kBlock), kBlock, 0, as_stream(stream)>>>(x, ldx, idx, M, int(F),
+                                                                                              out, ldo);
+    else
+        gather_rows_kernel<1><<<grid_for(M * F, kBlock), kBlock, 0, as_stream(stream)>>>(x, ldx, idx, M, int(F), out,
+                                                                                        ldo);
+    TFGX_LAUNCH_CHECK("gather_rows_kernel");
+    return TFGX_OK;
+}
+
+extern "C" size_t tfgx_halo_workspace_bytes(int64_t n_global)
+{
+    size_t temp = 0;
+    const int32_t* in = nullptr;
+    int32_t* out = nullptr;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, temp, in, out, static_cast<int>(n_global > 0 ? n_global : 1));
+    return temp + 256;
+}
+
+extern "C" int tfgx_halo_mark(const int32_t* col, int64_t E, int32_t own_lo, int32_t own_hi, int64_t n_global,
+                              int32_t* flags, tfgx_stream_t stream_)
+{
+    hipStream_t stream = as_stream(stream_);
+    TFGX_REQUIRE(E >= 0 && n_global >= 0 && flags, "bad argument");
+    TFGX_HIP_CHECK(hipMemsetAsync(flags, 0, sizeof(int32_t) * size_t(n_global), stream));
+    if (E == 0) return TFGX_OK;
+    halo_mark_kernel<<<grid_for(E, kBlock), kBlock, 0, stream>>>(col, E, own_lo, own_hi, flags);
+    TFGX_LAUNCH_CHECK("halo_mark_kernel");
+    return TFGX_OK;
+}
+
+extern "C" int tfgx_halo_compact(const int32_t* flags, int64_t n_global, int32_t* pos, int32_t* halo_ids,
+                                 int32_t* n_halo, void* workspace, size_t workspace_bytes, tfgx_stream_t stream_)
+{
+    hipStream_t stream = as_stream(stream_);
+    TFGX_REQUIRE(n_global >= 0 && n_halo, "bad argument");
+    if (n_global == 0) {
+        TFGX_HIP_CHECK(hipMemsetAsync(n_halo, 0, sizeof(int32_t), stream));
+        return TFGX_OK;
+    }
+    TFGX_REQUIRE(flags && pos && halo_ids && workspace, "null pointer");
+    if (workspace_bytes < tfgx_halo_workspace_bytes(n_global)) {
+        set_error("tfgx_halo_compact: workspace too small");
+        return TFGX_ERR_WORKSPACE;
+    }
+    size_t temp = workspace_bytes;
+    TFGX_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(workspace, temp, flags, pos, static_cast<int>(n_global), stream));
+    halo_scatter_kernel<<<grid_for(n_global, kBlock), kBlock, 0, stream>>>(flags, pos, n_global, halo_ids, n_halo);
+    TFGX_LAUNCH_CHECK("halo_scatter_kernel");
+    return TFGX_OK;
+}
+
+extern "C" int tfgx_halo_remap_cols(const int32_t* col, int64_t E, int32_t own_lo, int32_t own_hi,
+                                    const int32_t* pos, int32_t n_own, int32_t* col_local, tfgx_stream_t stream)
+{
+    TFGX_REQUIRE(E >= 0, "bad argument");
+    if (E == 0) return TFGX_OK;
+    TFGX_REQUIRE(col && pos && col_local, "null pointer");
+    halo_remap_kernel<<<grid_for(E, kBlock), kBlock, 0, as_stream(stream)>>>(col, E, own_lo, own_hi, pos, n_own,
+                                                                            col_local);
+    TFGX_LAUNCH_CHECK("halo_remap_kernel");
+    return TFGX_OK;
+}
+
+extern "C" int tfgx_split_local_halo(const int32_t* row_ptr, const int32_t* col_local, const float* w,
+                                     int64_t n_dst, int64_t E, int32_t n_own, int32_t* row_ptr2, int32_t* col_out,
+                                     float* w_out, tfgx_stream_t stream_)
+{
+    hipStream_t stream = as_stream(stream_);
+    TFGX_REQUIRE(n_dst >= 0 && E >= 0 && row_ptr2, "bad argument");
+    if (n_dst == 0) {
+        TFGX_HIP_CHECK(hipMemsetAsync(row_ptr2, 0, sizeof(int32_t), stream));
+        return TFGX_OK;
+    }
+    TFGX_REQUIRE(row_ptr != nullptr, "null pointer");
+    TFGX_REQUIRE((w == nullptr) == (w_out == nullptr), "w and w_out must both be given or both be null");
+    split_local_halo_kernel<<<grid_for(n_dst, kBlock), kBlock, 0, stream>>>(row_ptr, col_local, w, n_dst, n_own,
+                                                                            row_ptr2, col_out, w_out);
+    TFGX_LAUNCH_CHECK("split_local_halo_kernel");
+    return TFGX_OK;
+}

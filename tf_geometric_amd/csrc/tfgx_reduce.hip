@@ -1,0 +1,300 @@
+// Gather - scale - segment reduce over a CSR-by-destination plan (the hot kernel).
+//
+// Replaces tf.gather(x, col) -> gcn_mapper -> tf.math.unsorted_segment_{sum,mean,max}
+// (reference: tf_geometric/nn/kernel/map_reduce.py:60-70, :15-42; nn/conv/gcn.py:221-222, :280)
+// without ever materialising the [E, F] message tensor.
+//
+// Mapping (wave = 64 lanes): a destination row is owned by a GROUP of G lanes (G = 4..64, a power of
+// two, picked from F), so a wave owns 64/G consecutive destination rows and a 256-thread workgroup
+// 256/G of them.  Each lane owns VEC consecutive feature columns per chunk (16-byte loads when the
+// layout allows).  Per row the group reads G (col, w) pairs at a time, coalesced, one per lane, then
+// walks them: the pair is broadcast inside the group with a lane shuffle (G = 64: v_readlane, which
+// also makes the row base address scalar) and every lane issues one VEC-wide load of x[col] — the
+// source row is read as one contiguous 4*F-byte burst.  The walk is unrolled by UNROLL edges so that
+// UNROLL independent loads are in flight per lane before the first FMA.  Accumulation is a single
+// in-order FMA chain per output element: deterministic, no atomics, original edge order per row.
+#include "tfgx_common.h"
+#include <cfloat>
+
+namespace tfgx {
+namespace {
+
+template <int VEC> struct VecT;
+template <> struct VecT<1> { using type = float; };
+template <> struct VecT<2> { using type = float2; };
+template <> struct VecT<4> { using type = float4; };
+
+template <int VEC>
+__device__ __forceinline__ void load_vec(const float* p, float (&v)[VEC])
+{
+    using T = typename VecT<VEC>::type;
+    const T t = *reinterpret_cast<const T*>(p);
+    if constexpr (VEC == 1) { v[0] = t; }
+    if constexpr (VEC == 2) { v[0] = t.x; v[1] = t.y; }
+    if constexpr (VEC == 4) { v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+}
+
+template <int VEC>
+__device__ __forceinline__ void store_vec(float* p, const float (&v)[VEC])
+{
+    using T = typename VecT<VEC>::type;
+    T t;
+    if constexpr (VEC == 1) { t = v[0]; }
+    if constexpr (VEC == 2) { t.x = v[0]; t.y = v[1]; }
+    if constexpr (VEC == 4) { t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3]; }
+    *reinterpret_cast<T*>(p) = t;
+}
+
+template <int G>
+__device__ __forceinline__ int bcast_i(int v, int j)
+{
+    if constexpr (G == 64) return __builtin_amdgcn_readlane(v, j);
+    else return __shfl(v, j, G);
+}
+template <int G>
+__device__ __forceinline__ float bcast_f(float v, int j)
+{
+    if constexpr (G == 64) return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j));
+    else return __shfl(v, j, G);
+}
+
+struct KArgs {
+    const int32_t* row_begin;
+    const int32_t* row_end;
+    int64_t rp_stride;
+    const int32_t* col;
+    const float* w;
+    int64_t n_dst;
+    const float* x;
+    int64_t ldx;
+    int32_t F;
+    int32_t col0;     // first column handled by this launch's blockIdx.y == 0
+    float* out;
+    int64_t ldo;
+    int32_t op, act, accumulate;
+    const float* self_coef;
+    const float* bias;
+    const float* add_x;
+    int64_t ld_add;
+    const int32_t* mean_count;
+};
+
+template <int VEC, int G, int CH, bool IS_MAX, bool WEIGHTED>
+__global__ __launch_bounds__(kBlock) void seg_reduce_kernel(const KArgs a)
+{
+    constexpr int UNROLL = (CH >= 4) ? 2 : (CH == 2 ? 4 : 8);  // independent row loads in flight per lane
+    constexpr int ROWS_PER_BLOCK = kBlock / G;
+    constexpr int COLS_PER_PASS = G * VEC * CH;
+    const int lane = threadIdx.x % G;
+    const int grp = threadIdx.x / G;
+    const int colbase = a.col0 + blockIdx.y * COLS_PER_PASS;
+
+    // column offsets of this lane; lanes past F re-read the last valid vector (branch-free, discarded)
+    int coff[CH];
+    bool cvalid[CH];
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+        const int c = colbase + (k * G + lane) * VEC;
+        cvalid[k] = c < a.F;
+        coff[k] = cvalid[k] ? c : (a.F - VEC);
+    }
+    const float init = IS_MAX ? -FLT_MAX : 0.0f;
+
+    for (int64_t r = int64_t(blockIdx.x) * ROWS_PER_BLOCK + grp; r < a.n_dst;
+         r += int64_t(gridDim.x) * ROWS_PER_BLOCK) {
+        int s = a.row_begin[r * a.rp_stride];
+        int e = a.row_end[r * a.rp_stride];
+        if constexpr (G == 64) {
+            s = __builtin_amdgcn_readfirstlane(s);
+            e = __builtin_amdgcn_readfirstlane(e);
+        }
+        float acc[CH][VEC];
+#pragma unroll
+        for (int k = 0; k < CH; ++k)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc[k][v] = init;
+
+        for (int base = s; base < e; base += G) {
+            const int mine = base + lane;
+            int cj = 0;
+            float wj = 0.0f;
+            if (mine < e) {
+                cj = a.col[mine];
+                if constexpr (WEIGHTED) wj = a.w[mine];
+            }
+            const int cnt = min(G, e - base);
+            int j = 0;
+            for (; j + UNROLL <= cnt; j += UNROLL) {
+                float xv[UNROLL][CH][VEC];
+                float ww[UNROLL];
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) {
+                    const int c = bcast_i<G>(cj, j + u);
+                    if constexpr (WEIGHTED) ww[u] = bcast_f<G>(wj, j + u);
+                    const float* xr = a.x + int64_t(c) * a.ldx;
+#pragma unroll
+                    for (int k = 0; k < CH; ++k) load_vec<VEC>(xr + coff[k], xv[u][k]);
+                }
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+                    for (int k = 0; k < CH; ++k)
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) {
+                            if constexpr (IS_MAX) {
+                                const float m = WEIGHTED ? xv[u][k][v] * ww[u] : xv[u][k][v];
+                                acc[k][v] = fmaxf(acc[k][v], m);
+                            } else {
+                                acc[k][v] = WEIGHTED ? fmaf(ww[u], xv[u][k][v], acc[k][v]) : acc[k][v] + xv[u][k][v];
+                            }
+                        }
+            }
+            for (; j < cnt; ++j) {
+                const int c = bcast_i<G>(cj, j);
+                float wv = 1.0f;
+                if constexpr (WEIGHTED) wv = bcast_f<G>(wj, j);
+                const float* xr = a.x + int64_t(c) * a.ldx;
+#pragma unroll
+                for (int k = 0; k < CH; ++k) {
+                    float xv[VEC];
+                    load_vec<VEC>(xr + coff[k], xv);
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) {
+                        if constexpr (IS_MAX) {
+                            const float m = WEIGHTED ? xv[v] * wv : xv[v];
+                            acc[k][v] = fmaxf(acc[k][v], m);
+                        } else {
+                            acc[k][v] = WEIGHTED ? fmaf(wv, xv[v], acc[k][v]) : acc[k][v] + xv[v];
+                        }
+                    }
+                }
+            }
+        }
+
+        // ---- epilogue (per destination row) ----
+        const float sc = a.self_coef ? a.self_coef[r] : 0.0f;
+        float divisor = 1.0f;
+        if (a.op == TFGX_MEAN) {
+            const int cnt = a.mean_count ? a.mean_count[r] : (e - s);
+            divisor = float(cnt > 1 ? cnt : 1);
+        }
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            if (!cvalid[k]) continue;
+            float res[VEC];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) res[v] = acc[k][v];
+            float* op = a.out + r * a.ldo + coff[k];
+            if (a.accumulate) {
+                float prev[VEC];
+                load_vec<VEC>(op, prev);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) res[v] = IS_MAX ? fmaxf(prev[v], res[v]) : prev[v] + res[v];
+            }
+            if (a.self_coef) {
+                float xs[VEC];
+                load_vec<VEC>(a.x + r * a.ldx + coff[k], xs);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    if constexpr (IS_MAX) res[v] = fmaxf(res[v], sc * xs[v]);
+                    else res[v] = fmaf(sc, xs[v], res[v]);
+                }
+            }
+            if (a.op == TFGX_MEAN) {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) res[v] = res[v] / divisor;
+            }
+            if (a.add_x) {
+                float xa[VEC];
+                load_vec<VEC>(a.add_x + r * a.ld_add + coff[k], xa);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) res[v] = xa[v] + res[v];
+            }
+            if (a.bias) {
+                float b[VEC];
+                load_vec<VEC>(a.bias + coff[k], b);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) res[v] += b[v];
+            }
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) res[v] = apply_act(res[v], a.act);
+            store_vec<VEC>(op, res);
+        }
+    }
+}
+
+template <int VEC, int G, int CH>
+int launch_cfg(const KArgs& a, bool is_max, bool weighted, int ny, hipStream_t stream)
+{
+    constexpr int ROWS_PER_BLOCK = kBlock / G;
+    dim3 grid(grid_for(a.n_dst, ROWS_PER_BLOCK, 1 << 20), ny, 1);
+    dim3 block(kBlock, 1, 1);
+    if (is_max) {
+        if (weighted) seg_reduce_kernel<VEC, G, CH, true, true><<<grid, block, 0, stream>>>(a);
+        else seg_reduce_kernel<VEC, G, CH, true, false><<<grid, block, 0, stream>>>(a);
+    } else {
+        if (weighted) seg_reduce_kernel<VEC, G, CH, false, true><<<grid, block, 0, stream>>>(a);
+        else seg_reduce_kernel<VEC, G, CH, false, false><<<grid, block, 0, stream>>>(a);
+    }
+    TFGX_LAUNCH_CHECK("seg_reduce_kernel");
+    return TFGX_OK;
+}
+
+template <int VEC>
+int launch_vec(const KArgs& a, bool is_max, bool weighted, hipStream_t stream)
+{
+    const int lanes = (a.F + VEC - 1) / VEC;  // lanes needed to cover one row with one chunk each
+    if (lanes <= 4) return launch_cfg<VEC, 4, 1>(a, is_max, weighted, 1, stream);
+    if (lanes <= 8) return launch_cfg<VEC, 8, 1>(a, is_max, weighted, 1, stream);
+    if (lanes <= 16) return launch_cfg<VEC, 16, 1>(a, is_max, weighted, 1, stream);
+    if (lanes <= 32) return launch_cfg<VEC, 32, 1>(a, is_max, weighted, 1, stream);
+    if (lanes <= 64) return launch_cfg<VEC, 64, 1>(a, is_max, weighted, 1, stream);
+    if (lanes <= 128) return launch_cfg<VEC, 64, 2>(a, is_max, weighted, 1, stream);
+    // wider rows: column blocks of 64*VEC*4 on grid.y (col/w are re-read per block: 8 B vs >= 1 KiB of x)
+    const int per = 64 * VEC * 4;
+    return launch_cfg<VEC, 64, 4>(a, is_max, weighted, (a.F + per - 1) / per, stream);
+}
+
+inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+}  // namespace
+}  // namespace tfgx
+
+using namespace tfgx;
+
+extern "C" int tfgx_segment_reduce_f32(const tfgx_reduce_args* p, tfgx_stream_t stream_)
+{
+    TFGX_REQUIRE(p != nullptr, "args is null");
+    TFGX_REQUIRE(p->n_dst >= 0 && p->F >= 1 && p->F < (int64_t(1) << 30), "bad n_dst / F");
+    TFGX_REQUIRE(p->op == TFGX_SUM || p->op == TFGX_MEAN || p->op == TFGX_MAX, "bad op");
+    TFGX_REQUIRE(p->act == TFGX_ACT_NONE || p->act == TFGX_ACT_RELU, "bad act");
+    if (p->n_dst == 0) return TFGX_OK;
+    TFGX_REQUIRE(p->row_begin && p->row_end && p->out && p->x, "null pointer");
+    TFGX_REQUIRE(p->ldx >= p->F && p->ldo >= p->F, "leading dimension < F");
+    TFGX_REQUIRE(p->rp_stride >= 1, "rp_stride < 1");
+    TFGX_REQUIRE(!(p->add_x) || p->ld_add >= p->F, "ld_add < F");
+
+    KArgs a;
+    a.row_begin = p->row_begin; a.row_end = p->row_end; a.rp_stride = p->rp_stride;
+    a.col = p->col; a.w = p->w; a.n_dst = p->n_dst; a.x = p->x; a.ldx = p->ldx; a.F = int32_t(p->F);
+    a.col0 = 0; a.out = p->out; a.ldo = p->ldo; a.op = p->op; a.act = p->act; a.accumulate = p->accumulate;
+    a.self_coef = p->self_coef; a.bias = p->bias; a.add_x = p->add_x; a.ld_add = p->ld_add;
+    a.mean_count = p->mean_count;
+
+    const bool is_max = p->op == TFGX_MAX;
+    const bool weighted = p->w != nullptr;
+    hipStream_t stream = as_stream(stream_);
+
+    // widest vector the layout allows for every row pointer that is touched
+    auto ok = [&](int vec) {
+        const size_t al = sizeof(float) * vec;
+        bool good = (p->F % vec == 0) && (p->ldx % vec == 0) && (p->ldo % vec == 0) && aligned_to(p->x, al) &&
+                    aligned_to(p->out, al);
+        if (p->add_x) good = good && (p->ld_add % vec == 0) && aligned_to(p->add_x, al);
+        if (p->bias) good = good && aligned_to(p->bias, al);
+        return good;
+    };
+    if (ok(4)) return launch_vec<4>(a, is_max, weighted, stream);
+    if (ok(2)) return launch_vec<2>(a, is_max, weighted, stream);
+    return launch_vec<1>(a, is_max, weighted, stream);
+}

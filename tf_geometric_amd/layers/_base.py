@@ -1,0 +1,68 @@
+# coding=utf-8
+"""Tiny stand-in for the tf.keras.Model plumbing the reference layers rely on (add_weight / build / call)."""
+import math
+
+import torch
+
+from .. import _lib as L
+
+
+class Layer(object):
+    """Weights are created lazily from the first input's feature width, as Keras `build` does
+    (e.g. layers/conv/gcn.py:17-30).  `layer(inputs, **kw)` == `layer.call(inputs, **kw)`."""
+
+    def __init__(self, seed=None, name=None):
+        self.built = False
+        self.name = name or self.__class__.__name__
+        self._weights = {}
+        self._gen = None
+        self._seed = seed
+
+    def _rng(self, dev):
+        if self._gen is None:
+            self._gen = torch.Generator(device="cpu")
+            self._gen.manual_seed(0 if self._seed is None else int(self._seed))
+        return self._gen
+
+    def add_weight(self, name, shape, initializer="glorot_uniform"):
+        dev = L.device()
+        if initializer == "zeros":
+            w = torch.zeros(shape, dtype=torch.float32, device=dev)
+        elif initializer == "glorot_uniform":
+            fan_in, fan_out = (shape[0], shape[1]) if len(shape) == 2 else (shape[0], shape[0])
+            limit = math.sqrt(6.0 / (fan_in + fan_out))
+            w = ((torch.rand(shape, generator=self._rng(dev), dtype=torch.float32) * 2.0 - 1.0) * limit).to(dev)
+        else:
+            raise ValueError("unknown initializer {}".format(initializer))
+        self._weights[name] = w
+        return w
+
+    def set_weights(self, **named):
+        """Load weights by the reference's variable names (checkpoint compatibility)."""
+        for k, v in named.items():
+            if not hasattr(self, k):
+                raise KeyError("{} has no weight named {}".format(self.name, k))
+            t = L.as_f32(v).contiguous()
+            setattr(self, k, t)
+            self._weights[k] = t
+
+    @property
+    def weights(self):
+        return dict(self._weights)
+
+    def build(self, input_shapes):
+        raise NotImplementedError
+
+    def call(self, inputs, **kwargs):
+        raise NotImplementedError
+
+    def _maybe_build(self, inputs):
+        if not self.built:
+            L.require_gpu()
+            x = inputs[0]
+            self.build([tuple(x.shape)])
+            self.built = True
+
+    def __call__(self, inputs, **kwargs):
+        self._maybe_build(inputs)
+        return self.call(inputs, **kwargs)

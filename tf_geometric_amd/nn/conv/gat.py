@@ -1,0 +1,86 @@
+# coding=utf-8
+"""Transformer-style multi-head GAT on the HIP backend — functional mirror of tf_geometric/nn/conv/gat.py.
+
+Three MFMA GEMMs (Q, K with bias+activation fused; V), then ONE fused launch per layer that walks each
+destination row once: per-head score <Q[row], K[col]>/sqrt(d), online edge-softmax and the weighted sum of V.
+The reference's gathered [E', A] Q/K tensors (gat.py:56,65), the H-fold virtual graph (:73-76) and the score
+vector (:79) are never materialised; the N self-loop edges of add_self_loop_edge (:43) are implicit.
+"""
+import ctypes
+import math
+
+import torch
+
+from ... import _lib as L
+from ...activations import resolve as _resolve_act
+from ...plan import CsrPlan, gemm_bias_act
+
+
+def _linear(x, kernel, bias, activation):
+    act, post = _resolve_act(activation)
+    h = gemm_bias_act(x, kernel, bias=bias, act=act)
+    return post(h) if post is not None else h
+
+
+def gat_attention(plan, Q, K, V, num_heads, add_self_loop=True, bias=None, act=L.ACT_NONE):
+    """Fused SDDMM + edge softmax + SpMM over `plan` (tfgx_gat_fused_f32). Q:[n_dst,A] K:[n_src,A] V:[n_src,W]."""
+    lib = L.require_gpu()
+    Q, ldq = L.row_major_2d(Q)
+    K, ldk = L.row_major_2d(K)
+    V, ldv = L.row_major_2d(V)
+    A, W = int(Q.shape[1]), int(V.shape[1])
+    if A % num_heads or W % num_heads:
+        raise ValueError("attention_units ({}) and value width ({}) must be divisible by num_heads ({})"
+                         .format(A, W, num_heads))
+    out = torch.empty((plan.n_dst, W), dtype=torch.float32, device=V.device)
+    a = L.GatArgs()
+    a.row_ptr = plan.row_ptr.data_ptr()
+    a.col = plan.col.data_ptr()
+    a.n_dst = plan.n_dst
+    a.q, a.ldq = Q.data_ptr(), ldq
+    a.k, a.ldk = K.data_ptr(), ldk
+    a.v, a.ldv = V.data_ptr(), ldv
+    a.out, a.ldo = out.data_ptr(), max(W, 1)
+    a.H, a.d, a.dv = num_heads, A // num_heads, W // num_heads
+    a.add_self_loop = 1 if add_self_loop else 0
+    a.scale = math.sqrt(float(A // num_heads))            # gat.py:78  sqrt(shape(Q_)[-1])
+    a.act = act
+    a.bias = 0 if bias is None else bias.data_ptr()
+    L.check(lib.tfgx_gat_fused_f32(ctypes.byref(a), L.stream_ptr()), "tfgx_gat_fused_f32")
+    return out
+
+
+def gat(x, edge_index,
+        query_kernel, query_bias, query_activation,
+        key_kernel, key_bias, key_activation,
+        kernel, bias=None, activation=None, num_heads=1,
+        split_value_heads=True, edge_drop_rate=0.0, training=False, cache=None):
+    """
+    Functional GAT (reference: gat.py:13-122; same arguments, plus an optional `cache` dict for the CSR plan).
+
+    :param x: [num_nodes, num_features]
+    :param edge_index: [2, num_edges]
+    :param split_value_heads: True -> V is split into heads and the heads are concatenated (:112);
+        False -> kernel is [F, units*num_heads] and the heads are averaged (:114).
+    :return: [num_nodes, num_output_features]
+    """
+    lib = L.require_gpu()
+    if training and edge_drop_rate > 0.0:
+        raise NotImplementedError("attention dropout is a training-time op; this backend is inference-only")
+    x = L.as_f32(x)
+    n = int(x.shape[0])
+    plan = CsrPlan.from_cache(edge_index, n, n, cache)
+    Q = _linear(x, query_kernel, query_bias, query_activation)       # :52-54 (gather by row happens in-kernel)
+    K = _linear(x, key_kernel, key_bias, key_activation)             # :61-63
+    V = gemm_bias_act(x, kernel)                                     # :70
+    act, post = _resolve_act(activation)
+    bias_t = None if bias is None else L.as_f32(bias).contiguous()
+    if split_value_heads:
+        h = gat_attention(plan, Q, K, V, num_heads, True, bias=bias_t, act=act)
+    else:
+        h_ = gat_attention(plan, Q, K, V, num_heads, True)
+        U = int(V.shape[1]) // num_heads
+        h = torch.empty((n, U), dtype=torch.float32, device=x.device)
+        L.check(lib.tfgx_head_mean_f32(L.ptr(h_), int(V.shape[1]), n, num_heads, U, L.ptr(bias_t), act, L.ptr(h),
+                                       max(U, 1), L.stream_ptr()), "tfgx_head_mean_f32")
+    return post(h) if post is not None else h

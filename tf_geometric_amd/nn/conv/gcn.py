@@ -1,0 +1,160 @@
+# coding=utf-8
+"""GCN on the HIP backend — functional mirror of tf_geometric/nn/conv/gcn.py.
+
+act( A_hat @ (x @ kernel) + bias ):  x @ kernel on the fp32 MFMA GEMM, A_hat @ h as one fused
+gather-scale-segment-sum launch over the cached CSR plan (bias and activation in its epilogue); the added
+diagonal (SparseMatrix.add_diag, gcn.py:72,77,98) stays implicit as a per-row self coefficient.
+"""
+import torch
+
+from ... import _lib as L
+from ...activations import resolve as _resolve_act
+from ...plan import segment_reduce, gemm_bias_act
+from ...sparse import SparseMatrix
+
+CACHE_KEY_GCN_NORMED_ADJ_TEMPLATE = "gcn_normed_adj_{}_{}_{}_{}_{}"
+
+
+def compute_cache_key(norm, add_self_loop, sym, renorm, improved):
+    """Same key as the reference (gcn.py:9-20), so one cache dict serves both."""
+    return CACHE_KEY_GCN_NORMED_ADJ_TEMPLATE.format(norm, add_self_loop, sym, renorm, improved)
+
+
+class NormedAdj(object):
+    """Normalised adjacency in plan form: w_csr[E] (CSR order) + self_coef[n] (implicit diagonal)."""
+
+    def __init__(self, plan, w_csr, self_coef, shape):
+        self.plan = plan
+        self.w_csr = w_csr
+        self.self_coef = self_coef
+        self.shape = shape
+
+    def matmul(self, h, num_or_size_splits=None, bias=None, act=L.ACT_NONE):
+        return segment_reduce(self.plan, L.as_f32(h), L.SUM, w_csr=self.w_csr, self_coef=self.self_coef,
+                              bias=bias, act=act)
+
+    def __matmul__(self, h):
+        return self.matmul(h)
+
+    def dropout(self, rate, training=False):
+        if training and rate > 0.0:
+            raise NotImplementedError("edge dropout is a training-time op; this backend is inference-only")
+        return self
+
+    def to_sparse_matrix(self):
+        """COO view in the reference's layout: input edges (CSR order) followed by the N diagonal entries."""
+        plan = self.plan
+        rows = torch.repeat_interleave(torch.arange(plan.n_dst, dtype=torch.int32, device=plan.col.device),
+                                       plan.in_degree().to(torch.int64))
+        index = torch.stack([rows, plan.col])
+        value = self.w_csr
+        if self.self_coef is not None:
+            ar = torch.arange(plan.n_dst, dtype=torch.int32, device=plan.col.device)
+            index = torch.cat([index, torch.stack([ar, ar])], dim=1)
+            value = torch.cat([value, self.self_coef])
+        return SparseMatrix(index, value, self.shape)
+
+
+def gcn_norm_adj(sparse_adj, norm="both", add_self_loop=True, sym=True, renorm=True, improved=False, cache=None):
+    """Normalised adjacency for GCN (reference: gcn.py:32-130; same arguments, same cache key)."""
+    lib = L.require_gpu()
+    if cache is not None:
+        cache_key = compute_cache_key(norm, add_self_loop, sym, renorm, improved)
+        cached = cache.get(cache_key, None)
+        if cached is not None:
+            return cached
+    if norm not in L.NORM_MODES:
+        raise Exception("wrong GCN norm type: {}".format(norm))                                   # :122
+    fill_weight = 2.0 if improved else 1.0                                                        # :62
+    if sparse_adj.shape[0] != sparse_adj.shape[1]:                                                # :65-69
+        if add_self_loop:
+            raise Exception("cannot set add_self_loop=True for GCN when sparse_adj.shape[0] != sparse_adj.shape[1]")
+        if sym:
+            raise Exception("cannot set sym=True for GCN when sparse_adj.shape[0] != sparse_adj.shape[1]")
+    plan = sparse_adj.plan
+    n = plan.n_dst
+    dev = plan.row_ptr.device
+    w = sparse_adj.value_csr if sparse_adj._has_value else None
+    if norm == "both":
+        diag = fill_weight if (add_self_loop and renorm) else 0.0                                 # :76-77
+    else:
+        diag = fill_weight if add_self_loop else 0.0                                              # :71-72
+    row_deg = torch.empty(n, dtype=torch.float32, device=dev)
+    L.check(lib.tfgx_segment_weight_sum_f32(L.ptr(plan.row_ptr), L.ptr(w), n, diag, L.ptr(row_deg), L.stream_ptr()),
+            "tfgx_segment_weight_sum_f32")
+    col_deg = None
+    if norm == "both" and not sym:                                                                # :88-91
+        tplan = plan.transposed()
+        tw = tplan.edge_attr_to_csr(sparse_adj.value) if sparse_adj._has_value else None
+        col_deg = torch.empty(tplan.n_dst, dtype=torch.float32, device=dev)
+        L.check(lib.tfgx_segment_weight_sum_f32(L.ptr(tplan.row_ptr), L.ptr(tw), tplan.n_dst, diag, L.ptr(col_deg),
+                                                L.stream_ptr()), "tfgx_segment_weight_sum_f32")
+    w_out = torch.empty(plan.num_edges, dtype=torch.float32, device=dev)
+    self_coef = torch.empty(n, dtype=torch.float32, device=dev)
+    L.check(lib.tfgx_gcn_norm_edges_f32(L.ptr(plan.row_ptr), L.ptr(plan.col), L.ptr(w), n, L.ptr(row_deg),
+                                        L.ptr(col_deg), L.NORM_MODES[norm], fill_weight, int(bool(add_self_loop)),
+                                        int(bool(renorm)), L.ptr(w_out), L.ptr(self_coef), L.stream_ptr()),
+            "tfgx_gcn_norm_edges_f32")
+    normed = NormedAdj(plan, w_out, self_coef if add_self_loop else None, list(sparse_adj.shape))
+    if cache is not None:
+        cache[cache_key] = normed                                                                 # :125-128
+    return normed
+
+
+def gcn_build_cache_by_adj(sparse_adj, norm="both", add_self_loop=True, sym=True, renorm=True, improved=False,
+                           override=False, cache=None):
+    """Reference: gcn.py:133-153."""
+    if cache is None:
+        cache = {}
+    elif override:
+        cache[compute_cache_key(norm, add_self_loop, sym, renorm, improved)] = None
+    gcn_norm_adj(sparse_adj, norm, add_self_loop, sym, renorm, improved, cache)
+    return cache
+
+
+def gcn_build_cache_for_graph(graph, norm="both", add_self_loop=True, sym=True, renorm=True, improved=False,
+                              override=False):
+    """Reference: gcn.py:156-169. `graph` needs .x/.edge_index/.edge_weight/.cache (tfg.Graph duck type)."""
+    n = int(graph.x.shape[0])
+    adj = SparseMatrix(graph.edge_index, getattr(graph, "edge_weight", None), [n, n])
+    graph.cache = gcn_build_cache_by_adj(adj, norm=norm, add_self_loop=add_self_loop, sym=sym, renorm=renorm,
+                                         improved=improved, override=override, cache=graph.cache)
+    return graph.cache
+
+
+def gcn_norm_edge(edge_index, num_nodes, edge_weight=None, renorm=True, improved=False, cache=None):
+    """Deprecated old API of the reference (gcn.py:180-197): returns (index, value) incl. the diagonal."""
+    adj = SparseMatrix(edge_index, edge_weight, [num_nodes, num_nodes])
+    normed = gcn_norm_adj(adj, renorm=renorm, improved=improved, cache=cache).to_sparse_matrix()
+    return normed.index, normed.value
+
+
+def gcn_mapper(repeated_x, neighbor_x, edge_weight=None):
+    from ..kernel.map_reduce import gcn_mapper as _m
+    return _m(repeated_x, neighbor_x, edge_weight)
+
+
+def gcn(x, sparse_adj, kernel, bias=None, activation=None, norm="both", add_self_loop=True, sym=True,
+        renorm=True, improved=False, edge_drop_rate=0.0, num_or_size_splits=None, training=False, cache=None):
+    """
+    Functional GCN (reference: gcn.py:225-290; same arguments).
+
+    :param x: [num_nodes, num_features]
+    :param sparse_adj: SparseMatrix adjacency
+    :param kernel: [num_features, num_output_features] or None (skip the GEMM, :266-267)
+    :param num_or_size_splits: accepted for compatibility; it bounds memory in the reference and never changes
+        the output (:274-280) — the fused kernel materialises nothing edge-sized.
+    :return: [num_nodes, num_output_features]
+    """
+    L.require_gpu()
+    if getattr(x, "is_sparse", False):
+        raise NotImplementedError("sparse node features are outside the hot path (gcn.py:269-270)")
+    normed = gcn_norm_adj(sparse_adj, norm=norm, add_self_loop=add_self_loop, sym=sym, renorm=renorm,
+                          improved=improved, cache=cache)                                         # :260
+    normed = normed.dropout(edge_drop_rate, training=training)                                    # :262
+    x = L.as_f32(x)
+    h = x if kernel is None else gemm_bias_act(x, kernel)                                         # :266-272
+    act, post = _resolve_act(activation)
+    bias_t = None if bias is None else L.as_f32(bias).contiguous()
+    h = normed.matmul(h, bias=bias_t, act=act)                                                    # :280-288
+    return post(h) if post is not None else h

@@ -1,0 +1,119 @@
+# coding=utf-8
+"""GraphSAGE aggregators on the HIP backend — functional mirror of tf_geometric/nn/conv/graph_sage.py
+(mean / sum / gcn / mean-pool / max-pool; the LSTM aggregator is an RNN, not a segment reduce: out of scope).
+
+Reference quirks that are reproduced on purpose:
+  * mean_pool / max_pool / gcn variants REPLACE a provided edge_weight by ones (:139-140, :190-191, :253-254) and
+    the pool variants fail for edge_weight=None (gcn_mapper(None), :197, :260);
+  * the SAME activation is applied after the pooling MLP and again at the end (:203-204 and :219-220);
+  * gcn_graph_sage passes `cache` into gcn_norm_edge's `renorm` slot (:142 vs nn/conv/gcn.py:180).
+Because the pool variants' edge weight is exactly 1.0, act(x[col] @ W + b) == act(x @ W + b)[col]: the reference's
+per-EDGE GEMM ([E,F]x[F,4ku]) is done per NODE here, followed by the gather-reduce kernel.
+"""
+import torch
+
+from ... import _lib as L
+from ...activations import resolve as _resolve_act
+from ...plan import CsrPlan, segment_reduce, gemm_bias_act, l2_normalize_rows_
+from ...sparse import SparseMatrix
+from .gcn import gcn_norm_adj
+
+
+def _combine(from_x_kernel, x, from_neigh_kernel, reduced, bias, activation, concat, normalize):
+    """concat/add of x @ self_kernel and reduced @ neighbor_kernel, + bias, activation, l2-normalise
+    (reference :43-58). With concat the two GEMMs write straight into the two halves of the output."""
+    act, post = _resolve_act(activation)
+    n = int(x.shape[0])
+    ku_x, ku_n = int(from_x_kernel.shape[1]), int(from_neigh_kernel.shape[1])
+    bias_t = None if bias is None else L.as_f32(bias).contiguous()
+    if concat:
+        h = torch.empty((n, ku_x + ku_n), dtype=torch.float32, device=x.device)
+        gemm_bias_act(x, from_x_kernel, bias=None if bias_t is None else bias_t[:ku_x], act=act, out=h[:, :ku_x])
+        gemm_bias_act(reduced, from_neigh_kernel, bias=None if bias_t is None else bias_t[ku_x:], act=act,
+                      out=h[:, ku_x:])
+    else:
+        h = gemm_bias_act(x, from_x_kernel)
+        h2 = gemm_bias_act(reduced, from_neigh_kernel)
+        h = h + h2
+        if bias_t is not None:
+            h = h + bias_t
+        if act == L.ACT_RELU:
+            h = torch.relu_(h)
+    if post is not None:
+        h = post(h)
+    if normalize:
+        h = l2_normalize_rows_(h.contiguous())
+    return h
+
+
+def _neighbor_reduce(x, edge_index, edge_weight, op, cache):
+    x = L.as_f32(x)
+    n = int(x.shape[0])
+    plan = CsrPlan.from_cache(edge_index, n, n, cache)
+    w_csr = plan.edge_attr_to_csr(edge_weight) if edge_weight is not None else None   # :38-39
+    return x, segment_reduce(plan, x, op, w_csr=w_csr)
+
+
+def mean_graph_sage(x, edge_index, edge_weight, self_kernel, neighbor_kernel, bias=None, activation=None,
+                    concat=True, normalize=False, cache=None):
+    """Reference: graph_sage.py:9-60."""
+    x, reduced = _neighbor_reduce(x, edge_index, edge_weight, L.MEAN, cache)
+    return _combine(L.as_f32(self_kernel), x, L.as_f32(neighbor_kernel), reduced, bias, activation, concat, normalize)
+
+
+def sum_graph_sage(x, edge_index, edge_weight, self_kernel, neighbor_kernel, bias=None, activation=None,
+                   concat=True, normalize=False, cache=None):
+    """Reference: graph_sage.py:64-115."""
+    x, reduced = _neighbor_reduce(x, edge_index, edge_weight, L.SUM, cache)
+    return _combine(L.as_f32(self_kernel), x, L.as_f32(neighbor_kernel), reduced, bias, activation, concat, normalize)
+
+
+def gcn_graph_sage(x, edge_index, edge_weight, kernel, bias=None, activation=None, normalize=False, cache=None):
+    """Reference: graph_sage.py:118-161 (quirks kept, see module docstring)."""
+    x = L.as_f32(x)
+    n = int(x.shape[0])
+    ei = L.as_i32(edge_index)
+    E = int(ei.shape[1])
+    if edge_weight is not None:
+        edge_weight = torch.ones(E, dtype=torch.float32, device=x.device)          # :139-140
+    renorm = bool(cache)                                                            # :142 (positional slip)
+    adj = SparseMatrix(ei, edge_weight, [n, n])
+    normed = gcn_norm_adj(adj, renorm=renorm, improved=False, cache=None)
+    reduced = normed.matmul(x)                                                      # :143-150
+    act, post = _resolve_act(activation)
+    h = gemm_bias_act(reduced, kernel, bias=bias, act=act)                          # :152-157
+    if post is not None:
+        h = post(h)
+    if normalize:
+        h = l2_normalize_rows_(h)
+    return h
+
+
+def _pool_graph_sage(x, edge_index, edge_weight, self_kernel, neighbor_mlp_kernel, neighbor_kernel,
+                     neighbor_mlp_bias, bias, activation, concat, normalize, op, cache):
+    if edge_weight is None:
+        raise TypeError("edge_weight=None is not supported by the pooling aggregators "
+                        "(gcn_mapper(None) fails in the reference, graph_sage.py:197/260)")
+    x = L.as_f32(x)
+    n = int(x.shape[0])
+    plan = CsrPlan.from_cache(edge_index, n, n, cache)
+    act, post = _resolve_act(activation)
+    h = gemm_bias_act(x, neighbor_mlp_kernel, bias=neighbor_mlp_bias, act=act)      # :199-204 per node (weight == 1)
+    if post is not None:
+        h = post(h)
+    reduced = segment_reduce(plan, h, op)                                            # :206 / :269
+    return _combine(L.as_f32(self_kernel), x, L.as_f32(neighbor_kernel), reduced, bias, activation, concat, normalize)
+
+
+def mean_pool_graph_sage(x, edge_index, edge_weight, self_kernel, neighbor_mlp_kernel, neighbor_kernel,
+                         neighbor_mlp_bias=None, bias=None, activation=None, concat=True, normalize=False, cache=None):
+    """Reference: graph_sage.py:164-225."""
+    return _pool_graph_sage(x, edge_index, edge_weight, self_kernel, neighbor_mlp_kernel, neighbor_kernel,
+                            neighbor_mlp_bias, bias, activation, concat, normalize, L.MEAN, cache)
+
+
+def max_pool_graph_sage(x, edge_index, edge_weight, self_kernel, neighbor_mlp_kernel, neighbor_kernel,
+                        neighbor_mlp_bias=None, bias=None, activation=None, concat=True, normalize=False, cache=None):
+    """Reference: graph_sage.py:228-287. An isolated node keeps float32 lowest() through the next GEMM."""
+    return _pool_graph_sage(x, edge_index, edge_weight, self_kernel, neighbor_mlp_kernel, neighbor_kernel,
+                            neighbor_mlp_bias, bias, activation, concat, normalize, L.MAX, cache)

@@ -1,0 +1,4 @@
+# coding=utf-8
+from .map_reduce import (aggregate_neighbors, identity_mapper, neighbor_count_mapper, gcn_mapper, sum_reducer,
+                         mean_reducer, max_reducer, sum_updater, identity_updater)
+from .segment import segment_softmax, segment_count

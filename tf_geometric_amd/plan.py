@@ -1,0 +1,168 @@
+# coding=utf-8
+"""CSR-by-destination plan: the per-graph state the HIP kernels run on.
+
+The reference re-scatters on every call (tf.math.unsorted_segment_*); here the edge list is bucketed once per
+graph by edge_index[0] (the aggregating node, nn/kernel/map_reduce.py:60-70) and kept in the user's ``cache``
+dict exactly like the reference keeps its normalised adjacency (nn/conv/gcn.py:125-128, data/graph.py:48).
+"""
+import ctypes
+
+import torch
+
+from . import _lib as L
+
+CACHE_KEY_PLAN = "tfgx_csr_plan"
+
+
+class CsrPlan(object):
+    """row_ptr[n_dst+1], col[E] (source per CSR position), perm[E] (CSR position -> original edge id)."""
+
+    def __init__(self, row_ptr, col, perm, n_dst, n_src, num_edges):
+        self.row_ptr = row_ptr
+        self.col = col
+        self.perm = perm
+        self.n_dst = int(n_dst)
+        self.n_src = int(n_src)
+        self.num_edges = int(num_edges)
+        self._edge_index = None   # kept only to build the transposed plan on demand (sym=False)
+        self._transposed = None
+
+    @staticmethod
+    def build(edge_index, n_dst, n_src=None):
+        lib = L.require_gpu()
+        n_src = n_dst if n_src is None else n_src
+        ei = L.as_i32(edge_index)
+        if ei.dim() != 2 or ei.shape[0] != 2:
+            if ei.numel() == 0:
+                ei = ei.reshape(2, 0)
+            else:
+                raise ValueError("edge_index must have shape [2, num_edges]")
+        E = int(ei.shape[1])
+        dev = ei.device
+        row_ptr = torch.empty(n_dst + 1, dtype=torch.int32, device=dev)
+        col = torch.empty(E, dtype=torch.int32, device=dev)
+        perm = torch.empty(E, dtype=torch.int32, device=dev)
+        ws_bytes = lib.tfgx_csr_plan_workspace_bytes(n_dst, E)
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+        rc = lib.tfgx_build_csr_by_dst(L.ptr(ei[0]), L.ptr(ei[1]), E, n_dst, n_src, L.ptr(row_ptr), L.ptr(col),
+                                       L.ptr(perm), L.ptr(ws), ws_bytes, L.stream_ptr())
+        L.check(rc, "tfgx_build_csr_by_dst")
+        plan = CsrPlan(row_ptr, col, perm, n_dst, n_src, E)
+        plan._edge_index = ei
+        return plan
+
+    @staticmethod
+    def from_cache(edge_index, n_dst, n_src=None, cache=None, key=CACHE_KEY_PLAN):
+        if cache is not None:
+            plan = cache.get(key, None)
+            if plan is not None:
+                return plan
+        plan = CsrPlan.build(edge_index, n_dst, n_src)
+        if cache is not None:
+            cache[key] = plan
+        return plan
+
+    def edge_attr_to_csr(self, attr):
+        """attr[E] or attr[E, k] in the caller's edge order -> CSR order (None stays None)."""
+        if attr is None:
+            return None
+        lib = L.require_gpu()
+        a = L.as_f32(attr).contiguous()
+        width = 1 if a.dim() == 1 else int(a.shape[1])
+        if a.shape[0] != self.num_edges:
+            raise ValueError("edge attribute has {} rows, graph has {} edges".format(a.shape[0], self.num_edges))
+        out = torch.empty_like(a)
+        L.check(lib.tfgx_permute_rows_f32(L.ptr(a), L.ptr(self.perm), self.num_edges, width, L.ptr(out),
+                                          L.stream_ptr()), "tfgx_permute_rows_f32")
+        return out
+
+    def transposed(self):
+        """Plan bucketed by edge_index[1] (column sums for sym=False, nn/conv/gcn.py:88)."""
+        if self._transposed is None:
+            ei = self._edge_index
+            self._transposed = CsrPlan.build(torch.stack([ei[1], ei[0]]), self.n_src, self.n_dst)
+        return self._transposed
+
+    def in_degree(self):
+        return (self.row_ptr[1:] - self.row_ptr[:-1])
+
+
+def segment_reduce(plan, x, op, w_csr=None, out=None, act=L.ACT_NONE, self_coef=None, bias=None, add_x=None,
+                   accumulate=False, mean_count=None, row_begin=None, row_end=None, rp_stride=1, col=None,
+                   n_dst=None):
+    """One launch of tfgx_segment_reduce_f32 on `plan` (or on explicit row_begin/row_end/col views of it)."""
+    lib = L.require_gpu()
+    x, ldx = L.row_major_2d(x)
+    F = int(x.shape[1])
+    n_dst = plan.n_dst if n_dst is None else int(n_dst)
+    if out is None:
+        out = torch.empty((n_dst, F), dtype=torch.float32, device=x.device)
+    out2, ldo = L.row_major_2d(out)
+    assert out2 is out, "out must be row-major"
+    a = L.ReduceArgs()
+    rb = plan.row_ptr if row_begin is None else row_begin
+    re = plan.row_ptr[1:] if row_end is None else row_end
+    a.row_begin = rb.data_ptr()
+    a.row_end = re.data_ptr()
+    a.rp_stride = rp_stride
+    c = plan.col if col is None else col
+    a.col = c.data_ptr()
+    a.w = 0 if w_csr is None else w_csr.data_ptr()
+    a.n_dst = n_dst
+    a.x = x.data_ptr()
+    a.ldx = ldx
+    a.F = F
+    a.out = out.data_ptr()
+    a.ldo = ldo
+    a.op = op
+    a.act = act
+    a.accumulate = 1 if accumulate else 0
+    a.self_coef = 0 if self_coef is None else self_coef.data_ptr()
+    a.bias = 0 if bias is None else bias.data_ptr()
+    if add_x is not None:
+        add_x, ld_add = L.row_major_2d(add_x)
+        a.add_x = add_x.data_ptr()
+        a.ld_add = ld_add
+    a.mean_count = 0 if mean_count is None else mean_count.data_ptr()
+    L.check(lib.tfgx_segment_reduce_f32(ctypes.byref(a), L.stream_ptr()), "tfgx_segment_reduce_f32")
+    return out
+
+
+def gemm_bias_act(a, b, bias=None, act=L.ACT_NONE, out=None):
+    """act(a @ b + bias) on the fp32 MFMA kernel."""
+    lib = L.require_gpu()
+    a, lda = L.row_major_2d(L.as_f32(a))
+    b, ldb = L.row_major_2d(L.as_f32(b))
+    M, K = int(a.shape[0]), int(a.shape[1])
+    if int(b.shape[0]) != K:
+        raise ValueError("matmul shape mismatch: {} @ {}".format(tuple(a.shape), tuple(b.shape)))
+    N = int(b.shape[1])
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    _, ldc = L.row_major_2d(out)
+    bias_t = None if bias is None else L.as_f32(bias).contiguous()
+    L.check(lib.tfgx_gemm_bias_act_f32(L.ptr(a), lda, L.ptr(b), ldb, L.ptr(bias_t), act, L.ptr(out), ldc, M, K, N,
+                                       L.stream_ptr()), "tfgx_gemm_bias_act_f32")
+    return out
+
+
+def l2_normalize_rows_(h):
+    lib = L.require_gpu()
+    h2, ld = L.row_major_2d(h)
+    assert h2 is h
+    L.check(lib.tfgx_l2_normalize_rows_f32(L.ptr(h), ld, int(h.shape[0]), int(h.shape[1]), L.stream_ptr()),
+            "tfgx_l2_normalize_rows_f32")
+    return h
+
+
+def gather_rows(x, idx, out=None):
+    lib = L.require_gpu()
+    x, ldx = L.row_major_2d(x)
+    idx = L.as_i32(idx)
+    M, F = int(idx.shape[0]), int(x.shape[1])
+    if out is None:
+        out = torch.empty((M, F), dtype=torch.float32, device=x.device)
+    _, ldo = L.row_major_2d(out)
+    L.check(lib.tfgx_gather_rows_f32(L.ptr(x), ldx, L.ptr(idx), M, F, L.ptr(out), ldo, L.stream_ptr()),
+            "tfgx_gather_rows_f32")
+    return out
