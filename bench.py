@@ -56,9 +56,9 @@ def cpu_baseline(x_np, ei_np, w_np, self_coef_np, n, f, budget_edges):
     destination rows [0, n_s) of the same graph (full source range, so the gather locality is the job's)."""
     lib_path = os.path.join(ROOT, "oracle", "libtfg_oracle.so")
     lib = ctypes.CDLL(lib_path)
-    fn = lib.tfgo_aggregate_coo_f32
+    fn = lib.tfgo_aggregate_csr_f32
     fn.restype = ctypes.c_int
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     e_total = ei_np.shape[1]
     frac = min(1.0, float(budget_edges) / max(e_total, 1))
     n_s = max(1, int(n * frac))
@@ -69,11 +69,17 @@ def cpu_baseline(x_np, ei_np, w_np, self_coef_np, n, f, budget_edges):
     w = np.ascontiguousarray(np.concatenate([w_np[keep], self_coef_np[:n_s]]))
     out = np.empty((n_s, f), dtype=np.float32)
     P = ctypes.c_void_p
+    # plan (untimed, like the GPU leg's): stable sort by destination -> row_ptr / col / w in CSR order
+    order = np.argsort(row, kind="stable")
+    col = np.ascontiguousarray(col[order])
+    w = np.ascontiguousarray(w[order])
+    row_ptr = np.zeros(n_s + 1, dtype=np.int32)
+    np.cumsum(np.bincount(row, minlength=n_s), out=row_ptr[1:])
 
     def run():
-        rc = fn(P(x_np.ctypes.data), ctypes.c_int64(f), P(row.ctypes.data), P(col.ctypes.data), P(w.ctypes.data),
-                ctypes.c_int64(row.shape[0]), ctypes.c_int64(n_s), ctypes.c_int64(n), ctypes.c_int64(f),
-                ctypes.c_int(0), P(out.ctypes.data), ctypes.c_int64(f), ctypes.c_int(cores))
+        rc = fn(P(x_np.ctypes.data), ctypes.c_int64(f), P(row_ptr.ctypes.data), P(col.ctypes.data),
+                P(w.ctypes.data), ctypes.c_int64(n_s), ctypes.c_int64(f), ctypes.c_int(0), P(out.ctypes.data),
+                ctypes.c_int64(f), ctypes.c_int(cores))
         assert rc == 0
 
     run()  # warm
@@ -86,7 +92,8 @@ def cpu_baseline(x_np, ei_np, w_np, self_coef_np, n, f, budget_edges):
     dt = (time.perf_counter() - t0) / reps
     return {"value": row.shape[0] / dt, "unit": "edges/s", "cores": cores, "kind": "port",
             "sample": "dst rows [0,{}) of the same graph: {} edges x F={} , full source range, {:.2f} s per pass, "
-                      "tfgo_aggregate_coo_f32 (OpenMP, {} threads)".format(n_s, int(row.shape[0]), f, dt, cores)}, out, n_s
+                      "tfgo_aggregate_csr_f32 (row-sorted edges, OpenMP, {} threads; sort untimed)".format(
+                          n_s, int(row.shape[0]), f, dt, cores)}, out, n_s
 
 
 def main():
@@ -204,8 +211,17 @@ def main():
                             "frac": achieved / HBM_PEAK, "traffic": None,
                             "algorithmic_bytes_per_launch": bytes_alg, "kernel_ms": ev_ms,
                             "bytes_per_edge": 4 * f + 8}
+        # HBM-side bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE;
+        # see profiles/): a property of kernel + workload, cannot be sampled from inside this process.
+        pmc_path = os.path.join(ROOT, "profiles", "r01_{}_pmc.json".format(args.workload))
+        if os.path.exists(pmc_path):
+            with open(pmc_path) as fh:
+                pmc = json.load(fh)
+            line["roofline"]["traffic"] = pmc["traffic_bytes_per_launch"]
+            line["roofline"]["traffic_source"] = "profiles/" + os.path.basename(pmc_path)
+            line["roofline"]["traffic_GBps"] = pmc["traffic_bytes_per_launch"] / (ev_ms * 1e-3) / 1e9
         if not args.no_cpu_baseline:
-            budget = {"products": 24_000_000}.get(args.workload, e)
+            budget = {"products": 61_500_000}.get(args.workload, e)
             base, cpu_out, n_s = cpu_baseline(x_np, ei_np, normed_w_host(normed, ei_np, n),
                                               normed.self_coef.cpu().numpy(), n, f, budget)
             line["cpu_baseline"] = base

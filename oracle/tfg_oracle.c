@@ -128,3 +128,51 @@ void tfgo_gemm_f32(const float* a, const float* b, const float* bias, int64_t M,
         }
     }
 }
+
+/*
+ * Strong multi-core CPU baseline for bench.py: the same arithmetic (gather, * w, segment-sum/mean/max in edge
+ * order per destination) over a row-sorted (CSR-by-destination) edge list, destination ranges balanced by edge
+ * count across threads.  The sort is done once by the caller and not timed — exactly like the GPU plan.
+ */
+int tfgo_aggregate_csr_f32(const float* x, int64_t ldx, const int32_t* row_ptr, const int32_t* col,
+                           const float* w /* may be NULL */, int64_t n_dst, int64_t F, int op, float* out,
+                           int64_t ldo, int threads)
+{
+    if (threads < 1) threads = 1;
+    const int64_t E = row_ptr[n_dst];
+#pragma omp parallel num_threads(threads)
+    {
+#ifdef _OPENMP
+        const int t = omp_get_thread_num(), T = omp_get_num_threads();
+#else
+        const int t = 0, T = 1;
+#endif
+        /* first row whose start offset >= t*E/T (binary search) */
+        int64_t bounds[2];
+        for (int k = 0; k < 2; ++k) {
+            const int64_t target = E * (t + k) / T;
+            int64_t lo = 0, hi = n_dst;
+            if (t + k == T) lo = n_dst;
+            else while (lo < hi) { int64_t mid = (lo + hi) / 2; if (row_ptr[mid] < target) lo = mid + 1; else hi = mid; }
+            bounds[k] = (t + k == 0) ? 0 : lo;
+        }
+        for (int64_t r = bounds[0]; r < bounds[1]; ++r) {
+            float* o = out + r * ldo;
+            const float init = (op == TFGO_MAX) ? -FLT_MAX : 0.0f;
+            for (int64_t f = 0; f < F; ++f) o[f] = init;
+            for (int64_t i = row_ptr[r]; i < row_ptr[r + 1]; ++i) {
+                const float* xs = x + (int64_t)col[i] * ldx;
+                const float we = w ? w[i] : 1.0f;
+                if (op == TFGO_MAX) { for (int64_t f = 0; f < F; ++f) { float m = w ? xs[f] * we : xs[f]; o[f] = m > o[f] ? m : o[f]; } }
+                else if (w) { for (int64_t f = 0; f < F; ++f) o[f] += xs[f] * we; }
+                else { for (int64_t f = 0; f < F; ++f) o[f] += xs[f]; }
+            }
+            if (op == TFGO_MEAN) {
+                const int64_t c = row_ptr[r + 1] - row_ptr[r];
+                const float d = (float)(c > 1 ? c : 1);
+                for (int64_t f = 0; f < F; ++f) o[f] /= d;
+            }
+        }
+    }
+    return 0;
+}

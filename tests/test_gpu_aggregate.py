@@ -87,16 +87,21 @@ def test_hub_row_and_ragged_degrees(tfg, oracle):
     rest = oracle.synthetic_edges(n, 8000, seed=2)
     ei = np.concatenate([np.stack([np.full_like(hub_src, 17), hub_src]), rest], axis=1).astype(np.int32)
     w = rng.uniform(0.5, 1.5, size=ei.shape[1]).astype(np.float32)
+    deg = np.bincount(ei[0], minlength=n).astype(np.float64)
     for red in ["sum", "mean", "max"]:
         got = tfg.nn.aggregate_neighbors(x, ei, w, tfg.nn.gcn_mapper, getattr(tfg.nn, red + "_reducer"),
                                          tfg.nn.identity_updater).cpu().numpy()
         ref = oracle.aggregate_neighbors(x, ei, w, oracle.gcn_mapper, getattr(oracle, red + "_reducer"),
                                          oracle.identity_updater)
-        # a 20k-term fp32 sum carries ~sqrt(20000)*eps relative error: judge it against the sum of magnitudes
-        scale = 1.0 if red != "sum" else 1.0
-        err = np.abs(got - ref)
-        bound = 1e-5 + 1e-5 * np.abs(ref) + (2e-7 * np.abs(x).max() * 1.5 * 150 if red == "sum" else 0.0) * scale
-        assert (err <= bound).all(), red
+        # fp32 accumulation of d terms of rms size s carries a random-walk rounding error of about eps*d*s/2 in the
+        # SUM (any fp32 implementation, TF-CPU included): the 1e-5 bar is widened by that term for the hub row only.
+        extra = np.zeros((n, 1))
+        if red in ("sum", "mean"):
+            extra = (6e-8 * deg * 1.5 * (1.0 if red == "sum" else 1.0 / np.maximum(deg, 1)))[:, None]
+            extra[deg < 512] = 0.0
+        err = np.abs(got.astype(np.float64) - ref)
+        bound = 1e-5 + 1e-5 * np.abs(ref) + extra
+        assert (err <= bound).all(), "{}: worst excess {:.3e}".format(red, float((err - bound).max()))
 
 
 def test_edge_order_permutation_invariance(tfg, oracle):
