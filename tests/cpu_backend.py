@@ -1,0 +1,144 @@
+# coding=utf-8
+"""numpy stand-in for tf_geometric_amd.dist.sharded.HipBackend — TEST INFRASTRUCTURE.
+
+Lets the world_size-2 gloo tests exercise the sharding / halo-exchange ORCHESTRATION (partitioning, exchange
+lists, two-pass accumulate, sharded GCN normalisation) on CPU.  Each method restates the contract of the C-ABI
+entry point its HIP twin calls (include/tfgx.h); arithmetic is float64-accumulated like oracle/tfg_oracle.py.
+"""
+import numpy as np
+import torch
+
+SUM, MEAN, MAX = 0, 1, 2
+FLT_LOWEST = np.float32(-3.4028234663852886e38)
+
+
+def _np(t):
+    return None if t is None else t.detach().cpu().numpy()
+
+
+class NumpyBackend(object):
+    name = "numpy-test"
+    device = torch.device("cpu")
+
+    def i32(self, a):
+        a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+        return torch.from_numpy(np.ascontiguousarray(a.astype(np.int32)))
+
+    def f32(self, a):
+        a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+        return torch.from_numpy(np.ascontiguousarray(a.astype(np.float32)))
+
+    def empty(self, shape, dtype=torch.float32):
+        return torch.zeros(shape, dtype=dtype)
+
+    def build_csr(self, edge_index, n_dst, n_src):
+        ei = _np(edge_index).reshape(2, -1)
+        assert ei.size == 0 or (ei[0].min() >= 0 and ei[0].max() < n_dst and ei[1].min() >= 0 and ei[1].max() < n_src)
+        perm = np.argsort(ei[0], kind="stable").astype(np.int32)
+        row_ptr = np.zeros(n_dst + 1, dtype=np.int32)
+        np.cumsum(np.bincount(ei[0], minlength=n_dst), out=row_ptr[1:])
+        return torch.from_numpy(row_ptr), torch.from_numpy(ei[1][perm].astype(np.int32)), torch.from_numpy(perm)
+
+    def permute_rows(self, attr, perm):
+        return self.f32(_np(self.f32(attr))[_np(perm)])
+
+    def halo_plan(self, col, own_lo, own_hi, n_global):
+        c = _np(col)
+        remote = (c < own_lo) | (c >= own_hi)
+        ids = np.unique(c[remote]).astype(np.int32)
+        col_local = np.where(remote, (own_hi - own_lo) + np.searchsorted(ids, c), c - own_lo).astype(np.int32)
+        return torch.from_numpy(ids), torch.from_numpy(col_local)
+
+    def split_local_halo(self, row_ptr, col_local, w, n_own):
+        rp, c, wv = _np(row_ptr), _np(col_local), _np(w)
+        n = rp.shape[0] - 1
+        rp2 = np.zeros(2 * n + 1, dtype=np.int32)
+        c2 = np.empty_like(c)
+        w2 = None if wv is None else np.empty_like(wv)
+        for r in range(n):
+            s, e = rp[r], rp[r + 1]
+            loc = c[s:e] < n_own
+            order = np.concatenate([np.flatnonzero(loc), np.flatnonzero(~loc)]) + s
+            c2[s:e] = c[order]
+            if w2 is not None:
+                w2[s:e] = wv[order]
+            rp2[2 * r], rp2[2 * r + 1] = s, s + int(loc.sum())
+        rp2[2 * n] = rp[n]
+        return torch.from_numpy(rp2), torch.from_numpy(c2), None if w2 is None else torch.from_numpy(w2)
+
+    def gather_rows(self, x, idx, out=None):
+        res = x[idx.long()]
+        if out is not None:
+            out.copy_(res)
+            return out
+        return res.contiguous()
+
+    def segment_reduce(self, row_begin, row_end, rp_stride, col, w, n_dst, x, out, op, act=0, accumulate=False,
+                       self_coef=None, bias=None, mean_count=None):
+        rb, re, c, wv, xv = _np(row_begin), _np(row_end), _np(col), _np(w), _np(x).astype(np.float64)
+        o = _np(out)
+        for r in range(n_dst):
+            s, e = int(rb[r * rp_stride]), int(re[r * rp_stride])
+            msg = xv[c[s:e]]
+            if wv is not None:
+                msg = msg * wv[s:e, None].astype(np.float64)
+            if op == MAX:
+                acc = msg.max(axis=0) if e > s else np.full(xv.shape[1], FLT_LOWEST, np.float64)
+                if accumulate:
+                    acc = np.maximum(acc, o[r])
+                if self_coef is not None:
+                    acc = np.maximum(acc, float(self_coef[r]) * xv[r])
+            else:
+                acc = msg.sum(axis=0)
+                if accumulate:
+                    acc = acc + o[r]
+                if self_coef is not None:
+                    acc = acc + float(self_coef[r]) * xv[r]
+                if op == MEAN:
+                    cnt = int(mean_count[r]) if mean_count is not None else (e - s)
+                    acc = acc / max(cnt, 1)
+            if bias is not None:
+                acc = acc + _np(bias)
+            if act == 1:
+                acc = np.maximum(acc, 0)
+            o[r] = acc.astype(np.float32)
+        return out
+
+    def weight_sum(self, row_ptr, w, n, diag):
+        rp, wv = _np(row_ptr), _np(w)
+        deg = np.array([(wv[rp[r]:rp[r + 1]].astype(np.float64).sum() if wv is not None else rp[r + 1] - rp[r]) + diag
+                        for r in range(n)], dtype=np.float32)
+        return torch.from_numpy(deg)
+
+    def gcn_norm_edges(self, row_ptr, col, w, n, row_deg, mode, fill, add_self_loop, renorm):
+        rp, c, wv, deg = _np(row_ptr), _np(col), _np(w), _np(row_deg).astype(np.float64)
+        E = c.shape[0]
+        wv = np.ones(E, np.float64) if wv is None else wv.astype(np.float64)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            p = np.power(deg, -0.5 if mode == 0 else -1.0)
+        p = np.where(np.isfinite(p), p, 0.0)
+        rows = np.repeat(np.arange(n), np.diff(rp))
+        if mode == 0:
+            w_out = p[rows] * wv * p[c]
+            sc = (p[:n] * fill * p[:n]) if renorm else np.full(n, fill)
+        elif mode == 1:
+            w_out = p[rows] * wv
+            sc = p[:n] * fill
+        else:
+            w_out = wv * p[c]
+            sc = fill * p[:n]
+        if not add_self_loop:
+            sc = np.zeros(n)
+        return torch.from_numpy(w_out.astype(np.float32)), torch.from_numpy(sc.astype(np.float32))
+
+    def gemm_bias_act(self, a, b, bias=None, act=0, out=None):
+        res = _np(a).astype(np.float64) @ _np(self.f32(b)).astype(np.float64)
+        if bias is not None:
+            res = res + _np(bias)
+        if act == 1:
+            res = np.maximum(res, 0)
+        res = torch.from_numpy(res.astype(np.float32))
+        if out is not None:
+            out.copy_(res)
+            return out
+        return res

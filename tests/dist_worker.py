@@ -1,0 +1,101 @@
+# coding=utf-8
+"""Worker for the multi-process sharding tests (spawned by test_dist_gloo.py / test_gpu_dist.py)."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def make_inputs(n=400, e=5000, f=12, seed=0, skew=False):
+    from oracle import tfg_oracle as oracle
+    ei = oracle.synthetic_edges(n, e, seed=seed)
+    if skew:   # make the split points uneven: many edges into the first rows, some rows with no in-edges
+        rng = np.random.Generator(np.random.PCG64(seed + 5))
+        extra = np.stack([rng.integers(0, 20, size=e // 2, dtype=np.int32), rng.integers(0, n, size=e // 2, dtype=np.int32)])
+        ei = np.concatenate([ei, extra], axis=1)
+        ei = ei[:, ei[0] % 7 != 3]
+    rng = np.random.Generator(np.random.PCG64(seed + 1))
+    x = rng.standard_normal((n, f), dtype=np.float32)
+    w = rng.uniform(0.5, 1.5, size=ei.shape[1]).astype(np.float32)
+    k = oracle.glorot_uniform(rng, f, 10)
+    b = (rng.standard_normal(10) * 0.1).astype(np.float32)
+    return ei, x, w, k, b
+
+
+def run_checks(rank, world, use_gpu, skew, results):
+    """Build the shard, run sharded GCN / mean / max / sum and return this rank's rows (as numpy)."""
+    from tf_geometric_amd.dist.sharded import ShardedGraph
+    ei, x, w, k, b = make_inputs(skew=skew)
+    n = x.shape[0]
+    if use_gpu:
+        backend = None
+    else:
+        from cpu_backend import NumpyBackend
+        backend = NumpyBackend()
+    group = dist.group.WORLD if dist.is_initialized() else None
+    sg = ShardedGraph.from_global(ei, n, edge_weight=w, group=group, backend=backend)
+    be = sg.backend
+    x_own = be.f32(x[sg.own_lo:sg.own_hi])
+    out = {"lo": sg.own_lo, "hi": sg.own_hi, "edges": sg.num_edges, "n_halo": sg.n_halo}
+    sg.build_gcn_norm()
+    out["gcn"] = sg.gcn(x_own, be.f32(k), bias=be.f32(b), act=1).cpu().numpy()
+    out["gcn_nokernel"] = sg.gcn(x_own, None).cpu().numpy()
+    out["mean"] = sg.neighbor_reduce(x_own, 1).cpu().numpy()
+    out["max"] = sg.neighbor_reduce(x_own, 2).cpu().numpy()
+    out["sum_unweighted"] = sg.neighbor_reduce(x_own, 0, weighted=False).cpu().numpy()
+    sg2 = ShardedGraph.from_global(ei, n, edge_weight=None, group=group, backend=backend)
+    sg2.build_gcn_norm(norm="left", improved=True)
+    out["gcn_left_improved_unweighted"] = sg2.gcn(x_own, be.f32(k)).cpu().numpy()
+    results[rank] = out
+    return out
+
+
+def _entry(rank, world, port, use_gpu, skew, path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if use_gpu:
+        torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    res = {}
+    run_checks(rank, world, use_gpu, skew, res)
+    np.save(os.path.join(path, "rank{}.npy".format(rank)), np.array([res[rank]], dtype=object), allow_pickle=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def spawn(world, use_gpu, skew, path, port):
+    import torch.multiprocessing as mp
+    mp.spawn(_entry, args=(world, port, use_gpu, skew, path), nprocs=world, join=True)
+    return [np.load(os.path.join(path, "rank{}.npy".format(r)), allow_pickle=True)[0] for r in range(world)]
+
+
+def reference(skew):
+    from oracle import tfg_oracle as oracle
+    ei, x, w, k, b = make_inputs(skew=skew)
+    return {
+        "gcn": oracle.gcn(x, ei, w, k, b, "relu"),
+        "gcn_nokernel": oracle.gcn(x, ei, w, None),
+        "mean": oracle.aggregate_neighbors(x, ei, w, oracle.gcn_mapper, oracle.mean_reducer, oracle.identity_updater),
+        "max": oracle.aggregate_neighbors(x, ei, w, oracle.gcn_mapper, oracle.max_reducer, oracle.identity_updater),
+        "sum_unweighted": oracle.aggregate_neighbors(x, ei, None, oracle.identity_mapper, oracle.sum_reducer,
+                                                     oracle.identity_updater),
+        "gcn_left_improved_unweighted": oracle.gcn(x, ei, None, k, norm="left", improved=True),
+    }
+
+
+def check_against_reference(parts, skew, assert_parity):
+    ref = reference(skew)
+    parts = sorted(parts, key=lambda p: p["lo"])
+    assert parts[0]["lo"] == 0 and all(a["hi"] == b["lo"] for a, b in zip(parts, parts[1:]))
+    for key, full in ref.items():
+        got = np.concatenate([p[key] for p in parts], axis=0)
+        assert_parity(got, full, what="sharded " + key)
+    return parts

@@ -1,0 +1,134 @@
+# coding=utf-8
+"""The C-ABI library loads (no GPU needed) and exports every symbol include/tfgx.h declares; the ctypes structs
+match the header's structs; host-side argument checks fire; the product path refuses to run without a GPU."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+
+HEADER = os.path.join(ROOT, "include", "tfgx.h")
+
+
+def _declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(tfgx_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from tf_geometric_amd import _lib
+    lib = _lib.load_library()
+    names = _declared_functions()
+    assert len(names) >= 19
+    for name in names:
+        assert hasattr(lib, name), "libtfgx.so does not export {}".format(name)
+    assert set(names) == set(_lib.SIGNATURES), "ctypes table and header disagree: {}".format(
+        set(names) ^ set(_lib.SIGNATURES))
+    assert lib.tfgx_version() >= 100
+
+
+def test_structs_match_header_layout(tmp_path):
+    """Compile a tiny C program against include/tfgx.h and compare sizeof/offsetof with the ctypes mirrors."""
+    from tf_geometric_amd import _lib
+    src = tmp_path / "layout.c"
+    fields_r = [f for f, _ in _lib.ReduceArgs._fields_]
+    fields_g = [f for f, _ in _lib.GatArgs._fields_]
+    body = ['#include <stdio.h>', '#include <stddef.h>', '#include "tfgx.h"', 'int main(void){',
+            'printf("%zu\\n", sizeof(tfgx_reduce_args));']
+    body += ['printf("%zu\\n", offsetof(tfgx_reduce_args, {}));'.format(f) for f in fields_r]
+    body += ['printf("%zu\\n", sizeof(tfgx_gat_args));']
+    body += ['printf("%zu\\n", offsetof(tfgx_gat_args, {}));'.format(f) for f in fields_g]
+    body += ['return 0;}']
+    src.write_text("\n".join(body))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    vals = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    assert vals[0] == ctypes.sizeof(_lib.ReduceArgs)
+    for f, off in zip(fields_r, vals[1:1 + len(fields_r)]):
+        assert getattr(_lib.ReduceArgs, f).offset == off, f
+    rest = vals[1 + len(fields_r):]
+    assert rest[0] == ctypes.sizeof(_lib.GatArgs)
+    for f, off in zip(fields_g, rest[1:]):
+        assert getattr(_lib.GatArgs, f).offset == off, f
+
+
+def test_argument_validation_without_gpu():
+    """Host-side checks return TFGX_ERR_INVALID_ARG before anything touches a device."""
+    from tf_geometric_amd import _lib
+    lib = _lib.load_library()
+    assert lib.tfgx_segment_reduce_f32(None, None) == 1
+    assert b"args is null" in lib.tfgx_last_error()
+    a = _lib.ReduceArgs()
+    a.n_dst, a.F, a.op = 4, 0, 0
+    assert lib.tfgx_segment_reduce_f32(ctypes.byref(a), None) == 1
+    a.F, a.op = 8, 7
+    assert lib.tfgx_segment_reduce_f32(ctypes.byref(a), None) == 1 and b"bad op" in lib.tfgx_last_error()
+    assert lib.tfgx_gemm_bias_act_f32(None, 4, None, 4, None, 0, None, 4, 2, 0, 4, None) == 1
+    assert lib.tfgx_gcn_norm_edges_f32(None, None, None, 3, None, None, 9, 1.0, 1, 1, None, None, None) == 1
+    assert lib.tfgx_csr_plan_workspace_bytes(10, 100) > 800
+    assert lib.tfgx_build_csr_by_dst(None, None, -1, 3, 3, None, None, None, None, 0, None) == 1
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
+def test_product_path_fails_loudly_without_gpu():
+    import tf_geometric_amd as tfg
+    x = np.ones((4, 3), np.float32)
+    ei = np.array([[0, 1], [1, 0]], np.int32)
+    with pytest.raises(tfg._lib.TfgxError):
+        tfg.nn.aggregate_neighbors(x, ei, None)
+    with pytest.raises(tfg._lib.TfgxError):
+        tfg.layers.GCN(4)([x, ei])
+    with pytest.raises(tfg._lib.TfgxError):
+        tfg.layers.GAT(4)([x, ei])
+    with pytest.raises(tfg._lib.TfgxError):
+        tfg.layers.MeanGraphSage(4)([x, ei])
+    with pytest.raises(tfg._lib.TfgxError):
+        tfg.SparseMatrix(ei, None, [4, 4]) @ x
+
+
+def test_product_never_imports_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch oracle/."""
+    pkg = os.path.join(ROOT, "tf_geometric_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(dirpath, fn)).read()
+                assert "oracle" not in text.replace("oracle/", "ORACLE_PATH_IN_COMMENT").replace(
+                    "the oracle", "").replace("CPU oracle", "") or "import" not in "".join(
+                    l for l in text.splitlines() if "oracle" in l and "import" in l), fn
+                for line in text.splitlines():
+                    assert not re.match(r"\s*(from|import)\s+oracle", line), "{} imports oracle".format(fn)
+                    assert "libtfg_oracle" not in line, "{} links the oracle".format(fn)
+
+
+def test_activation_resolution_and_layer_contract():
+    import tf_geometric_amd as tfg
+    from tf_geometric_amd.activations import resolve
+    assert resolve(None) == (0, None) and resolve("relu") == (1, None) and resolve(tfg.relu) == (1, None)
+    assert resolve(torch.relu) == (1, None)
+    code, post = resolve(torch.tanh)
+    assert code == 0 and post is torch.tanh
+    with pytest.raises(ValueError):
+        resolve("gelu")
+    with pytest.raises(Exception):
+        tfg.layers.GCN(4, num_splits=2, num_or_size_splits=2)                 # layers/conv/gcn.py:82-83
+    with pytest.raises(Exception):
+        tfg.layers.MeanGraphSage(5, concat=True)                              # layers/conv/graph_sage.py:36-37
+    from tf_geometric_amd.nn.conv.gcn import compute_cache_key
+    assert compute_cache_key("both", True, True, True, False) == "gcn_normed_adj_both_True_True_True_False"
+
+
+def test_synthetic_inputs_are_reproducible():
+    from tf_geometric_amd import synthetic
+    a = synthetic.synthetic_edges(1000, 5000, seed=0)
+    b = synthetic.synthetic_edges(1000, 5000, seed=0)
+    assert np.array_equal(a, b) and a.dtype == np.int32 and a.shape[0] == 2
+    half = a.shape[1] // 2
+    assert np.array_equal(a[0, :half], a[1, half:]) and np.array_equal(a[1, :half], a[0, half:])   # (a,b) then (b,a)
+    assert (a[0] != a[1]).all()

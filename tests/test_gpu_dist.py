@@ -1,0 +1,25 @@
+# coding=utf-8
+"""Sharded path with the HIP backend on the GPU box: world_size 1 in-process, and world_size 2 as two processes that
+share cuda:0 with a gloo group (rows staged through the host) — the kernels and the plan code are the product's,
+only the transport differs from the RCCL path the 8-GPU bench uses."""
+import random
+
+import pytest
+
+from conftest import assert_parity
+import dist_worker
+
+pytestmark = pytest.mark.gpu
+
+
+def test_sharded_world1_hip(tfg):
+    res = {}
+    dist_worker.run_checks(0, 1, use_gpu=True, skew=True, results=res)
+    dist_worker.check_against_reference([res[0]], True, assert_parity)
+
+
+@pytest.mark.parametrize("skew", [False, True])
+def test_sharded_world2_hip_gloo_transport(tfg, tmp_path, skew):
+    port = 31500 + random.randint(0, 2000)
+    parts = dist_worker.spawn(2, use_gpu=True, skew=skew, path=str(tmp_path), port=port)
+    dist_worker.check_against_reference(parts, skew, assert_parity)

@@ -111,6 +111,7 @@ def require_gpu():
 
 
 def device():
+    require_gpu()
     return torch.device("cuda", torch.cuda.current_device())
 
 

@@ -1,0 +1,345 @@
+# coding=utf-8
+"""Destination-range sharding of ONE large graph over the GPUs of a node, with halo exchange.
+
+The reference has nothing like this: its two "distributed" demos replicate the whole graph on every GPU and only
+all-reduce gradients (demo/demo_distributed_gcn.py:38-57).  Here aggregation is sharded where it is independent —
+per destination node:
+
+  * rank g owns a contiguous destination range [lo_g, hi_g), split points chosen on the global row_ptr so that
+    EDGES (not nodes) are balanced; it owns those rows of x, their CSR rows and the output rows;
+  * a rank's sources are its own rows plus a "halo": the sorted, de-duplicated remote rows its edges reference.
+    The local source table is [own rows | halo rows], and col is remapped into it once (plan time);
+  * per layer ONE all-to-all-v moves halo rows (RCCL over xGMI: every GPU pair has its own link, so the
+    personalised exchange uses all 7 links at once — unlike a ring all-reduce);
+  * the exchange runs asynchronously while the LOCAL-source edges are aggregated; the HALO-source edges are then
+    accumulated into the same output rows (tfgx_reduce_args.accumulate) and the epilogue (self-loop term, mean
+    divisor, bias, activation) is applied once, in that second pass.
+
+Compute goes through a backend object whose methods map 1:1 onto C-ABI entry points (HipBackend, the default
+and the only one in this package).  tests/ injects a numpy backend to exercise THIS file's orchestration with
+world_size-2 gloo process groups on CPU; the product path never does.
+"""
+import ctypes
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .. import _lib as L
+
+
+class HipBackend(object):
+    """Thin adapter: every method is one (or a fixed short sequence of) C-ABI call(s) on the current HIP stream."""
+    name = "hip"
+
+    def __init__(self):
+        self.lib = L.require_gpu()
+        self.device = L.device()
+
+    # ---- memory
+    def i32(self, a):
+        return L.as_i32(a, self.device)
+
+    def f32(self, a):
+        return L.as_f32(a, self.device)
+
+    def empty(self, shape, dtype=torch.float32):
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    # ---- plan
+    def build_csr(self, edge_index, n_dst, n_src):
+        from ..plan import CsrPlan
+        p = CsrPlan.build(edge_index, n_dst, n_src)
+        return p.row_ptr, p.col, p.perm
+
+    def permute_rows(self, attr, perm):
+        a = self.f32(attr).contiguous()
+        out = torch.empty_like(a)
+        width = 1 if a.dim() == 1 else int(a.shape[1])
+        L.check(self.lib.tfgx_permute_rows_f32(L.ptr(a), L.ptr(perm), int(perm.shape[0]), width, L.ptr(out),
+                                               L.stream_ptr()), "tfgx_permute_rows_f32")
+        return out
+
+    def halo_plan(self, col, own_lo, own_hi, n_global):
+        """-> (halo_ids sorted int32 [n_halo], col_local int32 [E])."""
+        E = int(col.shape[0])
+        flags = self.empty(max(n_global, 1), torch.int32)
+        pos = self.empty(max(n_global, 1), torch.int32)
+        ids = self.empty(max(n_global, 1), torch.int32)
+        n_halo = torch.zeros(1, dtype=torch.int32, device=self.device)
+        ws_bytes = self.lib.tfgx_halo_workspace_bytes(n_global)
+        ws = self.empty(max(ws_bytes, 1), torch.uint8)
+        L.check(self.lib.tfgx_halo_mark(L.ptr(col), E, own_lo, own_hi, n_global, L.ptr(flags), L.stream_ptr()),
+                "tfgx_halo_mark")
+        L.check(self.lib.tfgx_halo_compact(L.ptr(flags), n_global, L.ptr(pos), L.ptr(ids), L.ptr(n_halo), L.ptr(ws),
+                                           ws_bytes, L.stream_ptr()), "tfgx_halo_compact")
+        col_local = self.empty(E, torch.int32)
+        L.check(self.lib.tfgx_halo_remap_cols(L.ptr(col), E, own_lo, own_hi, L.ptr(pos), own_hi - own_lo,
+                                              L.ptr(col_local), L.stream_ptr()), "tfgx_halo_remap_cols")
+        k = int(n_halo.item())
+        return ids[:k].clone(), col_local
+
+    def split_local_halo(self, row_ptr, col_local, w, n_own):
+        n_dst, E = int(row_ptr.shape[0]) - 1, int(col_local.shape[0])
+        rp2 = self.empty(2 * n_dst + 1, torch.int32)
+        col2 = torch.empty_like(col_local)
+        w2 = None if w is None else torch.empty_like(w)
+        L.check(self.lib.tfgx_split_local_halo(L.ptr(row_ptr), L.ptr(col_local), L.ptr(w), n_dst, E, n_own,
+                                               L.ptr(rp2), L.ptr(col2), L.ptr(w2), L.stream_ptr()),
+                "tfgx_split_local_halo")
+        return rp2, col2, w2
+
+    # ---- compute
+    def gather_rows(self, x, idx, out=None):
+        from ..plan import gather_rows
+        return gather_rows(x, idx, out=out)
+
+    def segment_reduce(self, row_begin, row_end, rp_stride, col, w, n_dst, x, out, op, act=L.ACT_NONE,
+                       accumulate=False, self_coef=None, bias=None, mean_count=None):
+        x, ldx = L.row_major_2d(x)
+        _, ldo = L.row_major_2d(out)
+        a = L.ReduceArgs()
+        a.row_begin, a.row_end, a.rp_stride = row_begin.data_ptr(), row_end.data_ptr(), rp_stride
+        a.col = col.data_ptr()
+        a.w = 0 if w is None else w.data_ptr()
+        a.n_dst = n_dst
+        a.x, a.ldx, a.F = x.data_ptr(), ldx, int(x.shape[1])
+        a.out, a.ldo = out.data_ptr(), ldo
+        a.op, a.act, a.accumulate = op, act, 1 if accumulate else 0
+        a.self_coef = 0 if self_coef is None else self_coef.data_ptr()
+        a.bias = 0 if bias is None else bias.data_ptr()
+        a.mean_count = 0 if mean_count is None else mean_count.data_ptr()
+        L.check(self.lib.tfgx_segment_reduce_f32(ctypes.byref(a), L.stream_ptr()), "tfgx_segment_reduce_f32")
+        return out
+
+    def weight_sum(self, row_ptr, w, n, diag):
+        deg = self.empty(n)
+        L.check(self.lib.tfgx_segment_weight_sum_f32(L.ptr(row_ptr), L.ptr(w), n, float(diag), L.ptr(deg),
+                                                     L.stream_ptr()), "tfgx_segment_weight_sum_f32")
+        return deg
+
+    def gcn_norm_edges(self, row_ptr, col, w, n, row_deg, mode, fill, add_self_loop, renorm):
+        E = int(col.shape[0])
+        w_out, self_coef = self.empty(E), self.empty(n)
+        L.check(self.lib.tfgx_gcn_norm_edges_f32(L.ptr(row_ptr), L.ptr(col), L.ptr(w), n, L.ptr(row_deg), None, mode,
+                                                 float(fill), int(add_self_loop), int(renorm), L.ptr(w_out),
+                                                 L.ptr(self_coef), L.stream_ptr()), "tfgx_gcn_norm_edges_f32")
+        return w_out, self_coef
+
+    def gemm_bias_act(self, a, b, bias=None, act=L.ACT_NONE, out=None):
+        from ..plan import gemm_bias_act
+        return gemm_bias_act(a, b, bias=bias, act=act, out=out)
+
+
+def edge_balanced_bounds(row_ptr_host, world):
+    """Split points on the global row_ptr so that each rank gets ~E/world edges. -> int64 [world+1] node ids."""
+    rp = np.asarray(row_ptr_host, dtype=np.int64)
+    n = rp.shape[0] - 1
+    E = int(rp[-1])
+    bounds = np.zeros(world + 1, dtype=np.int64)
+    bounds[world] = n
+    for k in range(1, world):
+        bounds[k] = int(np.searchsorted(rp, (E * k) // world, side="left"))
+    bounds = np.minimum(np.maximum.accumulate(bounds), n)
+    if E == 0:      # no edges: balance nodes
+        bounds = (np.arange(world + 1, dtype=np.int64) * n) // world
+    return bounds
+
+
+class ShardedGraph(object):
+    """One rank's shard: destination rows [own_lo, own_hi) of a global graph, plus its halo plan."""
+
+    def __init__(self):
+        self.backend = None
+        self.group = None
+        self.rank = 0
+        self.world = 1
+
+    # ------------------------------------------------------------------ construction
+    @staticmethod
+    def from_global(edge_index, num_nodes, edge_weight=None, group=None, backend=None):
+        """Every rank passes the SAME global edge_index [2, E] (and optional edge_weight [E]); each keeps its
+        slice.  (A rank-local constructor only needs steps 3+ and is the natural follow-up for graphs that do
+        not fit one host.)"""
+        self = ShardedGraph()
+        be = self.backend = backend or HipBackend()
+        self.group = group
+        self.world = dist.get_world_size(group) if (group is not None or dist.is_initialized()) else 1
+        self.rank = dist.get_rank(group) if (group is not None or dist.is_initialized()) else 0
+        self.n_global = int(num_nodes)
+
+        # 1. global CSR-by-destination (identical on every rank: stable sort of identical input)
+        ei = be.i32(edge_index)
+        if ei.numel() == 0:
+            ei = ei.reshape(2, 0)
+        row_ptr, col, perm = be.build_csr(ei, self.n_global, self.n_global)
+        w_csr = None if edge_weight is None else be.permute_rows(edge_weight, perm)
+
+        # 2. edge-balanced split points
+        rp_host = row_ptr.cpu().numpy()
+        self.bounds = edge_balanced_bounds(rp_host, self.world)
+        lo, hi = int(self.bounds[self.rank]), int(self.bounds[self.rank + 1])
+        self.own_lo, self.own_hi, self.n_own = lo, hi, hi - lo
+
+        # 3. my slice of the CSR
+        e0, e1 = int(rp_host[lo]), int(rp_host[hi])
+        self.num_edges = e1 - e0
+        self.num_edges_global = int(rp_host[-1])
+        self.row_ptr = (row_ptr[lo:hi + 1] - e0).contiguous()
+        col_slice = col[e0:e1].contiguous()
+        w_slice = None if w_csr is None else w_csr[e0:e1].contiguous()
+        self.perm = perm[e0:e1].contiguous()          # CSR position -> global edge id (caller's order)
+        del row_ptr, col, perm, w_csr
+
+        # 4. halo: remote sources, sorted + de-duplicated; col remapped into [own | halo]
+        self.halo_ids, col_local = be.halo_plan(col_slice, lo, hi, self.n_global)
+        self.n_halo = int(self.halo_ids.shape[0])
+        self.n_table = self.n_own + self.n_halo
+
+        # 5. who sends what: per-peer request counts -> id lists
+        self._build_exchange_lists()
+
+        # 6. per-row stable partition [local-source edges | halo-source edges]
+        self.row_ptr2, self.col, self.w = be.split_local_halo(self.row_ptr, col_local, w_slice, self.n_own)
+        self.in_degree = (self.row_ptr[1:] - self.row_ptr[:-1]).contiguous()
+        self.norm_w = None
+        self.self_coef = None
+        return self
+
+    def _build_exchange_lists(self):
+        be, W = self.backend, self.world
+        halo_host = self.halo_ids.cpu().numpy().astype(np.int64)
+        cuts = np.searchsorted(halo_host, self.bounds, side="left")
+        self.recv_counts = [int(cuts[p + 1] - cuts[p]) for p in range(W)]       # rows I receive from p
+        assert self.recv_counts[self.rank] == 0
+        if W == 1:
+            self.send_counts = [0]
+            self.send_idx = be.i32(np.zeros(0, np.int32))
+            return
+        rc = torch.tensor(self.recv_counts, dtype=torch.int64)
+        sc = torch.empty(W, dtype=torch.int64)
+        self._a2a_host(sc, rc, [1] * W, [1] * W)
+        self.send_counts = [int(v) for v in sc.tolist()]                         # rows p wants from me
+        want = torch.from_numpy(halo_host.astype(np.int64))
+        give = torch.empty(sum(self.send_counts), dtype=torch.int64)
+        self._a2a_host(give, want, self.send_counts, self.recv_counts)
+        give_np = give.numpy()
+        assert ((give_np >= self.own_lo) & (give_np < self.own_hi)).all(), "peer asked for rows I do not own"
+        self.send_idx = be.i32((give_np - self.own_lo).astype(np.int32))
+
+    def _a2a_host(self, out, inp, out_splits, in_splits):
+        """Small plan-time all-to-all-v of int64 host tensors (through the GPU when the group is NCCL)."""
+        if dist.get_backend(self.group) == "nccl":
+            dev = self.backend.device
+            o = out.to(dev)
+            dist.all_to_all_single(o, inp.to(dev), list(out_splits), list(in_splits), group=self.group)
+            out.copy_(o.cpu())
+        else:
+            dist.all_to_all_single(out, inp, list(out_splits), list(in_splits), group=self.group)
+
+    # ------------------------------------------------------------------ source table + exchange
+    def alloc_table(self, num_features):
+        """[n_own + n_halo, F] source table; rows [0, n_own) are this rank's own feature rows."""
+        return self.backend.empty((self.n_table, int(num_features)))
+
+    def own_rows(self, table):
+        return table[:self.n_own]
+
+    def halo_rows(self, table):
+        return table[self.n_own:]
+
+    def exchange_start(self, table):
+        """Pack the rows peers need and start the all-to-all-v into table[n_own:]. Returns a handle for
+        exchange_finish().  With NCCL the collective runs on RCCL's stream, concurrently with whatever is
+        launched on the current stream afterwards."""
+        if self.world == 1:
+            return None
+        be = self.backend
+        F = int(table.shape[1])
+        send = be.gather_rows(self.own_rows(table), self.send_idx)               # [sum(send_counts), F]
+        halo = self.halo_rows(table)
+        in_splits = [c for c in self.send_counts]
+        out_splits = [c for c in self.recv_counts]
+        if dist.get_backend(self.group) == "nccl":
+            work = dist.all_to_all_single(halo, send, out_splits, in_splits, group=self.group, async_op=True)
+            return ("nccl", work, send)
+        # gloo (tests / no-RCCL runs): stage through the host
+        send_h = send.cpu()
+        recv_h = torch.empty((self.n_halo, F), dtype=torch.float32)
+        dist.all_to_all_single(recv_h, send_h, out_splits, in_splits, group=self.group)
+        return ("host", recv_h, halo)
+
+    def exchange_finish(self, handle):
+        if handle is None:
+            return
+        if handle[0] == "nccl":
+            handle[1].wait()          # current stream waits for the RCCL stream
+        else:
+            handle[2].copy_(handle[1])
+
+    # ------------------------------------------------------------------ aggregation
+    def aggregate(self, table, op=L.SUM, w="plan", self_coef=None, bias=None, act=L.ACT_NONE, out=None,
+                  exchange=True):
+        """out[r] = reduce over ALL edges of own row r of w*table[col] (+ epilogue), halo exchange overlapped with
+        the local-source pass.  `w`: "plan" = the shard's edge weights, None = unweighted, or a tensor in this
+        shard's edge order."""
+        be = self.backend
+        w_t = self.w if (isinstance(w, str) and w == "plan") else w
+        F = int(table.shape[1])
+        if out is None:
+            out = be.empty((self.n_own, F))
+        handle = self.exchange_start(table) if exchange else None
+        rp2 = self.row_ptr2
+        # pass 1: local-source edges [rp2[2r], rp2[2r+1]) — needs only own rows, overlaps the exchange
+        be.segment_reduce(rp2, rp2[1:], 2, self.col, w_t, self.n_own, table, out, L.SUM if op == L.MEAN else op)
+        self.exchange_finish(handle)
+        # pass 2: halo-source edges [rp2[2r+1], rp2[2r+2]) accumulated on top, then the epilogue
+        be.segment_reduce(rp2[1:], rp2[2:], 2, self.col, w_t, self.n_own, table, out, op, act=act, accumulate=True,
+                          self_coef=self_coef, bias=bias, mean_count=self.in_degree if op == L.MEAN else None)
+        return out
+
+    # ------------------------------------------------------------------ GCN
+    def build_gcn_norm(self, norm="both", add_self_loop=True, renorm=True, improved=False):
+        """Sharded gcn_norm_adj (nn/conv/gcn.py:32-130, sym=True): row degrees are local to the owner; the degrees
+        of halo sources arrive through one 1-column halo exchange."""
+        be = self.backend
+        fill = 2.0 if improved else 1.0
+        if norm == "both":
+            diag = fill if (add_self_loop and renorm) else 0.0
+        else:
+            diag = fill if add_self_loop else 0.0
+        deg_table = self.alloc_table(1)
+        # degree over ALL edges of the row: local + halo parts are contiguous per row in self.w / self.col
+        own_deg = be.weight_sum(self.row_ptr, self.w, self.n_own, diag)
+        self.own_rows(deg_table)[:, 0] = own_deg
+        self.exchange_finish(self.exchange_start(deg_table))
+        mode = L.NORM_MODES[norm]
+        self.norm_w, sc = be.gcn_norm_edges(self.row_ptr, self.col, self.w, self.n_own,
+                                            deg_table[:, 0].contiguous(), mode, fill, add_self_loop, renorm)
+        self.self_coef = sc if add_self_loop else None
+        return self
+
+    def gcn_propagate(self, table, bias=None, act=L.ACT_NONE, out=None):
+        """A_hat @ h for own rows (h = table's own rows; halo rows are fetched here)."""
+        if self.norm_w is None:
+            self.build_gcn_norm()
+        return self.aggregate(table, L.SUM, w=self.norm_w, self_coef=self.self_coef, bias=bias, act=act, out=out)
+
+    def gcn(self, x_own, kernel, bias=None, act=L.ACT_NONE):
+        """Sharded GCN layer (nn/conv/gcn.py:225-290): the GEMM is row-local and writes straight into the source
+        table, so only `units`-wide rows travel."""
+        be = self.backend
+        if kernel is None:
+            table = self.alloc_table(int(x_own.shape[1]))
+            self.own_rows(table).copy_(x_own)
+        else:
+            table = self.alloc_table(int(kernel.shape[1]))
+            be.gemm_bias_act(x_own, kernel, out=self.own_rows(table))
+        return self.gcn_propagate(table, bias=bias, act=act)
+
+    # ------------------------------------------------------------------ GraphSAGE reduce
+    def neighbor_reduce(self, x_own, op, weighted=True):
+        """mean / sum / max of (w *) x[col] over in-edges of own rows (nn/conv/graph_sage.py:34-41)."""
+        table = self.alloc_table(int(x_own.shape[1]))
+        self.own_rows(table).copy_(x_own)
+        return self.aggregate(table, op, w="plan" if (weighted and self.w is not None) else None)
