@@ -89,13 +89,22 @@ typedef struct tfgx_reduce_args {
     int32_t act;              /* TFGX_ACT_* applied last */
     int32_t accumulate;       /* 1: combine with the values already in out (sum/mean: add, max: max) — the
                                  second pass of a local/halo split plan; epilogue terms are applied after */
-    int32_t reserved;
+    int32_t hub_threshold;    /* 0: off. > 0: rows with more than hub_threshold edges ("hubs" of a power-law graph) are
+                                 skipped by the main launch and reduced chunk-wise from the lists below */
     const float* self_coef;   /* [n_dst] or NULL: an implicit edge (r, r) of weight self_coef[r] appended after
                                  the row's edges (SparseMatrix.add_diag, nn/conv/gcn.py:72,77,98) */
     const float* bias;        /* [F] or NULL */
     const float* add_x;       /* [n_dst, ld_add] or NULL: sum_updater's "x +" */
     int64_t ld_add;
     const int32_t* mean_count;/* [n_dst] or NULL: divisor for TFGX_MEAN (NULL: row_end-row_begin); <1 -> 1 */
+    /* hub rows (only read when hub_threshold > 0 and n_hub_rows > 0); built once per plan by the host */
+    const int32_t* hub_rows;        /* [n_hub_rows] destination ids with in-degree > hub_threshold, ascending */
+    const int32_t* hub_chunk_ptr;   /* [n_hub_rows+1] chunk range of each hub row */
+    const int32_t* hub_chunk_begin; /* [n_hub_chunks] CSR positions: chunk c covers [begin[c], end[c]) */
+    const int32_t* hub_chunk_end;
+    int64_t n_hub_rows;
+    int64_t n_hub_chunks;
+    float* hub_scratch;             /* [n_hub_chunks, F] workspace for the per-chunk partial results */
 } tfgx_reduce_args;
 
 int tfgx_segment_reduce_f32(const tfgx_reduce_args* args /* host */, tfgx_stream_t stream);

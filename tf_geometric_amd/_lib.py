@@ -33,9 +33,12 @@ class ReduceArgs(ctypes.Structure):
         ("col", ctypes.c_void_p), ("w", ctypes.c_void_p), ("n_dst", ctypes.c_int64),
         ("x", ctypes.c_void_p), ("ldx", ctypes.c_int64), ("F", ctypes.c_int64),
         ("out", ctypes.c_void_p), ("ldo", ctypes.c_int64),
-        ("op", ctypes.c_int32), ("act", ctypes.c_int32), ("accumulate", ctypes.c_int32), ("reserved", ctypes.c_int32),
+        ("op", ctypes.c_int32), ("act", ctypes.c_int32), ("accumulate", ctypes.c_int32), ("hub_threshold", ctypes.c_int32),
         ("self_coef", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("add_x", ctypes.c_void_p),
         ("ld_add", ctypes.c_int64), ("mean_count", ctypes.c_void_p),
+        ("hub_rows", ctypes.c_void_p), ("hub_chunk_ptr", ctypes.c_void_p), ("hub_chunk_begin", ctypes.c_void_p),
+        ("hub_chunk_end", ctypes.c_void_p), ("n_hub_rows", ctypes.c_int64), ("n_hub_chunks", ctypes.c_int64),
+        ("hub_scratch", ctypes.c_void_p),
     ]
 
 

@@ -7,7 +7,7 @@
 // K and N are feature widths (16..1433), so the kernel is a tall-skinny GEMM close to the HBM roofline:
 // the A panel is streamed once, B (<= 1.5 MB) lives in L2/LDS.
 //
-// Tile: BM x BN per 256-thread workgroup (4 waves), BK = 16.  A is staged transposed in LDS (As[k][m]) so
+// Tile: BM x BN per 256-thread workgroup (4 waves), BK = 32.  A is staged transposed in LDS (As[k][m]) so
 // the MFMA A operand (lane l: A[m = l&31][k = l>>5]) is a conflict-free ds_read_b32 over consecutive m;
 // B is staged as Bs[k][n].  Global loads for tile t+1 are issued before the MFMAs of tile t (register
 // staging), LDS is single-buffered.
@@ -18,7 +18,7 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BK = 16;
+constexpr int BK = 32;   // 32 floats = one full 128-byte line of an A row per 8 lanes
 
 template <int BM, int BN, int WM, int WN, bool AV4, bool BV4>
 __global__ __launch_bounds__(kBlock) void gemm_kernel(const float* __restrict__ A, int64_t lda,
@@ -33,7 +33,7 @@ __global__ __launch_bounds__(kBlock) void gemm_kernel(const float* __restrict__ 
     constexpr int A_LOADS = BM * BK / 4 / kBlock;   // float4 per thread
     constexpr int B_LOADS = (BK * BN / 4 + kBlock - 1) / kBlock;
     constexpr int B_THREADS_PER_ROW = BN / 4;
-    constexpr int LDA_S = BM + 4, LDB_S = BN + 4;
+    constexpr int LDA_S = BM + 1, LDB_S = BN + 4;   // +1: spreads the transposed A stores over banks
 
     __shared__ __attribute__((aligned(16))) float As[BK * LDA_S];
     __shared__ __attribute__((aligned(16))) float Bs[BK * LDB_S];
@@ -125,8 +125,9 @@ __global__ __launch_bounds__(kBlock) void gemm_kernel(const float* __restrict__ 
         __syncthreads();
         if (k0 + BK < K) load_tiles(k0 + BK);
         const int kh = lane >> 5, l31 = lane & 31;
-#pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
+        const int kmax = min(BK, K - k0);   // the zero-padded tail of the last tile is skipped, not multiplied
+#pragma unroll 4
+        for (int kk = 0; kk < kmax; kk += 2) {
             float a[TM], b[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) a[i] = As[(kk + kh) * LDA_S + wm * WM + i * 32 + l31];

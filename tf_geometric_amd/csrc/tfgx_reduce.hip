@@ -77,6 +77,7 @@ struct KArgs {
     const float* add_x;
     int64_t ld_add;
     const int32_t* mean_count;
+    int32_t hub_threshold;   // > 0: rows with more edges than this are left to the hub path
 };
 
 template <int VEC, int G, int CH, bool IS_MAX, bool WEIGHTED>
@@ -108,6 +109,7 @@ __global__ __launch_bounds__(kBlock) void seg_reduce_kernel(const KArgs a)
             s = __builtin_amdgcn_readfirstlane(s);
             e = __builtin_amdgcn_readfirstlane(e);
         }
+        if (a.hub_threshold > 0 && e - s > a.hub_threshold) continue;   // handled by the chunked hub path
         float acc[CH][VEC];
 #pragma unroll
         for (int k = 0; k < CH; ++k)
@@ -257,6 +259,58 @@ int launch_vec(const KArgs& a, bool is_max, bool weighted, hipStream_t stream)
 
 inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
+// Hub rows (in-degree > hub_threshold): the row is cut into chunks of consecutive edges, every chunk is reduced like
+// an ordinary row into scratch[chunk, :] (second launch of seg_reduce_kernel over the chunk list), and this kernel
+// folds a row's chunk partials IN CHUNK ORDER and applies the epilogue: deterministic, no atomics, and the long
+// fp32 sum becomes a sum of short partial sums.
+struct HubArgs {
+    const int32_t* hub_rows;
+    const int32_t* hub_chunk_ptr;
+    const float* scratch;
+    int64_t n_hub;
+    KArgs k;
+};
+
+__global__ __launch_bounds__(kBlock) void hub_finalize_kernel(const HubArgs h)
+{
+    const KArgs& a = h.k;
+    const bool is_max = a.op == TFGX_MAX;
+    int64_t t = blockIdx.x * int64_t(kBlock) + threadIdx.x;
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    const int64_t total = h.n_hub * a.F;
+    for (; t < total; t += stride) {
+        const int64_t i = t / a.F;
+        const int j = int(t - i * a.F);
+        const int64_t r = h.hub_rows[i];
+        float res = is_max ? -FLT_MAX : 0.0f;
+        for (int c = h.hub_chunk_ptr[i]; c < h.hub_chunk_ptr[i + 1]; ++c) {
+            const float v = h.scratch[int64_t(c) * a.F + j];
+            res = is_max ? fmaxf(res, v) : res + v;
+        }
+        float* op = a.out + r * a.ldo + j;
+        if (a.accumulate) res = is_max ? fmaxf(*op, res) : *op + res;
+        if (a.self_coef) {
+            const float sv = a.self_coef[r] * a.x[r * a.ldx + j];
+            res = is_max ? fmaxf(res, sv) : res + sv;
+        }
+        if (a.op == TFGX_MEAN) {
+            const int cnt = a.mean_count ? a.mean_count[r]
+                                         : (a.row_end[r * a.rp_stride] - a.row_begin[r * a.rp_stride]);
+            res = res / float(cnt > 1 ? cnt : 1);
+        }
+        if (a.add_x) res = a.add_x[r * a.ld_add + j] + res;
+        if (a.bias) res += a.bias[j];
+        *op = apply_act(res, a.act);
+    }
+}
+
+int launch_any(const KArgs& a, int vec, bool is_max, bool weighted, hipStream_t stream)
+{
+    if (vec == 4) return launch_vec<4>(a, is_max, weighted, stream);
+    if (vec == 2) return launch_vec<2>(a, is_max, weighted, stream);
+    return launch_vec<1>(a, is_max, weighted, stream);
+}
+
 }  // namespace
 }  // namespace tfgx
 
@@ -280,6 +334,14 @@ extern "C" int tfgx_segment_reduce_f32(const tfgx_reduce_args* p, tfgx_stream_t 
     a.col0 = 0; a.out = p->out; a.ldo = p->ldo; a.op = p->op; a.act = p->act; a.accumulate = p->accumulate;
     a.self_coef = p->self_coef; a.bias = p->bias; a.add_x = p->add_x; a.ld_add = p->ld_add;
     a.mean_count = p->mean_count;
+    a.hub_threshold = 0;
+    const bool use_hub = p->hub_threshold > 0 && p->n_hub_rows > 0;
+    if (use_hub) {
+        TFGX_REQUIRE(p->hub_rows && p->hub_chunk_ptr && p->hub_chunk_begin && p->hub_chunk_end && p->hub_scratch &&
+                         p->n_hub_chunks > 0,
+                     "hub rows given without chunk lists / scratch");
+        a.hub_threshold = p->hub_threshold;
+    }
 
     const bool is_max = p->op == TFGX_MAX;
     const bool weighted = p->w != nullptr;
@@ -294,7 +356,24 @@ extern "C" int tfgx_segment_reduce_f32(const tfgx_reduce_args* p, tfgx_stream_t 
         if (p->bias) good = good && aligned_to(p->bias, al);
         return good;
     };
-    if (ok(4)) return launch_vec<4>(a, is_max, weighted, stream);
-    if (ok(2)) return launch_vec<2>(a, is_max, weighted, stream);
-    return launch_vec<1>(a, is_max, weighted, stream);
+    const int vec = ok(4) ? 4 : (ok(2) ? 2 : 1);
+    int rc = launch_any(a, vec, is_max, weighted, stream);
+    if (rc != TFGX_OK || !use_hub) return rc;
+
+    // hub path: (2) chunk partials -> scratch, (3) ordered fold + epilogue
+    KArgs c = a;
+    c.row_begin = p->hub_chunk_begin; c.row_end = p->hub_chunk_end; c.rp_stride = 1;
+    c.n_dst = p->n_hub_chunks; c.out = p->hub_scratch; c.ldo = p->F;
+    c.op = is_max ? TFGX_MAX : TFGX_SUM; c.act = TFGX_ACT_NONE; c.accumulate = 0;
+    c.self_coef = nullptr; c.bias = nullptr; c.add_x = nullptr; c.mean_count = nullptr; c.hub_threshold = 0;
+    const bool sok = (p->F % 4 == 0) && aligned_to(p->hub_scratch, 16) && (p->ldx % 4 == 0) && aligned_to(p->x, 16);
+    const bool sok2 = (p->F % 2 == 0) && aligned_to(p->hub_scratch, 8) && (p->ldx % 2 == 0) && aligned_to(p->x, 8);
+    rc = launch_any(c, sok ? 4 : (sok2 ? 2 : 1), is_max, weighted, stream);
+    if (rc != TFGX_OK) return rc;
+    HubArgs h;
+    h.hub_rows = p->hub_rows; h.hub_chunk_ptr = p->hub_chunk_ptr; h.scratch = p->hub_scratch;
+    h.n_hub = p->n_hub_rows; h.k = a;
+    hub_finalize_kernel<<<grid_for(p->n_hub_rows * p->F, kBlock), kBlock, 0, stream>>>(h);
+    TFGX_LAUNCH_CHECK("hub_finalize_kernel");
+    return TFGX_OK;
 }

@@ -26,6 +26,7 @@ class CsrPlan(object):
         self.num_edges = int(num_edges)
         self._edge_index = None   # kept only to build the transposed plan on demand (sym=False)
         self._transposed = None
+        self._hub = None
 
     @staticmethod
     def build(edge_index, n_dst, n_src=None):
@@ -86,6 +87,34 @@ class CsrPlan(object):
     def in_degree(self):
         return (self.row_ptr[1:] - self.row_ptr[:-1])
 
+    def hub_info(self):
+        """Chunk lists for destinations with more than HUB_THRESHOLD in-edges (power-law "hubs"), or None.
+        Small control-plane metadata, computed once per plan: (hub_rows, chunk_ptr, chunk_begin, chunk_end)."""
+        if self._hub is None:
+            deg = self.in_degree()
+            hub_rows = torch.nonzero(deg > HUB_THRESHOLD).flatten().to(torch.int32)
+            if hub_rows.numel() == 0:
+                self._hub = False
+            else:
+                rows64 = hub_rows.to(torch.int64)
+                start = self.row_ptr[rows64].to(torch.int64)
+                d = deg[rows64].to(torch.int64)
+                n_chunks = (d + HUB_CHUNK - 1) // HUB_CHUNK
+                chunk_ptr = torch.zeros(hub_rows.numel() + 1, dtype=torch.int64, device=deg.device)
+                chunk_ptr[1:] = torch.cumsum(n_chunks, 0)
+                total = int(chunk_ptr[-1].item())
+                owner = torch.repeat_interleave(torch.arange(hub_rows.numel(), device=deg.device), n_chunks)
+                k = torch.arange(total, device=deg.device) - chunk_ptr[owner]
+                begin = start[owner] + k * HUB_CHUNK
+                end = torch.minimum(begin + HUB_CHUNK, start[owner] + d[owner])
+                self._hub = (hub_rows.contiguous(), chunk_ptr.to(torch.int32).contiguous(),
+                             begin.to(torch.int32).contiguous(), end.to(torch.int32).contiguous())
+        return self._hub or None
+
+
+HUB_THRESHOLD = 2048   # rows with more in-edges than this take the chunked path of tfgx_segment_reduce_f32
+HUB_CHUNK = 1024       # edges per chunk
+
 
 def segment_reduce(plan, x, op, w_csr=None, out=None, act=L.ACT_NONE, self_coef=None, bias=None, add_x=None,
                    accumulate=False, mean_count=None, row_begin=None, row_end=None, rp_stride=1, col=None,
@@ -124,6 +153,15 @@ def segment_reduce(plan, x, op, w_csr=None, out=None, act=L.ACT_NONE, self_coef=
         a.add_x = add_x.data_ptr()
         a.ld_add = ld_add
     a.mean_count = 0 if mean_count is None else mean_count.data_ptr()
+    hub = plan.hub_info() if (row_begin is None and row_end is None and col is None) else None
+    if hub is not None:
+        hub_rows, chunk_ptr, chunk_begin, chunk_end = hub
+        scratch = torch.empty((int(chunk_begin.shape[0]), F), dtype=torch.float32, device=x.device)
+        a.hub_threshold = HUB_THRESHOLD
+        a.hub_rows, a.hub_chunk_ptr = hub_rows.data_ptr(), chunk_ptr.data_ptr()
+        a.hub_chunk_begin, a.hub_chunk_end = chunk_begin.data_ptr(), chunk_end.data_ptr()
+        a.n_hub_rows, a.n_hub_chunks = int(hub_rows.shape[0]), int(chunk_begin.shape[0])
+        a.hub_scratch = scratch.data_ptr()
     L.check(lib.tfgx_segment_reduce_f32(ctypes.byref(a), L.stream_ptr()), "tfgx_segment_reduce_f32")
     return out
 

@@ -1,0 +1,128 @@
+# coding=utf-8
+"""Kernel-level sweeps on one GPU (not the contract bench): segment-reduce time vs feature width / reducer / graph
+skew, GEMM TFLOP/s, fused GAT.  Prints one JSON object per line.  usage: python tools/bench_sweep.py [--quick]"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import tf_geometric_amd as tfg                      # noqa: E402
+from tf_geometric_amd import _lib as L, synthetic   # noqa: E402
+from tf_geometric_amd.plan import CsrPlan, segment_reduce, gemm_bias_act   # noqa: E402
+from tf_geometric_amd.nn.conv.gat import gat_attention                      # noqa: E402
+
+
+def timeit(fn, steps=10, warmup=3):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / steps
+
+
+def rmat_edges(scale, num_edges, seed=0, a=0.57, b=0.19, c=0.19):
+    """R-MAT (a,b,c,d) = (.57,.19,.19,.05) on 2^scale nodes, generated on the GPU; both directions emitted."""
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    half = num_edges // 2
+    src = torch.zeros(half, dtype=torch.int64, device="cuda")
+    dst = torch.zeros(half, dtype=torch.int64, device="cuda")
+    for _ in range(scale):
+        r = torch.rand(half, generator=g, device="cuda")
+        sbit = (r >= a + b).to(torch.int64)
+        dbit = (((r >= a) & (r < a + b)) | (r >= a + b + c)).to(torch.int64)
+        src = src * 2 + sbit
+        dst = dst * 2 + dbit
+    keep = src != dst
+    src, dst = src[keep], dst[keep]
+    return torch.stack([torch.cat([src, dst]), torch.cat([dst, src])]).to(torch.int32)
+
+
+def main():
+    quick = "--quick" in sys.argv
+    torch.cuda.set_device(0)
+    n, e = (2400000, 123000000) if not quick else (300000, 15000000)
+    ei = L.as_i32(synthetic.synthetic_edges(n, e, seed=0))
+    E = int(ei.shape[1])
+    plan = CsrPlan.build(ei, n, n)
+    w = torch.rand(E, device="cuda") + 0.5
+    for f in [16, 32, 64, 96, 100, 104, 128, 192, 256]:
+        x = torch.randn(n, f, device="cuda")
+        out = torch.empty_like(x)
+        for name, op, ww in [("sum_w", L.SUM, w), ("sum", L.SUM, None), ("max", L.MAX, None)]:
+            if name != "sum_w" and f not in (100, 128):
+                continue
+            ms = timeit(lambda: segment_reduce(plan, x, op, w_csr=ww, out=out))
+            balg = E * (4 * f + 4 + (4 if ww is not None else 0)) + n * 4 * f + 4 * (n + 1)
+            print(json.dumps({"kind": "segment_reduce", "graph": "uniform", "N": n, "E": E, "F": f, "op": name,
+                              "ms": ms, "GBps_alg": balg / ms / 1e6, "frac_of_8TBps": balg / ms / 1e6 / 8000,
+                              "Gedges_per_s": E / ms / 1e6}), flush=True)
+        del x, out
+    # skewed graph (R-MAT): hub rows take the chunked path
+    scale = 21 if not quick else 18
+    ei_r = rmat_edges(scale, e // 2 if not quick else e // 4, seed=1)
+    nr, Er = 1 << scale, int(ei_r.shape[1])
+    plan_r = CsrPlan.build(ei_r, nr, nr)
+    deg = plan_r.in_degree()
+    hub = plan_r.hub_info()
+    x = torch.randn(nr, 100, device="cuda")
+    out = torch.empty_like(x)
+    wr = torch.rand(Er, device="cuda") + 0.5
+    ms = timeit(lambda: segment_reduce(plan_r, x, L.SUM, w_csr=wr, out=out))
+    balg = Er * (400 + 8) + nr * 400 + 4 * (nr + 1)
+    print(json.dumps({"kind": "segment_reduce", "graph": "rmat(.57,.19,.19,.05)", "N": nr, "E": Er, "F": 100,
+                      "max_in_degree": int(deg.max().item()), "hub_rows": 0 if hub is None else int(hub[0].shape[0]),
+                      "hub_chunks": 0 if hub is None else int(hub[2].shape[0]), "ms": ms,
+                      "GBps_alg": balg / ms / 1e6, "frac_of_8TBps": balg / ms / 1e6 / 8000,
+                      "Gedges_per_s": Er / ms / 1e6}), flush=True)
+    # parity of the hub path against a float64 torch reference on the hub rows
+    if hub is not None:
+        rows = hub[0][:4].long()
+        got = out[rows].double().cpu()
+        ref = torch.zeros(len(rows), 100, dtype=torch.float64)
+        rp = plan_r.row_ptr.long()
+        for i, r in enumerate(rows.tolist()):
+            s, t = int(rp[r]), int(rp[r + 1])
+            ref[i] = (x[plan_r.col[s:t].long()].double() * wr_csr(plan_r, wr)[s:t, None].double()).sum(0).cpu()
+        print(json.dumps({"kind": "hub_parity", "max_abs_err": float((got - ref).abs().max()),
+                          "max_abs_ref": float(ref.abs().max())}), flush=True)
+    del x, out
+    # GEMM
+    for (m, k, nn) in [(n, 100, 256), (n, 100, 128), (n, 128, 256), (n, 100, 64), (n, 256, 128), (n, 100, 16),
+                       (233000, 602, 64), (2708 * 64, 1433, 16)]:
+        a = torch.randn(m, k, device="cuda")
+        b = torch.randn(k, nn, device="cuda") * 0.1
+        c = torch.empty(m, nn, device="cuda")
+        ms = timeit(lambda: gemm_bias_act(a, b, out=c))
+        ms_t = timeit(lambda: torch.matmul(a, b, out=c))
+        print(json.dumps({"kind": "gemm", "M": m, "K": k, "N": nn, "ms": ms, "TFLOPs": 2.0 * m * k * nn / ms / 1e9,
+                          "GBps": 4.0 * (m * k + m * nn) / ms / 1e6, "torch_matmul_ms": ms_t}), flush=True)
+        del a, b, c
+    # fused GAT attention (demo-literal H=8, A=8, U=64 and the heavy A=64 variant)
+    for (H, A, U) in [(8, 8, 64), (8, 64, 64), (1, 8, 64)]:
+        Q = torch.randn(n, A, device="cuda")
+        K = torch.randn(n, A, device="cuda")
+        V = torch.randn(n, U, device="cuda")
+        ms = timeit(lambda: gat_attention(plan, Q, K, V, H))
+        Eagg = E + n
+        balg = Eagg * (4 * A + 4 * U + 4) + n * 4 * (A + U) + 4 * (n + 1)
+        print(json.dumps({"kind": "gat_fused", "H": H, "A": A, "U": U, "ms": ms, "GBps_alg": balg / ms / 1e6,
+                          "frac_of_8TBps": balg / ms / 1e6 / 8000, "Gedges_per_s": Eagg / ms / 1e6}), flush=True)
+
+
+def wr_csr(plan, w):
+    return plan.edge_attr_to_csr(w)
+
+
+if __name__ == "__main__":
+    main()
