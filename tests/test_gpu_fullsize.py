@@ -1,0 +1,97 @@
+# coding=utf-8
+"""BASELINE.json's FULL sizes on the GPU, through size-independent properties (the oracle cannot finish these in
+seconds): checksum of checksums, linearity, mean*degree == sum, max invariances, softmax partition of unity,
+determinism.  Shapes: ogbn-products (N=2.4M, E=123M, F=100) and Reddit (N=233k, E=114M, 8-head GAT)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def products(tfg):
+    from tf_geometric_amd import synthetic
+    from tf_geometric_amd.plan import CsrPlan
+    n, e, f = synthetic.WORKLOADS["products"]
+    ei = tfg._lib.as_i32(synthetic.synthetic_edges(n, e, seed=0))
+    g = torch.Generator(device="cuda")
+    g.manual_seed(1)
+    x = torch.randn(n, f, generator=g, device="cuda")
+    w = torch.rand(int(ei.shape[1]), generator=g, device="cuda") + 0.5
+    plan = CsrPlan.build(ei, n, n)
+    return dict(n=n, f=f, ei=ei, x=x, w=w, plan=plan, w_csr=plan.edge_attr_to_csr(w))
+
+
+def test_products_checksum_of_checksums(tfg, products):
+    """sum_r out[r,:] == sum_c (sum of weights of edges leaving c) * x[c,:]  — column sums through the transposed
+    plan; both sides reduced in float64."""
+    from tf_geometric_amd.plan import segment_reduce
+    L = tfg._lib
+    p = products
+    out = segment_reduce(p["plan"], p["x"], L.SUM, w_csr=p["w_csr"])
+    lhs = out.double().sum(0)
+    colw = tfg.SparseMatrix(p["ei"], p["w"], [p["n"], p["n"]])
+    colw._plan = p["plan"]
+    cw = colw.segment_sum(axis=0)                     # [N] weights grouped by SOURCE
+    rhs = (cw.double()[:, None] * p["x"].double()).sum(0)
+    scale = (cw.double()[:, None] * p["x"].double().abs()).sum(0)
+    assert float(((lhs - rhs).abs() / scale).max()) < 2e-7       # relative to the sum of magnitudes
+    assert int(p["plan"].row_ptr[-1].item()) == int(p["ei"].shape[1])
+
+
+def test_products_linearity_mean_and_max(tfg, products):
+    from tf_geometric_amd.plan import segment_reduce
+    L = tfg._lib
+    p = products
+    s1 = segment_reduce(p["plan"], p["x"], L.SUM, w_csr=p["w_csr"])
+    s2 = segment_reduce(p["plan"], p["x"] * 2.0, L.SUM, w_csr=p["w_csr"])
+    assert torch.equal(s2, s1 * 2.0)                                  # scaling by 2 is exact in fp32: bit-identical
+    assert torch.equal(s1, segment_reduce(p["plan"], p["x"], L.SUM, w_csr=p["w_csr"]))   # deterministic
+    mean = segment_reduce(p["plan"], p["x"], L.MEAN, w_csr=p["w_csr"])
+    deg = p["plan"].in_degree().clamp(min=1).float()[:, None]
+    assert float((mean * deg - s1).abs().max()) <= 1e-4 * float(s1.abs().max())
+    mx = segment_reduce(p["plan"], p["x"], L.MAX)
+    su = segment_reduce(p["plan"], p["x"], L.SUM)
+    has = p["plan"].in_degree() > 0
+    assert bool((mx[has] * deg[has] >= su[has] - 1e-3).all())          # max >= mean
+    assert bool((mx[~has] == -3.4028234663852886e38).all())
+    mx_shift = segment_reduce(p["plan"], p["x"] + 1.0, L.MAX)
+    assert float((mx_shift[has] - (mx[has] + 1.0)).abs().max()) <= 1e-6  # max commutes with a shift
+
+
+def test_products_gcn_rows_sum_to_one_for_regularised_adjacency(tfg, products):
+    """norm='left' makes every row of (A+I) sum to one: propagating a constant vector returns it."""
+    p = products
+    layer = tfg.layers.GCN(1, use_kernel=False, use_bias=False, norm="left")
+    ones = torch.ones(p["n"], 4, device="cuda")
+    out = layer([ones, p["ei"], p["w"]], cache={"tfgx_csr_plan": p["plan"]})
+    assert float((out - 1.0).abs().max()) < 1e-5
+
+
+def test_reddit_shaped_gat_partition_of_unity_and_bounds(tfg):
+    """Reddit shape (N=233k, E=114M, avg in-degree 489), 8 heads: attention weights of a row sum to one, so
+    V == const -> out == const, and every output lies inside [min V, max V] of the row's neighbourhood."""
+    from tf_geometric_amd import synthetic
+    from tf_geometric_amd.plan import CsrPlan, segment_reduce
+    from tf_geometric_amd.nn.conv.gat import gat_attention
+    L = tfg._lib
+    n, e = 233000, 114000000
+    ei = L.as_i32(synthetic.synthetic_edges(n, e, seed=3))
+    plan = CsrPlan.build(ei, n, n)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(4)
+    Q = torch.randn(n, 64, generator=g, device="cuda")
+    K = torch.randn(n, 64, generator=g, device="cuda")
+    ones = gat_attention(plan, Q, K, torch.ones(n, 64, device="cuda"), 8)
+    assert float((ones - 1.0).abs().max()) < 2e-6
+    V = torch.randn(n, 64, generator=g, device="cuda")
+    out = gat_attention(plan, Q, K, V, 8)
+    hi = torch.maximum(segment_reduce(plan, V, L.MAX), V)          # neighbours + the appended self-loop
+    lo = -torch.maximum(segment_reduce(plan, -V, L.MAX), -V)
+    assert bool((out <= hi + 1e-5).all()) and bool((out >= lo - 1e-5).all())
+    assert torch.equal(out, gat_attention(plan, Q, K, V, 8))       # deterministic
+    # zero scores (Q = 0) -> uniform attention == mean over {neighbours + self}
+    uni = gat_attention(plan, torch.zeros_like(Q), K, V, 8)
+    ref = (segment_reduce(plan, V, L.SUM) + V) / (plan.in_degree().float()[:, None] + 1.0)
+    assert float((uni - ref).abs().max()) < 2e-5

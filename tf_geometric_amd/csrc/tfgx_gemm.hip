@@ -126,7 +126,6 @@ __global__ __launch_bounds__(kBlock) void gemm_kernel(const float* __restrict__ 
         if (k0 + BK < K) load_tiles(k0 + BK);
         const int kh = lane >> 5, l31 = lane & 31;
         const int kmax = min(BK, K - k0);   // the zero-padded tail of the last tile is skipped, not multiplied
-#pragma unroll 4
         for (int kk = 0; kk < kmax; kk += 2) {
             float a[TM], b[TN];
 #pragma unroll
