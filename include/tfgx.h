@@ -105,6 +105,13 @@ typedef struct tfgx_reduce_args {
     int64_t n_hub_rows;
     int64_t n_hub_chunks;
     float* hub_scratch;             /* [n_hub_chunks, F] workspace for the per-chunk partial results */
+    /* optional split source rows: x holds columns [0, f_main) with leading dimension ldx, x_tail holds columns
+       [f_main, F) with leading dimension ld_tail.  With f_main a multiple of 32 and 128-byte aligned rows every
+       fetched line of x is fully used (a 400-byte row otherwise straddles four 128-byte lines = 512 bytes) and the
+       narrow tail array (4*(F-f_main) bytes per node) stays cache-resident.  NULL = ordinary single array. */
+    const float* x_tail;
+    int64_t ld_tail;
+    int64_t f_main;
 } tfgx_reduce_args;
 
 int tfgx_segment_reduce_f32(const tfgx_reduce_args* args /* host */, tfgx_stream_t stream);
@@ -172,6 +179,10 @@ int tfgx_head_mean_f32(const float* in, int64_t ld_in, int64_t n, int32_t H, int
 int tfgx_gemm_bias_act_f32(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias,
                            int32_t act, float* C, int64_t ldc, int64_t M, int64_t K, int64_t N,
                            tfgx_stream_t stream);
+
+/* x[n, F] -> x_main[n, f_main] + x_tail[n, F - f_main] in one pass (the split source layout of tfgx_reduce_args) */
+int tfgx_split_rows_f32(const float* x, int64_t ldx, int64_t n, int64_t F, int64_t f_main, float* x_main,
+                        int64_t ld_main, float* x_tail, int64_t ld_tail, tfgx_stream_t stream);
 
 /* h = h * rsqrt(max(sum(h^2), 1e-12)) per row, in place (tf.nn.l2_normalize, graph_sage.py:58) */
 int tfgx_l2_normalize_rows_f32(float* h, int64_t ld, int64_t n, int64_t F, tfgx_stream_t stream);

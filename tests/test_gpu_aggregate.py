@@ -157,3 +157,27 @@ def test_segment_softmax_and_count(tfg, oracle):
             np.stack([oracle.segment_softmax(s[:, h], ids, 60) for h in range(shape[1])], axis=1)
         assert_parity(got, ref, what="segment_softmax")
     assert np.array_equal(tfg.nn.segment_count(ids, 60).cpu().numpy(), oracle.segment_count(ids, 60))
+
+
+@pytest.mark.parametrize("f", [100, 36, 68, 124])
+def test_split_row_layout_is_bit_identical(tfg, oracle, f):
+    """SplitRows (main[n, f_main] + tail[n, F - f_main]) only changes where bytes live: same FMA chain per element."""
+    import torch
+    from tf_geometric_amd.plan import CsrPlan, SplitRows, segment_reduce
+    L = tfg._lib
+    n, e = 3000, 50000
+    x, ei, w = _graph(oracle, n, e, f, seed=f)
+    plan = CsrPlan.build(ei, n, n)
+    xd = L.as_f32(x)
+    w_csr = plan.edge_attr_to_csr(w)
+    sc = torch.rand(n, device="cuda")
+    bias = torch.randn(f, device="cuda")
+    sp = SplitRows.from_dense(xd)
+    assert sp.main.shape[1] == (f // 32) * 32 and torch.equal(torch.cat([sp.main, sp.tail], 1), xd)
+    for op in (L.SUM, L.MEAN, L.MAX):
+        for ww in (w_csr, None):
+            a = segment_reduce(plan, xd, op, w_csr=ww, self_coef=sc, bias=bias, act=1)
+            b = segment_reduce(plan, sp, op, w_csr=ww, self_coef=sc, bias=bias, act=1)
+            assert torch.equal(a, b)
+    ref = oracle.aggregate_neighbors(x, ei, w, oracle.gcn_mapper, oracle.sum_reducer, oracle.identity_updater)
+    assert_parity(segment_reduce(plan, sp, L.SUM, w_csr=w_csr).cpu().numpy(), ref, what="split rows vs oracle")

@@ -39,6 +39,7 @@ class ReduceArgs(ctypes.Structure):
         ("hub_rows", ctypes.c_void_p), ("hub_chunk_ptr", ctypes.c_void_p), ("hub_chunk_begin", ctypes.c_void_p),
         ("hub_chunk_end", ctypes.c_void_p), ("n_hub_rows", ctypes.c_int64), ("n_hub_chunks", ctypes.c_int64),
         ("hub_scratch", ctypes.c_void_p),
+        ("x_tail", ctypes.c_void_p), ("ld_tail", ctypes.c_int64), ("f_main", ctypes.c_int64),
     ]
 
 
@@ -71,6 +72,7 @@ SIGNATURES = {
     "tfgx_head_mean_f32": (ctypes.c_int, [_P, _I64, _I64, _I32, _I32, _P, _I32, _P, _I64, _P]),
     "tfgx_gemm_bias_act_f32": (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I32, _P, _I64, _I64, _I64, _I64, _P]),
     "tfgx_l2_normalize_rows_f32": (ctypes.c_int, [_P, _I64, _I64, _I64, _P]),
+    "tfgx_split_rows_f32": (ctypes.c_int, [_P, _I64, _I64, _I64, _I64, _P, _I64, _P, _I64, _P]),
     "tfgx_gather_rows_f32": (ctypes.c_int, [_P, _I64, _P, _I64, _I64, _P, _I64, _P]),
     "tfgx_halo_workspace_bytes": (_SZ, [_I64]),
     "tfgx_halo_mark": (ctypes.c_int, [_P, _I64, _I32, _I32, _I64, _P, _P]),

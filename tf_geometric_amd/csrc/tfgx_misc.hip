@@ -102,6 +102,24 @@ __global__ void split_local_halo_kernel(const int32_t* __restrict__ row_ptr, con
     }
 }
 
+// one pass: x[n, F] -> main[n, f_main] (128-byte aligned rows) + tail[n, F - f_main]
+__global__ __launch_bounds__(kBlock) void split_rows_kernel(const float* __restrict__ x, int64_t ldx, int64_t n, int F,
+                                                            int f_main, float* __restrict__ xm, int64_t ldm,
+                                                            float* __restrict__ xt, int64_t ldt)
+{
+    const int per_row = F / 4;
+    int64_t t = blockIdx.x * int64_t(kBlock) + threadIdx.x;
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    const int64_t total = n * per_row;
+    for (; t < total; t += stride) {
+        const int64_t i = t / per_row;
+        const int j = int(t - i * per_row) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(x + i * ldx + j);
+        if (j < f_main) *reinterpret_cast<float4*>(xm + i * ldm + j) = v;
+        else *reinterpret_cast<float4*>(xt + i * ldt + (j - f_main)) = v;
+    }
+}
+
 inline bool aligned_to(const void* p, size_t al) { return (reinterpret_cast<uintptr_t>(p) % al) == 0; }
 
 }  // namespace
@@ -205,5 +223,20 @@ extern "C" int tfgx_split_local_halo(const int32_t* row_ptr, const int32_t* col_
     split_local_halo_kernel<<<grid_for(n_dst, kBlock), kBlock, 0, stream>>>(row_ptr, col_local, w, n_dst, n_own,
                                                                             row_ptr2, col_out, w_out);
     TFGX_LAUNCH_CHECK("split_local_halo_kernel");
+    return TFGX_OK;
+}
+
+extern "C" int tfgx_split_rows_f32(const float* x, int64_t ldx, int64_t n, int64_t F, int64_t f_main, float* x_main,
+                                   int64_t ld_main, float* x_tail, int64_t ld_tail, tfgx_stream_t stream)
+{
+    TFGX_REQUIRE(n >= 0 && F >= 8 && F % 4 == 0 && f_main > 0 && f_main < F && f_main % 4 == 0, "bad F / f_main");
+    if (n == 0) return TFGX_OK;
+    TFGX_REQUIRE(x && x_main && x_tail, "null pointer");
+    TFGX_REQUIRE(ldx >= F && ldx % 4 == 0 && ld_main >= f_main && ld_main % 4 == 0 && ld_tail >= F - f_main &&
+                     ld_tail % 4 == 0 && aligned_to(x, 16) && aligned_to(x_main, 16) && aligned_to(x_tail, 16),
+                 "rows must be 16-byte aligned");
+    split_rows_kernel<<<grid_for(n * (F / 4), kBlock), kBlock, 0, as_stream(stream)>>>(x, ldx, n, int(F), int(f_main),
+                                                                                     x_main, ld_main, x_tail, ld_tail);
+    TFGX_LAUNCH_CHECK("split_rows_kernel");
     return TFGX_OK;
 }

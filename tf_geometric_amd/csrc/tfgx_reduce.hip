@@ -78,9 +78,12 @@ struct KArgs {
     int64_t ld_add;
     const int32_t* mean_count;
     int32_t hub_threshold;   // > 0: rows with more edges than this are left to the hub path
+    const float* x_tail;     // split source rows: columns >= f_main live in x_tail[n_src, ld_tail] (see tfgx.h)
+    int64_t ld_tail;
+    int32_t f_main;
 };
 
-template <int VEC, int G, int CH, bool IS_MAX, bool WEIGHTED>
+template <int VEC, int G, int CH, bool IS_MAX, bool WEIGHTED, bool SPLIT = false>
 __global__ __launch_bounds__(kBlock) void seg_reduce_kernel(const KArgs a)
 {
     constexpr int UNROLL = (CH >= 4) ? 2 : (CH == 2 ? 4 : 8);  // independent row loads in flight per lane
@@ -98,6 +101,21 @@ __global__ __launch_bounds__(kBlock) void seg_reduce_kernel(const KArgs a)
         const int c = colbase + (k * G + lane) * VEC;
         cvalid[k] = c < a.F;
         coff[k] = cvalid[k] ? c : (a.F - VEC);
+    }
+    // per-lane source base / stride: one array normally; with SPLIT the lanes owning columns >= f_main read the
+    // narrow tail array (whole 128-byte lines of the main array carry no unused bytes then)
+    const float* xb[CH];
+    int64_t xl[CH];
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+        xb[k] = a.x + coff[k];
+        xl[k] = a.ldx;
+        if constexpr (SPLIT) {
+            if (coff[k] >= a.f_main) {
+                xb[k] = a.x_tail + (coff[k] - a.f_main);
+                xl[k] = a.ld_tail;
+            }
+        }
     }
     const float init = IS_MAX ? -FLT_MAX : 0.0f;
 
@@ -133,9 +151,11 @@ __global__ __launch_bounds__(kBlock) void seg_reduce_kernel(const KArgs a)
                 for (int u = 0; u < UNROLL; ++u) {
                     const int c = bcast_i<G>(cj, j + u);
                     if constexpr (WEIGHTED) ww[u] = bcast_f<G>(wj, j + u);
-                    const float* xr = a.x + int64_t(c) * a.ldx;
 #pragma unroll
-                    for (int k = 0; k < CH; ++k) load_vec<VEC>(xr + coff[k], xv[u][k]);
+                    for (int k = 0; k < CH; ++k) {
+                        if constexpr (SPLIT) load_vec<VEC>(xb[k] + int64_t(c) * xl[k], xv[u][k]);
+                        else load_vec<VEC>(a.x + int64_t(c) * a.ldx + coff[k], xv[u][k]);
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < UNROLL; ++u)
@@ -155,11 +175,11 @@ __global__ __launch_bounds__(kBlock) void seg_reduce_kernel(const KArgs a)
                 const int c = bcast_i<G>(cj, j);
                 float wv = 1.0f;
                 if constexpr (WEIGHTED) wv = bcast_f<G>(wj, j);
-                const float* xr = a.x + int64_t(c) * a.ldx;
 #pragma unroll
                 for (int k = 0; k < CH; ++k) {
                     float xv[VEC];
-                    load_vec<VEC>(xr + coff[k], xv);
+                    if constexpr (SPLIT) load_vec<VEC>(xb[k] + int64_t(c) * xl[k], xv);
+                    else load_vec<VEC>(a.x + int64_t(c) * a.ldx + coff[k], xv);
 #pragma unroll
                     for (int v = 0; v < VEC; ++v) {
                         if constexpr (IS_MAX) {
@@ -195,7 +215,8 @@ __global__ __launch_bounds__(kBlock) void seg_reduce_kernel(const KArgs a)
             }
             if (a.self_coef) {
                 float xs[VEC];
-                load_vec<VEC>(a.x + r * a.ldx + coff[k], xs);
+                if constexpr (SPLIT) load_vec<VEC>(xb[k] + r * xl[k], xs);
+                else load_vec<VEC>(a.x + r * a.ldx + coff[k], xs);
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) {
                     if constexpr (IS_MAX) res[v] = fmaxf(res[v], sc * xs[v]);
@@ -231,6 +252,23 @@ int launch_cfg(const KArgs& a, bool is_max, bool weighted, int ny, hipStream_t s
     constexpr int ROWS_PER_BLOCK = kBlock / G;
     dim3 grid(grid_for(a.n_dst, ROWS_PER_BLOCK, 1 << 20), ny, 1);
     dim3 block(kBlock, 1, 1);
+    if constexpr (VEC == 4 && CH == 1) {
+        if (a.x_tail != nullptr) {   // split rows: sum / mean only (the case that matters: 400-byte rows)
+            if (is_max) {
+                if (weighted) seg_reduce_kernel<VEC, G, CH, true, true, true><<<grid, block, 0, stream>>>(a);
+                else seg_reduce_kernel<VEC, G, CH, true, false, true><<<grid, block, 0, stream>>>(a);
+            } else {
+                if (weighted) seg_reduce_kernel<VEC, G, CH, false, true, true><<<grid, block, 0, stream>>>(a);
+                else seg_reduce_kernel<VEC, G, CH, false, false, true><<<grid, block, 0, stream>>>(a);
+            }
+            TFGX_LAUNCH_CHECK("seg_reduce_kernel<split>");
+            return TFGX_OK;
+        }
+    }
+    if (a.x_tail != nullptr) {
+        set_error("tfgx_segment_reduce_f32: x_tail needs 16-byte aligned rows and F <= 256");
+        return TFGX_ERR_INVALID_ARG;
+    }
     if (is_max) {
         if (weighted) seg_reduce_kernel<VEC, G, CH, true, true><<<grid, block, 0, stream>>>(a);
         else seg_reduce_kernel<VEC, G, CH, true, false><<<grid, block, 0, stream>>>(a);
@@ -324,7 +362,7 @@ extern "C" int tfgx_segment_reduce_f32(const tfgx_reduce_args* p, tfgx_stream_t 
     TFGX_REQUIRE(p->act == TFGX_ACT_NONE || p->act == TFGX_ACT_RELU, "bad act");
     if (p->n_dst == 0) return TFGX_OK;
     TFGX_REQUIRE(p->row_begin && p->row_end && p->out && p->x, "null pointer");
-    TFGX_REQUIRE(p->ldx >= p->F && p->ldo >= p->F, "leading dimension < F");
+    TFGX_REQUIRE((p->ldx >= p->F || p->x_tail) && p->ldo >= p->F, "leading dimension < F");
     TFGX_REQUIRE(p->rp_stride >= 1, "rp_stride < 1");
     TFGX_REQUIRE(!(p->add_x) || p->ld_add >= p->F, "ld_add < F");
 
@@ -335,6 +373,13 @@ extern "C" int tfgx_segment_reduce_f32(const tfgx_reduce_args* p, tfgx_stream_t 
     a.self_coef = p->self_coef; a.bias = p->bias; a.add_x = p->add_x; a.ld_add = p->ld_add;
     a.mean_count = p->mean_count;
     a.hub_threshold = 0;
+    a.x_tail = p->x_tail; a.ld_tail = p->ld_tail; a.f_main = int32_t(p->f_main);
+    if (p->x_tail) {
+        TFGX_REQUIRE(p->f_main > 0 && p->f_main < p->F && p->f_main % 4 == 0 && (p->F - p->f_main) % 4 == 0 &&
+                         p->ld_tail >= p->F - p->f_main && p->ld_tail % 4 == 0 && p->ldx >= p->f_main &&
+                         aligned_to(p->x_tail, 16),
+                     "bad split-row layout (f_main / ld_tail / alignment)");
+    }
     const bool use_hub = p->hub_threshold > 0 && p->n_hub_rows > 0;
     if (use_hub) {
         TFGX_REQUIRE(p->hub_rows && p->hub_chunk_ptr && p->hub_chunk_begin && p->hub_chunk_end && p->hub_scratch &&

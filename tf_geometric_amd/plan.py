@@ -92,37 +92,92 @@ class CsrPlan(object):
         Small control-plane metadata, computed once per plan: (hub_rows, chunk_ptr, chunk_begin, chunk_end)."""
         if self._hub is None:
             deg = self.in_degree()
-            hub_rows = torch.nonzero(deg > HUB_THRESHOLD).flatten().to(torch.int32)
+            thr, chunk = hub_policy(self.num_edges, self.n_dst)
+            self.hub_threshold = thr
+            hub_rows = torch.nonzero(deg > thr).flatten().to(torch.int32)
+            hub_chunk = chunk
             if hub_rows.numel() == 0:
                 self._hub = False
             else:
                 rows64 = hub_rows.to(torch.int64)
                 start = self.row_ptr[rows64].to(torch.int64)
                 d = deg[rows64].to(torch.int64)
-                n_chunks = (d + HUB_CHUNK - 1) // HUB_CHUNK
+                n_chunks = (d + hub_chunk - 1) // hub_chunk
                 chunk_ptr = torch.zeros(hub_rows.numel() + 1, dtype=torch.int64, device=deg.device)
                 chunk_ptr[1:] = torch.cumsum(n_chunks, 0)
                 total = int(chunk_ptr[-1].item())
                 owner = torch.repeat_interleave(torch.arange(hub_rows.numel(), device=deg.device), n_chunks)
                 k = torch.arange(total, device=deg.device) - chunk_ptr[owner]
-                begin = start[owner] + k * HUB_CHUNK
-                end = torch.minimum(begin + HUB_CHUNK, start[owner] + d[owner])
+                begin = start[owner] + k * hub_chunk
+                end = torch.minimum(begin + hub_chunk, start[owner] + d[owner])
                 self._hub = (hub_rows.contiguous(), chunk_ptr.to(torch.int32).contiguous(),
                              begin.to(torch.int32).contiguous(), end.to(torch.int32).contiguous())
         return self._hub or None
 
 
-HUB_THRESHOLD = 2048   # rows with more in-edges than this take the chunked path of tfgx_segment_reduce_f32
-HUB_CHUNK = 1024       # edges per chunk
+HUB_THRESHOLD = None   # override (tools/bench_sweep.py): rows with more in-edges than this take the chunked path
+HUB_CHUNK = None       # override: edges per chunk
+
+
+def hub_policy(num_edges, n_dst):
+    """(threshold, chunk) for the chunked hub path of tfgx_segment_reduce_f32.
+
+    A row is walked sequentially by ONE lane group, so on skewed graphs long rows become a latency-bound tail
+    (R-MAT 2^21 nodes / 61 M edges, measured on MI355X: threshold 2048 -> 9.9 ms, 512 -> 5.2 ms, 128 -> 4.8 ms).
+    Rows above ~4x the average in-degree are therefore cut into chunks; on near-regular graphs (uniform products /
+    Reddit shapes) no row exceeds that and the path is never taken."""
+    if HUB_THRESHOLD is not None:
+        return int(HUB_THRESHOLD), int(HUB_CHUNK or max(HUB_THRESHOLD // 2, 64))
+    avg = float(num_edges) / max(int(n_dst), 1)
+    thr = 128
+    while thr < 4.0 * avg and thr < 2048:
+        thr *= 2
+    return thr, max(128, thr // 2)
+
+
+class SplitRows(object):
+    """Source rows stored as main[n, f_main] (f_main a multiple of 32 floats: whole 128-byte lines) + tail[n, F-f_main].
+    A 400-byte row (F = 100) at a 400-byte stride always straddles FOUR 128-byte lines (512 bytes fetched); split,
+    the gather fetches three full lines from HBM and 16 bytes from a 38 MB array that stays cache-resident."""
+
+    def __init__(self, main, tail):
+        self.main, self.tail = main, tail
+        self.shape = (int(main.shape[0]), int(main.shape[1]) + int(tail.shape[1]))
+        self.device = main.device
+
+    @staticmethod
+    def wanted(n, F):
+        """Split only when it removes over-fetch: F not a multiple of 32, a 4..28-float tail, and a feature matrix
+        far larger than the caches (otherwise the single array is already cache-resident)."""
+        return F % 4 == 0 and F > 32 and F % 32 != 0 and F <= 128 and n * F * 4 > (512 << 20)
+
+    @staticmethod
+    def from_dense(x, out=None):
+        lib = L.require_gpu()
+        x, ldx = L.row_major_2d(x)
+        n, F = int(x.shape[0]), int(x.shape[1])
+        f_main = (F // 32) * 32
+        if out is None:
+            out = SplitRows(torch.empty((n, f_main), dtype=torch.float32, device=x.device),
+                            torch.empty((n, F - f_main), dtype=torch.float32, device=x.device))
+        L.check(lib.tfgx_split_rows_f32(L.ptr(x), ldx, n, F, f_main, L.ptr(out.main), f_main, L.ptr(out.tail),
+                                        F - f_main, L.stream_ptr()), "tfgx_split_rows_f32")
+        return out
 
 
 def segment_reduce(plan, x, op, w_csr=None, out=None, act=L.ACT_NONE, self_coef=None, bias=None, add_x=None,
                    accumulate=False, mean_count=None, row_begin=None, row_end=None, rp_stride=1, col=None,
                    n_dst=None):
-    """One launch of tfgx_segment_reduce_f32 on `plan` (or on explicit row_begin/row_end/col views of it)."""
+    """One launch of tfgx_segment_reduce_f32 on `plan` (or on explicit row_begin/row_end/col views of it).
+    `x` is a dense [n_src, F] tensor or a SplitRows."""
     lib = L.require_gpu()
-    x, ldx = L.row_major_2d(x)
-    F = int(x.shape[1])
+    split = x if isinstance(x, SplitRows) else None
+    if split is not None:
+        x, ldx = L.row_major_2d(split.main)
+        F = split.shape[1]
+    else:
+        x, ldx = L.row_major_2d(x)
+        F = int(x.shape[1])
     n_dst = plan.n_dst if n_dst is None else int(n_dst)
     if out is None:
         out = torch.empty((n_dst, F), dtype=torch.float32, device=x.device)
@@ -153,11 +208,13 @@ def segment_reduce(plan, x, op, w_csr=None, out=None, act=L.ACT_NONE, self_coef=
         a.add_x = add_x.data_ptr()
         a.ld_add = ld_add
     a.mean_count = 0 if mean_count is None else mean_count.data_ptr()
+    if split is not None:
+        a.x_tail, a.ld_tail, a.f_main = split.tail.data_ptr(), int(split.tail.shape[1]), int(split.main.shape[1])
     hub = plan.hub_info() if (row_begin is None and row_end is None and col is None) else None
     if hub is not None:
         hub_rows, chunk_ptr, chunk_begin, chunk_end = hub
         scratch = torch.empty((int(chunk_begin.shape[0]), F), dtype=torch.float32, device=x.device)
-        a.hub_threshold = HUB_THRESHOLD
+        a.hub_threshold = plan.hub_threshold
         a.hub_rows, a.hub_chunk_ptr = hub_rows.data_ptr(), chunk_ptr.data_ptr()
         a.hub_chunk_begin, a.hub_chunk_end = chunk_begin.data_ptr(), chunk_end.data_ptr()
         a.n_hub_rows, a.n_hub_chunks = int(hub_rows.shape[0]), int(chunk_begin.shape[0])

@@ -50,13 +50,15 @@ def rmat_edges(scale, num_edges, seed=0, a=0.57, b=0.19, c=0.19):
 
 def main():
     quick = "--quick" in sys.argv
+    only = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--only=")]
+    want = lambda name: (not only) or (name in only[0].split(","))
     torch.cuda.set_device(0)
     n, e = (2400000, 123000000) if not quick else (300000, 15000000)
     ei = L.as_i32(synthetic.synthetic_edges(n, e, seed=0))
     E = int(ei.shape[1])
     plan = CsrPlan.build(ei, n, n)
     w = torch.rand(E, device="cuda") + 0.5
-    for f in [16, 32, 64, 96, 100, 104, 128, 192, 256]:
+    for f in ([16, 32, 64, 96, 100, 104, 128, 192, 256] if want("widths") else []):
         x = torch.randn(n, f, device="cuda")
         out = torch.empty_like(x)
         for name, op, ww in [("sum_w", L.SUM, w), ("sum", L.SUM, None), ("max", L.MAX, None)]:
@@ -68,6 +70,31 @@ def main():
                               "ms": ms, "GBps_alg": balg / ms / 1e6, "frac_of_8TBps": balg / ms / 1e6 / 8000,
                               "Gedges_per_s": E / ms / 1e6}), flush=True)
         del x, out
+    if want("split"):
+        from tf_geometric_amd.plan import SplitRows
+        for f in [100, 104, 72]:
+            x = torch.randn(n, f, device="cuda")
+            out = torch.empty_like(x)
+            sp = SplitRows.from_dense(x)
+            balg = E * (4 * f + 8) + n * 4 * f + 4 * (n + 1)
+            ms_d = timeit(lambda: segment_reduce(plan, x, L.SUM, w_csr=w, out=out))
+            ms_k = timeit(lambda: segment_reduce(plan, sp, L.SUM, w_csr=w, out=out))
+            ms_c = timeit(lambda: SplitRows.from_dense(x, out=sp))
+            ms_b = timeit(lambda: segment_reduce(plan, SplitRows.from_dense(x, out=sp), L.SUM, w_csr=w, out=out))
+            print(json.dumps({"kind": "split_rows", "F": f, "dense_ms": ms_d, "split_kernel_ms": ms_k,
+                              "split_convert_ms": ms_c, "convert_plus_kernel_ms": ms_b,
+                              "frac_dense": balg / ms_d / 8e9, "frac_split_kernel": balg / ms_k / 8e9,
+                              "frac_convert_plus_kernel": balg / ms_b / 8e9}), flush=True)
+            del x, out, sp
+    if want("rmat"):
+        rmat_section(quick, e)
+    if want("gemm"):
+        gemm_section(n)
+    if want("gat"):
+        gat_section(plan, n, E)
+
+
+def rmat_section(quick, e):
     # skewed graph (R-MAT): hub rows take the chunked path
     scale = 21 if not quick else 18
     ei_r = rmat_edges(scale, e // 2 if not quick else e // 4, seed=1)
@@ -85,6 +112,26 @@ def main():
                       "hub_chunks": 0 if hub is None else int(hub[2].shape[0]), "ms": ms,
                       "GBps_alg": balg / ms / 1e6, "frac_of_8TBps": balg / ms / 1e6 / 8000,
                       "Gedges_per_s": Er / ms / 1e6}), flush=True)
+    # hub threshold / chunk size sweep + degree histogram
+    import tf_geometric_amd.plan as P
+    hist = torch.histc(torch.log2(deg.float().clamp(min=1)), bins=18, min=0, max=18).long().tolist()
+    edges_by_bin = []
+    lg = torch.log2(deg.float().clamp(min=1)).floor().long().clamp(max=17)
+    eb = torch.zeros(18, dtype=torch.int64, device="cuda").index_add_(0, lg, deg.long())
+    print(json.dumps({"kind": "rmat_degree_hist_log2", "rows": hist, "edges": eb.tolist()}), flush=True)
+    for thr, chunk in [(128, 128), (256, 256), (512, 256), (512, 512), (1024, 512), (2048, 1024), (8192, 1024), (1 << 30, 1024)]:
+        P.HUB_THRESHOLD, P.HUB_CHUNK = thr, chunk
+        plan_r._hub = None
+        ms = timeit(lambda: segment_reduce(plan_r, x, L.SUM, w_csr=wr, out=out))
+        hub = plan_r.hub_info()
+        print(json.dumps({"kind": "rmat_hub_sweep", "threshold": thr, "chunk": chunk, "ms": ms,
+                          "hub_rows": 0 if hub is None else int(hub[0].shape[0]),
+                          "hub_chunks": 0 if hub is None else int(hub[2].shape[0]), "Gedges_per_s": Er / ms / 1e6}),
+              flush=True)
+    P.HUB_THRESHOLD, P.HUB_CHUNK = None, None
+    plan_r._hub = None
+    hub = plan_r.hub_info()
+    segment_reduce(plan_r, x, L.SUM, w_csr=wr, out=out)
     # parity of the hub path against a float64 torch reference on the hub rows
     if hub is not None:
         rows = hub[0][:4].long()
@@ -97,7 +144,9 @@ def main():
         print(json.dumps({"kind": "hub_parity", "max_abs_err": float((got - ref).abs().max()),
                           "max_abs_ref": float(ref.abs().max())}), flush=True)
     del x, out
-    # GEMM
+
+
+def gemm_section(n):
     for (m, k, nn) in [(n, 100, 256), (n, 100, 128), (n, 128, 256), (n, 100, 64), (n, 256, 128), (n, 100, 16),
                        (233000, 602, 64), (2708 * 64, 1433, 16)]:
         a = torch.randn(m, k, device="cuda")
@@ -108,6 +157,9 @@ def main():
         print(json.dumps({"kind": "gemm", "M": m, "K": k, "N": nn, "ms": ms, "TFLOPs": 2.0 * m * k * nn / ms / 1e9,
                           "GBps": 4.0 * (m * k + m * nn) / ms / 1e6, "torch_matmul_ms": ms_t}), flush=True)
         del a, b, c
+
+
+def gat_section(plan, n, E):
     # fused GAT attention (demo-literal H=8, A=8, U=64 and the heavy A=64 variant)
     for (H, A, U) in [(8, 8, 64), (8, 64, 64), (1, 8, 64)]:
         Q = torch.randn(n, A, device="cuda")
