@@ -163,9 +163,36 @@ typedef struct tfgx_gat_args {
     float scale;                   /* sqrt(d) (gat.py:78) */
     int32_t act;
     const float* bias;             /* [H*dv] or NULL */
+    /* optional: explicit row spans (as in tfgx_reduce_args); NULL row_begin = plain row_ptr */
+    const int32_t* row_begin;
+    const int32_t* row_end;
+    int64_t rp_stride;
+    /* optional raw-state output: when non-NULL the kernel writes, per destination row, the un-normalised online
+       softmax state acc[H*dv] and (m, l)[H] over the given edge span and does NOT add the self-loop; several such
+       passes over disjoint edge spans (local / halo halves of a split plan) are combined by
+       tfgx_gat_merge_passes_f32. */
+    float* state_acc;              /* [n_dst, H*dv] */
+    float* state_ml;               /* [n_dst, 2*H]  */
+    /* hub rows (as in tfgx_reduce_args) + the destination of every chunk and two scratch arrays */
+    int32_t hub_threshold;
+    int32_t reserved;
+    const int32_t* hub_rows;
+    const int32_t* hub_chunk_ptr;
+    const int32_t* hub_chunk_begin;
+    const int32_t* hub_chunk_end;
+    const int32_t* hub_chunk_row;  /* [n_hub_chunks] destination id of each chunk */
+    int64_t n_hub_rows;
+    int64_t n_hub_chunks;
+    float* hub_scratch_acc;        /* [n_hub_chunks, H*dv] */
+    float* hub_scratch_ml;         /* [n_hub_chunks, 2*H]  */
 } tfgx_gat_args;
 
 int tfgx_gat_fused_f32(const tfgx_gat_args* args /* host */, tfgx_stream_t stream);
+
+/* out[r] = softmax-merge of n_passes raw states (pass t of row r at index t*n_dst + r) + self-loop edge + bias + act;
+   q/k/v/out/H/d/dv/scale/add_self_loop/act/bias/n_dst are read from args */
+int tfgx_gat_merge_passes_f32(const tfgx_gat_args* args /* host */, const float* state_acc, const float* state_ml,
+                              int32_t n_passes, tfgx_stream_t stream);
 
 /* out[r, j] = (1/H) * sum_h in[r, h*U + j]  (+ bias[j], act)   — gat.py:114-120, split_value_heads=False */
 int tfgx_head_mean_f32(const float* in, int64_t ld_in, int64_t n, int32_t H, int32_t U, const float* bias,

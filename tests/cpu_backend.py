@@ -142,3 +142,51 @@ class NumpyBackend(object):
             out.copy_(res)
             return out
         return res
+
+    def gat_pass(self, row_begin, row_end, rp_stride, col, n_dst, Q, K, V, num_heads, state_acc, state_ml):
+        rb, re, c = _np(row_begin), _np(row_end), _np(col)
+        q, k, v = _np(Q).astype(np.float64), _np(K).astype(np.float64), _np(V).astype(np.float64)
+        H = num_heads
+        d, dv = q.shape[1] // H, v.shape[1] // H
+        acc, ml = _np(state_acc), _np(state_ml)
+        for r in range(n_dst):
+            s, e = int(rb[r * rp_stride]), int(re[r * rp_stride])
+            cols = c[s:e]
+            for h in range(H):
+                if e == s:
+                    acc[r, h * dv:(h + 1) * dv] = 0
+                    ml[r, 2 * h], ml[r, 2 * h + 1] = FLT_LOWEST, 0.0
+                    continue
+                sc = (k[cols, h * d:(h + 1) * d] @ q[r, h * d:(h + 1) * d]) / np.sqrt(d)
+                m = sc.max()
+                p = np.exp(sc - m)
+                acc[r, h * dv:(h + 1) * dv] = (p[:, None] * v[cols, h * dv:(h + 1) * dv]).sum(0)
+                ml[r, 2 * h], ml[r, 2 * h + 1] = m, p.sum()
+
+    def gat_merge(self, Q, K, V, num_heads, n_dst, state_acc, state_ml, n_passes, bias, act, out):
+        q, k, v = _np(Q).astype(np.float64), _np(K).astype(np.float64), _np(V).astype(np.float64)
+        acc, ml = _np(state_acc).astype(np.float64), _np(state_ml).astype(np.float64)
+        H = num_heads
+        d, dv = q.shape[1] // H, v.shape[1] // H
+        o = _np(out)
+        for r in range(n_dst):
+            for h in range(H):
+                s_self = (q[r, h * d:(h + 1) * d] @ k[r, h * d:(h + 1) * d]) / np.sqrt(d)
+                ms = [ml[t * n_dst + r, 2 * h] for t in range(n_passes)]
+                ls = [ml[t * n_dst + r, 2 * h + 1] for t in range(n_passes)]
+                M = max([s_self] + [m for m, l in zip(ms, ls) if l > 0])
+                L_ = np.exp(s_self - M)
+                O = L_ * v[r, h * dv:(h + 1) * dv]
+                for t in range(n_passes):
+                    if ls[t] > 0:
+                        cf = np.exp(ms[t] - M)
+                        L_ += ls[t] * cf
+                        O = O + acc[t * n_dst + r, h * dv:(h + 1) * dv] * cf
+                o[r, h * dv:(h + 1) * dv] = O / (L_ + 1e-8)
+        res = o.astype(np.float64)
+        if bias is not None:
+            res = res + _np(bias)
+        if act == 1:
+            res = np.maximum(res, 0)
+        out.copy_(torch.from_numpy(res.astype(np.float32)))
+        return out

@@ -29,6 +29,13 @@ def make_inputs(n=400, e=5000, f=12, seed=0, skew=False):
     return ei, x, w, k, b
 
 
+def gat_weights():
+    from oracle import tfg_oracle as oracle
+    rng = np.random.Generator(np.random.PCG64(77))
+    return (oracle.glorot_uniform(rng, 12, 6), oracle.glorot_uniform(rng, 12, 6), oracle.glorot_uniform(rng, 12, 8),
+            (rng.standard_normal(6) * 0.2).astype(np.float32))
+
+
 def run_checks(rank, world, use_gpu, skew, results):
     """Build the shard, run sharded GCN / mean / max / sum and return this rank's rows (as numpy)."""
     from tf_geometric_amd.dist.sharded import ShardedGraph
@@ -50,6 +57,9 @@ def run_checks(rank, world, use_gpu, skew, results):
     out["mean"] = sg.neighbor_reduce(x_own, 1).cpu().numpy()
     out["max"] = sg.neighbor_reduce(x_own, 2).cpu().numpy()
     out["sum_unweighted"] = sg.neighbor_reduce(x_own, 0, weighted=False).cpu().numpy()
+    wq, wk, wv, bq = gat_weights()
+    out["gat"] = sg.gat(x_own, be.f32(wq), be.f32(bq), 1, be.f32(wk), be.f32(bq), 1, be.f32(wv), bias=be.f32(b[:8]),
+                        act=1, num_heads=2).cpu().numpy()
     sg2 = ShardedGraph.from_global(ei, n, edge_weight=None, group=group, backend=backend)
     sg2.build_gcn_norm(norm="left", improved=True)
     out["gcn_left_improved_unweighted"] = sg2.gcn(x_own, be.f32(k)).cpu().numpy()
@@ -88,6 +98,8 @@ def reference(skew):
         "sum_unweighted": oracle.aggregate_neighbors(x, ei, None, oracle.identity_mapper, oracle.sum_reducer,
                                                      oracle.identity_updater),
         "gcn_left_improved_unweighted": oracle.gcn(x, ei, None, k, norm="left", improved=True),
+        "gat": oracle.gat(x, ei, gat_weights()[0], gat_weights()[3], "relu", gat_weights()[1], gat_weights()[3], "relu",
+                          gat_weights()[2], b[:8], "relu", num_heads=2),
     }
 
 

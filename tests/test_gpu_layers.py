@@ -205,3 +205,25 @@ def test_golden_fixtures_through_hip(tfg, oracle):
                                          normalize=True).cpu().numpy(), g["sage_out"], what="golden sage")
     assert_parity(tfg.nn.gat(x, ei, g["gat_wq"], g["gat_bq"], tfg.relu, g["gat_wk"], g["gat_bk"], tfg.relu, g["gat_wv"],
                              g["gat_b"], tfg.relu, num_heads=4).cpu().numpy(), g["gat_out"], what="golden gat")
+
+
+def test_gat_hub_rows_chunked_merge(tfg, oracle):
+    """A destination with 6000 in-edges (and one with 700) takes the chunk + merge path; results match the oracle."""
+    n, f = 1500, 10
+    rng = np.random.Generator(np.random.PCG64(91))
+    x = rng.standard_normal((n, f), dtype=np.float32)
+    hub1 = np.stack([np.full(6000, 7, np.int32), rng.integers(0, n, 6000, dtype=np.int32)])
+    hub2 = np.stack([np.full(700, 1200, np.int32), rng.integers(0, n, 700, dtype=np.int32)])
+    ei = np.concatenate([hub1, oracle.synthetic_edges(n, 6000, seed=5), hub2], axis=1).astype(np.int32)
+    from tf_geometric_amd.plan import CsrPlan
+    plan = CsrPlan.build(ei, n, n)
+    assert plan.hub_info() is not None and int(plan.hub_info()[0].shape[0]) >= 2
+    for heads, att, units in [(4, 8, 16), (1, 3, 5), (2, 32, 8)]:
+        wq, wk = oracle.glorot_uniform(rng, f, att), oracle.glorot_uniform(rng, f, att)
+        bq = (rng.standard_normal(att) * 0.2).astype(np.float32)
+        wv = oracle.glorot_uniform(rng, f, units)
+        b = (rng.standard_normal(units) * 0.1).astype(np.float32)
+        got = tfg.nn.gat(x, ei, wq, bq, tfg.relu, wk, bq, tfg.relu, wv, b, tfg.relu, num_heads=heads,
+                         cache={"tfgx_csr_plan": plan}).cpu().numpy()
+        ref = oracle.gat(x, ei, wq, bq, "relu", wk, bq, "relu", wv, b, "relu", num_heads=heads)
+        assert_parity(got, ref, tol=2e-5, what="GAT hub H={}".format(heads))

@@ -53,6 +53,13 @@ class GatArgs(ctypes.Structure):
         ("out", ctypes.c_void_p), ("ldo", ctypes.c_int64),
         ("H", ctypes.c_int32), ("d", ctypes.c_int32), ("dv", ctypes.c_int32), ("add_self_loop", ctypes.c_int32),
         ("scale", ctypes.c_float), ("act", ctypes.c_int32), ("bias", ctypes.c_void_p),
+        ("row_begin", ctypes.c_void_p), ("row_end", ctypes.c_void_p), ("rp_stride", ctypes.c_int64),
+        ("state_acc", ctypes.c_void_p), ("state_ml", ctypes.c_void_p),
+        ("hub_threshold", ctypes.c_int32), ("reserved", ctypes.c_int32),
+        ("hub_rows", ctypes.c_void_p), ("hub_chunk_ptr", ctypes.c_void_p), ("hub_chunk_begin", ctypes.c_void_p),
+        ("hub_chunk_end", ctypes.c_void_p), ("hub_chunk_row", ctypes.c_void_p),
+        ("n_hub_rows", ctypes.c_int64), ("n_hub_chunks", ctypes.c_int64),
+        ("hub_scratch_acc", ctypes.c_void_p), ("hub_scratch_ml", ctypes.c_void_p),
     ]
 
 
@@ -69,6 +76,7 @@ SIGNATURES = {
     "tfgx_gcn_norm_edges_f32": (ctypes.c_int, [_P, _P, _P, _I64, _P, _P, _I32, _F32, _I32, _I32, _P, _P, _P]),
     "tfgx_edge_softmax_f32": (ctypes.c_int, [_P, _P, _P, _I64, _I64, _P, _P]),
     "tfgx_gat_fused_f32": (ctypes.c_int, [ctypes.POINTER(GatArgs), _P]),
+    "tfgx_gat_merge_passes_f32": (ctypes.c_int, [ctypes.POINTER(GatArgs), _P, _P, _I32, _P]),
     "tfgx_head_mean_f32": (ctypes.c_int, [_P, _I64, _I64, _I32, _I32, _P, _I32, _P, _I64, _P]),
     "tfgx_gemm_bias_act_f32": (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I32, _P, _I64, _I64, _I64, _I64, _P]),
     "tfgx_l2_normalize_rows_f32": (ctypes.c_int, [_P, _I64, _I64, _I64, _P]),

@@ -90,6 +90,17 @@ struct GArgs {
     int32_t act;
     const float* bias;
     int32_t kvec;         // 1: K/Q head slices are 16-byte aligned and d % 4 == 0
+    // parts: "row" p of the launch spans CSR positions [row_begin[p*rp_stride], row_end[p*rp_stride]) and belongs to
+    // destination part_row[p] (NULL: p). state_acc != NULL: write the raw online-softmax state (acc, m, l) of the
+    // part instead of the normalised output — chunks of hub rows and the two passes of a split plan are merged by
+    // gat_merge_kernel.
+    const int32_t* row_begin;
+    const int32_t* row_end;
+    int64_t rp_stride;
+    const int32_t* part_row;
+    float* state_acc;     // [n_parts, W]
+    float* state_ml;      // [n_parts, 2H]  (m, l) per head
+    int32_t hub_threshold;
 };
 
 // D > 0: compile-time head width (Q slice lives in registers); D == 0: runtime d, Q re-read (cache-hot)
@@ -136,7 +147,10 @@ __global__ __launch_bounds__(kBlock) void gat_fused_kernel(const GArgs a)
 
     for (int64_t r = int64_t(blockIdx.x) * ROWS_PER_BLOCK + grp; r < a.n_dst;
          r += int64_t(gridDim.x) * ROWS_PER_BLOCK) {
-        const int s = a.row_ptr[r], e = a.row_ptr[r + 1];
+        const int64_t part = r;
+        const int s = a.row_begin[part * a.rp_stride], e = a.row_end[part * a.rp_stride];
+        if (a.hub_threshold > 0 && e - s > a.hub_threshold) continue;   // chunked + merged separately
+        if (a.part_row) r = a.part_row[part];
         const float* qp = a.q + r * a.ldq + hoff;
         float qreg[D > 0 ? D : 1];
         if constexpr (D > 0) {
@@ -183,6 +197,17 @@ __global__ __launch_bounds__(kBlock) void gat_fused_kernel(const GArgs a)
                 step(sc, vv);
             }
         }
+        if (a.state_acc) {      // raw state of this part; the self-loop edge is added by the merge
+            if (cvalid) {
+                store_vec<VEC>(a.state_acc + part * a.W + coff, acc);
+                if (coff % a.dv == 0) {
+                    a.state_ml[part * 2 * a.H + 2 * head] = m;
+                    a.state_ml[part * 2 * a.H + 2 * head + 1] = l;
+                }
+            }
+            r = part;           // restore the loop variable
+            continue;
+        }
         if (a.add_self_loop) {  // the appended (r, r) edge comes last (graph_utils.py:350-366)
             const float sc = head_dot<D>(qreg, qp, a.k + r * a.ldk + hoff, a.d, a.kvec) / a.scale;
             float vv[VEC];
@@ -200,6 +225,72 @@ __global__ __launch_bounds__(kBlock) void gat_fused_kernel(const GArgs a)
             }
             store_vec<VEC>(a.out + r * a.ldo + coff, res);
         }
+        r = part;
+    }
+}
+
+// Merge the raw states of a destination's parts (hub chunks: parts [part_ptr[i], part_ptr[i+1]); split-plan passes:
+// parts {t * n_rows + i}), append the self-loop edge, normalise, bias, activation.  One thread per (row, column).
+struct GMerge {
+    const float* state_acc;
+    const float* state_ml;
+    const int32_t* rows;       // [n_merge] destination ids, or NULL (identity)
+    const int32_t* part_ptr;   // [n_merge+1] or NULL (-> fixed_parts passes with stride n_rows)
+    int32_t fixed_parts;
+    int64_t n_rows;            // stride between passes when part_ptr == NULL
+    int64_t n_merge;
+    const float* q; int64_t ldq;
+    const float* k; int64_t ldk;
+    const float* v; int64_t ldv;
+    float* out; int64_t ldo;
+    int32_t H, d, dv, W;
+    int32_t add_self_loop;
+    float scale;
+    int32_t act;
+    const float* bias;
+};
+
+__global__ __launch_bounds__(kBlock) void gat_merge_kernel(const GMerge g)
+{
+    int64_t t = blockIdx.x * int64_t(kBlock) + threadIdx.x;
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    const int64_t total = g.n_merge * g.W;
+    for (; t < total; t += stride) {
+        const int64_t i = t / g.W;
+        const int j = int(t - i * g.W);
+        const int h = j / g.dv;
+        const int64_t r = g.rows ? g.rows[i] : i;
+        const int np = g.part_ptr ? (g.part_ptr[i + 1] - g.part_ptr[i]) : g.fixed_parts;
+        float s_self = -FLT_MAX;
+        if (g.add_self_loop) {
+            const float* qp = g.q + r * g.ldq + h * g.d;
+            const float* kp = g.k + r * g.ldk + h * g.d;
+            float dot = 0.0f;
+            for (int u = 0; u < g.d; ++u) dot = fmaf(qp[u], kp[u], dot);
+            s_self = dot / g.scale;
+        }
+        float M = s_self;
+        for (int p = 0; p < np; ++p) {
+            const int64_t part = g.part_ptr ? (g.part_ptr[i] + p) : (int64_t(p) * g.n_rows + i);
+            M = fmaxf(M, g.state_ml[part * 2 * g.H + 2 * h]);
+        }
+        float Lsum = 0.0f, O = 0.0f;
+        for (int p = 0; p < np; ++p) {
+            const int64_t part = g.part_ptr ? (g.part_ptr[i] + p) : (int64_t(p) * g.n_rows + i);
+            const float mp = g.state_ml[part * 2 * g.H + 2 * h];
+            const float lp = g.state_ml[part * 2 * g.H + 2 * h + 1];
+            const float c = (lp > 0.0f) ? expf(mp - M) : 0.0f;     // an empty part holds (m, l) = (-FLT_MAX, 0)
+            Lsum = fmaf(lp, c, Lsum);
+            O = fmaf(g.state_acc[part * g.W + j], c, O);
+        }
+        if (g.add_self_loop) {
+            const float c = expf(s_self - M);
+            Lsum += c;
+            O = fmaf(c, g.v[r * g.ldv + j], O);
+        }
+        float o = O / (Lsum + 1e-8f);
+        if (g.bias) o += g.bias[j];
+        g.out[r * g.ldo + j] = apply_act(o, g.act);
     }
 }
 
@@ -274,24 +365,81 @@ extern "C" int tfgx_gat_fused_f32(const tfgx_gat_args* p, tfgx_stream_t stream_)
     TFGX_REQUIRE(p->H >= 1 && p->d >= 1 && p->dv >= 1 && p->n_dst >= 0, "bad H / d / dv / n_dst");
     TFGX_REQUIRE(p->scale > 0.0f, "scale must be positive");
     if (p->n_dst == 0) return TFGX_OK;
-    TFGX_REQUIRE(p->row_ptr && p->q && p->k && p->v && p->out, "null pointer");
+    TFGX_REQUIRE((p->row_ptr || p->row_begin) && p->q && p->k && p->v && (p->out || p->state_acc), "null pointer");
     const int64_t W = int64_t(p->H) * p->dv, A = int64_t(p->H) * p->d;
-    TFGX_REQUIRE(p->ldq >= A && p->ldk >= A && p->ldv >= W && p->ldo >= W, "leading dimension too small");
+    TFGX_REQUIRE(p->ldq >= A && p->ldk >= A && p->ldv >= W && (p->state_acc || p->ldo >= W),
+                 "leading dimension too small");
     GArgs a;
     a.row_ptr = p->row_ptr; a.col = p->col; a.n_dst = p->n_dst;
     a.q = p->q; a.ldq = p->ldq; a.k = p->k; a.ldk = p->ldk; a.v = p->v; a.ldv = p->ldv;
     a.out = p->out; a.ldo = p->ldo; a.H = p->H; a.d = p->d; a.dv = p->dv; a.W = int32_t(W);
     a.add_self_loop = p->add_self_loop; a.scale = p->scale; a.act = p->act; a.bias = p->bias;
     a.kvec = (p->d % 4 == 0) && (p->ldk % 4 == 0) && aligned_to(p->k, 16);
+    a.row_begin = p->row_begin ? p->row_begin : p->row_ptr;
+    a.row_end = p->row_begin ? p->row_end : p->row_ptr + 1;
+    a.rp_stride = p->row_begin ? p->rp_stride : 1;
+    TFGX_REQUIRE(a.row_end != nullptr && a.rp_stride >= 1, "bad row_begin / row_end / rp_stride");
+    a.part_row = nullptr; a.state_acc = p->state_acc; a.state_ml = p->state_ml; a.hub_threshold = 0;
+    TFGX_REQUIRE((p->state_acc == nullptr) == (p->state_ml == nullptr), "state_acc and state_ml go together");
+    const bool use_hub = p->hub_threshold > 0 && p->n_hub_rows > 0 && p->state_acc == nullptr;
+    if (use_hub) {
+        TFGX_REQUIRE(p->hub_rows && p->hub_chunk_ptr && p->hub_chunk_begin && p->hub_chunk_end && p->hub_chunk_row &&
+                         p->hub_scratch_acc && p->hub_scratch_ml && p->n_hub_chunks > 0,
+                     "hub rows given without chunk lists / scratch");
+        a.hub_threshold = p->hub_threshold;
+    }
     hipStream_t stream = as_stream(stream_);
-    auto ok = [&](int vec) {
-        const size_t al = sizeof(float) * vec;
-        return (p->dv % vec == 0) && (p->ldv % vec == 0) && (p->ldo % vec == 0) && aligned_to(p->v, al) &&
-               aligned_to(p->out, al);
+    auto vec_for = [&](const float* outp, int64_t ldo_) {
+        auto ok = [&](int vec) {
+            const size_t al = sizeof(float) * vec;
+            return (p->dv % vec == 0) && (p->ldv % vec == 0) && (ldo_ % vec == 0) && aligned_to(p->v, al) &&
+                   aligned_to(outp, al);
+        };
+        return ok(4) ? 4 : (ok(2) ? 2 : 1);
     };
-    if (ok(4)) return launch_gat<4>(a, stream);
-    if (ok(2)) return launch_gat<2>(a, stream);
-    return launch_gat<1>(a, stream);
+    auto launch = [&](const GArgs& g, int vec) {
+        if (vec == 4) return launch_gat<4>(g, stream);
+        if (vec == 2) return launch_gat<2>(g, stream);
+        return launch_gat<1>(g, stream);
+    };
+    int rc = launch(a, p->state_acc ? vec_for(p->state_acc, W) : vec_for(p->out, p->ldo));
+    if (rc != TFGX_OK || !use_hub) return rc;
+
+    // hub rows: raw state per chunk, then ordered merge (+ self loop, bias, activation)
+    GArgs c = a;
+    c.row_begin = p->hub_chunk_begin; c.row_end = p->hub_chunk_end; c.rp_stride = 1; c.n_dst = p->n_hub_chunks;
+    c.part_row = p->hub_chunk_row; c.state_acc = p->hub_scratch_acc; c.state_ml = p->hub_scratch_ml;
+    c.hub_threshold = 0;
+    rc = launch(c, vec_for(p->hub_scratch_acc, W));
+    if (rc != TFGX_OK) return rc;
+    GMerge g;
+    g.state_acc = p->hub_scratch_acc; g.state_ml = p->hub_scratch_ml; g.rows = p->hub_rows;
+    g.part_ptr = p->hub_chunk_ptr; g.fixed_parts = 0; g.n_rows = 0; g.n_merge = p->n_hub_rows;
+    g.q = p->q; g.ldq = p->ldq; g.k = p->k; g.ldk = p->ldk; g.v = p->v; g.ldv = p->ldv;
+    g.out = p->out; g.ldo = p->ldo; g.H = p->H; g.d = p->d; g.dv = p->dv; g.W = int32_t(W);
+    g.add_self_loop = p->add_self_loop; g.scale = p->scale; g.act = p->act; g.bias = p->bias;
+    gat_merge_kernel<<<grid_for(g.n_merge * W, kBlock), kBlock, 0, stream>>>(g);
+    TFGX_LAUNCH_CHECK("gat_merge_kernel");
+    return TFGX_OK;
+}
+
+extern "C" int tfgx_gat_merge_passes_f32(const tfgx_gat_args* p, const float* state_acc, const float* state_ml,
+                                         int32_t n_passes, tfgx_stream_t stream)
+{
+    TFGX_REQUIRE(p != nullptr && state_acc && state_ml && n_passes >= 1, "bad argument");
+    TFGX_REQUIRE(p->H >= 1 && p->d >= 1 && p->dv >= 1 && p->n_dst >= 0 && p->scale > 0.0f, "bad H / d / dv / n_dst");
+    if (p->n_dst == 0) return TFGX_OK;
+    TFGX_REQUIRE(p->q && p->k && p->v && p->out, "null pointer");
+    const int64_t W = int64_t(p->H) * p->dv;
+    GMerge g;
+    g.state_acc = state_acc; g.state_ml = state_ml; g.rows = nullptr; g.part_ptr = nullptr;
+    g.fixed_parts = n_passes; g.n_rows = p->n_dst; g.n_merge = p->n_dst;
+    g.q = p->q; g.ldq = p->ldq; g.k = p->k; g.ldk = p->ldk; g.v = p->v; g.ldv = p->ldv;
+    g.out = p->out; g.ldo = p->ldo; g.H = p->H; g.d = p->d; g.dv = p->dv; g.W = int32_t(W);
+    g.add_self_loop = p->add_self_loop; g.scale = p->scale; g.act = p->act; g.bias = p->bias;
+    gat_merge_kernel<<<grid_for(g.n_merge * W, kBlock), kBlock, 0, as_stream(stream)>>>(g);
+    TFGX_LAUNCH_CHECK("gat_merge_kernel");
+    return TFGX_OK;
 }
 
 extern "C" int tfgx_head_mean_f32(const float* in, int64_t ld_in, int64_t n, int32_t H, int32_t U,

@@ -130,6 +130,22 @@ class HipBackend(object):
         from ..plan import gemm_bias_act
         return gemm_bias_act(a, b, bias=bias, act=act, out=out)
 
+    def gat_pass(self, row_begin, row_end, rp_stride, col, n_dst, Q, K, V, num_heads, state_acc, state_ml):
+        """Raw online-softmax state of every destination over the given edge span (tfgx_gat_fused_f32, state mode)."""
+        from ..nn.conv.gat import gat_args
+        a, _, keep = gat_args(Q, K, V, num_heads, n_dst, col, add_self_loop=False, out=state_acc)
+        a.row_begin, a.row_end, a.rp_stride = row_begin.data_ptr(), row_end.data_ptr(), rp_stride
+        a.state_acc, a.state_ml = state_acc.data_ptr(), state_ml.data_ptr()
+        L.check(self.lib.tfgx_gat_fused_f32(ctypes.byref(a), L.stream_ptr()), "tfgx_gat_fused_f32")
+
+    def gat_merge(self, Q, K, V, num_heads, n_dst, state_acc, state_ml, n_passes, bias, act, out):
+        from ..nn.conv.gat import gat_args
+        a, out, keep = gat_args(Q, K, V, num_heads, n_dst, self.empty(1, torch.int32), add_self_loop=True, bias=bias,
+                                act=act, out=out)
+        L.check(self.lib.tfgx_gat_merge_passes_f32(ctypes.byref(a), L.ptr(state_acc), L.ptr(state_ml), n_passes,
+                                                   L.stream_ptr()), "tfgx_gat_merge_passes_f32")
+        return out
+
 
 def edge_balanced_bounds(row_ptr_host, world):
     """Split points on the global row_ptr so that each rank gets ~E/world edges. -> int64 [world+1] node ids."""
@@ -336,6 +352,31 @@ class ShardedGraph(object):
             table = self.alloc_table(int(kernel.shape[1]))
             be.gemm_bias_act(x_own, kernel, out=self.own_rows(table))
         return self.gcn_propagate(table, bias=bias, act=act)
+
+    # ------------------------------------------------------------------ GAT
+    def gat(self, x_own, query_kernel, query_bias, query_act, key_kernel, key_bias, key_act, kernel, bias=None,
+            act=L.ACT_NONE, num_heads=1):
+        """Sharded GAT layer (nn/conv/gat.py:13-122, split_value_heads=True): Q stays local; K and V of the halo
+        sources travel together in one [A + U]-wide exchange; the local-source edges are reduced to a raw
+        online-softmax state while the exchange is in flight, the halo-source edges afterwards, and the two states
+        plus the appended self-loop edge are merged (tfgx_gat_merge_passes_f32)."""
+        be = self.backend
+        A, U = int(query_kernel.shape[1]), int(kernel.shape[1])
+        Q = be.gemm_bias_act(x_own, query_kernel, bias=query_bias, act=query_act)
+        table = self.alloc_table(A + U)
+        be.gemm_bias_act(x_own, key_kernel, bias=key_bias, act=key_act, out=self.own_rows(table)[:, :A])
+        be.gemm_bias_act(x_own, kernel, out=self.own_rows(table)[:, A:])
+        handle = self.exchange_start(table)
+        K, V = table[:, :A], table[:, A:]
+        s_acc = be.empty((2 * self.n_own, U))
+        s_ml = be.empty((2 * self.n_own, 2 * num_heads))
+        rp2 = self.row_ptr2
+        be.gat_pass(rp2, rp2[1:], 2, self.col, self.n_own, Q, K, V, num_heads, s_acc[:self.n_own], s_ml[:self.n_own])
+        self.exchange_finish(handle)
+        be.gat_pass(rp2[1:], rp2[2:], 2, self.col, self.n_own, Q, K, V, num_heads, s_acc[self.n_own:],
+                    s_ml[self.n_own:])
+        out = be.empty((self.n_own, U))
+        return be.gat_merge(Q, K, V, num_heads, self.n_own, s_acc, s_ml, 2, bias, act, out)
 
     # ------------------------------------------------------------------ GraphSAGE reduce
     def neighbor_reduce(self, x_own, op, weighted=True):

@@ -22,9 +22,8 @@ def _linear(x, kernel, bias, activation):
     return post(h) if post is not None else h
 
 
-def gat_attention(plan, Q, K, V, num_heads, add_self_loop=True, bias=None, act=L.ACT_NONE):
-    """Fused SDDMM + edge softmax + SpMM over `plan` (tfgx_gat_fused_f32). Q:[n_dst,A] K:[n_src,A] V:[n_src,W]."""
-    lib = L.require_gpu()
+def gat_args(Q, K, V, num_heads, n_dst, col, add_self_loop=True, bias=None, act=L.ACT_NONE, out=None):
+    """Fill a tfgx_gat_args for Q:[n_dst,A] K:[n_src,A] V:[n_src,W]; returns (args, out, keep-alive tuple)."""
     Q, ldq = L.row_major_2d(Q)
     K, ldk = L.row_major_2d(K)
     V, ldv = L.row_major_2d(V)
@@ -32,11 +31,11 @@ def gat_attention(plan, Q, K, V, num_heads, add_self_loop=True, bias=None, act=L
     if A % num_heads or W % num_heads:
         raise ValueError("attention_units ({}) and value width ({}) must be divisible by num_heads ({})"
                          .format(A, W, num_heads))
-    out = torch.empty((plan.n_dst, W), dtype=torch.float32, device=V.device)
+    if out is None:
+        out = torch.empty((n_dst, W), dtype=torch.float32, device=V.device)
     a = L.GatArgs()
-    a.row_ptr = plan.row_ptr.data_ptr()
-    a.col = plan.col.data_ptr()
-    a.n_dst = plan.n_dst
+    a.col = col.data_ptr()
+    a.n_dst = n_dst
     a.q, a.ldq = Q.data_ptr(), ldq
     a.k, a.ldk = K.data_ptr(), ldk
     a.v, a.ldv = V.data_ptr(), ldv
@@ -46,6 +45,27 @@ def gat_attention(plan, Q, K, V, num_heads, add_self_loop=True, bias=None, act=L
     a.scale = math.sqrt(float(A // num_heads))            # gat.py:78  sqrt(shape(Q_)[-1])
     a.act = act
     a.bias = 0 if bias is None else bias.data_ptr()
+    return a, out, (Q, K, V)
+
+
+def gat_attention(plan, Q, K, V, num_heads, add_self_loop=True, bias=None, act=L.ACT_NONE):
+    """Fused SDDMM + edge softmax + SpMM over `plan` (tfgx_gat_fused_f32). Q:[n_dst,A] K:[n_src,A] V:[n_src,W].
+    Destinations with very many in-edges (plan.hub_info()) are processed chunk-wise and merged."""
+    lib = L.require_gpu()
+    a, out, keep = gat_args(Q, K, V, num_heads, plan.n_dst, plan.col, add_self_loop, bias, act)
+    a.row_ptr = plan.row_ptr.data_ptr()
+    hub = plan.hub_info()
+    if hub is not None:
+        hub_rows, chunk_ptr, chunk_begin, chunk_end, chunk_row = hub
+        W, nc = int(keep[2].shape[1]), int(chunk_begin.shape[0])
+        s_acc = torch.empty((nc, W), dtype=torch.float32, device=out.device)
+        s_ml = torch.empty((nc, 2 * num_heads), dtype=torch.float32, device=out.device)
+        a.hub_threshold = plan.hub_threshold
+        a.hub_rows, a.hub_chunk_ptr = hub_rows.data_ptr(), chunk_ptr.data_ptr()
+        a.hub_chunk_begin, a.hub_chunk_end = chunk_begin.data_ptr(), chunk_end.data_ptr()
+        a.hub_chunk_row = chunk_row.data_ptr()
+        a.n_hub_rows, a.n_hub_chunks = int(hub_rows.shape[0]), nc
+        a.hub_scratch_acc, a.hub_scratch_ml = s_acc.data_ptr(), s_ml.data_ptr()
     L.check(lib.tfgx_gat_fused_f32(ctypes.byref(a), L.stream_ptr()), "tfgx_gat_fused_f32")
     return out
 

@@ -89,7 +89,8 @@ class CsrPlan(object):
 
     def hub_info(self):
         """Chunk lists for destinations with more than HUB_THRESHOLD in-edges (power-law "hubs"), or None.
-        Small control-plane metadata, computed once per plan: (hub_rows, chunk_ptr, chunk_begin, chunk_end)."""
+        Small control-plane metadata, computed once per plan:
+        (hub_rows, chunk_ptr, chunk_begin, chunk_end, chunk_row)."""
         if self._hub is None:
             deg = self.in_degree()
             thr, chunk = hub_policy(self.num_edges, self.n_dst)
@@ -111,7 +112,8 @@ class CsrPlan(object):
                 begin = start[owner] + k * hub_chunk
                 end = torch.minimum(begin + hub_chunk, start[owner] + d[owner])
                 self._hub = (hub_rows.contiguous(), chunk_ptr.to(torch.int32).contiguous(),
-                             begin.to(torch.int32).contiguous(), end.to(torch.int32).contiguous())
+                             begin.to(torch.int32).contiguous(), end.to(torch.int32).contiguous(),
+                             hub_rows[owner].contiguous())
         return self._hub or None
 
 
@@ -212,7 +214,7 @@ def segment_reduce(plan, x, op, w_csr=None, out=None, act=L.ACT_NONE, self_coef=
         a.x_tail, a.ld_tail, a.f_main = split.tail.data_ptr(), int(split.tail.shape[1]), int(split.main.shape[1])
     hub = plan.hub_info() if (row_begin is None and row_end is None and col is None) else None
     if hub is not None:
-        hub_rows, chunk_ptr, chunk_begin, chunk_end = hub
+        hub_rows, chunk_ptr, chunk_begin, chunk_end, _ = hub
         scratch = torch.empty((int(chunk_begin.shape[0]), F), dtype=torch.float32, device=x.device)
         a.hub_threshold = plan.hub_threshold
         a.hub_rows, a.hub_chunk_ptr = hub_rows.data_ptr(), chunk_ptr.data_ptr()
