@@ -107,7 +107,7 @@ def main():
         raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node {} bench.py --gpus {}".format(
             args.gpus, args.gpus))
     assert torch.cuda.is_available(), "bench.py needs a GPU"
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank % torch.cuda.device_count())
 
     import tf_geometric_amd as tfg
     from tf_geometric_amd import synthetic
@@ -123,7 +123,9 @@ def main():
 
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl")
+        # RCCL ("nccl") always, except for the single-GPU plumbing check of this code path
+        # (TFGX_BENCH_BACKEND=gloo with all ranks on one device; rows are then staged through the host)
+        dist.init_process_group(os.environ.get("TFGX_BENCH_BACKEND", "nccl"))
         from tf_geometric_amd.dist.sharded import ShardedGraph
         t0 = time.perf_counter()
         sg = ShardedGraph.from_global(ei_np, n, edge_weight=None, group=dist.group.WORLD)
@@ -205,6 +207,16 @@ def main():
         "plan_build_s": plan_s,
     }
 
+    if rank == 0 and world > 1:
+        # whole job: algorithmic bytes of the full graph over the step time (exchange included) vs N x 8 TB/s
+        bytes_alg = b_alg(e_agg, n, f, weighted=True)
+        achieved = bytes_alg / (ms_per_step * 1e-3)
+        line["roofline"] = {"bound": "hbm", "kernel": "seg_reduce_kernel (local pass + halo pass) + RCCL all-to-all-v",
+                            "achieved": achieved / 1e9, "peak": world * HBM_PEAK / 1e9, "unit": "GB/s",
+                            "frac": achieved / (world * HBM_PEAK), "traffic": None,
+                            "algorithmic_bytes_per_launch": bytes_alg, "step_ms": ms_per_step,
+                            "halo_rows_received_rank0": sg.n_halo, "halo_bytes_received_rank0": sg.n_halo * f * 4,
+                            "edges_rank0": sg.num_edges, "rows_rank0": sg.n_own}
     if rank == 0 and world == 1:
         bytes_alg = b_alg(e_agg, n, f, weighted=True)
         achieved = bytes_alg / (ev_ms * 1e-3)

@@ -181,3 +181,15 @@ def test_split_row_layout_is_bit_identical(tfg, oracle, f):
             assert torch.equal(a, b)
     ref = oracle.aggregate_neighbors(x, ei, w, oracle.gcn_mapper, oracle.sum_reducer, oracle.identity_updater)
     assert_parity(segment_reduce(plan, sp, L.SUM, w_csr=w_csr).cpu().numpy(), ref, what="split rows vs oracle")
+
+
+def test_neighbor_count_mapper_and_utils(tfg, oracle):
+    x, ei, w = _graph(oracle, 120, 900, 5, seed=41)
+    got = tfg.nn.aggregate_neighbors(x, ei, w, tfg.nn.neighbor_count_mapper, tfg.nn.sum_reducer,
+                                     tfg.nn.identity_updater).cpu().numpy()
+    assert np.array_equal(got[:, 0], np.bincount(ei[0], minlength=120).astype(np.float32))
+    ei2, w2 = tfg.utils.add_self_loop_edge(ei, 120, w, fill_weight=2.0)
+    oe, ow = oracle.add_self_loop_edge(ei, 120, w, fill_weight=2.0)
+    assert np.array_equal(ei2, oe) and np.array_equal(w2, ow)
+    ei3, w3 = tfg.utils.add_self_loop_edge(tfg._lib.as_i32(ei), 120)
+    assert np.array_equal(ei3.cpu().numpy(), oe) and w3 is None

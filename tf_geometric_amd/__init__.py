@@ -15,5 +15,6 @@ from .sparse import SparseMatrix
 from . import nn
 from . import layers
 from . import dist
+from . import utils
 
 __version__ = "0.1.0"
