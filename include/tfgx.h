@@ -185,6 +185,8 @@ typedef struct tfgx_gat_args {
     int64_t n_hub_chunks;
     float* hub_scratch_acc;        /* [n_hub_chunks, H*dv] */
     float* hub_scratch_ml;         /* [n_hub_chunks, 2*H]  */
+    float* stats_ml;               /* optional [n_dst, 2*H]: final softmax statistics (m, l) per row and head, saved
+                                      for tfgx_gat_backward_*; NULL = not written */
 } tfgx_gat_args;
 
 int tfgx_gat_fused_f32(const tfgx_gat_args* args /* host */, tfgx_stream_t stream);
@@ -197,6 +199,51 @@ int tfgx_gat_merge_passes_f32(const tfgx_gat_args* args /* host */, const float*
 /* out[r, j] = (1/H) * sum_h in[r, h*U + j]  (+ bias[j], act)   — gat.py:114-120, split_value_heads=False */
 int tfgx_head_mean_f32(const float* in, int64_t ld_in, int64_t n, int32_t H, int32_t U, const float* bias,
                        int32_t act, float* out, int64_t ldo, tfgx_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Backward pass: what tf.GradientTape differentiates in the reference's training loops
+ * (demo/demo_gcn.py:68-77).  d/dx of the sum/mean aggregation is tfgx_segment_reduce_f32 on the transposed
+ * (CSR-by-source) plan; the entry points below cover the rest.
+ *   tfgx_sddmm_f32                 d/dw of gcn_mapper+sum: out[i] = <a[row(i), :], b[col[i], :]>  (CSR order)
+ *   tfgx_segment_max_count_f32     count[r,j] = #{i in row r : w[i]*x[col[i],j] == out[r,j]}
+ *   tfgx_segment_max_backward_f32  gx[c,j] = sum over the transposed plan of [tie] * w * g[dst,j] / count[dst,j]
+ *                                  (tf.math.unsorted_segment_max's gradient: split evenly among tied maxima)
+ *   tfgx_gat_backward_dst_f32      dQ; tfgx_gat_backward_src_f32: dK, dV — attention weights recomputed from
+ *                                  stats_ml saved by tfgx_gat_fused_f32; dsum[r,h] = <dO[r,h,:], O[r,h,:]>
+ * ------------------------------------------------------------------------------------------- */
+int tfgx_sddmm_f32(const int32_t* row_ptr, const int32_t* col, int64_t n_dst, const float* a, int64_t lda,
+                   const float* b, int64_t ldb, int64_t F, float* out, tfgx_stream_t stream);
+int tfgx_segment_max_count_f32(const int32_t* row_ptr, const int32_t* col, const float* w /* or NULL */, int64_t n_dst,
+                               const float* x, int64_t ldx, int64_t F, const float* out, int64_t ldo, float* count,
+                               int64_t ldc, tfgx_stream_t stream);
+int tfgx_segment_max_backward_f32(const int32_t* row_ptr_t, const int32_t* dst_t, const float* w_t /* or NULL */,
+                                  int64_t n_src, const float* x, int64_t ldx, int64_t F, const float* out, int64_t ldo,
+                                  const float* g, int64_t ldg, const float* count, int64_t ldc, float* gx, int64_t ldgx,
+                                  tfgx_stream_t stream);
+
+typedef struct tfgx_gat_backward_args {
+    const int32_t* row_ptr;    /* forward plan (by destination) + col: used by the dst pass */
+    const int32_t* col;
+    int64_t n_dst;
+    const int32_t* row_ptr_t;  /* transposed plan (by source) + destination per position: used by the src pass */
+    const int32_t* dst_t;
+    int64_t n_src;
+    const float* q; int64_t ldq;
+    const float* k; int64_t ldk;
+    const float* v; int64_t ldv;
+    const float* grad_out; int64_t ld_grad_out;   /* dO [n_dst, H*dv] */
+    const float* stats_ml;                        /* [n_dst, 2H] from the forward */
+    const float* dsum;                            /* [n_dst, H] */
+    int32_t H, d, dv, add_self_loop;
+    float scale;
+    int32_t reserved;
+    float* grad_q; int64_t ld_grad_q;             /* [n_dst, H*d]  (dst pass) */
+    float* grad_k; int64_t ld_grad_k;             /* [n_src, H*d]  (src pass) */
+    float* grad_v; int64_t ld_grad_v;             /* [n_src, H*dv] (src pass) */
+} tfgx_gat_backward_args;
+
+int tfgx_gat_backward_dst_f32(const tfgx_gat_backward_args* args /* host */, tfgx_stream_t stream);
+int tfgx_gat_backward_src_f32(const tfgx_gat_backward_args* args /* host */, tfgx_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Dense GEMM beside the path: C = act(A[M,K] @ B[K,N] + bias) with fp32-input MFMA

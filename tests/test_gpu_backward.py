@@ -1,0 +1,159 @@
+# coding=utf-8
+"""Backward pass: gradients of the HIP kernels vs torch autograd over a float64 dense/index
+restatement of the same maths (the reference differentiates these ops with tf.GradientTape, demo/demo_gcn.py:68-77)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_parity
+
+pytestmark = pytest.mark.gpu
+
+
+def _graph(oracle, n=300, e=3000, f=12, seed=0):
+    ei = oracle.synthetic_edges(n, e, seed=seed)
+    rng = np.random.Generator(np.random.PCG64(seed + 1))
+    x = rng.standard_normal((n, f)).astype(np.float32)
+    w = rng.uniform(0.5, 1.5, size=ei.shape[1]).astype(np.float32)
+    return x, ei, w, rng
+
+
+def _ref_aggregate(x, ei, w, op, n):
+    row, col = torch.from_numpy(ei[0]).long(), torch.from_numpy(ei[1]).long()
+    msg = x[col] * w[:, None] if w is not None else x[col]
+    if op == "sum":
+        return torch.zeros(n, x.shape[1], dtype=x.dtype).index_add(0, row, msg)
+    if op == "mean":
+        s = torch.zeros(n, x.shape[1], dtype=x.dtype).index_add(0, row, msg)
+        cnt = torch.bincount(row, minlength=n).clamp(min=1).to(x.dtype)
+        return s / cnt[:, None]
+    out = torch.full((n, x.shape[1]), -3.4028234663852886e38, dtype=x.dtype)
+    return out.scatter_reduce(0, row[:, None].expand_as(msg), msg, "amax")
+
+
+@pytest.mark.parametrize("op", ["sum", "mean", "max"])
+@pytest.mark.parametrize("weighted", [True, False])
+def test_aggregate_grad_x_and_w(tfg, oracle, op, weighted):
+    x, ei, w, rng = _graph(oracle, seed=3)
+    n = x.shape[0]
+    gout = rng.standard_normal(x.shape).astype(np.float32)
+    xt = torch.tensor(x, device="cuda", requires_grad=True)
+    wt = torch.tensor(w, device="cuda", requires_grad=(weighted and op != "max")) if weighted else None
+    red = getattr(tfg.nn, op + "_reducer")
+    mapper = tfg.nn.gcn_mapper if weighted else tfg.nn.identity_mapper
+    out = tfg.nn.aggregate_neighbors(xt, ei, wt, mapper, red, tfg.nn.sum_updater)
+    out.backward(torch.tensor(gout, device="cuda"))
+    xr = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    wr = torch.tensor(w, dtype=torch.float64, requires_grad=True) if weighted else None
+    ref = xr + _ref_aggregate(xr, ei, wr, op, n)
+    ref.backward(torch.tensor(gout, dtype=torch.float64))
+    assert_parity(out.detach().cpu().numpy(), ref.detach().numpy(), what="forward " + op)
+    assert_parity(xt.grad.cpu().numpy(), xr.grad.numpy(), tol=2e-5, what="d/dx " + op)
+    if weighted and op != "max":
+        assert_parity(wt.grad.cpu().numpy(), wr.grad.numpy(), tol=2e-5, what="d/dw " + op)
+
+
+def test_max_grad_ties_split_evenly(tfg):
+    """TF's unsorted_segment_max gradient divides by the number of tied maxima."""
+    ei = np.array([[0, 0, 0, 1], [1, 2, 3, 3]], np.int32)
+    x = np.array([[0.0], [5.0], [5.0], [1.0]], np.float32)
+    xt = torch.tensor(x, device="cuda", requires_grad=True)
+    out = tfg.nn.aggregate_neighbors(xt, ei, None, tfg.nn.identity_mapper, tfg.nn.max_reducer, tfg.nn.identity_updater)
+    out[:2].sum().backward()
+    assert np.allclose(xt.grad.cpu().numpy()[:, 0], [0.0, 0.5, 0.5, 1.0])
+
+
+@pytest.mark.parametrize("cfg", [dict(), dict(renorm=False), dict(norm="left")])
+@pytest.mark.parametrize("units", [8, 24])
+def test_gcn_layer_grads(tfg, oracle, cfg, units):
+    x, ei, w, rng = _graph(oracle, seed=5)
+    n, f = x.shape
+    layer = tfg.layers.GCN(units, activation=tfg.relu, **cfg)
+    layer._maybe_build([x])
+    layer.set_weights(kernel=oracle.glorot_uniform(rng, f, units), bias=(rng.standard_normal(units) * 0.1).astype(np.float32))
+    layer.trainable(True)
+    xt = torch.tensor(x, device="cuda", requires_grad=True)
+    out = layer([xt, ei, w], cache={})
+    gout = torch.tensor(rng.standard_normal((n, units)).astype(np.float32), device="cuda")
+    out.backward(gout)
+    # float64 reference: dense normalised adjacency from the oracle
+    idx, nw = oracle.gcn_norm_adj(ei, w, n, **cfg)
+    A = torch.zeros(n, n, dtype=torch.float64).index_put((torch.from_numpy(idx[0]).long(), torch.from_numpy(idx[1]).long()),
+                                                         torch.from_numpy(nw).double(), accumulate=True)
+    xr = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    kr = layer.kernel.detach().double().cpu().requires_grad_(True)
+    br = layer.bias.detach().double().cpu().requires_grad_(True)
+    ref = torch.relu(A @ (xr @ kr) + br)
+    ref.backward(gout.double().cpu())
+    assert_parity(out.detach().cpu().numpy(), ref.detach().numpy(), what="gcn forward")
+    assert_parity(xt.grad.cpu().numpy(), xr.grad.numpy(), tol=2e-5, what="gcn d/dx")
+    assert_parity(layer.kernel.grad.cpu().numpy(), kr.grad.numpy(), tol=1e-4, what="gcn d/dkernel")
+    assert_parity(layer.bias.grad.cpu().numpy(), br.grad.numpy(), tol=1e-4, what="gcn d/dbias")
+
+
+def _ref_gat(x, ei, wq, bq, wk, bk, wv, b, H, n):
+    ar = np.arange(n, dtype=np.int64)
+    row = torch.from_numpy(np.concatenate([ei[0].astype(np.int64), ar]))
+    col = torch.from_numpy(np.concatenate([ei[1].astype(np.int64), ar]))
+    Q, K, V = torch.relu(x @ wq + bq), torch.relu(x @ wk + bk), x @ wv
+    d, dv = Q.shape[1] // H, V.shape[1] // H
+    outs = []
+    for h in range(H):
+        s = (Q[row, h * d:(h + 1) * d] * K[col, h * d:(h + 1) * d]).sum(-1) / np.sqrt(d)
+        m = torch.full((n,), -1e30, dtype=x.dtype).scatter_reduce(0, row, s, "amax")
+        p = torch.exp(s - m[row].detach())
+        den = torch.zeros(n, dtype=x.dtype).index_add(0, row, p) + 1e-8
+        a = p / den[row]
+        outs.append(torch.zeros(n, dv, dtype=x.dtype).index_add(0, row, a[:, None] * V[col, h * dv:(h + 1) * dv]))
+    return torch.relu(torch.cat(outs, 1) + b)
+
+
+@pytest.mark.parametrize("heads,att,units", [(1, 4, 6), (4, 8, 16), (2, 6, 10)])
+def test_gat_layer_grads(tfg, oracle, heads, att, units):
+    x, ei, w, rng = _graph(oracle, n=200, e=2500, f=9, seed=7)
+    n, f = x.shape
+    layer = tfg.layers.GAT(units, attention_units=att, activation=tfg.relu, num_heads=heads)
+    layer._maybe_build([x])
+    ws = dict(query_kernel=oracle.glorot_uniform(rng, f, att), key_kernel=oracle.glorot_uniform(rng, f, att),
+              kernel=oracle.glorot_uniform(rng, f, units), query_bias=(rng.standard_normal(att) * 0.3).astype(np.float32),
+              key_bias=(rng.standard_normal(att) * 0.3).astype(np.float32), bias=(rng.standard_normal(units) * 0.1).astype(np.float32))
+    layer.set_weights(**ws)
+    layer.trainable(True)
+    xt = torch.tensor(x, device="cuda", requires_grad=True)
+    out = layer([xt, ei])
+    gout = torch.tensor(rng.standard_normal((n, units)).astype(np.float32), device="cuda")
+    out.backward(gout)
+    r = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in ws.items()}
+    xr = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    ref = _ref_gat(xr, ei, r["query_kernel"], r["query_bias"], r["key_kernel"], r["key_bias"], r["kernel"], r["bias"], heads, n)
+    ref.backward(gout.double().cpu())
+    assert_parity(out.detach().cpu().numpy(), ref.detach().numpy(), what="gat forward")
+    assert_parity(xt.grad.cpu().numpy(), xr.grad.numpy(), tol=5e-5, what="gat d/dx")
+    for k in ws:
+        assert_parity(getattr(layer, k).grad.cpu().numpy(), r[k].grad.numpy(), tol=2e-4, what="gat d/d" + k)
+
+
+@pytest.mark.parametrize("cls", ["MeanGraphSage", "SumGraphSage", "MaxPoolGraphSage", "MeanPoolGraphSage", "GCNGraphSage"])
+def test_sage_layers_train_step_decreases_loss(tfg, oracle, cls):
+    """Every GraphSAGE variant is differentiable end to end: a few SGD steps reduce a regression loss."""
+    x, ei, w, rng = _graph(oracle, n=250, e=3000, f=10, seed=9)
+    n = x.shape[0]
+    ring = np.stack([np.arange(n, dtype=np.int32), np.roll(np.arange(n, dtype=np.int32), 1)])
+    ei = np.concatenate([ei, ring], axis=1)
+    w = np.concatenate([w, np.ones(n, np.float32)])
+    layer = getattr(tfg.layers, cls)(8)
+    target = torch.tensor(rng.standard_normal((n, 8)).astype(np.float32), device="cuda").abs()
+    layer._maybe_build([x])
+    layer.trainable(True)
+    opt = torch.optim.SGD(layer.parameters(), lr=0.05)
+    losses = []
+    cache = {}
+    for _ in range(12):
+        opt.zero_grad()
+        out = layer([x, ei, w], cache=cache)
+        loss = ((out - target) ** 2).mean()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert losses[-1] < losses[0] * 0.98, losses
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in layer.parameters())

@@ -60,6 +60,25 @@ class GatArgs(ctypes.Structure):
         ("hub_chunk_end", ctypes.c_void_p), ("hub_chunk_row", ctypes.c_void_p),
         ("n_hub_rows", ctypes.c_int64), ("n_hub_chunks", ctypes.c_int64),
         ("hub_scratch_acc", ctypes.c_void_p), ("hub_scratch_ml", ctypes.c_void_p),
+        ("stats_ml", ctypes.c_void_p),
+    ]
+
+
+class GatBackwardArgs(ctypes.Structure):
+    """struct tfgx_gat_backward_args (include/tfgx.h)."""
+    _fields_ = [
+        ("row_ptr", ctypes.c_void_p), ("col", ctypes.c_void_p), ("n_dst", ctypes.c_int64),
+        ("row_ptr_t", ctypes.c_void_p), ("dst_t", ctypes.c_void_p), ("n_src", ctypes.c_int64),
+        ("q", ctypes.c_void_p), ("ldq", ctypes.c_int64),
+        ("k", ctypes.c_void_p), ("ldk", ctypes.c_int64),
+        ("v", ctypes.c_void_p), ("ldv", ctypes.c_int64),
+        ("grad_out", ctypes.c_void_p), ("ld_grad_out", ctypes.c_int64),
+        ("stats_ml", ctypes.c_void_p), ("dsum", ctypes.c_void_p),
+        ("H", ctypes.c_int32), ("d", ctypes.c_int32), ("dv", ctypes.c_int32), ("add_self_loop", ctypes.c_int32),
+        ("scale", ctypes.c_float), ("reserved", ctypes.c_int32),
+        ("grad_q", ctypes.c_void_p), ("ld_grad_q", ctypes.c_int64),
+        ("grad_k", ctypes.c_void_p), ("ld_grad_k", ctypes.c_int64),
+        ("grad_v", ctypes.c_void_p), ("ld_grad_v", ctypes.c_int64),
     ]
 
 
@@ -77,6 +96,12 @@ SIGNATURES = {
     "tfgx_edge_softmax_f32": (ctypes.c_int, [_P, _P, _P, _I64, _I64, _P, _P]),
     "tfgx_gat_fused_f32": (ctypes.c_int, [ctypes.POINTER(GatArgs), _P]),
     "tfgx_gat_merge_passes_f32": (ctypes.c_int, [ctypes.POINTER(GatArgs), _P, _P, _I32, _P]),
+    "tfgx_sddmm_f32": (ctypes.c_int, [_P, _P, _I64, _P, _I64, _P, _I64, _I64, _P, _P]),
+    "tfgx_segment_max_count_f32": (ctypes.c_int, [_P, _P, _P, _I64, _P, _I64, _I64, _P, _I64, _P, _I64, _P]),
+    "tfgx_segment_max_backward_f32": (ctypes.c_int, [_P, _P, _P, _I64, _P, _I64, _I64, _P, _I64, _P, _I64, _P, _I64,
+                                                     _P, _I64, _P]),
+    "tfgx_gat_backward_dst_f32": (ctypes.c_int, [ctypes.POINTER(GatBackwardArgs), _P]),
+    "tfgx_gat_backward_src_f32": (ctypes.c_int, [ctypes.POINTER(GatBackwardArgs), _P]),
     "tfgx_head_mean_f32": (ctypes.c_int, [_P, _I64, _I64, _I32, _I32, _P, _I32, _P, _I64, _P]),
     "tfgx_gemm_bias_act_f32": (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I32, _P, _I64, _I64, _I64, _I64, _P]),
     "tfgx_l2_normalize_rows_f32": (ctypes.c_int, [_P, _I64, _I64, _I64, _P]),
@@ -143,7 +168,8 @@ def as_f32(x, dev=None):
     """numpy / list / torch -> contiguous float32 tensor on the GPU (float64 is down-cast as data/graph.py:79-86)."""
     dev = dev or device()
     if isinstance(x, torch.Tensor):
-        t = x.detach()
+        # keep the autograd edge of tensors that are being trained (autograd.py); plain inputs are detached
+        t = x if (x.requires_grad and torch.is_grad_enabled()) else x.detach()
     else:
         t = torch.from_numpy(np.ascontiguousarray(np.asarray(x)))
     if t.dtype != torch.float32:

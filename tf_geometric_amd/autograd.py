@@ -1,0 +1,196 @@
+# coding=utf-8
+"""Differentiable wrappers of the hot-path kernels (the backward pass).
+
+The reference trains with tf.GradientTape over TensorFlow ops (demo/demo_gcn.py:68-77); here the host tensor
+library is PyTorch, so the same role is played by torch.autograd.Function objects whose forward AND backward are
+C-ABI kernel launches:
+
+  aggregate (sum / mean, weighted)  backward wrt x  = the forward kernel on the transposed (CSR-by-source) plan
+                                    backward wrt w  = tfgx_sddmm_f32
+  aggregate (max)                   tfgx_segment_max_count_f32 + tfgx_segment_max_backward_f32 (TF tie semantics)
+  gat_attention                     tfgx_gat_backward_dst_f32 (dQ) + tfgx_gat_backward_src_f32 (dK, dV)
+  linear (x @ W + b, relu)          forward = tfgx_gemm_bias_act_f32; backward = two plain library GEMMs (torch.matmul)
+
+The functional API (nn/conv/*.py) routes through these only when torch.is_grad_enabled() and an input requires
+grad; inference keeps the fused single-launch paths.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _lib as L
+from .plan import segment_reduce, gemm_bias_act
+
+
+def needs_grad(*tensors):
+    return torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors)
+
+
+def _transposed(plan):
+    """(transposed plan, t2d) where t2d[j] = forward-CSR position of the edge at transposed-CSR position j."""
+    if getattr(plan, "_t2d", None) is None:
+        pt = plan.transposed()
+        inv = torch.empty_like(plan.perm)
+        inv[plan.perm.long()] = torch.arange(plan.num_edges, dtype=torch.int32, device=plan.perm.device)
+        plan._t2d = inv[pt.perm.long()].contiguous()
+    return plan.transposed(), plan._t2d
+
+
+def _permute(attr, idx):
+    lib = L.require_gpu()
+    a = attr.contiguous()
+    out = torch.empty_like(a)
+    L.check(lib.tfgx_permute_rows_f32(L.ptr(a), L.ptr(idx), int(idx.shape[0]), 1, L.ptr(out), L.stream_ptr()),
+            "tfgx_permute_rows_f32")
+    return out
+
+
+class _Aggregate(torch.autograd.Function):
+    """out[r] = (1/cnt[r]) * ( sum_{i in row r} w[i] x[col[i]] + self_coef[r] x[r] )   (cnt only for mean)."""
+
+    @staticmethod
+    def forward(ctx, plan, mean, x, w_csr, self_coef):
+        ctx.plan, ctx.mean = plan, mean
+        ctx.save_for_backward(x, w_csr, self_coef)
+        return segment_reduce(plan, x.detach(), L.MEAN if mean else L.SUM, w_csr=None if w_csr is None else w_csr.detach(),
+                              self_coef=None if self_coef is None else self_coef.detach())
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = L.require_gpu()
+        plan = ctx.plan
+        x, w_csr, self_coef = ctx.saved_tensors
+        g = g.contiguous()
+        if ctx.mean:
+            g = g / plan.in_degree().clamp(min=1).to(g.dtype).unsqueeze(1)
+        gx = gw = gs = None
+        if ctx.needs_input_grad[2]:
+            pt, t2d = _transposed(plan)
+            w_t = None if w_csr is None else _permute(w_csr.detach(), t2d)
+            gx = segment_reduce(pt, g, L.SUM, w_csr=w_t)
+            if self_coef is not None:
+                gx = gx + self_coef.detach().unsqueeze(1) * g
+        if w_csr is not None and ctx.needs_input_grad[3]:
+            gw = torch.empty_like(w_csr)
+            g2, ldg = L.row_major_2d(g)
+            x2, ldx = L.row_major_2d(x.detach())
+            L.check(lib.tfgx_sddmm_f32(L.ptr(plan.row_ptr), L.ptr(plan.col), plan.n_dst, L.ptr(g2), ldg, L.ptr(x2), ldx,
+                                       int(x2.shape[1]), L.ptr(gw), L.stream_ptr()), "tfgx_sddmm_f32")
+        if self_coef is not None and ctx.needs_input_grad[4]:
+            gs = (x.detach() * g).sum(1)
+        return None, None, gx, gw, gs
+
+
+class _AggregateMax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, plan, x, w_csr):
+        out = segment_reduce(plan, x.detach(), L.MAX, w_csr=None if w_csr is None else w_csr.detach())
+        ctx.plan = plan
+        ctx.save_for_backward(x, w_csr, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = L.require_gpu()
+        plan = ctx.plan
+        x, w_csr, out = ctx.saved_tensors
+        if w_csr is not None and ctx.needs_input_grad[2]:
+            raise NotImplementedError("d(max aggregate)/d(edge_weight) is not implemented")
+        x2, ldx = L.row_major_2d(x.detach())
+        g2, ldg = L.row_major_2d(g.contiguous())
+        F = int(x2.shape[1])
+        count = torch.empty_like(out)
+        L.check(lib.tfgx_segment_max_count_f32(L.ptr(plan.row_ptr), L.ptr(plan.col), L.ptr(w_csr), plan.n_dst, L.ptr(x2),
+                                               ldx, F, L.ptr(out), F, L.ptr(count), F, L.stream_ptr()),
+                "tfgx_segment_max_count_f32")
+        pt, t2d = _transposed(plan)
+        w_t = None if w_csr is None else _permute(w_csr.detach(), t2d)
+        gx = torch.empty_like(x2)
+        L.check(lib.tfgx_segment_max_backward_f32(L.ptr(pt.row_ptr), L.ptr(pt.col), L.ptr(w_t), pt.n_dst, L.ptr(x2), ldx,
+                                                  F, L.ptr(out), F, L.ptr(g2), ldg, L.ptr(count), F, L.ptr(gx), F,
+                                                  L.stream_ptr()), "tfgx_segment_max_backward_f32")
+        return None, gx, None
+
+
+def aggregate(plan, x, op, w_csr=None, self_coef=None):
+    """Differentiable gather-scale-segment-reduce (sum / mean / max) on `plan`."""
+    if op == L.MAX:
+        if self_coef is not None:
+            raise NotImplementedError("max aggregation with an implicit self-loop is inference-only")
+        return _AggregateMax.apply(plan, x, w_csr)
+    return _Aggregate.apply(plan, op == L.MEAN, x, w_csr, self_coef)
+
+
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, kernel, bias, act):
+        out = gemm_bias_act(x.detach(), kernel.detach(), bias=None if bias is None else bias.detach(), act=act)
+        ctx.act = act
+        ctx.save_for_backward(x, kernel, bias, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, kernel, bias, out = ctx.saved_tensors
+        if ctx.act == L.ACT_RELU:
+            g = g * (out > 0).to(g.dtype)
+        gx = g @ kernel.detach().t() if ctx.needs_input_grad[0] else None
+        gk = x.detach().t() @ g if ctx.needs_input_grad[1] else None
+        gb = g.sum(0) if (bias is not None and ctx.needs_input_grad[2]) else None
+        return gx, gk, gb, None
+
+
+def linear(x, kernel, bias=None, act=L.ACT_NONE):
+    """act(x @ kernel + bias): forward on the MFMA kernel, differentiable."""
+    return _Linear.apply(x, L.as_f32(kernel), None if bias is None else L.as_f32(bias), act)
+
+
+class _GatAttention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, plan, num_heads, Q, K, V):
+        from .nn.conv.gat import gat_attention
+        stats = torch.empty((plan.n_dst, 2 * num_heads), dtype=torch.float32, device=V.device)
+        out = gat_attention(plan, Q.detach(), K.detach(), V.detach(), num_heads, True, stats_ml=stats)
+        ctx.plan, ctx.H = plan, num_heads
+        ctx.save_for_backward(Q, K, V, out, stats)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = L.require_gpu()
+        plan, H = ctx.plan, ctx.H
+        Q, K, V, out, stats = ctx.saved_tensors
+        Q2, ldq = L.row_major_2d(Q.detach())
+        K2, ldk = L.row_major_2d(K.detach())
+        V2, ldv = L.row_major_2d(V.detach())
+        g2, ldg = L.row_major_2d(g.contiguous())
+        n, A, W = plan.n_dst, int(Q2.shape[1]), int(V2.shape[1])
+        dsum = (g2 * out).view(n, H, W // H).sum(-1).contiguous()
+        pt, _ = _transposed(plan)
+        gq, gk, gv = torch.empty_like(Q2), torch.empty_like(K2), torch.empty_like(V2)
+        a = L.GatBackwardArgs()
+        a.row_ptr, a.col, a.n_dst = plan.row_ptr.data_ptr(), plan.col.data_ptr(), n
+        a.row_ptr_t, a.dst_t, a.n_src = pt.row_ptr.data_ptr(), pt.col.data_ptr(), pt.n_dst
+        a.q, a.ldq, a.k, a.ldk, a.v, a.ldv = Q2.data_ptr(), ldq, K2.data_ptr(), ldk, V2.data_ptr(), ldv
+        a.grad_out, a.ld_grad_out = g2.data_ptr(), ldg
+        a.stats_ml, a.dsum = stats.data_ptr(), dsum.data_ptr()
+        a.H, a.d, a.dv, a.add_self_loop = H, A // H, W // H, 1
+        a.scale = math.sqrt(float(A // H))
+        a.grad_q, a.ld_grad_q = gq.data_ptr(), A
+        a.grad_k, a.ld_grad_k = gk.data_ptr(), A
+        a.grad_v, a.ld_grad_v = gv.data_ptr(), W
+        L.check(lib.tfgx_gat_backward_dst_f32(ctypes.byref(a), L.stream_ptr()), "tfgx_gat_backward_dst_f32")
+        L.check(lib.tfgx_gat_backward_src_f32(ctypes.byref(a), L.stream_ptr()), "tfgx_gat_backward_src_f32")
+        return None, None, gq, gk, gv
+
+
+def gat_attention(plan, Q, K, V, num_heads):
+    """Differentiable fused attention (self-loop edge appended, as nn/conv/gat.py:43)."""
+    return _GatAttention.apply(plan, num_heads, Q, K, V)
+
+
+def apply_activation(h, act, post):
+    if act == L.ACT_RELU:
+        h = torch.relu(h)
+    return post(h) if post is not None else h

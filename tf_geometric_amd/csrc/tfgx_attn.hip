@@ -101,6 +101,7 @@ struct GArgs {
     float* state_acc;     // [n_parts, W]
     float* state_ml;      // [n_parts, 2H]  (m, l) per head
     int32_t hub_threshold;
+    float* stats_ml;      // [n_dst, 2H] final (m, l) for the backward pass, or NULL
 };
 
 // D > 0: compile-time head width (Q slice lives in registers); D == 0: runtime d, Q re-read (cache-hot)
@@ -214,6 +215,10 @@ __global__ __launch_bounds__(kBlock) void gat_fused_kernel(const GArgs a)
             load_vec<VEC>(a.v + r * a.ldv + coff, vv);
             step(sc, vv);
         }
+        if (a.stats_ml && cvalid && (coff % a.dv == 0)) {
+            a.stats_ml[r * 2 * a.H + 2 * head] = m;
+            a.stats_ml[r * 2 * a.H + 2 * head + 1] = l;
+        }
         if (cvalid) {
             const float den = l + 1e-8f;   // segment.py:30
             float res[VEC];
@@ -248,6 +253,7 @@ struct GMerge {
     float scale;
     int32_t act;
     const float* bias;
+    float* stats_ml;
 };
 
 __global__ __launch_bounds__(kBlock) void gat_merge_kernel(const GMerge g)
@@ -287,6 +293,10 @@ __global__ __launch_bounds__(kBlock) void gat_merge_kernel(const GMerge g)
             const float c = expf(s_self - M);
             Lsum += c;
             O = fmaf(c, g.v[r * g.ldv + j], O);
+        }
+        if (g.stats_ml && (j % g.dv == 0)) {
+            g.stats_ml[r * 2 * g.H + 2 * h] = M;
+            g.stats_ml[r * 2 * g.H + 2 * h + 1] = Lsum;
         }
         float o = O / (Lsum + 1e-8f);
         if (g.bias) o += g.bias[j];
@@ -380,6 +390,7 @@ extern "C" int tfgx_gat_fused_f32(const tfgx_gat_args* p, tfgx_stream_t stream_)
     a.rp_stride = p->row_begin ? p->rp_stride : 1;
     TFGX_REQUIRE(a.row_end != nullptr && a.rp_stride >= 1, "bad row_begin / row_end / rp_stride");
     a.part_row = nullptr; a.state_acc = p->state_acc; a.state_ml = p->state_ml; a.hub_threshold = 0;
+    a.stats_ml = p->stats_ml;
     TFGX_REQUIRE((p->state_acc == nullptr) == (p->state_ml == nullptr), "state_acc and state_ml go together");
     const bool use_hub = p->hub_threshold > 0 && p->n_hub_rows > 0 && p->state_acc == nullptr;
     if (use_hub) {
@@ -409,7 +420,7 @@ extern "C" int tfgx_gat_fused_f32(const tfgx_gat_args* p, tfgx_stream_t stream_)
     GArgs c = a;
     c.row_begin = p->hub_chunk_begin; c.row_end = p->hub_chunk_end; c.rp_stride = 1; c.n_dst = p->n_hub_chunks;
     c.part_row = p->hub_chunk_row; c.state_acc = p->hub_scratch_acc; c.state_ml = p->hub_scratch_ml;
-    c.hub_threshold = 0;
+    c.hub_threshold = 0; c.stats_ml = nullptr;
     rc = launch(c, vec_for(p->hub_scratch_acc, W));
     if (rc != TFGX_OK) return rc;
     GMerge g;
@@ -418,6 +429,7 @@ extern "C" int tfgx_gat_fused_f32(const tfgx_gat_args* p, tfgx_stream_t stream_)
     g.q = p->q; g.ldq = p->ldq; g.k = p->k; g.ldk = p->ldk; g.v = p->v; g.ldv = p->ldv;
     g.out = p->out; g.ldo = p->ldo; g.H = p->H; g.d = p->d; g.dv = p->dv; g.W = int32_t(W);
     g.add_self_loop = p->add_self_loop; g.scale = p->scale; g.act = p->act; g.bias = p->bias;
+    g.stats_ml = p->stats_ml;
     gat_merge_kernel<<<grid_for(g.n_merge * W, kBlock), kBlock, 0, stream>>>(g);
     TFGX_LAUNCH_CHECK("gat_merge_kernel");
     return TFGX_OK;
@@ -437,6 +449,7 @@ extern "C" int tfgx_gat_merge_passes_f32(const tfgx_gat_args* p, const float* st
     g.q = p->q; g.ldq = p->ldq; g.k = p->k; g.ldk = p->ldk; g.v = p->v; g.ldv = p->ldv;
     g.out = p->out; g.ldo = p->ldo; g.H = p->H; g.d = p->d; g.dv = p->dv; g.W = int32_t(W);
     g.add_self_loop = p->add_self_loop; g.scale = p->scale; g.act = p->act; g.bias = p->bias;
+    g.stats_ml = p->stats_ml;
     gat_merge_kernel<<<grid_for(g.n_merge * W, kBlock), kBlock, 0, as_stream(stream)>>>(g);
     TFGX_LAUNCH_CHECK("gat_merge_kernel");
     return TFGX_OK;

@@ -50,6 +50,19 @@ class Layer(object):
     def weights(self):
         return dict(self._weights)
 
+    def parameters(self):
+        """The layer's weight tensors (for torch.optim); call trainable(True) first to track gradients."""
+        return [getattr(self, k) for k in self._weights if getattr(self, k, None) is not None]
+
+    def trainable(self, flag=True):
+        """Turn gradient tracking of every weight on/off.  With it on, calls run through the differentiable
+        kernels of tf_geometric_amd.autograd (the role tf.GradientTape plays for the reference's keras layers)."""
+        for k in list(self._weights):
+            t = getattr(self, k, None)
+            if t is not None:
+                t.requires_grad_(flag)
+        return self
+
     def build(self, input_shapes):
         raise NotImplementedError
 

@@ -14,6 +14,7 @@ import torch
 from ... import _lib as L
 from ...activations import resolve as _resolve_act
 from ...plan import CsrPlan, gemm_bias_act
+from ... import autograd as AG
 
 
 def _linear(x, kernel, bias, activation):
@@ -48,12 +49,14 @@ def gat_args(Q, K, V, num_heads, n_dst, col, add_self_loop=True, bias=None, act=
     return a, out, (Q, K, V)
 
 
-def gat_attention(plan, Q, K, V, num_heads, add_self_loop=True, bias=None, act=L.ACT_NONE):
+def gat_attention(plan, Q, K, V, num_heads, add_self_loop=True, bias=None, act=L.ACT_NONE, stats_ml=None):
     """Fused SDDMM + edge softmax + SpMM over `plan` (tfgx_gat_fused_f32). Q:[n_dst,A] K:[n_src,A] V:[n_src,W].
     Destinations with very many in-edges (plan.hub_info()) are processed chunk-wise and merged."""
     lib = L.require_gpu()
     a, out, keep = gat_args(Q, K, V, num_heads, plan.n_dst, plan.col, add_self_loop, bias, act)
     a.row_ptr = plan.row_ptr.data_ptr()
+    if stats_ml is not None:
+        a.stats_ml = stats_ml.data_ptr()      # (m, l) per row and head, kept for the backward pass
     hub = plan.hub_info()
     if hub is not None:
         hub_rows, chunk_ptr, chunk_begin, chunk_end, chunk_row = hub
@@ -68,6 +71,22 @@ def gat_attention(plan, Q, K, V, num_heads, add_self_loop=True, bias=None, act=L
         a.hub_scratch_acc, a.hub_scratch_ml = s_acc.data_ptr(), s_ml.data_ptr()
     L.check(lib.tfgx_gat_fused_f32(ctypes.byref(a), L.stream_ptr()), "tfgx_gat_fused_f32")
     return out
+
+
+def _gat_train(x, plan, wq, bq, qact, wk, bk, kact, kernel, bias, activation, num_heads, split_value_heads):
+    """Differentiable route (autograd.py): same math, un-fused epilogues."""
+    def lin(w, b, actv):
+        code, post = _resolve_act(actv)
+        return AG.apply_activation(AG.linear(x, w, b, code), L.ACT_NONE, post)
+    Q, K, V = lin(wq, bq, qact), lin(wk, bk, kact), AG.linear(x, kernel)
+    h = AG.gat_attention(plan, Q, K, V, num_heads)
+    if not split_value_heads:
+        U = int(V.shape[1]) // num_heads
+        h = h.view(h.shape[0], num_heads, U).sum(1) / num_heads
+    if bias is not None:
+        h = h + L.as_f32(bias)
+    code, post = _resolve_act(activation)
+    return AG.apply_activation(h, code, post)
 
 
 def gat(x, edge_index,
@@ -90,6 +109,9 @@ def gat(x, edge_index,
     x = L.as_f32(x)
     n = int(x.shape[0])
     plan = CsrPlan.from_cache(edge_index, n, n, cache)
+    if AG.needs_grad(x, query_kernel, query_bias, key_kernel, key_bias, kernel, bias):
+        return _gat_train(x, plan, query_kernel, query_bias, query_activation, key_kernel, key_bias, key_activation,
+                          kernel, bias, activation, num_heads, split_value_heads)
     Q = _linear(x, query_kernel, query_bias, query_activation)       # :52-54 (gather by row happens in-kernel)
     K = _linear(x, key_kernel, key_bias, key_activation)             # :61-63
     V = gemm_bias_act(x, kernel)                                     # :70

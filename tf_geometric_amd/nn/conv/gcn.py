@@ -11,6 +11,7 @@ from ... import _lib as L
 from ...activations import resolve as _resolve_act
 from ...plan import segment_reduce, gemm_bias_act
 from ...sparse import SparseMatrix
+from ... import autograd as AG
 
 CACHE_KEY_GCN_NORMED_ADJ_TEMPLATE = "gcn_normed_adj_{}_{}_{}_{}_{}"
 
@@ -154,6 +155,15 @@ def gcn(x, sparse_adj, kernel, bias=None, activation=None, norm="both", add_self
     normed = normed.dropout(edge_drop_rate, training=training)                                    # :262
     x = L.as_f32(x)
     act, post = _resolve_act(activation)
+    if AG.needs_grad(x, kernel, bias):      # training: differentiable un-fused route (autograd.py)
+        narrow_first = kernel is not None and int(x.shape[1]) < int(kernel.shape[1])
+        h = x if (kernel is None or narrow_first) else AG.linear(x, kernel)
+        h = AG.aggregate(normed.plan, h, L.SUM, normed.w_csr, normed.self_coef)
+        if narrow_first:
+            h = AG.linear(h, kernel)
+        if bias is not None:
+            h = h + L.as_f32(bias)
+        return AG.apply_activation(h, act, post)
     bias_t = None if bias is None else L.as_f32(bias).contiguous()
     if kernel is not None and int(x.shape[1]) < int(kernel.shape[1]):
         # A_hat @ (x @ W) == (A_hat @ x) @ W: gather at the NARROWER width (bytes per edge = 4*min(F, units) + 8),

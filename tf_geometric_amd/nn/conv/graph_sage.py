@@ -17,6 +17,7 @@ from ...activations import resolve as _resolve_act
 from ...plan import CsrPlan, segment_reduce, gemm_bias_act, l2_normalize_rows_
 from ...sparse import SparseMatrix
 from .gcn import gcn_norm_adj
+from ... import autograd as AG
 
 
 def _combine(from_x_kernel, x, from_neigh_kernel, reduced, bias, activation, concat, normalize):
@@ -25,6 +26,15 @@ def _combine(from_x_kernel, x, from_neigh_kernel, reduced, bias, activation, con
     act, post = _resolve_act(activation)
     n = int(x.shape[0])
     ku_x, ku_n = int(from_x_kernel.shape[1]), int(from_neigh_kernel.shape[1])
+    if AG.needs_grad(x, reduced, from_x_kernel, from_neigh_kernel, bias):     # training route (autograd.py)
+        a, b = AG.linear(x, from_x_kernel), AG.linear(reduced, from_neigh_kernel)
+        h = torch.cat([a, b], dim=1) if concat else a + b
+        if bias is not None:
+            h = h + L.as_f32(bias)
+        h = AG.apply_activation(h, act, post)
+        if normalize:
+            h = h * torch.rsqrt(torch.clamp((h * h).sum(-1, keepdim=True), min=1e-12))
+        return h
     bias_t = None if bias is None else L.as_f32(bias).contiguous()
     if concat:
         h = torch.empty((n, ku_x + ku_n), dtype=torch.float32, device=x.device)
@@ -51,6 +61,8 @@ def _neighbor_reduce(x, edge_index, edge_weight, op, cache):
     n = int(x.shape[0])
     plan = CsrPlan.from_cache(edge_index, n, n, cache)
     w_csr = plan.edge_attr_to_csr(edge_weight) if edge_weight is not None else None   # :38-39
+    if AG.needs_grad(x):
+        return x, AG.aggregate(plan, x, op, w_csr)
     return x, segment_reduce(plan, x, op, w_csr=w_csr)
 
 
@@ -79,8 +91,14 @@ def gcn_graph_sage(x, edge_index, edge_weight, kernel, bias=None, activation=Non
     renorm = bool(cache)                                                            # :142 (positional slip)
     adj = SparseMatrix(ei, edge_weight, [n, n])
     normed = gcn_norm_adj(adj, renorm=renorm, improved=False, cache=None)
-    reduced = normed.matmul(x)                                                      # :143-150
     act, post = _resolve_act(activation)
+    if AG.needs_grad(x, kernel, bias):
+        reduced = AG.aggregate(normed.plan, x, L.SUM, normed.w_csr, normed.self_coef)
+        h = AG.apply_activation(AG.linear(reduced, kernel, bias, act), L.ACT_NONE, post)
+        if normalize:
+            h = h * torch.rsqrt(torch.clamp((h * h).sum(-1, keepdim=True), min=1e-12))
+        return h
+    reduced = normed.matmul(x)                                                      # :143-150
     h = gemm_bias_act(reduced, kernel, bias=bias, act=act)                          # :152-157
     if post is not None:
         h = post(h)
@@ -98,6 +116,11 @@ def _pool_graph_sage(x, edge_index, edge_weight, self_kernel, neighbor_mlp_kerne
     n = int(x.shape[0])
     plan = CsrPlan.from_cache(edge_index, n, n, cache)
     act, post = _resolve_act(activation)
+    if AG.needs_grad(x, neighbor_mlp_kernel, neighbor_mlp_bias, self_kernel, neighbor_kernel, bias):
+        h = AG.apply_activation(AG.linear(x, neighbor_mlp_kernel, neighbor_mlp_bias, act), L.ACT_NONE, post)
+        reduced = AG.aggregate(plan, h, op)
+        return _combine(L.as_f32(self_kernel), x, L.as_f32(neighbor_kernel), reduced, bias, activation, concat,
+                        normalize)
     h = gemm_bias_act(x, neighbor_mlp_kernel, bias=neighbor_mlp_bias, act=act)      # :199-204 per node (weight == 1)
     if post is not None:
         h = post(h)

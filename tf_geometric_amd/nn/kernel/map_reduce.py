@@ -10,6 +10,7 @@ import torch
 
 from ... import _lib as L
 from ...plan import CsrPlan, segment_reduce, gather_rows
+from ... import autograd as AG
 
 
 def identity_mapper(repeated_x, neighbor_x, edge_weight=None):
@@ -89,6 +90,11 @@ def aggregate_neighbors(x, edge_index, edge_weight=None, mapper=identity_mapper,
             raise TypeError("gcn_mapper needs edge_weight (tf.expand_dims(None) in the reference, gcn.py:222)")
         plan = CsrPlan.from_cache(ei, n, int(x.shape[0]), cache)
         w_csr = plan.edge_attr_to_csr(edge_weight) if mapper is gcn_mapper else None
+        if AG.needs_grad(x, edge_weight):        # training route: kernels with a backward (autograd.py)
+            if mapper is gcn_mapper and isinstance(edge_weight, torch.Tensor) and edge_weight.requires_grad:
+                w_csr = L.as_f32(edge_weight)[plan.perm.long()]          # differentiable permutation
+            red = AG.aggregate(plan, x, _REDUCER_OPS[reducer], w_csr)
+            return x + red if updater is sum_updater else red
         return segment_reduce(plan, x, _REDUCER_OPS[reducer], w_csr=w_csr,
                               add_x=x if updater is sum_updater else None)
     # generic route: explicit gathers, user mapper, HIP reducer
