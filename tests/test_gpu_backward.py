@@ -154,6 +154,6 @@ def test_sage_layers_train_step_decreases_loss(tfg, oracle, cls):
         loss = ((out - target) ** 2).mean()
         loss.backward()
         opt.step()
-        losses.append(float(loss))
-    assert losses[-1] < losses[0] * 0.98, losses
+        losses.append(float(loss.detach()))
+    assert losses[-1] < losses[0] * 0.995 and all(b <= a + 1e-6 for a, b in zip(losses, losses[1:])), losses
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in layer.parameters())
