@@ -421,3 +421,143 @@ def synthetic_edges(num_nodes, num_edges, seed=0):
 def glorot_uniform(rng, fan_in, fan_out):
     limit = np.sqrt(6.0 / (fan_in + fan_out))
     return rng.uniform(-limit, limit, size=(fan_in, fan_out)).astype(np.float32)
+
+
+# ----------------------------------------------------------------------------
+# "next row 2" convolutions: restated line by line for the parity tests
+# ----------------------------------------------------------------------------
+
+def _mlp_encoder(x, kernels, biases, dense_activation, acc):
+    h = np.asarray(x, np.float32)
+    if kernels is not None:
+        last = len(kernels) - 1
+        for i, (k_, b_) in enumerate(zip(kernels, biases)):
+            h = matmul(h, k_, acc)
+            if b_ is not None:
+                h = h + np.asarray(b_, np.float32)
+            if i < last:
+                h = _act(dense_activation, h)
+    return h.astype(np.float32)
+
+
+def gin(x, edge_index, mlp_model, eps=0.0, acc=np.float64):
+    """nn/conv/gin.py:11-38."""
+    x = np.asarray(x, np.float32)
+    N = x.shape[0]
+    E = np.asarray(edge_index).shape[1]
+    neighbor_h = spmm(edge_index, np.ones(E, np.float32), (N, N), x, acc=acc)     # :32-34
+    return mlp_model((x * (1.0 + eps) + neighbor_h).astype(np.float32))           # :35-36
+
+
+def sgc(x, edge_index, edge_weight, k, kernel, bias=None, activation=None, renorm=True, improved=False, acc=np.float64):
+    """nn/conv/sgc.py:10-61."""
+    x = np.asarray(x, np.float32)
+    N = x.shape[0]
+    ei, nw = gcn_norm_adj(edge_index, edge_weight, N, renorm=renorm, improved=improved, acc=acc)
+    h = matmul(x, kernel, acc)
+    for _ in range(k):
+        h = spmm(ei, nw, (N, N), h, acc=acc)
+    if bias is not None:
+        h = h + np.asarray(bias, np.float32)
+    return _act(activation, h).astype(np.float32)
+
+
+def tagcn(x, edge_index, edge_weight, k, kernel, bias=None, activation=None, renorm=False, improved=False, acc=np.float64):
+    """nn/conv/tagcn.py:10-51."""
+    x = np.asarray(x, np.float32)
+    N = x.shape[0]
+    ei, nw = gcn_norm_adj(edge_index, edge_weight, N, renorm=renorm, improved=improved, acc=acc)
+    xs = [x]
+    for _ in range(k):
+        xs.append(spmm(ei, nw, (N, N), xs[-1], acc=acc))
+    out = matmul(np.concatenate(xs, axis=-1), kernel, acc)
+    if bias is not None:
+        out = out + np.asarray(bias, np.float32)
+    return _act(activation, out).astype(np.float32)
+
+
+def appnp(x, edge_index, edge_weight, kernels, biases, dense_activation="relu", activation=None, k=10, alpha=0.1,
+          acc=np.float64):
+    """nn/conv/appnp.py:11-92 (inference)."""
+    N = np.asarray(x).shape[0]
+    ei, nw = gcn_norm_adj(edge_index, edge_weight, N, acc=acc)
+    h = _mlp_encoder(x, kernels, biases, dense_activation, acc)
+    output = h
+    for _ in range(k):
+        output = spmm(ei, nw, (N, N), output, acc=acc)
+        output = (output * (1.0 - alpha) + h * alpha).astype(np.float32)
+    return _act(activation, output).astype(np.float32)
+
+
+def ssgc(x, edge_index, edge_weight, kernels=None, biases=None, k=10, alpha=0.1, dense_activation="relu",
+         activation=None, acc=np.float64):
+    """nn/conv/ssgc.py:11-99 (inference)."""
+    N = np.asarray(x).shape[0]
+    ei, nw = gcn_norm_adj(edge_index, edge_weight, N, acc=acc)
+    h = _mlp_encoder(x, kernels, biases, dense_activation, acc)
+    output = h * alpha
+    for _ in range(k):
+        h = spmm(ei, nw, (N, N), h, acc=acc)
+        output = output + (1 - alpha) * h / k
+    return _act(activation, output).astype(np.float32)
+
+
+def le_conv(x, edge_index, edge_weight, self_kernel, self_bias, aggr_self_kernel, aggr_self_bias,
+            aggr_neighbor_kernel, aggr_neighbor_bias, activation=None, acc=np.float64):
+    """nn/conv/le_conv.py:5-52, incl. its indexing: both gathered terms use `col` (:40-41)."""
+    x = np.asarray(x, np.float32)
+    N = x.shape[0]
+    ei = np.asarray(edge_index)
+    w = np.ones(ei.shape[1], np.float32) if edge_weight is None else np.asarray(edge_weight, np.float32)
+
+    def lin(k_, b_):
+        h = matmul(x, k_, acc)
+        return h + np.asarray(b_, np.float32) if b_ is not None else h
+    self_h, a_self, a_nb = lin(self_kernel, self_bias), lin(aggr_self_kernel, aggr_self_bias), lin(aggr_neighbor_kernel, aggr_neighbor_bias)
+    row, col = ei[0], ei[1]
+    rep = (a_self[col].astype(acc) - a_nb[col].astype(acc)) * w[:, None].astype(acc)
+    aggr = unsorted_segment_sum(rep, row, N, acc=acc).astype(np.float32)
+    return _act(activation, self_h + aggr).astype(np.float32)
+
+
+def get_laplacian(edge_index, num_nodes, edge_weight, normalization_type, fill_weight=1.0, acc=np.float64):
+    """utils/graph_utils.py:554-603."""
+    ei = np.asarray(edge_index, np.int32)
+    w = np.asarray(edge_weight, np.float32)
+    row, col = ei[0], ei[1]
+    deg = unsorted_segment_sum(w.astype(acc), row, num_nodes, acc=acc)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        if normalization_type is None:
+            ei2, w2 = add_self_loop_edge(ei, num_nodes, w, fill_weight=fill_weight)
+            return ei2, (_remove_inf_and_nan(deg)[ei2[0]] - w2).astype(np.float32)
+        if normalization_type == "sym":
+            dis = _remove_inf_and_nan(np.power(deg, -0.5))
+            nw = dis[row] * w * dis[col]
+        else:
+            dinv = _remove_inf_and_nan(1.0 / deg)
+            nw = dinv[row] * w
+    return add_self_loop_edge(ei, num_nodes, nw.astype(np.float32), fill_weight=fill_weight)
+
+
+def chebynet(x, edge_index, edge_weight, k, kernels, bias=None, activation=None, normalization_type="sym",
+             acc=np.float64):
+    """nn/conv/chebynet.py:27-137 with lambda_max = 2.0."""
+    x = np.asarray(x, np.float32)
+    N = x.shape[0]
+    ei = np.asarray(edge_index, np.int32)
+    w = np.ones(ei.shape[1], np.float32) if edge_weight is None else np.asarray(edge_weight, np.float32)
+    keep = ei[0] != ei[1]                                               # remove_self_loop_edge (:34)
+    lei, lw = get_laplacian(ei[:, keep], N, w[keep], normalization_type, acc=acc)
+    lw = (2.0 * lw) / 2.0                                                # :43
+    T0 = x
+    out = matmul(T0, kernels[0], acc)
+    if k > 1:
+        T1 = spmm(lei, lw, (N, N), x, acc=acc)
+        out = out + matmul(T1, kernels[1], acc)
+    for i in range(2, k):
+        T2 = (spmm(lei, lw, (N, N), T1, acc=acc) * 2.0 - T0).astype(np.float32)
+        out = out + matmul(T2, kernels[i], acc)
+        T0, T1 = T1, T2
+    if bias is not None:
+        out = out + np.asarray(bias, np.float32)
+    return _act(activation, out).astype(np.float32)

@@ -8,3 +8,4 @@ from .conv.gcn import (gcn, gcn_norm_adj, gcn_norm_edge, gcn_build_cache_by_adj,
 from .conv.gat import gat
 from .conv.graph_sage import (mean_graph_sage, sum_graph_sage, gcn_graph_sage, mean_pool_graph_sage,
                               max_pool_graph_sage)
+from .conv.propagation import gin, sgc, tagcn, appnp, ssgc, chebynet, le_conv, chebynet_norm_edge

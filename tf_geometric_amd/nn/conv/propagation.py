@@ -1,0 +1,199 @@
+# coding=utf-8
+"""The remaining SpMM-shaped convolutions of tf_geometric as compositions of the hot-path kernels (SURVEY.md §8f
+rank 2): every one is "dense GEMM(s) + k x (A_hat @ h)" over ONE cached plan — no new kernels.
+
+    gin       nn/conv/gin.py:11-38          sgc      nn/conv/sgc.py:10-61        tagcn  nn/conv/tagcn.py:10-51
+    appnp     nn/conv/appnp.py:11-92        ssgc     nn/conv/ssgc.py:11-99       le_conv nn/conv/le_conv.py:5-52
+    chebynet  nn/conv/chebynet.py:27-137 (+ utils/graph_utils.py:554-603 get_laplacian)
+
+A_hat @ h is `prop(...)`: the differentiable aggregate when gradients are being recorded, the fused kernel otherwise.
+"""
+import torch
+
+from ... import _lib as L
+from ... import autograd as AG
+from ...activations import resolve as _resolve_act
+from ...plan import CsrPlan, segment_reduce, gemm_bias_act
+from ...sparse import SparseMatrix
+from .gcn import gcn_norm_adj, NormedAdj
+
+CACHE_KEY_CHEBYNET_NORMED_EDGE_TEMPLATE = "chebynet_normed_edge_{}"
+
+
+def _prop(plan, h, w_csr, self_coef):
+    if AG.needs_grad(h):
+        return AG.aggregate(plan, h, L.SUM, w_csr, self_coef)
+    return segment_reduce(plan, h, L.SUM, w_csr=w_csr, self_coef=self_coef)
+
+
+def _dense(h, kernel, bias=None, activation=None):
+    act, post = _resolve_act(activation)
+    if AG.needs_grad(h, kernel, bias):
+        return AG.apply_activation(AG.linear(h, kernel, bias, act), L.ACT_NONE, post)
+    out = gemm_bias_act(h, kernel, bias=bias, act=act)
+    return post(out) if post is not None else out
+
+
+def _finish(h, bias, activation):
+    act, post = _resolve_act(activation)
+    if bias is not None:
+        h = h + L.as_f32(bias)
+    return AG.apply_activation(h, act, post)
+
+
+def _normed(x, edge_index, edge_weight, cache, **norm_kwargs):
+    n = int(x.shape[0])
+    key = "tfgx_gcn_adj"
+    adj = cache.get(key) if cache is not None else None
+    if adj is None:
+        adj = SparseMatrix(edge_index, edge_weight, [n, n])
+        if cache is not None:
+            cache[key] = adj
+    return gcn_norm_adj(adj, cache=cache, **norm_kwargs)
+
+
+def gin(x, edge_index, mlp_model, eps=0.0, training=None, cache=None):
+    """h = mlp((1 + eps) * x + sum_{j in N(i)} x_j)   (reference: gin.py:11-38). `mlp_model` is any callable."""
+    x = L.as_f32(x)
+    n = int(x.shape[0])
+    plan = CsrPlan.from_cache(edge_index, n, n, cache)
+    neighbor_h = _prop(plan, x, None, None)                           # SparseMatrix(edge_index) @ x  (:32-34)
+    h = x * (1.0 + eps) + neighbor_h                                   # :35
+    try:
+        return mlp_model(h, training=training)                         # :36
+    except TypeError:
+        return mlp_model(h)
+
+
+def sgc(x, edge_index, edge_weight, k, kernel, bias=None, activation=None, renorm=True, improved=False, cache=None):
+    """A_hat^k (x @ kernel) + bias  (reference: sgc.py:10-61; the GEMM comes first there too)."""
+    x = L.as_f32(x)
+    normed = _normed(x, edge_index, edge_weight, cache, renorm=renorm, improved=improved)
+    h = _dense(x, kernel)                                              # :33-36
+    for _ in range(k):
+        h = _prop(normed.plan, h, normed.w_csr, normed.self_coef)      # :38-39
+    return _finish(h, bias, activation)
+
+
+def tagcn(x, edge_index, edge_weight, k, kernel, bias=None, activation=None, renorm=False, improved=False, cache=None):
+    """concat(x, A x, ..., A^k x) @ kernel  (reference: tagcn.py:10-51)."""
+    x = L.as_f32(x)
+    normed = _normed(x, edge_index, edge_weight, cache, renorm=renorm, improved=improved)
+    xs = [x]
+    for _ in range(k):
+        xs.append(_prop(normed.plan, xs[-1], normed.w_csr, normed.self_coef))    # :37-40
+    h = torch.cat(xs, dim=-1)                                          # :42
+    return _finish(_dense(h, kernel), bias, activation)                # :44-49
+
+
+def _mlp_encoder(x, kernels, biases, dense_activation, training, dense_drop_rate, last_dense_drop_rate):
+    if training and (dense_drop_rate > 0.0 or last_dense_drop_rate > 0.0):
+        raise NotImplementedError("dropout inside APPNP / SSGC is not implemented (inference or rate 0 only)")
+    h = x
+    if kernels is not None:
+        last = len(kernels) - 1
+        for i, (kernel, bias) in enumerate(zip(kernels, biases)):
+            h = _dense(h, kernel, bias, dense_activation if i < last else None)
+    return h
+
+
+def appnp(x, edge_index, edge_weight, kernels, biases, dense_activation="relu", activation=None, k=10, alpha=0.1,
+          dense_drop_rate=0.0, last_dense_drop_rate=0.0, edge_drop_rate=0.0, cache=None, training=False):
+    """Z <- (1 - alpha) A_hat Z + alpha H, k times, H = MLP(x)  (reference: appnp.py:11-92)."""
+    x = L.as_f32(x)
+    normed = _normed(x, edge_index, edge_weight, cache).dropout(edge_drop_rate, training=training)
+    h = _mlp_encoder(x, kernels, biases, dense_activation, training, dense_drop_rate, last_dense_drop_rate)
+    output = h
+    for _ in range(k):
+        output = _prop(normed.plan, output, normed.w_csr, normed.self_coef)       # :84-86
+        output = output * (1.0 - alpha) + h * alpha
+    return _finish(output, None, activation)
+
+
+def ssgc(x, edge_index, edge_weight, kernels=None, biases=None, k=10, alpha=0.1, dense_activation="relu",
+         activation=None, dense_drop_rate=0.0, last_dense_drop_rate=0.0, edge_drop_rate=0.0, cache=None,
+         training=False):
+    """alpha H + (1 - alpha)/k * sum_{t=1..k} A_hat^t H  (reference: ssgc.py:11-99)."""
+    x = L.as_f32(x)
+    normed = _normed(x, edge_index, edge_weight, cache).dropout(edge_drop_rate, training=training)
+    h = _mlp_encoder(x, kernels, biases, dense_activation, training, dense_drop_rate, last_dense_drop_rate)
+    output = h * alpha                                                 # :90
+    for _ in range(k):
+        h = _prop(normed.plan, h, normed.w_csr, normed.self_coef)      # :92-94
+        output = output + (1 - alpha) * h / k
+    return _finish(output, None, activation)
+
+
+def le_conv(x, edge_index, edge_weight, self_kernel, self_bias, aggr_self_kernel, aggr_self_bias,
+            aggr_neighbor_kernel, aggr_neighbor_bias, activation=None, cache=None):
+    """Reference le_conv.py:5-52, literally: BOTH gathered terms are indexed by `col` (:40-41), so the aggregate is
+    sum_j w_ij * (x_j @ aggr_self_kernel - x_j @ aggr_neighbor_kernel)."""
+    x = L.as_f32(x)
+    n = int(x.shape[0])
+    plan = CsrPlan.from_cache(edge_index, n, n, cache)
+    if edge_weight is None:
+        w_csr = None                                                   # ones (:21-22)
+    else:
+        w_csr = plan.edge_attr_to_csr(edge_weight)
+    self_h = _dense(x, self_kernel, self_bias)
+    diff = _dense(x, aggr_self_kernel, aggr_self_bias) - _dense(x, aggr_neighbor_kernel, aggr_neighbor_bias)
+    h = self_h + _prop(plan, diff, w_csr, None)                        # :43-47
+    return _finish(h, None, activation)
+
+
+def chebynet_norm_edge(edge_index, num_nodes, edge_weight=None, normalization_type="sym",
+                       use_dynamic_lambda_max=False, cache=None):
+    """Scaled "Laplacian" of chebynet.py:27-54 + graph_utils.get_laplacian (:554-603), in plan form (a NormedAdj):
+    self-loops removed, sym: D^-1/2 A D^-1/2 + I, rw: D^-1 A + I, None: (deg_r - w) on edges and on an appended
+    unit self-loop; everything times 2 / lambda_max (lambda_max = 2 unless dynamic, which needs scipy eigs)."""
+    if cache is not None:
+        key = CACHE_KEY_CHEBYNET_NORMED_EDGE_TEMPLATE.format(normalization_type)
+        if cache.get(key) is not None:
+            return cache[key]
+    if use_dynamic_lambda_max:
+        raise NotImplementedError("use_dynamic_lambda_max needs a sparse eigen-solver (scipy eigs in the reference)")
+    if normalization_type not in (None, "sym", "rw"):
+        raise AssertionError("normalization_type must be None, 'sym' or 'rw'")        # graph_utils.py:556
+    ei = L.as_i32(edge_index)
+    E = int(ei.shape[1])
+    w = torch.ones(E, dtype=torch.float32, device=ei.device) if edge_weight is None else L.as_f32(edge_weight)
+    keep = ei[0] != ei[1]                                              # remove_self_loop_edge (chebynet.py:34)
+    ei, w = ei[:, keep].contiguous(), w[keep].contiguous()
+    adj = SparseMatrix(ei, w, [num_nodes, num_nodes])
+    if normalization_type == "sym":
+        normed = gcn_norm_adj(adj, renorm=False)                      # D^-1/2 A D^-1/2, + fill*I afterwards
+        w_csr, self_coef = normed.w_csr, normed.self_coef
+    elif normalization_type == "rw":
+        normed = gcn_norm_adj(adj, norm="left", add_self_loop=False, sym=False)
+        w_csr = normed.w_csr
+        self_coef = torch.ones(num_nodes, dtype=torch.float32, device=ei.device)
+    else:
+        deg = adj.segment_sum(axis=-1)
+        plan = adj.plan
+        rows = torch.repeat_interleave(torch.arange(num_nodes, device=ei.device), plan.in_degree().long())
+        w_csr = deg[rows] - adj.value_csr
+        self_coef = deg - 1.0
+        normed = NormedAdj(plan, w_csr, self_coef, [num_nodes, num_nodes])
+    scale = 2.0 / 2.0                                                  # lambda_max = 2.0 (chebynet.py:41-43)
+    out = NormedAdj(normed.plan, w_csr * scale, self_coef * scale, [num_nodes, num_nodes])
+    if cache is not None:
+        cache[key] = out
+    return out
+
+
+def chebynet(x, edge_index, edge_weight, k, kernels, bias=None, activation=None, normalization_type="sym",
+             use_dynamic_lambda_max=False, cache=None):
+    """sum_i T_i(L~) x @ kernels[i]  (reference: chebynet.py:83-137)."""
+    x = L.as_f32(x)
+    n = int(x.shape[0])
+    normed = chebynet_norm_edge(edge_index, n, edge_weight, normalization_type, use_dynamic_lambda_max, cache)
+    T0 = x
+    out = _dense(T0, kernels[0])                                       # :101-106
+    if k > 1:
+        T1 = _prop(normed.plan, x, normed.w_csr, normed.self_coef)     # :112
+        out = out + _dense(T1, kernels[1])
+    for i in range(2, k):
+        T2 = _prop(normed.plan, T1, normed.w_csr, normed.self_coef) * 2.0 - T0       # :123-125
+        out = out + _dense(T2, kernels[i])
+        T0, T1 = T1, T2
+    return _finish(out, bias, activation)
