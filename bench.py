@@ -285,6 +285,15 @@ def extras(tfg, L, synthetic, x, ei, n, e, f, cache):
     res["maxpool_sage_layer_units64_ms"] = _time(lambda: mp([x, ei, w1], cache=cache))
     gat = tfg.layers.GAT(64, attention_units=8, num_heads=8, activation=tfg.relu)
     res["gat_layer_H8_A8_U64_ms"] = _time(lambda: gat([x, ei], cache=cache))
+    # 2-layer GCN (F -> 256 -> 40, BASELINE configs[1] model): eager launches vs one hipGraph replay
+    g0, g1 = tfg.layers.GCN(256, activation=tfg.relu), tfg.layers.GCN(40)
+
+    def two_layer(xx):
+        return g1([g0([xx, ei], cache=cache), ei], cache=cache)
+
+    res["gcn_2layer_eager_ms"] = _time(lambda: two_layer(x))
+    cap = tfg.CapturedForward(two_layer, x)
+    res["gcn_2layer_hipgraph_ms"] = _time(lambda: cap.graph.replay())
     from tf_geometric_amd.plan import gemm_bias_act
     k = L.as_f32(synthetic.glorot_uniform(f, 256))
     ms = _time(lambda: gemm_bias_act(x, k))

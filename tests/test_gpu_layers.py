@@ -227,3 +227,24 @@ def test_gat_hub_rows_chunked_merge(tfg, oracle):
                          cache={"tfgx_csr_plan": plan}).cpu().numpy()
         ref = oracle.gat(x, ei, wq, bq, "relu", wk, bq, "relu", wv, b, "relu", num_heads=heads)
         assert_parity(got, ref, tol=2e-5, what="GAT hub H={}".format(heads))
+
+
+def test_hip_graph_replay_of_two_layer_gcn(tfg, oracle):
+    """A 2-layer GCN forward over a cached plan is captured into a hipGraph and replayed on new inputs."""
+    import torch
+    x, ei, w, rng = _graph(oracle, 3000, 40000, 32, seed=33)
+    l0, l1 = tfg.layers.GCN(16, activation=tfg.relu), tfg.layers.GCN(7)
+    cache = {}
+
+    def model(xx):
+        return l1([l0([xx, ei, w], cache=cache), ei, w], cache=cache)
+
+    eager = model(tfg._lib.as_f32(x)).clone()
+    cap = tfg.CapturedForward(model, x)
+    assert torch.equal(cap(x), eager)
+    x2 = (x * 0.5 + 1.0).astype(np.float32)
+    got = cap(x2).clone()
+    assert torch.equal(got, model(tfg._lib.as_f32(x2)))
+    ref = oracle.gcn(oracle.gcn(x2, ei, w, l0.kernel.cpu().numpy(), l0.bias.cpu().numpy(), "relu"), ei, w,
+                     l1.kernel.cpu().numpy(), l1.bias.cpu().numpy())
+    assert_parity(got.cpu().numpy(), ref, what="captured 2-layer GCN")

@@ -16,5 +16,6 @@ from . import nn
 from . import layers
 from . import dist
 from . import utils
+from .graph_capture import CapturedForward
 
 __version__ = "0.1.0"
