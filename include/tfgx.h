@@ -63,6 +63,18 @@ int tfgx_permute_rows_f32(const float* src, const int32_t* perm, int64_t E, int6
                           tfgx_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Edge preprocessing right before the path: merge_duplicated_edge
+ * (tf_geometric/utils/graph_utils.py:67-125) = tf.unique over the hash n*row+col.  Outputs the unique edges in
+ * FIRST-OCCURRENCE order (tf.unique's order) and unique_index[E] (edge -> unique edge), with which edge
+ * properties are merged by tfgx_segment_reduce_f32 (sum / mean / max; min = -max(-x)).  *n_unique is a device int32.
+ * convert_edge_to_upper / convert_edge_to_directed (:126-212) are this call on (min, max) endpoint pairs.
+ * ------------------------------------------------------------------------------------------- */
+size_t tfgx_merge_edges_workspace_bytes(int64_t E, int64_t n);
+int tfgx_merge_duplicated_edges(const int32_t* row, const int32_t* col, int64_t E, int64_t n, int32_t* out_row,
+                                int32_t* out_col, int32_t* unique_index, int32_t* n_unique, void* workspace,
+                                size_t workspace_bytes, tfgx_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Gather - scale - segment reduce.  Replaces, fused and without materialising [E,F]:
  *   tf.gather(x, col)                               nn/kernel/map_reduce.py:63, nn/conv/graph_sage.py:36
  *   gcn_mapper (neighbor_x * w[:,None])             nn/conv/gcn.py:221-222

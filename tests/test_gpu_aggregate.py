@@ -193,3 +193,53 @@ def test_neighbor_count_mapper_and_utils(tfg, oracle):
     assert np.array_equal(ei2, oe) and np.array_equal(w2, ow)
     ei3, w3 = tfg.utils.add_self_loop_edge(tfg._lib.as_i32(ei), 120)
     assert np.array_equal(ei3.cpu().numpy(), oe) and w3 is None
+
+
+def _np_merge(ei, props, modes):
+    """tf.unique-order merge restated with numpy (first-occurrence order)."""
+    n = int(ei.max()) + 1
+    h = ei[0].astype(np.int64) * n + ei[1]
+    _, first, inv = np.unique(h, return_index=True, return_inverse=True)
+    order = np.argsort(first, kind="stable")
+    rank = np.empty_like(order)
+    rank[order] = np.arange(order.size)
+    uidx = rank[inv]
+    u = ei[:, np.sort(first)]
+    out = []
+    for p, m in zip(props, modes):
+        res = np.zeros(order.size, np.float64) if m in ("sum", "mean") else np.full(order.size, -np.inf if m == "max" else np.inf)
+        cnt = np.bincount(uidx, minlength=order.size)
+        if m in ("sum", "mean"):
+            np.add.at(res, uidx, p.astype(np.float64))
+            res = res / cnt if m == "mean" else res
+        elif m == "max":
+            np.maximum.at(res, uidx, p)
+        else:
+            np.minimum.at(res, uidx, p)
+        out.append(res.astype(np.float32))
+    return u, out
+
+
+def test_edge_preprocessing_on_device(tfg):
+    # the reference's docstring example (graph_utils.py:157-158)
+    d, _ = tfg.utils.convert_edge_to_directed(np.array([[1, 3, 5], [2, 1, 4]], np.int32))
+    assert d.tolist() == [[1, 1, 4, 2, 3, 5], [2, 3, 5, 1, 1, 4]] or d.tolist() == [[1, 3, 5, 2, 1, 4], [2, 1, 4, 1, 3, 5]]
+    rng = np.random.Generator(np.random.PCG64(8))
+    ei = rng.integers(0, 60, size=(2, 3000), dtype=np.int32)              # many duplicates and self-loops
+    w = rng.uniform(0.5, 1.5, 3000).astype(np.float32)
+    u, props = tfg.utils.merge_duplicated_edge(ei, [w, w, w, w], ["sum", "mean", "max", "min"])
+    ru, rprops = _np_merge(ei, [w, w, w, w], ["sum", "mean", "max", "min"])
+    assert np.array_equal(u, ru)
+    for a, b in zip(props, rprops):
+        assert_parity(a, b, what="merged edge prop")
+    up, (uw,) = tfg.utils.convert_edge_to_upper(ei, [w])
+    rup, (ruw,) = _np_merge(np.stack([ei.min(0), ei.max(0)]), [w], ["sum"])
+    assert np.array_equal(up, rup)
+    assert_parity(uw, ruw, what="upper weights")
+    de, (dw,) = tfg.utils.convert_edge_to_directed(ei, [w])
+    m = rup[0] != rup[1]
+    assert np.array_equal(de, np.concatenate([rup, rup[::-1][:, m]], axis=1))
+    assert_parity(dw, np.concatenate([ruw, ruw[m]]), what="directed weights")
+    e2, w2 = tfg.utils.remove_self_loop_edge(ei, w)
+    keep = ei[0] != ei[1]
+    assert np.array_equal(e2, ei[:, keep]) and np.array_equal(w2, w[keep])

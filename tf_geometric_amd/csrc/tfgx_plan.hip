@@ -78,6 +78,60 @@ __global__ void permute_rows(const float* __restrict__ src, const int32_t* __res
     }
 }
 
+// ---- duplicate-edge merge (tf.unique on n*row+col, first-occurrence order) -------------------------------
+__global__ void edge_hash_iota(const int32_t* __restrict__ row, const int32_t* __restrict__ col, int64_t E, int64_t n,
+                               int64_t* __restrict__ keys, int32_t* __restrict__ vals)
+{
+    int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (; i < E; i += stride) {
+        keys[i] = n * int64_t(row[i]) + int64_t(col[i]);
+        vals[i] = static_cast<int32_t>(i);
+    }
+}
+
+__global__ void mark_heads(const int64_t* __restrict__ keys_s, int64_t E, int32_t* __restrict__ head)
+{
+    int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (; i < E; i += stride) head[i] = (i == 0 || keys_s[i] != keys_s[i - 1]) ? 1 : 0;
+}
+
+// gid_incl = inclusive scan of head (group id + 1 per sorted position)
+__global__ void record_first_pos(const int32_t* __restrict__ head, const int32_t* __restrict__ gid_incl,
+                                 const int32_t* __restrict__ vals_s, int64_t E, int32_t* __restrict__ first_pos,
+                                 int32_t* __restrict__ mark)
+{
+    int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (; i < E; i += stride) {
+        if (head[i]) {   // stable sort: the head of a group is its FIRST occurrence in the caller's order
+            first_pos[gid_incl[i] - 1] = vals_s[i];
+            mark[vals_s[i]] = 1;
+        }
+    }
+}
+
+__global__ void emit_unique(const int64_t* __restrict__ keys_s, const int32_t* __restrict__ vals_s,
+                            const int32_t* __restrict__ head, const int32_t* __restrict__ gid_incl,
+                            const int32_t* __restrict__ first_pos, const int32_t* __restrict__ posrank, int64_t E,
+                            int64_t n, int32_t* __restrict__ out_row, int32_t* __restrict__ out_col,
+                            int32_t* __restrict__ unique_index, int32_t* __restrict__ n_unique)
+{
+    int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (; i < E; i += stride) {
+        const int32_t g = gid_incl[i] - 1;
+        const int32_t r = posrank[first_pos[g]];      // rank of the group by first occurrence
+        unique_index[vals_s[i]] = r;
+        if (head[i]) {
+            out_row[r] = static_cast<int32_t>(keys_s[i] / n);
+            out_col[r] = static_cast<int32_t>(keys_s[i] % n);
+        }
+        if (i == E - 1) *n_unique = gid_incl[i];
+    }
+}
+
 }  // namespace
 }  // namespace tfgx
 
@@ -154,5 +208,76 @@ extern "C" int tfgx_permute_rows_f32(const float* src, const int32_t* perm, int6
     TFGX_REQUIRE(src && perm && dst, "null pointer");
     permute_rows<<<grid_for(E * width, kBlock), kBlock, 0, as_stream(stream)>>>(src, perm, E, width, dst);
     TFGX_LAUNCH_CHECK("permute_rows");
+    return TFGX_OK;
+}
+
+static inline int hash_bits(int64_t n)
+{
+    int b = 1;
+    while (b < 62 && (int64_t(1) << b) < n * n) ++b;
+    return b;
+}
+
+extern "C" size_t tfgx_merge_edges_workspace_bytes(int64_t E, int64_t n)
+{
+    if (E <= 0) return 256;
+    size_t t1 = 0, t2 = 0;
+    const int64_t* k = nullptr;
+    int64_t* ko = nullptr;
+    const int32_t* v = nullptr;
+    int32_t* vo = nullptr;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, t1, k, ko, v, vo, static_cast<int>(E), 0, hash_bits(n));
+    (void)hipcub::DeviceScan::InclusiveSum(nullptr, t2, v, vo, static_cast<int>(E));
+    const size_t a8 = align_up(sizeof(int64_t) * size_t(E)), a4 = align_up(sizeof(int32_t) * size_t(E));
+    return 2 * a8 + 7 * a4 + align_up(t1 > t2 ? t1 : t2) + 256;
+}
+
+extern "C" int tfgx_merge_duplicated_edges(const int32_t* row, const int32_t* col, int64_t E, int64_t n,
+                                           int32_t* out_row, int32_t* out_col, int32_t* unique_index,
+                                           int32_t* n_unique, void* workspace, size_t workspace_bytes,
+                                           tfgx_stream_t stream_)
+{
+    hipStream_t stream = as_stream(stream_);
+    TFGX_REQUIRE(E >= 0 && n >= 1 && n < (int64_t(1) << 31) && n_unique, "bad argument");
+    if (E == 0) {
+        TFGX_HIP_CHECK(hipMemsetAsync(n_unique, 0, sizeof(int32_t), stream));
+        return TFGX_OK;
+    }
+    TFGX_REQUIRE(row && col && out_row && out_col && unique_index && workspace, "null pointer");
+    if (workspace_bytes < tfgx_merge_edges_workspace_bytes(E, n)) {
+        set_error("tfgx_merge_duplicated_edges: workspace too small");
+        return TFGX_ERR_WORKSPACE;
+    }
+    const size_t a8 = align_up(sizeof(int64_t) * size_t(E)), a4 = align_up(sizeof(int32_t) * size_t(E));
+    char* ws = static_cast<char*>(workspace);
+    int64_t* keys = reinterpret_cast<int64_t*>(ws);
+    int64_t* keys_s = reinterpret_cast<int64_t*>(ws + a8);
+    int32_t* vals = reinterpret_cast<int32_t*>(ws + 2 * a8);
+    int32_t* vals_s = reinterpret_cast<int32_t*>(ws + 2 * a8 + a4);
+    int32_t* head = reinterpret_cast<int32_t*>(ws + 2 * a8 + 2 * a4);
+    int32_t* gid = reinterpret_cast<int32_t*>(ws + 2 * a8 + 3 * a4);
+    int32_t* first_pos = reinterpret_cast<int32_t*>(ws + 2 * a8 + 4 * a4);
+    int32_t* mark = reinterpret_cast<int32_t*>(ws + 2 * a8 + 5 * a4);
+    int32_t* posrank = reinterpret_cast<int32_t*>(ws + 2 * a8 + 6 * a4);
+    void* temp = ws + 2 * a8 + 7 * a4;
+    size_t temp_bytes = workspace_bytes - (2 * a8 + 7 * a4);
+    const int g = grid_for(E, kBlock);
+    edge_hash_iota<<<g, kBlock, 0, stream>>>(row, col, E, n, keys, vals);
+    TFGX_LAUNCH_CHECK("edge_hash_iota");
+    size_t tb = temp_bytes;
+    TFGX_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(temp, tb, keys, keys_s, vals, vals_s, static_cast<int>(E), 0,
+                                                      hash_bits(n), stream));
+    mark_heads<<<g, kBlock, 0, stream>>>(keys_s, E, head);
+    TFGX_LAUNCH_CHECK("mark_heads");
+    tb = temp_bytes;
+    TFGX_HIP_CHECK(hipcub::DeviceScan::InclusiveSum(temp, tb, head, gid, static_cast<int>(E), stream));
+    TFGX_HIP_CHECK(hipMemsetAsync(mark, 0, sizeof(int32_t) * size_t(E), stream));
+    record_first_pos<<<g, kBlock, 0, stream>>>(head, gid, vals_s, E, first_pos, mark);
+    TFGX_LAUNCH_CHECK("record_first_pos");
+    tb = temp_bytes;
+    TFGX_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(temp, tb, mark, posrank, static_cast<int>(E), stream));
+    emit_unique<<<g, kBlock, 0, stream>>>(keys_s, vals_s, head, gid, first_pos, posrank, E, n, out_row, out_col,
+                                          unique_index, n_unique);
+    TFGX_LAUNCH_CHECK("emit_unique");
     return TFGX_OK;
 }

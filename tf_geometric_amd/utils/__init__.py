@@ -26,3 +26,111 @@ def add_self_loop_edge(edge_index, num_nodes, edge_weight=None, fill_weight=1.0)
         ew = torch.cat([L.as_f32(edge_weight, edge_index.device),
                         torch.full((num_nodes,), float(fill_weight), dtype=torch.float32, device=edge_index.device)])
     return ei, ew
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Edge preprocessing on the device — the step immediately before the hot path.
+# Reference: tf_geometric/utils/graph_utils.py:67-125 (merge_duplicated_edge), :126-150 (convert_edge_to_upper),
+# :155-212 (convert_edge_to_directed), :252-269 (remove_self_loop_edge).  numpy in -> numpy out, tensor in -> tensor.
+# ---------------------------------------------------------------------------------------------------------------
+
+def _out(t, as_numpy):
+    return t.cpu().numpy() if (as_numpy and t is not None) else t
+
+
+def remove_self_loop_edge(edge_index, edge_weight=None):
+    """Drop edges (i, i) (reference :252-269)."""
+    as_np = not isinstance(edge_index, torch.Tensor)
+    ei = L.as_i32(edge_index)
+    mask = ei[0] != ei[1]
+    w = None if edge_weight is None else L.as_f32(edge_weight)[mask]
+    return _out(ei[:, mask], as_np), _out(w, as_np and not isinstance(edge_weight, torch.Tensor))
+
+
+def merge_duplicated_edge(edge_index, edge_props=None, merge_modes=None):
+    """Unique edges in first-occurrence order (tf.unique) + edge properties merged per unique edge with
+    "sum" | "mean" | "max" | "min" (reference :67-125).  The unique pass is tfgx_merge_duplicated_edges (radix sort on
+    the hash n*row+col); the merges are tfgx_segment_reduce_f32 launches."""
+    import ctypes
+    from ..plan import CsrPlan, segment_reduce
+    if edge_props is not None and len(edge_props) > 0:
+        if merge_modes is None:
+            merge_modes = ["sum"] * len(edge_props)
+        elif type(merge_modes) is not list:
+            raise Exception("type error: merge_modes should be a list of strings")
+    lib = L.require_gpu()
+    as_np = not isinstance(edge_index, torch.Tensor)
+    ei = L.as_i32(edge_index)
+    E = int(ei.shape[1])
+    if E == 0:
+        return _out(ei, as_np), edge_props
+    n = int(ei.max().item()) + 1                                  # convert_edge_index_to_edge_hash(num_nodes=None)
+    dev = ei.device
+    out_row = torch.empty(E, dtype=torch.int32, device=dev)
+    out_col = torch.empty(E, dtype=torch.int32, device=dev)
+    uidx = torch.empty(E, dtype=torch.int32, device=dev)
+    n_unique = torch.zeros(1, dtype=torch.int32, device=dev)
+    ws_bytes = lib.tfgx_merge_edges_workspace_bytes(E, n)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    L.check(lib.tfgx_merge_duplicated_edges(L.ptr(ei[0]), L.ptr(ei[1]), E, n, L.ptr(out_row), L.ptr(out_col),
+                                            L.ptr(uidx), L.ptr(n_unique), L.ptr(ws), ws_bytes, L.stream_ptr()),
+            "tfgx_merge_duplicated_edges")
+    U = int(n_unique.item())
+    unique_ei = torch.stack([out_row[:U], out_col[:U]])
+    if edge_props is None:
+        return _out(unique_ei, as_np), None
+    plan = None
+    merged = []
+    for prop, mode in zip(edge_props, merge_modes):
+        if prop is None:
+            merged.append(None)
+            continue
+        if mode not in ("min", "max", "mean", "sum"):
+            raise Exception("wrong merge mode: {}".format(mode))
+        p = L.as_f32(prop)
+        squeeze = p.dim() == 1
+        p2 = p.unsqueeze(1) if squeeze else p
+        if plan is None:   # message i -> segment unique_index[i]
+            plan = CsrPlan.build(torch.stack([uidx, torch.arange(E, dtype=torch.int32, device=dev)]), U, E)
+        if mode == "min":
+            red = -segment_reduce(plan, -p2, L.MAX)
+        else:
+            red = segment_reduce(plan, p2, {"sum": L.SUM, "mean": L.MEAN, "max": L.MAX}[mode])
+        red = red[:, 0] if squeeze else red
+        merged.append(_out(red, not isinstance(prop, torch.Tensor)))
+    return _out(unique_ei, as_np), merged
+
+
+def convert_edge_to_upper(edge_index, edge_props=None, merge_modes=None):
+    """(min(u,v), max(u,v)) per edge, duplicates merged (reference :126-150)."""
+    as_np = not isinstance(edge_index, torch.Tensor)
+    ei = L.as_i32(edge_index)
+    upper = torch.stack([torch.minimum(ei[0], ei[1]), torch.maximum(ei[0], ei[1])])
+    u, props = merge_duplicated_edge(upper, edge_props, merge_modes)
+    return _out(u, as_np), props
+
+
+def convert_edge_to_directed(edge_index, edge_props=None, merge_modes=None):
+    """[[1,3,5],[2,1,4]] -> [[1,3,5,2,1,4],[2,1,4,1,3,5]]: upper-triangular unique edges followed by their
+    mirrored non-self-loop copies, properties alike (reference :155-212)."""
+    as_np = not isinstance(edge_index, torch.Tensor)
+    ei = L.as_i32(edge_index)
+    if edge_props is not None and len(edge_props) > 0 and merge_modes is None:
+        merge_modes = ["sum"] * len(edge_props)
+    upper, upper_props = convert_edge_to_upper(ei, edge_props, merge_modes)
+    mask = upper[0] != upper[1]
+    if not bool(mask.any()):
+        return edge_index, edge_props                                                  # :205-207
+    lower = torch.stack([upper[1][mask], upper[0][mask]])
+    updated = torch.cat([upper, lower], dim=1)
+    if edge_props is None:
+        return _out(updated, as_np), None
+    out_props = []
+    for prop, up in zip(edge_props, upper_props):
+        if prop is None:
+            out_props.append(None)
+            continue
+        was_np = not isinstance(up, torch.Tensor)
+        up_t = L.as_f32(up)
+        out_props.append(_out(torch.cat([up_t, up_t[mask]], dim=0), was_np))
+    return _out(updated, as_np), out_props
