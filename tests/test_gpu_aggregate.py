@@ -243,3 +243,18 @@ def test_edge_preprocessing_on_device(tfg):
     e2, w2 = tfg.utils.remove_self_loop_edge(ei, w)
     keep = ei[0] != ei[1]
     assert np.array_equal(e2, ei[:, keep]) and np.array_equal(w2, w[keep])
+
+
+def test_graph_readout_pools(tfg, oracle):
+    """nn/pool/common_pool.py:7-52 on the segment kernels (graph id = destination)."""
+    rng = np.random.Generator(np.random.PCG64(17))
+    x = rng.standard_normal((900, 11), dtype=np.float32)
+    gid = np.sort(rng.integers(0, 37, size=900, dtype=np.int32))
+    gid[gid == 20] = 21                                              # graph 20 is empty
+    cnt = np.bincount(gid, minlength=40).astype(np.float32)
+    s = oracle.unsorted_segment_sum(x, gid, 40)
+    assert_parity(tfg.nn.sum_pool(x, gid, 40).cpu().numpy(), s, what="sum_pool")
+    assert_parity(tfg.nn.mean_pool(x, gid, 40).cpu().numpy(), s / (cnt[:, None] + 1e-8), what="mean_pool")
+    assert np.array_equal(tfg.nn.max_pool(x, gid, 40).cpu().numpy(), oracle.unsorted_segment_max(x, gid, 40))
+    assert np.array_equal(tfg.nn.min_pool(x, gid, 40).cpu().numpy(), -oracle.unsorted_segment_max(-x, gid, 40))
+    assert tfg.nn.max_pool(x, gid).shape[0] == int(gid.max()) + 1

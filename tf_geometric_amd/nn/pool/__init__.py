@@ -1,0 +1,2 @@
+# coding=utf-8
+from .common_pool import mean_pool, sum_pool, max_pool, min_pool
