@@ -124,6 +124,12 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    if not os.path.exists(LIB_PATH) and os.path.exists("/opt/rocm/bin/hipcc"):
+        try:     # sources are in-tree: build once (hipcc --offload-arch=gfx950, ~15 s); never a CPU fallback
+            from . import _build
+            _build.build(verbose=False)
+        except Exception as ex:      # noqa: BLE001 - reported below with the build hint
+            raise TfgxError("tf_geometric_amd: building {} failed: {}".format(LIB_PATH, ex))
     if not os.path.exists(LIB_PATH):
         raise TfgxError(
             "tf_geometric_amd: HIP library {} is missing. Build it with `python -c 'import __graft_entry__ as g; "

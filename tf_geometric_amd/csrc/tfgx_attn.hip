@@ -51,31 +51,6 @@ __global__ __launch_bounds__(kBlock) void edge_softmax_kernel(const int32_t* __r
 }
 
 // ---------------------------------------------------------------- fused GAT
-template <int VEC> struct VecT;
-template <> struct VecT<1> { using type = float; };
-template <> struct VecT<2> { using type = float2; };
-template <> struct VecT<4> { using type = float4; };
-
-template <int VEC>
-__device__ __forceinline__ void load_vec(const float* p, float (&v)[VEC])
-{
-    using T = typename VecT<VEC>::type;
-    const T t = *reinterpret_cast<const T*>(p);
-    if constexpr (VEC == 1) { v[0] = t; }
-    if constexpr (VEC == 2) { v[0] = t.x; v[1] = t.y; }
-    if constexpr (VEC == 4) { v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
-}
-template <int VEC>
-__device__ __forceinline__ void store_vec(float* p, const float (&v)[VEC])
-{
-    using T = typename VecT<VEC>::type;
-    T t;
-    if constexpr (VEC == 1) { t = v[0]; }
-    if constexpr (VEC == 2) { t.x = v[0]; t.y = v[1]; }
-    if constexpr (VEC == 4) { t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3]; }
-    *reinterpret_cast<T*>(p) = t;
-}
-
 struct GArgs {
     const int32_t* row_ptr;
     const int32_t* col;
@@ -349,8 +324,6 @@ __global__ __launch_bounds__(kBlock) void head_mean_kernel(const float* __restri
         out[r * ldo + j] = apply_act(s, act);
     }
 }
-
-inline bool aligned_to(const void* p, size_t al) { return (reinterpret_cast<uintptr_t>(p) % al) == 0; }
 
 }  // namespace
 }  // namespace tfgx

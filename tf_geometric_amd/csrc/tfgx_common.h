@@ -53,4 +53,33 @@ inline int grid_for(int64_t work_items, int per_block, int cap = kMaxGrid)
 
 __device__ __forceinline__ float apply_act(float v, int act) { return (act == TFGX_ACT_RELU) ? fmaxf(v, 0.0f) : v; }
 
+// ---- vector load/store helpers shared by the streaming kernels (VEC floats per lane: 4 -> global_load_dwordx4)
+template <int VEC> struct VecT;
+template <> struct VecT<1> { using type = float; };
+template <> struct VecT<2> { using type = float2; };
+template <> struct VecT<4> { using type = float4; };
+
+template <int VEC>
+__device__ __forceinline__ void load_vec(const float* p, float (&v)[VEC])
+{
+    using T = typename VecT<VEC>::type;
+    const T t = *reinterpret_cast<const T*>(p);
+    if constexpr (VEC == 1) { v[0] = t; }
+    if constexpr (VEC == 2) { v[0] = t.x; v[1] = t.y; }
+    if constexpr (VEC == 4) { v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+}
+
+template <int VEC>
+__device__ __forceinline__ void store_vec(float* p, const float (&v)[VEC])
+{
+    using T = typename VecT<VEC>::type;
+    T t;
+    if constexpr (VEC == 1) { t = v[0]; }
+    if constexpr (VEC == 2) { t.x = v[0]; t.y = v[1]; }
+    if constexpr (VEC == 4) { t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3]; }
+    *reinterpret_cast<T*>(p) = t;
+}
+
+inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
 }  // namespace tfgx

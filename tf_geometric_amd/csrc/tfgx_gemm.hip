@@ -126,7 +126,7 @@ __global__ __launch_bounds__(kBlock) void gemm_kernel(const float* __restrict__ 
         if (k0 + BK < K) load_tiles(k0 + BK);
         const int kh = lane >> 5, l31 = lane & 31;
         const int kmax = min(BK, K - k0);   // the zero-padded tail of the last tile is skipped, not multiplied
-        for (int kk = 0; kk < kmax; kk += 2) {
+        auto kstep = [&](int kk) {
             float a[TM], b[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) a[i] = As[(kk + kh) * LDA_S + wm * WM + i * 32 + l31];
@@ -137,6 +137,12 @@ __global__ __launch_bounds__(kBlock) void gemm_kernel(const float* __restrict__ 
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        };
+        if (kmax == BK) {   // full tile: fully unrolled, so the LDS reads of step kk+1 are issued under the MFMAs of kk
+#pragma unroll
+            for (int kk = 0; kk < BK; kk += 2) kstep(kk);
+        } else {
+            for (int kk = 0; kk < kmax; kk += 2) kstep(kk);
         }
         __syncthreads();
     }
@@ -158,8 +164,6 @@ __global__ __launch_bounds__(kBlock) void gemm_kernel(const float* __restrict__ 
         }
     }
 }
-
-inline bool aligned_to(const void* p, size_t al) { return (reinterpret_cast<uintptr_t>(p) % al) == 0; }
 
 template <int BM, int BN, int WM, int WN>
 int launch_gemm(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, int act, float* C,

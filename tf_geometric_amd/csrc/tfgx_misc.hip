@@ -120,8 +120,6 @@ __global__ __launch_bounds__(kBlock) void split_rows_kernel(const float* __restr
     }
 }
 
-inline bool aligned_to(const void* p, size_t al) { return (reinterpret_cast<uintptr_t>(p) % al) == 0; }
-
 }  // namespace
 }  // namespace tfgx
 

@@ -19,32 +19,6 @@
 namespace tfgx {
 namespace {
 
-template <int VEC> struct VecT;
-template <> struct VecT<1> { using type = float; };
-template <> struct VecT<2> { using type = float2; };
-template <> struct VecT<4> { using type = float4; };
-
-template <int VEC>
-__device__ __forceinline__ void load_vec(const float* p, float (&v)[VEC])
-{
-    using T = typename VecT<VEC>::type;
-    const T t = *reinterpret_cast<const T*>(p);
-    if constexpr (VEC == 1) { v[0] = t; }
-    if constexpr (VEC == 2) { v[0] = t.x; v[1] = t.y; }
-    if constexpr (VEC == 4) { v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
-}
-
-template <int VEC>
-__device__ __forceinline__ void store_vec(float* p, const float (&v)[VEC])
-{
-    using T = typename VecT<VEC>::type;
-    T t;
-    if constexpr (VEC == 1) { t = v[0]; }
-    if constexpr (VEC == 2) { t.x = v[0]; t.y = v[1]; }
-    if constexpr (VEC == 4) { t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3]; }
-    *reinterpret_cast<T*>(p) = t;
-}
-
 template <int G>
 __device__ __forceinline__ int bcast_i(int v, int j)
 {
@@ -294,8 +268,6 @@ int launch_vec(const KArgs& a, bool is_max, bool weighted, hipStream_t stream)
     const int per = 64 * VEC * 4;
     return launch_cfg<VEC, 64, 4>(a, is_max, weighted, (a.F + per - 1) / per, stream);
 }
-
-inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
 // Hub rows (in-degree > hub_threshold): the row is cut into chunks of consecutive edges, every chunk is reduced like
 // an ordinary row into scratch[chunk, :] (second launch of seg_reduce_kernel over the chunk list), and this kernel
