@@ -7,7 +7,7 @@
 // K and N are feature widths (16..1433), so the kernel is a tall-skinny GEMM close to the HBM roofline:
 // the A panel is streamed once, B (<= 1.5 MB) lives in L2/LDS.
 //
-// Tile: BM x BN per 256-thread workgroup (4 waves), BK = 32.  A is staged transposed in LDS (As[k][m]) so
+// Tile: BM x BN per 256-thread workgroup (4 waves), BK = 16.  A is staged transposed in LDS (As[k][m]) so
 // the MFMA A operand (lane l: A[m = l&31][k = l>>5]) is a conflict-free ds_read_b32 over consecutive m;
 // B is staged as Bs[k][n].  Global loads for tile t+1 are issued before the MFMAs of tile t (register
 // staging), LDS is single-buffered.
@@ -18,7 +18,7 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BK = 32;   // 32 floats = one full 128-byte line of an A row per 8 lanes
+constexpr int BK = 16;   // 16 keeps load-staging registers low enough for 3 workgroups per CU (BK = 32: 2)
 
 template <int BM, int BN, int WM, int WN, bool AV4, bool BV4>
 __global__ __launch_bounds__(kBlock) void gemm_kernel(const float* __restrict__ A, int64_t lda,
@@ -138,11 +138,11 @@ __global__ __launch_bounds__(kBlock) void gemm_kernel(const float* __restrict__ 
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         };
-        if (kmax == BK) {   // full tile: fully unrolled, so the LDS reads of step kk+1 are issued under the MFMAs of kk
+        // unrolled, so the LDS reads of step kk+1 issue under the MFMAs of step kk; the zero-padded tail of the last
+        // tile is skipped by a wave-uniform guard per step (one accumulator copy, no second loop body)
 #pragma unroll
-            for (int kk = 0; kk < BK; kk += 2) kstep(kk);
-        } else {
-            for (int kk = 0; kk < kmax; kk += 2) kstep(kk);
+        for (int kk = 0; kk < BK; kk += 2) {
+            if (kk < kmax) kstep(kk);
         }
         __syncthreads();
     }
