@@ -266,6 +266,12 @@ int tfgx_gemm_bias_act_f32(const float* A, int64_t lda, const float* B, int64_t 
                            int32_t act, float* C, int64_t ldc, int64_t M, int64_t K, int64_t N,
                            tfgx_stream_t stream);
 
+/* same, with the activation applied to columns [0, act_cols) only: one pass over x for several projections that
+   share the input (GAT's Q | K | V = x @ [Wq | Wk | W], relu on Q and K, none on V — nn/conv/gat.py:52-70) */
+int tfgx_gemm_bias_act_cols_f32(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias,
+                                int32_t act, int64_t act_cols, float* C, int64_t ldc, int64_t M, int64_t K, int64_t N,
+                                tfgx_stream_t stream);
+
 /* x[n, F] -> x_main[n, f_main] + x_tail[n, F - f_main] in one pass (the split source layout of tfgx_reduce_args) */
 int tfgx_split_rows_f32(const float* x, int64_t ldx, int64_t n, int64_t F, int64_t f_main, float* x_main,
                         int64_t ld_main, float* x_tail, int64_t ld_tail, tfgx_stream_t stream);

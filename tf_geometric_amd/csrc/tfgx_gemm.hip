@@ -25,7 +25,7 @@ __global__ __launch_bounds__(kBlock) void gemm_kernel(const float* __restrict__ 
                                                       const float* __restrict__ B, int64_t ldb,
                                                       const float* __restrict__ bias, int act,
                                                       float* __restrict__ C, int64_t ldc, int64_t M, int K, int N,
-                                                      int n_tiles_n)
+                                                      int n_tiles_n, int act_cols)
 {
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_N = BN / WN;
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(kBlock) void gemm_kernel(const float* __restrict__ 
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
                 const int64_t gm = m0 + wm * WM + i * 32 + (t & 3) + 8 * (t >> 2) + 4 * lh;
-                if (gm < M) C[gm * ldc + gn] = apply_act(acc[i][j][t] + bv, act);
+                if (gm < M) C[gm * ldc + gn] = apply_act(acc[i][j][t] + bv, gn < act_cols ? act : TFGX_ACT_NONE);
             }
         }
     }
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(kBlock) void gemm_kernel(const float* __restrict__ 
 
 template <int BM, int BN, int WM, int WN>
 int launch_gemm(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, int act, float* C,
-                int64_t ldc, int64_t M, int K, int N, hipStream_t stream)
+                int64_t ldc, int64_t M, int K, int N, int act_cols, hipStream_t stream)
 {
     const int ntn = (N + BN - 1) / BN;
     const int64_t ntm = (M + BM - 1) / BM;
@@ -180,7 +180,7 @@ int launch_gemm(const float* A, int64_t lda, const float* B, int64_t ldb, const 
     const bool bv4 = (ldb % 4 == 0) && aligned_to(B, 16);
     dim3 grid(static_cast<unsigned>(blocks), 1, 1), block(kBlock, 1, 1);
 #define TFGX_GEMM_GO(AV, BV) \
-    gemm_kernel<BM, BN, WM, WN, AV, BV><<<grid, block, 0, stream>>>(A, lda, B, ldb, bias, act, C, ldc, M, K, N, ntn)
+    gemm_kernel<BM, BN, WM, WN, AV, BV><<<grid, block, 0, stream>>>(A, lda, B, ldb, bias, act, C, ldc, M, K, N, ntn, act_cols)
     if (av4 && bv4) TFGX_GEMM_GO(true, true);
     else if (av4) TFGX_GEMM_GO(true, false);
     else if (bv4) TFGX_GEMM_GO(false, true);
@@ -195,18 +195,27 @@ int launch_gemm(const float* A, int64_t lda, const float* B, int64_t ldb, const 
 
 using namespace tfgx;
 
-extern "C" int tfgx_gemm_bias_act_f32(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias,
-                                      int32_t act, float* C, int64_t ldc, int64_t M, int64_t K, int64_t N,
-                                      tfgx_stream_t stream_)
+extern "C" int tfgx_gemm_bias_act_cols_f32(const float* A, int64_t lda, const float* B, int64_t ldb,
+                                           const float* bias, int32_t act, int64_t act_cols, float* C, int64_t ldc,
+                                           int64_t M, int64_t K, int64_t N, tfgx_stream_t stream_)
 {
     TFGX_REQUIRE(M >= 0 && K >= 1 && N >= 1, "bad M / K / N");
     TFGX_REQUIRE(K < (int64_t(1) << 30) && N < (int64_t(1) << 30), "K / N too large");
     TFGX_REQUIRE(act == TFGX_ACT_NONE || act == TFGX_ACT_RELU, "bad act");
+    TFGX_REQUIRE(act_cols >= 0 && act_cols <= N, "act_cols outside [0, N]");
     if (M == 0) return TFGX_OK;
     TFGX_REQUIRE(A && B && C, "null pointer");
     TFGX_REQUIRE(lda >= K && ldb >= N && ldc >= N, "leading dimension too small");
     hipStream_t stream = as_stream(stream_);
-    if (N <= 32) return launch_gemm<256, 32, 64, 32>(A, lda, B, ldb, bias, act, C, ldc, M, int(K), int(N), stream);
-    if (N <= 64) return launch_gemm<128, 64, 32, 64>(A, lda, B, ldb, bias, act, C, ldc, M, int(K), int(N), stream);
-    return launch_gemm<128, 128, 64, 64>(A, lda, B, ldb, bias, act, C, ldc, M, int(K), int(N), stream);
+    const int ac = int(act_cols);
+    if (N <= 32) return launch_gemm<256, 32, 64, 32>(A, lda, B, ldb, bias, act, C, ldc, M, int(K), int(N), ac, stream);
+    if (N <= 64) return launch_gemm<128, 64, 32, 64>(A, lda, B, ldb, bias, act, C, ldc, M, int(K), int(N), ac, stream);
+    return launch_gemm<128, 128, 64, 64>(A, lda, B, ldb, bias, act, C, ldc, M, int(K), int(N), ac, stream);
+}
+
+extern "C" int tfgx_gemm_bias_act_f32(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias,
+                                      int32_t act, float* C, int64_t ldc, int64_t M, int64_t K, int64_t N,
+                                      tfgx_stream_t stream)
+{
+    return tfgx_gemm_bias_act_cols_f32(A, lda, B, ldb, bias, act, N, C, ldc, M, K, N, stream);
 }

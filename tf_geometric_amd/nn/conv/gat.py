@@ -23,6 +23,24 @@ def _linear(x, kernel, bias, activation):
     return post(h) if post is not None else h
 
 
+def _project_qkv(x, wq, bq, qact, wk, bk, kact, wv):
+    """Q = qact(x@Wq+bq), K = kact(x@Wk+bk), V = x@W (gat.py:52-70).  When Q and K use the same fusable activation
+    the three projections are ONE pass over x: x @ [Wq | Wk | W] with the activation limited to the first 2A columns
+    (tfgx_gemm_bias_act_cols_f32); Q, K, V are then column views of one [N, 2A+U] buffer."""
+    qc, qpost = _resolve_act(qact)
+    kc, kpost = _resolve_act(kact)
+    wq, wk, wv = L.as_f32(wq), L.as_f32(wk), L.as_f32(wv)
+    A, U = int(wq.shape[1]), int(wv.shape[1])
+    if qc == kc and qpost is None and kpost is None and int(wk.shape[1]) == A and A % 4 == 0:
+        w_all = torch.cat([wq, wk, wv], dim=1)
+        zq = torch.zeros(A, dtype=torch.float32, device=x.device)
+        b_all = torch.cat([L.as_f32(bq) if bq is not None else zq, L.as_f32(bk) if bk is not None else zq,
+                           torch.zeros(U, dtype=torch.float32, device=x.device)])
+        qkv = gemm_bias_act(x, w_all, bias=b_all, act=qc, act_cols=2 * A)
+        return qkv[:, :A], qkv[:, A:2 * A], qkv[:, 2 * A:]
+    return _linear(x, wq, bq, qact), _linear(x, wk, bk, kact), gemm_bias_act(x, wv)
+
+
 def gat_args(Q, K, V, num_heads, n_dst, col, add_self_loop=True, bias=None, act=L.ACT_NONE, out=None):
     """Fill a tfgx_gat_args for Q:[n_dst,A] K:[n_src,A] V:[n_src,W]; returns (args, out, keep-alive tuple)."""
     Q, ldq = L.row_major_2d(Q)
@@ -112,9 +130,7 @@ def gat(x, edge_index,
     if AG.needs_grad(x, query_kernel, query_bias, key_kernel, key_bias, kernel, bias):
         return _gat_train(x, plan, query_kernel, query_bias, query_activation, key_kernel, key_bias, key_activation,
                           kernel, bias, activation, num_heads, split_value_heads)
-    Q = _linear(x, query_kernel, query_bias, query_activation)       # :52-54 (gather by row happens in-kernel)
-    K = _linear(x, key_kernel, key_bias, key_activation)             # :61-63
-    V = gemm_bias_act(x, kernel)                                     # :70
+    Q, K, V = _project_qkv(x, query_kernel, query_bias, query_activation, key_kernel, key_bias, key_activation, kernel)
     act, post = _resolve_act(activation)
     bias_t = None if bias is None else L.as_f32(bias).contiguous()
     if split_value_heads:

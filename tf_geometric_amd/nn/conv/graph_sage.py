@@ -14,7 +14,7 @@ import torch
 
 from ... import _lib as L
 from ...activations import resolve as _resolve_act
-from ...plan import CsrPlan, segment_reduce, gemm_bias_act, l2_normalize_rows_
+from ...plan import CsrPlan, segment_reduce, gemm_bias_act, l2_normalize_rows_, edge_weight_csr
 from ...sparse import SparseMatrix
 from .gcn import gcn_norm_adj
 from ... import autograd as AG
@@ -60,7 +60,7 @@ def _neighbor_reduce(x, edge_index, edge_weight, op, cache):
     x = L.as_f32(x)
     n = int(x.shape[0])
     plan = CsrPlan.from_cache(edge_index, n, n, cache)
-    w_csr = plan.edge_attr_to_csr(edge_weight) if edge_weight is not None else None   # :38-39
+    w_csr = edge_weight_csr(plan, edge_weight, cache)                                  # :38-39
     if AG.needs_grad(x):
         return x, AG.aggregate(plan, x, op, w_csr)
     return x, segment_reduce(plan, x, op, w_csr=w_csr)

@@ -9,7 +9,7 @@ tensors -> segment-reduce kernel over the explicit messages.
 import torch
 
 from ... import _lib as L
-from ...plan import CsrPlan, segment_reduce, gather_rows
+from ...plan import CsrPlan, segment_reduce, gather_rows, edge_weight_csr
 from ... import autograd as AG
 
 
@@ -89,7 +89,7 @@ def aggregate_neighbors(x, edge_index, edge_weight=None, mapper=identity_mapper,
         if mapper is gcn_mapper and edge_weight is None:
             raise TypeError("gcn_mapper needs edge_weight (tf.expand_dims(None) in the reference, gcn.py:222)")
         plan = CsrPlan.from_cache(ei, n, int(x.shape[0]), cache)
-        w_csr = plan.edge_attr_to_csr(edge_weight) if mapper is gcn_mapper else None
+        w_csr = edge_weight_csr(plan, edge_weight, cache) if mapper is gcn_mapper else None
         if AG.needs_grad(x, edge_weight):        # training route: kernels with a backward (autograd.py)
             if mapper is gcn_mapper and isinstance(edge_weight, torch.Tensor) and edge_weight.requires_grad:
                 w_csr = L.as_f32(edge_weight)[plan.perm.long()]          # differentiable permutation

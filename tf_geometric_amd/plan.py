@@ -167,6 +167,22 @@ class SplitRows(object):
         return out
 
 
+def edge_weight_csr(plan, edge_weight, cache=None):
+    """edge_weight (caller's edge order) -> CSR order, memoised in the graph's `cache` dict for as long as the SAME
+    array object is passed (the reference caches its normalised adjacency under the same contract: one cache per
+    graph, inputs not mutated in place — nn/conv/gcn.py:125-128)."""
+    if edge_weight is None:
+        return None
+    if cache is not None:
+        hit = cache.get("tfgx_edge_weight_csr")
+        if hit is not None and hit[0] is edge_weight and hit[2] is plan:
+            return hit[1]
+    w_csr = plan.edge_attr_to_csr(edge_weight)
+    if cache is not None:
+        cache["tfgx_edge_weight_csr"] = (edge_weight, w_csr, plan)
+    return w_csr
+
+
 def segment_reduce(plan, x, op, w_csr=None, out=None, act=L.ACT_NONE, self_coef=None, bias=None, add_x=None,
                    accumulate=False, mean_count=None, row_begin=None, row_end=None, rp_stride=1, col=None,
                    n_dst=None):
@@ -225,8 +241,8 @@ def segment_reduce(plan, x, op, w_csr=None, out=None, act=L.ACT_NONE, self_coef=
     return out
 
 
-def gemm_bias_act(a, b, bias=None, act=L.ACT_NONE, out=None):
-    """act(a @ b + bias) on the fp32 MFMA kernel."""
+def gemm_bias_act(a, b, bias=None, act=L.ACT_NONE, out=None, act_cols=None):
+    """act(a @ b + bias) on the fp32 MFMA kernel; `act_cols`: activate only columns [0, act_cols)."""
     lib = L.require_gpu()
     a, lda = L.row_major_2d(L.as_f32(a))
     b, ldb = L.row_major_2d(L.as_f32(b))
@@ -238,8 +254,9 @@ def gemm_bias_act(a, b, bias=None, act=L.ACT_NONE, out=None):
         out = torch.empty((M, N), dtype=torch.float32, device=a.device)
     _, ldc = L.row_major_2d(out)
     bias_t = None if bias is None else L.as_f32(bias).contiguous()
-    L.check(lib.tfgx_gemm_bias_act_f32(L.ptr(a), lda, L.ptr(b), ldb, L.ptr(bias_t), act, L.ptr(out), ldc, M, K, N,
-                                       L.stream_ptr()), "tfgx_gemm_bias_act_f32")
+    L.check(lib.tfgx_gemm_bias_act_cols_f32(L.ptr(a), lda, L.ptr(b), ldb, L.ptr(bias_t), act,
+                                            N if act_cols is None else int(act_cols), L.ptr(out), ldc, M, K, N,
+                                            L.stream_ptr()), "tfgx_gemm_bias_act_cols_f32")
     return out
 
 
