@@ -248,3 +248,16 @@ def test_hip_graph_replay_of_two_layer_gcn(tfg, oracle):
     ref = oracle.gcn(oracle.gcn(x2, ei, w, l0.kernel.cpu().numpy(), l0.bias.cpu().numpy(), "relu"), ei, w,
                      l1.kernel.cpu().numpy(), l1.bias.cpu().numpy())
     assert_parity(got.cpu().numpy(), ref, what="captured 2-layer GCN")
+
+
+def test_gemm_column_limited_activation(tfg, oracle):
+    from tf_geometric_amd.plan import gemm_bias_act
+    rng = np.random.Generator(np.random.PCG64(5))
+    a = rng.standard_normal((700, 40), dtype=np.float32)
+    b = oracle.glorot_uniform(rng, 40, 80)
+    bias = (rng.standard_normal(80) * 0.1).astype(np.float32)
+    got = gemm_bias_act(a, b, bias=bias, act=1, act_cols=16).cpu().numpy()
+    ref = oracle.matmul(a, b) + bias
+    ref[:, :16] = np.maximum(ref[:, :16], 0)
+    assert_parity(got, ref, what="act_cols")
+    assert (got[:, 16:] < 0).any()
