@@ -174,9 +174,9 @@ class ShardedGraph(object):
     # ------------------------------------------------------------------ construction
     @staticmethod
     def from_global(edge_index, num_nodes, edge_weight=None, group=None, backend=None):
-        """Every rank passes the SAME global edge_index [2, E] (and optional edge_weight [E]); each keeps its
-        slice.  (A rank-local constructor only needs steps 3+ and is the natural follow-up for graphs that do
-        not fit one host.)"""
+        """Every rank passes the SAME global edge_index [2, E] (numpy on the host, or a tensor) and optional
+        edge_weight [E]; each rank counts in-degrees over the whole list (to agree on the split points) but uploads,
+        sorts and keeps only its own E/W slice."""
         self = ShardedGraph()
         be = self.backend = backend or HipBackend()
         self.group = group
@@ -184,28 +184,45 @@ class ShardedGraph(object):
         self.rank = dist.get_rank(group) if (group is not None or dist.is_initialized()) else 0
         self.n_global = int(num_nodes)
 
-        # 1. global CSR-by-destination (identical on every rank: stable sort of identical input)
-        ei = be.i32(edge_index)
-        if ei.numel() == 0:
-            ei = ei.reshape(2, 0)
-        row_ptr, col, perm = be.build_csr(ei, self.n_global, self.n_global)
-        w_csr = None if edge_weight is None else be.permute_rows(edge_weight, perm)
+        # 1. in-degree histogram of the GLOBAL edge list -> global row_ptr (host; N+1 ints) -> edge-balanced bounds.
+        #    Only counting touches all E edges; sorting happens on the rank's own E/W slice (step 3).
+        if isinstance(edge_index, torch.Tensor):
+            ei_all = edge_index.reshape(2, -1)
+            deg = torch.bincount(ei_all[0].long(), minlength=self.n_global).cpu().numpy()
+            if deg.shape[0] != self.n_global or (ei_all.numel() and int(ei_all.min()) < 0):
+                raise L.TfgxError("edge endpoint outside [0, {})".format(self.n_global))
+        else:
+            ei_all = np.asarray(edge_index).reshape(2, -1)
+            if ei_all.size and (ei_all.min() < 0 or ei_all.max() >= self.n_global):
+                raise L.TfgxError("edge endpoint outside [0, {})".format(self.n_global))
+            deg = np.bincount(ei_all[0], minlength=self.n_global)
+        rp_host = np.zeros(self.n_global + 1, dtype=np.int64)
+        np.cumsum(deg, out=rp_host[1:])
 
-        # 2. edge-balanced split points
-        rp_host = row_ptr.cpu().numpy()
+        # 2. edge-balanced split points (identical on every rank)
         self.bounds = edge_balanced_bounds(rp_host, self.world)
         lo, hi = int(self.bounds[self.rank]), int(self.bounds[self.rank + 1])
         self.own_lo, self.own_hi, self.n_own = lo, hi, hi - lo
-
-        # 3. my slice of the CSR
-        e0, e1 = int(rp_host[lo]), int(rp_host[hi])
-        self.num_edges = e1 - e0
         self.num_edges_global = int(rp_host[-1])
-        self.row_ptr = (row_ptr[lo:hi + 1] - e0).contiguous()
-        col_slice = col[e0:e1].contiguous()
-        w_slice = None if w_csr is None else w_csr[e0:e1].contiguous()
-        self.perm = perm[e0:e1].contiguous()          # CSR position -> global edge id (caller's order)
-        del row_ptr, col, perm, w_csr
+
+        # 3. my edges (destination in [lo, hi)), kept in the caller's relative order, then the stable CSR build of
+        #    that slice alone — the same rows a global stable sort would put in positions [rp[lo], rp[hi])
+        mine = (ei_all[0] >= lo) & (ei_all[0] < hi)
+        if isinstance(edge_index, torch.Tensor):
+            edge_ids = torch.nonzero(mine).flatten()
+            local = torch.stack([ei_all[0][edge_ids] - lo, ei_all[1][edge_ids]])
+            w_local = None if edge_weight is None else be.f32(edge_weight)[edge_ids.to(be.device)]
+        else:
+            edge_ids = np.flatnonzero(mine)
+            local = np.stack([ei_all[0][edge_ids] - lo, ei_all[1][edge_ids]]).astype(np.int32)
+            w_local = None if edge_weight is None else np.asarray(edge_weight, dtype=np.float32)[edge_ids]
+        self.num_edges = int(local.shape[1])
+        assert self.num_edges == int(rp_host[hi] - rp_host[lo])
+        self.row_ptr, col_slice, perm_local = be.build_csr(be.i32(local), self.n_own, self.n_global)
+        w_slice = None if w_local is None else be.permute_rows(w_local, perm_local)
+        ids_dev = be.i32(edge_ids) if not isinstance(edge_ids, torch.Tensor) else edge_ids.to(torch.int32).to(be.device)
+        self.perm = ids_dev[perm_local.long()].contiguous()     # CSR position -> global edge id (caller's order)
+        del local, mine
 
         # 4. halo: remote sources, sorted + de-duplicated; col remapped into [own | halo]
         self.halo_ids, col_local = be.halo_plan(col_slice, lo, hi, self.n_global)
