@@ -25,7 +25,7 @@ __global__ __launch_bounds__(kBlock) void gemm_kernel(const float* __restrict__ 
                                                       const float* __restrict__ B, int64_t ldb,
                                                       const float* __restrict__ bias, int act,
                                                       float* __restrict__ C, int64_t ldc, int64_t M, int K, int N,
-                                                      int n_tiles_n, int act_cols, int64_t n_tiles_total)
+                                                      int n_tiles_n, int act_cols)
 {
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_N = BN / WN;
@@ -41,13 +41,18 @@ __global__ __launch_bounds__(kBlock) void gemm_kernel(const float* __restrict__ 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    // persistent: a workgroup walks tiles tile, tile + gridDim.x, ...; the first K-tile of the NEXT output tile is
-    // requested before the epilogue stores of the current one, so its HBM latency hides under them
-    int64_t tile = blockIdx.x;
-    int64_t m0 = (tile / n_tiles_n) * BM;
-    int n0 = int(tile % n_tiles_n) * BN;
+    const int64_t tile = blockIdx.x;
+    const int64_t m0 = (tile / n_tiles_n) * BM;
+    const int n0 = int(tile % n_tiles_n) * BN;
 
     f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) acc[i][j][t] = 0.0f;
+
     float4 ra[A_LOADS], rb[B_LOADS];
 
     auto load_tiles = [&](int k0) {
@@ -114,14 +119,7 @@ __global__ __launch_bounds__(kBlock) void gemm_kernel(const float* __restrict__ 
         }
     };
 
-    if (tile < n_tiles_total) load_tiles(0);
-    for (; tile < n_tiles_total; tile += gridDim.x) {
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int t = 0; t < 16; ++t) acc[i][j][t] = 0.0f;
+    load_tiles(0);
     for (int k0 = 0; k0 < K; k0 += BK) {
         store_tiles();
         __syncthreads();
@@ -150,30 +148,21 @@ __global__ __launch_bounds__(kBlock) void gemm_kernel(const float* __restrict__ 
     }
 
     // epilogue: D layout col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    const int64_t m_out = m0;
-    const int n_out = n0;
-    const int64_t next = tile + gridDim.x;
-    if (next < n_tiles_total) {          // prefetch the next tile's first K-slice under this tile's stores
-        m0 = (next / n_tiles_n) * BM;
-        n0 = int(next % n_tiles_n) * BN;
-        load_tiles(0);
-    }
     const int l31 = lane & 31, lh = lane >> 5;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int gn = n_out + wn * WN + j * 32 + l31;
+        const int gn = n0 + wn * WN + j * 32 + l31;
         if (gn >= N) continue;
         const float bv = bias ? bias[gn] : 0.0f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
-                const int64_t gm = m_out + wm * WM + i * 32 + (t & 3) + 8 * (t >> 2) + 4 * lh;
+                const int64_t gm = m0 + wm * WM + i * 32 + (t & 3) + 8 * (t >> 2) + 4 * lh;
                 if (gm < M) C[gm * ldc + gn] = apply_act(acc[i][j][t] + bv, gn < act_cols ? act : TFGX_ACT_NONE);
             }
         }
     }
-    }   // persistent tile loop
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -189,26 +178,9 @@ int launch_gemm(const float* A, int64_t lda, const float* B, int64_t ldb, const 
     }
     const bool av4 = (lda % 4 == 0) && aligned_to(A, 16);
     const bool bv4 = (ldb % 4 == 0) && aligned_to(B, 16);
-    dim3 grid(1, 1, 1), block(kBlock, 1, 1);
-    // persistent grid = CUs x workgroups that actually fit per CU (asked from the runtime per instantiation)
-#define TFGX_GEMM_GO(AV, BV)                                                                                      \
-    {                                                                                                             \
-        static int per_cu = 0, cus = 0;                                                                           \
-        if (per_cu == 0) {                                                                                        \
-            int dev = 0;                                                                                          \
-            hipDeviceProp_t prop;                                                                                 \
-            if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||           \
-                hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_kernel<BM, BN, WM, WN, AV, BV>, kBlock, \
-                                                             0) != hipSuccess || per_cu < 1)                      \
-                per_cu = 2;                                                                                       \
-            else                                                                                                  \
-                cus = prop.multiProcessorCount;                                                                   \
-            if (cus < 1) cus = 256;                                                                               \
-        }                                                                                                         \
-        const int64_t resident = int64_t(per_cu) * cus;                                                           \
-        grid.x = static_cast<unsigned>(blocks < resident ? blocks : resident);                                    \
-    }                                                                                                             \
-    gemm_kernel<BM, BN, WM, WN, AV, BV><<<grid, block, 0, stream>>>(A, lda, B, ldb, bias, act, C, ldc, M, K, N, ntn, act_cols, blocks)
+    dim3 grid(static_cast<unsigned>(blocks), 1, 1), block(kBlock, 1, 1);
+#define TFGX_GEMM_GO(AV, BV) \
+    gemm_kernel<BM, BN, WM, WN, AV, BV><<<grid, block, 0, stream>>>(A, lda, B, ldb, bias, act, C, ldc, M, K, N, ntn, act_cols)
     if (av4 && bv4) TFGX_GEMM_GO(true, true);
     else if (av4) TFGX_GEMM_GO(true, false);
     else if (bv4) TFGX_GEMM_GO(false, true);
