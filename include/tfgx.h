@@ -272,6 +272,15 @@ int tfgx_gemm_bias_act_cols_f32(const float* A, int64_t lda, const float* B, int
                                 int32_t act, int64_t act_cols, float* C, int64_t ldc, int64_t M, int64_t K, int64_t N,
                                 tfgx_stream_t stream);
 
+/* Neighbour sampling on the CSR plan (RandomNeighborSampler.sample, tf_geometric/utils/graph_utils.py:667-772, a
+   pure-Python per-node loop in the reference).  Row r receives out_ptr[r+1]-out_ptr[r] = m neighbours out of its d:
+   m >= d: all of them, in order; m < d: m distinct ones, uniformly (Floyd); m > d with replace_when_short: m draws
+   with replacement ("padding").  Counter-based generator keyed by (seed, row, draw): reproducible for a seed, but NOT
+   numpy's stream — parity with the reference is distributional, not bitwise.  m <= 256. */
+int tfgx_sample_neighbors(const int32_t* row_ptr, const int32_t* col, const float* w /* or NULL */, int64_t n_dst,
+                          const int32_t* out_ptr, int32_t max_per_row, int32_t replace_when_short, uint64_t seed,
+                          int32_t* out_col, float* out_w /* or NULL */, tfgx_stream_t stream);
+
 /* x[n, F] -> x_main[n, f_main] + x_tail[n, F - f_main] in one pass (the split source layout of tfgx_reduce_args) */
 int tfgx_split_rows_f32(const float* x, int64_t ldx, int64_t n, int64_t F, int64_t f_main, float* x_main,
                         int64_t ld_main, float* x_tail, int64_t ld_tail, tfgx_stream_t stream);

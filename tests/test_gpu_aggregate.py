@@ -258,3 +258,39 @@ def test_graph_readout_pools(tfg, oracle):
     assert np.array_equal(tfg.nn.max_pool(x, gid, 40).cpu().numpy(), oracle.unsorted_segment_max(x, gid, 40))
     assert np.array_equal(tfg.nn.min_pool(x, gid, 40).cpu().numpy(), -oracle.unsorted_segment_max(-x, gid, 40))
     assert tfg.nn.max_pool(x, gid).shape[0] == int(gid.max()) + 1
+
+
+def test_random_neighbor_sampler(tfg, oracle):
+    """Distributional parity with RandomNeighborSampler.sample (graph_utils.py:667-772): counts, subset, no repeats,
+    order of rows, determinism per seed, and uniformity of the without-replacement draw."""
+    n = 300
+    ei = oracle.synthetic_edges(n, 12000, seed=4)
+    ei = ei[:, ei[0] != 5]                                              # node 5 has no in-edges
+    w = np.arange(ei.shape[1], dtype=np.float32)                        # unique weights identify the edge
+    sampler = tfg.utils.RandomNeighborSampler(ei, w)
+    deg = np.bincount(ei[0], minlength=n)
+    nbrs = {r: set(zip(ei[1][ei[0] == r].tolist(), w[ei[0] == r].tolist())) for r in range(n)}
+    for k in (1, 5, 25):
+        sei, sw = sampler.sample(k=k, seed=7)
+        cnt = np.bincount(sei[0], minlength=n)
+        assert np.array_equal(cnt, np.minimum(deg, k)) and (np.diff(sei[0]) >= 0).all()
+        for r in (0, 17, 123):
+            got = list(zip(sei[1][sei[0] == r].tolist(), sw[sei[0] == r].tolist()))
+            assert len(set(got)) == len(got) and set(got) <= nbrs[r]
+        sei2, sw2 = sampler.sample(k=k, seed=7)
+        assert np.array_equal(sei, sei2) and np.array_equal(sw, sw2)
+        sei3, _ = sampler.sample(k=k, seed=8)
+        assert not np.array_equal(sei, sei3) or k >= deg.max()
+    alle, allw = sampler.sample()
+    assert alle.shape[1] == ei.shape[1] and np.array_equal(np.sort(allw), np.sort(w))
+    re_, _ = sampler.sample(ratio=0.5)
+    assert np.array_equal(np.bincount(re_[0], minlength=n), np.ceil(deg * 0.5).astype(np.int64))
+    pe, _ = sampler.sample(k=60, padding=True)
+    assert np.array_equal(np.bincount(pe[0], minlength=n), np.where(deg > 0, 60, 0))
+    # uniformity: a row with d neighbours, k = 1, many seeds -> each neighbour about equally often
+    r = int(np.argmax(deg))
+    hits = {}
+    for seed in range(400):
+        e1, w1 = sampler.sample(k=1, seed=seed)
+        hits[w1[e1[0] == r][0]] = hits.get(w1[e1[0] == r][0], 0) + 1
+    assert len(hits) > 0.8 * min(deg[r], 400 * 0.63) and max(hits.values()) <= 400 / deg[r] * 6 + 6

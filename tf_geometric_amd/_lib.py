@@ -108,6 +108,7 @@ SIGNATURES = {
     "tfgx_gemm_bias_act_f32": (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I32, _P, _I64, _I64, _I64, _I64, _P]),
     "tfgx_gemm_bias_act_cols_f32": (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I32, _I64, _P, _I64, _I64, _I64, _I64, _P]),
     "tfgx_l2_normalize_rows_f32": (ctypes.c_int, [_P, _I64, _I64, _I64, _P]),
+    "tfgx_sample_neighbors": (ctypes.c_int, [_P, _P, _P, _I64, _P, _I32, _I32, ctypes.c_uint64, _P, _P, _P]),
     "tfgx_split_rows_f32": (ctypes.c_int, [_P, _I64, _I64, _I64, _I64, _P, _I64, _P, _I64, _P]),
     "tfgx_gather_rows_f32": (ctypes.c_int, [_P, _I64, _P, _I64, _I64, _P, _I64, _P]),
     "tfgx_halo_workspace_bytes": (_SZ, [_I64]),

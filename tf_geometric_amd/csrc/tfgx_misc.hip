@@ -102,6 +102,65 @@ __global__ void split_local_halo_kernel(const int32_t* __restrict__ row_ptr, con
     }
 }
 
+// ---- neighbour sampling (RandomNeighborSampler.sample, tf_geometric/utils/graph_utils.py:667-772) ----------
+// counter-based generator: a 64-bit mix of (seed, row, draw) — reproducible, order-independent, no state
+__device__ __forceinline__ uint32_t draw_u32(uint64_t seed, uint64_t row, uint32_t i)
+{
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (row * 0x100000001B3ull + i + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return static_cast<uint32_t>((z ^ (z >> 31)) >> 32);
+}
+__device__ __forceinline__ int draw_below(uint64_t seed, uint64_t row, uint32_t i, int n)   // uniform in [0, n)
+{
+    return static_cast<int>((uint64_t(draw_u32(seed, row, i)) * uint64_t(n)) >> 32);
+}
+
+constexpr int kMaxSampleK = 256;
+
+// one thread per destination row; out row r holds cnt[r] = out_ptr[r+1]-out_ptr[r] sampled CSR positions' (col, w)
+__global__ void sample_neighbors_kernel(const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
+                                        const float* __restrict__ w, int64_t n_dst,
+                                        const int32_t* __restrict__ out_ptr, int replace_when_short, uint64_t seed,
+                                        int32_t* __restrict__ out_col, float* __restrict__ out_w)
+{
+    int64_t r = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (; r < n_dst; r += stride) {
+        const int s = row_ptr[r], d = row_ptr[r + 1] - s;
+        const int o = out_ptr[r], m = out_ptr[r + 1] - o;
+        if (m == 0) continue;
+        if (m >= d && !(replace_when_short && m > d)) {          // keep every neighbour, in order (:742-744)
+            for (int i = 0; i < d; ++i) {
+                out_col[o + i] = col[s + i];
+                if (out_w) out_w[o + i] = w ? w[s + i] : 1.0f;
+            }
+            continue;
+        }
+        if (m > d) {                                             // padding: m draws WITH replacement (:749)
+            for (int i = 0; i < m; ++i) {
+                const int t = draw_below(seed, uint64_t(r), uint32_t(i), d);
+                out_col[o + i] = col[s + t];
+                if (out_w) out_w[o + i] = w ? w[s + t] : 1.0f;
+            }
+            continue;
+        }
+        // m < d: Floyd's algorithm — m distinct positions of [0, d) with uniform probability, no replacement
+        int chosen[kMaxSampleK];
+        int c = 0;
+        for (int j = d - m; j < d; ++j) {
+            int t = draw_below(seed, uint64_t(r), uint32_t(j - (d - m)), j + 1);
+            bool dup = false;
+            for (int q = 0; q < c; ++q) dup |= (chosen[q] == t);
+            chosen[c++] = dup ? j : t;
+        }
+        for (int i = 0; i < m; ++i) {
+            out_col[o + i] = col[s + chosen[i]];
+            if (out_w) out_w[o + i] = w ? w[s + chosen[i]] : 1.0f;
+        }
+    }
+}
+
 // one pass: x[n, F] -> main[n, f_main] (128-byte aligned rows) + tail[n, F - f_main]
 __global__ __launch_bounds__(kBlock) void split_rows_kernel(const float* __restrict__ x, int64_t ldx, int64_t n, int F,
                                                             int f_main, float* __restrict__ xm, int64_t ldm,
@@ -236,5 +295,19 @@ extern "C" int tfgx_split_rows_f32(const float* x, int64_t ldx, int64_t n, int64
     split_rows_kernel<<<grid_for(n * (F / 4), kBlock), kBlock, 0, as_stream(stream)>>>(x, ldx, n, int(F), int(f_main),
                                                                                      x_main, ld_main, x_tail, ld_tail);
     TFGX_LAUNCH_CHECK("split_rows_kernel");
+    return TFGX_OK;
+}
+
+extern "C" int tfgx_sample_neighbors(const int32_t* row_ptr, const int32_t* col, const float* w, int64_t n_dst,
+                                     const int32_t* out_ptr, int32_t max_per_row, int32_t replace_when_short,
+                                     uint64_t seed, int32_t* out_col, float* out_w, tfgx_stream_t stream)
+{
+    TFGX_REQUIRE(n_dst >= 0 && max_per_row >= 0, "bad size");
+    TFGX_REQUIRE(max_per_row <= kMaxSampleK, "at most 256 sampled neighbours per row");
+    if (n_dst == 0) return TFGX_OK;
+    TFGX_REQUIRE(row_ptr && out_ptr, "null pointer");
+    sample_neighbors_kernel<<<grid_for(n_dst, kBlock), kBlock, 0, as_stream(stream)>>>(
+        row_ptr, col, w, n_dst, out_ptr, replace_when_short, seed, out_col, out_w);
+    TFGX_LAUNCH_CHECK("sample_neighbors_kernel");
     return TFGX_OK;
 }

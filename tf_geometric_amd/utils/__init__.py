@@ -134,3 +134,51 @@ def convert_edge_to_directed(edge_index, edge_props=None, merge_modes=None):
         up_t = L.as_f32(up)
         out_props.append(_out(torch.cat([up_t, up_t[mask]], dim=0), was_np))
     return _out(updated, as_np), out_props
+
+
+class RandomNeighborSampler(object):
+    """Neighbour sampler on the device.  Mirrors tf_geometric.utils.RandomNeighborSampler
+    (graph_utils.py:630-772) for whole-graph sampling (`sampled_node_index=None`): `sample(k=...)`, `sample(ratio=...)`,
+    `padding=True`.  The reference loops over nodes in Python with np.random.choice; here one kernel launch samples
+    every row with a counter-based generator — same distribution, different random stream, reproducible per seed."""
+
+    def __init__(self, edge_index, edge_weight=None):
+        from ..plan import CsrPlan
+        ei = L.as_i32(edge_index)
+        self._numpy = not isinstance(edge_index, torch.Tensor)
+        self.num_row_nodes = int(ei[0].max().item()) + 1
+        self.num_col_nodes = int(ei[1].max().item()) + 1
+        self.plan = CsrPlan.build(ei, self.num_row_nodes, self.num_col_nodes)
+        w = torch.ones(int(ei.shape[1]), dtype=torch.float32, device=ei.device) if edge_weight is None \
+            else L.as_f32(edge_weight)                                        # :635-638: weights default to ones
+        self.w_csr = self.plan.edge_attr_to_csr(w)
+
+    def sample(self, k=None, ratio=None, sampled_node_index=None, padding=False, seed=0):
+        if k is not None and ratio is not None:
+            raise Exception("k and ratio cannot be provided simultaneously")   # :674-675
+        if sampled_node_index is not None:
+            raise NotImplementedError("sub-graph (virtual index) sampling is not implemented on the device")
+        lib = L.require_gpu()
+        plan = self.plan
+        deg = plan.in_degree()
+        if k is None and ratio is None:
+            cnt = deg                                                           # sample_all
+        elif ratio is not None:
+            cnt = torch.ceil(deg.to(torch.float64) * float(ratio)).to(torch.int32)   # :752
+        elif padding:
+            cnt = torch.where(deg > 0, torch.full_like(deg, int(k)), torch.zeros_like(deg))
+        else:
+            cnt = torch.clamp(deg, max=int(k))
+        out_ptr = torch.zeros(plan.n_dst + 1, dtype=torch.int32, device=deg.device)
+        out_ptr[1:] = torch.cumsum(cnt, 0)
+        total = int(out_ptr[-1].item())
+        if total == 0:
+            return None, None                                                   # :767-769
+        out_col = torch.empty(total, dtype=torch.int32, device=deg.device)
+        out_w = torch.empty(total, dtype=torch.float32, device=deg.device)
+        L.check(lib.tfgx_sample_neighbors(L.ptr(plan.row_ptr), L.ptr(plan.col), L.ptr(self.w_csr), plan.n_dst,
+                                          L.ptr(out_ptr), int(cnt.max().item()), 1 if padding else 0, int(seed),
+                                          L.ptr(out_col), L.ptr(out_w), L.stream_ptr()), "tfgx_sample_neighbors")
+        rows = torch.repeat_interleave(torch.arange(plan.n_dst, dtype=torch.int32, device=deg.device), cnt.long())
+        ei = torch.stack([rows, out_col])
+        return _out(ei, self._numpy), _out(out_w, self._numpy)
