@@ -94,8 +94,16 @@ class HipBackend(object):
         from ..plan import gather_rows
         return gather_rows(x, idx, out=out)
 
+    def hub_lists(self, row_begin, row_end, rp_stride, n_dst, num_edges):
+        """Chunk lists for the long spans of one pass (skewed graphs), or None — see plan.hub_policy."""
+        from ..plan import build_hub_lists, hub_policy
+        thr, chunk = hub_policy(num_edges, n_dst)
+        idx = torch.arange(n_dst, device=row_begin.device) * rp_stride
+        lists = build_hub_lists(row_begin[idx], row_end[idx], thr, chunk)
+        return None if lists is None else (thr,) + lists
+
     def segment_reduce(self, row_begin, row_end, rp_stride, col, w, n_dst, x, out, op, act=L.ACT_NONE,
-                       accumulate=False, self_coef=None, bias=None, mean_count=None):
+                       accumulate=False, self_coef=None, bias=None, mean_count=None, hub=None):
         x, ldx = L.row_major_2d(x)
         _, ldo = L.row_major_2d(out)
         a = L.ReduceArgs()
@@ -109,6 +117,14 @@ class HipBackend(object):
         a.self_coef = 0 if self_coef is None else self_coef.data_ptr()
         a.bias = 0 if bias is None else bias.data_ptr()
         a.mean_count = 0 if mean_count is None else mean_count.data_ptr()
+        if hub is not None:
+            thr, hub_rows, chunk_ptr, chunk_begin, chunk_end, _ = hub
+            scratch = self.empty((int(chunk_begin.shape[0]), int(x.shape[1])))
+            a.hub_threshold = thr
+            a.hub_rows, a.hub_chunk_ptr = hub_rows.data_ptr(), chunk_ptr.data_ptr()
+            a.hub_chunk_begin, a.hub_chunk_end = chunk_begin.data_ptr(), chunk_end.data_ptr()
+            a.n_hub_rows, a.n_hub_chunks = int(hub_rows.shape[0]), int(chunk_begin.shape[0])
+            a.hub_scratch = scratch.data_ptr()
         L.check(self.lib.tfgx_segment_reduce_f32(ctypes.byref(a), L.stream_ptr()), "tfgx_segment_reduce_f32")
         return out
 
@@ -235,6 +251,11 @@ class ShardedGraph(object):
         # 6. per-row stable partition [local-source edges | halo-source edges]
         self.row_ptr2, self.col, self.w = be.split_local_halo(self.row_ptr, col_local, w_slice, self.n_own)
         self.in_degree = (self.row_ptr[1:] - self.row_ptr[:-1]).contiguous()
+        # long spans of either pass are reduced chunk-wise (skewed graphs); None on near-regular graphs
+        hub_fn = getattr(be, "hub_lists", None)
+        rp2 = self.row_ptr2
+        self.hub_local = hub_fn(rp2, rp2[1:], 2, self.n_own, self.num_edges) if hub_fn else None
+        self.hub_halo = hub_fn(rp2[1:], rp2[2:], 2, self.n_own, self.num_edges) if hub_fn else None
         self.norm_w = None
         self.self_coef = None
         return self
@@ -324,11 +345,13 @@ class ShardedGraph(object):
         handle = self.exchange_start(table) if exchange else None
         rp2 = self.row_ptr2
         # pass 1: local-source edges [rp2[2r], rp2[2r+1]) — needs only own rows, overlaps the exchange
-        be.segment_reduce(rp2, rp2[1:], 2, self.col, w_t, self.n_own, table, out, L.SUM if op == L.MEAN else op)
+        be.segment_reduce(rp2, rp2[1:], 2, self.col, w_t, self.n_own, table, out, L.SUM if op == L.MEAN else op,
+                          **({"hub": self.hub_local} if self.hub_local is not None else {}))
         self.exchange_finish(handle)
         # pass 2: halo-source edges [rp2[2r+1], rp2[2r+2]) accumulated on top, then the epilogue
         be.segment_reduce(rp2[1:], rp2[2:], 2, self.col, w_t, self.n_own, table, out, op, act=act, accumulate=True,
-                          self_coef=self_coef, bias=bias, mean_count=self.in_degree if op == L.MEAN else None)
+                          self_coef=self_coef, bias=bias, mean_count=self.in_degree if op == L.MEAN else None,
+                          **({"hub": self.hub_halo} if self.hub_halo is not None else {}))
         return out
 
     # ------------------------------------------------------------------ GCN

@@ -88,33 +88,36 @@ class CsrPlan(object):
         return (self.row_ptr[1:] - self.row_ptr[:-1])
 
     def hub_info(self):
-        """Chunk lists for destinations with more than HUB_THRESHOLD in-edges (power-law "hubs"), or None.
+        """Chunk lists for destinations with more than hub_threshold in-edges (power-law "hubs"), or None.
         Small control-plane metadata, computed once per plan:
         (hub_rows, chunk_ptr, chunk_begin, chunk_end, chunk_row)."""
         if self._hub is None:
-            deg = self.in_degree()
             thr, chunk = hub_policy(self.num_edges, self.n_dst)
             self.hub_threshold = thr
-            hub_rows = torch.nonzero(deg > thr).flatten().to(torch.int32)
-            hub_chunk = chunk
-            if hub_rows.numel() == 0:
-                self._hub = False
-            else:
-                rows64 = hub_rows.to(torch.int64)
-                start = self.row_ptr[rows64].to(torch.int64)
-                d = deg[rows64].to(torch.int64)
-                n_chunks = (d + hub_chunk - 1) // hub_chunk
-                chunk_ptr = torch.zeros(hub_rows.numel() + 1, dtype=torch.int64, device=deg.device)
-                chunk_ptr[1:] = torch.cumsum(n_chunks, 0)
-                total = int(chunk_ptr[-1].item())
-                owner = torch.repeat_interleave(torch.arange(hub_rows.numel(), device=deg.device), n_chunks)
-                k = torch.arange(total, device=deg.device) - chunk_ptr[owner]
-                begin = start[owner] + k * hub_chunk
-                end = torch.minimum(begin + hub_chunk, start[owner] + d[owner])
-                self._hub = (hub_rows.contiguous(), chunk_ptr.to(torch.int32).contiguous(),
-                             begin.to(torch.int32).contiguous(), end.to(torch.int32).contiguous(),
-                             hub_rows[owner].contiguous())
+            self._hub = build_hub_lists(self.row_ptr[:-1], self.row_ptr[1:], thr, chunk) or False
         return self._hub or None
+
+
+def build_hub_lists(span_begin, span_end, threshold, chunk):
+    """Cut every span [begin[r], end[r]) longer than `threshold` into chunks of `chunk` CSR positions.
+    -> (rows, chunk_ptr, chunk_begin, chunk_end, chunk_row) int32 device tensors, or None if no span is that long."""
+    length = (span_end - span_begin)
+    hub_rows = torch.nonzero(length > threshold).flatten()
+    if hub_rows.numel() == 0:
+        return None
+    start = span_begin[hub_rows].to(torch.int64)
+    d = length[hub_rows].to(torch.int64)
+    n_chunks = (d + chunk - 1) // chunk
+    chunk_ptr = torch.zeros(hub_rows.numel() + 1, dtype=torch.int64, device=length.device)
+    chunk_ptr[1:] = torch.cumsum(n_chunks, 0)
+    total = int(chunk_ptr[-1].item())
+    owner = torch.repeat_interleave(torch.arange(hub_rows.numel(), device=length.device), n_chunks)
+    k = torch.arange(total, device=length.device) - chunk_ptr[owner]
+    begin = start[owner] + k * chunk
+    end = torch.minimum(begin + chunk, start[owner] + d[owner])
+    hub_rows = hub_rows.to(torch.int32)
+    return (hub_rows.contiguous(), chunk_ptr.to(torch.int32).contiguous(), begin.to(torch.int32).contiguous(),
+            end.to(torch.int32).contiguous(), hub_rows[owner].contiguous())
 
 
 HUB_THRESHOLD = None   # override (tools/bench_sweep.py): rows with more in-edges than this take the chunked path
