@@ -299,6 +299,13 @@ int tfgx_l2_normalize_rows_f32(float* h, int64_t ld, int64_t n, int64_t F, tfgx_
  * ------------------------------------------------------------------------------------------- */
 int tfgx_gather_rows_f32(const float* x, int64_t ldx, const int32_t* idx, int64_t M, int64_t F,
                          float* out, int64_t ldo, tfgx_stream_t stream);
+/* generalisation of tfgx_split_local_halo to n_class source classes (own rows + one class per halo exchange ROUND, so
+   the halo pass of round j can run while round j+1 is still on the wire): class of source c = first k with
+   c < class_bounds[k] (device int32 [n_class-1] used); row r's class-k edges = [rpk[r*n_class+k], rpk[r*n_class+k+1]);
+   row_ptr_k has n_dst*n_class + 1 entries; n_class <= 17 */
+int tfgx_split_by_source_class(const int32_t* row_ptr, const int32_t* col_local, const float* w /* or NULL */,
+                               int64_t n_dst, int64_t E, const int32_t* class_bounds, int32_t n_class,
+                               int32_t* row_ptr_k, int32_t* col_out, float* w_out /* or NULL */, tfgx_stream_t stream);
 size_t tfgx_halo_workspace_bytes(int64_t n_global);
 int tfgx_halo_mark(const int32_t* col, int64_t E, int32_t own_lo, int32_t own_hi, int64_t n_global,
                    int32_t* flags /* [n_global], zeroed here */, tfgx_stream_t stream);

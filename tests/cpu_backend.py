@@ -66,6 +66,25 @@ class NumpyBackend(object):
         rp2[2 * n] = rp[n]
         return torch.from_numpy(rp2), torch.from_numpy(c2), None if w2 is None else torch.from_numpy(w2)
 
+    def split_by_class(self, row_ptr, col_local, w, class_bounds, n_class):
+        rp, c, wv = _np(row_ptr), _np(col_local), _np(w)
+        n = rp.shape[0] - 1
+        bounds = np.asarray(list(class_bounds), dtype=np.int64)
+        rpk = np.zeros(n_class * n + 1, dtype=np.int32)
+        c2 = np.empty_like(c)
+        w2 = None if wv is None else np.empty_like(wv)
+        for r in range(n):
+            s, e = rp[r], rp[r + 1]
+            cls = np.searchsorted(bounds, c[s:e], side="right") if n_class > 1 else np.zeros(e - s, np.int64)
+            order = np.argsort(cls, kind="stable") + s
+            c2[s:e] = c[order]
+            if w2 is not None:
+                w2[s:e] = wv[order]
+            cnt = np.bincount(cls, minlength=n_class)
+            rpk[r * n_class:(r + 1) * n_class] = s + np.concatenate([[0], np.cumsum(cnt)[:-1]])
+        rpk[n * n_class] = rp[n]
+        return torch.from_numpy(rpk), torch.from_numpy(c2), None if w2 is None else torch.from_numpy(w2)
+
     def gather_rows(self, x, idx, out=None):
         res = x[idx.long()]
         if out is not None:

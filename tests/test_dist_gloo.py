@@ -10,10 +10,11 @@ from conftest import assert_parity
 import dist_worker
 
 
-@pytest.mark.parametrize("world,skew", [(2, False), (2, True), (3, True)])
-def test_sharded_matches_oracle_gloo(tmp_path, world, skew):
+@pytest.mark.parametrize("world,skew,rounds", [(2, False, None), (2, True, 3), (3, True, 4), (2, False, 16)])
+def test_sharded_matches_oracle_gloo(tmp_path, world, skew, rounds):
+    """rounds = number of all-to-all-v rounds the halo travels in (pipelined with the per-round reduce passes)."""
     port = 29500 + random.randint(0, 2000)
-    parts = dist_worker.spawn(world, use_gpu=False, skew=skew, path=str(tmp_path), port=port)
+    parts = dist_worker.spawn(world, use_gpu=False, skew=skew, path=str(tmp_path), port=port, rounds=rounds)
     parts = dist_worker.check_against_reference(parts, skew, assert_parity)
     edges = [p["edges"] for p in parts]
     assert sum(edges) > 0 and all(p["n_halo"] > 0 for p in parts)

@@ -18,8 +18,8 @@ def test_sharded_world1_hip(tfg):
     dist_worker.check_against_reference([res[0]], True, assert_parity)
 
 
-@pytest.mark.parametrize("skew", [False, True])
-def test_sharded_world2_hip_gloo_transport(tfg, tmp_path, skew):
+@pytest.mark.parametrize("skew,rounds", [(False, None), (True, 4)])
+def test_sharded_world2_hip_gloo_transport(tfg, tmp_path, skew, rounds):
     port = 31500 + random.randint(0, 2000)
-    parts = dist_worker.spawn(2, use_gpu=True, skew=skew, path=str(tmp_path), port=port)
+    parts = dist_worker.spawn(2, use_gpu=True, skew=skew, path=str(tmp_path), port=port, rounds=rounds)
     dist_worker.check_against_reference(parts, skew, assert_parity)

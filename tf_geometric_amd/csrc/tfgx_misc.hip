@@ -102,6 +102,45 @@ __global__ void split_local_halo_kernel(const int32_t* __restrict__ row_ptr, con
     }
 }
 
+// stable per-row partition into n_class source classes: class of a source c = first k with c < bounds[k]
+// (class 0 = own rows, classes 1.. = exchange rounds of the halo); one thread per destination row (plan time only)
+constexpr int kMaxClasses = 17;
+__global__ void split_by_class_kernel(const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col_local,
+                                      const float* __restrict__ w, int64_t n_dst, const int32_t* __restrict__ bounds,
+                                      int n_class, int32_t* __restrict__ rpk, int32_t* __restrict__ col_out,
+                                      float* __restrict__ w_out)
+{
+    int64_t r = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (; r < n_dst; r += stride) {
+        const int s = row_ptr[r], e = row_ptr[r + 1];
+        int cnt[kMaxClasses];
+        for (int k = 0; k < n_class; ++k) cnt[k] = 0;
+        for (int i = s; i < e; ++i) {
+            const int32_t c = col_local[i];
+            int k = 0;
+            while (k < n_class - 1 && c >= bounds[k]) ++k;
+            cnt[k]++;
+        }
+        int pos[kMaxClasses];
+        int acc = s;
+        for (int k = 0; k < n_class; ++k) {
+            rpk[r * n_class + k] = acc;
+            pos[k] = acc;
+            acc += cnt[k];
+        }
+        for (int i = s; i < e; ++i) {
+            const int32_t c = col_local[i];
+            int k = 0;
+            while (k < n_class - 1 && c >= bounds[k]) ++k;
+            const int dst = pos[k]++;
+            col_out[dst] = c;
+            if (w_out) w_out[dst] = w[i];
+        }
+        if (r == n_dst - 1) rpk[n_dst * n_class] = e;
+    }
+}
+
 // ---- neighbour sampling (RandomNeighborSampler.sample, tf_geometric/utils/graph_utils.py:667-772) ----------
 // counter-based generator: a 64-bit mix of (seed, row, draw) — reproducible, order-independent, no state
 __device__ __forceinline__ uint32_t draw_u32(uint64_t seed, uint64_t row, uint32_t i)
@@ -309,5 +348,23 @@ extern "C" int tfgx_sample_neighbors(const int32_t* row_ptr, const int32_t* col,
     sample_neighbors_kernel<<<grid_for(n_dst, kBlock), kBlock, 0, as_stream(stream)>>>(
         row_ptr, col, w, n_dst, out_ptr, replace_when_short, seed, out_col, out_w);
     TFGX_LAUNCH_CHECK("sample_neighbors_kernel");
+    return TFGX_OK;
+}
+
+extern "C" int tfgx_split_by_source_class(const int32_t* row_ptr, const int32_t* col_local, const float* w,
+                                          int64_t n_dst, int64_t E, const int32_t* class_bounds, int32_t n_class,
+                                          int32_t* row_ptr_k, int32_t* col_out, float* w_out, tfgx_stream_t stream_)
+{
+    hipStream_t stream = as_stream(stream_);
+    TFGX_REQUIRE(n_dst >= 0 && E >= 0 && row_ptr_k && n_class >= 1 && n_class <= kMaxClasses, "bad argument");
+    if (n_dst == 0) {
+        TFGX_HIP_CHECK(hipMemsetAsync(row_ptr_k, 0, sizeof(int32_t), stream));
+        return TFGX_OK;
+    }
+    TFGX_REQUIRE(row_ptr && class_bounds, "null pointer");
+    TFGX_REQUIRE((w == nullptr) == (w_out == nullptr), "w and w_out must both be given or both be null");
+    split_by_class_kernel<<<grid_for(n_dst, kBlock), kBlock, 0, stream>>>(row_ptr, col_local, w, n_dst, class_bounds,
+                                                                          n_class, row_ptr_k, col_out, w_out);
+    TFGX_LAUNCH_CHECK("split_by_class_kernel");
     return TFGX_OK;
 }

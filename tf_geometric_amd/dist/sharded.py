@@ -20,6 +20,7 @@ and the only one in this package).  tests/ injects a numpy backend to exercise T
 world_size-2 gloo process groups on CPU; the product path never does.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -88,6 +89,17 @@ class HipBackend(object):
                                                L.ptr(rp2), L.ptr(col2), L.ptr(w2), L.stream_ptr()),
                 "tfgx_split_local_halo")
         return rp2, col2, w2
+
+    def split_by_class(self, row_ptr, col_local, w, class_bounds, n_class):
+        n_dst, E = int(row_ptr.shape[0]) - 1, int(col_local.shape[0])
+        rpk = self.empty(n_class * n_dst + 1, torch.int32)
+        col2 = torch.empty_like(col_local)
+        w2 = None if w is None else torch.empty_like(w)
+        bounds = self.i32(np.asarray(list(class_bounds) + [2 ** 31 - 1], dtype=np.int64))
+        L.check(self.lib.tfgx_split_by_source_class(L.ptr(row_ptr), L.ptr(col_local), L.ptr(w), n_dst, E, L.ptr(bounds),
+                                                    n_class, L.ptr(rpk), L.ptr(col2), L.ptr(w2), L.stream_ptr()),
+                "tfgx_split_by_source_class")
+        return rpk, col2, w2
 
     # ---- compute
     def gather_rows(self, x, idx, out=None):
@@ -189,7 +201,7 @@ class ShardedGraph(object):
 
     # ------------------------------------------------------------------ construction
     @staticmethod
-    def from_global(edge_index, num_nodes, edge_weight=None, group=None, backend=None):
+    def from_global(edge_index, num_nodes, edge_weight=None, group=None, backend=None, rounds=None):
         """Every rank passes the SAME global edge_index [2, E] (numpy on the host, or a tensor) and optional
         edge_weight [E]; each rank counts in-degrees over the whole list (to agree on the split points) but uploads,
         sorts and keeps only its own E/W slice."""
@@ -245,17 +257,25 @@ class ShardedGraph(object):
         self.n_halo = int(self.halo_ids.shape[0])
         self.n_table = self.n_own + self.n_halo
 
-        # 5. who sends what: per-peer request counts -> id lists
+        # 5. who sends what: per-peer request counts -> id lists, then cut every peer's list into `rounds` slices:
+        #    the halo travels in R all-to-all-v rounds and the edges of round j are reduced while round j+1 flies
+        if rounds is None:
+            rounds = int(os.environ.get("TFGX_HALO_ROUNDS", "4" if self.n_global // max(self.world, 1) >= 16384 else "1"))
+        self.rounds = max(1, min(int(rounds), 16)) if self.world > 1 else 0
         self._build_exchange_lists()
+        col_local = self._round_major_layout(col_local)
 
-        # 6. per-row stable partition [local-source edges | halo-source edges]
-        self.row_ptr2, self.col, self.w = be.split_local_halo(self.row_ptr, col_local, w_slice, self.n_own)
+        # 6. per-row stable partition [own-source edges | round-0 halo edges | round-1 halo edges | ...]
+        self.n_class = self.rounds + 1
+        class_bounds = [self.n_own + int(v) for v in self.round_offset[1:self.rounds]] if self.rounds > 1 else []
+        self.rpk, self.col, self.w = be.split_by_class(self.row_ptr, col_local, w_slice, [self.n_own] + class_bounds
+                                                       if self.rounds >= 1 else [], self.n_class)
         self.in_degree = (self.row_ptr[1:] - self.row_ptr[:-1]).contiguous()
-        # long spans of either pass are reduced chunk-wise (skewed graphs); None on near-regular graphs
+        # long spans of any pass are reduced chunk-wise (skewed graphs); None on near-regular graphs
         hub_fn = getattr(be, "hub_lists", None)
-        rp2 = self.row_ptr2
-        self.hub_local = hub_fn(rp2, rp2[1:], 2, self.n_own, self.num_edges) if hub_fn else None
-        self.hub_halo = hub_fn(rp2[1:], rp2[2:], 2, self.n_own, self.num_edges) if hub_fn else None
+        K1 = self.n_class
+        self.hub = [hub_fn(self.rpk[k:], self.rpk[k + 1:], K1, self.n_own, self.num_edges) if hub_fn else None
+                    for k in range(K1)]
         self.norm_w = None
         self.self_coef = None
         return self
@@ -280,6 +300,45 @@ class ShardedGraph(object):
         give_np = give.numpy()
         assert ((give_np >= self.own_lo) & (give_np < self.own_hi)).all(), "peer asked for rows I do not own"
         self.send_idx = be.i32((give_np - self.own_lo).astype(np.int32))
+        self._give_local = (give_np - self.own_lo).astype(np.int32)
+
+    def _round_major_layout(self, col_local):
+        """Cut each peer's halo segment (and the matching send list) into `rounds` contiguous slices and lay the halo
+        table out round-major: [round 0: peer 0 slice, peer 1 slice, ... | round 1: ...].  Sender and receiver use the
+        same floor(L*j/R) cut points, so slice j of the list peer q requested is slice j of what q expects."""
+        be, W, R = self.backend, self.world, self.rounds
+        if W == 1 or R == 0:
+            self.round_offset = np.zeros(1, dtype=np.int64)
+            self.round_recv_counts, self.round_send_counts, self.round_send_idx = [], [], []
+            return col_local
+        cut = lambda length, j: (length * j) // R
+        seg_start = np.concatenate([[0], np.cumsum(self.recv_counts)]).astype(np.int64)   # old halo layout: by peer
+        self.round_recv_counts = [[cut(self.recv_counts[p], j + 1) - cut(self.recv_counts[p], j) for p in range(W)]
+                                  for j in range(R)]
+        self.round_send_counts = [[cut(self.send_counts[p], j + 1) - cut(self.send_counts[p], j) for p in range(W)]
+                                  for j in range(R)]
+        self.round_offset = np.concatenate([[0], np.cumsum([sum(c) for c in self.round_recv_counts])]).astype(np.int64)
+        newpos = np.empty(self.n_halo, dtype=np.int32)
+        for j in range(R):
+            base = int(self.round_offset[j])
+            for p in range(W):
+                a, b = int(seg_start[p]) + cut(self.recv_counts[p], j), int(seg_start[p]) + cut(self.recv_counts[p], j + 1)
+                newpos[a:b] = base + np.arange(b - a, dtype=np.int32)
+                base += b - a
+        order = np.argsort(newpos, kind="stable")
+        self.halo_ids = be.i32(self.halo_ids.cpu().numpy()[order])                # halo ids in table order
+        send_start = np.concatenate([[0], np.cumsum(self.send_counts)]).astype(np.int64)
+        self.round_send_idx = []
+        for j in range(R):
+            parts = [self._give_local[int(send_start[p]) + cut(self.send_counts[p], j):
+                                      int(send_start[p]) + cut(self.send_counts[p], j + 1)] for p in range(W)]
+            self.round_send_idx.append(be.i32(np.concatenate(parts) if parts else np.zeros(0, np.int32)))
+        # remap halo columns old position -> round-major position
+        newpos_t = be.i32(newpos)
+        cl = col_local.long()
+        is_halo = cl >= self.n_own
+        remapped = torch.where(is_halo, self.n_own + newpos_t[(cl - self.n_own).clamp(min=0)].long(), cl)
+        return remapped.to(torch.int32).contiguous()
 
     def _a2a_host(self, out, inp, out_splits, in_splits):
         """Small plan-time all-to-all-v of int64 host tensors (through the GPU when the group is NCCL)."""
@@ -303,33 +362,38 @@ class ShardedGraph(object):
         return table[self.n_own:]
 
     def exchange_start(self, table):
-        """Pack the rows peers need and start the all-to-all-v into table[n_own:]. Returns a handle for
-        exchange_finish().  With NCCL the collective runs on RCCL's stream, concurrently with whatever is
-        launched on the current stream afterwards."""
+        """Pack the rows peers need and start the R all-to-all-v rounds into table[n_own:] (round-major).  Returns a
+        list of per-round handles for exchange_finish().  With NCCL the collectives queue on RCCL's stream and run
+        concurrently with whatever is launched on the current stream afterwards, round 0 completing first."""
         if self.world == 1:
             return None
         be = self.backend
         F = int(table.shape[1])
-        send = be.gather_rows(self.own_rows(table), self.send_idx)               # [sum(send_counts), F]
-        halo = self.halo_rows(table)
-        in_splits = [c for c in self.send_counts]
-        out_splits = [c for c in self.recv_counts]
-        if dist.get_backend(self.group) == "nccl":
-            work = dist.all_to_all_single(halo, send, out_splits, in_splits, group=self.group, async_op=True)
-            return ("nccl", work, send)
-        # gloo (tests / no-RCCL runs): stage through the host
-        send_h = send.cpu()
-        recv_h = torch.empty((self.n_halo, F), dtype=torch.float32)
-        dist.all_to_all_single(recv_h, send_h, out_splits, in_splits, group=self.group)
-        return ("host", recv_h, halo)
+        nccl = dist.get_backend(self.group) == "nccl"
+        handles = []
+        for j in range(self.rounds):
+            send = be.gather_rows(self.own_rows(table), self.round_send_idx[j])
+            halo = table[self.n_own + int(self.round_offset[j]):self.n_own + int(self.round_offset[j + 1])]
+            out_splits, in_splits = list(self.round_recv_counts[j]), list(self.round_send_counts[j])
+            if nccl:
+                work = dist.all_to_all_single(halo, send, out_splits, in_splits, group=self.group, async_op=True)
+                handles.append(["nccl", work, send])
+            else:      # gloo (tests / no-RCCL runs): stage through the host
+                recv_h = torch.empty((int(halo.shape[0]), F), dtype=torch.float32)
+                dist.all_to_all_single(recv_h, send.cpu(), out_splits, in_splits, group=self.group)
+                handles.append(["host", recv_h, halo])
+        return handles
 
-    def exchange_finish(self, handle):
-        if handle is None:
+    def exchange_finish(self, handles, j=None):
+        """Wait for round j (None: all rounds)."""
+        if handles is None:
             return
-        if handle[0] == "nccl":
-            handle[1].wait()          # current stream waits for the RCCL stream
-        else:
-            handle[2].copy_(handle[1])
+        for h in (handles if j is None else [handles[j]]):
+            if h[0] == "nccl":
+                h[1].wait()           # current stream waits for the RCCL stream
+            elif h[0] == "host":
+                h[2].copy_(h[1])
+            h[0] = "done"
 
     # ------------------------------------------------------------------ aggregation
     def aggregate(self, table, op=L.SUM, w="plan", self_coef=None, bias=None, act=L.ACT_NONE, out=None,
@@ -342,16 +406,20 @@ class ShardedGraph(object):
         F = int(table.shape[1])
         if out is None:
             out = be.empty((self.n_own, F))
-        handle = self.exchange_start(table) if exchange else None
-        rp2 = self.row_ptr2
-        # pass 1: local-source edges [rp2[2r], rp2[2r+1]) — needs only own rows, overlaps the exchange
-        be.segment_reduce(rp2, rp2[1:], 2, self.col, w_t, self.n_own, table, out, L.SUM if op == L.MEAN else op,
-                          **({"hub": self.hub_local} if self.hub_local is not None else {}))
-        self.exchange_finish(handle)
-        # pass 2: halo-source edges [rp2[2r+1], rp2[2r+2]) accumulated on top, then the epilogue
-        be.segment_reduce(rp2[1:], rp2[2:], 2, self.col, w_t, self.n_own, table, out, op, act=act, accumulate=True,
-                          self_coef=self_coef, bias=bias, mean_count=self.in_degree if op == L.MEAN else None,
-                          **({"hub": self.hub_halo} if self.hub_halo is not None else {}))
+        handles = self.exchange_start(table) if exchange else None
+        K1, rpk = self.n_class, self.rpk
+        for k in range(K1):
+            last = k == K1 - 1
+            if k >= 1:
+                self.exchange_finish(handles, k - 1)          # class k reads the rows of round k-1
+            kw = {"hub": self.hub[k]} if self.hub[k] is not None else {}
+            if last:      # epilogue (self-loop term, mean divisor, bias, activation) once, in the final pass
+                be.segment_reduce(rpk[k:], rpk[k + 1:], K1, self.col, w_t, self.n_own, table, out, op, act=act,
+                                  accumulate=k > 0, self_coef=self_coef, bias=bias,
+                                  mean_count=self.in_degree if op == L.MEAN else None, **kw)
+            else:         # class 0 (own-source edges) overlaps the whole exchange, class j+1 overlaps rounds > j
+                be.segment_reduce(rpk[k:], rpk[k + 1:], K1, self.col, w_t, self.n_own, table, out,
+                                  L.SUM if op == L.MEAN else op, accumulate=k > 0, **kw)
         return out
 
     # ------------------------------------------------------------------ GCN
@@ -410,13 +478,16 @@ class ShardedGraph(object):
         K, V = table[:, :A], table[:, A:]
         s_acc = be.empty((2 * self.n_own, U))
         s_ml = be.empty((2 * self.n_own, 2 * num_heads))
-        rp2 = self.row_ptr2
-        be.gat_pass(rp2, rp2[1:], 2, self.col, self.n_own, Q, K, V, num_heads, s_acc[:self.n_own], s_ml[:self.n_own])
+        K1, rpk = self.n_class, self.rpk
+        be.gat_pass(rpk, rpk[1:], K1, self.col, self.n_own, Q, K, V, num_heads, s_acc[:self.n_own], s_ml[:self.n_own])
         self.exchange_finish(handle)
-        be.gat_pass(rp2[1:], rp2[2:], 2, self.col, self.n_own, Q, K, V, num_heads, s_acc[self.n_own:],
-                    s_ml[self.n_own:])
+        n_passes = 1
+        if K1 > 1:      # all halo classes are one contiguous span per row: [rpk[r*K1+1], rpk[(r+1)*K1])
+            be.gat_pass(rpk[1:], rpk[K1:], K1, self.col, self.n_own, Q, K, V, num_heads, s_acc[self.n_own:],
+                        s_ml[self.n_own:])
+            n_passes = 2
         out = be.empty((self.n_own, U))
-        return be.gat_merge(Q, K, V, num_heads, self.n_own, s_acc, s_ml, 2, bias, act, out)
+        return be.gat_merge(Q, K, V, num_heads, self.n_own, s_acc, s_ml, n_passes, bias, act, out)
 
     # ------------------------------------------------------------------ GraphSAGE reduce
     def neighbor_reduce(self, x_own, op, weighted=True):
