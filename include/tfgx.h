@@ -294,13 +294,13 @@ int tfgx_l2_normalize_rows_f32(float* h, int64_t ld, int64_t n, int64_t F, tfgx_
  *   tfgx_halo_mark         : flags[c] = 1 for every source c of the slice outside [own_lo, own_hi)
  *   tfgx_halo_compact      : halo_ids = sorted ids with flags set; pos[c] = its rank; *n_halo (device int32)
  *   tfgx_halo_remap_cols   : col -> local source-table index: own rows first, then halo rows
- *   tfgx_split_local_halo  : stable per-row partition into [local | halo] edges; row_ptr2 has 2n+1 entries:
- *                            local part of row r = [rp2[2r], rp2[2r+1]), halo part = [rp2[2r+1], rp2[2r+2])
+ *   tfgx_split_by_source_class : stable per-row partition of the edges by source class (own rows | halo round 0 |
+ *                            halo round 1 | ...), so each class is one strided view of a single row_ptr_k array
  * ------------------------------------------------------------------------------------------- */
 int tfgx_gather_rows_f32(const float* x, int64_t ldx, const int32_t* idx, int64_t M, int64_t F,
                          float* out, int64_t ldo, tfgx_stream_t stream);
-/* generalisation of tfgx_split_local_halo to n_class source classes (own rows + one class per halo exchange ROUND, so
-   the halo pass of round j can run while round j+1 is still on the wire): class of source c = first k with
+/* n_class source classes (own rows + one class per halo exchange ROUND, so the halo pass of round j can run while
+   round j+1 is still on the wire): class of source c = first k with
    c < class_bounds[k] (device int32 [n_class-1] used); row r's class-k edges = [rpk[r*n_class+k], rpk[r*n_class+k+1]);
    row_ptr_k has n_dst*n_class + 1 entries; n_class <= 17 */
 int tfgx_split_by_source_class(const int32_t* row_ptr, const int32_t* col_local, const float* w /* or NULL */,
@@ -314,11 +314,6 @@ int tfgx_halo_compact(const int32_t* flags, int64_t n_global, int32_t* pos /* [n
                       void* workspace, size_t workspace_bytes, tfgx_stream_t stream);
 int tfgx_halo_remap_cols(const int32_t* col, int64_t E, int32_t own_lo, int32_t own_hi, const int32_t* pos,
                          int32_t n_own, int32_t* col_local, tfgx_stream_t stream);
-int tfgx_split_local_halo(const int32_t* row_ptr, const int32_t* col_local, const float* w /* or NULL */,
-                          int64_t n_dst, int64_t E, int32_t n_own,
-                          int32_t* row_ptr2 /* [2*n_dst+1] */, int32_t* col_out, float* w_out /* or NULL */,
-                          tfgx_stream_t stream);
-
 #ifdef __cplusplus
 }
 #endif

@@ -49,23 +49,6 @@ class NumpyBackend(object):
         col_local = np.where(remote, (own_hi - own_lo) + np.searchsorted(ids, c), c - own_lo).astype(np.int32)
         return torch.from_numpy(ids), torch.from_numpy(col_local)
 
-    def split_local_halo(self, row_ptr, col_local, w, n_own):
-        rp, c, wv = _np(row_ptr), _np(col_local), _np(w)
-        n = rp.shape[0] - 1
-        rp2 = np.zeros(2 * n + 1, dtype=np.int32)
-        c2 = np.empty_like(c)
-        w2 = None if wv is None else np.empty_like(wv)
-        for r in range(n):
-            s, e = rp[r], rp[r + 1]
-            loc = c[s:e] < n_own
-            order = np.concatenate([np.flatnonzero(loc), np.flatnonzero(~loc)]) + s
-            c2[s:e] = c[order]
-            if w2 is not None:
-                w2[s:e] = wv[order]
-            rp2[2 * r], rp2[2 * r + 1] = s, s + int(loc.sum())
-        rp2[2 * n] = rp[n]
-        return torch.from_numpy(rp2), torch.from_numpy(c2), None if w2 is None else torch.from_numpy(w2)
-
     def split_by_class(self, row_ptr, col_local, w, class_bounds, n_class):
         rp, c, wv = _np(row_ptr), _np(col_local), _np(w)
         n = rp.shape[0] - 1

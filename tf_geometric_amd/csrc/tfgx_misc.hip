@@ -2,7 +2,7 @@
 //   tfgx_l2_normalize_rows_f32 : tf.nn.l2_normalize(h, axis=-1) (tf_geometric/nn/conv/graph_sage.py:58)
 //   tfgx_gather_rows_f32       : send-side pack of the halo all-to-all-v (no counterpart in the reference,
 //                                which replicates the whole graph per GPU: demo/demo_distributed_gcn.py:38-57)
-//   tfgx_halo_* / tfgx_split_local_halo : per-rank plan for a destination-range shard
+//   tfgx_halo_* / tfgx_split_by_source_class : per-rank plan for a destination-range shard
 #include "tfgx_common.h"
 #include <hipcub/hipcub.hpp>
 
@@ -74,31 +74,6 @@ __global__ void halo_remap_kernel(const int32_t* __restrict__ col, int64_t E, in
     for (; i < E; i += stride) {
         const int32_t c = col[i];
         col_local[i] = (c >= lo && c < hi) ? (c - lo) : (n_own + pos[c]);
-    }
-}
-
-// stable per-row partition into [local | halo]; one thread per destination row (plan time only)
-__global__ void split_local_halo_kernel(const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col_local,
-                                        const float* __restrict__ w, int64_t n_dst, int32_t n_own,
-                                        int32_t* __restrict__ row_ptr2, int32_t* __restrict__ col_out,
-                                        float* __restrict__ w_out)
-{
-    int64_t r = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
-    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
-    for (; r < n_dst; r += stride) {
-        const int s = row_ptr[r], e = row_ptr[r + 1];
-        int nloc = 0;
-        for (int i = s; i < e; ++i) nloc += (col_local[i] < n_own);
-        int pl = s, ph = s + nloc;
-        for (int i = s; i < e; ++i) {
-            const int32_t c = col_local[i];
-            const int dst = (c < n_own) ? pl++ : ph++;
-            col_out[dst] = c;
-            if (w_out) w_out[dst] = w[i];
-        }
-        row_ptr2[2 * r] = s;
-        row_ptr2[2 * r + 1] = s + nloc;
-        if (r == n_dst - 1) row_ptr2[2 * n_dst] = e;
     }
 }
 
@@ -301,24 +276,6 @@ extern "C" int tfgx_halo_remap_cols(const int32_t* col, int64_t E, int32_t own_l
     halo_remap_kernel<<<grid_for(E, kBlock), kBlock, 0, as_stream(stream)>>>(col, E, own_lo, own_hi, pos, n_own,
                                                                             col_local);
     TFGX_LAUNCH_CHECK("halo_remap_kernel");
-    return TFGX_OK;
-}
-
-extern "C" int tfgx_split_local_halo(const int32_t* row_ptr, const int32_t* col_local, const float* w,
-                                     int64_t n_dst, int64_t E, int32_t n_own, int32_t* row_ptr2, int32_t* col_out,
-                                     float* w_out, tfgx_stream_t stream_)
-{
-    hipStream_t stream = as_stream(stream_);
-    TFGX_REQUIRE(n_dst >= 0 && E >= 0 && row_ptr2, "bad argument");
-    if (n_dst == 0) {
-        TFGX_HIP_CHECK(hipMemsetAsync(row_ptr2, 0, sizeof(int32_t), stream));
-        return TFGX_OK;
-    }
-    TFGX_REQUIRE(row_ptr != nullptr, "null pointer");
-    TFGX_REQUIRE((w == nullptr) == (w_out == nullptr), "w and w_out must both be given or both be null");
-    split_local_halo_kernel<<<grid_for(n_dst, kBlock), kBlock, 0, stream>>>(row_ptr, col_local, w, n_dst, n_own,
-                                                                            row_ptr2, col_out, w_out);
-    TFGX_LAUNCH_CHECK("split_local_halo_kernel");
     return TFGX_OK;
 }
 

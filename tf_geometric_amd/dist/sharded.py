@@ -80,16 +80,6 @@ class HipBackend(object):
         k = int(n_halo.item())
         return ids[:k].clone(), col_local
 
-    def split_local_halo(self, row_ptr, col_local, w, n_own):
-        n_dst, E = int(row_ptr.shape[0]) - 1, int(col_local.shape[0])
-        rp2 = self.empty(2 * n_dst + 1, torch.int32)
-        col2 = torch.empty_like(col_local)
-        w2 = None if w is None else torch.empty_like(w)
-        L.check(self.lib.tfgx_split_local_halo(L.ptr(row_ptr), L.ptr(col_local), L.ptr(w), n_dst, E, n_own,
-                                               L.ptr(rp2), L.ptr(col2), L.ptr(w2), L.stream_ptr()),
-                "tfgx_split_local_halo")
-        return rp2, col2, w2
-
     def split_by_class(self, row_ptr, col_local, w, class_bounds, n_class):
         n_dst, E = int(row_ptr.shape[0]) - 1, int(col_local.shape[0])
         rpk = self.empty(n_class * n_dst + 1, torch.int32)
