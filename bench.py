@@ -294,6 +294,17 @@ def extras(tfg, L, synthetic, x, ei, n, e, f, cache):
     res["gcn_2layer_eager_ms"] = _time(lambda: two_layer(x))
     cap = tfg.CapturedForward(two_layer, x)
     res["gcn_2layer_hipgraph_ms"] = _time(lambda: cap.graph.replay())
+    # training step of one GCN layer (forward + backward through the autograd kernels)
+    gt = tfg.layers.GCN(256, activation=tfg.relu)
+    gt._maybe_build([x])
+    gt.trainable(True)
+
+    def train_step():
+        for p_ in gt.parameters():
+            p_.grad = None
+        gt([x, ei], cache=cache).sum().backward()
+
+    res["gcn_layer_fwd_bwd_ms"] = _time(train_step, steps=5, warmup=2)
     from tf_geometric_amd.plan import gemm_bias_act
     k = L.as_f32(synthetic.glorot_uniform(f, 256))
     ms = _time(lambda: gemm_bias_act(x, k))
