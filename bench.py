@@ -69,6 +69,10 @@ def cpu_baseline(x_np, ei_np, w_np, self_coef_np, n, f, budget_edges):
     w = np.ascontiguousarray(np.concatenate([w_np[keep], self_coef_np[:n_s]]))
     out = np.empty((n_s, f), dtype=np.float32)
     P = ctypes.c_void_p
+    # NUMA: spread the feature matrix over the host's memory controllers by first-touch in parallel (untimed)
+    x_cpu = np.empty_like(x_np)
+    lib.tfgo_parallel_copy_f32(P(x_cpu.ctypes.data), P(x_np.ctypes.data), ctypes.c_int64(x_np.size), ctypes.c_int(cores))
+    x_np = x_cpu
     # plan (untimed, like the GPU leg's): stable sort by destination -> row_ptr / col / w in CSR order
     order = np.argsort(row, kind="stable")
     col = np.ascontiguousarray(col[order])

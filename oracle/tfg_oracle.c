@@ -176,3 +176,13 @@ int tfgo_aggregate_csr_f32(const float* x, int64_t ldx, const int32_t* row_ptr, 
     }
     return 0;
 }
+
+/* first-touch copy: pages of dst are faulted in by the thread that later owns the same index range, so a large
+   array ends up spread over the NUMA nodes of the host instead of sitting on the allocating thread's node
+   (bench.py's cpu_baseline: random row gathers then draw on every memory controller) */
+void tfgo_parallel_copy_f32(float* dst, const float* src, int64_t n, int threads)
+{
+    if (threads < 1) threads = 1;
+#pragma omp parallel for num_threads(threads) schedule(static)
+    for (int64_t i = 0; i < n; ++i) dst[i] = src[i];
+}
