@@ -1,0 +1,113 @@
+# coding=utf-8
+"""2-layer GCN on a Cora-SHAPED synthetic graph — the MI355X counterpart of the reference's demo/demo_gcn.py
+(BASELINE.json configs[0]; real Cora needs a download, there is no network here).
+
+Same model (GCN(16, relu) -> GCN(num_classes), dropout 0.5, Adam 1e-2, L2 5e-4 on kernels), same layer call
+signature `[x, edge_index, edge_weight], cache=graph_cache`, same closing "mean forward time" measurement
+(demo/demo_gcn.py:99-105).  tf.GradientTape -> torch.autograd over the kernels' own backward (tf_geometric_amd.autograd).
+
+    python examples/demo_gcn.py [--steps 200]
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import tf_geometric_amd as tfg   # noqa: E402
+
+
+def cora_shaped(seed=0, n=2708, e=10556, f=1433, classes=7):
+    """Planted-partition graph with bag-of-words-like sparse features that carry a weak class signal."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    y = rng.integers(0, classes, size=n)
+    half = e // 2
+    a = rng.integers(0, n, size=half)
+    same = rng.random(half) < 0.8                                   # 80% of edges stay inside a class (homophily)
+    order = np.argsort(y, kind="stable")                            # nodes of a class are contiguous in `order`
+    pos = np.empty(n, dtype=np.int64)
+    pos[order] = np.arange(n)
+    near = order[np.clip(pos[a] + rng.integers(-40, 41, half), 0, n - 1)]
+    b = np.where(same, near, rng.integers(0, n, size=half))
+    keep = a != b
+    a, b = a[keep], b[keep]
+    edge_index = np.stack([np.concatenate([a, b]), np.concatenate([b, a])]).astype(np.int32)
+    x = (rng.random((n, f)) < 0.012).astype(np.float32)             # ~17 active words per node, like Cora
+    for c in range(classes):                                        # class-specific vocabulary block
+        cols = slice(c * 60, c * 60 + 60)
+        x[y == c, cols] = (rng.random((int((y == c).sum()), 60)) < 0.12).astype(np.float32)
+    x = x / np.maximum(x.sum(1, keepdims=True), 1.0)
+    idx = rng.permutation(n)
+    return x, edge_index, y.astype(np.int64), idx[:140], idx[140:640], idx[1708:]
+
+
+class GCNModel(object):
+    def __init__(self, num_classes, drop_rate=0.5):
+        self.gcn0 = tfg.layers.GCN(16, activation=tfg.relu)
+        self.gcn1 = tfg.layers.GCN(num_classes)
+        self.drop_rate = drop_rate
+
+    def __call__(self, inputs, training=False, cache=None):
+        x, edge_index, edge_weight = inputs
+        h = torch.nn.functional.dropout(x, self.drop_rate, training)
+        h = self.gcn0([h, edge_index, edge_weight], cache=cache)
+        h = torch.nn.functional.dropout(h, self.drop_rate, training)
+        return self.gcn1([h, edge_index, edge_weight], cache=cache)
+
+    def parameters(self):
+        return self.gcn0.parameters() + self.gcn1.parameters()
+
+
+def main(steps=200, forward_iters=1000, quiet=False):
+    x_np, edge_index, y_np, train_index, valid_index, test_index = cora_shaped()
+    num_classes = int(y_np.max()) + 1
+    x = tfg._lib.as_f32(x_np)
+    y = torch.as_tensor(y_np, device=x.device)
+    edge_weight = np.ones(edge_index.shape[1], dtype=np.float32)    # Graph default (data/graph.py:53-56)
+    cache = {}                                                       # graph.cache
+    model = GCNModel(num_classes)
+    model([x, edge_index, edge_weight], cache=cache)                 # builds weights + plan + normalised adjacency
+    model.gcn0.trainable(True)
+    model.gcn1.trainable(True)
+    optimizer = torch.optim.Adam(model.parameters(), lr=1e-2)
+    tr, te = torch.as_tensor(train_index, device=x.device), torch.as_tensor(test_index, device=x.device)
+
+    def evaluate():
+        with torch.no_grad():
+            logits = model([x, edge_index, edge_weight], cache=cache)
+        return float((logits[te].argmax(-1) == y[te]).float().mean())
+
+    acc = evaluate()
+    for step in range(1, steps + 1):
+        optimizer.zero_grad()
+        logits = model([x, edge_index, edge_weight], training=True, cache=cache)
+        loss = torch.nn.functional.cross_entropy(logits[tr], y[tr])
+        loss = loss + 5e-4 * sum(0.5 * (p ** 2).sum() for p in (model.gcn0.kernel, model.gcn1.kernel))
+        loss.backward()
+        optimizer.step()
+        if step % 20 == 0:
+            acc = evaluate()
+            if not quiet:
+                print("step = {}\tloss = {:.4f}\taccuracy = {:.4f}".format(step, float(loss.detach()), acc))
+    mean_forward = None
+    if forward_iters:
+        with torch.no_grad():
+            torch.cuda.synchronize()
+            start = time.time()
+            for _ in range(forward_iters):
+                model([x, edge_index, edge_weight], cache=cache)
+            torch.cuda.synchronize()
+            mean_forward = (time.time() - start) / forward_iters
+        if not quiet:
+            print("mean forward time: {:.6f} seconds".format(mean_forward))
+    return acc, mean_forward
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=200)
+    args = ap.parse_args()
+    main(steps=args.steps)

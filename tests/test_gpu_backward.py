@@ -157,3 +157,13 @@ def test_sage_layers_train_step_decreases_loss(tfg, oracle, cls):
         losses.append(float(loss.detach()))
     assert losses[-1] < losses[0] * 0.995 and all(b <= a + 1e-6 for a, b in zip(losses, losses[1:])), losses
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in layer.parameters())
+
+
+def test_demo_gcn_trains_on_cora_shaped_graph(tfg):
+    """examples/demo_gcn.py (counterpart of the reference's demo/demo_gcn.py): accuracy far above 1/7 chance."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    import demo_gcn
+    acc, _ = demo_gcn.main(steps=60, forward_iters=0, quiet=True)
+    assert acc > 0.5, acc
