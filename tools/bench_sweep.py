@@ -92,6 +92,8 @@ def main():
         gemm_section(n)
     if want("gat"):
         gat_section(plan, n, E)
+    if want("backward"):
+        backward_section(plan, n, E, w)
 
 
 def rmat_section(quick, e):
@@ -178,3 +180,28 @@ def wr_csr(plan, w):
 
 if __name__ == "__main__":
     main()
+
+
+def backward_section(plan, n, E, w):
+    """Backward kernels at products shape: transposed aggregation (d/dx), SDDMM (d/dw), max gradient, GAT gradient."""
+    import tf_geometric_amd.autograd as AG
+    w_csr = plan.edge_attr_to_csr(w)
+    for f in [100]:
+        x = torch.randn(n, f, device="cuda", requires_grad=True)
+        g = torch.randn(n, f, device="cuda")
+        for name, op, ww in [("sum_w", L.SUM, w_csr), ("max", L.MAX, None)]:
+            out = AG.aggregate(plan, x, op, ww)
+            ms = timeit(lambda: torch.autograd.grad(out, x, g, retain_graph=True), steps=5, warmup=2)
+            print(json.dumps({"kind": "backward", "what": "d/dx aggregate " + name, "F": f, "ms": ms}), flush=True)
+        wreq = w_csr.clone().requires_grad_(True)
+        out = AG.aggregate(plan, x.detach(), L.SUM, wreq)
+        ms = timeit(lambda: torch.autograd.grad(out, wreq, g, retain_graph=True), steps=5, warmup=2)
+        print(json.dumps({"kind": "backward", "what": "d/dw (sddmm)", "F": f, "ms": ms}), flush=True)
+    for (H, A, U) in [(8, 8, 64)]:
+        Q = torch.randn(n, A, device="cuda", requires_grad=True)
+        K = torch.randn(n, A, device="cuda", requires_grad=True)
+        V = torch.randn(n, U, device="cuda", requires_grad=True)
+        g = torch.randn(n, U, device="cuda")
+        out = AG.gat_attention(plan, Q, K, V, H)
+        ms = timeit(lambda: torch.autograd.grad(out, (Q, K, V), g, retain_graph=True), steps=3, warmup=1)
+        print(json.dumps({"kind": "backward", "what": "GAT dQ,dK,dV", "H": H, "A": A, "U": U, "ms": ms}), flush=True)
