@@ -178,8 +178,6 @@ def wr_csr(plan, w):
     return plan.edge_attr_to_csr(w)
 
 
-if __name__ == "__main__":
-    main()
 
 
 def backward_section(plan, n, E, w):
@@ -205,3 +203,7 @@ def backward_section(plan, n, E, w):
         out = AG.gat_attention(plan, Q, K, V, H)
         ms = timeit(lambda: torch.autograd.grad(out, (Q, K, V), g, retain_graph=True), steps=3, warmup=1)
         print(json.dumps({"kind": "backward", "what": "GAT dQ,dK,dV", "H": H, "A": A, "U": U, "ms": ms}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
