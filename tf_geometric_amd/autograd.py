@@ -46,6 +46,21 @@ def _permute(attr, idx):
     return out
 
 
+def _transposed_weights(plan, w_csr, t2d):
+    """w_csr permuted into the transposed plan's order, memoised per (tensor storage, version) on the plan —
+    GCN's normalised weights are the same tensor for every layer and every step."""
+    if w_csr is None:
+        return None
+    key = (w_csr.data_ptr(), w_csr._version, int(w_csr.shape[0]))
+    cache = plan.__dict__.setdefault("_wt_cache", {})
+    hit = cache.get("w")
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    w_t = _permute(w_csr.detach(), t2d)
+    cache["w"] = (key, w_t, w_csr)      # keeps w_csr alive so the data_ptr cannot be recycled
+    return w_t
+
+
 class _Aggregate(torch.autograd.Function):
     """out[r] = (1/cnt[r]) * ( sum_{i in row r} w[i] x[col[i]] + self_coef[r] x[r] )   (cnt only for mean)."""
 
@@ -67,7 +82,7 @@ class _Aggregate(torch.autograd.Function):
         gx = gw = gs = None
         if ctx.needs_input_grad[2]:
             pt, t2d = _transposed(plan)
-            w_t = None if w_csr is None else _permute(w_csr.detach(), t2d)
+            w_t = _transposed_weights(plan, w_csr, t2d)
             gx = segment_reduce(pt, g, L.SUM, w_csr=w_t)
             if self_coef is not None:
                 gx = gx + self_coef.detach().unsqueeze(1) * g

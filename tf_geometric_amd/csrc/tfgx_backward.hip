@@ -184,6 +184,144 @@ __global__ __launch_bounds__(kBlock) void gat_backward_src_kernel(const GB a)
     }
 }
 
+// ---- fast GAT backward: a group of G lanes per row, lane -> 4 value columns of one head (as the forward kernel).
+// Needs dv % 4 == 0, LH = dv/4 a power of two (the head's lanes form an aligned butterfly), d in {1,2,4,8,16}.
+// Per edge the bytes moved are the forward's (K row + V row) for the dst pass and Q row + dO row + 3 scalars for the
+// src pass; everything else lives in registers.
+template <int D>
+__device__ __forceinline__ float dot_d(const float (&a)[D], const float* __restrict__ b, float (&bout)[D])
+{
+    float s = 0.0f;
+#pragma unroll
+    for (int t = 0; t < D; ++t) {
+        bout[t] = b[t];
+        s = fmaf(a[t], bout[t], s);
+    }
+    return s;
+}
+
+template <int G>
+__device__ __forceinline__ float head_sum(float v, int lh)
+{
+    for (int o = lh >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, G);
+    return v;
+}
+
+template <int G, int D, bool SRC>
+__global__ __launch_bounds__(kBlock) void gat_backward_fast_kernel(const GB a)
+{
+    constexpr int VEC = 4;
+    constexpr int ROWS_PER_BLOCK = kBlock / G;
+    const int lane = threadIdx.x % G, grp = threadIdx.x / G;
+    const int W = a.H * a.dv;
+    const int c_raw = (blockIdx.y * G + lane) * VEC;
+    const bool cvalid = c_raw < W;
+    const int coff = cvalid ? c_raw : (W - VEC);
+    const int head = coff / a.dv;
+    const int lh = a.dv / VEC;
+    const bool head_first = cvalid && (coff % a.dv == 0);
+
+    for (int64_t row = int64_t(blockIdx.x) * ROWS_PER_BLOCK + grp; row < a.n; row += int64_t(gridDim.x) * ROWS_PER_BLOCK) {
+        const int s0 = a.row_ptr[row], e0 = a.row_ptr[row + 1];
+        // "mine": the row this group owns (destination r for the dst pass, source c for the src pass)
+        float mine_qk[D];     // dst pass: Q[r,h,:]   src pass: K[c,h,:]
+        float mine_v[VEC];    // dst pass: dO[r,cols] src pass: V[c,cols]
+        float acc_qk[D];      // dst pass: dQ[r,h,:]  src pass: dK[c,h,:]
+        float acc_v[VEC];     // src pass only: dV[c,cols]
+        const float* own_qk = (SRC ? a.k + row * a.ldk : a.q + row * a.ldq) + head * a.d;
+#pragma unroll
+        for (int t = 0; t < D; ++t) { mine_qk[t] = own_qk[t]; acc_qk[t] = 0.0f; }
+        load_vec<VEC>((SRC ? a.v + row * a.ldv : a.go + row * a.ldgo) + coff, mine_v);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc_v[i] = 0.0f;
+        float m_r = 0.0f, linv_r = 0.0f, d_r = 0.0f;
+        if (!SRC) {
+            m_r = a.ml[row * 2 * a.H + 2 * head];
+            linv_r = 1.0f / (a.ml[row * 2 * a.H + 2 * head + 1] + 1e-8f);
+            d_r = a.dsum[row * a.H + head];
+        }
+        auto edge = [&](int64_t o) {   // o: the other endpoint (source c for dst pass, destination r for src pass)
+            float oth_qk[D];
+            const float sc = dot_d<D>(mine_qk, (SRC ? a.q + o * a.ldq : a.k + o * a.ldk) + head * a.d, oth_qk) / a.scale;
+            float oth_v[VEC];
+            load_vec<VEC>((SRC ? a.go + o * a.ldgo : a.v + o * a.ldv) + coff, oth_v);
+            float part = 0.0f;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) part = fmaf(mine_v[i], oth_v[i], part);   // <dO, V> over this lane's columns
+            const float da = head_sum<G>(part, lh);
+            float m = m_r, linv = linv_r, dd = d_r;
+            if (SRC) {
+                m = a.ml[o * 2 * a.H + 2 * head];
+                linv = 1.0f / (a.ml[o * 2 * a.H + 2 * head + 1] + 1e-8f);
+                dd = a.dsum[o * a.H + head];
+            }
+            const float alpha = expf(sc - m) * linv;
+            const float ds = alpha * (da - dd) / a.scale;
+#pragma unroll
+            for (int t = 0; t < D; ++t) acc_qk[t] = fmaf(ds, oth_qk[t], acc_qk[t]);
+            if (SRC) {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) acc_v[i] = fmaf(alpha, oth_v[i], acc_v[i]);
+            }
+        };
+        for (int base = s0; base < e0; base += G) {
+            const int idx = base + lane;
+            const int oj = (idx < e0) ? a.other[idx] : 0;
+            const int cnt = min(G, e0 - base);
+            for (int j = 0; j < cnt; ++j) edge(int64_t(__shfl(oj, j, G)));
+        }
+        if (a.add_self_loop) edge(row);
+        if (SRC) {
+            if (cvalid) store_vec<VEC>(a.gv + row * a.ldgv + coff, acc_v);
+        }
+        if (head_first) {
+            float* dst = (SRC ? a.gk + row * a.ldgk : a.gq + row * a.ldgq) + head * a.d;
+#pragma unroll
+            for (int t = 0; t < D; ++t) dst[t] = acc_qk[t];
+        }
+    }
+}
+
+template <int G, bool SRC>
+int launch_gat_bwd_d(const GB& a, hipStream_t stream)
+{
+    constexpr int ROWS_PER_BLOCK = kBlock / G;
+    const int W = a.H * a.dv;
+    dim3 grid(grid_for(a.n, ROWS_PER_BLOCK, 1 << 20), (W + G * 4 - 1) / (G * 4), 1), block(kBlock, 1, 1);
+    switch (a.d) {
+        case 1: gat_backward_fast_kernel<G, 1, SRC><<<grid, block, 0, stream>>>(a); break;
+        case 2: gat_backward_fast_kernel<G, 2, SRC><<<grid, block, 0, stream>>>(a); break;
+        case 4: gat_backward_fast_kernel<G, 4, SRC><<<grid, block, 0, stream>>>(a); break;
+        case 8: gat_backward_fast_kernel<G, 8, SRC><<<grid, block, 0, stream>>>(a); break;
+        default: gat_backward_fast_kernel<G, 16, SRC><<<grid, block, 0, stream>>>(a); break;
+    }
+    TFGX_LAUNCH_CHECK("gat_backward_fast_kernel");
+    return TFGX_OK;
+}
+
+template <bool SRC>
+int launch_gat_bwd(const GB& a, hipStream_t stream)
+{
+    const int lanes = (a.H * a.dv + 3) / 4;
+    if (lanes <= 4) return launch_gat_bwd_d<4, SRC>(a, stream);
+    if (lanes <= 8) return launch_gat_bwd_d<8, SRC>(a, stream);
+    if (lanes <= 16) return launch_gat_bwd_d<16, SRC>(a, stream);
+    if (lanes <= 32) return launch_gat_bwd_d<32, SRC>(a, stream);
+    return launch_gat_bwd_d<64, SRC>(a, stream);
+}
+
+inline bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+// layout conditions of the fast kernels (else the one-lane-per-(row, head) kernels above are used)
+bool gat_bwd_fast_ok(const tfgx_gat_backward_args* p)
+{
+    const bool d_ok = p->d == 1 || p->d == 2 || p->d == 4 || p->d == 8 || p->d == 16;
+    const bool v_ok = p->dv % 4 == 0 && pow2(p->dv / 4) && p->dv / 4 <= 64;
+    const bool al = p->ldv % 4 == 0 && p->ld_grad_out % 4 == 0 && aligned_to(p->v, 16) && aligned_to(p->grad_out, 16) &&
+                    (p->grad_v == nullptr || (p->ld_grad_v % 4 == 0 && aligned_to(p->grad_v, 16)));
+    return d_ok && v_ok && al;
+}
+
 }  // namespace
 }  // namespace tfgx
 
@@ -251,6 +389,7 @@ extern "C" int tfgx_gat_backward_dst_f32(const tfgx_gat_backward_args* p, tfgx_s
     TFGX_REQUIRE(p->row_ptr && p->grad_q && p->n_dst >= 0, "dst pass needs row_ptr / grad_q");
     if (p->n_dst == 0) return TFGX_OK;
     a.row_ptr = p->row_ptr; a.other = p->col; a.n = p->n_dst;
+    if (gat_bwd_fast_ok(p)) return launch_gat_bwd<false>(a, as_stream(stream));
     gat_backward_dst_kernel<<<grid_for(a.n * a.H, kBlock), kBlock, 0, as_stream(stream)>>>(a);
     TFGX_LAUNCH_CHECK("gat_backward_dst_kernel");
     return TFGX_OK;
@@ -264,6 +403,7 @@ extern "C" int tfgx_gat_backward_src_f32(const tfgx_gat_backward_args* p, tfgx_s
     TFGX_REQUIRE(p->row_ptr_t && p->grad_k && p->grad_v && p->n_src >= 0, "src pass needs row_ptr_t / grad_k / grad_v");
     if (p->n_src == 0) return TFGX_OK;
     a.row_ptr = p->row_ptr_t; a.other = p->dst_t; a.n = p->n_src;
+    if (gat_bwd_fast_ok(p)) return launch_gat_bwd<true>(a, as_stream(stream));
     gat_backward_src_kernel<<<grid_for(a.n * a.H, kBlock), kBlock, 0, as_stream(stream)>>>(a);
     TFGX_LAUNCH_CHECK("gat_backward_src_kernel");
     return TFGX_OK;
