@@ -231,6 +231,7 @@ int tfgx_segment_max_count_f32(const int32_t* row_ptr, const int32_t* col, const
 int tfgx_segment_max_backward_f32(const int32_t* row_ptr_t, const int32_t* dst_t, const float* w_t /* or NULL */,
                                   int64_t n_src, const float* x, int64_t ldx, int64_t F, const float* out, int64_t ldo,
                                   const float* g, int64_t ldg, const float* count, int64_t ldc, float* gx, int64_t ldgx,
+                                  int64_t n_dst, float* gn_scratch /* [n_dst, F] workspace or NULL (slow path) */,
                                   tfgx_stream_t stream);
 
 typedef struct tfgx_gat_backward_args {

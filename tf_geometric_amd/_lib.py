@@ -101,7 +101,7 @@ SIGNATURES = {
     "tfgx_sddmm_f32": (ctypes.c_int, [_P, _P, _I64, _P, _I64, _P, _I64, _I64, _P, _P]),
     "tfgx_segment_max_count_f32": (ctypes.c_int, [_P, _P, _P, _I64, _P, _I64, _I64, _P, _I64, _P, _I64, _P]),
     "tfgx_segment_max_backward_f32": (ctypes.c_int, [_P, _P, _P, _I64, _P, _I64, _I64, _P, _I64, _P, _I64, _P, _I64,
-                                                     _P, _I64, _P]),
+                                                     _P, _I64, _I64, _P, _P]),
     "tfgx_gat_backward_dst_f32": (ctypes.c_int, [ctypes.POINTER(GatBackwardArgs), _P]),
     "tfgx_gat_backward_src_f32": (ctypes.c_int, [ctypes.POINTER(GatBackwardArgs), _P]),
     "tfgx_head_mean_f32": (ctypes.c_int, [_P, _I64, _I64, _I32, _I32, _P, _I32, _P, _I64, _P]),

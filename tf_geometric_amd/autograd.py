@@ -120,11 +120,13 @@ class _AggregateMax(torch.autograd.Function):
                                                ldx, F, L.ptr(out), F, L.ptr(count), F, L.stream_ptr()),
                 "tfgx_segment_max_count_f32")
         pt, t2d = _transposed(plan)
-        w_t = None if w_csr is None else _permute(w_csr.detach(), t2d)
+        w_t = _transposed_weights(plan, w_csr, t2d)
         gx = torch.empty_like(x2)
+        gn = torch.empty_like(out)          # workspace: g / count per destination row
         L.check(lib.tfgx_segment_max_backward_f32(L.ptr(pt.row_ptr), L.ptr(pt.col), L.ptr(w_t), pt.n_dst, L.ptr(x2), ldx,
                                                   F, L.ptr(out), F, L.ptr(g2), ldg, L.ptr(count), F, L.ptr(gx), F,
-                                                  L.stream_ptr()), "tfgx_segment_max_backward_f32")
+                                                  plan.n_dst, L.ptr(gn), L.stream_ptr()),
+                "tfgx_segment_max_backward_f32")
         return None, gx, None
 
 

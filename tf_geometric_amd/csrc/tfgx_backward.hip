@@ -94,6 +94,90 @@ __global__ __launch_bounds__(kBlock) void max_backward_kernel(const int32_t* __r
     }
 }
 
+// fast variants of the two kernels above: a lane group per row, 4 columns per lane (rows 16-byte aligned, F % 4 == 0)
+// MODE 0: count[r, :] = #ties;  MODE 1 (transposed plan): gx[c, :] = sum [tie] * w * gn[dst, :], gn = g / count
+template <int G, int MODE>
+__global__ __launch_bounds__(kBlock) void max_grad_fast_kernel(const int32_t* __restrict__ row_ptr,
+                                                               const int32_t* __restrict__ other,
+                                                               const float* __restrict__ w, int64_t n,
+                                                               const float* __restrict__ x, int64_t ldx, int F,
+                                                               const float* __restrict__ out, int64_t ldo,
+                                                               const float* __restrict__ gn, int64_t ldg,
+                                                               float* __restrict__ res, int64_t ldr)
+{
+    constexpr int VEC = 4;
+    constexpr int ROWS_PER_BLOCK = kBlock / G;
+    const int lane = threadIdx.x % G, grp = threadIdx.x / G;
+    const int c_raw = (blockIdx.y * G + lane) * VEC;
+    const bool cvalid = c_raw < F;
+    const int coff = cvalid ? c_raw : (F - VEC);
+    for (int64_t row = int64_t(blockIdx.x) * ROWS_PER_BLOCK + grp; row < n; row += int64_t(gridDim.x) * ROWS_PER_BLOCK) {
+        const int s = row_ptr[row], e = row_ptr[row + 1];
+        float mine[VEC], acc[VEC];
+        load_vec<VEC>((MODE == 0 ? out + row * ldo : x + row * ldx) + coff, mine);   // out[r,:] | x[c,:]
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] = 0.0f;
+        for (int base = s; base < e; base += G) {
+            const int idx = base + lane;
+            const int oj = (idx < e) ? other[idx] : 0;
+            const float wj = (w && idx < e) ? w[idx] : 1.0f;
+            const int cnt = min(G, e - base);
+            for (int j = 0; j < cnt; ++j) {
+                const int64_t o = __shfl(oj, j, G);
+                const float wi = __shfl(wj, j, G);
+                if (MODE == 0) {
+                    float xv[VEC];
+                    load_vec<VEC>(x + o * ldx + coff, xv);
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) acc[i] += ((w ? wi * xv[i] : xv[i]) == mine[i]) ? 1.0f : 0.0f;
+                } else {
+                    float ov[VEC], gv[VEC];
+                    load_vec<VEC>(out + o * ldo + coff, ov);
+                    load_vec<VEC>(gn + o * ldg + coff, gv);
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i)
+                        acc[i] += ((w ? wi * mine[i] : mine[i]) == ov[i]) ? wi * gv[i] : 0.0f;
+                }
+            }
+        }
+        if (cvalid) store_vec<VEC>(res + row * ldr + coff, acc);
+    }
+}
+
+template <int MODE>
+int launch_max_grad(const int32_t* row_ptr, const int32_t* other, const float* w, int64_t n, const float* x,
+                    int64_t ldx, int F, const float* out, int64_t ldo, const float* gn, int64_t ldg, float* res,
+                    int64_t ldr, hipStream_t stream)
+{
+    const int lanes = (F + 3) / 4;
+#define TFGX_MG(GG)                                                                                            \
+    {                                                                                                          \
+        dim3 grid(grid_for(n, kBlock / GG, 1 << 20), (lanes + GG - 1) / GG, 1);                                \
+        max_grad_fast_kernel<GG, MODE><<<grid, kBlock, 0, stream>>>(row_ptr, other, w, n, x, ldx, F, out, ldo, \
+                                                                      gn, ldg, res, ldr);                     \
+    }
+    if (lanes <= 8) TFGX_MG(8)
+    else if (lanes <= 16) TFGX_MG(16)
+    else if (lanes <= 32) TFGX_MG(32)
+    else TFGX_MG(64)
+#undef TFGX_MG
+    TFGX_LAUNCH_CHECK("max_grad_fast_kernel");
+    return TFGX_OK;
+}
+
+__global__ void divide_kernel(const float* __restrict__ g, int64_t ldg, const float* __restrict__ cnt, int64_t ldc,
+                              int64_t n, int F, float* __restrict__ gn)
+{
+    int64_t t = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (; t < n * F; t += stride) {
+        const int64_t r = t / F;
+        const int j = int(t - r * F);
+        const float c = cnt[r * ldc + j];
+        gn[t] = c > 0.0f ? g[r * ldg + j] / c : 0.0f;
+    }
+}
+
 // ---------------------------------------------------------------- GAT backward
 struct GB {
     const int32_t* row_ptr;   // forward plan (by destination) or transposed plan (by source)
@@ -348,6 +432,10 @@ extern "C" int tfgx_segment_max_count_f32(const int32_t* row_ptr, const int32_t*
     TFGX_REQUIRE(n_dst >= 0 && F >= 1 && ldx >= F && ldo >= F && ldc >= F, "bad size");
     if (n_dst == 0) return TFGX_OK;
     TFGX_REQUIRE(row_ptr && x && out && count, "null pointer");
+    if (F % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && ldc % 4 == 0 && aligned_to(x, 16) && aligned_to(out, 16) &&
+        aligned_to(count, 16))
+        return launch_max_grad<0>(row_ptr, col, w, n_dst, x, ldx, int(F), out, ldo, nullptr, 0, count, ldc,
+                                  as_stream(stream));
     max_count_kernel<<<grid_for(n_dst * F, kBlock), kBlock, 0, as_stream(stream)>>>(row_ptr, col, w, n_dst, x, ldx,
                                                                                    int(F), out, ldo, count, ldc);
     TFGX_LAUNCH_CHECK("max_count_kernel");
@@ -357,11 +445,21 @@ extern "C" int tfgx_segment_max_count_f32(const int32_t* row_ptr, const int32_t*
 extern "C" int tfgx_segment_max_backward_f32(const int32_t* row_ptr_t, const int32_t* dst_t, const float* w_t,
                                              int64_t n_src, const float* x, int64_t ldx, int64_t F, const float* out,
                                              int64_t ldo, const float* g, int64_t ldg, const float* count, int64_t ldc,
-                                             float* gx, int64_t ldgx, tfgx_stream_t stream)
+                                             float* gx, int64_t ldgx, int64_t n_dst, float* gn_scratch,
+                                             tfgx_stream_t stream)
 {
     TFGX_REQUIRE(n_src >= 0 && F >= 1 && ldx >= F && ldo >= F && ldg >= F && ldc >= F && ldgx >= F, "bad size");
     if (n_src == 0) return TFGX_OK;
     TFGX_REQUIRE(row_ptr_t && x && out && g && count && gx, "null pointer");
+    if (gn_scratch != nullptr && F % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && ldgx % 4 == 0 && aligned_to(x, 16) &&
+        aligned_to(out, 16) && aligned_to(gx, 16) && aligned_to(gn_scratch, 16)) {
+        // gn = g / count once per destination row, then one pass over the transposed plan with two row gathers per edge
+        divide_kernel<<<grid_for(n_dst * F, kBlock), kBlock, 0, as_stream(stream)>>>(g, ldg, count, ldc, n_dst, int(F),
+                                                                                   gn_scratch);
+        TFGX_LAUNCH_CHECK("divide_kernel");
+        return launch_max_grad<1>(row_ptr_t, dst_t, w_t, n_src, x, ldx, int(F), out, ldo, gn_scratch, F, gx, ldgx,
+                                  as_stream(stream));
+    }
     max_backward_kernel<<<grid_for(n_src * F, kBlock), kBlock, 0, as_stream(stream)>>>(
         row_ptr_t, dst_t, w_t, n_src, x, ldx, int(F), out, ldo, g, ldg, count, ldc, gx, ldgx);
     TFGX_LAUNCH_CHECK("max_backward_kernel");
