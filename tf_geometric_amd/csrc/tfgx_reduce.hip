@@ -60,7 +60,8 @@ struct KArgs {
 template <int VEC, int G, int CH, bool IS_MAX, bool WEIGHTED, bool SPLIT = false>
 __global__ __launch_bounds__(kBlock) void seg_reduce_kernel(const KArgs a)
 {
-    constexpr int UNROLL = (CH >= 4) ? 2 : (CH == 2 ? 4 : 8);  // independent row loads in flight per lane
+    constexpr int UNROLL_W = (CH >= 4) ? 2 : (CH == 2 ? 4 : 8);   // independent row loads in flight per lane
+    constexpr int UNROLL = UNROLL_W < G ? UNROLL_W : G;              // a batch holds G edges: never unroll past it
     constexpr int ROWS_PER_BLOCK = kBlock / G;
     constexpr int COLS_PER_PASS = G * VEC * CH;
     const int lane = threadIdx.x % G;
