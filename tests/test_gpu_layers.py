@@ -261,3 +261,20 @@ def test_gemm_column_limited_activation(tfg, oracle):
     ref[:, :16] = np.maximum(ref[:, :16], 0)
     assert_parity(got, ref, what="act_cols")
     assert (got[:, 16:] < 0).any()
+
+
+@pytest.mark.parametrize("m,k,n", [(33000, 100, 256), (40001, 36, 100), (50000, 128, 200), (32768, 100, 65), (70000, 20, 129)])
+def test_gemm_streaming_kernel(tfg, oracle, m, k, n):
+    """Tall-skinny shapes (M >= 32768, 64 < N <= 256, K % 4 == 0) take the persistent B-in-LDS kernel."""
+    from tf_geometric_amd.plan import gemm_bias_act
+    rng = np.random.Generator(np.random.PCG64(m + k))
+    a = rng.standard_normal((m, k), dtype=np.float32)
+    b = oracle.glorot_uniform(rng, k, n)
+    bias = (rng.standard_normal(n) * 0.1).astype(np.float32)
+    got = gemm_bias_act(a, b, bias=bias, act=1).cpu().numpy()
+    ref = np.maximum(oracle.matmul(a, b) + bias, 0)
+    assert_parity(got, ref, what="stream gemm {}x{}x{}".format(m, k, n))
+    got2 = gemm_bias_act(a, b, act=1, act_cols=n // 2).cpu().numpy()
+    ref2 = oracle.matmul(a, b)
+    ref2[:, :n // 2] = np.maximum(ref2[:, :n // 2], 0)
+    assert_parity(got2, ref2, what="stream gemm act_cols")

@@ -165,6 +165,134 @@ __global__ __launch_bounds__(kBlock) void gemm_kernel(const float* __restrict__ 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Streaming variant for the shape this library actually meets: M = nodes (10^5..10^8), K and N = feature widths
+// with K*N small enough that the WHOLE weight matrix lives in LDS (160 KB per CU).  One 512-thread workgroup per CU
+// (8 waves: 4 along M x 2 along N, two waves per SIMD) is persistent: B is loaded into LDS once, then the workgroup
+// walks M-tiles of 128 rows; A streams through a double-buffered LDS tile (BK = 16) with ONE barrier per k-step and
+// the global loads of the next step (or of the next M-tile's first step) issued before the MFMAs of the current
+// one, so there is no per-tile prologue bubble.  Same arithmetic as gemm_kernel: k-ordered fp32 FMA chain.
+template <int TN>
+__global__ __launch_bounds__(512) void gemm_stream_kernel(const float* __restrict__ A, int64_t lda,
+                                                          const float* __restrict__ B, int64_t ldb,
+                                                          const float* __restrict__ bias, int act, int act_cols,
+                                                          float* __restrict__ C, int64_t ldc, int64_t M, int K, int N,
+                                                          int64_t n_mtiles)
+{
+    constexpr int BM = 128, SBK = 16, LDA_S = BM + 1;
+    constexpr int LDB_S = 2 * TN * 32 + 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int nk = (K + SBK - 1) / SBK;
+    float* Bs = smem;                         // [nk*SBK][LDB_S], zero padded
+    float* As = smem + nk * SBK * LDB_S;      // [2][SBK][LDA_S]
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, kh = lane >> 5;
+
+    for (int idx = tid; idx < nk * SBK * LDB_S; idx += 512) {
+        const int k = idx / LDB_S, n = idx - k * LDB_S;
+        Bs[idx] = (k < K && n < N) ? B[int64_t(k) * ldb + n] : 0.0f;
+    }
+
+    const int arow = tid >> 2, akq = (tid & 3) * 4;   // one float4 of the 128 x 16 A tile per thread
+    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto load_a = [&](int64_t mt, int k0) {
+        const int64_t gm = mt * BM + arow;
+        const int gk = k0 + akq;
+        ra = (gm < M && gk < K) ? *reinterpret_cast<const float4*>(A + gm * lda + gk) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto store_a = [&](int buf) {
+        float* a = As + buf * SBK * LDA_S;
+        a[(akq + 0) * LDA_S + arow] = ra.x;
+        a[(akq + 1) * LDA_S + arow] = ra.y;
+        a[(akq + 2) * LDA_S + arow] = ra.z;
+        a[(akq + 3) * LDA_S + arow] = ra.w;
+    };
+
+    f32x16 acc[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc[j][t] = 0.0f;
+
+    int64_t mt = blockIdx.x;
+    if (mt < n_mtiles) load_a(mt, 0);
+    int buf = 0;
+    for (; mt < n_mtiles; mt += gridDim.x) {
+        for (int kt = 0; kt < nk; ++kt) {
+            store_a(buf);
+            __syncthreads();
+            if (kt + 1 < nk) load_a(mt, (kt + 1) * SBK);
+            else if (mt + gridDim.x < n_mtiles) load_a(mt + gridDim.x, 0);
+            const float* a_s = As + buf * SBK * LDA_S;
+            const float* b_s = Bs + kt * SBK * LDB_S;
+            const int kmax = min(SBK, K - kt * SBK);
+#pragma unroll
+            for (int kk = 0; kk < SBK; kk += 2) {
+                if (kk < kmax) {
+                    const float a = a_s[(kk + kh) * LDA_S + wm * 32 + l31];
+                    float b[TN];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) b[j] = b_s[(kk + kh) * LDB_S + (wn * TN + j) * 32 + l31];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[j], acc[j], 0, 0, 0);
+                }
+            }
+            buf ^= 1;
+        }
+        // epilogue of this M-tile; the next tile's first A slice is already in flight
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int gn = (wn * TN + j) * 32 + l31;
+            const float bv = (bias && gn < N) ? bias[gn] : 0.0f;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int64_t gm = mt * BM + wm * 32 + (t & 3) + 8 * (t >> 2) + 4 * kh;
+                if (gn < N && gm < M) C[gm * ldc + gn] = apply_act(acc[j][t] + bv, gn < act_cols ? act : TFGX_ACT_NONE);
+                acc[j][t] = 0.0f;
+            }
+        }
+    }
+}
+
+template <int TN>
+int launch_gemm_stream(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, int act, float* C,
+                       int64_t ldc, int64_t M, int K, int N, int act_cols, hipStream_t stream)
+{
+    constexpr int LDB_S = 2 * TN * 32 + 4;
+    const int nk = (K + 15) / 16;
+    const size_t lds = sizeof(float) * (size_t(nk) * 16 * LDB_S + 2 * 16 * 129);
+    static int cus = 0;
+    static bool attr_set = false;
+    if (!attr_set) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        TFGX_HIP_CHECK(hipGetDevice(&dev));
+        TFGX_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+        cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        TFGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_stream_kernel<TN>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    const int64_t n_mtiles = (M + 127) / 128;
+    dim3 grid(static_cast<unsigned>(n_mtiles < cus ? n_mtiles : cus), 1, 1), block(512, 1, 1);
+    gemm_stream_kernel<TN><<<grid, block, lds, stream>>>(A, lda, B, ldb, bias, act, act_cols, C, ldc, M, K, N, n_mtiles);
+    TFGX_LAUNCH_CHECK("gemm_stream_kernel");
+    return TFGX_OK;
+}
+
+// the streaming kernel needs: 16-byte aligned A rows with K % 4 == 0, 64 < N <= 256, B + A buffers within 160 KB of LDS,
+// and enough M-tiles to keep a persistent grid busy
+inline bool stream_ok(const float* A, int64_t lda, int64_t M, int64_t K, int64_t N)
+{
+    if (N <= 64 || N > 256 || K % 4 != 0 || lda % 4 != 0 || !aligned_to(A, 16) || M < 128 * 256) return false;
+    const int tn = int((N + 63) / 64);
+    const size_t lds = sizeof(float) * (size_t((K + 15) / 16) * 16 * (2 * tn * 32 + 4) + 2 * 16 * 129);
+    return lds <= 160 * 1024;
+}
+
 template <int BM, int BN, int WM, int WN>
 int launch_gemm(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, int act, float* C,
                 int64_t ldc, int64_t M, int K, int N, int act_cols, hipStream_t stream)
@@ -208,6 +336,13 @@ extern "C" int tfgx_gemm_bias_act_cols_f32(const float* A, int64_t lda, const fl
     TFGX_REQUIRE(lda >= K && ldb >= N && ldc >= N, "leading dimension too small");
     hipStream_t stream = as_stream(stream_);
     const int ac = int(act_cols);
+    if (stream_ok(A, lda, M, K, N)) {
+        switch ((N + 63) / 64) {
+            case 2: return launch_gemm_stream<2>(A, lda, B, ldb, bias, act, C, ldc, M, int(K), int(N), ac, stream);
+            case 3: return launch_gemm_stream<3>(A, lda, B, ldb, bias, act, C, ldc, M, int(K), int(N), ac, stream);
+            default: return launch_gemm_stream<4>(A, lda, B, ldb, bias, act, C, ldc, M, int(K), int(N), ac, stream);
+        }
+    }
     if (N <= 32) return launch_gemm<256, 32, 64, 32>(A, lda, B, ldb, bias, act, C, ldc, M, int(K), int(N), ac, stream);
     if (N <= 64) return launch_gemm<128, 64, 32, 64>(A, lda, B, ldb, bias, act, C, ldc, M, int(K), int(N), ac, stream);
     return launch_gemm<128, 128, 64, 64>(A, lda, B, ldb, bias, act, C, ldc, M, int(K), int(N), ac, stream);
