@@ -147,19 +147,34 @@ __global__ __launch_bounds__(kBlock) void gemm_kernel(const float* __restrict__ 
         __syncthreads();
     }
 
-    // epilogue: D layout col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    // epilogue: D layout col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+    // Two phases on purpose: bias + activation are applied IN PLACE first, then every store reads its own accumulator
+    // register.  Computing each result into a temporary right before its store makes all 64 stores share one data
+    // register, and the compiler then drains vmcnt(0) between consecutive stores (write-after-read on the register of
+    // an in-flight store): 64 fully serialised round trips per tile.
     const int l31 = lane & 31, lh = lane >> 5;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int gn = n0 + wn * WN + j * 32 + l31;
+        const float bv = (bias && gn < N) ? bias[gn] : 0.0f;
+        const int a_j = gn < act_cols ? act : TFGX_ACT_NONE;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) acc[i][j][t] = apply_act(acc[i][j][t] + bv, a_j);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int gn = n0 + wn * WN + j * 32 + l31;
         if (gn >= N) continue;
-        const float bv = bias ? bias[gn] : 0.0f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            float* cp = C + (m0 + wm * WM + i * 32 + 4 * lh) * ldc + gn;
+            const int64_t rows_left = M - (m0 + wm * WM + i * 32 + 4 * lh);
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
-                const int64_t gm = m0 + wm * WM + i * 32 + (t & 3) + 8 * (t >> 2) + 4 * lh;
-                if (gm < M) C[gm * ldc + gn] = apply_act(acc[i][j][t] + bv, gn < act_cols ? act : TFGX_ACT_NONE);
+                const int dr = (t & 3) + 8 * (t >> 2);
+                if (dr < rows_left) cp[int64_t(dr) * ldc] = acc[i][j][t];
             }
         }
     }
@@ -242,18 +257,33 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const float* __restric
             }
             buf ^= 1;
         }
-        // epilogue of this M-tile; the next tile's first A slice is already in flight
+        // epilogue of this M-tile; the next tile's first A slice is already in flight.  Bias + activation in place
+        // first, then stores straight from the accumulator registers (see gemm_kernel's epilogue note).
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int gn = (wn * TN + j) * 32 + l31;
             const float bv = (bias && gn < N) ? bias[gn] : 0.0f;
+            const int a_j = gn < act_cols ? act : TFGX_ACT_NONE;
 #pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const int64_t gm = mt * BM + wm * 32 + (t & 3) + 8 * (t >> 2) + 4 * kh;
-                if (gn < N && gm < M) C[gm * ldc + gn] = apply_act(acc[j][t] + bv, gn < act_cols ? act : TFGX_ACT_NONE);
-                acc[j][t] = 0.0f;
+            for (int t = 0; t < 16; ++t) acc[j][t] = apply_act(acc[j][t] + bv, a_j);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int gn = (wn * TN + j) * 32 + l31;
+            if (gn < N) {
+                float* cp = C + (mt * BM + wm * 32 + 4 * kh) * ldc + gn;
+                const int64_t rows_left = M - (mt * BM + wm * 32 + 4 * kh);
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const int dr = (t & 3) + 8 * (t >> 2);
+                    if (dr < rows_left) cp[int64_t(dr) * ldc] = acc[j][t];
+                }
             }
         }
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) acc[j][t] = 0.0f;
     }
 }
 
