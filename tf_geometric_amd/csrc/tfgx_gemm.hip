@@ -181,146 +181,221 @@ __global__ __launch_bounds__(kBlock) void gemm_kernel(const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Streaming variant for the shape this library actually meets: M = nodes (10^5..10^8), K and N = feature widths
-// with K*N small enough that the WHOLE weight matrix lives in LDS (160 KB per CU).  One 512-thread workgroup per CU
-// (8 waves: 4 along M x 2 along N, two waves per SIMD) is persistent: B is loaded into LDS once, then the workgroup
-// walks M-tiles of 128 rows; A streams through a double-buffered LDS tile (BK = 16) with ONE barrier per k-step and
-// the global loads of the next step (or of the next M-tile's first step) issued before the MFMAs of the current
-// one, so there is no per-tile prologue bubble.  Same arithmetic as gemm_kernel: k-ordered fp32 FMA chain.
-template <int TN>
-__global__ __launch_bounds__(512) void gemm_stream_kernel(const float* __restrict__ A, int64_t lda,
-                                                          const float* __restrict__ B, int64_t ldb,
-                                                          const float* __restrict__ bias, int act, int act_cols,
-                                                          float* __restrict__ C, int64_t ldc, int64_t M, int K, int N,
-                                                          int64_t n_mtiles)
+// Row-streaming variant for the shape this library actually meets: M = nodes (10^5..10^8), K and N = feature widths
+// with K*N small enough that the WHOLE weight matrix lives in LDS (160 KB per CU).
+//
+// One persistent 512-thread workgroup per CU loads B into LDS once; after that single barrier the 8 waves never
+// synchronise again.  Each wave owns 32-row x N output tiles (TN = ceil(N/32) accumulators) and reads its A rows
+// straight from global memory INTO THE MFMA OPERAND LAYOUT: v_mfma_f32_32x32x2_f32 pairs any two k's as long as A and
+// B agree, so lane (m = lane & 31, kh = lane >> 5) loads the 64 contiguous bytes A[m][k0 + 16 kh .. + 15] (4 x
+// dwordx4) and the i-th MFMA of the step multiplies k = k0 + 16 kh + i against B row k0 + 16 kh + i from LDS.  A never
+// touches LDS, there is no transposition and no per-k-step barrier; the next step's A registers are loaded before
+// the current step's 16 x TN MFMAs, B operands are double-buffered in registers one MFMA group ahead, and because
+// waves drift apart the store epilogue of one wave overlaps the MFMAs of the other wave on its SIMD.
+// Arithmetic: fp32 FMA chain per output element in the k order above (a permutation of 0..K-1).
+// NG consecutive MFMA groups of gemm_rows_kernel (one group = one k pair x TN accumulators; a full step is 16 groups),
+// B operands read from LDS one group ahead.  The sched_barriers pin that order: left alone, the scheduler sinks every
+// ds_read next to its MFMA (fewest live registers), which puts a full LDS round trip in front of each group.
+template <int TN, int NG>
+__device__ __forceinline__ void rows_mfma_groups(f32x16 (&acc)[TN], const float* a, const float* b_s)
 {
-    constexpr int BM = 128, SBK = 16, LDA_S = BM + 1;
-    constexpr int LDB_S = 2 * TN * 32 + 4;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int nk = (K + SBK - 1) / SBK;
-    float* Bs = smem;                         // [nk*SBK][LDB_S], zero padded
-    float* As = smem + nk * SBK * LDB_S;      // [2][SBK][LDA_S]
+    constexpr int LDB_S = TN * 32 + 8;
+    float bb[2][TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bb[0][j] = b_s[j * 32];
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+        if (i + 1 < NG) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bb[(i + 1) & 1][j] = b_s[(i + 1) * LDB_S + j * 32];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[i & 1][j], acc[j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int TN>
+__global__ __launch_bounds__(512) void gemm_rows_kernel(const float* __restrict__ A, int64_t lda,
+                                                        const float* __restrict__ B, int64_t ldb,
+                                                        const float* __restrict__ bias, int act, int act_cols,
+                                                        float* __restrict__ C, int64_t ldc, int64_t M, int K, int N,
+                                                        int64_t n_tiles, int b_vec4)
+{
+    constexpr int LDB_S = TN * 32 + 8;   // (4 * LDB_S) % 64 == 32: the two half-waves hit disjoint banks
+    constexpr int NQ = LDB_S / 4;
+    extern __shared__ __attribute__((aligned(16))) float Bs[];   // [K + 16][LDB_S], zero padded
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
-    const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, kh = lane >> 5;
 
-    for (int idx = tid; idx < nk * SBK * LDB_S; idx += 512) {
-        const int k = idx / LDB_S, n = idx - k * LDB_S;
-        Bs[idx] = (k < K && n < N) ? B[int64_t(k) * ldb + n] : 0.0f;
-    }
-
-    const int arow = tid >> 2, akq = (tid & 3) * 4;   // one float4 of the 128 x 16 A tile per thread
-    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto load_a = [&](int64_t mt, int k0) {
-        const int64_t gm = mt * BM + arow;
-        const int gk = k0 + akq;
-        ra = (gm < M && gk < K) ? *reinterpret_cast<const float4*>(A + gm * lda + gk) : make_float4(0.f, 0.f, 0.f, 0.f);
-    };
-    auto store_a = [&](int buf) {
-        float* a = As + buf * SBK * LDA_S;
-        a[(akq + 0) * LDA_S + arow] = ra.x;
-        a[(akq + 1) * LDA_S + arow] = ra.y;
-        a[(akq + 2) * LDA_S + arow] = ra.z;
-        a[(akq + 3) * LDA_S + arow] = ra.w;
-    };
-
-    f32x16 acc[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int t = 0; t < 16; ++t) acc[j][t] = 0.0f;
-
-    int64_t mt = blockIdx.x;
-    if (mt < n_mtiles) load_a(mt, 0);
-    int buf = 0;
-    for (; mt < n_mtiles; mt += gridDim.x) {
-        for (int kt = 0; kt < nk; ++kt) {
-            store_a(buf);
-            __syncthreads();
-            if (kt + 1 < nk) load_a(mt, (kt + 1) * SBK);
-            else if (mt + gridDim.x < n_mtiles) load_a(mt + gridDim.x, 0);
-            const float* a_s = As + buf * SBK * LDA_S;
-            const float* b_s = Bs + kt * SBK * LDB_S;
-            const int kmax = min(SBK, K - kt * SBK);
-#pragma unroll
-            for (int kk = 0; kk < SBK; kk += 2) {
-                if (kk < kmax) {
-                    const float a = a_s[(kk + kh) * LDA_S + wm * 32 + l31];
-                    float b[TN];
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) b[j] = b_s[(kk + kh) * LDB_S + (wn * TN + j) * 32 + l31];
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[j], acc[j], 0, 0, 0);
-                }
+    const int krows = K + 16;   // kh = 1 lanes of a partially valid tail group read up to row K + 15
+    for (int f = tid; f < krows * NQ; f += 512) {
+        const int k = f / NQ, n4 = (f - k * NQ) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < K) {
+            const float* p = B + int64_t(k) * ldb + n4;
+            if (b_vec4 && n4 + 3 < N) {
+                v = *reinterpret_cast<const float4*>(p);
+            } else {
+                if (n4 < N) v.x = p[0];
+                if (n4 + 1 < N) v.y = p[1];
+                if (n4 + 2 < N) v.z = p[2];
+                if (n4 + 3 < N) v.w = p[3];
             }
-            buf ^= 1;
         }
-        // epilogue of this M-tile; the next tile's first A slice is already in flight.  Bias + activation in place
-        // first, then stores straight from the accumulator registers (see gemm_kernel's epilogue note).
+        *reinterpret_cast<float4*>(&Bs[k * LDB_S + n4]) = v;
+    }
+    __syncthreads();
+
+    const int nfull = K / 32;                 // steps of 32 k's with every operand valid
+    const int nsteps = (K + 31) / 32;
+    const int64_t stride = int64_t(gridDim.x) * 8;
+
+    // Unconditional loads from clamped addresses (row <= M - 1, k <= K - 4): with no branch around a load the compiler
+    // knows how many are in flight and waits with vmcnt(4) for the current step's registers while the next step's stay
+    // outstanding (a predicated load forces vmcnt(0), which serialises the prefetch).  Rows >= M compute values that
+    // are never stored; k >= K only occurs in the tail step, which zeroes those operands itself.
+    float cur[16], nxt[16];
+    auto load_a = [&](float (&r)[16], int64_t t, int ks) {
+        const int64_t gm = min(t * 32 + l31, M - 1);
+        const int kb = ks * 32 + 16 * kh;
+        const float* p = A + gm * lda;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float4 v = *reinterpret_cast<const float4*>(p + min(kb + 4 * u, K - 4));
+            r[4 * u + 0] = v.x;
+            r[4 * u + 1] = v.y;
+            r[4 * u + 2] = v.z;
+            r[4 * u + 3] = v.w;
+        }
+    };
+
+    // zero_acc: the empty asm makes the zeroed accumulators opaque register values.  Without it the compiler treats
+    // them as constants, keeps a second, permanently zero accumulator set alive across the tile loop and writes the
+    // first MFMA of each tile into a different register set (twice the accumulator registers, spills at TN = 8).
+    f32x16 acc[TN];
+    auto zero_acc = [&]() {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int gn = (wn * TN + j) * 32 + l31;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) acc[j][t] = 0.0f;
+            asm volatile("" : "+v"(acc[j]));
+        }
+    };
+    zero_acc();
+    // branch-free on purpose (see load_a): past the last tile the row clamp turns this into a harmless re-read
+    auto prefetch = [&](int64_t t, int ks) {
+        const bool same = ks + 1 < nsteps;
+        load_a(nxt, same ? t : t + stride, same ? ks + 1 : 0);
+    };
+
+    int64_t tile = int64_t(blockIdx.x) * 8 + wave;
+    if (tile < n_tiles) load_a(cur, tile, 0);
+    // Consume the first A registers here so their wait sits in front of the loop.  Otherwise every step carries a
+    // "first iteration" vmcnt(7..4) wait; harmless in steady state (only 4 loads are in flight), but right after an
+    // epilogue the 16 * TN stores are in flight too and that wait stalls the wave until they have drained.
+#pragma unroll
+    for (int u = 0; u < 4; ++u) asm volatile("" ::"v"(cur[4 * u]));
+    for (; tile < n_tiles; tile += stride) {
+        for (int ks = 0; ks < nfull; ++ks) {
+            prefetch(tile, ks);
+            rows_mfma_groups<TN, 16>(acc, cur, Bs + (ks * 32 + 16 * kh) * LDB_S + l31);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) cur[i] = nxt[i];
+        }
+        if (nfull < nsteps) {
+            // tail step (K % 32 != 0), kept OUTSIDE the step loop (an if/else inside it makes the compiler carry a second
+            // accumulator set): groups of 4 k's, skipped wave-uniformly once even the kh = 0 half is past K; the kh = 1
+            // half may already be past K inside a group that runs, so its A operand is zeroed
+            prefetch(tile, nfull);
+            const float* b_s = Bs + (nfull * 32 + 16 * kh) * LDB_S + l31;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (nfull * 32 + 4 * u < K) {
+                    const bool hi_ok = nfull * 32 + 16 * kh + 4 * u < K;
+                    float a[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) a[t] = hi_ok ? cur[4 * u + t] : 0.0f;
+                    rows_mfma_groups<TN, 4>(acc, a, b_s + 4 * u * LDB_S);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) cur[i] = nxt[i];
+        }
+        // epilogue (D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)); bias + activation in
+        // place first, then stores straight from the accumulator registers (see gemm_kernel's epilogue note)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int gn = j * 32 + l31;
             const float bv = (bias && gn < N) ? bias[gn] : 0.0f;
             const int a_j = gn < act_cols ? act : TFGX_ACT_NONE;
 #pragma unroll
             for (int t = 0; t < 16; ++t) acc[j][t] = apply_act(acc[j][t] + bv, a_j);
         }
+        const int64_t r0 = tile * 32 + 4 * kh;
+        if (tile * 32 + 32 <= M) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int gn = (wn * TN + j) * 32 + l31;
-            if (gn < N) {
-                float* cp = C + (mt * BM + wm * 32 + 4 * kh) * ldc + gn;
-                const int64_t rows_left = M - (mt * BM + wm * 32 + 4 * kh);
+            for (int j = 0; j < TN; ++j) {
+                const int gn = j * 32 + l31;
+                if (gn < N) {
+                    float* cp = C + r0 * ldc + gn;
 #pragma unroll
-                for (int t = 0; t < 16; ++t) {
-                    const int dr = (t & 3) + 8 * (t >> 2);
-                    if (dr < rows_left) cp[int64_t(dr) * ldc] = acc[j][t];
+                    for (int t = 0; t < 16; ++t) cp[int64_t((t & 3) + 8 * (t >> 2)) * ldc] = acc[j][t];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int gn = j * 32 + l31;
+                if (gn < N) {
+                    float* cp = C + r0 * ldc + gn;
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) {
+                        const int dr = (t & 3) + 8 * (t >> 2);
+                        if (r0 + dr < M) cp[int64_t(dr) * ldc] = acc[j][t];
+                    }
                 }
             }
         }
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int t = 0; t < 16; ++t) acc[j][t] = 0.0f;
+        zero_acc();
     }
 }
 
+inline size_t rows_lds_bytes(int64_t K, int tn) { return sizeof(float) * size_t(K + 16) * size_t(tn * 32 + 8); }
+
 template <int TN>
-int launch_gemm_stream(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, int act, float* C,
-                       int64_t ldc, int64_t M, int K, int N, int act_cols, hipStream_t stream)
+int launch_gemm_rows(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, int act, float* C,
+                     int64_t ldc, int64_t M, int K, int N, int act_cols, hipStream_t stream)
 {
-    constexpr int LDB_S = 2 * TN * 32 + 4;
-    const int nk = (K + 15) / 16;
-    const size_t lds = sizeof(float) * (size_t(nk) * 16 * LDB_S + 2 * 16 * 129);
     static int cus = 0;
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (cus == 0) {
         int dev = 0;
         hipDeviceProp_t prop;
         TFGX_HIP_CHECK(hipGetDevice(&dev));
         TFGX_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-        cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        TFGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_stream_kernel<TN>),
+        TFGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_rows_kernel<TN>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+        cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    const int64_t n_mtiles = (M + 127) / 128;
-    dim3 grid(static_cast<unsigned>(n_mtiles < cus ? n_mtiles : cus), 1, 1), block(512, 1, 1);
-    gemm_stream_kernel<TN><<<grid, block, lds, stream>>>(A, lda, B, ldb, bias, act, act_cols, C, ldc, M, K, N, n_mtiles);
-    TFGX_LAUNCH_CHECK("gemm_stream_kernel");
+    const int64_t n_tiles = (M + 31) / 32;
+    const int64_t wgs = (n_tiles + 7) / 8;
+    const int b_vec4 = (ldb % 4 == 0) && aligned_to(B, 16);
+    dim3 grid(static_cast<unsigned>(wgs < cus ? wgs : cus), 1, 1), block(512, 1, 1);
+    gemm_rows_kernel<TN><<<grid, block, rows_lds_bytes(K, TN), stream>>>(A, lda, B, ldb, bias, act, act_cols, C, ldc, M, K,
+                                                                         N, n_tiles, b_vec4);
+    TFGX_LAUNCH_CHECK("gemm_rows_kernel");
     return TFGX_OK;
 }
 
-// the streaming kernel needs: 16-byte aligned A rows with K % 4 == 0, 64 < N <= 256, B + A buffers within 160 KB of LDS,
-// and enough M-tiles to keep a persistent grid busy
-inline bool stream_ok(const float* A, int64_t lda, int64_t M, int64_t K, int64_t N)
+// the row-streaming kernel needs 16-byte aligned A rows with K % 4 == 0, 64 < N <= 256, all of B within 160 KB of LDS,
+// and enough 32-row tiles to keep 8 waves on every CU busy for many tiles
+inline bool rows_ok(const float* A, int64_t lda, int64_t M, int64_t K, int64_t N)
 {
-    if (N <= 64 || N > 256 || K % 4 != 0 || lda % 4 != 0 || !aligned_to(A, 16) || M < 128 * 256) return false;
-    const int tn = int((N + 63) / 64);
-    const size_t lds = sizeof(float) * (size_t((K + 15) / 16) * 16 * (2 * tn * 32 + 4) + 2 * 16 * 129);
-    return lds <= 160 * 1024;
+    if (N <= 64 || N > 256 || K < 32 || K % 4 != 0 || lda % 4 != 0 || !aligned_to(A, 16) || M < 128 * 256) return false;
+    return rows_lds_bytes(K, int((N + 31) / 32)) <= 160 * 1024;
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -366,12 +441,18 @@ extern "C" int tfgx_gemm_bias_act_cols_f32(const float* A, int64_t lda, const fl
     TFGX_REQUIRE(lda >= K && ldb >= N && ldc >= N, "leading dimension too small");
     hipStream_t stream = as_stream(stream_);
     const int ac = int(act_cols);
-    if (stream_ok(A, lda, M, K, N)) {
-        switch ((N + 63) / 64) {
-            case 2: return launch_gemm_stream<2>(A, lda, B, ldb, bias, act, C, ldc, M, int(K), int(N), ac, stream);
-            case 3: return launch_gemm_stream<3>(A, lda, B, ldb, bias, act, C, ldc, M, int(K), int(N), ac, stream);
-            default: return launch_gemm_stream<4>(A, lda, B, ldb, bias, act, C, ldc, M, int(K), int(N), ac, stream);
+    if (rows_ok(A, lda, M, K, N)) {
+#define TFGX_ROWS_CASE(T) \
+    case T: return launch_gemm_rows<T>(A, lda, B, ldb, bias, act, C, ldc, M, int(K), int(N), ac, stream)
+        switch ((N + 31) / 32) {
+            TFGX_ROWS_CASE(3);
+            TFGX_ROWS_CASE(4);
+            TFGX_ROWS_CASE(5);
+            TFGX_ROWS_CASE(6);
+            TFGX_ROWS_CASE(7);
+            default: TFGX_ROWS_CASE(8);
         }
+#undef TFGX_ROWS_CASE
     }
     if (N <= 32) return launch_gemm<256, 32, 64, 32>(A, lda, B, ldb, bias, act, C, ldc, M, int(K), int(N), ac, stream);
     if (N <= 64) return launch_gemm<128, 64, 32, 64>(A, lda, B, ldb, bias, act, C, ldc, M, int(K), int(N), ac, stream);
