@@ -53,28 +53,43 @@ __global__ __launch_bounds__(kBlock) void gemm_kernel(const float* __restrict__ 
 #pragma unroll
             for (int t = 0; t < 16; ++t) acc[i][j][t] = 0.0f;
 
-    float4 ra[A_LOADS], rb[B_LOADS];
+    float ra[A_LOADS * 4];
+    float4 rb[B_LOADS];
 
     auto load_tiles = [&](int k0) {
+        if (AV4) {
 #pragma unroll
-        for (int i = 0; i < A_LOADS; ++i) {
-            const int f = tid + i * kBlock;          // float4 index inside the BM x BK tile
-            const int row = f / (BK / 4), kq = (f % (BK / 4)) * 4;
-            const int64_t gm = m0 + row;
-            const int gk = k0 + kq;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gm < M) {
-                const float* p = A + gm * lda + gk;
-                if (AV4 && gk + 3 < K) {
-                    v = *reinterpret_cast<const float4*>(p);
-                } else {
-                    if (gk < K) v.x = p[0];
-                    if (gk + 1 < K) v.y = p[1];
-                    if (gk + 2 < K) v.z = p[2];
-                    if (gk + 3 < K) v.w = p[3];
+            for (int i = 0; i < A_LOADS; ++i) {
+                const int f = tid + i * kBlock;          // float4 index inside the BM x BK tile
+                const int row = f / (BK / 4), kq = (f % (BK / 4)) * 4;
+                const int64_t gm = m0 + row;
+                const int gk = k0 + kq;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (gm < M) {
+                    const float* p = A + gm * lda + gk;
+                    if (gk + 3 < K) {
+                        v = *reinterpret_cast<const float4*>(p);
+                    } else {
+                        if (gk < K) v.x = p[0];
+                        if (gk + 1 < K) v.y = p[1];
+                        if (gk + 2 < K) v.z = p[2];
+                    }
                 }
+                ra[4 * i + 0] = v.x;
+                ra[4 * i + 1] = v.y;
+                ra[4 * i + 2] = v.z;
+                ra[4 * i + 3] = v.w;
             }
-            ra[i] = v;
+        } else {
+            // rows that are not 16-byte aligned (K = 1433, 3703 ...): dword loads, 16 consecutive lanes on 16 consecutive
+            // k of one row, so one instruction touches 4 rows x 64 contiguous bytes
+#pragma unroll
+            for (int j = 0; j < A_LOADS * 4; ++j) {
+                const int e = tid + j * kBlock;
+                const int64_t gm = m0 + e / BK;
+                const int gk = k0 + e % BK;
+                ra[j] = (gm < M && gk < K) ? A[gm * lda + gk] : 0.0f;
+            }
         }
 #pragma unroll
         for (int i = 0; i < B_LOADS; ++i) {
@@ -100,14 +115,20 @@ __global__ __launch_bounds__(kBlock) void gemm_kernel(const float* __restrict__ 
     };
 
     auto store_tiles = [&]() {
+        if (AV4) {
 #pragma unroll
-        for (int i = 0; i < A_LOADS; ++i) {
-            const int f = tid + i * kBlock;
-            const int row = f / (BK / 4), kq = (f % (BK / 4)) * 4;
-            As[(kq + 0) * LDA_S + row] = ra[i].x;
-            As[(kq + 1) * LDA_S + row] = ra[i].y;
-            As[(kq + 2) * LDA_S + row] = ra[i].z;
-            As[(kq + 3) * LDA_S + row] = ra[i].w;
+            for (int i = 0; i < A_LOADS; ++i) {
+                const int f = tid + i * kBlock;
+                const int row = f / (BK / 4), kq = (f % (BK / 4)) * 4;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) As[(kq + c) * LDA_S + row] = ra[4 * i + c];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < A_LOADS * 4; ++j) {
+                const int e = tid + j * kBlock;
+                As[(e % BK) * LDA_S + e / BK] = ra[j];
+            }
         }
 #pragma unroll
         for (int i = 0; i < B_LOADS; ++i) {
@@ -187,8 +208,8 @@ __global__ __launch_bounds__(kBlock) void gemm_kernel(const float* __restrict__ 
 // One persistent 512-thread workgroup per CU loads B into LDS once; after that single barrier the 8 waves never
 // synchronise again.  Each wave owns 32-row x N output tiles (TN = ceil(N/32) accumulators) and reads its A rows
 // straight from global memory INTO THE MFMA OPERAND LAYOUT: v_mfma_f32_32x32x2_f32 pairs any two k's as long as A and
-// B agree, so lane (m = lane & 31, kh = lane >> 5) loads the 64 contiguous bytes A[m][k0 + 16 kh .. + 15] (4 x
-// dwordx4) and the i-th MFMA of the step multiplies k = k0 + 16 kh + i against B row k0 + 16 kh + i from LDS.  A never
+// B agree, so lane (m = lane & 31, kh = lane >> 5) loads the 64 contiguous bytes A[m][k0 + 16 kh .. + 15]
+// and the i-th MFMA of the step multiplies k = k0 + 16 kh + i against B row k0 + 16 kh + i from LDS.  A never
 // touches LDS, there is no transposition and no per-k-step barrier; the next step's A registers are loaded before
 // the current step's 16 x TN MFMAs, B operands are double-buffered in registers one MFMA group ahead, and because
 // waves drift apart the store epilogue of one wave overlaps the MFMAs of the other wave on its SIMD.
@@ -216,8 +237,13 @@ __device__ __forceinline__ void rows_mfma_groups(f32x16 (&acc)[TN], const float*
     }
 }
 
+// threads per workgroup: 8 waves, 2 per SIMD, <= 256 registers each (TN = 8 needs 218).  12 waves for the TN <= 4
+// kernels (< 170 registers) measured 2 % slower than 8.
 template <int TN>
-__global__ __launch_bounds__(512) void gemm_rows_kernel(const float* __restrict__ A, int64_t lda,
+constexpr int rows_threads() { return 512; }
+
+template <int TN>
+__global__ __launch_bounds__(rows_threads<TN>()) void gemm_rows_kernel(const float* __restrict__ A, int64_t lda,
                                                         const float* __restrict__ B, int64_t ldb,
                                                         const float* __restrict__ bias, int act, int act_cols,
                                                         float* __restrict__ C, int64_t ldc, int64_t M, int K, int N,
@@ -225,14 +251,14 @@ __global__ __launch_bounds__(512) void gemm_rows_kernel(const float* __restrict_
 {
     constexpr int LDB_S = TN * 32 + 8;   // (4 * LDB_S) % 64 == 32: the two half-waves hit disjoint banks
     constexpr int NQ = LDB_S / 4;
-    extern __shared__ __attribute__((aligned(16))) float Bs[];   // [K + 16][LDB_S], zero padded
+    extern __shared__ __attribute__((aligned(16))) float Bs[];   // [K][LDB_S], columns >= N zero
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int l31 = lane & 31, kh = lane >> 5;
 
-    const int krows = K + 16;   // kh = 1 lanes of a partially valid tail group read up to row K + 15
-    for (int f = tid; f < krows * NQ; f += 512) {
+    constexpr int NT = rows_threads<TN>();
+    for (int f = tid; f < K * NQ; f += NT) {
         const int k = f / NQ, n4 = (f - k * NQ) * 4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (k < K) {
@@ -252,24 +278,30 @@ __global__ __launch_bounds__(512) void gemm_rows_kernel(const float* __restrict_
 
     const int nfull = K / 32;                 // steps of 32 k's with every operand valid
     const int nsteps = (K + 31) / 32;
-    const int64_t stride = int64_t(gridDim.x) * 8;
+    const int64_t stride = int64_t(gridDim.x) * (NT / 64);
 
-    // Unconditional loads from clamped addresses (row <= M - 1, k <= K - 4): with no branch around a load the compiler
-    // knows how many are in flight and waits with vmcnt(4) for the current step's registers while the next step's stay
-    // outstanding (a predicated load forces vmcnt(0), which serialises the prefetch).  Rows >= M compute values that
-    // are never stored; k >= K only occurs in the tail step, which zeroes those operands itself.
+    // Per step a lane holds 16 consecutive k's of its row (4 dwordx4 loads).  Full step ks: k = 32 ks + 16 kh + i.
+    // Tail step (T = K % 32 left, a multiple of 4): the two half-waves split it evenly, k = 32 nfull + kh T/2 + i for
+    // i < T/2, so a tail costs T/2 fully used MFMA groups; T/2 may be only 8-byte aligned, hence the aligned(8) vector
+    // type (global_load_dwordx4 itself has no 16-byte requirement).
+    // Loads are unconditional from clamped addresses (row <= M - 1, k <= K - 4): with no branch around a load the
+    // compiler knows how many are in flight and the next step's loads stay outstanding while the current step's
+    // registers are used (a predicated load forces vmcnt(0), which serialises the prefetch).  Rows >= M compute
+    // values that are never stored; the tail step accounts for its own clamped vector.
+    typedef float f32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
+    const int half_t = (K - nfull * 32) >> 1;
     float cur[16], nxt[16];
     auto load_a = [&](float (&r)[16], int64_t t, int ks) {
         const int64_t gm = min(t * 32 + l31, M - 1);
-        const int kb = ks * 32 + 16 * kh;
+        const int kb = ks * 32 + (ks < nfull ? 16 : half_t) * kh;
         const float* p = A + gm * lda;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const float4 v = *reinterpret_cast<const float4*>(p + min(kb + 4 * u, K - 4));
-            r[4 * u + 0] = v.x;
-            r[4 * u + 1] = v.y;
-            r[4 * u + 2] = v.z;
-            r[4 * u + 3] = v.w;
+            const f32x4_a8 v = *reinterpret_cast<const f32x4_a8*>(p + min(kb + 4 * u, K - 4));
+            r[4 * u + 0] = v[0];
+            r[4 * u + 1] = v[1];
+            r[4 * u + 2] = v[2];
+            r[4 * u + 3] = v[3];
         }
     };
 
@@ -292,10 +324,14 @@ __global__ __launch_bounds__(512) void gemm_rows_kernel(const float* __restrict_
         load_a(nxt, same ? t : t + stride, same ? ks + 1 : 0);
     };
 
-    int64_t tile = int64_t(blockIdx.x) * 8 + wave;
+    float bv[TN];   // this lane's bias values, loaded once (a per-tile load would put a memory round trip in every epilogue)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bv[j] = (bias && j * 32 + l31 < N) ? bias[j * 32 + l31] : 0.0f;
+
+    int64_t tile = int64_t(blockIdx.x) * (NT / 64) + wave;
     if (tile < n_tiles) load_a(cur, tile, 0);
     // Consume the first A registers here so their wait sits in front of the loop.  Otherwise every step carries a
-    // "first iteration" vmcnt(7..4) wait; harmless in steady state (only 4 loads are in flight), but right after an
+    // "first iteration" vmcnt wait; harmless in steady state (only the 4 prefetch loads are in flight), but right after an
     // epilogue the 16 * TN stores are in flight too and that wait stalls the wave until they have drained.
 #pragma unroll
     for (int u = 0; u < 4; ++u) asm volatile("" ::"v"(cur[4 * u]));
@@ -308,18 +344,20 @@ __global__ __launch_bounds__(512) void gemm_rows_kernel(const float* __restrict_
         }
         if (nfull < nsteps) {
             // tail step (K % 32 != 0), kept OUTSIDE the step loop (an if/else inside it makes the compiler carry a second
-            // accumulator set): groups of 4 k's, skipped wave-uniformly once even the kh = 0 half is past K; the kh = 1
-            // half may already be past K inside a group that runs, so its A operand is zeroed
+            // accumulator set): half_t groups in pairs, skipped wave-uniformly past the end
             prefetch(tile, nfull);
-            const float* b_s = Bs + (nfull * 32 + 16 * kh) * LDB_S + l31;
+            const float* b_s = Bs + (nfull * 32 + half_t * kh) * LDB_S + l31;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (nfull * 32 + 4 * u < K) {
-                    const bool hi_ok = nfull * 32 + 16 * kh + 4 * u < K;
-                    float a[4];
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) a[t] = hi_ok ? cur[4 * u + t] : 0.0f;
-                    rows_mfma_groups<TN, 4>(acc, a, b_s + 4 * u * LDB_S);
+            for (int q = 0; q < 7; ++q) {
+                if (2 * q < half_t) {
+                    // When T/2 % 4 == 2 the kh = 1 half's last vector would start at K - 2; load_a clamped it to K - 4,
+                    // so the two values it needs sit in elements 2, 3 instead of 0, 1.
+                    float a[2] = {cur[2 * q], cur[2 * q + 1]};
+                    if (q % 2 == 0 && kh == 1 && 2 * q + 2 == half_t) {
+                        a[0] = cur[2 * q + 2];
+                        a[1] = cur[2 * q + 3];
+                    }
+                    rows_mfma_groups<TN, 2>(acc, a, b_s + 2 * q * LDB_S);
                 }
             }
 #pragma unroll
@@ -329,11 +367,9 @@ __global__ __launch_bounds__(512) void gemm_rows_kernel(const float* __restrict_
         // place first, then stores straight from the accumulator registers (see gemm_kernel's epilogue note)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int gn = j * 32 + l31;
-            const float bv = (bias && gn < N) ? bias[gn] : 0.0f;
-            const int a_j = gn < act_cols ? act : TFGX_ACT_NONE;
+            const int a_j = j * 32 + l31 < act_cols ? act : TFGX_ACT_NONE;
 #pragma unroll
-            for (int t = 0; t < 16; ++t) acc[j][t] = apply_act(acc[j][t] + bv, a_j);
+            for (int t = 0; t < 16; ++t) acc[j][t] = apply_act(acc[j][t] + bv[j], a_j);
         }
         const int64_t r0 = tile * 32 + 4 * kh;
         if (tile * 32 + 32 <= M) {
@@ -364,7 +400,7 @@ __global__ __launch_bounds__(512) void gemm_rows_kernel(const float* __restrict_
     }
 }
 
-inline size_t rows_lds_bytes(int64_t K, int tn) { return sizeof(float) * size_t(K + 16) * size_t(tn * 32 + 8); }
+inline size_t rows_lds_bytes(int64_t K, int tn) { return sizeof(float) * size_t(K) * size_t(tn * 32 + 8); }
 
 template <int TN>
 int launch_gemm_rows(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, int act, float* C,
@@ -381,9 +417,10 @@ int launch_gemm_rows(const float* A, int64_t lda, const float* B, int64_t ldb, c
         cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     const int64_t n_tiles = (M + 31) / 32;
-    const int64_t wgs = (n_tiles + 7) / 8;
+    constexpr int kWaves = rows_threads<TN>() / 64;
+    const int64_t wgs = (n_tiles + kWaves - 1) / kWaves;
     const int b_vec4 = (ldb % 4 == 0) && aligned_to(B, 16);
-    dim3 grid(static_cast<unsigned>(wgs < cus ? wgs : cus), 1, 1), block(512, 1, 1);
+    dim3 grid(static_cast<unsigned>(wgs < cus ? wgs : cus), 1, 1), block(rows_threads<TN>(), 1, 1);
     gemm_rows_kernel<TN><<<grid, block, rows_lds_bytes(K, TN), stream>>>(A, lda, B, ldb, bias, act, act_cols, C, ldc, M, K,
                                                                          N, n_tiles, b_vec4);
     TFGX_LAUNCH_CHECK("gemm_rows_kernel");
