@@ -282,6 +282,17 @@ int tfgx_sample_neighbors(const int32_t* row_ptr, const int32_t* col, const floa
                           const int32_t* out_ptr, int32_t max_per_row, int32_t replace_when_short, uint64_t seed,
                           int32_t* out_col, float* out_w /* or NULL */, tfgx_stream_t stream);
 
+/* Segmented top-k (topk_pool, tf_geometric/nn/pool/topk_pool.py:6-87): for every segment id s in [0, num_segments)
+   keep the node_k(s) highest-scored of its count(s) items, node_k = min(k, count) when k >= 0, otherwise
+   min(count, ceil(float32(count) * ratio)).  out_index[0 .. *out_count) receives the kept items' positions in the
+   caller's arrays, ordered as the reference returns them: segments ascending, scores descending, equal scores in the
+   caller's order (-0.0 == +0.0).  out_index must hold n entries; out_count is one device int32.  Segment ids outside
+   [0, num_segments) -> TFGX_ERR_INDEX.  Synchronises the stream once (id validation). */
+size_t tfgx_segment_topk_workspace_bytes(int64_t n, int64_t num_segments);
+int tfgx_segment_topk(const int32_t* segment, const float* score, int64_t n, int64_t num_segments, int32_t k,
+                      float ratio, int32_t* out_index, int32_t* out_count, void* workspace, size_t workspace_bytes,
+                      tfgx_stream_t stream);
+
 /* x[n, F] -> x_main[n, f_main] + x_tail[n, F - f_main] in one pass (the split source layout of tfgx_reduce_args) */
 int tfgx_split_rows_f32(const float* x, int64_t ldx, int64_t n, int64_t F, int64_t f_main, float* x_main,
                         int64_t ld_main, float* x_tail, int64_t ld_tail, tfgx_stream_t stream);

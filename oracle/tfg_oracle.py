@@ -561,3 +561,45 @@ def chebynet(x, edge_index, edge_weight, k, kernels, bias=None, activation=None,
     if bias is not None:
         out = out + np.asarray(bias, np.float32)
     return _act(activation, out).astype(np.float32)
+
+
+# ----------------------------------------------------------------------------
+# pooling: top-k selection
+# ----------------------------------------------------------------------------
+
+def topk_pool(source_index, score, k=None, ratio=None):
+    """nn/pool/topk_pool.py:6-87, step by step (dense padded score matrix, row-wise argsort, mask).
+    tf.argsort is top_k underneath, so both sorts are stable with the lower index first on ties; a ratio whose
+    node_k exceeds a source's count would select the reference's padding columns — restated as "keep all"."""
+    if k is None and ratio is None:
+        raise Exception("you should provide either k or ratio for topk_pool")
+    elif k is not None and ratio is not None:
+        raise Exception("you should provide either k or ratio for topk_pool, not both of them")
+    source_index = np.asarray(source_index, dtype=np.int64).reshape(-1)
+    score = np.asarray(score, dtype=np.float32).reshape(-1)
+    if source_index.shape[0] == 0:
+        return np.zeros(0, dtype=np.int32)
+    perm = np.argsort(source_index, kind="stable")                               # :31
+    sorted_source = source_index[perm]
+    sorted_score = score[perm]
+    num_targets = sorted_source.shape[0]
+    counts = np.bincount(sorted_source)                                          # :38-39 segment_sum of ones
+    num_cols = int(counts.max())
+    num_seen = counts.shape[0]
+    min_score = sorted_score.min()
+    before = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.int64)      # :48-51
+    target_in_source = np.arange(num_targets) - before[sorted_source]            # :53
+    score_matrix = np.full((num_seen, num_cols), min_score - np.float32(1.0), dtype=np.float32)   # :55
+    score_matrix[sorted_source, target_in_source] = sorted_score                 # :56-57
+    sort_index = np.argsort(-score_matrix, axis=-1, kind="stable")               # :59 DESCENDING
+    if k is not None:
+        node_k = np.minimum(k, counts)                                           # :62-65
+    else:
+        node_k = np.ceil(counts.astype(np.float32) * np.float32(ratio)).astype(np.int64)   # :67-70
+        node_k = np.minimum(node_k, counts)
+    out = []
+    for s in range(num_seen):                                                    # :73-84 meshgrid + mask, row-major
+        cols = sort_index[s, :node_k[s]]
+        out.append(before[s] + cols)
+    topk_index = np.concatenate(out) if out else np.zeros(0, np.int64)
+    return perm[topk_index].astype(np.int32)                                     # :89

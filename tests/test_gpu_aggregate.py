@@ -260,6 +260,46 @@ def test_graph_readout_pools(tfg, oracle):
     assert tfg.nn.max_pool(x, gid).shape[0] == int(gid.max()) + 1
 
 
+@pytest.mark.parametrize("n,num_src,kw", [(5000, 97, dict(k=3)), (5000, 97, dict(ratio=0.3)), (20000, 3, dict(k=50)),
+                                          (300, 400, dict(ratio=1.0)), (1, 1, dict(k=1)), (777, 50, dict(k=0)),
+                                          (4000, 60, dict(ratio=2.5)), (200000, 5000, dict(ratio=0.5))])
+def test_topk_pool(tfg, oracle, n, num_src, kw):
+    """nn/pool/topk_pool.py:6-87: bit-exact index lists — unsorted sources, gaps in the ids, heavy ties (quantised
+    scores, +-0.0), k = 0, ratio beyond 1."""
+    rng = np.random.Generator(np.random.PCG64(n + num_src))
+    src = rng.integers(0, num_src, size=n).astype(np.int32)
+    src[src == 7] = 8 if num_src > 8 else src[src == 7]            # a gap in the ids
+    score = np.round(rng.standard_normal(n).astype(np.float32) * 4) / 4   # many equal scores
+    score[rng.random(n) < 0.05] = -0.0
+    got = tfg.nn.topk_pool(src, score, **kw)
+    ref = oracle.topk_pool(src, score, **kw)
+    assert got.dtype == np.int32 and np.array_equal(got, ref)
+    import torch
+    got_t = tfg.nn.topk_pool(torch.from_numpy(src).cuda(), torch.from_numpy(score).cuda(), **kw)
+    assert got_t.is_cuda and np.array_equal(got_t.cpu().numpy(), ref)
+
+
+def test_topk_pool_errors(tfg):
+    src, score = np.zeros(4, np.int32), np.ones(4, np.float32)
+    with pytest.raises(Exception, match="either k or ratio"):
+        tfg.nn.topk_pool(src, score)
+    with pytest.raises(Exception, match="not both"):
+        tfg.nn.topk_pool(src, score, k=1, ratio=0.5)
+    assert tfg.nn.topk_pool(np.zeros(0, np.int32), np.zeros(0, np.float32), k=2).shape == (0,)
+    from tf_geometric_amd import _lib as L
+    import torch
+    lib = L.require_gpu()
+    seg = torch.tensor([0, 5, 1], dtype=torch.int32, device="cuda")      # id 5 outside [0, 3)
+    sc = torch.ones(3, device="cuda")
+    out, cnt = torch.empty(3, dtype=torch.int32, device="cuda"), torch.zeros(1, dtype=torch.int32, device="cuda")
+    nb = lib.tfgx_segment_topk_workspace_bytes(3, 3)
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    rc = lib.tfgx_segment_topk(L.ptr(seg), L.ptr(sc), 3, 3, 1, 0.0, L.ptr(out), L.ptr(cnt), L.ptr(ws), nb, L.stream_ptr())
+    assert rc == L.ERR_INDEX if hasattr(L, "ERR_INDEX") else rc != 0
+    rc = lib.tfgx_segment_topk(L.ptr(seg), L.ptr(sc), 3, 6, 1, 0.0, L.ptr(out), L.ptr(cnt), L.ptr(ws), 16, L.stream_ptr())
+    assert rc != 0 and b"workspace" in lib.tfgx_last_error()
+
+
 def test_random_neighbor_sampler(tfg, oracle):
     """Distributional parity with RandomNeighborSampler.sample (graph_utils.py:667-772): counts, subset, no repeats,
     order of rows, determinism per seed, and uniformity of the without-replacement draw."""

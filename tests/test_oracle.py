@@ -230,3 +230,19 @@ def test_golden_fixtures(oracle):
                                          normalize=True), g["sage_out"], tol=1e-6, what="golden sage")
     assert_parity(oracle.gat(x, ei, g["gat_wq"], g["gat_bq"], "relu", g["gat_wk"], g["gat_bk"], "relu", g["gat_wv"],
                              g["gat_b"], "relu", num_heads=4), g["gat_out"], tol=1e-6, what="golden gat")
+
+
+def test_topk_pool_known_answers(oracle):
+    """Hand-derived: source 0 holds items 1 (.5), 3 (.5), 6 (.7); source 2 holds 0 (.1), 2 (.9), 4 (.3); source 5 holds
+    5.  Sources ascending, scores descending, the lower position wins the .5 tie (nn/pool/topk_pool.py:59)."""
+    src = np.array([2, 0, 2, 0, 2, 5, 0])
+    sc = np.array([.1, .5, .9, .5, .3, .2, .7], dtype=np.float32)
+    assert oracle.topk_pool(src, sc, k=2).tolist() == [6, 1, 2, 4, 5]
+    assert oracle.topk_pool(src, sc, k=1).tolist() == [6, 2, 5]
+    assert oracle.topk_pool(src, sc, ratio=0.5).tolist() == [6, 1, 2, 4, 5]          # ceil(1.5) = 2, ceil(.5) = 1
+    assert oracle.topk_pool(src, sc, ratio=1.0).tolist() == [6, 1, 3, 2, 4, 0, 5]
+    assert oracle.topk_pool(src, sc, k=0).tolist() == []
+    with pytest.raises(Exception):
+        oracle.topk_pool(src, sc)
+    with pytest.raises(Exception):
+        oracle.topk_pool(src, sc, k=1, ratio=0.5)

@@ -91,6 +91,8 @@ SIGNATURES = {
     "tfgx_build_csr_by_dst": (ctypes.c_int, [_P, _P, _I64, _I64, _I64, _P, _P, _P, _P, _SZ, _P]),
     "tfgx_merge_edges_workspace_bytes": (_SZ, [_I64, _I64]),
     "tfgx_merge_duplicated_edges": (ctypes.c_int, [_P, _P, _I64, _I64, _P, _P, _P, _P, _P, _SZ, _P]),
+    "tfgx_segment_topk_workspace_bytes": (_SZ, [_I64, _I64]),
+    "tfgx_segment_topk": (ctypes.c_int, [_P, _P, _I64, _I64, _I32, _F32, _P, _P, _P, _SZ, _P]),
     "tfgx_permute_rows_f32": (ctypes.c_int, [_P, _P, _I64, _I64, _P, _P]),
     "tfgx_segment_reduce_f32": (ctypes.c_int, [ctypes.POINTER(ReduceArgs), _P]),
     "tfgx_segment_weight_sum_f32": (ctypes.c_int, [_P, _P, _I64, _F32, _P, _P]),

@@ -9,4 +9,4 @@ from .conv.gat import gat
 from .conv.graph_sage import (mean_graph_sage, sum_graph_sage, gcn_graph_sage, mean_pool_graph_sage,
                               max_pool_graph_sage)
 from .conv.propagation import gin, sgc, tagcn, appnp, ssgc, chebynet, le_conv, chebynet_norm_edge
-from .pool import mean_pool, sum_pool, max_pool, min_pool
+from .pool import mean_pool, sum_pool, max_pool, min_pool, topk_pool
