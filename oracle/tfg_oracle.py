@@ -603,3 +603,46 @@ def topk_pool(source_index, score, k=None, ratio=None):
         out.append(before[s] + cols)
     topk_index = np.concatenate(out) if out else np.zeros(0, np.int64)
     return perm[topk_index].astype(np.int32)                                     # :89
+
+
+def neighbor_lists(edge_index, edge_weight=None, sampled_node_index=None):
+    """The deterministic part of RandomNeighborSampler (utils/graph_utils.py:631-731): per sampled row, the list of
+    (virtual neighbour id, weight) the random draw chooses from, in the reference's order.  Returns
+    (virtual_row_ids, [ (neighbour ids, weights), ... ]) skipping rows without (kept) neighbours, as the loop does."""
+    edge_index = np.asarray(edge_index, dtype=np.int64)
+    w = np.ones(edge_index.shape[1], np.float32) if edge_weight is None else np.asarray(edge_weight, np.float32)
+    num_rows, num_cols = int(edge_index[0].max()) + 1, int(edge_index[1].max()) + 1
+    nbr = {}
+    for (a, b), ww in zip(edge_index.T, w):                                           # :645-655
+        nbr.setdefault(int(a), ([], []))
+        nbr[int(a)][0].append(int(b))
+        nbr[int(a)][1].append(ww)
+    if sampled_node_index is None:
+        rows = sorted(nbr.keys())                                                     # :662
+        virt = rows
+        col_map = None
+    else:
+        if isinstance(sampled_node_index, tuple):
+            rows, cols = sampled_node_index
+        else:
+            rows = cols = sampled_node_index
+        rows, cols = [int(r) for r in rows], [int(c) for c in cols]
+        virt = list(range(len(rows)))
+        col_map = -np.ones(num_cols, np.int64)                                        # :701-703
+        for i, c in enumerate(cols):
+            if c < num_cols:
+                col_map[c] = i
+    out_rows, out = [], []
+    for vi, r in zip(virt, rows):                                                     # :716-731
+        if r not in nbr:
+            continue
+        ids, ws = np.asarray(nbr[r][0]), np.asarray(nbr[r][1], np.float32)
+        if col_map is not None:
+            v = col_map[ids]
+            m = v >= 0
+            ids, ws = v[m], ws[m]
+            if len(ids) == 0:
+                continue
+        out_rows.append(vi)
+        out.append((ids, ws))
+    return out_rows, out

@@ -260,6 +260,41 @@ def test_graph_readout_pools(tfg, oracle):
     assert tfg.nn.max_pool(x, gid).shape[0] == int(gid.max()) + 1
 
 
+@pytest.mark.parametrize("as_tuple", [False, True])
+def test_neighbor_sampler_subgraph(tfg, oracle, as_tuple):
+    """sampled_node_index (graph_utils.py:689-731): rows in the given order (with a duplicate and an id without edges),
+    neighbours restricted to the column set and renamed to virtual ids.  sample_all is deterministic -> exact match
+    with the restated loop; k / ratio / padding -> counts, subset, no repeats."""
+    n = 400
+    ei = oracle.synthetic_edges(n, 6000, seed=9)
+    ei = ei[:, ei[0] != 11]                                             # node 11 has no in-edges
+    w = np.arange(ei.shape[1], dtype=np.float32)
+    rng = np.random.Generator(np.random.PCG64(3))
+    rows = rng.permutation(n)[:150].astype(np.int32)
+    rows[5], rows[9] = 11, rows[2]                                      # an empty row, a duplicate row
+    cols = rng.permutation(n)[:220].astype(np.int32)
+    sni = (rows, cols) if as_tuple else rows
+    sampler = tfg.utils.RandomNeighborSampler(ei, w)
+    ref_rows, ref = oracle.neighbor_lists(ei, w, sni)
+    sei, sw = sampler.sample(sampled_node_index=sni)                    # sample_all
+    ref_ei = np.concatenate([np.stack([np.full(len(ids), r), ids]) for r, (ids, _) in zip(ref_rows, ref)], axis=1)
+    ref_w = np.concatenate([ws for _, ws in ref])
+    assert np.array_equal(sei, ref_ei) and np.array_equal(sw, ref_w)
+    avail = {r: set(zip(ids.tolist(), ws.tolist())) for r, (ids, ws) in zip(ref_rows, ref)}
+    for kw in (dict(k=2), dict(ratio=0.5), dict(k=6, padding=True)):
+        sei, sw = sampler.sample(sampled_node_index=sni, seed=5, **kw)
+        cnt = np.bincount(sei[0], minlength=len(rows))
+        for r in range(len(rows)):
+            d = len(avail.get(r, ()))
+            want = (min(d, 2) if "k" in kw and not kw.get("padding") else
+                    (int(np.ceil(d * 0.5)) if "ratio" in kw else (6 if d > 0 else 0)))
+            assert cnt[r] == want
+            got = list(zip(sei[1][sei[0] == r].tolist(), sw[sei[0] == r].tolist()))
+            assert set(got) <= avail.get(r, set())
+            if not kw.get("padding"):
+                assert len(set(got)) == len(got)
+
+
 @pytest.mark.parametrize("n,num_src,kw", [(5000, 97, dict(k=3)), (5000, 97, dict(ratio=0.3)), (20000, 3, dict(k=50)),
                                           (300, 400, dict(ratio=1.0)), (1, 1, dict(k=1)), (777, 50, dict(k=0)),
                                           (4000, 60, dict(ratio=2.5)), (200000, 5000, dict(ratio=0.5))])

@@ -138,9 +138,10 @@ def convert_edge_to_directed(edge_index, edge_props=None, merge_modes=None):
 
 class RandomNeighborSampler(object):
     """Neighbour sampler on the device.  Mirrors tf_geometric.utils.RandomNeighborSampler
-    (graph_utils.py:630-772) for whole-graph sampling (`sampled_node_index=None`): `sample(k=...)`, `sample(ratio=...)`,
-    `padding=True`.  The reference loops over nodes in Python with np.random.choice; here one kernel launch samples
-    every row with a counter-based generator — same distribution, different random stream, reproducible per seed."""
+    (graph_utils.py:630-772): `sample(k=...)`, `sample(ratio=...)`, `padding=True`, and sub-graph sampling in virtual
+    ids (`sampled_node_index=` one index array, or a `(rows, cols)` tuple).  The reference loops over nodes in Python
+    with np.random.choice; here one kernel launch samples every row with a counter-based generator — same distribution,
+    different random stream, reproducible per seed."""
 
     def __init__(self, edge_index, edge_weight=None):
         from ..plan import CsrPlan
@@ -153,14 +154,50 @@ class RandomNeighborSampler(object):
             else L.as_f32(edge_weight)                                        # :635-638: weights default to ones
         self.w_csr = self.plan.edge_attr_to_csr(w)
 
+    def _virtual_subgraph(self, sampled_node_index):
+        """CSR (row_ptr, col, w) of the sub-graph in VIRTUAL ids (:689-731): virtual row i = node rows[i] (duplicates
+        and any order allowed), its neighbours restricted to `cols` and renamed to their position in `cols` (for a
+        repeated column id the last position wins, as the numpy assignment :698,:703 does), original neighbour order
+        kept.  Index bookkeeping only (torch on the device); the sampling itself stays one kernel launch."""
+        plan = self.plan
+        dev = plan.col.device
+        if isinstance(sampled_node_index, tuple):
+            rows, cols = sampled_node_index
+        else:
+            rows = cols = sampled_node_index
+        rows = L.as_i32(rows).long().reshape(-1)
+        cols = L.as_i32(cols).long().reshape(-1)
+        col_map = torch.full((self.num_col_nodes,), -1, dtype=torch.int64, device=dev)
+        ok = cols < self.num_col_nodes
+        # "last position wins" for a repeated id == the largest position (an indexed store would be order-dependent)
+        col_map.scatter_reduce_(0, cols[ok], torch.arange(int(cols.shape[0]), device=dev)[ok], reduce="amax")
+        vcol = col_map[plan.col.long()]                                         # per CSR edge
+        keep = vcol >= 0
+        csum = torch.zeros(plan.num_edges + 1, dtype=torch.int64, device=dev)
+        csum[1:] = torch.cumsum(keep.to(torch.int64), 0)
+        kept_ptr = csum[plan.row_ptr.long()]                                    # row_ptr of the column-filtered graph
+        kept_col = vcol[keep].to(torch.int32)
+        kept_w = self.w_csr[keep]
+        in_range = rows < self.num_row_nodes
+        r = torch.where(in_range, rows, torch.zeros_like(rows))
+        cnt = torch.where(in_range, kept_ptr[r + 1] - kept_ptr[r], torch.zeros_like(r))
+        sub_ptr = torch.zeros(int(rows.shape[0]) + 1, dtype=torch.int64, device=dev)
+        sub_ptr[1:] = torch.cumsum(cnt, 0)
+        total = int(sub_ptr[-1].item())
+        seg = torch.repeat_interleave(torch.arange(int(rows.shape[0]), device=dev), cnt)
+        pos = kept_ptr[r][seg] + (torch.arange(total, device=dev) - sub_ptr[:-1][seg])
+        return sub_ptr.to(torch.int32), kept_col[pos].contiguous(), kept_w[pos].contiguous()
+
     def sample(self, k=None, ratio=None, sampled_node_index=None, padding=False, seed=0):
         if k is not None and ratio is not None:
             raise Exception("k and ratio cannot be provided simultaneously")   # :674-675
-        if sampled_node_index is not None:
-            raise NotImplementedError("sub-graph (virtual index) sampling is not implemented on the device")
         lib = L.require_gpu()
-        plan = self.plan
-        deg = plan.in_degree()
+        if sampled_node_index is None:
+            row_ptr, col, w_csr = self.plan.row_ptr, self.plan.col, self.w_csr
+        else:
+            row_ptr, col, w_csr = self._virtual_subgraph(sampled_node_index)
+        n_rows = int(row_ptr.shape[0]) - 1
+        deg = (row_ptr[1:] - row_ptr[:-1]).to(torch.int32)
         if k is None and ratio is None:
             cnt = deg                                                           # sample_all
         elif ratio is not None:
@@ -169,16 +206,16 @@ class RandomNeighborSampler(object):
             cnt = torch.where(deg > 0, torch.full_like(deg, int(k)), torch.zeros_like(deg))
         else:
             cnt = torch.clamp(deg, max=int(k))
-        out_ptr = torch.zeros(plan.n_dst + 1, dtype=torch.int32, device=deg.device)
+        out_ptr = torch.zeros(n_rows + 1, dtype=torch.int32, device=deg.device)
         out_ptr[1:] = torch.cumsum(cnt, 0)
-        total = int(out_ptr[-1].item())
+        total = int(out_ptr[-1].item()) if n_rows > 0 else 0
         if total == 0:
             return None, None                                                   # :767-769
         out_col = torch.empty(total, dtype=torch.int32, device=deg.device)
         out_w = torch.empty(total, dtype=torch.float32, device=deg.device)
-        L.check(lib.tfgx_sample_neighbors(L.ptr(plan.row_ptr), L.ptr(plan.col), L.ptr(self.w_csr), plan.n_dst,
+        L.check(lib.tfgx_sample_neighbors(L.ptr(row_ptr), L.ptr(col), L.ptr(w_csr), n_rows,
                                           L.ptr(out_ptr), int(cnt.max().item()), 1 if padding else 0, int(seed),
                                           L.ptr(out_col), L.ptr(out_w), L.stream_ptr()), "tfgx_sample_neighbors")
-        rows = torch.repeat_interleave(torch.arange(plan.n_dst, dtype=torch.int32, device=deg.device), cnt.long())
+        rows = torch.repeat_interleave(torch.arange(n_rows, dtype=torch.int32, device=deg.device), cnt.long())
         ei = torch.stack([rows, out_col])
         return _out(ei, self._numpy), _out(out_w, self._numpy)
