@@ -53,6 +53,33 @@ def test_aggregate_grad_x_and_w(tfg, oracle, op, weighted):
         assert_parity(wt.grad.cpu().numpy(), wr.grad.numpy(), tol=2e-5, what="d/dw " + op)
 
 
+@pytest.mark.parametrize("f", [4, 16, 24, 37, 64, 100, 128, 200, 256, 300, 512, 516])
+def test_sddmm_widths(tfg, oracle, f):
+    """tfgx_sddmm_f32 out[i] = <a[row(i)], b[col[i]]> on every dispatch (tuned float4 kernel 16 <= F <= 512, F % 4 == 0;
+    scalar kernel otherwise), rows with 0 / 1 / 8 / 9 / many edges."""
+    import ctypes
+    from tf_geometric_amd import _lib as L
+    from tf_geometric_amd.plan import CsrPlan
+    rng = np.random.Generator(np.random.PCG64(f))
+    n = 600
+    ei = oracle.synthetic_edges(n, 9000, seed=f)
+    ei = ei[:, ei[0] != 3]                                              # row 3 empty
+    extra = np.stack([np.full(700, 5, np.int32), rng.integers(0, n, 700).astype(np.int32)])   # a long row
+    ei = np.concatenate([ei, extra], axis=1)
+    a = rng.standard_normal((n, f), dtype=np.float32)
+    b = rng.standard_normal((n, f), dtype=np.float32)
+    plan = CsrPlan.build(L.as_i32(ei), n, n)
+    at, bt = L.as_f32(a), L.as_f32(b)
+    out = torch.empty(plan.num_edges, dtype=torch.float32, device="cuda")
+    lib = L.require_gpu()
+    L.check(lib.tfgx_sddmm_f32(L.ptr(plan.row_ptr), L.ptr(plan.col), n, L.ptr(at), f, L.ptr(bt), f, f, L.ptr(out),
+                               L.stream_ptr()), "tfgx_sddmm_f32")
+    rp, col = plan.row_ptr.cpu().numpy(), plan.col.cpu().numpy()
+    rows = np.repeat(np.arange(n), np.diff(rp))
+    ref = np.einsum("ij,ij->i", a[rows].astype(np.float64), b[col].astype(np.float64))
+    assert_parity(out.cpu().numpy(), ref, tol=1e-5 * np.sqrt(f), what="sddmm F={}".format(f))
+
+
 def test_max_grad_ties_split_evenly(tfg):
     """TF's unsorted_segment_max gradient divides by the number of tied maxima."""
     ei = np.array([[0, 0, 0, 1], [1, 2, 3, 3]], np.int32)

@@ -40,6 +40,61 @@ __global__ __launch_bounds__(kBlock) void sddmm_kernel(const int32_t* __restrict
     }
 }
 
+// Tuned variant (16-byte aligned rows, F % 4 == 0, F <= 4 * G * CH): G lanes per destination row, the a-row lives in
+// registers, U = 8 edges in flight (8 independent dwordx4 gathers per lane before the first FMA), the 8 partial dot
+// products are reduced across the group and written as one coalesced 8-wide store.  Same traffic as the forward
+// segment-sum: one gathered source row per edge.
+template <int G, int CH>
+__global__ __launch_bounds__(kBlock) void sddmm_fast_kernel(const int32_t* __restrict__ row_ptr,
+                                                            const int32_t* __restrict__ col, int64_t n_dst,
+                                                            const float* __restrict__ a, int64_t lda,
+                                                            const float* __restrict__ b, int64_t ldb, int F,
+                                                            float* __restrict__ out)
+{
+    constexpr int ROWS_PER_BLOCK = kBlock / G, U = 8;
+    const int lane = threadIdx.x % G, grp = threadIdx.x / G;
+    for (int64_t r = int64_t(blockIdx.x) * ROWS_PER_BLOCK + grp; r < n_dst; r += int64_t(gridDim.x) * ROWS_PER_BLOCK) {
+        const int s = row_ptr[r], e = row_ptr[r + 1];
+        float4 av[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int j = 4 * (lane + c * G);
+            av[c] = j < F ? *reinterpret_cast<const float4*>(a + r * lda + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        for (int i0 = s; i0 < e; i0 += U) {
+            const int mine = (lane < U && i0 + lane < e) ? col[i0 + lane] : 0;   // a valid row for the padded slots
+            float acc[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int cu = __shfl(mine, u, G);
+                const float* br = b + int64_t(cu) * ldb;
+                float t = 0.0f;
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    const int j = 4 * (lane + c * G);
+                    if (j < F) {
+                        const float4 bv = *reinterpret_cast<const float4*>(br + j);
+                        t = fmaf(av[c].x, bv.x, t);
+                        t = fmaf(av[c].y, bv.y, t);
+                        t = fmaf(av[c].z, bv.z, t);
+                        t = fmaf(av[c].w, bv.w, t);
+                    }
+                }
+                acc[u] = t;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+#pragma unroll
+                for (int o = G / 2; o > 0; o >>= 1) acc[u] += __shfl_xor(acc[u], o, G);
+            }
+            float v = acc[0];
+#pragma unroll
+            for (int u = 1; u < U; ++u) v = (lane == u) ? acc[u] : v;
+            if (lane < U && i0 + lane < e) out[i0 + lane] = v;
+        }
+    }
+}
+
 // ---------------------------------------------------------------- segment-max gradient
 // count[r, j] = #{ i in row r : w[i] * x[col[i], j] == out[r, j] }
 __global__ __launch_bounds__(kBlock) void max_count_kernel(const int32_t* __restrict__ row_ptr,
@@ -418,6 +473,18 @@ extern "C" int tfgx_sddmm_f32(const int32_t* row_ptr, const int32_t* col, int64_
     if (n_dst == 0) return TFGX_OK;
     TFGX_REQUIRE(row_ptr && a && b, "null pointer");
     hipStream_t s = as_stream(stream);
+    if (F % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && aligned_to(a, 16) && aligned_to(b, 16) && F >= 16 && F <= 512) {
+#define TFGX_SDDMM_GO(G, CH) \
+    sddmm_fast_kernel<G, CH><<<grid_for(n_dst, kBlock / G, 1 << 20), kBlock, 0, s>>>(row_ptr, col, n_dst, a, lda, b, ldb, int(F), out)
+        if (F <= 32) TFGX_SDDMM_GO(8, 1);
+        else if (F <= 64) TFGX_SDDMM_GO(16, 1);
+        else if (F <= 128) TFGX_SDDMM_GO(32, 1);
+        else if (F <= 256) TFGX_SDDMM_GO(32, 2);
+        else TFGX_SDDMM_GO(32, 4);
+#undef TFGX_SDDMM_GO
+        TFGX_LAUNCH_CHECK("sddmm_fast_kernel");
+        return TFGX_OK;
+    }
     if (F <= 8) sddmm_kernel<8><<<grid_for(n_dst, kBlock / 8, 1 << 20), kBlock, 0, s>>>(row_ptr, col, n_dst, a, lda, b, ldb, int(F), out);
     else if (F <= 32) sddmm_kernel<16><<<grid_for(n_dst, kBlock / 16, 1 << 20), kBlock, 0, s>>>(row_ptr, col, n_dst, a, lda, b, ldb, int(F), out);
     else sddmm_kernel<32><<<grid_for(n_dst, kBlock / 32, 1 << 20), kBlock, 0, s>>>(row_ptr, col, n_dst, a, lda, b, ldb, int(F), out);
