@@ -36,6 +36,7 @@ WORKLOADS = {
     # name: (nodes, edges, features)  — BASELINE.json configs
     "products": (2400000, 123000000, 100),   # ogbn-products-shaped: north-star target (segment-sum, 1 GPU)
     "arxiv": (170000, 1200000, 128),         # ogbn-arxiv-shaped (configs[1])
+    "reddit": (233000, 114000000, 602),      # Reddit-shaped (configs[2]: 8-head GAT)
     "cora": (2708, 10556, 1433),             # Cora-shaped (configs[0])
     "tiny": (20000, 400000, 100),            # plumbing check
 }

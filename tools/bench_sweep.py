@@ -54,6 +54,12 @@ def main():
     want = lambda name: (not only) or (name in only[0].split(","))
     torch.cuda.set_device(0)
     n, e = (2400000, 123000000) if not quick else (300000, 15000000)
+    if want("reddit"):
+        reddit_section(quick)
+    if want("gemm"):
+        gemm_section(n)
+    if only and not any(want(s) for s in ("widths", "split", "rmat", "gat", "backward")):
+        return
     ei = L.as_i32(synthetic.synthetic_edges(n, e, seed=0))
     E = int(ei.shape[1])
     plan = CsrPlan.build(ei, n, n)
@@ -88,8 +94,6 @@ def main():
             del x, out, sp
     if want("rmat"):
         rmat_section(quick, e)
-    if want("gemm"):
-        gemm_section(n)
     if want("gat"):
         gat_section(plan, n, E)
     if want("backward"):
@@ -172,6 +176,33 @@ def gat_section(plan, n, E):
         balg = Eagg * (4 * A + 4 * U + 4) + n * 4 * (A + U) + 4 * (n + 1)
         print(json.dumps({"kind": "gat_fused", "H": H, "A": A, "U": U, "ms": ms, "GBps_alg": balg / ms / 1e6,
                           "frac_of_8TBps": balg / ms / 1e6 / 8000, "Gedges_per_s": Eagg / ms / 1e6}), flush=True)
+
+
+def reddit_section(quick):
+    """BASELINE.json configs[2]: multi-head GAT on the Reddit-shaped graph (N=233k, E=114M, F=602, avg in-degree 489).
+    demo/demo_gat.py:22 literal layer GAT(64, num_heads=8, attention_units=8), the heavy attention_units=64 variant,
+    and the attention kernel alone."""
+    import tf_geometric_amd as tfg
+    n, e, f = synthetic.WORKLOADS["reddit"] if not quick else (233000, 11400000, 602)
+    ei = L.as_i32(synthetic.synthetic_edges(n, e, seed=3))
+    E = int(ei.shape[1])
+    plan = CsrPlan.build(ei, n, n)
+    x = torch.randn(n, f, device="cuda")
+    cache = {"tfgx_csr_plan": plan}
+    for (H, A, U) in [(8, 8, 64), (8, 64, 64)]:
+        layer = tfg.layers.GAT(U, attention_units=A, num_heads=H, activation=tfg.relu)
+        ms_layer = timeit(lambda: layer([x, ei], cache=cache))
+        Q = torch.randn(n, A, device="cuda")
+        K = torch.randn(n, A, device="cuda")
+        V = torch.randn(n, U, device="cuda")
+        ms_att = timeit(lambda: gat_attention(plan, Q, K, V, H))
+        Eagg = E + n
+        balg = Eagg * (4 * A + 4 * U + 4) + n * 4 * (A + U) + 4 * (n + 1)
+        print(json.dumps({"kind": "reddit_gat", "N": n, "E": E, "F": f, "H": H, "A": A, "U": U, "layer_ms": ms_layer,
+                          "attention_ms": ms_att, "attention_GBps_alg": balg / ms_att / 1e6,
+                          "attention_frac_of_8TBps": balg / ms_att / 1e6 / 8000,
+                          "Gedges_per_s_layer": E / ms_layer / 1e6}), flush=True)
+    del x, plan, ei
 
 
 def wr_csr(plan, w):
