@@ -56,6 +56,8 @@ def main():
     n, e = (2400000, 123000000) if not quick else (300000, 15000000)
     if want("reddit"):
         reddit_section(quick)
+    if want("papers_shard"):
+        papers_shard_section(quick)
     if want("gemm"):
         gemm_section(n)
     if only and not any(want(s) for s in ("widths", "split", "rmat", "gat", "backward")):
@@ -203,6 +205,42 @@ def reddit_section(quick):
                           "attention_frac_of_8TBps": balg / ms_att / 1e6 / 8000,
                           "Gedges_per_s_layer": E / ms_layer / 1e6}), flush=True)
     del x, plan, ei
+
+
+def papers_shard_section(quick):
+    """BASELINE.json configs[4] seen from ONE of its 8 GPUs: ogbn-papers100M-shaped GCN (N = 111 M, E = 1.6 G, F = 128),
+    destination rows [0, N/8) with their E/8 in-edges whose sources are spread over all N nodes — i.e. the rectangular
+    aggregation a shard runs once its halo rows are resident (table = 111 M x 128 fp32 = 56.8 GB of the 288 GB)."""
+    n_src = 111000000 if not quick else 11100000
+    n_dst = n_src // 8
+    E = 200000000 if not quick else 20000000
+    f = 128
+    g = torch.Generator(device="cuda")
+    g.manual_seed(11)
+    row = torch.randint(0, n_dst, (E,), generator=g, device="cuda", dtype=torch.int32)
+    col = torch.randint(0, n_src, (E,), generator=g, device="cuda", dtype=torch.int32)
+    plan = CsrPlan.build(torch.stack([row, col]), n_dst, n_src)
+    del row, col
+    x = torch.empty(n_src, f, device="cuda")
+    for i in range(0, n_src, 1 << 24):                     # fill in slabs: randn of the whole table would double it
+        x[i:i + (1 << 24)].normal_(generator=g)
+    w = torch.rand(E, generator=g, device="cuda") + 0.5
+    out = torch.empty(n_dst, f, device="cuda")
+    ms = timeit(lambda: segment_reduce(plan, x, L.SUM, w_csr=w, out=out))
+    balg = E * (4 * f + 8) + n_dst * 4 * f + 4 * (n_dst + 1)
+    # spot parity on a few rows against float64
+    rp = plan.row_ptr.long()
+    rows = [0, n_dst // 3, n_dst - 1]
+    err = 0.0
+    for r in rows:
+        s, t = int(rp[r]), int(rp[r + 1])
+        ref = (x[plan.col[s:t].long()].double() * w[s:t, None].double()).sum(0)
+        err = max(err, float((out[r].double() - ref).abs().max()))
+    print(json.dumps({"kind": "papers100M_shard", "n_dst": n_dst, "n_src": n_src, "E": E, "F": f,
+                      "table_GB": n_src * f * 4 / 1e9, "ms": ms, "GBps_alg": balg / ms / 1e6,
+                      "frac_of_8TBps": balg / ms / 1e6 / 8000, "Gedges_per_s": E / ms / 1e6,
+                      "spot_max_abs_err": err, "mem_allocated_GB": torch.cuda.max_memory_allocated() / 1e9}), flush=True)
+    del x, out, plan, w
 
 
 def wr_csr(plan, w):
