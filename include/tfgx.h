@@ -199,7 +199,20 @@ typedef struct tfgx_gat_args {
     float* hub_scratch_ml;         /* [n_hub_chunks, 2*H]  */
     float* stats_ml;               /* optional [n_dst, 2*H]: final softmax statistics (m, l) per row and head, saved
                                       for tfgx_gat_backward_*; NULL = not written */
+    /* training only — dropout of the attention weights AFTER the softmax (SparseMatrix.dropout, gat.py:85; tf.nn.dropout
+       semantics: a_e -> a_e * keep_e / (1 - rate)).  keep_e is a pure function of (drop_seed, edge position in this
+       plan's CSR order, head) — tfgx_dropout_keep() below — so the backward kernels regenerate it.  The appended
+       self-loop edge of row r has position drop_self_base + r (pass the plan's edge count).  0 = no dropout; with
+       dropout the hub / raw-state options must be off. */
+    float drop_rate;
+    int32_t reserved2;
+    uint64_t drop_seed;
+    int64_t drop_self_base;
 } tfgx_gat_args;
+
+/* 1 if the item survives dropout at `rate`, else 0: the exact decision every kernel of this library makes for
+   item = (uint32)(position * H + head) (attention) or the edge position (edge-weight dropout).  Host function. */
+int32_t tfgx_dropout_keep(uint64_t seed, uint32_t item, float rate);
 
 int tfgx_gat_fused_f32(const tfgx_gat_args* args /* host */, tfgx_stream_t stream);
 
@@ -253,6 +266,13 @@ typedef struct tfgx_gat_backward_args {
     float* grad_q; int64_t ld_grad_q;             /* [n_dst, H*d]  (dst pass) */
     float* grad_k; int64_t ld_grad_k;             /* [n_src, H*d]  (src pass) */
     float* grad_v; int64_t ld_grad_v;             /* [n_src, H*dv] (src pass) */
+    /* attention dropout of the forward (same three values as tfgx_gat_args) + for the src pass the forward-CSR
+       position of every transposed-plan position */
+    float drop_rate;
+    int32_t reserved2;
+    uint64_t drop_seed;
+    int64_t drop_self_base;
+    const int32_t* edge_pos_t;                    /* [E] or NULL when drop_rate == 0 */
 } tfgx_gat_backward_args;
 
 int tfgx_gat_backward_dst_f32(const tfgx_gat_backward_args* args /* host */, tfgx_stream_t stream);

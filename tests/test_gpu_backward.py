@@ -135,6 +135,131 @@ def _ref_gat(x, ei, wq, bq, wk, bk, wv, b, H, n):
     return torch.relu(torch.cat(outs, 1) + b)
 
 
+def _keep_mask_host(seed, n_items, rate):
+    """numpy restatement of drop_hash / drop_scale (tf_geometric_amd/csrc/tfgx_common.h) — test infrastructure."""
+    x = np.arange(n_items, dtype=np.uint64).astype(np.uint32) ^ np.uint32(seed & 0xFFFFFFFF)
+    x ^= x >> np.uint32(16)
+    x = (x.astype(np.uint64) * np.uint64(0x85ebca6b)).astype(np.uint32)
+    x ^= np.uint32(seed >> 32)
+    x ^= x >> np.uint32(13)
+    x = (x.astype(np.uint64) * np.uint64(0xc2b2ae35)).astype(np.uint32)
+    x ^= x >> np.uint32(16)
+    return (x >> np.uint32(8)) >= np.uint32(int(np.float32(rate) * np.float32(16777216.0)))
+
+
+@pytest.mark.parametrize("heads,att,units,rate", [(1, 4, 8, 0.5), (4, 8, 16, 0.6), (2, 32, 8, 0.25), (2, 6, 10, 0.4)])
+def test_gat_attention_dropout_forward_and_grads(tfg, oracle, heads, att, units, rate):
+    """Attention dropout (SparseMatrix.dropout after segment_softmax, gat.py:85): out = sum_e a_e keep_e/(1-rate) V.
+    The mask is regenerated on the host from (seed, CSR position, head); forward and dQ, dK, dV are compared with torch
+    autograd over a float64 restatement that uses that mask.  Covers the tuned and the one-lane-per-row backward."""
+    import tf_geometric_amd.autograd as AG
+    from tf_geometric_amd import _lib as L
+    from tf_geometric_amd.plan import CsrPlan
+    x, ei, w, rng = _graph(oracle, n=300, e=4000, f=5, seed=heads + att)
+    n = x.shape[0]
+    plan = CsrPlan.build(L.as_i32(ei), n, n)
+    E = plan.num_edges
+    seed = (0x1234ABCD << 32) | (77 + heads)
+    lib = L.require_gpu()
+    keep = _keep_mask_host(seed, (E + n) * heads, rate)
+    for item in (0, 1, 17, (E + n) * heads - 1, E * heads + 3):
+        assert bool(keep[item]) == bool(lib.tfgx_dropout_keep(seed, int(item), float(rate)))
+    assert abs(keep.mean() - (1.0 - rate)) < 0.02
+    keep = keep.reshape(E + n, heads)
+    Q = rng.standard_normal((n, att)).astype(np.float32)
+    K = rng.standard_normal((n, att)).astype(np.float32)
+    V = rng.standard_normal((n, units)).astype(np.float32)
+    gout = rng.standard_normal((n, units)).astype(np.float32)
+    t = {k: torch.tensor(v, device="cuda", requires_grad=True) for k, v in dict(Q=Q, K=K, V=V).items()}
+    out = AG.gat_attention(plan, t["Q"], t["K"], t["V"], heads, drop_rate=rate, drop_seed=seed)
+    out.backward(torch.tensor(gout, device="cuda"))
+    # float64 reference in CSR order, self-loops appended (positions E .. E+n-1)
+    rp = plan.row_ptr.cpu().numpy()
+    ar = np.arange(n, dtype=np.int64)
+    row = torch.from_numpy(np.concatenate([np.repeat(ar, np.diff(rp)), ar]))
+    col = torch.from_numpy(np.concatenate([plan.col.cpu().numpy().astype(np.int64), ar]))
+    r = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in dict(Q=Q, K=K, V=V).items()}
+    d, dv = att // heads, units // heads
+    outs = []
+    for h in range(heads):
+        s = (r["Q"][row, h * d:(h + 1) * d] * r["K"][col, h * d:(h + 1) * d]).sum(-1) / np.sqrt(d)
+        m = torch.full((n,), -1e30, dtype=torch.float64).scatter_reduce(0, row, s, "amax")
+        p = torch.exp(s - m[row].detach())
+        den = torch.zeros(n, dtype=torch.float64).index_add(0, row, p) + 1e-8
+        a = p / den[row] * torch.from_numpy(keep[:, h].astype(np.float64)) / (1.0 - rate)
+        outs.append(torch.zeros(n, dv, dtype=torch.float64).index_add(0, row, a[:, None] * r["V"][col, h * dv:(h + 1) * dv]))
+    ref = torch.cat(outs, 1)
+    ref.backward(torch.tensor(gout, dtype=torch.float64))
+    assert_parity(out.detach().cpu().numpy(), ref.detach().numpy(), tol=2e-5, what="dropout forward")
+    for k in ("Q", "K", "V"):
+        assert_parity(t[k].grad.cpu().numpy(), r[k].grad.numpy(), tol=5e-5, what="dropout d/d" + k)
+    # rate 0 through the same entry == the plain kernel
+    plain = AG.gat_attention(plan, t["Q"].detach(), t["K"].detach(), t["V"].detach(), heads)
+    assert not torch.equal(plain, out.detach())
+
+
+def test_gat_layer_edge_dropout_training(tfg, oracle):
+    """layers.GAT(edge_drop_rate=...) as demo/demo_gat.py:22 builds it: identity at inference, active under
+    training=True, repeatable under torch.manual_seed, unbiased on average, differentiable."""
+    x, ei, w, rng = _graph(oracle, n=400, e=6000, f=12, seed=5)
+    layer = tfg.layers.GAT(16, attention_units=8, activation=tfg.relu, num_heads=4, edge_drop_rate=0.6)
+    ev = layer([x, ei], training=False)
+    layer0 = tfg.layers.GAT(16, attention_units=8, activation=tfg.relu, num_heads=4)
+    layer0._maybe_build([x])
+    layer0.set_weights(**{k: getattr(layer, k).detach().cpu().numpy() for k in
+                          ("query_kernel", "key_kernel", "kernel", "query_bias", "key_bias", "bias")})
+    assert torch.equal(ev, layer0([x, ei]))
+    torch.manual_seed(11)
+    t1 = layer([x, ei], training=True)
+    torch.manual_seed(11)
+    t2 = layer([x, ei], training=True)
+    t3 = layer([x, ei], training=True)
+    assert torch.equal(t1, t2) and not torch.equal(t1, t3) and not torch.equal(t1, ev)
+    layer.activation = None
+    ev_lin = layer([x, ei], training=False)
+    acc = torch.zeros_like(ev_lin)
+    for _ in range(200):
+        acc += layer([x, ei], training=True)
+    err = float((acc / 200 - ev_lin).abs().mean() / ev_lin.abs().mean())
+    assert err < 0.1, err                                   # E[dropout(a)] = a
+    layer.trainable(True)
+    out = layer([torch.tensor(x, device="cuda", requires_grad=True), ei], training=True)
+    out.square().sum().backward()
+    assert layer.kernel.grad is not None and float(layer.kernel.grad.abs().sum()) > 0
+    assert float(layer.query_kernel.grad.abs().sum()) > 0
+
+
+def test_gcn_edge_dropout_training(tfg, oracle):
+    """GCN(edge_drop_rate=...) (gcn.py:262: SparseMatrix.dropout on the normalised adjacency): identity at inference,
+    unbiased and repeatable in training, plan shared, gradients flow; SparseMatrix.dropout likewise."""
+    x, ei, w, rng = _graph(oracle, n=500, e=8000, f=10, seed=8)
+    layer = tfg.layers.GCN(6, edge_drop_rate=0.5)
+    cache = {}
+    ev = layer([x, ei, w], cache=cache, training=False)
+    assert torch.equal(ev, layer([x, ei, w], cache=cache))
+    torch.manual_seed(3)
+    t1 = layer([x, ei, w], cache=cache, training=True)
+    torch.manual_seed(3)
+    t2 = layer([x, ei, w], cache=cache, training=True)
+    assert torch.equal(t1, t2) and not torch.equal(t1, ev)
+    acc = torch.zeros_like(ev)
+    for _ in range(300):
+        acc += layer([x, ei, w], cache=cache, training=True)
+    assert float((acc / 300 - ev).abs().mean() / ev.abs().mean()) < 0.1
+    layer.trainable(True)
+    out = layer([torch.tensor(x, device="cuda", requires_grad=True), ei, w], cache=cache, training=True)
+    out.square().sum().backward()
+    assert float(layer.kernel.grad.abs().sum()) > 0
+    adj = tfg.SparseMatrix(ei, w, [500, 500])
+    _ = adj.plan                                            # built once; the dropped copy shares it
+    assert adj.dropout(0.3, training=False) is adj
+    torch.manual_seed(1)
+    d = adj.dropout(0.3, training=True)
+    kept = d.value != 0
+    assert abs(float(kept.float().mean()) - 0.7) < 0.03 and d.plan is adj.plan
+    assert torch.allclose(d.value[kept], adj.value[kept] / 0.7, rtol=1e-6)
+
+
 @pytest.mark.parametrize("heads,att,units", [(1, 4, 6), (4, 8, 16), (2, 6, 10)])
 def test_gat_layer_grads(tfg, oracle, heads, att, units):
     x, ei, w, rng = _graph(oracle, n=200, e=2500, f=9, seed=7)

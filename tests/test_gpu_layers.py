@@ -281,3 +281,38 @@ def test_gemm_streaming_kernel(tfg, oracle, m, k, n):
     ref2 = oracle.matmul(a, b)
     ref2[:, :n // 2] = np.maximum(ref2[:, :n // 2], 0)
     assert_parity(got2, ref2, what="stream gemm act_cols")
+
+
+def test_gcn_sparse_node_features(tfg, oracle):
+    """gcn.py:269-270: sparse x (bag-of-words rows) -> x @ W as a segment-sum over the kernel rows; SparseMatrix and
+    torch sparse COO inputs, forward parity with the dense path and the kernel gradient."""
+    import torch
+    rng = np.random.Generator(np.random.PCG64(21))
+    n, f, u = 300, 50, 7
+    dense = (rng.random((n, f)) < 0.08) * rng.standard_normal((n, f))
+    dense = dense.astype(np.float32)
+    dense[5] = 0                                                    # a node without features
+    ei = oracle.synthetic_edges(n, 3000, seed=2)
+    w = rng.uniform(0.5, 1.5, ei.shape[1]).astype(np.float32)
+    k = oracle.glorot_uniform(rng, f, u)
+    b = (rng.standard_normal(u) * 0.1).astype(np.float32)
+    ref = oracle.gcn(dense, ei, w, k, b, "relu")
+    r, c = np.nonzero(dense)
+    xs = tfg.SparseMatrix(np.stack([r, c]).astype(np.int32), dense[r, c], [n, f])
+    adj = tfg.SparseMatrix(ei, w, [n, n])
+    got = tfg.nn.gcn(xs, adj, k, b, activation=tfg.relu)
+    assert_parity(got.cpu().numpy(), ref, what="gcn sparse x (SparseMatrix)")
+    xt = torch.sparse_coo_tensor(np.stack([r, c]), dense[r, c], (n, f)).cuda()
+    got2 = tfg.nn.gcn(xt, adj, k, b, activation=tfg.relu)
+    assert_parity(got2.cpu().numpy(), ref, what="gcn sparse x (torch COO)")
+    kt = torch.tensor(k, device="cuda", requires_grad=True)
+    out = tfg.nn.gcn(xs, adj, kt, torch.tensor(b, device="cuda"), activation=tfg.relu)
+    out.square().sum().backward()
+    kd = torch.tensor(k, device="cuda", requires_grad=True)
+    out_d = tfg.nn.gcn(torch.tensor(dense, device="cuda"), adj, kd, torch.tensor(b, device="cuda"), activation=tfg.relu)
+    out_d.square().sum().backward()
+    assert_parity(kt.grad.cpu().numpy(), kd.grad.cpu().numpy(), tol=1e-4, what="d/dkernel through sparse x")
+    layer = tfg.layers.GCN(u, activation=tfg.relu)
+    layer._maybe_build([xs])
+    layer.set_weights(kernel=k, bias=b)
+    assert_parity(layer([xs, ei, w]).cpu().numpy(), ref, what="layers.GCN with sparse x")

@@ -61,6 +61,8 @@ class GatArgs(ctypes.Structure):
         ("n_hub_rows", ctypes.c_int64), ("n_hub_chunks", ctypes.c_int64),
         ("hub_scratch_acc", ctypes.c_void_p), ("hub_scratch_ml", ctypes.c_void_p),
         ("stats_ml", ctypes.c_void_p),
+        ("drop_rate", ctypes.c_float), ("reserved2", ctypes.c_int32), ("drop_seed", ctypes.c_uint64),
+        ("drop_self_base", ctypes.c_int64),
     ]
 
 
@@ -79,6 +81,8 @@ class GatBackwardArgs(ctypes.Structure):
         ("grad_q", ctypes.c_void_p), ("ld_grad_q", ctypes.c_int64),
         ("grad_k", ctypes.c_void_p), ("ld_grad_k", ctypes.c_int64),
         ("grad_v", ctypes.c_void_p), ("ld_grad_v", ctypes.c_int64),
+        ("drop_rate", ctypes.c_float), ("reserved2", ctypes.c_int32), ("drop_seed", ctypes.c_uint64),
+        ("drop_self_base", ctypes.c_int64), ("edge_pos_t", ctypes.c_void_p),
     ]
 
 
@@ -93,6 +97,7 @@ SIGNATURES = {
     "tfgx_merge_duplicated_edges": (ctypes.c_int, [_P, _P, _I64, _I64, _P, _P, _P, _P, _P, _SZ, _P]),
     "tfgx_segment_topk_workspace_bytes": (_SZ, [_I64, _I64]),
     "tfgx_segment_topk": (ctypes.c_int, [_P, _P, _I64, _I64, _I32, _F32, _P, _P, _P, _SZ, _P]),
+    "tfgx_dropout_keep": (ctypes.c_int32, [ctypes.c_uint64, ctypes.c_uint32, _F32]),
     "tfgx_permute_rows_f32": (ctypes.c_int, [_P, _P, _I64, _I64, _P, _P]),
     "tfgx_segment_reduce_f32": (ctypes.c_int, [ctypes.POINTER(ReduceArgs), _P]),
     "tfgx_segment_weight_sum_f32": (ctypes.c_int, [_P, _P, _I64, _F32, _P, _P]),

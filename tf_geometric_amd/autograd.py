@@ -165,11 +165,12 @@ def linear(x, kernel, bias=None, act=L.ACT_NONE):
 
 class _GatAttention(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, plan, num_heads, Q, K, V):
+    def forward(ctx, plan, num_heads, Q, K, V, drop_rate, drop_seed):
         from .nn.conv.gat import gat_attention
         stats = torch.empty((plan.n_dst, 2 * num_heads), dtype=torch.float32, device=V.device)
-        out = gat_attention(plan, Q.detach(), K.detach(), V.detach(), num_heads, True, stats_ml=stats)
-        ctx.plan, ctx.H = plan, num_heads
+        out = gat_attention(plan, Q.detach(), K.detach(), V.detach(), num_heads, True, stats_ml=stats,
+                            drop_rate=drop_rate, drop_seed=drop_seed)
+        ctx.plan, ctx.H, ctx.drop = plan, num_heads, (float(drop_rate), int(drop_seed))
         ctx.save_for_backward(Q, K, V, out, stats)
         return out
 
@@ -184,7 +185,7 @@ class _GatAttention(torch.autograd.Function):
         g2, ldg = L.row_major_2d(g.contiguous())
         n, A, W = plan.n_dst, int(Q2.shape[1]), int(V2.shape[1])
         dsum = (g2 * out).view(n, H, W // H).sum(-1).contiguous()
-        pt, _ = _transposed(plan)
+        pt, t2d = _transposed(plan)
         gq, gk, gv = torch.empty_like(Q2), torch.empty_like(K2), torch.empty_like(V2)
         a = L.GatBackwardArgs()
         a.row_ptr, a.col, a.n_dst = plan.row_ptr.data_ptr(), plan.col.data_ptr(), n
@@ -197,14 +198,18 @@ class _GatAttention(torch.autograd.Function):
         a.grad_q, a.ld_grad_q = gq.data_ptr(), A
         a.grad_k, a.ld_grad_k = gk.data_ptr(), A
         a.grad_v, a.ld_grad_v = gv.data_ptr(), W
+        if ctx.drop[0] > 0.0:      # regenerate the forward's keep mask: same seed, forward-CSR edge positions
+            a.drop_rate, a.drop_seed, a.drop_self_base = ctx.drop[0], ctx.drop[1], plan.num_edges
+            a.edge_pos_t = t2d.data_ptr()
         L.check(lib.tfgx_gat_backward_dst_f32(ctypes.byref(a), L.stream_ptr()), "tfgx_gat_backward_dst_f32")
         L.check(lib.tfgx_gat_backward_src_f32(ctypes.byref(a), L.stream_ptr()), "tfgx_gat_backward_src_f32")
-        return None, None, gq, gk, gv
+        return None, None, gq, gk, gv, None, None
 
 
-def gat_attention(plan, Q, K, V, num_heads):
-    """Differentiable fused attention (self-loop edge appended, as nn/conv/gat.py:43)."""
-    return _GatAttention.apply(plan, num_heads, Q, K, V)
+def gat_attention(plan, Q, K, V, num_heads, drop_rate=0.0, drop_seed=0):
+    """Differentiable fused attention (self-loop edge appended, as nn/conv/gat.py:43); drop_rate > 0 = training-time
+    dropout of the attention weights (gat.py:85)."""
+    return _GatAttention.apply(plan, num_heads, Q, K, V, float(drop_rate), int(drop_seed))
 
 
 def apply_activation(h, act, post):

@@ -77,6 +77,7 @@ struct GArgs {
     float* state_ml;      // [n_parts, 2H]  (m, l) per head
     int32_t hub_threshold;
     float* stats_ml;      // [n_dst, 2H] final (m, l) for the backward pass, or NULL
+    DropCfg drop;         // attention dropout (training): acc += p * keep_scale_or_0 * V; the denominator is untouched
 };
 
 // D > 0: compile-time head width (Q slice lives in registers); D == 0: runtime d, Q re-read (cache-hot)
@@ -138,13 +139,14 @@ __global__ __launch_bounds__(kBlock) void gat_fused_kernel(const GArgs a)
 #pragma unroll
         for (int i = 0; i < VEC; ++i) acc[i] = 0.0f;
 
-        auto step = [&](float sc, const float (&vv)[VEC]) {
+        auto step = [&](float sc, const float (&vv)[VEC], int64_t pos) {
             const float mn = fmaxf(m, sc);
             const float corr = expf(m - mn);
             const float p = expf(sc - mn);
             l = fmaf(l, corr, p);
+            const float pk = p * drop_scale(a.drop, uint32_t(pos * a.H + head));
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) acc[i] = fmaf(acc[i], corr, p * vv[i]);
+            for (int i = 0; i < VEC; ++i) acc[i] = fmaf(acc[i], corr, pk * vv[i]);
             m = mn;
         };
 
@@ -163,14 +165,14 @@ __global__ __launch_bounds__(kBlock) void gat_fused_kernel(const GArgs a)
                     load_vec<VEC>(a.v + int64_t(c) * a.ldv + coff, vv[u]);
                 }
 #pragma unroll
-                for (int u = 0; u < UNROLL; ++u) step(sc[u], vv[u]);
+                for (int u = 0; u < UNROLL; ++u) step(sc[u], vv[u], base + j + u);
             }
             for (; j < cnt; ++j) {
                 const int c = __shfl(cj, j, G);
                 const float sc = head_dot<D>(qreg, qp, a.k + int64_t(c) * a.ldk + hoff, a.d, a.kvec) / a.scale;
                 float vv[VEC];
                 load_vec<VEC>(a.v + int64_t(c) * a.ldv + coff, vv);
-                step(sc, vv);
+                step(sc, vv, base + j);
             }
         }
         if (a.state_acc) {      // raw state of this part; the self-loop edge is added by the merge
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(kBlock) void gat_fused_kernel(const GArgs a)
             const float sc = head_dot<D>(qreg, qp, a.k + r * a.ldk + hoff, a.d, a.kvec) / a.scale;
             float vv[VEC];
             load_vec<VEC>(a.v + r * a.ldv + coff, vv);
-            step(sc, vv);
+            step(sc, vv, a.drop.self_base + r);
         }
         if (a.stats_ml && cvalid && (coff % a.dv == 0)) {
             a.stats_ml[r * 2 * a.H + 2 * head] = m;
@@ -364,6 +366,10 @@ extern "C" int tfgx_gat_fused_f32(const tfgx_gat_args* p, tfgx_stream_t stream_)
     TFGX_REQUIRE(a.row_end != nullptr && a.rp_stride >= 1, "bad row_begin / row_end / rp_stride");
     a.part_row = nullptr; a.state_acc = p->state_acc; a.state_ml = p->state_ml; a.hub_threshold = 0;
     a.stats_ml = p->stats_ml;
+    TFGX_REQUIRE(p->drop_rate >= 0.0f && p->drop_rate < 1.0f, "drop_rate outside [0, 1)");
+    TFGX_REQUIRE(p->drop_rate == 0.0f || (p->state_acc == nullptr && !(p->hub_threshold > 0 && p->n_hub_rows > 0)),
+                 "attention dropout cannot be combined with the raw-state / hub options");
+    a.drop = make_drop(p->drop_rate, p->drop_seed, p->drop_self_base);
     TFGX_REQUIRE((p->state_acc == nullptr) == (p->state_ml == nullptr), "state_acc and state_ml go together");
     const bool use_hub = p->hub_threshold > 0 && p->n_hub_rows > 0 && p->state_acc == nullptr;
     if (use_hub) {
@@ -413,6 +419,7 @@ extern "C" int tfgx_gat_merge_passes_f32(const tfgx_gat_args* p, const float* st
 {
     TFGX_REQUIRE(p != nullptr && state_acc && state_ml && n_passes >= 1, "bad argument");
     TFGX_REQUIRE(p->H >= 1 && p->d >= 1 && p->dv >= 1 && p->n_dst >= 0 && p->scale > 0.0f, "bad H / d / dv / n_dst");
+    TFGX_REQUIRE(p->drop_rate == 0.0f, "attention dropout is not available on merged passes");
     if (p->n_dst == 0) return TFGX_OK;
     TFGX_REQUIRE(p->q && p->k && p->v && p->out, "null pointer");
     const int64_t W = int64_t(p->H) * p->dv;
@@ -426,6 +433,11 @@ extern "C" int tfgx_gat_merge_passes_f32(const tfgx_gat_args* p, const float* st
     gat_merge_kernel<<<grid_for(g.n_merge * W, kBlock), kBlock, 0, as_stream(stream)>>>(g);
     TFGX_LAUNCH_CHECK("gat_merge_kernel");
     return TFGX_OK;
+}
+
+extern "C" int32_t tfgx_dropout_keep(uint64_t seed, uint32_t item, float rate)
+{
+    return drop_scale(make_drop(rate, seed, 0), item) != 0.0f ? 1 : 0;
 }
 
 extern "C" int tfgx_head_mean_f32(const float* in, int64_t ld_in, int64_t n, int32_t H, int32_t U,

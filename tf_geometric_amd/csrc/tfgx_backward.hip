@@ -249,7 +249,16 @@ struct GB {
     float* gq; int64_t ldgq;
     float* gk; int64_t ldgk;
     float* gv; int64_t ldgv;
+    DropCfg drop;                    // the forward's attention dropout (keep mask regenerated from the edge position)
+    const int32_t* pos;              // src pass: forward-CSR position of each transposed position (NULL: identity)
 };
+
+// keep_scale_or_0 of edge (position p of this pass, destination r when it is the appended self-loop) for head h
+__device__ __forceinline__ float edge_keep(const GB& a, int64_t p, bool self_loop, int64_t r, int h)
+{
+    const int64_t fwd = self_loop ? a.drop.self_base + r : (a.pos ? int64_t(a.pos[p]) : p);
+    return drop_scale(a.drop, uint32_t(fwd * a.H + h));
+}
 
 __device__ __forceinline__ float edge_alpha(const GB& a, int64_t r, int64_t c, int h, float& s_out)
 {
@@ -262,13 +271,14 @@ __device__ __forceinline__ float edge_alpha(const GB& a, int64_t r, int64_t c, i
     return expf(s - a.ml[r * 2 * a.H + 2 * h]) / (a.ml[r * 2 * a.H + 2 * h + 1] + 1e-8f);
 }
 
-__device__ __forceinline__ float edge_ds(const GB& a, int64_t r, int64_t c, int h, float alpha)
+__device__ __forceinline__ float edge_ds(const GB& a, int64_t r, int64_t c, int h, float alpha, float keep)
 {
     const float* gop = a.go + r * a.ldgo + h * a.dv;
     const float* vp = a.v + c * a.ldv + h * a.dv;
     float da = 0.0f;
     for (int u = 0; u < a.dv; ++u) da = fmaf(gop[u], vp[u], da);
-    return alpha * (da - a.dsum[r * a.H + h]);    // softmax backward: ds = alpha * (dalpha - sum alpha*dalpha)
+    // softmax backward: ds = alpha * (dalpha - sum alpha*dalpha), dalpha = keep * <dO, V> under attention dropout
+    return alpha * (keep * da - a.dsum[r * a.H + h]);
 }
 
 // one lane per (destination r, head h): dQ[r,h,:] = sum_e ds_e * K[c_e,h,:] / scale
@@ -288,7 +298,7 @@ __global__ __launch_bounds__(kBlock) void gat_backward_dst_kernel(const GB a)
             const int64_t c = (i == e) ? r : a.other[i];
             float sc;
             const float alpha = edge_alpha(a, r, c, h, sc);
-            const float ds = edge_ds(a, r, c, h, alpha) / a.scale;
+            const float ds = edge_ds(a, r, c, h, alpha, edge_keep(a, i, i == e, r, h)) / a.scale;
             const float* kp = a.k + c * a.ldk + h * a.d;
             for (int u = 0; u < a.d; ++u) gqp[u] = fmaf(ds, kp[u], gqp[u]);
         }
@@ -314,11 +324,12 @@ __global__ __launch_bounds__(kBlock) void gat_backward_src_kernel(const GB a)
             const int64_t r = (i == e) ? c : a.other[i];
             float sc;
             const float alpha = edge_alpha(a, r, c, h, sc);
-            const float ds = edge_ds(a, r, c, h, alpha) / a.scale;
+            const float keep = edge_keep(a, i, i == e, r, h);
+            const float ds = edge_ds(a, r, c, h, alpha, keep) / a.scale;
             const float* qp = a.q + r * a.ldq + h * a.d;
             const float* gop = a.go + r * a.ldgo + h * a.dv;
             for (int u = 0; u < a.d; ++u) gkp[u] = fmaf(ds, qp[u], gkp[u]);
-            for (int u = 0; u < a.dv; ++u) gvp[u] = fmaf(alpha, gop[u], gvp[u]);
+            for (int u = 0; u < a.dv; ++u) gvp[u] = fmaf(alpha * keep, gop[u], gvp[u]);
         }
     }
 }
@@ -379,7 +390,7 @@ __global__ __launch_bounds__(kBlock) void gat_backward_fast_kernel(const GB a)
             linv_r = 1.0f / (a.ml[row * 2 * a.H + 2 * head + 1] + 1e-8f);
             d_r = a.dsum[row * a.H + head];
         }
-        auto edge = [&](int64_t o) {   // o: the other endpoint (source c for dst pass, destination r for src pass)
+        auto edge = [&](int64_t o, float keep) {   // o: the other endpoint (source c / destination r); keep: dropout
             float oth_qk[D];
             const float sc = dot_d<D>(mine_qk, (SRC ? a.q + o * a.ldq : a.k + o * a.ldk) + head * a.d, oth_qk) / a.scale;
             float oth_v[VEC];
@@ -395,21 +406,24 @@ __global__ __launch_bounds__(kBlock) void gat_backward_fast_kernel(const GB a)
                 dd = a.dsum[o * a.H + head];
             }
             const float alpha = expf(sc - m) * linv;
-            const float ds = alpha * (da - dd) / a.scale;
+            const float ds = alpha * (keep * da - dd) / a.scale;
 #pragma unroll
             for (int t = 0; t < D; ++t) acc_qk[t] = fmaf(ds, oth_qk[t], acc_qk[t]);
             if (SRC) {
+                const float ak = alpha * keep;
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) acc_v[i] = fmaf(alpha, oth_v[i], acc_v[i]);
+                for (int i = 0; i < VEC; ++i) acc_v[i] = fmaf(ak, oth_v[i], acc_v[i]);
             }
         };
         for (int base = s0; base < e0; base += G) {
             const int idx = base + lane;
             const int oj = (idx < e0) ? a.other[idx] : 0;
+            const int pj = (a.drop.thr != 0u && a.pos && idx < e0) ? a.pos[idx] : idx;   // forward-CSR position
             const int cnt = min(G, e0 - base);
-            for (int j = 0; j < cnt; ++j) edge(int64_t(__shfl(oj, j, G)));
+            for (int j = 0; j < cnt; ++j)
+                edge(int64_t(__shfl(oj, j, G)), drop_scale(a.drop, uint32_t(int64_t(__shfl(pj, j, G)) * a.H + head)));
         }
-        if (a.add_self_loop) edge(row);
+        if (a.add_self_loop) edge(row, drop_scale(a.drop, uint32_t((a.drop.self_base + row) * a.H + head)));
         if (SRC) {
             if (cvalid) store_vec<VEC>(a.gv + row * a.ldgv + coff, acc_v);
         }
@@ -543,6 +557,9 @@ static int fill_gb(const tfgx_gat_backward_args* p, GB& a)
     a.H = p->H; a.d = p->d; a.dv = p->dv; a.add_self_loop = p->add_self_loop; a.scale = p->scale;
     a.gq = p->grad_q; a.ldgq = p->ld_grad_q; a.gk = p->grad_k; a.ldgk = p->ld_grad_k;
     a.gv = p->grad_v; a.ldgv = p->ld_grad_v;
+    TFGX_REQUIRE(p->drop_rate >= 0.0f && p->drop_rate < 1.0f, "drop_rate outside [0, 1)");
+    a.drop = make_drop(p->drop_rate, p->drop_seed, p->drop_self_base);
+    a.pos = nullptr;
     return TFGX_OK;
 }
 
@@ -568,6 +585,8 @@ extern "C" int tfgx_gat_backward_src_f32(const tfgx_gat_backward_args* p, tfgx_s
     TFGX_REQUIRE(p->row_ptr_t && p->grad_k && p->grad_v && p->n_src >= 0, "src pass needs row_ptr_t / grad_k / grad_v");
     if (p->n_src == 0) return TFGX_OK;
     a.row_ptr = p->row_ptr_t; a.other = p->dst_t; a.n = p->n_src;
+    TFGX_REQUIRE(p->drop_rate == 0.0f || p->edge_pos_t, "the src pass needs edge_pos_t to regenerate the dropout mask");
+    a.pos = p->drop_rate > 0.0f ? p->edge_pos_t : nullptr;
     if (gat_bwd_fast_ok(p)) return launch_gat_bwd<true>(a, as_stream(stream));
     gat_backward_src_kernel<<<grid_for(a.n * a.H, kBlock), kBlock, 0, as_stream(stream)>>>(a);
     TFGX_LAUNCH_CHECK("gat_backward_src_kernel");

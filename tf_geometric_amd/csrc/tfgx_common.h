@@ -80,6 +80,44 @@ __device__ __forceinline__ void store_vec(float* p, const float (&v)[VEC])
     *reinterpret_cast<T*>(p) = t;
 }
 
+// ---- dropout decisions: a pure function of (seed, item), so the forward kernel, both backward kernels and the host
+// (tfgx_dropout_keep, used by the tests) regenerate the same mask.  murmur3 finaliser over item ^ seed_lo, mixed with
+// seed_hi between the two multiplies; keep <=> top 24 bits >= rate * 2^24.
+__host__ __device__ inline uint32_t drop_hash(uint64_t seed, uint32_t item)
+{
+    uint32_t x = item ^ static_cast<uint32_t>(seed);
+    x ^= x >> 16;
+    x *= 0x85ebca6bu;
+    x ^= static_cast<uint32_t>(seed >> 32);
+    x ^= x >> 13;
+    x *= 0xc2b2ae35u;
+    x ^= x >> 16;
+    return x;
+}
+
+struct DropCfg {
+    uint32_t thr;       // 0 = dropout off
+    float keep_scale;   // 1 / (1 - rate)
+    uint64_t seed;
+    int64_t self_base;
+};
+
+inline DropCfg make_drop(float rate, uint64_t seed, int64_t self_base)
+{
+    DropCfg c;
+    c.thr = rate > 0.0f ? static_cast<uint32_t>(rate * 16777216.0f) : 0u;
+    c.keep_scale = rate > 0.0f ? 1.0f / (1.0f - rate) : 1.0f;
+    c.seed = seed;
+    c.self_base = self_base;
+    return c;
+}
+
+__host__ __device__ inline float drop_scale(const DropCfg& c, uint32_t item)
+{
+    if (c.thr == 0u) return 1.0f;
+    return (drop_hash(c.seed, item) >> 8) >= c.thr ? c.keep_scale : 0.0f;
+}
+
 inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
 }  // namespace tfgx

@@ -79,7 +79,8 @@ class GCN(Layer):
                     else:
                         cache[CACHE_KEY_PLAN] = sparse_adj.plan
                     cache[key] = sparse_adj
-        return gcn(as_f32(x), sparse_adj, self.kernel, self.bias, activation=self.activation,
+        x_in = x if (isinstance(x, SparseMatrix) or getattr(x, "is_sparse", False)) else as_f32(x)   # sparse x: :269-270
+        return gcn(x_in, sparse_adj, self.kernel, self.bias, activation=self.activation,
                    norm=self.norm, add_self_loop=self.add_self_loop, sym=self.sym, renorm=self.renorm,
                    improved=self.improved, edge_drop_rate=self.edge_drop_rate,
                    num_or_size_splits=self.num_or_size_splits if split else None,

@@ -57,15 +57,26 @@ def gat_args(Q, K, V, num_heads, n_dst, col, add_self_loop=True, bias=None, act=
     return a, out, (Q, K, V)
 
 
-def gat_attention(plan, Q, K, V, num_heads, add_self_loop=True, bias=None, act=L.ACT_NONE, stats_ml=None):
+def new_drop_seed():
+    """A fresh 64-bit dropout seed from torch's host generator (torch.manual_seed makes training runs repeatable)."""
+    hi, lo = torch.randint(0, 2 ** 31 - 1, (2,)).tolist()
+    return (int(hi) << 32) | int(lo)
+
+
+def gat_attention(plan, Q, K, V, num_heads, add_self_loop=True, bias=None, act=L.ACT_NONE, stats_ml=None,
+                  drop_rate=0.0, drop_seed=0):
     """Fused SDDMM + edge softmax + SpMM over `plan` (tfgx_gat_fused_f32). Q:[n_dst,A] K:[n_src,A] V:[n_src,W].
-    Destinations with very many in-edges (plan.hub_info()) are processed chunk-wise and merged."""
+    Destinations with very many in-edges (plan.hub_info()) are processed chunk-wise and merged.
+    drop_rate > 0 (training): the softmax weights are dropped / rescaled inside the kernel (gat.py:85); the keep
+    decision is a function of (drop_seed, CSR position, head), positions [E, E+n) being the appended self-loops."""
     lib = L.require_gpu()
     a, out, keep = gat_args(Q, K, V, num_heads, plan.n_dst, plan.col, add_self_loop, bias, act)
     a.row_ptr = plan.row_ptr.data_ptr()
     if stats_ml is not None:
         a.stats_ml = stats_ml.data_ptr()      # (m, l) per row and head, kept for the backward pass
-    hub = plan.hub_info()
+    if drop_rate > 0.0:
+        a.drop_rate, a.drop_seed, a.drop_self_base = float(drop_rate), int(drop_seed), plan.num_edges
+    hub = plan.hub_info() if drop_rate <= 0.0 else None      # the chunk-merge path has no dropout; long rows run inline
     if hub is not None:
         hub_rows, chunk_ptr, chunk_begin, chunk_end, chunk_row = hub
         W, nc = int(keep[2].shape[1]), int(chunk_begin.shape[0])
@@ -81,13 +92,15 @@ def gat_attention(plan, Q, K, V, num_heads, add_self_loop=True, bias=None, act=L
     return out
 
 
-def _gat_train(x, plan, wq, bq, qact, wk, bk, kact, kernel, bias, activation, num_heads, split_value_heads):
+def _gat_train(x, plan, wq, bq, qact, wk, bk, kact, kernel, bias, activation, num_heads, split_value_heads,
+               drop_rate=0.0):
     """Differentiable route (autograd.py): same math, un-fused epilogues."""
     def lin(w, b, actv):
         code, post = _resolve_act(actv)
         return AG.apply_activation(AG.linear(x, w, b, code), L.ACT_NONE, post)
     Q, K, V = lin(wq, bq, qact), lin(wk, bk, kact), AG.linear(x, kernel)
-    h = AG.gat_attention(plan, Q, K, V, num_heads)
+    h = AG.gat_attention(plan, Q, K, V, num_heads, drop_rate=drop_rate,
+                         drop_seed=new_drop_seed() if drop_rate > 0.0 else 0)
     if not split_value_heads:
         U = int(V.shape[1]) // num_heads
         h = h.view(h.shape[0], num_heads, U).sum(1) / num_heads
@@ -112,14 +125,15 @@ def gat(x, edge_index,
     :return: [num_nodes, num_output_features]
     """
     lib = L.require_gpu()
-    if training and edge_drop_rate > 0.0:
-        raise NotImplementedError("attention dropout is a training-time op; this backend is inference-only")
+    drop = float(edge_drop_rate) if training else 0.0           # SparseMatrix.dropout(rate, training) (:85)
+    if not 0.0 <= drop < 1.0:
+        raise Exception("edge_drop_rate must be in [0, 1)")
     x = L.as_f32(x)
     n = int(x.shape[0])
     plan = CsrPlan.from_cache(edge_index, n, n, cache)
-    if AG.needs_grad(x, query_kernel, query_bias, key_kernel, key_bias, kernel, bias):
+    if drop > 0.0 or AG.needs_grad(x, query_kernel, query_bias, key_kernel, key_bias, kernel, bias):
         return _gat_train(x, plan, query_kernel, query_bias, query_activation, key_kernel, key_bias, key_activation,
-                          kernel, bias, activation, num_heads, split_value_heads)
+                          kernel, bias, activation, num_heads, split_value_heads, drop_rate=drop)
     Q, K, V = _project_qkv(x, query_kernel, query_bias, query_activation, key_kernel, key_bias, key_activation, kernel)
     act, post = _resolve_act(activation)
     bias_t = None if bias is None else L.as_f32(bias).contiguous()

@@ -38,9 +38,19 @@ class NormedAdj(object):
         return self.matmul(h)
 
     def dropout(self, rate, training=False):
-        if training and rate > 0.0:
-            raise NotImplementedError("edge dropout is a training-time op; this backend is inference-only")
-        return self
+        """SparseMatrix.dropout on the normalised values (gcn.py:262): every stored entry — the edges AND the diagonal
+        the normalisation added — is kept with probability 1 - rate and rescaled by 1 / (1 - rate) (tf.nn.dropout
+        semantics).  Identity unless training; the plan is shared, only the two value arrays are new."""
+        if not training or rate <= 0.0:
+            return self
+        if not rate < 1.0:
+            raise Exception("edge_drop_rate must be in [0, 1)")
+        scale = 1.0 / (1.0 - float(rate))
+        w = self.w_csr * ((torch.rand_like(self.w_csr) >= rate).to(torch.float32) * scale)
+        sc = self.self_coef
+        if sc is not None:
+            sc = sc * ((torch.rand_like(sc) >= rate).to(torch.float32) * scale)
+        return NormedAdj(self.plan, w, sc, self.shape)
 
     def to_sparse_matrix(self):
         """COO view in the reference's layout: input edges (CSR order) followed by the N diagonal entries."""
@@ -135,12 +145,17 @@ def gcn_mapper(repeated_x, neighbor_x, edge_weight=None):
     return _m(repeated_x, neighbor_x, edge_weight)
 
 
+def _from_torch_sparse(x):
+    x = x.coalesce()
+    return SparseMatrix(x.indices().to(torch.int32), x.values(), list(x.shape))
+
+
 def gcn(x, sparse_adj, kernel, bias=None, activation=None, norm="both", add_self_loop=True, sym=True,
         renorm=True, improved=False, edge_drop_rate=0.0, num_or_size_splits=None, training=False, cache=None):
     """
     Functional GCN (reference: gcn.py:225-290; same arguments).
 
-    :param x: [num_nodes, num_features]
+    :param x: [num_nodes, num_features]; dense, or sparse (this package's SparseMatrix / a torch sparse COO tensor)
     :param sparse_adj: SparseMatrix adjacency
     :param kernel: [num_features, num_output_features] or None (skip the GEMM, :266-267)
     :param num_or_size_splits: accepted for compatibility; it bounds memory in the reference and never changes
@@ -148,8 +163,15 @@ def gcn(x, sparse_adj, kernel, bias=None, activation=None, norm="both", add_self
     :return: [num_nodes, num_output_features]
     """
     L.require_gpu()
-    if getattr(x, "is_sparse", False):
-        raise NotImplementedError("sparse node features are outside the hot path (gcn.py:269-270)")
+    if isinstance(x, SparseMatrix) or getattr(x, "is_sparse", False):
+        # sparse node features (one-hot / bag-of-words rows; tf.sparse.sparse_dense_matmul, :269-270):
+        # x @ W is itself a gather-scale-segment-sum with the KERNEL as the source table — the same HIP kernel
+        if kernel is None:
+            raise Exception("sparse node features need a kernel (the reference would propagate the SparseTensor itself)")
+        xs = x if isinstance(x, SparseMatrix) else _from_torch_sparse(x)
+        x = (AG.aggregate(xs.plan, L.as_f32(kernel), L.SUM, xs.value_csr) if AG.needs_grad(kernel)
+             else xs.matmul(L.as_f32(kernel)))
+        kernel = None
     normed = gcn_norm_adj(sparse_adj, norm=norm, add_self_loop=add_self_loop, sym=sym, renorm=renorm,
                           improved=improved, cache=cache)                                         # :260
     normed = normed.dropout(edge_drop_rate, training=training)                                    # :262

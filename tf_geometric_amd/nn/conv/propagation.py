@@ -87,13 +87,16 @@ def tagcn(x, edge_index, edge_weight, k, kernel, bias=None, activation=None, ren
 
 
 def _mlp_encoder(x, kernels, biases, dense_activation, training, dense_drop_rate, last_dense_drop_rate):
-    if training and (dense_drop_rate > 0.0 or last_dense_drop_rate > 0.0):
-        raise NotImplementedError("dropout inside APPNP / SSGC is not implemented (inference or rate 0 only)")
+    """The MLP encoder of APPNP / SSGC (appnp.py:60-80, ssgc.py:66-87): tf.nn.dropout after every hidden layer's
+    activation (dense_drop_rate) and after the last layer (last_dense_drop_rate), training only."""
     h = x
     if kernels is not None:
         last = len(kernels) - 1
         for i, (kernel, bias) in enumerate(zip(kernels, biases)):
             h = _dense(h, kernel, bias, dense_activation if i < last else None)
+            rate = dense_drop_rate if i < last else last_dense_drop_rate
+            if training and rate > 0.0:
+                h = torch.nn.functional.dropout(h, p=float(rate), training=True)
     return h
 
 

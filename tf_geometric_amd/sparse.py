@@ -96,9 +96,16 @@ class SparseMatrix(object):
         return SparseMatrix(index, value, self._shape)
 
     def dropout(self, rate, training=False):
-        if training and rate > 0.0:
-            raise NotImplementedError("edge dropout is a training-time op; this backend is inference-only")
-        return self
+        """Values kept with probability 1 - rate and rescaled by 1 / (1 - rate) when training (tf.nn.dropout on
+        .value); the index — and therefore the cached CSR plan — is shared with self."""
+        if not training or rate <= 0.0:
+            return self
+        if not rate < 1.0:
+            raise Exception("dropout rate must be in [0, 1)")
+        value = self.value * ((torch.rand_like(self.value) >= rate).to(torch.float32) * (1.0 / (1.0 - float(rate))))
+        out = SparseMatrix(self.index, value, self._shape)
+        out._plan = getattr(self, "_plan", None)
+        return out
 
     def transpose(self):
         return SparseMatrix(torch.stack([self.index[1], self.index[0]]), self.value,
