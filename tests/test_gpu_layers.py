@@ -265,7 +265,7 @@ def test_gemm_column_limited_activation(tfg, oracle):
 
 @pytest.mark.parametrize("m,k,n", [(33000, 100, 256), (40001, 36, 100), (50000, 128, 200), (32768, 100, 65), (70000, 20, 129),
                                    (33001, 60, 96), (40000, 32, 256), (35000, 128, 256), (33333, 256, 128),
-                                   (34000, 44, 224), (36000, 64, 160), (32800, 92, 192)])
+                                   (34000, 44, 224), (36000, 64, 160), (32800, 92, 192), (33000, 256, 256), (33000, 200, 384)])
 def test_gemm_streaming_kernel(tfg, oracle, m, k, n):
     """Tall-skinny shapes (M >= 32768, 64 < N <= 256, 32 <= K, K % 4 == 0, B within LDS) take the persistent
     row-streaming kernel: full steps only (K % 32 == 0), every tail length class, ragged M and N."""

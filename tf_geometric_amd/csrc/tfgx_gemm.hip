@@ -478,6 +478,17 @@ extern "C" int tfgx_gemm_bias_act_cols_f32(const float* A, int64_t lda, const fl
     TFGX_REQUIRE(lda >= K && ldb >= N && ldc >= N, "leading dimension too small");
     hipStream_t stream = as_stream(stream_);
     const int ac = int(act_cols);
+    // K * N too large for LDS but a column slice fits (hidden -> hidden, 256 -> 256): run the row-streaming kernel once
+    // per slice of 128 columns.  A is streamed once per slice; at these widths the MFMA time still dominates.
+    if (N > 128 && N <= 512 && N % 128 == 0 && !rows_ok(A, lda, M, K, N) && rows_ok(A, lda, M, K, 128)) {
+        for (int64_t n0 = 0; n0 < N; n0 += 128) {
+            const int64_t ac_slice = act_cols > n0 ? (act_cols - n0 < 128 ? act_cols - n0 : 128) : 0;
+            const int rc = tfgx_gemm_bias_act_cols_f32(A, lda, B + n0, ldb, bias ? bias + n0 : nullptr, act, ac_slice,
+                                                       C + n0, ldc, M, K, 128, stream_);
+            if (rc != TFGX_OK) return rc;
+        }
+        return TFGX_OK;
+    }
     if (rows_ok(A, lda, M, K, N)) {
 #define TFGX_ROWS_CASE(T) \
     case T: return launch_gemm_rows<T>(A, lda, B, ldb, bias, act, C, ldc, M, int(K), int(N), ac, stream)
