@@ -36,7 +36,7 @@ def gat_weights():
             (rng.standard_normal(6) * 0.2).astype(np.float32))
 
 
-def run_checks(rank, world, use_gpu, skew, results, rounds=None):
+def run_checks(rank, world, use_gpu, skew, results, rounds=None, partitioned=False):
     """Build the shard, run sharded GCN / mean / max / sum and return this rank's rows (as numpy)."""
     from tf_geometric_amd.dist.sharded import ShardedGraph
     ei, x, w, k, b = make_inputs(skew=skew)
@@ -47,7 +47,15 @@ def run_checks(rank, world, use_gpu, skew, results, rounds=None):
         from cpu_backend import NumpyBackend
         backend = NumpyBackend()
     group = dist.group.WORLD if dist.is_initialized() else None
-    sg = ShardedGraph.from_global(ei, n, edge_weight=w, group=group, backend=backend, rounds=rounds)
+
+    def make(weights):
+        if not partitioned:
+            return ShardedGraph.from_global(ei, n, edge_weight=weights, group=group, backend=backend, rounds=rounds)
+        # every rank holds a different, interleaved stripe of the edge list (destinations all over the graph)
+        part = slice(rank, None, world)
+        return ShardedGraph.from_partitioned(ei[:, part], n, edge_weight_part=None if weights is None else weights[part],
+                                             group=group, backend=backend, rounds=rounds)
+    sg = make(w)
     assert sg.rounds == (0 if world == 1 else (rounds or 1))
     be = sg.backend
     x_own = be.f32(x[sg.own_lo:sg.own_hi])
@@ -61,14 +69,14 @@ def run_checks(rank, world, use_gpu, skew, results, rounds=None):
     wq, wk, wv, bq = gat_weights()
     out["gat"] = sg.gat(x_own, be.f32(wq), be.f32(bq), 1, be.f32(wk), be.f32(bq), 1, be.f32(wv), bias=be.f32(b[:8]),
                         act=1, num_heads=2).cpu().numpy()
-    sg2 = ShardedGraph.from_global(ei, n, edge_weight=None, group=group, backend=backend, rounds=rounds)
+    sg2 = make(None)
     sg2.build_gcn_norm(norm="left", improved=True)
     out["gcn_left_improved_unweighted"] = sg2.gcn(x_own, be.f32(k)).cpu().numpy()
     results[rank] = out
     return out
 
 
-def _entry(rank, world, port, use_gpu, skew, path, rounds=None):
+def _entry(rank, world, port, use_gpu, skew, path, rounds=None, partitioned=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -76,15 +84,15 @@ def _entry(rank, world, port, use_gpu, skew, path, rounds=None):
         torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     res = {}
-    run_checks(rank, world, use_gpu, skew, res, rounds=rounds)
+    run_checks(rank, world, use_gpu, skew, res, rounds=rounds, partitioned=partitioned)
     np.save(os.path.join(path, "rank{}.npy".format(rank)), np.array([res[rank]], dtype=object), allow_pickle=True)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def spawn(world, use_gpu, skew, path, port, rounds=None):
+def spawn(world, use_gpu, skew, path, port, rounds=None, partitioned=False):
     import torch.multiprocessing as mp
-    mp.spawn(_entry, args=(world, port, use_gpu, skew, path, rounds), nprocs=world, join=True)
+    mp.spawn(_entry, args=(world, port, use_gpu, skew, path, rounds, partitioned), nprocs=world, join=True)
     return [np.load(os.path.join(path, "rank{}.npy".format(r)), allow_pickle=True)[0] for r in range(world)]
 
 

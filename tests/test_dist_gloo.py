@@ -22,6 +22,23 @@ def test_sharded_matches_oracle_gloo(tmp_path, world, skew, rounds):
         assert max(edges) <= 1.25 * (sum(edges) / world)
 
 
+@pytest.mark.parametrize("world,skew,rounds", [(2, True, 2), (3, False, None)])
+def test_from_partitioned_matches_oracle_gloo(tmp_path, world, skew, rounds):
+    """ShardedGraph.from_partitioned: every rank starts from its own stripe of the edge list (nothing edge-sized is
+    replicated); after the degree all-reduce and the edge all-to-all-v the shards give the same layer outputs."""
+    port = 29500 + random.randint(2001, 4000)
+    parts = dist_worker.spawn(world, use_gpu=False, skew=skew, path=str(tmp_path), port=port, rounds=rounds,
+                              partitioned=True)
+    parts = dist_worker.check_against_reference(parts, skew, assert_parity)
+    assert sum(p["edges"] for p in parts) > 0
+
+
+def test_from_partitioned_single_rank():
+    res = {}
+    dist_worker.run_checks(0, 1, use_gpu=False, skew=False, results=res, partitioned=True)
+    dist_worker.check_against_reference([res[0]], False, assert_parity)
+
+
 def test_single_rank_no_process_group():
     res = {}
     dist_worker.run_checks(0, 1, use_gpu=False, skew=True, results=res)

@@ -23,3 +23,9 @@ def test_sharded_world2_hip_gloo_transport(tfg, tmp_path, skew, rounds):
     port = 31500 + random.randint(0, 2000)
     parts = dist_worker.spawn(2, use_gpu=True, skew=skew, path=str(tmp_path), port=port, rounds=rounds)
     dist_worker.check_against_reference(parts, skew, assert_parity)
+
+
+def test_from_partitioned_world2_hip_gloo_transport(tfg, tmp_path):
+    port = 33600 + random.randint(0, 2000)
+    parts = dist_worker.spawn(2, use_gpu=True, skew=True, path=str(tmp_path), port=port, rounds=3, partitioned=True)
+    dist_worker.check_against_reference(parts, True, assert_parity)

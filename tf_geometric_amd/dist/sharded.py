@@ -234,13 +234,87 @@ class ShardedGraph(object):
             edge_ids = np.flatnonzero(mine)
             local = np.stack([ei_all[0][edge_ids] - lo, ei_all[1][edge_ids]]).astype(np.int32)
             w_local = None if edge_weight is None else np.asarray(edge_weight, dtype=np.float32)[edge_ids]
+        assert int(local.shape[1]) == int(rp_host[hi] - rp_host[lo])
+        self._finish_build(local, w_local, edge_ids, rounds)
+        return self
+
+    @staticmethod
+    def from_partitioned(edge_index_part, num_nodes, edge_weight_part=None, group=None, backend=None, rounds=None):
+        """Every rank passes ITS OWN PART of the global edge list (any split: file shards, a generator's stripes —
+        destinations need not be local) as a numpy [2, E_part] array, and optionally that part's weights.  Nothing
+        edge-sized is ever replicated: ranks all-reduce the in-degree histogram (N ints) to agree on the edge-balanced
+        split points, route every edge to the owner of its destination with one all-to-all-v, and from there build
+        exactly what from_global builds.  "This shard's edge order" (self.perm, weights passed later) is the arrival
+        order: parts concatenated by sending rank, each in its own order."""
+        self = ShardedGraph()
+        be = self.backend = backend or HipBackend()
+        self.group = group
+        self.world = dist.get_world_size(group) if (group is not None or dist.is_initialized()) else 1
+        self.rank = dist.get_rank(group) if (group is not None or dist.is_initialized()) else 0
+        self.n_global = int(num_nodes)
+        ei = np.asarray(edge_index_part).reshape(2, -1)
+        if ei.size and (ei.min() < 0 or ei.max() >= self.n_global):
+            raise L.TfgxError("edge endpoint outside [0, {})".format(self.n_global))
+        w_part = None if edge_weight_part is None else np.asarray(edge_weight_part, dtype=np.float32).reshape(-1)
+        deg = torch.from_numpy(np.bincount(ei[0], minlength=self.n_global).astype(np.int64))
+        if self.world > 1:
+            deg = self._all_reduce_sum_host(deg)
+        rp_host = np.zeros(self.n_global + 1, dtype=np.int64)
+        np.cumsum(deg.numpy(), out=rp_host[1:])
+        self.bounds = edge_balanced_bounds(rp_host, self.world)
+        lo, hi = int(self.bounds[self.rank]), int(self.bounds[self.rank + 1])
+        self.own_lo, self.own_hi, self.n_own = lo, hi, hi - lo
+        self.num_edges_global = int(rp_host[-1])
+        if self.world > 1:
+            # destination owner of every edge of my part; a stable sort by owner keeps each part's own order
+            owner = np.searchsorted(self.bounds, ei[0], side="right") - 1
+            owner = np.minimum(owner, self.world - 1)
+            order = np.argsort(owner, kind="stable")
+            send_counts = np.bincount(owner, minlength=self.world).astype(np.int64)
+            sc = torch.from_numpy(send_counts.copy())
+            rc = torch.empty(self.world, dtype=torch.int64)
+            self._a2a_host(rc, sc, [1] * self.world, [1] * self.world)
+            recv_counts = [int(v) for v in rc.tolist()]
+            send_list = [int(v) for v in send_counts.tolist()]
+            got = []
+            for arr in (ei[0], ei[1]):
+                out = torch.empty(sum(recv_counts), dtype=torch.int64)
+                self._a2a_host(out, torch.from_numpy(arr[order].astype(np.int64)), recv_counts, send_list)
+                got.append(out.numpy())
+            if w_part is not None:
+                wout = torch.empty(sum(recv_counts), dtype=torch.int64)
+                self._a2a_host(wout, torch.from_numpy(w_part[order].view(np.int32).astype(np.int64)), recv_counts, send_list)
+                w_local = wout.numpy().astype(np.int32).view(np.float32)
+            else:
+                w_local = None
+            rows, cols = got
+        else:
+            rows, cols, w_local = ei[0].astype(np.int64), ei[1].astype(np.int64), w_part
+        assert rows.size == 0 or (rows.min() >= lo and rows.max() < hi)
+        local = np.stack([rows - lo, cols]).astype(np.int32)
+        assert int(local.shape[1]) == int(rp_host[hi] - rp_host[lo])
+        self._finish_build(local, w_local, np.arange(local.shape[1], dtype=np.int64), rounds)
+        return self
+
+    def _all_reduce_sum_host(self, t):
+        """Sum a host int64 tensor over the group (through the GPU when the group is NCCL)."""
+        if dist.get_backend(self.group) == "nccl":
+            d = t.to(self.backend.device)
+            dist.all_reduce(d, group=self.group)
+            return d.cpu()
+        dist.all_reduce(t, group=self.group)
+        return t
+
+    def _finish_build(self, local, w_local, edge_ids, rounds):
+        """Steps 3b-6 of the shard build from this rank's edges (`local`: [2, E_own], destinations already relative to
+        own_lo, in this shard's edge order; `edge_ids`: what self.perm should point at)."""
+        be = self.backend
+        lo, hi = self.own_lo, self.own_hi
         self.num_edges = int(local.shape[1])
-        assert self.num_edges == int(rp_host[hi] - rp_host[lo])
         self.row_ptr, col_slice, perm_local = be.build_csr(be.i32(local), self.n_own, self.n_global)
         w_slice = None if w_local is None else be.permute_rows(w_local, perm_local)
         ids_dev = be.i32(edge_ids) if not isinstance(edge_ids, torch.Tensor) else edge_ids.to(torch.int32).to(be.device)
         self.perm = ids_dev[perm_local.long()].contiguous()     # CSR position -> global edge id (caller's order)
-        del local, mine
 
         # 4. halo: remote sources, sorted + de-duplicated; col remapped into [own | halo]
         self.halo_ids, col_local = be.halo_plan(col_slice, lo, hi, self.n_global)
@@ -268,7 +342,6 @@ class ShardedGraph(object):
                     for k in range(K1)]
         self.norm_w = None
         self.self_coef = None
-        return self
 
     def _build_exchange_lists(self):
         be, W = self.backend, self.world
