@@ -273,6 +273,11 @@ typedef struct tfgx_gat_backward_args {
     uint64_t drop_seed;
     int64_t drop_self_base;
     const int32_t* edge_pos_t;                    /* [E] or NULL when drop_rate == 0 */
+    /* row strides of stats_ml / dsum; 0 = dense (2H / H).  The src pass gathers, per edge, the destination's dO, Q,
+       (m, l) and D rows: a caller that interleaves them into ONE row per destination (then grad_out / q / stats_ml /
+       dsum point into that table with its row stride) turns four gathers into one contiguous burst. */
+    int64_t ld_stats_ml;
+    int64_t ld_dsum;
 } tfgx_gat_backward_args;
 
 int tfgx_gat_backward_dst_f32(const tfgx_gat_backward_args* args /* host */, tfgx_stream_t stream);

@@ -83,6 +83,7 @@ class GatBackwardArgs(ctypes.Structure):
         ("grad_v", ctypes.c_void_p), ("ld_grad_v", ctypes.c_int64),
         ("drop_rate", ctypes.c_float), ("reserved2", ctypes.c_int32), ("drop_seed", ctypes.c_uint64),
         ("drop_self_base", ctypes.c_int64), ("edge_pos_t", ctypes.c_void_p),
+        ("ld_stats_ml", ctypes.c_int64), ("ld_dsum", ctypes.c_int64),
     ]
 
 

@@ -202,6 +202,19 @@ class _GatAttention(torch.autograd.Function):
             a.drop_rate, a.drop_seed, a.drop_self_base = ctx.drop[0], ctx.drop[1], plan.num_edges
             a.edge_pos_t = t2d.data_ptr()
         L.check(lib.tfgx_gat_backward_dst_f32(ctypes.byref(a), L.stream_ptr()), "tfgx_gat_backward_dst_f32")
+        # src pass: per edge it gathers the DESTINATION's dO, Q, (m, l) and D rows.  Interleave them into one row per
+        # destination, padded to whole 128-byte lines: one burst of P*4 bytes per edge instead of four gathers
+        # (H=8, A=8, U=64: 96 floats = 3 lines instead of 5).
+        P = -(-(W + A + 3 * H) // 32) * 32
+        pack = torch.empty((n, P), dtype=torch.float32, device=g2.device)
+        pack[:, :W] = g2
+        pack[:, W:W + A] = Q2
+        pack[:, W + A:W + A + 2 * H] = stats
+        pack[:, W + A + 2 * H:W + A + 3 * H] = dsum
+        a.grad_out, a.ld_grad_out = pack.data_ptr(), P
+        a.q, a.ldq = pack.data_ptr() + 4 * W, P
+        a.stats_ml, a.ld_stats_ml = pack.data_ptr() + 4 * (W + A), P
+        a.dsum, a.ld_dsum = pack.data_ptr() + 4 * (W + A + 2 * H), P
         L.check(lib.tfgx_gat_backward_src_f32(ctypes.byref(a), L.stream_ptr()), "tfgx_gat_backward_src_f32")
         return None, None, gq, gk, gv, None, None
 

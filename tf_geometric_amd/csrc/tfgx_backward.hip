@@ -244,6 +244,7 @@ struct GB {
     const float* go; int64_t ldgo;   // dO [n_dst, H*dv]
     const float* ml;                 // [n_dst, 2H] saved (m, l) of the forward softmax
     const float* dsum;               // [n_dst, H]  D = <dO, O> per head
+    int64_t ldml, lddsum;            // row strides of ml / dsum (2H / H unless the caller packed the per-row data)
     int32_t H, d, dv, add_self_loop;
     float scale;
     float* gq; int64_t ldgq;
@@ -268,7 +269,7 @@ __device__ __forceinline__ float edge_alpha(const GB& a, int64_t r, int64_t c, i
     for (int u = 0; u < a.d; ++u) dot = fmaf(qp[u], kp[u], dot);
     const float s = dot / a.scale;
     s_out = s;
-    return expf(s - a.ml[r * 2 * a.H + 2 * h]) / (a.ml[r * 2 * a.H + 2 * h + 1] + 1e-8f);
+    return expf(s - a.ml[r * a.ldml + 2 * h]) / (a.ml[r * a.ldml + 2 * h + 1] + 1e-8f);
 }
 
 __device__ __forceinline__ float edge_ds(const GB& a, int64_t r, int64_t c, int h, float alpha, float keep)
@@ -278,7 +279,7 @@ __device__ __forceinline__ float edge_ds(const GB& a, int64_t r, int64_t c, int 
     float da = 0.0f;
     for (int u = 0; u < a.dv; ++u) da = fmaf(gop[u], vp[u], da);
     // softmax backward: ds = alpha * (dalpha - sum alpha*dalpha), dalpha = keep * <dO, V> under attention dropout
-    return alpha * (keep * da - a.dsum[r * a.H + h]);
+    return alpha * (keep * da - a.dsum[r * a.lddsum + h]);
 }
 
 // one lane per (destination r, head h): dQ[r,h,:] = sum_e ds_e * K[c_e,h,:] / scale
@@ -386,9 +387,9 @@ __global__ __launch_bounds__(kBlock) void gat_backward_fast_kernel(const GB a)
         for (int i = 0; i < VEC; ++i) acc_v[i] = 0.0f;
         float m_r = 0.0f, linv_r = 0.0f, d_r = 0.0f;
         if (!SRC) {
-            m_r = a.ml[row * 2 * a.H + 2 * head];
-            linv_r = 1.0f / (a.ml[row * 2 * a.H + 2 * head + 1] + 1e-8f);
-            d_r = a.dsum[row * a.H + head];
+            m_r = a.ml[row * a.ldml + 2 * head];
+            linv_r = 1.0f / (a.ml[row * a.ldml + 2 * head + 1] + 1e-8f);
+            d_r = a.dsum[row * a.lddsum + head];
         }
         auto edge = [&](int64_t o, float keep) {   // o: the other endpoint (source c / destination r); keep: dropout
             float oth_qk[D];
@@ -401,9 +402,9 @@ __global__ __launch_bounds__(kBlock) void gat_backward_fast_kernel(const GB a)
             const float da = head_sum<G>(part, lh);
             float m = m_r, linv = linv_r, dd = d_r;
             if (SRC) {
-                m = a.ml[o * 2 * a.H + 2 * head];
-                linv = 1.0f / (a.ml[o * 2 * a.H + 2 * head + 1] + 1e-8f);
-                dd = a.dsum[o * a.H + head];
+                m = a.ml[o * a.ldml + 2 * head];
+                linv = 1.0f / (a.ml[o * a.ldml + 2 * head + 1] + 1e-8f);
+                dd = a.dsum[o * a.lddsum + head];
             }
             const float alpha = expf(sc - m) * linv;
             const float ds = alpha * (keep * da - dd) / a.scale;
@@ -554,6 +555,9 @@ static int fill_gb(const tfgx_gat_backward_args* p, GB& a)
     TFGX_REQUIRE(p->q && p->k && p->v && p->grad_out && p->stats_ml && p->dsum, "null pointer");
     a.q = p->q; a.ldq = p->ldq; a.k = p->k; a.ldk = p->ldk; a.v = p->v; a.ldv = p->ldv;
     a.go = p->grad_out; a.ldgo = p->ld_grad_out; a.ml = p->stats_ml; a.dsum = p->dsum;
+    a.ldml = p->ld_stats_ml > 0 ? p->ld_stats_ml : 2 * int64_t(p->H);
+    a.lddsum = p->ld_dsum > 0 ? p->ld_dsum : int64_t(p->H);
+    TFGX_REQUIRE(a.ldml >= 2 * p->H && a.lddsum >= p->H, "ld_stats_ml / ld_dsum too small");
     a.H = p->H; a.d = p->d; a.dv = p->dv; a.add_self_loop = p->add_self_loop; a.scale = p->scale;
     a.gq = p->grad_q; a.ldgq = p->ld_grad_q; a.gk = p->grad_k; a.ldgk = p->ld_grad_k;
     a.gv = p->grad_v; a.ldgv = p->ld_grad_v;
