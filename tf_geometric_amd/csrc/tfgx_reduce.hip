@@ -374,7 +374,10 @@ extern "C" int tfgx_segment_reduce_f32(const tfgx_reduce_args* p, tfgx_stream_t 
         if (p->bias) good = good && aligned_to(p->bias, al);
         return good;
     };
-    const int vec = ok(4) ? 4 : (ok(2) ? 2 : 1);
+    int vec = ok(4) ? 4 : (ok(2) ? 2 : 1);
+    // narrow rows: prefer 8 lanes with narrower loads over 4 lanes x dwordx4 — 8 rows per wave instead of 16 (less
+    // degree divergence inside a wave) and 8 edges in flight per row instead of 4
+    while (vec > 1 && p->F / vec < 8) vec /= 2;
     int rc = launch_any(a, vec, is_max, weighted, stream);
     if (rc != TFGX_OK || !use_hub) return rc;
 

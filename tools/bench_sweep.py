@@ -66,7 +66,7 @@ def main():
     E = int(ei.shape[1])
     plan = CsrPlan.build(ei, n, n)
     w = torch.rand(E, device="cuda") + 0.5
-    for f in ([16, 32, 64, 96, 100, 104, 128, 192, 256] if want("widths") else []):
+    for f in ([8, 16, 32, 40, 64, 96, 100, 104, 128, 192, 256] if want("widths") else []):
         x = torch.randn(n, f, device="cuda")
         out = torch.empty_like(x)
         for name, op, ww in [("sum_w", L.SUM, w), ("sum", L.SUM, None), ("max", L.MAX, None)]:
