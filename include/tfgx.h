@@ -241,6 +241,11 @@ int tfgx_sddmm_f32(const int32_t* row_ptr, const int32_t* col, int64_t n_dst, co
 int tfgx_segment_max_count_f32(const int32_t* row_ptr, const int32_t* col, const float* w /* or NULL */, int64_t n_dst,
                                const float* x, int64_t ldx, int64_t F, const float* out, int64_t ldo, float* count,
                                int64_t ldc, tfgx_stream_t stream);
+/* d(max aggregate)/d(edge weight), forward-CSR order: grad_w[i] = sum_j [w[i]*x[col[i],j] == out[r,j]] * x[col[i],j] * gn[r,j]
+   with gn = grad_out / count (the tie-splitting of tf.math.unsorted_segment_max's gradient), r = row of position i */
+int tfgx_segment_max_backward_w_f32(const int32_t* row_ptr, const int32_t* col, const float* w, int64_t n_dst,
+                                    const float* x, int64_t ldx, int64_t F, const float* out, int64_t ldo,
+                                    const float* gn, int64_t ldgn, float* grad_w, tfgx_stream_t stream);
 int tfgx_segment_max_backward_f32(const int32_t* row_ptr_t, const int32_t* dst_t, const float* w_t /* or NULL */,
                                   int64_t n_src, const float* x, int64_t ldx, int64_t F, const float* out, int64_t ldo,
                                   const float* g, int64_t ldg, const float* count, int64_t ldc, float* gx, int64_t ldgx,

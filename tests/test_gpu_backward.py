@@ -38,7 +38,7 @@ def test_aggregate_grad_x_and_w(tfg, oracle, op, weighted):
     n = x.shape[0]
     gout = rng.standard_normal(x.shape).astype(np.float32)
     xt = torch.tensor(x, device="cuda", requires_grad=True)
-    wt = torch.tensor(w, device="cuda", requires_grad=(weighted and op != "max")) if weighted else None
+    wt = torch.tensor(w, device="cuda", requires_grad=weighted) if weighted else None
     red = getattr(tfg.nn, op + "_reducer")
     mapper = tfg.nn.gcn_mapper if weighted else tfg.nn.identity_mapper
     out = tfg.nn.aggregate_neighbors(xt, ei, wt, mapper, red, tfg.nn.sum_updater)
@@ -49,7 +49,7 @@ def test_aggregate_grad_x_and_w(tfg, oracle, op, weighted):
     ref.backward(torch.tensor(gout, dtype=torch.float64))
     assert_parity(out.detach().cpu().numpy(), ref.detach().numpy(), what="forward " + op)
     assert_parity(xt.grad.cpu().numpy(), xr.grad.numpy(), tol=2e-5, what="d/dx " + op)
-    if weighted and op != "max":
+    if weighted:      # max included: d/dw flows to the edges that attain the row maximum (tfgx_segment_max_backward_w_f32)
         assert_parity(wt.grad.cpu().numpy(), wr.grad.numpy(), tol=2e-5, what="d/dw " + op)
 
 

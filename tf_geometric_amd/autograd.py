@@ -110,8 +110,6 @@ class _AggregateMax(torch.autograd.Function):
         lib = L.require_gpu()
         plan = ctx.plan
         x, w_csr, out = ctx.saved_tensors
-        if w_csr is not None and ctx.needs_input_grad[2]:
-            raise NotImplementedError("d(max aggregate)/d(edge_weight) is not implemented")
         x2, ldx = L.row_major_2d(x.detach())
         g2, ldg = L.row_major_2d(g.contiguous())
         F = int(x2.shape[1])
@@ -127,7 +125,14 @@ class _AggregateMax(torch.autograd.Function):
                                                   F, L.ptr(out), F, L.ptr(g2), ldg, L.ptr(count), F, L.ptr(gx), F,
                                                   plan.n_dst, L.ptr(gn), L.stream_ptr()),
                 "tfgx_segment_max_backward_f32")
-        return None, gx, None
+        gw = None
+        if w_csr is not None and ctx.needs_input_grad[2]:
+            gn2 = g2 / count.clamp(min=1.0)          # TF splits the gradient evenly among tied maxima
+            gw = torch.empty_like(w_csr)
+            L.check(lib.tfgx_segment_max_backward_w_f32(L.ptr(plan.row_ptr), L.ptr(plan.col), L.ptr(w_csr.detach()),
+                                                        plan.n_dst, L.ptr(x2), ldx, F, L.ptr(out), F, L.ptr(gn2), F,
+                                                        L.ptr(gw), L.stream_ptr()), "tfgx_segment_max_backward_w_f32")
+        return None, gx, gw
 
 
 def aggregate(plan, x, op, w_csr=None, self_coef=None):

@@ -22,7 +22,8 @@ __global__ __launch_bounds__(kBlock) void sddmm_kernel(const int32_t* __restrict
                                                        const int32_t* __restrict__ col, int64_t n_dst,
                                                        const float* __restrict__ a, int64_t lda,
                                                        const float* __restrict__ b, int64_t ldb, int F,
-                                                       float* __restrict__ out)
+                                                       float* __restrict__ out, const float* __restrict__ w = nullptr,
+                                                       const float* __restrict__ mx = nullptr, int64_t ldmx = 0)
 {
     constexpr int ROWS_PER_BLOCK = kBlock / G;
     const int lane = threadIdx.x % G, grp = threadIdx.x / G;
@@ -32,6 +33,10 @@ __global__ __launch_bounds__(kBlock) void sddmm_kernel(const int32_t* __restrict
         for (int i = s; i < e; ++i) {
             const float* br = b + int64_t(col[i]) * ldb;
             float acc = 0.0f;
+            if (mx) {   // d(max)/dw: only the features where this edge attains the row maximum contribute
+                const float wi = w[i];
+                for (int j = lane; j < F; j += G) acc = (wi * br[j] == mx[r * ldmx + j]) ? fmaf(ar[j], br[j], acc) : acc;
+            } else
             for (int j = lane; j < F; j += G) acc = fmaf(ar[j], br[j], acc);
 #pragma unroll
             for (int o = G / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, G);
@@ -44,12 +49,15 @@ __global__ __launch_bounds__(kBlock) void sddmm_kernel(const int32_t* __restrict
 // registers, U = 8 edges in flight (8 independent dwordx4 gathers per lane before the first FMA), the 8 partial dot
 // products are reduced across the group and written as one coalesced 8-wide store.  Same traffic as the forward
 // segment-sum: one gathered source row per edge.
-template <int G, int CH>
+// MASKED (d(max aggregate)/d(edge weight)): a = g / count, and only features j with w[i] * b[col[i], j] == mx[r, j]
+// (the edge attains the row maximum there) enter the dot product.
+template <int G, int CH, bool MASKED>
 __global__ __launch_bounds__(kBlock) void sddmm_fast_kernel(const int32_t* __restrict__ row_ptr,
                                                             const int32_t* __restrict__ col, int64_t n_dst,
                                                             const float* __restrict__ a, int64_t lda,
                                                             const float* __restrict__ b, int64_t ldb, int F,
-                                                            float* __restrict__ out)
+                                                            float* __restrict__ out, const float* __restrict__ w,
+                                                            const float* __restrict__ mx, int64_t ldmx)
 {
     constexpr int ROWS_PER_BLOCK = kBlock / G, U = 8;
     const int lane = threadIdx.x % G, grp = threadIdx.x / G;
@@ -61,12 +69,22 @@ __global__ __launch_bounds__(kBlock) void sddmm_fast_kernel(const int32_t* __res
             const int j = 4 * (lane + c * G);
             av[c] = j < F ? *reinterpret_cast<const float4*>(a + r * lda + j) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+        float4 mv[MASKED ? CH : 1];
+        if (MASKED) {
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const int j = 4 * (lane + c * G);
+                mv[c] = j < F ? *reinterpret_cast<const float4*>(mx + r * ldmx + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
         for (int i0 = s; i0 < e; i0 += U) {
             const int mine = (lane < U && i0 + lane < e) ? col[i0 + lane] : 0;   // a valid row for the padded slots
+            const float wmine = (MASKED && lane < U && i0 + lane < e) ? w[i0 + lane] : 0.0f;
             float acc[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int cu = __shfl(mine, u, G);
+                const float wu = MASKED ? __shfl(wmine, u, G) : 0.0f;
                 const float* br = b + int64_t(cu) * ldb;
                 float t = 0.0f;
 #pragma unroll
@@ -74,10 +92,18 @@ __global__ __launch_bounds__(kBlock) void sddmm_fast_kernel(const int32_t* __res
                     const int j = 4 * (lane + c * G);
                     if (j < F) {
                         const float4 bv = *reinterpret_cast<const float4*>(br + j);
-                        t = fmaf(av[c].x, bv.x, t);
-                        t = fmaf(av[c].y, bv.y, t);
-                        t = fmaf(av[c].z, bv.z, t);
-                        t = fmaf(av[c].w, bv.w, t);
+                        if (MASKED) {
+                            const float4 m4 = mv[c];
+                            t = (wu * bv.x == m4.x) ? fmaf(av[c].x, bv.x, t) : t;
+                            t = (wu * bv.y == m4.y) ? fmaf(av[c].y, bv.y, t) : t;
+                            t = (wu * bv.z == m4.z) ? fmaf(av[c].z, bv.z, t) : t;
+                            t = (wu * bv.w == m4.w) ? fmaf(av[c].w, bv.w, t) : t;
+                        } else {
+                            t = fmaf(av[c].x, bv.x, t);
+                            t = fmaf(av[c].y, bv.y, t);
+                            t = fmaf(av[c].z, bv.z, t);
+                            t = fmaf(av[c].w, bv.w, t);
+                        }
                     }
                 }
                 acc[u] = t;
@@ -481,30 +507,58 @@ bool gat_bwd_fast_ok(const tfgx_gat_backward_args* p)
 
 using namespace tfgx;
 
-extern "C" int tfgx_sddmm_f32(const int32_t* row_ptr, const int32_t* col, int64_t n_dst, const float* a, int64_t lda,
-                              const float* b, int64_t ldb, int64_t F, float* out, tfgx_stream_t stream)
+static int sddmm_dispatch(const char* who, const int32_t* row_ptr, const int32_t* col, int64_t n_dst, const float* a,
+                          int64_t lda, const float* b, int64_t ldb, int64_t F, float* out, const float* w,
+                          const float* mx, int64_t ldmx, hipStream_t s)
 {
-    TFGX_REQUIRE(n_dst >= 0 && F >= 1 && lda >= F && ldb >= F, "bad size");
-    if (n_dst == 0) return TFGX_OK;
-    TFGX_REQUIRE(row_ptr && a && b, "null pointer");
-    hipStream_t s = as_stream(stream);
-    if (F % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && aligned_to(a, 16) && aligned_to(b, 16) && F >= 16 && F <= 512) {
-#define TFGX_SDDMM_GO(G, CH) \
-    sddmm_fast_kernel<G, CH><<<grid_for(n_dst, kBlock / G, 1 << 20), kBlock, 0, s>>>(row_ptr, col, n_dst, a, lda, b, ldb, int(F), out)
+    const bool masked = mx != nullptr;
+    const bool al = F % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && aligned_to(a, 16) && aligned_to(b, 16) &&
+                    (!masked || (ldmx % 4 == 0 && aligned_to(mx, 16)));
+    if (al && F >= 16 && F <= 512) {
+#define TFGX_SDDMM_GO(G, CH)                                                                                          \
+    do {                                                                                                              \
+        if (masked)                                                                                                   \
+            sddmm_fast_kernel<G, CH, true><<<grid_for(n_dst, kBlock / G, 1 << 20), kBlock, 0, s>>>(                   \
+                row_ptr, col, n_dst, a, lda, b, ldb, int(F), out, w, mx, ldmx);                                       \
+        else                                                                                                          \
+            sddmm_fast_kernel<G, CH, false><<<grid_for(n_dst, kBlock / G, 1 << 20), kBlock, 0, s>>>(                  \
+                row_ptr, col, n_dst, a, lda, b, ldb, int(F), out, nullptr, nullptr, 0);                               \
+    } while (0)
         if (F <= 32) TFGX_SDDMM_GO(8, 1);
         else if (F <= 64) TFGX_SDDMM_GO(16, 1);
         else if (F <= 128) TFGX_SDDMM_GO(32, 1);
         else if (F <= 256) TFGX_SDDMM_GO(32, 2);
         else TFGX_SDDMM_GO(32, 4);
 #undef TFGX_SDDMM_GO
-        TFGX_LAUNCH_CHECK("sddmm_fast_kernel");
+        TFGX_LAUNCH_CHECK(who);
         return TFGX_OK;
     }
-    if (F <= 8) sddmm_kernel<8><<<grid_for(n_dst, kBlock / 8, 1 << 20), kBlock, 0, s>>>(row_ptr, col, n_dst, a, lda, b, ldb, int(F), out);
-    else if (F <= 32) sddmm_kernel<16><<<grid_for(n_dst, kBlock / 16, 1 << 20), kBlock, 0, s>>>(row_ptr, col, n_dst, a, lda, b, ldb, int(F), out);
-    else sddmm_kernel<32><<<grid_for(n_dst, kBlock / 32, 1 << 20), kBlock, 0, s>>>(row_ptr, col, n_dst, a, lda, b, ldb, int(F), out);
-    TFGX_LAUNCH_CHECK("sddmm_kernel");
+    if (F <= 8) sddmm_kernel<8><<<grid_for(n_dst, kBlock / 8, 1 << 20), kBlock, 0, s>>>(row_ptr, col, n_dst, a, lda, b, ldb, int(F), out, w, mx, ldmx);
+    else if (F <= 32) sddmm_kernel<16><<<grid_for(n_dst, kBlock / 16, 1 << 20), kBlock, 0, s>>>(row_ptr, col, n_dst, a, lda, b, ldb, int(F), out, w, mx, ldmx);
+    else sddmm_kernel<32><<<grid_for(n_dst, kBlock / 32, 1 << 20), kBlock, 0, s>>>(row_ptr, col, n_dst, a, lda, b, ldb, int(F), out, w, mx, ldmx);
+    TFGX_LAUNCH_CHECK(who);
     return TFGX_OK;
+}
+
+extern "C" int tfgx_sddmm_f32(const int32_t* row_ptr, const int32_t* col, int64_t n_dst, const float* a, int64_t lda,
+                              const float* b, int64_t ldb, int64_t F, float* out, tfgx_stream_t stream)
+{
+    TFGX_REQUIRE(n_dst >= 0 && F >= 1 && lda >= F && ldb >= F, "bad size");
+    if (n_dst == 0) return TFGX_OK;
+    TFGX_REQUIRE(row_ptr && a && b, "null pointer");
+    return sddmm_dispatch("sddmm_kernel", row_ptr, col, n_dst, a, lda, b, ldb, F, out, nullptr, nullptr, 0,
+                          as_stream(stream));
+}
+
+extern "C" int tfgx_segment_max_backward_w_f32(const int32_t* row_ptr, const int32_t* col, const float* w, int64_t n_dst,
+                                               const float* x, int64_t ldx, int64_t F, const float* out, int64_t ldo,
+                                               const float* gn, int64_t ldgn, float* grad_w, tfgx_stream_t stream)
+{
+    TFGX_REQUIRE(n_dst >= 0 && F >= 1 && ldx >= F && ldo >= F && ldgn >= F, "bad size");
+    if (n_dst == 0) return TFGX_OK;
+    TFGX_REQUIRE(row_ptr && col && w && x && out && gn && grad_w, "null pointer");
+    return sddmm_dispatch("sddmm_kernel<masked>", row_ptr, col, n_dst, gn, ldgn, x, ldx, F, grad_w, w, out, ldo,
+                          as_stream(stream));
 }
 
 extern "C" int tfgx_segment_max_count_f32(const int32_t* row_ptr, const int32_t* col, const float* w, int64_t n_dst,
