@@ -558,3 +558,37 @@ class ShardedGraph(object):
         table = self.alloc_table(int(x_own.shape[1]))
         self.own_rows(table).copy_(x_own)
         return self.aggregate(table, op, w="plan" if (weighted and self.w is not None) else None)
+
+    # ------------------------------------------------------------------ GraphSAGE layers
+    def _sage_combine(self, x_own, reduced, self_kernel, neighbor_kernel, bias, act, concat):
+        """x @ self_kernel (concat | +) reduced @ neighbor_kernel, + bias, activation (graph_sage.py:43-58); both
+        GEMMs are row-local.  With concat they write into the two halves of the output."""
+        be = self.backend
+        ku_x, ku_n = int(self_kernel.shape[1]), int(neighbor_kernel.shape[1])
+        if concat:
+            h = be.empty((self.n_own, ku_x + ku_n))
+            be.gemm_bias_act(x_own, self_kernel, bias=None if bias is None else bias[:ku_x], act=act, out=h[:, :ku_x])
+            be.gemm_bias_act(reduced, neighbor_kernel, bias=None if bias is None else bias[ku_x:], act=act,
+                             out=h[:, ku_x:])
+            return h
+        h = be.gemm_bias_act(x_own, self_kernel) + be.gemm_bias_act(reduced, neighbor_kernel)
+        if bias is not None:
+            h = h + bias
+        return torch.relu(h) if act == L.ACT_RELU else h
+
+    def graph_sage(self, x_own, self_kernel, neighbor_kernel, bias=None, act=L.ACT_NONE, concat=True, op=L.MEAN):
+        """Sharded mean_graph_sage / sum_graph_sage (nn/conv/graph_sage.py:9-115): raw x rows travel once, the
+        weighted mean / sum over in-edges overlaps the exchange, the two GEMMs are local."""
+        reduced = self.neighbor_reduce(x_own, op, weighted=True)
+        return self._sage_combine(x_own, reduced, self_kernel, neighbor_kernel, bias, act, concat)
+
+    def pool_graph_sage(self, x_own, self_kernel, neighbor_mlp_kernel, neighbor_kernel, neighbor_mlp_bias=None,
+                        bias=None, act=L.ACT_NONE, concat=True, op=L.MAX):
+        """Sharded mean_pool / max_pool_graph_sage (:164-287).  The reference overwrites the edge weights with ones, so
+        the per-edge MLP act(x[col] @ W + b) is a per-NODE GEMM (as on one GPU): it runs on the owner and its output
+        rows are what the halo exchange carries."""
+        be = self.backend
+        table = self.alloc_table(int(neighbor_mlp_kernel.shape[1]))
+        be.gemm_bias_act(x_own, neighbor_mlp_kernel, bias=neighbor_mlp_bias, act=act, out=self.own_rows(table))
+        reduced = self.aggregate(table, op, w=None)
+        return self._sage_combine(x_own, reduced, self_kernel, neighbor_kernel, bias, act, concat)
