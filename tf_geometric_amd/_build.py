@@ -45,7 +45,26 @@ def build(force=False, verbose=True):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+    build_c_abi_demo(force=force or bool(jobs), verbose=verbose)
     return LIB_PATH
+
+
+DEMO_SRC = os.path.join(_HERE, "..", "examples", "c_abi_demo.cpp")
+DEMO_BIN = os.path.join(LIB_DIR, "c_abi_demo")
+
+
+def build_c_abi_demo(force=False, verbose=True):
+    """examples/c_abi_demo.cpp: a HIP host program (no Python, no torch) linked against libtfgx.so through
+    include/tfgx.h — run by tests/test_gpu_c_abi.py on the GPU box."""
+    if not os.path.exists(DEMO_SRC):
+        return None
+    if force or _newer(DEMO_SRC, DEMO_BIN) or _newer(LIB_PATH, DEMO_BIN):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O2", "-I", os.path.join(_HERE, "..", "include"), DEMO_SRC,
+               "-L", LIB_DIR, "-ltfgx", "-Wl,-rpath,$ORIGIN", "-o", DEMO_BIN]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return DEMO_BIN
 
 
 if __name__ == "__main__":
