@@ -124,6 +124,12 @@ typedef struct tfgx_reduce_args {
     const float* x_tail;
     int64_t ld_tail;
     int64_t f_main;
+    /* optional, with x_tail: edge_tail[i, :] = x_tail[col[i], :] for every edge position i of THIS plan (built once per
+       (plan, x) with tfgx_gather_rows_f32).  The tail columns are then streamed next to col / w instead of gathered:
+       a 400-byte row costs three line requests + 16 streamed bytes instead of four requests.  For source features
+       that do not change between launches (the dataset's input features: layer 0 of every model, every epoch). */
+    const float* edge_tail;
+    int64_t ld_edge_tail;
 } tfgx_reduce_args;
 
 int tfgx_segment_reduce_f32(const tfgx_reduce_args* args /* host */, tfgx_stream_t stream);

@@ -181,6 +181,36 @@ def test_split_row_layout_is_bit_identical(tfg, oracle, f):
             assert torch.equal(a, b)
     ref = oracle.aggregate_neighbors(x, ei, w, oracle.gcn_mapper, oracle.sum_reducer, oracle.identity_updater)
     assert_parity(segment_reduce(plan, sp, L.SUM, w_csr=w_csr).cpu().numpy(), ref, what="split rows vs oracle")
+    # edge-resident tail (the tail columns of each edge's source row streamed next to col / w): still bit-identical,
+    # including the self-loop term (read from the node table), hub rows, and only on the plan it was built for
+    spe = SplitRows.from_dense(xd).with_edge_tail(plan)
+    assert spe.edge_tail.shape == (plan.num_edges, f - (f // 32) * 32)
+    for op in (L.SUM, L.MEAN, L.MAX):
+        for ww in (w_csr, None):
+            a = segment_reduce(plan, xd, op, w_csr=ww, self_coef=sc, bias=bias, act=1)
+            b = segment_reduce(plan, spe, op, w_csr=ww, self_coef=sc, bias=bias, act=1)
+            assert torch.equal(a, b)
+    other = CsrPlan.build(ei[:, ::-1].copy(), n, n)
+    assert torch.equal(segment_reduce(other, spe, L.SUM), segment_reduce(other, xd, L.SUM))   # falls back to the gather
+
+
+def test_edge_tail_on_hub_rows(tfg, oracle):
+    import torch
+    from tf_geometric_amd.plan import CsrPlan, SplitRows, segment_reduce
+    import tf_geometric_amd.plan as P
+    L = tfg._lib
+    n, f = 2000, 100
+    rng = np.random.Generator(np.random.PCG64(5))
+    ei = oracle.synthetic_edges(n, 20000, seed=6)
+    hubs = np.stack([np.full(5000, 7, np.int32), rng.integers(0, n, 5000).astype(np.int32)])
+    ei = np.concatenate([ei, hubs], axis=1)
+    x = rng.standard_normal((n, f), dtype=np.float32)
+    plan = CsrPlan.build(ei, n, n)
+    assert plan.hub_info() is not None
+    xd = L.as_f32(x)
+    w_csr = torch.rand(plan.num_edges, device="cuda") + 0.5
+    spe = SplitRows.from_dense(xd).with_edge_tail(plan)
+    assert torch.equal(segment_reduce(plan, xd, L.SUM, w_csr=w_csr), segment_reduce(plan, spe, L.SUM, w_csr=w_csr))
 
 
 def test_neighbor_count_mapper_and_utils(tfg, oracle):

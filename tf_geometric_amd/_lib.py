@@ -40,6 +40,7 @@ class ReduceArgs(ctypes.Structure):
         ("hub_chunk_end", ctypes.c_void_p), ("n_hub_rows", ctypes.c_int64), ("n_hub_chunks", ctypes.c_int64),
         ("hub_scratch", ctypes.c_void_p),
         ("x_tail", ctypes.c_void_p), ("ld_tail", ctypes.c_int64), ("f_main", ctypes.c_int64),
+        ("edge_tail", ctypes.c_void_p), ("ld_edge_tail", ctypes.c_int64),
     ]
 
 

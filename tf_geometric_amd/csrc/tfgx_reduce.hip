@@ -55,6 +55,8 @@ struct KArgs {
     const float* x_tail;     // split source rows: columns >= f_main live in x_tail[n_src, ld_tail] (see tfgx.h)
     int64_t ld_tail;
     int32_t f_main;
+    const float* edge_tail;  // optional with SPLIT: the tail columns of every edge's SOURCE row, in this plan's edge order
+    int64_t ld_edge_tail;    // (streamed next to col / w instead of gathered: one line request fewer per edge)
 };
 
 template <int VEC, int G, int CH, bool IS_MAX, bool WEIGHTED, bool SPLIT = false>
@@ -79,16 +81,29 @@ __global__ __launch_bounds__(kBlock) void seg_reduce_kernel(const KArgs a)
     }
     // per-lane source base / stride: one array normally; with SPLIT the lanes owning columns >= f_main read the
     // narrow tail array (whole 128-byte lines of the main array carry no unused bytes then)
-    const float* xb[CH];
-    int64_t xl[CH];
+    const float* xb[CH];     // base / stride of the rows this lane gathers (indexed by source id, or by edge position
+    int64_t xl[CH];          // when by_edge[k])
+    const float* xs[CH];     // base / stride of the lane's slice of a NODE's row (self-loop term of the epilogue)
+    int64_t xsl[CH];
+    bool by_edge[CH];
 #pragma unroll
     for (int k = 0; k < CH; ++k) {
         xb[k] = a.x + coff[k];
         xl[k] = a.ldx;
+        by_edge[k] = false;
         if constexpr (SPLIT) {
             if (coff[k] >= a.f_main) {
                 xb[k] = a.x_tail + (coff[k] - a.f_main);
                 xl[k] = a.ld_tail;
+            }
+        }
+        xs[k] = xb[k];
+        xsl[k] = xl[k];
+        if constexpr (SPLIT) {
+            if (coff[k] >= a.f_main && a.edge_tail != nullptr) {
+                xb[k] = a.edge_tail + (coff[k] - a.f_main);
+                xl[k] = a.ld_edge_tail;
+                by_edge[k] = true;
             }
         }
     }
@@ -128,7 +143,7 @@ __global__ __launch_bounds__(kBlock) void seg_reduce_kernel(const KArgs a)
                     if constexpr (WEIGHTED) ww[u] = bcast_f<G>(wj, j + u);
 #pragma unroll
                     for (int k = 0; k < CH; ++k) {
-                        if constexpr (SPLIT) load_vec<VEC>(xb[k] + int64_t(c) * xl[k], xv[u][k]);
+                        if constexpr (SPLIT) load_vec<VEC>(xb[k] + (by_edge[k] ? int64_t(base + j + u) : int64_t(c)) * xl[k], xv[u][k]);
                         else load_vec<VEC>(a.x + int64_t(c) * a.ldx + coff[k], xv[u][k]);
                     }
                 }
@@ -153,7 +168,7 @@ __global__ __launch_bounds__(kBlock) void seg_reduce_kernel(const KArgs a)
 #pragma unroll
                 for (int k = 0; k < CH; ++k) {
                     float xv[VEC];
-                    if constexpr (SPLIT) load_vec<VEC>(xb[k] + int64_t(c) * xl[k], xv);
+                    if constexpr (SPLIT) load_vec<VEC>(xb[k] + (by_edge[k] ? int64_t(base + j) : int64_t(c)) * xl[k], xv);
                     else load_vec<VEC>(a.x + int64_t(c) * a.ldx + coff[k], xv);
 #pragma unroll
                     for (int v = 0; v < VEC; ++v) {
@@ -189,13 +204,13 @@ __global__ __launch_bounds__(kBlock) void seg_reduce_kernel(const KArgs a)
                 for (int v = 0; v < VEC; ++v) res[v] = IS_MAX ? fmaxf(prev[v], res[v]) : prev[v] + res[v];
             }
             if (a.self_coef) {
-                float xs[VEC];
-                if constexpr (SPLIT) load_vec<VEC>(xb[k] + r * xl[k], xs);
-                else load_vec<VEC>(a.x + r * a.ldx + coff[k], xs);
+                float xself[VEC];
+                if constexpr (SPLIT) load_vec<VEC>(xs[k] + r * xsl[k], xself);
+                else load_vec<VEC>(a.x + r * a.ldx + coff[k], xself);
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) {
-                    if constexpr (IS_MAX) res[v] = fmaxf(res[v], sc * xs[v]);
-                    else res[v] = fmaf(sc, xs[v], res[v]);
+                    if constexpr (IS_MAX) res[v] = fmaxf(res[v], sc * xself[v]);
+                    else res[v] = fmaf(sc, xself[v], res[v]);
                 }
             }
             if (a.op == TFGX_MEAN) {
@@ -347,6 +362,11 @@ extern "C" int tfgx_segment_reduce_f32(const tfgx_reduce_args* p, tfgx_stream_t 
     a.mean_count = p->mean_count;
     a.hub_threshold = 0;
     a.x_tail = p->x_tail; a.ld_tail = p->ld_tail; a.f_main = int32_t(p->f_main);
+    a.edge_tail = p->edge_tail; a.ld_edge_tail = p->ld_edge_tail;
+    TFGX_REQUIRE(p->edge_tail == nullptr ||
+                     (p->x_tail != nullptr && p->ld_edge_tail >= p->F - p->f_main && p->ld_edge_tail % 4 == 0 &&
+                      aligned_to(p->edge_tail, 16)),
+                 "edge_tail needs the split-row layout (x_tail) and 16-byte aligned rows");
     if (p->x_tail) {
         TFGX_REQUIRE(p->f_main > 0 && p->f_main < p->F && p->f_main % 4 == 0 && (p->F - p->f_main) % 4 == 0 &&
                          p->ld_tail >= p->F - p->f_main && p->ld_tail % 4 == 0 && p->ldx >= p->f_main &&

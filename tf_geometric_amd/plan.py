@@ -149,6 +149,17 @@ class SplitRows(object):
         self.main, self.tail = main, tail
         self.shape = (int(main.shape[0]), int(main.shape[1]) + int(tail.shape[1]))
         self.device = main.device
+        self.edge_tail, self.edge_plan = None, None
+
+    def with_edge_tail(self, plan):
+        """Also keep the tail columns PER EDGE of `plan` (edge_tail[i] = tail[col[i]], 4*(F - f_main) bytes per edge,
+        16 B at F = 100): launches on that plan then stream the tail next to col / w instead of gathering it, so a
+        400-byte source row costs three line requests instead of four.  Worth its memory when the same features are
+        aggregated many times over the same graph — the dataset's input features (layer 0, every epoch); it has to be
+        rebuilt whenever the features change."""
+        self.edge_tail = gather_rows(self.tail, plan.col)
+        self.edge_plan = plan
+        return self
 
     @staticmethod
     def wanted(n, F):
@@ -231,6 +242,8 @@ def segment_reduce(plan, x, op, w_csr=None, out=None, act=L.ACT_NONE, self_coef=
     a.mean_count = 0 if mean_count is None else mean_count.data_ptr()
     if split is not None:
         a.x_tail, a.ld_tail, a.f_main = split.tail.data_ptr(), int(split.tail.shape[1]), int(split.main.shape[1])
+        if split.edge_tail is not None and split.edge_plan is plan and col is None:
+            a.edge_tail, a.ld_edge_tail = split.edge_tail.data_ptr(), int(split.edge_tail.shape[1])
     hub = plan.hub_info() if (row_begin is None and row_end is None and col is None) else None
     if hub is not None:
         hub_rows, chunk_ptr, chunk_begin, chunk_end, _ = hub

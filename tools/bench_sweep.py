@@ -89,7 +89,16 @@ def main():
             ms_k = timeit(lambda: segment_reduce(plan, sp, L.SUM, w_csr=w, out=out))
             ms_c = timeit(lambda: SplitRows.from_dense(x, out=sp))
             ms_b = timeit(lambda: segment_reduce(plan, SplitRows.from_dense(x, out=sp), L.SUM, w_csr=w, out=out))
+            t0 = time.perf_counter()
+            sp.with_edge_tail(plan)
+            torch.cuda.synchronize()
+            et_build_ms = (time.perf_counter() - t0) * 1e3
+            ms_e = timeit(lambda: segment_reduce(plan, sp, L.SUM, w_csr=w, out=out))
+            assert torch.equal(out, segment_reduce(plan, x, L.SUM, w_csr=w))
+            sp.edge_tail = None
             print(json.dumps({"kind": "split_rows", "F": f, "dense_ms": ms_d, "split_kernel_ms": ms_k,
+                              "edge_tail_kernel_ms": ms_e, "edge_tail_build_ms": et_build_ms,
+                              "frac_edge_tail_kernel": balg / ms_e / 8e9,
                               "split_convert_ms": ms_c, "convert_plus_kernel_ms": ms_b,
                               "frac_dense": balg / ms_d / 8e9, "frac_split_kernel": balg / ms_k / 8e9,
                               "frac_convert_plus_kernel": balg / ms_b / 8e9}), flush=True)
