@@ -238,6 +238,33 @@ def main():
             line["roofline"]["traffic"] = pmc["traffic_bytes_per_launch"]
             line["roofline"]["traffic_source"] = "profiles/" + os.path.basename(pmc_path)
             line["roofline"]["traffic_GBps"] = pmc["traffic_bytes_per_launch"] / (ev_ms * 1e-3) / 1e9
+        # The same pass with the source features in the static-feature layout (SplitRows + edge-resident tail columns,
+        # DESIGN.md §2.1): what layer 0 runs from the second epoch on.  Reported NEXT TO the headline, never as it: the
+        # layout is derived from the feature values once (build_ms), like the plan is derived from the edges.
+        from tf_geometric_amd.plan import SplitRows
+        if SplitRows.wanted(n, f):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            rows = SplitRows.from_dense(x).with_edge_tail(normed.plan)
+            torch.cuda.synchronize()
+            build_ms = (time.perf_counter() - t1) * 1e3
+            out2 = torch.empty_like(out)
+            for _ in range(args.warmup):
+                segment_reduce(normed.plan, rows, L.SUM, w_csr=normed.w_csr, self_coef=normed.self_coef, out=out2)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.steps):
+                segment_reduce(normed.plan, rows, L.SUM, w_csr=normed.w_csr, self_coef=normed.self_coef, out=out2)
+            e1.record()
+            torch.cuda.synchronize()
+            ms2 = e0.elapsed_time(e1) / args.steps
+            line["static_feature_layout"] = {
+                "what": "same launch, x stored as main[N,96] + tail[N,4] + the tail columns of each edge's source row "
+                        "streamed next to col/w (3 line requests per gathered row instead of 4)",
+                "kernel_ms": ms2, "edges_per_s": e / (ms2 * 1e-3), "frac_of_hbm_peak_algorithmic": bytes_alg / (ms2 * 1e-3) / HBM_PEAK,
+                "build_ms_once_per_feature_matrix": build_ms, "extra_bytes": int(rows.edge_tail.numel() * 4),
+                "bit_identical_to_headline_output": bool(torch.equal(out2, res))}
+            del rows, out2
         if not args.no_cpu_baseline:
             budget = {"products": 61_500_000}.get(args.workload, e)
             base, cpu_out, n_s = cpu_baseline(x_np, ei_np, normed_w_host(normed, ei_np, n),

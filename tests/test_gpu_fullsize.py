@@ -95,3 +95,29 @@ def test_reddit_shaped_gat_partition_of_unity_and_bounds(tfg):
     uni = gat_attention(plan, torch.zeros_like(Q), K, V, 8)
     ref = (segment_reduce(plan, V, L.SUM) + V) / (plan.in_degree().float()[:, None] + 1.0)
     assert float((uni - ref).abs().max()) < 2e-5
+
+
+def test_products_static_features_switch_to_edge_tail_layout(tfg, products):
+    """The same feature tensor aggregated repeatedly over the same graph (layer 0, every epoch): from the second call
+    on, the layer runs the SplitRows + edge-resident-tail layout (plan.static_rows) — bit-identical outputs; an
+    in-place update of the features invalidates it."""
+    from tf_geometric_amd.plan import SplitRows
+    p = products
+    x = p["x"].clone()
+    cache = {"tfgx_csr_plan": p["plan"]}
+    layer = tfg.layers.GCN(1, use_kernel=False, use_bias=False)
+    o1 = layer([x, p["ei"], p["w"]], cache=cache)
+    assert cache["tfgx_static_rows"][1] is None                      # first sighting: nothing built
+    o2 = layer([x, p["ei"], p["w"]], cache=cache)
+    rows = cache["tfgx_static_rows"][1]
+    assert isinstance(rows, SplitRows) and rows.edge_tail.shape == (p["plan"].num_edges, 4)
+    o3 = layer([x, p["ei"], p["w"]], cache=cache)
+    assert torch.equal(o1, o2) and torch.equal(o1, o3)
+    x.mul_(2.0)                                                      # new version of the same storage
+    o4 = layer([x, p["ei"], p["w"]], cache=cache)
+    assert cache["tfgx_static_rows"][1] is None and torch.equal(o4, o1 * 2.0)
+    sage = tfg.layers.MeanGraphSage(8)
+    s1 = sage([x, p["ei"], p["w"]], cache=cache)
+    s2 = sage([x, p["ei"], p["w"]], cache=cache)
+    s3 = sage([x, p["ei"], p["w"]], cache=cache)
+    assert torch.equal(s1, s2) and torch.equal(s1, s3) and cache["tfgx_static_rows"][1] is not None

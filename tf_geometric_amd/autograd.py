@@ -20,7 +20,7 @@ import math
 import torch
 
 from . import _lib as L
-from .plan import segment_reduce, gemm_bias_act
+from .plan import segment_reduce, gemm_bias_act, SplitRows
 
 
 def needs_grad(*tensors):
@@ -65,10 +65,12 @@ class _Aggregate(torch.autograd.Function):
     """out[r] = (1/cnt[r]) * ( sum_{i in row r} w[i] x[col[i]] + self_coef[r] x[r] )   (cnt only for mean)."""
 
     @staticmethod
-    def forward(ctx, plan, mean, x, w_csr, self_coef):
+    def forward(ctx, plan, mean, x, w_csr, self_coef, rows=None):
+        """`rows`: x in another source layout (plan.static_rows) — same values, same result bits."""
         ctx.plan, ctx.mean = plan, mean
         ctx.save_for_backward(x, w_csr, self_coef)
-        return segment_reduce(plan, x.detach(), L.MEAN if mean else L.SUM, w_csr=None if w_csr is None else w_csr.detach(),
+        return segment_reduce(plan, x.detach() if rows is None else rows, L.MEAN if mean else L.SUM,
+                              w_csr=None if w_csr is None else w_csr.detach(),
                               self_coef=None if self_coef is None else self_coef.detach())
 
     @staticmethod
@@ -94,7 +96,7 @@ class _Aggregate(torch.autograd.Function):
                                        int(x2.shape[1]), L.ptr(gw), L.stream_ptr()), "tfgx_sddmm_f32")
         if self_coef is not None and ctx.needs_input_grad[4]:
             gs = (x.detach() * g).sum(1)
-        return None, None, gx, gw, gs
+        return None, None, gx, gw, gs, None
 
 
 class _AggregateMax(torch.autograd.Function):
@@ -135,13 +137,13 @@ class _AggregateMax(torch.autograd.Function):
         return None, gx, gw
 
 
-def aggregate(plan, x, op, w_csr=None, self_coef=None):
+def aggregate(plan, x, op, w_csr=None, self_coef=None, rows=None):
     """Differentiable gather-scale-segment-reduce (sum / mean / max) on `plan`."""
     if op == L.MAX:
         if self_coef is not None:
             raise NotImplementedError("max aggregation with an implicit self-loop is inference-only")
         return _AggregateMax.apply(plan, x, w_csr)
-    return _Aggregate.apply(plan, op == L.MEAN, x, w_csr, self_coef)
+    return _Aggregate.apply(plan, op == L.MEAN, x, w_csr, self_coef, rows if isinstance(rows, SplitRows) else None)
 
 
 class _Linear(torch.autograd.Function):

@@ -9,7 +9,7 @@ import torch
 
 from ... import _lib as L
 from ...activations import resolve as _resolve_act
-from ...plan import segment_reduce, gemm_bias_act
+from ...plan import segment_reduce, gemm_bias_act, static_rows
 from ...sparse import SparseMatrix
 from ... import autograd as AG
 
@@ -30,9 +30,11 @@ class NormedAdj(object):
         self.self_coef = self_coef
         self.shape = shape
 
-    def matmul(self, h, num_or_size_splits=None, bias=None, act=L.ACT_NONE):
-        return segment_reduce(self.plan, L.as_f32(h), L.SUM, w_csr=self.w_csr, self_coef=self.self_coef,
-                              bias=bias, act=act)
+    def matmul(self, h, num_or_size_splits=None, bias=None, act=L.ACT_NONE, cache=None):
+        """`cache`: the graph's cache dict — lets repeated products with the SAME h (static input features) switch to
+        the edge-resident-tail layout (plan.static_rows)."""
+        return segment_reduce(self.plan, static_rows(L.as_f32(h), self.plan, cache), L.SUM, w_csr=self.w_csr,
+                              self_coef=self.self_coef, bias=bias, act=act)
 
     def __matmul__(self, h):
         return self.matmul(h)
@@ -180,7 +182,8 @@ def gcn(x, sparse_adj, kernel, bias=None, activation=None, norm="both", add_self
     if AG.needs_grad(x, kernel, bias):      # training: differentiable un-fused route (autograd.py)
         narrow_first = kernel is not None and int(x.shape[1]) < int(kernel.shape[1])
         h = x if (kernel is None or narrow_first) else AG.linear(x, kernel)
-        h = AG.aggregate(normed.plan, h, L.SUM, normed.w_csr, normed.self_coef)
+        rows = static_rows(h, normed.plan, cache) if h is x else None       # raw input features: static across epochs
+        h = AG.aggregate(normed.plan, h, L.SUM, normed.w_csr, normed.self_coef, rows=rows)
         if narrow_first:
             h = AG.linear(h, kernel)
         if bias is not None:
@@ -190,8 +193,8 @@ def gcn(x, sparse_adj, kernel, bias=None, activation=None, norm="both", add_self
     if kernel is not None and int(x.shape[1]) < int(kernel.shape[1]):
         # A_hat @ (x @ W) == (A_hat @ x) @ W: gather at the NARROWER width (bytes per edge = 4*min(F, units) + 8),
         # bias + activation move into the GEMM epilogue. Same result up to fp32 re-association (inside 1e-5).
-        h = gemm_bias_act(normed.matmul(x), kernel, bias=bias_t, act=act)
+        h = gemm_bias_act(normed.matmul(x, cache=cache), kernel, bias=bias_t, act=act)
     else:
         h = x if kernel is None else gemm_bias_act(x, kernel)                                     # :266-272
-        h = normed.matmul(h, bias=bias_t, act=act)                                                # :280-288
+        h = normed.matmul(h, bias=bias_t, act=act, cache=cache if kernel is None else None)       # :280-288
     return post(h) if post is not None else h

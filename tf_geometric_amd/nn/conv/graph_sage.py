@@ -14,7 +14,7 @@ import torch
 
 from ... import _lib as L
 from ...activations import resolve as _resolve_act
-from ...plan import CsrPlan, segment_reduce, gemm_bias_act, l2_normalize_rows_, edge_weight_csr
+from ...plan import CsrPlan, segment_reduce, gemm_bias_act, l2_normalize_rows_, edge_weight_csr, static_rows
 from ...sparse import SparseMatrix
 from .gcn import gcn_norm_adj
 from ... import autograd as AG
@@ -63,7 +63,8 @@ def _neighbor_reduce(x, edge_index, edge_weight, op, cache):
     w_csr = edge_weight_csr(plan, edge_weight, cache)                                  # :38-39
     if AG.needs_grad(x):
         return x, AG.aggregate(plan, x, op, w_csr)
-    return x, segment_reduce(plan, x, op, w_csr=w_csr)
+    # raw input features seen twice with the same cache are static: edge-resident-tail layout (plan.static_rows)
+    return x, segment_reduce(plan, static_rows(x, plan, cache), op, w_csr=w_csr)
 
 
 def mean_graph_sage(x, edge_index, edge_weight, self_kernel, neighbor_kernel, bias=None, activation=None,

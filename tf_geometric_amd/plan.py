@@ -181,6 +181,29 @@ class SplitRows(object):
         return out
 
 
+def static_rows(x, plan, cache):
+    """`x`, or — from the SECOND time the same feature tensor (storage, version, shape) is aggregated over the same
+    plan with the same `cache` dict — its SplitRows + edge-resident-tail form.  A tensor seen twice is taken to be the
+    dataset's static input features (layer 0 of a model, every epoch); the first sighting pays nothing, the second
+    pays the one-off conversion (about a third of one aggregation at products shape), later ones run the faster
+    layout.  Results are bit-identical either way.  Only widths where it matters (SplitRows.wanted)."""
+    if cache is None or not isinstance(x, torch.Tensor) or x.dim() != 2 or not x.is_contiguous():
+        return x
+    n, F = int(x.shape[0]), int(x.shape[1])
+    if not SplitRows.wanted(n, F):
+        return x
+    key = (x.data_ptr(), x._version, n, F, id(plan))
+    hit = cache.get("tfgx_static_rows")
+    if hit is None or hit[0] != key:
+        cache["tfgx_static_rows"] = (key, None, x, plan)      # holds x and plan: neither address can be recycled
+        return x
+    if hit[1] is None:
+        rows = SplitRows.from_dense(x).with_edge_tail(plan)
+        cache["tfgx_static_rows"] = (key, rows, x, plan)
+        return rows
+    return hit[1]
+
+
 def edge_weight_csr(plan, edge_weight, cache=None):
     """edge_weight (caller's edge order) -> CSR order, memoised in the graph's `cache` dict for as long as the SAME
     array object is passed (the reference caches its normalised adjacency under the same contract: one cache per
