@@ -13,7 +13,8 @@ OBJ_DIR = os.path.join(LIB_DIR, "obj")
 SOURCES = ["tfgx_plan.hip", "tfgx_reduce.hip", "tfgx_norm.hip", "tfgx_attn.hip", "tfgx_gemm.hip", "tfgx_misc.hip", "tfgx_backward.hip",
            "tfgx_topk.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + \
+    os.environ.get("TFGX_EXTRA_HIPCC_FLAGS", "").split()      # developer A/B switches (e.g. -DTFGX_PREFETCH_INDEX=0)
 
 
 def _newer(a, b):
