@@ -224,11 +224,15 @@ def main():
     if rank == 0 and world == 1:
         bytes_alg = b_alg(e_agg, n, f, weighted=True)
         achieved = bytes_alg / (ev_ms * 1e-3)
+        # compulsory lower bound: every array touched exactly once
+        bytes_min = 8 * e_agg + 4 * (n + 1) + 2 * n * 4 * f
         line["roofline"] = {"bound": "hbm", "kernel": "seg_reduce_kernel<4,32,1,sum,weighted>",
                             "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                             "frac": achieved / HBM_PEAK, "traffic": None,
                             "algorithmic_bytes_per_launch": bytes_alg, "kernel_ms": ev_ms,
-                            "bytes_per_edge": 4 * f + 8}
+                            "bytes_per_edge": 4 * f + 8,
+                            "compulsory_bytes_per_launch": bytes_min,
+                            "frac_compulsory": bytes_min / (ev_ms * 1e-3) / HBM_PEAK}
         # HBM-side bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE;
         # see profiles/): a property of kernel + workload, cannot be sampled from inside this process.
         pmc_path = os.path.join(ROOT, "profiles", "r01_{}_pmc.json".format(args.workload))
@@ -238,6 +242,7 @@ def main():
             line["roofline"]["traffic"] = pmc["traffic_bytes_per_launch"]
             line["roofline"]["traffic_source"] = "profiles/" + os.path.basename(pmc_path)
             line["roofline"]["traffic_GBps"] = pmc["traffic_bytes_per_launch"] / (ev_ms * 1e-3) / 1e9
+            line["roofline"]["frac_traffic"] = pmc["traffic_bytes_per_launch"] / (ev_ms * 1e-3) / HBM_PEAK
         # The same pass with the source features in the static-feature layout (SplitRows + edge-resident tail columns,
         # DESIGN.md §2.1): what layer 0 runs from the second epoch on.  Reported NEXT TO the headline, never as it: the
         # layout is derived from the feature values once (build_ms), like the plan is derived from the edges.
