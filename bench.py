@@ -51,6 +51,27 @@ def b_alg(e_agg, n, f, weighted=True):
     return e_agg * (4 * f + 4 + (4 if weighted else 0)) + n * 4 * f + 4 * (n + 1)
 
 
+def usable_cores():
+    """CPUs this process may actually use: the affinity mask, capped by the cgroup CPU quota.  (On the GPU boxes of
+    this pool the mask shows all 256 hardware threads of the 2 x EPYC 9575F host but cpu.max grants 16 CPUs; 256
+    OpenMP threads under that quota run 6x slower than 16 — measured 37 vs 226 M edges/s.)"""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:                    # cgroup v2: "<quota> <period>" or "max <period>"
+            quota, period = fh.read().split()[:2]
+        if quota != "max":
+            cores = max(1, min(cores, int(-(-int(quota) // int(period)))))
+    except (OSError, ValueError):
+        try:                                                          # cgroup v1
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fq, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fp:
+                quota, period = int(fq.read()), int(fp.read())
+            if quota > 0:
+                cores = max(1, min(cores, -(-quota // period)))
+        except (OSError, ValueError):
+            pass
+    return cores
+
+
 def cpu_baseline(x_np, ei_np, w_np, self_coef_np, n, f, budget_edges):
     """C port of gather -> gcn_mapper -> unsorted_segment_sum (oracle/tfg_oracle.c), all host cores, on the
     destination rows [0, n_s) of the same graph (full source range, so the gather locality is the job's)."""
@@ -58,7 +79,7 @@ def cpu_baseline(x_np, ei_np, w_np, self_coef_np, n, f, budget_edges):
     lib = ctypes.CDLL(lib_path)
     fn = lib.tfgo_aggregate_csr_f32
     fn.restype = ctypes.c_int
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = usable_cores()
     e_total = ei_np.shape[1]
     frac = min(1.0, float(budget_edges) / max(e_total, 1))
     n_s = max(1, int(n * frac))
