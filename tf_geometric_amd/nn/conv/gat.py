@@ -27,7 +27,10 @@ def _project_qkv(x, wq, bq, qact, wk, bk, kact, wv):
     """Q = qact(x@Wq+bq), K = kact(x@Wk+bk), V = x@W (gat.py:52-70): three launches of the MFMA GEMM.
     (One fused x @ [Wq | Wk | W] pass with a column-limited activation — tfgx_gemm_bias_act_cols_f32 — was measured
     at products shape, H=8/A=8/U=64: 8.1 ms per layer vs 7.6 ms for the three GEMMs, because K and V then share
-    320-byte rows that straddle more 128-byte lines in the attention kernel; not used.)"""
+    320-byte rows that straddle more 128-byte lines in the attention kernel.  A second attempt with rows padded to
+    whole lines ([Q | K | pad | V], V line-aligned, K in a line of its own) kept the attention kernel at 3 lines per
+    edge but the layer still took 7.55-7.58 ms: each of the three GEMMs is already bound by streaming x once, and the
+    fused one is a low-efficiency N = 96 tile shape.  Not used.)"""
     return _linear(x, wq, bq, qact), _linear(x, wk, bk, kact), gemm_bias_act(x, wv)
 
 
