@@ -244,6 +244,11 @@ int tfgx_head_mean_f32(const float* in, int64_t ld_in, int64_t n, int32_t H, int
  * ------------------------------------------------------------------------------------------- */
 int tfgx_sddmm_f32(const int32_t* row_ptr, const int32_t* col, int64_t n_dst, const float* a, int64_t lda,
                    const float* b, int64_t ldb, int64_t F, float* out, tfgx_stream_t stream);
+/* training-time forward of the max aggregation: out[r,j] = max_i w[i]*x[col[i],j] (float32 lowest for an empty row) AND
+   count[r,j] = number of edges attaining it, in one pass over the edges (the backward then needs no count pass) */
+int tfgx_segment_max_with_count_f32(const int32_t* row_ptr, const int32_t* col, const float* w /* or NULL */,
+                                    int64_t n_dst, const float* x, int64_t ldx, int64_t F, float* out, int64_t ldo,
+                                    float* count, int64_t ldc, tfgx_stream_t stream);
 int tfgx_segment_max_count_f32(const int32_t* row_ptr, const int32_t* col, const float* w /* or NULL */, int64_t n_dst,
                                const float* x, int64_t ldx, int64_t F, const float* out, int64_t ldo, float* count,
                                int64_t ldc, tfgx_stream_t stream);

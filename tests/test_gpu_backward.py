@@ -80,6 +80,34 @@ def test_sddmm_widths(tfg, oracle, f):
     assert_parity(out.cpu().numpy(), ref, tol=1e-5 * np.sqrt(f), what="sddmm F={}".format(f))
 
 
+@pytest.mark.parametrize("f,weighted", [(100, True), (64, False), (16, True), (37, True), (260, False)])
+def test_max_with_count_one_pass_equals_forward_plus_count(tfg, oracle, f, weighted):
+    """tfgx_segment_max_with_count_f32 (training forward): bit-identical maxima to the plain forward and the same tie
+    counts as the separate count pass — empty rows, duplicated sources (ties), aligned and unaligned widths."""
+    from tf_geometric_amd import _lib as L
+    from tf_geometric_amd.plan import CsrPlan, segment_reduce
+    rng = np.random.Generator(np.random.PCG64(f))
+    n = 700
+    ei = oracle.synthetic_edges(n, 9000, seed=f)
+    ei = ei[:, ei[0] != 9]
+    ei = np.concatenate([ei, ei[:, :3000]], axis=1)                     # duplicated edges: guaranteed ties
+    x = np.round(rng.standard_normal((n, f)).astype(np.float32) * 2) / 2   # quantised: more ties
+    plan = CsrPlan.build(L.as_i32(ei), n, n)
+    xd = L.as_f32(x)
+    w = (torch.randint(1, 3, (plan.num_edges,), device="cuda").float() * 0.5) if weighted else None
+    lib = L.require_gpu()
+    out = torch.empty((n, f), device="cuda")
+    cnt = torch.empty((n, f), device="cuda")
+    L.check(lib.tfgx_segment_max_with_count_f32(L.ptr(plan.row_ptr), L.ptr(plan.col), L.ptr(w), n, L.ptr(xd), f, f,
+                                                L.ptr(out), f, L.ptr(cnt), f, L.stream_ptr()), "max_with_count")
+    ref_out = segment_reduce(plan, xd, L.MAX, w_csr=w)
+    ref_cnt = torch.empty_like(ref_out)
+    L.check(lib.tfgx_segment_max_count_f32(L.ptr(plan.row_ptr), L.ptr(plan.col), L.ptr(w), n, L.ptr(xd), f, f,
+                                           L.ptr(ref_out), f, L.ptr(ref_cnt), f, L.stream_ptr()), "max_count")
+    assert torch.equal(out, ref_out) and torch.equal(cnt, ref_cnt)
+    assert float(cnt.max()) >= 2 and float(cnt[9].abs().max()) == 0 and float(out[9].max()) == -3.4028234663852886e38
+
+
 def test_max_grad_ties_split_evenly(tfg):
     """TF's unsorted_segment_max gradient divides by the number of tied maxima."""
     ei = np.array([[0, 0, 0, 1], [1, 2, 3, 3]], np.int32)

@@ -102,8 +102,21 @@ class _Aggregate(torch.autograd.Function):
 class _AggregateMax(torch.autograd.Function):
     @staticmethod
     def forward(ctx, plan, x, w_csr):
-        out = segment_reduce(plan, x.detach(), L.MAX, w_csr=None if w_csr is None else w_csr.detach())
-        ctx.plan = plan
+        lib = L.require_gpu()
+        x2, ldx = L.row_major_2d(x.detach())
+        F = int(x2.shape[1])
+        if plan.hub_info() is None:
+            # one pass: row maxima AND how many edges attain each (the tie count TF's gradient divides by)
+            out = torch.empty((plan.n_dst, F), dtype=torch.float32, device=x2.device)
+            count = torch.empty_like(out)
+            L.check(lib.tfgx_segment_max_with_count_f32(L.ptr(plan.row_ptr), L.ptr(plan.col),
+                                                        L.ptr(None if w_csr is None else w_csr.detach()), plan.n_dst,
+                                                        L.ptr(x2), ldx, F, L.ptr(out), F, L.ptr(count), F, L.stream_ptr()),
+                    "tfgx_segment_max_with_count_f32")
+        else:   # skewed graph: the chunked forward keeps long rows off one lane group; count in the backward
+            out = segment_reduce(plan, x2, L.MAX, w_csr=None if w_csr is None else w_csr.detach())
+            count = None
+        ctx.plan, ctx.count = plan, count
         ctx.save_for_backward(x, w_csr, out)
         return out
 
@@ -115,10 +128,12 @@ class _AggregateMax(torch.autograd.Function):
         x2, ldx = L.row_major_2d(x.detach())
         g2, ldg = L.row_major_2d(g.contiguous())
         F = int(x2.shape[1])
-        count = torch.empty_like(out)
-        L.check(lib.tfgx_segment_max_count_f32(L.ptr(plan.row_ptr), L.ptr(plan.col), L.ptr(w_csr), plan.n_dst, L.ptr(x2),
-                                               ldx, F, L.ptr(out), F, L.ptr(count), F, L.stream_ptr()),
-                "tfgx_segment_max_count_f32")
+        count = ctx.count
+        if count is None:
+            count = torch.empty_like(out)
+            L.check(lib.tfgx_segment_max_count_f32(L.ptr(plan.row_ptr), L.ptr(plan.col), L.ptr(w_csr), plan.n_dst,
+                                                   L.ptr(x2), ldx, F, L.ptr(out), F, L.ptr(count), F, L.stream_ptr()),
+                    "tfgx_segment_max_count_f32")
         pt, t2d = _transposed(plan)
         w_t = _transposed_weights(plan, w_csr, t2d)
         gx = torch.empty_like(x2)

@@ -12,6 +12,7 @@
 // These kernels favour clarity over speed (one lane per (row, head) for GAT); the forward path is the tuned one.
 #include "tfgx_common.h"
 #include <cfloat>
+#include <cstring>
 
 namespace tfgx {
 namespace {
@@ -184,8 +185,12 @@ __global__ __launch_bounds__(kBlock) void max_grad_fast_kernel(const int32_t* __
                                                                const float* __restrict__ x, int64_t ldx, int F,
                                                                const float* __restrict__ out, int64_t ldo,
                                                                const float* __restrict__ gn, int64_t ldg,
-                                                               float* __restrict__ res, int64_t ldr)
+                                                               float* __restrict__ res, int64_t ldr,
+                                                               float* __restrict__ out_w = nullptr)
 {
+    // MODE 0: res = tie count given the row maxima `out`;  MODE 1: res = gradient wrt x (transposed plan);
+    // MODE 2: the FORWARD of training: row maximum -> out_w and tie count -> res in ONE pass (online: a value above the
+    //         running maximum restarts the count at 1, an equal one increments it), so the backward needs no count pass
     constexpr int VEC = 4;
     constexpr int ROWS_PER_BLOCK = kBlock / G;
     const int lane = threadIdx.x % G, grp = threadIdx.x / G;
@@ -195,7 +200,12 @@ __global__ __launch_bounds__(kBlock) void max_grad_fast_kernel(const int32_t* __
     for (int64_t row = int64_t(blockIdx.x) * ROWS_PER_BLOCK + grp; row < n; row += int64_t(gridDim.x) * ROWS_PER_BLOCK) {
         const int s = row_ptr[row], e = row_ptr[row + 1];
         float mine[VEC], acc[VEC];
-        load_vec<VEC>((MODE == 0 ? out + row * ldo : x + row * ldx) + coff, mine);   // out[r,:] | x[c,:]
+        if (MODE == 2) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) mine[i] = -FLT_MAX;                        // running maximum
+        } else {
+            load_vec<VEC>((MODE == 0 ? out + row * ldo : x + row * ldx) + coff, mine);   // out[r,:] | x[c,:]
+        }
 #pragma unroll
         for (int i = 0; i < VEC; ++i) acc[i] = 0.0f;
         for (int base = s; base < e; base += G) {
@@ -211,6 +221,15 @@ __global__ __launch_bounds__(kBlock) void max_grad_fast_kernel(const int32_t* __
                     load_vec<VEC>(x + o * ldx + coff, xv);
 #pragma unroll
                     for (int i = 0; i < VEC; ++i) acc[i] += ((w ? wi * xv[i] : xv[i]) == mine[i]) ? 1.0f : 0.0f;
+                } else if (MODE == 2) {
+                    float xv[VEC];
+                    load_vec<VEC>(x + o * ldx + coff, xv);
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) {
+                        const float m = w ? wi * xv[i] : xv[i];
+                        acc[i] = m > mine[i] ? 1.0f : (m == mine[i] ? acc[i] + 1.0f : acc[i]);
+                        mine[i] = fmaxf(mine[i], m);
+                    }
                 } else {
                     float ov[VEC], gv[VEC];
                     load_vec<VEC>(out + o * ldo + coff, ov);
@@ -221,21 +240,24 @@ __global__ __launch_bounds__(kBlock) void max_grad_fast_kernel(const int32_t* __
                 }
             }
         }
-        if (cvalid) store_vec<VEC>(res + row * ldr + coff, acc);
+        if (cvalid) {
+            store_vec<VEC>(res + row * ldr + coff, acc);
+            if (MODE == 2) store_vec<VEC>(out_w + row * ldo + coff, mine);
+        }
     }
 }
 
 template <int MODE>
 int launch_max_grad(const int32_t* row_ptr, const int32_t* other, const float* w, int64_t n, const float* x,
                     int64_t ldx, int F, const float* out, int64_t ldo, const float* gn, int64_t ldg, float* res,
-                    int64_t ldr, hipStream_t stream)
+                    int64_t ldr, hipStream_t stream, float* out_w = nullptr)
 {
     const int lanes = (F + 3) / 4;
 #define TFGX_MG(GG)                                                                                            \
     {                                                                                                          \
         dim3 grid(grid_for(n, kBlock / GG, 1 << 20), (lanes + GG - 1) / GG, 1);                                \
         max_grad_fast_kernel<GG, MODE><<<grid, kBlock, 0, stream>>>(row_ptr, other, w, n, x, ldx, F, out, ldo, \
-                                                                      gn, ldg, res, ldr);                     \
+                                                                      gn, ldg, res, ldr, out_w);              \
     }
     if (lanes <= 8) TFGX_MG(8)
     else if (lanes <= 16) TFGX_MG(16)
@@ -576,6 +598,27 @@ extern "C" int tfgx_segment_max_count_f32(const int32_t* row_ptr, const int32_t*
                                                                                    int(F), out, ldo, count, ldc);
     TFGX_LAUNCH_CHECK("max_count_kernel");
     return TFGX_OK;
+}
+
+extern "C" int tfgx_segment_max_with_count_f32(const int32_t* row_ptr, const int32_t* col, const float* w,
+                                              int64_t n_dst, const float* x, int64_t ldx, int64_t F, float* out,
+                                              int64_t ldo, float* count, int64_t ldc, tfgx_stream_t stream)
+{
+    TFGX_REQUIRE(n_dst >= 0 && F >= 1 && ldx >= F && ldo >= F && ldc >= F, "bad size");
+    if (n_dst == 0) return TFGX_OK;
+    TFGX_REQUIRE(row_ptr && x && out && count, "null pointer");
+    if (F % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && ldc % 4 == 0 && aligned_to(x, 16) && aligned_to(out, 16) &&
+        aligned_to(count, 16))
+        return launch_max_grad<2>(row_ptr, col, w, n_dst, x, ldx, int(F), nullptr, ldo, nullptr, 0, count, ldc,
+                                  as_stream(stream), out);
+    // layouts the one-pass kernel does not cover: plain forward, then the count pass
+    tfgx_reduce_args a;
+    memset(&a, 0, sizeof(a));
+    a.row_begin = row_ptr; a.row_end = row_ptr + 1; a.rp_stride = 1; a.col = col; a.w = w; a.n_dst = n_dst;
+    a.x = x; a.ldx = ldx; a.F = F; a.out = out; a.ldo = ldo; a.op = TFGX_MAX; a.act = TFGX_ACT_NONE;
+    const int rc = tfgx_segment_reduce_f32(&a, stream);
+    if (rc != TFGX_OK) return rc;
+    return tfgx_segment_max_count_f32(row_ptr, col, w, n_dst, x, ldx, F, out, ldo, count, ldc, stream);
 }
 
 extern "C" int tfgx_segment_max_backward_f32(const int32_t* row_ptr_t, const int32_t* dst_t, const float* w_t,
