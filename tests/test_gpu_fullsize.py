@@ -116,6 +116,10 @@ def test_products_static_features_switch_to_edge_tail_layout(tfg, products):
     x.mul_(2.0)                                                      # new version of the same storage
     o4 = layer([x, p["ei"], p["w"]], cache=cache)
     assert cache["tfgx_static_rows"][1] is None and torch.equal(o4, o1 * 2.0)
+    off = {"tfgx_csr_plan": p["plan"], "tfgx_static_features": False}       # opt-out: never builds the layout
+    for _ in range(3):
+        assert torch.equal(layer([x, p["ei"], p["w"]], cache=off), o4)
+    assert "tfgx_static_rows" not in off
     sage = tfg.layers.MeanGraphSage(8)
     s1 = sage([x, p["ei"], p["w"]], cache=cache)
     s2 = sage([x, p["ei"], p["w"]], cache=cache)

@@ -186,8 +186,14 @@ def static_rows(x, plan, cache):
     plan with the same `cache` dict — its SplitRows + edge-resident-tail form.  A tensor seen twice is taken to be the
     dataset's static input features (layer 0 of a model, every epoch); the first sighting pays nothing, the second
     pays the one-off conversion (about a third of one aggregation at products shape), later ones run the faster
-    layout.  Results are bit-identical either way.  Only widths where it matters (SplitRows.wanted)."""
+    layout.  Results are bit-identical either way.  Only widths where it matters (SplitRows.wanted).
+    Contract (the same one autograd relies on): a change of the features must be visible to torch — a new tensor, or an
+    in-place op that bumps the version counter.  Writers that bypass it (`x.data.mul_()`, another framework writing
+    through a shared pointer) must switch the detection off: `cache["tfgx_static_features"] = False`.  Never active
+    while a hipGraph is being captured (the layout build allocates)."""
     if cache is None or not isinstance(x, torch.Tensor) or x.dim() != 2 or not x.is_contiguous():
+        return x
+    if cache.get("tfgx_static_features", True) is False or torch.cuda.is_current_stream_capturing():
         return x
     n, F = int(x.shape[0]), int(x.shape[1])
     if not SplitRows.wanted(n, F):
