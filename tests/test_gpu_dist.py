@@ -29,3 +29,16 @@ def test_from_partitioned_world2_hip_gloo_transport(tfg, tmp_path):
     port = 33600 + random.randint(0, 2000)
     parts = dist_worker.spawn(2, use_gpu=True, skew=True, path=str(tmp_path), port=port, rounds=3, partitioned=True)
     dist_worker.check_against_reference(parts, True, assert_parity)
+
+
+def test_rccl_world1_api_smoke(tfg):
+    """The RCCL calls of the sharded path, on a one-rank "nccl" group (tests/rccl_world1_smoke.py)."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(35600 + random.randint(0, 2000)), RANK="0",
+               WORLD_SIZE="1")
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_world1_smoke.py")
+    res = subprocess.run([sys.executable, script], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    text = res.stdout.decode()
+    assert res.returncode == 0 and "RCCL_WORLD1_OK" in text and "True" in text and "False" not in text, text
