@@ -30,7 +30,19 @@ def _project_qkv(x, wq, bq, qact, wk, bk, kact, wv):
     320-byte rows that straddle more 128-byte lines in the attention kernel.  A second attempt with rows padded to
     whole lines ([Q | K | pad | V], V line-aligned, K in a line of its own) kept the attention kernel at 3 lines per
     edge but the layer still took 7.55-7.58 ms: each of the three GEMMs is already bound by streaming x once, and the
-    fused one is a low-efficiency N = 96 tile shape.  Not used.)"""
+    fused one is a low-efficiency N = 96 tile shape.  Not used.)
+    What IS fused: Q and K when they share the activation — one x @ [Wq | Wk] pass instead of two (both are narrow,
+    HBM-bound reads of x); K rows stay inside one line (A <= 16) or line-aligned (A % 32 == 0)."""
+    qa, qpost = _resolve_act(qact)
+    ka, kpost = _resolve_act(kact)
+    A = int(wq.shape[1])
+    if (qa == ka and qpost is None and kpost is None and (bq is None) == (bk is None) and int(wk.shape[1]) == A and
+            (A <= 16 or A % 32 == 0)):
+        dev = x.device
+        w_qk = torch.cat([L.as_f32(wq, dev), L.as_f32(wk, dev)], dim=1).contiguous()
+        b_qk = None if bq is None else torch.cat([L.as_f32(bq, dev).reshape(-1), L.as_f32(bk, dev).reshape(-1)])
+        qk = gemm_bias_act(x, w_qk, bias=b_qk, act=qa)
+        return qk[:, :A], qk[:, A:], gemm_bias_act(x, wv)
     return _linear(x, wq, bq, qact), _linear(x, wk, bk, kact), gemm_bias_act(x, wv)
 
 
