@@ -420,7 +420,10 @@ int launch_gemm_rows(const float* A, int64_t lda, const float* B, int64_t ldb, c
     constexpr int kWaves = rows_threads<TN>() / 64;
     const int64_t wgs = (n_tiles + kWaves - 1) / kWaves;
     const int b_vec4 = (ldb % 4 == 0) && aligned_to(B, 16);
-    dim3 grid(static_cast<unsigned>(wgs < cus ? wgs : cus), 1, 1), block(rows_threads<TN>(), 1, 1);
+    // narrow outputs (TN <= 2) are A-streaming kernels with few registers and a small B: several workgroups per CU
+    // keep more row loads in flight than one workgroup's single-step prefetch can
+    const int64_t max_wgs = int64_t(cus) * (TN <= 2 ? 3 : 1);
+    dim3 grid(static_cast<unsigned>(wgs < max_wgs ? wgs : max_wgs), 1, 1), block(rows_threads<TN>(), 1, 1);
     gemm_rows_kernel<TN><<<grid, block, rows_lds_bytes(K, TN), stream>>>(A, lda, B, ldb, bias, act, act_cols, C, ldc, M, K,
                                                                          N, n_tiles, b_vec4);
     TFGX_LAUNCH_CHECK("gemm_rows_kernel");
@@ -431,7 +434,7 @@ int launch_gemm_rows(const float* A, int64_t lda, const float* B, int64_t ldb, c
 // and enough 32-row tiles to keep 8 waves on every CU busy for many tiles
 inline bool rows_ok(const float* A, int64_t lda, int64_t M, int64_t K, int64_t N)
 {
-    if (N <= 64 || N > 256 || K < 32 || K % 4 != 0 || lda % 4 != 0 || !aligned_to(A, 16) || M < 128 * 256) return false;
+    if (N < 1 || N > 256 || K < 32 || K % 4 != 0 || lda % 4 != 0 || !aligned_to(A, 16) || M < 128 * 256) return false;
     return rows_lds_bytes(K, int((N + 31) / 32)) <= 160 * 1024;
 }
 
@@ -493,6 +496,8 @@ extern "C" int tfgx_gemm_bias_act_cols_f32(const float* A, int64_t lda, const fl
 #define TFGX_ROWS_CASE(T) \
     case T: return launch_gemm_rows<T>(A, lda, B, ldb, bias, act, C, ldc, M, int(K), int(N), ac, stream)
         switch ((N + 31) / 32) {
+            TFGX_ROWS_CASE(1);
+            TFGX_ROWS_CASE(2);
             TFGX_ROWS_CASE(3);
             TFGX_ROWS_CASE(4);
             TFGX_ROWS_CASE(5);
