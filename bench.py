@@ -221,7 +221,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
         "higher_is_better": True,
-        "scaling": "strong" if world > 1 else "weak",
+        "scaling": "strong",          # the SAME graph at every N: total work fixed, per-GPU work shrinks
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
