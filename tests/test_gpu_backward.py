@@ -347,3 +347,14 @@ def test_demo_gcn_trains_on_cora_shaped_graph(tfg):
     import demo_gcn
     acc, _ = demo_gcn.main(steps=60, forward_iters=0, quiet=True)
     assert acc > 0.5, acc
+
+
+def test_demo_gat_trains_with_attention_dropout(tfg):
+    """examples/demo_gat.py (counterpart of demo/demo_gat.py: 8-head GAT, edge_drop_rate 0.6 in both layers, weights
+    made trainable BEFORE the lazy build): the loss falls and the accuracy ends far above 1/7 chance."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    import demo_gat
+    acc, loss = demo_gat.main(steps=80, quiet=True)
+    assert acc > 0.5 and loss < 1.9, (acc, loss)

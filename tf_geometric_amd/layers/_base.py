@@ -17,6 +17,7 @@ class Layer(object):
         self._weights = {}
         self._gen = None
         self._seed = seed
+        self._trainable = False
 
     def _rng(self, dev):
         if self._gen is None:
@@ -57,6 +58,7 @@ class Layer(object):
     def trainable(self, flag=True):
         """Turn gradient tracking of every weight on/off.  With it on, calls run through the differentiable
         kernels of tf_geometric_amd.autograd (the role tf.GradientTape plays for the reference's keras layers)."""
+        self._trainable = bool(flag)          # also applies to weights created later (lazy build on the first call)
         for k in list(self._weights):
             t = getattr(self, k, None)
             if t is not None:
@@ -75,6 +77,8 @@ class Layer(object):
             x = inputs[0]
             self.build([tuple(x.shape)])
             self.built = True
+            if self._trainable:
+                self.trainable(True)
 
     def __call__(self, inputs, **kwargs):
         self._maybe_build(inputs)
