@@ -358,3 +358,14 @@ def test_demo_gat_trains_with_attention_dropout(tfg):
     import demo_gat
     acc, loss = demo_gat.main(steps=80, quiet=True)
     assert acc > 0.5 and loss < 1.9, (acc, loss)
+
+
+def test_demo_graph_sage_trains_with_neighbour_sampling(tfg):
+    """examples/demo_graph_sage.py (counterpart of demo/demo_graph_sage.py): a fresh k = 25 / 10 neighbour sample and a
+    fresh CSR plan per layer and step, MeanGraphSage x 2, multi-label loss — micro-F1 on an unseen graph improves."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    import demo_graph_sage
+    f1, loss = demo_graph_sage.main(epochs=4, quiet=True, num_train=3)
+    assert f1 > 0.68 and loss < 0.62, (f1, loss)
