@@ -53,7 +53,7 @@ def main(epochs=10, quiet=False, num_train=4):
     torch.manual_seed(0)
     train, test = ppi_shaped(num_train, seed=1), ppi_shaped(1, seed=2)
     for g in train + test:                                        # traverse all graphs (demo :15-18)
-        g["sampler"] = RandomNeighborSampler(g["edge_index"])
+        g["sampler"] = RandomNeighborSampler(tfg._lib.as_i32(g["edge_index"]))   # device tensors in -> device tensors out
         g["xt"], g["yt"] = tfg._lib.as_f32(g["x"]), tfg._lib.as_f32(g["y"])
     num_classes = train[0]["y"].shape[1]
     sages = [tfg.layers.MeanGraphSage(units=256, activation=tfg.relu, concat=True),

@@ -290,6 +290,34 @@ def test_graph_readout_pools(tfg, oracle):
     assert tfg.nn.max_pool(x, gid).shape[0] == int(gid.max()) + 1
 
 
+def test_sampler_output_carries_a_ready_plan(tfg, oracle):
+    """Tensor-mode sampler output is already grouped by destination: the layers reuse its CSR (no second sort) and get
+    the same result as from the bare edge list; gradients flow through the attached plan's transposed view."""
+    import torch
+    from tf_geometric_amd.plan import CsrPlan
+    n = 500
+    ei = oracle.synthetic_edges(n, 9000, seed=21)
+    ei = ei[:, ei[0] < 470]                                            # the last 30 nodes receive nothing
+    rng = np.random.Generator(np.random.PCG64(2))
+    x = rng.standard_normal((n, 12), dtype=np.float32)
+    sampler = tfg.utils.RandomNeighborSampler(tfg._lib.as_i32(ei))
+    sei, sw = sampler.sample(k=7, seed=3)
+    assert sei.is_cuda and hasattr(sei, "_tfgx_plan")
+    plan = CsrPlan.from_cache(sei, n, n, None)
+    assert plan.n_dst == n and plan.num_edges == sei.shape[1] and bool((plan.perm == torch.arange(plan.num_edges, device="cuda")).all())
+    layer = tfg.layers.MeanGraphSage(8, activation=tfg.relu)
+    a = layer([x, sei, sw])
+    b = layer([x, sei.cpu().numpy(), sw.cpu().numpy()])               # numpy copy: no attached plan, sorted again
+    assert torch.equal(a, b)
+    layer.trainable(True)
+    xt = torch.tensor(x, device="cuda", requires_grad=True)
+    layer([xt, sei, sw]).square().sum().backward()
+    g1 = xt.grad.clone()
+    xt.grad = None
+    layer([xt, sei.cpu().numpy(), sw.cpu().numpy()]).square().sum().backward()
+    assert torch.allclose(g1, xt.grad, rtol=1e-5, atol=1e-6)
+
+
 @pytest.mark.parametrize("as_tuple", [False, True])
 def test_neighbor_sampler_subgraph(tfg, oracle, as_tuple):
     """sampled_node_index (graph_utils.py:689-731): rows in the given order (with a duplicate and an id without edges),

@@ -53,12 +53,38 @@ class CsrPlan(object):
         return plan
 
     @staticmethod
+    def from_sorted(row_ptr, col, n_src, edge_index=None):
+        """Plan for edges that are ALREADY grouped by destination (row_ptr given): no sort, identity perm.  What the
+        neighbour sampler produces (its out_ptr is the row_ptr)."""
+        E = int(col.shape[0])
+        perm = torch.arange(E, dtype=torch.int32, device=col.device)
+        plan = CsrPlan(row_ptr.contiguous(), col.contiguous(), perm, int(row_ptr.shape[0]) - 1, n_src, E)
+        plan._edge_index = edge_index
+        plan._identity_perm = True
+        return plan
+
+    def padded_to(self, n_dst, n_src):
+        """The same plan seen as an [n_dst, n_src] operator (trailing destinations without edges)."""
+        if n_dst == self.n_dst and n_src == self.n_src:
+            return self
+        if n_dst < self.n_dst or n_src < self.n_src:
+            return None
+        tail = self.row_ptr[-1:].expand(n_dst - self.n_dst)
+        plan = CsrPlan(torch.cat([self.row_ptr, tail]).contiguous(), self.col, self.perm, n_dst, n_src, self.num_edges)
+        plan._edge_index = self._edge_index
+        plan._identity_perm = getattr(self, "_identity_perm", False)
+        return plan
+
+    @staticmethod
     def from_cache(edge_index, n_dst, n_src=None, cache=None, key=CACHE_KEY_PLAN):
         if cache is not None:
             plan = cache.get(key, None)
             if plan is not None:
                 return plan
-        plan = CsrPlan.build(edge_index, n_dst, n_src)
+        attached = getattr(edge_index, "_tfgx_plan", None)      # a producer that already knows the CSR (the sampler)
+        plan = attached.padded_to(n_dst, n_dst if n_src is None else n_src) if attached is not None else None
+        if plan is None:
+            plan = CsrPlan.build(edge_index, n_dst, n_src)
         if cache is not None:
             cache[key] = plan
         return plan
@@ -72,6 +98,8 @@ class CsrPlan(object):
         width = 1 if a.dim() == 1 else int(a.shape[1])
         if a.shape[0] != self.num_edges:
             raise ValueError("edge attribute has {} rows, graph has {} edges".format(a.shape[0], self.num_edges))
+        if getattr(self, "_identity_perm", False):
+            return a
         out = torch.empty_like(a)
         L.check(lib.tfgx_permute_rows_f32(L.ptr(a), L.ptr(self.perm), self.num_edges, width, L.ptr(out),
                                           L.stream_ptr()), "tfgx_permute_rows_f32")

@@ -218,4 +218,10 @@ class RandomNeighborSampler(object):
                                           L.ptr(out_col), L.ptr(out_w), L.stream_ptr()), "tfgx_sample_neighbors")
         rows = torch.repeat_interleave(torch.arange(n_rows, dtype=torch.int32, device=deg.device), cnt.long())
         ei = torch.stack([rows, out_col])
+        if not self._numpy:
+            # the sample is already grouped by destination and out_ptr is its row_ptr: hand the layers a ready CSR plan
+            # (CsrPlan.from_cache picks it up) instead of letting each of them sort the edge list again
+            from ..plan import CsrPlan
+            n_cols = self.num_col_nodes if sampled_node_index is None else int(col.max().item()) + 1 if total else 0
+            ei._tfgx_plan = CsrPlan.from_sorted(out_ptr, out_col, n_cols, edge_index=ei)
         return _out(ei, self._numpy), _out(out_w, self._numpy)
