@@ -314,6 +314,14 @@ int tfgx_gemm_bias_act_cols_f32(const float* A, int64_t lda, const float* B, int
                                 int32_t act, int64_t act_cols, float* C, int64_t ldc, int64_t M, int64_t K, int64_t N,
                                 tfgx_stream_t stream);
 
+/* same, with a caller-lent workspace of tfgx_gemm_workspace_bytes(M, K, N) bytes (0 for most shapes): small-M / long-K
+   products (Cora: 2708 x 1433 x 16) are cut along K over the idle CUs, the partial products are summed in split order
+   (deterministic) together with bias and activation.  workspace == NULL behaves like tfgx_gemm_bias_act_cols_f32. */
+size_t tfgx_gemm_workspace_bytes(int64_t M, int64_t K, int64_t N);
+int tfgx_gemm_bias_act_cols_ws_f32(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias,
+                                   int32_t act, int64_t act_cols, float* C, int64_t ldc, int64_t M, int64_t K, int64_t N,
+                                   void* workspace, size_t workspace_bytes, tfgx_stream_t stream);
+
 /* Neighbour sampling on the CSR plan (RandomNeighborSampler.sample, tf_geometric/utils/graph_utils.py:667-772, a
    pure-Python per-node loop in the reference).  Row r receives out_ptr[r+1]-out_ptr[r] = m neighbours out of its d:
    m >= d: all of them, in order; m < d: m distinct ones, uniformly (Floyd); m > d with replace_when_short: m draws

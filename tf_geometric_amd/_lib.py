@@ -101,6 +101,8 @@ SIGNATURES = {
     "tfgx_segment_topk": (ctypes.c_int, [_P, _P, _I64, _I64, _I32, _F32, _P, _P, _P, _SZ, _P]),
     "tfgx_segment_max_with_count_f32": (ctypes.c_int, [_P, _P, _P, _I64, _P, _I64, _I64, _P, _I64, _P, _I64, _P]),
     "tfgx_segment_max_backward_w_f32": (ctypes.c_int, [_P, _P, _P, _I64, _P, _I64, _I64, _P, _I64, _P, _I64, _P, _P]),
+    "tfgx_gemm_workspace_bytes": (_SZ, [_I64, _I64, _I64]),
+    "tfgx_gemm_bias_act_cols_ws_f32": (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I32, _I64, _P, _I64, _I64, _I64, _I64, _P, _SZ, _P]),
     "tfgx_dropout_keep": (ctypes.c_int32, [ctypes.c_uint64, ctypes.c_uint32, _F32]),
     "tfgx_permute_rows_f32": (ctypes.c_int, [_P, _P, _I64, _I64, _P, _P]),
     "tfgx_segment_reduce_f32": (ctypes.c_int, [ctypes.POINTER(ReduceArgs), _P]),

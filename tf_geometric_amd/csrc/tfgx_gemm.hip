@@ -25,8 +25,17 @@ __global__ __launch_bounds__(kBlock) void gemm_kernel(const float* __restrict__ 
                                                       const float* __restrict__ B, int64_t ldb,
                                                       const float* __restrict__ bias, int act,
                                                       float* __restrict__ C, int64_t ldc, int64_t M, int K, int N,
-                                                      int n_tiles_n, int act_cols)
+                                                      int n_tiles_n, int act_cols, int k_chunk, int64_t c_split_stride)
 {
+    // split-K (small M, long K — Cora's 2708 x 1433): blockIdx.y owns k in [y * k_chunk, (y + 1) * k_chunk) and writes
+    // its partial product to its own slab of C (a workspace; bias / activation are applied by splitk_reduce_kernel)
+    if (gridDim.y > 1) {
+        const int k_lo = blockIdx.y * k_chunk;
+        A += k_lo;
+        B += int64_t(k_lo) * ldb;
+        C += int64_t(blockIdx.y) * c_split_stride;
+        K = min(k_chunk, K - k_lo);
+    }
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_N = BN / WN;
     static_assert((BM / WM) * WAVES_N == 4, "4 waves per workgroup");
@@ -438,9 +447,37 @@ inline bool rows_ok(const float* A, int64_t lda, int64_t M, int64_t K, int64_t N
     return rows_lds_bytes(K, int((N + 31) / 32)) <= 160 * 1024;
 }
 
+// sum of the split-K partials + bias + activation, in split order (deterministic)
+__global__ void splitk_reduce_kernel(const float* __restrict__ parts, int splits, int64_t M, int N, const float* __restrict__ bias,
+                                     int act, int act_cols, float* __restrict__ C, int64_t ldc)
+{
+    int64_t t = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    const int64_t total = M * N;
+    for (; t < total; t += stride) {
+        const int64_t m = t / N;
+        const int n = int(t - m * N);
+        float acc = 0.0f;
+        for (int s2 = 0; s2 < splits; ++s2) acc += parts[int64_t(s2) * total + t];
+        if (bias) acc += bias[n];
+        C[m * ldc + n] = apply_act(acc, n < act_cols ? act : TFGX_ACT_NONE);
+    }
+}
+
+// how many K slices a generic-kernel launch with `tiles` output tiles should be cut into (1 = no split)
+inline int splitk_factor(int64_t tiles, int64_t K)
+{
+    if (tiles >= 128 || K < 512) return 1;
+    int64_t s = 256 / (tiles > 0 ? tiles : 1);
+    if (s > K / 128) s = K / 128;
+    if (s > 16) s = 16;
+    return s < 2 ? 1 : int(s);
+}
+
 template <int BM, int BN, int WM, int WN>
 int launch_gemm(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, int act, float* C,
-                int64_t ldc, int64_t M, int K, int N, int act_cols, hipStream_t stream)
+                int64_t ldc, int64_t M, int K, int N, int act_cols, hipStream_t stream, float* split_ws = nullptr,
+                int splits = 1)
 {
     const int ntn = (N + BN - 1) / BN;
     const int64_t ntm = (M + BM - 1) / BM;
@@ -451,15 +488,27 @@ int launch_gemm(const float* A, int64_t lda, const float* B, int64_t ldb, const 
     }
     const bool av4 = (lda % 4 == 0) && aligned_to(A, 16);
     const bool bv4 = (ldb % 4 == 0) && aligned_to(B, 16);
-    dim3 grid(static_cast<unsigned>(blocks), 1, 1), block(kBlock, 1, 1);
-#define TFGX_GEMM_GO(AV, BV) \
-    gemm_kernel<BM, BN, WM, WN, AV, BV><<<grid, block, 0, stream>>>(A, lda, B, ldb, bias, act, C, ldc, M, K, N, ntn, act_cols)
+    const bool split = split_ws != nullptr && splits > 1;
+    const int k_chunk = split ? int((((K + splits - 1) / splits) + 15) / 16 * 16) : K;
+    const int ny = split ? (K + k_chunk - 1) / k_chunk : 1;
+    float* out = split ? split_ws : C;
+    const int64_t ldo = split ? N : ldc;
+    const float* kb = split ? nullptr : bias;
+    const int ka = split ? TFGX_ACT_NONE : act;
+    dim3 grid(static_cast<unsigned>(blocks), static_cast<unsigned>(ny), 1), block(kBlock, 1, 1);
+#define TFGX_GEMM_GO(AV, BV)                                                                                         \
+    gemm_kernel<BM, BN, WM, WN, AV, BV><<<grid, block, 0, stream>>>(A, lda, B, ldb, kb, ka, out, ldo, M, K, N, ntn, \
+                                                                     act_cols, k_chunk, M * int64_t(N))
     if (av4 && bv4) TFGX_GEMM_GO(true, true);
     else if (av4) TFGX_GEMM_GO(true, false);
     else if (bv4) TFGX_GEMM_GO(false, true);
     else TFGX_GEMM_GO(false, false);
 #undef TFGX_GEMM_GO
     TFGX_LAUNCH_CHECK("gemm_kernel");
+    if (split) {
+        splitk_reduce_kernel<<<grid_for(M * N, kBlock), kBlock, 0, stream>>>(split_ws, ny, M, N, bias, act, act_cols, C, ldc);
+        TFGX_LAUNCH_CHECK("splitk_reduce_kernel");
+    }
     return TFGX_OK;
 }
 
@@ -468,9 +517,35 @@ int launch_gemm(const float* A, int64_t lda, const float* B, int64_t ldb, const 
 
 using namespace tfgx;
 
+static inline int64_t generic_tiles(int64_t M, int64_t N)
+{
+    const int64_t bm = N <= 32 ? 256 : 128, bn = N <= 32 ? 32 : (N <= 64 ? 64 : 128);
+    return ((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+}
+
+extern "C" size_t tfgx_gemm_workspace_bytes(int64_t M, int64_t K, int64_t N)
+{
+    if (M <= 0 || K <= 0 || N <= 0) return 0;
+    const int s = splitk_factor(generic_tiles(M, N), K);
+    return s > 1 ? sizeof(float) * size_t(s) * size_t(M) * size_t(N) : 0;
+}
+
+extern "C" int tfgx_gemm_bias_act_cols_ws_f32(const float* A, int64_t lda, const float* B, int64_t ldb,
+                                              const float* bias, int32_t act, int64_t act_cols, float* C, int64_t ldc,
+                                              int64_t M, int64_t K, int64_t N, void* workspace, size_t workspace_bytes,
+                                              tfgx_stream_t stream_);
+
 extern "C" int tfgx_gemm_bias_act_cols_f32(const float* A, int64_t lda, const float* B, int64_t ldb,
                                            const float* bias, int32_t act, int64_t act_cols, float* C, int64_t ldc,
                                            int64_t M, int64_t K, int64_t N, tfgx_stream_t stream_)
+{
+    return tfgx_gemm_bias_act_cols_ws_f32(A, lda, B, ldb, bias, act, act_cols, C, ldc, M, K, N, nullptr, 0, stream_);
+}
+
+extern "C" int tfgx_gemm_bias_act_cols_ws_f32(const float* A, int64_t lda, const float* B, int64_t ldb,
+                                              const float* bias, int32_t act, int64_t act_cols, float* C, int64_t ldc,
+                                              int64_t M, int64_t K, int64_t N, void* workspace, size_t workspace_bytes,
+                                              tfgx_stream_t stream_)
 {
     TFGX_REQUIRE(M >= 0 && K >= 1 && N >= 1, "bad M / K / N");
     TFGX_REQUIRE(K < (int64_t(1) << 30) && N < (int64_t(1) << 30), "K / N too large");
@@ -507,9 +582,15 @@ extern "C" int tfgx_gemm_bias_act_cols_f32(const float* A, int64_t lda, const fl
         }
 #undef TFGX_ROWS_CASE
     }
-    if (N <= 32) return launch_gemm<256, 32, 64, 32>(A, lda, B, ldb, bias, act, C, ldc, M, int(K), int(N), ac, stream);
-    if (N <= 64) return launch_gemm<128, 64, 32, 64>(A, lda, B, ldb, bias, act, C, ldc, M, int(K), int(N), ac, stream);
-    return launch_gemm<128, 128, 64, 64>(A, lda, B, ldb, bias, act, C, ldc, M, int(K), int(N), ac, stream);
+    // small M with a long K leaves most CUs idle: split K over blockIdx.y when the caller lent a workspace
+    int splits = splitk_factor(generic_tiles(M, N), K);
+    float* ws = static_cast<float*>(workspace);
+    if (ws == nullptr || workspace_bytes < sizeof(float) * size_t(splits) * size_t(M) * size_t(N)) splits = 1;
+    if (N <= 32)
+        return launch_gemm<256, 32, 64, 32>(A, lda, B, ldb, bias, act, C, ldc, M, int(K), int(N), ac, stream, ws, splits);
+    if (N <= 64)
+        return launch_gemm<128, 64, 32, 64>(A, lda, B, ldb, bias, act, C, ldc, M, int(K), int(N), ac, stream, ws, splits);
+    return launch_gemm<128, 128, 64, 64>(A, lda, B, ldb, bias, act, C, ldc, M, int(K), int(N), ac, stream, ws, splits);
 }
 
 extern "C" int tfgx_gemm_bias_act_f32(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias,
