@@ -49,8 +49,18 @@ __global__ __launch_bounds__(256) void gather_spans(const float* __restrict__ ta
 
 __global__ __launch_bounds__(256) void stream_read(const float4* __restrict__ table, int64_t n4, float* __restrict__ out)
 {
+    constexpr int U = 8;   // 8 independent 16-byte loads in flight per lane, like the gather probe
     float acc = 0.0f;
-    for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < n4; i += int64_t(gridDim.x) * 256) {
+    const int64_t stride = int64_t(gridDim.x) * 256;
+    int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    for (; i + (U - 1) * stride < n4; i += U * stride) {
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = table[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc += v[u].x + v[u].y + v[u].z + v[u].w;
+    }
+    for (; i < n4; i += stride) {
         const float4 v = table[i];
         acc += v.x + v.y + v.z + v.w;
     }
