@@ -8,8 +8,11 @@
 //                                            (TF semantics: the gradient is split evenly among tied maxima)
 //   GAT attention gradient                 = tfgx_gat_backward_dst_f32 (dQ) + tfgx_gat_backward_src_f32 (dK, dV),
 //                                            flash-attention style: alpha is recomputed from the saved (m, l)
+//   unsorted_segment_max (training forward) = tfgx_segment_max_with_count_f32: maxima and tie counts in one pass
+//   d(max)/d(edge weight)                  = tfgx_segment_max_backward_w_f32 (the SDDMM kernel with an arg-max mask)
 // Every accumulation has one owner (a destination row or a source row): deterministic, no atomics.
-// These kernels favour clarity over speed (one lane per (row, head) for GAT); the forward path is the tuned one.
+// Each entry point has a tuned kernel (lane group per row, float4 columns, the forward kernel's mapping) and a plain
+// one-lane-per-output fallback for layouts the tuned one does not cover.
 #include "tfgx_common.h"
 #include <cfloat>
 #include <cstring>

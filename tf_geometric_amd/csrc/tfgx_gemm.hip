@@ -7,10 +7,14 @@
 // K and N are feature widths (16..1433), so the kernel is a tall-skinny GEMM close to the HBM roofline:
 // the A panel is streamed once, B (<= 1.5 MB) lives in L2/LDS.
 //
-// Tile: BM x BN per 256-thread workgroup (4 waves), BK = 16.  A is staged transposed in LDS (As[k][m]) so
-// the MFMA A operand (lane l: A[m = l&31][k = l>>5]) is a conflict-free ds_read_b32 over consecutive m;
-// B is staged as Bs[k][n].  Global loads for tile t+1 are issued before the MFMAs of tile t (register
-// staging), LDS is single-buffered.
+// Two kernels:
+//  * gemm_rows_kernel (N <= 256, K % 4 == 0, B within 160 KB of LDS, M >= 32768 — the shapes the layers produce on
+//    large graphs): persistent, B resident in LDS, A loaded straight into the MFMA operand layout, no barriers after
+//    the B load.  See its own header comment below.
+//  * gemm_kernel (everything else): BM x BN tile per 256-thread workgroup (4 waves), BK = 16.  A is staged transposed
+//    in LDS (As[k][m]) so the MFMA A operand (lane l: A[m = l&31][k = l>>5]) is a conflict-free ds_read_b32 over
+//    consecutive m; B is staged as Bs[k][n].  Global loads for tile t+1 are issued before the MFMAs of tile t
+//    (register staging), LDS is single-buffered.  Optional split-K over blockIdx.y for small M with a long K.
 #include "tfgx_common.h"
 
 namespace tfgx {
