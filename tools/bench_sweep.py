@@ -58,6 +58,8 @@ def main():
         reddit_section(quick)
     if want("papers_shard"):
         papers_shard_section(quick)
+    if only and "papers_full" in only[0].split(","):        # explicit only: ~140 GB of HBM
+        papers_full_section(quick)
     if want("gemm"):
         gemm_section(n)
     if only and not any(want(s) for s in ("widths", "split", "rmat", "gat", "backward")):
@@ -249,6 +251,48 @@ def papers_shard_section(quick):
                       "table_GB": n_src * f * 4 / 1e9, "ms": ms, "GBps_alg": balg / ms / 1e6,
                       "frac_of_8TBps": balg / ms / 1e6 / 8000, "Gedges_per_s": E / ms / 1e6,
                       "spot_max_abs_err": err, "mem_allocated_GB": torch.cuda.max_memory_allocated() / 1e9}), flush=True)
+    del x, out, plan, w
+
+
+def papers_full_section(quick):
+    """BASELINE.json configs[4] on ONE GPU: the whole ogbn-papers100M-shaped graph (N = 111 M, E = 1.6 G, F = 128) —
+    edge list, plan, features and output resident together (~140 GB of the 288 GB).  The HBM-capacity stress the
+    config names, without the 8-way split: plan build time, one weighted segment-sum pass, spot parity."""
+    n = 111000000 if not quick else 11100000
+    E = 1600000000 if not quick else 160000000
+    f = 128
+    g = torch.Generator(device="cuda")
+    g.manual_seed(12)
+    row = torch.randint(0, n, (E,), generator=g, device="cuda", dtype=torch.int32)
+    col = torch.randint(0, n, (E,), generator=g, device="cuda", dtype=torch.int32)
+    ei = torch.stack([row, col])
+    del row, col
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    plan = CsrPlan.build(ei, n, n)
+    torch.cuda.synchronize()
+    plan_s = time.perf_counter() - t0
+    plan._edge_index = None
+    del ei
+    torch.cuda.empty_cache()
+    x = torch.empty(n, f, device="cuda")
+    for i in range(0, n, 1 << 24):
+        x[i:i + (1 << 24)].normal_(generator=g)
+    w = torch.rand(E, generator=g, device="cuda") + 0.5
+    out = torch.empty(n, f, device="cuda")
+    ms = timeit(lambda: segment_reduce(plan, x, L.SUM, w_csr=w, out=out), steps=5, warmup=2)
+    balg = E * (4 * f + 8) + n * 4 * f + 4 * (n + 1)
+    rp = plan.row_ptr.long()
+    err = 0.0
+    for r in (0, n // 2, n - 1):
+        s, t = int(rp[r]), int(rp[r + 1])
+        ref = (x[plan.col[s:t].long()].double() * w[s:t, None].double()).sum(0)
+        err = max(err, float((out[r].double() - ref).abs().max()))
+    assert int(rp[-1]) == E
+    print(json.dumps({"kind": "papers100M_full_one_gpu", "N": n, "E": E, "F": f, "plan_build_s": plan_s, "ms": ms,
+                      "GBps_alg": balg / ms / 1e6, "frac_of_8TBps": balg / ms / 1e6 / 8000,
+                      "Gedges_per_s": E / ms / 1e6, "spot_max_abs_err": err,
+                      "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9}), flush=True)
     del x, out, plan, w
 
 
