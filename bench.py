@@ -376,6 +376,24 @@ def extras(tfg, L, synthetic, x, ei, n, e, f, cache):
         gt([x, ei], cache=cache).sum().backward()
 
     res["gcn_layer_fwd_bwd_ms"] = _time(train_step, steps=5, warmup=2)
+    # one full-batch training step of the 2-layer model (F -> 256 -> 40): forward, cross-entropy on 10 % of the nodes,
+    # backward through both layers (aggregation on the transposed plan, GEMM gradients), Adam update
+    t0l, t1l = tfg.layers.GCN(256, activation=tfg.relu), tfg.layers.GCN(40)
+    t0l.trainable(True)
+    t1l.trainable(True)
+    with torch.no_grad():
+        t1l([t0l([x, ei], cache=cache), ei], cache=cache)
+    opt = torch.optim.Adam(t0l.parameters() + t1l.parameters(), lr=1e-2)
+    idx = torch.arange(0, n, 10, device=x.device)
+    labels = torch.randint(0, 40, (int(idx.shape[0]),), device=x.device)
+
+    def full_step():
+        opt.zero_grad(set_to_none=True)
+        logits = t1l([t0l([x, ei], cache=cache), ei], cache=cache)
+        torch.nn.functional.cross_entropy(logits[idx], labels).backward()
+        opt.step()
+
+    res["gcn_2layer_train_step_ms"] = _time(full_step, steps=5, warmup=2)
     from tf_geometric_amd.plan import gemm_bias_act
     k = L.as_f32(synthetic.glorot_uniform(f, 256))
     ms = _time(lambda: gemm_bias_act(x, k))
