@@ -247,7 +247,8 @@ def main():
         achieved = bytes_alg / (ev_ms * 1e-3)
         # compulsory lower bound: every array touched exactly once
         bytes_min = 8 * e_agg + 4 * (n + 1) + 2 * n * 4 * f
-        line["roofline"] = {"bound": "hbm", "kernel": "seg_reduce_kernel<4,32,1,sum,weighted>",
+        kname = "seg_reduce_kernel<4,32,1,sum,weighted>" if f == 100 else "seg_reduce_kernel (sum, weighted; F={})".format(f)
+        line["roofline"] = {"bound": "hbm", "kernel": kname,
                             "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                             "frac": achieved / HBM_PEAK, "traffic": None,
                             "algorithmic_bytes_per_launch": bytes_alg, "kernel_ms": ev_ms,
