@@ -10,7 +10,7 @@
  *   - every pointer is a DEVICE pointer owned by the caller unless it says "host";
  *   - nothing is allocated here: outputs and workspaces are caller buffers;
  *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), except
- *     tfgx_build_csr_by_dst, which synchronises once to report bad indices;
+ *     tfgx_build_csr_by_dst and tfgx_segment_topk, which synchronise once to report bad indices;
  *   - return value: 0 = ok, otherwise a TFGX_ERR_* code; text via tfgx_last_error();
  *   - results are deterministic (no floating-point atomics anywhere);
  *   - index convention of the reference: edge_index[0] = row = DESTINATION (aggregating node),
