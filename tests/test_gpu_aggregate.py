@@ -197,7 +197,6 @@ def test_split_row_layout_is_bit_identical(tfg, oracle, f):
 def test_edge_tail_on_hub_rows(tfg, oracle):
     import torch
     from tf_geometric_amd.plan import CsrPlan, SplitRows, segment_reduce
-    import tf_geometric_amd.plan as P
     L = tfg._lib
     n, f = 2000, 100
     rng = np.random.Generator(np.random.PCG64(5))

@@ -57,7 +57,6 @@ def test_aggregate_grad_x_and_w(tfg, oracle, op, weighted):
 def test_sddmm_widths(tfg, oracle, f):
     """tfgx_sddmm_f32 out[i] = <a[row(i)], b[col[i]]> on every dispatch (tuned float4 kernel 16 <= F <= 512, F % 4 == 0;
     scalar kernel otherwise), rows with 0 / 1 / 8 / 9 / many edges."""
-    import ctypes
     from tf_geometric_amd import _lib as L
     from tf_geometric_amd.plan import CsrPlan
     rng = np.random.Generator(np.random.PCG64(f))

@@ -2,7 +2,6 @@
 """BASELINE.json's FULL sizes on the GPU, through size-independent properties (the oracle cannot finish these in
 seconds): checksum of checksums, linearity, mean*degree == sum, max invariances, softmax partition of unity,
 determinism.  Shapes: ogbn-products (N=2.4M, E=123M, F=100) and Reddit (N=233k, E=114M, 8-head GAT)."""
-import numpy as np
 import pytest
 import torch
 

@@ -2,7 +2,6 @@
 """Layer wrappers of nn/conv/propagation.py — drop-ins for tf_geometric.layers.{GIN, SGC, TAGCN, APPNP, SSGC,
 ChebyNet, LEConv} (reference: layers/conv/{gin,sgc,tagcn,appnp,ssgc,chebynet,le_conv}.py; same constructor
 arguments and weight names)."""
-import torch
 
 from ...activations import relu
 from ...nn.conv.propagation import gin, sgc, tagcn, appnp, ssgc, chebynet, le_conv, chebynet_norm_edge
