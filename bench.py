@@ -291,6 +291,11 @@ def main():
                 "kernel_ms": ms2, "edges_per_s": e / (ms2 * 1e-3), "frac_of_hbm_peak_algorithmic": bytes_alg / (ms2 * 1e-3) / HBM_PEAK,
                 "build_ms_once_per_feature_matrix": build_ms, "extra_bytes": int(rows.edge_tail.numel() * 4),
                 "bit_identical_to_headline_output": bool(torch.equal(out2, res))}
+            et_path = os.path.join(ROOT, "profiles", "r01_{}_edge_tail_pmc.json".format(args.workload))
+            if os.path.exists(et_path):          # measured HBM-side bytes of this launch (rocprofv3 PMC passes)
+                with open(et_path) as fh:
+                    line["static_feature_layout"]["traffic"] = json.load(fh)["traffic_bytes_per_launch"]
+                line["static_feature_layout"]["traffic_source"] = "profiles/" + os.path.basename(et_path)
             del rows, out2
         if not args.no_cpu_baseline:
             budget = {"products": 61_500_000}.get(args.workload, e)
