@@ -255,6 +255,24 @@ def main():
                             "bytes_per_edge": 4 * f + 8,
                             "compulsory_bytes_per_launch": bytes_min,
                             "frac_compulsory": bytes_min / (ev_ms * 1e-3) / HBM_PEAK}
+        # 128-byte line requests: what actually bounds a gather.  A 4F-byte row at a 4F-byte stride
+        # touches ceil((offset mod 128 + 4F) / 128) lines; the ceiling is the measured random-span fetch rate of
+        # tools/line_rate_probe.cpp over a table of this size, when that profile is committed.
+        row_bytes = 4 * f
+        offs = sorted({(row_bytes * i) % 128 for i in range(128)})
+        lines_per_row = sum(-(-(o + row_bytes) // 128) for o in offs) / float(len(offs))
+        line["roofline"]["row_lines_per_launch"] = e_agg * lines_per_row
+        line["roofline"]["row_lines_per_s"] = e_agg * lines_per_row / (ev_ms * 1e-3)
+        probe_path = os.path.join(ROOT, "profiles", "r01_line_rate_probe_916MiB.jsonl")
+        if args.workload == "products" and os.path.exists(probe_path):
+            best = 0.0
+            with open(probe_path) as fh:
+                for ln in fh:
+                    rec = json.loads(ln)
+                    if rec.get("probe") == "random_spans":
+                        best = max(best, rec["G_lines_per_s"] * 1e9)
+            line["roofline"]["random_line_ceiling_per_s"] = best
+            line["roofline"]["frac_of_random_line_ceiling"] = line["roofline"]["row_lines_per_s"] / best
         # HBM-side bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE;
         # see profiles/): a property of kernel + workload, cannot be sampled from inside this process.
         pmc_path = os.path.join(ROOT, "profiles", "r01_{}_pmc.json".format(args.workload))
