@@ -100,3 +100,41 @@ def test_propagation_layers_are_trainable(tfg, g):
     out.square().mean().backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() and float(p.grad.abs().sum()) > 0
                for p in layer.parameters())
+
+
+def test_sparse_node_features_across_convs(tfg, oracle, g):
+    """Sparse x (the reference's isinstance(x, tf.sparse.SparseTensor) branches: gat.py:47-68, sgc.py:31, tagcn.py:32,
+    appnp.py:64, ssgc.py:73, chebynet.py:100-119): same outputs as the dense features they encode, as a SparseMatrix and
+    as a torch sparse COO tensor; GAT's kernels receive gradients through the sparse projections."""
+    rng = np.random.Generator(np.random.PCG64(77))
+    n, f = g["n"], g["f"]
+    dense = ((rng.random((n, f)) < 0.2) * rng.standard_normal((n, f))).astype(np.float32)
+    dense[3] = 0
+    r, c = np.nonzero(dense)
+    xs = tfg.SparseMatrix(np.stack([r, c]).astype(np.int32), dense[r, c], [n, f])
+    xt = torch.sparse_coo_tensor(np.stack([r, c]), dense[r, c], (n, f)).cuda()
+    ei, w = g["ei"], g["w"]
+
+    def both(make, call, what, tol=1e-5):
+        layer = make()
+        ref = call(layer, dense).cpu().numpy()
+        assert_parity(call(layer, xs).cpu().numpy(), ref, tol=tol, what=what + " (SparseMatrix)")
+        assert_parity(call(layer, xt).cpu().numpy(), ref, tol=tol, what=what + " (torch COO)")
+
+    both(lambda: tfg.layers.GAT(16, attention_units=8, num_heads=4, activation=tfg.relu),
+         lambda l, x: l([x, ei]), "GAT", tol=2e-5)
+    both(lambda: tfg.layers.SGC(9, k=2, activation=tfg.relu), lambda l, x: l([x, ei, w], cache={}), "SGC")
+    both(lambda: tfg.layers.TAGCN(7, k=2), lambda l, x: l([x, ei, w]), "TAGCN")
+    both(lambda: tfg.layers.APPNP([16, 6], k=4, alpha=0.1), lambda l, x: l([x, ei, w]), "APPNP")
+    both(lambda: tfg.layers.SSGC([16, 6], k=3, alpha=0.2), lambda l, x: l([x, ei, w]), "SSGC")
+    both(lambda: tfg.layers.SSGC(None, k=3), lambda l, x: l([x, ei]), "SSGC without MLP")
+    both(lambda: tfg.layers.ChebyNet(8, k=3), lambda l, x: l([x, ei, w]), "ChebyNet")
+    gat = tfg.layers.GAT(8, attention_units=4, num_heads=2)
+    gat.trainable(True)
+    gat([xs, ei]).square().sum().backward()
+    gs = {k: getattr(gat, k).grad.clone() for k in ("query_kernel", "key_kernel", "kernel")}
+    for p_ in gat.parameters():
+        p_.grad = None
+    gat([dense, ei]).square().sum().backward()
+    for k, v in gs.items():
+        assert_parity(v.cpu().numpy(), getattr(gat, k).grad.cpu().numpy(), tol=1e-4, what="GAT d/d" + k + " via sparse x")

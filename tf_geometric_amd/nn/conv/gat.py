@@ -14,6 +14,7 @@ import torch
 from ... import _lib as L
 from ...activations import resolve as _resolve_act
 from ...plan import CsrPlan, gemm_bias_act
+from ...sparse import sparse_features, sparse_dense_matmul
 from ... import autograd as AG
 
 
@@ -36,6 +37,12 @@ def _project_qkv(x, wq, bq, qact, wk, bk, kact, wv):
     qa, qpost = _resolve_act(qact)
     ka, kpost = _resolve_act(kact)
     A = int(wq.shape[1])
+    xs = sparse_features(x)
+    if xs is not None:      # sparse node features: the three projections are sparse_dense_matmuls (gat.py:49-68)
+        def sp(wm, bm, code, post):
+            h = sparse_dense_matmul(xs, wm, bias=bm, act=code)
+            return post(h) if post is not None else h
+        return sp(wq, bq, qa, qpost), sp(wk, bk, ka, kpost), sparse_dense_matmul(xs, wv)
     if (qa == ka and qpost is None and kpost is None and (bq is None) == (bk is None) and int(wk.shape[1]) == A and
             (A <= 16 or A % 32 == 0)):
         dev = x.device
@@ -110,10 +117,15 @@ def gat_attention(plan, Q, K, V, num_heads, add_self_loop=True, bias=None, act=L
 def _gat_train(x, plan, wq, bq, qact, wk, bk, kact, kernel, bias, activation, num_heads, split_value_heads,
                drop_rate=0.0):
     """Differentiable route (autograd.py): same math, un-fused epilogues."""
+    xs = sparse_features(x)
+
     def lin(w, b, actv):
         code, post = _resolve_act(actv)
+        if xs is not None:
+            return AG.apply_activation(sparse_dense_matmul(xs, w, bias=b, act=code), L.ACT_NONE, post)
         return AG.apply_activation(AG.linear(x, w, b, code), L.ACT_NONE, post)
-    Q, K, V = lin(wq, bq, qact), lin(wk, bk, kact), AG.linear(x, kernel)
+    Q, K, V = lin(wq, bq, qact), lin(wk, bk, kact), (sparse_dense_matmul(xs, kernel) if xs is not None
+                                                      else AG.linear(x, kernel))
     h = AG.gat_attention(plan, Q, K, V, num_heads, drop_rate=drop_rate,
                          drop_seed=new_drop_seed() if drop_rate > 0.0 else 0)
     if not split_value_heads:
@@ -143,10 +155,12 @@ def gat(x, edge_index,
     drop = float(edge_drop_rate) if training else 0.0           # SparseMatrix.dropout(rate, training) (:85)
     if not 0.0 <= drop < 1.0:
         raise Exception("edge_drop_rate must be in [0, 1)")
-    x = L.as_f32(x)
+    xs = sparse_features(x)
+    x = xs if xs is not None else L.as_f32(x)
     n = int(x.shape[0])
     plan = CsrPlan.from_cache(edge_index, n, n, cache)
-    if drop > 0.0 or AG.needs_grad(x, query_kernel, query_bias, key_kernel, key_bias, kernel, bias):
+    if drop > 0.0 or AG.needs_grad(None if xs is not None else x, query_kernel, query_bias, key_kernel, key_bias, kernel,
+                                   bias):
         return _gat_train(x, plan, query_kernel, query_bias, query_activation, key_kernel, key_bias, key_activation,
                           kernel, bias, activation, num_heads, split_value_heads, drop_rate=drop)
     Q, K, V = _project_qkv(x, query_kernel, query_bias, query_activation, key_kernel, key_bias, key_activation, kernel)

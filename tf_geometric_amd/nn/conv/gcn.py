@@ -10,7 +10,7 @@ import torch
 from ... import _lib as L
 from ...activations import resolve as _resolve_act
 from ...plan import segment_reduce, gemm_bias_act, static_rows
-from ...sparse import SparseMatrix
+from ...sparse import SparseMatrix, sparse_features, sparse_dense_matmul
 from ... import autograd as AG
 
 CACHE_KEY_GCN_NORMED_ADJ_TEMPLATE = "gcn_normed_adj_{}_{}_{}_{}_{}"
@@ -147,11 +147,6 @@ def gcn_mapper(repeated_x, neighbor_x, edge_weight=None):
     return _m(repeated_x, neighbor_x, edge_weight)
 
 
-def _from_torch_sparse(x):
-    x = x.coalesce()
-    return SparseMatrix(x.indices().to(torch.int32), x.values(), list(x.shape))
-
-
 def gcn(x, sparse_adj, kernel, bias=None, activation=None, norm="both", add_self_loop=True, sym=True,
         renorm=True, improved=False, edge_drop_rate=0.0, num_or_size_splits=None, training=False, cache=None):
     """
@@ -165,14 +160,13 @@ def gcn(x, sparse_adj, kernel, bias=None, activation=None, norm="both", add_self
     :return: [num_nodes, num_output_features]
     """
     L.require_gpu()
-    if isinstance(x, SparseMatrix) or getattr(x, "is_sparse", False):
+    xs = sparse_features(x)
+    if xs is not None:
         # sparse node features (one-hot / bag-of-words rows; tf.sparse.sparse_dense_matmul, :269-270):
         # x @ W is itself a gather-scale-segment-sum with the KERNEL as the source table — the same HIP kernel
         if kernel is None:
             raise Exception("sparse node features need a kernel (the reference would propagate the SparseTensor itself)")
-        xs = x if isinstance(x, SparseMatrix) else _from_torch_sparse(x)
-        x = (AG.aggregate(xs.plan, L.as_f32(kernel), L.SUM, xs.value_csr) if AG.needs_grad(kernel)
-             else xs.matmul(L.as_f32(kernel)))
+        x = sparse_dense_matmul(xs, kernel)
         kernel = None
     normed = gcn_norm_adj(sparse_adj, norm=norm, add_self_loop=add_self_loop, sym=sym, renorm=renorm,
                           improved=improved, cache=cache)                                         # :260

@@ -14,7 +14,7 @@ from ... import _lib as L
 from ... import autograd as AG
 from ...activations import resolve as _resolve_act
 from ...plan import CsrPlan, segment_reduce, gemm_bias_act
-from ...sparse import SparseMatrix
+from ...sparse import SparseMatrix, sparse_features, sparse_dense_matmul
 from .gcn import gcn_norm_adj, NormedAdj
 
 CACHE_KEY_CHEBYNET_NORMED_EDGE_TEMPLATE = "chebynet_normed_edge_{}"
@@ -28,10 +28,22 @@ def _prop(plan, h, w_csr, self_coef):
 
 def _dense(h, kernel, bias=None, activation=None):
     act, post = _resolve_act(activation)
+    hs = sparse_features(h)
+    if hs is not None:      # sparse node features: tf.sparse.sparse_dense_matmul at the reference's call sites
+        out = sparse_dense_matmul(hs, kernel, bias=bias, act=act)
+        return post(out) if post is not None else out
     if AG.needs_grad(h, kernel, bias):
         return AG.apply_activation(AG.linear(h, kernel, bias, act), L.ACT_NONE, post)
     out = gemm_bias_act(h, kernel, bias=bias, act=act)
     return post(out) if post is not None else out
+
+
+def _features(x, densify=False):
+    """Dense fp32 features, or the SparseMatrix form of sparse ones (densified where the reference densifies)."""
+    xs = sparse_features(x)
+    if xs is None:
+        return L.as_f32(x)
+    return xs.to_dense() if densify else xs
 
 
 def _finish(h, bias, activation):
@@ -66,8 +78,8 @@ def gin(x, edge_index, mlp_model, eps=0.0, training=None, cache=None):
 
 
 def sgc(x, edge_index, edge_weight, k, kernel, bias=None, activation=None, renorm=True, improved=False, cache=None):
-    """A_hat^k (x @ kernel) + bias  (reference: sgc.py:10-61; the GEMM comes first there too)."""
-    x = L.as_f32(x)
+    """A_hat^k (x @ kernel) + bias  (reference: sgc.py:10-61; the GEMM comes first there too; x may be sparse, :31)."""
+    x = _features(x)
     normed = _normed(x, edge_index, edge_weight, cache, renorm=renorm, improved=improved)
     h = _dense(x, kernel)                                              # :33-36
     for _ in range(k):
@@ -76,8 +88,8 @@ def sgc(x, edge_index, edge_weight, k, kernel, bias=None, activation=None, renor
 
 
 def tagcn(x, edge_index, edge_weight, k, kernel, bias=None, activation=None, renorm=False, improved=False, cache=None):
-    """concat(x, A x, ..., A^k x) @ kernel  (reference: tagcn.py:10-51)."""
-    x = L.as_f32(x)
+    """concat(x, A x, ..., A^k x) @ kernel  (reference: tagcn.py:10-51; sparse x is densified first, :32-35)."""
+    x = _features(x, densify=True)
     normed = _normed(x, edge_index, edge_weight, cache, renorm=renorm, improved=improved)
     xs = [x]
     for _ in range(k):
@@ -102,8 +114,8 @@ def _mlp_encoder(x, kernels, biases, dense_activation, training, dense_drop_rate
 
 def appnp(x, edge_index, edge_weight, kernels, biases, dense_activation="relu", activation=None, k=10, alpha=0.1,
           dense_drop_rate=0.0, last_dense_drop_rate=0.0, edge_drop_rate=0.0, cache=None, training=False):
-    """Z <- (1 - alpha) A_hat Z + alpha H, k times, H = MLP(x)  (reference: appnp.py:11-92)."""
-    x = L.as_f32(x)
+    """Z <- (1 - alpha) A_hat Z + alpha H, k times, H = MLP(x)  (reference: appnp.py:11-92; x may be sparse, :64)."""
+    x = _features(x)
     normed = _normed(x, edge_index, edge_weight, cache).dropout(edge_drop_rate, training=training)
     h = _mlp_encoder(x, kernels, biases, dense_activation, training, dense_drop_rate, last_dense_drop_rate)
     output = h
@@ -116,8 +128,8 @@ def appnp(x, edge_index, edge_weight, kernels, biases, dense_activation="relu", 
 def ssgc(x, edge_index, edge_weight, kernels=None, biases=None, k=10, alpha=0.1, dense_activation="relu",
          activation=None, dense_drop_rate=0.0, last_dense_drop_rate=0.0, edge_drop_rate=0.0, cache=None,
          training=False):
-    """alpha H + (1 - alpha)/k * sum_{t=1..k} A_hat^t H  (reference: ssgc.py:11-99)."""
-    x = L.as_f32(x)
+    """alpha H + (1 - alpha)/k * sum_{t=1..k} A_hat^t H  (reference: ssgc.py:11-99; x may be sparse, :73)."""
+    x = _features(x, densify=kernels is None)
     normed = _normed(x, edge_index, edge_weight, cache).dropout(edge_drop_rate, training=training)
     h = _mlp_encoder(x, kernels, biases, dense_activation, training, dense_drop_rate, last_dense_drop_rate)
     output = h * alpha                                                 # :90
@@ -186,12 +198,14 @@ def chebynet_norm_edge(edge_index, num_nodes, edge_weight=None, normalization_ty
 
 def chebynet(x, edge_index, edge_weight, k, kernels, bias=None, activation=None, normalization_type="sym",
              use_dynamic_lambda_max=False, cache=None):
-    """sum_i T_i(L~) x @ kernels[i]  (reference: chebynet.py:83-137)."""
-    x = L.as_f32(x)
+    """sum_i T_i(L~) x @ kernels[i]  (reference: chebynet.py:83-137; a sparse x feeds kernels[0] sparsely and is
+    densified for the propagation, :100-119)."""
+    x0 = _features(x)
+    x = x0.to_dense() if isinstance(x0, SparseMatrix) else x0
     n = int(x.shape[0])
     normed = chebynet_norm_edge(edge_index, n, edge_weight, normalization_type, use_dynamic_lambda_max, cache)
     T0 = x
-    out = _dense(T0, kernels[0])                                       # :101-106
+    out = _dense(x0, kernels[0])                                       # :101-106
     if k > 1:
         T1 = _prop(normed.plan, x, normed.w_csr, normed.self_coef)     # :112
         out = out + _dense(T1, kernels[1])

@@ -114,3 +114,29 @@ class SparseMatrix(object):
     def to_dense(self):
         eye = torch.eye(self._shape[1], dtype=torch.float32, device=self.index.device)
         return self.matmul(eye)
+
+
+def sparse_features(x):
+    """x as a SparseMatrix when it is one (or a torch sparse COO tensor), else None — the reference's
+    isinstance(x, tf.sparse.SparseTensor) test (nn/conv/gcn.py:269, gat.py:47, sgc.py:31, appnp.py:64 ...)."""
+    if isinstance(x, SparseMatrix):
+        return x
+    if isinstance(x, torch.Tensor) and x.is_sparse:
+        x = x.coalesce()
+        return SparseMatrix(x.indices().to(torch.int32), x.values(), list(x.shape))
+    return None
+
+
+def sparse_dense_matmul(xs, kernel, bias=None, act=L.ACT_NONE):
+    """act(xs @ kernel + bias) for sparse node features (tf.sparse.sparse_dense_matmul at the call sites above): a
+    gather-scale-segment-sum over the nonzeros of xs with the KERNEL rows as the source table — the same HIP kernel as
+    the neighbour aggregation.  Differentiable wrt kernel / bias when they are being tracked."""
+    from . import autograd as AG
+    k = L.as_f32(kernel)
+    b = None if bias is None else L.as_f32(bias)
+    if AG.needs_grad(k, b):
+        h = AG.aggregate(xs.plan, k, L.SUM, xs.value_csr)
+        if b is not None:
+            h = h + b
+        return torch.relu(h) if act == L.ACT_RELU else h
+    return segment_reduce(xs.plan, k, L.SUM, w_csr=xs.value_csr, bias=None if b is None else b.contiguous(), act=act)
