@@ -316,3 +316,39 @@ def test_gcn_sparse_node_features(tfg, oracle):
     layer._maybe_build([xs])
     layer.set_weights(kernel=k, bias=b)
     assert_parity(layer([xs, ei, w]).cpu().numpy(), ref, what="layers.GCN with sparse x")
+
+
+def test_gcn_cache_builders_and_old_api(tfg, oracle):
+    """gcn_build_cache_for_graph / gcn_build_cache_by_adj / gcn_norm_edge / gcn_cache_normed_edge (gcn.py:133-218) fill
+    the same cache key the layer reads, and the layer then reuses it (same output, no second normalisation)."""
+    class G(object):
+        pass
+    rng = np.random.Generator(np.random.PCG64(31))
+    n = 200
+    g_ = G()
+    g_.edge_index = oracle.synthetic_edges(n, 1500, seed=5)
+    g_.edge_weight = rng.uniform(0.5, 1.5, g_.edge_index.shape[1]).astype(np.float32)
+    g_.x = rng.standard_normal((n, 6), dtype=np.float32)
+    g_.num_nodes, g_.cache = n, {}
+    cache = tfg.nn.gcn_build_cache_for_graph(g_)
+    key = tfg.nn.conv.gcn.compute_cache_key("both", True, True, True, False) if hasattr(tfg.nn, "conv") else None
+    assert cache is g_.cache and len(cache) >= 1
+    idx, val = tfg.nn.gcn_norm_edge(g_.edge_index, n, g_.edge_weight, cache=g_.cache)
+    oi, ov = oracle.gcn_norm_adj(g_.edge_index, g_.edge_weight, n)
+    dense = np.zeros((n, n))
+    np.add.at(dense, (idx.cpu().numpy()[0], idx.cpu().numpy()[1]), val.cpu().numpy())
+    ref = np.zeros((n, n))
+    np.add.at(ref, (oi[0], oi[1]), ov)
+    assert_parity(dense.astype(np.float32), ref.astype(np.float32), what="gcn_norm_edge")
+    before = dict(g_.cache)
+    tfg.nn.gcn_cache_normed_edge(g_)                         # already cached: nothing changes
+    assert all(g_.cache[k] is before[k] for k in before)
+    tfg.nn.gcn_cache_normed_edge(g_, override=True)          # recomputed
+    k0 = [k for k in before if k.startswith("gcn_normed_adj")][0]
+    assert g_.cache[k0] is not None and g_.cache[k0] is not before[k0]
+    layer = tfg.layers.GCN(4)
+    kernel = oracle.glorot_uniform(rng, 6, 4)
+    layer._maybe_build([g_.x])
+    layer.set_weights(kernel=kernel, bias=np.zeros(4, np.float32))
+    assert_parity(layer([g_.x, g_.edge_index, g_.edge_weight], cache=g_.cache).cpu().numpy(),
+                  oracle.gcn(g_.x, g_.edge_index, g_.edge_weight, kernel), what="GCN on a prebuilt cache")

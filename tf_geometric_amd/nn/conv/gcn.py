@@ -142,6 +142,16 @@ def gcn_norm_edge(edge_index, num_nodes, edge_weight=None, renorm=True, improved
     return normed.index, normed.value
 
 
+def gcn_cache_normed_edge(graph, renorm=True, improved=False, override=False):
+    """Deprecated old API (reference gcn.py:201-218): put the normalised adjacency for (renorm, improved) into
+    graph.cache.  The reference's override branch calls compute_cache_key with two arguments and raises TypeError; here
+    override resets the entry gcn_norm_adj would reuse (norm="both", add_self_loop=True, sym=True)."""
+    if override:
+        graph.cache[compute_cache_key("both", True, True, renorm, improved)] = None
+    n = int(getattr(graph, "num_nodes", None) or graph.x.shape[0])
+    gcn_norm_edge(graph.edge_index, n, getattr(graph, "edge_weight", None), renorm, improved, graph.cache)
+
+
 def gcn_mapper(repeated_x, neighbor_x, edge_weight=None):
     from ..kernel.map_reduce import gcn_mapper as _m
     return _m(repeated_x, neighbor_x, edge_weight)
