@@ -287,6 +287,10 @@ def test_graph_readout_pools(tfg, oracle):
     assert np.array_equal(tfg.nn.max_pool(x, gid, 40).cpu().numpy(), oracle.unsorted_segment_max(x, gid, 40))
     assert np.array_equal(tfg.nn.min_pool(x, gid, 40).cpu().numpy(), -oracle.unsorted_segment_max(-x, gid, 40))
     assert tfg.nn.max_pool(x, gid).shape[0] == int(gid.max()) + 1
+    for cls, fn in ((tfg.layers.MeanPool, tfg.nn.mean_pool), (tfg.layers.SumPool, tfg.nn.sum_pool),
+                    (tfg.layers.MaxPool, tfg.nn.max_pool), (tfg.layers.MinPool, tfg.nn.min_pool)):
+        import torch
+        assert torch.equal(cls()([x, gid, 40]), fn(x, gid, 40)) and cls()([x, gid]).shape[0] == int(gid.max()) + 1
 
 
 def test_sampler_output_carries_a_ready_plan(tfg, oracle):

@@ -5,3 +5,4 @@ from .conv.gat import GAT
 from .conv.graph_sage import MeanGraphSage, SumGraphSage, GCNGraphSage, MeanPoolGraphSage, MaxPoolGraphSage
 from .kernel.map_reduce import MapReduceGNN
 from .conv.propagation import GIN, SGC, TAGCN, APPNP, SSGC, ChebyNet, LEConv
+from .pool import CommonPool, MeanPool, SumPool, MaxPool, MinPool
