@@ -73,6 +73,24 @@ def test_argument_validation_without_gpu():
     assert lib.tfgx_gcn_norm_edges_f32(None, None, None, 3, None, None, 9, 1.0, 1, 1, None, None, None) == 1
     assert lib.tfgx_csr_plan_workspace_bytes(10, 100) > 800
     assert lib.tfgx_build_csr_by_dst(None, None, -1, 3, 3, None, None, None, None, 0, None) == 1
+    # entry points added later in the round: same contract (argument errors are reported before any device work)
+    assert lib.tfgx_segment_topk(None, None, -1, 3, 1, 0.0, None, None, None, 0, None) == 1
+    assert lib.tfgx_segment_topk(None, None, 5, 3, -1, -0.5, None, None, None, 0, None) == 1
+    assert lib.tfgx_segment_topk(None, None, 5, 3, 1, 0.0, None, None, None, 0, None) == 1 and b"out_count" in lib.tfgx_last_error()
+    assert lib.tfgx_segment_topk_workspace_bytes(1000, 10) > 1000 * 24 and lib.tfgx_segment_topk_workspace_bytes(-1, 1) == 0
+    assert lib.tfgx_gemm_workspace_bytes(2708, 1433, 256) >= 2 * 4 * 2708 * 256      # small M, long K: split-K
+    assert lib.tfgx_gemm_workspace_bytes(2400000, 100, 256) == 0                      # plenty of tiles: no split
+    assert lib.tfgx_gemm_bias_act_cols_ws_f32(None, 4, None, 4, None, 0, 9, None, 4, 2, 4, 4, None, 0, None) == 1
+    assert b"act_cols" in lib.tfgx_last_error()
+    assert lib.tfgx_segment_max_with_count_f32(None, None, None, 4, None, 2, 8, None, 8, None, 8, None) == 1
+    assert lib.tfgx_segment_max_backward_w_f32(None, None, None, 4, None, 8, 8, None, 8, None, 4, None, None) == 1
+    g = _lib.GatArgs()
+    g.H, g.d, g.dv, g.n_dst, g.scale, g.drop_rate = 2, 4, 4, 3, 2.0, 1.5
+    assert lib.tfgx_gat_fused_f32(ctypes.byref(g), None) == 1
+    assert lib.tfgx_dropout_keep(7, 3, 0.0) == 1                                      # rate 0 keeps everything
+    kept = sum(lib.tfgx_dropout_keep(0x1234567890, i, 0.25) for i in range(4000))
+    assert 2850 < kept < 3150                                                         # ~75 %
+    assert [lib.tfgx_dropout_keep(99, i, 0.5) for i in range(64)] == [lib.tfgx_dropout_keep(99, i, 0.5) for i in range(64)]
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
