@@ -326,7 +326,8 @@ int tfgx_gemm_bias_act_cols_ws_f32(const float* A, int64_t lda, const float* B, 
    pure-Python per-node loop in the reference).  Row r receives out_ptr[r+1]-out_ptr[r] = m neighbours out of its d:
    m >= d: all of them, in order; m < d: m distinct ones, uniformly (Floyd); m > d with replace_when_short: m draws
    with replacement ("padding").  Counter-based generator keyed by (seed, row, draw): reproducible for a seed, but NOT
-   numpy's stream — parity with the reference is distributional, not bitwise.  m <= 256. */
+   numpy's stream — parity with the reference is distributional, not bitwise.  Rows with more than 256 draws out of a
+   longer neighbour list use selection sampling (one ordered pass, no scratch); max_per_row is informative. */
 int tfgx_sample_neighbors(const int32_t* row_ptr, const int32_t* col, const float* w /* or NULL */, int64_t n_dst,
                           const int32_t* out_ptr, int32_t max_per_row, int32_t replace_when_short, uint64_t seed,
                           int32_t* out_col, float* out_w /* or NULL */, tfgx_stream_t stream);

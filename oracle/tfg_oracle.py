@@ -158,9 +158,12 @@ def aggregate_neighbors(x, edge_index, edge_weight=None, mapper=identity_mapper,
     """nn/kernel/map_reduce.py:45-73 line by line."""
     x = np.asarray(x, dtype=np.float32)
     edge_index = np.asarray(edge_index)
-    # :57 `tf.shape(edge_index)[0] == 0` — true only for a 0-row tensor, i.e. "no edges" given as []
-    if edge_index.shape[0] == 0 or edge_index.size == 0:
+    # :57 `tf.shape(edge_index)[0] == 0` tests the FIRST dimension: true only for "no edges" given as [] / shape [0, ...].
+    # A [2, 0] edge_index goes on (checked against the reference itself: empty gathers, then the reducer's value for
+    # empty segments — 0 for sum/mean, float32 lowest for max — and the updater)
+    if edge_index.shape[0] == 0:
         return x
+    edge_index = edge_index.astype(np.int64)
     row, col = edge_index[0], edge_index[1]                                # :60
     repeated_x = x[row]                                                    # :62
     neighbor_x = x[col]                                                    # :63

@@ -1,0 +1,696 @@
+# coding=utf-8
+"""
+One table of parity cases, three executors.
+
+Every case builds seeded inputs and knows how to run them through
+  * ``ref``  — the reference's OWN Python, loaded unmodified from /root/reference by oracle/ref_harness (only in this
+               container: tests/golden/make_golden_from_reference.py and tests/test_oracle_vs_reference.py),
+  * ``orc``  — the CPU oracle restatement (oracle/tfg_oracle.py),
+  * ``hip``  — the product (tf_geometric_amd, HIP kernels through the C ABI; ``-m gpu`` tests).
+Each executor returns ``{output name: numpy array}``.  The reference's outputs are committed as
+tests/golden/reference_cases.npz (key ``<case>::<output>``) so the GPU box — where /root/reference does not exist —
+still checks the product against what the reference itself produced.
+
+``exact`` lists the outputs that must be bit-identical (index work, max/min reductions); everything else is held to
+|a - b| <= tol + tol*|b| with tol = 1e-5 (BASELINE.json north_star) unless the case widens it and says why.
+"""
+import numpy as np
+
+TOL = 1e-5
+
+
+class Case(object):
+    def __init__(self, name, inputs, ref, orc=None, hip=None, exact=(), tol=TOL, key_tol=None, note=""):
+        self.name, self.inputs, self.ref, self.orc, self.hip = name, inputs, ref, orc, hip
+        self.exact, self.tol, self.key_tol, self.note = set(exact), tol, dict(key_tol or {}), note
+
+    def tol_of(self, key):
+        return self.key_tol.get(key, self.tol)
+
+    def __repr__(self):
+        return "Case({})".format(self.name)
+
+
+CASES = []
+
+
+def _add(*a, **k):
+    CASES.append(Case(*a, **k))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# seeded inputs
+# ---------------------------------------------------------------------------------------------------------------------
+def graph(n, e, f, seed, self_loops=0, isolated=0, weighted=True):
+    """Random multigraph: duplicates allowed, ``self_loops`` explicit (i,i) edges, the last ``isolated`` nodes receive
+    no edge (empty segments)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    hi = n - isolated
+    row = rng.integers(0, hi, size=e, dtype=np.int32)
+    col = rng.integers(0, n, size=e, dtype=np.int32)
+    if self_loops:
+        d = rng.integers(0, hi, size=self_loops, dtype=np.int32)
+        row, col = np.concatenate([row, d]), np.concatenate([col, d])
+        p = rng.permutation(row.size)
+        row, col = row[p], col[p]
+    ei = np.stack([row, col]).astype(np.int32)
+    x = rng.standard_normal((n, f), dtype=np.float32)
+    w = rng.uniform(0.5, 1.5, size=ei.shape[1]).astype(np.float32) if weighted else None
+    return dict(n=n, f=f, x=x, ei=ei, w=w, rng=rng)
+
+
+def glorot(rng, a, b):
+    lim = np.sqrt(6.0 / (a + b))
+    return rng.uniform(-lim, lim, size=(a, b)).astype(np.float32)
+
+
+def small_bias(rng, n):
+    return (rng.standard_normal(n) * 0.1).astype(np.float32)
+
+
+def sym_graph(n, e, f, seed):
+    """Undirected graph without duplicates or self-loops (what sym=True assumes)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    a = rng.integers(0, n, size=e)
+    b = rng.integers(0, n, size=e)
+    keep = a != b
+    lo, hi = np.minimum(a, b)[keep], np.maximum(a, b)[keep]
+    _, first = np.unique(lo * n + hi, return_index=True)
+    lo, hi = lo[np.sort(first)], hi[np.sort(first)]
+    ei = np.stack([np.concatenate([lo, hi]), np.concatenate([hi, lo])]).astype(np.int32)
+    wu = rng.uniform(0.5, 1.5, size=lo.size).astype(np.float32)
+    x = rng.standard_normal((n, f), dtype=np.float32)
+    return dict(n=n, f=f, x=x, ei=ei, w=np.concatenate([wu, wu]), rng=rng)
+
+
+def _np(v):
+    """tensor-like (reference Tensor / torch tensor / ndarray) -> ndarray."""
+    if v is None:
+        return None
+    if hasattr(v, "detach"):
+        return v.detach().cpu().numpy()
+    if hasattr(v, "numpy") and not isinstance(v, np.ndarray):
+        return np.asarray(v.numpy())
+    return np.asarray(v)
+
+
+def _dense(index, value, shape):
+    out = np.zeros(shape, dtype=np.float64)
+    index = _np(index)
+    np.add.at(out, (index[0], index[1]), _np(value).astype(np.float64))
+    return out.astype(np.float32)
+
+
+def _ract(R, a):
+    return None if a is None else R.tf.nn.relu
+
+
+def _hact(T, a):
+    return None if a is None else T.relu
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# (a1-a5) aggregate_neighbors and its mappers / reducers / updaters   — nn/kernel/map_reduce.py:7-73
+# ---------------------------------------------------------------------------------------------------------------------
+def _agg_inputs():
+    return graph(150, 1400, 13, seed=101, self_loops=9, isolated=7)
+
+
+def _agg_all(ns, mapper_of, reducer_of, updater_of, call, g):
+    out = {}
+    for m in ("identity", "gcn"):
+        for r in ("sum", "mean", "max"):
+            for u in ("sum", "identity"):
+                out["{}-{}-{}".format(m, r, u)] = _np(call(g["x"], g["ei"], g["w"], mapper_of(m), reducer_of(r),
+                                                           updater_of(u)))
+    return out
+
+
+def _agg_ref(R, g):
+    nn = R.tfg.nn
+    gm = R.tfg.nn.conv.gcn.gcn_mapper
+    return _agg_all(nn, lambda m: gm if m == "gcn" else nn.identity_mapper,
+                    lambda r: getattr(nn, r + "_reducer"), lambda u: getattr(nn, u + "_updater"),
+                    lambda x, ei, w, m, r, u: nn.aggregate_neighbors(x, ei, w, m, r, u), g)
+
+
+def _agg_orc(o, g):
+    return _agg_all(o, lambda m: getattr(o, m + "_mapper"), lambda r: getattr(o, r + "_reducer"),
+                    lambda u: getattr(o, u + "_updater"),
+                    lambda x, ei, w, m, r, u: o.aggregate_neighbors(x, ei, w, m, r, u), g)
+
+
+def _agg_hip(T, g):
+    nn = T.nn
+    return _agg_all(nn, lambda m: getattr(nn, m + "_mapper"), lambda r: getattr(nn, r + "_reducer"),
+                    lambda u: getattr(nn, u + "_updater"),
+                    lambda x, ei, w, m, r, u: nn.aggregate_neighbors(x, ei, w, m, r, u), g)
+
+
+_add("aggregate_neighbors", _agg_inputs, _agg_ref, _agg_orc, _agg_hip,
+     exact=["identity-max-identity", "gcn-max-identity"],
+     note="max over w*x: products are single fp32 roundings, so identity-updater outputs are bit-exact")
+
+
+def _count_ref(R, g):
+    nn = R.tfg.nn
+    return {"count": _np(nn.aggregate_neighbors(g["x"], g["ei"], None, nn.neighbor_count_mapper, nn.sum_reducer,
+                                                nn.identity_updater)),
+            "max_rows_default": _np(nn.max_reducer(R.tf.gather(g["x"], g["ei"][1]), g["ei"][0])),
+            "segment_count": _np(R.tfg.nn.kernel.segment.segment_count(g["ei"][0], g["n"]))}
+
+
+def _count_orc(o, g):
+    return {"count": o.aggregate_neighbors(g["x"], g["ei"], None, o.neighbor_count_mapper, o.sum_reducer,
+                                           o.identity_updater),
+            "max_rows_default": o.max_reducer(g["x"][g["ei"][1]], g["ei"][0]),
+            "segment_count": o.segment_count(g["ei"][0], g["n"])}
+
+
+def _count_hip(T, g):
+    nn = T.nn
+    return {"count": _np(nn.aggregate_neighbors(g["x"], g["ei"], None, nn.neighbor_count_mapper, nn.sum_reducer,
+                                                nn.identity_updater)),
+            "max_rows_default": _np(nn.max_reducer(g["x"][g["ei"][1]], g["ei"][0])),
+            "segment_count": _np(nn.segment_count(g["ei"][0], g["n"]))}
+
+
+_add("neighbor_count_and_defaults", _agg_inputs, _count_ref, _count_orc, _count_hip,
+     exact=["count", "max_rows_default", "segment_count"],
+     note="max_reducer(num_nodes=None) has max(row)+1 rows (map_reduce.py:38-42); the isolated tail nodes drop out")
+
+
+def _empty_inputs():
+    g = graph(9, 20, 5, seed=111)
+    g["ei"], g["w"] = np.zeros((2, 0), np.int32), np.zeros((0,), np.float32)
+    return g
+
+
+def _empty_ref(R, g):
+    out = _agg_ref(R, g)
+    out["no_edges_as_empty_list"] = _np(R.tfg.nn.aggregate_neighbors(g["x"], np.zeros((0,), np.int32)))
+    return out
+
+
+def _empty_orc(o, g):
+    out = _agg_orc(o, g)
+    out["no_edges_as_empty_list"] = o.aggregate_neighbors(g["x"], np.zeros((0,), np.int32))
+    return out
+
+
+def _empty_hip(T, g):
+    out = _agg_hip(T, g)
+    out["no_edges_as_empty_list"] = _np(T.nn.aggregate_neighbors(g["x"], np.zeros((0,), np.int32)))
+    return out
+
+
+_add("aggregate_neighbors_no_edges", _empty_inputs, _empty_ref, _empty_orc, _empty_hip,
+     exact=["{}-{}-{}".format(m, r, u) for m in ("identity", "gcn") for r in ("sum", "mean", "max")
+            for u in ("sum", "identity")] + ["no_edges_as_empty_list"],
+     note="map_reduce.py:57 tests tf.shape(edge_index)[0]: a [2, 0] index is NOT the early return")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# (a6) segment_softmax   — nn/kernel/segment.py:26-33
+# ---------------------------------------------------------------------------------------------------------------------
+def _softmax_inputs():
+    g = graph(90, 1100, 4, seed=102, isolated=5)
+    g["s1"] = (g["rng"].standard_normal(g["ei"].shape[1]) * 3).astype(np.float32)
+    g["s2"] = (g["rng"].standard_normal((g["ei"].shape[1], 6)) * 3).astype(np.float32)
+    return g
+
+
+_add("segment_softmax", _softmax_inputs,
+     lambda R, g: {"1d": _np(R.tfg.nn.kernel.segment.segment_softmax(g["s1"], g["ei"][0], g["n"])),
+                   "2d": _np(R.tfg.nn.kernel.segment.segment_softmax(g["s2"], g["ei"][0], g["n"]))},
+     lambda o, g: {"1d": o.segment_softmax(g["s1"], g["ei"][0], g["n"]),
+                   "2d": o.segment_softmax(g["s2"], g["ei"][0], g["n"])},
+     lambda T, g: {"1d": _np(T.nn.segment_softmax(g["s1"], g["ei"][0], g["n"])),
+                   "2d": _np(T.nn.segment_softmax(g["s2"], g["ei"][0], g["n"]))})
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# (a7) gcn_norm_adj — nn/conv/gcn.py:32-130 — compared as dense matrices (the stored entry order is not part of the
+# contract: tf_sparse merges coordinates, the product keeps the diagonal implicit)
+# ---------------------------------------------------------------------------------------------------------------------
+NORM_CFGS = [dict(), dict(renorm=False), dict(improved=True), dict(renorm=False, improved=True), dict(norm="left"),
+             dict(norm="right"), dict(sym=False), dict(add_self_loop=False), dict(norm="left", add_self_loop=False),
+             dict(norm="right", add_self_loop=False), dict(sym=False, add_self_loop=False)]
+
+
+def _cfg_name(cfg):
+    return ",".join("{}={}".format(k, v) for k, v in sorted(cfg.items())) or "default"
+
+
+def _norm_inputs():
+    return graph(70, 500, 3, seed=103, self_loops=6, isolated=4)
+
+
+def _norm_ref(R, g):
+    out = {}
+    for cfg in NORM_CFGS:
+        adj = R.tfs.SparseMatrix(g["ei"], g["w"], [g["n"], g["n"]])
+        nadj = R.tfg.nn.gcn_norm_adj(adj, **cfg)
+        out[_cfg_name(cfg)] = _dense(nadj.index, nadj.value, (g["n"], g["n"]))
+    ei, w = R.tfg.nn.gcn_norm_edge(g["ei"], g["n"], g["w"])
+    out["gcn_norm_edge"] = _dense(ei, w, (g["n"], g["n"]))
+    return out
+
+
+def _norm_orc(o, g):
+    out = {}
+    for cfg in NORM_CFGS:
+        ei, w = o.gcn_norm_adj(g["ei"], g["w"], g["n"], **cfg)
+        out[_cfg_name(cfg)] = _dense(ei, w, (g["n"], g["n"]))
+    ei, w = o.gcn_norm_adj(g["ei"], g["w"], g["n"])
+    out["gcn_norm_edge"] = _dense(ei, w, (g["n"], g["n"]))
+    return out
+
+
+def _norm_hip(T, g):
+    out = {}
+    for cfg in NORM_CFGS:
+        adj = T.SparseMatrix(g["ei"], g["w"], [g["n"], g["n"]])
+        nadj = T.nn.gcn_norm_adj(adj, **cfg).to_sparse_matrix()
+        out[_cfg_name(cfg)] = _dense(nadj.index, nadj.value, (g["n"], g["n"]))
+    ei, w = T.nn.gcn_norm_edge(g["ei"], g["n"], g["w"])
+    out["gcn_norm_edge"] = _dense(ei, w, (g["n"], g["n"]))
+    return out
+
+
+_add("gcn_norm_adj", _norm_inputs, _norm_ref, _norm_orc, _norm_hip)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# (a8-a10) gcn functional + SparseMatrix surface — nn/conv/gcn.py:225-290
+# ---------------------------------------------------------------------------------------------------------------------
+def _gcn_inputs():
+    g = graph(200, 1800, 24, seed=104, self_loops=5, isolated=6)
+    g["kernel"], g["bias"] = glorot(g["rng"], 24, 10), small_bias(g["rng"], 10)
+    g["wide_kernel"], g["wide_bias"] = glorot(g["rng"], 24, 40), small_bias(g["rng"], 40)
+    g["bias_f"] = small_bias(g["rng"], 24)
+    return g
+
+
+def _gcn_ref(R, g):
+    tfg, tf, tfs = R.tfg, R.tf, R.tfs
+    adj = lambda: tfs.SparseMatrix(g["ei"], g["w"], [g["n"], g["n"]])       # noqa: E731
+    out = {}
+    for cfg in NORM_CFGS:
+        out[_cfg_name(cfg)] = _np(tfg.nn.gcn(g["x"], adj(), g["kernel"], g["bias"], activation=tf.nn.relu, **cfg))
+    out["wide"] = _np(tfg.nn.gcn(g["x"], adj(), g["wide_kernel"], g["wide_bias"], activation=tf.nn.relu))
+    out["no_kernel"] = _np(tfg.nn.gcn(g["x"], adj(), None, g["bias_f"]))
+    out["no_bias_no_act"] = _np(tfg.nn.gcn(g["x"], adj(), g["kernel"]))
+    out["splits"] = _np(tfg.nn.gcn(g["x"], adj(), g["kernel"], g["bias"], num_or_size_splits=[3, 3, 4]))
+    out["unweighted"] = _np(tfg.nn.gcn(g["x"], tfs.SparseMatrix(g["ei"], shape=[g["n"], g["n"]]), g["kernel"]))
+    out["cached_twice"] = _np((lambda c: (tfg.nn.gcn(g["x"], adj(), g["kernel"], cache=c),
+                                          tfg.nn.gcn(g["x"], adj(), g["kernel"], cache=c))[1])({}))
+    a = adj()
+    out["spmm"] = _np(a @ g["x"])
+    out["row_sum"], out["col_sum"] = _np(a.segment_sum(axis=-1)), _np(a.segment_sum(axis=0))
+    out["add_diag_dense"] = _np(a.add_diag(2.0).to_dense())
+    sm = a.segment_softmax(axis=-1)
+    out["softmax_spmm"] = _np(sm @ g["x"])
+    out["transpose_spmm"] = _np(a.transpose() @ g["x"])
+    return out
+
+
+def _gcn_orc(o, g):
+    n = g["n"]
+    out = {}
+    for cfg in NORM_CFGS:
+        out[_cfg_name(cfg)] = o.gcn(g["x"], g["ei"], g["w"], g["kernel"], g["bias"], "relu", **cfg)
+    out["wide"] = o.gcn(g["x"], g["ei"], g["w"], g["wide_kernel"], g["wide_bias"], "relu")
+    out["no_kernel"] = o.gcn(g["x"], g["ei"], g["w"], None, g["bias_f"])
+    out["no_bias_no_act"] = o.gcn(g["x"], g["ei"], g["w"], g["kernel"])
+    out["splits"] = o.gcn(g["x"], g["ei"], g["w"], g["kernel"], g["bias"])
+    out["unweighted"] = o.gcn(g["x"], g["ei"], None, g["kernel"])
+    out["cached_twice"] = out["no_bias_no_act"]
+    out["spmm"] = o.spmm(g["ei"], g["w"], (n, n), g["x"])
+    out["row_sum"] = o.unsorted_segment_sum(g["w"], g["ei"][0], n)
+    out["col_sum"] = o.unsorted_segment_sum(g["w"], g["ei"][1], n)
+    ei2, w2 = o.add_self_loop_edge(g["ei"], n, g["w"], fill_weight=2.0)
+    out["add_diag_dense"] = _dense(ei2, w2, (n, n))
+    out["softmax_spmm"] = o.spmm(g["ei"], o.segment_softmax(g["w"], g["ei"][0], n), (n, n), g["x"])
+    out["transpose_spmm"] = o.spmm(g["ei"][::-1], g["w"], (n, n), g["x"])
+    return out
+
+
+def _gcn_hip(T, g):
+    n = g["n"]
+    adj = lambda: T.SparseMatrix(g["ei"], g["w"], [n, n])       # noqa: E731
+    out = {}
+    for cfg in NORM_CFGS:
+        out[_cfg_name(cfg)] = _np(T.nn.gcn(g["x"], adj(), g["kernel"], g["bias"], activation=T.relu, **cfg))
+    out["wide"] = _np(T.nn.gcn(g["x"], adj(), g["wide_kernel"], g["wide_bias"], activation=T.relu))
+    out["no_kernel"] = _np(T.nn.gcn(g["x"], adj(), None, g["bias_f"]))
+    out["no_bias_no_act"] = _np(T.nn.gcn(g["x"], adj(), g["kernel"]))
+    out["splits"] = _np(T.nn.gcn(g["x"], adj(), g["kernel"], g["bias"], num_or_size_splits=[3, 3, 4]))
+    out["unweighted"] = _np(T.nn.gcn(g["x"], T.SparseMatrix(g["ei"], shape=[n, n]), g["kernel"]))
+    c = {}
+    T.nn.gcn(g["x"], adj(), g["kernel"], cache=c)
+    out["cached_twice"] = _np(T.nn.gcn(g["x"], adj(), g["kernel"], cache=c))
+    a = adj()
+    out["spmm"] = _np(a @ g["x"])
+    out["row_sum"], out["col_sum"] = _np(a.segment_sum(axis=-1)), _np(a.segment_sum(axis=0))
+    d = a.add_diag(2.0)
+    out["add_diag_dense"] = _dense(d.index, d.value, (n, n))
+    out["softmax_spmm"] = _np(a.segment_softmax(axis=-1) @ g["x"])
+    out["transpose_spmm"] = _np(a.transpose() @ g["x"])
+    return out
+
+
+_add("gcn", _gcn_inputs, _gcn_ref, _gcn_orc, _gcn_hip)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# (a11-a12) gat + add_self_loop_edge — nn/conv/gat.py:13-122
+# ---------------------------------------------------------------------------------------------------------------------
+GAT_CFGS = [dict(H=1, A=4, U=6), dict(H=4, A=8, U=16), dict(H=8, A=8, U=64), dict(H=8, A=64, U=64),
+            dict(H=2, A=6, U=10, qact=None, kact=None, act=None), dict(H=4, A=8, U=5, split=False),
+            dict(H=3, A=12, U=9, bias=False)]
+
+
+def _gat_name(c):
+    return "H{H}-A{A}-U{U}".format(**c) + ("-nosplit" if not c.get("split", True) else "") + \
+        ("-linearqk" if "qact" in c else "") + ("-nobias" if not c.get("bias", True) else "")
+
+
+def _gat_inputs():
+    g = graph(130, 1500, 20, seed=105, self_loops=7, isolated=5)
+    rng = g["rng"]
+    g["gat"] = []
+    for c in GAT_CFGS:
+        uw = c["U"] if c.get("split", True) else c["U"] * c["H"]
+        g["gat"].append(dict(wq=glorot(rng, 20, c["A"]), bq=small_bias(rng, c["A"]), wk=glorot(rng, 20, c["A"]),
+                             bk=small_bias(rng, c["A"]), wv=glorot(rng, 20, uw),
+                             b=small_bias(rng, c["U"]) if c.get("bias", True) else None))
+    return g
+
+
+def _gat_run(fn, act_of, g):
+    out = {}
+    for c, p in zip(GAT_CFGS, g["gat"]):
+        out[_gat_name(c)] = _np(fn(g["x"], g["ei"], p["wq"], p["bq"], act_of(c.get("qact", "relu")), p["wk"], p["bk"],
+                                   act_of(c.get("kact", "relu")), p["wv"], p["b"], act_of(c.get("act", "relu")),
+                                   num_heads=c["H"], split_value_heads=c.get("split", True)))
+    return out
+
+
+def _selfloop_ref(R, g):
+    ei, w = R.tfg.utils.graph_utils.add_self_loop_edge(g["ei"], g["n"], g["w"], fill_weight=2.0)
+    ei2, w2 = R.tfg.utils.graph_utils.add_self_loop_edge(g["ei"], g["n"])
+    assert w2 is None
+    return {"self_loop_index": _np(ei), "self_loop_weight": _np(w), "self_loop_index_noweight": _np(ei2)}
+
+
+def _gat_ref(R, g):
+    out = _gat_run(R.tfg.nn.gat, lambda a: _ract(R, a), g)
+    out.update(_selfloop_ref(R, g))
+    return out
+
+
+def _gat_orc(o, g):
+    out = _gat_run(o.gat, lambda a: a, g)
+    ei, w = o.add_self_loop_edge(g["ei"], g["n"], g["w"], fill_weight=2.0)
+    out.update({"self_loop_index": ei, "self_loop_weight": w,
+                "self_loop_index_noweight": o.add_self_loop_edge(g["ei"], g["n"])[0]})
+    return out
+
+
+def _gat_hip(T, g):
+    out = _gat_run(T.nn.gat, lambda a: _hact(T, a), g)
+    ei, w = T.utils.add_self_loop_edge(g["ei"], g["n"], g["w"], fill_weight=2.0)
+    out.update({"self_loop_index": _np(ei), "self_loop_weight": _np(w),
+                "self_loop_index_noweight": _np(T.utils.add_self_loop_edge(g["ei"], g["n"])[0])})
+    return out
+
+
+_add("gat", _gat_inputs, _gat_ref, _gat_orc, _gat_hip,
+     exact=["self_loop_index", "self_loop_weight", "self_loop_index_noweight"])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# (a13-a15) GraphSAGE — nn/conv/graph_sage.py:9-287
+# ---------------------------------------------------------------------------------------------------------------------
+def _sage_inputs():
+    g = graph(160, 1500, 18, seed=106, self_loops=4, isolated=6)
+    rng = g["rng"]
+    g.update(ws=glorot(rng, 18, 7), wn=glorot(rng, 18, 7), b14=small_bias(rng, 14), b7=small_bias(rng, 7),
+             wmlp=glorot(rng, 18, 28), bmlp=small_bias(rng, 28), wpn=glorot(rng, 28, 7),
+             wg=glorot(rng, 18, 9), bg=small_bias(rng, 9))
+    # the pooling variants run on a copy where every node has an in-edge: max over an EMPTY neighbourhood is float32
+    # lowest (covered bit-exactly by the aggregate_neighbors case) and lowest @ W overflows to inf/NaN in the reference
+    iso = np.arange(g["n"] - 6, g["n"], dtype=np.int32)
+    g["ei_full"] = np.concatenate([g["ei"], np.stack([iso, (iso * 7) % g["n"]])], axis=1).astype(np.int32)
+    g["w_full"] = np.concatenate([g["w"], np.ones(6, np.float32)])
+    return g
+
+
+def _sage_run(ns, act, g, gcn_cache):
+    out = {}
+    for name in ("mean", "sum"):
+        fn = getattr(ns, name + "_graph_sage")
+        for concat in (True, False):
+            for weighted in (True, False):
+                for normalize in (False, True):
+                    key = "{}-concat{}-w{}-l2{}".format(name, int(concat), int(weighted), int(normalize))
+                    out[key] = _np(fn(g["x"], g["ei"], g["w"] if weighted else None, g["ws"], g["wn"],
+                                      g["b14"] if concat else g["b7"], act, concat=concat, normalize=normalize))
+    for name in ("mean_pool", "max_pool"):
+        fn = getattr(ns, name + "_graph_sage")
+        for concat in (True, False):
+            key = "{}-concat{}".format(name, int(concat))
+            out[key] = _np(fn(g["x"], g["ei_full"], g["w_full"], g["ws"], g["wmlp"], g["wpn"], g["bmlp"],
+                              g["b14"] if concat else g["b7"], act, concat=concat, normalize=True))
+    out["gcn-cacheNone"] = _np(ns.gcn_graph_sage(g["x"], g["ei"], g["w"], g["wg"], g["bg"], act, normalize=True))
+    out["gcn-cacheDict"] = _np(ns.gcn_graph_sage(g["x"], g["ei"], g["w"], g["wg"], g["bg"], act, cache=gcn_cache()))
+    out["gcn-unweighted"] = _np(ns.gcn_graph_sage(g["x"], g["ei"], None, g["wg"], g["bg"], act))
+    return out
+
+
+_add("graph_sage", _sage_inputs,
+     lambda R, g: _sage_run(R.tfg.nn, R.tf.nn.relu, g, dict),
+     lambda o, g: _sage_run(o, "relu", g, dict),
+     lambda T, g: _sage_run(T.nn, T.relu, g, dict))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# (b) the layer classes: constructor kwargs, weight names and shapes, call signature — layers/conv/*.py
+# The reference layer is built first; ITS variables (by the names it registered) are loaded into the product layer.
+# ---------------------------------------------------------------------------------------------------------------------
+LAYER_SPECS = [
+    ("GCN", dict(units=9, activation="relu"), "xew", dict(cache=True)),
+    ("GCN", dict(units=9, use_bias=False, renorm=False, improved=True), "xe", dict()),
+    ("GCN", dict(units=9, use_kernel=False, norm="left"), "xew", dict()),
+    ("GAT", dict(units=16, attention_units=8, num_heads=4, activation="relu"), "xe", dict()),
+    ("GAT", dict(units=64, attention_units=8, num_heads=8), "xew", dict()),
+    ("GAT", dict(units=6, num_heads=3, split_value_heads=False, use_bias=False), "xe", dict()),
+    ("MeanGraphSage", dict(units=12), "xew", dict()),
+    ("MeanGraphSage", dict(units=12, concat=False, normalize=True, use_bias=False), "xe", dict()),
+    ("SumGraphSage", dict(units=10), "xew", dict()),
+    ("GCNGraphSage", dict(units=10, normalize=True), "xew", dict()),
+    ("MeanPoolGraphSage", dict(units=8), "xew", dict()),
+    ("MaxPoolGraphSage", dict(units=8, concat=False), "xew", dict()),
+]
+
+
+def _layer_key(i):
+    return "{:02d}-{}".format(i, LAYER_SPECS[i][0])
+
+
+def _layer_inputs():
+    return graph(110, 1000, 15, seed=107, self_loops=3, isolated=0)   # empty rows + max-pool overflow: see graph_sage case
+
+
+def _layer_kwargs(kw, act):
+    kw = dict(kw)
+    if "activation" in kw:
+        kw["activation"] = act
+    return kw
+
+
+def _layer_ref(R, g):
+    R.tf.random.set_seed(1234)
+    out = {}
+    for i, (cls, kw, sig, opts) in enumerate(LAYER_SPECS):
+        layer = getattr(R.tfg.layers, cls)(**_layer_kwargs(kw, R.tf.nn.relu))
+        inputs = [g["x"], g["ei"]] + ([g["w"]] if sig == "xew" else [])
+        y = layer(inputs, cache={}) if opts.get("cache") else layer(inputs)
+        out[_layer_key(i)] = _np(y)
+        for v in layer.trainable_variables:
+            val = np.array(_np(v))
+            if v.name.endswith("bias"):          # zero-initialised in the reference; make them matter
+                val = (np.sin(np.arange(val.size, dtype=np.float32)) * 0.1).astype(np.float32)
+                v.assign(val)
+            out["{}::{}".format(_layer_key(i), v.name)] = val
+        y = layer(inputs, cache={}) if opts.get("cache") else layer(inputs)
+        out[_layer_key(i)] = _np(y)
+    return out
+
+
+def layer_weights(golden, i):
+    """{variable name: value} the reference layer registered for spec i (read back from the golden file)."""
+    pre = "layers::{}::".format(_layer_key(i))
+    return {k[len(pre):]: v for k, v in golden.items() if k.startswith(pre)}
+
+
+def _layer_hip(T, g, golden):
+    out = {}
+    for i, (cls, kw, sig, opts) in enumerate(LAYER_SPECS):
+        layer = getattr(T.layers, cls)(**_layer_kwargs(kw, T.relu))
+        inputs = [g["x"], g["ei"]] + ([g["w"]] if sig == "xew" else [])
+        layer._maybe_build(inputs)
+        ref_w = layer_weights(golden, i)
+        mine = {k: tuple(v.shape) for k, v in layer.weights.items()}
+        theirs = {k: tuple(v.shape) for k, v in ref_w.items()}
+        assert mine == theirs, "{}: weight names/shapes {} differ from the reference's {}".format(cls, mine, theirs)
+        layer.set_weights(**ref_w)
+        out[_layer_key(i)] = _np(layer(inputs, cache={}) if opts.get("cache") else layer(inputs))
+        out.update({"{}::{}".format(_layer_key(i), k): v for k, v in ref_w.items()})
+    return out
+
+
+_add("layers", _layer_inputs, _layer_ref, None, _layer_hip,
+     note="the hip executor takes the golden dict as third argument (weights come from the reference's own variables)")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# (f3) edge preprocessing — utils/graph_utils.py:14-212, 252-269 — index work, bit-exact
+# ---------------------------------------------------------------------------------------------------------------------
+def _edge_inputs():
+    rng = np.random.Generator(np.random.PCG64(108))
+    ei = rng.integers(0, 40, size=(2, 900), dtype=np.int32)        # many duplicates and self-loops
+    w = rng.uniform(0.5, 1.5, 900).astype(np.float32)
+    return dict(ei=ei, w=w, doc=np.array([[1, 3, 5], [2, 1, 4]], np.int32))
+
+
+def _edge_run(U, g):
+    out = {}
+    d, _ = U.convert_edge_to_directed(g["doc"])
+    out["doc_directed"] = _np(d)
+    u, props = U.merge_duplicated_edge(g["ei"], [g["w"]] * 4, ["sum", "mean", "max", "min"])
+    out["merged_index"] = _np(u)
+    for m, p in zip(["sum", "mean", "max", "min"], props):
+        out["merged_" + m] = _np(p)
+    up, (uw,) = U.convert_edge_to_upper(g["ei"], [g["w"]])
+    out["upper_index"], out["upper_w"] = _np(up), _np(uw)
+    de, (dw,) = U.convert_edge_to_directed(g["ei"], [g["w"]])
+    out["directed_index"], out["directed_w"] = _np(de), _np(dw)
+    e2, w2 = U.remove_self_loop_edge(g["ei"], g["w"])
+    out["noself_index"], out["noself_w"] = _np(e2), _np(w2)
+    return out
+
+
+_add("edge_preprocessing", _edge_inputs,
+     lambda R, g: _edge_run(R.tfg.utils.graph_utils, g), None, lambda T, g: _edge_run(T.utils, g),
+     exact=["doc_directed", "merged_index", "merged_max", "merged_min", "upper_index", "directed_index", "noself_index",
+            "noself_w"])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# (f2) the other SpMM-shaped convolutions — nn/conv/{sgc,tagcn,appnp,ssgc,chebynet,gin,le_conv}.py
+# ---------------------------------------------------------------------------------------------------------------------
+def _prop_inputs():
+    g = sym_graph(140, 700, 14, seed=109)
+    rng = g["rng"]
+    g.update(k9=glorot(rng, 14, 9), b9=small_bias(rng, 9), tk=glorot(rng, 14 * 4, 7), tb=small_bias(rng, 7),
+             ks=[glorot(rng, 14, 16), glorot(rng, 16, 6)], bs=[small_bias(rng, 16), small_bias(rng, 6)],
+             ck=[glorot(rng, 14, 5) for _ in range(3)], cb=small_bias(rng, 5),
+             lk=[glorot(rng, 14, 6) for _ in range(3)], lb=[small_bias(rng, 6) for _ in range(3)],
+             gin_w=glorot(rng, 14, 8))
+    return g
+
+
+def _prop_ref(R, g):
+    nn, relu = R.tfg.nn, R.tf.nn.relu
+    x, ei, w = g["x"], g["ei"], g["w"]
+    out = {}
+    for k in (1, 3):
+        out["sgc-k{}".format(k)] = _np(nn.sgc(x, ei, w, k, g["k9"], g["b9"], relu))
+    out["tagcn"] = _np(nn.tagcn(x, ei, w, 3, g["tk"], g["tb"], relu))
+    out["appnp"] = _np(nn.appnp(x, ei, w, g["ks"], g["bs"], relu, None, k=6, alpha=0.15))
+    out["ssgc"] = _np(nn.ssgc(x, ei, w, g["ks"], g["bs"], k=5, alpha=0.2))
+    out["ssgc-plain"] = _np(nn.ssgc(x, ei, None, None, None, k=4))
+    for norm in ("sym", "rw", None):
+        out["chebynet-{}".format(norm)] = _np(nn.chebynet(x, ei, w, 3, g["ck"], g["cb"], relu, norm))
+    mlp = lambda h, training=None: relu(h @ g["gin_w"])      # noqa: E731
+    out["gin"] = _np(nn.gin(x, ei, mlp, eps=0.3))
+    out["le_conv"] = _np(nn.le_conv(x, ei, w, g["lk"][0], g["lb"][0], g["lk"][1], g["lb"][1], g["lk"][2], g["lb"][2],
+                                    relu))
+    return out
+
+
+def _prop_orc(o, g):
+    x, ei, w = g["x"], g["ei"], g["w"]
+    out = {}
+    for k in (1, 3):
+        out["sgc-k{}".format(k)] = o.sgc(x, ei, w, k, g["k9"], g["b9"], "relu")
+    out["tagcn"] = o.tagcn(x, ei, w, 3, g["tk"], g["tb"], "relu")
+    out["appnp"] = o.appnp(x, ei, w, g["ks"], g["bs"], "relu", None, k=6, alpha=0.15)
+    out["ssgc"] = o.ssgc(x, ei, w, g["ks"], g["bs"], k=5, alpha=0.2)
+    out["ssgc-plain"] = o.ssgc(x, ei, None, None, None, k=4)
+    for norm in ("sym", "rw", None):
+        out["chebynet-{}".format(norm)] = o.chebynet(x, ei, w, 3, g["ck"], g["cb"], "relu", norm)
+    out["gin"] = np.maximum(o.matmul(o.gin(x, ei, lambda h: h, eps=0.3), g["gin_w"]), 0)
+    out["le_conv"] = o.le_conv(x, ei, w, g["lk"][0], g["lb"][0], g["lk"][1], g["lb"][1], g["lk"][2], g["lb"][2], "relu")
+    return out
+
+
+def _prop_hip(T, g):
+    import torch
+    nn, relu = T.nn, T.relu
+    x, ei, w = g["x"], g["ei"], g["w"]
+    out = {}
+    for k in (1, 3):
+        out["sgc-k{}".format(k)] = _np(nn.sgc(x, ei, w, k, g["k9"], g["b9"], relu))
+    out["tagcn"] = _np(nn.tagcn(x, ei, w, 3, g["tk"], g["tb"], relu))
+    out["appnp"] = _np(nn.appnp(x, ei, w, g["ks"], g["bs"], relu, None, k=6, alpha=0.15))
+    out["ssgc"] = _np(nn.ssgc(x, ei, w, g["ks"], g["bs"], k=5, alpha=0.2))
+    out["ssgc-plain"] = _np(nn.ssgc(x, ei, None, None, None, k=4))
+    for norm in ("sym", "rw", None):
+        out["chebynet-{}".format(norm)] = _np(nn.chebynet(x, ei, w, 3, g["ck"], g["cb"], relu, norm))
+    gw = T._lib.as_f32(g["gin_w"])
+    out["gin"] = _np(nn.gin(x, ei, lambda h, training=None: torch.relu(h @ gw), eps=0.3))
+    out["le_conv"] = _np(nn.le_conv(x, ei, w, g["lk"][0], g["lb"][0], g["lk"][1], g["lb"][1], g["lk"][2], g["lb"][2],
+                                    relu))
+    return out
+
+
+_add("propagation_convs", _prop_inputs, _prop_ref, _prop_orc, _prop_hip, tol=2e-5, key_tol={"chebynet-None": 2e-4},
+     note="k-hop chains re-associate k fp32 SpMMs (2e-5); chebynet(normalization_type=None) applies the UN-normalised "
+          "Laplacian twice: terms of magnitude 1e4 cancel, so the fp32 reference itself carries ~1e-4 absolute noise")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# (f4) readouts + topk_pool — nn/pool/common_pool.py:7-52, nn/pool/topk_pool.py:6-87
+# ---------------------------------------------------------------------------------------------------------------------
+def _pool_inputs():
+    rng = np.random.Generator(np.random.PCG64(110))
+    x = rng.standard_normal((700, 9), dtype=np.float32)
+    gid = np.sort(rng.integers(0, 30, size=700, dtype=np.int32))
+    gid[gid == 20] = 21                                             # graph 20 is empty
+    score = rng.standard_normal(700).astype(np.float32)
+    score[::50] = score[1::50]                                       # ties
+    return dict(x=x, gid=gid, score=score)
+
+
+def _pool_run(nn, g):
+    out = {}
+    for name in ("sum", "mean", "max", "min"):
+        out[name] = _np(getattr(nn, name + "_pool")(g["x"], g["gid"], 33))
+        out[name + "-default"] = _np(getattr(nn, name + "_pool")(g["x"], g["gid"]))
+    out["topk-k5"] = _np(nn.topk_pool(g["gid"], g["score"], k=5))
+    out["topk-ratio"] = _np(nn.topk_pool(g["gid"], g["score"], ratio=0.3))
+    return out
+
+
+_add("pooling", _pool_inputs, lambda R, g: _pool_run(R.tfg.nn, g), None, lambda T, g: _pool_run(T.nn, g),
+     exact=["max", "min", "max-default", "min-default", "topk-k5", "topk-ratio"])
+
+
+def by_name(name):
+    for c in CASES:
+        if c.name == name:
+            return c
+    raise KeyError(name)

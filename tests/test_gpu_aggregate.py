@@ -212,6 +212,50 @@ def test_edge_tail_on_hub_rows(tfg, oracle):
     assert torch.equal(segment_reduce(plan, xd, L.SUM, w_csr=w_csr), segment_reduce(plan, spe, L.SUM, w_csr=w_csr))
 
 
+@pytest.mark.parametrize("op_name", ["SUM", "MEAN", "MAX"])
+def test_hub_rows_with_split_layout_and_epilogue(tfg, oracle, op_name):
+    """the hub finalisation must read the self-loop term of a split-row source from x_tail for the
+    tail columns.  Hub rows (incl. the LAST row, where the old read ran out of bounds) x {dense, SplitRows, edge tail}
+    x self_coef + bias + ReLU must all be bit-identical."""
+    import torch
+    from tf_geometric_amd.plan import CsrPlan, SplitRows, segment_reduce
+    L = tfg._lib
+    op = getattr(L, op_name)
+    n, f = 1500, 100
+    rng = np.random.Generator(np.random.PCG64(15))
+    ei = oracle.synthetic_edges(n, 12000, seed=16)
+    hubs = [np.stack([np.full(4000, r, np.int32), rng.integers(0, n, 4000).astype(np.int32)]) for r in (3, n - 1)]
+    ei = np.concatenate([ei] + hubs, axis=1)
+    x = rng.standard_normal((n, f), dtype=np.float32)
+    plan = CsrPlan.build(ei, n, n)
+    hub = plan.hub_info()
+    assert hub is not None and set(hub[0].cpu().tolist()) >= {3, n - 1}
+    xd = L.as_f32(x)
+    w_csr = torch.rand(plan.num_edges, device="cuda") + 0.5
+    sc = torch.rand(n, device="cuda") + 0.25
+    bias = torch.randn(f, device="cuda") * 0.1
+    kw = dict(w_csr=w_csr, self_coef=sc, bias=bias, act=L.ACT_RELU)
+    dense = segment_reduce(plan, xd, op, **kw)
+    sp = SplitRows.from_dense(xd)
+    assert torch.equal(dense, segment_reduce(plan, sp, op, **kw))
+    assert torch.equal(dense, segment_reduce(plan, sp.with_edge_tail(plan), op, **kw))
+    # and against the oracle: A@x with the self term folded in as explicit (r, r, sc_r) edges
+    ew = np.empty(plan.num_edges, np.float32)
+    ew[plan.perm.cpu().numpy()] = w_csr.cpu().numpy()
+    ar = np.arange(n, dtype=np.int32)
+    ei2 = np.concatenate([ei, np.stack([ar, ar])], axis=1)
+    w2 = np.concatenate([ew, sc.cpu().numpy()])
+    red = dict(SUM=oracle.sum_reducer, MEAN=oracle.sum_reducer, MAX=oracle.max_reducer)[op_name]
+    ref = oracle.aggregate_neighbors(x, ei2, w2, oracle.gcn_mapper, red, oracle.identity_updater)
+    if op_name == "MEAN":       # the kernel's divisor is the in-degree WITHOUT the implicit self edge
+        ref = ref / np.maximum(np.bincount(ei[0], minlength=n), 1)[:, None]
+    ref = np.maximum(ref + bias.cpu().numpy(), 0)
+    deg = np.bincount(ei[0], minlength=n).astype(np.float64)
+    got = dense.cpu().numpy()
+    band = 1e-5 + 1e-5 * np.abs(ref) + 6e-8 * np.sqrt(deg)[:, None] * 1.5      # fp32 random-walk term on 4000-term rows
+    assert (np.abs(got - ref) <= band).all()
+
+
 def test_neighbor_count_mapper_and_utils(tfg, oracle):
     x, ei, w = _graph(oracle, 120, 900, 5, seed=41)
     got = tfg.nn.aggregate_neighbors(x, ei, w, tfg.nn.neighbor_count_mapper, tfg.nn.sum_reducer,
@@ -252,7 +296,9 @@ def _np_merge(ei, props, modes):
 def test_edge_preprocessing_on_device(tfg):
     # the reference's docstring example (graph_utils.py:157-158)
     d, _ = tfg.utils.convert_edge_to_directed(np.array([[1, 3, 5], [2, 1, 4]], np.int32))
-    assert d.tolist() == [[1, 1, 4, 2, 3, 5], [2, 3, 5, 1, 1, 4]] or d.tolist() == [[1, 3, 5, 2, 1, 4], [2, 1, 4, 1, 3, 5]]
+    # the reference's answer (run unmodified, tests/golden/reference_cases.npz edge_preprocessing::doc_directed):
+    # convert_edge_to_upper's first-occurrence order through tf.unique, then the mirrored copies
+    assert d.tolist() == [[1, 1, 4, 2, 3, 5], [2, 3, 5, 1, 1, 4]]
     rng = np.random.Generator(np.random.PCG64(8))
     ei = rng.integers(0, 60, size=(2, 3000), dtype=np.int32)              # many duplicates and self-loops
     w = rng.uniform(0.5, 1.5, 3000).astype(np.float32)
@@ -430,3 +476,35 @@ def test_random_neighbor_sampler(tfg, oracle):
         e1, w1 = sampler.sample(k=1, seed=seed)
         hits[w1[e1[0] == r][0]] = hits.get(w1[e1[0] == r][0], 0) + 1
     assert len(hits) > 0.8 * min(deg[r], 400 * 0.63) and max(hits.values()) <= 400 / deg[r] * 6 + 6
+
+
+def test_sampler_fresh_seed_and_hub_rows(tfg):
+    """(i) the reference draws fresh np.random samples on every call — sample() without a seed must not
+    return the same sub-graph twice, yet be reproducible under torch.manual_seed; (ii) sample() / ratio= sampling must
+    work on rows with more than 256 neighbours (keep-all needs no scratch; large draws use selection sampling)."""
+    import torch
+    rng = np.random.Generator(np.random.PCG64(3))
+    n, hub_deg = 50, 3000
+    hub = np.stack([np.full(hub_deg, 7, np.int32), rng.integers(0, n, hub_deg).astype(np.int32)])
+    rest = rng.integers(0, n, size=(2, 600)).astype(np.int32)
+    ei = np.concatenate([hub, rest], axis=1)
+    w = np.arange(ei.shape[1], dtype=np.float32)
+    s = tfg.utils.RandomNeighborSampler(ei, w)
+    deg = np.bincount(ei[0], minlength=n)
+    alle, allw = s.sample()                                           # sample_all on a hub row
+    assert alle.shape[1] == ei.shape[1] and np.array_equal(np.sort(allw), np.sort(w))
+    re_, rw = s.sample(ratio=0.5, seed=1)                             # 1500 draws out of 3000: selection sampling
+    assert np.array_equal(np.bincount(re_[0], minlength=n), np.ceil(deg * 0.5).astype(np.int64))
+    hub_w = rw[re_[0] == 7]
+    assert len(set(hub_w.tolist())) == hub_w.size and set(hub_w.tolist()) <= set(w[ei[0] == 7].tolist())
+    assert (np.diff(hub_w) > 0).all()                                 # neighbour order kept
+    first_half = float((hub_w < np.median(w[ei[0] == 7])).mean())     # uniform over the row, not front-loaded
+    assert 0.42 < first_half < 0.58
+    a, _ = s.sample(k=3)
+    b, _ = s.sample(k=3)
+    assert not np.array_equal(a, b)
+    torch.manual_seed(11)
+    c, _ = s.sample(k=3)
+    torch.manual_seed(11)
+    d, _ = s.sample(k=3)
+    assert np.array_equal(c, d)

@@ -368,3 +368,73 @@ def test_demo_graph_sage_trains_with_neighbour_sampling(tfg):
     import demo_graph_sage
     f1, loss = demo_graph_sage.main(epochs=4, quiet=True, num_train=3)
     assert f1 > 0.68 and loss < 0.62, (f1, loss)
+
+
+def test_gradients_reach_through_readouts_sparse_matmul_and_generic_route(tfg):
+    """readouts, SparseMatrix.matmul / segment_softmax, the generic aggregate_neighbors route and
+    nn.segment_softmax must carry a grad_fn (the reference's TF ops are all differentiable) — checked against torch
+    autograd over the same maths in float64."""
+    import torch
+    dev = "cuda"
+    rng = np.random.Generator(np.random.PCG64(31))
+    n, f, g_ = 120, 7, 9
+    x64 = torch.tensor(rng.standard_normal((n, f)), device=dev, requires_grad=True)
+    gid = torch.tensor(np.sort(rng.integers(0, g_, n)), device=dev)
+    ei = torch.tensor(rng.integers(0, n, size=(2, 900)), device=dev)
+    w64 = torch.tensor(rng.uniform(0.5, 1.5, 900), device=dev, requires_grad=True)
+    proj = torch.tensor(rng.standard_normal((g_, f)), device=dev)
+
+    def check(got_fn, ref_fn, inputs64, what, tol=2e-4):
+        ins32 = [t.detach().float().requires_grad_(True) for t in inputs64]
+        out = got_fn(*ins32)
+        assert out.grad_fn is not None, what + ": output is detached"
+        out.double().mul(ref_fn.weight(out)).sum().backward()
+        ref = ref_fn(*inputs64)
+        grads64 = torch.autograd.grad(ref.mul(ref_fn.weight(ref)).sum(), inputs64)
+        for a, b in zip(ins32, grads64):
+            assert a.grad is not None, what + ": no gradient"
+            assert_parity(a.grad.cpu().numpy(), b.cpu().numpy(), tol=tol, what=what)
+
+    class Ref(object):
+        def __init__(self, fn):
+            self.fn = fn
+
+        def __call__(self, *a):
+            return self.fn(*a)
+
+        @staticmethod
+        def weight(o):
+            return torch.linspace(0.5, 1.5, o.numel(), device=o.device, dtype=torch.float64).reshape(o.shape)
+
+    cnt = torch.bincount(gid, minlength=g_).double().unsqueeze(1)
+    seg_sum = lambda v, ids, m: torch.zeros((m,) + v.shape[1:], dtype=v.dtype, device=dev).index_add_(0, ids, v)   # noqa: E731
+    check(lambda x: tfg.nn.sum_pool(x, gid.int(), g_), Ref(lambda x: seg_sum(x, gid, g_)), [x64], "sum_pool")
+    check(lambda x: tfg.nn.mean_pool(x, gid.int(), g_), Ref(lambda x: seg_sum(x, gid, g_) / (cnt + 1e-8)), [x64], "mean_pool")
+    mx = lambda x: torch.stack([x[gid == i].max(0).values for i in range(g_)])      # noqa: E731
+    check(lambda x: tfg.nn.max_pool(x, gid.int(), g_), Ref(mx), [x64], "max_pool")
+    check(lambda x: tfg.nn.min_pool(x, gid.int(), g_), Ref(lambda x: -mx(-x)), [x64], "min_pool")
+    check(lambda x: tfg.layers.MeanPool()([x, gid.int(), g_]), Ref(lambda x: seg_sum(x, gid, g_) / (cnt + 1e-8)), [x64],
+          "MeanPool layer")
+    # SparseMatrix.matmul: gradients wrt the dense operand AND the stored values
+    check(lambda x, w: tfg.SparseMatrix(ei.int(), w, [n, n]) @ x,
+          Ref(lambda x, w: seg_sum(x[ei[1]] * w.unsqueeze(1), ei[0], n)), [x64, w64], "SparseMatrix @ x")
+    # segment_softmax (functional and SparseMatrix method)
+    def soft(s):
+        m = torch.stack([s[ei[0] == i].max() if (ei[0] == i).any() else s.new_zeros(()) for i in range(n)]).detach()
+        e = torch.exp(s - m[ei[0]])
+        return e / (seg_sum(e, ei[0], n) + 1e-8)[ei[0]]
+    check(lambda s: tfg.nn.segment_softmax(s, ei[0].int(), n), Ref(soft), [w64], "segment_softmax")
+    check(lambda s, x: tfg.SparseMatrix(ei.int(), s, [n, n]).segment_softmax(axis=-1) @ x,
+          Ref(lambda s, x: seg_sum(x[ei[1]] * soft(s).unsqueeze(1), ei[0], n)), [w64, x64], "softmax @ x")
+    # generic aggregate_neighbors route (a user mapper): gathers + user maths + HIP reducer, all tracked
+    mapper = lambda rx, nx, edge_weight=None: (nx - rx) * edge_weight.unsqueeze(1)      # noqa: E731
+    check(lambda x, w: tfg.nn.aggregate_neighbors(x, ei.int(), w, mapper, tfg.nn.mean_reducer, tfg.nn.sum_updater),
+          Ref(lambda x, w: x + seg_sum((x[ei[1]] - x[ei[0]]) * w.unsqueeze(1), ei[0], n) /
+              torch.bincount(ei[0], minlength=n).clamp(min=1).double().unsqueeze(1)), [x64, w64], "generic route")
+    # edge_weight gradient through GraphSAGE's neighbour reduce
+    ws = torch.tensor(rng.standard_normal((f, 4)), device=dev)
+    wn = torch.tensor(rng.standard_normal((f, 4)), device=dev)
+    check(lambda x, w: tfg.nn.sum_graph_sage(x, ei.int(), w, ws.float(), wn.float()),
+          Ref(lambda x, w: torch.cat([x @ ws, seg_sum(x[ei[1]] * w.unsqueeze(1), ei[0], n) @ wn], 1)), [x64, w64],
+          "sum_graph_sage d/dw")
+    _ = proj

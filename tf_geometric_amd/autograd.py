@@ -10,6 +10,7 @@ C-ABI kernel launches:
   aggregate (max)                   tfgx_segment_max_count_f32 + tfgx_segment_max_backward_f32 (TF tie semantics)
   gat_attention                     tfgx_gat_backward_dst_f32 (dQ) + tfgx_gat_backward_src_f32 (dK, dV)
   linear (x @ W + b, relu)          forward = tfgx_gemm_bias_act_f32; backward = two plain library GEMMs (torch.matmul)
+  segment_softmax                   forward = tfgx_edge_softmax_f32; backward = out * (g - segsum(out * g)) on the segment kernel
 
 The functional API (nn/conv/*.py) routes through these only when torch.is_grad_enabled() and an input requires
 grad; inference keeps the fused single-launch paths.
@@ -245,6 +246,57 @@ def gat_attention(plan, Q, K, V, num_heads, drop_rate=0.0, drop_seed=0):
     """Differentiable fused attention (self-loop edge appended, as nn/conv/gat.py:43); drop_rate > 0 = training-time
     dropout of the attention weights (gat.py:85)."""
     return _GatAttention.apply(plan, num_heads, Q, K, V, float(drop_rate), int(drop_seed))
+
+
+def edge_attr_csr(plan, edge_attr, cache=None):
+    """edge attribute (caller's edge order) -> the plan's CSR order; a differentiable permutation when the attribute is
+    being tracked, the memoised kernel copy (plan.edge_weight_csr) otherwise."""
+    from .plan import edge_weight_csr
+    if edge_attr is None:
+        return None
+    if needs_grad(edge_attr):
+        return L.as_f32(edge_attr)[plan.perm.long()]
+    return edge_weight_csr(plan, edge_attr, cache)
+
+
+def gather(x, idx):
+    """x[idx] (tf.gather): the gather kernel, or torch indexing when x is being tracked."""
+    from .plan import gather_rows
+    if needs_grad(x):
+        return L.as_f32(x)[L.as_i32(idx).long()]
+    return gather_rows(x, idx)
+
+
+class _SegmentSoftmax(torch.autograd.Function):
+    """out = exp(d - stop_gradient(segmax)) / (segsum + 1e-8)  (nn/kernel/segment.py:26-33):
+    d out_i / d d_j = [i == j] out_i - out_i out_j inside a segment, so grad = out * (g - segsum(out * g))."""
+
+    @staticmethod
+    def forward(ctx, plan, ids, d):
+        lib = L.require_gpu()
+        dd = d.detach().contiguous()
+        out = torch.empty_like(dd)
+        H = 1 if dd.dim() == 1 else int(dd.shape[1])
+        if int(ids.shape[0]):
+            L.check(lib.tfgx_edge_softmax_f32(L.ptr(plan.row_ptr), L.ptr(plan.perm), L.ptr(dd), H, plan.n_dst,
+                                              L.ptr(out), L.stream_ptr()), "tfgx_edge_softmax_f32")
+        ctx.plan, ctx.ids = plan, ids
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (out,) = ctx.saved_tensors
+        s = out * g
+        s2 = s if s.dim() == 2 else s.unsqueeze(1)
+        # plan.col is all zeros for this plan: reduce the E explicit rows through perm instead
+        seg = segment_reduce(ctx.plan, s2.contiguous(), L.SUM, col=ctx.plan.perm)
+        back = seg[ctx.ids.long()]
+        return None, None, s - out * (back if s.dim() == 2 else back[:, 0])
+
+
+def segment_softmax(plan, ids, data):
+    return _SegmentSoftmax.apply(plan, ids, data)
 
 
 def apply_activation(h, act, post):

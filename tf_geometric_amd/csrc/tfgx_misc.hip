@@ -159,6 +159,20 @@ __global__ void sample_neighbors_kernel(const int32_t* __restrict__ row_ptr, con
             }
             continue;
         }
+        if (m > kMaxSampleK) {
+            // m < d, many draws (ratio sampling on a hub row): Knuth's selection sampling (Algorithm S) — one pass over
+            // the d neighbours, position j is taken with probability (m - taken) / (d - j): uniform without replacement,
+            // no scratch, neighbour order kept
+            int taken = 0;
+            for (int j = 0; j < d && taken < m; ++j) {
+                if (draw_below(seed, uint64_t(r), uint32_t(j), d - j) < m - taken) {
+                    out_col[o + taken] = col[s + j];
+                    if (out_w) out_w[o + taken] = w ? w[s + j] : 1.0f;
+                    ++taken;
+                }
+            }
+            continue;
+        }
         // m < d: Floyd's algorithm — m distinct positions of [0, d) with uniform probability, no replacement
         int chosen[kMaxSampleK];
         int c = 0;
@@ -299,7 +313,8 @@ extern "C" int tfgx_sample_neighbors(const int32_t* row_ptr, const int32_t* col,
                                      uint64_t seed, int32_t* out_col, float* out_w, tfgx_stream_t stream)
 {
     TFGX_REQUIRE(n_dst >= 0 && max_per_row >= 0, "bad size");
-    TFGX_REQUIRE(max_per_row <= kMaxSampleK, "at most 256 sampled neighbours per row");
+    // max_per_row is informative only: rows with more than kMaxSampleK draws take the scratch-free selection-sampling
+    // branch, keep-all rows need no scratch at all
     if (n_dst == 0) return TFGX_OK;
     TFGX_REQUIRE(row_ptr && out_ptr, "null pointer");
     sample_neighbors_kernel<<<grid_for(n_dst, kBlock), kBlock, 0, as_stream(stream)>>>(

@@ -324,7 +324,10 @@ __global__ __launch_bounds__(kBlock) void hub_finalize_kernel(const HubArgs h)
         float* op = a.out + r * a.ldo + j;
         if (a.accumulate) res = is_max ? fmaxf(*op, res) : *op + res;
         if (a.self_coef) {
-            const float sv = a.self_coef[r] * a.x[r * a.ldx + j];
+            // split source rows: columns >= f_main of a NODE's row live in x_tail (ldx is then f_main-wide)
+            const float xv = (a.x_tail != nullptr && j >= a.f_main) ? a.x_tail[r * a.ld_tail + (j - a.f_main)]
+                                                                    : a.x[r * a.ldx + j];
+            const float sv = a.self_coef[r] * xv;
             res = is_max ? fmaxf(res, sv) : res + sv;
         }
         if (a.op == TFGX_MEAN) {

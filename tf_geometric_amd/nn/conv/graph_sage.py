@@ -60,8 +60,8 @@ def _neighbor_reduce(x, edge_index, edge_weight, op, cache):
     x = L.as_f32(x)
     n = int(x.shape[0])
     plan = CsrPlan.from_cache(edge_index, n, n, cache)
-    w_csr = edge_weight_csr(plan, edge_weight, cache)                                  # :38-39
-    if AG.needs_grad(x):
+    w_csr = AG.edge_attr_csr(plan, edge_weight, cache)                                 # :38-39
+    if AG.needs_grad(x, edge_weight):
         return x, AG.aggregate(plan, x, op, w_csr)
     # raw input features seen twice with the same cache are static: edge-resident-tail layout (plan.static_rows)
     return x, segment_reduce(plan, static_rows(x, plan, cache), op, w_csr=w_csr)

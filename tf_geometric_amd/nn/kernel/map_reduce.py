@@ -37,7 +37,7 @@ def _reduce_messages(neighbor_msg, node_index, num_nodes, op):
     # plan with col = edge id: the "gather" reads message perm[i] for CSR position i
     plan = CsrPlan.build(torch.stack([ids, torch.arange(ids.shape[0], dtype=torch.int32, device=ids.device)]),
                          int(num_nodes), max(int(msg.shape[0]), 1))
-    out = segment_reduce(plan, msg, op)
+    out = AG.aggregate(plan, msg, op) if AG.needs_grad(msg) else segment_reduce(plan, msg, op)
     return out[:, 0] if squeeze else out
 
 
@@ -80,8 +80,9 @@ def aggregate_neighbors(x, edge_index, edge_weight=None, mapper=identity_mapper,
     L.require_gpu()
     x = L.as_f32(x)
     ei = L.as_i32(edge_index)
-    if ei.shape[0] == 0 or ei.numel() == 0:                 # :57
+    if ei.shape[0] == 0:                                    # :57 tests dimension 0 only: "no edges" given as []
         return x
+    # a [2, 0] edge_index goes on, as in the reference: every segment is empty (0 for sum/mean, float32 lowest for max)
     n = int(x.shape[0]) if num_nodes is None else int(num_nodes)
     fused = (mapper in (identity_mapper, gcn_mapper)) and (reducer in _REDUCER_OPS) and \
             (updater in (sum_updater, identity_updater)) and (updater is identity_updater or n == int(x.shape[0]))
@@ -89,17 +90,15 @@ def aggregate_neighbors(x, edge_index, edge_weight=None, mapper=identity_mapper,
         if mapper is gcn_mapper and edge_weight is None:
             raise TypeError("gcn_mapper needs edge_weight (tf.expand_dims(None) in the reference, gcn.py:222)")
         plan = CsrPlan.from_cache(ei, n, int(x.shape[0]), cache)
-        w_csr = edge_weight_csr(plan, edge_weight, cache) if mapper is gcn_mapper else None
+        w_csr = AG.edge_attr_csr(plan, edge_weight, cache) if mapper is gcn_mapper else None
         if AG.needs_grad(x, edge_weight):        # training route: kernels with a backward (autograd.py)
-            if mapper is gcn_mapper and isinstance(edge_weight, torch.Tensor) and edge_weight.requires_grad:
-                w_csr = L.as_f32(edge_weight)[plan.perm.long()]          # differentiable permutation
             red = AG.aggregate(plan, x, _REDUCER_OPS[reducer], w_csr)
             return x + red if updater is sum_updater else red
         return segment_reduce(plan, x, _REDUCER_OPS[reducer], w_csr=w_csr,
                               add_x=x if updater is sum_updater else None)
     # generic route: explicit gathers, user mapper, HIP reducer
-    repeated_x = gather_rows(x, ei[0])                      # :62
-    neighbor_x = gather_rows(x, ei[1])                      # :63
+    repeated_x = AG.gather(x, ei[0])                        # :62
+    neighbor_x = AG.gather(x, ei[1])                        # :63
     neighbor_msg = mapper(repeated_x, neighbor_x, edge_weight=edge_weight)     # :65
     reduced_msg = reducer(neighbor_msg, ei[0], num_nodes=n)                    # :70
     return updater(x, reduced_msg)                          # :71

@@ -4,6 +4,7 @@ import torch
 
 from ... import _lib as L
 from ...plan import CsrPlan
+from ... import autograd as AG
 
 
 def segment_softmax(data, segment_ids, num_segments):
@@ -16,6 +17,8 @@ def segment_softmax(data, segment_ids, num_segments):
     squeeze = d.dim() == 1
     H = 1 if squeeze else int(d.shape[1])
     plan = CsrPlan.build(torch.stack([ids, torch.zeros_like(ids)]), int(num_segments), 1)
+    if AG.needs_grad(d):
+        return AG.segment_softmax(plan, ids, d)
     out = torch.empty_like(d)
     if E:
         L.check(lib.tfgx_edge_softmax_f32(L.ptr(plan.row_ptr), L.ptr(plan.perm), L.ptr(d), H, plan.n_dst, L.ptr(out),

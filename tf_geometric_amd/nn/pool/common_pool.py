@@ -5,6 +5,7 @@ import torch
 
 from ... import _lib as L
 from ...plan import CsrPlan, segment_reduce
+from ... import autograd as AG
 
 
 def _pool(x, node_graph_index, num_graphs, op):
@@ -15,6 +16,8 @@ def _pool(x, node_graph_index, num_graphs, op):
     n = int(ids.shape[0])
     plan = CsrPlan.build(torch.stack([ids, torch.arange(n, dtype=torch.int32, device=ids.device)]), int(num_graphs),
                          max(n, 1))
+    if AG.needs_grad(x):         # graph classification trains THROUGH the readout (the reference's TF ops all have gradients)
+        return plan, x, AG.aggregate(plan, x, op)
     return plan, x, segment_reduce(plan, x, op)
 
 

@@ -54,7 +54,12 @@ class SparseMatrix(object):
         squeeze = h.dim() == 1
         if squeeze:
             h = h.unsqueeze(1)
-        out = segment_reduce(self.plan, h, L.SUM, w_csr=self.value_csr)
+        from . import autograd as AG
+        if AG.needs_grad(h, self.value):
+            w = self.value[self.plan.perm.long()] if AG.needs_grad(self.value) else self.value_csr
+            out = AG.aggregate(self.plan, h, L.SUM, w)
+        else:
+            out = segment_reduce(self.plan, h, L.SUM, w_csr=self.value_csr)
         return out[:, 0] if squeeze else out
 
     def __matmul__(self, h):
@@ -81,6 +86,9 @@ class SparseMatrix(object):
                                       "reference uses (nn/conv/gat.py:83-84)")
         lib = L.require_gpu()
         plan = self.plan
+        from . import autograd as AG
+        if AG.needs_grad(self.value):
+            return self.with_value(AG.segment_softmax(plan, self.index[0], self.value))
         out = torch.empty_like(self.value)
         if plan.num_edges:
             L.check(lib.tfgx_edge_softmax_f32(L.ptr(plan.row_ptr), L.ptr(plan.perm), L.ptr(self.value.contiguous()), 1,

@@ -188,10 +188,15 @@ class RandomNeighborSampler(object):
         pos = kept_ptr[r][seg] + (torch.arange(total, device=dev) - sub_ptr[:-1][seg])
         return sub_ptr.to(torch.int32), kept_col[pos].contiguous(), kept_w[pos].contiguous()
 
-    def sample(self, k=None, ratio=None, sampled_node_index=None, padding=False, seed=0):
+    def sample(self, k=None, ratio=None, sampled_node_index=None, padding=False, seed=None):
+        """`seed=None` (default, as the reference which draws from np.random on every call): a fresh 63-bit seed from
+        torch's generator per call — reproducible under torch.manual_seed, different on every call.  Pass an int to pin
+        one sample."""
         if k is not None and ratio is not None:
             raise Exception("k and ratio cannot be provided simultaneously")   # :674-675
         lib = L.require_gpu()
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
         if sampled_node_index is None:
             row_ptr, col, w_csr = self.plan.row_ptr, self.plan.col, self.w_csr
         else:
