@@ -9,14 +9,25 @@ A "step" is one pass of the hot path over the whole graph: out = A_hat @ h with 
 use_bias=False) on the cached plan.  Default workload: the ogbn-products-shaped graph BASELINE.json's target is
 quoted on (N = 2.4 M, E = 123 M, F = 100).
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the SAME graph is sharded by destination-node range,
-halo source rows are exchanged as an all-to-all-v over RCCL and overlapped with the local-edge pass
-("scaling": "strong").
+N > 1 (launched by torch.distributed.run, one rank per GPU): the SAME graph is sharded by destination-node range
+(every rank generates only ITS stripe of the edge list: ShardedGraph.from_partitioned), halo source rows are
+exchanged as an all-to-all-v over RCCL and overlapped with the local-edge pass ("scaling": "strong").  The line then
+carries per-rank halo bytes and the exchange / local-pass / halo-pass times measured alone, so a scaling curve can be
+read (roofline.per_rank, roofline.overlap_frac).
 
-Prints ONE JSON line (rank 0). `roofline` prices the dominant kernel (seg_reduce_kernel) with ALGORITHMIC bytes
-(SURVEY.md §8d): B_alg = E_agg*(4F + 8) + N*4F + 4(N+1), E_agg = E + N, against the 8 TB/s HBM3E peak.
-`cpu_baseline` times the C restatement of the reference path (oracle/tfg_oracle.c, "port") on the host cores over
-a bounded sample of the same workload.
+Prints ONE JSON line (rank 0).
+  roofline      prices the dominant kernel with ALGORITHMIC bytes: B_alg = E_agg*(4F + 8) + N*4F +
+                4(N+1), E_agg = E + N, against the 8 TB/s HBM3E peak; `kernel` is the symbol the dispatcher reports for
+                this launch (tfgx_segment_reduce_describe); kernel_ms comes from HIP events on the launch stream.
+                `traffic` is IMPORTED from the committed rocprofv3 PMC profile of the same command (a counter pass
+                cannot run inside this process) and is priced with that profile's own kernel time.
+  cpu_baseline  the C restatement of the reference path (oracle/tfg_oracle.c, "port": CSR + OpenMP — a STRONG CPU
+                baseline) on a bounded sample; `cpu_baseline_op_for_op` next to it times the reference's formulation AS
+                WRITTEN (nn/kernel/map_reduce.py:62-70: gather -> multiply -> unsorted_segment_sum, three [E, F]
+                tensors) in torch-CPU on the same cores.
+  rmat          the same launch on an R-MAT graph of the same size (skewed in-degrees, hub path) — beside the uniform
+                graph, never instead of it.
+  static_feature_layout   the same launch with the features in the opt-in static layout (tfg.prepare_static_features).
 """
 import argparse
 import ctypes
@@ -42,6 +53,7 @@ def parse_args():
     p.add_argument("--warmup", type=int, default=5)
     p.add_argument("--workload", default="products")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-rmat", action="store_true")
     p.add_argument("--extras", action="store_true", help="also time GEMM+aggregation layers (GCN/SAGE/GAT)")
     p.add_argument("--seed", type=int, default=0)
     return p.parse_args()
@@ -72,38 +84,45 @@ def usable_cores():
     return cores
 
 
-def cpu_baseline(x_np, ei_np, w_np, self_coef_np, n, f, budget_edges):
-    """C port of gather -> gcn_mapper -> unsorted_segment_sum (oracle/tfg_oracle.c), all host cores, on the
-    destination rows [0, n_s) of the same graph (full source range, so the gather locality is the job's)."""
-    lib_path = os.path.join(ROOT, "oracle", "libtfg_oracle.so")
-    lib = ctypes.CDLL(lib_path)
-    fn = lib.tfgo_aggregate_csr_f32
-    fn.restype = ctypes.c_int
-    cores = usable_cores()
+# ----------------------------------------------------------------------------------------------------------------------
+# CPU legs (rank 0, N = 1 only; bounded samples of the same workload; the oracle library is used here and only here)
+# ----------------------------------------------------------------------------------------------------------------------
+def _sample_rows(ei_np, w_np, self_coef_np, n, budget_edges):
+    """Destination rows [0, n_s) of the same graph with ALL their in-edges (full source range, so the gather locality
+    is the job's), the appended self-loop edges included (add_diag, gcn.py:77)."""
     e_total = ei_np.shape[1]
     frac = min(1.0, float(budget_edges) / max(e_total, 1))
     n_s = max(1, int(n * frac))
     keep = ei_np[0] < n_s
-    diag = np.arange(n_s, dtype=np.int32)            # the appended self-loop edges (add_diag, gcn.py:77)
+    diag = np.arange(n_s, dtype=np.int32)
     row = np.ascontiguousarray(np.concatenate([ei_np[0][keep], diag]))
     col = np.ascontiguousarray(np.concatenate([ei_np[1][keep], diag]))
     w = np.ascontiguousarray(np.concatenate([w_np[keep], self_coef_np[:n_s]]))
+    return row, col, w, n_s
+
+
+def cpu_baseline_port(x_np, ei_np, w_np, self_coef_np, n, f, budget_edges):
+    """C port of gather -> gcn_mapper -> unsorted_segment_sum as a CSR loop (oracle/tfg_oracle.c), all usable cores."""
+    lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "libtfg_oracle.so"))
+    fn = lib.tfgo_aggregate_csr_f32
+    fn.restype = ctypes.c_int
+    cores = usable_cores()
+    row, col, w, n_s = _sample_rows(ei_np, w_np, self_coef_np, n, budget_edges)
     out = np.empty((n_s, f), dtype=np.float32)
     P = ctypes.c_void_p
     # NUMA: spread the feature matrix over the host's memory controllers by first-touch in parallel (untimed)
     x_cpu = np.empty_like(x_np)
     lib.tfgo_parallel_copy_f32(P(x_cpu.ctypes.data), P(x_np.ctypes.data), ctypes.c_int64(x_np.size), ctypes.c_int(cores))
-    x_np = x_cpu
     # plan (untimed, like the GPU leg's): stable sort by destination -> row_ptr / col / w in CSR order
     order = np.argsort(row, kind="stable")
-    col = np.ascontiguousarray(col[order])
-    w = np.ascontiguousarray(w[order])
+    col_s = np.ascontiguousarray(col[order])
+    w_s = np.ascontiguousarray(w[order])
     row_ptr = np.zeros(n_s + 1, dtype=np.int32)
     np.cumsum(np.bincount(row, minlength=n_s), out=row_ptr[1:])
 
     def run():
-        rc = fn(P(x_np.ctypes.data), ctypes.c_int64(f), P(row_ptr.ctypes.data), P(col.ctypes.data),
-                P(w.ctypes.data), ctypes.c_int64(n_s), ctypes.c_int64(f), ctypes.c_int(0), P(out.ctypes.data),
+        rc = fn(P(x_cpu.ctypes.data), ctypes.c_int64(f), P(row_ptr.ctypes.data), P(col_s.ctypes.data),
+                P(w_s.ctypes.data), ctypes.c_int64(n_s), ctypes.c_int64(f), ctypes.c_int(0), P(out.ctypes.data),
                 ctypes.c_int64(f), ctypes.c_int(cores))
         assert rc == 0
 
@@ -112,15 +131,123 @@ def cpu_baseline(x_np, ei_np, w_np, self_coef_np, n, f, budget_edges):
     while True:
         run()
         reps += 1
-        if time.perf_counter() - t0 > 10.0:
+        if time.perf_counter() - t0 > 8.0:
             break
     dt = (time.perf_counter() - t0) / reps
     return {"value": row.shape[0] / dt, "unit": "edges/s", "cores": cores, "kind": "port",
+            "formulation": "CSR loop over destination rows (row-sorted edges, OpenMP): a STRONG CPU baseline, not how "
+                           "the reference computes",
             "sample": "dst rows [0,{}) of the same graph: {} edges x F={} , full source range, {:.2f} s per pass, "
-                      "tfgo_aggregate_csr_f32 (row-sorted edges, OpenMP, {} threads; sort untimed)".format(
-                          n_s, int(row.shape[0]), f, dt, cores)}, out, n_s
+                      "tfgo_aggregate_csr_f32 ({} threads; sort untimed)".format(n_s, int(row.shape[0]), f, dt, cores)
+            }, out, n_s
 
 
+def cpu_baseline_op_for_op(x_np, ei_np, w_np, self_coef_np, n, f, budget_edges):
+    """The reference's formulation AS WRITTEN (nn/kernel/map_reduce.py:62-70 with gcn_mapper, nn/conv/gcn.py:221-222):
+    repeated_x = gather(x, row); neighbor_x = gather(x, col); msg = neighbor_x * w[:, None];
+    out = unsorted_segment_sum(msg, row, n) — three [E, F] tensors materialised — in torch-CPU on the same cores
+    (TensorFlow itself is not installable in this image)."""
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    row, col, w, n_s = _sample_rows(ei_np, w_np, self_coef_np, n, budget_edges)
+    xt = torch.from_numpy(x_np)
+    rt, ct, wt = torch.from_numpy(row.astype(np.int64)), torch.from_numpy(col.astype(np.int64)), torch.from_numpy(w)
+
+    def run():
+        repeated_x = xt.index_select(0, rt.clamp(max=n - 1))       # map_reduce.py:62 (dead for gcn_mapper, still executed)
+        neighbor_x = xt.index_select(0, ct)                         # :63
+        msg = neighbor_x * wt.unsqueeze(1)                          # gcn.py:222
+        out = torch.zeros((n_s, f), dtype=torch.float32).index_add_(0, rt, msg)     # :70 unsorted_segment_sum
+        del repeated_x
+        return out
+
+    out = run()  # warm
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        out = run()
+        reps += 1
+        if time.perf_counter() - t0 > 8.0:
+            break
+    dt = (time.perf_counter() - t0) / reps
+    return {"value": row.shape[0] / dt, "unit": "edges/s", "cores": cores, "kind": "port",
+            "formulation": "op for op as the reference executes: gather x2 -> multiply -> unsorted_segment_sum "
+                           "(torch-CPU index_select / mul / index_add_), three [E,F] float32 tensors materialised",
+            "sample": "dst rows [0,{}) of the same graph: {} edges x F={}, {:.2f} s per pass, {} threads".format(
+                n_s, int(row.shape[0]), f, dt, cores)}, out.numpy()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# R-MAT variant (SURVEY.md §8d): (a,b,c,d) = (0.57,0.19,0.19,0.05), generated on the GPU
+# ----------------------------------------------------------------------------------------------------------------------
+def rmat_edges(n, e, seed, dev):
+    """E/2 R-MAT pairs over 2^ceil(log2 n) ids, pairs with an id >= n or a == b dropped, both directions emitted
+    [all (a,b) | all (b,a)] like the uniform generator.  int32 [2, ~E] on the device."""
+    k = max(1, int(np.ceil(np.log2(max(n, 2)))))
+    half = e // 2
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    got_a, got_b, have = [], [], 0
+    a_, b_, c_ = 0.57, 0.19, 0.19
+    for _ in range(8):
+        m = int((half - have) * 1.7) + 1024
+        src = torch.zeros(m, dtype=torch.int64, device=dev)
+        dst = torch.zeros(m, dtype=torch.int64, device=dev)
+        for _lvl in range(k):
+            r = torch.rand(m, generator=g, device=dev)
+            sbit = r >= (a_ + b_)
+            dbit = ((r >= a_) & (r < a_ + b_)) | (r >= a_ + b_ + c_)
+            src = src * 2 + sbit
+            dst = dst * 2 + dbit
+        keep = (src < n) & (dst < n) & (src != dst)
+        got_a.append(src[keep])
+        got_b.append(dst[keep])
+        have += int(keep.sum().item())
+        if have >= half:
+            break
+    a = torch.cat(got_a)[:half].to(torch.int32)
+    b = torch.cat(got_b)[:half].to(torch.int32)
+    return torch.stack([torch.cat([a, b]), torch.cat([b, a])]).contiguous()
+
+
+def _event_time(fn, steps, warmup):
+    for _ in range(warmup):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / steps
+
+
+def rmat_line(tfg, L, n, e, f, x, steps, warmup, seed):
+    from tf_geometric_amd.nn.conv.gcn import gcn_norm_adj
+    from tf_geometric_amd.plan import segment_reduce
+    ei = rmat_edges(n, e, seed, x.device)
+    e_r = int(ei.shape[1])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    normed = gcn_norm_adj(tfg.SparseMatrix(ei, None, [n, n]), sym=True)
+    plan = normed.plan
+    hub = plan.hub_info()
+    torch.cuda.synchronize()
+    plan_s = time.perf_counter() - t0
+    out = torch.empty((n, f), dtype=torch.float32, device=x.device)
+    ms = _event_time(lambda: segment_reduce(plan, x, L.SUM, w_csr=normed.w_csr, self_coef=normed.self_coef, out=out),
+                     steps, warmup)
+    bytes_alg = b_alg(e_r + n, n, f)
+    deg = plan.in_degree()
+    return {"what": "same launch on an R-MAT graph (a,b,c,d)=(0.57,0.19,0.19,0.05) of the same N / E / F "
+                    "(generated on the GPU, both directions emitted); long rows take the chunked hub path",
+            "edges": e_r, "kernel_ms": ms, "edges_per_s": e_r / (ms * 1e-3),
+            "frac_of_hbm_peak_algorithmic": bytes_alg / (ms * 1e-3) / HBM_PEAK,
+            "max_in_degree": int(deg.max().item()), "empty_rows": int((deg == 0).sum().item()),
+            "hub_rows": 0 if hub is None else int(hub[0].shape[0]), "hub_threshold": int(getattr(plan, "hub_threshold", 0)),
+            "plan_build_s": plan_s}
+
+
+# ----------------------------------------------------------------------------------------------------------------------
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -141,10 +268,9 @@ def main():
 
     L.require_gpu()
     n, e_req, f = synthetic.WORKLOADS[args.workload]
-    ei_np = synthetic.synthetic_edges(n, e_req, seed=args.seed)
+    ei_np = synthetic.synthetic_edges(n, e_req, seed=args.seed)      # deterministic: every rank derives the same list
     e = int(ei_np.shape[1])
-    x_np = synthetic.synthetic_features(n, f, seed=args.seed + 1)
-    w_np = np.ones(e, dtype=np.float32)      # Graph default edge_weight (data/graph.py:53-56)
+    diag = None
 
     if world > 1:
         import torch.distributed as dist
@@ -153,10 +279,18 @@ def main():
         dist.init_process_group(os.environ.get("TFGX_BENCH_BACKEND", "nccl"))
         from tf_geometric_amd.dist.sharded import ShardedGraph
         t0 = time.perf_counter()
-        sg = ShardedGraph.from_global(ei_np, n, edge_weight=None, group=dist.group.WORLD)
+        # every rank keeps only ITS stripe of the edge list (what a per-rank file shard / generator stripe would be);
+        # from_partitioned routes each edge to its destination's owner — nothing edge-sized is replicated on a GPU
+        lo_e, hi_e = (e * rank) // world, (e * (rank + 1)) // world
+        stripe = np.ascontiguousarray(ei_np[:, lo_e:hi_e])
+        del ei_np
+        sg = ShardedGraph.from_partitioned(stripe, n, group=dist.group.WORLD)
+        del stripe
         sg.build_gcn_norm()
         table = sg.alloc_table(f)                       # [own rows | halo rows]; own rows resident before timing
-        sg.own_rows(table).copy_(L.as_f32(x_np[sg.own_lo:sg.own_hi]))
+        x_own = synthetic.synthetic_features(n, f, seed=args.seed + 1)[sg.own_lo:sg.own_hi]
+        sg.own_rows(table).copy_(L.as_f32(x_own))
+        del x_own
         out = torch.empty((sg.n_own, f), dtype=torch.float32, device=table.device)
         torch.cuda.synchronize()
         plan_s = time.perf_counter() - t0
@@ -167,11 +301,13 @@ def main():
         def barrier():
             dist.barrier()
     else:
+        x_np = synthetic.synthetic_features(n, f, seed=args.seed + 1)
         t0 = time.perf_counter()
         ei = L.as_i32(ei_np)
         adj = tfg.SparseMatrix(ei, None, [n, n])
         cache = {}
         normed = gcn_norm_adj(adj, cache=cache)
+        cache["tfgx_csr_plan"] = adj.plan           # one CSR plan per graph, shared by every layer given this cache
         x = L.as_f32(x_np)
         out = torch.empty((n, f), dtype=torch.float32, device=x.device)
         torch.cuda.synchronize()
@@ -209,6 +345,7 @@ def main():
         t = torch.tensor([ev_ms], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         ev_ms = float(t.item())
+        diag = shard_diagnostics(sg, table, out, f, L, dist, max(3, min(args.steps, 10)))
 
     ms_per_step = wall * 1e3 / args.steps
     e_agg = e + n
@@ -236,18 +373,27 @@ def main():
         # whole job: algorithmic bytes of the full graph over the step time (exchange included) vs N x 8 TB/s
         bytes_alg = b_alg(e_agg, n, f, weighted=True)
         achieved = bytes_alg / (ms_per_step * 1e-3)
-        line["roofline"] = {"bound": "hbm", "kernel": "seg_reduce_kernel (local pass + halo pass) + RCCL all-to-all-v",
+        slow = max(diag, key=lambda d: d["exchange_ms"] + d["local_pass_ms"] + d["halo_pass_ms"])
+        serial = slow["exchange_ms"] + slow["local_pass_ms"] + slow["halo_pass_ms"]
+        hideable = min(slow["exchange_ms"], slow["local_pass_ms"] + slow["halo_pass_ms"])
+        line["roofline"] = {"bound": "hbm", "kernel": "seg_reduce_kernel (local-source pass + {} halo-round passes) "
+                                                      "+ RCCL all-to-all-v in {} rounds".format(sg.rounds, sg.rounds),
                             "achieved": achieved / 1e9, "peak": world * HBM_PEAK / 1e9, "unit": "GB/s",
                             "frac": achieved / (world * HBM_PEAK), "traffic": None,
                             "algorithmic_bytes_per_launch": bytes_alg, "step_ms": ms_per_step,
-                            "halo_rows_received_rank0": sg.n_halo, "halo_bytes_received_rank0": sg.n_halo * f * 4,
-                            "edges_rank0": sg.num_edges, "rows_rank0": sg.n_own}
+                            "per_rank": diag,
+                            "overlap_frac": max(0.0, min(1.0, (serial - ms_per_step) / hideable)) if hideable > 0 else None,
+                            "overlap_note": "exchange_ms / local_pass_ms / halo_pass_ms are each measured ALONE "
+                                            "(barrier-separated) after the timed loop; overlap_frac = (their sum on the "
+                                            "slowest rank - step_ms) / min(exchange, passes): 1 = the exchange is fully "
+                                            "hidden, 0 = fully serial"}
     if rank == 0 and world == 1:
         bytes_alg = b_alg(e_agg, n, f, weighted=True)
         achieved = bytes_alg / (ev_ms * 1e-3)
         # compulsory lower bound: every array touched exactly once
         bytes_min = 8 * e_agg + 4 * (n + 1) + 2 * n * 4 * f
-        kname = "seg_reduce_kernel<4,32,1,sum,weighted>" if f == 100 else "seg_reduce_kernel (sum, weighted; F={})".format(f)
+        kname = segment_reduce(normed.plan, x, L.SUM, w_csr=normed.w_csr, self_coef=normed.self_coef, out=out,
+                               describe=True)
         line["roofline"] = {"bound": "hbm", "kernel": kname,
                             "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                             "frac": achieved / HBM_PEAK, "traffic": None,
@@ -256,73 +402,76 @@ def main():
                             "compulsory_bytes_per_launch": bytes_min,
                             "frac_compulsory": bytes_min / (ev_ms * 1e-3) / HBM_PEAK}
         # 128-byte line requests: what actually bounds a gather.  A 4F-byte row at a 4F-byte stride
-        # touches ceil((offset mod 128 + 4F) / 128) lines; the ceiling is the measured random-span fetch rate of
-        # tools/line_rate_probe.cpp over a table of this size, when that profile is committed.
+        # touches ceil((offset mod 128 + 4F) / 128) lines.
         row_bytes = 4 * f
         offs = sorted({(row_bytes * i) % 128 for i in range(128)})
         lines_per_row = sum(-(-(o + row_bytes) // 128) for o in offs) / float(len(offs))
         line["roofline"]["row_lines_per_launch"] = e_agg * lines_per_row
         line["roofline"]["row_lines_per_s"] = e_agg * lines_per_row / (ev_ms * 1e-3)
-        probe_path = os.path.join(ROOT, "profiles", "r01_line_rate_probe_916MiB.jsonl")
-        if args.workload == "products" and os.path.exists(probe_path):
-            best = 0.0
-            with open(probe_path) as fh:
-                for ln in fh:
-                    rec = json.loads(ln)
-                    if rec.get("probe") == "random_spans":
-                        best = max(best, rec["G_lines_per_s"] * 1e9)
-            line["roofline"]["random_line_ceiling_per_s"] = best
-            line["roofline"]["frac_of_random_line_ceiling"] = line["roofline"]["row_lines_per_s"] / best
-        # HBM-side bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE;
-        # see profiles/): a property of kernel + workload, cannot be sampled from inside this process.
-        pmc_path = os.path.join(ROOT, "profiles", "r01_{}_pmc.json".format(args.workload))
-        if os.path.exists(pmc_path):
-            with open(pmc_path) as fh:
-                pmc = json.load(fh)
-            line["roofline"]["traffic"] = pmc["traffic_bytes_per_launch"]
-            line["roofline"]["traffic_source"] = "profiles/" + os.path.basename(pmc_path)
-            line["roofline"]["traffic_GBps"] = pmc["traffic_bytes_per_launch"] / (ev_ms * 1e-3) / 1e9
-            line["roofline"]["frac_traffic"] = pmc["traffic_bytes_per_launch"] / (ev_ms * 1e-3) / HBM_PEAK
-        # The same pass with the source features in the static-feature layout (SplitRows + edge-resident tail columns,
-        # DESIGN.md §2.1): what layer 0 runs from the second epoch on.  Reported NEXT TO the headline, never as it: the
-        # layout is derived from the feature values once (build_ms), like the plan is derived from the edges.
-        from tf_geometric_amd.plan import SplitRows
-        if SplitRows.wanted(n, f):
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            rows = SplitRows.from_dense(x).with_edge_tail(normed.plan)
-            torch.cuda.synchronize()
-            build_ms = (time.perf_counter() - t1) * 1e3
+        # HBM-side bytes per launch: IMPORTED from the committed rocprofv3 PMC profile of this command (FETCH_SIZE x2 on
+        # gfx950 + WRITE_SIZE, separate --pmc passes; see profiles/).  Priced with the PROFILE's own kernel time — it
+        # was taken on another box of the pool — never with this run's.
+        for tag in ("r02", "r01"):
+            pmc_path = os.path.join(ROOT, "profiles", "{}_{}_pmc.json".format(tag, args.workload))
+            if os.path.exists(pmc_path):
+                with open(pmc_path) as fh:
+                    pmc = json.load(fh)
+                line["roofline"]["traffic"] = pmc["traffic_bytes_per_launch"]
+                line["roofline"]["traffic_is"] = "imported from profiles/{} (not measured in this run)".format(
+                    os.path.basename(pmc_path))
+                pms = pmc.get("kernel_ms")
+                if pms:
+                    line["roofline"]["traffic_profile_kernel_ms"] = pms
+                    line["roofline"]["traffic_GBps_in_profile"] = pmc["traffic_bytes_per_launch"] / (pms * 1e-3) / 1e9
+                    line["roofline"]["frac_traffic_in_profile"] = pmc["traffic_bytes_per_launch"] / (pms * 1e-3) / HBM_PEAK
+                line["roofline"]["traffic_over_algorithmic"] = pmc["traffic_bytes_per_launch"] / float(bytes_alg)
+                break
+        # The same pass with the features declared static (tfg.prepare_static_features: SplitRows + edge-resident tail
+        # columns) — what layer 0 of a model runs in every epoch once the caller has opted in.  Reported
+        # NEXT TO the headline, never as it: the layout is derived from the feature values (build_ms, extra bytes).
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        info = tfg.prepare_static_features(x, normed.plan, cache)
+        torch.cuda.synchronize()
+        build_ms = (time.perf_counter() - t1) * 1e3
+        if info["layout"] == "edge_tail":
+            from tf_geometric_amd.plan import static_rows
+            rows = static_rows(x, normed.plan, cache)
             out2 = torch.empty_like(out)
-            for _ in range(args.warmup):
-                segment_reduce(normed.plan, rows, L.SUM, w_csr=normed.w_csr, self_coef=normed.self_coef, out=out2)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(args.steps):
-                segment_reduce(normed.plan, rows, L.SUM, w_csr=normed.w_csr, self_coef=normed.self_coef, out=out2)
-            e1.record()
-            torch.cuda.synchronize()
-            ms2 = e0.elapsed_time(e1) / args.steps
+            fn2 = lambda: segment_reduce(normed.plan, rows, L.SUM, w_csr=normed.w_csr, self_coef=normed.self_coef, out=out2)   # noqa: E731
+            ms2 = _event_time(fn2, args.steps, args.warmup)
             line["static_feature_layout"] = {
-                "what": "same launch, x stored as main[N,96] + tail[N,4] + the tail columns of each edge's source row "
-                        "streamed next to col/w (3 line requests per gathered row instead of 4)",
-                "kernel_ms": ms2, "edges_per_s": e / (ms2 * 1e-3), "frac_of_hbm_peak_algorithmic": bytes_alg / (ms2 * 1e-3) / HBM_PEAK,
-                "build_ms_once_per_feature_matrix": build_ms, "extra_bytes": int(rows.edge_tail.numel() * 4),
+                "what": "same launch after tfg.prepare_static_features(x, ...): x stored as main[N,{}] + tail[N,{}] + "
+                        "the tail columns of each edge's source row streamed next to col/w (3 line requests per "
+                        "gathered row instead of 4)".format(info["f_main"], info["f_tail"]),
+                "kernel": segment_reduce(normed.plan, rows, L.SUM, w_csr=normed.w_csr, self_coef=normed.self_coef,
+                                         out=out2, describe=True),
+                "kernel_ms": ms2, "edges_per_s": e / (ms2 * 1e-3),
+                "frac_of_hbm_peak_algorithmic": bytes_alg / (ms2 * 1e-3) / HBM_PEAK,
+                "build_ms_once_per_feature_matrix": build_ms, "layout_bytes": int(info["bytes"]),
                 "bit_identical_to_headline_output": bool(torch.equal(out2, res))}
             et_path = os.path.join(ROOT, "profiles", "r01_{}_edge_tail_pmc.json".format(args.workload))
-            if os.path.exists(et_path):          # measured HBM-side bytes of this launch (rocprofv3 PMC passes)
+            if os.path.exists(et_path):          # HBM-side bytes of this launch, imported like roofline.traffic
                 with open(et_path) as fh:
-                    line["static_feature_layout"]["traffic"] = json.load(fh)["traffic_bytes_per_launch"]
+                    line["static_feature_layout"]["traffic_imported"] = json.load(fh)["traffic_bytes_per_launch"]
                 line["static_feature_layout"]["traffic_source"] = "profiles/" + os.path.basename(et_path)
             del rows, out2
+        tfg.release_static_features(cache)
+        if not args.no_rmat and n >= 100000:
+            line["rmat"] = rmat_line(tfg, L, n, e_req, f, x, max(3, args.steps // 2), 2, args.seed + 7)
         if not args.no_cpu_baseline:
             budget = {"products": 61_500_000}.get(args.workload, e)
-            base, cpu_out, n_s = cpu_baseline(x_np, ei_np, normed_w_host(normed, ei_np, n),
-                                              normed.self_coef.cpu().numpy(), n, f, budget)
+            w_host, sc_host = normed_w_host(normed, ei_np, n), normed.self_coef.cpu().numpy()
+            base, cpu_out, n_s = cpu_baseline_port(x_np, ei_np, w_host, sc_host, n, f, budget)
             line["cpu_baseline"] = base
             gpu_rows = res[:n_s].cpu().numpy()
             line["parity_vs_cpu_port_max_abs_err"] = float(np.abs(gpu_rows - cpu_out).max())
             line["speedup_vs_cpu_baseline"] = line["value"] / base["value"]
+            budget2 = {"products": 6_000_000}.get(args.workload, min(e, 6_000_000))     # 3 x [E_s, F] f32 host tensors
+            base2, cpu_out2 = cpu_baseline_op_for_op(x_np, ei_np, w_host, sc_host, n, f, budget2)
+            line["cpu_baseline_op_for_op"] = base2
+            line["parity_vs_cpu_op_for_op_max_abs_err"] = float(np.abs(res[:cpu_out2.shape[0]].cpu().numpy() - cpu_out2).max())
+            line["speedup_vs_cpu_op_for_op"] = line["value"] / base2["value"]
     if args.extras and world == 1 and rank == 0:
         line["extras"] = extras(tfg, L, synthetic, x, ei, n, e, f, cache)
     if rank == 0:
@@ -330,6 +479,37 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
+
+
+def shard_diagnostics(sg, table, out, f, L, dist, reps):
+    """Per rank, each measured ALONE with a barrier in front (so a slow peer is not counted as local time): the halo
+    exchange (pack + all-to-all-v rounds + wait), the own-source pass, the halo-source passes on resident rows."""
+    def timed(fn):
+        ms = []
+        for _ in range(reps):
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            ms.append((time.perf_counter() - t0) * 1e3)
+        ms.sort()
+        return ms[len(ms) // 2]
+
+    kw = dict(w=sg.norm_w, out=out, exchange=False)
+    exch = timed(lambda: sg.exchange_finish(sg.exchange_start(table)))
+    local = timed(lambda: sg.aggregate(table, L.SUM, classes=[0], **kw))
+    halo = timed(lambda: sg.aggregate(table, L.SUM, classes=list(range(1, sg.n_class)), self_coef=sg.self_coef, **kw))
+    rpk = sg.rpk
+    own_edges = int((rpk[1::sg.n_class] - rpk[0:-1:sg.n_class]).sum().item()) if sg.n_class > 1 else sg.num_edges
+    mine = {"rank": sg.rank, "rows": sg.n_own, "edges": sg.num_edges, "own_source_edges": own_edges,
+            "halo_rows_received": sg.n_halo, "halo_bytes_received": sg.n_halo * f * 4,
+            "rows_sent": int(sum(sg.send_counts)), "bytes_sent": int(sum(sg.send_counts)) * f * 4,
+            "exchange_ms": exch, "local_pass_ms": local, "halo_pass_ms": halo,
+            "exchange_GBps_received": sg.n_halo * f * 4 / (exch * 1e-3) / 1e9 if exch > 0 else None}
+    gathered = [None] * sg.world
+    dist.all_gather_object(gathered, mine)
+    return gathered
 
 
 def normed_w_host(normed, ei_np, n):
@@ -355,40 +535,37 @@ def _time(fn, steps=10, warmup=3):
 
 
 def extras(tfg, L, synthetic, x, ei, n, e, f, cache):
-    """Whole-layer timings on the same graph (ms): GEMM + aggregation through the layer API."""
-    res = {"note": "layers called repeatedly with the SAME feature tensor and cache switch to the static-feature layout "
-                   "from the second call on (DESIGN.md §2.1); *_first_call_ms keys time the plain dense layout"}
+    """Whole-layer timings on the same graph (ms): GEMM + aggregation through the layer API.  `*_static_ms` keys are
+    measured after tfg.prepare_static_features(x, ...) (explicit opt-in); everything else reads x as
+    it is."""
+    res = {}
     w1 = torch.ones(e, dtype=torch.float32, device=x.device)
     gcn = tfg.layers.GCN(256, activation=tfg.relu)
-    plain = {k: v for k, v in cache.items()}           # same plan / normalised adjacency, but forget the feature tensor
-
-    def first_call(layer, inputs):
-        c = dict(plain)
-        c.pop("tfgx_static_rows", None)
-        return layer(inputs, cache=c)
-
-    gcn([x, ei], cache=cache)
-    plain = {k: v for k, v in cache.items() if k != "tfgx_static_rows"}
-    res["gcn_layer_F{}_to_256_first_call_ms".format(f)] = _time(lambda: first_call(gcn, [x, ei]))
-    res["gcn_layer_F{}_to_256_ms".format(f)] = _time(lambda: gcn([x, ei], cache=cache))
     sage = tfg.layers.MeanGraphSage(256)
-    sage([x, ei, w1], cache=cache)
-    plain = {k: v for k, v in cache.items() if k != "tfgx_static_rows"}
-    res["mean_sage_layer_units256_first_call_ms"] = _time(lambda: first_call(sage, [x, ei, w1]))
+    res["gcn_layer_F{}_to_256_ms".format(f)] = _time(lambda: gcn([x, ei], cache=cache))
     res["mean_sage_layer_units256_ms"] = _time(lambda: sage([x, ei, w1], cache=cache))
     mp = tfg.layers.MaxPoolGraphSage(64)
     res["maxpool_sage_layer_units64_ms"] = _time(lambda: mp([x, ei, w1], cache=cache))
     gat = tfg.layers.GAT(64, attention_units=8, num_heads=8, activation=tfg.relu)
     res["gat_layer_H8_A8_U64_ms"] = _time(lambda: gat([x, ei], cache=cache))
-    # 2-layer GCN (F -> 256 -> 40, BASELINE configs[1] model): eager launches vs one hipGraph replay
+    # 2-layer GCN (F -> 256 -> 40, BASELINE configs[1] model): eager launches vs one hipGraph replay; the model closes
+    # over its static input features (the hipGraph captures their address either way)
     g0, g1 = tfg.layers.GCN(256, activation=tfg.relu), tfg.layers.GCN(40)
 
-    def two_layer(xx):
-        return g1([g0([xx, ei], cache=cache), ei], cache=cache)
+    def two_layer():
+        return g1([g0([x, ei], cache=cache), ei], cache=cache)
 
-    res["gcn_2layer_eager_ms"] = _time(lambda: two_layer(x))
-    cap = tfg.CapturedForward(two_layer, x)
+    res["gcn_2layer_eager_ms"] = _time(two_layer)
+    cap = tfg.CapturedForward(two_layer)
     res["gcn_2layer_hipgraph_ms"] = _time(lambda: cap.graph.replay())
+    info = tfg.prepare_static_features(x, ei, cache)
+    res["static_layout_bytes"] = int(info["bytes"])
+    res["gcn_layer_F{}_to_256_static_ms".format(f)] = _time(lambda: gcn([x, ei], cache=cache))
+    res["mean_sage_layer_units256_static_ms"] = _time(lambda: sage([x, ei, w1], cache=cache))
+    res["gcn_2layer_eager_static_ms"] = _time(two_layer)
+    cap2 = tfg.CapturedForward(two_layer)                 # prepared BEFORE capture: the replay runs the static layout
+    res["gcn_2layer_hipgraph_static_ms"] = _time(lambda: cap2.graph.replay())
+    tfg.release_static_features(cache)
     # training step of one GCN layer (forward + backward through the autograd kernels, SURVEY.md §8f rank 1)
     gt = tfg.layers.GCN(256, activation=tfg.relu)
     gt._maybe_build([x])

@@ -134,6 +134,11 @@ typedef struct tfgx_reduce_args {
 
 int tfgx_segment_reduce_f32(const tfgx_reduce_args* args /* host */, tfgx_stream_t stream);
 
+/* The kernel symbol tfgx_segment_reduce_f32 would launch for `args` (template arguments as rocprofv3 prints them:
+   seg_reduce_kernel<VEC, G, CH, IS_MAX, WEIGHTED, SPLIT>), written NUL-terminated into buf.  Host-only, launches
+   nothing: measurement code (bench.py's roofline.kernel) names the kernel from the dispatch itself. */
+int tfgx_segment_reduce_describe(const tfgx_reduce_args* args /* host */, char* buf, size_t buf_bytes);
+
 /* ---------------------------------------------------------------------------------------------
  * GCN normalisation (nn/conv/gcn.py:32-130), on the CSR plan.
  *   tfgx_segment_weight_sum_f32 : deg[r] = sum_{i in row r} w[i] (+ diag)     SparseMatrix.segment_sum(axis=-1) :80
@@ -321,6 +326,19 @@ size_t tfgx_gemm_workspace_bytes(int64_t M, int64_t K, int64_t N);
 int tfgx_gemm_bias_act_cols_ws_f32(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias,
                                    int32_t act, int64_t act_cols, float* C, int64_t ldc, int64_t M, int64_t K, int64_t N,
                                    void* workspace, size_t workspace_bytes, tfgx_stream_t stream);
+
+/* Weight gradient of a dense layer (the backward of tfgx_gemm_bias_act_f32):
+   dW[Ka, N] = X[M, Ka]^T @ G[M, N] and, when db != NULL, db[N] = column sums of G (the bias gradient), reduced over
+   the M rows on the fp32 matrix cores.  Per-workgroup partials live in the caller's workspace
+   (tfgx_gemm_tn_workspace_bytes) and are summed in a fixed order: deterministic, no atomics.  Ka <= 2016. */
+size_t tfgx_gemm_tn_workspace_bytes(int64_t M, int64_t Ka, int64_t N, int32_t want_bias);
+int tfgx_gemm_tn_f32(const float* X, int64_t ldx, const float* G, int64_t ldg, int64_t M, int64_t Ka, int64_t N,
+                     float* dW, int64_t ldw, float* db /* or NULL */, void* workspace, size_t workspace_bytes,
+                     tfgx_stream_t stream);
+
+/* out[c, r] = in[r, c] (a layer's [K, N] kernel transposed, so that d/dx = G @ kernel^T runs on the forward GEMM). */
+int tfgx_transpose_f32(const float* in, int64_t ldi, int64_t rows, int64_t cols, float* out, int64_t ldo,
+                       tfgx_stream_t stream);
 
 /* Neighbour sampling on the CSR plan (RandomNeighborSampler.sample, tf_geometric/utils/graph_utils.py:667-772, a
    pure-Python per-node loop in the reference).  Row r receives out_ptr[r+1]-out_ptr[r] = m neighbours out of its d:

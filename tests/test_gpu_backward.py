@@ -438,3 +438,33 @@ def test_gradients_reach_through_readouts_sparse_matmul_and_generic_route(tfg):
           Ref(lambda x, w: torch.cat([x @ ws, seg_sum(x[ei[1]] * w.unsqueeze(1), ei[0], n) @ wn], 1)), [x64, w64],
           "sum_graph_sage d/dw")
     _ = proj
+
+
+@pytest.mark.parametrize("m,ka,n", [(1, 1, 1), (37, 5, 3), (1000, 100, 256), (4099, 100, 40), (70001, 128, 128),
+                                    (5000, 256, 256), (3000, 602, 64), (2708, 1433, 16), (999, 33, 300), (64, 32, 32)])
+@pytest.mark.parametrize("want_bias", [False, True])
+def test_gemm_tn_weight_gradient_kernel(tfg, m, ka, n, want_bias):
+    """tfgx_gemm_tn_f32 (dW = x^T g, db = column sums of g) vs float64, and the transpose kernel."""
+    import torch
+    from tf_geometric_amd.plan import gemm_tn, transpose
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(m * 31 + ka)
+    x = torch.randn(m, ka, generator=gen, device="cuda")
+    g = torch.randn(m, n, generator=gen, device="cuda")
+    dW, db = gemm_tn(x, g, want_bias=want_bias)
+    ref = (x.double().t() @ g.double())
+    scale = (x.double().abs().t() @ g.double().abs())            # fp32 reduction over m terms: error ~ eps * sum |terms|
+    assert float(((dW.double() - ref).abs() / (scale + 1e-30)).max()) < 3e-7
+    if want_bias:
+        rb = g.double().sum(0)
+        assert float(((db.double() - rb).abs() / (g.double().abs().sum(0) + 1e-30)).max()) < 3e-7
+    else:
+        assert db is None
+    dW2, _ = gemm_tn(x, g, want_bias=want_bias)
+    assert torch.equal(dW, dW2)                                   # deterministic
+    assert torch.equal(transpose(x), x.t().contiguous())
+    # strided views (a column block of a wider matrix) are honoured
+    wide = torch.randn(m, n + 8, generator=gen, device="cuda")
+    dW3, _ = gemm_tn(x, wide[:, 4:4 + n], want_bias=False)
+    ref3 = x.double().t() @ wide[:, 4:4 + n].double()
+    assert float(((dW3.double() - ref3).abs() / ((x.double().abs().t() @ wide[:, 4:4 + n].double().abs()) + 1e-30)).max()) < 3e-7

@@ -10,7 +10,7 @@ lib/libtfgx.so (C ABI: include/tfgx.h); importing works without a GPU, calling a
 """
 from . import _lib
 from .activations import relu
-from .plan import CsrPlan
+from .plan import CsrPlan, prepare_static_features, release_static_features
 from .sparse import SparseMatrix
 from . import nn
 from . import layers

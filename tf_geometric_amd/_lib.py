@@ -102,10 +102,14 @@ SIGNATURES = {
     "tfgx_segment_max_with_count_f32": (ctypes.c_int, [_P, _P, _P, _I64, _P, _I64, _I64, _P, _I64, _P, _I64, _P]),
     "tfgx_segment_max_backward_w_f32": (ctypes.c_int, [_P, _P, _P, _I64, _P, _I64, _I64, _P, _I64, _P, _I64, _P, _P]),
     "tfgx_gemm_workspace_bytes": (_SZ, [_I64, _I64, _I64]),
+    "tfgx_gemm_tn_workspace_bytes": (_SZ, [_I64, _I64, _I64, _I32]),
+    "tfgx_gemm_tn_f32": (ctypes.c_int, [_P, _I64, _P, _I64, _I64, _I64, _I64, _P, _I64, _P, _P, _SZ, _P]),
+    "tfgx_transpose_f32": (ctypes.c_int, [_P, _I64, _I64, _I64, _P, _I64, _P]),
     "tfgx_gemm_bias_act_cols_ws_f32": (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I32, _I64, _P, _I64, _I64, _I64, _I64, _P, _SZ, _P]),
     "tfgx_dropout_keep": (ctypes.c_int32, [ctypes.c_uint64, ctypes.c_uint32, _F32]),
     "tfgx_permute_rows_f32": (ctypes.c_int, [_P, _P, _I64, _I64, _P, _P]),
     "tfgx_segment_reduce_f32": (ctypes.c_int, [ctypes.POINTER(ReduceArgs), _P]),
+    "tfgx_segment_reduce_describe": (ctypes.c_int, [ctypes.POINTER(ReduceArgs), ctypes.c_char_p, ctypes.c_size_t]),
     "tfgx_segment_weight_sum_f32": (ctypes.c_int, [_P, _P, _I64, _F32, _P, _P]),
     "tfgx_gcn_norm_edges_f32": (ctypes.c_int, [_P, _P, _P, _I64, _P, _P, _I32, _F32, _I32, _I32, _P, _P, _P]),
     "tfgx_edge_softmax_f32": (ctypes.c_int, [_P, _P, _P, _I64, _I64, _P, _P]),

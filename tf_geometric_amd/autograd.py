@@ -9,7 +9,8 @@ C-ABI kernel launches:
                                     backward wrt w  = tfgx_sddmm_f32
   aggregate (max)                   tfgx_segment_max_count_f32 + tfgx_segment_max_backward_f32 (TF tie semantics)
   gat_attention                     tfgx_gat_backward_dst_f32 (dQ) + tfgx_gat_backward_src_f32 (dK, dV)
-  linear (x @ W + b, relu)          forward = tfgx_gemm_bias_act_f32; backward = two plain library GEMMs (torch.matmul)
+  linear (x @ W + b, relu)          forward = tfgx_gemm_bias_act_f32; d/dx = the same kernel on W^T (tfgx_transpose_f32);
+                                    d/dW, d/db = tfgx_gemm_tn_f32 (MFMA reduction over the node dimension)
   segment_softmax                   forward = tfgx_edge_softmax_f32; backward = out * (g - segsum(out * g)) on the segment kernel
 
 The functional API (nn/conv/*.py) routes through these only when torch.is_grad_enabled() and an input requires
@@ -21,7 +22,7 @@ import math
 import torch
 
 from . import _lib as L
-from .plan import segment_reduce, gemm_bias_act, SplitRows
+from .plan import segment_reduce, gemm_bias_act, gemm_tn, transpose, SplitRows
 
 
 def needs_grad(*tensors):
@@ -175,9 +176,16 @@ class _Linear(torch.autograd.Function):
         x, kernel, bias, out = ctx.saved_tensors
         if ctx.act == L.ACT_RELU:
             g = g * (out > 0).to(g.dtype)
-        gx = g @ kernel.detach().t() if ctx.needs_input_grad[0] else None
-        gk = x.detach().t() @ g if ctx.needs_input_grad[1] else None
-        gb = g.sum(0) if (bias is not None and ctx.needs_input_grad[2]) else None
+        g = g.contiguous()
+        # d/dx = g @ kernel^T: the forward MFMA kernel with the (small) transposed kernel as B
+        gx = gemm_bias_act(g, transpose(kernel.detach())) if ctx.needs_input_grad[0] else None
+        # d/dkernel = x^T @ g and d/dbias = column sums of g: ONE reduction over the node dimension (tfgx_gemm_tn_f32)
+        gk = gb = None
+        want_b = bias is not None and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1] or want_b:
+            gk, gb = gemm_tn(x.detach(), g, want_bias=want_b)
+            if not ctx.needs_input_grad[1]:
+                gk = None
         return gx, gk, gb, None
 
 

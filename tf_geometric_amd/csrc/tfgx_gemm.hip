@@ -413,6 +413,157 @@ __global__ __launch_bounds__(rows_threads<TN>()) void gemm_rows_kernel(const flo
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// dW[Ka, N] = X[M, Ka]^T @ G[M, N]  (+ db[N] = column sums of G): the weight gradient of `x @ kernel + bias`
+// (what tf.GradientTape produces for the dense layers next to the aggregation, demo/demo_gcn.py:68-77).
+// A reduction over M = nodes (10^5..10^8) into a small [Ka, N] output: every workgroup owns a strided set of R-row
+// slabs, stages a slab of X and G in LDS with coalesced float4 loads, and its 8 waves accumulate TPW 32x32 output
+// tiles each with v_mfma_f32_32x32x2_f32 — the MFMA's k index IS the row m, so lane (l31, kh) feeds
+// A[i = l31][k = kh] = Xs[2s + kh][i0 + l31] and B[k = kh][n = l31] = Gs[2s + kh][n0 + l31]: consecutive floats of an
+// LDS row, conflict-free, no transposition anywhere.  Per-workgroup partial outputs go to the caller's workspace and
+// are summed in workgroup order by tn_reduce_kernel (deterministic; no atomics).  A virtual all-ones column Ka of X
+// (a padding column of the LDS slab) makes row Ka of the product the bias gradient for free.
+constexpr int kTnThreads = 512;
+
+template <int TPW>
+__global__ __launch_bounds__(kTnThreads) void gemm_tn_kernel(const float* __restrict__ X, int64_t ldx,
+                                                             const float* __restrict__ G, int64_t ldg, int64_t M, int Ka,
+                                                             int N, int n_first, int ng_cols, int R, int ka_pad,
+                                                             int ng_pad, int want_bias, float* __restrict__ parts,
+                                                             int64_t part_stride, int x_vec4, int g_vec4)
+{
+    extern __shared__ float lds[];
+    float* Xs = lds;                              // [R][ka_pad]
+    float* Gs = lds + size_t(R) * ka_pad;         // [R][ng_pad]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
+    const int Ti = ka_pad / 32, Tn = ng_pad / 32, T = Ti * Tn;
+    int ti[TPW], tn[TPW];
+    bool tv[TPW];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+        const int t = wave * TPW + j;
+        tv[j] = t < T;
+        ti[j] = tv[j] ? t / Tn : 0;
+        tn[j] = tv[j] ? t % Tn : 0;
+    }
+    f32x16 acc[TPW];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[j][q] = 0.0f;
+
+    // padding columns are written once: zeros, except the virtual ones column at Ka (bias gradient)
+    for (int idx = tid; idx < R * (ka_pad - Ka); idx += kTnThreads) {
+        const int r = idx / (ka_pad - Ka), c = Ka + idx % (ka_pad - Ka);
+        Xs[r * ka_pad + c] = (want_bias && c == Ka) ? 1.0f : 0.0f;
+    }
+    for (int idx = tid; idx < R * (ng_pad - ng_cols); idx += kTnThreads) {
+        const int r = idx / (ng_pad - ng_cols), c = ng_cols + idx % (ng_pad - ng_cols);
+        Gs[r * ng_pad + c] = 0.0f;
+    }
+    const int64_t n_slabs = (M + R - 1) / R;
+    for (int64_t slab = blockIdx.x; slab < n_slabs; slab += gridDim.x) {
+        const int64_t m0 = slab * R;
+        __syncthreads();                           // previous slab fully consumed
+        if (x_vec4) {
+            const int per = Ka / 4;
+            for (int idx = tid; idx < R * per; idx += kTnThreads) {
+                const int r = idx / per, c = (idx % per) * 4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (m0 + r < M) v = *reinterpret_cast<const float4*>(X + (m0 + r) * ldx + c);
+                *reinterpret_cast<float4*>(Xs + r * ka_pad + c) = v;
+            }
+        } else {
+            for (int idx = tid; idx < R * Ka; idx += kTnThreads) {
+                const int r = idx / Ka, c = idx % Ka;
+                Xs[r * ka_pad + c] = (m0 + r < M) ? X[(m0 + r) * ldx + c] : 0.0f;
+            }
+        }
+        if (want_bias && m0 + R > M) {             // rows past M must not count in the ones column
+            for (int r = tid; r < R; r += kTnThreads) Xs[r * ka_pad + Ka] = (m0 + r < M) ? 1.0f : 0.0f;
+        }
+        if (g_vec4) {
+            const int per = ng_cols / 4;
+            for (int idx = tid; idx < R * per; idx += kTnThreads) {
+                const int r = idx / per, c = (idx % per) * 4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (m0 + r < M) v = *reinterpret_cast<const float4*>(G + (m0 + r) * ldg + n_first + c);
+                *reinterpret_cast<float4*>(Gs + r * ng_pad + c) = v;
+            }
+        } else {
+            for (int idx = tid; idx < R * ng_cols; idx += kTnThreads) {
+                const int r = idx / ng_cols, c = idx % ng_cols;
+                Gs[r * ng_pad + c] = (m0 + r < M) ? G[(m0 + r) * ldg + n_first + c] : 0.0f;
+            }
+        }
+        __syncthreads();
+        for (int st = 0; st < R / 2; ++st) {
+            const float* xr = Xs + (2 * st + kh) * ka_pad + l31;
+            const float* gr = Gs + (2 * st + kh) * ng_pad + l31;
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) {
+                if (tv[j]) {                        // wave-uniform
+                    const float a = xr[ti[j] * 32];
+                    const float b = gr[tn[j] * 32];
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // partial [ka_pad rows used: Ka (+1 bias row)][ng_cols] of this workgroup; D layout: col = lane & 31,
+    // row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    float* out = parts + int64_t(blockIdx.x) * part_stride;
+    const int rows_out = Ka + (want_bias ? 1 : 0);
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+        if (!tv[j]) continue;
+        const int n = tn[j] * 32 + l31;
+        if (n >= ng_cols) continue;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int i = ti[j] * 32 + (q & 3) + 8 * (q >> 2) + 4 * kh;
+            if (i < rows_out) out[int64_t(i) * ng_cols + n] = acc[j][q];
+        }
+    }
+}
+
+// dW[i, n_first + n] = sum over workgroups (in order) of parts[b][i][n]; row Ka -> db
+__global__ void tn_reduce_kernel(const float* __restrict__ parts, int n_parts, int64_t part_stride, int Ka, int ng_cols,
+                                 int n_first, int want_bias, float* __restrict__ dW, int64_t ldw, float* __restrict__ db)
+{
+    const int rows = Ka + (want_bias ? 1 : 0);
+    int64_t t = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+    const int64_t total = int64_t(rows) * ng_cols, stride = int64_t(gridDim.x) * blockDim.x;
+    for (; t < total; t += stride) {
+        const int i = int(t / ng_cols), n = int(t % ng_cols);
+        float acc = 0.0f;
+        for (int b = 0; b < n_parts; ++b) acc += parts[int64_t(b) * part_stride + t];
+        if (i < Ka) dW[int64_t(i) * ldw + n_first + n] = acc;
+        else db[n_first + n] = acc;
+    }
+}
+
+struct TnCfg {
+    int ka_pad, tn_group, groups, R, wgs;
+    size_t part_floats, lds_bytes;
+};
+
+inline TnCfg tn_config(int64_t M, int64_t Ka, int64_t N, bool want_bias)
+{
+    TnCfg c;
+    c.ka_pad = int((Ka + (want_bias ? 1 : 0) + 31) / 32) * 32;
+    const int Ti = c.ka_pad / 32, Tn = int((N + 31) / 32);
+    c.tn_group = 64 / Ti < 1 ? 1 : (64 / Ti > Tn ? Tn : 64 / Ti);      // <= 64 output tiles per pass (8 waves x 8)
+    c.groups = (Tn + c.tn_group - 1) / c.tn_group;
+    c.R = 32;
+    while (c.R > 4 && sizeof(float) * size_t(c.R) * size_t(c.ka_pad + c.tn_group * 32) > 72 * 1024) c.R /= 2;
+    const int64_t slabs = (M + c.R - 1) / c.R;
+    c.wgs = int(slabs < 512 ? (slabs < 1 ? 1 : slabs) : 512);
+    c.part_floats = size_t(Ka + (want_bias ? 1 : 0)) * size_t(c.tn_group) * 32;
+    c.lds_bytes = sizeof(float) * size_t(c.R) * size_t(c.ka_pad + c.tn_group * 32);
+    return c;
+}
+
 inline size_t rows_lds_bytes(int64_t K, int tn) { return sizeof(float) * size_t(K) * size_t(tn * 32 + 8); }
 
 template <int TN>
@@ -602,4 +753,99 @@ extern "C" int tfgx_gemm_bias_act_f32(const float* A, int64_t lda, const float* 
                                       tfgx_stream_t stream)
 {
     return tfgx_gemm_bias_act_cols_f32(A, lda, B, ldb, bias, act, N, C, ldc, M, K, N, stream);
+}
+
+extern "C" size_t tfgx_gemm_tn_workspace_bytes(int64_t M, int64_t Ka, int64_t N, int32_t want_bias)
+{
+    if (M <= 0 || Ka <= 0 || N <= 0 || Ka > 2016) return 0;
+    const TnCfg c = tn_config(M, Ka, N, want_bias != 0);
+    return sizeof(float) * c.part_floats * size_t(c.wgs);
+}
+
+extern "C" int tfgx_gemm_tn_f32(const float* X, int64_t ldx, const float* G, int64_t ldg, int64_t M, int64_t Ka,
+                                int64_t N, float* dW, int64_t ldw, float* db, void* workspace, size_t workspace_bytes,
+                                tfgx_stream_t stream_)
+{
+    TFGX_REQUIRE(M >= 0 && Ka >= 1 && N >= 1, "bad M / Ka / N");
+    TFGX_REQUIRE(Ka <= 2016 && N < (int64_t(1) << 30), "Ka > 2016 is not supported");
+    TFGX_REQUIRE(dW != nullptr && ldw >= N, "bad dW");
+    hipStream_t stream = as_stream(stream_);
+    if (M == 0) {
+        for (int64_t i = 0; i < Ka; ++i) TFGX_HIP_CHECK(hipMemsetAsync(dW + i * ldw, 0, sizeof(float) * N, stream));
+        if (db) TFGX_HIP_CHECK(hipMemsetAsync(db, 0, sizeof(float) * N, stream));
+        return TFGX_OK;
+    }
+    TFGX_REQUIRE(X && G && ldx >= Ka && ldg >= N, "null pointer / leading dimension too small");
+    const bool want_bias = db != nullptr;
+    const TnCfg c = tn_config(M, Ka, N, want_bias);
+    TFGX_REQUIRE(workspace != nullptr && workspace_bytes >= sizeof(float) * c.part_floats * size_t(c.wgs),
+                 "workspace too small (tfgx_gemm_tn_workspace_bytes)");
+    float* parts = static_cast<float*>(workspace);
+    const int x_vec4 = (Ka % 4 == 0) && (ldx % 4 == 0) && aligned_to(X, 16);
+    const int Ti = c.ka_pad / 32;
+    for (int gidx = 0; gidx < c.groups; ++gidx) {
+        const int n_first = gidx * c.tn_group * 32;
+        const int ng_cols = int(N - n_first < c.tn_group * 32 ? N - n_first : c.tn_group * 32);
+        const int ng_pad = (ng_cols + 31) / 32 * 32;
+        const int g_vec4 = (ng_cols % 4 == 0) && (ldg % 4 == 0) && aligned_to(G + n_first, 16);
+        const int tiles = Ti * (ng_pad / 32);
+        const int tpw = (tiles + 7) / 8;
+        const size_t lds = sizeof(float) * size_t(c.R) * size_t(c.ka_pad + ng_pad);
+        const int64_t part_stride = int64_t(Ka + (want_bias ? 1 : 0)) * ng_cols;
+#define TFGX_TN(TPW)                                                                                                    \
+    {                                                                                                                   \
+        static bool attr_set = false;                                                                                   \
+        if (!attr_set) {                                                                                                \
+            TFGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_kernel<TPW>),                      \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                \
+            attr_set = true;                                                                                            \
+        }                                                                                                               \
+        gemm_tn_kernel<TPW><<<c.wgs, kTnThreads, lds, stream>>>(X, ldx, G, ldg, M, int(Ka), int(N), n_first, ng_cols,    \
+                                                                c.R, c.ka_pad, ng_pad, want_bias ? 1 : 0, parts,        \
+                                                                part_stride, x_vec4, g_vec4);                          \
+    }
+        if (tpw <= 1) TFGX_TN(1)
+        else if (tpw <= 2) TFGX_TN(2)
+        else if (tpw <= 4) TFGX_TN(4)
+        else TFGX_TN(8)
+#undef TFGX_TN
+        TFGX_LAUNCH_CHECK("gemm_tn_kernel");
+        tn_reduce_kernel<<<grid_for(part_stride, 256), 256, 0, stream>>>(parts, c.wgs, part_stride, int(Ka), ng_cols,
+                                                                        n_first, want_bias ? 1 : 0, dW, ldw, db);
+        TFGX_LAUNCH_CHECK("tn_reduce_kernel");
+    }
+    return TFGX_OK;
+}
+
+// out[c, r] = in[r, c]  (the [K, N] kernel of a dense layer, transposed for d/dx = g @ kernel^T on the forward GEMM)
+namespace tfgx {
+namespace {
+__global__ void transpose_kernel(const float* __restrict__ in, int64_t ldi, int64_t rows, int64_t cols,
+                                 float* __restrict__ out, int64_t ldo)
+{
+    __shared__ float tile[32][33];
+    const int64_t r0 = int64_t(blockIdx.y) * 32, c0 = int64_t(blockIdx.x) * 32;
+    for (int dy = threadIdx.y; dy < 32; dy += blockDim.y) {
+        const int64_t r = r0 + dy, c = c0 + threadIdx.x;
+        tile[dy][threadIdx.x] = (r < rows && c < cols) ? in[r * ldi + c] : 0.0f;
+    }
+    __syncthreads();
+    for (int dy = threadIdx.y; dy < 32; dy += blockDim.y) {
+        const int64_t c = c0 + dy, r = r0 + threadIdx.x;
+        if (c < cols && r < rows) out[c * ldo + r] = tile[threadIdx.x][dy];
+    }
+}
+}  // namespace
+}  // namespace tfgx
+
+extern "C" int tfgx_transpose_f32(const float* in, int64_t ldi, int64_t rows, int64_t cols, float* out, int64_t ldo,
+                                  tfgx_stream_t stream)
+{
+    TFGX_REQUIRE(rows >= 0 && cols >= 0 && ldi >= cols && ldo >= rows, "bad shape");
+    if (rows == 0 || cols == 0) return TFGX_OK;
+    TFGX_REQUIRE(in && out, "null pointer");
+    dim3 grid(unsigned((cols + 31) / 32), unsigned((rows + 31) / 32), 1), block(32, 8, 1);
+    tfgx::transpose_kernel<<<grid, block, 0, as_stream(stream)>>>(in, ldi, rows, cols, out, ldo);
+    TFGX_LAUNCH_CHECK("transpose_kernel");
+    return TFGX_OK;
 }

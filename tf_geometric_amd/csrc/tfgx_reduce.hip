@@ -15,6 +15,7 @@
 // in-order FMA chain per output element: deterministic, no atomics, original edge order per row.
 #include "tfgx_common.h"
 #include <cfloat>
+#include <cstdio>
 
 namespace tfgx {
 namespace {
@@ -278,17 +279,36 @@ int launch_cfg(const KArgs& a, bool is_max, bool weighted, int ny, hipStream_t s
     return TFGX_OK;
 }
 
+// lanes needed to cover one row with one chunk each -> (G, CH): the ONE place the group shape is decided
+// (launch_vec dispatches on it, tfgx_segment_reduce_describe reports it)
+inline void group_shape(int lanes, int* G, int* CH)
+{
+    *CH = 1;
+    if (lanes <= 4) *G = 4;
+    else if (lanes <= 8) *G = 8;
+    else if (lanes <= 16) *G = 16;
+    else if (lanes <= 32) *G = 32;
+    else if (lanes <= 64) *G = 64;
+    else if (lanes <= 128) { *G = 64; *CH = 2; }
+    else { *G = 64; *CH = 4; }      // wider rows: column blocks of 64*VEC*4 on grid.y
+}
+
 template <int VEC>
 int launch_vec(const KArgs& a, bool is_max, bool weighted, hipStream_t stream)
 {
-    const int lanes = (a.F + VEC - 1) / VEC;  // lanes needed to cover one row with one chunk each
-    if (lanes <= 4) return launch_cfg<VEC, 4, 1>(a, is_max, weighted, 1, stream);
-    if (lanes <= 8) return launch_cfg<VEC, 8, 1>(a, is_max, weighted, 1, stream);
-    if (lanes <= 16) return launch_cfg<VEC, 16, 1>(a, is_max, weighted, 1, stream);
-    if (lanes <= 32) return launch_cfg<VEC, 32, 1>(a, is_max, weighted, 1, stream);
-    if (lanes <= 64) return launch_cfg<VEC, 64, 1>(a, is_max, weighted, 1, stream);
-    if (lanes <= 128) return launch_cfg<VEC, 64, 2>(a, is_max, weighted, 1, stream);
-    // wider rows: column blocks of 64*VEC*4 on grid.y (col/w are re-read per block: 8 B vs >= 1 KiB of x)
+    int G, CH;
+    group_shape((a.F + VEC - 1) / VEC, &G, &CH);
+    if (CH == 1) {
+        switch (G) {
+            case 4: return launch_cfg<VEC, 4, 1>(a, is_max, weighted, 1, stream);
+            case 8: return launch_cfg<VEC, 8, 1>(a, is_max, weighted, 1, stream);
+            case 16: return launch_cfg<VEC, 16, 1>(a, is_max, weighted, 1, stream);
+            case 32: return launch_cfg<VEC, 32, 1>(a, is_max, weighted, 1, stream);
+            default: return launch_cfg<VEC, 64, 1>(a, is_max, weighted, 1, stream);
+        }
+    }
+    if (CH == 2) return launch_cfg<VEC, 64, 2>(a, is_max, weighted, 1, stream);
+    // col/w are re-read per column block: 8 B vs >= 1 KiB of x
     const int per = 64 * VEC * 4;
     return launch_cfg<VEC, 64, 4>(a, is_max, weighted, (a.F + per - 1) / per, stream);
 }
@@ -353,6 +373,36 @@ int launch_any(const KArgs& a, int vec, bool is_max, bool weighted, hipStream_t 
 
 using namespace tfgx;
 
+// widest vector the layout allows for every row pointer that is touched
+static int vector_width(const tfgx_reduce_args* p)
+{
+    auto ok = [&](int vec) {
+        const size_t al = sizeof(float) * vec;
+        bool good = (p->F % vec == 0) && (p->ldx % vec == 0) && (p->ldo % vec == 0) && aligned_to(p->x, al) &&
+                    aligned_to(p->out, al);
+        if (p->add_x) good = good && (p->ld_add % vec == 0) && aligned_to(p->add_x, al);
+        if (p->bias) good = good && aligned_to(p->bias, al);
+        return good;
+    };
+    int vec = ok(4) ? 4 : (ok(2) ? 2 : 1);
+    // narrow rows: prefer 8 lanes with narrower loads over 4 lanes x dwordx4 — 8 rows per wave instead of 16 (less
+    // degree divergence inside a wave) and 8 edges in flight per row instead of 4
+    while (vec > 1 && p->F / vec < 8) vec /= 2;
+    return vec;
+}
+
+extern "C" int tfgx_segment_reduce_describe(const tfgx_reduce_args* p, char* buf, size_t buf_bytes)
+{
+    TFGX_REQUIRE(p != nullptr && buf != nullptr && buf_bytes > 0, "null argument");
+    const int vec = vector_width(p);
+    int G, CH;
+    group_shape(int((p->F + vec - 1) / vec), &G, &CH);
+    const bool split = p->x_tail != nullptr && vec == 4 && CH == 1;
+    snprintf(buf, buf_bytes, "seg_reduce_kernel<%d, %d, %d, %s, %s, %s>", vec, G, CH, p->op == TFGX_MAX ? "true" : "false",
+             p->w ? "true" : "false", split ? "true" : "false");
+    return TFGX_OK;
+}
+
 extern "C" int tfgx_segment_reduce_f32(const tfgx_reduce_args* p, tfgx_stream_t stream_)
 {
     TFGX_REQUIRE(p != nullptr, "args is null");
@@ -396,19 +446,7 @@ extern "C" int tfgx_segment_reduce_f32(const tfgx_reduce_args* p, tfgx_stream_t 
     const bool weighted = p->w != nullptr;
     hipStream_t stream = as_stream(stream_);
 
-    // widest vector the layout allows for every row pointer that is touched
-    auto ok = [&](int vec) {
-        const size_t al = sizeof(float) * vec;
-        bool good = (p->F % vec == 0) && (p->ldx % vec == 0) && (p->ldo % vec == 0) && aligned_to(p->x, al) &&
-                    aligned_to(p->out, al);
-        if (p->add_x) good = good && (p->ld_add % vec == 0) && aligned_to(p->add_x, al);
-        if (p->bias) good = good && aligned_to(p->bias, al);
-        return good;
-    };
-    int vec = ok(4) ? 4 : (ok(2) ? 2 : 1);
-    // narrow rows: prefer 8 lanes with narrower loads over 4 lanes x dwordx4 — 8 rows per wave instead of 16 (less
-    // degree divergence inside a wave) and 8 edges in flight per row instead of 4
-    while (vec > 1 && p->F / vec < 8) vec /= 2;
+    int vec = vector_width(p);
     int rc = launch_any(a, vec, is_max, weighted, stream);
     if (rc != TFGX_OK || !use_hub) return rc;
 

@@ -460,10 +460,11 @@ class ShardedGraph(object):
 
     # ------------------------------------------------------------------ aggregation
     def aggregate(self, table, op=L.SUM, w="plan", self_coef=None, bias=None, act=L.ACT_NONE, out=None,
-                  exchange=True):
+                  exchange=True, classes=None):
         """out[r] = reduce over ALL edges of own row r of w*table[col] (+ epilogue), halo exchange overlapped with
         the local-source pass.  `w`: "plan" = the shard's edge weights, None = unweighted, or a tensor in this
-        shard's edge order."""
+        shard's edge order.  `classes` (diagnostics, bench.py): run only these source classes (0 = own-source edges,
+        j+1 = round-j halo edges) on whatever the table holds — used with exchange=False to time the passes alone."""
         be = self.backend
         w_t = self.w if (isinstance(w, str) and w == "plan") else w
         F = int(table.shape[1])
@@ -471,7 +472,7 @@ class ShardedGraph(object):
             out = be.empty((self.n_own, F))
         handles = self.exchange_start(table) if exchange else None
         K1, rpk = self.n_class, self.rpk
-        for k in range(K1):
+        for k in (range(K1) if classes is None else classes):
             last = k == K1 - 1
             if k >= 1:
                 self.exchange_finish(handles, k - 1)          # class k reads the rows of round k-1

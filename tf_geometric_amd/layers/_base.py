@@ -41,11 +41,24 @@ class Layer(object):
     def set_weights(self, **named):
         """Load weights by the reference's variable names (checkpoint compatibility)."""
         for k, v in named.items():
-            if not hasattr(self, k):
+            # `k` is the VARIABLE name the reference registered with add_weight (what a checkpoint stores); the python
+            # attribute may differ (MaxPoolGraphSage: variable "mlp_kernel" lives in self.neighbor_mlp_kernel,
+            # layers/conv/graph_sage.py:322-328).  Attribute names are accepted too.
+            attr = None
+            if k in self._weights:
+                old = self._weights[k]
+                attr = next((a for a, val in self.__dict__.items() if val is old), None)
+            if attr is None and hasattr(self, k):
+                attr = k
+            if attr is None:
                 raise KeyError("{} has no weight named {}".format(self.name, k))
             t = L.as_f32(v).contiguous()
-            setattr(self, k, t)
-            self._weights[k] = t
+            if self._trainable:
+                t.requires_grad_(True)
+            name = k if k in self._weights else next((n for n, val in self._weights.items()
+                                                      if val is getattr(self, attr)), k)
+            setattr(self, attr, t)
+            self._weights[name] = t
 
     @property
     def weights(self):
@@ -53,14 +66,13 @@ class Layer(object):
 
     def parameters(self):
         """The layer's weight tensors (for torch.optim); call trainable(True) first to track gradients."""
-        return [getattr(self, k) for k in self._weights if getattr(self, k, None) is not None]
+        return [t for t in self._weights.values() if t is not None]
 
     def trainable(self, flag=True):
         """Turn gradient tracking of every weight on/off.  With it on, calls run through the differentiable
         kernels of tf_geometric_amd.autograd (the role tf.GradientTape plays for the reference's keras layers)."""
         self._trainable = bool(flag)          # also applies to weights created later (lazy build on the first call)
-        for k in list(self._weights):
-            t = getattr(self, k, None)
+        for t in self._weights.values():
             if t is not None:
                 t.requires_grad_(flag)
         return self

@@ -84,6 +84,11 @@ def gcn_norm_adj(sparse_adj, norm="both", add_self_loop=True, sym=True, renorm=T
             raise Exception("cannot set add_self_loop=True for GCN when sparse_adj.shape[0] != sparse_adj.shape[1]")
         if sym:
             raise Exception("cannot set sym=True for GCN when sparse_adj.shape[0] != sparse_adj.shape[1]")
+    if norm == "right" and sparse_adj.shape[1] > sparse_adj.shape[0]:
+        # :113-119 scales column c by the ROW degree of node c: with more columns than rows the reference's tf.gather
+        # runs out of range (InvalidArgumentError on TF-CPU); never read past row_deg here
+        raise Exception("norm='right' indexes the row degrees by column id: sparse_adj.shape[1] must not exceed "
+                        "sparse_adj.shape[0]")
     plan = sparse_adj.plan
     n = plan.n_dst
     dev = plan.row_ptr.device

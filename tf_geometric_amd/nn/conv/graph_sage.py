@@ -89,9 +89,24 @@ def gcn_graph_sage(x, edge_index, edge_weight, kernel, bias=None, activation=Non
     E = int(ei.shape[1])
     if edge_weight is not None:
         edge_weight = torch.ones(E, dtype=torch.float32, device=x.device)          # :139-140
-    renorm = bool(cache)                                                            # :142 (positional slip)
-    adj = SparseMatrix(ei, edge_weight, [n, n])
-    normed = gcn_norm_adj(adj, renorm=renorm, improved=False, cache=None)
+    # :142 (positional slip): `cache` lands in gcn_norm_edge's `renorm` slot, so renorm = truthiness of the dict.  This
+    # package's own bookkeeping entries ("tfgx_*") must not flip it: the reference never writes to that dict here.
+    renorm = bool(cache) if not isinstance(cache, dict) else any(
+        not str(k[0] if isinstance(k, tuple) else k).startswith("tfgx_") for k in cache)
+    # the reference caches nothing here (its `cache` lands in `renorm`); with a dict we still reuse the graph's CSR plan
+    # and memoise the normalised adjacency under a PRIVATE key (same values, no radix sort / sync per forward, so the
+    # layer can be captured by graph_capture.CapturedForward)
+    key = ("tfgx_gcn_graph_sage_normed", edge_weight is not None, renorm)
+    hit = cache.get(key) if isinstance(cache, dict) else None
+    if hit is not None and hit[0] is edge_index:
+        normed = hit[1]
+    else:
+        adj = SparseMatrix(ei, edge_weight, [n, n])
+        if isinstance(cache, dict):
+            adj._plan = CsrPlan.from_cache(ei, n, n, cache)
+        normed = gcn_norm_adj(adj, renorm=renorm, improved=False, cache=None)
+        if isinstance(cache, dict):
+            cache[key] = (edge_index, normed)
     act, post = _resolve_act(activation)
     if AG.needs_grad(x, kernel, bias):
         reduced = AG.aggregate(normed.plan, x, L.SUM, normed.w_csr, normed.self_coef)

@@ -209,33 +209,85 @@ class SplitRows(object):
         return out
 
 
-def static_rows(x, plan, cache):
-    """`x`, or — from the SECOND time the same feature tensor (storage, version, shape) is aggregated over the same
-    plan with the same `cache` dict — its SplitRows + edge-resident-tail form.  A tensor seen twice is taken to be the
-    dataset's static input features (layer 0 of a model, every epoch); the first sighting pays nothing, the second
-    pays the one-off conversion (about a third of one aggregation at products shape), later ones run the faster
-    layout.  Results are bit-identical either way.  Only widths where it matters (SplitRows.wanted).
-    Contract (the same one autograd relies on): a change of the features must be visible to torch — a new tensor, or an
-    in-place op that bumps the version counter.  Writers that bypass it (`x.data.mul_()`, another framework writing
-    through a shared pointer) must switch the detection off: `cache["tfgx_static_features"] = False`.  Never active
-    while a hipGraph is being captured (the layout build allocates)."""
-    if cache is None or not isinstance(x, torch.Tensor) or x.dim() != 2 or not x.is_contiguous():
-        return x
-    if cache.get("tfgx_static_features", True) is False or torch.cuda.is_current_stream_capturing():
-        return x
+CACHE_KEY_STATIC = "tfgx_static_features"      # user opt-in: cache[CACHE_KEY_STATIC] = the static feature tensor
+CACHE_KEY_STATIC_ROWS = "tfgx_static_rows"      # the layout built for it: (key, SplitRows | None, x, plan, bytes)
+
+
+STATIC_STATS = {"hits": 0, "builds": 0}         # diagnostics: how often the prepared layout was used / (re)built
+
+
+def _static_key(x, plan):
+    return (x.data_ptr(), x._version, int(x.shape[0]), int(x.shape[1]), id(plan))
+
+
+def _build_static_rows(x, plan, cache):
     n, F = int(x.shape[0]), int(x.shape[1])
-    if not SplitRows.wanted(n, F):
-        return x
-    key = (x.data_ptr(), x._version, n, F, id(plan))
-    hit = cache.get("tfgx_static_rows")
-    if hit is None or hit[0] != key:
-        cache["tfgx_static_rows"] = (key, None, x, plan)      # holds x and plan: neither address can be recycled
-        return x
-    if hit[1] is None:
+    rows, nbytes = None, 0
+    if SplitRows.wanted(n, F):
         rows = SplitRows.from_dense(x).with_edge_tail(plan)
-        cache["tfgx_static_rows"] = (key, rows, x, plan)
-        return rows
-    return hit[1]
+        nbytes = 4 * (rows.main.numel() + rows.tail.numel() + rows.edge_tail.numel())
+    cache[CACHE_KEY_STATIC_ROWS] = (_static_key(x, plan), rows, x, plan, nbytes)    # holds x and plan alive
+    STATIC_STATS["builds"] += 1
+    return rows, nbytes
+
+
+def prepare_static_features(x, edge_index, cache, num_nodes=None):
+    """EXPLICIT opt-in to the static-feature layout: declares that the tensor `x` is the graph's
+    static input features — aggregated again and again over the same graph (layer 0 of a model, every epoch) and not
+    written to in between — and builds, now, the SplitRows + edge-resident-tail form the aggregation kernel then uses
+    for `x` (bit-identical results, one 128-byte line request fewer per edge at widths like F = 100).
+
+    Nothing is ever built without this call (or `cache["tfgx_static_features"] = x`, which builds lazily on the first
+    eager aggregation of x): the layout is derived from feature VALUES and costs 4*N*F + 4*E*(F mod 32) bytes, so it
+    is the caller's decision.  Because it is built here, eagerly, a later hipGraph capture (CapturedForward) of a model
+    that closes over the same `x` replays the fast layout.  Contract: while opted in, change x only through torch (a
+    new tensor, or an in-place op — the version counter invalidates the layout and it is rebuilt); writes that bypass
+    the counter (`x.data`, foreign pointers) require `release_static_features(cache)` first.
+
+    :return: dict(bytes=..., layout="edge_tail" | "dense", f_main=..., f_tail=...) — what was built and what it costs."""
+    if cache is None:
+        raise ValueError("prepare_static_features needs the graph's cache dict")
+    x = L.as_f32(x)
+    if x.dim() != 2 or not x.is_contiguous():
+        raise ValueError("static features must be a contiguous [num_nodes, num_features] float32 tensor")
+    n = int(x.shape[0]) if num_nodes is None else int(num_nodes)
+    plan = edge_index if isinstance(edge_index, CsrPlan) else CsrPlan.from_cache(edge_index, n, int(x.shape[0]), cache)
+    cache[CACHE_KEY_STATIC] = x
+    rows, nbytes = _build_static_rows(x, plan, cache)
+    F = int(x.shape[1])
+    return dict(bytes=nbytes, layout="edge_tail" if rows is not None else "dense", tensor=x,
+                f_main=(F // 32) * 32 if rows is not None else F, f_tail=F % 32 if rows is not None else 0)
+
+
+def release_static_features(cache):
+    """Undo prepare_static_features: frees the layout; later aggregations read x itself."""
+    cache.pop(CACHE_KEY_STATIC, None)
+    cache.pop(CACHE_KEY_STATIC_ROWS, None)
+
+
+def static_rows(x, plan, cache):
+    """`x`, or its prepared SplitRows + edge-resident-tail form when — and only when — the caller opted in for exactly
+    this tensor (`prepare_static_features`, or `cache["tfgx_static_features"] = x`).  No heuristics: a tensor that was
+    not declared static is always read as it is.  A torch-visible change of x (version counter) rebuilds the layout
+    outside hipGraph capture and falls back to x inside it (building allocates)."""
+    if cache is None or not isinstance(x, torch.Tensor):
+        return x
+    opt = cache.get(CACHE_KEY_STATIC, None)
+    if opt is None or opt is False or not isinstance(opt, torch.Tensor):
+        return x
+    # "the same tensor": same storage window (views made by .detach() / as_f32 share it); opt is kept alive by the
+    # cache entry, so the address cannot have been recycled
+    if opt.data_ptr() != x.data_ptr() or opt.shape != x.shape or opt.dtype != x.dtype or opt.stride() != x.stride():
+        return x
+    hit = cache.get(CACHE_KEY_STATIC_ROWS)
+    if hit is not None and hit[0] == _static_key(x, plan):
+        if hit[1] is not None:
+            STATIC_STATS["hits"] += 1
+        return x if hit[1] is None else hit[1]
+    if torch.cuda.is_current_stream_capturing() or x.dim() != 2 or not x.is_contiguous():
+        return x
+    rows, _ = _build_static_rows(x, plan, cache)
+    return x if rows is None else rows
 
 
 def edge_weight_csr(plan, edge_weight, cache=None):
@@ -256,9 +308,10 @@ def edge_weight_csr(plan, edge_weight, cache=None):
 
 def segment_reduce(plan, x, op, w_csr=None, out=None, act=L.ACT_NONE, self_coef=None, bias=None, add_x=None,
                    accumulate=False, mean_count=None, row_begin=None, row_end=None, rp_stride=1, col=None,
-                   n_dst=None):
+                   n_dst=None, describe=False):
     """One launch of tfgx_segment_reduce_f32 on `plan` (or on explicit row_begin/row_end/col views of it).
-    `x` is a dense [n_src, F] tensor or a SplitRows."""
+    `x` is a dense [n_src, F] tensor or a SplitRows.  describe=True launches nothing and returns the kernel symbol the
+    dispatcher picks for these arguments (tfgx_segment_reduce_describe)."""
     lib = L.require_gpu()
     split = x if isinstance(x, SplitRows) else None
     if split is not None:
@@ -310,6 +363,10 @@ def segment_reduce(plan, x, op, w_csr=None, out=None, act=L.ACT_NONE, self_coef=
         a.hub_chunk_begin, a.hub_chunk_end = chunk_begin.data_ptr(), chunk_end.data_ptr()
         a.n_hub_rows, a.n_hub_chunks = int(hub_rows.shape[0]), int(chunk_begin.shape[0])
         a.hub_scratch = scratch.data_ptr()
+    if describe:
+        buf = ctypes.create_string_buffer(160)
+        L.check(lib.tfgx_segment_reduce_describe(ctypes.byref(a), buf, 160), "tfgx_segment_reduce_describe")
+        return buf.value.decode()
     L.check(lib.tfgx_segment_reduce_f32(ctypes.byref(a), L.stream_ptr()), "tfgx_segment_reduce_f32")
     return out
 
@@ -354,4 +411,34 @@ def gather_rows(x, idx, out=None):
     _, ldo = L.row_major_2d(out)
     L.check(lib.tfgx_gather_rows_f32(L.ptr(x), ldx, L.ptr(idx), M, F, L.ptr(out), ldo, L.stream_ptr()),
             "tfgx_gather_rows_f32")
+    return out
+
+
+def gemm_tn(x, g, want_bias=False):
+    """(x^T @ g, column sums of g or None): the weight / bias gradient of a dense layer on the MFMA reduction kernel
+    (tfgx_gemm_tn_f32).  x [M, Ka], g [M, N] -> dW [Ka, N], db [N]."""
+    lib = L.require_gpu()
+    x, ldx = L.row_major_2d(L.as_f32(x))
+    g, ldg = L.row_major_2d(L.as_f32(g))
+    M, Ka, N = int(x.shape[0]), int(x.shape[1]), int(g.shape[1])
+    if int(g.shape[0]) != M:
+        raise ValueError("gemm_tn: x has {} rows, g has {}".format(M, int(g.shape[0])))
+    if Ka > 2016:        # beyond the kernel's tile budget (no layer of the path is that wide on the input side)
+        return x.t() @ g, (g.sum(0) if want_bias else None)
+    dW = torch.empty((Ka, N), dtype=torch.float32, device=x.device)
+    db = torch.empty(N, dtype=torch.float32, device=x.device) if want_bias else None
+    ws_bytes = lib.tfgx_gemm_tn_workspace_bytes(M, Ka, N, 1 if want_bias else 0)
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=x.device)
+    L.check(lib.tfgx_gemm_tn_f32(L.ptr(x), ldx, L.ptr(g), ldg, M, Ka, N, L.ptr(dW), N, L.ptr(db), L.ptr(ws), ws_bytes,
+                                 L.stream_ptr()), "tfgx_gemm_tn_f32")
+    return dW, db
+
+
+def transpose(a):
+    """a^T as a new row-major tensor (tfgx_transpose_f32)."""
+    lib = L.require_gpu()
+    a, lda = L.row_major_2d(L.as_f32(a))
+    r, c = int(a.shape[0]), int(a.shape[1])
+    out = torch.empty((c, r), dtype=torch.float32, device=a.device)
+    L.check(lib.tfgx_transpose_f32(L.ptr(a), lda, r, c, L.ptr(out), r, L.stream_ptr()), "tfgx_transpose_f32")
     return out
