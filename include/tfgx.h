@@ -379,6 +379,11 @@ int tfgx_l2_normalize_rows_f32(float* h, int64_t ld, int64_t n, int64_t F, tfgx_
  * ------------------------------------------------------------------------------------------- */
 int tfgx_gather_rows_f32(const float* x, int64_t ldx, const int32_t* idx, int64_t M, int64_t F,
                          float* out, int64_t ldo, tfgx_stream_t stream);
+/* dst[idx[i], :] += src[i, :] for i in [0, M): owner-side accumulate of the reverse halo exchange (gradients of halo rows
+   returning to their owners during training).  idx must hold UNIQUE ids within one call (one peer's request list does);
+   peers are applied by the caller in a fixed order, so the sum is deterministic without atomics. */
+int tfgx_scatter_add_rows_f32(float* dst, int64_t ldd, const int32_t* idx, int64_t M, int64_t F, const float* src,
+                              int64_t lds, tfgx_stream_t stream);
 /* n_class source classes (own rows + one class per halo exchange ROUND, so the halo pass of round j can run while
    round j+1 is still on the wire): class of source c = first k with
    c < class_bounds[k] (device int32 [n_class-1] used); row r's class-k edges = [rpk[r*n_class+k], rpk[r*n_class+k+1]);

@@ -1,0 +1,61 @@
+/* tfgx_dist.h — C ABI of the halo exchange of a destination-range sharded graph (SURVEY.md §8b last table row, §8e).
+ *
+ * Lives in its own library (tf_geometric_amd/lib/libtfgx_dist.so = these entry points + librccl) so that libtfgx.so,
+ * the compute library, has no communication dependency.  Replaces nothing in the reference — tf_geometric's two
+ * "distributed" demos replicate the whole graph per GPU and all-reduce gradients (demo/demo_distributed_gcn.py:38-57,
+ * :99); this is what a non-torch host (the tf.load_op_library route of INTEGRATION.md) calls to reach the sharded
+ * path: one process per GPU, an ncclComm_t the HOST created (ncclCommInitRank), plain device pointers.
+ *
+ * Exchange = an all-to-all-v of source-feature rows in R rounds.  Round j: rank p packs the rows peer q asked for
+ * (send_idx, precomputed by the plan) and posts grouped ncclSend / ncclRecv to every peer on the COMM stream; the
+ * compute stream goes on with the own-source edge pass and later waits per round (exchange_finish) before reducing
+ * that round's halo edges.  xGMI is point-to-point: one grouped exchange drives all 7 links of a GPU at once.
+ * All functions return 0 on success; message via tfgx_last_error() of libtfgx.so is NOT shared — use
+ * tfgx_dist_last_error().
+ */
+#ifndef TFGX_DIST_H
+#define TFGX_DIST_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tfgx_halo_plan tfgx_halo_plan;   /* host object: counts, offsets, events */
+
+const char* tfgx_dist_last_error(void);
+
+/* world, rank        : communicator geometry (must match the ncclComm_t passed later)
+ * rounds             : R >= 1
+ * send_counts[R*world], recv_counts[R*world] (host): rows sent to / received from peer p in round j at [j*world + p];
+ *                      a shard never asks itself for rows, so the plan builder leaves the entries of `rank` itself 0
+ *                      (equal non-zero self counts are accepted: RCCL matches a self send/recv inside the group)
+ * send_idx (device)  : int32 local row ids to pack, concatenated round-major then peer-major
+ *                      (sum(send_counts) entries); the plan keeps the pointer, the caller keeps the memory alive
+ * The halo table is laid out round-major then peer-major: round j, peer p starts at row
+ * sum(recv_counts[0 .. j*world + p)). */
+int tfgx_halo_plan_create(int32_t world, int32_t rank, int32_t rounds, const int64_t* send_counts,
+                          const int64_t* recv_counts, const int32_t* send_idx, tfgx_halo_plan** out);
+int tfgx_halo_plan_destroy(tfgx_halo_plan* plan);
+int64_t tfgx_halo_plan_rows_sent(const tfgx_halo_plan* plan);
+int64_t tfgx_halo_plan_rows_received(const tfgx_halo_plan* plan);
+
+/* Pack + post every round.  x_own [n_own, F] (ld = ldx): this rank's rows; halo [rows_received, F] (ld = ld_halo);
+ * send_buf: device scratch of at least rows_sent * F floats, owned by the caller, untouched until finish(all).
+ * nccl_comm: an ncclComm_t.  compute_stream orders the packs after whatever produced x_own; comm_stream carries the
+ * sends / receives.  Returns immediately (asynchronous). */
+int tfgx_halo_exchange_start(tfgx_halo_plan* plan, const float* x_own, int64_t ldx, int64_t F, float* halo,
+                             int64_t ld_halo, float* send_buf, size_t send_buf_floats, void* nccl_comm,
+                             void* compute_stream, void* comm_stream);
+
+/* Make compute_stream wait for round `round` (0 <= round < R), or for all rounds when round < 0. */
+int tfgx_halo_exchange_finish(tfgx_halo_plan* plan, int32_t round, void* compute_stream);
+
+/* sum-all-reduce of a float buffer in place (weight gradients of replicated layer weights: the one collective the
+ * reference's distributed demos perform, demo/demo_distributed_gcn.py:52-57). */
+int tfgx_allreduce_sum_f32(float* buf, int64_t count, void* nccl_comm, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TFGX_DIST_H */

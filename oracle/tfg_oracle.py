@@ -7,32 +7,38 @@ module: it is the checker for ``tests/``, ``__graft_entry__.smoke()`` and the
 ``cpu_baseline`` leg of ``bench.py``, never the thing that is shipped or timed
 as the product.
 
-PARITY UNPINNED.  The reference (/root/reference, tf_geometric 0.1.7) ships no
-tests, golden vectors or fixtures for this path, and its
-arithmetic lives in two un-vendored third-party packages that are not
-installable here: ``tensorflow`` (>=1.15,<2 or >=2.4.0, setup.py:33-38) and
-``tf_sparse >= 0.0.17`` (setup.py:25).  This file therefore restates the
-reference's *own* Python line by line (each function cites the file:line it
-follows) and restates the published semantics of the TF / tf_sparse ops at the
-call sites:
+PINNED TO THE REFERENCE'S OWN PYTHON (round 2).  The reference (/root/reference, tf_geometric 0.1.7) ships no
+tests, golden vectors or fixtures for this path and hard-depends on two third-party packages that
+are not installable here: ``tensorflow`` (>=1.15,<2 or >=2.4.0, setup.py:33-38) and ``tf_sparse >= 0.0.17``
+(setup.py:25).  ``oracle/ref_harness`` therefore provides numpy stand-ins for exactly those two modules and imports
+``/root/reference/tf_geometric`` UNMODIFIED on top of them: every line of the reference's composition logic
+(aggregate_neighbors, segment_softmax, gcn_norm_adj, gcn, gat, the GraphSAGE variants, graph_utils, the tfg.layers
+classes, the other convs and pools) executes as written and produces ``tests/golden/reference_cases.npz``
+(``tests/golden/make_golden_from_reference.py``).  ``tests/test_oracle_vs_reference.py`` holds this file to those
+outputs (and, where /root/reference exists, to the live reference on further fuzz seeds).  That check already found one
+deviation of the first-round restatement: ``aggregate_neighbors`` with a ``[2, 0]`` edge_index does NOT take the
+early return of map_reduce.py:57.
+
+What is still RESTATED rather than executed — in the stand-ins, and equally here — is the arithmetic of the TF /
+tf_sparse primitives at the call sites (TensorFlow itself has never run in this image):
 
   * tf.gather(params, idx)                      -> params[idx]
   * tf.math.unsorted_segment_sum(d, ids, n)     -> zeros(n) then out[ids[i]] += d[i]; empty segment = 0
   * tf.math.unsorted_segment_mean(d, ids, n)    -> segment_sum / max(count, 1); empty segment = 0
   * tf.math.unsorted_segment_max(d, ids, n)     -> empty segment = numeric_limits<float>::lowest()
   * tf.nn.l2_normalize(x, axis, eps=1e-12)      -> x * rsqrt(max(sum(x**2), eps))
+  * tf.unique                                   -> first-occurrence order
   * tf_sparse.SparseMatrix(index, value, shape) -> COO matrix, duplicate entries are summed by matmul
   * SparseMatrix.segment_sum(axis=-1 | 0)       -> row sums | column sums of the values
-  * SparseMatrix.add_diag(c)                    -> A + c*I  (restated as N appended (i,i,c) entries:
-                                                   identical under matmul / segment_sum)
+  * SparseMatrix.add_diag(c)                    -> A + c*I, existing diagonal entries added to (restated here as N
+                                                   appended (i,i,c) entries: identical under matmul / segment_sum)
   * SparseMatrix.segment_softmax(axis=-1)       -> nn/kernel/segment.py:26-33 grouped by row
   * SparseMatrix.dropout(rate, training=False)  -> identity
 
-What pins it instead (tests/test_oracle.py): hand-derived known answers on the
-reference's own example graphs (tutorial_intro.py:24-30, datasets/synthetic.py:
-47-66), an independent second implementation (torch CPU index_add_ /
-scatter_reduce and the C restatement oracle/tfg_oracle.c), and algebraic
-properties (edge-order permutation invariance, duplicate edges sum, linearity).
+Further pins (tests/test_oracle.py): hand-derived known answers on the reference's own example graphs
+(tutorial_intro.py:24-30, datasets/synthetic.py:47-66), an independent second implementation (torch CPU index_add_ /
+scatter_reduce and the C restatement oracle/tfg_oracle.c), and algebraic properties (edge-order permutation
+invariance, duplicate edges sum, linearity).
 
 Two accumulation modes: ``acc=np.float64`` (default; the "true" value the fp32
 implementations are compared with under 1e-5 + 1e-5*|ref|) and

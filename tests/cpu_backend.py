@@ -75,6 +75,17 @@ class NumpyBackend(object):
             return out
         return res.contiguous()
 
+    def scatter_add_rows(self, dst, idx, src):
+        i = _np(idx).astype(np.int64)
+        assert np.unique(i).size == i.size, "scatter_add_rows needs unique ids per call"
+        d = _np(dst)
+        d[i] += _np(src)
+        return dst
+
+    def linear(self, x, kernel, bias=None):
+        h = x @ kernel                        # torch CPU autograd (test backend)
+        return h if bias is None else h + bias
+
     def segment_reduce(self, row_begin, row_end, rp_stride, col, w, n_dst, x, out, op, act=0, accumulate=False,
                        self_coef=None, bias=None, mean_count=None):
         rb, re, c, wv, xv = _np(row_begin), _np(row_end), _np(col), _np(w), _np(x).astype(np.float64)

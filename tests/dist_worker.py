@@ -149,3 +149,93 @@ def check_against_reference(parts, skew, assert_parity):
             got, full = got[~huge], full[~huge]
         assert_parity(got, full, what="sharded " + key)
     return parts
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# training: sharded backward (reverse halo exchange + owner-side accumulate) and the weight-gradient all-reduce
+# ----------------------------------------------------------------------------------------------------------------------
+def _loss_coef(n, u):
+    return (np.sin(np.arange(n * u, dtype=np.float64) * 0.37).reshape(n, u) + 1.5).astype(np.float32)
+
+
+def run_training(rank, world, use_gpu, skew, rounds=None, num_splits=None):
+    from tf_geometric_amd.dist.sharded import ShardedGraph
+    ei, x, w, k, b = make_inputs(skew=skew)
+    n = x.shape[0]
+    if use_gpu:
+        backend = None
+    else:
+        from cpu_backend import NumpyBackend
+        backend = NumpyBackend()
+    group = dist.group.WORLD if dist.is_initialized() else None
+    sg = ShardedGraph.from_global(ei, n, edge_weight=w, group=group, backend=backend, rounds=rounds)
+    be = sg.backend
+    sg.build_gcn_norm()
+    x_own = be.f32(x[sg.own_lo:sg.own_hi]).requires_grad_(True)
+    kernel = be.f32(k).requires_grad_(True)
+    bias = be.f32(b).requires_grad_(True)
+    coef = be.f32(_loss_coef(n, k.shape[1])[sg.own_lo:sg.own_hi])
+    out = sg.gcn_trainable(x_own, kernel, bias, torch.relu)
+    (out * coef).sum().backward()
+    local_dk = kernel.grad.detach().clone()
+    sg.all_reduce_gradients([kernel, bias])
+    res = {"lo": sg.own_lo, "hi": sg.own_hi, "out": out.detach().cpu().numpy(), "dx": x_own.grad.cpu().numpy(),
+           "dk": kernel.grad.cpu().numpy(), "db": bias.grad.cpu().numpy(), "dk_local": local_dk.cpu().numpy()}
+    # mean aggregation (GraphSAGE's reduce) through the same backward
+    x2 = be.f32(x[sg.own_lo:sg.own_hi]).requires_grad_(True)
+    m = sg.aggregate_trainable(x2, 1)
+    (m * be.f32(_loss_coef(n, x.shape[1])[sg.own_lo:sg.own_hi])).sum().backward()
+    res["dx_mean"] = x2.grad.cpu().numpy()
+    if num_splits:
+        chunked = sg.aggregate_chunked(be.f32(x[sg.own_lo:sg.own_hi]), num_splits, w=sg.norm_w, self_coef=sg.self_coef,
+                                       bias=be.f32(np.arange(x.shape[1], dtype=np.float32) * 0.01), act=1)
+        table = sg.alloc_table(x.shape[1])
+        sg.own_rows(table).copy_(be.f32(x[sg.own_lo:sg.own_hi]))
+        whole = sg.aggregate(table, 0, w=sg.norm_w, self_coef=sg.self_coef,
+                             bias=be.f32(np.arange(x.shape[1], dtype=np.float32) * 0.01), act=1)
+        res["chunked"], res["whole"] = chunked.cpu().numpy(), whole.cpu().numpy()
+        res["chunk_table_floats"], res["full_table_floats"] = sg.last_chunk_table_floats, int(table.numel())
+    return res
+
+
+def _train_entry(rank, world, port, use_gpu, skew, path, rounds, num_splits):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if use_gpu:
+        torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    res = run_training(rank, world, use_gpu, skew, rounds, num_splits)
+    np.save(os.path.join(path, "train{}.npy".format(rank)), np.array([res], dtype=object), allow_pickle=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def spawn_training(world, use_gpu, skew, path, port, rounds=None, num_splits=None):
+    import torch.multiprocessing as mp
+    mp.spawn(_train_entry, args=(world, port, use_gpu, skew, path, rounds, num_splits), nprocs=world, join=True)
+    return [np.load(os.path.join(path, "train{}.npy".format(r)), allow_pickle=True)[0] for r in range(world)]
+
+
+def training_reference(skew):
+    """Single-process float64 autograd over the oracle's normalised adjacency: what tf.GradientTape yields."""
+    from oracle import tfg_oracle as oracle
+    ei, x, w, k, b = make_inputs(skew=skew)
+    n = x.shape[0]
+    nei, nw = oracle.gcn_norm_adj(ei, w, n)
+    A = torch.zeros((n, n), dtype=torch.float64)
+    A.index_put_((torch.from_numpy(nei[0].astype(np.int64)), torch.from_numpy(nei[1].astype(np.int64))),
+                 torch.from_numpy(nw.astype(np.float64)), accumulate=True)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    kt = torch.tensor(k, dtype=torch.float64, requires_grad=True)
+    bt = torch.tensor(b, dtype=torch.float64, requires_grad=True)
+    out = torch.relu(A @ (xt @ kt) + bt)
+    (out * torch.from_numpy(_loss_coef(n, k.shape[1]).astype(np.float64))).sum().backward()
+    W = torch.zeros((n, n), dtype=torch.float64)
+    W.index_put_((torch.from_numpy(ei[0].astype(np.int64)), torch.from_numpy(ei[1].astype(np.int64))),
+                 torch.from_numpy(w.astype(np.float64)), accumulate=True)
+    deg = torch.from_numpy(np.maximum(np.bincount(ei[0], minlength=n), 1).astype(np.float64))
+    x2 = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    ((W @ x2) / deg[:, None] * torch.from_numpy(_loss_coef(n, x.shape[1]).astype(np.float64))).sum().backward()
+    return {"out": out.detach().numpy(), "dx": xt.grad.numpy(), "dk": kt.grad.numpy(), "db": bt.grad.numpy(),
+            "dx_mean": x2.grad.numpy()}

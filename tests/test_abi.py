@@ -147,3 +147,25 @@ def test_synthetic_inputs_are_reproducible():
     half = a.shape[1] // 2
     assert np.array_equal(a[0, :half], a[1, half:]) and np.array_equal(a[1, :half], a[0, half:])   # (a,b) then (b,a)
     assert (a[0] != a[1]).all()
+
+
+def test_dist_library_exports_every_declared_symbol():
+    """include/tfgx_dist.h (the halo-exchange C ABI: ncclComm_t + streams) vs lib/libtfgx_dist.so; host
+    argument checks run without a GPU (no RCCL call is reached)."""
+    from tf_geometric_amd import _build
+    with open(os.path.join(ROOT, "include", "tfgx_dist.h")) as fh:
+        src = re.sub(r"/\*.*?\*/", "", fh.read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(tfgx_[a-z0-9_]+)\s*\(", src)))
+    assert len(names) == 8, names
+    if not os.path.exists(_build.DIST_LIB):
+        _build.build_dist(verbose=False)
+    lib = ctypes.CDLL(_build.DIST_LIB)
+    for name in names:
+        assert hasattr(lib, name), "libtfgx_dist.so does not export {}".format(name)
+    lib.tfgx_dist_last_error.restype = ctypes.c_char_p
+    plan = ctypes.c_void_p()
+    cnt = (ctypes.c_int64 * 4)(0, 3, 0, 2)
+    assert lib.tfgx_halo_plan_create(2, 5, 2, cnt, cnt, None, ctypes.byref(plan)) == 1      # rank outside world
+    assert b"bad world" in lib.tfgx_dist_last_error()
+    assert lib.tfgx_halo_plan_create(2, 0, 2, cnt, cnt, None, ctypes.byref(plan)) == 1      # rows to send, no index list
+    assert lib.tfgx_halo_exchange_finish(None, 0, None) == 1

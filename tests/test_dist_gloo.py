@@ -53,3 +53,37 @@ def test_edge_balanced_bounds():
     assert b[0] == 0 and b[-1] == 7 and (np.diff(b) >= 0).all()
     assert list(edge_balanced_bounds(np.zeros(9, np.int64), 4)) == [0, 2, 4, 6, 8]
     assert list(edge_balanced_bounds(rp, 1)) == [0, 7]
+
+
+@pytest.mark.parametrize("world,skew,rounds", [(2, False, 2), (3, True, 3), (1, True, None)])
+def test_sharded_training_gradients_gloo(tmp_path, world, skew, rounds):
+    """Sharded backward: reverse halo all-to-all-v, owner-side accumulate in fixed peer order, weight-gradient
+    all-reduce.  d/dx (per owner), d/dkernel and d/dbias (summed over ranks) must equal single-process float64 autograd
+    over the oracle's normalised adjacency — what tf.GradientTape produces in the reference's training loops
+    (demo/demo_gcn.py:68-77; distributed: demo/demo_distributed_gcn.py:52-57,99)."""
+    if world == 1:
+        parts = [dist_worker.run_training(0, 1, False, skew)]
+    else:
+        port = 29500 + random.randint(4001, 6000)
+        parts = dist_worker.spawn_training(world, False, skew, str(tmp_path), port, rounds=rounds)
+    ref = dist_worker.training_reference(skew)
+    parts = sorted(parts, key=lambda p: p["lo"])
+    assert_parity(np.concatenate([p["out"] for p in parts]), ref["out"], what="sharded trainable forward")
+    assert_parity(np.concatenate([p["dx"] for p in parts]), ref["dx"], tol=2e-5, what="sharded d/dx")
+    assert_parity(np.concatenate([p["dx_mean"] for p in parts]), ref["dx_mean"], tol=2e-5, what="sharded mean d/dx")
+    for p in parts:                       # every rank holds the SAME all-reduced weight gradients
+        assert_parity(p["dk"], ref["dk"], tol=1e-4, what="all-reduced d/dkernel")
+        assert_parity(p["db"], ref["db"], tol=1e-4, what="all-reduced d/dbias")
+    if world > 1:                         # ... which are the sum of different local parts
+        assert np.abs(parts[0]["dk_local"] - parts[1]["dk_local"]).max() > 1e-3
+        assert_parity(sum(p["dk_local"] for p in parts), ref["dk"], tol=1e-4, what="sum of local d/dkernel")
+
+
+def test_column_chunked_halo_bounds_the_table_gloo(tmp_path):
+    """aggregate_chunked(num_splits) (the reference's num_splits, utils/tf_sparse_utils.py:71-90): same rows as the
+    unchunked pass, with a source table num_splits times smaller."""
+    port = 29500 + random.randint(6001, 8000)
+    parts = dist_worker.spawn_training(2, False, True, str(tmp_path), port, rounds=2, num_splits=4)   # F = 12 -> four 3-column chunks
+    for p in parts:
+        assert np.array_equal(p["chunked"], p["whole"])
+        assert p["chunk_table_floats"] * 4 == p["full_table_floats"]

@@ -42,3 +42,26 @@ def test_rccl_world1_api_smoke(tfg):
     res = subprocess.run([sys.executable, script], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     text = res.stdout.decode()
     assert res.returncode == 0 and "RCCL_WORLD1_OK" in text and "True" in text and "False" not in text, text
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_sharded_training_hip(tfg, tmp_path, world):
+    """Sharded backward on the HIP kernels (transposed local pass, tfgx_scatter_add_rows_f32 owner-side accumulate,
+    MFMA weight gradients) + the reverse exchange and weight-gradient all-reduce over a gloo group sharing cuda:0, and
+    the column-chunked halo (bit-identical rows, a quarter of the table)."""
+    import numpy as np
+    if world == 1:
+        parts = [dist_worker.run_training(0, 1, True, True, num_splits=4)]
+    else:
+        port = 37600 + random.randint(0, 2000)
+        parts = dist_worker.spawn_training(2, True, True, str(tmp_path), port, rounds=3, num_splits=4)
+    ref = dist_worker.training_reference(True)
+    parts = sorted(parts, key=lambda p: p["lo"])
+    assert_parity(np.concatenate([p["out"] for p in parts]), ref["out"], what="sharded trainable forward (HIP)")
+    assert_parity(np.concatenate([p["dx"] for p in parts]), ref["dx"], tol=2e-5, what="sharded d/dx (HIP)")
+    assert_parity(np.concatenate([p["dx_mean"] for p in parts]), ref["dx_mean"], tol=2e-5, what="sharded mean d/dx (HIP)")
+    for p in parts:
+        assert_parity(p["dk"], ref["dk"], tol=1e-4, what="all-reduced d/dkernel (HIP)")
+        assert_parity(p["db"], ref["db"], tol=1e-4, what="all-reduced d/dbias (HIP)")
+        assert np.array_equal(p["chunked"], p["whole"])
+        assert p["chunk_table_floats"] * 4 == p["full_table_floats"]

@@ -119,3 +119,24 @@ def test_oracle_equals_reference_python(seed, R, oracle):
     s = (rng.standard_normal(ei.shape[1]) * 4).astype(np.float32)
     assert_parity(o.segment_softmax(s, ei[0], n), R.tfg.nn.kernel.segment.segment_softmax(s, ei[0], n).numpy(),
                   what="segment_softmax")
+
+
+@needs_ref
+def test_num_splits_rule_equals_reference(R):
+    """dist.sharded.compute_num_or_size_splits (column-chunked halo) vs the reference's helper of the same name
+    (utils/tf_sparse_utils.py:71-90): same split sizes, same refusals."""
+    from tf_geometric_amd.dist.sharded import compute_num_or_size_splits as mine
+    theirs = R.tfg.utils.tf_sparse_utils.compute_num_or_size_splits
+    for f in (1, 7, 12, 100, 128, 602, 1433):
+        for k in (None, 1, 2, 3, 4, 5, 7, 8, 16, 100):
+            try:
+                want = theirs(f, k)
+            except Exception:
+                want = "raises"
+            try:
+                got = mine(f, k)
+            except Exception:
+                got = "raises"
+            if isinstance(want, list):
+                want = [int(v) for v in want]
+            assert got == want, (f, k, got, want)

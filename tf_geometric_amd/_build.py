@@ -46,8 +46,38 @@ def build(force=False, verbose=True):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+    build_dist(force=force or bool(jobs), verbose=verbose)
     build_c_abi_demo(force=force or bool(jobs), verbose=verbose)
     return LIB_PATH
+
+
+DIST_SRC = os.path.join(CSRC, "tfgx_dist.cpp")
+DIST_LIB = os.path.join(LIB_DIR, "libtfgx_dist.so")
+HALO_DEMO_SRC = os.path.join(_HERE, "..", "examples", "c_abi_halo_demo.cpp")
+HALO_DEMO_BIN = os.path.join(LIB_DIR, "c_abi_halo_demo")
+ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
+
+
+def build_dist(force=False, verbose=True):
+    """lib/libtfgx_dist.so: the halo-exchange C ABI (include/tfgx_dist.h) = host code over libtfgx.so + librccl, kept out
+    of the compute library so libtfgx.so has no communication dependency; and its torch-free demo program."""
+    inc = os.path.join(_HERE, "..", "include")
+    hdr = os.path.join(inc, "tfgx_dist.h")
+    if force or _newer(DIST_SRC, DIST_LIB) or _newer(hdr, DIST_LIB) or _newer(LIB_PATH, DIST_LIB):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-I", os.path.join(ROCM, "include"),
+               DIST_SRC, "-o", DIST_LIB, "-L", LIB_DIR, "-ltfgx", "-L", os.path.join(ROCM, "lib"), "-lrccl",
+               "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    if os.path.exists(HALO_DEMO_SRC) and (force or _newer(HALO_DEMO_SRC, HALO_DEMO_BIN) or _newer(DIST_LIB, HALO_DEMO_BIN)):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O2", "-I", inc, "-I", os.path.join(ROCM, "include"), HALO_DEMO_SRC,
+               "-L", LIB_DIR, "-ltfgx_dist", "-ltfgx", "-L", os.path.join(ROCM, "lib"), "-lrccl", "-Wl,-rpath,$ORIGIN",
+               "-o", HALO_DEMO_BIN]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return DIST_LIB
 
 
 DEMO_SRC = os.path.join(_HERE, "..", "examples", "c_abi_demo.cpp")

@@ -1,0 +1,176 @@
+// Halo exchange of the destination-range sharded graph over RCCL (include/tfgx_dist.h).
+// Host code only: the pack kernel is libtfgx.so's tfgx_gather_rows_f32, the transport is grouped ncclSend / ncclRecv
+// (RCCL: every GPU pair of an MI355X node has its own xGMI link, so one grouped personalised exchange uses all 7 links
+// at once), ordering is by HIP events between the caller's compute stream and a communication stream.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+#include "../../include/tfgx.h"
+#include "../../include/tfgx_dist.h"
+
+namespace {
+thread_local char g_err[512] = "";
+void set_err(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+#define DIST_REQUIRE(cond, msg)                 \
+    do {                                        \
+        if (!(cond)) {                          \
+            set_err("%s: %s", __func__, msg);   \
+            return TFGX_ERR_INVALID_ARG;        \
+        }                                       \
+    } while (0)
+#define DIST_HIP(expr)                                                    \
+    do {                                                                  \
+        hipError_t e_ = (expr);                                           \
+        if (e_ != hipSuccess) {                                           \
+            set_err("%s: %s", #expr, hipGetErrorString(e_));              \
+            return TFGX_ERR_HIP;                                          \
+        }                                                                 \
+    } while (0)
+#define DIST_NCCL(expr)                                                   \
+    do {                                                                  \
+        ncclResult_t r_ = (expr);                                         \
+        if (r_ != ncclSuccess) {                                          \
+            set_err("%s: %s", #expr, ncclGetErrorString(r_));             \
+            return TFGX_ERR_HIP;                                          \
+        }                                                                 \
+    } while (0)
+}  // namespace
+
+struct tfgx_halo_plan {
+    int32_t world, rank, rounds;
+    std::vector<int64_t> send_counts, recv_counts;     // [rounds * world]
+    std::vector<int64_t> send_off, recv_off;           // row offsets, same indexing (+1 total at the end)
+    const int32_t* send_idx;                           // device
+    std::vector<hipEvent_t> packed, done;              // per round
+    bool in_flight;
+};
+
+extern "C" const char* tfgx_dist_last_error(void) { return g_err; }
+
+extern "C" int tfgx_halo_plan_create(int32_t world, int32_t rank, int32_t rounds, const int64_t* send_counts,
+                                     const int64_t* recv_counts, const int32_t* send_idx, tfgx_halo_plan** out)
+{
+    DIST_REQUIRE(out != nullptr, "out is null");
+    DIST_REQUIRE(world >= 1 && rank >= 0 && rank < world && rounds >= 1 && rounds <= 64, "bad world / rank / rounds");
+    DIST_REQUIRE(send_counts && recv_counts, "null counts");
+    tfgx_halo_plan* p = new tfgx_halo_plan();
+    p->world = world; p->rank = rank; p->rounds = rounds; p->send_idx = send_idx; p->in_flight = false;
+    const size_t n = size_t(rounds) * size_t(world);
+    p->send_counts.assign(send_counts, send_counts + n);
+    p->recv_counts.assign(recv_counts, recv_counts + n);
+    p->send_off.assign(n + 1, 0);
+    p->recv_off.assign(n + 1, 0);
+    for (size_t i = 0; i < n; ++i) {
+        const bool self = int32_t(i % size_t(world)) == rank;
+        if (send_counts[i] < 0 || recv_counts[i] < 0 || (self && send_counts[i] != recv_counts[i])) {
+            delete p;
+            set_err("tfgx_halo_plan_create: negative count, or unmatched counts for the rank itself");
+            return TFGX_ERR_INVALID_ARG;
+        }
+        p->send_off[i + 1] = p->send_off[i] + send_counts[i];
+        p->recv_off[i + 1] = p->recv_off[i] + recv_counts[i];
+    }
+    if (p->send_off[n] > 0 && send_idx == nullptr) {
+        delete p;
+        set_err("tfgx_halo_plan_create: send_idx is null but rows are to be sent");
+        return TFGX_ERR_INVALID_ARG;
+    }
+    p->packed.resize(rounds);
+    p->done.resize(rounds);
+    for (int j = 0; j < rounds; ++j) {
+        DIST_HIP(hipEventCreateWithFlags(&p->packed[j], hipEventDisableTiming));
+        DIST_HIP(hipEventCreateWithFlags(&p->done[j], hipEventDisableTiming));
+    }
+    *out = p;
+    return TFGX_OK;
+}
+
+extern "C" int tfgx_halo_plan_destroy(tfgx_halo_plan* p)
+{
+    if (p == nullptr) return TFGX_OK;
+    for (hipEvent_t e : p->packed) (void)hipEventDestroy(e);
+    for (hipEvent_t e : p->done) (void)hipEventDestroy(e);
+    delete p;
+    return TFGX_OK;
+}
+
+extern "C" int64_t tfgx_halo_plan_rows_sent(const tfgx_halo_plan* p) { return p ? p->send_off.back() : -1; }
+extern "C" int64_t tfgx_halo_plan_rows_received(const tfgx_halo_plan* p) { return p ? p->recv_off.back() : -1; }
+
+extern "C" int tfgx_halo_exchange_start(tfgx_halo_plan* p, const float* x_own, int64_t ldx, int64_t F, float* halo,
+                                        int64_t ld_halo, float* send_buf, size_t send_buf_floats, void* nccl_comm,
+                                        void* compute_stream, void* comm_stream)
+{
+    DIST_REQUIRE(p != nullptr, "plan is null");
+    DIST_REQUIRE(F >= 1 && ldx >= F && ld_halo >= F, "bad F / leading dimension");
+    DIST_REQUIRE(ld_halo == F, "the halo table must be dense (ld_halo == F): rows of one peer arrive as one message");
+    const int64_t rows_sent = p->send_off.back(), rows_recv = p->recv_off.back();
+    DIST_REQUIRE(rows_sent == 0 || (x_own && send_buf && send_buf_floats >= size_t(rows_sent) * size_t(F)),
+                 "send buffer too small / null x_own");
+    DIST_REQUIRE(rows_recv == 0 || halo != nullptr, "halo is null");
+    DIST_REQUIRE(nccl_comm != nullptr || (rows_sent == 0 && rows_recv == 0), "nccl_comm is null");
+    hipStream_t cs = reinterpret_cast<hipStream_t>(compute_stream);
+    hipStream_t ms = reinterpret_cast<hipStream_t>(comm_stream);
+    ncclComm_t comm = reinterpret_cast<ncclComm_t>(nccl_comm);
+    for (int j = 0; j < p->rounds; ++j) {
+        const size_t base = size_t(j) * size_t(p->world);
+        const int64_t r0 = p->send_off[base], r1 = p->send_off[base + p->world];
+        if (r1 > r0) {   // pack this round's rows (all peers) with ONE gather launch on the compute stream
+            const int rc = tfgx_gather_rows_f32(x_own, ldx, p->send_idx + r0, r1 - r0, F, send_buf + r0 * F, F,
+                                                reinterpret_cast<tfgx_stream_t>(cs));
+            if (rc != TFGX_OK) {
+                set_err("tfgx_gather_rows_f32: %s", tfgx_last_error());
+                return rc;
+            }
+        }
+        DIST_HIP(hipEventRecord(p->packed[j], cs));
+        DIST_HIP(hipStreamWaitEvent(ms, p->packed[j], 0));
+        if (nccl_comm != nullptr) {
+            DIST_NCCL(ncclGroupStart());
+            for (int q = 0; q < p->world; ++q) {
+                const int64_t sc = p->send_counts[base + q], rc = p->recv_counts[base + q];
+                if (sc > 0)
+                    DIST_NCCL(ncclSend(send_buf + p->send_off[base + q] * F, size_t(sc) * size_t(F), ncclFloat, q, comm, ms));
+                if (rc > 0)
+                    DIST_NCCL(ncclRecv(halo + p->recv_off[base + q] * F, size_t(rc) * size_t(F), ncclFloat, q, comm, ms));
+            }
+            DIST_NCCL(ncclGroupEnd());
+        }
+        DIST_HIP(hipEventRecord(p->done[j], ms));
+    }
+    p->in_flight = true;
+    return TFGX_OK;
+}
+
+extern "C" int tfgx_halo_exchange_finish(tfgx_halo_plan* p, int32_t round, void* compute_stream)
+{
+    DIST_REQUIRE(p != nullptr, "plan is null");
+    DIST_REQUIRE(round < p->rounds, "round out of range");
+    DIST_REQUIRE(p->in_flight, "no exchange was started");
+    hipStream_t cs = reinterpret_cast<hipStream_t>(compute_stream);
+    if (round >= 0) {
+        DIST_HIP(hipStreamWaitEvent(cs, p->done[round], 0));
+    } else {
+        for (int j = 0; j < p->rounds; ++j) DIST_HIP(hipStreamWaitEvent(cs, p->done[j], 0));
+    }
+    return TFGX_OK;
+}
+
+extern "C" int tfgx_allreduce_sum_f32(float* buf, int64_t count, void* nccl_comm, void* stream)
+{
+    DIST_REQUIRE(count >= 0, "negative count");
+    if (count == 0) return TFGX_OK;
+    DIST_REQUIRE(buf != nullptr && nccl_comm != nullptr, "null pointer");
+    DIST_NCCL(ncclAllReduce(buf, buf, size_t(count), ncclFloat, ncclSum, reinterpret_cast<ncclComm_t>(nccl_comm),
+                            reinterpret_cast<hipStream_t>(stream)));
+    return TFGX_OK;
+}

@@ -44,6 +44,34 @@ __global__ __launch_bounds__(kBlock) void gather_rows_kernel(const float* __rest
     }
 }
 
+// dst[idx[i], :] += src[i, :] — the owner-side accumulate of the REVERSE halo exchange (gradients of halo rows coming
+// home).  The ids of one call must be unique (one peer's request list is): then every destination element has exactly
+// one writer and the result is deterministic without atomics; the caller applies the peers in a fixed order.
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void scatter_add_rows_kernel(float* __restrict__ dst, int64_t ldd,
+                                                                  const int32_t* __restrict__ idx, int64_t M, int F,
+                                                                  const float* __restrict__ src, int64_t lds)
+{
+    const int per_row = F / VEC;
+    int64_t t = blockIdx.x * int64_t(kBlock) + threadIdx.x;
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    const int64_t total = M * per_row;
+    for (; t < total; t += stride) {
+        const int64_t i = t / per_row;
+        const int j = int(t - i * per_row) * VEC;
+        float* d = dst + int64_t(idx[i]) * ldd + j;
+        const float* sp = src + i * lds + j;
+        if constexpr (VEC == 4) {
+            float4 a = *reinterpret_cast<float4*>(d);
+            const float4 b = *reinterpret_cast<const float4*>(sp);
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+            *reinterpret_cast<float4*>(d) = a;
+        } else {
+            *d += *sp;
+        }
+    }
+}
+
 __global__ void halo_mark_kernel(const int32_t* __restrict__ col, int64_t E, int32_t lo, int32_t hi,
                                  int32_t* __restrict__ flags)
 {
@@ -236,6 +264,23 @@ extern "C" int tfgx_gather_rows_f32(const float* x, int64_t ldx, const int32_t* 
         gather_rows_kernel<1><<<grid_for(M * F, kBlock), kBlock, 0, as_stream(stream)>>>(x, ldx, idx, M, int(F), out,
                                                                                         ldo);
     TFGX_LAUNCH_CHECK("gather_rows_kernel");
+    return TFGX_OK;
+}
+
+extern "C" int tfgx_scatter_add_rows_f32(float* dst, int64_t ldd, const int32_t* idx, int64_t M, int64_t F,
+                                        const float* src, int64_t lds, tfgx_stream_t stream)
+{
+    TFGX_REQUIRE(M >= 0 && F >= 1 && ldd >= F && lds >= F, "bad shape");
+    if (M == 0) return TFGX_OK;
+    TFGX_REQUIRE(dst && idx && src, "null pointer");
+    const bool v4 = (F % 4 == 0) && (ldd % 4 == 0) && (lds % 4 == 0) && aligned_to(dst, 16) && aligned_to(src, 16);
+    if (v4)
+        scatter_add_rows_kernel<4><<<grid_for(M * (F / 4), kBlock), kBlock, 0, as_stream(stream)>>>(dst, ldd, idx, M,
+                                                                                                   int(F), src, lds);
+    else
+        scatter_add_rows_kernel<1><<<grid_for(M * F, kBlock), kBlock, 0, as_stream(stream)>>>(dst, ldd, idx, M, int(F),
+                                                                                             src, lds);
+    TFGX_LAUNCH_CHECK("scatter_add_rows_kernel");
     return TFGX_OK;
 }
 

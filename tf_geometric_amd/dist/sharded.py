@@ -96,6 +96,19 @@ class HipBackend(object):
         from ..plan import gather_rows
         return gather_rows(x, idx, out=out)
 
+    def scatter_add_rows(self, dst, idx, src):
+        """dst[idx[i]] += src[i] with unique idx (tfgx_scatter_add_rows_f32)."""
+        _, ldd = L.row_major_2d(dst)
+        src, lds = L.row_major_2d(src)
+        L.check(self.lib.tfgx_scatter_add_rows_f32(L.ptr(dst), ldd, L.ptr(idx), int(idx.shape[0]), int(dst.shape[1]),
+                                                   L.ptr(src), lds, L.stream_ptr()), "tfgx_scatter_add_rows_f32")
+        return dst
+
+    def linear(self, x, kernel, bias=None):
+        """Differentiable x @ kernel (+ bias): forward AND backward on the MFMA kernels (autograd.linear)."""
+        from .. import autograd as AG
+        return AG.linear(x, kernel, bias)
+
     def hub_lists(self, row_begin, row_end, rp_stride, n_dst, num_edges):
         """Chunk lists for the long spans of one pass (skewed graphs), or None — see plan.hub_policy."""
         from ..plan import build_hub_lists, hub_policy
@@ -470,7 +483,8 @@ class ShardedGraph(object):
         F = int(table.shape[1])
         if out is None:
             out = be.empty((self.n_own, F))
-        handles = self.exchange_start(table) if exchange else None
+        # exchange: True = start it here; a list = handles of an exchange the caller already started; False = none
+        handles = exchange if isinstance(exchange, list) else (self.exchange_start(table) if exchange else None)
         K1, rpk = self.n_class, self.rpk
         for k in (range(K1) if classes is None else classes):
             last = k == K1 - 1
@@ -485,6 +499,137 @@ class ShardedGraph(object):
                 be.segment_reduce(rpk[k:], rpk[k + 1:], K1, self.col, w_t, self.n_own, table, out,
                                   L.SUM if op == L.MEAN else op, accumulate=k > 0, **kw)
         return out
+
+    # ------------------------------------------------------------------ feature-column-chunked halo
+    def aggregate_chunked(self, x_own, num_splits, op=L.SUM, w="plan", self_coef=None, bias=None, act=L.ACT_NONE):
+        """aggregate() with the feature columns cut into `num_splits` chunks (the reference's own remedy for graphs
+        whose [E, F] / [N, F] intermediates do not fit: `num_splits`, layers/conv/gcn.py:21-23 ->
+        utils/tf_sparse_utils.py:71-90 -> SparseMatrix.matmul's column splits, nn/conv/gcn.py:274-280 — "does not
+        affect the output").  Here it bounds the HALO: only (n_own + n_halo) x chunk_width floats of source table exist
+        at a time instead of (n_own + n_halo) x F — at papers100M shape the 49.7 GB halo of a shard becomes 49.7 /
+        num_splits GB.  Two chunk tables are alive so that chunk c+1's exchange overlaps chunk c's passes."""
+        be = self.backend
+        F = int(x_own.shape[1])
+        sizes = compute_num_or_size_splits(F, num_splits)
+        if sizes is None:
+            sizes = [F]
+        elif isinstance(sizes, int):
+            sizes = [F // sizes] * sizes
+        out = be.empty((self.n_own, F))
+        starts = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        self.last_chunk_table_floats = 0
+
+        def launch(c):
+            lo, hi = int(starts[c]), int(starts[c + 1])
+            table = self.alloc_table(hi - lo)
+            self.last_chunk_table_floats = max(self.last_chunk_table_floats, int(table.numel()))
+            self.own_rows(table).copy_(x_own[:, lo:hi])
+            return table, self.exchange_start(table)
+
+        nxt = launch(0)
+        for c in range(len(sizes)):
+            table, handles = nxt
+            nxt = launch(c + 1) if c + 1 < len(sizes) else None
+            lo, hi = int(starts[c]), int(starts[c + 1])
+            b = None if bias is None else bias[lo:hi].contiguous()
+            self.aggregate(table, op, w=w, self_coef=self_coef, bias=b, act=act, out=out[:, lo:hi], exchange=handles)
+        return out
+
+    # ------------------------------------------------------------------ training (backward of the sharded aggregation)
+    def _transposed_local(self):
+        """CSR of this shard's edges by SOURCE-TABLE index (own rows, then halo rows): row t lists the own destination
+        rows its table row feeds.  (row_ptr_t [n_table+1], dst_t [E], perm_t [E]: transposed position -> position in
+        self.col / self.w order).  Built once, on the first backward."""
+        if getattr(self, "_tl", None) is None:
+            be = self.backend
+            deg = self.in_degree.long()
+            rows = torch.repeat_interleave(torch.arange(self.n_own, device=deg.device), deg).to(torch.int32)
+            self._tl = be.build_csr(torch.stack([self.col, rows]), max(self.n_table, 1), max(self.n_own, 1))
+        return self._tl
+
+    def aggregate_backward(self, g_out, w="plan", self_coef=None, mean=False):
+        """d(loss)/d(own table rows) of out = aggregate(table, SUM | MEAN, w, self_coef) given g_out = d(loss)/d(out).
+
+        1. local transposed pass: dT[t] = sum over this shard's edges with source t of w * g[row] — for own rows AND for
+           halo rows (gradients that belong to peers);
+        2. REVERSE halo exchange: the halo-row gradients travel back along the forward exchange's lists (what I received
+           from p in round j, I send to p; what I sent, I receive), one all-to-all-v per round;
+        3. owner-side accumulate: returned rows are added into dT_own at the forward send indices, peer by peer in rank
+           order and round by round — a fixed order, and one peer's list has no repeated row, so the sum is deterministic
+           without atomics (tfgx_scatter_add_rows_f32);
+        4. the implicit self-loop term self_coef[r] * g[r]."""
+        be = self.backend
+        w_t = self.w if (isinstance(w, str) and w == "plan") else w
+        g = g_out.contiguous()
+        if mean:
+            g = g / self.in_degree.clamp(min=1).to(g.dtype).unsqueeze(1)
+        U = int(g.shape[1])
+        rp_t, dst_t, perm_t = self._transposed_local()
+        wt = None if w_t is None else be.permute_rows(w_t, perm_t)
+        d_table = be.empty((max(self.n_table, 1), U))
+        be.segment_reduce(rp_t, rp_t[1:], 1, dst_t, wt, self.n_table, g, d_table, L.SUM)
+        d_own = d_table[:self.n_own]
+        if self.world > 1:
+            d_halo = d_table[self.n_own:self.n_table]
+            nccl = dist.get_backend(self.group) == "nccl"
+            for j in range(self.rounds):
+                seg = d_halo[int(self.round_offset[j]):int(self.round_offset[j + 1])].contiguous()
+                n_back = int(sum(self.round_send_counts[j]))
+                back = be.empty((n_back, U))
+                # reverse direction: my forward RECEIVE counts are what I now send, and vice versa
+                out_splits, in_splits = list(self.round_send_counts[j]), list(self.round_recv_counts[j])
+                if nccl:
+                    dist.all_to_all_single(back, seg, out_splits, in_splits, group=self.group)
+                else:
+                    back_h = torch.empty((n_back, U), dtype=torch.float32)
+                    dist.all_to_all_single(back_h, seg.cpu(), out_splits, in_splits, group=self.group)
+                    back.copy_(back_h)
+                off = 0
+                for p in range(self.world):            # fixed peer order
+                    cnt = int(self.round_send_counts[j][p])
+                    if cnt:
+                        be.scatter_add_rows(d_own, self.round_send_idx[j][off:off + cnt], back[off:off + cnt])
+                    off += cnt
+        if self_coef is not None:
+            d_own = d_own + self_coef.unsqueeze(1) * g
+        return d_own
+
+    def aggregate_trainable(self, h_own, op=L.SUM, w="plan", self_coef=None):
+        """Differentiable sharded aggregation of own rows `h_own` [n_own, U] (torch autograd; forward = aggregate with the
+        overlapped halo exchange, backward = aggregate_backward with the reverse exchange)."""
+        if op not in (L.SUM, L.MEAN):
+            raise NotImplementedError("the sharded backward covers sum / mean aggregation")
+        return _ShardedAggregate.apply(self, op, w, self_coef, h_own)
+
+    def gcn_trainable(self, x_own, kernel, bias=None, activation=None):
+        """Sharded GCN layer whose output carries gradients to kernel / bias / x_own (nn/conv/gcn.py:225-290 under a
+        tf.GradientTape in the reference's training loops).  Weights are replicated: call all_reduce_gradients() after
+        backward() — the one collective the reference's distributed demos perform (demo_distributed_gcn.py:52-57)."""
+        if self.norm_w is None:
+            self.build_gcn_norm()
+        h = x_own if kernel is None else self.backend.linear(x_own, kernel)
+        out = self.aggregate_trainable(h, L.SUM, w=self.norm_w, self_coef=self.self_coef)
+        if bias is not None:
+            out = out + bias
+        return activation(out) if activation is not None else out
+
+    def all_reduce_gradients(self, params):
+        """Sum the gradients of replicated weights over the ranks, bucketed into ONE flat all-reduce (the weights of
+        this path are KB-sized; a collective per tensor would be latency-bound on xGMI)."""
+        grads = [p.grad for p in params if p.grad is not None]
+        if self.world == 1 or not grads:
+            return
+        flat = torch.cat([g_.reshape(-1) for g_ in grads])
+        if dist.get_backend(self.group) == "nccl":
+            dist.all_reduce(flat, group=self.group)
+        else:
+            host = flat.cpu()
+            dist.all_reduce(host, group=self.group)
+            flat = host.to(flat.device)
+        off = 0
+        for g_ in grads:
+            g_.copy_(flat[off:off + g_.numel()].reshape(g_.shape))
+            off += g_.numel()
 
     # ------------------------------------------------------------------ GCN
     def build_gcn_norm(self, norm="both", add_self_loop=True, renorm=True, improved=False):
@@ -593,3 +738,34 @@ class ShardedGraph(object):
         be.gemm_bias_act(x_own, neighbor_mlp_kernel, bias=neighbor_mlp_bias, act=act, out=self.own_rows(table))
         reduced = self.aggregate(table, op, w=None)
         return self._sage_combine(x_own, reduced, self_kernel, neighbor_kernel, bias, act, concat)
+
+
+def compute_num_or_size_splits(num_h_features, num_splits):
+    """Same contract as the reference's helper (utils/tf_sparse_utils.py:71-90): None for no split, an int when the
+    width divides evenly, else a list [ceil] * k + [remainder] that must have exactly num_splits entries."""
+    if num_splits is None or num_splits == 1:
+        return None
+    if num_h_features % num_splits == 0:
+        return int(num_splits)
+    split_size = int(np.ceil(num_h_features / num_splits))
+    num_pre = int(np.floor(num_h_features / split_size))
+    last = num_h_features % split_size
+    sizes = [split_size] * num_pre + ([last] if last > 0 else [])
+    if len(sizes) != num_splits:
+        raise Exception("cannot split H of shape [None, {}] into {} matrices, please provide a valid num_splits".format(
+            num_h_features, num_splits))
+    return sizes
+
+
+class _ShardedAggregate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, sg, op, w, self_coef, h_own):
+        table = sg.alloc_table(int(h_own.shape[1]))
+        sg.own_rows(table).copy_(h_own.detach())
+        ctx.sg, ctx.op, ctx.w, ctx.self_coef = sg, op, w, self_coef
+        return sg.aggregate(table, op, w=w, self_coef=self_coef)
+
+    @staticmethod
+    def backward(ctx, g):
+        d_own = ctx.sg.aggregate_backward(g, w=ctx.w, self_coef=ctx.self_coef, mean=ctx.op == L.MEAN)
+        return None, None, None, None, d_own
