@@ -1,8 +1,11 @@
 // TensorFlow custom-op shim over the tfgx C ABI (include/tfgx.h) — the `tf.load_op_library` route BASELINE.json's
-// north_star names.  NOT BUILT OR TESTED IN THIS REPO: TensorFlow (and tf_sparse) are absent from the image and
-// cannot be installed (no network), so this file is the reference-side binding a maintainer with a TensorFlow-ROCm
-// build would compile (build_tf_shim.sh) and load; the executable, tested boundary here is the ctypes/PyTorch host
-// in tf_geometric_amd/.  Each op forwards raw device pointers + sizes to one C-ABI call on TF's own HIP stream.
+// north_star names.  A SKETCH, NEVER LINKED OR RUN: TensorFlow (and tf_sparse) are absent from the image and cannot be
+// installed (no network).  What IS checked here: the file type-checks (`g++ -fsyntax-only`) against include/tfgx.h and
+// a mock of the four TensorFlow headers it uses (integration/tf_shim/mock/, tests/test_abi.py) — so every C-ABI call
+// below has the argument types the header declares.  A maintainer with a TensorFlow-ROCm build compiles it with
+// build_tf_shim.sh; the executable, tested boundary of this repo is the ctypes host in tf_geometric_amd/ and the
+// torch-free C++ programs in examples/.  Each op forwards raw device pointers + sizes to C-ABI calls on TF's own HIP
+// stream.  Gradients are registered on the Python side (integration/tf_shim/tfgx_tf.py) in terms of the same ops.
 //
 //   TfgxBuildCsrByDst   edge_index[2,E] -> row_ptr[N+1], col[E], perm[E]          (tfgx_build_csr_by_dst)
 //   TfgxSegmentReduce   plan + x[N,F] (+ w[E] in CSR order) -> out[N,F]           (tfgx_segment_reduce_f32)
@@ -10,9 +13,15 @@
 //                       (tf_geometric/nn/kernel/map_reduce.py:15-42,60-70)
 //   TfgxGatFused        plan + Q,K,V -> out                                       (tfgx_gat_fused_f32)
 //                       replaces tf_geometric/nn/conv/gat.py:56-89,112
+//   TfgxGcnNormEdges    plan + raw weights -> normalised weights (CSR order) + self_coef   (tfgx_segment_weight_sum_f32 +
+//                       tfgx_gcn_norm_edges_f32; gcn_norm_adj, nn/conv/gcn.py:32-130, sym=True)
+//   TfgxGemmBiasAct     act(x @ kernel + bias) on the fp32 matrix cores          (tfgx_gemm_bias_act_f32; gcn.py:272,284-288)
+// With these five a tfg.layers.GCN call ([x, edge_index, edge_weight], layers/conv/gcn.py:129-156) is:
+//   BuildCsrByDst (cached) -> GcnNormEdges (cached) -> GemmBiasAct(x, kernel) -> SegmentReduce(sum, w, self_coef, bias, act)
 #include "tensorflow/core/framework/op.h"
 #include "tensorflow/core/framework/op_kernel.h"
 #include "tensorflow/core/framework/shape_inference.h"
+#include <cmath>
 #include "tfgx.h"
 
 using namespace tensorflow;
@@ -57,14 +66,21 @@ REGISTER_OP("TfgxSegmentReduce")
     .Input("col: int32")
     .Input("w: float")          // [E] in CSR order, or [0] for the unweighted (identity_mapper) path
     .Input("x: float")
+    .Input("self_coef: float")  // [N] weight of the implicit (r, r) edge (GCN's added diagonal), or [0]
+    .Input("bias: float")       // [F] or [0]
     .Attr("op: int")            // 0 sum, 1 mean, 2 max
+    .Attr("act: int = 0")       // 0 none, 1 relu
     .Output("out: float");
 
 class TfgxSegmentReduceOp : public OpKernel {
  public:
-  explicit TfgxSegmentReduceOp(OpKernelConstruction* c) : OpKernel(c) { OP_REQUIRES_OK(c, c->GetAttr("op", &op_)); }
+  explicit TfgxSegmentReduceOp(OpKernelConstruction* c) : OpKernel(c) {
+    OP_REQUIRES_OK(c, c->GetAttr("op", &op_));
+    OP_REQUIRES_OK(c, c->GetAttr("act", &act_));
+  }
   void Compute(OpKernelContext* ctx) override {
     const Tensor &rp = ctx->input(0), &col = ctx->input(1), &w = ctx->input(2), &x = ctx->input(3);
+    const Tensor &sc = ctx->input(4), &bias = ctx->input(5);
     const int64_t n = rp.dim_size(0) - 1, F = x.dim_size(1);
     Tensor* out = nullptr;
     OP_REQUIRES_OK(ctx, ctx->allocate_output(0, {n, F}, &out));
@@ -81,9 +97,12 @@ class TfgxSegmentReduceOp : public OpKernel {
     a.out = out->flat<float>().data();
     a.ldo = F;
     a.op = op_;
+    a.act = act_;
+    a.self_coef = sc.NumElements() ? sc.flat<float>().data() : nullptr;
+    a.bias = bias.NumElements() ? bias.flat<float>().data() : nullptr;
     OP_REQUIRES(ctx, tfgx_segment_reduce_f32(&a, TfStream(ctx)) == 0, errors::Internal(tfgx_last_error()));
   }
-  int op_;
+  int op_, act_;
 };
 REGISTER_KERNEL_BUILDER(Name("TfgxSegmentReduce").Device(DEVICE_GPU), TfgxSegmentReduceOp);
 
@@ -120,3 +139,71 @@ class TfgxGatFusedOp : public OpKernel {
   int h_;
 };
 REGISTER_KERNEL_BUILDER(Name("TfgxGatFused").Device(DEVICE_GPU), TfgxGatFusedOp);
+
+REGISTER_OP("TfgxGcnNormEdges")
+    .Input("row_ptr: int32")
+    .Input("col: int32")
+    .Input("w: float")               // [E] raw weights in CSR order, or [0] = ones (Graph default, data/graph.py:53-56)
+    .Attr("norm: int = 0")           // 0 both, 1 left, 2 right (nn/conv/gcn.py:74,101,111)
+    .Attr("add_self_loop: bool = true")
+    .Attr("renorm: bool = true")
+    .Attr("improved: bool = false")
+    .Output("w_out: float")          // [E] normalised weights, CSR order
+    .Output("self_coef: float");     // [N] weight of the implicit diagonal entry
+
+class TfgxGcnNormEdgesOp : public OpKernel {
+ public:
+  explicit TfgxGcnNormEdgesOp(OpKernelConstruction* c) : OpKernel(c) {
+    OP_REQUIRES_OK(c, c->GetAttr("norm", &norm_));
+    OP_REQUIRES_OK(c, c->GetAttr("add_self_loop", &add_self_loop_));
+    OP_REQUIRES_OK(c, c->GetAttr("renorm", &renorm_));
+    OP_REQUIRES_OK(c, c->GetAttr("improved", &improved_));
+  }
+  void Compute(OpKernelContext* ctx) override {
+    const Tensor &rp = ctx->input(0), &col = ctx->input(1), &w = ctx->input(2);
+    const int64_t n = rp.dim_size(0) - 1, E = col.dim_size(0);
+    Tensor *w_out = nullptr, *self_coef = nullptr, deg;
+    OP_REQUIRES_OK(ctx, ctx->allocate_output(0, {E}, &w_out));
+    OP_REQUIRES_OK(ctx, ctx->allocate_output(1, {n}, &self_coef));
+    OP_REQUIRES_OK(ctx, ctx->allocate_temp(DT_FLOAT, {n}, &deg));
+    const float fill = improved_ ? 2.0f : 1.0f;                                  // gcn.py:62
+    const float diag = norm_ == 0 ? ((add_self_loop_ && renorm_) ? fill : 0.0f)  // :76-77
+                                  : (add_self_loop_ ? fill : 0.0f);              // :71-72
+    const float* wp = w.NumElements() ? w.flat<float>().data() : nullptr;
+    OP_REQUIRES(ctx, tfgx_segment_weight_sum_f32(rp.flat<int32>().data(), wp, n, diag, deg.flat<float>().data(),
+                                                 TfStream(ctx)) == 0, errors::Internal(tfgx_last_error()));
+    OP_REQUIRES(ctx, tfgx_gcn_norm_edges_f32(rp.flat<int32>().data(), col.flat<int32>().data(), wp, n,
+                                             deg.flat<float>().data(), nullptr /* sym=True */, norm_, fill,
+                                             add_self_loop_ ? 1 : 0, renorm_ ? 1 : 0, w_out->flat<float>().data(),
+                                             self_coef->flat<float>().data(), TfStream(ctx)) == 0,
+                errors::Internal(tfgx_last_error()));
+  }
+  int norm_;
+  bool add_self_loop_, renorm_, improved_;
+};
+REGISTER_KERNEL_BUILDER(Name("TfgxGcnNormEdges").Device(DEVICE_GPU), TfgxGcnNormEdgesOp);
+
+REGISTER_OP("TfgxGemmBiasAct")
+    .Input("x: float")               // [M, K]
+    .Input("kernel: float")          // [K, N]
+    .Input("bias: float")            // [N] or [0]
+    .Attr("act: int = 0")
+    .Output("out: float");
+
+class TfgxGemmBiasActOp : public OpKernel {
+ public:
+  explicit TfgxGemmBiasActOp(OpKernelConstruction* c) : OpKernel(c) { OP_REQUIRES_OK(c, c->GetAttr("act", &act_)); }
+  void Compute(OpKernelContext* ctx) override {
+    const Tensor &x = ctx->input(0), &k = ctx->input(1), &b = ctx->input(2);
+    const int64_t M = x.dim_size(0), K = x.dim_size(1), N = k.dim_size(1);
+    OP_REQUIRES(ctx, k.dim_size(0) == K, errors::InvalidArgument("x and kernel do not agree on K"));
+    Tensor* out = nullptr;
+    OP_REQUIRES_OK(ctx, ctx->allocate_output(0, {M, N}, &out));
+    OP_REQUIRES(ctx, tfgx_gemm_bias_act_f32(x.flat<float>().data(), K, k.flat<float>().data(), N,
+                                            b.NumElements() ? b.flat<float>().data() : nullptr, act_,
+                                            out->flat<float>().data(), N, M, K, N, TfStream(ctx)) == 0,
+                errors::Internal(tfgx_last_error()));
+  }
+  int act_;
+};
+REGISTER_KERNEL_BUILDER(Name("TfgxGemmBiasAct").Device(DEVICE_GPU), TfgxGemmBiasActOp);

@@ -169,3 +169,17 @@ def test_dist_library_exports_every_declared_symbol():
     assert b"bad world" in lib.tfgx_dist_last_error()
     assert lib.tfgx_halo_plan_create(2, 0, 2, cnt, cnt, None, ctypes.byref(plan)) == 1      # rows to send, no index list
     assert lib.tfgx_halo_exchange_finish(None, 0, None) == 1
+
+
+def test_tf_shim_compiles_against_mock_headers():
+    """integration/tf_shim/tfgx_tf_ops.cc (the tf.load_op_library binding of INTEGRATION.md) type-checks against
+    include/tfgx.h and a mock of the TensorFlow headers it uses: every C-ABI call in it has the declared argument
+    types.  TensorFlow itself is not installable here — the shim is a sketch that has never been linked or run."""
+    shim = os.path.join(ROOT, "integration", "tf_shim")
+    res = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-I", os.path.join(shim, "mock"),
+                          "-I", os.path.join(ROOT, "include"), os.path.join(shim, "tfgx_tf_ops.cc")],
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert res.returncode == 0, res.stdout.decode()
+    src = open(os.path.join(shim, "tfgx_tf_ops.cc")).read()
+    for op in ("TfgxBuildCsrByDst", "TfgxSegmentReduce", "TfgxGatFused", "TfgxGcnNormEdges", "TfgxGemmBiasAct"):
+        assert 'REGISTER_OP("{}")'.format(op) in src and 'Name("{}")'.format(op) in src
