@@ -335,6 +335,7 @@ using namespace tfgx;
 extern "C" int tfgx_edge_softmax_f32(const int32_t* row_ptr, const int32_t* perm, const float* score, int64_t H,
                                      int64_t n_dst, float* out, tfgx_stream_t stream)
 {
+    TFGX_RANGE();
     TFGX_REQUIRE(H >= 1 && n_dst >= 0, "bad H / n_dst");
     if (n_dst == 0) return TFGX_OK;
     TFGX_REQUIRE(row_ptr != nullptr, "row_ptr is null");
@@ -346,6 +347,7 @@ extern "C" int tfgx_edge_softmax_f32(const int32_t* row_ptr, const int32_t* perm
 
 extern "C" int tfgx_gat_fused_f32(const tfgx_gat_args* p, tfgx_stream_t stream_)
 {
+    TFGX_RANGE();
     TFGX_REQUIRE(p != nullptr, "args is null");
     TFGX_REQUIRE(p->H >= 1 && p->d >= 1 && p->dv >= 1 && p->n_dst >= 0, "bad H / d / dv / n_dst");
     TFGX_REQUIRE(p->scale > 0.0f, "scale must be positive");
@@ -417,6 +419,7 @@ extern "C" int tfgx_gat_fused_f32(const tfgx_gat_args* p, tfgx_stream_t stream_)
 extern "C" int tfgx_gat_merge_passes_f32(const tfgx_gat_args* p, const float* state_acc, const float* state_ml,
                                          int32_t n_passes, tfgx_stream_t stream)
 {
+    TFGX_RANGE();
     TFGX_REQUIRE(p != nullptr && state_acc && state_ml && n_passes >= 1, "bad argument");
     TFGX_REQUIRE(p->H >= 1 && p->d >= 1 && p->dv >= 1 && p->n_dst >= 0 && p->scale > 0.0f, "bad H / d / dv / n_dst");
     TFGX_REQUIRE(p->drop_rate == 0.0f, "attention dropout is not available on merged passes");
@@ -443,6 +446,7 @@ extern "C" int32_t tfgx_dropout_keep(uint64_t seed, uint32_t item, float rate)
 extern "C" int tfgx_head_mean_f32(const float* in, int64_t ld_in, int64_t n, int32_t H, int32_t U,
                                   const float* bias, int32_t act, float* out, int64_t ldo, tfgx_stream_t stream)
 {
+    TFGX_RANGE();
     TFGX_REQUIRE(n >= 0 && H >= 1 && U >= 1, "bad size");
     if (n == 0) return TFGX_OK;
     TFGX_REQUIRE(in && out && ld_in >= int64_t(H) * U && ldo >= U, "bad pointer / leading dimension");

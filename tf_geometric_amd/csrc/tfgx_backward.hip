@@ -568,6 +568,7 @@ static int sddmm_dispatch(const char* who, const int32_t* row_ptr, const int32_t
 extern "C" int tfgx_sddmm_f32(const int32_t* row_ptr, const int32_t* col, int64_t n_dst, const float* a, int64_t lda,
                               const float* b, int64_t ldb, int64_t F, float* out, tfgx_stream_t stream)
 {
+    TFGX_RANGE();
     TFGX_REQUIRE(n_dst >= 0 && F >= 1 && lda >= F && ldb >= F, "bad size");
     if (n_dst == 0) return TFGX_OK;
     TFGX_REQUIRE(row_ptr && a && b, "null pointer");
@@ -579,6 +580,7 @@ extern "C" int tfgx_segment_max_backward_w_f32(const int32_t* row_ptr, const int
                                                const float* x, int64_t ldx, int64_t F, const float* out, int64_t ldo,
                                                const float* gn, int64_t ldgn, float* grad_w, tfgx_stream_t stream)
 {
+    TFGX_RANGE();
     TFGX_REQUIRE(n_dst >= 0 && F >= 1 && ldx >= F && ldo >= F && ldgn >= F, "bad size");
     if (n_dst == 0) return TFGX_OK;
     TFGX_REQUIRE(row_ptr && col && w && x && out && gn && grad_w, "null pointer");
@@ -590,6 +592,7 @@ extern "C" int tfgx_segment_max_count_f32(const int32_t* row_ptr, const int32_t*
                                           const float* x, int64_t ldx, int64_t F, const float* out, int64_t ldo,
                                           float* count, int64_t ldc, tfgx_stream_t stream)
 {
+    TFGX_RANGE();
     TFGX_REQUIRE(n_dst >= 0 && F >= 1 && ldx >= F && ldo >= F && ldc >= F, "bad size");
     if (n_dst == 0) return TFGX_OK;
     TFGX_REQUIRE(row_ptr && x && out && count, "null pointer");
@@ -607,6 +610,7 @@ extern "C" int tfgx_segment_max_with_count_f32(const int32_t* row_ptr, const int
                                               int64_t n_dst, const float* x, int64_t ldx, int64_t F, float* out,
                                               int64_t ldo, float* count, int64_t ldc, tfgx_stream_t stream)
 {
+    TFGX_RANGE();
     TFGX_REQUIRE(n_dst >= 0 && F >= 1 && ldx >= F && ldo >= F && ldc >= F, "bad size");
     if (n_dst == 0) return TFGX_OK;
     TFGX_REQUIRE(row_ptr && x && out && count, "null pointer");
@@ -630,6 +634,7 @@ extern "C" int tfgx_segment_max_backward_f32(const int32_t* row_ptr_t, const int
                                              float* gx, int64_t ldgx, int64_t n_dst, float* gn_scratch,
                                              tfgx_stream_t stream)
 {
+    TFGX_RANGE();
     TFGX_REQUIRE(n_src >= 0 && F >= 1 && ldx >= F && ldo >= F && ldg >= F && ldc >= F && ldgx >= F, "bad size");
     if (n_src == 0) return TFGX_OK;
     TFGX_REQUIRE(row_ptr_t && x && out && g && count && gx, "null pointer");
@@ -669,6 +674,7 @@ static int fill_gb(const tfgx_gat_backward_args* p, GB& a)
 
 extern "C" int tfgx_gat_backward_dst_f32(const tfgx_gat_backward_args* p, tfgx_stream_t stream)
 {
+    TFGX_RANGE();
     GB a;
     int rc = fill_gb(p, a);
     if (rc) return rc;
@@ -683,6 +689,7 @@ extern "C" int tfgx_gat_backward_dst_f32(const tfgx_gat_backward_args* p, tfgx_s
 
 extern "C" int tfgx_gat_backward_src_f32(const tfgx_gat_backward_args* p, tfgx_stream_t stream)
 {
+    TFGX_RANGE();
     GB a;
     int rc = fill_gb(p, a);
     if (rc) return rc;

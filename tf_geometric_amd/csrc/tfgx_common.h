@@ -38,6 +38,20 @@ inline int hip_fail(hipError_t e, const char* what)
 
 inline hipStream_t as_stream(tfgx_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// roctx ranges around every C-ABI entry point (the tracing hook): with TFGX_ROCTX=1 in the environment
+// each call shows up as a named range in rocprofv3 --marker-trace next to the kernels it launched.  libroctx64.so is
+// opened lazily with dlopen, so the library has no link-time dependency on it and costs one predictable branch per
+// call when tracing is off.
+void roctx_push(const char* name);
+void roctx_pop();
+struct RoctxRange {
+    explicit RoctxRange(const char* name) { roctx_push(name); }
+    ~RoctxRange() { roctx_pop(); }
+    RoctxRange(const RoctxRange&) = delete;
+    RoctxRange& operator=(const RoctxRange&) = delete;
+};
+#define TFGX_RANGE() ::tfgx::RoctxRange tfgx_roctx_range_(__func__)
+
 constexpr int kWave = 64;
 constexpr int kBlock = 256;
 // memory-bound grids: enough workgroups to fill 256 CUs x 8 XCDs several times over

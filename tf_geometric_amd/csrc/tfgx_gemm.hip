@@ -694,6 +694,7 @@ extern "C" int tfgx_gemm_bias_act_cols_f32(const float* A, int64_t lda, const fl
                                            const float* bias, int32_t act, int64_t act_cols, float* C, int64_t ldc,
                                            int64_t M, int64_t K, int64_t N, tfgx_stream_t stream_)
 {
+    TFGX_RANGE();
     return tfgx_gemm_bias_act_cols_ws_f32(A, lda, B, ldb, bias, act, act_cols, C, ldc, M, K, N, nullptr, 0, stream_);
 }
 
@@ -702,6 +703,7 @@ extern "C" int tfgx_gemm_bias_act_cols_ws_f32(const float* A, int64_t lda, const
                                               int64_t M, int64_t K, int64_t N, void* workspace, size_t workspace_bytes,
                                               tfgx_stream_t stream_)
 {
+    TFGX_RANGE();
     TFGX_REQUIRE(M >= 0 && K >= 1 && N >= 1, "bad M / K / N");
     TFGX_REQUIRE(K < (int64_t(1) << 30) && N < (int64_t(1) << 30), "K / N too large");
     TFGX_REQUIRE(act == TFGX_ACT_NONE || act == TFGX_ACT_RELU, "bad act");
@@ -752,6 +754,7 @@ extern "C" int tfgx_gemm_bias_act_f32(const float* A, int64_t lda, const float* 
                                       int32_t act, float* C, int64_t ldc, int64_t M, int64_t K, int64_t N,
                                       tfgx_stream_t stream)
 {
+    TFGX_RANGE();
     return tfgx_gemm_bias_act_cols_f32(A, lda, B, ldb, bias, act, N, C, ldc, M, K, N, stream);
 }
 
@@ -766,6 +769,7 @@ extern "C" int tfgx_gemm_tn_f32(const float* X, int64_t ldx, const float* G, int
                                 int64_t N, float* dW, int64_t ldw, float* db, void* workspace, size_t workspace_bytes,
                                 tfgx_stream_t stream_)
 {
+    TFGX_RANGE();
     TFGX_REQUIRE(M >= 0 && Ka >= 1 && N >= 1, "bad M / Ka / N");
     TFGX_REQUIRE(Ka <= 2016 && N < (int64_t(1) << 30), "Ka > 2016 is not supported");
     TFGX_REQUIRE(dW != nullptr && ldw >= N, "bad dW");
@@ -841,6 +845,7 @@ __global__ void transpose_kernel(const float* __restrict__ in, int64_t ldi, int6
 extern "C" int tfgx_transpose_f32(const float* in, int64_t ldi, int64_t rows, int64_t cols, float* out, int64_t ldo,
                                   tfgx_stream_t stream)
 {
+    TFGX_RANGE();
     TFGX_REQUIRE(rows >= 0 && cols >= 0 && ldi >= cols && ldo >= rows, "bad shape");
     if (rows == 0 || cols == 0) return TFGX_OK;
     TFGX_REQUIRE(in && out, "null pointer");

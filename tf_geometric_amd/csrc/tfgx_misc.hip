@@ -242,6 +242,7 @@ using namespace tfgx;
 
 extern "C" int tfgx_l2_normalize_rows_f32(float* h, int64_t ld, int64_t n, int64_t F, tfgx_stream_t stream)
 {
+    TFGX_RANGE();
     TFGX_REQUIRE(n >= 0 && F >= 1 && ld >= F, "bad size");
     if (n == 0) return TFGX_OK;
     TFGX_REQUIRE(h != nullptr, "null pointer");
@@ -253,6 +254,7 @@ extern "C" int tfgx_l2_normalize_rows_f32(float* h, int64_t ld, int64_t n, int64
 extern "C" int tfgx_gather_rows_f32(const float* x, int64_t ldx, const int32_t* idx, int64_t M, int64_t F,
                                     float* out, int64_t ldo, tfgx_stream_t stream)
 {
+    TFGX_RANGE();
     TFGX_REQUIRE(M >= 0 && F >= 1 && ldx >= F && ldo >= F, "bad size");
     if (M == 0) return TFGX_OK;
     TFGX_REQUIRE(x && idx && out, "null pointer");
@@ -270,6 +272,7 @@ extern "C" int tfgx_gather_rows_f32(const float* x, int64_t ldx, const int32_t* 
 extern "C" int tfgx_scatter_add_rows_f32(float* dst, int64_t ldd, const int32_t* idx, int64_t M, int64_t F,
                                         const float* src, int64_t lds, tfgx_stream_t stream)
 {
+    TFGX_RANGE();
     TFGX_REQUIRE(M >= 0 && F >= 1 && ldd >= F && lds >= F, "bad shape");
     if (M == 0) return TFGX_OK;
     TFGX_REQUIRE(dst && idx && src, "null pointer");
@@ -296,6 +299,7 @@ extern "C" size_t tfgx_halo_workspace_bytes(int64_t n_global)
 extern "C" int tfgx_halo_mark(const int32_t* col, int64_t E, int32_t own_lo, int32_t own_hi, int64_t n_global,
                               int32_t* flags, tfgx_stream_t stream_)
 {
+    TFGX_RANGE();
     hipStream_t stream = as_stream(stream_);
     TFGX_REQUIRE(E >= 0 && n_global >= 0 && flags, "bad argument");
     TFGX_HIP_CHECK(hipMemsetAsync(flags, 0, sizeof(int32_t) * size_t(n_global), stream));
@@ -308,6 +312,7 @@ extern "C" int tfgx_halo_mark(const int32_t* col, int64_t E, int32_t own_lo, int
 extern "C" int tfgx_halo_compact(const int32_t* flags, int64_t n_global, int32_t* pos, int32_t* halo_ids,
                                  int32_t* n_halo, void* workspace, size_t workspace_bytes, tfgx_stream_t stream_)
 {
+    TFGX_RANGE();
     hipStream_t stream = as_stream(stream_);
     TFGX_REQUIRE(n_global >= 0 && n_halo, "bad argument");
     if (n_global == 0) {
@@ -329,6 +334,7 @@ extern "C" int tfgx_halo_compact(const int32_t* flags, int64_t n_global, int32_t
 extern "C" int tfgx_halo_remap_cols(const int32_t* col, int64_t E, int32_t own_lo, int32_t own_hi,
                                     const int32_t* pos, int32_t n_own, int32_t* col_local, tfgx_stream_t stream)
 {
+    TFGX_RANGE();
     TFGX_REQUIRE(E >= 0, "bad argument");
     if (E == 0) return TFGX_OK;
     TFGX_REQUIRE(col && pos && col_local, "null pointer");
@@ -341,6 +347,7 @@ extern "C" int tfgx_halo_remap_cols(const int32_t* col, int64_t E, int32_t own_l
 extern "C" int tfgx_split_rows_f32(const float* x, int64_t ldx, int64_t n, int64_t F, int64_t f_main, float* x_main,
                                    int64_t ld_main, float* x_tail, int64_t ld_tail, tfgx_stream_t stream)
 {
+    TFGX_RANGE();
     TFGX_REQUIRE(n >= 0 && F >= 8 && F % 4 == 0 && f_main > 0 && f_main < F && f_main % 4 == 0, "bad F / f_main");
     if (n == 0) return TFGX_OK;
     TFGX_REQUIRE(x && x_main && x_tail, "null pointer");
@@ -357,6 +364,7 @@ extern "C" int tfgx_sample_neighbors(const int32_t* row_ptr, const int32_t* col,
                                      const int32_t* out_ptr, int32_t max_per_row, int32_t replace_when_short,
                                      uint64_t seed, int32_t* out_col, float* out_w, tfgx_stream_t stream)
 {
+    TFGX_RANGE();
     TFGX_REQUIRE(n_dst >= 0 && max_per_row >= 0, "bad size");
     // max_per_row is informative only: rows with more than kMaxSampleK draws take the scratch-free selection-sampling
     // branch, keep-all rows need no scratch at all
@@ -372,6 +380,7 @@ extern "C" int tfgx_split_by_source_class(const int32_t* row_ptr, const int32_t*
                                           int64_t n_dst, int64_t E, const int32_t* class_bounds, int32_t n_class,
                                           int32_t* row_ptr_k, int32_t* col_out, float* w_out, tfgx_stream_t stream_)
 {
+    TFGX_RANGE();
     hipStream_t stream = as_stream(stream_);
     TFGX_REQUIRE(n_dst >= 0 && E >= 0 && row_ptr_k && n_class >= 1 && n_class <= kMaxClasses, "bad argument");
     if (n_dst == 0) {

@@ -87,6 +87,7 @@ using namespace tfgx;
 extern "C" int tfgx_segment_weight_sum_f32(const int32_t* row_ptr, const float* w, int64_t n, float diag,
                                            float* deg, tfgx_stream_t stream)
 {
+    TFGX_RANGE();
     TFGX_REQUIRE(n >= 0, "negative n");
     if (n == 0) return TFGX_OK;
     TFGX_REQUIRE(row_ptr && deg, "null pointer");
@@ -100,6 +101,7 @@ extern "C" int tfgx_gcn_norm_edges_f32(const int32_t* row_ptr, const int32_t* co
                                        int32_t add_self_loop, int32_t renorm, float* w_out, float* self_coef,
                                        tfgx_stream_t stream)
 {
+    TFGX_RANGE();
     TFGX_REQUIRE(n >= 0, "negative n");
     TFGX_REQUIRE(norm_mode >= TFGX_NORM_BOTH && norm_mode <= TFGX_NORM_RIGHT, "bad norm mode");
     if (n == 0) return TFGX_OK;

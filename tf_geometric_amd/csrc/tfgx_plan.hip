@@ -6,8 +6,46 @@
 // then row_ptr from the sorted keys' boundaries (no atomics, no scan).
 #include "tfgx_common.h"
 #include <hipcub/hipcub.hpp>
+#include <dlfcn.h>
+#include <cstdlib>
 
 namespace tfgx {
+
+namespace {
+typedef int (*roctx_push_fn)(const char*);
+typedef int (*roctx_pop_fn)();
+struct RoctxApi {
+    roctx_push_fn push = nullptr;
+    roctx_pop_fn pop = nullptr;
+    RoctxApi()
+    {
+        const char* on = getenv("TFGX_ROCTX");
+        if (on == nullptr || on[0] == '\0' || on[0] == '0') return;
+        void* h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (h == nullptr) h = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
+        if (h == nullptr) return;
+        push = reinterpret_cast<roctx_push_fn>(dlsym(h, "roctxRangePushA"));
+        pop = reinterpret_cast<roctx_pop_fn>(dlsym(h, "roctxRangePop"));
+        if (push == nullptr || pop == nullptr) push = nullptr, pop = nullptr;
+    }
+};
+const RoctxApi& roctx_api()
+{
+    static const RoctxApi api;
+    return api;
+}
+}  // namespace
+
+void roctx_push(const char* name)
+{
+    const RoctxApi& a = roctx_api();
+    if (a.push) a.push(name);
+}
+void roctx_pop()
+{
+    const RoctxApi& a = roctx_api();
+    if (a.pop) a.pop();
+}
 
 static thread_local char g_err[512] = "";
 
@@ -157,6 +195,7 @@ extern "C" int tfgx_build_csr_by_dst(const int32_t* row, const int32_t* col, int
                                      int64_t n_src, int32_t* row_ptr, int32_t* col_sorted, int32_t* perm,
                                      void* workspace, size_t workspace_bytes, tfgx_stream_t stream_)
 {
+    TFGX_RANGE();
     hipStream_t stream = as_stream(stream_);
     TFGX_REQUIRE(E >= 0 && n_dst >= 0 && n_src >= 0, "negative size");
     TFGX_REQUIRE(E < (int64_t(1) << 31) - 1 && n_dst < (int64_t(1) << 31) - 1 && n_src < (int64_t(1) << 31) - 1,
@@ -203,6 +242,7 @@ extern "C" int tfgx_build_csr_by_dst(const int32_t* row, const int32_t* col, int
 extern "C" int tfgx_permute_rows_f32(const float* src, const int32_t* perm, int64_t E, int64_t width, float* dst,
                                      tfgx_stream_t stream)
 {
+    TFGX_RANGE();
     TFGX_REQUIRE(E >= 0 && width >= 1, "bad size");
     if (E == 0) return TFGX_OK;
     TFGX_REQUIRE(src && perm && dst, "null pointer");
@@ -237,6 +277,7 @@ extern "C" int tfgx_merge_duplicated_edges(const int32_t* row, const int32_t* co
                                            int32_t* n_unique, void* workspace, size_t workspace_bytes,
                                            tfgx_stream_t stream_)
 {
+    TFGX_RANGE();
     hipStream_t stream = as_stream(stream_);
     TFGX_REQUIRE(E >= 0 && n >= 1 && n < (int64_t(1) << 31) && n_unique, "bad argument");
     if (E == 0) {

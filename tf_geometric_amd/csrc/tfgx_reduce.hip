@@ -405,6 +405,7 @@ extern "C" int tfgx_segment_reduce_describe(const tfgx_reduce_args* p, char* buf
 
 extern "C" int tfgx_segment_reduce_f32(const tfgx_reduce_args* p, tfgx_stream_t stream_)
 {
+    TFGX_RANGE();
     TFGX_REQUIRE(p != nullptr, "args is null");
     TFGX_REQUIRE(p->n_dst >= 0 && p->F >= 1 && p->F < (int64_t(1) << 30), "bad n_dst / F");
     TFGX_REQUIRE(p->op == TFGX_SUM || p->op == TFGX_MEAN || p->op == TFGX_MAX, "bad op");

@@ -136,6 +136,7 @@ extern "C" int tfgx_segment_topk(const int32_t* segment, const float* score, int
                                  int32_t k, float ratio, int32_t* out_index, int32_t* out_count, void* workspace,
                                  size_t workspace_bytes, tfgx_stream_t stream_)
 {
+    TFGX_RANGE();
     hipStream_t stream = as_stream(stream_);
     TFGX_REQUIRE(n >= 0 && num_segments >= 0, "negative size");
     TFGX_REQUIRE(n < (int64_t(1) << 31) - 1 && num_segments < (int64_t(1) << 31) - 1, "sizes must fit int32");
