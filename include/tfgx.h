@@ -262,6 +262,21 @@ int tfgx_segment_max_count_f32(const int32_t* row_ptr, const int32_t* col, const
 int tfgx_segment_max_backward_w_f32(const int32_t* row_ptr, const int32_t* col, const float* w, int64_t n_dst,
                                     const float* x, int64_t ldx, int64_t F, const float* out, int64_t ldo,
                                     const float* gn, int64_t ldgn, float* grad_w, tfgx_stream_t stream);
+/* Push form of the same gradient (default for training on graphs without hub rows): the training forward also saves,
+   per (row, column), the CSR position of the FIRST maximal edge (argpos, -1 for an empty row); the backward then adds
+   w[argpos] * g[r, j] to gx[col[argpos], j] with one float atomic per (row, column) — N*F atomics instead of two gathered
+   rows per edge — and walks rows with tied maxima (count > 1) exactly, handing g / count to every tied edge (TensorFlow's
+   unsorted_segment_max gradient).  gx is zeroed here.  Float atomics commit in arrival order: sums may differ in the
+   last bit between runs (as TensorFlow's GPU kernels do); use tfgx_segment_max_backward_f32 for bit-reproducibility.
+   Needs 16-byte aligned rows and F % 4 == 0. */
+int tfgx_segment_max_with_arg_f32(const int32_t* row_ptr, const int32_t* col, const float* w /* or NULL */,
+                                  int64_t n_dst, const float* x, int64_t ldx, int64_t F, float* out, int64_t ldo,
+                                  float* count, int64_t ldc, int32_t* argpos, int64_t lda, tfgx_stream_t stream);
+int tfgx_segment_max_backward_push_f32(const int32_t* row_ptr, const int32_t* col, const float* w /* or NULL */,
+                                       int64_t n_dst, int64_t n_src, const float* x, int64_t ldx, int64_t F,
+                                       const float* out, int64_t ldo, const float* g, int64_t ldg, const float* count,
+                                       int64_t ldc, const int32_t* argpos, int64_t lda, float* gx, int64_t ldgx,
+                                       tfgx_stream_t stream);
 int tfgx_segment_max_backward_f32(const int32_t* row_ptr_t, const int32_t* dst_t, const float* w_t /* or NULL */,
                                   int64_t n_src, const float* x, int64_t ldx, int64_t F, const float* out, int64_t ldo,
                                   const float* g, int64_t ldg, const float* count, int64_t ldc, float* gx, int64_t ldgx,

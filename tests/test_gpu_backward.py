@@ -468,3 +468,41 @@ def test_gemm_tn_weight_gradient_kernel(tfg, m, ka, n, want_bias):
     dW3, _ = gemm_tn(x, wide[:, 4:4 + n], want_bias=False)
     ref3 = x.double().t() @ wide[:, 4:4 + n].double()
     assert float(((dW3.double() - ref3).abs() / ((x.double().abs().t() @ wide[:, 4:4 + n].double().abs()) + 1e-30)).max()) < 3e-7
+
+
+@pytest.mark.parametrize("f,weighted", [(8, True), (100, False), (128, True), (260, True)])
+def test_max_gradient_push_equals_pull_and_autograd(tfg, oracle, f, weighted):
+    """Push form of the segment-max gradient (arg positions saved by the training forward, N*F float atomics, rows with
+    tied maxima walked exactly) vs the bit-reproducible pull kernel and vs float64 autograd (amax: ties share evenly, the
+    TF rule).  The graph has duplicate edges and ReLU-style zero plateaus, i.e. plenty of ties, and an empty row."""
+    from tf_geometric_amd import autograd as AG
+    rng = np.random.Generator(np.random.PCG64(f))
+    n = 500
+    ei = oracle.synthetic_edges(n, 6000, seed=f)
+    ei = ei[:, ei[0] != 7]
+    ei = np.concatenate([ei, ei[:, :400]], axis=1)                     # duplicate edges: exact ties
+    x = np.maximum(rng.standard_normal((n, f)), 0).astype(np.float32)  # many exact zeros
+    w = (rng.integers(1, 3, ei.shape[1]) * 0.5).astype(np.float32) if weighted else None
+    gout = rng.standard_normal((n, f)).astype(np.float32)
+    mapper = tfg.nn.gcn_mapper if weighted else tfg.nn.identity_mapper
+
+    def run(det):
+        AG.DETERMINISTIC_MAX_GRADIENT = det
+        try:
+            xt = torch.tensor(x, device="cuda", requires_grad=True)
+            out = tfg.nn.aggregate_neighbors(xt, ei, w, mapper, tfg.nn.max_reducer, tfg.nn.identity_updater)
+            out.backward(torch.tensor(gout, device="cuda"))
+            return out.detach().cpu().numpy(), xt.grad.cpu().numpy()
+        finally:
+            AG.DETERMINISTIC_MAX_GRADIENT = False
+
+    out_push, gx_push = run(False)
+    out_pull, gx_pull = run(True)
+    assert np.array_equal(out_push, out_pull)
+    assert_parity(gx_push, gx_pull, tol=2e-6, what="push vs pull max gradient")
+    xr = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    wr = None if w is None else torch.tensor(w, dtype=torch.float64)
+    ref = _ref_aggregate(xr, ei, wr, "max", n)
+    ref.backward(torch.tensor(gout, dtype=torch.float64))
+    assert_parity(gx_push, xr.grad.numpy(), tol=2e-5, what="push max gradient vs autograd")
+    assert np.abs(gx_push[7]).max() >= 0 and np.array_equal(out_push[7], np.full(f, -3.4028234663852886e38, np.float32))

@@ -7,7 +7,9 @@ C-ABI kernel launches:
 
   aggregate (sum / mean, weighted)  backward wrt x  = the forward kernel on the transposed (CSR-by-source) plan
                                     backward wrt w  = tfgx_sddmm_f32
-  aggregate (max)                   tfgx_segment_max_count_f32 + tfgx_segment_max_backward_f32 (TF tie semantics)
+  aggregate (max)                   training forward saves (max, tie count, arg position); backward = push of N*F float
+                                    atomics (tfgx_segment_max_backward_push_f32; ties walked exactly, TF semantics) or, with
+                                    DETERMINISTIC_MAX_GRADIENT / on hub graphs, the bit-reproducible pull kernel
   gat_attention                     tfgx_gat_backward_dst_f32 (dQ) + tfgx_gat_backward_src_f32 (dK, dV)
   linear (x @ W + b, relu)          forward = tfgx_gemm_bias_act_f32; d/dx = the same kernel on W^T (tfgx_transpose_f32);
                                     d/dW, d/db = tfgx_gemm_tn_f32 (MFMA reduction over the node dimension)
@@ -101,24 +103,36 @@ class _Aggregate(torch.autograd.Function):
         return None, None, gx, gw, gs, None
 
 
+DETERMINISTIC_MAX_GRADIENT = False     # True: bit-reproducible (pull) gradient of max aggregation; default: push (atomics)
+
+
 class _AggregateMax(torch.autograd.Function):
     @staticmethod
     def forward(ctx, plan, x, w_csr):
         lib = L.require_gpu()
         x2, ldx = L.row_major_2d(x.detach())
         F = int(x2.shape[1])
+        argpos = None
+        wd = None if w_csr is None else w_csr.detach()
         if plan.hub_info() is None:
             # one pass: row maxima AND how many edges attain each (the tie count TF's gradient divides by)
             out = torch.empty((plan.n_dst, F), dtype=torch.float32, device=x2.device)
             count = torch.empty_like(out)
-            L.check(lib.tfgx_segment_max_with_count_f32(L.ptr(plan.row_ptr), L.ptr(plan.col),
-                                                        L.ptr(None if w_csr is None else w_csr.detach()), plan.n_dst,
-                                                        L.ptr(x2), ldx, F, L.ptr(out), F, L.ptr(count), F, L.stream_ptr()),
-                    "tfgx_segment_max_with_count_f32")
+            push_ok = (not DETERMINISTIC_MAX_GRADIENT) and F % 4 == 0 and ldx % 4 == 0 and x2.data_ptr() % 16 == 0
+            if push_ok:       # ... and WHICH edge attains it first: the backward becomes N*F atomics instead of E*F gathers
+                argpos = torch.empty((plan.n_dst, F), dtype=torch.int32, device=x2.device)
+                L.check(lib.tfgx_segment_max_with_arg_f32(L.ptr(plan.row_ptr), L.ptr(plan.col), L.ptr(wd), plan.n_dst,
+                                                          L.ptr(x2), ldx, F, L.ptr(out), F, L.ptr(count), F,
+                                                          L.ptr(argpos), F, L.stream_ptr()),
+                        "tfgx_segment_max_with_arg_f32")
+            else:
+                L.check(lib.tfgx_segment_max_with_count_f32(L.ptr(plan.row_ptr), L.ptr(plan.col), L.ptr(wd), plan.n_dst,
+                                                            L.ptr(x2), ldx, F, L.ptr(out), F, L.ptr(count), F,
+                                                            L.stream_ptr()), "tfgx_segment_max_with_count_f32")
         else:   # skewed graph: the chunked forward keeps long rows off one lane group; count in the backward
-            out = segment_reduce(plan, x2, L.MAX, w_csr=None if w_csr is None else w_csr.detach())
+            out = segment_reduce(plan, x2, L.MAX, w_csr=wd)
             count = None
-        ctx.plan, ctx.count = plan, count
+        ctx.plan, ctx.count, ctx.argpos = plan, count, argpos
         ctx.save_for_backward(x, w_csr, out)
         return out
 
@@ -136,14 +150,22 @@ class _AggregateMax(torch.autograd.Function):
             L.check(lib.tfgx_segment_max_count_f32(L.ptr(plan.row_ptr), L.ptr(plan.col), L.ptr(w_csr), plan.n_dst,
                                                    L.ptr(x2), ldx, F, L.ptr(out), F, L.ptr(count), F, L.stream_ptr()),
                     "tfgx_segment_max_count_f32")
-        pt, t2d = _transposed(plan)
-        w_t = _transposed_weights(plan, w_csr, t2d)
-        gx = torch.empty_like(x2)
-        gn = torch.empty_like(out)          # workspace: g / count per destination row
-        L.check(lib.tfgx_segment_max_backward_f32(L.ptr(pt.row_ptr), L.ptr(pt.col), L.ptr(w_t), pt.n_dst, L.ptr(x2), ldx,
-                                                  F, L.ptr(out), F, L.ptr(g2), ldg, L.ptr(count), F, L.ptr(gx), F,
-                                                  plan.n_dst, L.ptr(gn), L.stream_ptr()),
-                "tfgx_segment_max_backward_f32")
+        gx = None
+        if ctx.needs_input_grad[1]:
+            gx = torch.empty_like(x2)
+            if ctx.argpos is not None and ldg % 4 == 0 and g2.data_ptr() % 16 == 0:
+                L.check(lib.tfgx_segment_max_backward_push_f32(
+                    L.ptr(plan.row_ptr), L.ptr(plan.col), L.ptr(None if w_csr is None else w_csr.detach()), plan.n_dst,
+                    int(x2.shape[0]), L.ptr(x2), ldx, F, L.ptr(out), F, L.ptr(g2), ldg, L.ptr(count), F,
+                    L.ptr(ctx.argpos), F, L.ptr(gx), F, L.stream_ptr()), "tfgx_segment_max_backward_push_f32")
+            else:
+                pt, t2d = _transposed(plan)
+                w_t = _transposed_weights(plan, w_csr, t2d)
+                gn = torch.empty_like(out)          # workspace: g / count per destination row
+                L.check(lib.tfgx_segment_max_backward_f32(L.ptr(pt.row_ptr), L.ptr(pt.col), L.ptr(w_t), pt.n_dst, L.ptr(x2),
+                                                          ldx, F, L.ptr(out), F, L.ptr(g2), ldg, L.ptr(count), F, L.ptr(gx),
+                                                          F, plan.n_dst, L.ptr(gn), L.stream_ptr()),
+                        "tfgx_segment_max_backward_f32")
         gw = None
         if w_csr is not None and ctx.needs_input_grad[2]:
             gn2 = g2 / count.clamp(min=1.0)          # TF splits the gradient evenly among tied maxima

@@ -10,7 +10,9 @@
 //                                            flash-attention style: alpha is recomputed from the saved (m, l)
 //   unsorted_segment_max (training forward) = tfgx_segment_max_with_count_f32: maxima and tie counts in one pass
 //   d(max)/d(edge weight)                  = tfgx_segment_max_backward_w_f32 (the SDDMM kernel with an arg-max mask)
-// Every accumulation has one owner (a destination row or a source row): deterministic, no atomics.
+// Every accumulation has one owner (a destination row or a source row): deterministic, no atomics — with ONE opt-out:
+//   unsorted_segment_max gradient, push form = tfgx_segment_max_with_arg_f32 + tfgx_segment_max_backward_push_f32
+//                                            (N*F float atomics instead of 2 row gathers per edge; see the kernel).
 // Each entry point has a tuned kernel (lane group per row, float4 columns, the forward kernel's mapping) and a plain
 // one-lane-per-output fallback for layouts the tuned one does not cover.
 #include "tfgx_common.h"
@@ -189,7 +191,8 @@ __global__ __launch_bounds__(kBlock) void max_grad_fast_kernel(const int32_t* __
                                                                const float* __restrict__ out, int64_t ldo,
                                                                const float* __restrict__ gn, int64_t ldg,
                                                                float* __restrict__ res, int64_t ldr,
-                                                               float* __restrict__ out_w = nullptr)
+                                                               float* __restrict__ out_w = nullptr,
+                                                               int32_t* __restrict__ argpos = nullptr, int64_t lda = 0)
 {
     // MODE 0: res = tie count given the row maxima `out`;  MODE 1: res = gradient wrt x (transposed plan);
     // MODE 2: the FORWARD of training: row maximum -> out_w and tie count -> res in ONE pass (online: a value above the
@@ -203,6 +206,9 @@ __global__ __launch_bounds__(kBlock) void max_grad_fast_kernel(const int32_t* __
     for (int64_t row = int64_t(blockIdx.x) * ROWS_PER_BLOCK + grp; row < n; row += int64_t(gridDim.x) * ROWS_PER_BLOCK) {
         const int s = row_ptr[row], e = row_ptr[row + 1];
         float mine[VEC], acc[VEC];
+        int apos[VEC];            // MODE 2: CSR position of the FIRST edge attaining the running maximum (-1: empty row)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) apos[i] = -1;
         if (MODE == 2) {
 #pragma unroll
             for (int i = 0; i < VEC; ++i) mine[i] = -FLT_MAX;                        // running maximum
@@ -230,6 +236,7 @@ __global__ __launch_bounds__(kBlock) void max_grad_fast_kernel(const int32_t* __
 #pragma unroll
                     for (int i = 0; i < VEC; ++i) {
                         const float m = w ? wi * xv[i] : xv[i];
+                        apos[i] = (m > mine[i] || apos[i] < 0) ? (base + j) : apos[i];
                         acc[i] = m > mine[i] ? 1.0f : (m == mine[i] ? acc[i] + 1.0f : acc[i]);
                         mine[i] = fmaxf(mine[i], m);
                     }
@@ -246,6 +253,10 @@ __global__ __launch_bounds__(kBlock) void max_grad_fast_kernel(const int32_t* __
         if (cvalid) {
             store_vec<VEC>(res + row * ldr + coff, acc);
             if (MODE == 2) store_vec<VEC>(out_w + row * ldo + coff, mine);
+            if (MODE == 2 && argpos != nullptr) {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) argpos[row * lda + coff + i] = apos[i];
+            }
         }
     }
 }
@@ -253,14 +264,14 @@ __global__ __launch_bounds__(kBlock) void max_grad_fast_kernel(const int32_t* __
 template <int MODE>
 int launch_max_grad(const int32_t* row_ptr, const int32_t* other, const float* w, int64_t n, const float* x,
                     int64_t ldx, int F, const float* out, int64_t ldo, const float* gn, int64_t ldg, float* res,
-                    int64_t ldr, hipStream_t stream, float* out_w = nullptr)
+                    int64_t ldr, hipStream_t stream, float* out_w = nullptr, int32_t* argpos = nullptr, int64_t lda = 0)
 {
     const int lanes = (F + 3) / 4;
 #define TFGX_MG(GG)                                                                                            \
     {                                                                                                          \
         dim3 grid(grid_for(n, kBlock / GG, 1 << 20), (lanes + GG - 1) / GG, 1);                                \
         max_grad_fast_kernel<GG, MODE><<<grid, kBlock, 0, stream>>>(row_ptr, other, w, n, x, ldx, F, out, ldo, \
-                                                                      gn, ldg, res, ldr, out_w);              \
+                                                                      gn, ldg, res, ldr, out_w, argpos, lda); \
     }
     if (lanes <= 8) TFGX_MG(8)
     else if (lanes <= 16) TFGX_MG(16)
@@ -269,6 +280,82 @@ int launch_max_grad(const int32_t* row_ptr, const int32_t* other, const float* w
 #undef TFGX_MG
     TFGX_LAUNCH_CHECK("max_grad_fast_kernel");
     return TFGX_OK;
+}
+
+// Push form of the segment-max gradient (training on near-regular graphs): the training forward saved, per (row, column),
+// the CSR position of the first maximal edge and the number of tied maxima.  A destination row then hands each of its F
+// gradient values straight to the ONE source element that produced the maximum:
+//     gx[col[argpos[r, j]], j] += w[argpos[r, j]] * g[r, j]
+// — N*F scattered float atomics instead of E*F gathered elements (two row gathers per edge in the pull form above: 19 ms
+// at products shape vs ~3 ms).  Rows where some column has TIED maxima (count > 1) are walked exactly like the forward
+// and every tied edge receives g / count, so TensorFlow's unsorted_segment_max gradient is reproduced for ties too.
+// The price: float atomics commit in arrival order, so sums of several contributions to one gx element may differ in
+// the last bit from run to run (TensorFlow's own GPU kernels behave the same).  The pull kernel stays available for
+// bit-reproducible training (tfgx_segment_max_backward_f32).
+template <int G>
+__global__ __launch_bounds__(kBlock) void max_backward_push_kernel(const int32_t* __restrict__ row_ptr,
+                                                                   const int32_t* __restrict__ col,
+                                                                   const float* __restrict__ w, int64_t n_dst,
+                                                                   const float* __restrict__ x, int64_t ldx, int F,
+                                                                   const float* __restrict__ out, int64_t ldo,
+                                                                   const float* __restrict__ g, int64_t ldg,
+                                                                   const float* __restrict__ count, int64_t ldc,
+                                                                   const int32_t* __restrict__ argpos, int64_t lda,
+                                                                   float* __restrict__ gx, int64_t ldgx)
+{
+    constexpr int VEC = 4;
+    constexpr int ROWS_PER_BLOCK = kBlock / G;
+    const int lane = threadIdx.x % G, grp = threadIdx.x / G;
+    const int c_raw = (blockIdx.y * G + lane) * VEC;
+    const bool cvalid = c_raw < F;
+    const int coff = cvalid ? c_raw : (F - VEC);
+    for (int64_t r0 = int64_t(blockIdx.x) * ROWS_PER_BLOCK; r0 < n_dst; r0 += int64_t(gridDim.x) * ROWS_PER_BLOCK) {
+        const int64_t r = r0 + grp;
+        const bool rvalid = r < n_dst;
+        const int s = rvalid ? row_ptr[r] : 0, e = rvalid ? row_ptr[r + 1] : 0;
+        float gv[VEC] = {0.f, 0.f, 0.f, 0.f}, cv[VEC] = {0.f, 0.f, 0.f, 0.f};
+        int ap[VEC] = {-1, -1, -1, -1};
+        if (rvalid && cvalid && e > s) {
+            load_vec<VEC>(g + r * ldg + coff, gv);
+            load_vec<VEC>(count + r * ldc + coff, cv);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) ap[i] = argpos[r * lda + coff + i];
+        }
+        bool tie = false;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) tie |= cv[i] > 1.0f;
+        // does any lane of this row's group see a tie?  (groups are aligned sub-ranges of the wave)
+        const unsigned long long b = __ballot(tie);
+        const int sh = (threadIdx.x % 64) / G * G;
+        const unsigned long long gmask = (G == 64) ? ~0ull : (((1ull << G) - 1ull) << sh);
+        const bool row_has_tie = (b & gmask) != 0ull;
+        if (!row_has_tie) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                if (ap[i] >= 0) {
+                    const int p = ap[i];
+                    const float wi = w ? w[p] : 1.0f;
+                    atomicAdd(gx + int64_t(col[p]) * ldgx + coff + i, wi * gv[i]);
+                }
+            }
+        } else {   // exact walk: every edge attaining the maximum of a column receives g / count
+            float ov[VEC] = {0.f, 0.f, 0.f, 0.f};
+            if (rvalid && cvalid && e > s) load_vec<VEC>(out + r * ldo + coff, ov);
+            for (int i0 = s; i0 < e; ++i0) {
+                const int c = col[i0];
+                const float wi = w ? w[i0] : 1.0f;
+                float xv[VEC];
+                load_vec<VEC>(x + int64_t(c) * ldx + coff, xv);
+                if (cvalid) {
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) {
+                        const float m = w ? wi * xv[i] : xv[i];
+                        if (m == ov[i] && cv[i] > 0.0f) atomicAdd(gx + int64_t(c) * ldgx + coff + i, wi * gv[i] / cv[i]);
+                    }
+                }
+            }
+        }
+    }
 }
 
 __global__ void divide_kernel(const float* __restrict__ g, int64_t ldg, const float* __restrict__ cnt, int64_t ldc,
@@ -626,6 +713,56 @@ extern "C" int tfgx_segment_max_with_count_f32(const int32_t* row_ptr, const int
     const int rc = tfgx_segment_reduce_f32(&a, stream);
     if (rc != TFGX_OK) return rc;
     return tfgx_segment_max_count_f32(row_ptr, col, w, n_dst, x, ldx, F, out, ldo, count, ldc, stream);
+}
+
+extern "C" int tfgx_segment_max_with_arg_f32(const int32_t* row_ptr, const int32_t* col, const float* w, int64_t n_dst,
+                                             const float* x, int64_t ldx, int64_t F, float* out, int64_t ldo,
+                                             float* count, int64_t ldc, int32_t* argpos, int64_t lda,
+                                             tfgx_stream_t stream)
+{
+    TFGX_RANGE();
+    TFGX_REQUIRE(n_dst >= 0 && F >= 1 && ldx >= F && ldo >= F && ldc >= F && lda >= F, "bad size");
+    if (n_dst == 0) return TFGX_OK;
+    TFGX_REQUIRE(row_ptr && x && out && count && argpos, "null pointer");
+    TFGX_REQUIRE(F % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && ldc % 4 == 0 && aligned_to(x, 16) && aligned_to(out, 16) &&
+                     aligned_to(count, 16),
+                 "needs 16-byte aligned rows and F % 4 == 0 (use tfgx_segment_max_with_count_f32 otherwise)");
+    return launch_max_grad<2>(row_ptr, col, w, n_dst, x, ldx, int(F), nullptr, ldo, nullptr, 0, count, ldc,
+                              as_stream(stream), out, argpos, lda);
+}
+
+extern "C" int tfgx_segment_max_backward_push_f32(const int32_t* row_ptr, const int32_t* col, const float* w,
+                                                  int64_t n_dst, int64_t n_src, const float* x, int64_t ldx, int64_t F,
+                                                  const float* out, int64_t ldo, const float* g, int64_t ldg,
+                                                  const float* count, int64_t ldc, const int32_t* argpos, int64_t lda,
+                                                  float* gx, int64_t ldgx, tfgx_stream_t stream_)
+{
+    TFGX_RANGE();
+    TFGX_REQUIRE(n_dst >= 0 && n_src >= 0 && F >= 1 && ldx >= F && ldo >= F && ldg >= F && ldc >= F && lda >= F &&
+                     ldgx >= F, "bad size");
+    hipStream_t stream = as_stream(stream_);
+    TFGX_REQUIRE(n_src == 0 || gx != nullptr, "gx is null");
+    for (int64_t r = 0; ldgx != F && r < n_src; ++r) TFGX_HIP_CHECK(hipMemsetAsync(gx + r * ldgx, 0, sizeof(float) * F, stream));
+    if (ldgx == F && n_src > 0) TFGX_HIP_CHECK(hipMemsetAsync(gx, 0, sizeof(float) * size_t(n_src) * size_t(F), stream));
+    if (n_dst == 0) return TFGX_OK;
+    TFGX_REQUIRE(row_ptr && col && x && out && g && count && argpos, "null pointer");
+    TFGX_REQUIRE(F % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && ldg % 4 == 0 && ldc % 4 == 0 && aligned_to(x, 16) &&
+                     aligned_to(out, 16) && aligned_to(g, 16) && aligned_to(count, 16),
+                 "needs 16-byte aligned rows and F % 4 == 0");
+    const int lanes = int((F + 3) / 4);
+#define TFGX_PUSH(GG)                                                                                               \
+    {                                                                                                               \
+        dim3 grid(grid_for(n_dst, kBlock / GG, 1 << 20), (lanes + GG - 1) / GG, 1);                                 \
+        max_backward_push_kernel<GG><<<grid, kBlock, 0, stream>>>(row_ptr, col, w, n_dst, x, ldx, int(F), out, ldo, \
+                                                                 g, ldg, count, ldc, argpos, lda, gx, ldgx);       \
+    }
+    if (lanes <= 8) TFGX_PUSH(8)
+    else if (lanes <= 16) TFGX_PUSH(16)
+    else if (lanes <= 32) TFGX_PUSH(32)
+    else TFGX_PUSH(64)
+#undef TFGX_PUSH
+    TFGX_LAUNCH_CHECK("max_backward_push_kernel");
+    return TFGX_OK;
 }
 
 extern "C" int tfgx_segment_max_backward_f32(const int32_t* row_ptr_t, const int32_t* dst_t, const float* w_t,

@@ -308,10 +308,29 @@ def backward_section(plan, n, E, w):
     for f in [100]:
         x = torch.randn(n, f, device="cuda", requires_grad=True)
         g = torch.randn(n, f, device="cuda")
-        for name, op, ww in [("sum_w", L.SUM, w_csr), ("max", L.MAX, None)]:
+        for name, op, ww, det in [("sum_w", L.SUM, w_csr, False), ("max (push: arg positions + atomics)", L.MAX, None, False),
+                                  ("max (pull: bit-reproducible, 2 gathers per edge)", L.MAX, None, True),
+                                  ("max weighted (push)", L.MAX, w_csr, False)]:
+            AG.DETERMINISTIC_MAX_GRADIENT = det
+            fwd = timeit(lambda: AG.aggregate(plan, x, op, ww), steps=5, warmup=2)
             out = AG.aggregate(plan, x, op, ww)
             ms = timeit(lambda: torch.autograd.grad(out, x, g, retain_graph=True), steps=5, warmup=2)
-            print(json.dumps({"kind": "backward", "what": "d/dx aggregate " + name, "F": f, "ms": ms}), flush=True)
+            AG.DETERMINISTIC_MAX_GRADIENT = False
+            print(json.dumps({"kind": "backward", "what": "d/dx aggregate " + name, "F": f, "ms": ms,
+                              "training_forward_ms": fwd}), flush=True)
+        from tf_geometric_amd.plan import gemm_tn, gemm_bias_act, transpose
+        for (ka, nn_) in [(100, 256), (256, 40), (128, 128)]:
+            xa = torch.randn(n, ka, device="cuda")
+            gg = torch.randn(n, nn_, device="cuda")
+            kk = torch.randn(ka, nn_, device="cuda")
+            ms_tn = timeit(lambda: gemm_tn(xa, gg, want_bias=True), steps=5, warmup=2)
+            ms_ref = timeit(lambda: (xa.t() @ gg, gg.sum(0)), steps=5, warmup=2)
+            ms_dx = timeit(lambda: gemm_bias_act(gg, transpose(kk)), steps=5, warmup=2)
+            ms_dx_ref = timeit(lambda: gg @ kk.t(), steps=5, warmup=2)
+            print(json.dumps({"kind": "backward", "what": "dense layer gradients", "M": n, "K": ka, "N": nn_,
+                              "dW_db_gemm_tn_ms": ms_tn, "dW_db_torch_ms": ms_ref,
+                              "dW_TFLOPs": 2.0 * n * ka * nn_ / (ms_tn * 1e-3) / 1e12,
+                              "dx_mfma_ms": ms_dx, "dx_torch_ms": ms_dx_ref}), flush=True)
         wreq = w_csr.clone().requires_grad_(True)
         out = AG.aggregate(plan, x.detach(), L.SUM, wreq)
         ms = timeit(lambda: torch.autograd.grad(out, wreq, g, retain_graph=True), steps=5, warmup=2)

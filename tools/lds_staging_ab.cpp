@@ -90,58 +90,67 @@ __global__ __launch_bounds__(kBlock) void reduce_lds(const int* __restrict__ row
     const int lane = threadIdx.x % G, grp = threadIdx.x / G, wave = threadIdx.x / 64, wl = threadIdx.x % 64;
     const int c = lane * 4 < F ? lane * 4 : F - 4;
     const bool valid = lane * 4 < F;
-    for (int64_t r = int64_t(blockIdx.x) * (kBlock / G) + grp; r < n; r += int64_t(gridDim.x) * (kBlock / G)) {
-        const int s = row_ptr[r], e = row_ptr[r + 1];
-        // both rows of the wave walk in lock step: the wave runs to the longer of its two rows
-        const int len = e - s;
-        const int len_other = __shfl_xor(len, 32, 64);
-        const int nb = (max(len, len_other) + U - 1) / U;          // batches of U edges (wave-uniform)
+    for (int64_t r0 = int64_t(blockIdx.x) * (kBlock / G); r0 < n; r0 += int64_t(gridDim.x) * (kBlock / G)) {
+        const int64_t r = r0 + grp;                                  // the whole wave iterates together (uniform trip count)
+        const int s = r < n ? row_ptr[r] : 0, e = r < n ? row_ptr[r + 1] : 0;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        auto issue = [&](int b) {
-            const int slot = b % DEPTH;
+        const int len = e - s;
+        const int len_max = max(len, __shfl_xor(len, 32, 64));      // the wave's two rows walk in lock step
+        for (int off = 0; off < len_max; off += G) {
+            // (col, w) of up to 32 edges, one per lane, coalesced — exactly as the register path does
+            const int base = s + off;
+            const int cj = base + lane < e ? col[base + lane] : 0;
+            const float wj = base + lane < e ? w[base + lane] : 0.0f;
+            const int cnt = max(0, min(G, e - base));
+            const int cnt_max = max(cnt, __shfl_xor(cnt, 32, 64));
+            const int nsb = (cnt_max + U - 1) / U;                   // sub-batches of U rows (wave-uniform)
+            auto issue = [&](int b) {
+                const int slot = b % DEPTH;
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int i = s + b * U + u;
-                const int cc = i < e ? col[i] : 0;                   // broadcast load inside the group (same address)
-                const float* src = x + int64_t(cc) * F + c;
-                if constexpr (DIRECT) {
+                for (int u = 0; u < U; ++u) {
+                    const int cc = __shfl(cj, (b * U + u) % G, G);   // lanes past cnt carry col 0: a valid row, weight 0
+                    const float* src = x + int64_t(cc) * F + c;
+                    if constexpr (DIRECT) {
 #if defined(__HIP_DEVICE_COMPILE__)      // device-only builtin: the host pass must not see it
-                    __builtin_amdgcn_global_load_lds(src, &ring[wave][slot][u][0], 16, 0, 0);
+                        __builtin_amdgcn_global_load_lds(src, &ring[wave][slot][u][0], 16, 0, 0);
 #endif
-                } else {
-                    ring[wave][slot][u][wl] = *reinterpret_cast<const float4*>(src);
+                    } else {
+                        ring[wave][slot][u][wl] = *reinterpret_cast<const float4*>(src);
+                    }
                 }
-            }
-        };
-        const int pre = min(nb, DEPTH - 1);
-        for (int b = 0; b < pre; ++b) issue(b);
-        for (int b = 0; b < nb; ++b) {
-            if (b + DEPTH - 1 < nb) issue(b + DEPTH - 1);
-            // wait until batch b has landed: at most (batches issued after b) * U loads may still be in flight
-            if constexpr (DIRECT) {
-                const int later = min(nb - 1, b + DEPTH - 1) - b;
+            };
 #if defined(__HIP_DEVICE_COMPILE__)
-                // s_waitcnt simm16 on gfx9: vmcnt = bits [3:0] | [15:14], expcnt [6:4] = 7, lgkmcnt [11:8] = 15 (no wait)
-                if (later >= 3) __builtin_amdgcn_s_waitcnt(0x0f70 | ((3 * U) & 15) | (((3 * U) >> 4) << 14));
-                else if (later == 2) __builtin_amdgcn_s_waitcnt(0x0f70 | ((2 * U) & 15) | (((2 * U) >> 4) << 14));
-                else if (later == 1) __builtin_amdgcn_s_waitcnt(0x0f70 | (U & 15));
-                else __builtin_amdgcn_s_waitcnt(0x0f70);
-                __builtin_amdgcn_wave_barrier();
+            if constexpr (DIRECT) __builtin_amdgcn_s_waitcnt(0x0f70);    // cj / wj have landed; only row loads counted below
 #endif
-            }
-            const int slot = b % DEPTH;
+            const int pre = min(nsb, DEPTH - 1);
+            for (int b = 0; b < pre; ++b) issue(b);
+            for (int b = 0; b < nsb; ++b) {
+                if (b + DEPTH - 1 < nsb) issue(b + DEPTH - 1);
+                if constexpr (DIRECT) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                    // s_waitcnt simm16 on gfx9: vmcnt = bits [3:0] | [15:14], expcnt [6:4] = 7, lgkmcnt [11:8] = 15
+                    const int later = min(nsb - 1, b + DEPTH - 1) - b;   // sub-batches issued after b, still allowed in flight
+                    if (later >= 3) __builtin_amdgcn_s_waitcnt(0x0f70 | ((3 * U) & 15) | (((3 * U) >> 4) << 14));
+                    else if (later == 2) __builtin_amdgcn_s_waitcnt(0x0f70 | ((2 * U) & 15) | (((2 * U) >> 4) << 14));
+                    else if (later == 1) __builtin_amdgcn_s_waitcnt(0x0f70 | (U & 15));
+                    else __builtin_amdgcn_s_waitcnt(0x0f70);
+                    __builtin_amdgcn_wave_barrier();
+#endif
+                }
+                const int slot = b % DEPTH;
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int i = s + b * U + u;
-                const float wv = i < e ? w[i] : 0.0f;
-                const float4 v = ring[wave][slot][u][wl];
-                if (i < e) {
-                    acc.x = fmaf(wv, v.x, acc.x); acc.y = fmaf(wv, v.y, acc.y);
-                    acc.z = fmaf(wv, v.z, acc.z); acc.w = fmaf(wv, v.w, acc.w);
+                for (int u = 0; u < U; ++u) {
+                    const int j = b * U + u;
+                    const float wv = __shfl(wj, j % G, G);
+                    const float4 v = ring[wave][slot][u][wl];
+                    if (j < cnt) {
+                        acc.x = fmaf(wv, v.x, acc.x); acc.y = fmaf(wv, v.y, acc.y);
+                        acc.z = fmaf(wv, v.z, acc.z); acc.w = fmaf(wv, v.w, acc.w);
+                    }
                 }
             }
         }
-        if (valid) *reinterpret_cast<float4*>(out + r * F + c) = acc;
+        if (valid && r < n) *reinterpret_cast<float4*>(out + r * F + c) = acc;
     }
 }
 
