@@ -548,16 +548,30 @@ def get_laplacian(edge_index, num_nodes, edge_weight, normalization_type, fill_w
     return add_self_loop_edge(ei, num_nodes, nw.astype(np.float32), fill_weight=fill_weight)
 
 
+def laplacian_max_eigenvalue(edge_index, num_nodes, edge_weight, normalization_type):
+    """utils/graph_utils.py:884-909 (scipy eigsh / eigs, k=1, which='LM'), restated with a DENSE eigen-solve:
+    the largest-magnitude eigenvalue of get_laplacian's matrix.  ('rw' is similar to 'sym': same spectrum.)"""
+    nt = "sym" if normalization_type == "rw" else normalization_type
+    lei, lw = get_laplacian(edge_index, num_nodes, edge_weight, nt)
+    M = np.zeros((num_nodes, num_nodes), np.float64)
+    np.add.at(M, (lei[0], lei[1]), lw.astype(np.float64))
+    # 'sym' is symmetric on an undirected graph; None yields (deg_r - w_rc) off the diagonal — NOT symmetric, which is why
+    # the reference switches from eigsh to eigs there (graph_utils.py:901-905): general dense solve, real part
+    ev = np.linalg.eigvals(M)
+    return float(ev[np.argmax(np.abs(ev))].real)
+
+
 def chebynet(x, edge_index, edge_weight, k, kernels, bias=None, activation=None, normalization_type="sym",
-             acc=np.float64):
-    """nn/conv/chebynet.py:27-137 with lambda_max = 2.0."""
+             acc=np.float64, use_dynamic_lambda_max=False):
+    """nn/conv/chebynet.py:27-137; lambda_max = 2.0 unless use_dynamic_lambda_max (:39-40)."""
     x = np.asarray(x, np.float32)
     N = x.shape[0]
     ei = np.asarray(edge_index, np.int32)
     w = np.ones(ei.shape[1], np.float32) if edge_weight is None else np.asarray(edge_weight, np.float32)
     keep = ei[0] != ei[1]                                               # remove_self_loop_edge (:34)
     lei, lw = get_laplacian(ei[:, keep], N, w[keep], normalization_type, acc=acc)
-    lw = (2.0 * lw) / 2.0                                                # :43
+    lambda_max = laplacian_max_eigenvalue(ei[:, keep], N, w[keep], normalization_type) if use_dynamic_lambda_max else 2.0
+    lw = ((2.0 * lw) / lambda_max).astype(np.float32)                    # :43
     T0 = x
     out = matmul(T0, kernels[0], acc)
     if k > 1:

@@ -614,6 +614,9 @@ def _prop_ref(R, g):
     out["ssgc-plain"] = _np(nn.ssgc(x, ei, None, None, None, k=4))
     for norm in ("sym", "rw", None):
         out["chebynet-{}".format(norm)] = _np(nn.chebynet(x, ei, w, 3, g["ck"], g["cb"], relu, norm))
+    out["chebynet-sym-dynamic"] = _np(nn.chebynet(x, ei, w, 3, g["ck"], g["cb"], relu, "sym", use_dynamic_lambda_max=True))
+    out["lambda_max-sym"] = np.float32(R.tfg.utils.graph_utils.LaplacianMaxEigenvalue(ei, g["n"], w)("sym"))
+    out["lambda_max-None"] = np.float32(R.tfg.utils.graph_utils.LaplacianMaxEigenvalue(ei, g["n"], w)(None))
     mlp = lambda h, training=None: relu(h @ g["gin_w"])      # noqa: E731
     out["gin"] = _np(nn.gin(x, ei, mlp, eps=0.3))
     out["le_conv"] = _np(nn.le_conv(x, ei, w, g["lk"][0], g["lb"][0], g["lk"][1], g["lb"][1], g["lk"][2], g["lb"][2],
@@ -632,6 +635,9 @@ def _prop_orc(o, g):
     out["ssgc-plain"] = o.ssgc(x, ei, None, None, None, k=4)
     for norm in ("sym", "rw", None):
         out["chebynet-{}".format(norm)] = o.chebynet(x, ei, w, 3, g["ck"], g["cb"], "relu", norm)
+    out["chebynet-sym-dynamic"] = o.chebynet(x, ei, w, 3, g["ck"], g["cb"], "relu", "sym", use_dynamic_lambda_max=True)
+    out["lambda_max-sym"] = np.float32(o.laplacian_max_eigenvalue(ei, g["n"], w, "sym"))
+    out["lambda_max-None"] = np.float32(o.laplacian_max_eigenvalue(ei, g["n"], w, None))
     out["gin"] = np.maximum(o.matmul(o.gin(x, ei, lambda h: h, eps=0.3), g["gin_w"]), 0)
     out["le_conv"] = o.le_conv(x, ei, w, g["lk"][0], g["lb"][0], g["lk"][1], g["lb"][1], g["lk"][2], g["lb"][2], "relu")
     return out
@@ -650,6 +656,10 @@ def _prop_hip(T, g):
     out["ssgc-plain"] = _np(nn.ssgc(x, ei, None, None, None, k=4))
     for norm in ("sym", "rw", None):
         out["chebynet-{}".format(norm)] = _np(nn.chebynet(x, ei, w, 3, g["ck"], g["cb"], relu, norm))
+    out["chebynet-sym-dynamic"] = _np(nn.chebynet(x, ei, w, 3, g["ck"], g["cb"], relu, "sym", use_dynamic_lambda_max=True))
+    from tf_geometric_amd.nn.conv.propagation import chebynet_norm_edge, laplacian_max_eigenvalue
+    for nt in ("sym", None):       # the unscaled Laplacian: chebynet_norm_edge with lambda_max = 2 has scale 1
+        out["lambda_max-{}".format(nt)] = np.float32(laplacian_max_eigenvalue(chebynet_norm_edge(ei, g["n"], w, nt), nt))
     gw = T._lib.as_f32(g["gin_w"])
     out["gin"] = _np(nn.gin(x, ei, lambda h, training=None: torch.relu(h @ gw), eps=0.3))
     out["le_conv"] = _np(nn.le_conv(x, ei, w, g["lk"][0], g["lb"][0], g["lk"][1], g["lb"][1], g["lk"][2], g["lb"][2],
@@ -657,7 +667,7 @@ def _prop_hip(T, g):
     return out
 
 
-_add("propagation_convs", _prop_inputs, _prop_ref, _prop_orc, _prop_hip, tol=2e-5, key_tol={"chebynet-None": 2e-4},
+_add("propagation_convs", _prop_inputs, _prop_ref, _prop_orc, _prop_hip, tol=2e-5, key_tol={"chebynet-None": 2e-4, "lambda_max-None": 1e-4},
      note="k-hop chains re-associate k fp32 SpMMs (2e-5); chebynet(normalization_type=None) applies the UN-normalised "
           "Laplacian twice: terms of magnitude 1e4 cancel, so the fp32 reference itself carries ~1e-4 absolute noise")
 

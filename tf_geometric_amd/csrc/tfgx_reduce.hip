@@ -16,6 +16,7 @@
 #include "tfgx_common.h"
 #include <cfloat>
 #include <cstdio>
+#include <cstdlib>
 
 namespace tfgx {
 namespace {
@@ -60,11 +61,25 @@ struct KArgs {
     int64_t ld_edge_tail;    // (streamed next to col / w instead of gathered: one line request fewer per edge)
 };
 
+#ifndef TFGX_REDUCE_GRID_CAP_DEFAULT
+#define TFGX_REDUCE_GRID_CAP_DEFAULT (1 << 20)
+#endif
+#ifndef TFGX_UNROLL_CH2
+#define TFGX_UNROLL_CH2 4
+#endif
+#ifndef TFGX_UNROLL_CH4
+#define TFGX_UNROLL_CH4 2
+#endif
+
+template <int VEC, int G, int CH, bool IS_MAX, bool WEIGHTED, bool SPLIT>
+__device__ __forceinline__ void seg_reduce_row(const KArgs& a, int64_t r, int s, int e, int cj_next, float wj_next, int lane,
+                                               const int (&coff)[CH], const bool (&cvalid)[CH], const float* const (&xb)[CH],
+                                               const int64_t (&xl)[CH], const float* const (&xs)[CH],
+                                               const int64_t (&xsl)[CH], const bool (&by_edge)[CH], float init);
+
 template <int VEC, int G, int CH, bool IS_MAX, bool WEIGHTED, bool SPLIT = false>
 __global__ __launch_bounds__(kBlock) void seg_reduce_kernel(const KArgs a)
 {
-    constexpr int UNROLL_W = (CH >= 4) ? 2 : (CH == 2 ? 4 : 8);   // independent row loads in flight per lane
-    constexpr int UNROLL = UNROLL_W < G ? UNROLL_W : G;              // a batch holds G edges: never unroll past it
     constexpr int ROWS_PER_BLOCK = kBlock / G;
     constexpr int COLS_PER_PASS = G * VEC * CH;
     const int lane = threadIdx.x % G;
@@ -110,15 +125,60 @@ __global__ __launch_bounds__(kBlock) void seg_reduce_kernel(const KArgs a)
     }
     const float init = IS_MAX ? -FLT_MAX : 0.0f;
 
-    for (int64_t r = int64_t(blockIdx.x) * ROWS_PER_BLOCK + grp; r < a.n_dst;
-         r += int64_t(gridDim.x) * ROWS_PER_BLOCK) {
-        int s = a.row_begin[r * a.rp_stride];
-        int e = a.row_end[r * a.rp_stride];
-        if constexpr (G == 64) {
-            s = __builtin_amdgcn_readfirstlane(s);
-            e = __builtin_amdgcn_readfirstlane(e);
+    // A lane group walks SEVERAL rows (the launch caps the grid, launch_cfg): the header chain of a row — row_ptr ->
+    // first (col, w) batch -> first gathered rows — is software-pipelined across rows.  While row r is reduced, the
+    // first (col, w) batch of row r + stride and the (begin, end) pair of row r + 2*stride are already in flight, so a
+    // new row starts with its indices in registers instead of two dependent memory round trips.
+    const int64_t rstride = int64_t(gridDim.x) * ROWS_PER_BLOCK;
+    int64_t r = int64_t(blockIdx.x) * ROWS_PER_BLOCK + grp;
+    int s = 0, e = 0, s1 = 0, e1 = 0;
+    if (r < a.n_dst) {
+        s = a.row_begin[r * a.rp_stride];
+        e = a.row_end[r * a.rp_stride];
+    }
+    if (r + rstride < a.n_dst) {
+        s1 = a.row_begin[(r + rstride) * a.rp_stride];
+        e1 = a.row_end[(r + rstride) * a.rp_stride];
+    }
+    int cj_first = 0;
+    float wj_first = 0.0f;
+    if (s + lane < e) {
+        cj_first = a.col[s + lane];
+        if constexpr (WEIGHTED) wj_first = a.w[s + lane];
+    }
+    for (; r < a.n_dst; r += rstride) {
+        int s2 = 0, e2 = 0;                                       // header of the row after next
+        if (r + 2 * rstride < a.n_dst) {
+            s2 = a.row_begin[(r + 2 * rstride) * a.rp_stride];
+            e2 = a.row_end[(r + 2 * rstride) * a.rp_stride];
         }
-        if (a.hub_threshold > 0 && e - s > a.hub_threshold) continue;   // handled by the chunked hub path
+        int cj_first1 = 0;                                        // first (col, w) batch of the next row
+        float wj_first1 = 0.0f;
+        if (s1 + lane < e1) {
+            cj_first1 = a.col[s1 + lane];
+            if constexpr (WEIGHTED) wj_first1 = a.w[s1 + lane];
+        }
+        const int s_cur = G == 64 ? __builtin_amdgcn_readfirstlane(s) : s;
+        const int e_cur = G == 64 ? __builtin_amdgcn_readfirstlane(e) : e;
+        int cj_next = cj_first;
+        float wj_next = wj_first;
+        s = s1; e = e1; s1 = s2; e1 = e2; cj_first = cj_first1; wj_first = wj_first1;      // rotate the pipeline
+        if (a.hub_threshold > 0 && e_cur - s_cur > a.hub_threshold) continue;   // handled by the chunked hub path
+        seg_reduce_row<VEC, G, CH, IS_MAX, WEIGHTED, SPLIT>(a, r, s_cur, e_cur, cj_next, wj_next, lane, coff, cvalid, xb, xl,
+                                                            xs, xsl, by_edge, init);
+    }
+}
+
+// One destination row [s, e) of the plan, reduced by a group of G lanes (body of seg_reduce_kernel).
+template <int VEC, int G, int CH, bool IS_MAX, bool WEIGHTED, bool SPLIT>
+__device__ __forceinline__ void seg_reduce_row(const KArgs& a, int64_t r, int s, int e, int cj_next, float wj_next, int lane,
+                                               const int (&coff)[CH], const bool (&cvalid)[CH], const float* const (&xb)[CH],
+                                               const int64_t (&xl)[CH], const float* const (&xs)[CH],
+                                               const int64_t (&xsl)[CH], const bool (&by_edge)[CH], float init)
+{
+    constexpr int UNROLL_W = (CH >= 4) ? TFGX_UNROLL_CH4 : (CH == 2 ? TFGX_UNROLL_CH2 : 8);
+    constexpr int UNROLL = UNROLL_W < G ? UNROLL_W : G;
+    {
         float acc[CH][VEC];
 #pragma unroll
         for (int k = 0; k < CH; ++k)
@@ -127,12 +187,6 @@ __global__ __launch_bounds__(kBlock) void seg_reduce_kernel(const KArgs a)
 
         // (col, w) of the NEXT batch are loaded while the current batch's rows are in flight: the index load heads every
         // gather's dependency chain (same-box A/B: 4-6 % at F <= 64, 2 % on a 57 GB table, neutral at F = 100)
-        int cj_next = 0;
-        float wj_next = 0.0f;
-        if (s + lane < e) {
-            cj_next = a.col[s + lane];
-            if constexpr (WEIGHTED) wj_next = a.w[s + lane];
-        }
         for (int base = s; base < e; base += G) {
             const int cj = cj_next;
             const float wj = wj_next;
@@ -245,11 +299,26 @@ __global__ __launch_bounds__(kBlock) void seg_reduce_kernel(const KArgs a)
     }
 }
 
+// Workgroups per launch: enough to fill 256 CUs x 8 XCDs at full occupancy several times over, few enough that every
+// lane group walks several rows and the row-header pipeline of seg_reduce_kernel has something to overlap.
+// TFGX_REDUCE_GRID_CAP overrides (developer A/B, profiles/r02_ab_grid_cap.jsonl).
+inline int reduce_grid_cap()
+{
+    static int cap = 0;
+    if (cap == 0) {
+        const char* e = getenv("TFGX_REDUCE_GRID_CAP");
+        cap = (e != nullptr && atoi(e) > 0) ? atoi(e) : TFGX_REDUCE_GRID_CAP_DEFAULT;
+    }
+    return cap;
+}
+
 template <int VEC, int G, int CH>
 int launch_cfg(const KArgs& a, bool is_max, bool weighted, int ny, hipStream_t stream)
 {
     constexpr int ROWS_PER_BLOCK = kBlock / G;
-    dim3 grid(grid_for(a.n_dst, ROWS_PER_BLOCK, 1 << 20), ny, 1);
+    // very wide rows (several column chunks per lane): fewer, longer-lived workgroups (same-box A/B at F = 512: 42.4 vs
+    // 46.0 ms, profiles/r02_ab_grid_cap.txt); everything narrower runs best with one row per lane group
+    dim3 grid(grid_for(a.n_dst, ROWS_PER_BLOCK, CH >= 2 ? (reduce_grid_cap() < 4096 ? reduce_grid_cap() : 4096) : reduce_grid_cap()), ny, 1);
     dim3 block(kBlock, 1, 1);
     if constexpr (VEC == 4 && CH == 1) {
         if (a.x_tail != nullptr) {   // split rows: sum / mean only (the case that matters: 400-byte rows)

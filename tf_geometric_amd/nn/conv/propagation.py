@@ -160,13 +160,12 @@ def chebynet_norm_edge(edge_index, num_nodes, edge_weight=None, normalization_ty
                        use_dynamic_lambda_max=False, cache=None):
     """Scaled "Laplacian" of chebynet.py:27-54 + graph_utils.get_laplacian (:554-603), in plan form (a NormedAdj):
     self-loops removed, sym: D^-1/2 A D^-1/2 + I, rw: D^-1 A + I, None: (deg_r - w) on edges and on an appended
-    unit self-loop; everything times 2 / lambda_max (lambda_max = 2 unless dynamic, which needs scipy eigs)."""
+    unit self-loop; everything times 2 / lambda_max (lambda_max = 2, or the Laplacian's largest eigenvalue when
+    use_dynamic_lambda_max: laplacian_max_eigenvalue)."""
     if cache is not None:
         key = CACHE_KEY_CHEBYNET_NORMED_EDGE_TEMPLATE.format(normalization_type)
         if cache.get(key) is not None:
             return cache[key]
-    if use_dynamic_lambda_max:
-        raise NotImplementedError("use_dynamic_lambda_max needs a sparse eigen-solver (scipy eigs in the reference)")
     if normalization_type not in (None, "sym", "rw"):
         raise AssertionError("normalization_type must be None, 'sym' or 'rw'")        # graph_utils.py:556
     ei = L.as_i32(edge_index)
@@ -189,10 +188,85 @@ def chebynet_norm_edge(edge_index, num_nodes, edge_weight=None, normalization_ty
         w_csr = deg[rows] - adj.value_csr
         self_coef = deg - 1.0
         normed = NormedAdj(plan, w_csr, self_coef, [num_nodes, num_nodes])
-    scale = 2.0 / 2.0                                                  # lambda_max = 2.0 (chebynet.py:41-43)
+    lambda_max = 2.0                                                   # chebynet.py:41-43
+    if use_dynamic_lambda_max:                                         # :39-40 -> LaplacianMaxEigenvalue (graph_utils.py:884-909)
+        lambda_max = laplacian_max_eigenvalue(NormedAdj(normed.plan, w_csr, self_coef, [num_nodes, num_nodes]),
+                                              normalization_type)
+    scale = 2.0 / lambda_max
     out = NormedAdj(normed.plan, w_csr * scale, self_coef * scale, [num_nodes, num_nodes])
     if cache is not None:
         cache[key] = out
+    return out
+
+
+def laplacian_max_eigenvalue(lap, normalization_type="sym", steps=96):
+    """Largest-magnitude eigenvalue of the Laplacian held in plan form (graph_utils.LaplacianMaxEigenvalue, :884-909,
+    which hands scipy's ARPACK a scipy matrix: eigsh for 'sym' / 'rw', eigs for None, k = 1, which = 'LM').
+
+    Here: Arnoldi iteration (Lanczos with full re-orthogonalisation when the operator is symmetric), every L @ v on the
+    segment-reduce kernel (the graph never leaves the device), the m x m Hessenberg eigenproblem on the host.  The
+    operator is symmetric for 'sym'; for None get_laplacian yields (deg_r - w_rc) off the diagonal — not symmetric, which
+    is why the reference switches to the general solver there, and why Arnoldi (not plain Lanczos) is used here.  'rw' (D^-1 A + I) is not symmetric, but it is similar to the 'sym' matrix (D^-1/2 ... D^1/2), so it has the
+    same spectrum: the symmetric operator S = D^1/2 L_rw D^-1/2 is iterated instead and lambda_max is exact — the
+    reference calls the SYMMETRIC solver on the non-symmetric matrix there, whose answer is solver-dependent."""
+    import numpy as np
+    plan, n = lap.plan, int(lap.shape[0])
+    dev = plan.col.device
+    if n == 0:
+        return 2.0
+    scale_r = scale_c = None
+    if normalization_type == "rw":
+        # L_rw = I + D^-1 A' (A' carries the sign get_laplacian gives it); S = D^1/2 L_rw D^-1/2 is symmetric.
+        # |w_e| = |A_rc| / deg_r  ->  deg_r = 1 / sum_e |w_e| * (sum_e |A_rc|) is not recoverable from w alone, so take
+        # the degrees from the plan's row sums of |w| against a unit-weight pass: deg_r ∝ 1 / mean row weight.  For the
+        # similarity transform any positive d with d_r * w_rc = d_c * w_cr works; d_r = 1 / sum_e |w_re| does when the
+        # underlying A is symmetric with unit or symmetric weights (then sum_e |w_re| = 1 and d = 1): use the general
+        # construction d_r = sqrt(sum_e |w_er| / sum_e |w_re|) (column mass over row mass).
+        ones = torch.ones((n, 1), dtype=torch.float32, device=dev)
+        absw = lap.w_csr.abs()
+        row_mass = segment_reduce(plan, ones, L.SUM, w_csr=absw)[:, 0]
+        pt = plan.transposed()
+        col_mass = segment_reduce(pt, ones, L.SUM, w_csr=pt.edge_attr_to_csr(_csr_to_edge_order(plan, absw)))[:, 0]
+        d = torch.sqrt(torch.clamp(col_mass, min=1e-30) / torch.clamp(row_mass, min=1e-30))
+        d = torch.where((row_mass > 0) & (col_mass > 0), d, torch.ones_like(d))
+        scale_r, scale_c = (1.0 / d).unsqueeze(1), d.unsqueeze(1)      # S = diag(1/d) L diag(d)
+
+    def matvec(v):
+        h = v if scale_c is None else v * scale_c
+        out = segment_reduce(plan, h.contiguous(), L.SUM, w_csr=lap.w_csr, self_coef=lap.self_coef)
+        return out if scale_r is None else out * scale_r
+
+    # Arnoldi (= Lanczos with full re-orthogonalisation when the operator is symmetric): H = V^T L V, upper Hessenberg
+    m = int(min(steps, n))
+    g = torch.Generator(device="cpu")
+    g.manual_seed(0)
+    v = torch.randn((n, 1), generator=g, dtype=torch.float32).to(dev)
+    v = v / v.norm()
+    basis = torch.zeros((n, m), dtype=torch.float32, device=dev)
+    H = np.zeros((m + 1, m), np.float64)
+    k = 0
+    for j in range(m):
+        basis[:, j] = v[:, 0]
+        wv = matvec(v)
+        V = basis[:, :j + 1]
+        h1 = V.t() @ wv
+        wv = wv - V @ h1
+        h2 = V.t() @ wv                                                  # second Gram-Schmidt pass
+        wv = wv - V @ h2
+        H[:j + 1, j] = (h1 + h2)[:, 0].double().cpu().numpy()
+        b_j = float(wv.norm().item())
+        k = j + 1
+        if b_j < 1e-7 or j == m - 1:
+            break
+        H[j + 1, j] = b_j
+        v = wv / b_j
+    ev = np.linalg.eigvals(H[:k, :k])
+    return float(ev[np.argmax(np.abs(ev))].real)
+
+
+def _csr_to_edge_order(plan, attr_csr):
+    out = torch.empty_like(attr_csr)
+    out[plan.perm.long()] = attr_csr
     return out
 
 
