@@ -450,11 +450,16 @@ def main():
                 "frac_of_hbm_peak_algorithmic": bytes_alg / (ms2 * 1e-3) / HBM_PEAK,
                 "build_ms_once_per_feature_matrix": build_ms, "layout_bytes": int(info["bytes"]),
                 "bit_identical_to_headline_output": bool(torch.equal(out2, res))}
-            et_path = os.path.join(ROOT, "profiles", "r01_{}_edge_tail_pmc.json".format(args.workload))
-            if os.path.exists(et_path):          # HBM-side bytes of this launch, imported like roofline.traffic
-                with open(et_path) as fh:
-                    line["static_feature_layout"]["traffic_imported"] = json.load(fh)["traffic_bytes_per_launch"]
-                line["static_feature_layout"]["traffic_source"] = "profiles/" + os.path.basename(et_path)
+            for tag in ("r02", "r01"):          # HBM-side bytes of this launch, imported like roofline.traffic
+                et_path = os.path.join(ROOT, "profiles", "{}_{}_edge_tail_pmc.json".format(tag, args.workload))
+                if os.path.exists(et_path):
+                    with open(et_path) as fh:
+                        et = json.load(fh)
+                    line["static_feature_layout"]["traffic_imported"] = et["traffic_bytes_per_launch"]
+                    line["static_feature_layout"]["traffic_source"] = "profiles/" + os.path.basename(et_path)
+                    if et.get("kernel_ms"):
+                        line["static_feature_layout"]["traffic_profile_kernel_ms"] = et["kernel_ms"]
+                    break
             del rows, out2
         tfg.release_static_features(cache)
         if not args.no_rmat and n >= 100000:

@@ -123,8 +123,12 @@ class NumpyBackend(object):
                         for r in range(n)], dtype=np.float32)
         return torch.from_numpy(deg)
 
-    def gcn_norm_edges(self, row_ptr, col, w, n, row_deg, mode, fill, add_self_loop, renorm):
+    def gcn_norm_edges(self, row_ptr, col, w, n, row_deg, mode, fill, add_self_loop, renorm, col_deg=None):
         rp, c, wv, deg = _np(row_ptr), _np(col), _np(w), _np(row_deg).astype(np.float64)
+        cdeg = deg if col_deg is None else _np(col_deg).astype(np.float64)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            pc = np.power(cdeg, -0.5 if mode == 0 else -1.0)
+        pc = np.where(np.isfinite(pc), pc, 0.0)
         E = c.shape[0]
         wv = np.ones(E, np.float64) if wv is None else wv.astype(np.float64)
         with np.errstate(divide="ignore", invalid="ignore"):
@@ -132,8 +136,8 @@ class NumpyBackend(object):
         p = np.where(np.isfinite(p), p, 0.0)
         rows = np.repeat(np.arange(n), np.diff(rp))
         if mode == 0:
-            w_out = p[rows] * wv * p[c]
-            sc = (p[:n] * fill * p[:n]) if renorm else np.full(n, fill)
+            w_out = p[rows] * wv * pc[c]
+            sc = (p[:n] * fill * pc[:n]) if renorm else np.full(n, fill)
         elif mode == 1:
             w_out = p[rows] * wv
             sc = p[:n] * fill

@@ -82,6 +82,9 @@ def run_checks(rank, world, use_gpu, skew, results, rounds=None, partitioned=Fal
     sg2 = make(None)
     sg2.build_gcn_norm(norm="left", improved=True)
     out["gcn_left_improved_unweighted"] = sg2.gcn(x_own, be.f32(k)).cpu().numpy()
+    sg3 = make(w)
+    sg3.build_gcn_norm(sym=False)                      # column degrees: reverse-exchange of a ones column
+    out["gcn_sym_false"] = sg3.gcn(x_own, be.f32(k)).cpu().numpy()
     results[rank] = out
     return out
 
@@ -117,6 +120,7 @@ def reference(skew):
         "sum_unweighted": oracle.aggregate_neighbors(x, ei, None, oracle.identity_mapper, oracle.sum_reducer,
                                                      oracle.identity_updater),
         "gcn_left_improved_unweighted": oracle.gcn(x, ei, None, k, norm="left", improved=True),
+        "gcn_sym_false": oracle.gcn(x, ei, w, k, sym=False),
         **_sage_reference(oracle, x, ei, w),
         "gat": oracle.gat(x, ei, gat_weights()[0], gat_weights()[3], "relu", gat_weights()[1], gat_weights()[3], "relu",
                           gat_weights()[2], b[:8], "relu", num_heads=2),

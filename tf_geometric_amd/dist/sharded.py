@@ -149,10 +149,10 @@ class HipBackend(object):
                                                      L.stream_ptr()), "tfgx_segment_weight_sum_f32")
         return deg
 
-    def gcn_norm_edges(self, row_ptr, col, w, n, row_deg, mode, fill, add_self_loop, renorm):
+    def gcn_norm_edges(self, row_ptr, col, w, n, row_deg, mode, fill, add_self_loop, renorm, col_deg=None):
         E = int(col.shape[0])
         w_out, self_coef = self.empty(E), self.empty(n)
-        L.check(self.lib.tfgx_gcn_norm_edges_f32(L.ptr(row_ptr), L.ptr(col), L.ptr(w), n, L.ptr(row_deg), None, mode,
+        L.check(self.lib.tfgx_gcn_norm_edges_f32(L.ptr(row_ptr), L.ptr(col), L.ptr(w), n, L.ptr(row_deg), L.ptr(col_deg), mode,
                                                  float(fill), int(add_self_loop), int(renorm), L.ptr(w_out),
                                                  L.ptr(self_coef), L.stream_ptr()), "tfgx_gcn_norm_edges_f32")
         return w_out, self_coef
@@ -632,9 +632,11 @@ class ShardedGraph(object):
             off += g_.numel()
 
     # ------------------------------------------------------------------ GCN
-    def build_gcn_norm(self, norm="both", add_self_loop=True, renorm=True, improved=False):
-        """Sharded gcn_norm_adj (nn/conv/gcn.py:32-130, sym=True): row degrees are local to the owner; the degrees
-        of halo sources arrive through one 1-column halo exchange."""
+    def build_gcn_norm(self, norm="both", add_self_loop=True, sym=True, renorm=True, improved=False):
+        """Sharded gcn_norm_adj (nn/conv/gcn.py:32-130): row degrees are local to the owner; the degrees of halo sources
+        arrive through one 1-column halo exchange.  sym=False (:87-91: the right factor uses COLUMN sums): a column sum
+        collects weights of edges that live on other ranks, i.e. it is exactly the backward of a 1-column aggregation
+        of ones — local transposed pass, reverse halo exchange, owner-side accumulate (aggregate_backward)."""
         be = self.backend
         fill = 2.0 if improved else 1.0
         if norm == "both":
@@ -647,8 +649,17 @@ class ShardedGraph(object):
         self.own_rows(deg_table)[:, 0] = own_deg
         self.exchange_finish(self.exchange_start(deg_table))
         mode = L.NORM_MODES[norm]
+        col_table = None
+        if norm == "both" and not sym:
+            ones = be.f32(np.ones((self.n_own, 1), np.float32))
+            col_own = self.aggregate_backward(ones, w="plan" if self.w is not None else None)[:, 0] + diag
+            col_table = self.alloc_table(1)
+            self.own_rows(col_table)[:, 0] = col_own
+            self.exchange_finish(self.exchange_start(col_table))
+            col_table = col_table[:, 0].contiguous()
         self.norm_w, sc = be.gcn_norm_edges(self.row_ptr, self.col, self.w, self.n_own,
-                                            deg_table[:, 0].contiguous(), mode, fill, add_self_loop, renorm)
+                                            deg_table[:, 0].contiguous(), mode, fill, add_self_loop, renorm,
+                                            col_deg=col_table)
         self.self_coef = sc if add_self_loop else None
         return self
 
