@@ -539,6 +539,19 @@ def _time(fn, steps=10, warmup=3):
     return e0.elapsed_time(e1) / steps
 
 
+def _latency(fn, steps=20, warmup=3):
+    """Mean wall time of fn() + synchronize, one step at a time (what a serving request or a training loop that reads the
+    loss every step sees)."""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+        torch.cuda.synchronize()
+    return (time.perf_counter() - t0) * 1e3 / steps
+
+
 def extras(tfg, L, synthetic, x, ei, n, e, f, cache):
     """Whole-layer timings on the same graph (ms): GEMM + aggregation through the layer API.  `*_static_ms` keys are
     measured after tfg.prepare_static_features(x, ...) (explicit opt-in); everything else reads x as
@@ -563,6 +576,10 @@ def extras(tfg, L, synthetic, x, ei, n, e, f, cache):
     res["gcn_2layer_eager_ms"] = _time(two_layer)
     cap = tfg.CapturedForward(two_layer)
     res["gcn_2layer_hipgraph_ms"] = _time(lambda: cap.graph.replay())
+    # the two numbers above are THROUGHPUT (steps queued back to back: the host runs ahead, launch cost is hidden, a
+    # graph replay cannot win); what a hipGraph removes is per-step host LATENCY — one forward, then wait for it:
+    res["gcn_2layer_eager_latency_ms"] = _latency(two_layer)
+    res["gcn_2layer_hipgraph_latency_ms"] = _latency(lambda: cap.graph.replay())
     info = tfg.prepare_static_features(x, ei, cache)
     res["static_layout_bytes"] = int(info["bytes"])
     res["gcn_layer_F{}_to_256_static_ms".format(f)] = _time(lambda: gcn([x, ei], cache=cache))
@@ -570,6 +587,8 @@ def extras(tfg, L, synthetic, x, ei, n, e, f, cache):
     res["gcn_2layer_eager_static_ms"] = _time(two_layer)
     cap2 = tfg.CapturedForward(two_layer)                 # prepared BEFORE capture: the replay runs the static layout
     res["gcn_2layer_hipgraph_static_ms"] = _time(lambda: cap2.graph.replay())
+    res["gcn_2layer_eager_static_latency_ms"] = _latency(two_layer)
+    res["gcn_2layer_hipgraph_static_latency_ms"] = _latency(lambda: cap2.graph.replay())
     tfg.release_static_features(cache)
     # training step of one GCN layer (forward + backward through the autograd kernels)
     gt = tfg.layers.GCN(256, activation=tfg.relu)

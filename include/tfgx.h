@@ -316,6 +316,12 @@ typedef struct tfgx_gat_backward_args {
     int64_t ld_dsum;
 } tfgx_gat_backward_args;
 
+/* Prepares both backward passes in ONE sweep over the destination rows: dsum[r, h] = <dO[r, h, :], O[r, h, :]> (dense
+   [n_dst, H]) and the packed table pack[r] = [ dO (H*dv) | Q (H*d) | (m, l) (2H) | D (H) ] with row stride ld_pack
+   (>= H*dv + H*d + 3H; a multiple of 32 floats keeps rows on whole 128-byte lines) that the source pass gathers. */
+int tfgx_gat_pack_dst_f32(const float* grad_out, int64_t ld_grad_out, const float* out, int64_t ldo, const float* q,
+                          int64_t ldq, const float* stats_ml /* [n_dst, 2H] */, int64_t n_dst, int32_t H, int32_t d,
+                          int32_t dv, float* pack, int64_t ld_pack, float* dsum /* [n_dst, H] */, tfgx_stream_t stream);
 int tfgx_gat_backward_dst_f32(const tfgx_gat_backward_args* args /* host */, tfgx_stream_t stream);
 int tfgx_gat_backward_src_f32(const tfgx_gat_backward_args* args /* host */, tfgx_stream_t stream);
 

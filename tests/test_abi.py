@@ -183,3 +183,19 @@ def test_tf_shim_compiles_against_mock_headers():
     src = open(os.path.join(shim, "tfgx_tf_ops.cc")).read()
     for op in ("TfgxBuildCsrByDst", "TfgxSegmentReduce", "TfgxGatFused", "TfgxGcnNormEdges", "TfgxGemmBiasAct"):
         assert 'REGISTER_OP("{}")'.format(op) in src and 'Name("{}")'.format(op) in src
+
+
+def test_host_code_under_address_sanitizer():
+    """SURVEY.md §5 (memory-error detection): the host side of the C-ABI library built with AddressSanitizer
+    (lib/asan/libtfgx.so, device code untouched) survives a sweep over its entry points' validation / query paths —
+    including a deliberately short output buffer — without an ASAN report."""
+    from tf_geometric_amd import _build
+    rt = _build.asan_runtime()
+    if rt is None:
+        pytest.skip("clang's shared ASAN runtime is not in this ROCm image")
+    lib = _build.build_asan(verbose=False)
+    env = dict(os.environ, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1")
+    res = subprocess.run([os.sys.executable, os.path.join(ROOT, "tools", "asan_host_check.py"), lib], env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    text = res.stdout.decode()
+    assert res.returncode == 0 and "ASAN_HOST_CHECK_OK" in text and "AddressSanitizer" not in text, text[-3000:]

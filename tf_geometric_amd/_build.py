@@ -100,3 +100,45 @@ def build_c_abi_demo(force=False, verbose=True):
 
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
+
+
+ASAN_DIR = os.path.join(LIB_DIR, "asan")
+ASAN_LIB = os.path.join(ASAN_DIR, "libtfgx.so")
+
+
+def asan_runtime():
+    """Path of clang's shared AddressSanitizer runtime (must be LD_PRELOADed into an uninstrumented host process)."""
+    import glob
+    hits = sorted(glob.glob(os.path.join(ROCM, "lib", "llvm", "lib", "clang", "*", "lib", "linux",
+                                         "libclang_rt.asan-x86_64.so")))
+    return hits[-1] if hits else None
+
+
+def build_asan(force=False, verbose=True):
+    """lib/asan/libtfgx.so: the same sources with the HOST side instrumented by AddressSanitizer (the
+    memory-error detector of the plan; device code is left alone: -fno-gpu-sanitize).  Used by
+    tests/test_abi.py::test_host_code_under_address_sanitizer and tools/asan_host_check.py."""
+    os.makedirs(ASAN_DIR, exist_ok=True)
+    srcs = [os.path.join(CSRC, x) for x in SOURCES]
+    deps = srcs + [os.path.join(CSRC, "tfgx_common.h"), os.path.join(_HERE, "..", "include", "tfgx.h")]
+    if not force and os.path.exists(ASAN_LIB) and not any(_newer(d, ASAN_LIB) for d in deps):
+        return ASAN_LIB
+    flags = ["--offload-arch=gfx950", "-O1", "-g", "-std=c++17", "-fPIC", "-fsanitize=address", "-fno-gpu-sanitize",
+             "-shared-libsan", "-Wno-unused-function"]
+
+    def compile_one(src):
+        obj = os.path.join(ASAN_DIR, os.path.basename(src).replace(".hip", ".o"))
+        cmd = [HIPCC] + flags + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=6) as ex:
+        objs = list(ex.map(compile_one, srcs))
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-fsanitize=address", "-fno-gpu-sanitize", "-shared-libsan",
+           "-o", ASAN_LIB] + objs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return ASAN_LIB

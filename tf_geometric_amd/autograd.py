@@ -237,7 +237,16 @@ class _GatAttention(torch.autograd.Function):
         V2, ldv = L.row_major_2d(V.detach())
         g2, ldg = L.row_major_2d(g.contiguous())
         n, A, W = plan.n_dst, int(Q2.shape[1]), int(V2.shape[1])
-        dsum = (g2 * out).view(n, H, W // H).sum(-1).contiguous()
+        # one sweep over the destination rows: D = <dO, O> per head AND the packed rows the source pass gathers — per
+        # edge it needs the DESTINATION's dO, Q, (m, l) and D; interleaved into one row per destination, padded to whole
+        # 128-byte lines, that is one burst of P*4 bytes per edge instead of four gathers (H=8, A=8, U=64: 96 floats =
+        # 3 lines instead of 5)
+        P = -(-(W + A + 3 * H) // 32) * 32
+        pack = torch.empty((n, P), dtype=torch.float32, device=g2.device)
+        dsum = torch.empty((n, H), dtype=torch.float32, device=g2.device)
+        out2, ldo = L.row_major_2d(out)
+        L.check(lib.tfgx_gat_pack_dst_f32(L.ptr(g2), ldg, L.ptr(out2), ldo, L.ptr(Q2), ldq, L.ptr(stats), n, H, A // H,
+                                          W // H, L.ptr(pack), P, L.ptr(dsum), L.stream_ptr()), "tfgx_gat_pack_dst_f32")
         pt, t2d = _transposed(plan)
         gq, gk, gv = torch.empty_like(Q2), torch.empty_like(K2), torch.empty_like(V2)
         a = L.GatBackwardArgs()
@@ -255,15 +264,6 @@ class _GatAttention(torch.autograd.Function):
             a.drop_rate, a.drop_seed, a.drop_self_base = ctx.drop[0], ctx.drop[1], plan.num_edges
             a.edge_pos_t = t2d.data_ptr()
         L.check(lib.tfgx_gat_backward_dst_f32(ctypes.byref(a), L.stream_ptr()), "tfgx_gat_backward_dst_f32")
-        # src pass: per edge it gathers the DESTINATION's dO, Q, (m, l) and D rows.  Interleave them into one row per
-        # destination, padded to whole 128-byte lines: one burst of P*4 bytes per edge instead of four gathers
-        # (H=8, A=8, U=64: 96 floats = 3 lines instead of 5).
-        P = -(-(W + A + 3 * H) // 32) * 32
-        pack = torch.empty((n, P), dtype=torch.float32, device=g2.device)
-        pack[:, :W] = g2
-        pack[:, W:W + A] = Q2
-        pack[:, W + A:W + A + 2 * H] = stats
-        pack[:, W + A + 2 * H:W + A + 3 * H] = dsum
         a.grad_out, a.ld_grad_out = pack.data_ptr(), P
         a.q, a.ldq = pack.data_ptr() + 4 * W, P
         a.stats_ml, a.ld_stats_ml = pack.data_ptr() + 4 * (W + A), P

@@ -496,6 +496,43 @@ __device__ __forceinline__ float head_sum(float v, int lh)
     return v;
 }
 
+// One pass that prepares the GAT source pass's packed destination rows (see tfgx_gat_backward_args.ld_stats_ml):
+//   pack[r] = [ dO[r, 0..W) | Q[r, 0..A) | (m, l)[r, 0..2H) | D[r, 0..H) ],  D[r, h] = <dO[r, h, :], O[r, h, :]>
+// and the dense dsum[r, h] the destination pass reads.  Replaces a reduction and four strided copies.
+__global__ __launch_bounds__(kBlock) void gat_pack_dst_kernel(const float* __restrict__ go, int64_t ldgo,
+                                                              const float* __restrict__ o, int64_t ldo,
+                                                              const float* __restrict__ q, int64_t ldq,
+                                                              const float* __restrict__ ml, int64_t n, int H, int dv,
+                                                              int A, float* __restrict__ pack, int64_t P,
+                                                              float* __restrict__ dsum)
+{
+    const int W = H * dv;
+    int64_t t = blockIdx.x * int64_t(kBlock) + threadIdx.x;
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    const int per_row = H + (A + 2 * H + 3) / 4;       // H "head" work items + the small copies, per destination row
+    for (; t < n * per_row; t += stride) {
+        const int64_t r = t / per_row;
+        const int k = int(t - r * per_row);
+        float* pr = pack + r * P;
+        if (k < H) {                                    // one head: copy dO and reduce <dO, O>
+            const float* gp = go + r * ldgo + k * dv;
+            const float* op = o + r * ldo + k * dv;
+            float acc = 0.0f;
+            for (int i = 0; i < dv; ++i) {
+                const float gvv = gp[i];
+                acc = fmaf(gvv, op[i], acc);
+                pr[k * dv + i] = gvv;
+            }
+            dsum[r * H + k] = acc;
+            pr[W + A + 2 * H + k] = acc;
+        } else {                                        // four floats of [Q | (m, l)]
+            const int c0 = (k - H) * 4;
+            for (int c = c0; c < c0 + 4 && c < A + 2 * H; ++c)
+                pr[W + c] = c < A ? q[r * ldq + c] : ml[r * 2 * H + (c - A)];
+        }
+    }
+}
+
 template <int G, int D, bool SRC>
 __global__ __launch_bounds__(kBlock) void gat_backward_fast_kernel(const GB a)
 {
@@ -529,37 +566,67 @@ __global__ __launch_bounds__(kBlock) void gat_backward_fast_kernel(const GB a)
             linv_r = 1.0f / (a.ml[row * a.ldml + 2 * head + 1] + 1e-8f);
             d_r = a.dsum[row * a.lddsum + head];
         }
-        auto edge = [&](int64_t o, float keep) {   // o: the other endpoint (source c / destination r); keep: dropout
-            float oth_qk[D];
-            const float sc = dot_d<D>(mine_qk, (SRC ? a.q + o * a.ldq : a.k + o * a.ldk) + head * a.d, oth_qk) / a.scale;
-            float oth_v[VEC];
-            load_vec<VEC>((SRC ? a.go + o * a.ldgo : a.v + o * a.ldv) + coff, oth_v);
+        // an edge in two halves, so that U edges can have their loads in flight before the first one is consumed
+        // (the one-edge-at-a-time loop left the source pass at 42 G lines/s; the forward's 8-deep walk sustains 55)
+        struct EdgeIn {
+            float qk[D];
+            float v[VEC];
+            float m, l, dd;
+        };
+        auto edge_load = [&](int64_t o, EdgeIn& in) {   // o: the other endpoint (source c / destination r)
+            const float* pq = (SRC ? a.q + o * a.ldq : a.k + o * a.ldk) + head * a.d;
+#pragma unroll
+            for (int t = 0; t < D; ++t) in.qk[t] = pq[t];
+            load_vec<VEC>((SRC ? a.go + o * a.ldgo : a.v + o * a.ldv) + coff, in.v);
+            if (SRC) {
+                in.m = a.ml[o * a.ldml + 2 * head];
+                in.l = a.ml[o * a.ldml + 2 * head + 1];
+                in.dd = a.dsum[o * a.lddsum + head];
+            }
+        };
+        auto edge_apply = [&](const EdgeIn& in, float keep) {
+            float sc = 0.0f;
+#pragma unroll
+            for (int t = 0; t < D; ++t) sc = fmaf(mine_qk[t], in.qk[t], sc);
+            sc = sc / a.scale;
             float part = 0.0f;
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) part = fmaf(mine_v[i], oth_v[i], part);   // <dO, V> over this lane's columns
+            for (int i = 0; i < VEC; ++i) part = fmaf(mine_v[i], in.v[i], part);   // <dO, V> over this lane's columns
             const float da = head_sum<G>(part, lh);
-            float m = m_r, linv = linv_r, dd = d_r;
-            if (SRC) {
-                m = a.ml[o * a.ldml + 2 * head];
-                linv = 1.0f / (a.ml[o * a.ldml + 2 * head + 1] + 1e-8f);
-                dd = a.dsum[o * a.lddsum + head];
-            }
+            const float m = SRC ? in.m : m_r;
+            const float linv = SRC ? 1.0f / (in.l + 1e-8f) : linv_r;
+            const float dd = SRC ? in.dd : d_r;
             const float alpha = expf(sc - m) * linv;
             const float ds = alpha * (keep * da - dd) / a.scale;
 #pragma unroll
-            for (int t = 0; t < D; ++t) acc_qk[t] = fmaf(ds, oth_qk[t], acc_qk[t]);
+            for (int t = 0; t < D; ++t) acc_qk[t] = fmaf(ds, in.qk[t], acc_qk[t]);
             if (SRC) {
                 const float ak = alpha * keep;
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) acc_v[i] = fmaf(ak, oth_v[i], acc_v[i]);
+                for (int i = 0; i < VEC; ++i) acc_v[i] = fmaf(ak, in.v[i], acc_v[i]);
             }
         };
+        auto edge = [&](int64_t o, float keep) {
+            EdgeIn in;
+            edge_load(o, in);
+            edge_apply(in, keep);
+        };
+        constexpr int U = (D <= 4) ? 4 : 2;
         for (int base = s0; base < e0; base += G) {
             const int idx = base + lane;
             const int oj = (idx < e0) ? a.other[idx] : 0;
             const int pj = (a.drop.thr != 0u && a.pos && idx < e0) ? a.pos[idx] : idx;   // forward-CSR position
             const int cnt = min(G, e0 - base);
-            for (int j = 0; j < cnt; ++j)
+            int j = 0;
+            for (; j + U <= cnt; j += U) {
+                EdgeIn in[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) edge_load(int64_t(__shfl(oj, j + u, G)), in[u]);
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    edge_apply(in[u], drop_scale(a.drop, uint32_t(int64_t(__shfl(pj, j + u, G)) * a.H + head)));
+            }
+            for (; j < cnt; ++j)
                 edge(int64_t(__shfl(oj, j, G)), drop_scale(a.drop, uint32_t(int64_t(__shfl(pj, j, G)) * a.H + head)));
         }
         if (a.add_self_loop) edge(row, drop_scale(a.drop, uint32_t((a.drop.self_base + row) * a.H + head)));
@@ -806,6 +873,24 @@ static int fill_gb(const tfgx_gat_backward_args* p, GB& a)
     TFGX_REQUIRE(p->drop_rate >= 0.0f && p->drop_rate < 1.0f, "drop_rate outside [0, 1)");
     a.drop = make_drop(p->drop_rate, p->drop_seed, p->drop_self_base);
     a.pos = nullptr;
+    return TFGX_OK;
+}
+
+extern "C" int tfgx_gat_pack_dst_f32(const float* grad_out, int64_t ld_grad_out, const float* out, int64_t ldo,
+                                     const float* q, int64_t ldq, const float* stats_ml, int64_t n_dst, int32_t H,
+                                     int32_t d, int32_t dv, float* pack, int64_t ld_pack, float* dsum,
+                                     tfgx_stream_t stream)
+{
+    TFGX_RANGE();
+    TFGX_REQUIRE(n_dst >= 0 && H >= 1 && d >= 1 && dv >= 1, "bad size");
+    const int64_t W = int64_t(H) * dv, A = int64_t(H) * d;
+    TFGX_REQUIRE(ld_grad_out >= W && ldo >= W && ldq >= A && ld_pack >= W + A + 3 * int64_t(H), "leading dimension too small");
+    if (n_dst == 0) return TFGX_OK;
+    TFGX_REQUIRE(grad_out && out && q && stats_ml && pack && dsum, "null pointer");
+    const int per_row = H + int((A + 2 * H + 3) / 4);
+    gat_pack_dst_kernel<<<grid_for(n_dst * per_row, kBlock), kBlock, 0, as_stream(stream)>>>(
+        grad_out, ld_grad_out, out, ldo, q, ldq, stats_ml, n_dst, H, dv, int(A), pack, ld_pack, dsum);
+    TFGX_LAUNCH_CHECK("gat_pack_dst_kernel");
     return TFGX_OK;
 }
 
