@@ -277,6 +277,21 @@ int tfgx_segment_max_backward_push_f32(const int32_t* row_ptr, const int32_t* co
                                        const float* out, int64_t ldo, const float* g, int64_t ldg, const float* count,
                                        int64_t ldc, const int32_t* argpos, int64_t lda, float* gx, int64_t ldgx,
                                        tfgx_stream_t stream);
+/* Mask form of the same gradient: deterministic AND one gather per edge.  From the arg positions / tie counts of
+   tfgx_segment_max_with_arg_f32 a per-edge bit mask over the F columns is built (bit j of edge p: p attains the maximum
+   of column j of its row; rows with tied maxima are walked exactly so every tied edge is marked) together with
+   gn = g / count; then every SOURCE row walks its out-edges in transposed order (row_ptr_t, dst_t, w_t, and pos_t = the
+   forward CSR position of each transposed position, or NULL if identical), reads 4*ceil(F/32) mask bytes per edge and
+   gathers gn[dst, j] only where a bit is set (N*F/E columns per edge on average).  One owner per gx element, fixed
+   order: bit-reproducible.  workspace: tfgx_segment_max_backward_mask_workspace_bytes(n_dst, E, F) bytes. */
+size_t tfgx_segment_max_backward_mask_workspace_bytes(int64_t n_dst, int64_t E, int64_t F);
+int tfgx_segment_max_backward_mask_f32(const int32_t* row_ptr, const int32_t* col, const float* w /* or NULL */,
+                                       int64_t n_dst, int64_t E, const float* x, int64_t ldx, int64_t F, const float* out,
+                                       int64_t ldo, const float* g, int64_t ldg, const float* count, int64_t ldc,
+                                       const int32_t* argpos, int64_t lda, const int32_t* row_ptr_t, const int32_t* dst_t,
+                                       const float* w_t /* or NULL */, const int32_t* pos_t /* or NULL */, int64_t n_src,
+                                       float* gx, int64_t ldgx, void* workspace, size_t workspace_bytes,
+                                       tfgx_stream_t stream);
 int tfgx_segment_max_backward_f32(const int32_t* row_ptr_t, const int32_t* dst_t, const float* w_t /* or NULL */,
                                   int64_t n_src, const float* x, int64_t ldx, int64_t F, const float* out, int64_t ldo,
                                   const float* g, int64_t ldg, const float* count, int64_t ldc, float* gx, int64_t ldgx,

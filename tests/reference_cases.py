@@ -699,6 +699,63 @@ _add("pooling", _pool_inputs, lambda R, g: _pool_run(R.tfg.nn, g), None, lambda 
      exact=["max", "min", "max-default", "min-default", "topk-k5", "topk-ratio"])
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# fuzz: the core hot-path functions on six more seeded graphs each (sizes, widths, head counts, normalisation configs
+# and graph irregularities vary with the seed) — reference outputs in the same golden file
+# ---------------------------------------------------------------------------------------------------------------------
+def _fuzz_inputs(seed):
+    def make():
+        g = graph(80 + 37 * seed, 700 + 260 * seed, 8 + 4 * seed, seed=500 + seed, self_loops=2 * seed,
+                  isolated=(seed * 3) % 5)
+        rng, f = g["rng"], g["f"]
+        u = 6 + 2 * seed
+        H = [1, 2, 4, 8, 2, 4][seed]
+        A, U = H * (1 + seed % 3), H * (2 + seed % 2)
+        g.update(kernel=glorot(rng, f, u), bias=small_bias(rng, u), cfg=NORM_CFGS[(seed * 2 + 1) % len(NORM_CFGS)], H=H,
+                 wq=glorot(rng, f, A), bq=small_bias(rng, A), wk=glorot(rng, f, A), bk=small_bias(rng, A),
+                 wv=glorot(rng, f, U), b=small_bias(rng, U), ws=glorot(rng, f, u), wn=glorot(rng, f, u),
+                 b2=small_bias(rng, 2 * u), normalize=bool(seed % 2))
+        return g
+    return make
+
+
+def _fuzz_run(nn, adj_of, gcn_mapper, act, g):
+    out = {}
+    x, ei, w = g["x"], g["ei"], g["w"]
+    for red in ("sum", "mean", "max"):
+        out["agg-" + red] = _np(nn.aggregate_neighbors(x, ei, w, gcn_mapper, getattr(nn, red + "_reducer"),
+                                                       nn.identity_updater))
+    out["gcn"] = _np(nn.gcn(x, adj_of(g), g["kernel"], g["bias"], activation=act, **g["cfg"]))
+    out["gat"] = _np(nn.gat(x, ei, g["wq"], g["bq"], act, g["wk"], g["bk"], act, g["wv"], g["b"], act, num_heads=g["H"]))
+    for name in ("mean", "sum"):
+        out["sage-" + name] = _np(getattr(nn, name + "_graph_sage")(x, ei, w, g["ws"], g["wn"], g["b2"], act,
+                                                                    normalize=g["normalize"]))
+    return out
+
+
+def _fuzz_orc(o, g):
+    out = {}
+    x, ei, w = g["x"], g["ei"], g["w"]
+    for red in ("sum", "mean", "max"):
+        out["agg-" + red] = o.aggregate_neighbors(x, ei, w, o.gcn_mapper, getattr(o, red + "_reducer"), o.identity_updater)
+    out["gcn"] = o.gcn(x, ei, w, g["kernel"], g["bias"], "relu", **g["cfg"])
+    out["gat"] = o.gat(x, ei, g["wq"], g["bq"], "relu", g["wk"], g["bk"], "relu", g["wv"], g["b"], "relu", num_heads=g["H"])
+    for name in ("mean", "sum"):
+        out["sage-" + name] = getattr(o, name + "_graph_sage")(x, ei, w, g["ws"], g["wn"], g["b2"], "relu",
+                                                               normalize=g["normalize"])
+    return out
+
+
+for _seed in range(6):
+    _add("fuzz-{}".format(_seed), _fuzz_inputs(_seed),
+         lambda R, g: _fuzz_run(R.tfg.nn, lambda g_: R.tfs.SparseMatrix(g_["ei"], g_["w"], [g_["n"], g_["n"]]),
+                                R.tfg.nn.conv.gcn.gcn_mapper, R.tf.nn.relu, g),
+         _fuzz_orc,
+         lambda T, g: _fuzz_run(T.nn, lambda g_: T.SparseMatrix(g_["ei"], g_["w"], [g_["n"], g_["n"]]), T.nn.gcn_mapper,
+                                T.relu, g),
+         exact=["agg-max"])
+
+
 def by_name(name):
     for c in CASES:
         if c.name == name:

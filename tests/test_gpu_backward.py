@@ -472,7 +472,7 @@ def test_gemm_tn_weight_gradient_kernel(tfg, m, ka, n, want_bias):
 
 @pytest.mark.parametrize("f,weighted", [(8, True), (100, False), (128, True), (260, True)])
 def test_max_gradient_push_equals_pull_and_autograd(tfg, oracle, f, weighted):
-    """Push form of the segment-max gradient (arg positions saved by the training forward, N*F float atomics, rows with
+    """Mask form (default: per-edge winner bit masks, one gather per edge, deterministic) and push form of the segment-max gradient (arg positions saved by the training forward, N*F float atomics, rows with
     tied maxima walked exactly) vs the bit-reproducible pull kernel and vs float64 autograd (amax: ties share evenly, the
     TF rule).  The graph has duplicate edges and ReLU-style zero plateaus, i.e. plenty of ties, and an empty row."""
     from tf_geometric_amd import autograd as AG
@@ -486,20 +486,23 @@ def test_max_gradient_push_equals_pull_and_autograd(tfg, oracle, f, weighted):
     gout = rng.standard_normal((n, f)).astype(np.float32)
     mapper = tfg.nn.gcn_mapper if weighted else tfg.nn.identity_mapper
 
-    def run(det):
-        AG.DETERMINISTIC_MAX_GRADIENT = det
+    def run(mode):
+        AG.MAX_GRADIENT_MODE = mode
         try:
             xt = torch.tensor(x, device="cuda", requires_grad=True)
             out = tfg.nn.aggregate_neighbors(xt, ei, w, mapper, tfg.nn.max_reducer, tfg.nn.identity_updater)
             out.backward(torch.tensor(gout, device="cuda"))
             return out.detach().cpu().numpy(), xt.grad.cpu().numpy()
         finally:
-            AG.DETERMINISTIC_MAX_GRADIENT = False
+            AG.MAX_GRADIENT_MODE = "mask"
 
-    out_push, gx_push = run(False)
-    out_pull, gx_pull = run(True)
-    assert np.array_equal(out_push, out_pull)
+    out_push, gx_push = run("push")
+    out_pull, gx_pull = run("pull")
+    out_mask, gx_mask = run("mask")
+    assert np.array_equal(out_push, out_pull) and np.array_equal(out_mask, out_pull)
     assert_parity(gx_push, gx_pull, tol=2e-6, what="push vs pull max gradient")
+    assert_parity(gx_mask, gx_pull, tol=2e-6, what="mask vs pull max gradient")
+    assert np.array_equal(gx_mask, run("mask")[1])                     # the mask form is bit-reproducible
     xr = torch.tensor(x, dtype=torch.float64, requires_grad=True)
     wr = None if w is None else torch.tensor(w, dtype=torch.float64)
     ref = _ref_aggregate(xr, ei, wr, "max", n)

@@ -197,21 +197,6 @@ def test_map_reduce_gnn_layer(tfg, oracle):
     assert_parity(got, ref, what="MapReduceGNN")
 
 
-def test_golden_fixtures_through_hip(tfg, oracle):
-    """The committed vectors of tests/golden/ replayed through the HIP path."""
-    import os
-    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hot_path_small.npz"))
-    x, ei, w = g["x"], g["edge_index"], g["edge_weight"]
-    assert_parity(tfg.nn.gcn(x, tfg.SparseMatrix(ei, w, [64, 64]), g["gcn_kernel"], g["gcn_bias"], tfg.relu).cpu().numpy(),
-                  g["gcn_out"], what="golden gcn")
-    got = tfg.nn.aggregate_neighbors(x, ei, w, tfg.nn.gcn_mapper, tfg.nn.max_reducer, tfg.nn.identity_updater)
-    assert np.array_equal(got.cpu().numpy(), g["max_out"])      # max of fp32 products: bit-exact
-    assert_parity(tfg.nn.mean_graph_sage(x, ei, w, g["sage_self"], g["sage_neigh"], g["sage_bias"], tfg.relu,
-                                         normalize=True).cpu().numpy(), g["sage_out"], what="golden sage")
-    assert_parity(tfg.nn.gat(x, ei, g["gat_wq"], g["gat_bq"], tfg.relu, g["gat_wk"], g["gat_bk"], tfg.relu, g["gat_wv"],
-                             g["gat_b"], tfg.relu, num_heads=4).cpu().numpy(), g["gat_out"], what="golden gat")
-
-
 def test_gat_hub_rows_chunked_merge(tfg, oracle):
     """A destination with 6000 in-edges (and one with 700) takes the chunk + merge path; results match the oracle."""
     n, f = 1500, 10

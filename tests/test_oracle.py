@@ -2,7 +2,8 @@
 """Pins the CPU oracle (the reference ships no tests or golden vectors — SURVEY.md §4, §8c):
  (1) hand-derived known answers on the reference's own example graphs,
  (2) an independent second implementation (torch CPU index_add_/scatter_reduce, and the C restatement),
- (3) algebraic properties, (4) the committed golden fixtures under tests/golden/."""
+ (3) algebraic properties.  (The golden vectors — outputs of the reference's own Python — are in tests/golden/reference_cases.npz and
+checked by tests/test_oracle_vs_reference.py.)"""
 import ctypes
 import os
 
@@ -220,19 +221,6 @@ def test_properties(oracle):
 
 
 # ------------------------------------------------------------------ (4) committed fixtures
-def test_golden_fixtures(oracle):
-    path = os.path.join(ROOT, "tests", "golden", "hot_path_small.npz")
-    g = np.load(path)
-    x, ei, w = g["x"], g["edge_index"], g["edge_weight"]
-    assert_parity(oracle.gcn(x, ei, w, g["gcn_kernel"], g["gcn_bias"], "relu"), g["gcn_out"], tol=1e-6, what="golden gcn")
-    assert_parity(oracle.aggregate_neighbors(x, ei, w, oracle.gcn_mapper, oracle.max_reducer, oracle.identity_updater),
-                  g["max_out"], tol=0, what="golden max")
-    assert_parity(oracle.mean_graph_sage(x, ei, w, g["sage_self"], g["sage_neigh"], g["sage_bias"], "relu",
-                                         normalize=True), g["sage_out"], tol=1e-6, what="golden sage")
-    assert_parity(oracle.gat(x, ei, g["gat_wq"], g["gat_bq"], "relu", g["gat_wk"], g["gat_bk"], "relu", g["gat_wv"],
-                             g["gat_b"], "relu", num_heads=4), g["gat_out"], tol=1e-6, what="golden gat")
-
-
 def test_topk_pool_known_answers(oracle):
     """Hand-derived: source 0 holds items 1 (.5), 3 (.5), 6 (.7); source 2 holds 0 (.1), 2 (.9), 4 (.3); source 5 holds
     5.  Sources ascending, scores descending, the lower position wins the .5 tie (nn/pool/topk_pool.py:59)."""

@@ -101,6 +101,9 @@ SIGNATURES = {
     "tfgx_segment_topk": (ctypes.c_int, [_P, _P, _I64, _I64, _I32, _F32, _P, _P, _P, _SZ, _P]),
     "tfgx_segment_max_with_count_f32": (ctypes.c_int, [_P, _P, _P, _I64, _P, _I64, _I64, _P, _I64, _P, _I64, _P]),
     "tfgx_segment_max_with_arg_f32": (ctypes.c_int, [_P, _P, _P, _I64, _P, _I64, _I64, _P, _I64, _P, _I64, _P, _I64, _P]),
+    "tfgx_segment_max_backward_mask_workspace_bytes": (_SZ, [_I64, _I64, _I64]),
+    "tfgx_segment_max_backward_mask_f32": (ctypes.c_int, [_P, _P, _P, _I64, _I64, _P, _I64, _I64, _P, _I64, _P, _I64, _P,
+                                                          _I64, _P, _I64, _P, _P, _P, _P, _I64, _P, _I64, _P, _SZ, _P]),
     "tfgx_segment_max_backward_push_f32": (ctypes.c_int, [_P, _P, _P, _I64, _I64, _P, _I64, _I64, _P, _I64, _P, _I64, _P,
                                                           _I64, _P, _I64, _P, _I64, _P]),
     "tfgx_segment_max_backward_w_f32": (ctypes.c_int, [_P, _P, _P, _I64, _P, _I64, _I64, _P, _I64, _P, _I64, _P, _P]),

@@ -7,9 +7,9 @@ C-ABI kernel launches:
 
   aggregate (sum / mean, weighted)  backward wrt x  = the forward kernel on the transposed (CSR-by-source) plan
                                     backward wrt w  = tfgx_sddmm_f32
-  aggregate (max)                   training forward saves (max, tie count, arg position); backward = push of N*F float
-                                    atomics (tfgx_segment_max_backward_push_f32; ties walked exactly, TF semantics) or, with
-                                    DETERMINISTIC_MAX_GRADIENT / on hub graphs, the bit-reproducible pull kernel
+  aggregate (max)                   training forward saves (max, tie count, arg position); backward = per-edge winner masks +
+                                    one gather per edge (tfgx_segment_max_backward_mask_f32, bit-reproducible; ties walked
+                                    exactly, TF semantics); MAX_GRADIENT_MODE selects the atomics ("push") or two-gather ("pull") forms
   gat_attention                     tfgx_gat_backward_dst_f32 (dQ) + tfgx_gat_backward_src_f32 (dK, dV)
   linear (x @ W + b, relu)          forward = tfgx_gemm_bias_act_f32; d/dx = the same kernel on W^T (tfgx_transpose_f32);
                                     d/dW, d/db = tfgx_gemm_tn_f32 (MFMA reduction over the node dimension)
@@ -103,7 +103,16 @@ class _Aggregate(torch.autograd.Function):
         return None, None, gx, gw, gs, None
 
 
-DETERMINISTIC_MAX_GRADIENT = False     # True: bit-reproducible (pull) gradient of max aggregation; default: push (atomics)
+# Gradient of max aggregation (tf.math.unsorted_segment_max, ties share evenly):
+#   "mask"  (default) per-edge winner bit masks from the saved arg positions, one gather per edge, bit-reproducible
+#   "push"  N*F float atomics from the saved arg positions (summation order = arrival order)
+#   "pull"  two row gathers per edge over the transposed plan, bit-reproducible, needs nothing saved (hub graphs)
+MAX_GRADIENT_MODE = "mask"
+DETERMINISTIC_MAX_GRADIENT = False     # legacy switch: True forces "pull"
+
+
+def _max_mode():
+    return "pull" if DETERMINISTIC_MAX_GRADIENT else MAX_GRADIENT_MODE
 
 
 class _AggregateMax(torch.autograd.Function):
@@ -118,7 +127,7 @@ class _AggregateMax(torch.autograd.Function):
             # one pass: row maxima AND how many edges attain each (the tie count TF's gradient divides by)
             out = torch.empty((plan.n_dst, F), dtype=torch.float32, device=x2.device)
             count = torch.empty_like(out)
-            push_ok = (not DETERMINISTIC_MAX_GRADIENT) and F % 4 == 0 and ldx % 4 == 0 and x2.data_ptr() % 16 == 0
+            push_ok = _max_mode() in ("mask", "push") and F % 4 == 0 and ldx % 4 == 0 and x2.data_ptr() % 16 == 0
             if push_ok:       # ... and WHICH edge attains it first: the backward becomes N*F atomics instead of E*F gathers
                 argpos = torch.empty((plan.n_dst, F), dtype=torch.int32, device=x2.device)
                 L.check(lib.tfgx_segment_max_with_arg_f32(L.ptr(plan.row_ptr), L.ptr(plan.col), L.ptr(wd), plan.n_dst,
@@ -132,7 +141,7 @@ class _AggregateMax(torch.autograd.Function):
         else:   # skewed graph: the chunked forward keeps long rows off one lane group; count in the backward
             out = segment_reduce(plan, x2, L.MAX, w_csr=wd)
             count = None
-        ctx.plan, ctx.count, ctx.argpos = plan, count, argpos
+        ctx.plan, ctx.count, ctx.argpos, ctx.mode = plan, count, argpos, _max_mode()
         ctx.save_for_backward(x, w_csr, out)
         return out
 
@@ -153,7 +162,18 @@ class _AggregateMax(torch.autograd.Function):
         gx = None
         if ctx.needs_input_grad[1]:
             gx = torch.empty_like(x2)
-            if ctx.argpos is not None and ldg % 4 == 0 and g2.data_ptr() % 16 == 0:
+            aligned = ctx.argpos is not None and ldg % 4 == 0 and g2.data_ptr() % 16 == 0
+            if aligned and ctx.mode == "mask":
+                pt, t2d = _transposed(plan)
+                w_t = _transposed_weights(plan, w_csr, t2d)
+                ws_bytes = lib.tfgx_segment_max_backward_mask_workspace_bytes(plan.n_dst, plan.num_edges, F)
+                ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=x2.device)
+                L.check(lib.tfgx_segment_max_backward_mask_f32(
+                    L.ptr(plan.row_ptr), L.ptr(plan.col), L.ptr(None if w_csr is None else w_csr.detach()), plan.n_dst,
+                    plan.num_edges, L.ptr(x2), ldx, F, L.ptr(out), F, L.ptr(g2), ldg, L.ptr(count), F, L.ptr(ctx.argpos), F,
+                    L.ptr(pt.row_ptr), L.ptr(pt.col), L.ptr(w_t), L.ptr(t2d), int(x2.shape[0]), L.ptr(gx), F, L.ptr(ws),
+                    ws_bytes, L.stream_ptr()), "tfgx_segment_max_backward_mask_f32")
+            elif aligned:
                 L.check(lib.tfgx_segment_max_backward_push_f32(
                     L.ptr(plan.row_ptr), L.ptr(plan.col), L.ptr(None if w_csr is None else w_csr.detach()), plan.n_dst,
                     int(x2.shape[0]), L.ptr(x2), ldx, F, L.ptr(out), F, L.ptr(g2), ldg, L.ptr(count), F,

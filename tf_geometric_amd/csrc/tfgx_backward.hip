@@ -358,6 +358,153 @@ __global__ __launch_bounds__(kBlock) void max_backward_push_kernel(const int32_t
     }
 }
 
+// Deterministic single-gather form of the segment-max gradient ("mask" form).
+//   A (by destination, this kernel): from the arg positions / tie counts the training forward saved, write per EDGE a
+//     bit mask over the F columns — bit j of edge p is set iff edge p attains the maximum of column j of its row (rows
+//     with tied maxima are walked exactly so that EVERY tied edge is marked) — and gn = g / count per destination row.
+//     A row's mask is assembled in LDS (atomicOr on a window of 256 edges) and written out coalesced.
+//   B (by source, max_backward_mask_apply_kernel): a source row walks its out-edges in transposed order, reads the
+//     16 bytes of mask of each edge's forward position (one line request) and gathers gn[dst, j] only for the columns
+//     whose bit is set — on average N*F/E (about 2 of 100) per edge — instead of two whole rows per edge.
+// Every gx element has one owner and a fixed summation order: bit-reproducible, no atomics on global memory.
+constexpr int kMaskWindow = 256;      // edges of a row whose masks are assembled in LDS at a time
+
+template <int G>
+__global__ __launch_bounds__(kBlock) void max_mask_build_kernel(const int32_t* __restrict__ row_ptr,
+                                                                const int32_t* __restrict__ col,
+                                                                const float* __restrict__ w, int64_t n_dst,
+                                                                const float* __restrict__ x, int64_t ldx, int F,
+                                                                const float* __restrict__ out, int64_t ldo,
+                                                                const float* __restrict__ g, int64_t ldg,
+                                                                const float* __restrict__ count, int64_t ldc,
+                                                                const int32_t* __restrict__ argpos, int64_t lda,
+                                                                float* __restrict__ gn, uint32_t* __restrict__ mask,
+                                                                int MW)
+{
+    constexpr int VEC = 4;
+    constexpr int ROWS_PER_BLOCK = kBlock / G;
+    constexpr int WPB = G / 8;                                   // mask words covered by one lane group (4*G columns)
+    __shared__ uint32_t lds[ROWS_PER_BLOCK][kMaskWindow * WPB];
+    const int lane = threadIdx.x % G, grp = threadIdx.x / G;
+    const int c_raw = (blockIdx.y * G + lane) * VEC;
+    const bool cvalid = c_raw < F;
+    const int coff = cvalid ? c_raw : (F - VEC);
+    const int word0 = blockIdx.y * WPB;                         // first mask word of this column block
+    uint32_t* my = lds[grp];
+    for (int64_t r0 = int64_t(blockIdx.x) * ROWS_PER_BLOCK; r0 < n_dst; r0 += int64_t(gridDim.x) * ROWS_PER_BLOCK) {
+        const int64_t r = r0 + grp;
+        const bool rvalid = r < n_dst;
+        const int s = rvalid ? row_ptr[r] : 0, e = rvalid ? row_ptr[r + 1] : 0;
+        float gv[VEC] = {0.f, 0.f, 0.f, 0.f}, cv[VEC] = {0.f, 0.f, 0.f, 0.f}, ov[VEC] = {0.f, 0.f, 0.f, 0.f};
+        int ap[VEC] = {-1, -1, -1, -1};
+        if (rvalid && cvalid) {
+            load_vec<VEC>(g + r * ldg + coff, gv);
+            load_vec<VEC>(count + r * ldc + coff, cv);
+            load_vec<VEC>(out + r * ldo + coff, ov);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) ap[i] = argpos[r * lda + coff + i];
+            float gnv[VEC];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) gnv[i] = cv[i] > 0.0f ? gv[i] / cv[i] : 0.0f;
+            store_vec<VEC>(gn + r * int64_t(F) + coff, gnv);
+        }
+        bool tie = false;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) tie |= cvalid && cv[i] > 1.0f;
+        const unsigned long long bal = __ballot(tie);
+        const int sh = (threadIdx.x % 64) / G * G;
+        const unsigned long long gmask = (G == 64) ? ~0ull : (((1ull << G) - 1ull) << sh);
+        const bool row_has_tie = (bal & gmask) != 0ull;
+        for (int wb = s; wb < e; wb += kMaskWindow) {
+            const int wlen = min(kMaskWindow, e - wb);
+            for (int i = lane; i < wlen * WPB; i += G) my[i] = 0u;
+            __builtin_amdgcn_wave_barrier();
+            if (!row_has_tie) {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    const int p = ap[i] - wb;
+                    if (cvalid && p >= 0 && p < wlen) atomicOr(&my[p * WPB + lane / 8], 1u << ((lane % 8) * 4 + i));
+                }
+            } else {      // tied maxima somewhere in this row: mark every edge that attains a column's maximum
+                for (int k = 0; k < wlen; ++k) {
+                    const int c = col[wb + k];
+                    const float wi = w ? w[wb + k] : 1.0f;
+                    float xv[VEC];
+                    load_vec<VEC>(x + int64_t(c) * ldx + coff, xv);
+                    uint32_t nib = 0u;
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) nib |= ((w ? wi * xv[i] : xv[i]) == ov[i] && cv[i] > 0.0f) ? (1u << i) : 0u;
+                    if (cvalid && nib) atomicOr(&my[k * WPB + lane / 8], nib << ((lane % 8) * 4));
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            for (int i = lane; i < wlen * WPB; i += G) {
+                const int k = i / WPB, ww = i % WPB;
+                if (word0 + ww < MW) mask[int64_t(wb + k) * MW + word0 + ww] = my[i];
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+template <int G>
+__global__ __launch_bounds__(kBlock) void max_backward_mask_apply_kernel(const int32_t* __restrict__ row_ptr_t,
+                                                                         const int32_t* __restrict__ dst_t,
+                                                                         const float* __restrict__ w_t,
+                                                                         const int32_t* __restrict__ pos_t,
+                                                                         int64_t n_src, int F,
+                                                                         const float* __restrict__ gn,
+                                                                         const uint32_t* __restrict__ mask, int MW,
+                                                                         float* __restrict__ gx, int64_t ldgx)
+{
+    constexpr int VEC = 4;
+    constexpr int ROWS_PER_BLOCK = kBlock / G;
+    constexpr int WPB = G / 8;
+    constexpr int U = 8;
+    const int lane = threadIdx.x % G, grp = threadIdx.x / G;
+    const int c_raw = (blockIdx.y * G + lane) * VEC;
+    const bool cvalid = c_raw < F;
+    const int coff = cvalid ? c_raw : (F - VEC);
+    const int word = blockIdx.y * WPB + lane / 8;
+    const bool wvalid = word < MW;
+    const int shift = (lane % 8) * 4;
+    for (int64_t c = int64_t(blockIdx.x) * ROWS_PER_BLOCK + grp; c < n_src; c += int64_t(gridDim.x) * ROWS_PER_BLOCK) {
+        const int s = row_ptr_t[c], e = row_ptr_t[c + 1];
+        float acc[VEC] = {0.f, 0.f, 0.f, 0.f};
+        for (int base = s; base < e; base += G) {
+            const int idx = base + lane;
+            const int rj = idx < e ? dst_t[idx] : 0;
+            const int pj = idx < e ? (pos_t ? pos_t[idx] : idx) : 0;
+            const float wj = (w_t && idx < e) ? w_t[idx] : 1.0f;
+            const int cnt = min(G, e - base);
+            for (int j0 = 0; j0 < cnt; j0 += U) {
+                uint32_t nib[U];
+                int64_t rr[U];
+                float ww[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {          // U mask words in flight before the first is looked at
+                    const int j = j0 + u < cnt ? j0 + u : cnt - 1;
+                    const int64_t p = __shfl(pj, j, G);
+                    rr[u] = __shfl(rj, j, G);
+                    ww[u] = __shfl(wj, j, G);
+                    const uint32_t mw = wvalid ? mask[p * MW + word] : 0u;
+                    nib[u] = (j0 + u < cnt) ? ((mw >> shift) & 15u) : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (nib[u]) {                       // this edge attains the maximum in some of my columns
+                        const float* gp = gn + rr[u] * int64_t(F) + coff;
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i)
+                            if (nib[u] & (1u << i)) acc[i] = fmaf(ww[u], gp[i], acc[i]);
+                    }
+                }
+            }
+        }
+        if (cvalid) store_vec<VEC>(gx + c * ldgx + coff, acc);
+    }
+}
+
 __global__ void divide_kernel(const float* __restrict__ g, int64_t ldg, const float* __restrict__ cnt, int64_t ldc,
                               int64_t n, int F, float* __restrict__ gn)
 {
@@ -829,6 +976,64 @@ extern "C" int tfgx_segment_max_backward_push_f32(const int32_t* row_ptr, const 
     else TFGX_PUSH(64)
 #undef TFGX_PUSH
     TFGX_LAUNCH_CHECK("max_backward_push_kernel");
+    return TFGX_OK;
+}
+
+extern "C" size_t tfgx_segment_max_backward_mask_workspace_bytes(int64_t n_dst, int64_t E, int64_t F)
+{
+    if (n_dst < 0 || E < 0 || F < 1) return 0;
+    const size_t gn = sizeof(float) * size_t(n_dst) * size_t(F);
+    const size_t mk = sizeof(uint32_t) * size_t(E) * size_t((F + 31) / 32);
+    return (gn + 255) / 256 * 256 + mk + 256;
+}
+
+extern "C" int tfgx_segment_max_backward_mask_f32(const int32_t* row_ptr, const int32_t* col, const float* w,
+                                                  int64_t n_dst, int64_t E, const float* x, int64_t ldx, int64_t F,
+                                                  const float* out, int64_t ldo, const float* g, int64_t ldg,
+                                                  const float* count, int64_t ldc, const int32_t* argpos, int64_t lda,
+                                                  const int32_t* row_ptr_t, const int32_t* dst_t, const float* w_t,
+                                                  const int32_t* pos_t, int64_t n_src, float* gx, int64_t ldgx,
+                                                  void* workspace, size_t workspace_bytes, tfgx_stream_t stream_)
+{
+    TFGX_RANGE();
+    TFGX_REQUIRE(n_dst >= 0 && n_src >= 0 && E >= 0 && F >= 1 && ldx >= F && ldo >= F && ldg >= F && ldc >= F &&
+                     lda >= F && ldgx >= F, "bad size");
+    if (n_src == 0) return TFGX_OK;
+    TFGX_REQUIRE(row_ptr_t && gx, "null pointer");
+    TFGX_REQUIRE(n_dst == 0 || (row_ptr && x && out && g && count && argpos), "null pointer");
+    TFGX_REQUIRE(E == 0 || (col && dst_t), "null pointer");
+    TFGX_REQUIRE((w == nullptr) == (w_t == nullptr), "w and w_t go together");
+    TFGX_REQUIRE(F % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && ldg % 4 == 0 && ldc % 4 == 0 && ldgx % 4 == 0 &&
+                     aligned_to(x, 16) && aligned_to(out, 16) && aligned_to(g, 16) && aligned_to(count, 16) &&
+                     aligned_to(gx, 16),
+                 "needs 16-byte aligned rows and F % 4 == 0");
+    TFGX_REQUIRE(workspace != nullptr &&
+                     workspace_bytes >= tfgx_segment_max_backward_mask_workspace_bytes(n_dst, E, F),
+                 "workspace too small (tfgx_segment_max_backward_mask_workspace_bytes)");
+    hipStream_t stream = as_stream(stream_);
+    const int MW = int((F + 31) / 32);
+    float* gn = static_cast<float*>(workspace);
+    const size_t gn_bytes = (sizeof(float) * size_t(n_dst) * size_t(F) + 255) / 256 * 256;
+    uint32_t* mask = reinterpret_cast<uint32_t*>(static_cast<char*>(workspace) + gn_bytes);
+    const int lanes = int((F + 3) / 4);
+#define TFGX_MASK(GG)                                                                                                  \
+    {                                                                                                                  \
+        const int ny = (lanes + GG - 1) / GG;                                                                          \
+        if (n_dst > 0) {                                                                                               \
+            dim3 ga(grid_for(n_dst, kBlock / GG, 1 << 20), ny, 1);                                                     \
+            max_mask_build_kernel<GG><<<ga, kBlock, 0, stream>>>(row_ptr, col, w, n_dst, x, ldx, int(F), out, ldo, g,  \
+                                                                 ldg, count, ldc, argpos, lda, gn, mask, MW);         \
+        }                                                                                                              \
+        dim3 gb(grid_for(n_src, kBlock / GG, 1 << 20), ny, 1);                                                         \
+        max_backward_mask_apply_kernel<GG><<<gb, kBlock, 0, stream>>>(row_ptr_t, dst_t, w_t, pos_t, n_src, int(F), gn, \
+                                                                      mask, MW, gx, ldgx);                            \
+    }
+    if (lanes <= 8) TFGX_MASK(8)
+    else if (lanes <= 16) TFGX_MASK(16)
+    else if (lanes <= 32) TFGX_MASK(32)
+    else TFGX_MASK(64)
+#undef TFGX_MASK
+    TFGX_LAUNCH_CHECK("max_backward_mask kernels");
     return TFGX_OK;
 }
 

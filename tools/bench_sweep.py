@@ -308,14 +308,16 @@ def backward_section(plan, n, E, w):
     for f in [100]:
         x = torch.randn(n, f, device="cuda", requires_grad=True)
         g = torch.randn(n, f, device="cuda")
-        for name, op, ww, det in [("sum_w", L.SUM, w_csr, False), ("max (push: arg positions + atomics)", L.MAX, None, False),
-                                  ("max (pull: bit-reproducible, 2 gathers per edge)", L.MAX, None, True),
-                                  ("max weighted (push)", L.MAX, w_csr, False)]:
-            AG.DETERMINISTIC_MAX_GRADIENT = det
+        for name, op, ww, det in [("sum_w", L.SUM, w_csr, "mask"),
+                                  ("max (mask: winner bit masks, 1 gather per edge, deterministic)", L.MAX, None, "mask"),
+                                  ("max (push: arg positions + atomics)", L.MAX, None, "push"),
+                                  ("max (pull: bit-reproducible, 2 gathers per edge)", L.MAX, None, "pull"),
+                                  ("max weighted (mask)", L.MAX, w_csr, "mask")]:
+            AG.MAX_GRADIENT_MODE = det
             fwd = timeit(lambda: AG.aggregate(plan, x, op, ww), steps=5, warmup=2)
             out = AG.aggregate(plan, x, op, ww)
             ms = timeit(lambda: torch.autograd.grad(out, x, g, retain_graph=True), steps=5, warmup=2)
-            AG.DETERMINISTIC_MAX_GRADIENT = False
+            AG.MAX_GRADIENT_MODE = "mask"
             print(json.dumps({"kind": "backward", "what": "d/dx aggregate " + name, "F": f, "ms": ms,
                               "training_forward_ms": fwd}), flush=True)
         from tf_geometric_amd.plan import gemm_tn, gemm_bias_act, transpose
