@@ -10,9 +10,10 @@
 //                                            flash-attention style: alpha is recomputed from the saved (m, l)
 //   unsorted_segment_max (training forward) = tfgx_segment_max_with_count_f32: maxima and tie counts in one pass
 //   d(max)/d(edge weight)                  = tfgx_segment_max_backward_w_f32 (the SDDMM kernel with an arg-max mask)
-// Every accumulation has one owner (a destination row or a source row): deterministic, no atomics — with ONE opt-out:
-//   unsorted_segment_max gradient, push form = tfgx_segment_max_with_arg_f32 + tfgx_segment_max_backward_push_f32
-//                                            (N*F float atomics instead of 2 row gathers per edge; see the kernel).
+//   unsorted_segment_max gradient, mask form = tfgx_segment_max_with_arg_f32 + tfgx_segment_max_backward_mask_f32
+//                                            (per-edge winner bit masks, one gather per edge; the default)
+// Every accumulation has one owner (a destination row or a source row): deterministic, no atomics on global memory —
+// except the OPTIONAL push form of the max gradient (tfgx_segment_max_backward_push_f32, N*F float atomics).
 // Each entry point has a tuned kernel (lane group per row, float4 columns, the forward kernel's mapping) and a plain
 // one-lane-per-output fallback for layouts the tuned one does not cover.
 #include "tfgx_common.h"
@@ -490,15 +491,22 @@ __global__ __launch_bounds__(kBlock) void max_backward_mask_apply_kernel(const i
                     const uint32_t mw = wvalid ? mask[p * MW + word] : 0u;
                     nib[u] = (j0 + u < cnt) ? ((mw >> shift) & 15u) : 0u;
                 }
+                // gather gn[dst, j] for the set bits only — as PREDICATED loads issued back to back (no branch between
+                // them, so all of a batch's gathers are in flight together), then the FMAs in edge order
+                float val[U][VEC];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    if (nib[u]) {                       // this edge attains the maximum in some of my columns
-                        const float* gp = gn + rr[u] * int64_t(F) + coff;
+                    const float* gp = gn + rr[u] * int64_t(F) + coff;
 #pragma unroll
-                        for (int i = 0; i < VEC; ++i)
-                            if (nib[u] & (1u << i)) acc[i] = fmaf(ww[u], gp[i], acc[i]);
+                    for (int i = 0; i < VEC; ++i) {
+                        val[u][i] = 0.0f;
+                        if (nib[u] & (1u << i)) val[u][i] = gp[i];
                     }
                 }
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) acc[i] = fmaf(ww[u], val[u][i], acc[i]);
             }
         }
         if (cvalid) store_vec<VEC>(gx + c * ldgx + coff, acc);
