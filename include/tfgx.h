@@ -229,6 +229,12 @@ int tfgx_gat_fused_f32(const tfgx_gat_args* args /* host */, tfgx_stream_t strea
 
 /* out[r] = softmax-merge of n_passes raw states (pass t of row r at index t*n_dst + r) + self-loop edge + bias + act;
    q/k/v/out/H/d/dv/scale/add_self_loop/act/bias/n_dst are read from args */
+/* The general form: row i of the output merges the raw states part_idx[part_ptr[i] .. part_ptr[i+1]) — any mix of whole
+   passes and chunks of long spans.  Raw-state launches of tfgx_gat_fused_f32 (state_acc != NULL) accept two of the hub
+   fields for this: hub_chunk_row[p] = destination (Q row) of launched part p (NULL: p itself), and hub_threshold > 0 =
+   skip spans longer than that (their chunks are launched separately, with row_begin / row_end = the chunk bounds). */
+int tfgx_gat_merge_parts_f32(const tfgx_gat_args* args /* host */, const float* state_acc, const float* state_ml,
+                             const int32_t* part_ptr /* [n_dst+1] */, const int32_t* part_idx, tfgx_stream_t stream);
 int tfgx_gat_merge_passes_f32(const tfgx_gat_args* args /* host */, const float* state_acc, const float* state_ml,
                               int32_t n_passes, tfgx_stream_t stream);
 

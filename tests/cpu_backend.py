@@ -86,8 +86,16 @@ class NumpyBackend(object):
         h = x @ kernel                        # torch CPU autograd (test backend)
         return h if bias is None else h + bias
 
+    def hub_lists(self, row_begin, row_end, rp_stride, n_dst, num_edges):
+        """Same chunking policy as HipBackend.hub_lists (plan.hub_policy / build_hub_lists are plain torch)."""
+        from tf_geometric_amd.plan import build_hub_lists, hub_policy
+        thr, chunk = hub_policy(num_edges, n_dst)
+        idx = torch.arange(n_dst) * rp_stride
+        lists = build_hub_lists(row_begin[idx], row_end[idx], thr, chunk)
+        return None if lists is None else (thr,) + lists
+
     def segment_reduce(self, row_begin, row_end, rp_stride, col, w, n_dst, x, out, op, act=0, accumulate=False,
-                       self_coef=None, bias=None, mean_count=None):
+                       self_coef=None, bias=None, mean_count=None, hub=None):
         rb, re, c, wv, xv = _np(row_begin), _np(row_end), _np(col), _np(w), _np(x).astype(np.float64)
         o = _np(out)
         for r in range(n_dst):
@@ -160,25 +168,59 @@ class NumpyBackend(object):
             return out
         return res
 
-    def gat_pass(self, row_begin, row_end, rp_stride, col, n_dst, Q, K, V, num_heads, state_acc, state_ml):
+    def gat_pass(self, row_begin, row_end, rp_stride, col, n_dst, Q, K, V, num_heads, state_acc, state_ml,
+                 skip_longer_than=0, part_row=None):
         rb, re, c = _np(row_begin), _np(row_end), _np(col)
         q, k, v = _np(Q).astype(np.float64), _np(K).astype(np.float64), _np(V).astype(np.float64)
+        pr = None if part_row is None else _np(part_row)
         H = num_heads
         d, dv = q.shape[1] // H, v.shape[1] // H
         acc, ml = _np(state_acc), _np(state_ml)
-        for r in range(n_dst):
-            s, e = int(rb[r * rp_stride]), int(re[r * rp_stride])
+        for p in range(n_dst):
+            s, e = int(rb[p * rp_stride]), int(re[p * rp_stride])
+            if skip_longer_than > 0 and e - s > skip_longer_than:
+                acc[p], ml[p] = np.nan, np.nan            # must never be read: its chunks are merged instead
+                continue
+            r = p if pr is None else int(pr[p])
             cols = c[s:e]
             for h in range(H):
                 if e == s:
-                    acc[r, h * dv:(h + 1) * dv] = 0
-                    ml[r, 2 * h], ml[r, 2 * h + 1] = FLT_LOWEST, 0.0
+                    acc[p, h * dv:(h + 1) * dv] = 0
+                    ml[p, 2 * h], ml[p, 2 * h + 1] = FLT_LOWEST, 0.0
                     continue
                 sc = (k[cols, h * d:(h + 1) * d] @ q[r, h * d:(h + 1) * d]) / np.sqrt(d)
                 m = sc.max()
-                p = np.exp(sc - m)
-                acc[r, h * dv:(h + 1) * dv] = (p[:, None] * v[cols, h * dv:(h + 1) * dv]).sum(0)
-                ml[r, 2 * h], ml[r, 2 * h + 1] = m, p.sum()
+                pe = np.exp(sc - m)
+                acc[p, h * dv:(h + 1) * dv] = (pe[:, None] * v[cols, h * dv:(h + 1) * dv]).sum(0)
+                ml[p, 2 * h], ml[p, 2 * h + 1] = m, pe.sum()
+
+    def gat_merge_parts(self, Q, K, V, num_heads, n_dst, state_acc, state_ml, part_ptr, part_idx, bias, act, out):
+        q, k, v = _np(Q).astype(np.float64), _np(K).astype(np.float64), _np(V).astype(np.float64)
+        acc, ml = _np(state_acc).astype(np.float64), _np(state_ml).astype(np.float64)
+        pp, pi = _np(part_ptr), _np(part_idx)
+        H = num_heads
+        d, dv = q.shape[1] // H, v.shape[1] // H
+        res = np.zeros((n_dst, v.shape[1]))
+        for r in range(n_dst):
+            parts = pi[pp[r]:pp[r + 1]]
+            for h in range(H):
+                s_self = (q[r, h * d:(h + 1) * d] @ k[r, h * d:(h + 1) * d]) / np.sqrt(d)
+                live = [p for p in parts if ml[p, 2 * h + 1] > 0]
+                M = max([s_self] + [ml[p, 2 * h] for p in live])
+                L_ = np.exp(s_self - M)
+                O = L_ * v[r, h * dv:(h + 1) * dv]
+                for p in live:
+                    cf = np.exp(ml[p, 2 * h] - M)
+                    L_ += ml[p, 2 * h + 1] * cf
+                    O = O + acc[p, h * dv:(h + 1) * dv] * cf
+                res[r, h * dv:(h + 1) * dv] = O / (L_ + 1e-8)
+        assert np.isfinite(res).all(), "a skipped (hub) state row was merged"
+        if bias is not None:
+            res = res + _np(bias)
+        if act == 1:
+            res = np.maximum(res, 0)
+        out.copy_(torch.from_numpy(res.astype(np.float32)))
+        return out
 
     def gat_merge(self, Q, K, V, num_heads, n_dst, state_acc, state_ml, n_passes, bias, act, out):
         q, k, v = _np(Q).astype(np.float64), _np(K).astype(np.float64), _np(V).astype(np.float64)

@@ -36,9 +36,12 @@ def gat_weights():
             (rng.standard_normal(6) * 0.2).astype(np.float32))
 
 
-def run_checks(rank, world, use_gpu, skew, results, rounds=None, partitioned=False):
-    """Build the shard, run sharded GCN / mean / max / sum and return this rank's rows (as numpy)."""
+def run_checks(rank, world, use_gpu, skew, results, rounds=None, partitioned=False, hub_threshold=None):
+    """Build the shard, run sharded GCN / mean / max / sum and return this rank's rows (as numpy).  hub_threshold: force
+    the chunked long-span paths (reduce passes AND the sharded GAT's part lists) on this small graph."""
     from tf_geometric_amd.dist.sharded import ShardedGraph
+    import tf_geometric_amd.plan as P
+    P.HUB_THRESHOLD, P.HUB_CHUNK = hub_threshold, (None if hub_threshold is None else max(2, hub_threshold // 2))
     ei, x, w, k, b = make_inputs(skew=skew)
     n = x.shape[0]
     if use_gpu:
@@ -85,11 +88,13 @@ def run_checks(rank, world, use_gpu, skew, results, rounds=None, partitioned=Fal
     sg3 = make(w)
     sg3.build_gcn_norm(sym=False)                      # column degrees: reverse-exchange of a ones column
     out["gcn_sym_false"] = sg3.gcn(x_own, be.f32(k)).cpu().numpy()
+    out["gat_used_parts"] = bool(getattr(sg, "_gat_parts_cache", None))
+    P.HUB_THRESHOLD, P.HUB_CHUNK = None, None
     results[rank] = out
     return out
 
 
-def _entry(rank, world, port, use_gpu, skew, path, rounds=None, partitioned=False):
+def _entry(rank, world, port, use_gpu, skew, path, rounds=None, partitioned=False, hub_threshold=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -97,15 +102,15 @@ def _entry(rank, world, port, use_gpu, skew, path, rounds=None, partitioned=Fals
         torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     res = {}
-    run_checks(rank, world, use_gpu, skew, res, rounds=rounds, partitioned=partitioned)
+    run_checks(rank, world, use_gpu, skew, res, rounds=rounds, partitioned=partitioned, hub_threshold=hub_threshold)
     np.save(os.path.join(path, "rank{}.npy".format(rank)), np.array([res[rank]], dtype=object), allow_pickle=True)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def spawn(world, use_gpu, skew, path, port, rounds=None, partitioned=False):
+def spawn(world, use_gpu, skew, path, port, rounds=None, partitioned=False, hub_threshold=None):
     import torch.multiprocessing as mp
-    mp.spawn(_entry, args=(world, port, use_gpu, skew, path, rounds, partitioned), nprocs=world, join=True)
+    mp.spawn(_entry, args=(world, port, use_gpu, skew, path, rounds, partitioned, hub_threshold), nprocs=world, join=True)
     return [np.load(os.path.join(path, "rank{}.npy".format(r)), allow_pickle=True)[0] for r in range(world)]
 
 
@@ -145,6 +150,8 @@ def check_against_reference(parts, skew, assert_parity):
     parts = sorted(parts, key=lambda p: p["lo"])
     assert parts[0]["lo"] == 0 and all(a["hi"] == b["lo"] for a, b in zip(parts, parts[1:]))
     for key, full in ref.items():
+        if key not in parts[0]:
+            continue
         got = np.concatenate([p[key] for p in parts], axis=0)
         if key == "sage_max_pool":
             # an isolated node keeps float32 lowest() through the next GEMM (graph_sage.py:269): sums of +-1e38 terms

@@ -87,3 +87,20 @@ def test_column_chunked_halo_bounds_the_table_gloo(tmp_path):
     for p in parts:
         assert np.array_equal(p["chunked"], p["whole"])
         assert p["chunk_table_floats"] * 4 == p["full_table_floats"]
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_sharded_long_spans_are_chunked_gloo(tmp_path, world):
+    """A forced low hub threshold makes spans "long" on the small test graph: the reduce passes take their chunk lists
+    and the sharded GAT merges per-row PART LISTS (whole passes + chunks of long spans) instead of two fixed states —
+    same rows as the oracle."""
+    if world == 1:
+        res = {}
+        dist_worker.run_checks(0, 1, use_gpu=False, skew=True, results=res, hub_threshold=8)
+        parts = [res[0]]
+    else:
+        port = 29500 + random.randint(8001, 9000)
+        parts = dist_worker.spawn(world, use_gpu=False, skew=True, path=str(tmp_path), port=port, rounds=2,
+                                  hub_threshold=8)
+    assert all(p["gat_used_parts"] for p in parts)
+    dist_worker.check_against_reference(parts, True, assert_parity)

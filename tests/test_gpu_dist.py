@@ -65,3 +65,18 @@ def test_sharded_training_hip(tfg, tmp_path, world):
         assert_parity(p["db"], ref["db"], tol=1e-4, what="all-reduced d/dbias (HIP)")
         assert np.array_equal(p["chunked"], p["whole"])
         assert p["chunk_table_floats"] * 4 == p["full_table_floats"]
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_sharded_long_spans_are_chunked_hip(tfg, tmp_path, world):
+    """Forced low hub threshold on the HIP backend: chunked reduce passes, and the sharded GAT through raw-state launches
+    over parts (tfgx_gat_fused_f32 with part rows / skipped long spans) + tfgx_gat_merge_parts_f32."""
+    if world == 1:
+        res = {}
+        dist_worker.run_checks(0, 1, use_gpu=True, skew=True, results=res, hub_threshold=8)
+        parts = [res[0]]
+    else:
+        port = 39600 + random.randint(0, 2000)
+        parts = dist_worker.spawn(2, use_gpu=True, skew=True, path=str(tmp_path), port=port, rounds=2, hub_threshold=8)
+    assert all(p["gat_used_parts"] for p in parts)
+    dist_worker.check_against_reference(parts, True, assert_parity)

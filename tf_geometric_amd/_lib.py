@@ -123,6 +123,7 @@ SIGNATURES = {
     "tfgx_edge_softmax_f32": (ctypes.c_int, [_P, _P, _P, _I64, _I64, _P, _P]),
     "tfgx_gat_fused_f32": (ctypes.c_int, [ctypes.POINTER(GatArgs), _P]),
     "tfgx_gat_merge_passes_f32": (ctypes.c_int, [ctypes.POINTER(GatArgs), _P, _P, _I32, _P]),
+    "tfgx_gat_merge_parts_f32": (ctypes.c_int, [ctypes.POINTER(GatArgs), _P, _P, _P, _P, _P]),
     "tfgx_sddmm_f32": (ctypes.c_int, [_P, _P, _I64, _P, _I64, _P, _I64, _I64, _P, _P]),
     "tfgx_segment_max_count_f32": (ctypes.c_int, [_P, _P, _P, _I64, _P, _I64, _I64, _P, _I64, _P, _I64, _P]),
     "tfgx_segment_max_backward_f32": (ctypes.c_int, [_P, _P, _P, _I64, _P, _I64, _I64, _P, _I64, _P, _I64, _P, _I64,

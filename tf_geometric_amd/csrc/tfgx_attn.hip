@@ -218,6 +218,7 @@ struct GMerge {
     const float* state_ml;
     const int32_t* rows;       // [n_merge] destination ids, or NULL (identity)
     const int32_t* part_ptr;   // [n_merge+1] or NULL (-> fixed_parts passes with stride n_rows)
+    const int32_t* part_idx;   // optional with part_ptr: state index of the k-th part = part_idx[part_ptr[i] + k]
     int32_t fixed_parts;
     int64_t n_rows;            // stride between passes when part_ptr == NULL
     int64_t n_merge;
@@ -254,12 +255,14 @@ __global__ __launch_bounds__(kBlock) void gat_merge_kernel(const GMerge g)
         }
         float M = s_self;
         for (int p = 0; p < np; ++p) {
-            const int64_t part = g.part_ptr ? (g.part_ptr[i] + p) : (int64_t(p) * g.n_rows + i);
+            int64_t part = g.part_ptr ? (g.part_ptr[i] + p) : (int64_t(p) * g.n_rows + i);
+            if (g.part_idx) part = g.part_idx[part];
             M = fmaxf(M, g.state_ml[part * 2 * g.H + 2 * h]);
         }
         float Lsum = 0.0f, O = 0.0f;
         for (int p = 0; p < np; ++p) {
-            const int64_t part = g.part_ptr ? (g.part_ptr[i] + p) : (int64_t(p) * g.n_rows + i);
+            int64_t part = g.part_ptr ? (g.part_ptr[i] + p) : (int64_t(p) * g.n_rows + i);
+            if (g.part_idx) part = g.part_idx[part];
             const float mp = g.state_ml[part * 2 * g.H + 2 * h];
             const float lp = g.state_ml[part * 2 * g.H + 2 * h + 1];
             const float c = (lp > 0.0f) ? expf(mp - M) : 0.0f;     // an empty part holds (m, l) = (-FLT_MAX, 0)
@@ -368,6 +371,12 @@ extern "C" int tfgx_gat_fused_f32(const tfgx_gat_args* p, tfgx_stream_t stream_)
     TFGX_REQUIRE(a.row_end != nullptr && a.rp_stride >= 1, "bad row_begin / row_end / rp_stride");
     a.part_row = nullptr; a.state_acc = p->state_acc; a.state_ml = p->state_ml; a.hub_threshold = 0;
     a.stats_ml = p->stats_ml;
+    if (p->state_acc) {
+        // raw-state launches over arbitrary PARTS (tfgx.h): hub_chunk_row, when given, names the destination (Q row) of
+        // every launched part; hub_threshold > 0 skips spans longer than that (their chunks are launched separately)
+        a.part_row = p->hub_chunk_row;
+        a.hub_threshold = p->hub_threshold > 0 ? p->hub_threshold : 0;
+    }
     TFGX_REQUIRE(p->drop_rate >= 0.0f && p->drop_rate < 1.0f, "drop_rate outside [0, 1)");
     TFGX_REQUIRE(p->drop_rate == 0.0f || (p->state_acc == nullptr && !(p->hub_threshold > 0 && p->n_hub_rows > 0)),
                  "attention dropout cannot be combined with the raw-state / hub options");
@@ -406,7 +415,7 @@ extern "C" int tfgx_gat_fused_f32(const tfgx_gat_args* p, tfgx_stream_t stream_)
     if (rc != TFGX_OK) return rc;
     GMerge g;
     g.state_acc = p->hub_scratch_acc; g.state_ml = p->hub_scratch_ml; g.rows = p->hub_rows;
-    g.part_ptr = p->hub_chunk_ptr; g.fixed_parts = 0; g.n_rows = 0; g.n_merge = p->n_hub_rows;
+    g.part_ptr = p->hub_chunk_ptr; g.part_idx = nullptr; g.fixed_parts = 0; g.n_rows = 0; g.n_merge = p->n_hub_rows;
     g.q = p->q; g.ldq = p->ldq; g.k = p->k; g.ldk = p->ldk; g.v = p->v; g.ldv = p->ldv;
     g.out = p->out; g.ldo = p->ldo; g.H = p->H; g.d = p->d; g.dv = p->dv; g.W = int32_t(W);
     g.add_self_loop = p->add_self_loop; g.scale = p->scale; g.act = p->act; g.bias = p->bias;
@@ -427,8 +436,30 @@ extern "C" int tfgx_gat_merge_passes_f32(const tfgx_gat_args* p, const float* st
     TFGX_REQUIRE(p->q && p->k && p->v && p->out, "null pointer");
     const int64_t W = int64_t(p->H) * p->dv;
     GMerge g;
-    g.state_acc = state_acc; g.state_ml = state_ml; g.rows = nullptr; g.part_ptr = nullptr;
+    g.state_acc = state_acc; g.state_ml = state_ml; g.rows = nullptr; g.part_ptr = nullptr; g.part_idx = nullptr;
     g.fixed_parts = n_passes; g.n_rows = p->n_dst; g.n_merge = p->n_dst;
+    g.q = p->q; g.ldq = p->ldq; g.k = p->k; g.ldk = p->ldk; g.v = p->v; g.ldv = p->ldv;
+    g.out = p->out; g.ldo = p->ldo; g.H = p->H; g.d = p->d; g.dv = p->dv; g.W = int32_t(W);
+    g.add_self_loop = p->add_self_loop; g.scale = p->scale; g.act = p->act; g.bias = p->bias;
+    g.stats_ml = p->stats_ml;
+    gat_merge_kernel<<<grid_for(g.n_merge * W, kBlock), kBlock, 0, as_stream(stream)>>>(g);
+    TFGX_LAUNCH_CHECK("gat_merge_kernel");
+    return TFGX_OK;
+}
+
+extern "C" int tfgx_gat_merge_parts_f32(const tfgx_gat_args* p, const float* state_acc, const float* state_ml,
+                                        const int32_t* part_ptr, const int32_t* part_idx, tfgx_stream_t stream)
+{
+    TFGX_RANGE();
+    TFGX_REQUIRE(p != nullptr && state_acc && state_ml && part_ptr && part_idx, "bad argument");
+    TFGX_REQUIRE(p->H >= 1 && p->d >= 1 && p->dv >= 1 && p->n_dst >= 0 && p->scale > 0.0f, "bad H / d / dv / n_dst");
+    TFGX_REQUIRE(p->drop_rate == 0.0f, "attention dropout is not available on merged parts");
+    if (p->n_dst == 0) return TFGX_OK;
+    TFGX_REQUIRE(p->q && p->k && p->v && p->out, "null pointer");
+    const int64_t W = int64_t(p->H) * p->dv;
+    GMerge g;
+    g.state_acc = state_acc; g.state_ml = state_ml; g.rows = nullptr; g.part_ptr = part_ptr; g.part_idx = part_idx;
+    g.fixed_parts = 0; g.n_rows = p->n_dst; g.n_merge = p->n_dst;
     g.q = p->q; g.ldq = p->ldq; g.k = p->k; g.ldk = p->ldk; g.v = p->v; g.ldv = p->ldv;
     g.out = p->out; g.ldo = p->ldo; g.H = p->H; g.d = p->d; g.dv = p->dv; g.W = int32_t(W);
     g.add_self_loop = p->add_self_loop; g.scale = p->scale; g.act = p->act; g.bias = p->bias;

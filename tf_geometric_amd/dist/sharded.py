@@ -161,13 +161,27 @@ class HipBackend(object):
         from ..plan import gemm_bias_act
         return gemm_bias_act(a, b, bias=bias, act=act, out=out)
 
-    def gat_pass(self, row_begin, row_end, rp_stride, col, n_dst, Q, K, V, num_heads, state_acc, state_ml):
-        """Raw online-softmax state of every destination over the given edge span (tfgx_gat_fused_f32, state mode)."""
+    def gat_pass(self, row_begin, row_end, rp_stride, col, n_dst, Q, K, V, num_heads, state_acc, state_ml,
+                 skip_longer_than=0, part_row=None):
+        """Raw online-softmax state of every launched part over its edge span (tfgx_gat_fused_f32, state mode).  A part
+        is a destination row (part_row None) or a chunk of one (part_row[p] = its destination); spans longer than
+        skip_longer_than (> 0) are left to the chunk launch."""
         from ..nn.conv.gat import gat_args
         a, _, keep = gat_args(Q, K, V, num_heads, n_dst, col, add_self_loop=False, out=state_acc)
         a.row_begin, a.row_end, a.rp_stride = row_begin.data_ptr(), row_end.data_ptr(), rp_stride
         a.state_acc, a.state_ml = state_acc.data_ptr(), state_ml.data_ptr()
+        a.hub_threshold = int(skip_longer_than)
+        if part_row is not None:
+            a.hub_chunk_row = part_row.data_ptr()
         L.check(self.lib.tfgx_gat_fused_f32(ctypes.byref(a), L.stream_ptr()), "tfgx_gat_fused_f32")
+
+    def gat_merge_parts(self, Q, K, V, num_heads, n_dst, state_acc, state_ml, part_ptr, part_idx, bias, act, out):
+        from ..nn.conv.gat import gat_args
+        a, out, keep = gat_args(Q, K, V, num_heads, n_dst, self.empty(1, torch.int32), add_self_loop=True, bias=bias,
+                                act=act, out=out)
+        L.check(self.lib.tfgx_gat_merge_parts_f32(ctypes.byref(a), L.ptr(state_acc), L.ptr(state_ml), L.ptr(part_ptr),
+                                                  L.ptr(part_idx), L.stream_ptr()), "tfgx_gat_merge_parts_f32")
+        return out
 
     def gat_merge(self, Q, K, V, num_heads, n_dst, state_acc, state_ml, n_passes, bias, act, out):
         from ..nn.conv.gat import gat_args
@@ -696,18 +710,86 @@ class ShardedGraph(object):
         be.gemm_bias_act(x_own, kernel, out=self.own_rows(table)[:, A:])
         handle = self.exchange_start(table)
         K, V = table[:, :A], table[:, A:]
-        s_acc = be.empty((2 * self.n_own, U))
-        s_ml = be.empty((2 * self.n_own, 2 * num_heads))
         K1, rpk = self.n_class, self.rpk
-        be.gat_pass(rpk, rpk[1:], K1, self.col, self.n_own, Q, K, V, num_heads, s_acc[:self.n_own], s_ml[:self.n_own])
-        self.exchange_finish(handle)
-        n_passes = 1
-        if K1 > 1:      # all halo classes are one contiguous span per row: [rpk[r*K1+1], rpk[(r+1)*K1])
-            be.gat_pass(rpk[1:], rpk[K1:], K1, self.col, self.n_own, Q, K, V, num_heads, s_acc[self.n_own:],
-                        s_ml[self.n_own:])
-            n_passes = 2
+        spans = [(rpk, rpk[1:])] + ([(rpk[1:], rpk[K1:])] if K1 > 1 else [])   # own-source span | all halo classes
+        plan = self._gat_parts(spans)
         out = be.empty((self.n_own, U))
-        return be.gat_merge(Q, K, V, num_heads, self.n_own, s_acc, s_ml, n_passes, bias, act, out)
+        if plan is None:        # near-regular shard: two raw states per row, fixed-stride merge
+            s_acc = be.empty((2 * self.n_own, U))
+            s_ml = be.empty((2 * self.n_own, 2 * num_heads))
+            be.gat_pass(rpk, rpk[1:], K1, self.col, self.n_own, Q, K, V, num_heads, s_acc[:self.n_own], s_ml[:self.n_own])
+            self.exchange_finish(handle)
+            n_passes = 1
+            if K1 > 1:      # all halo classes are one contiguous span per row: [rpk[r*K1+1], rpk[(r+1)*K1])
+                be.gat_pass(rpk[1:], rpk[K1:], K1, self.col, self.n_own, Q, K, V, num_heads, s_acc[self.n_own:],
+                            s_ml[self.n_own:])
+                n_passes = 2
+            return be.gat_merge(Q, K, V, num_heads, self.n_own, s_acc, s_ml, n_passes, bias, act, out)
+        # skewed shard: long spans of either pass are cut into chunks (as single-GPU hub rows are); every row then merges
+        # a LIST of parts — whole passes and chunks — named by (part_ptr, part_idx)
+        n_states = plan["n_states"]
+        s_acc = be.empty((n_states, U))
+        s_ml = be.empty((n_states, 2 * num_heads))
+        for t, (rb, re) in enumerate(spans):
+            if t == 1:
+                self.exchange_finish(handle)
+            lo = t * self.n_own
+            hub = plan["hub"][t]
+            be.gat_pass(rb, re, K1, self.col, self.n_own, Q, K, V, num_heads, s_acc[lo:lo + self.n_own],
+                        s_ml[lo:lo + self.n_own], skip_longer_than=hub[0] if hub is not None else 0)
+            if hub is not None:
+                thr, hub_rows, chunk_ptr, chunk_begin, chunk_end, chunk_row = hub
+                c0, nc = plan["chunk_off"][t], int(chunk_begin.shape[0])
+                be.gat_pass(chunk_begin, chunk_end, 1, self.col, nc, Q, K, V, num_heads, s_acc[c0:c0 + nc],
+                            s_ml[c0:c0 + nc], part_row=chunk_row)
+        if len(spans) == 1:
+            self.exchange_finish(handle)
+        return be.gat_merge_parts(Q, K, V, num_heads, self.n_own, s_acc, s_ml, plan["part_ptr"], plan["part_idx"], bias,
+                                  act, out)
+
+    def _gat_parts(self, spans):
+        """Part lists for the sharded GAT on a skewed shard, or None when no span of either pass is long.  State rows:
+        [pass 0 rows | pass 1 rows | pass 0 chunks | pass 1 chunks]; row r merges, per pass, either its whole-pass state
+        or the states of its chunks."""
+        if getattr(self, "_gat_parts_cache", None) is not None:
+            return self._gat_parts_cache or None
+        be = self.backend
+        hub_fn = getattr(be, "hub_lists", None)
+        hubs = [hub_fn(rb, re, self.n_class, self.n_own, self.num_edges) if hub_fn else None for rb, re in spans]
+        if all(h is None for h in hubs):
+            self._gat_parts_cache = False
+            return None
+        dev = self.row_ptr.device
+        n, T = self.n_own, len(spans)
+        cnt = torch.ones((T, n), dtype=torch.int64, device=dev)
+        chunk_off, off = [], T * n
+        for t, h in enumerate(hubs):
+            chunk_off.append(off)
+            if h is not None:
+                _, hub_rows, chunk_ptr, chunk_begin, _, _ = h
+                cnt[t, hub_rows.long()] = (chunk_ptr[1:] - chunk_ptr[:-1]).long()
+                off += int(chunk_begin.shape[0])
+        per_row = cnt.sum(0)
+        part_ptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+        part_ptr[1:] = torch.cumsum(per_row, 0)
+        part_idx = torch.empty(int(part_ptr[-1].item()), dtype=torch.int64, device=dev)
+        start = part_ptr[:-1].clone()
+        for t, h in enumerate(hubs):
+            whole = torch.ones(n, dtype=torch.bool, device=dev)
+            if h is not None:
+                _, hub_rows, chunk_ptr, _, _, _ = h
+                hr = hub_rows.long()
+                whole[hr] = False
+                nch = (chunk_ptr[1:] - chunk_ptr[:-1]).long()
+                owner = torch.repeat_interleave(torch.arange(hr.shape[0], device=dev), nch)
+                k = torch.arange(int(nch.sum().item()), device=dev) - chunk_ptr[:-1].long()[owner]
+                part_idx[start[hr][owner] + k] = chunk_off[t] + chunk_ptr[:-1].long()[owner] + k
+            rows = torch.nonzero(whole).flatten()
+            part_idx[start[rows]] = t * n + rows
+            start = start + cnt[t]
+        self._gat_parts_cache = dict(hub=hubs, chunk_off=chunk_off, n_states=off, part_ptr=part_ptr.to(torch.int32).contiguous(),
+                                     part_idx=part_idx.to(torch.int32).contiguous())
+        return self._gat_parts_cache
 
     # ------------------------------------------------------------------ GraphSAGE reduce
     def neighbor_reduce(self, x_own, op, weighted=True):
