@@ -642,6 +642,32 @@ def extras(tfg, L, synthetic, x, ei, n, e, f, cache):
         opt.step()
 
     res["gcn_2layer_train_step_ms"] = _time(full_step, steps=5, warmup=2)
+    # BASELINE configs[3]: GraphSAGE mean / max-pool aggregators (units 256, concat, as demo/demo_graph_sage.py:29-30):
+    # one full-batch training step of a 2-layer mean model, and forward + backward of one max-pool layer
+    s0, s1 = tfg.layers.MeanGraphSage(256, activation=tfg.relu), tfg.layers.MeanGraphSage(40, activation=None)
+    s0.trainable(True)
+    s1.trainable(True)
+    with torch.no_grad():
+        s1([s0([x, ei, w1], cache=cache), ei, w1], cache=cache)
+    opt2 = torch.optim.Adam(s0.parameters() + s1.parameters(), lr=1e-2)
+
+    def sage_step():
+        opt2.zero_grad(set_to_none=True)
+        logits = s1([s0([x, ei, w1], cache=cache), ei, w1], cache=cache)
+        torch.nn.functional.cross_entropy(logits[idx], labels).backward()
+        opt2.step()
+
+    res["mean_sage_2layer_train_step_ms"] = _time(sage_step, steps=4, warmup=2)
+    mpt = tfg.layers.MaxPoolGraphSage(64)
+    mpt._maybe_build([x])
+    mpt.trainable(True)
+
+    def maxpool_fwd_bwd():
+        for p_ in mpt.parameters():
+            p_.grad = None
+        mpt([x, ei, w1], cache=cache).sum().backward()
+
+    res["maxpool_sage_layer_units64_fwd_bwd_ms"] = _time(maxpool_fwd_bwd, steps=4, warmup=2)
     from tf_geometric_amd.plan import gemm_bias_act
     k = L.as_f32(synthetic.glorot_uniform(f, 256))
     ms = _time(lambda: gemm_bias_act(x, k))

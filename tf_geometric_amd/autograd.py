@@ -161,7 +161,7 @@ class _AggregateMax(torch.autograd.Function):
                     "tfgx_segment_max_count_f32")
         gx = None
         if ctx.needs_input_grad[1]:
-            gx = torch.empty_like(x2)
+            gx = torch.empty((int(x2.shape[0]), F), dtype=torch.float32, device=x2.device)   # dense: ld = F below
             aligned = ctx.argpos is not None and ldg % 4 == 0 and g2.data_ptr() % 16 == 0
             if aligned and ctx.mode == "mask":
                 pt, t2d = _transposed(plan)

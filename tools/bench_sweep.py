@@ -210,7 +210,18 @@ def reddit_section(quick):
         ms_att = timeit(lambda: gat_attention(plan, Q, K, V, H))
         Eagg = E + n
         balg = Eagg * (4 * A + 4 * U + 4) + n * 4 * (A + U) + 4 * (n + 1)
+        # one training step of the layer: forward + backward through the fused attention kernels and the MFMA GEMMs
+        tl = tfg.layers.GAT(U, attention_units=A, num_heads=H, activation=tfg.relu)
+        tl._maybe_build([x])
+        tl.trainable(True)
+
+        def fwd_bwd():
+            for p_ in tl.parameters():
+                p_.grad = None
+            tl([x, ei], cache=cache).sum().backward()
+        ms_train = timeit(fwd_bwd, steps=4, warmup=2)
         print(json.dumps({"kind": "reddit_gat", "N": n, "E": E, "F": f, "H": H, "A": A, "U": U, "layer_ms": ms_layer,
+                          "layer_fwd_bwd_ms": ms_train,
                           "attention_ms": ms_att, "attention_GBps_alg": balg / ms_att / 1e6,
                           "attention_frac_of_8TBps": balg / ms_att / 1e6 / 8000,
                           "Gedges_per_s_layer": E / ms_layer / 1e6}), flush=True)
