@@ -816,10 +816,28 @@ class ShardedGraph(object):
         return torch.relu(h) if act == L.ACT_RELU else h
 
     def graph_sage(self, x_own, self_kernel, neighbor_kernel, bias=None, act=L.ACT_NONE, concat=True, op=L.MEAN):
-        """Sharded mean_graph_sage / sum_graph_sage (nn/conv/graph_sage.py:9-115): raw x rows travel once, the
-        weighted mean / sum over in-edges overlaps the exchange, the two GEMMs are local."""
-        reduced = self.neighbor_reduce(x_own, op, weighted=True)
-        return self._sage_combine(x_own, reduced, self_kernel, neighbor_kernel, bias, act, concat)
+        """Sharded mean_graph_sage / sum_graph_sage (nn/conv/graph_sage.py:9-115): the weighted mean / sum over in-edges
+        overlaps the exchange, the GEMMs are local.  mean and sum are linear, so when the neighbour projection is
+        narrower than the input (units/2 < F: every hidden layer) it runs FIRST and only ku-wide rows travel and are
+        gathered — the halo shrinks by F / ku; otherwise raw x rows travel once."""
+        be = self.backend
+        F, ku_x, ku_n = int(x_own.shape[1]), int(self_kernel.shape[1]), int(neighbor_kernel.shape[1])
+        if not ku_n < F:
+            reduced = self.neighbor_reduce(x_own, op, weighted=True)
+            return self._sage_combine(x_own, reduced, self_kernel, neighbor_kernel, bias, act, concat)
+        table = self.alloc_table(ku_n)
+        be.gemm_bias_act(x_own, neighbor_kernel, out=self.own_rows(table))
+        w = "plan" if self.w is not None else None
+        if concat:
+            h = be.empty((self.n_own, ku_x + ku_n))
+            be.gemm_bias_act(x_own, self_kernel, bias=None if bias is None else bias[:ku_x], act=act, out=h[:, :ku_x])
+            nb = self.aggregate(table, op, w=w, bias=None if bias is None else bias[ku_x:].contiguous(), act=act)
+            h[:, ku_x:] = nb
+            return h
+        h = be.gemm_bias_act(x_own, self_kernel) + self.aggregate(table, op, w=w)
+        if bias is not None:
+            h = h + bias
+        return torch.relu(h) if act == L.ACT_RELU else h
 
     def pool_graph_sage(self, x_own, self_kernel, neighbor_mlp_kernel, neighbor_kernel, neighbor_mlp_bias=None,
                         bias=None, act=L.ACT_NONE, concat=True, op=L.MAX):

@@ -67,18 +67,62 @@ def _neighbor_reduce(x, edge_index, edge_weight, op, cache):
     return x, segment_reduce(plan, static_rows(x, plan, cache), op, w_csr=w_csr)
 
 
+def _self_neighbor_sage(x, edge_index, edge_weight, self_kernel, neighbor_kernel, bias, activation, concat, normalize,
+                        op, cache):
+    """mean / sum GraphSAGE (reference :9-115).  Both reducers are linear, so
+    reduce(w * x[col]) @ W_neigh == reduce(w * (x @ W_neigh)[col]): when the neighbour projection is NARROWER than the
+    input (hidden layers: 256 -> units/2) the GEMM runs first and the gather moves 4*ku instead of 4*F bytes per edge —
+    the same move as GCN's narrow-side aggregation; bias and activation ride in the aggregation's
+    epilogue and the result lands directly in its half of the output.  Same value up to fp32 re-association."""
+    x = L.as_f32(x)
+    wn = L.as_f32(neighbor_kernel)
+    ws = L.as_f32(self_kernel)
+    F, ku_x, ku_n = int(x.shape[1]), int(ws.shape[1]), int(wn.shape[1])
+    if not ku_n < F:
+        x, reduced = _neighbor_reduce(x, edge_index, edge_weight, op, cache)
+        return _combine(ws, x, wn, reduced, bias, activation, concat, normalize)
+    n = int(x.shape[0])
+    plan = CsrPlan.from_cache(edge_index, n, n, cache)
+    w_csr = AG.edge_attr_csr(plan, edge_weight, cache)
+    act, post = _resolve_act(activation)
+    if AG.needs_grad(x, edge_weight, ws, wn, bias):
+        a = AG.linear(x, ws)
+        b = AG.aggregate(plan, AG.linear(x, wn), op, w_csr)
+        h = torch.cat([a, b], dim=1) if concat else a + b
+        if bias is not None:
+            h = h + L.as_f32(bias)
+        h = AG.apply_activation(h, act, post)
+        if normalize:
+            h = h * torch.rsqrt(torch.clamp((h * h).sum(-1, keepdim=True), min=1e-12))
+        return h
+    bias_t = None if bias is None else L.as_f32(bias).contiguous()
+    z = gemm_bias_act(x, wn)
+    if concat:
+        h = torch.empty((n, ku_x + ku_n), dtype=torch.float32, device=x.device)
+        gemm_bias_act(x, ws, bias=None if bias_t is None else bias_t[:ku_x], act=act, out=h[:, :ku_x])
+        segment_reduce(plan, z, op, w_csr=w_csr, out=h[:, ku_x:], act=act,
+                       bias=None if bias_t is None else bias_t[ku_x:].contiguous())
+    else:
+        h = segment_reduce(plan, z, op, w_csr=w_csr, add_x=gemm_bias_act(x, ws), bias=bias_t, act=act)
+    if post is not None:
+        h = post(h)
+    if normalize:
+        h = l2_normalize_rows_(h.contiguous())
+    return h
+
+
 def mean_graph_sage(x, edge_index, edge_weight, self_kernel, neighbor_kernel, bias=None, activation=None,
                     concat=True, normalize=False, cache=None):
     """Reference: graph_sage.py:9-60."""
-    x, reduced = _neighbor_reduce(x, edge_index, edge_weight, L.MEAN, cache)
-    return _combine(L.as_f32(self_kernel), x, L.as_f32(neighbor_kernel), reduced, bias, activation, concat, normalize)
+    return _self_neighbor_sage(x, edge_index, edge_weight, self_kernel, neighbor_kernel, bias, activation, concat,
+                               normalize, L.MEAN, cache)
 
 
 def sum_graph_sage(x, edge_index, edge_weight, self_kernel, neighbor_kernel, bias=None, activation=None,
                    concat=True, normalize=False, cache=None):
     """Reference: graph_sage.py:64-115."""
-    x, reduced = _neighbor_reduce(x, edge_index, edge_weight, L.SUM, cache)
-    return _combine(L.as_f32(self_kernel), x, L.as_f32(neighbor_kernel), reduced, bias, activation, concat, normalize)
+    return _self_neighbor_sage(x, edge_index, edge_weight, self_kernel, neighbor_kernel, bias, activation, concat,
+                               normalize, L.SUM, cache)
 
 
 def gcn_graph_sage(x, edge_index, edge_weight, kernel, bias=None, activation=None, normalize=False, cache=None):
