@@ -91,6 +91,18 @@ def tagcn(x, edge_index, edge_weight, k, kernel, bias=None, activation=None, ren
     """concat(x, A x, ..., A^k x) @ kernel  (reference: tagcn.py:10-51; sparse x is densified first, :32-35)."""
     x = _features(x, densify=True)
     normed = _normed(x, edge_index, edge_weight, cache, renorm=renorm, improved=improved)
+    F, units = int(x.shape[1]), int(kernel.shape[1])
+    if units < F:
+        # [x | A x | ... | A^k x] @ kernel = sum_i A^i (x @ W_i), W_i = rows [i*F, (i+1)*F) of the kernel: ONE GEMM
+        # x @ [W_0 | ... | W_k], then Horner's rule y_0 + A (y_1 + A (... + A y_k)) — the k propagations gather
+        # `units`-wide rows instead of F-wide ones (same value up to fp32 re-association; DESIGN.md §2.8)
+        kt = L.as_f32(kernel)
+        wcat = kt.view(k + 1, F, units).permute(1, 0, 2).reshape(F, (k + 1) * units).contiguous()
+        y = _dense(x, wcat)
+        acc = y[:, k * units:(k + 1) * units]
+        for i in range(k - 1, -1, -1):
+            acc = y[:, i * units:(i + 1) * units] + _prop(normed.plan, acc.contiguous(), normed.w_csr, normed.self_coef)
+        return _finish(acc, bias, activation)
     xs = [x]
     for _ in range(k):
         xs.append(_prop(normed.plan, xs[-1], normed.w_csr, normed.self_coef))    # :37-40
