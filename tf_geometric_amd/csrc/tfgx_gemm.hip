@@ -497,15 +497,30 @@ __global__ __launch_bounds__(kTnThreads) void gemm_tn_kernel(const float* __rest
             }
         }
         __syncthreads();
-        for (int st = 0; st < R / 2; ++st) {
-            const float* xr = Xs + (2 * st + kh) * ka_pad + l31;
-            const float* gr = Gs + (2 * st + kh) * ng_pad + l31;
+        // TFGX_TN_BATCH steps at a time
+        // is not waiting on one ds_read round trip per instruction
+#ifndef TFGX_TN_BATCH
+#define TFGX_TN_BATCH 1
+#endif
+        for (int st0 = 0; st0 < R / 2; st0 += TFGX_TN_BATCH) {
+            float av[TFGX_TN_BATCH][TPW], bv[TFGX_TN_BATCH][TPW];
 #pragma unroll
-            for (int j = 0; j < TPW; ++j) {
-                if (tv[j]) {                        // wave-uniform
-                    const float a = xr[ti[j] * 32];
-                    const float b = gr[tn[j] * 32];
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
+            for (int u = 0; u < TFGX_TN_BATCH; ++u) {
+                const int st = st0 + u < R / 2 ? st0 + u : R / 2 - 1;
+                const float* xr = Xs + (2 * st + kh) * ka_pad + l31;
+                const float* gr = Gs + (2 * st + kh) * ng_pad + l31;
+#pragma unroll
+                for (int j = 0; j < TPW; ++j) {
+                    av[u][j] = xr[ti[j] * 32];
+                    bv[u][j] = gr[tn[j] * 32];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < TFGX_TN_BATCH; ++u) {
+                if (st0 + u < R / 2) {
+#pragma unroll
+                    for (int j = 0; j < TPW; ++j)
+                        if (tv[j]) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][j], bv[u][j], acc[j], 0, 0, 0);
                 }
             }
         }
@@ -543,6 +558,9 @@ __global__ void tn_reduce_kernel(const float* __restrict__ parts, int n_parts, i
     }
 }
 
+#ifndef TFGX_TN_WGS
+#define TFGX_TN_WGS 512
+#endif
 struct TnCfg {
     int ka_pad, tn_group, groups, R, wgs;
     size_t part_floats, lds_bytes;
@@ -558,7 +576,7 @@ inline TnCfg tn_config(int64_t M, int64_t Ka, int64_t N, bool want_bias)
     c.R = 32;
     while (c.R > 4 && sizeof(float) * size_t(c.R) * size_t(c.ka_pad + c.tn_group * 32) > 72 * 1024) c.R /= 2;
     const int64_t slabs = (M + c.R - 1) / c.R;
-    c.wgs = int(slabs < 512 ? (slabs < 1 ? 1 : slabs) : 512);
+    c.wgs = int(slabs < TFGX_TN_WGS ? (slabs < 1 ? 1 : slabs) : TFGX_TN_WGS);
     c.part_floats = size_t(Ka + (want_bias ? 1 : 0)) * size_t(c.tn_group) * 32;
     c.lds_bytes = sizeof(float) * size_t(c.R) * size_t(c.ka_pad + c.tn_group * 32);
     return c;
