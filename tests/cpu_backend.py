@@ -95,7 +95,7 @@ class NumpyBackend(object):
         return None if lists is None else (thr,) + lists
 
     def segment_reduce(self, row_begin, row_end, rp_stride, col, w, n_dst, x, out, op, act=0, accumulate=False,
-                       self_coef=None, bias=None, mean_count=None, hub=None):
+                       self_coef=None, bias=None, mean_count=None, hub=None, split=None):
         rb, re, c, wv, xv = _np(row_begin), _np(row_end), _np(col), _np(w), _np(x).astype(np.float64)
         o = _np(out)
         for r in range(n_dst):

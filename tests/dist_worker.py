@@ -197,6 +197,23 @@ def run_training(rank, world, use_gpu, skew, rounds=None, num_splits=None):
     m = sg.aggregate_trainable(x2, 1)
     (m * be.f32(_loss_coef(n, x.shape[1])[sg.own_lo:sg.own_hi])).sum().backward()
     res["dx_mean"] = x2.grad.cpu().numpy()
+    # static input features: the halo is exchanged once, later aggregations run without any exchange
+    st = sg.prepare_static_features(be.f32(x[sg.own_lo:sg.own_hi]))
+    calls = {"n": 0}
+    real_start = sg.exchange_start
+
+    def counting_start(table):
+        calls["n"] += 1
+        return real_start(table)
+    sg.exchange_start = counting_start
+    a1 = sg.aggregate_static(st, 0, w=sg.norm_w, self_coef=sg.self_coef)
+    a2 = sg.aggregate_static(st, 1)
+    sg.exchange_start = real_start
+    t_ref = sg.alloc_table(x.shape[1])
+    sg.own_rows(t_ref).copy_(be.f32(x[sg.own_lo:sg.own_hi]))
+    res["static_sum"], res["static_sum_ref"] = a1.cpu().numpy(), sg.aggregate(t_ref, 0, w=sg.norm_w, self_coef=sg.self_coef).cpu().numpy()
+    res["static_mean"], res["static_mean_ref"] = a2.cpu().numpy(), sg.neighbor_reduce(be.f32(x[sg.own_lo:sg.own_hi]), 1).cpu().numpy()
+    res["static_exchanges"] = calls["n"]
     if num_splits:
         chunked = sg.aggregate_chunked(be.f32(x[sg.own_lo:sg.own_hi]), num_splits, w=sg.norm_w, self_coef=sg.self_coef,
                                        bias=be.f32(np.arange(x.shape[1], dtype=np.float32) * 0.01), act=1)

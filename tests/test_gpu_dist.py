@@ -65,6 +65,8 @@ def test_sharded_training_hip(tfg, tmp_path, world):
         assert_parity(p["db"], ref["db"], tol=1e-4, what="all-reduced d/dbias (HIP)")
         assert np.array_equal(p["chunked"], p["whole"])
         assert p["chunk_table_floats"] * 4 == p["full_table_floats"]
+        assert np.array_equal(p["static_sum"], p["static_sum_ref"]) and np.array_equal(p["static_mean"], p["static_mean_ref"])
+        assert p["static_exchanges"] == 0
 
 
 @pytest.mark.parametrize("world", [1, 2])

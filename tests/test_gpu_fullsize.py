@@ -316,3 +316,23 @@ def test_papers_shard_sampled_rows_match_oracle(tfg, oracle):
     assert_parity(out[rows].cpu().numpy(), ref, what="papers100M-shard sum on sampled rows")
     del x, out, plan, ei, w
     torch.cuda.empty_cache()
+
+
+def test_products_shard_static_features_use_the_edge_tail_layout(tfg, products):
+    """ShardedGraph.prepare_static_features (the shard-table form of the static-feature opt-in): at products shape the
+    table is kept in the edge-resident-tail layout (in the shard's own CSR order, incl. its per-class edge partition) and
+    aggregate_static returns the same bits as the plain pass."""
+    from tf_geometric_amd.dist.sharded import ShardedGraph
+    L = tfg._lib
+    p = products
+    sg = ShardedGraph.from_global(p["ei"], p["n"], edge_weight=p["w"])
+    sg.build_gcn_norm()
+    st = sg.prepare_static_features(p["x"])
+    assert st["split"] is not None and st["split"][2].shape == (sg.num_edges, 4)
+    assert st["bytes"] == 4 * (2 * p["n"] * 100 + sg.num_edges * 4)
+    table = sg.alloc_table(p["f"])
+    sg.own_rows(table).copy_(p["x"])
+    plain = sg.aggregate(table, L.SUM, w=sg.norm_w, self_coef=sg.self_coef)
+    fast = sg.aggregate_static(st, L.SUM, w=sg.norm_w, self_coef=sg.self_coef)
+    assert torch.equal(plain, fast)
+    assert torch.equal(sg.aggregate(table, L.MEAN), sg.aggregate_static(st, L.MEAN))

@@ -117,8 +117,21 @@ class HipBackend(object):
         lists = build_hub_lists(row_begin[idx], row_end[idx], thr, chunk)
         return None if lists is None else (thr,) + lists
 
+    def split_rows(self, table, col):
+        """Static source table -> (main, tail, edge_tail): the edge-resident-tail layout of DESIGN.md §2.1 for a shard's
+        [own | halo] table, edge_tail in THIS shard's CSR order; None when the width does not call for it."""
+        from ..plan import SplitRows, gather_rows
+        n, F = int(table.shape[0]), int(table.shape[1])
+        if not SplitRows.wanted(n, F):
+            return None
+        sp = SplitRows.from_dense(table)
+        return sp.main, sp.tail, gather_rows(sp.tail, col)
+
     def segment_reduce(self, row_begin, row_end, rp_stride, col, w, n_dst, x, out, op, act=L.ACT_NONE,
-                       accumulate=False, self_coef=None, bias=None, mean_count=None, hub=None):
+                       accumulate=False, self_coef=None, bias=None, mean_count=None, hub=None, split=None):
+        F_total = int(x.shape[1])
+        if split is not None:
+            x = split[0]
         x, ldx = L.row_major_2d(x)
         _, ldo = L.row_major_2d(out)
         a = L.ReduceArgs()
@@ -126,7 +139,12 @@ class HipBackend(object):
         a.col = col.data_ptr()
         a.w = 0 if w is None else w.data_ptr()
         a.n_dst = n_dst
-        a.x, a.ldx, a.F = x.data_ptr(), ldx, int(x.shape[1])
+        a.x, a.ldx, a.F = x.data_ptr(), ldx, F_total
+        if split is not None:
+            main, tail, edge_tail = split
+            a.x_tail, a.ld_tail, a.f_main = tail.data_ptr(), int(tail.shape[1]), int(main.shape[1])
+            if hub is None:       # chunk scratch passes re-walk spans with their own positions: keep those dense-tail
+                a.edge_tail, a.ld_edge_tail = edge_tail.data_ptr(), int(edge_tail.shape[1])
         a.out, a.ldo = out.data_ptr(), ldo
         a.op, a.act, a.accumulate = op, act, 1 if accumulate else 0
         a.self_coef = 0 if self_coef is None else self_coef.data_ptr()
@@ -134,7 +152,7 @@ class HipBackend(object):
         a.mean_count = 0 if mean_count is None else mean_count.data_ptr()
         if hub is not None:
             thr, hub_rows, chunk_ptr, chunk_begin, chunk_end, _ = hub
-            scratch = self.empty((int(chunk_begin.shape[0]), int(x.shape[1])))
+            scratch = self.empty((int(chunk_begin.shape[0]), F_total))
             a.hub_threshold = thr
             a.hub_rows, a.hub_chunk_ptr = hub_rows.data_ptr(), chunk_ptr.data_ptr()
             a.hub_chunk_begin, a.hub_chunk_end = chunk_begin.data_ptr(), chunk_end.data_ptr()
@@ -487,7 +505,7 @@ class ShardedGraph(object):
 
     # ------------------------------------------------------------------ aggregation
     def aggregate(self, table, op=L.SUM, w="plan", self_coef=None, bias=None, act=L.ACT_NONE, out=None,
-                  exchange=True, classes=None):
+                  exchange=True, classes=None, split=None):
         """out[r] = reduce over ALL edges of own row r of w*table[col] (+ epilogue), halo exchange overlapped with
         the local-source pass.  `w`: "plan" = the shard's edge weights, None = unweighted, or a tensor in this
         shard's edge order.  `classes` (diagnostics, bench.py): run only these source classes (0 = own-source edges,
@@ -505,6 +523,8 @@ class ShardedGraph(object):
             if k >= 1:
                 self.exchange_finish(handles, k - 1)          # class k reads the rows of round k-1
             kw = {"hub": self.hub[k]} if self.hub[k] is not None else {}
+            if split is not None:
+                kw["split"] = split
             if last:      # epilogue (self-loop term, mean divisor, bias, activation) once, in the final pass
                 be.segment_reduce(rpk[k:], rpk[k + 1:], K1, self.col, w_t, self.n_own, table, out, op, act=act,
                                   accumulate=k > 0, self_coef=self_coef, bias=bias,
@@ -513,6 +533,27 @@ class ShardedGraph(object):
                 be.segment_reduce(rpk[k:], rpk[k + 1:], K1, self.col, w_t, self.n_own, table, out,
                                   L.SUM if op == L.MEAN else op, accumulate=k > 0, **kw)
         return out
+
+    # ------------------------------------------------------------------ static input features (layer 0)
+    def prepare_static_features(self, x_own):
+        """EXPLICIT opt-in, the sharded twin of tfg.prepare_static_features: `x_own` are this rank's rows
+        of the dataset's input features, which never change.  The halo is exchanged ONCE, the [own | halo] table is kept,
+        and — at widths where a row straddles an extra 128-byte line (F = 100) — so is its edge-resident-tail layout in
+        this shard's CSR order.  Every later layer-0 aggregation (`aggregate_static`) runs without any exchange.
+        Returns the handle; its `bytes` entry reports what it holds."""
+        be = self.backend
+        table = self.alloc_table(int(x_own.shape[1]))
+        self.own_rows(table).copy_(x_own)
+        self.exchange_finish(self.exchange_start(table))
+        split_fn = getattr(be, "split_rows", None)
+        split = split_fn(table, self.col) if split_fn is not None else None
+        nbytes = 4 * int(table.numel()) + (0 if split is None else 4 * sum(int(t.numel()) for t in split))
+        return {"table": table, "split": split, "bytes": nbytes}
+
+    def aggregate_static(self, static, op=L.SUM, w="plan", self_coef=None, bias=None, act=L.ACT_NONE, out=None):
+        """aggregate() over a table prepared by prepare_static_features: no exchange, static layout when present."""
+        return self.aggregate(static["table"], op, w=w, self_coef=self_coef, bias=bias, act=act, out=out, exchange=False,
+                              split=static["split"])
 
     # ------------------------------------------------------------------ feature-column-chunked halo
     def aggregate_chunked(self, x_own, num_splits, op=L.SUM, w="plan", self_coef=None, bias=None, act=L.ACT_NONE):
