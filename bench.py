@@ -354,6 +354,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         ev_ms = float(t.item())
         diag = shard_diagnostics(sg, table, out, f, L, dist, max(3, min(args.steps, 10)))
+        # beside the headline (which exchanges the halo every step, as any hidden layer must): layer 0 with its input
+        # features declared static — halo exchanged once, shard table in the edge-resident-tail layout, no exchange per step
+        st = sg.prepare_static_features(sg.own_rows(table))
+        dist.barrier()
+        ms_static = _event_time(lambda: sg.aggregate_static(st, L.SUM, w=sg.norm_w, self_coef=sg.self_coef, out=out),
+                                max(3, min(args.steps, 10)), 2)
+        t = torch.tensor([ms_static], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        static_shard = {"what": "layer 0 after ShardedGraph.prepare_static_features: halo exchanged once, no exchange per "
+                                "step, shard table in the static layout where the width calls for it",
+                        "step_ms_max_over_ranks": float(t.item()), "edges_per_s": e / (float(t.item()) * 1e-3),
+                        "bytes_rank0": int(st["bytes"]), "layout_rank0": "edge_tail" if st["split"] is not None else "dense"}
+        del st
 
     ms_per_step = wall * 1e3 / args.steps
     e_agg = e + n
@@ -389,7 +402,7 @@ def main():
                             "achieved": achieved / 1e9, "peak": world * HBM_PEAK / 1e9, "unit": "GB/s",
                             "frac": achieved / (world * HBM_PEAK), "traffic": None,
                             "algorithmic_bytes_per_launch": bytes_alg, "step_ms": ms_per_step,
-                            "per_rank": diag,
+                            "per_rank": diag, "static_feature_layout": static_shard,
                             "overlap_frac": max(0.0, min(1.0, (serial - ms_per_step) / hideable)) if hideable > 0 else None,
                             "overlap_note": "exchange_ms / local_pass_ms / halo_pass_ms are each measured ALONE "
                                             "(barrier-separated) after the timed loop; overlap_frac = (their sum on the "
