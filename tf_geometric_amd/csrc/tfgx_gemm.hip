@@ -16,6 +16,7 @@
 //    consecutive m; B is staged as Bs[k][n].  Global loads for tile t+1 are issued before the MFMAs of tile t
 //    (register staging), LDS is single-buffered.  Optional split-K over blockIdx.y for small M with a long K.
 #include "tfgx_common.h"
+#include <cstdlib>
 
 namespace tfgx {
 namespace {
@@ -574,9 +575,18 @@ inline TnCfg tn_config(int64_t M, int64_t Ka, int64_t N, bool want_bias)
     c.tn_group = 64 / Ti < 1 ? 1 : (64 / Ti > Tn ? Tn : 64 / Ti);      // <= 64 output tiles per pass (8 waves x 8)
     c.groups = (Tn + c.tn_group - 1) / c.tn_group;
     c.R = 32;
+    static int r_env = -1, w_env = -1;      // developer A/B: TFGX_TN_R (rows per slab), TFGX_TN_WGS_ENV (workgroups)
+    if (r_env < 0) {
+        const char* e = getenv("TFGX_TN_R");
+        r_env = e ? atoi(e) : 0;
+        const char* w = getenv("TFGX_TN_WGS_ENV");
+        w_env = w ? atoi(w) : 0;
+    }
+    if (r_env >= 4) c.R = r_env;
     while (c.R > 4 && sizeof(float) * size_t(c.R) * size_t(c.ka_pad + c.tn_group * 32) > 72 * 1024) c.R /= 2;
     const int64_t slabs = (M + c.R - 1) / c.R;
-    c.wgs = int(slabs < TFGX_TN_WGS ? (slabs < 1 ? 1 : slabs) : TFGX_TN_WGS);
+    const int64_t wcap = w_env > 0 ? w_env : TFGX_TN_WGS;
+    c.wgs = int(slabs < wcap ? (slabs < 1 ? 1 : slabs) : wcap);
     c.part_floats = size_t(Ka + (want_bias ? 1 : 0)) * size_t(c.tn_group) * 32;
     c.lds_bytes = sizeof(float) * size_t(c.R) * size_t(c.ka_pad + c.tn_group * 32);
     return c;
