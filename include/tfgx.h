@@ -310,7 +310,8 @@ typedef struct tfgx_gat_backward_args {
     int64_t n_dst;
     const int32_t* row_ptr_t;  /* transposed plan (by source) + destination per position: used by the src pass */
     const int32_t* dst_t;
-    int64_t n_src;
+    int64_t n_src;             /* may exceed n_dst (a shard's [own | halo] source table): the appended self-loop of
+                                  destination r is source r, so only sources [0, n_dst) take part in one */
     const float* q; int64_t ldq;
     const float* k; int64_t ldk;
     const float* v; int64_t ldv;

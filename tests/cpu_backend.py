@@ -82,9 +82,40 @@ class NumpyBackend(object):
         d[i] += _np(src)
         return dst
 
-    def linear(self, x, kernel, bias=None):
+    def linear(self, x, kernel, bias=None, act=0):
         h = x @ kernel                        # torch CPU autograd (test backend)
-        return h if bias is None else h + bias
+        h = h if bias is None else h + bias
+        return torch.relu(h) if act == 1 else h
+
+    @staticmethod
+    def _rows_of(sg):
+        deg = (sg.row_ptr[1:] - sg.row_ptr[:-1]).long()
+        return torch.repeat_interleave(torch.arange(sg.n_own), deg)
+
+    def aggregate_autograd(self, sg, table, op, w):
+        """max over the shard's edges in plain torch (scatter_reduce amax: tied maxima share the gradient evenly, as
+        tf.math.unsorted_segment_max's gradient does)."""
+        assert op == 2
+        rows, col = self._rows_of(sg), sg.col.long()
+        msg = table[col] if w is None else table[col] * w.unsqueeze(1)
+        out = torch.full((sg.n_own, table.shape[1]), FLT_LOWEST, dtype=table.dtype)
+        return out.scatter_reduce(0, rows.unsqueeze(1).expand_as(msg), msg, reduce="amax", include_self=True)
+
+    def gat_attention_autograd(self, sg, Q, K, V, num_heads):
+        """nn/conv/gat.py:40-122 over the shard's edges + the appended self-loop (source r = table row r), plain torch."""
+        n, H = sg.n_own, num_heads
+        rows = torch.cat([self._rows_of(sg), torch.arange(n)])
+        col = torch.cat([sg.col.long(), torch.arange(n)])
+        d, dv = Q.shape[1] // H, V.shape[1] // H
+        q, k, v = Q.view(n, H, d)[rows], K.reshape(-1, H, d)[col], V.reshape(-1, H, dv)[col]
+        sc = (q * k).sum(-1) / float(np.sqrt(d))                                   # [E', H]
+        mx = torch.full((n, H), -1e30, dtype=sc.dtype).scatter_reduce(0, rows.unsqueeze(1).expand_as(sc), sc.detach(),
+                                                                      reduce="amax")
+        ex = torch.exp(sc - mx[rows])
+        den = torch.zeros((n, H), dtype=sc.dtype).index_add(0, rows, ex)
+        alpha = ex / (den[rows] + 1e-8)
+        out = torch.zeros((n, H, dv), dtype=V.dtype).index_add(0, rows, alpha.unsqueeze(-1) * v)
+        return out.reshape(n, H * dv)
 
     def hub_lists(self, row_begin, row_end, rp_stride, n_dst, num_edges):
         """Same chunking policy as HipBackend.hub_lists (plan.hub_policy / build_hub_lists are plain torch)."""

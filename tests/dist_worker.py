@@ -36,6 +36,26 @@ def gat_weights():
             (rng.standard_normal(6) * 0.2).astype(np.float32))
 
 
+GAT_HEADS = 2
+
+
+def gat_train_weights():
+    """(query_kernel, query_bias, key_kernel, key_bias, kernel, bias) of a GAT(8, heads 2, attention_units 6) layer."""
+    from oracle import tfg_oracle as oracle
+    rng = np.random.Generator(np.random.PCG64(78))
+    return (oracle.glorot_uniform(rng, 12, 6), (rng.standard_normal(6) * 0.2).astype(np.float32),
+            oracle.glorot_uniform(rng, 12, 6), (rng.standard_normal(6) * 0.2).astype(np.float32),
+            oracle.glorot_uniform(rng, 12, 8), (rng.standard_normal(8) * 0.2).astype(np.float32))
+
+
+def pool_weights():
+    """(self_kernel, neighbor_mlp_kernel, neighbor_kernel, neighbor_mlp_bias, bias) of MaxPoolGraphSage(10, concat)."""
+    from oracle import tfg_oracle as oracle
+    rng = np.random.Generator(np.random.PCG64(79))
+    return (oracle.glorot_uniform(rng, 12, 5), oracle.glorot_uniform(rng, 12, 20), oracle.glorot_uniform(rng, 20, 5),
+            (rng.standard_normal(20) * 0.2).astype(np.float32), (rng.standard_normal(10) * 0.2).astype(np.float32))
+
+
 def run_checks(rank, world, use_gpu, skew, results, rounds=None, partitioned=False, hub_threshold=None):
     """Build the shard, run sharded GCN / mean / max / sum and return this rank's rows (as numpy).  hub_threshold: force
     the chunked long-span paths (reduce passes AND the sharded GAT's part lists) on this small graph."""
@@ -197,6 +217,26 @@ def run_training(rank, world, use_gpu, skew, rounds=None, num_splits=None):
     m = sg.aggregate_trainable(x2, 1)
     (m * be.f32(_loss_coef(n, x.shape[1])[sg.own_lo:sg.own_hi])).sum().backward()
     res["dx_mean"] = x2.grad.cpu().numpy()
+    # max aggregation and the fused attention: differentiable halo table + the single-GPU backward on the shard's plan
+    x3 = be.f32(x[sg.own_lo:sg.own_hi]).requires_grad_(True)
+    mx = sg.aggregate_trainable(x3, 2, w=None)
+    (mx * be.f32(_loss_coef(n, x.shape[1])[sg.own_lo:sg.own_hi])).sum().backward()
+    res["out_max"], res["dx_max"] = mx.detach().cpu().numpy(), x3.grad.cpu().numpy()
+    gw = [be.f32(a).requires_grad_(True) for a in gat_train_weights()]
+    x4 = be.f32(x[sg.own_lo:sg.own_hi]).requires_grad_(True)
+    og = sg.gat_trainable(x4, gw[0], gw[1], 1, gw[2], gw[3], 1, gw[4], gw[5], torch.relu, GAT_HEADS)
+    (og * be.f32(_loss_coef(n, og.shape[1])[sg.own_lo:sg.own_hi])).sum().backward()
+    sg.all_reduce_gradients(gw)
+    res["out_gat"], res["dx_gat"] = og.detach().cpu().numpy(), x4.grad.cpu().numpy()
+    res["dw_gat"] = [t.grad.cpu().numpy() for t in gw]
+    if not skew:     # (the skewed graph has rows without in-edges: their float-lowest maxima overflow the next GEMM in fp32)
+        pw = [be.f32(a).requires_grad_(True) for a in pool_weights()]
+        x5 = be.f32(x[sg.own_lo:sg.own_hi]).requires_grad_(True)
+        op_ = sg.pool_graph_sage_trainable(x5, pw[0], pw[1], pw[2], pw[3], pw[4], act=1, concat=True, op=2)
+        (op_ * be.f32(_loss_coef(n, op_.shape[1])[sg.own_lo:sg.own_hi])).sum().backward()
+        sg.all_reduce_gradients(pw)
+        res["out_pool"], res["dx_pool"] = op_.detach().cpu().numpy(), x5.grad.cpu().numpy()
+        res["dw_pool"] = [t.grad.cpu().numpy() for t in pw]
     # static input features: the halo is exchanged once, later aggregations run without any exchange
     st = sg.prepare_static_features(be.f32(x[sg.own_lo:sg.own_hi]))
     calls = {"n": 0}
@@ -265,5 +305,57 @@ def training_reference(skew):
     deg = torch.from_numpy(np.maximum(np.bincount(ei[0], minlength=n), 1).astype(np.float64))
     x2 = torch.tensor(x, dtype=torch.float64, requires_grad=True)
     ((W @ x2) / deg[:, None] * torch.from_numpy(_loss_coef(n, x.shape[1]).astype(np.float64))).sum().backward()
-    return {"out": out.detach().numpy(), "dx": xt.grad.numpy(), "dk": kt.grad.numpy(), "db": bt.grad.numpy(),
-            "dx_mean": x2.grad.numpy()}
+    ref = {"out": out.detach().numpy(), "dx": xt.grad.numpy(), "dk": kt.grad.numpy(), "db": bt.grad.numpy(),
+           "dx_mean": x2.grad.numpy()}
+    # max aggregation, GAT layer, max-pool GraphSAGE layer: float64 torch autograd over the edge list as the reference
+    # composes them (map_reduce.py:31-42; gat.py:40-122; graph_sage.py:228-287) — scatter amax shares tied gradients
+    rows, cols = torch.from_numpy(ei[0].astype(np.int64)), torch.from_numpy(ei[1].astype(np.int64))
+    lowest = float(np.finfo(np.float32).min)
+
+    def seg_max(msg):
+        base = torch.full((n, msg.shape[1]), lowest, dtype=torch.float64)
+        return base.scatter_reduce(0, rows.unsqueeze(1).expand_as(msg), msg, reduce="amax", include_self=True)
+    x3 = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    mx = seg_max(x3[cols])
+    (mx * torch.from_numpy(_loss_coef(n, x.shape[1]).astype(np.float64))).sum().backward()
+    ref["out_max"], ref["dx_max"] = mx.detach().numpy(), x3.grad.numpy()
+    gw = [torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in gat_train_weights()]
+    x4 = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    H = GAT_HEADS
+    r2, c2 = torch.cat([rows, torch.arange(n)]), torch.cat([cols, torch.arange(n)])
+    Q, K, V = torch.relu(x4 @ gw[0] + gw[1]), torch.relu(x4 @ gw[2] + gw[3]), x4 @ gw[4]
+    d, dv = Q.shape[1] // H, V.shape[1] // H
+    sc = (Q.view(n, H, d)[r2] * K.view(n, H, d)[c2]).sum(-1) / float(np.sqrt(d))
+    mxs = torch.full((n, H), -1e300, dtype=torch.float64).scatter_reduce(0, r2.unsqueeze(1).expand_as(sc), sc.detach(),
+                                                                         reduce="amax")
+    ex = torch.exp(sc - mxs[r2])
+    den = torch.zeros((n, H), dtype=torch.float64).index_add(0, r2, ex)
+    alpha = ex / (den[r2] + 1e-8)
+    og = torch.zeros((n, H, dv), dtype=torch.float64).index_add(0, r2, alpha.unsqueeze(-1) * V.view(n, H, dv)[c2])
+    og = torch.relu(og.reshape(n, H * dv) + gw[5])
+    (og * torch.from_numpy(_loss_coef(n, og.shape[1]).astype(np.float64))).sum().backward()
+    ref["out_gat"], ref["dx_gat"], ref["dw_gat"] = og.detach().numpy(), x4.grad.numpy(), [t.grad.numpy() for t in gw]
+    if not skew:
+        pw = [torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in pool_weights()]
+        x5 = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+        hm = torch.relu(x5 @ pw[1] + pw[3])
+        op_ = torch.relu(torch.cat([x5 @ pw[0], seg_max(hm[cols]) @ pw[2]], 1) + pw[4])
+        (op_ * torch.from_numpy(_loss_coef(n, op_.shape[1]).astype(np.float64))).sum().backward()
+        ref["out_pool"], ref["dx_pool"], ref["dw_pool"] = op_.detach().numpy(), x5.grad.numpy(), [t.grad.numpy() for t in pw]
+    return ref
+
+
+def check_training_extras(parts, ref, assert_parity):
+    """max aggregation / GAT layer / max-pool SAGE layer of the sharded training path against the float64 reference."""
+    parts = sorted(parts, key=lambda p: p["lo"])
+    for key in ("max", "gat", "pool"):
+        if "out_" + key not in ref:
+            continue
+        assert_parity(np.concatenate([p["out_" + key] for p in parts]), ref["out_" + key], tol=2e-5,
+                      what="sharded trainable {} forward".format(key))
+        assert_parity(np.concatenate([p["dx_" + key] for p in parts]), ref["dx_" + key], tol=1e-4,
+                      what="sharded {} d/dx".format(key))
+        if "dw_" + key in ref:
+            for p in parts:
+                for i, (got, want) in enumerate(zip(p["dw_" + key], ref["dw_" + key])):
+                    assert_parity(got, want, tol=2e-4, what="all-reduced {} weight gradient {}".format(key, i))

@@ -74,6 +74,7 @@ def test_sharded_training_gradients_gloo(tmp_path, world, skew, rounds):
     for p in parts:                       # every rank holds the SAME all-reduced weight gradients
         assert_parity(p["dk"], ref["dk"], tol=1e-4, what="all-reduced d/dkernel")
         assert_parity(p["db"], ref["db"], tol=1e-4, what="all-reduced d/dbias")
+    dist_worker.check_training_extras(parts, ref, assert_parity)     # max / GAT / max-pool SAGE through halo_table
     for p in parts:                       # static layer-0 features: same rows, and NO exchange after the preparation
         assert np.array_equal(p["static_sum"], p["static_sum_ref"]) and np.array_equal(p["static_mean"], p["static_mean_ref"])
         assert p["static_exchanges"] == 0

@@ -44,22 +44,25 @@ def test_rccl_world1_api_smoke(tfg):
     assert res.returncode == 0 and "RCCL_WORLD1_OK" in text and "True" in text and "False" not in text, text
 
 
-@pytest.mark.parametrize("world", [1, 2])
-def test_sharded_training_hip(tfg, tmp_path, world):
+@pytest.mark.parametrize("world,skew", [(1, True), (2, True), (2, False)])
+def test_sharded_training_hip(tfg, tmp_path, world, skew):
     """Sharded backward on the HIP kernels (transposed local pass, tfgx_scatter_add_rows_f32 owner-side accumulate,
     MFMA weight gradients) + the reverse exchange and weight-gradient all-reduce over a gloo group sharing cuda:0, and
     the column-chunked halo (bit-identical rows, a quarter of the table)."""
     import numpy as np
     if world == 1:
-        parts = [dist_worker.run_training(0, 1, True, True, num_splits=4)]
+        parts = [dist_worker.run_training(0, 1, True, skew, num_splits=4)]
     else:
         port = 37600 + random.randint(0, 2000)
-        parts = dist_worker.spawn_training(2, True, True, str(tmp_path), port, rounds=3, num_splits=4)
-    ref = dist_worker.training_reference(True)
+        parts = dist_worker.spawn_training(2, True, skew, str(tmp_path), port, rounds=3, num_splits=4)
+    ref = dist_worker.training_reference(skew)
     parts = sorted(parts, key=lambda p: p["lo"])
     assert_parity(np.concatenate([p["out"] for p in parts]), ref["out"], what="sharded trainable forward (HIP)")
     assert_parity(np.concatenate([p["dx"] for p in parts]), ref["dx"], tol=2e-5, what="sharded d/dx (HIP)")
     assert_parity(np.concatenate([p["dx_mean"] for p in parts]), ref["dx_mean"], tol=2e-5, what="sharded mean d/dx (HIP)")
+    # max aggregation, the GAT layer and (unskewed graph) the max-pool SAGE layer: differentiable halo table + the
+    # single-GPU backward kernels on the shard's rectangular plan, halo-row gradients returned by the reverse exchange
+    dist_worker.check_training_extras(parts, ref, assert_parity)
     for p in parts:
         assert_parity(p["dk"], ref["dk"], tol=1e-4, what="all-reduced d/dkernel (HIP)")
         assert_parity(p["db"], ref["db"], tol=1e-4, what="all-reduced d/dbias (HIP)")

@@ -268,7 +268,11 @@ class _GatAttention(torch.autograd.Function):
         L.check(lib.tfgx_gat_pack_dst_f32(L.ptr(g2), ldg, L.ptr(out2), ldo, L.ptr(Q2), ldq, L.ptr(stats), n, H, A // H,
                                           W // H, L.ptr(pack), P, L.ptr(dsum), L.stream_ptr()), "tfgx_gat_pack_dst_f32")
         pt, t2d = _transposed(plan)
-        gq, gk, gv = torch.empty_like(Q2), torch.empty_like(K2), torch.empty_like(V2)
+        # dense outputs (K2 / V2 may be column slices of a wider table — the sharded [K | V] halo table)
+        dev = g2.device
+        gq = torch.empty((n, A), dtype=torch.float32, device=dev)
+        gk = torch.empty((int(K2.shape[0]), A), dtype=torch.float32, device=dev)
+        gv = torch.empty((int(V2.shape[0]), W), dtype=torch.float32, device=dev)
         a = L.GatBackwardArgs()
         a.row_ptr, a.col, a.n_dst = plan.row_ptr.data_ptr(), plan.col.data_ptr(), n
         a.row_ptr_t, a.dst_t, a.n_src = pt.row_ptr.data_ptr(), pt.col.data_ptr(), pt.n_dst

@@ -531,6 +531,8 @@ struct GB {
     const int32_t* row_ptr;   // forward plan (by destination) or transposed plan (by source)
     const int32_t* other;     // col (sources) for the dst pass; destinations for the src pass
     int64_t n;                // rows of this pass
+    int64_t n_self;           // rows [0, n_self) of this pass own the appended self-loop (src pass of a rectangular
+                              // operator: only sources that are also destinations, i.e. a shard's own rows)
     const float* q; int64_t ldq;
     const float* k; int64_t ldk;
     const float* v; int64_t ldv;
@@ -614,7 +616,7 @@ __global__ __launch_bounds__(kBlock) void gat_backward_src_kernel(const GB a)
         for (int u = 0; u < a.dv; ++u) gvp[u] = 0.0f;
         const int s = a.row_ptr[c], e = a.row_ptr[c + 1];
         for (int i = s; i <= e; ++i) {
-            if (i == e && !a.add_self_loop) break;
+            if (i == e && (!a.add_self_loop || c >= a.n_self)) break;
             const int64_t r = (i == e) ? c : a.other[i];
             float sc;
             const float alpha = edge_alpha(a, r, c, h, sc);
@@ -784,7 +786,7 @@ __global__ __launch_bounds__(kBlock) void gat_backward_fast_kernel(const GB a)
             for (; j < cnt; ++j)
                 edge(int64_t(__shfl(oj, j, G)), drop_scale(a.drop, uint32_t(int64_t(__shfl(pj, j, G)) * a.H + head)));
         }
-        if (a.add_self_loop) edge(row, drop_scale(a.drop, uint32_t((a.drop.self_base + row) * a.H + head)));
+        if (a.add_self_loop && row < a.n_self) edge(row, drop_scale(a.drop, uint32_t((a.drop.self_base + row) * a.H + head)));
         if (SRC) {
             if (cvalid) store_vec<VEC>(a.gv + row * a.ldgv + coff, acc_v);
         }
@@ -1115,7 +1117,7 @@ extern "C" int tfgx_gat_backward_dst_f32(const tfgx_gat_backward_args* p, tfgx_s
     if (rc) return rc;
     TFGX_REQUIRE(p->row_ptr && p->grad_q && p->n_dst >= 0, "dst pass needs row_ptr / grad_q");
     if (p->n_dst == 0) return TFGX_OK;
-    a.row_ptr = p->row_ptr; a.other = p->col; a.n = p->n_dst;
+    a.row_ptr = p->row_ptr; a.other = p->col; a.n = p->n_dst; a.n_self = p->n_dst;
     if (gat_bwd_fast_ok(p)) return launch_gat_bwd<false>(a, as_stream(stream));
     gat_backward_dst_kernel<<<grid_for(a.n * a.H, kBlock), kBlock, 0, as_stream(stream)>>>(a);
     TFGX_LAUNCH_CHECK("gat_backward_dst_kernel");
@@ -1131,6 +1133,7 @@ extern "C" int tfgx_gat_backward_src_f32(const tfgx_gat_backward_args* p, tfgx_s
     TFGX_REQUIRE(p->row_ptr_t && p->grad_k && p->grad_v && p->n_src >= 0, "src pass needs row_ptr_t / grad_k / grad_v");
     if (p->n_src == 0) return TFGX_OK;
     a.row_ptr = p->row_ptr_t; a.other = p->dst_t; a.n = p->n_src;
+    a.n_self = p->n_src < p->n_dst ? p->n_src : p->n_dst;   // source c has a self-loop only if it is destination c too
     TFGX_REQUIRE(p->drop_rate == 0.0f || p->edge_pos_t, "the src pass needs edge_pos_t to regenerate the dropout mask");
     a.pos = p->drop_rate > 0.0f ? p->edge_pos_t : nullptr;
     if (gat_bwd_fast_ok(p)) return launch_gat_bwd<true>(a, as_stream(stream));

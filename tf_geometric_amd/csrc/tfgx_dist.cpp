@@ -84,11 +84,16 @@ extern "C" int tfgx_halo_plan_create(int32_t world, int32_t rank, int32_t rounds
         set_err("tfgx_halo_plan_create: send_idx is null but rows are to be sent");
         return TFGX_ERR_INVALID_ARG;
     }
-    p->packed.resize(rounds);
-    p->done.resize(rounds);
+    p->packed.assign(rounds, nullptr);
+    p->done.assign(rounds, nullptr);
     for (int j = 0; j < rounds; ++j) {
-        DIST_HIP(hipEventCreateWithFlags(&p->packed[j], hipEventDisableTiming));
-        DIST_HIP(hipEventCreateWithFlags(&p->done[j], hipEventDisableTiming));
+        hipError_t e = hipEventCreateWithFlags(&p->packed[j], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&p->done[j], hipEventDisableTiming);
+        if (e != hipSuccess) {
+            set_err("tfgx_halo_plan_create: hipEventCreateWithFlags: %s", hipGetErrorString(e));
+            tfgx_halo_plan_destroy(p);
+            return TFGX_ERR_HIP;
+        }
     }
     *out = p;
     return TFGX_OK;
@@ -97,8 +102,8 @@ extern "C" int tfgx_halo_plan_create(int32_t world, int32_t rank, int32_t rounds
 extern "C" int tfgx_halo_plan_destroy(tfgx_halo_plan* p)
 {
     if (p == nullptr) return TFGX_OK;
-    for (hipEvent_t e : p->packed) (void)hipEventDestroy(e);
-    for (hipEvent_t e : p->done) (void)hipEventDestroy(e);
+    for (hipEvent_t e : p->packed) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : p->done) if (e) (void)hipEventDestroy(e);
     delete p;
     return TFGX_OK;
 }
@@ -121,6 +126,9 @@ extern "C" int tfgx_halo_exchange_start(tfgx_halo_plan* p, const float* x_own, i
     hipStream_t cs = reinterpret_cast<hipStream_t>(compute_stream);
     hipStream_t ms = reinterpret_cast<hipStream_t>(comm_stream);
     ncclComm_t comm = reinterpret_cast<ncclComm_t>(nccl_comm);
+    if (p->in_flight) {   // a previous exchange may still be reading send_buf / writing halo on the communication stream
+        for (int j = 0; j < p->rounds; ++j) DIST_HIP(hipStreamWaitEvent(cs, p->done[j], 0));
+    }
     for (int j = 0; j < p->rounds; ++j) {
         const size_t base = size_t(j) * size_t(p->world);
         const int64_t r0 = p->send_off[base], r1 = p->send_off[base + p->world];

@@ -104,10 +104,22 @@ class HipBackend(object):
                                                    L.ptr(src), lds, L.stream_ptr()), "tfgx_scatter_add_rows_f32")
         return dst
 
-    def linear(self, x, kernel, bias=None):
-        """Differentiable x @ kernel (+ bias): forward AND backward on the MFMA kernels (autograd.linear)."""
+    def linear(self, x, kernel, bias=None, act=L.ACT_NONE):
+        """Differentiable act(x @ kernel + bias): forward AND backward on the MFMA kernels (autograd.linear)."""
         from .. import autograd as AG
-        return AG.linear(x, kernel, bias)
+        return AG.linear(x, kernel, bias, act)
+
+    def aggregate_autograd(self, sg, table, op, w):
+        """Differentiable reduce of w * table[col] over the shard's rows, table = [own | halo] (n_own x n_table
+        operator): the single-GPU autograd functions on the shard's rectangular plan."""
+        from .. import autograd as AG
+        return AG.aggregate(sg.local_plan(), table, op, w_csr=w)
+
+    def gat_attention_autograd(self, sg, Q, K, V, num_heads):
+        """Differentiable fused attention of own destinations over table sources (self-loop = table row r, own rows
+        come first in the table)."""
+        from .. import autograd as AG
+        return AG.gat_attention(sg.local_plan(), Q, K, V, num_heads)
 
     def hub_lists(self, row_begin, row_end, rp_stride, n_dst, num_edges):
         """Chunk lists for the long spans of one pass (skewed graphs), or None — see plan.hub_policy."""
@@ -602,17 +614,65 @@ class ShardedGraph(object):
             self._tl = be.build_csr(torch.stack([self.col, rows]), max(self.n_table, 1), max(self.n_own, 1))
         return self._tl
 
+    def reverse_exchange(self, d_table, inplace=False):
+        """Gradient w.r.t. the [own | halo] source table -> gradient w.r.t. this rank's own rows (the backward of the
+        halo exchange).  The halo-row gradients travel back along the forward exchange's lists (what I received from p in
+        round j, I send to p; what I sent, I receive), one all-to-all-v per round; returned rows are added into the own
+        rows at the forward send indices, peer by peer in rank order and round by round — a fixed order, and one peer's
+        list has no repeated row, so the sum is deterministic without atomics (tfgx_scatter_add_rows_f32)."""
+        be = self.backend
+        U = int(d_table.shape[1])
+        d_own = d_table[:self.n_own]
+        if not inplace:
+            d_own = d_own.clone()
+        if self.world == 1:
+            return d_own
+        d_halo = d_table[self.n_own:self.n_table]
+        nccl = dist.get_backend(self.group) == "nccl"
+        for j in range(self.rounds):
+            seg = d_halo[int(self.round_offset[j]):int(self.round_offset[j + 1])].contiguous()
+            n_back = int(sum(self.round_send_counts[j]))
+            back = be.empty((n_back, U))
+            # reverse direction: my forward RECEIVE counts are what I now send, and vice versa
+            out_splits, in_splits = list(self.round_send_counts[j]), list(self.round_recv_counts[j])
+            if nccl:
+                dist.all_to_all_single(back, seg, out_splits, in_splits, group=self.group)
+            else:
+                back_h = torch.empty((n_back, U), dtype=torch.float32)
+                dist.all_to_all_single(back_h, seg.cpu(), out_splits, in_splits, group=self.group)
+                back.copy_(back_h)
+            off = 0
+            for p in range(self.world):            # fixed peer order
+                cnt = int(self.round_send_counts[j][p])
+                if cnt:
+                    be.scatter_add_rows(d_own, self.round_send_idx[j][off:off + cnt], back[off:off + cnt])
+                off += cnt
+        return d_own
+
+    def halo_table(self, h_own):
+        """Differentiable [own | halo] source table of own rows `h_own`: forward = the halo exchange, backward =
+        reverse_exchange.  Any single-GPU differentiable operator on local_plan() composed with it is the sharded
+        operator WITH its backward (max aggregation, the fused attention)."""
+        return _HaloGather.apply(self, h_own)
+
+    def local_plan(self):
+        """This shard as an [n_own x n_table] CSR operator (plan.CsrPlan over row_ptr / col — rows stay contiguous
+        through the per-class partition), with the transposed plan available for the backward passes."""
+        if getattr(self, "_local_plan", None) is None:
+            from ..plan import CsrPlan
+            rows = torch.repeat_interleave(torch.arange(self.n_own, device=self.col.device),
+                                           self.in_degree.long()).to(torch.int32)
+            self._local_plan = CsrPlan.from_sorted(self.row_ptr, self.col, max(self.n_table, 1),
+                                                   edge_index=torch.stack([rows, self.col]))
+        return self._local_plan
+
     def aggregate_backward(self, g_out, w="plan", self_coef=None, mean=False):
         """d(loss)/d(own table rows) of out = aggregate(table, SUM | MEAN, w, self_coef) given g_out = d(loss)/d(out).
 
         1. local transposed pass: dT[t] = sum over this shard's edges with source t of w * g[row] — for own rows AND for
            halo rows (gradients that belong to peers);
-        2. REVERSE halo exchange: the halo-row gradients travel back along the forward exchange's lists (what I received
-           from p in round j, I send to p; what I sent, I receive), one all-to-all-v per round;
-        3. owner-side accumulate: returned rows are added into dT_own at the forward send indices, peer by peer in rank
-           order and round by round — a fixed order, and one peer's list has no repeated row, so the sum is deterministic
-           without atomics (tfgx_scatter_add_rows_f32);
-        4. the implicit self-loop term self_coef[r] * g[r]."""
+        2. reverse_exchange: halo-row gradients go back to their owners and are accumulated there in a fixed order;
+        3. the implicit self-loop term self_coef[r] * g[r]."""
         be = self.backend
         w_t = self.w if (isinstance(w, str) and w == "plan") else w
         g = g_out.contiguous()
@@ -623,28 +683,7 @@ class ShardedGraph(object):
         wt = None if w_t is None else be.permute_rows(w_t, perm_t)
         d_table = be.empty((max(self.n_table, 1), U))
         be.segment_reduce(rp_t, rp_t[1:], 1, dst_t, wt, self.n_table, g, d_table, L.SUM)
-        d_own = d_table[:self.n_own]
-        if self.world > 1:
-            d_halo = d_table[self.n_own:self.n_table]
-            nccl = dist.get_backend(self.group) == "nccl"
-            for j in range(self.rounds):
-                seg = d_halo[int(self.round_offset[j]):int(self.round_offset[j + 1])].contiguous()
-                n_back = int(sum(self.round_send_counts[j]))
-                back = be.empty((n_back, U))
-                # reverse direction: my forward RECEIVE counts are what I now send, and vice versa
-                out_splits, in_splits = list(self.round_send_counts[j]), list(self.round_recv_counts[j])
-                if nccl:
-                    dist.all_to_all_single(back, seg, out_splits, in_splits, group=self.group)
-                else:
-                    back_h = torch.empty((n_back, U), dtype=torch.float32)
-                    dist.all_to_all_single(back_h, seg.cpu(), out_splits, in_splits, group=self.group)
-                    back.copy_(back_h)
-                off = 0
-                for p in range(self.world):            # fixed peer order
-                    cnt = int(self.round_send_counts[j][p])
-                    if cnt:
-                        be.scatter_add_rows(d_own, self.round_send_idx[j][off:off + cnt], back[off:off + cnt])
-                    off += cnt
+        d_own = self.reverse_exchange(d_table, inplace=True)
         if self_coef is not None:
             d_own = d_own + self_coef.unsqueeze(1) * g
         return d_own
@@ -652,9 +691,44 @@ class ShardedGraph(object):
     def aggregate_trainable(self, h_own, op=L.SUM, w="plan", self_coef=None):
         """Differentiable sharded aggregation of own rows `h_own` [n_own, U] (torch autograd; forward = aggregate with the
         overlapped halo exchange, backward = aggregate_backward with the reverse exchange)."""
-        if op not in (L.SUM, L.MEAN):
-            raise NotImplementedError("the sharded backward covers sum / mean aggregation")
-        return _ShardedAggregate.apply(self, op, w, self_coef, h_own)
+        if op in (L.SUM, L.MEAN):
+            return _ShardedAggregate.apply(self, op, w, self_coef, h_own)
+        if self_coef is not None:
+            raise NotImplementedError("max aggregation with an implicit self-loop is inference-only")
+        # max (the reducer of max_pool_graph_sage): differentiable halo table, then the single-GPU max aggregation with
+        # its tie-sharing gradient on the shard's rectangular plan; halo-row gradients return through reverse_exchange
+        w_t = self.w if (isinstance(w, str) and w == "plan") else w
+        return self.backend.aggregate_autograd(self, self.halo_table(h_own), op, w_t)
+
+    def gat_trainable(self, x_own, query_kernel, query_bias, query_act, key_kernel, key_bias, key_act, kernel, bias=None,
+                      activation=None, num_heads=1):
+        """Sharded GAT layer (nn/conv/gat.py:13-122, split_value_heads=True) whose output carries gradients to the five
+        weights and to x_own: Q stays local, [K | V] rows travel once as ONE differentiable halo table, the fused
+        attention runs on the shard's rectangular plan, and the d[K | V] of halo rows return to their owners in the
+        backward (reverse_exchange).  query_act / key_act: L.ACT_* codes (as gat()); activation: a callable or None."""
+        be = self.backend
+        A = int(query_kernel.shape[1])
+        Q = be.linear(x_own, query_kernel, query_bias, query_act)
+        K = be.linear(x_own, key_kernel, key_bias, key_act)
+        V = be.linear(x_own, kernel)
+        table = self.halo_table(torch.cat([K, V], 1))
+        out = be.gat_attention_autograd(self, Q, table[:, :A], table[:, A:], num_heads)
+        if bias is not None:
+            out = out + bias
+        return activation(out) if activation is not None else out
+
+    def pool_graph_sage_trainable(self, x_own, self_kernel, neighbor_mlp_kernel, neighbor_kernel, neighbor_mlp_bias=None,
+                                  bias=None, act=L.ACT_NONE, concat=True, op=L.MAX):
+        """pool_graph_sage with gradients (nn/conv/graph_sage.py:164-287): the per-node MLP rows are the halo table; the
+        SAME activation after the MLP and at the end, as the reference applies it."""
+        be = self.backend
+        h = be.linear(x_own, neighbor_mlp_kernel, neighbor_mlp_bias, act)
+        reduced = self.aggregate_trainable(h, op, w=None)
+        a, b = be.linear(x_own, self_kernel), be.linear(reduced, neighbor_kernel)
+        out = torch.cat([a, b], 1) if concat else a + b
+        if bias is not None:
+            out = out + bias
+        return torch.relu(out) if act == L.ACT_RELU else out
 
     def gcn_trainable(self, x_own, kernel, bias=None, activation=None):
         """Sharded GCN layer whose output carries gradients to kernel / bias / x_own (nn/conv/gcn.py:225-290 under a
@@ -921,3 +995,19 @@ class _ShardedAggregate(torch.autograd.Function):
     def backward(ctx, g):
         d_own = ctx.sg.aggregate_backward(g, w=ctx.w, self_coef=ctx.self_coef, mean=ctx.op == L.MEAN)
         return None, None, None, None, d_own
+
+
+class _HaloGather(torch.autograd.Function):
+    """own rows -> [own | halo] table (forward: halo exchange; backward: ShardedGraph.reverse_exchange)."""
+
+    @staticmethod
+    def forward(ctx, sg, h_own):
+        ctx.sg = sg
+        table = sg.alloc_table(int(h_own.shape[1]))
+        sg.own_rows(table).copy_(h_own.detach())
+        sg.exchange_finish(sg.exchange_start(table))
+        return table
+
+    @staticmethod
+    def backward(ctx, g_table):
+        return None, ctx.sg.reverse_exchange(g_table.contiguous())
