@@ -372,8 +372,9 @@ int tfgx_gemm_bias_act_cols_ws_f32(const float* A, int64_t lda, const float* B, 
 
 /* Weight gradient of a dense layer (the backward of tfgx_gemm_bias_act_f32):
    dW[Ka, N] = X[M, Ka]^T @ G[M, N] and, when db != NULL, db[N] = column sums of G (the bias gradient), reduced over
-   the M rows on the fp32 matrix cores.  Per-workgroup partials live in the caller's workspace
-   (tfgx_gemm_tn_workspace_bytes) and are summed in a fixed order: deterministic, no atomics.  Ka <= 2016. */
+   the M rows on the fp32 matrix cores (operands streamed from global memory in the MFMA's own layout, no LDS).
+   Per-workgroup partials live in the caller's workspace (tfgx_gemm_tn_workspace_bytes) and are summed in a fixed
+   order: deterministic, no atomics. */
 size_t tfgx_gemm_tn_workspace_bytes(int64_t M, int64_t Ka, int64_t N, int32_t want_bias);
 int tfgx_gemm_tn_f32(const float* X, int64_t ldx, const float* G, int64_t ldg, int64_t M, int64_t Ka, int64_t N,
                      float* dW, int64_t ldw, float* db /* or NULL */, void* workspace, size_t workspace_bytes,

@@ -441,7 +441,8 @@ def test_gradients_reach_through_readouts_sparse_matmul_and_generic_route(tfg):
 
 
 @pytest.mark.parametrize("m,ka,n", [(1, 1, 1), (37, 5, 3), (1000, 100, 256), (4099, 100, 40), (70001, 128, 128),
-                                    (5000, 256, 256), (3000, 602, 64), (2708, 1433, 16), (999, 33, 300), (64, 32, 32)])
+                                    (5000, 256, 256), (3000, 602, 64), (2708, 1433, 16), (999, 33, 300), (64, 32, 32),
+                                    (700, 2500, 24), (3001, 7, 700), (9, 17, 16), (100003, 101, 41)])
 @pytest.mark.parametrize("want_bias", [False, True])
 def test_gemm_tn_weight_gradient_kernel(tfg, m, ka, n, want_bias):
     """tfgx_gemm_tn_f32 (dW = x^T g, db = column sums of g) vs float64, and the transpose kernel."""

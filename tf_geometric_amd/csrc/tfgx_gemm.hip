@@ -22,6 +22,7 @@ namespace tfgx {
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 16;   // 16 keeps load-staging registers low enough for 3 workgroups per CU (BK = 32: 2)
 
@@ -543,6 +544,207 @@ __global__ __launch_bounds__(kTnThreads) void gemm_tn_kernel(const float* __rest
     }
 }
 
+// ---- the same product without LDS: with k = the node row, the MFMA operand layouts ARE row-major reads — for
+// v_mfma_f32_32x32x2_f32 lane (l % 32, l / 32) of the A operand wants X[r + l/32][i0 + l%32] (32 consecutive floats of a
+// row) and of the B operand G[r + l/32][n0 + l%32]; for v_mfma_f32_16x16x4_f32 it is X[r + l/16][i0 + l%16] — so every
+// wave streams its operands straight from global memory, keeps TM x TN output tiles in registers and reuses each A
+// value TN times and each B value TM times.  No barriers: the four waves of a workgroup (WM x WN arrangement) walk the
+// same rows and share them through L1/L2.  Loads of the next U k-steps are in flight while the current U are
+// multiplied.  S = 16 pads Ka (+1) and N to multiples of 16 instead of 32: 101 x 256 costs 112 x 256 multiplies
+// instead of 128 x 256.
+template <int S>
+struct TnTile;
+template <>
+struct TnTile<32> {
+    typedef f32x16 acc_t;
+    static constexpr int NQ = 16, KS = 2;             // accumulator registers per tile; node rows per MFMA
+    __device__ static __forceinline__ acc_t mfma(float a, float b, acc_t c)
+    {
+        return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+    }
+    __device__ static __forceinline__ int out_row(int q, int kk) { return (q & 3) + 8 * (q >> 2) + 4 * kk; }
+};
+template <>
+struct TnTile<16> {
+    typedef f32x4 acc_t;
+    static constexpr int NQ = 4, KS = 4;
+    __device__ static __forceinline__ acc_t mfma(float a, float b, acc_t c)
+    {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+    __device__ static __forceinline__ int out_row(int q, int kk) { return 4 * kk + q; }
+};
+
+template <int S, int TM, int TN, int U>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void gemm_tn_direct_kernel(
+    const float* __restrict__ X, int64_t ldx, const float* __restrict__ G, int64_t ldg, int64_t M, int Ka, int N,
+    int want_bias, int WM, int m_groups, int tm_r, int tn_r, int64_t rows_per_wg, float* __restrict__ parts,
+    int64_t part_stride)
+{
+    // tm_r <= TM, tn_r <= TN: the tiles per wave the configuration asked for (the instantiation may be larger)
+    typedef TnTile<S> T;
+    typedef typename T::acc_t acc_t;
+    constexpr int KS = T::KS;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lc = lane % S, kk = lane / S;
+    const int WN = 4 / WM;
+    const int wm = wave % WM, wn = wave / WM;
+    const int gm = blockIdx.y % m_groups, gn = blockIdx.y / m_groups;
+    const int Ti = (Ka + (want_bias ? 1 : 0) + S - 1) / S, Tn = (N + S - 1) / S;
+    const int mt0 = (gm * WM + wm) * tm_r, nt0 = (gn * WN + wn) * tn_r;
+    int mcol[TM], ncol[TN];
+    bool mval[TM], nval[TN], mtile[TM], ntile[TN];
+    float mfill[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        mcol[i] = (mt0 + i) * S + lc;
+        mval[i] = mcol[i] < Ka;
+        mfill[i] = (want_bias && mcol[i] == Ka) ? 1.0f : 0.0f;       // the virtual all-ones column: row Ka = bias gradient
+        mtile[i] = i < tm_r && mt0 + i < Ti;
+        if (!mval[i]) mcol[i] = 0;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        ncol[j] = (nt0 + j) * S + lc;
+        nval[j] = ncol[j] < N;
+        ntile[j] = j < tn_r && nt0 + j < Tn;
+        if (!nval[j]) ncol[j] = 0;
+    }
+    acc_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < T::NQ; ++q) acc[i][j][q] = 0.0f;
+
+    const int64_t r_begin = int64_t(blockIdx.x) * rows_per_wg;
+    const int64_t r_end = r_begin + rows_per_wg < M ? r_begin + rows_per_wg : M;
+    struct Ops {
+        float a[U][TM], b[U][TN];
+    };
+    constexpr int BR = KS * U;                    // node rows per batch
+    auto load = [&](Ops& o, int64_t r) {          // full batch: rows r .. r + BR - 1 all < r_end
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float* xr = X + (r + KS * u + kk) * ldx;
+            const float* gr = G + (r + KS * u + kk) * ldg;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) o.a[u][i] = mval[i] ? xr[mcol[i]] : mfill[i];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) o.b[u][j] = nval[j] ? gr[ncol[j]] : 0.0f;
+        }
+    };
+    auto mul = [&](const Ops& o) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    if (mtile[i] && ntile[j]) acc[i][j] = T::mfma(o.a[u][i], o.b[u][j], acc[i][j]);
+    };
+    int64_t r = r_begin;
+    if (r + BR <= r_end) {
+        Ops cur;
+        load(cur, r);
+        for (; r + 2 * BR <= r_end; r += BR) {
+            Ops nxt;
+            load(nxt, r + BR);
+            mul(cur);
+            cur = nxt;
+        }
+        mul(cur);
+        r += BR;
+    }
+    for (; r < r_end; r += KS) {                   // tail: one k-step at a time, rows past r_end contribute zeros
+        const int64_t row = r + kk;
+        const bool rv = row < r_end;
+        float a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = rv ? (mval[i] ? X[row * ldx + mcol[i]] : mfill[i]) : 0.0f;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = (rv && nval[j]) ? G[row * ldg + ncol[j]] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                if (mtile[i] && ntile[j]) acc[i][j] = T::mfma(a[i], b[j], acc[i][j]);
+    }
+    // partial of this workgroup: [rows_out][N]; D layout: col = lane % S, row = TnTile::out_row(register, lane / S)
+    float* out = parts + int64_t(blockIdx.x) * part_stride;
+    const int rows_out = Ka + (want_bias ? 1 : 0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        if (!mtile[i]) continue;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            if (!ntile[j]) continue;
+            const int n = (nt0 + j) * S + lc;
+            if (n >= N) continue;
+#pragma unroll
+            for (int q = 0; q < T::NQ; ++q) {
+                const int row = (mt0 + i) * S + T::out_row(q, kk);
+                if (row < rows_out) out[int64_t(row) * N + n] = acc[i][j][q];
+            }
+        }
+    }
+}
+
+struct TnDirectCfg {
+    int S, WM, TM, TN, m_groups, n_groups, wgs;
+    int64_t rows_per_wg;
+};
+
+inline int tn_env(const char* name, int dflt)
+{
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+// tile size, wave arrangement and tiles per wave.  Cost = multiplies on the critical path (the busiest wave's valid
+// tiles x groups x tile area), then operand loads per MFMA.  Instantiated wave tiles: S = 32: TM <= 4, TN <= 2;
+// S = 16: TM <= 8, TN <= 4 (128 accumulator registers either way).
+inline TnDirectCfg tn_direct_config(int64_t M, int64_t Ka, int64_t N, bool want_bias)
+{
+    static const int s_env = tn_env("TFGX_TN_S", 0), wm_env = tn_env("TFGX_TN_WM", 0), w_env = tn_env("TFGX_TN_WGS_ENV", 0);
+    TnDirectCfg best{};
+    double best_cost = 1e30, best_loads = 1e30;
+    for (int S = 16; S <= 32; S *= 2) {
+        if (s_env > 0 && S != s_env) continue;
+        const int Ti = int((Ka + (want_bias ? 1 : 0) + S - 1) / S), Tn = int((N + S - 1) / S);
+        const int tm_max = S == 32 ? 4 : 8, tn_max = S == 32 ? 2 : 4;
+        for (int WM = 1; WM <= 4; WM *= 2) {
+            if (wm_env > 0 && WM != wm_env) continue;
+            const int WN = 4 / WM;
+            int TM = (Ti + WM - 1) / WM, TN = (Tn + WN - 1) / WN;
+            int mg = 1, ng = 1;
+            if (TM > tm_max) { mg = (TM + tm_max - 1) / tm_max; TM = (TM + mg - 1) / mg; }
+            if (TN > tn_max) { ng = (TN + tn_max - 1) / tn_max; TN = (TN + ng - 1) / ng; }
+            const double cost = double(mg) * ng * TM * TN * S * S, loads = double(TM + TN) / (TM * TN) / (S / 16);
+            if (cost < best_cost * 0.999 || (cost < best_cost * 1.001 && loads < best_loads)) {
+                best_cost = cost; best_loads = loads;
+                best.S = S; best.WM = WM; best.TM = TM; best.TN = TN; best.m_groups = mg; best.n_groups = ng;
+            }
+        }
+    }
+    const int groups = best.m_groups * best.n_groups;
+    int wgs = (w_env > 0 ? w_env : 512) / groups;
+    if (wgs < 32) wgs = 32;
+    int64_t rows = (M + wgs - 1) / wgs;
+    rows = (rows + 7) / 8 * 8;                    // whole batches (8 node rows for both tile sizes)
+    if (rows < 8) rows = 8;
+    best.rows_per_wg = rows;
+    best.wgs = int((M + rows - 1) / rows);
+    if (best.wgs < 1) best.wgs = 1;
+    return best;
+}
+
+inline bool tn_use_direct()
+{
+    static const int v = tn_env("TFGX_TN_DIRECT", 1);      // 0: the LDS-staged kernel above (kept for the A/B, Ka <= 2016)
+    return v != 0;
+}
+
 // dW[i, n_first + n] = sum over workgroups (in order) of parts[b][i][n]; row Ka -> db
 __global__ void tn_reduce_kernel(const float* __restrict__ parts, int n_parts, int64_t part_stride, int Ka, int ng_cols,
                                  int n_first, int want_bias, float* __restrict__ dW, int64_t ldw, float* __restrict__ db)
@@ -788,7 +990,12 @@ extern "C" int tfgx_gemm_bias_act_f32(const float* A, int64_t lda, const float* 
 
 extern "C" size_t tfgx_gemm_tn_workspace_bytes(int64_t M, int64_t Ka, int64_t N, int32_t want_bias)
 {
-    if (M <= 0 || Ka <= 0 || N <= 0 || Ka > 2016) return 0;
+    if (M <= 0 || Ka <= 0 || N <= 0) return 0;
+    if (tn_use_direct()) {
+        const TnDirectCfg d = tn_direct_config(M, Ka, N, want_bias != 0);
+        return sizeof(float) * size_t(Ka + (want_bias ? 1 : 0)) * size_t(N) * size_t(d.wgs);
+    }
+    if (Ka > 2016) return 0;
     const TnCfg c = tn_config(M, Ka, N, want_bias != 0);
     return sizeof(float) * c.part_floats * size_t(c.wgs);
 }
@@ -799,7 +1006,8 @@ extern "C" int tfgx_gemm_tn_f32(const float* X, int64_t ldx, const float* G, int
 {
     TFGX_RANGE();
     TFGX_REQUIRE(M >= 0 && Ka >= 1 && N >= 1, "bad M / Ka / N");
-    TFGX_REQUIRE(Ka <= 2016 && N < (int64_t(1) << 30), "Ka > 2016 is not supported");
+    TFGX_REQUIRE(Ka < (int64_t(1) << 30) && N < (int64_t(1) << 30), "Ka / N too large");
+    TFGX_REQUIRE(tn_use_direct() || Ka <= 2016, "Ka > 2016 is not supported by the LDS-staged kernel (TFGX_TN_DIRECT=0)");
     TFGX_REQUIRE(dW != nullptr && ldw >= N, "bad dW");
     hipStream_t stream = as_stream(stream_);
     if (M == 0) {
@@ -809,6 +1017,53 @@ extern "C" int tfgx_gemm_tn_f32(const float* X, int64_t ldx, const float* G, int
     }
     TFGX_REQUIRE(X && G && ldx >= Ka && ldg >= N, "null pointer / leading dimension too small");
     const bool want_bias = db != nullptr;
+    if (tn_use_direct()) {
+        const TnDirectCfg d = tn_direct_config(M, Ka, N, want_bias);
+        const int64_t part_stride = int64_t(Ka + (want_bias ? 1 : 0)) * N;
+        TFGX_REQUIRE(workspace != nullptr && workspace_bytes >= sizeof(float) * size_t(part_stride) * size_t(d.wgs),
+                     "workspace too small (tfgx_gemm_tn_workspace_bytes)");
+        float* parts = static_cast<float*>(workspace);
+        dim3 grid(d.wgs, d.m_groups * d.n_groups, 1), block(256, 1, 1);
+#define TFGX_TND(S_, TM_, TN_, U_)                                                                                      \
+    gemm_tn_direct_kernel<S_, TM_, TN_, U_><<<grid, block, 0, stream>>>(X, ldx, G, ldg, M, int(Ka), int(N),             \
+                                                                        want_bias ? 1 : 0, d.WM, d.m_groups, d.TM,      \
+                                                                        d.TN, d.rows_per_wg, parts, part_stride)
+        // wave tiles are instantiated at a few sizes; a smaller request runs on the next larger one (tiles past the
+        // request are skipped by wave-uniform branches)
+        if (d.S == 32) {
+            if (d.TN <= 1) {
+                if (d.TM <= 1) TFGX_TND(32, 1, 1, 4);
+                else if (d.TM <= 2) TFGX_TND(32, 2, 1, 4);
+                else TFGX_TND(32, 4, 1, 4);
+            } else {
+                if (d.TM <= 1) TFGX_TND(32, 1, 2, 4);
+                else if (d.TM <= 2) TFGX_TND(32, 2, 2, 4);
+                else if (d.TM <= 3) TFGX_TND(32, 3, 2, 4);
+                else TFGX_TND(32, 4, 2, 4);
+            }
+        } else {
+            if (d.TN <= 1) {
+                if (d.TM <= 2) TFGX_TND(16, 2, 1, 2);
+                else if (d.TM <= 4) TFGX_TND(16, 4, 1, 2);
+                else TFGX_TND(16, 8, 1, 2);
+            } else if (d.TN <= 2) {
+                if (d.TM <= 2) TFGX_TND(16, 2, 2, 2);
+                else if (d.TM <= 4) TFGX_TND(16, 4, 2, 2);
+                else TFGX_TND(16, 8, 2, 2);
+            } else {
+                if (d.TM <= 2) TFGX_TND(16, 2, 4, 2);
+                else if (d.TM <= 4) TFGX_TND(16, 4, 4, 2);
+                else if (d.TM <= 6) TFGX_TND(16, 6, 4, 2);
+                else TFGX_TND(16, 8, 4, 2);
+            }
+        }
+#undef TFGX_TND
+        TFGX_LAUNCH_CHECK("gemm_tn_direct_kernel");
+        tn_reduce_kernel<<<grid_for(part_stride, 256), 256, 0, stream>>>(parts, d.wgs, part_stride, int(Ka), int(N), 0,
+                                                                        want_bias ? 1 : 0, dW, ldw, db);
+        TFGX_LAUNCH_CHECK("tn_reduce_kernel");
+        return TFGX_OK;
+    }
     const TnCfg c = tn_config(M, Ka, N, want_bias);
     TFGX_REQUIRE(workspace != nullptr && workspace_bytes >= sizeof(float) * c.part_floats * size_t(c.wgs),
                  "workspace too small (tfgx_gemm_tn_workspace_bytes)");

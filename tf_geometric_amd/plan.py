@@ -423,8 +423,6 @@ def gemm_tn(x, g, want_bias=False):
     M, Ka, N = int(x.shape[0]), int(x.shape[1]), int(g.shape[1])
     if int(g.shape[0]) != M:
         raise ValueError("gemm_tn: x has {} rows, g has {}".format(M, int(g.shape[0])))
-    if Ka > 2016:        # beyond the kernel's tile budget (no layer of the path is that wide on the input side)
-        return x.t() @ g, (g.sum(0) if want_bias else None)
     dW = torch.empty((Ka, N), dtype=torch.float32, device=x.device)
     db = torch.empty(N, dtype=torch.float32, device=x.device) if want_bias else None
     ws_bytes = lib.tfgx_gemm_tn_workspace_bytes(M, Ka, N, 1 if want_bias else 0)
