@@ -42,7 +42,7 @@ def main(path):
     assert lib.tfgx_gemm_bias_act_f32(None, 4, None, 4, None, 0, None, 4, 2, 0, 4, None) == 1
     assert lib.tfgx_gemm_bias_act_cols_ws_f32(None, 4, None, 4, None, 0, 9, None, 4, 2, 4, 4, None, 0, None) == 1
     assert lib.tfgx_gemm_workspace_bytes(2708, 1433, 256) > 0 and lib.tfgx_gemm_workspace_bytes(0, 1, 1) == 0
-    assert lib.tfgx_gemm_tn_workspace_bytes(2400000, 100, 256, 1) > 0 and lib.tfgx_gemm_tn_workspace_bytes(5, 3000, 4, 0) == 0
+    assert lib.tfgx_gemm_tn_workspace_bytes(2400000, 100, 256, 1) > 0 and lib.tfgx_gemm_tn_workspace_bytes(5, 3000, 4, 0) > 0 and lib.tfgx_gemm_tn_workspace_bytes(0, 3, 4, 0) == 0
     assert lib.tfgx_gemm_tn_f32(None, 4, None, 4, 10, 4, 4, None, 4, None, None, 0, None) == 1
     assert lib.tfgx_transpose_f32(None, 1, 4, 4, None, 4, None) == 1
     assert lib.tfgx_gcn_norm_edges_f32(None, None, None, 3, None, None, 9, 1.0, 1, 1, None, None, None) == 1
