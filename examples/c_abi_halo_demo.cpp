@@ -55,11 +55,35 @@ int main()
     for (int i = 0; i < 457; ++i)
         for (int j = 0; j < F; ++j)
             if (halo[i * F + j] != x[size_t(idx[i]) * F + j]) { std::fprintf(stderr, "mismatch at row %d col %d\n", i, j); return 3; }
+    // backward of the exchange: every halo row carries the gradient (row index + 1); row idx[i] of d_own must end up
+    // with (i + 1) added once (each (round, peer) list holds unique rows; rows 0..299 and 300..456 are disjoint too)
+    {
+        std::vector<float> dh(457 * F);
+        for (int i = 0; i < 457; ++i)
+            for (int j = 0; j < F; ++j) dh[i * F + j] = float(i + 1);
+        float *d_dhalo, *d_back, *d_down;
+        HK(hipMalloc(&d_dhalo, dh.size() * 4));
+        HK(hipMalloc(&d_back, dh.size() * 4));
+        HK(hipMalloc(&d_down, n_own * F * 4));
+        HK(hipMemcpy(d_dhalo, dh.data(), dh.size() * 4, hipMemcpyHostToDevice));
+        HK(hipMemset(d_down, 0, n_own * F * 4));
+        HK(hipDeviceSynchronize());
+        CK(tfgx_halo_reverse_start(plan, d_dhalo, F, d_back, size_t(457) * F, comm, compute, comms));
+        CK(tfgx_halo_reverse_finish(plan, d_down, F, F, d_back, compute));
+        HK(hipStreamSynchronize(compute));
+        std::vector<float> down(n_own * F), want(n_own * F, 0.0f);
+        HK(hipMemcpy(down.data(), d_down, down.size() * 4, hipMemcpyDeviceToHost));
+        for (int i = 0; i < 457; ++i)
+            for (int j = 0; j < F; ++j) want[size_t(idx[i]) * F + j] += float(i + 1);
+        for (size_t t = 0; t < down.size(); ++t)
+            if (down[t] != want[t]) { std::fprintf(stderr, "reverse exchange mismatch at %zu: %g vs %g\n", t, down[t], want[t]); return 4; }
+        HK(hipFree(d_dhalo)); HK(hipFree(d_back)); HK(hipFree(d_down));
+    }
     // the weight-gradient all-reduce (world 1: identity)
     CK(tfgx_allreduce_sum_f32(dhalo, 457 * F, comm, compute));
     HK(hipStreamSynchronize(compute));
     CK(tfgx_halo_plan_destroy(plan));
     ncclCommDestroy(comm);
-    std::printf("c_abi_halo_demo: OK (2 rounds, 457 rows x %lld floats through RCCL)\n", (long long)F);
+    std::printf("c_abi_halo_demo: OK (2 rounds, 457 rows x %lld floats through RCCL, forward and reverse)\n", (long long)F);
     return 0;
 }

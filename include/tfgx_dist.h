@@ -51,6 +51,17 @@ int tfgx_halo_exchange_start(tfgx_halo_plan* plan, const float* x_own, int64_t l
 /* Make compute_stream wait for round `round` (0 <= round < R), or for all rounds when round < 0. */
 int tfgx_halo_exchange_finish(tfgx_halo_plan* plan, int32_t round, void* compute_stream);
 
+/* Backward of the exchange (training: d(loss)/d(halo rows) belongs to the rows' owners).  d_halo [rows_received, F]
+ * dense, laid out as the halo table; back_buf: device scratch of rows_sent * F floats.  start() posts, per round, the
+ * grouped sends of this rank's halo-row gradients and the receives of what peers computed for THIS rank's rows, ordered
+ * after whatever wrote d_halo on compute_stream.  finish() makes compute_stream wait round by round and adds the
+ * returned rows into d_own [n_own, F] (ld = ldd) at the forward send indices — round by round, peer by peer in rank
+ * order, one writer per element and launch (tfgx_scatter_add_rows_f32): bit-reproducible, no atomics. */
+int tfgx_halo_reverse_start(tfgx_halo_plan* plan, const float* d_halo, int64_t F, float* back_buf,
+                            size_t back_buf_floats, void* nccl_comm, void* compute_stream, void* comm_stream);
+int tfgx_halo_reverse_finish(tfgx_halo_plan* plan, float* d_own, int64_t ldd, int64_t F, const float* back_buf,
+                             void* compute_stream);
+
 /* sum-all-reduce of a float buffer in place (weight gradients of replicated layer weights: the one collective the
  * reference's distributed demos perform, demo/demo_distributed_gcn.py:52-57). */
 int tfgx_allreduce_sum_f32(float* buf, int64_t count, void* nccl_comm, void* stream);

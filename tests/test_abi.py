@@ -156,7 +156,7 @@ def test_dist_library_exports_every_declared_symbol():
     with open(os.path.join(ROOT, "include", "tfgx_dist.h")) as fh:
         src = re.sub(r"/\*.*?\*/", "", fh.read(), flags=re.S)
     names = sorted(set(re.findall(r"\b(tfgx_[a-z0-9_]+)\s*\(", src)))
-    assert len(names) == 8, names
+    assert len(names) == 10, names
     if not os.path.exists(_build.DIST_LIB):
         _build.build_dist(verbose=False)
     lib = ctypes.CDLL(_build.DIST_LIB)
@@ -169,6 +169,8 @@ def test_dist_library_exports_every_declared_symbol():
     assert b"bad world" in lib.tfgx_dist_last_error()
     assert lib.tfgx_halo_plan_create(2, 0, 2, cnt, cnt, None, ctypes.byref(plan)) == 1      # rows to send, no index list
     assert lib.tfgx_halo_exchange_finish(None, 0, None) == 1
+    assert lib.tfgx_halo_reverse_start(None, None, 4, None, 0, None, None, None) == 1
+    assert lib.tfgx_halo_reverse_finish(None, None, 4, 4, None, None) == 1
 
 
 def test_tf_shim_compiles_against_mock_headers():

@@ -50,8 +50,8 @@ struct tfgx_halo_plan {
     std::vector<int64_t> send_counts, recv_counts;     // [rounds * world]
     std::vector<int64_t> send_off, recv_off;           // row offsets, same indexing (+1 total at the end)
     const int32_t* send_idx;                           // device
-    std::vector<hipEvent_t> packed, done;              // per round
-    bool in_flight;
+    std::vector<hipEvent_t> packed, done, rdone;       // per round (rdone: the reverse exchange)
+    bool in_flight, reverse_in_flight;
 };
 
 extern "C" const char* tfgx_dist_last_error(void) { return g_err; }
@@ -63,7 +63,7 @@ extern "C" int tfgx_halo_plan_create(int32_t world, int32_t rank, int32_t rounds
     DIST_REQUIRE(world >= 1 && rank >= 0 && rank < world && rounds >= 1 && rounds <= 64, "bad world / rank / rounds");
     DIST_REQUIRE(send_counts && recv_counts, "null counts");
     tfgx_halo_plan* p = new tfgx_halo_plan();
-    p->world = world; p->rank = rank; p->rounds = rounds; p->send_idx = send_idx; p->in_flight = false;
+    p->world = world; p->rank = rank; p->rounds = rounds; p->send_idx = send_idx; p->in_flight = false; p->reverse_in_flight = false;
     const size_t n = size_t(rounds) * size_t(world);
     p->send_counts.assign(send_counts, send_counts + n);
     p->recv_counts.assign(recv_counts, recv_counts + n);
@@ -86,9 +86,11 @@ extern "C" int tfgx_halo_plan_create(int32_t world, int32_t rank, int32_t rounds
     }
     p->packed.assign(rounds, nullptr);
     p->done.assign(rounds, nullptr);
+    p->rdone.assign(rounds, nullptr);
     for (int j = 0; j < rounds; ++j) {
         hipError_t e = hipEventCreateWithFlags(&p->packed[j], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&p->done[j], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&p->rdone[j], hipEventDisableTiming);
         if (e != hipSuccess) {
             set_err("tfgx_halo_plan_create: hipEventCreateWithFlags: %s", hipGetErrorString(e));
             tfgx_halo_plan_destroy(p);
@@ -104,6 +106,7 @@ extern "C" int tfgx_halo_plan_destroy(tfgx_halo_plan* p)
     if (p == nullptr) return TFGX_OK;
     for (hipEvent_t e : p->packed) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : p->done) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : p->rdone) if (e) (void)hipEventDestroy(e);
     delete p;
     return TFGX_OK;
 }
@@ -169,6 +172,73 @@ extern "C" int tfgx_halo_exchange_finish(tfgx_halo_plan* p, int32_t round, void*
         DIST_HIP(hipStreamWaitEvent(cs, p->done[round], 0));
     } else {
         for (int j = 0; j < p->rounds; ++j) DIST_HIP(hipStreamWaitEvent(cs, p->done[j], 0));
+    }
+    return TFGX_OK;
+}
+
+// ---- backward of the exchange: halo-row gradients return to their owners along the same lists, reversed
+extern "C" int tfgx_halo_reverse_start(tfgx_halo_plan* p, const float* d_halo, int64_t F, float* back_buf,
+                                       size_t back_buf_floats, void* nccl_comm, void* compute_stream, void* comm_stream)
+{
+    DIST_REQUIRE(p != nullptr, "plan is null");
+    DIST_REQUIRE(F >= 1, "bad F");
+    const int64_t rows_sent = p->send_off.back(), rows_recv = p->recv_off.back();
+    DIST_REQUIRE(rows_recv == 0 || d_halo != nullptr, "d_halo is null");
+    DIST_REQUIRE(rows_sent == 0 || (back_buf && back_buf_floats >= size_t(rows_sent) * size_t(F)), "back_buf too small");
+    DIST_REQUIRE(nccl_comm != nullptr || (rows_sent == 0 && rows_recv == 0), "nccl_comm is null");
+    hipStream_t cs = reinterpret_cast<hipStream_t>(compute_stream);
+    hipStream_t ms = reinterpret_cast<hipStream_t>(comm_stream);
+    ncclComm_t comm = reinterpret_cast<ncclComm_t>(nccl_comm);
+    if (p->reverse_in_flight) {   // a previous reverse exchange may still be writing back_buf
+        for (int j = 0; j < p->rounds; ++j) DIST_HIP(hipStreamWaitEvent(cs, p->rdone[j], 0));
+    }
+    // d_halo is produced on the compute stream (the transposed local pass): order the sends after it
+    DIST_HIP(hipEventRecord(p->packed[0], cs));
+    DIST_HIP(hipStreamWaitEvent(ms, p->packed[0], 0));
+    for (int j = 0; j < p->rounds; ++j) {
+        const size_t base = size_t(j) * size_t(p->world);
+        if (nccl_comm != nullptr) {
+            DIST_NCCL(ncclGroupStart());
+            for (int q = 0; q < p->world; ++q) {
+                // what I RECEIVED from q in the forward exchange is what I now SEND to q, and vice versa
+                const int64_t sc = p->recv_counts[base + q], rc = p->send_counts[base + q];
+                if (sc > 0)
+                    DIST_NCCL(ncclSend(d_halo + p->recv_off[base + q] * F, size_t(sc) * size_t(F), ncclFloat, q, comm, ms));
+                if (rc > 0)
+                    DIST_NCCL(ncclRecv(back_buf + p->send_off[base + q] * F, size_t(rc) * size_t(F), ncclFloat, q, comm, ms));
+            }
+            DIST_NCCL(ncclGroupEnd());
+        }
+        DIST_HIP(hipEventRecord(p->rdone[j], ms));
+    }
+    p->reverse_in_flight = true;
+    return TFGX_OK;
+}
+
+extern "C" int tfgx_halo_reverse_finish(tfgx_halo_plan* p, float* d_own, int64_t ldd, int64_t F, const float* back_buf,
+                                        void* compute_stream)
+{
+    DIST_REQUIRE(p != nullptr, "plan is null");
+    DIST_REQUIRE(p->reverse_in_flight, "no reverse exchange was started");
+    DIST_REQUIRE(F >= 1 && ldd >= F, "bad F / leading dimension");
+    const int64_t rows_sent = p->send_off.back();
+    DIST_REQUIRE(rows_sent == 0 || (d_own && back_buf), "null pointer");
+    hipStream_t cs = reinterpret_cast<hipStream_t>(compute_stream);
+    // owner-side accumulate, round by round and peer by peer in rank order: one (round, peer) list holds no repeated
+    // row, so every element of d_own has ONE writer per launch and the sum order is fixed — deterministic, no atomics
+    for (int j = 0; j < p->rounds; ++j) {
+        DIST_HIP(hipStreamWaitEvent(cs, p->rdone[j], 0));
+        const size_t base = size_t(j) * size_t(p->world);
+        for (int q = 0; q < p->world; ++q) {
+            const int64_t cnt = p->send_counts[base + q], off = p->send_off[base + q];
+            if (cnt == 0) continue;
+            const int rc = tfgx_scatter_add_rows_f32(d_own, ldd, p->send_idx + off, cnt, F, back_buf + off * F, F,
+                                                     reinterpret_cast<tfgx_stream_t>(cs));
+            if (rc != TFGX_OK) {
+                set_err("tfgx_scatter_add_rows_f32: %s", tfgx_last_error());
+                return rc;
+            }
+        }
     }
     return TFGX_OK;
 }
