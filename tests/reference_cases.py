@@ -588,6 +588,47 @@ _add("edge_preprocessing", _edge_inputs,
             "noself_w"])
 
 
+def _gutil_inputs():
+    g = sym_graph(90, 500, 4, seed=208)                              # undirected, no self-loops, weighted
+    rng = np.random.Generator(np.random.PCG64(209))
+    loops = graph(60, 400, 3, seed=210, self_loops=25)               # directed multigraph WITH self-loops and duplicates
+    sampled_nodes = rng.permutation(90)[:40].astype(np.int32)
+    sub = rng.integers(0, 90, size=(2, 300), dtype=np.int32)        # some endpoints were not sampled -> -1
+    return dict(g=g, loops=loops, sampled_nodes=sampled_nodes, sub=sub)
+
+
+def _gutil_run(U, d):
+    g, lp = d["g"], d["loops"]
+    out = {}
+    for nt in ("sym", "rw", None):
+        for tag, gg in (("sym_graph", g), ("loops", lp)):
+            ei, w = U.get_laplacian(gg["ei"], gg["n"], gg["w"], nt, fill_weight=1.5 if tag == "loops" else 1.0)
+            out["laplacian-{}-{}-index".format(nt, tag)], out["laplacian-{}-{}-w".format(nt, tag)] = _np(ei), _np(w)
+    for asl in (False, True):
+        ei, w = U.adj_norm_edge(lp["ei"], lp["n"], lp["w"], add_self_loop=asl)
+        out["adj_norm-{}-index".format(asl)], out["adj_norm-{}-w".format(asl)] = _np(ei), _np(w)
+    ei, w = U.adj_norm_edge(g["ei"], g["n"], None)
+    out["adj_norm-unweighted-w"] = _np(w)
+    cache = {}
+    first = U.adj_norm_edge(g["ei"], g["n"], g["w"], cache=cache)
+    again = U.adj_norm_edge(lp["ei"], lp["n"], lp["w"], cache=cache)          # the cache wins over the arguments (:916-920)
+    out["adj_norm-cache-hit"] = np.array([_np(first[1]).shape[0] == _np(again[1]).shape[0], "adj_normed_edge" in cache])
+    out["reindexed"] = _np(U.reindex_sampled_edge_index(d["sub"], d["sampled_nodes"]))
+    out["lambda_max-sym"] = np.float32(U.LaplacianMaxEigenvalue(g["ei"], g["n"], g["w"])("sym"))
+    out["lambda_max-unweighted-sym"] = np.float32(U.LaplacianMaxEigenvalue(g["ei"], g["n"], None)("sym"))
+    return out
+
+
+_add("graph_utils_laplacian_reindex", _gutil_inputs,
+     lambda R, d: _gutil_run(R.tfg.utils.graph_utils, d), None, lambda T, d: _gutil_run(T.utils, d),
+     exact=["reindexed", "adj_norm-cache-hit"] + ["laplacian-{}-{}-index".format(nt, t) for nt in ("sym", "rw", None)
+                                                  for t in ("sym_graph", "loops")]
+           + ["adj_norm-{}-index".format(a) for a in (False, True)],
+     key_tol={"laplacian-None-loops-w": 2e-5, "laplacian-None-sym_graph-w": 2e-5},
+     note="get_laplacian(None) subtracts a weight from a degree (a sum of ~10 weights): one fp32 rounding of the sum "
+          "order shows at 1e-5 relative to the difference")
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # (f2) the other SpMM-shaped convolutions — nn/conv/{sgc,tagcn,appnp,ssgc,chebynet,gin,le_conv}.py
 # ---------------------------------------------------------------------------------------------------------------------

@@ -107,9 +107,11 @@ class _MlpPropagation(Layer):
 class APPNP(_MlpPropagation):
     """layers/conv/appnp.py:31-35."""
 
-    def __init__(self, units_list, dense_activation=relu, activation=None, k=10, alpha=0.1, **kwargs):
-        super().__init__(units_list=units_list, dense_activation=dense_activation, activation=activation, k=k,
-                         alpha=alpha, **kwargs)
+    def __init__(self, units_list, dense_activation=relu, activation=None, k=10, alpha=0.1, dense_drop_rate=0.0,
+                 last_dense_drop_rate=0.0, edge_drop_rate=0.0, kernel_regularizer=None, bias_regularizer=None,
+                 *args, **kwargs):
+        super().__init__(units_list, dense_activation, activation, k, alpha, dense_drop_rate, last_dense_drop_rate,
+                         edge_drop_rate, kernel_regularizer, bias_regularizer, *args, **kwargs)
 
     def call(self, inputs, cache=None, training=None, mask=None):
         x, edge_index, edge_weight = _unpack(inputs)

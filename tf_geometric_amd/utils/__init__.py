@@ -230,3 +230,110 @@ class RandomNeighborSampler(object):
             n_cols = self.num_col_nodes if sampled_node_index is None else int(col.max().item()) + 1 if total else 0
             ei._tfgx_plan = CsrPlan.from_sorted(out_ptr, out_col, n_cols, edge_index=ei)
         return _out(ei, self._numpy), _out(out_w, self._numpy)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Laplacian / adjacency normalisation in EDGE-LIST form and sampled-subgraph re-indexing — the reference's public
+# helpers around the path (ChebyNet's prologue, the sampler's epilogue).  Device tensors throughout; degrees come
+# from the segment kernels (tfgx_segment_weight_sum_f32 over a CSR plan), the rest is per-edge elementwise work.
+# ---------------------------------------------------------------------------------------------------------------
+
+def _row_degree(ei, w, num_nodes):
+    """deg[r] = sum of w over edges with edge_index[0] == r (tf.math.unsorted_segment_sum), on the plan kernels."""
+    from ..plan import CsrPlan
+    lib = L.require_gpu()
+    plan = CsrPlan.build(ei, num_nodes)
+    w_csr = plan.edge_attr_to_csr(w)
+    deg = torch.empty(num_nodes, dtype=torch.float32, device=ei.device)
+    L.check(lib.tfgx_segment_weight_sum_f32(L.ptr(plan.row_ptr), L.ptr(w_csr), num_nodes, 0.0, L.ptr(deg),
+                                            L.stream_ptr()), "tfgx_segment_weight_sum_f32")
+    return deg
+
+
+def _finite_or_zero(t):
+    return torch.where(torch.isinf(t) | torch.isnan(t), torch.zeros_like(t), t)
+
+
+def get_laplacian(edge_index, num_nodes, edge_weight, normalization_type, fill_weight=1.0):
+    """Edge list of the graph Laplacian as the reference writes it (utils/graph_utils.py:554-603): degrees are the row
+    sums of the GIVEN edges; None: the N diagonal edges are appended with `fill_weight` and every edge (appended ones
+    included) becomes deg[row] - w; 'sym': D^-1/2 A D^-1/2 then the diagonal appended with fill_weight; 'rw': D^-1 A
+    then the diagonal.  numpy in -> numpy out, tensor in -> tensor out."""
+    if normalization_type is not None:
+        assert normalization_type in [None, 'sym', 'rw']                                   # :555-556
+    as_np = not isinstance(edge_index, torch.Tensor)
+    ei = L.as_i32(edge_index)
+    w = L.as_f32(edge_weight, ei.device)
+    deg = _row_degree(ei, w, num_nodes)
+    row, col = ei[0].long(), ei[1].long()
+    if normalization_type is None:
+        ei2, w2 = add_self_loop_edge(ei, num_nodes, w, fill_weight=fill_weight)
+        out_w = _finite_or_zero(deg)[ei2[0].long()] - w2
+    elif normalization_type == 'sym':
+        dis = _finite_or_zero(torch.pow(deg, -0.5))
+        ei2, out_w = add_self_loop_edge(ei, num_nodes, dis[row] * w * dis[col], fill_weight=fill_weight)
+    else:
+        dinv = _finite_or_zero(1.0 / deg)
+        ei2, out_w = add_self_loop_edge(ei, num_nodes, dinv[row] * w, fill_weight=fill_weight)
+    return _out(ei2, as_np), _out(out_w, as_np)
+
+
+def adj_norm_edge(edge_index, num_nodes, edge_weight=None, add_self_loop=False, cache=None):
+    """D^-1/2 A D^-1/2 on the edge list, D = row sums, optional appended unit self-loops first; cached under
+    "adj_normed_edge" (utils/graph_utils.py:914-943)."""
+    cache_key = "adj_normed_edge"
+    if cache is not None:
+        cached = cache.get(cache_key, None)
+        if cached is not None:
+            return cached
+    as_np = not isinstance(edge_index, torch.Tensor)
+    ei = L.as_i32(edge_index)
+    w = (torch.ones(int(ei.shape[1]), dtype=torch.float32, device=ei.device) if edge_weight is None
+         else L.as_f32(edge_weight, ei.device))
+    if add_self_loop:
+        ei, w = add_self_loop_edge(ei, num_nodes, w, fill_weight=1.0)
+    dis = _finite_or_zero(torch.pow(_row_degree(ei, w, num_nodes), -0.5))
+    res = _out(ei, as_np), _out(dis[ei[0].long()] * w * dis[ei[1].long()], as_np)
+    if cache is not None:
+        cache[cache_key] = res
+    return res
+
+
+class LaplacianMaxEigenvalue(object):
+    """Largest-magnitude eigenvalue of the graph Laplacian (utils/graph_utils.py:884-909; ChebyNet's
+    use_dynamic_lambda_max).  The reference hands a scipy matrix to ARPACK; here the operator stays on the device and an
+    Arnoldi iteration runs every L @ v on the segment-reduce kernel (nn/conv/propagation.laplacian_max_eigenvalue)."""
+
+    def __init__(self, edge_index, num_nodes, edge_weight, is_undirected=True):
+        self.num_nodes = num_nodes
+        self.edge_index = L.as_i32(edge_index)
+        self.edge_weight = (torch.ones(int(self.edge_index.shape[1]), dtype=torch.float32, device=self.edge_index.device)
+                            if edge_weight is None else L.as_f32(edge_weight, self.edge_index.device))
+        self.is_undirected = is_undirected
+
+    def __call__(self, normalization_type='sym'):
+        assert normalization_type in [None, 'sym', 'rw']
+        from ..nn.conv.propagation import chebynet_norm_edge, laplacian_max_eigenvalue
+        if bool((self.edge_index[0] == self.edge_index[1]).any()):
+            # the reference filters the WEIGHTS of self-loops but keeps the unfiltered edge_index (:896-898): with a
+            # self-loop present its tf ops fail on the shape mismatch — same contract here, as an explicit error
+            raise ValueError("LaplacianMaxEigenvalue: edge_index holds self-loops (the reference fails on them too: "
+                             "graph_utils.py:896-898 pairs filtered weights with the unfiltered index)")
+        lap = chebynet_norm_edge(self.edge_index, self.num_nodes, self.edge_weight, normalization_type,
+                                 use_dynamic_lambda_max=False)
+        # chebynet_norm_edge scales by 2 / lambda_max with lambda_max = 2: the plan holds the Laplacian itself
+        return laplacian_max_eigenvalue(lap, normalization_type)
+
+
+def reindex_sampled_edge_index(sampled_edge_index, sampled_node_index):
+    """Map node ids of a sampled edge list to their positions in `sampled_node_index`; ids that were not sampled become
+    -1 (the StaticHashTable default of utils/graph_utils.py:946-973).  numpy in -> numpy out, tensor in -> tensor out."""
+    as_np = not isinstance(sampled_edge_index, torch.Tensor)
+    ei = L.as_i32(sampled_edge_index)
+    idx = L.as_i32(sampled_node_index, ei.device).long()
+    hi = int(max(int(ei.max().item()) if ei.numel() else -1, int(idx.max().item()) if idx.numel() else -1)) + 1
+    table = torch.full((max(hi, 1),), -1, dtype=torch.int32, device=ei.device)
+    table[idx] = torch.arange(int(idx.shape[0]), dtype=torch.int32, device=ei.device)
+    out = table[ei.long().clamp(min=0)]
+    out = torch.where(ei < 0, torch.full_like(out, -1), out)
+    return _out(out, as_np)
