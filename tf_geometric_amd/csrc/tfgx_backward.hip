@@ -690,6 +690,46 @@ __global__ __launch_bounds__(kBlock) void gat_pack_dst_kernel(const float* __res
     }
 }
 
+// Same result, one lane per FOUR value columns (16-byte loads / stores; the lanes of a head reduce <dO, O> with a
+// butterfly) plus ceil((A + 2H) / 4) lanes per row for the [Q | (m, l)] copies.  Needs dv % 4 == 0, LH = dv / 4 a power of
+// two that divides the lanes per row, 16-byte aligned dO / O / pack rows.
+__global__ __launch_bounds__(kBlock) void gat_pack_dst_vec4_kernel(const float* __restrict__ go, int64_t ldgo,
+                                                                   const float* __restrict__ o, int64_t ldo,
+                                                                   const float* __restrict__ q, int64_t ldq,
+                                                                   const float* __restrict__ ml, int64_t n, int H, int dv,
+                                                                   int A, float* __restrict__ pack, int64_t P,
+                                                                   float* __restrict__ dsum)
+{
+    const int W = H * dv, w4 = W / 4, lh = dv / 4;
+    const int per_row = w4 + (A + 2 * H + 3) / 4;
+    int64_t t = blockIdx.x * int64_t(kBlock) + threadIdx.x;
+    const int64_t stride = int64_t(gridDim.x) * kBlock;      // a multiple of 64: lane groups stay aligned
+    for (; t < n * per_row; t += stride) {
+        const int64_t r = t / per_row;
+        const int k = int(t - r * per_row);
+        float* pr = pack + r * P;
+        if (k < w4) {
+            float g4[4], o4[4];
+            load_vec<4>(go + r * ldgo + 4 * k, g4);
+            load_vec<4>(o + r * ldo + 4 * k, o4);
+            store_vec<4>(pr + 4 * k, g4);
+            float acc = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc = fmaf(g4[i], o4[i], acc);
+            for (int off = lh >> 1; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+            if (k % lh == 0) {
+                const int head = k / lh;
+                dsum[r * H + head] = acc;
+                pr[W + A + 2 * H + head] = acc;
+            }
+        } else {                                        // four floats of [Q | (m, l)]
+            const int c0 = (k - w4) * 4;
+            for (int c = c0; c < c0 + 4 && c < A + 2 * H; ++c)
+                pr[W + c] = c < A ? q[r * ldq + c] : ml[r * 2 * H + (c - A)];
+        }
+    }
+}
+
 template <int G, int D, bool SRC>
 __global__ __launch_bounds__(kBlock) void gat_backward_fast_kernel(const GB a)
 {
@@ -1102,6 +1142,16 @@ extern "C" int tfgx_gat_pack_dst_f32(const float* grad_out, int64_t ld_grad_out,
     TFGX_REQUIRE(ld_grad_out >= W && ldo >= W && ldq >= A && ld_pack >= W + A + 3 * int64_t(H), "leading dimension too small");
     if (n_dst == 0) return TFGX_OK;
     TFGX_REQUIRE(grad_out && out && q && stats_ml && pack && dsum, "null pointer");
+    const int lh = dv / 4;
+    const int per_row4 = int(W / 4 + (A + 2 * H + 3) / 4);
+    const bool vec4 = dv % 4 == 0 && pow2(lh) && lh <= 64 && per_row4 % lh == 0 && ld_grad_out % 4 == 0 && ldo % 4 == 0 &&
+                      ld_pack % 4 == 0 && aligned_to(grad_out, 16) && aligned_to(out, 16) && aligned_to(pack, 16);
+    if (vec4) {
+        gat_pack_dst_vec4_kernel<<<grid_for(n_dst * per_row4, kBlock), kBlock, 0, as_stream(stream)>>>(
+            grad_out, ld_grad_out, out, ldo, q, ldq, stats_ml, n_dst, H, dv, int(A), pack, ld_pack, dsum);
+        TFGX_LAUNCH_CHECK("gat_pack_dst_vec4_kernel");
+        return TFGX_OK;
+    }
     const int per_row = H + int((A + 2 * H + 3) / 4);
     gat_pack_dst_kernel<<<grid_for(n_dst * per_row, kBlock), kBlock, 0, as_stream(stream)>>>(
         grad_out, ld_grad_out, out, ldo, q, ldq, stats_ml, n_dst, H, dv, int(A), pack, ld_pack, dsum);
