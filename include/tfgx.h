@@ -423,6 +423,10 @@ int tfgx_l2_normalize_rows_f32(float* h, int64_t ld, int64_t n, int64_t F, tfgx_
  * ------------------------------------------------------------------------------------------- */
 int tfgx_gather_rows_f32(const float* x, int64_t ldx, const int32_t* idx, int64_t M, int64_t F,
                          float* out, int64_t ldo, tfgx_stream_t stream);
+/* gout[m, n] = out[m, n] > 0 ? g[m, n] : 0: backward of the ReLU fused into tfgx_gemm_bias_act_f32 /
+   tfgx_segment_reduce_f32 epilogues (tf.nn.relu under a GradientTape, demo/demo_gcn.py:68-77).  gout may alias g. */
+int tfgx_relu_backward_f32(const float* g, int64_t ldg, const float* out, int64_t ldo, int64_t M, int64_t N,
+                           float* gout, int64_t ldgo, tfgx_stream_t stream);
 /* dst[idx[i], :] += src[i, :] for i in [0, M): owner-side accumulate of the reverse halo exchange (gradients of halo rows
    returning to their owners during training).  idx must hold UNIQUE ids within one call (one peer's request list does);
    peers are applied by the caller in a fixed order, so the sum is deterministic without atomics. */

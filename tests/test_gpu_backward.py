@@ -338,6 +338,41 @@ def test_sage_layers_train_step_decreases_loss(tfg, oracle, cls):
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in layer.parameters())
 
 
+@pytest.mark.parametrize("cls,f,units,concat", [("MeanGraphSage", 10, 32, True), ("MeanGraphSage", 40, 16, True),
+                                                 ("SumGraphSage", 40, 16, True), ("MeanGraphSage", 40, 16, False),
+                                                 ("SumGraphSage", 12, 24, False)])
+def test_mean_sum_sage_layer_grads_fused_epilogues(tfg, oracle, cls, f, units, concat):
+    """The training route of mean / sum GraphSAGE: with concat both halves are written in place with bias + ReLU in the
+    GEMM / aggregation epilogues (autograd._DualLinear when the reduction runs at the input width, autograd._SageNarrow
+    when the neighbour projection runs first), without concat the un-fused operators — outputs and the gradients of x,
+    both kernels and the bias vs float64 autograd over graph_sage.py:9-115's formula."""
+    x, ei, w, rng = _graph(oracle, n=260, e=2600, f=f, seed=21)
+    n = x.shape[0]
+    ei = ei[:, ei[0] != 5]                                             # an empty row: mean divides by max(count, 1)
+    w = w[:ei.shape[1]]
+    layer = getattr(tfg.layers, cls)(units, activation=tfg.relu, concat=concat)
+    layer._maybe_build([x])
+    ku = units // 2 if concat else units
+    ws = {"self_kernel": oracle.glorot_uniform(rng, f, ku), "neighbor_kernel": oracle.glorot_uniform(rng, f, ku),
+          "bias": (rng.standard_normal(units) * 0.3).astype(np.float32)}
+    layer.set_weights(**ws)
+    layer.trainable(True)
+    xt = torch.tensor(x, device="cuda", requires_grad=True)
+    out = layer([xt, ei, w], cache={})
+    gout = torch.tensor(rng.standard_normal((n, units)).astype(np.float32), device="cuda")
+    out.backward(gout)
+    r = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in ws.items()}
+    xr = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    red = _ref_aggregate(xr, ei, torch.tensor(w, dtype=torch.float64), "mean" if cls.startswith("Mean") else "sum", n)
+    a, b = xr @ r["self_kernel"], red @ r["neighbor_kernel"]
+    ref = torch.relu((torch.cat([a, b], 1) if concat else a + b) + r["bias"])
+    ref.backward(gout.double().cpu())
+    assert_parity(out.detach().cpu().numpy(), ref.detach().numpy(), what=cls + " forward")
+    assert_parity(xt.grad.cpu().numpy(), xr.grad.numpy(), tol=5e-5, what=cls + " d/dx")
+    for k in ws:
+        assert_parity(getattr(layer, k).grad.cpu().numpy(), r[k].grad.numpy(), tol=2e-4, what=cls + " d/d" + k)
+
+
 def test_demo_gcn_trains_on_cora_shaped_graph(tfg):
     """examples/demo_gcn.py (counterpart of the reference's demo/demo_gcn.py): accuracy far above 1/7 chance."""
     import os

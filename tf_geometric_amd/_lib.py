@@ -115,6 +115,7 @@ SIGNATURES = {
     "tfgx_dropout_keep": (ctypes.c_int32, [ctypes.c_uint64, ctypes.c_uint32, _F32]),
     "tfgx_permute_rows_f32": (ctypes.c_int, [_P, _P, _I64, _I64, _P, _P]),
     "tfgx_gat_pack_dst_f32": (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _I64, _P, _P]),
+    "tfgx_relu_backward_f32": (ctypes.c_int, [_P, _I64, _P, _I64, _I64, _I64, _P, _I64, _P]),
     "tfgx_scatter_add_rows_f32": (ctypes.c_int, [_P, _I64, _P, _I64, _I64, _P, _I64, _P]),
     "tfgx_segment_reduce_f32": (ctypes.c_int, [ctypes.POINTER(ReduceArgs), _P]),
     "tfgx_segment_reduce_describe": (ctypes.c_int, [ctypes.POINTER(ReduceArgs), ctypes.c_char_p, ctypes.c_size_t]),

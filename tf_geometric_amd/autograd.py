@@ -65,33 +65,61 @@ def _transposed_weights(plan, w_csr, t2d):
     return w_t
 
 
+def relu_backward(g, out):
+    """g where out > 0, else 0 — ONE pass (tfgx_relu_backward_f32) instead of compare + cast + multiply; g / out may be
+    column slices of wider matrices."""
+    lib = L.require_gpu()
+    g2, ldg = L.row_major_2d(g)
+    o2, ldo = L.row_major_2d(out)
+    M, N = int(g2.shape[0]), int(g2.shape[1])
+    res = torch.empty((M, N), dtype=torch.float32, device=g2.device)
+    L.check(lib.tfgx_relu_backward_f32(L.ptr(g2), ldg, L.ptr(o2), ldo, M, N, L.ptr(res), N, L.stream_ptr()),
+            "tfgx_relu_backward_f32")
+    return res
+
+
+def _aggregate_grad_x(plan, mean, g, w_csr, self_coef):
+    """d/dx of out = (1/cnt) (sum_i w_i x[col_i] + self_coef x): the transposed plan on the same kernel; on a square
+    operator the self-loop term self_coef[r] * g[r] rides in that launch's epilogue."""
+    if mean:
+        g = g / plan.in_degree().clamp(min=1).to(g.dtype).unsqueeze(1)
+    pt, t2d = _transposed(plan)
+    w_t = _transposed_weights(plan, w_csr, t2d)
+    if self_coef is not None and plan.n_dst == plan.n_src:
+        return segment_reduce(pt, g, L.SUM, w_csr=w_t, self_coef=self_coef.detach()), g
+    gx = segment_reduce(pt, g, L.SUM, w_csr=w_t)
+    if self_coef is not None:
+        gx = gx + self_coef.detach().unsqueeze(1) * g
+    return gx, g
+
+
 class _Aggregate(torch.autograd.Function):
-    """out[r] = (1/cnt[r]) * ( sum_{i in row r} w[i] x[col[i]] + self_coef[r] x[r] )   (cnt only for mean)."""
+    """out = act( (1/cnt[r]) * ( sum_{i in row r} w[i] x[col[i]] + self_coef[r] x[r] ) + bias )   (cnt only for mean);
+    bias and activation ride in the kernel's epilogue, the ReLU's backward is one masked copy of the gradient."""
 
     @staticmethod
-    def forward(ctx, plan, mean, x, w_csr, self_coef, rows=None):
+    def forward(ctx, plan, mean, x, w_csr, self_coef, rows=None, bias=None, act=L.ACT_NONE):
         """`rows`: x in another source layout (plan.static_rows) — same values, same result bits."""
-        ctx.plan, ctx.mean = plan, mean
-        ctx.save_for_backward(x, w_csr, self_coef)
-        return segment_reduce(plan, x.detach() if rows is None else rows, L.MEAN if mean else L.SUM,
-                              w_csr=None if w_csr is None else w_csr.detach(),
-                              self_coef=None if self_coef is None else self_coef.detach())
+        ctx.plan, ctx.mean, ctx.act = plan, mean, act
+        out = segment_reduce(plan, x.detach() if rows is None else rows, L.MEAN if mean else L.SUM,
+                             w_csr=None if w_csr is None else w_csr.detach(),
+                             self_coef=None if self_coef is None else self_coef.detach(),
+                             bias=None if bias is None else bias.detach().contiguous(), act=act)
+        ctx.save_for_backward(x, w_csr, self_coef, bias, out if act == L.ACT_RELU else None)
+        return out
 
     @staticmethod
     def backward(ctx, g):
         lib = L.require_gpu()
         plan = ctx.plan
-        x, w_csr, self_coef = ctx.saved_tensors
-        g = g.contiguous()
-        if ctx.mean:
-            g = g / plan.in_degree().clamp(min=1).to(g.dtype).unsqueeze(1)
+        x, w_csr, self_coef, bias, out = ctx.saved_tensors
+        g = relu_backward(g, out) if ctx.act == L.ACT_RELU else g.contiguous()
+        gb = g.sum(0) if (bias is not None and ctx.needs_input_grad[6]) else None
         gx = gw = gs = None
+        if ctx.mean and (ctx.needs_input_grad[3] or ctx.needs_input_grad[4]) and not ctx.needs_input_grad[2]:
+            g = g / plan.in_degree().clamp(min=1).to(g.dtype).unsqueeze(1)
         if ctx.needs_input_grad[2]:
-            pt, t2d = _transposed(plan)
-            w_t = _transposed_weights(plan, w_csr, t2d)
-            gx = segment_reduce(pt, g, L.SUM, w_csr=w_t)
-            if self_coef is not None:
-                gx = gx + self_coef.detach().unsqueeze(1) * g
+            gx, g = _aggregate_grad_x(plan, ctx.mean, g, w_csr, self_coef)
         if w_csr is not None and ctx.needs_input_grad[3]:
             gw = torch.empty_like(w_csr)
             g2, ldg = L.row_major_2d(g)
@@ -100,7 +128,7 @@ class _Aggregate(torch.autograd.Function):
                                        int(x2.shape[1]), L.ptr(gw), L.stream_ptr()), "tfgx_sddmm_f32")
         if self_coef is not None and ctx.needs_input_grad[4]:
             gs = (x.detach() * g).sum(1)
-        return None, None, gx, gw, gs, None
+        return None, None, gx, gw, gs, None, gb, None
 
 
 # Gradient of max aggregation (tf.math.unsorted_segment_max, ties share evenly):
@@ -196,13 +224,108 @@ class _AggregateMax(torch.autograd.Function):
         return None, gx, gw
 
 
-def aggregate(plan, x, op, w_csr=None, self_coef=None, rows=None):
-    """Differentiable gather-scale-segment-reduce (sum / mean / max) on `plan`."""
+def aggregate(plan, x, op, w_csr=None, self_coef=None, rows=None, bias=None, act=L.ACT_NONE):
+    """Differentiable gather-scale-segment-reduce (sum / mean / max) on `plan`; sum / mean take the layer's bias and
+    ReLU in the kernel epilogue (bias: a tensor that may require grad)."""
     if op == L.MAX:
         if self_coef is not None:
             raise NotImplementedError("max aggregation with an implicit self-loop is inference-only")
-        return _AggregateMax.apply(plan, x, w_csr)
-    return _Aggregate.apply(plan, op == L.MEAN, x, w_csr, self_coef, rows if isinstance(rows, SplitRows) else None)
+        h = _AggregateMax.apply(plan, x, w_csr)
+        if bias is not None:
+            h = h + bias
+        return torch.relu(h) if act == L.ACT_RELU else h
+    return _Aggregate.apply(plan, op == L.MEAN, x, w_csr, self_coef, rows if isinstance(rows, SplitRows) else None,
+                            bias, act)
+
+
+def _linear_grads(x, kernel, g, need_x, need_k, need_b):
+    """(d/dx, d/dkernel, d/dbias) of x @ kernel + bias given g (which may be a column slice of a wider gradient)."""
+    # d/dx = g @ kernel^T: the forward MFMA kernel with the (small) transposed kernel as B
+    gx = gemm_bias_act(g, transpose(kernel.detach())) if need_x else None
+    # d/dkernel = x^T @ g and d/dbias = column sums of g: ONE reduction over the node dimension (tfgx_gemm_tn_f32)
+    gk = gb = None
+    if need_k or need_b:
+        gk, gb = gemm_tn(x.detach(), g, want_bias=need_b)
+        if not need_k:
+            gk = None
+    return gx, gk, gb
+
+
+class _DualLinear(torch.autograd.Function):
+    """h = act([x @ ka | r @ kb] + bias): GraphSAGE's concat of the self and neighbour projections (graph_sage.py:43-58)
+    with both GEMMs writing straight into their halves of the output (bias + activation in the epilogues) — no concat,
+    no bias add, no activation pass; the backward slices the (masked) gradient by column views."""
+
+    @staticmethod
+    def forward(ctx, x, ka, r, kb, bias, act):
+        n, na, nb = int(x.shape[0]), int(ka.shape[1]), int(kb.shape[1])
+        h = torch.empty((n, na + nb), dtype=torch.float32, device=x.device)
+        bd = None if bias is None else bias.detach().contiguous()
+        gemm_bias_act(x.detach(), ka.detach(), bias=None if bd is None else bd[:na], act=act, out=h[:, :na])
+        gemm_bias_act(r.detach(), kb.detach(), bias=None if bd is None else bd[na:], act=act, out=h[:, na:])
+        ctx.act, ctx.na = act, na
+        ctx.save_for_backward(x, ka, r, kb, bias, h if act == L.ACT_RELU else None)
+        return h
+
+    @staticmethod
+    def backward(ctx, g):
+        x, ka, r, kb, bias, h = ctx.saved_tensors
+        na = ctx.na
+        g = relu_backward(g, h) if ctx.act == L.ACT_RELU else g.contiguous()
+        need = ctx.needs_input_grad
+        want_b = bias is not None and need[4]
+        gx, gka, gba = _linear_grads(x, ka, g[:, :na], need[0], need[1], want_b)
+        gr, gkb, gbb = _linear_grads(r, kb, g[:, na:], need[2], need[3], want_b)
+        gb = torch.cat([gba, gbb]) if want_b else None
+        return gx, gka, gr, gkb, gb, None
+
+
+class _SageNarrow(torch.autograd.Function):
+    """h = act([x @ ks | reduce(w * (x @ kn)[col])] + bias): mean / sum GraphSAGE with the neighbour projection run
+    BEFORE the (linear) reduction (nn/conv/graph_sage._self_neighbor_sage), both halves written in place — the GEMM's and
+    the aggregation's epilogues carry bias + activation, nothing is concatenated."""
+
+    @staticmethod
+    def forward(ctx, plan, mean, x, ks, kn, w_csr, bias, act):
+        n, na, nb = int(x.shape[0]), int(ks.shape[1]), int(kn.shape[1])
+        h = torch.empty((n, na + nb), dtype=torch.float32, device=x.device)
+        bd = None if bias is None else bias.detach().contiguous()
+        gemm_bias_act(x.detach(), ks.detach(), bias=None if bd is None else bd[:na], act=act, out=h[:, :na])
+        z = gemm_bias_act(x.detach(), kn.detach())
+        segment_reduce(plan, z, L.MEAN if mean else L.SUM, w_csr=None if w_csr is None else w_csr.detach(),
+                       out=h[:, na:], act=act, bias=None if bd is None else bd[na:].contiguous())
+        ctx.plan, ctx.mean, ctx.act, ctx.na = plan, mean, act, na
+        ctx.save_for_backward(x, ks, kn, w_csr, bias, h if act == L.ACT_RELU else None)
+        return h
+
+    @staticmethod
+    def backward(ctx, g):
+        x, ks, kn, w_csr, bias, h = ctx.saved_tensors
+        na, need = ctx.na, ctx.needs_input_grad
+        g = relu_backward(g, h) if ctx.act == L.ACT_RELU else g.contiguous()
+        want_b = bias is not None and need[6]
+        gx, gks, gba = _linear_grads(x, ks, g[:, :na], need[2], need[3], want_b)
+        gn = g[:, na:]
+        gbb = gn.sum(0) if want_b else None
+        gkn = None
+        if need[2] or need[4]:
+            dz, _ = _aggregate_grad_x(ctx.plan, ctx.mean, gn if ctx.mean else gn.contiguous(), w_csr, None)
+            gx_b, gkn, _ = _linear_grads(x, kn, dz, need[2], need[4], False)
+            if gx_b is not None:
+                gx = gx_b if gx is None else gx + gx_b
+        gb = torch.cat([gba, gbb]) if want_b else None
+        return None, None, gx, gks, gkn, None, gb, None
+
+
+def sage_narrow(plan, op, x, ks, kn, w_csr=None, bias=None, act=L.ACT_NONE):
+    """Fused differentiable mean / sum GraphSAGE layer body (concat form, neighbour projection first).  The edge weights
+    are treated as constants (callers route trainable edge weights through the un-fused operators)."""
+    return _SageNarrow.apply(plan, op == L.MEAN, x, L.as_f32(ks), L.as_f32(kn), w_csr,
+                             None if bias is None else L.as_f32(bias), act)
+
+
+def dual_linear(x, ka, r, kb, bias=None, act=L.ACT_NONE):
+    return _DualLinear.apply(x, L.as_f32(ka), r, L.as_f32(kb), None if bias is None else L.as_f32(bias), act)
 
 
 class _Linear(torch.autograd.Function):
@@ -216,18 +339,9 @@ class _Linear(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, kernel, bias, out = ctx.saved_tensors
-        if ctx.act == L.ACT_RELU:
-            g = g * (out > 0).to(g.dtype)
-        g = g.contiguous()
-        # d/dx = g @ kernel^T: the forward MFMA kernel with the (small) transposed kernel as B
-        gx = gemm_bias_act(g, transpose(kernel.detach())) if ctx.needs_input_grad[0] else None
-        # d/dkernel = x^T @ g and d/dbias = column sums of g: ONE reduction over the node dimension (tfgx_gemm_tn_f32)
-        gk = gb = None
-        want_b = bias is not None and ctx.needs_input_grad[2]
-        if ctx.needs_input_grad[1] or want_b:
-            gk, gb = gemm_tn(x.detach(), g, want_bias=want_b)
-            if not ctx.needs_input_grad[1]:
-                gk = None
+        g = relu_backward(g, out) if ctx.act == L.ACT_RELU else g.contiguous()
+        gx, gk, gb = _linear_grads(x, kernel, g, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+                                   bias is not None and ctx.needs_input_grad[2])
         return gx, gk, gb, None
 
 

@@ -269,6 +269,52 @@ extern "C" int tfgx_gather_rows_f32(const float* x, int64_t ldx, const int32_t* 
     return TFGX_OK;
 }
 
+// gout[m, n] = out[m, n] > 0 ? g[m, n] : 0 — the backward of the ReLU that rides in a GEMM / aggregation epilogue
+// (one pass instead of compare + cast + multiply); row strides allow column slices of wider matrices
+namespace tfgx {
+namespace {
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void relu_backward_kernel(const float* __restrict__ g, int64_t ldg,
+                                                               const float* __restrict__ out, int64_t ldo, int64_t M,
+                                                               int N, float* __restrict__ gout, int64_t ldgo)
+{
+    const int per_row = N / VEC;
+    int64_t t = blockIdx.x * int64_t(kBlock) + threadIdx.x;
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    for (; t < M * per_row; t += stride) {
+        const int64_t m = t / per_row;
+        const int c = int(t - m * per_row) * VEC;
+        float gv[VEC], ov[VEC];
+        load_vec<VEC>(g + m * ldg + c, gv);
+        load_vec<VEC>(out + m * ldo + c, ov);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) gv[i] = ov[i] > 0.0f ? gv[i] : 0.0f;
+        store_vec<VEC>(gout + m * ldgo + c, gv);
+    }
+}
+}  // namespace
+}  // namespace tfgx
+
+extern "C" int tfgx_relu_backward_f32(const float* g, int64_t ldg, const float* out, int64_t ldo, int64_t M, int64_t N,
+                                      float* gout, int64_t ldgo, tfgx_stream_t stream)
+{
+    TFGX_RANGE();
+    TFGX_REQUIRE(M >= 0 && N >= 1 && N < (int64_t(1) << 30), "bad M / N");
+    TFGX_REQUIRE(ldg >= N && ldo >= N && ldgo >= N, "leading dimension too small");
+    if (M == 0) return TFGX_OK;
+    TFGX_REQUIRE(g && out && gout, "null pointer");
+    const bool v4 = N % 4 == 0 && ldg % 4 == 0 && ldo % 4 == 0 && ldgo % 4 == 0 && tfgx::aligned_to(g, 16) &&
+                    tfgx::aligned_to(out, 16) && tfgx::aligned_to(gout, 16);
+    if (v4)
+        tfgx::relu_backward_kernel<4><<<tfgx::grid_for(M * (N / 4), tfgx::kBlock), tfgx::kBlock, 0, tfgx::as_stream(stream)>>>(
+            g, ldg, out, ldo, M, int(N), gout, ldgo);
+    else
+        tfgx::relu_backward_kernel<1><<<tfgx::grid_for(M * N, tfgx::kBlock), tfgx::kBlock, 0, tfgx::as_stream(stream)>>>(
+            g, ldg, out, ldo, M, int(N), gout, ldgo);
+    TFGX_LAUNCH_CHECK("relu_backward_kernel");
+    return TFGX_OK;
+}
+
 extern "C" int tfgx_scatter_add_rows_f32(float* dst, int64_t ldd, const int32_t* idx, int64_t M, int64_t F,
                                         const float* src, int64_t lds, tfgx_stream_t stream)
 {

@@ -192,12 +192,14 @@ def gcn(x, sparse_adj, kernel, bias=None, activation=None, norm="both", add_self
         narrow_first = kernel is not None and int(x.shape[1]) < int(kernel.shape[1])
         h = x if (kernel is None or narrow_first) else AG.linear(x, kernel)
         rows = static_rows(h, normed.plan, cache) if h is x else None       # raw input features: static across epochs
-        h = AG.aggregate(normed.plan, h, L.SUM, normed.w_csr, normed.self_coef, rows=rows)
+        # bias + ReLU ride in the LAST kernel's epilogue (GEMM when the aggregation ran first, else the aggregation)
+        bias_t = None if bias is None else L.as_f32(bias)
         if narrow_first:
-            h = AG.linear(h, kernel)
-        if bias is not None:
-            h = h + L.as_f32(bias)
-        return AG.apply_activation(h, act, post)
+            h = AG.aggregate(normed.plan, h, L.SUM, normed.w_csr, normed.self_coef, rows=rows)
+            h = AG.linear(h, kernel, bias_t, act)
+        else:
+            h = AG.aggregate(normed.plan, h, L.SUM, normed.w_csr, normed.self_coef, rows=rows, bias=bias_t, act=act)
+        return post(h) if post is not None else h
     bias_t = None if bias is None else L.as_f32(bias).contiguous()
     if kernel is not None and int(x.shape[1]) < int(kernel.shape[1]):
         # A_hat @ (x @ W) == (A_hat @ x) @ W: gather at the NARROWER width (bytes per edge = 4*min(F, units) + 8),

@@ -27,11 +27,14 @@ def _combine(from_x_kernel, x, from_neigh_kernel, reduced, bias, activation, con
     n = int(x.shape[0])
     ku_x, ku_n = int(from_x_kernel.shape[1]), int(from_neigh_kernel.shape[1])
     if AG.needs_grad(x, reduced, from_x_kernel, from_neigh_kernel, bias):     # training route (autograd.py)
-        a, b = AG.linear(x, from_x_kernel), AG.linear(reduced, from_neigh_kernel)
-        h = torch.cat([a, b], dim=1) if concat else a + b
-        if bias is not None:
-            h = h + L.as_f32(bias)
-        h = AG.apply_activation(h, act, post)
+        if concat:      # both GEMMs write into their halves of the output, bias + activation in the epilogues
+            h = AG.dual_linear(x, from_x_kernel, reduced, from_neigh_kernel, bias, act)
+            h = post(h) if post is not None else h
+        else:
+            h = AG.linear(x, from_x_kernel) + AG.linear(reduced, from_neigh_kernel)
+            if bias is not None:
+                h = h + L.as_f32(bias)
+            h = AG.apply_activation(h, act, post)
         if normalize:
             h = h * torch.rsqrt(torch.clamp((h * h).sum(-1, keepdim=True), min=1e-12))
         return h
@@ -86,12 +89,22 @@ def _self_neighbor_sage(x, edge_index, edge_weight, self_kernel, neighbor_kernel
     w_csr = AG.edge_attr_csr(plan, edge_weight, cache)
     act, post = _resolve_act(activation)
     if AG.needs_grad(x, edge_weight, ws, wn, bias):
-        a = AG.linear(x, ws)
-        b = AG.aggregate(plan, AG.linear(x, wn), op, w_csr)
-        h = torch.cat([a, b], dim=1) if concat else a + b
-        if bias is not None:
-            h = h + L.as_f32(bias)
-        h = AG.apply_activation(h, act, post)
+        if concat and not AG.needs_grad(w_csr):
+            # one fused operator: both halves written in place, bias + activation in the GEMM's / the aggregation's
+            # epilogue — no concat, no bias add, no activation pass
+            h = AG.sage_narrow(plan, op, x, ws, wn, w_csr, bias, act)
+            h = post(h) if post is not None else h
+        elif concat:    # trainable edge weights: the un-fused operators carry d/dw
+            bias_t = None if bias is None else L.as_f32(bias)
+            a = AG.linear(x, ws, None if bias_t is None else bias_t[:ku_x], act)
+            b = AG.aggregate(plan, AG.linear(x, wn), op, w_csr, bias=None if bias_t is None else bias_t[ku_x:], act=act)
+            h = torch.cat([a, b], dim=1)
+            h = post(h) if post is not None else h
+        else:
+            h = AG.linear(x, ws) + AG.aggregate(plan, AG.linear(x, wn), op, w_csr)
+            if bias is not None:
+                h = h + L.as_f32(bias)
+            h = AG.apply_activation(h, act, post)
         if normalize:
             h = h * torch.rsqrt(torch.clamp((h * h).sum(-1, keepdim=True), min=1e-12))
         return h
