@@ -379,6 +379,11 @@ size_t tfgx_gemm_tn_workspace_bytes(int64_t M, int64_t Ka, int64_t N, int32_t wa
 int tfgx_gemm_tn_f32(const float* X, int64_t ldx, const float* G, int64_t ldg, int64_t M, int64_t Ka, int64_t N,
                      float* dW, int64_t ldw, float* db /* or NULL */, void* workspace, size_t workspace_bytes,
                      tfgx_stream_t stream);
+/* same with G gated by a ReLU output: G[m, n] counts only where gate[m, n] > 0 (gate = the output of the layer whose
+   epilogue applied the ReLU) — the masked gradient is consumed in registers and never written out. */
+int tfgx_gemm_tn_gated_f32(const float* X, int64_t ldx, const float* G, int64_t ldg, const float* gate, int64_t ld_gate,
+                           int64_t M, int64_t Ka, int64_t N, float* dW, int64_t ldw, float* db /* or NULL */,
+                           void* workspace, size_t workspace_bytes, tfgx_stream_t stream);
 
 /* out[c, r] = in[r, c] (a layer's [K, N] kernel transposed, so that d/dx = G @ kernel^T runs on the forward GEMM). */
 int tfgx_transpose_f32(const float* in, int64_t ldi, int64_t rows, int64_t cols, float* out, int64_t ldo,

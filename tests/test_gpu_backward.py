@@ -498,6 +498,12 @@ def test_gemm_tn_weight_gradient_kernel(tfg, m, ka, n, want_bias):
         assert db is None
     dW2, _ = gemm_tn(x, g, want_bias=want_bias)
     assert torch.equal(dW, dW2)                                   # deterministic
+    # gated form (the ReLU mask of the producing layer applied in registers) == the product with the masked gradient
+    gate = torch.randn(m, n, generator=gen, device="cuda")
+    gm = torch.where(gate > 0, g, torch.zeros_like(g))
+    dWg, dbg = gemm_tn(x, g, want_bias=want_bias, gate=gate)
+    dWm, dbm = gemm_tn(x, gm, want_bias=want_bias)
+    assert torch.equal(dWg, dWm) and (dbg is None or torch.equal(dbg, dbm))
     assert torch.equal(transpose(x), x.t().contiguous())
     # strided views (a column block of a wider matrix) are honoured
     wide = torch.randn(m, n + 8, generator=gen, device="cuda")

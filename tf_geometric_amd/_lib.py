@@ -110,6 +110,7 @@ SIGNATURES = {
     "tfgx_gemm_workspace_bytes": (_SZ, [_I64, _I64, _I64]),
     "tfgx_gemm_tn_workspace_bytes": (_SZ, [_I64, _I64, _I64, _I32]),
     "tfgx_gemm_tn_f32": (ctypes.c_int, [_P, _I64, _P, _I64, _I64, _I64, _I64, _P, _I64, _P, _P, _SZ, _P]),
+    "tfgx_gemm_tn_gated_f32": (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _P, _I64, _P, _P, _SZ, _P]),
     "tfgx_transpose_f32": (ctypes.c_int, [_P, _I64, _I64, _I64, _P, _I64, _P]),
     "tfgx_gemm_bias_act_cols_ws_f32": (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I32, _I64, _P, _I64, _I64, _I64, _I64, _P, _SZ, _P]),
     "tfgx_dropout_keep": (ctypes.c_int32, [ctypes.c_uint64, ctypes.c_uint32, _F32]),

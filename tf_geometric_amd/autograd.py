@@ -65,6 +65,13 @@ def _transposed_weights(plan, w_csr, t2d):
     return w_t
 
 
+import os as _os
+# Apply a layer-0 ReLU mask INSIDE the weight-gradient reduction (tfgx_gemm_tn_gated_f32) instead of one masked copy of the
+# gradient first.  Same-box A/B at products shape: a wash (GCN step 25.84 / 26.06 vs 25.62 / 26.15 ms, mean SAGE 27.49 /
+# 27.67 vs 27.52 / 27.99 ms) — the kernel reads the gate where the copy was written and re-read — so it stays off.
+GATED_WEIGHT_GRADIENTS = _os.environ.get("TFGX_GATED_WGRAD", "0") != "0"
+
+
 def relu_backward(g, out):
     """g where out > 0, else 0 — ONE pass (tfgx_relu_backward_f32) instead of compare + cast + multiply; g / out may be
     column slices of wider matrices."""
@@ -238,14 +245,17 @@ def aggregate(plan, x, op, w_csr=None, self_coef=None, rows=None, bias=None, act
                             bias, act)
 
 
-def _linear_grads(x, kernel, g, need_x, need_k, need_b):
-    """(d/dx, d/dkernel, d/dbias) of x @ kernel + bias given g (which may be a column slice of a wider gradient)."""
+def _linear_grads(x, kernel, g, need_x, need_k, need_b, gate=None):
+    """(d/dx, d/dkernel, d/dbias) of x @ kernel + bias given g (which may be a column slice of a wider gradient).
+    `gate`: the layer's ReLU output when g is still UN-masked — only valid without d/dx (the reduction kernel applies
+    the mask in registers; layer 0 of every model, whose input carries no gradient)."""
+    assert gate is None or not need_x
     # d/dx = g @ kernel^T: the forward MFMA kernel with the (small) transposed kernel as B
     gx = gemm_bias_act(g, transpose(kernel.detach())) if need_x else None
     # d/dkernel = x^T @ g and d/dbias = column sums of g: ONE reduction over the node dimension (tfgx_gemm_tn_f32)
     gk = gb = None
     if need_k or need_b:
-        gk, gb = gemm_tn(x.detach(), g, want_bias=need_b)
+        gk, gb = gemm_tn(x.detach(), g, want_bias=need_b, gate=gate)
         if not need_k:
             gk = None
     return gx, gk, gb
@@ -271,11 +281,14 @@ class _DualLinear(torch.autograd.Function):
     def backward(ctx, g):
         x, ka, r, kb, bias, h = ctx.saved_tensors
         na = ctx.na
-        g = relu_backward(g, h) if ctx.act == L.ACT_RELU else g.contiguous()
         need = ctx.needs_input_grad
+        relu = ctx.act == L.ACT_RELU
+        # no d/dx, d/dr wanted (layer 0: the inputs are data): the ReLU mask is applied inside the reduction kernels
+        gated = relu and not need[0] and not need[2] and GATED_WEIGHT_GRADIENTS
+        g = relu_backward(g, h) if (relu and not gated) else g.contiguous()
         want_b = bias is not None and need[4]
-        gx, gka, gba = _linear_grads(x, ka, g[:, :na], need[0], need[1], want_b)
-        gr, gkb, gbb = _linear_grads(r, kb, g[:, na:], need[2], need[3], want_b)
+        gx, gka, gba = _linear_grads(x, ka, g[:, :na], need[0], need[1], want_b, gate=h[:, :na] if gated else None)
+        gr, gkb, gbb = _linear_grads(r, kb, g[:, na:], need[2], need[3], want_b, gate=h[:, na:] if gated else None)
         gb = torch.cat([gba, gbb]) if want_b else None
         return gx, gka, gr, gkb, gb, None
 
@@ -339,9 +352,11 @@ class _Linear(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, kernel, bias, out = ctx.saved_tensors
-        g = relu_backward(g, out) if ctx.act == L.ACT_RELU else g.contiguous()
+        relu = ctx.act == L.ACT_RELU
+        gated = relu and not ctx.needs_input_grad[0] and GATED_WEIGHT_GRADIENTS      # no d/dx: mask applied inside the reduction kernel
+        g = relu_backward(g, out) if (relu and not gated) else g.contiguous()
         gx, gk, gb = _linear_grads(x, kernel, g, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
-                                   bias is not None and ctx.needs_input_grad[2])
+                                   bias is not None and ctx.needs_input_grad[2], gate=out if gated else None)
         return gx, gk, gb, None
 
 

@@ -575,12 +575,14 @@ struct TnTile<16> {
     __device__ static __forceinline__ int out_row(int q, int kk) { return 4 * kk + q; }
 };
 
-template <int S, int TM, int TN, int U>
+template <int S, int TM, int TN, int U, bool GATED>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void gemm_tn_direct_kernel(
-    const float* __restrict__ X, int64_t ldx, const float* __restrict__ G, int64_t ldg, int64_t M, int Ka, int N,
-    int want_bias, int WM, int m_groups, int tm_r, int tn_r, int64_t rows_per_wg, float* __restrict__ parts,
-    int64_t part_stride)
+    const float* __restrict__ X, int64_t ldx, const float* __restrict__ G, int64_t ldg, const float* __restrict__ gate,
+    int64_t ldgate, int64_t M, int Ka, int N, int want_bias, int WM, int m_groups, int tm_r, int tn_r,
+    int64_t rows_per_wg, float* __restrict__ parts, int64_t part_stride)
 {
+    // GATED: G[m, n] counts only where gate[m, n] > 0 — the backward of a ReLU fused into the producing layer's epilogue
+    // (gate = that layer's output), so the masked gradient is never written out
     // tm_r <= TM, tn_r <= TN: the tiles per wave the configuration asked for (the instantiation may be larger)
     typedef TnTile<S> T;
     typedef typename T::acc_t acc_t;
@@ -632,6 +634,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
             for (int i = 0; i < TM; ++i) o.a[u][i] = mval[i] ? xr[mcol[i]] : mfill[i];
 #pragma unroll
             for (int j = 0; j < TN; ++j) o.b[u][j] = nval[j] ? gr[ncol[j]] : 0.0f;
+            if constexpr (GATED) {
+                const float* tr = gate + (r + KS * u + kk) * ldgate;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const float t = nval[j] ? tr[ncol[j]] : 0.0f;
+                    o.b[u][j] = t > 0.0f ? o.b[u][j] : 0.0f;
+                }
+            }
         }
     };
     auto mul = [&](const Ops& o) {
@@ -664,6 +674,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
         for (int i = 0; i < TM; ++i) a[i] = rv ? (mval[i] ? X[row * ldx + mcol[i]] : mfill[i]) : 0.0f;
 #pragma unroll
         for (int j = 0; j < TN; ++j) b[j] = (rv && nval[j]) ? G[row * ldg + ncol[j]] : 0.0f;
+        if constexpr (GATED) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const float t = (rv && nval[j]) ? gate[row * ldgate + ncol[j]] : 0.0f;
+                b[j] = t > 0.0f ? b[j] : 0.0f;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1004,7 +1021,15 @@ extern "C" int tfgx_gemm_tn_f32(const float* X, int64_t ldx, const float* G, int
                                 int64_t N, float* dW, int64_t ldw, float* db, void* workspace, size_t workspace_bytes,
                                 tfgx_stream_t stream_)
 {
+    return tfgx_gemm_tn_gated_f32(X, ldx, G, ldg, nullptr, 0, M, Ka, N, dW, ldw, db, workspace, workspace_bytes, stream_);
+}
+
+extern "C" int tfgx_gemm_tn_gated_f32(const float* X, int64_t ldx, const float* G, int64_t ldg, const float* gate,
+                                      int64_t ld_gate, int64_t M, int64_t Ka, int64_t N, float* dW, int64_t ldw, float* db,
+                                      void* workspace, size_t workspace_bytes, tfgx_stream_t stream_)
+{
     TFGX_RANGE();
+    TFGX_REQUIRE(gate == nullptr || (ld_gate >= N && tn_use_direct()), "gate: leading dimension too small / needs the direct kernel");
     TFGX_REQUIRE(M >= 0 && Ka >= 1 && N >= 1, "bad M / Ka / N");
     TFGX_REQUIRE(Ka < (int64_t(1) << 30) && N < (int64_t(1) << 30), "Ka / N too large");
     TFGX_REQUIRE(tn_use_direct() || Ka <= 2016, "Ka > 2016 is not supported by the LDS-staged kernel (TFGX_TN_DIRECT=0)");
@@ -1025,36 +1050,42 @@ extern "C" int tfgx_gemm_tn_f32(const float* X, int64_t ldx, const float* G, int
         float* parts = static_cast<float*>(workspace);
         dim3 grid(d.wgs, d.m_groups * d.n_groups, 1), block(256, 1, 1);
 #define TFGX_TND(S_, TM_, TN_, U_)                                                                                      \
-    gemm_tn_direct_kernel<S_, TM_, TN_, U_><<<grid, block, 0, stream>>>(X, ldx, G, ldg, M, int(Ka), int(N),             \
-                                                                        want_bias ? 1 : 0, d.WM, d.m_groups, d.TM,      \
-                                                                        d.TN, d.rows_per_wg, parts, part_stride)
+    if (gate != nullptr)                                                                                                \
+        gemm_tn_direct_kernel<S_, TM_, TN_, U_, true><<<grid, block, 0, stream>>>(                                      \
+            X, ldx, G, ldg, gate, ld_gate, M, int(Ka), int(N), want_bias ? 1 : 0, d.WM, d.m_groups, d.TM, d.TN,         \
+            d.rows_per_wg, parts, part_stride);                                                                         \
+    else                                                                                                                \
+        gemm_tn_direct_kernel<S_, TM_, TN_, U_, false><<<grid, block, 0, stream>>>(                                     \
+            X, ldx, G, ldg, nullptr, 0, M, int(Ka), int(N), want_bias ? 1 : 0, d.WM, d.m_groups, d.TM, d.TN,            \
+            d.rows_per_wg, parts, part_stride)
         // wave tiles are instantiated at a few sizes; a smaller request runs on the next larger one (tiles past the
         // request are skipped by wave-uniform branches)
         if (d.S == 32) {
             if (d.TN <= 1) {
-                if (d.TM <= 1) TFGX_TND(32, 1, 1, 4);
-                else if (d.TM <= 2) TFGX_TND(32, 2, 1, 4);
-                else TFGX_TND(32, 4, 1, 4);
+                if (d.TM <= 1) { TFGX_TND(32, 1, 1, 4); }
+                else if (d.TM <= 2) { TFGX_TND(32, 2, 1, 4); }
+                else { TFGX_TND(32, 4, 1, 4); }
             } else {
-                if (d.TM <= 1) TFGX_TND(32, 1, 2, 4);
-                else if (d.TM <= 2) TFGX_TND(32, 2, 2, 4);
-                else if (d.TM <= 3) TFGX_TND(32, 3, 2, 4);
-                else TFGX_TND(32, 4, 2, 4);
+                if (d.TM <= 1) { TFGX_TND(32, 1, 2, 4); }
+                else if (d.TM <= 2) { TFGX_TND(32, 2, 2, 4); }
+                else if (d.TM <= 3) { TFGX_TND(32, 3, 2, 4); }
+                else { TFGX_TND(32, 4, 2, 4); }
             }
         } else {
             if (d.TN <= 1) {
-                if (d.TM <= 2) TFGX_TND(16, 2, 1, 2);
-                else if (d.TM <= 4) TFGX_TND(16, 4, 1, 2);
-                else TFGX_TND(16, 8, 1, 2);
+                if (d.TM <= 2) { TFGX_TND(16, 2, 1, 2); }
+                else if (d.TM <= 4) { TFGX_TND(16, 4, 1, 2); }
+                else { TFGX_TND(16, 8, 1, 2); }
             } else if (d.TN <= 2) {
-                if (d.TM <= 2) TFGX_TND(16, 2, 2, 2);
-                else if (d.TM <= 4) TFGX_TND(16, 4, 2, 2);
-                else TFGX_TND(16, 8, 2, 2);
+                if (d.TM <= 2) { TFGX_TND(16, 2, 2, 2); }
+                else if (d.TM <= 4) { TFGX_TND(16, 4, 2, 2); }
+                else { TFGX_TND(16, 8, 2, 2); }
             } else {
-                if (d.TM <= 2) TFGX_TND(16, 2, 4, 2);
-                else if (d.TM <= 4) TFGX_TND(16, 4, 4, 2);
-                else if (d.TM <= 6) TFGX_TND(16, 6, 4, 2);
-                else TFGX_TND(16, 8, 4, 2);
+                if (d.TM <= 2) { TFGX_TND(16, 2, 4, 2); }
+                else if (d.TM <= 4) { TFGX_TND(16, 4, 4, 2); }
+                else if (d.TM <= 6) { TFGX_TND(16, 6, 4, 2); }
+                else if (d.TM <= 7) { TFGX_TND(16, 7, 4, 2); }
+                else { TFGX_TND(16, 8, 4, 2); }
             }
         }
 #undef TFGX_TND

@@ -414,21 +414,27 @@ def gather_rows(x, idx, out=None):
     return out
 
 
-def gemm_tn(x, g, want_bias=False):
+def gemm_tn(x, g, want_bias=False, gate=None):
     """(x^T @ g, column sums of g or None): the weight / bias gradient of a dense layer on the MFMA reduction kernel
-    (tfgx_gemm_tn_f32).  x [M, Ka], g [M, N] -> dW [Ka, N], db [N]."""
+    (tfgx_gemm_tn_f32).  x [M, Ka], g [M, N] -> dW [Ka, N], db [N].  `gate` [M, N]: count g only where gate > 0 (the
+    ReLU of the layer's epilogue, gate = the layer's output) — the masked gradient is never materialised."""
     lib = L.require_gpu()
     x, ldx = L.row_major_2d(L.as_f32(x))
     g, ldg = L.row_major_2d(L.as_f32(g))
     M, Ka, N = int(x.shape[0]), int(x.shape[1]), int(g.shape[1])
     if int(g.shape[0]) != M:
         raise ValueError("gemm_tn: x has {} rows, g has {}".format(M, int(g.shape[0])))
+    ldt = 0
+    if gate is not None:
+        gate, ldt = L.row_major_2d(gate)
+        if tuple(gate.shape) != (M, N):
+            raise ValueError("gemm_tn: gate has shape {}, g has {}".format(tuple(gate.shape), (M, N)))
     dW = torch.empty((Ka, N), dtype=torch.float32, device=x.device)
     db = torch.empty(N, dtype=torch.float32, device=x.device) if want_bias else None
     ws_bytes = lib.tfgx_gemm_tn_workspace_bytes(M, Ka, N, 1 if want_bias else 0)
     ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=x.device)
-    L.check(lib.tfgx_gemm_tn_f32(L.ptr(x), ldx, L.ptr(g), ldg, M, Ka, N, L.ptr(dW), N, L.ptr(db), L.ptr(ws), ws_bytes,
-                                 L.stream_ptr()), "tfgx_gemm_tn_f32")
+    L.check(lib.tfgx_gemm_tn_gated_f32(L.ptr(x), ldx, L.ptr(g), ldg, L.ptr(gate), ldt, M, Ka, N, L.ptr(dW), N, L.ptr(db),
+                                       L.ptr(ws), ws_bytes, L.stream_ptr()), "tfgx_gemm_tn_gated_f32")
     return dW, db
 
 
