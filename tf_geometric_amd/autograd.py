@@ -72,15 +72,17 @@ import os as _os
 GATED_WEIGHT_GRADIENTS = _os.environ.get("TFGX_GATED_WGRAD", "0") != "0"
 
 
-def relu_backward(g, out):
-    """g where out > 0, else 0 — ONE pass (tfgx_relu_backward_f32) instead of compare + cast + multiply; g / out may be
-    column slices of wider matrices."""
+def relu_backward(g, out, into=None):
+    """g where out > 0, else 0 — ONE pass (tfgx_relu_backward_f32) instead of compare + cast + multiply; g / out / into
+    may be column slices of wider matrices."""
     lib = L.require_gpu()
     g2, ldg = L.row_major_2d(g)
     o2, ldo = L.row_major_2d(out)
     M, N = int(g2.shape[0]), int(g2.shape[1])
-    res = torch.empty((M, N), dtype=torch.float32, device=g2.device)
-    L.check(lib.tfgx_relu_backward_f32(L.ptr(g2), ldg, L.ptr(o2), ldo, M, N, L.ptr(res), N, L.stream_ptr()),
+    res = torch.empty((M, N), dtype=torch.float32, device=g2.device) if into is None else into
+    r2, ldr = L.row_major_2d(res)
+    assert r2 is res, "relu_backward: `into` must have dense rows"
+    L.check(lib.tfgx_relu_backward_f32(L.ptr(g2), ldg, L.ptr(o2), ldo, M, N, L.ptr(res), ldr, L.stream_ptr()),
             "tfgx_relu_backward_f32")
     return res
 
@@ -313,20 +315,34 @@ class _SageNarrow(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        """D = [masked g of the self half | d/dz of the neighbour half] is assembled in ONE buffer, so that both kernels'
+        gradients come from one reduction over x (x^T @ D = [d/dks | d/dkn]) and d/dx from one GEMM (D @ [ks | kn]^T)
+        instead of two of each plus an add."""
         x, ks, kn, w_csr, bias, h = ctx.saved_tensors
-        na, need = ctx.na, ctx.needs_input_grad
-        g = relu_backward(g, h) if ctx.act == L.ACT_RELU else g.contiguous()
+        plan, na, need = ctx.plan, ctx.na, ctx.needs_input_grad
+        n, nb = int(g.shape[0]), int(kn.shape[1])
+        relu = ctx.act == L.ACT_RELU
         want_b = bias is not None and need[6]
-        gx, gks, gba = _linear_grads(x, ks, g[:, :na], need[2], need[3], want_b)
-        gn = g[:, na:]
+        D = torch.empty((n, na + nb), dtype=torch.float32, device=g.device)
+        if relu:
+            relu_backward(g[:, :na], h[:, :na], into=D[:, :na])
+            gn = relu_backward(g[:, na:], h[:, na:])
+        else:
+            D[:, :na] = g[:, :na]
+            gn = g[:, na:].contiguous()
         gbb = gn.sum(0) if want_b else None
-        gkn = None
-        if need[2] or need[4]:
-            dz, _ = _aggregate_grad_x(ctx.plan, ctx.mean, gn if ctx.mean else gn.contiguous(), w_csr, None)
-            gx_b, gkn, _ = _linear_grads(x, kn, dz, need[2], need[4], False)
-            if gx_b is not None:
-                gx = gx_b if gx is None else gx + gx_b
-        gb = torch.cat([gba, gbb]) if want_b else None
+        if ctx.mean:
+            gn = gn / plan.in_degree().clamp(min=1).to(gn.dtype).unsqueeze(1)
+        pt, t2d = _transposed(plan)
+        segment_reduce(pt, gn, L.SUM, w_csr=_transposed_weights(plan, w_csr, t2d), out=D[:, na:])
+        gks = gkn = gb = gx = None
+        if need[3] or need[4] or want_b:
+            gW, gb_all = gemm_tn(x.detach(), D, want_bias=want_b)
+            gks, gkn = (gW[:, :na] if need[3] else None), (gW[:, na:] if need[4] else None)
+            if want_b:
+                gb = torch.cat([gb_all[:na], gbb])
+        if need[2]:
+            gx = gemm_bias_act(D, transpose(torch.cat([ks.detach(), kn.detach()], dim=1)))
         return None, None, gx, gks, gkn, None, gb, None
 
 
