@@ -342,3 +342,49 @@ def test_gcn_cache_builders_and_old_api(tfg, oracle):
     layer.set_weights(kernel=kernel, bias=np.zeros(4, np.float32))
     assert_parity(layer([g_.x, g_.edge_index, g_.edge_weight], cache=g_.cache).cpu().numpy(),
                   oracle.gcn(g_.x, g_.edge_index, g_.edge_weight, kernel), what="GCN on a prebuilt cache")
+
+
+def test_static_aggregation_memo_is_opt_in_exact_and_invalidated(tfg, oracle):
+    """prepare_static_features(..., cache_aggregation=True): layer 0's A_hat @ x (GCN, aggregation-first route) and the
+    neighbour mean of x (GraphSAGE) are computed once and reused while x and the edge weights do not change — same bits as
+    the plain path, in inference and in training (weight gradients equal), recomputed after a torch-visible update of
+    x, never used for another tensor, gone after release_static_features."""
+    import torch
+    from tf_geometric_amd import plan as P
+    rng = np.random.Generator(np.random.PCG64(31))
+    n, f = 500, 20
+    ei = oracle.synthetic_edges(n, 6000, seed=31)
+    x = torch.tensor(rng.standard_normal((n, f)).astype(np.float32), device="cuda")
+    w = rng.uniform(0.5, 1.5, ei.shape[1]).astype(np.float32)
+    gcn = tfg.layers.GCN(48, activation=tfg.relu)            # 20 < 48: aggregation first
+    sage = tfg.layers.MeanGraphSage(64, activation=tfg.relu)   # ku = 32 >= 20: reduce at the input width
+    plain_cache = {}
+    o_gcn, o_sage = gcn([x, ei, w], cache=plain_cache), sage([x, ei, w], cache=plain_cache)
+    cache = {}
+    tfg.prepare_static_features(x, ei, cache)                 # layout only: no memo
+    gcn([x, ei, w], cache=cache)
+    assert "tfgx_static_aggregated" not in cache
+    tfg.prepare_static_features(x, ei, cache, cache_aggregation=True)
+    P.STATIC_STATS["agg_hits"] = 0
+    for _ in range(3):
+        assert torch.equal(gcn([x, ei, w], cache=cache), o_gcn) and torch.equal(sage([x, ei, w], cache=cache), o_sage)
+    assert P.STATIC_STATS["agg_hits"] == 4                    # first call of each layer computes, the rest hit
+    other = x.clone()
+    assert torch.equal(gcn([other, ei, w], cache=cache), o_gcn) and P.STATIC_STATS["agg_hits"] == 4
+    # training: the memo feeds the differentiable GEMM; gradients equal the plain route's
+    def grads(c):
+        for layer in (gcn, sage):
+            layer.trainable(True)
+            for p_ in layer.parameters():
+                p_.grad = None
+        (gcn([x, ei, w], cache=c).sum() + sage([x, ei, w], cache=c).sum()).backward()
+        return [p_.grad.clone() for p_ in gcn.parameters() + sage.parameters()]
+    for a, b in zip(grads(cache), grads(plain_cache)):
+        assert torch.equal(a, b)
+    assert P.STATIC_STATS["agg_hits"] == 6
+    x.mul_(1.5)                                               # torch-visible update: recomputed, not stale
+    with torch.no_grad():
+        fresh = gcn([x, ei, w], cache=cache)
+        assert torch.equal(fresh, gcn([x.clone(), ei, w], cache={}))
+    tfg.release_static_features(cache)
+    assert "tfgx_static_aggregated" not in cache

@@ -9,7 +9,7 @@ import torch
 
 from ... import _lib as L
 from ...activations import resolve as _resolve_act
-from ...plan import segment_reduce, gemm_bias_act, static_rows
+from ...plan import segment_reduce, gemm_bias_act, static_rows, static_aggregate
 from ...sparse import SparseMatrix, sparse_features, sparse_dense_matmul
 from ... import autograd as AG
 
@@ -195,7 +195,8 @@ def gcn(x, sparse_adj, kernel, bias=None, activation=None, norm="both", add_self
         # bias + ReLU ride in the LAST kernel's epilogue (GEMM when the aggregation ran first, else the aggregation)
         bias_t = None if bias is None else L.as_f32(bias)
         if narrow_first:
-            h = AG.aggregate(normed.plan, h, L.SUM, normed.w_csr, normed.self_coef, rows=rows)
+            pre = static_aggregate(h, normed.plan, cache, L.SUM, normed.w_csr, normed.self_coef)   # opt-in memo (layer 0)
+            h = pre if pre is not None else AG.aggregate(normed.plan, h, L.SUM, normed.w_csr, normed.self_coef, rows=rows)
             h = AG.linear(h, kernel, bias_t, act)
         else:
             h = AG.aggregate(normed.plan, h, L.SUM, normed.w_csr, normed.self_coef, rows=rows, bias=bias_t, act=act)
@@ -204,7 +205,8 @@ def gcn(x, sparse_adj, kernel, bias=None, activation=None, norm="both", add_self
     if kernel is not None and int(x.shape[1]) < int(kernel.shape[1]):
         # A_hat @ (x @ W) == (A_hat @ x) @ W: gather at the NARROWER width (bytes per edge = 4*min(F, units) + 8),
         # bias + activation move into the GEMM epilogue. Same result up to fp32 re-association (inside 1e-5).
-        h = gemm_bias_act(normed.matmul(x, cache=cache), kernel, bias=bias_t, act=act)
+        pre = static_aggregate(x, normed.plan, cache, L.SUM, normed.w_csr, normed.self_coef)       # opt-in memo (layer 0)
+        h = gemm_bias_act(pre if pre is not None else normed.matmul(x, cache=cache), kernel, bias=bias_t, act=act)
     else:
         h = x if kernel is None else gemm_bias_act(x, kernel)                                     # :266-272
         h = normed.matmul(h, bias=bias_t, act=act, cache=cache if kernel is None else None)       # :280-288

@@ -14,7 +14,8 @@ import torch
 
 from ... import _lib as L
 from ...activations import resolve as _resolve_act
-from ...plan import CsrPlan, segment_reduce, gemm_bias_act, l2_normalize_rows_, edge_weight_csr, static_rows
+from ...plan import (CsrPlan, segment_reduce, gemm_bias_act, l2_normalize_rows_, edge_weight_csr, static_rows,
+                     static_aggregate)
 from ...sparse import SparseMatrix
 from .gcn import gcn_norm_adj
 from ... import autograd as AG
@@ -66,7 +67,10 @@ def _neighbor_reduce(x, edge_index, edge_weight, op, cache):
     w_csr = AG.edge_attr_csr(plan, edge_weight, cache)                                 # :38-39
     if AG.needs_grad(x, edge_weight):
         return x, AG.aggregate(plan, x, op, w_csr)
-    # raw input features seen twice with the same cache are static: edge-resident-tail layout (plan.static_rows)
+    pre = static_aggregate(x, plan, cache, op, w_csr)      # opt-in memo: the reduce of declared-static features (layer 0)
+    if pre is not None:
+        return x, pre
+    # declared-static input features are read in their edge-resident-tail layout (plan.static_rows)
     return x, segment_reduce(plan, static_rows(x, plan, cache), op, w_csr=w_csr)
 
 

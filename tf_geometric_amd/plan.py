@@ -231,7 +231,10 @@ def _build_static_rows(x, plan, cache):
     return rows, nbytes
 
 
-def prepare_static_features(x, edge_index, cache, num_nodes=None):
+CACHE_KEY_STATIC_AGG = "tfgx_static_aggregated"   # opt-in memo of layer-0 aggregations of the static features
+
+
+def prepare_static_features(x, edge_index, cache, num_nodes=None, cache_aggregation=False):
     """EXPLICIT opt-in to the static-feature layout: declares that the tensor `x` is the graph's
     static input features — aggregated again and again over the same graph (layer 0 of a model, every epoch) and not
     written to in between — and builds, now, the SplitRows + edge-resident-tail form the aggregation kernel then uses
@@ -244,6 +247,11 @@ def prepare_static_features(x, edge_index, cache, num_nodes=None):
     new tensor, or an in-place op — the version counter invalidates the layout and it is rebuilt); writes that bypass
     the counter (`x.data`, foreign pointers) require `release_static_features(cache)` first.
 
+    cache_aggregation=True additionally lets layer 0 keep its AGGREGATED input — A_hat @ x (GCN) or the neighbour
+    mean / sum of x (GraphSAGE) is the same tensor in every step while neither x nor the edge weights change, so it is
+    computed once and reused (`static_aggregate`; +4*N*F bytes per distinct aggregation).  Training-time input or edge
+    dropout changes the operands every step, so nothing is reused then.
+
     :return: dict(bytes=..., layout="edge_tail" | "dense", f_main=..., f_tail=...) — what was built and what it costs."""
     if cache is None:
         raise ValueError("prepare_static_features needs the graph's cache dict")
@@ -253,6 +261,10 @@ def prepare_static_features(x, edge_index, cache, num_nodes=None):
     n = int(x.shape[0]) if num_nodes is None else int(num_nodes)
     plan = edge_index if isinstance(edge_index, CsrPlan) else CsrPlan.from_cache(edge_index, n, int(x.shape[0]), cache)
     cache[CACHE_KEY_STATIC] = x
+    if cache_aggregation:
+        cache[CACHE_KEY_STATIC_AGG] = {}
+    else:
+        cache.pop(CACHE_KEY_STATIC_AGG, None)
     rows, nbytes = _build_static_rows(x, plan, cache)
     F = int(x.shape[1])
     return dict(bytes=nbytes, layout="edge_tail" if rows is not None else "dense", tensor=x,
@@ -263,6 +275,40 @@ def release_static_features(cache):
     """Undo prepare_static_features: frees the layout; later aggregations read x itself."""
     cache.pop(CACHE_KEY_STATIC, None)
     cache.pop(CACHE_KEY_STATIC_ROWS, None)
+    cache.pop(CACHE_KEY_STATIC_AGG, None)
+
+
+def _declared_static(x, cache):
+    if cache is None or not isinstance(x, torch.Tensor):
+        return False
+    opt = cache.get(CACHE_KEY_STATIC, None)
+    if opt is None or opt is False or not isinstance(opt, torch.Tensor):
+        return False
+    return (opt.data_ptr() == x.data_ptr() and opt.shape == x.shape and opt.dtype == x.dtype
+            and opt.stride() == x.stride())
+
+
+def static_aggregate(x, plan, cache, op, w_csr=None, self_coef=None):
+    """segment_reduce(plan, x, op, w_csr, self_coef) for the graph's declared-static features — computed ONCE per
+    (x contents, plan, op, weights) when the caller opted in with prepare_static_features(..., cache_aggregation=True),
+    returned from the memo afterwards; None when the memo does not apply (the caller then aggregates as usual).
+    The result must be treated as read-only."""
+    store = cache.get(CACHE_KEY_STATIC_AGG) if cache is not None else None
+    if store is None or not _declared_static(x, cache):
+        return None
+    if any(t is not None and t.requires_grad for t in (x, w_csr, self_coef)):
+        return None
+    ident = lambda t: None if t is None else (t.data_ptr(), t._version, int(t.numel()))      # noqa: E731
+    key = (_static_key(x, plan), ident(w_csr), ident(self_coef))
+    hit = store.get(op)
+    if hit is not None and hit[0] == key:
+        STATIC_STATS["agg_hits"] = STATIC_STATS.get("agg_hits", 0) + 1
+        return hit[1]
+    if torch.cuda.is_current_stream_capturing():
+        return None
+    out = segment_reduce(plan, static_rows(x, plan, cache), op, w_csr=w_csr, self_coef=self_coef)
+    store[op] = (key, out, x, w_csr, self_coef)            # the operands stay alive: their addresses cannot be recycled
+    return out
 
 
 def static_rows(x, plan, cache):
