@@ -340,7 +340,10 @@ def test_sage_layers_train_step_decreases_loss(tfg, oracle, cls):
 
 @pytest.mark.parametrize("cls,f,units,concat", [("MeanGraphSage", 10, 32, True), ("MeanGraphSage", 40, 16, True),
                                                  ("SumGraphSage", 40, 16, True), ("MeanGraphSage", 40, 16, False),
-                                                 ("SumGraphSage", 12, 24, False)])
+                                                 ("SumGraphSage", 12, 24, False),
+                                                 # odd widths: the halves start at unaligned columns (ku = 5, 7, 3)
+                                                 ("MeanGraphSage", 23, 10, True), ("SumGraphSage", 5, 14, True),
+                                                 ("MeanGraphSage", 9, 6, True), ("SumGraphSage", 101, 130, True)])
 def test_mean_sum_sage_layer_grads_fused_epilogues(tfg, oracle, cls, f, units, concat):
     """The training route of mean / sum GraphSAGE: with concat both halves are written in place with bias + ReLU in the
     GEMM / aggregation epilogues (autograd._DualLinear when the reduction runs at the input width, autograd._SageNarrow

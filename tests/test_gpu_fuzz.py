@@ -2,6 +2,8 @@
 """Seeded random sweeps through the C ABI against the float64 oracle: shapes, widths (every vector / lane-group /
 chunk dispatch), reducers, optional operands and ragged graphs (empty rows, duplicate edges, self-loops, one very long
 row) drawn at random — the combinations the hand-written cases do not enumerate."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -9,6 +11,9 @@ import torch
 from conftest import assert_parity
 
 pytestmark = pytest.mark.gpu
+
+# soak runs: TFGX_FUZZ_SCALE=10 multiplies the number of seeds of every sweep
+_SCALE = int(os.environ.get("TFGX_FUZZ_SCALE", "1"))
 
 
 def _random_graph(rng, n, e):
@@ -24,7 +29,7 @@ def _random_graph(rng, n, e):
     return np.stack([row, col])
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(40 * _SCALE))
 def test_fuzz_segment_reduce(tfg, oracle, seed):
     from tf_geometric_amd.plan import CsrPlan, segment_reduce
     L = tfg._lib
@@ -78,7 +83,7 @@ def test_fuzz_segment_reduce(tfg, oracle, seed):
                   what="fuzz seg_reduce seed {} n={} e={} f={} op={}".format(seed, n, e, f, op))
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(24 * _SCALE))
 def test_fuzz_gat_attention(tfg, oracle, seed):
     from tf_geometric_amd.plan import CsrPlan
     from tf_geometric_amd.nn.conv.gat import gat_attention
@@ -112,7 +117,7 @@ def test_fuzz_gat_attention(tfg, oracle, seed):
         seed, n, e, H, d, dv))
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(24 * _SCALE))
 def test_fuzz_gemm(tfg, oracle, seed):
     from tf_geometric_amd.plan import gemm_bias_act
     rng = np.random.Generator(np.random.PCG64(3000 + seed))
