@@ -24,7 +24,8 @@ import math
 import torch
 
 from . import _lib as L
-from .plan import segment_reduce, gemm_bias_act, gemm_tn, transpose, SplitRows
+from .plan import (segment_reduce, gemm_bias_act, gemm_tn, transpose, SplitRows, gather_friendly_empty,
+                   gather_friendly_copy)
 
 
 def needs_grad(*tensors):
@@ -91,7 +92,11 @@ def _aggregate_grad_x(plan, mean, g, w_csr, self_coef):
     """d/dx of out = (1/cnt) (sum_i w_i x[col_i] + self_coef x): the transposed plan on the same kernel; on a square
     operator the self-loop term self_coef[r] * g[r] rides in that launch's epilogue."""
     if mean:
-        g = g / plan.in_degree().clamp(min=1).to(g.dtype).unsqueeze(1)
+        scaled = gather_friendly_empty(int(g.shape[0]), int(g.shape[1]), g.device)
+        torch.div(g, plan.in_degree().clamp(min=1).to(g.dtype).unsqueeze(1), out=scaled)
+        g = scaled
+    else:
+        g = gather_friendly_copy(g)        # the transposed pass GATHERS rows of g: narrow / odd widths get a padded stride
     pt, t2d = _transposed(plan)
     w_t = _transposed_weights(plan, w_csr, t2d)
     if self_coef is not None and plan.n_dst == plan.n_src:
@@ -306,7 +311,7 @@ class _SageNarrow(torch.autograd.Function):
         h = torch.empty((n, na + nb), dtype=torch.float32, device=x.device)
         bd = None if bias is None else bias.detach().contiguous()
         gemm_bias_act(x.detach(), ks.detach(), bias=None if bd is None else bd[:na], act=act, out=h[:, :na])
-        z = gemm_bias_act(x.detach(), kn.detach())
+        z = gemm_bias_act(x.detach(), kn.detach(), out=gather_friendly_empty(n, nb, x.device))
         segment_reduce(plan, z, L.MEAN if mean else L.SUM, w_csr=None if w_csr is None else w_csr.detach(),
                        out=h[:, na:], act=act, bias=None if bd is None else bd[na:].contiguous())
         ctx.plan, ctx.mean, ctx.act, ctx.na = plan, mean, act, na
@@ -324,15 +329,16 @@ class _SageNarrow(torch.autograd.Function):
         relu = ctx.act == L.ACT_RELU
         want_b = bias is not None and need[6]
         D = torch.empty((n, na + nb), dtype=torch.float32, device=g.device)
+        gn = gather_friendly_empty(n, nb, g.device)      # gathered by the transposed pass: line-friendly stride
         if relu:
             relu_backward(g[:, :na], h[:, :na], into=D[:, :na])
-            gn = relu_backward(g[:, na:], h[:, na:])
+            relu_backward(g[:, na:], h[:, na:], into=gn)
         else:
             D[:, :na] = g[:, :na]
-            gn = g[:, na:].contiguous()
+            gn.copy_(g[:, na:])
         gbb = gn.sum(0) if want_b else None
         if ctx.mean:
-            gn = gn / plan.in_degree().clamp(min=1).to(gn.dtype).unsqueeze(1)
+            gn.div_(plan.in_degree().clamp(min=1).to(gn.dtype).unsqueeze(1))
         pt, t2d = _transposed(plan)
         segment_reduce(pt, gn, L.SUM, w_csr=_transposed_weights(plan, w_csr, t2d), out=D[:, na:])
         gks = gkn = gb = gx = None
@@ -359,8 +365,10 @@ def dual_linear(x, ka, r, kb, bias=None, act=L.ACT_NONE):
 
 class _Linear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, kernel, bias, act):
-        out = gemm_bias_act(x.detach(), kernel.detach(), bias=None if bias is None else bias.detach(), act=act)
+    def forward(ctx, x, kernel, bias, act, gathered=False):
+        """gathered=True: the rows are gathered by an aggregation next — written at a line-friendly stride."""
+        dst = gather_friendly_empty(int(x.shape[0]), int(kernel.shape[1]), x.device) if gathered else None
+        out = gemm_bias_act(x.detach(), kernel.detach(), bias=None if bias is None else bias.detach(), act=act, out=dst)
         ctx.act = act
         ctx.save_for_backward(x, kernel, bias, out)
         return out
@@ -373,12 +381,13 @@ class _Linear(torch.autograd.Function):
         g = relu_backward(g, out) if (relu and not gated) else g.contiguous()
         gx, gk, gb = _linear_grads(x, kernel, g, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
                                    bias is not None and ctx.needs_input_grad[2], gate=out if gated else None)
-        return gx, gk, gb, None
+        return gx, gk, gb, None, None
 
 
-def linear(x, kernel, bias=None, act=L.ACT_NONE):
-    """act(x @ kernel + bias): forward on the MFMA kernel, differentiable."""
-    return _Linear.apply(x, L.as_f32(kernel), None if bias is None else L.as_f32(bias), act)
+def linear(x, kernel, bias=None, act=L.ACT_NONE, gathered=False):
+    """act(x @ kernel + bias): forward on the MFMA kernel, differentiable.  gathered=True when an aggregation reads the
+    result next (plan.gather_friendly_ld)."""
+    return _Linear.apply(x, L.as_f32(kernel), None if bias is None else L.as_f32(bias), act, gathered)
 
 
 class _GatAttention(torch.autograd.Function):

@@ -9,7 +9,7 @@ import torch
 
 from ... import _lib as L
 from ...activations import resolve as _resolve_act
-from ...plan import segment_reduce, gemm_bias_act, static_rows, static_aggregate
+from ...plan import segment_reduce, gemm_bias_act, static_rows, static_aggregate, gather_friendly_empty
 from ...sparse import SparseMatrix, sparse_features, sparse_dense_matmul
 from ... import autograd as AG
 
@@ -190,7 +190,7 @@ def gcn(x, sparse_adj, kernel, bias=None, activation=None, norm="both", add_self
     act, post = _resolve_act(activation)
     if AG.needs_grad(x, kernel, bias):      # training: differentiable un-fused route (autograd.py)
         narrow_first = kernel is not None and int(x.shape[1]) < int(kernel.shape[1])
-        h = x if (kernel is None or narrow_first) else AG.linear(x, kernel)
+        h = x if (kernel is None or narrow_first) else AG.linear(x, kernel, gathered=True)
         rows = static_rows(h, normed.plan, cache) if h is x else None       # raw input features: static across epochs
         # bias + ReLU ride in the LAST kernel's epilogue (GEMM when the aggregation ran first, else the aggregation)
         bias_t = None if bias is None else L.as_f32(bias)
@@ -208,6 +208,7 @@ def gcn(x, sparse_adj, kernel, bias=None, activation=None, norm="both", add_self
         pre = static_aggregate(x, normed.plan, cache, L.SUM, normed.w_csr, normed.self_coef)       # opt-in memo (layer 0)
         h = gemm_bias_act(pre if pre is not None else normed.matmul(x, cache=cache), kernel, bias=bias_t, act=act)
     else:
-        h = x if kernel is None else gemm_bias_act(x, kernel)                                     # :266-272
+        # the GEMM's rows are gathered next: written at a line-friendly stride (plan.gather_friendly_ld)
+        h = x if kernel is None else gemm_bias_act(x, kernel, out=gather_friendly_empty(int(x.shape[0]), int(kernel.shape[1]), x.device))     # :266-272
         h = normed.matmul(h, bias=bias_t, act=act, cache=cache if kernel is None else None)       # :280-288
     return post(h) if post is not None else h

@@ -15,7 +15,7 @@ import torch
 from ... import _lib as L
 from ...activations import resolve as _resolve_act
 from ...plan import (CsrPlan, segment_reduce, gemm_bias_act, l2_normalize_rows_, edge_weight_csr, static_rows,
-                     static_aggregate)
+                     static_aggregate, gather_friendly_empty)
 from ...sparse import SparseMatrix
 from .gcn import gcn_norm_adj
 from ... import autograd as AG
@@ -101,11 +101,12 @@ def _self_neighbor_sage(x, edge_index, edge_weight, self_kernel, neighbor_kernel
         elif concat:    # trainable edge weights: the un-fused operators carry d/dw
             bias_t = None if bias is None else L.as_f32(bias)
             a = AG.linear(x, ws, None if bias_t is None else bias_t[:ku_x], act)
-            b = AG.aggregate(plan, AG.linear(x, wn), op, w_csr, bias=None if bias_t is None else bias_t[ku_x:], act=act)
+            b = AG.aggregate(plan, AG.linear(x, wn, gathered=True), op, w_csr,
+                             bias=None if bias_t is None else bias_t[ku_x:], act=act)
             h = torch.cat([a, b], dim=1)
             h = post(h) if post is not None else h
         else:
-            h = AG.linear(x, ws) + AG.aggregate(plan, AG.linear(x, wn), op, w_csr)
+            h = AG.linear(x, ws) + AG.aggregate(plan, AG.linear(x, wn, gathered=True), op, w_csr)
             if bias is not None:
                 h = h + L.as_f32(bias)
             h = AG.apply_activation(h, act, post)
@@ -113,7 +114,7 @@ def _self_neighbor_sage(x, edge_index, edge_weight, self_kernel, neighbor_kernel
             h = h * torch.rsqrt(torch.clamp((h * h).sum(-1, keepdim=True), min=1e-12))
         return h
     bias_t = None if bias is None else L.as_f32(bias).contiguous()
-    z = gemm_bias_act(x, wn)
+    z = gemm_bias_act(x, wn, out=gather_friendly_empty(n, ku_n, x.device))      # rows gathered next: line-friendly stride
     if concat:
         h = torch.empty((n, ku_x + ku_n), dtype=torch.float32, device=x.device)
         gemm_bias_act(x, ws, bias=None if bias_t is None else bias_t[:ku_x], act=act, out=h[:, :ku_x])

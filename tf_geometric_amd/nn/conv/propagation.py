@@ -13,7 +13,7 @@ import torch
 from ... import _lib as L
 from ... import autograd as AG
 from ...activations import resolve as _resolve_act
-from ...plan import CsrPlan, segment_reduce, gemm_bias_act
+from ...plan import CsrPlan, segment_reduce, gemm_bias_act, gather_friendly_copy, gather_friendly_empty
 from ...sparse import SparseMatrix, sparse_features, sparse_dense_matmul
 from .gcn import gcn_norm_adj, NormedAdj
 
@@ -23,7 +23,11 @@ CACHE_KEY_CHEBYNET_NORMED_EDGE_TEMPLATE = "chebynet_normed_edge_{}"
 def _prop(plan, h, w_csr, self_coef):
     if AG.needs_grad(h):
         return AG.aggregate(plan, h, L.SUM, w_csr, self_coef)
-    return segment_reduce(plan, h, L.SUM, w_csr=w_csr, self_coef=self_coef)
+    # k-hop chains gather narrow / odd-width rows (class scores: 7, 40, 47 ...) again and again: keep every link of the
+    # chain on a line-friendly row stride (plan.gather_friendly_ld: F = 47 gathers 15 % faster at stride 48)
+    n, F = int(plan.n_dst), int(h.shape[1])
+    return segment_reduce(plan, gather_friendly_copy(h), L.SUM, w_csr=w_csr, self_coef=self_coef,
+                          out=gather_friendly_empty(n, F, h.device))
 
 
 def _dense(h, kernel, bias=None, activation=None):

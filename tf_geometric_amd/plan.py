@@ -417,6 +417,42 @@ def segment_reduce(plan, x, op, w_csr=None, out=None, act=L.ACT_NONE, self_coef=
     return out
 
 
+def gather_friendly_ld(F):
+    """Row stride (in floats) that keeps a GATHERED [*, F] row on the fewest 128-byte lines.  The aggregation kernels run
+    at the part's line-request ceiling, so a row that straddles an extra line costs exactly that much: F <= 32 rounds up
+    to a power of two (20 floats at stride 20 touch 1.6 lines on average, at stride 32 exactly one: 3.32 -> 2.36 ms per
+    products-shaped pass), rows that are not a multiple of 16 bytes round up to 64 bytes (47 -> 48: 5.14 -> 4.35 ms).
+    16-byte-aligned rows wider than a line are left alone (F = 100: padding to 112 / 128 LOSES 3-9 %).
+    Same-box A/B: tools/ab_row_stride.py, profiles/r02_ab_row_stride.jsonl."""
+    F = int(F)
+    if F <= 32:
+        return 1 << max(F - 1, 0).bit_length()
+    if F % 4 != 0:
+        return (F + 15) // 16 * 16
+    return F
+
+
+def gather_friendly_empty(n, F, device):
+    """Uninitialised float32 [n, F] whose rows start gather_friendly_ld(F) floats apart (a column view of a slightly
+    wider buffer when that differs from F).  For tensors this package PRODUCES and then gathers by row — GEMM outputs that
+    feed an aggregation, gradients fed to the transposed aggregation — never for the caller's own arrays."""
+    ld = gather_friendly_ld(F)
+    buf = torch.empty((int(n), ld), dtype=torch.float32, device=device)
+    return buf if ld == int(F) else buf[:, :int(F)]
+
+
+def gather_friendly_copy(t):
+    """`t` itself when its rows already sit on a gather-friendly stride, else a copy that does."""
+    F = int(t.shape[1])
+    if t.stride(1) == 1 and t.stride(0) == gather_friendly_ld(F):
+        return t
+    if gather_friendly_ld(F) == F:
+        return t.contiguous()
+    out = gather_friendly_empty(int(t.shape[0]), F, t.device)
+    out.copy_(t)
+    return out
+
+
 def gemm_bias_act(a, b, bias=None, act=L.ACT_NONE, out=None, act_cols=None):
     """act(a @ b + bias) on the fp32 MFMA kernel; `act_cols`: activate only columns [0, act_cols)."""
     lib = L.require_gpu()
