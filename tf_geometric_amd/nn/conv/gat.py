@@ -13,7 +13,7 @@ import torch
 
 from ... import _lib as L
 from ...activations import resolve as _resolve_act
-from ...plan import CsrPlan, gemm_bias_act
+from ...plan import CsrPlan, gemm_bias_act, gather_friendly_empty
 from ...sparse import sparse_features, sparse_dense_matmul
 from ... import autograd as AG
 
@@ -22,6 +22,11 @@ def _linear(x, kernel, bias, activation):
     act, post = _resolve_act(activation)
     h = gemm_bias_act(x, kernel, bias=bias, act=act)
     return post(h) if post is not None else h
+
+
+def _values(x, wv):
+    """V = x @ W, rows gathered per edge by the attention kernel: written at a line-friendly stride (U = 44 -> 48)."""
+    return gemm_bias_act(x, wv, out=gather_friendly_empty(int(x.shape[0]), int(wv.shape[1]), x.device))
 
 
 def _project_qkv(x, wq, bq, qact, wk, bk, kact, wv):
@@ -49,8 +54,8 @@ def _project_qkv(x, wq, bq, qact, wk, bk, kact, wv):
         w_qk = torch.cat([L.as_f32(wq, dev), L.as_f32(wk, dev)], dim=1).contiguous()
         b_qk = None if bq is None else torch.cat([L.as_f32(bq, dev).reshape(-1), L.as_f32(bk, dev).reshape(-1)])
         qk = gemm_bias_act(x, w_qk, bias=b_qk, act=qa)
-        return qk[:, :A], qk[:, A:], gemm_bias_act(x, wv)
-    return _linear(x, wq, bq, qact), _linear(x, wk, bk, kact), gemm_bias_act(x, wv)
+        return qk[:, :A], qk[:, A:], _values(x, wv)
+    return _linear(x, wq, bq, qact), _linear(x, wk, bk, kact), _values(x, wv)
 
 
 def gat_args(Q, K, V, num_heads, n_dst, col, add_self_loop=True, bias=None, act=L.ACT_NONE, out=None):
@@ -125,7 +130,7 @@ def _gat_train(x, plan, wq, bq, qact, wk, bk, kact, kernel, bias, activation, nu
             return AG.apply_activation(sparse_dense_matmul(xs, w, bias=b, act=code), L.ACT_NONE, post)
         return AG.apply_activation(AG.linear(x, w, b, code), L.ACT_NONE, post)
     Q, K, V = lin(wq, bq, qact), lin(wk, bk, kact), (sparse_dense_matmul(xs, kernel) if xs is not None
-                                                      else AG.linear(x, kernel))
+                                                      else AG.linear(x, kernel, gathered=True))
     h = AG.gat_attention(plan, Q, K, V, num_heads, drop_rate=drop_rate,
                          drop_seed=new_drop_seed() if drop_rate > 0.0 else 0)
     if not split_value_heads:
@@ -155,6 +160,23 @@ def gat(x, edge_index,
     drop = float(edge_drop_rate) if training else 0.0           # SparseMatrix.dropout(rate, training) (:85)
     if not 0.0 <= drop < 1.0:
         raise Exception("edge_drop_rate must be in [0, 1)")
+    U_out = int(kernel.shape[1])
+    if num_heads == 1 and U_out % 4 != 0:
+        # single-head output layers have odd widths (demo/demo_gat.py:23: 41 Reddit classes): value rows of U floats are
+        # neither 16-byte aligned nor a whole number of vector lanes, and the attention kernels (forward AND both backward
+        # passes) fall back to scalar lanes — 9.3 ms instead of 4.6 ms at the Reddit shape.  Up to three ZERO columns
+        # appended to the value kernel (and bias) make the width a multiple of four: the extra output columns are
+        # act(0 + 0) and are cut off again; the real columns see exactly the same arithmetic.
+        pad = (-U_out) % 4
+        kf = L.as_f32(kernel)
+        kernel_p = torch.cat([kf, kf.new_zeros((int(kf.shape[0]), pad))], dim=1)
+        bias_p = None
+        if bias is not None:
+            bf = L.as_f32(bias)
+            bias_p = torch.cat([bf, bf.new_zeros(pad)])
+        h = gat(x, edge_index, query_kernel, query_bias, query_activation, key_kernel, key_bias, key_activation,
+                kernel_p, bias_p, activation, 1, split_value_heads, edge_drop_rate, training, cache)
+        return h[:, :U_out].contiguous()
     xs = sparse_features(x)
     x = xs if xs is not None else L.as_f32(x)
     n = int(x.shape[0])

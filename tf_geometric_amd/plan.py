@@ -417,19 +417,30 @@ def segment_reduce(plan, x, op, w_csr=None, out=None, act=L.ACT_NONE, self_coef=
     return out
 
 
+def _avg_lines(F, ld):
+    """Average number of 128-byte lines a row of F floats touches when rows start ld floats apart (rows 4-byte aligned)."""
+    import math
+    row, stride = 4 * F, 4 * ld
+    period = 128 // math.gcd(stride, 128)
+    return sum(((i * stride) % 128 + row - 1) // 128 + 1 for i in range(period)) / period
+
+
 def gather_friendly_ld(F):
     """Row stride (in floats) that keeps a GATHERED [*, F] row on the fewest 128-byte lines.  The aggregation kernels run
-    at the part's line-request ceiling, so a row that straddles an extra line costs exactly that much: F <= 32 rounds up
-    to a power of two (20 floats at stride 20 touch 1.6 lines on average, at stride 32 exactly one: 3.32 -> 2.36 ms per
-    products-shaped pass), rows that are not a multiple of 16 bytes round up to 64 bytes (47 -> 48: 5.14 -> 4.35 ms).
-    16-byte-aligned rows wider than a line are left alone (F = 100: padding to 112 / 128 LOSES 3-9 %).
+    at the part's line-request ceiling, so a row that straddles an extra line costs exactly that much.  Candidates: F
+    itself, the next power of two (F <= 32), the next multiple of 16 and of 32 floats; the one with the fewest lines per
+    row on average wins, ties go to the smaller stride.  20 -> 32 (1.5 -> 1 line: 3.32 -> 2.36 ms per products-shaped
+    pass), 47 -> 48 (2.44 -> 2: 5.14 -> 4.35 ms), 44 -> 48 (2.25 -> 2), 172 -> 176 (6.25 -> 6); 40, 64, 100, 128 stay
+    dense (F = 100 touches 4 lines at any stride; padding it to 112 / 128 LOSES 3-9 % to the larger footprint).
     Same-box A/B: tools/ab_row_stride.py, profiles/r02_ab_row_stride.jsonl."""
     F = int(F)
+    if F <= 0:
+        return max(F, 1)
+    cands = [F, (F + 15) // 16 * 16, (F + 31) // 32 * 32]
     if F <= 32:
-        return 1 << max(F - 1, 0).bit_length()
-    if F % 4 != 0:
-        return (F + 15) // 16 * 16
-    return F
+        cands.append(1 << (F - 1).bit_length())
+    best = min(sorted(set(cands)), key=lambda ld: (round(_avg_lines(F, ld), 6), ld))
+    return best
 
 
 def gather_friendly_empty(n, F, device):

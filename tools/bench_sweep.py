@@ -225,6 +225,23 @@ def reddit_section(quick):
                           "attention_ms": ms_att, "attention_GBps_alg": balg / ms_att / 1e6,
                           "attention_frac_of_8TBps": balg / ms_att / 1e6 / 8000,
                           "Gedges_per_s_layer": E / ms_layer / 1e6}), flush=True)
+    # the demo's whole model (demo/demo_gat.py:22-23): GAT(64, 8 heads, attention_units 8) -> GAT(41, 1 head,
+    # attention_units 1) on the 41 Reddit classes; the second layer's odd value width runs zero-padded to 44 columns
+    g0 = tfg.layers.GAT(64, attention_units=8, num_heads=8, activation=tfg.relu)
+    g1 = tfg.layers.GAT(41, attention_units=1, num_heads=1)
+    ms_model = timeit(lambda: g1([g0([x, ei], cache=cache), ei], cache=cache))
+    h0 = g0([x, ei], cache=cache)
+    ms_l1 = timeit(lambda: g1([h0, ei], cache=cache))
+    g0.trainable(True)
+    g1.trainable(True)
+
+    def model_step():
+        for p_ in g0.parameters() + g1.parameters():
+            p_.grad = None
+        g1([g0([x, ei], cache=cache), ei], cache=cache).sum().backward()
+    ms_model_train = timeit(model_step, steps=3, warmup=2)
+    print(json.dumps({"kind": "reddit_gat_model", "what": "GAT(64, H8, A8) -> GAT(41, H1, A1), demo/demo_gat.py:22-23",
+                      "forward_ms": ms_model, "second_layer_ms": ms_l1, "fwd_bwd_ms": ms_model_train}), flush=True)
     del x, plan, ei
 
 
