@@ -333,6 +333,9 @@ def main():
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
+    import gc
+    gc.collect()
+    gc.disable()            # as timeit does: a full cyclic collection of a torch process is a 40 ms host pause
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
@@ -343,6 +346,7 @@ def main():
     barrier()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
+    gc.enable()
     ev_ms = ev0.elapsed_time(ev1) / args.steps
 
     if world > 1:

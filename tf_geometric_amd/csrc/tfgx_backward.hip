@@ -741,7 +741,9 @@ __global__ __launch_bounds__(kBlock) void gat_backward_fast_kernel(const GB a)
     const bool cvalid = c_raw < W;
     const int coff = cvalid ? c_raw : (W - VEC);
     const int head = coff / a.dv;
-    const int lh = a.dv / VEC;
+    // lanes that reduce <dO, V> together: the lanes of one head (a power of two, aligned) — or, for a single head of any
+    // width (dv / 4 lanes, e.g. 11 for the 44-wide output layer), the whole group with the idle lanes contributing zero
+    const int lh = (a.H == 1) ? G : a.dv / VEC;
     const bool head_first = cvalid && (coff % a.dv == 0);
 
     for (int64_t row = int64_t(blockIdx.x) * ROWS_PER_BLOCK + grp; row < a.n; row += int64_t(gridDim.x) * ROWS_PER_BLOCK) {
@@ -789,7 +791,7 @@ __global__ __launch_bounds__(kBlock) void gat_backward_fast_kernel(const GB a)
             float part = 0.0f;
 #pragma unroll
             for (int i = 0; i < VEC; ++i) part = fmaf(mine_v[i], in.v[i], part);   // <dO, V> over this lane's columns
-            const float da = head_sum<G>(part, lh);
+            const float da = head_sum<G>(cvalid ? part : 0.0f, lh);
             const float m = SRC ? in.m : m_r;
             const float linv = SRC ? 1.0f / (in.l + 1e-8f) : linv_r;
             const float dd = SRC ? in.dd : d_r;
@@ -872,7 +874,8 @@ inline bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 bool gat_bwd_fast_ok(const tfgx_gat_backward_args* p)
 {
     const bool d_ok = p->d == 1 || p->d == 2 || p->d == 4 || p->d == 8 || p->d == 16;
-    const bool v_ok = p->dv % 4 == 0 && pow2(p->dv / 4) && p->dv / 4 <= 64;
+    // one head of any width (dv / 4 <= 64 lanes: the group reduces as a whole), or several heads of a power-of-two width
+    const bool v_ok = p->dv % 4 == 0 && p->dv / 4 <= 64 && (pow2(p->dv / 4) || p->H == 1);
     const bool al = p->ldv % 4 == 0 && p->ld_grad_out % 4 == 0 && aligned_to(p->v, 16) && aligned_to(p->grad_out, 16) &&
                     (p->grad_v == nullptr || (p->ld_grad_v % 4 == 0 && aligned_to(p->grad_v, 16)));
     return d_ok && v_ok && al;
