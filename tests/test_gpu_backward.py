@@ -287,7 +287,8 @@ def test_gcn_edge_dropout_training(tfg, oracle):
     assert torch.allclose(d.value[kept], adj.value[kept] / 0.7, rtol=1e-6)
 
 
-@pytest.mark.parametrize("heads,att,units", [(1, 4, 6), (4, 8, 16), (2, 6, 10), (1, 1, 41), (1, 2, 7)])
+@pytest.mark.parametrize("heads,att,units", [(1, 4, 6), (4, 8, 16), (2, 6, 10), (1, 1, 41), (1, 2, 7), (2, 64, 8), (4, 12, 20),
+                                             (2, 2, 82), (3, 9, 9), (1, 4, 300)])
 def test_gat_layer_grads(tfg, oracle, heads, att, units):
     x, ei, w, rng = _graph(oracle, n=200, e=2500, f=9, seed=7)
     n, f = x.shape

@@ -72,7 +72,8 @@ def test_gcn_no_kernel_unweighted_and_path_graph_kat(tfg, oracle):
 
 @pytest.mark.parametrize("heads,att,units,split", [(1, 8, 8, True), (8, 8, 64, True), (8, 64, 64, True),
                                                   (4, 16, 20, True), (2, 6, 10, False), (8, 8, 16, False),
-                                                  (1, 1, 41, True), (3, 9, 9, True)])
+                                                  (1, 1, 41, True), (3, 9, 9, True), (8, 256, 64, True), (4, 12, 64, True),
+                                                  (2, 2, 82, True), (4, 4, 10, False), (5, 20, 40, True), (2, 80, 8, True)])
 def test_gat_layer(tfg, oracle, heads, att, units, split):
     x, ei, w, rng = _graph(oracle, 400, 4000, 30, seed=heads + att)
     layer = tfg.layers.GAT(units, attention_units=att, activation=tfg.relu, num_heads=heads, split_value_heads=split)

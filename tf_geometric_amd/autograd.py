@@ -392,12 +392,13 @@ def linear(x, kernel, bias=None, act=L.ACT_NONE, gathered=False):
 
 class _GatAttention(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, plan, num_heads, Q, K, V, drop_rate, drop_seed):
+    def forward(ctx, plan, num_heads, Q, K, V, drop_rate, drop_seed, scale_d=None):
         from .nn.conv.gat import gat_attention
         stats = torch.empty((plan.n_dst, 2 * num_heads), dtype=torch.float32, device=V.device)
         out = gat_attention(plan, Q.detach(), K.detach(), V.detach(), num_heads, True, stats_ml=stats,
-                            drop_rate=drop_rate, drop_seed=drop_seed)
+                            drop_rate=drop_rate, drop_seed=drop_seed, scale_d=scale_d)
         ctx.plan, ctx.H, ctx.drop = plan, num_heads, (float(drop_rate), int(drop_seed))
+        ctx.scale_d = scale_d
         ctx.save_for_backward(Q, K, V, out, stats)
         return out
 
@@ -434,7 +435,7 @@ class _GatAttention(torch.autograd.Function):
         a.grad_out, a.ld_grad_out = g2.data_ptr(), ldg
         a.stats_ml, a.dsum = stats.data_ptr(), dsum.data_ptr()
         a.H, a.d, a.dv, a.add_self_loop = H, A // H, W // H, 1
-        a.scale = math.sqrt(float(A // H))
+        a.scale = math.sqrt(float(A // H if ctx.scale_d is None else ctx.scale_d))
         a.grad_q, a.ld_grad_q = gq.data_ptr(), A
         a.grad_k, a.ld_grad_k = gk.data_ptr(), A
         a.grad_v, a.ld_grad_v = gv.data_ptr(), W
@@ -447,13 +448,14 @@ class _GatAttention(torch.autograd.Function):
         a.stats_ml, a.ld_stats_ml = pack.data_ptr() + 4 * (W + A), P
         a.dsum, a.ld_dsum = pack.data_ptr() + 4 * (W + A + 2 * H), P
         L.check(lib.tfgx_gat_backward_src_f32(ctypes.byref(a), L.stream_ptr()), "tfgx_gat_backward_src_f32")
-        return None, None, gq, gk, gv, None, None
+        return None, None, gq, gk, gv, None, None, None
 
 
-def gat_attention(plan, Q, K, V, num_heads, drop_rate=0.0, drop_seed=0):
+def gat_attention(plan, Q, K, V, num_heads, drop_rate=0.0, drop_seed=0, scale_d=None):
     """Differentiable fused attention (self-loop edge appended, as nn/conv/gat.py:43); drop_rate > 0 = training-time
-    dropout of the attention weights (gat.py:85)."""
-    return _GatAttention.apply(plan, num_heads, Q, K, V, float(drop_rate), int(drop_seed))
+    dropout of the attention weights (gat.py:85).  scale_d: the per-head width the scores are scaled by when Q / K
+    arrive zero-padded per head (nn/conv/gat._kernel_widths)."""
+    return _GatAttention.apply(plan, num_heads, Q, K, V, float(drop_rate), int(drop_seed), scale_d)
 
 
 def edge_attr_csr(plan, edge_attr, cache=None):

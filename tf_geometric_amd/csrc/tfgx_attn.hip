@@ -296,6 +296,7 @@ int launch_gat_d(const GArgs& a, hipStream_t stream)
         case 4: gat_fused_kernel<VEC, G, 4><<<grid, block, 0, stream>>>(a); break;
         case 8: gat_fused_kernel<VEC, G, 8><<<grid, block, 0, stream>>>(a); break;
         case 16: gat_fused_kernel<VEC, G, 16><<<grid, block, 0, stream>>>(a); break;
+        case 32: gat_fused_kernel<VEC, G, 32><<<grid, block, 0, stream>>>(a); break;
         default: gat_fused_kernel<VEC, G, 0><<<grid, block, 0, stream>>>(a); break;
     }
     TFGX_LAUNCH_CHECK("gat_fused_kernel");

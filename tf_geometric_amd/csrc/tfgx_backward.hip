@@ -631,7 +631,8 @@ __global__ __launch_bounds__(kBlock) void gat_backward_src_kernel(const GB a)
 }
 
 // ---- fast GAT backward: a group of G lanes per row, lane -> 4 value columns of one head (as the forward kernel).
-// Needs dv % 4 == 0, LH = dv/4 a power of two (the head's lanes form an aligned butterfly), d in {1,2,4,8,16}.
+// Needs dv % 4 == 0, LH = dv/4 a power of two (the head's lanes form an aligned butterfly) or ONE head of any width,
+// d in {1,2,4,8,16,32}; other per-head widths reach these kernels zero-padded by the host (nn/conv/gat.py).
 // Per edge the bytes moved are the forward's (K row + V row) for the dst pass and Q row + dO row + 3 scalars for the
 // src pass; everything else lives in registers.
 template <int D>
@@ -810,7 +811,7 @@ __global__ __launch_bounds__(kBlock) void gat_backward_fast_kernel(const GB a)
             edge_load(o, in);
             edge_apply(in, keep);
         };
-        constexpr int U = (D <= 4) ? 4 : 2;
+        constexpr int U = (D <= 4) ? 4 : (D <= 16 ? 2 : 1);
         for (int base = s0; base < e0; base += G) {
             const int idx = base + lane;
             const int oj = (idx < e0) ? a.other[idx] : 0;
@@ -851,7 +852,8 @@ int launch_gat_bwd_d(const GB& a, hipStream_t stream)
         case 2: gat_backward_fast_kernel<G, 2, SRC><<<grid, block, 0, stream>>>(a); break;
         case 4: gat_backward_fast_kernel<G, 4, SRC><<<grid, block, 0, stream>>>(a); break;
         case 8: gat_backward_fast_kernel<G, 8, SRC><<<grid, block, 0, stream>>>(a); break;
-        default: gat_backward_fast_kernel<G, 16, SRC><<<grid, block, 0, stream>>>(a); break;
+        case 16: gat_backward_fast_kernel<G, 16, SRC><<<grid, block, 0, stream>>>(a); break;
+        default: gat_backward_fast_kernel<G, 32, SRC><<<grid, block, 0, stream>>>(a); break;
     }
     TFGX_LAUNCH_CHECK("gat_backward_fast_kernel");
     return TFGX_OK;
@@ -873,7 +875,7 @@ inline bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 // layout conditions of the fast kernels (else the one-lane-per-(row, head) kernels above are used)
 bool gat_bwd_fast_ok(const tfgx_gat_backward_args* p)
 {
-    const bool d_ok = p->d == 1 || p->d == 2 || p->d == 4 || p->d == 8 || p->d == 16;
+    const bool d_ok = p->d == 1 || p->d == 2 || p->d == 4 || p->d == 8 || p->d == 16 || p->d == 32;
     // one head of any width (dv / 4 <= 64 lanes: the group reduces as a whole), or several heads of a power-of-two width
     const bool v_ok = p->dv % 4 == 0 && p->dv / 4 <= 64 && (pow2(p->dv / 4) || p->H == 1);
     const bool al = p->ldv % 4 == 0 && p->ld_grad_out % 4 == 0 && aligned_to(p->v, 16) && aligned_to(p->grad_out, 16) &&

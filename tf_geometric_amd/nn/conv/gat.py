@@ -58,7 +58,7 @@ def _project_qkv(x, wq, bq, qact, wk, bk, kact, wv):
     return _linear(x, wq, bq, qact), _linear(x, wk, bk, kact), _values(x, wv)
 
 
-def gat_args(Q, K, V, num_heads, n_dst, col, add_self_loop=True, bias=None, act=L.ACT_NONE, out=None):
+def gat_args(Q, K, V, num_heads, n_dst, col, add_self_loop=True, bias=None, act=L.ACT_NONE, out=None, scale_d=None):
     """Fill a tfgx_gat_args for Q:[n_dst,A] K:[n_src,A] V:[n_src,W]; returns (args, out, keep-alive tuple)."""
     Q, ldq = L.row_major_2d(Q)
     K, ldk = L.row_major_2d(K)
@@ -78,7 +78,8 @@ def gat_args(Q, K, V, num_heads, n_dst, col, add_self_loop=True, bias=None, act=
     a.out, a.ldo = out.data_ptr(), max(W, 1)
     a.H, a.d, a.dv = num_heads, A // num_heads, W // num_heads
     a.add_self_loop = 1 if add_self_loop else 0
-    a.scale = math.sqrt(float(A // num_heads))            # gat.py:78  sqrt(shape(Q_)[-1])
+    # gat.py:78  sqrt(shape(Q_)[-1]); scale_d: the reference's per-head width when Q / K arrive zero-padded per head
+    a.scale = math.sqrt(float(A // num_heads if scale_d is None else scale_d))
     a.act = act
     a.bias = 0 if bias is None else bias.data_ptr()
     return a, out, (Q, K, V)
@@ -91,13 +92,13 @@ def new_drop_seed():
 
 
 def gat_attention(plan, Q, K, V, num_heads, add_self_loop=True, bias=None, act=L.ACT_NONE, stats_ml=None,
-                  drop_rate=0.0, drop_seed=0):
+                  drop_rate=0.0, drop_seed=0, scale_d=None):
     """Fused SDDMM + edge softmax + SpMM over `plan` (tfgx_gat_fused_f32). Q:[n_dst,A] K:[n_src,A] V:[n_src,W].
     Destinations with very many in-edges (plan.hub_info()) are processed chunk-wise and merged.
     drop_rate > 0 (training): the softmax weights are dropped / rescaled inside the kernel (gat.py:85); the keep
     decision is a function of (drop_seed, CSR position, head), positions [E, E+n) being the appended self-loops."""
     lib = L.require_gpu()
-    a, out, keep = gat_args(Q, K, V, num_heads, plan.n_dst, plan.col, add_self_loop, bias, act)
+    a, out, keep = gat_args(Q, K, V, num_heads, plan.n_dst, plan.col, add_self_loop, bias, act, scale_d=scale_d)
     a.row_ptr = plan.row_ptr.data_ptr()
     if stats_ml is not None:
         a.stats_ml = stats_ml.data_ptr()      # (m, l) per row and head, kept for the backward pass
@@ -119,6 +120,43 @@ def gat_attention(plan, Q, K, V, num_heads, add_self_loop=True, bias=None, act=L
     return out
 
 
+_FAST_D = (1, 2, 4, 8, 16, 32)      # attention units per head the fused kernels are instantiated for
+
+
+def _pow2_ceil(v):
+    return 1 << max(int(v) - 1, 0).bit_length()
+
+
+def _kernel_widths(d, dv, num_heads):
+    """(d', dv'): per-head widths the fast attention kernels (forward and both backward passes) accept — d in
+    {1, 2, 4, 8, 16, 32}; dv a multiple of 4 whose lane count dv / 4 is a power of two (several heads) — or the widths
+    themselves when they already qualify / cannot be helped.  Zero columns change neither <Q, K> nor the real output
+    columns; without them the layer falls to the one-lane-per-(row, head) kernels (10-100 x slower on large graphs)."""
+    d2 = d if (d in _FAST_D or d > 32) else min(v for v in _FAST_D if v >= d)
+    dv2 = dv
+    if num_heads > 1:
+        lanes = -(-dv // 4)
+        if dv % 4 != 0 or (lanes & (lanes - 1)) != 0:
+            cand = 4 * _pow2_ceil(lanes)
+            dv2 = cand if cand // 4 <= 64 else dv
+    return d2, dv2
+
+
+def _pad_heads(t, num_heads, w_new):
+    """[n, H * w] -> [n, H * w_new], every head's block zero-padded on the right (differentiable)."""
+    n, w = int(t.shape[0]), int(t.shape[1]) // num_heads
+    if w_new == w:
+        return t
+    return torch.nn.functional.pad(t.reshape(n, num_heads, w), (0, w_new - w)).reshape(n, num_heads * w_new)
+
+
+def _unpad_heads(t, num_heads, w):
+    n, w_pad = int(t.shape[0]), int(t.shape[1]) // num_heads
+    if w_pad == w:
+        return t
+    return t.reshape(n, num_heads, w_pad)[:, :, :w].reshape(n, num_heads * w)
+
+
 def _gat_train(x, plan, wq, bq, qact, wk, bk, kact, kernel, bias, activation, num_heads, split_value_heads,
                drop_rate=0.0):
     """Differentiable route (autograd.py): same math, un-fused epilogues."""
@@ -131,8 +169,20 @@ def _gat_train(x, plan, wq, bq, qact, wk, bk, kact, kernel, bias, activation, nu
         return AG.apply_activation(AG.linear(x, w, b, code), L.ACT_NONE, post)
     Q, K, V = lin(wq, bq, qact), lin(wk, bk, kact), (sparse_dense_matmul(xs, kernel) if xs is not None
                                                       else AG.linear(x, kernel, gathered=True))
-    h = AG.gat_attention(plan, Q, K, V, num_heads, drop_rate=drop_rate,
-                         drop_seed=new_drop_seed() if drop_rate > 0.0 else 0)
+    d, dv = int(Q.shape[1]) // num_heads, int(V.shape[1]) // num_heads
+    d2, dv2 = _kernel_widths(d, dv, num_heads)
+    seed = new_drop_seed() if drop_rate > 0.0 else 0
+    Qp, Kp = _pad_heads(Q, num_heads, d2), _pad_heads(K, num_heads, d2)
+    if num_heads == 1 and dv > 256:
+        # one head wider than the backward kernels' 64 lanes x 4 columns: the attention weights do not depend on the
+        # value columns, so the layer is exactly the concatenation of the same attention over 256-column blocks of V
+        # (same dropout seed -> same kept edges); autograd sums the blocks' d/dQ, d/dK
+        h = torch.cat([AG.gat_attention(plan, Qp, Kp, V[:, c0:c0 + 256], 1, drop_rate=drop_rate, drop_seed=seed, scale_d=d)
+                       for c0 in range(0, dv, 256)], dim=1)
+    else:
+        h = AG.gat_attention(plan, Qp, Kp, _pad_heads(V, num_heads, dv2), num_heads, drop_rate=drop_rate,
+                             drop_seed=seed, scale_d=d)
+        h = _unpad_heads(h, num_heads, dv)
     if not split_value_heads:
         U = int(V.shape[1]) // num_heads
         h = h.view(h.shape[0], num_heads, U).sum(1) / num_heads
@@ -188,10 +238,21 @@ def gat(x, edge_index,
     Q, K, V = _project_qkv(x, query_kernel, query_bias, query_activation, key_kernel, key_bias, key_activation, kernel)
     act, post = _resolve_act(activation)
     bias_t = None if bias is None else L.as_f32(bias).contiguous()
+    d, dv = int(Q.shape[1]) // num_heads, int(V.shape[1]) // num_heads
+    d2, dv2 = _kernel_widths(d, dv, num_heads)
+    Q, K = _pad_heads(Q, num_heads, d2), _pad_heads(K, num_heads, d2)
+    if dv2 != dv:           # padded value heads: bias / activation cannot ride in the kernel (its columns are shifted)
+        h = _unpad_heads(gat_attention(plan, Q, K, _pad_heads(V, num_heads, dv2), num_heads, True, scale_d=d), num_heads, dv)
+        if not split_value_heads:
+            h = h.reshape(n, num_heads, dv).sum(1) / num_heads
+        if bias_t is not None:
+            h = h + bias_t
+        h = torch.relu(h) if act == L.ACT_RELU else h
+        return post(h) if post is not None else h
     if split_value_heads:
-        h = gat_attention(plan, Q, K, V, num_heads, True, bias=bias_t, act=act)
+        h = gat_attention(plan, Q, K, V, num_heads, True, bias=bias_t, act=act, scale_d=d)
     else:
-        h_ = gat_attention(plan, Q, K, V, num_heads, True)
+        h_ = gat_attention(plan, Q, K, V, num_heads, True, scale_d=d)
         U = int(V.shape[1]) // num_heads
         h = torch.empty((n, U), dtype=torch.float32, device=x.device)
         L.check(lib.tfgx_head_mean_f32(L.ptr(h_), int(V.shape[1]), n, num_heads, U, L.ptr(bias_t), act, L.ptr(h),
