@@ -142,6 +142,18 @@ def appnp(x, edge_index, edge_weight, kernels, biases, dense_activation="relu", 
     normed = _normed(x, edge_index, edge_weight, cache).dropout(edge_drop_rate, training=training)
     h = _mlp_encoder(x, kernels, biases, dense_activation, training, dense_drop_rate, last_dense_drop_rate)
     output = h
+    if not AG.needs_grad(h) and k > 0:
+        # inference: (1 - alpha) A_hat Z + alpha H in ONE launch per hop — the edge weights and the self-loop coefficient
+        # are scaled by (1 - alpha) once, alpha H rides in the kernel's epilogue (add_x); no elementwise pass per hop
+        n, F = int(h.shape[0]), int(h.shape[1])
+        w_s = normed.w_csr * (1.0 - alpha)
+        sc_s = None if normed.self_coef is None else normed.self_coef * (1.0 - alpha)
+        ah = gather_friendly_copy(h * alpha)
+        output = gather_friendly_copy(h)
+        for _ in range(k):
+            output = segment_reduce(normed.plan, output, L.SUM, w_csr=w_s, self_coef=sc_s, add_x=ah,
+                                    out=gather_friendly_empty(n, F, h.device))
+        return _finish(output, None, activation)
     for _ in range(k):
         output = _prop(normed.plan, output, normed.w_csr, normed.self_coef)       # :84-86
         output = output * (1.0 - alpha) + h * alpha
