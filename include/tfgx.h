@@ -304,6 +304,24 @@ int tfgx_segment_max_backward_f32(const int32_t* row_ptr_t, const int32_t* dst_t
                                   int64_t n_dst, float* gn_scratch /* [n_dst, F] workspace or NULL (slow path) */,
                                   tfgx_stream_t stream);
 
+/* Chunk lists of the rows of a plan that are too long for one lane group ("hubs" of a power-law graph), as the host
+   builds them once per plan (the same lists tfgx_reduce_args / tfgx_gat_args carry for the forward): rows with more
+   than `threshold` positions; hub row rows[i] owns chunks [chunk_ptr[i], chunk_ptr[i+1]); chunk c covers CSR positions
+   [chunk_begin[c], chunk_end[c]) of row chunk_row[c].  The *_hub_f32 backward entry points below take them (NULL: every
+   row is walked by one lane group), run the hub rows chunk-wise into a caller-lent scratch and add a row's chunk
+   partials in chunk order — deterministic, no atomics. */
+typedef struct tfgx_hub_lists {
+    int32_t threshold;
+    int32_t reserved;
+    int64_t n_rows;
+    int64_t n_chunks;
+    const int32_t* rows;
+    const int32_t* chunk_ptr;
+    const int32_t* chunk_begin;
+    const int32_t* chunk_end;
+    const int32_t* chunk_row;
+} tfgx_hub_lists;
+
 typedef struct tfgx_gat_backward_args {
     const int32_t* row_ptr;    /* forward plan (by destination) + col: used by the dst pass */
     const int32_t* col;
@@ -346,6 +364,22 @@ int tfgx_gat_pack_dst_f32(const float* grad_out, int64_t ld_grad_out, const floa
                           int32_t dv, float* pack, int64_t ld_pack, float* dsum /* [n_dst, H] */, tfgx_stream_t stream);
 int tfgx_gat_backward_dst_f32(const tfgx_gat_backward_args* args /* host */, tfgx_stream_t stream);
 int tfgx_gat_backward_src_f32(const tfgx_gat_backward_args* args /* host */, tfgx_stream_t stream);
+/* the same passes on a graph with hub rows: `hub` = chunk lists of the forward plan (dst pass) / of the transposed plan
+   (src pass); hub_scratch: n_chunks * H*d floats (dst) / n_chunks * (H*d + H*dv) floats (src).  NULL lists = plain pass. */
+int tfgx_gat_backward_dst_hub_f32(const tfgx_gat_backward_args* args, const tfgx_hub_lists* hub, float* hub_scratch,
+                                  tfgx_stream_t stream);
+int tfgx_gat_backward_src_hub_f32(const tfgx_gat_backward_args* args, const tfgx_hub_lists* hub_t, float* hub_scratch,
+                                  tfgx_stream_t stream);
+/* hub-aware forms of tfgx_segment_max_count_f32 / tfgx_segment_max_backward_f32 (hub lists of the forward plan / of the
+   transposed plan; hub_scratch: n_chunks * F floats) */
+int tfgx_segment_max_count_hub_f32(const int32_t* row_ptr, const int32_t* col, const float* w /* or NULL */, int64_t n_dst,
+                                   const float* x, int64_t ldx, int64_t F, const float* out, int64_t ldo, float* count,
+                                   int64_t ldc, const tfgx_hub_lists* hub, float* hub_scratch, tfgx_stream_t stream);
+int tfgx_segment_max_backward_hub_f32(const int32_t* row_ptr_t, const int32_t* dst_t, const float* w_t /* or NULL */,
+                                      int64_t n_src, const float* x, int64_t ldx, int64_t F, const float* out,
+                                      int64_t ldo, const float* g, int64_t ldg, const float* count, int64_t ldc, float* gx,
+                                      int64_t ldgx, int64_t n_dst, float* gn_scratch, const tfgx_hub_lists* hub_t,
+                                      float* hub_scratch, tfgx_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Dense GEMM beside the path: C = act(A[M,K] @ B[K,N] + bias) with fp32-input MFMA

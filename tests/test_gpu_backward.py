@@ -555,3 +555,59 @@ def test_max_gradient_push_equals_pull_and_autograd(tfg, oracle, f, weighted):
     ref.backward(torch.tensor(gout, dtype=torch.float64))
     assert_parity(gx_push, xr.grad.numpy(), tol=2e-5, what="push max gradient vs autograd")
     assert np.abs(gx_push[7]).max() >= 0 and np.array_equal(out_push[7], np.full(f, -3.4028234663852886e38, np.float32))
+
+
+@pytest.mark.parametrize("threshold", [None, 64])
+def test_hub_rows_in_the_backward_passes(tfg, oracle, threshold):
+    """Power-law graphs: a destination with 6000 in-edges and a source with 5000 out-edges.  The GAT backward (dQ over hub
+    destinations, dK / dV over hub sources) and the max-aggregation gradient (tie count over hub destinations, pull pass
+    over hub sources) walk such rows chunk-wise and add the chunk partials in order — gradients equal float64 autograd,
+    with the plan's own hub policy and with a forced low threshold that turns many rows into hubs."""
+    import tf_geometric_amd.plan as P
+    from tf_geometric_amd.plan import CsrPlan
+    n, f = 1500, 12
+    rng = np.random.Generator(np.random.PCG64(97))
+    x = rng.standard_normal((n, f)).astype(np.float32)
+    hub_dst = np.stack([np.full(6000, 7, np.int32), rng.integers(0, n, 6000, dtype=np.int32)])
+    hub_src = np.stack([rng.integers(0, n, 5000, dtype=np.int32), np.full(5000, 11, np.int32)])
+    ei = np.concatenate([hub_dst, oracle.synthetic_edges(n, 8000, seed=6), hub_src], axis=1).astype(np.int32)
+    old = (P.HUB_THRESHOLD, P.HUB_CHUNK)
+    P.HUB_THRESHOLD, P.HUB_CHUNK = threshold, (None if threshold is None else 48)
+    try:
+        plan = CsrPlan.build(ei, n, n)
+        assert plan.hub_info() is not None and plan.transposed().hub_info() is not None
+        cache = {"tfgx_csr_plan": plan}
+        # GAT layer gradients
+        heads, att, units = 4, 8, 16
+        layer = tfg.layers.GAT(units, attention_units=att, num_heads=heads, activation=tfg.relu)
+        layer._maybe_build([x])
+        ws = {"query_kernel": oracle.glorot_uniform(rng, f, att), "query_bias": (rng.standard_normal(att) * 0.2).astype(np.float32),
+              "key_kernel": oracle.glorot_uniform(rng, f, att), "key_bias": (rng.standard_normal(att) * 0.2).astype(np.float32),
+              "kernel": oracle.glorot_uniform(rng, f, units), "bias": (rng.standard_normal(units) * 0.1).astype(np.float32)}
+        layer.set_weights(**ws)
+        layer.trainable(True)
+        xt = torch.tensor(x, device="cuda", requires_grad=True)
+        out = layer([xt, ei], cache=cache)
+        gout = torch.tensor(rng.standard_normal((n, units)).astype(np.float32), device="cuda")
+        out.backward(gout)
+        r = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in ws.items()}
+        xr = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+        ref = _ref_gat(xr, ei, r["query_kernel"], r["query_bias"], r["key_kernel"], r["key_bias"], r["kernel"], r["bias"], heads, n)
+        ref.backward(gout.double().cpu())
+        assert_parity(out.detach().cpu().numpy(), ref.detach().numpy(), tol=2e-5, what="hub gat forward")
+        assert_parity(xt.grad.cpu().numpy(), xr.grad.numpy(), tol=2e-4, what="hub gat d/dx")
+        for k in ws:
+            assert_parity(getattr(layer, k).grad.cpu().numpy(), r[k].grad.numpy(), tol=5e-4, what="hub gat d/d" + k)
+        # max aggregation gradient (ties included: ReLU-style zero plateaus)
+        xm = np.maximum(rng.standard_normal((n, f)), 0).astype(np.float32)
+        xt2 = torch.tensor(xm, device="cuda", requires_grad=True)
+        o2 = tfg.nn.aggregate_neighbors(xt2, ei, None, tfg.nn.identity_mapper, tfg.nn.max_reducer, tfg.nn.identity_updater)
+        g2 = torch.tensor(rng.standard_normal((n, f)).astype(np.float32), device="cuda")
+        o2.backward(g2)
+        xr2 = torch.tensor(xm, dtype=torch.float64, requires_grad=True)
+        r2 = _ref_aggregate(xr2, ei, None, "max", n)
+        r2.backward(g2.double().cpu())
+        assert np.array_equal(o2.detach().cpu().numpy(), r2.detach().numpy().astype(np.float32))
+        assert_parity(xt2.grad.cpu().numpy(), xr2.grad.numpy(), tol=2e-5, what="hub max d/dx")
+    finally:
+        P.HUB_THRESHOLD, P.HUB_CHUNK = old

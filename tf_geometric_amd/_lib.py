@@ -67,6 +67,26 @@ class GatArgs(ctypes.Structure):
     ]
 
 
+class HubLists(ctypes.Structure):
+    """struct tfgx_hub_lists (include/tfgx.h)."""
+    _fields_ = [("threshold", ctypes.c_int32), ("reserved", ctypes.c_int32), ("n_rows", ctypes.c_int64),
+                ("n_chunks", ctypes.c_int64), ("rows", ctypes.c_void_p), ("chunk_ptr", ctypes.c_void_p),
+                ("chunk_begin", ctypes.c_void_p), ("chunk_end", ctypes.c_void_p), ("chunk_row", ctypes.c_void_p)]
+
+
+def hub_lists(plan):
+    """(HubLists struct, n_chunks) of a plan's long rows, or (None, 0) when the plan has none (plan.hub_info())."""
+    info = plan.hub_info()
+    if info is None:
+        return None, 0
+    hub_rows, chunk_ptr, chunk_begin, chunk_end, chunk_row = info
+    h = HubLists()
+    h.threshold, h.n_rows, h.n_chunks = int(plan.hub_threshold), int(hub_rows.shape[0]), int(chunk_begin.shape[0])
+    h.rows, h.chunk_ptr = hub_rows.data_ptr(), chunk_ptr.data_ptr()
+    h.chunk_begin, h.chunk_end, h.chunk_row = chunk_begin.data_ptr(), chunk_end.data_ptr(), chunk_row.data_ptr()
+    return h, int(chunk_begin.shape[0])
+
+
 class GatBackwardArgs(ctypes.Structure):
     """struct tfgx_gat_backward_args (include/tfgx.h)."""
     _fields_ = [
@@ -132,6 +152,12 @@ SIGNATURES = {
                                                      _P, _I64, _I64, _P, _P]),
     "tfgx_gat_backward_dst_f32": (ctypes.c_int, [ctypes.POINTER(GatBackwardArgs), _P]),
     "tfgx_gat_backward_src_f32": (ctypes.c_int, [ctypes.POINTER(GatBackwardArgs), _P]),
+    "tfgx_gat_backward_dst_hub_f32": (ctypes.c_int, [ctypes.POINTER(GatBackwardArgs), ctypes.POINTER(HubLists), _P, _P]),
+    "tfgx_gat_backward_src_hub_f32": (ctypes.c_int, [ctypes.POINTER(GatBackwardArgs), ctypes.POINTER(HubLists), _P, _P]),
+    "tfgx_segment_max_count_hub_f32": (ctypes.c_int, [_P, _P, _P, _I64, _P, _I64, _I64, _P, _I64, _P, _I64,
+                                                      ctypes.POINTER(HubLists), _P, _P]),
+    "tfgx_segment_max_backward_hub_f32": (ctypes.c_int, [_P, _P, _P, _I64, _P, _I64, _I64, _P, _I64, _P, _I64, _P, _I64,
+                                                         _P, _I64, _I64, _P, ctypes.POINTER(HubLists), _P, _P]),
     "tfgx_head_mean_f32": (ctypes.c_int, [_P, _I64, _I64, _I32, _I32, _P, _I32, _P, _I64, _P]),
     "tfgx_gemm_bias_act_f32": (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I32, _P, _I64, _I64, _I64, _I64, _P]),
     "tfgx_gemm_bias_act_cols_f32": (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I32, _I64, _P, _I64, _I64, _I64, _I64, _P]),

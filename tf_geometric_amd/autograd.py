@@ -196,15 +196,21 @@ class _AggregateMax(torch.autograd.Function):
         g2, ldg = L.row_major_2d(g.contiguous())
         F = int(x2.shape[1])
         count = ctx.count
-        if count is None:
+        if count is None:          # skewed graph: hub rows counted chunk-wise
             count = torch.empty_like(out)
-            L.check(lib.tfgx_segment_max_count_f32(L.ptr(plan.row_ptr), L.ptr(plan.col), L.ptr(w_csr), plan.n_dst,
-                                                   L.ptr(x2), ldx, F, L.ptr(out), F, L.ptr(count), F, L.stream_ptr()),
-                    "tfgx_segment_max_count_f32")
+            hub_c, nc_c = L.hub_lists(plan)
+            sc_c = torch.empty(max(nc_c * F, 1), dtype=torch.float32, device=x2.device) if hub_c is not None else None
+            L.check(lib.tfgx_segment_max_count_hub_f32(L.ptr(plan.row_ptr), L.ptr(plan.col), L.ptr(w_csr), plan.n_dst,
+                                                       L.ptr(x2), ldx, F, L.ptr(out), F, L.ptr(count), F,
+                                                       None if hub_c is None else ctypes.byref(hub_c), L.ptr(sc_c),
+                                                       L.stream_ptr()), "tfgx_segment_max_count_hub_f32")
         gx = None
         if ctx.needs_input_grad[1]:
             gx = torch.empty((int(x2.shape[0]), F), dtype=torch.float32, device=x2.device)   # dense: ld = F below
             aligned = ctx.argpos is not None and ldg % 4 == 0 and g2.data_ptr() % 16 == 0
+            pt_hub, nc_t = L.hub_lists(_transposed(plan)[0])
+            if pt_hub is not None:
+                aligned = False        # hub SOURCES: the per-source walks of the mask / push forms would serialise; pull, chunked
             if aligned and ctx.mode == "mask":
                 pt, t2d = _transposed(plan)
                 w_t = _transposed_weights(plan, w_csr, t2d)
@@ -224,10 +230,11 @@ class _AggregateMax(torch.autograd.Function):
                 pt, t2d = _transposed(plan)
                 w_t = _transposed_weights(plan, w_csr, t2d)
                 gn = torch.empty_like(out)          # workspace: g / count per destination row
-                L.check(lib.tfgx_segment_max_backward_f32(L.ptr(pt.row_ptr), L.ptr(pt.col), L.ptr(w_t), pt.n_dst, L.ptr(x2),
-                                                          ldx, F, L.ptr(out), F, L.ptr(g2), ldg, L.ptr(count), F, L.ptr(gx),
-                                                          F, plan.n_dst, L.ptr(gn), L.stream_ptr()),
-                        "tfgx_segment_max_backward_f32")
+                sc_t = torch.empty(max(nc_t * F, 1), dtype=torch.float32, device=x2.device) if pt_hub is not None else None
+                L.check(lib.tfgx_segment_max_backward_hub_f32(
+                    L.ptr(pt.row_ptr), L.ptr(pt.col), L.ptr(w_t), pt.n_dst, L.ptr(x2), ldx, F, L.ptr(out), F, L.ptr(g2), ldg,
+                    L.ptr(count), F, L.ptr(gx), F, plan.n_dst, L.ptr(gn), None if pt_hub is None else ctypes.byref(pt_hub),
+                    L.ptr(sc_t), L.stream_ptr()), "tfgx_segment_max_backward_hub_f32")
         gw = None
         if w_csr is not None and ctx.needs_input_grad[2]:
             gn2 = g2 / count.clamp(min=1.0)          # TF splits the gradient evenly among tied maxima
@@ -442,12 +449,20 @@ class _GatAttention(torch.autograd.Function):
         if ctx.drop[0] > 0.0:      # regenerate the forward's keep mask: same seed, forward-CSR edge positions
             a.drop_rate, a.drop_seed, a.drop_self_base = ctx.drop[0], ctx.drop[1], plan.num_edges
             a.edge_pos_t = t2d.data_ptr()
-        L.check(lib.tfgx_gat_backward_dst_f32(ctypes.byref(a), L.stream_ptr()), "tfgx_gat_backward_dst_f32")
+        # power-law graphs: rows too long for one lane group are walked chunk-wise (the plans' hub lists) and their chunk
+        # partials added in order — dQ over the forward plan's hub destinations, dK / dV over the transposed plan's hub sources
+        hub_d, nc_d = L.hub_lists(plan)
+        sc_d = torch.empty(max(nc_d * A, 1), dtype=torch.float32, device=dev) if hub_d is not None else None
+        L.check(lib.tfgx_gat_backward_dst_hub_f32(ctypes.byref(a), None if hub_d is None else ctypes.byref(hub_d),
+                                                  L.ptr(sc_d), L.stream_ptr()), "tfgx_gat_backward_dst_hub_f32")
         a.grad_out, a.ld_grad_out = pack.data_ptr(), P
         a.q, a.ldq = pack.data_ptr() + 4 * W, P
         a.stats_ml, a.ld_stats_ml = pack.data_ptr() + 4 * (W + A), P
         a.dsum, a.ld_dsum = pack.data_ptr() + 4 * (W + A + 2 * H), P
-        L.check(lib.tfgx_gat_backward_src_f32(ctypes.byref(a), L.stream_ptr()), "tfgx_gat_backward_src_f32")
+        hub_s, nc_s = L.hub_lists(pt)
+        sc_s = torch.empty(max(nc_s * (A + W), 1), dtype=torch.float32, device=dev) if hub_s is not None else None
+        L.check(lib.tfgx_gat_backward_src_hub_f32(ctypes.byref(a), None if hub_s is None else ctypes.byref(hub_s),
+                                                  L.ptr(sc_s), L.stream_ptr()), "tfgx_gat_backward_src_hub_f32")
         return None, None, gq, gk, gv, None, None, None
 
 

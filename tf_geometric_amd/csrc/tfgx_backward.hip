@@ -184,8 +184,46 @@ __global__ __launch_bounds__(kBlock) void max_backward_kernel(const int32_t* __r
 
 // fast variants of the two kernels above: a lane group per row, 4 columns per lane (rows 16-byte aligned, F % 4 == 0)
 // MODE 0: count[r, :] = #ties;  MODE 1 (transposed plan): gx[c, :] = sum [tie] * w * gn[dst, :], gn = g / count
+// Long rows ("hubs" of a power-law graph) must not be walked by one lane group: the launches below take VIRTUAL rows —
+// part p spans CSR positions [rb[p], re[p]) of row part_row[p] (NULL: p itself) and writes its (partial) sums to row p of
+// `res`; parts longer than `skip` (> 0) are left out.  A hub-aware caller runs the plan's rows with skip = threshold,
+// then the hub rows' chunks into a scratch, then hub_sum_finalize_kernel adds a row's chunk partials in chunk order
+// (deterministic) — the backward twin of the forward's chunked hub path.
+struct HubLists {
+    int thr;
+    int64_t n_rows, n_chunks;
+    const int32_t *rows, *chunk_ptr, *chunk_begin, *chunk_end, *chunk_row;
+};
+
+__global__ __launch_bounds__(kBlock) void hub_sum_finalize_kernel(const float* __restrict__ scratch, int64_t lds,
+                                                                  const int32_t* __restrict__ chunk_ptr,
+                                                                  const int32_t* __restrict__ hub_rows, int64_t n_hub_rows,
+                                                                  int F, float* __restrict__ out, int64_t ldo)
+{
+    int64_t t = blockIdx.x * int64_t(kBlock) + threadIdx.x;
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    for (; t < n_hub_rows * F; t += stride) {
+        const int64_t i = t / F;
+        const int j = int(t - i * F);
+        float acc = 0.0f;
+        for (int c = chunk_ptr[i]; c < chunk_ptr[i + 1]; ++c) acc += scratch[int64_t(c) * lds + j];
+        out[int64_t(hub_rows[i]) * ldo + j] = acc;
+    }
+}
+
+inline bool fill_hub(const tfgx_hub_lists* h, HubLists& o)
+{
+    if (h == nullptr || h->threshold <= 0 || h->n_rows <= 0 || h->n_chunks <= 0) return false;
+    o.thr = h->threshold; o.n_rows = h->n_rows; o.n_chunks = h->n_chunks;
+    o.rows = h->rows; o.chunk_ptr = h->chunk_ptr; o.chunk_begin = h->chunk_begin; o.chunk_end = h->chunk_end;
+    o.chunk_row = h->chunk_row;
+    return o.rows && o.chunk_ptr && o.chunk_begin && o.chunk_end && o.chunk_row;
+}
+
 template <int G, int MODE>
-__global__ __launch_bounds__(kBlock) void max_grad_fast_kernel(const int32_t* __restrict__ row_ptr,
+__global__ __launch_bounds__(kBlock) void max_grad_fast_kernel(const int32_t* __restrict__ rb,
+                                                               const int32_t* __restrict__ re,
+                                                               const int32_t* __restrict__ part_row, int skip,
                                                                const int32_t* __restrict__ other,
                                                                const float* __restrict__ w, int64_t n,
                                                                const float* __restrict__ x, int64_t ldx, int F,
@@ -204,8 +242,10 @@ __global__ __launch_bounds__(kBlock) void max_grad_fast_kernel(const int32_t* __
     const int c_raw = (blockIdx.y * G + lane) * VEC;
     const bool cvalid = c_raw < F;
     const int coff = cvalid ? c_raw : (F - VEC);
-    for (int64_t row = int64_t(blockIdx.x) * ROWS_PER_BLOCK + grp; row < n; row += int64_t(gridDim.x) * ROWS_PER_BLOCK) {
-        const int s = row_ptr[row], e = row_ptr[row + 1];
+    for (int64_t part = int64_t(blockIdx.x) * ROWS_PER_BLOCK + grp; part < n; part += int64_t(gridDim.x) * ROWS_PER_BLOCK) {
+        const int s = rb[part], e = re[part];
+        if (skip > 0 && e - s > skip) continue;                  // a hub row: its chunks are launched separately
+        const int64_t row = part_row ? int64_t(part_row[part]) : part;
         float mine[VEC], acc[VEC];
         int apos[VEC];            // MODE 2: CSR position of the FIRST edge attaining the running maximum (-1: empty row)
 #pragma unroll
@@ -252,27 +292,28 @@ __global__ __launch_bounds__(kBlock) void max_grad_fast_kernel(const int32_t* __
             }
         }
         if (cvalid) {
-            store_vec<VEC>(res + row * ldr + coff, acc);
-            if (MODE == 2) store_vec<VEC>(out_w + row * ldo + coff, mine);
+            store_vec<VEC>(res + part * ldr + coff, acc);
+            if (MODE == 2) store_vec<VEC>(out_w + part * ldo + coff, mine);
             if (MODE == 2 && argpos != nullptr) {
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) argpos[row * lda + coff + i] = apos[i];
+                for (int i = 0; i < VEC; ++i) argpos[part * lda + coff + i] = apos[i];
             }
         }
     }
 }
 
 template <int MODE>
-int launch_max_grad(const int32_t* row_ptr, const int32_t* other, const float* w, int64_t n, const float* x,
-                    int64_t ldx, int F, const float* out, int64_t ldo, const float* gn, int64_t ldg, float* res,
-                    int64_t ldr, hipStream_t stream, float* out_w = nullptr, int32_t* argpos = nullptr, int64_t lda = 0)
+int launch_max_grad_parts(const int32_t* rb, const int32_t* re, const int32_t* part_row, int skip, const int32_t* other,
+                          const float* w, int64_t n, const float* x, int64_t ldx, int F, const float* out, int64_t ldo,
+                          const float* gn, int64_t ldg, float* res, int64_t ldr, hipStream_t stream,
+                          float* out_w = nullptr, int32_t* argpos = nullptr, int64_t lda = 0)
 {
     const int lanes = (F + 3) / 4;
 #define TFGX_MG(GG)                                                                                            \
     {                                                                                                          \
         dim3 grid(grid_for(n, kBlock / GG, 1 << 20), (lanes + GG - 1) / GG, 1);                                \
-        max_grad_fast_kernel<GG, MODE><<<grid, kBlock, 0, stream>>>(row_ptr, other, w, n, x, ldx, F, out, ldo, \
-                                                                      gn, ldg, res, ldr, out_w, argpos, lda); \
+        max_grad_fast_kernel<GG, MODE><<<grid, kBlock, 0, stream>>>(rb, re, part_row, skip, other, w, n, x, ldx, F, out,  \
+                                                                      ldo, gn, ldg, res, ldr, out_w, argpos, lda);     \
     }
     if (lanes <= 8) TFGX_MG(8)
     else if (lanes <= 16) TFGX_MG(16)
@@ -280,6 +321,26 @@ int launch_max_grad(const int32_t* row_ptr, const int32_t* other, const float* w
     else TFGX_MG(64)
 #undef TFGX_MG
     TFGX_LAUNCH_CHECK("max_grad_fast_kernel");
+    return TFGX_OK;
+}
+
+// rows of a plan; with hub lists: rows up to the threshold, then the hub rows' chunks + the ordered sum of their partials
+template <int MODE>
+int launch_max_grad(const int32_t* row_ptr, const int32_t* other, const float* w, int64_t n, const float* x,
+                    int64_t ldx, int F, const float* out, int64_t ldo, const float* gn, int64_t ldg, float* res,
+                    int64_t ldr, hipStream_t stream, float* out_w = nullptr, int32_t* argpos = nullptr, int64_t lda = 0,
+                    const HubLists* hub = nullptr, float* scratch = nullptr)
+{
+    const bool chunked = hub != nullptr && scratch != nullptr && MODE != 2;
+    int rc = launch_max_grad_parts<MODE>(row_ptr, row_ptr + 1, nullptr, chunked ? hub->thr : 0, other, w, n, x, ldx, F, out,
+                                         ldo, gn, ldg, res, ldr, stream, out_w, argpos, lda);
+    if (rc != TFGX_OK || !chunked) return rc;
+    rc = launch_max_grad_parts<MODE>(hub->chunk_begin, hub->chunk_end, hub->chunk_row, 0, other, w, hub->n_chunks, x, ldx, F,
+                                     out, ldo, gn, ldg, scratch, F, stream);
+    if (rc != TFGX_OK) return rc;
+    hub_sum_finalize_kernel<<<grid_for(hub->n_rows * F, kBlock), kBlock, 0, stream>>>(scratch, F, hub->chunk_ptr, hub->rows,
+                                                                                     hub->n_rows, F, res, ldr);
+    TFGX_LAUNCH_CHECK("hub_sum_finalize_kernel");
     return TFGX_OK;
 }
 
@@ -530,7 +591,11 @@ __global__ void divide_kernel(const float* __restrict__ g, int64_t ldg, const fl
 struct GB {
     const int32_t* row_ptr;   // forward plan (by destination) or transposed plan (by source)
     const int32_t* other;     // col (sources) for the dst pass; destinations for the src pass
-    int64_t n;                // rows of this pass
+    int64_t n;                // rows (or parts) of this launch
+    const int32_t* row_begin; // part p spans [row_begin[p], row_end[p]) of row part_row[p] (NULL: p); plain launch: row_ptr, row_ptr+1
+    const int32_t* row_end;
+    const int32_t* part_row;
+    int32_t skip;             // > 0: parts longer than this are left to the chunk launch (hub rows)
     int64_t n_self;           // rows [0, n_self) of this pass own the appended self-loop (src pass of a rectangular
                               // operator: only sources that are also destinations, i.e. a shard's own rows)
     const float* q; int64_t ldq;
@@ -747,8 +812,10 @@ __global__ __launch_bounds__(kBlock) void gat_backward_fast_kernel(const GB a)
     const int lh = (a.H == 1) ? G : a.dv / VEC;
     const bool head_first = cvalid && (coff % a.dv == 0);
 
-    for (int64_t row = int64_t(blockIdx.x) * ROWS_PER_BLOCK + grp; row < a.n; row += int64_t(gridDim.x) * ROWS_PER_BLOCK) {
-        const int s0 = a.row_ptr[row], e0 = a.row_ptr[row + 1];
+    for (int64_t part = int64_t(blockIdx.x) * ROWS_PER_BLOCK + grp; part < a.n; part += int64_t(gridDim.x) * ROWS_PER_BLOCK) {
+        const int s0 = a.row_begin[part], e0 = a.row_end[part];
+        if (a.skip > 0 && e0 - s0 > a.skip) continue;             // a hub row: walked chunk-wise by a second launch
+        const int64_t row = a.part_row ? int64_t(a.part_row[part]) : part;
         // "mine": the row this group owns (destination r for the dst pass, source c for the src pass)
         float mine_qk[D];     // dst pass: Q[r,h,:]   src pass: K[c,h,:]
         float mine_v[VEC];    // dst pass: dO[r,cols] src pass: V[c,cols]
@@ -829,12 +896,14 @@ __global__ __launch_bounds__(kBlock) void gat_backward_fast_kernel(const GB a)
             for (; j < cnt; ++j)
                 edge(int64_t(__shfl(oj, j, G)), drop_scale(a.drop, uint32_t(int64_t(__shfl(pj, j, G)) * a.H + head)));
         }
-        if (a.add_self_loop && row < a.n_self) edge(row, drop_scale(a.drop, uint32_t((a.drop.self_base + row) * a.H + head)));
+        // the appended self-loop belongs to the row's LAST part (chunk launches: the chunk that ends where the row ends)
+        if (a.add_self_loop && row < a.n_self && (a.part_row == nullptr || e0 == a.row_ptr[row + 1]))
+            edge(row, drop_scale(a.drop, uint32_t((a.drop.self_base + row) * a.H + head)));
         if (SRC) {
-            if (cvalid) store_vec<VEC>(a.gv + row * a.ldgv + coff, acc_v);
+            if (cvalid) store_vec<VEC>(a.gv + part * a.ldgv + coff, acc_v);
         }
         if (head_first) {
-            float* dst = (SRC ? a.gk + row * a.ldgk : a.gq + row * a.ldgq) + head * a.d;
+            float* dst = (SRC ? a.gk + part * a.ldgk : a.gq + part * a.ldgq) + head * a.d;
 #pragma unroll
             for (int t = 0; t < D; ++t) dst[t] = acc_qk[t];
         }
@@ -948,14 +1017,24 @@ extern "C" int tfgx_segment_max_count_f32(const int32_t* row_ptr, const int32_t*
                                           const float* x, int64_t ldx, int64_t F, const float* out, int64_t ldo,
                                           float* count, int64_t ldc, tfgx_stream_t stream)
 {
+    return tfgx_segment_max_count_hub_f32(row_ptr, col, w, n_dst, x, ldx, F, out, ldo, count, ldc, nullptr, nullptr, stream);
+}
+
+extern "C" int tfgx_segment_max_count_hub_f32(const int32_t* row_ptr, const int32_t* col, const float* w, int64_t n_dst,
+                                              const float* x, int64_t ldx, int64_t F, const float* out, int64_t ldo,
+                                              float* count, int64_t ldc, const tfgx_hub_lists* hub, float* hub_scratch,
+                                              tfgx_stream_t stream)
+{
     TFGX_RANGE();
+    HubLists hl;
+    const bool chunked = fill_hub(hub, hl) && hub_scratch != nullptr;
     TFGX_REQUIRE(n_dst >= 0 && F >= 1 && ldx >= F && ldo >= F && ldc >= F, "bad size");
     if (n_dst == 0) return TFGX_OK;
     TFGX_REQUIRE(row_ptr && x && out && count, "null pointer");
     if (F % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && ldc % 4 == 0 && aligned_to(x, 16) && aligned_to(out, 16) &&
         aligned_to(count, 16))
         return launch_max_grad<0>(row_ptr, col, w, n_dst, x, ldx, int(F), out, ldo, nullptr, 0, count, ldc,
-                                  as_stream(stream));
+                                  as_stream(stream), nullptr, nullptr, 0, chunked ? &hl : nullptr, hub_scratch);
     max_count_kernel<<<grid_for(n_dst * F, kBlock), kBlock, 0, as_stream(stream)>>>(row_ptr, col, w, n_dst, x, ldx,
                                                                                    int(F), out, ldo, count, ldc);
     TFGX_LAUNCH_CHECK("max_count_kernel");
@@ -1098,7 +1177,19 @@ extern "C" int tfgx_segment_max_backward_f32(const int32_t* row_ptr_t, const int
                                              float* gx, int64_t ldgx, int64_t n_dst, float* gn_scratch,
                                              tfgx_stream_t stream)
 {
+    return tfgx_segment_max_backward_hub_f32(row_ptr_t, dst_t, w_t, n_src, x, ldx, F, out, ldo, g, ldg, count, ldc, gx, ldgx,
+                                             n_dst, gn_scratch, nullptr, nullptr, stream);
+}
+
+extern "C" int tfgx_segment_max_backward_hub_f32(const int32_t* row_ptr_t, const int32_t* dst_t, const float* w_t,
+                                                 int64_t n_src, const float* x, int64_t ldx, int64_t F, const float* out,
+                                                 int64_t ldo, const float* g, int64_t ldg, const float* count,
+                                                 int64_t ldc, float* gx, int64_t ldgx, int64_t n_dst, float* gn_scratch,
+                                                 const tfgx_hub_lists* hub_t, float* hub_scratch, tfgx_stream_t stream)
+{
     TFGX_RANGE();
+    HubLists hl;
+    const bool chunked = fill_hub(hub_t, hl) && hub_scratch != nullptr;
     TFGX_REQUIRE(n_src >= 0 && F >= 1 && ldx >= F && ldo >= F && ldg >= F && ldc >= F && ldgx >= F, "bad size");
     if (n_src == 0) return TFGX_OK;
     TFGX_REQUIRE(row_ptr_t && x && out && g && count && gx, "null pointer");
@@ -1109,7 +1200,7 @@ extern "C" int tfgx_segment_max_backward_f32(const int32_t* row_ptr_t, const int
                                                                                    gn_scratch);
         TFGX_LAUNCH_CHECK("divide_kernel");
         return launch_max_grad<1>(row_ptr_t, dst_t, w_t, n_src, x, ldx, int(F), out, ldo, gn_scratch, F, gx, ldgx,
-                                  as_stream(stream));
+                                  as_stream(stream), nullptr, nullptr, 0, chunked ? &hl : nullptr, hub_scratch);
     }
     max_backward_kernel<<<grid_for(n_src * F, kBlock), kBlock, 0, as_stream(stream)>>>(
         row_ptr_t, dst_t, w_t, n_src, x, ldx, int(F), out, ldo, g, ldg, count, ldc, gx, ldgx);
@@ -1164,7 +1255,52 @@ extern "C" int tfgx_gat_pack_dst_f32(const float* grad_out, int64_t ld_grad_out,
     return TFGX_OK;
 }
 
+// one pass of the GAT backward over a plan's rows; with hub lists (fast kernels only): rows up to the threshold, then the
+// hub rows' chunks into the scratch ([n_chunks, H*d] for the dst pass, [n_chunks, H*d + H*dv] for the src pass), then
+// the ordered sum of every hub row's chunk partials
+template <bool SRC>
+static int gat_backward_pass(const tfgx_gat_backward_args* p, GB& a, const tfgx_hub_lists* hub, float* scratch,
+                             hipStream_t stream)
+{
+    a.row_begin = a.row_ptr; a.row_end = a.row_ptr + 1; a.part_row = nullptr; a.skip = 0;
+    if (!gat_bwd_fast_ok(p)) {
+        if (SRC) gat_backward_src_kernel<<<grid_for(a.n * a.H, kBlock), kBlock, 0, stream>>>(a);
+        else gat_backward_dst_kernel<<<grid_for(a.n * a.H, kBlock), kBlock, 0, stream>>>(a);
+        TFGX_LAUNCH_CHECK("gat_backward_{dst,src}_kernel");
+        return TFGX_OK;
+    }
+    HubLists hl;
+    const bool chunked = fill_hub(hub, hl) && scratch != nullptr;
+    if (chunked) a.skip = hl.thr;
+    int rc = launch_gat_bwd<SRC>(a, stream);
+    if (rc != TFGX_OK || !chunked) return rc;
+    const int A = a.H * a.d, W = a.H * a.dv;
+    GB c = a;
+    c.n = hl.n_chunks; c.row_begin = hl.chunk_begin; c.row_end = hl.chunk_end; c.part_row = hl.chunk_row; c.skip = 0;
+    float* sq = scratch;                                   // [n_chunks, A]: dQ (dst pass) / dK (src pass) partials
+    float* sv = scratch + size_t(hl.n_chunks) * size_t(A); // [n_chunks, W]: dV partials (src pass)
+    if (SRC) { c.gk = sq; c.ldgk = A; c.gv = sv; c.ldgv = W; }
+    else { c.gq = sq; c.ldgq = A; }
+    rc = launch_gat_bwd<SRC>(c, stream);
+    if (rc != TFGX_OK) return rc;
+    hub_sum_finalize_kernel<<<grid_for(hl.n_rows * A, kBlock), kBlock, 0, stream>>>(sq, A, hl.chunk_ptr, hl.rows, hl.n_rows, A,
+                                                                                  SRC ? a.gk : a.gq, SRC ? a.ldgk : a.ldgq);
+    TFGX_LAUNCH_CHECK("hub_sum_finalize_kernel");
+    if (SRC) {
+        hub_sum_finalize_kernel<<<grid_for(hl.n_rows * W, kBlock), kBlock, 0, stream>>>(sv, W, hl.chunk_ptr, hl.rows, hl.n_rows,
+                                                                                      W, a.gv, a.ldgv);
+        TFGX_LAUNCH_CHECK("hub_sum_finalize_kernel");
+    }
+    return TFGX_OK;
+}
+
 extern "C" int tfgx_gat_backward_dst_f32(const tfgx_gat_backward_args* p, tfgx_stream_t stream)
+{
+    return tfgx_gat_backward_dst_hub_f32(p, nullptr, nullptr, stream);
+}
+
+extern "C" int tfgx_gat_backward_dst_hub_f32(const tfgx_gat_backward_args* p, const tfgx_hub_lists* hub, float* hub_scratch,
+                                             tfgx_stream_t stream)
 {
     TFGX_RANGE();
     GB a;
@@ -1173,13 +1309,16 @@ extern "C" int tfgx_gat_backward_dst_f32(const tfgx_gat_backward_args* p, tfgx_s
     TFGX_REQUIRE(p->row_ptr && p->grad_q && p->n_dst >= 0, "dst pass needs row_ptr / grad_q");
     if (p->n_dst == 0) return TFGX_OK;
     a.row_ptr = p->row_ptr; a.other = p->col; a.n = p->n_dst; a.n_self = p->n_dst;
-    if (gat_bwd_fast_ok(p)) return launch_gat_bwd<false>(a, as_stream(stream));
-    gat_backward_dst_kernel<<<grid_for(a.n * a.H, kBlock), kBlock, 0, as_stream(stream)>>>(a);
-    TFGX_LAUNCH_CHECK("gat_backward_dst_kernel");
-    return TFGX_OK;
+    return gat_backward_pass<false>(p, a, hub, hub_scratch, as_stream(stream));
 }
 
 extern "C" int tfgx_gat_backward_src_f32(const tfgx_gat_backward_args* p, tfgx_stream_t stream)
+{
+    return tfgx_gat_backward_src_hub_f32(p, nullptr, nullptr, stream);
+}
+
+extern "C" int tfgx_gat_backward_src_hub_f32(const tfgx_gat_backward_args* p, const tfgx_hub_lists* hub_t, float* hub_scratch,
+                                             tfgx_stream_t stream)
 {
     TFGX_RANGE();
     GB a;
@@ -1191,8 +1330,5 @@ extern "C" int tfgx_gat_backward_src_f32(const tfgx_gat_backward_args* p, tfgx_s
     a.n_self = p->n_src < p->n_dst ? p->n_src : p->n_dst;   // source c has a self-loop only if it is destination c too
     TFGX_REQUIRE(p->drop_rate == 0.0f || p->edge_pos_t, "the src pass needs edge_pos_t to regenerate the dropout mask");
     a.pos = p->drop_rate > 0.0f ? p->edge_pos_t : nullptr;
-    if (gat_bwd_fast_ok(p)) return launch_gat_bwd<true>(a, as_stream(stream));
-    gat_backward_src_kernel<<<grid_for(a.n * a.H, kBlock), kBlock, 0, as_stream(stream)>>>(a);
-    TFGX_LAUNCH_CHECK("gat_backward_src_kernel");
-    return TFGX_OK;
+    return gat_backward_pass<true>(p, a, hub_t, hub_scratch, as_stream(stream));
 }
