@@ -366,6 +366,13 @@ int tfgx_gat_backward_dst_f32(const tfgx_gat_backward_args* args /* host */, tfg
 int tfgx_gat_backward_src_f32(const tfgx_gat_backward_args* args /* host */, tfgx_stream_t stream);
 /* the same passes on a graph with hub rows: `hub` = chunk lists of the forward plan (dst pass) / of the transposed plan
    (src pass); hub_scratch: n_chunks * H*d floats (dst) / n_chunks * (H*d + H*dv) floats (src).  NULL lists = plain pass. */
+/* tfgx_edge_softmax_f32 with hub rows handled chunk-wise (per-chunk statistics, ordered fold per row, per-chunk
+   normalisation); hub_scratch: n_chunks * 2 * Hp floats, Hp = H rounded up to a power of two */
+int tfgx_edge_softmax_hub_f32(const int32_t* row_ptr, const int32_t* perm, const float* score, int64_t H, int64_t n_dst,
+                              float* out, const tfgx_hub_lists* hub, float* hub_scratch, tfgx_stream_t stream);
+/* tfgx_sddmm_f32 with hub rows walked chunk-wise (every edge owns its output element: no scratch) */
+int tfgx_sddmm_hub_f32(const int32_t* row_ptr, const int32_t* col, int64_t n_dst, const float* a, int64_t lda,
+                       const float* b, int64_t ldb, int64_t F, float* out, const tfgx_hub_lists* hub, tfgx_stream_t stream);
 int tfgx_gat_backward_dst_hub_f32(const tfgx_gat_backward_args* args, const tfgx_hub_lists* hub, float* hub_scratch,
                                   tfgx_stream_t stream);
 int tfgx_gat_backward_src_hub_f32(const tfgx_gat_backward_args* args, const tfgx_hub_lists* hub_t, float* hub_scratch,

@@ -502,6 +502,22 @@ def test_sampler_fresh_seed_and_hub_rows(tfg):
     assert (np.diff(hub_w) > 0).all()                                 # neighbour order kept
     first_half = float((hub_w < np.median(w[ei[0] == 7])).mean())     # uniform over the row, not front-loaded
     assert 0.42 < first_half < 0.58
+    # wave-per-row path (rows with more than 64 neighbours): every neighbour is included with probability m / d — also
+    # when the 64 strata are small (d = 100 .. 3000, m = 40 .. 80 % of d), where a fixed per-stratum quota would make
+    # some positions certain and others impossible
+    for d_row, ratio in ((100, 0.5), (257, 0.4), (3000, 0.8)):
+        e2 = np.stack([np.zeros(d_row, np.int32), np.arange(d_row, dtype=np.int32) % n])
+        s2 = tfg.utils.RandomNeighborSampler(e2, np.arange(d_row, dtype=np.float32))
+        m_row = int(np.ceil(d_row * ratio))
+        freq = np.zeros(d_row)
+        trials = 300
+        for seed in range(trials):
+            ee, ww = s2.sample(ratio=ratio, seed=1000 + seed)
+            assert ww.size == m_row and len(set(ww.tolist())) == m_row and (np.diff(ww) > 0).all()
+            freq[ww.astype(np.int64)] += 1
+        p = m_row / d_row
+        sigma = np.sqrt(p * (1 - p) / trials)
+        assert np.abs(freq / trials - p).max() < 5.5 * sigma + 1e-9, (d_row, ratio, np.abs(freq / trials - p).max(), sigma)
     a, _ = s.sample(k=3)
     b, _ = s.sample(k=3)
     assert not np.array_equal(a, b)
@@ -510,3 +526,26 @@ def test_sampler_fresh_seed_and_hub_rows(tfg):
     torch.manual_seed(11)
     d, _ = s.sample(k=3)
     assert np.array_equal(c, d)
+
+
+@pytest.mark.parametrize("heads", [1, 3, 8])
+def test_segment_softmax_hub_rows(tfg, oracle, heads):
+    """Standalone segment softmax on a graph with a 9000-edge segment: cooperative lanes for ordinary rows, the chunked
+    path (per-chunk statistics, ordered fold, per-chunk normalisation) for hub rows — with the plan's own policy (the
+    workgroup-per-row kernel when the plan declares no hub) and with a forced low threshold — equals the oracle."""
+    import tf_geometric_amd.plan as P
+    rng = np.random.Generator(np.random.PCG64(5 + heads))
+    n = 300
+    ids = np.concatenate([np.full(9000, 4, np.int32), rng.integers(0, n, 5000).astype(np.int32),
+                          np.full(1500, 250, np.int32)])
+    ids = ids[rng.permutation(ids.size)]
+    data = (rng.standard_normal((ids.size, heads)) * 3).astype(np.float32)
+    ref = np.stack([oracle.segment_softmax(data[:, h], ids, n) for h in range(heads)], axis=1)
+    old = (P.HUB_THRESHOLD, P.HUB_CHUNK)
+    try:
+        for thr in (None, 128):
+            P.HUB_THRESHOLD, P.HUB_CHUNK = thr, (None if thr is None else 96)
+            got = tfg.nn.segment_softmax(data if heads > 1 else data[:, 0], ids, n).cpu().numpy().reshape(ids.size, heads)
+            assert_parity(got, ref, tol=2e-6, what="segment_softmax hub thr={}".format(thr))
+    finally:
+        P.HUB_THRESHOLD, P.HUB_CHUNK = old

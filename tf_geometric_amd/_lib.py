@@ -74,6 +74,20 @@ class HubLists(ctypes.Structure):
                 ("chunk_begin", ctypes.c_void_p), ("chunk_end", ctypes.c_void_p), ("chunk_row", ctypes.c_void_p)]
 
 
+def edge_softmax(plan, score, H, out):
+    """tfgx_edge_softmax_hub_f32 on `plan` (hub rows chunk-wise when the plan has any)."""
+    lib = require_gpu()
+    hub, nc = hub_lists(plan)
+    hp = 1
+    while hp < H:
+        hp <<= 1
+    scratch = torch.empty(max(nc * 2 * hp, 1), dtype=torch.float32, device=out.device) if hub is not None else None
+    check(lib.tfgx_edge_softmax_hub_f32(ptr(plan.row_ptr), ptr(plan.perm), ptr(score), H, plan.n_dst, ptr(out),
+                                        None if hub is None else ctypes.byref(hub), ptr(scratch), stream_ptr()),
+          "tfgx_edge_softmax_hub_f32")
+    return out
+
+
 def hub_lists(plan):
     """(HubLists struct, n_chunks) of a plan's long rows, or (None, 0) when the plan has none (plan.hub_info())."""
     info = plan.hub_info()
@@ -152,6 +166,8 @@ SIGNATURES = {
                                                      _P, _I64, _I64, _P, _P]),
     "tfgx_gat_backward_dst_f32": (ctypes.c_int, [ctypes.POINTER(GatBackwardArgs), _P]),
     "tfgx_gat_backward_src_f32": (ctypes.c_int, [ctypes.POINTER(GatBackwardArgs), _P]),
+    "tfgx_edge_softmax_hub_f32": (ctypes.c_int, [_P, _P, _P, _I64, _I64, _P, ctypes.POINTER(HubLists), _P, _P]),
+    "tfgx_sddmm_hub_f32": (ctypes.c_int, [_P, _P, _I64, _P, _I64, _P, _I64, _I64, _P, ctypes.POINTER(HubLists), _P]),
     "tfgx_gat_backward_dst_hub_f32": (ctypes.c_int, [ctypes.POINTER(GatBackwardArgs), ctypes.POINTER(HubLists), _P, _P]),
     "tfgx_gat_backward_src_hub_f32": (ctypes.c_int, [ctypes.POINTER(GatBackwardArgs), ctypes.POINTER(HubLists), _P, _P]),
     "tfgx_segment_max_count_hub_f32": (ctypes.c_int, [_P, _P, _P, _I64, _P, _I64, _I64, _P, _I64, _P, _I64,

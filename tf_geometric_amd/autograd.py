@@ -138,8 +138,10 @@ class _Aggregate(torch.autograd.Function):
             gw = torch.empty_like(w_csr)
             g2, ldg = L.row_major_2d(g)
             x2, ldx = L.row_major_2d(x.detach())
-            L.check(lib.tfgx_sddmm_f32(L.ptr(plan.row_ptr), L.ptr(plan.col), plan.n_dst, L.ptr(g2), ldg, L.ptr(x2), ldx,
-                                       int(x2.shape[1]), L.ptr(gw), L.stream_ptr()), "tfgx_sddmm_f32")
+            hub_w, _ = L.hub_lists(plan)           # hub destinations: their edges are walked chunk-wise
+            L.check(lib.tfgx_sddmm_hub_f32(L.ptr(plan.row_ptr), L.ptr(plan.col), plan.n_dst, L.ptr(g2), ldg, L.ptr(x2), ldx,
+                                           int(x2.shape[1]), L.ptr(gw), None if hub_w is None else ctypes.byref(hub_w),
+                                           L.stream_ptr()), "tfgx_sddmm_hub_f32")
         if self_coef is not None and ctx.needs_input_grad[4]:
             gs = (x.detach() * g).sum(1)
         return None, None, gx, gw, gs, None, gb, None
@@ -503,8 +505,7 @@ class _SegmentSoftmax(torch.autograd.Function):
         out = torch.empty_like(dd)
         H = 1 if dd.dim() == 1 else int(dd.shape[1])
         if int(ids.shape[0]):
-            L.check(lib.tfgx_edge_softmax_f32(L.ptr(plan.row_ptr), L.ptr(plan.perm), L.ptr(dd), H, plan.n_dst,
-                                              L.ptr(out), L.stream_ptr()), "tfgx_edge_softmax_f32")
+            L.edge_softmax(plan, dd, H, out)
         ctx.plan, ctx.ids = plan, ids
         ctx.save_for_backward(out)
         return out

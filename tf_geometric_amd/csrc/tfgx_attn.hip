@@ -20,10 +20,11 @@ namespace tfgx {
 namespace {
 
 // ---------------------------------------------------------------- edge softmax (standalone)
-__global__ __launch_bounds__(kBlock) void edge_softmax_kernel(const int32_t* __restrict__ row_ptr,
-                                                              const int32_t* __restrict__ perm,
-                                                              const float* __restrict__ score, int H, int64_t n_dst,
-                                                              float* __restrict__ out)
+// one thread per (row, head): any H; rows are walked serially (kept for H > 64)
+__global__ __launch_bounds__(kBlock) void edge_softmax_serial_kernel(const int32_t* __restrict__ row_ptr,
+                                                                     const int32_t* __restrict__ perm,
+                                                                     const float* __restrict__ score, int H,
+                                                                     int64_t n_dst, float* __restrict__ out)
 {
     int64_t t = blockIdx.x * int64_t(kBlock) + threadIdx.x;
     const int64_t stride = int64_t(gridDim.x) * kBlock;
@@ -33,19 +34,152 @@ __global__ __launch_bounds__(kBlock) void edge_softmax_kernel(const int32_t* __r
         const int h = int(t - r * H);
         const int s = row_ptr[r], e = row_ptr[r + 1];
         float m = -FLT_MAX;
-        for (int i = s; i < e; ++i) {
-            const int64_t eid = perm ? perm[i] : i;
-            m = fmaxf(m, score[eid * H + h]);
-        }
+        for (int i = s; i < e; ++i) m = fmaxf(m, score[int64_t(perm ? perm[i] : i) * H + h]);
         float d = 0.0f;
-        for (int i = s; i < e; ++i) {
-            const int64_t eid = perm ? perm[i] : i;
-            d += expf(score[eid * H + h] - m);
-        }
+        for (int i = s; i < e; ++i) d += expf(score[int64_t(perm ? perm[i] : i) * H + h] - m);
         d += 1e-8f;
         for (int i = s; i < e; ++i) {
             const int64_t eid = perm ? perm[i] : i;
             out[eid * H + h] = expf(score[eid * H + h] - m) / d;
+        }
+    }
+}
+
+// A group of G lanes per destination row, arranged as (G / Hp edge slots) x (Hp = next power of two >= H heads): adjacent
+// lanes read adjacent heads of one edge (coalesced), the slots stride over the row's edges, per-head reductions are
+// butterflies across the slots.  Short rows run with the smallest G that holds Hp (H = 8: exactly the one-thread-per-
+// (row, head) mapping); rows longer than kSoftmaxWide edges (hubs of a power-law graph) are left to a second launch with
+// a whole wave per row — R-MAT, 30 M edges, H = 8: 340 ms (serial rows) -> see profiles/r02_skew_cliff_scan.jsonl.
+constexpr int kSoftmaxWide = 1024;
+
+template <int G>
+__device__ __forceinline__ float softmax_group_reduce(float v, int Hp, bool is_max, float* lds)
+{
+    constexpr int W = G < 64 ? G : 64;
+    for (int o = W / 2; o >= Hp; o >>= 1) {
+        const float t = __shfl_xor(v, o, W);
+        v = is_max ? fmaxf(v, t) : v + t;
+    }
+    if constexpr (G > 64) {          // a whole workgroup per row: combine the waves' per-head values through LDS
+        const int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
+        __syncthreads();
+        if (lane < Hp) lds[wave * 64 + lane] = v;
+        __syncthreads();
+        float acc = lds[lane % Hp];
+        for (int k = 1; k < G / 64; ++k) {
+            const float t = lds[k * 64 + lane % Hp];
+            acc = is_max ? fmaxf(acc, t) : acc + t;
+        }
+        v = acc;
+    }
+    return v;
+}
+
+template <int G, bool WIDE>
+__global__ __launch_bounds__(kBlock) void edge_softmax_kernel(const int32_t* __restrict__ row_ptr,
+                                                              const int32_t* __restrict__ perm,
+                                                              const float* __restrict__ score, int H, int Hp,
+                                                              int64_t n_dst, float* __restrict__ out, int wide_limit)
+{
+    constexpr int ROWS_PER_BLOCK = kBlock / G;
+    __shared__ float lds[G > 64 ? (G / 64) * 64 : 1];
+    const int lane = threadIdx.x % G, grp = threadIdx.x / G;
+    const int h = lane % Hp, slot = lane / Hp, slots = G / Hp;
+    const bool hv = h < H;
+    for (int64_t r = int64_t(blockIdx.x) * ROWS_PER_BLOCK + grp; r < n_dst; r += int64_t(gridDim.x) * ROWS_PER_BLOCK) {
+        const int s = row_ptr[r], e = row_ptr[r + 1];
+        if (WIDE != (e - s > wide_limit)) continue;              // (uniform over the group / workgroup: it owns ONE row)
+        float m = -FLT_MAX;
+        if (hv) {
+            int i = s + slot;
+            for (; i + 3 * slots < e; i += 4 * slots) {          // four independent index -> score chains in flight
+                const float a0 = score[int64_t(perm ? perm[i] : i) * H + h];
+                const float a1 = score[int64_t(perm ? perm[i + slots] : i + slots) * H + h];
+                const float a2 = score[int64_t(perm ? perm[i + 2 * slots] : i + 2 * slots) * H + h];
+                const float a3 = score[int64_t(perm ? perm[i + 3 * slots] : i + 3 * slots) * H + h];
+                m = fmaxf(fmaxf(m, fmaxf(a0, a1)), fmaxf(a2, a3));
+            }
+            for (; i < e; i += slots) m = fmaxf(m, score[int64_t(perm ? perm[i] : i) * H + h]);
+        }
+        m = softmax_group_reduce<G>(m, Hp, true, lds);
+        float d = 0.0f;
+        if (hv) {
+            int i = s + slot;
+            for (; i + 3 * slots < e; i += 4 * slots) {
+                const float a0 = score[int64_t(perm ? perm[i] : i) * H + h];
+                const float a1 = score[int64_t(perm ? perm[i + slots] : i + slots) * H + h];
+                const float a2 = score[int64_t(perm ? perm[i + 2 * slots] : i + 2 * slots) * H + h];
+                const float a3 = score[int64_t(perm ? perm[i + 3 * slots] : i + 3 * slots) * H + h];
+                d += (expf(a0 - m) + expf(a1 - m)) + (expf(a2 - m) + expf(a3 - m));
+            }
+            for (; i < e; i += slots) d += expf(score[int64_t(perm ? perm[i] : i) * H + h] - m);
+        }
+        d = softmax_group_reduce<G>(d, Hp, false, lds) + 1e-8f;
+        if (hv)
+            for (int i = s + slot; i < e; i += slots) {
+                const int64_t eid = perm ? perm[i] : i;
+                out[eid * H + h] = expf(score[eid * H + h] - m) / d;
+            }
+    }
+}
+
+// Hub rows with the plan's chunk lists (tfgx_edge_softmax_hub_f32): a wave per CHUNK instead of a workgroup per row —
+// (1) per-chunk (max, sum of exp) of every head, (2) per hub row: fold its chunks' pairs in chunk order into the row's
+// (M, D) and hand them back to every chunk, (3) per chunk: normalise.  A 10^5-edge hub becomes ~10^2 independent waves.
+template <int MODE>       // 0: chunk statistics -> ml[p, 0..Hp) = max, ml[p, Hp..2Hp) = sum;  1: normalise with ml[p]
+__global__ __launch_bounds__(kBlock) void edge_softmax_chunk_kernel(const int32_t* __restrict__ cb,
+                                                                    const int32_t* __restrict__ ce, int64_t n_chunks,
+                                                                    const int32_t* __restrict__ perm,
+                                                                    const float* __restrict__ score, int H, int Hp,
+                                                                    float* __restrict__ ml, float* __restrict__ out)
+{
+    constexpr int G = 64;
+    const int lane = threadIdx.x % G;
+    const int h = lane % Hp, slot = lane / Hp, slots = G / Hp;
+    const bool hv = h < H;
+    for (int64_t p = (blockIdx.x * int64_t(kBlock) + threadIdx.x) / G; p < n_chunks; p += int64_t(gridDim.x) * kBlock / G) {
+        const int s = cb[p], e = ce[p];
+        if (MODE == 0) {
+            float m = -FLT_MAX;
+            if (hv)
+                for (int i = s + slot; i < e; i += slots) m = fmaxf(m, score[int64_t(perm ? perm[i] : i) * H + h]);
+            for (int o = G / 2; o >= Hp; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, G));
+            float d = 0.0f;
+            if (hv)
+                for (int i = s + slot; i < e; i += slots) d += expf(score[int64_t(perm ? perm[i] : i) * H + h] - m);
+            for (int o = G / 2; o >= Hp; o >>= 1) d += __shfl_xor(d, o, G);
+            if (lane < Hp) {
+                ml[p * 2 * Hp + lane] = m;
+                ml[p * 2 * Hp + Hp + lane] = d;
+            }
+        } else {
+            const float m = ml[p * 2 * Hp + h], d = ml[p * 2 * Hp + Hp + h];
+            if (hv)
+                for (int i = s + slot; i < e; i += slots) {
+                    const int64_t eid = perm ? perm[i] : i;
+                    out[eid * H + h] = expf(score[eid * H + h] - m) / d;
+                }
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void edge_softmax_hub_combine_kernel(const int32_t* __restrict__ chunk_ptr,
+                                                                          int64_t n_hub_rows, int Hp,
+                                                                          float* __restrict__ ml)
+{
+    int64_t t = blockIdx.x * int64_t(kBlock) + threadIdx.x;
+    for (; t < n_hub_rows * Hp; t += int64_t(gridDim.x) * kBlock) {
+        const int64_t i = t / Hp;
+        const int h = int(t - i * Hp);
+        const int c0 = chunk_ptr[i], c1 = chunk_ptr[i + 1];
+        float M = -FLT_MAX;
+        for (int c = c0; c < c1; ++c) M = fmaxf(M, ml[int64_t(c) * 2 * Hp + h]);
+        float D = 0.0f;
+        for (int c = c0; c < c1; ++c) D += ml[int64_t(c) * 2 * Hp + Hp + h] * expf(ml[int64_t(c) * 2 * Hp + h] - M);
+        D += 1e-8f;                                                      // segment.py:30
+        for (int c = c0; c < c1; ++c) {
+            ml[int64_t(c) * 2 * Hp + h] = M;
+            ml[int64_t(c) * 2 * Hp + Hp + h] = D;
         }
     }
 }
@@ -339,12 +473,45 @@ using namespace tfgx;
 extern "C" int tfgx_edge_softmax_f32(const int32_t* row_ptr, const int32_t* perm, const float* score, int64_t H,
                                      int64_t n_dst, float* out, tfgx_stream_t stream)
 {
+    return tfgx_edge_softmax_hub_f32(row_ptr, perm, score, H, n_dst, out, nullptr, nullptr, stream);
+}
+
+extern "C" int tfgx_edge_softmax_hub_f32(const int32_t* row_ptr, const int32_t* perm, const float* score, int64_t H,
+                                         int64_t n_dst, float* out, const tfgx_hub_lists* hub, float* hub_scratch,
+                                         tfgx_stream_t stream)
+{
     TFGX_RANGE();
     TFGX_REQUIRE(H >= 1 && n_dst >= 0, "bad H / n_dst");
     if (n_dst == 0) return TFGX_OK;
     TFGX_REQUIRE(row_ptr != nullptr, "row_ptr is null");
-    edge_softmax_kernel<<<grid_for(n_dst * H, kBlock), kBlock, 0, as_stream(stream)>>>(row_ptr, perm, score,
-                                                                                      int(H), n_dst, out);
+    hipStream_t st = as_stream(stream);
+    if (H > 64) {
+        edge_softmax_serial_kernel<<<grid_for(n_dst * H, kBlock), kBlock, 0, st>>>(row_ptr, perm, score, int(H), n_dst, out);
+    } else {
+        int Hp = 1;
+        while (Hp < H) Hp <<= 1;
+        const bool chunked = hub != nullptr && hub_scratch != nullptr && hub->threshold > 0 && hub->n_rows > 0 &&
+                             hub->n_chunks > 0 && hub->chunk_ptr && hub->chunk_begin && hub->chunk_end;
+        const int limit = chunked ? hub->threshold : kSoftmaxWide;
+#define TFGX_SM(GG) edge_softmax_kernel<GG, false><<<grid_for(n_dst, kBlock / GG, 1 << 20), kBlock, 0, st>>>(row_ptr, perm, score, int(H), Hp, n_dst, out, limit)
+        if (Hp <= 8) TFGX_SM(8);
+        else if (Hp <= 16) TFGX_SM(16);
+        else if (Hp <= 32) TFGX_SM(32);
+        else TFGX_SM(64);
+#undef TFGX_SM
+        if (chunked) {       // hub_scratch: n_chunks * 2 * Hp floats
+            edge_softmax_chunk_kernel<0><<<grid_for(hub->n_chunks * 64, kBlock), kBlock, 0, st>>>(
+                hub->chunk_begin, hub->chunk_end, hub->n_chunks, perm, score, int(H), Hp, hub_scratch, out);
+            edge_softmax_hub_combine_kernel<<<grid_for(hub->n_rows * Hp, kBlock), kBlock, 0, st>>>(hub->chunk_ptr, hub->n_rows,
+                                                                                               Hp, hub_scratch);
+            edge_softmax_chunk_kernel<1><<<grid_for(hub->n_chunks * 64, kBlock), kBlock, 0, st>>>(
+                hub->chunk_begin, hub->chunk_end, hub->n_chunks, perm, score, int(H), Hp, hub_scratch, out);
+        } else {
+            // no chunk lists: long rows get a whole 256-thread workgroup each (a pass over row_ptr when there are none)
+            edge_softmax_kernel<kBlock, true><<<grid_for(n_dst, 1, 1 << 14), kBlock, 0, st>>>(row_ptr, perm, score, int(H), Hp,
+                                                                                             n_dst, out, limit);
+        }
+    }
     TFGX_LAUNCH_CHECK("edge_softmax_kernel");
     return TFGX_OK;
 }

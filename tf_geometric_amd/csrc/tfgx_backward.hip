@@ -25,7 +25,8 @@ namespace {
 
 // ---------------------------------------------------------------- SDDMM: out[i] = <a[r], b[col[i]]>
 template <int G>
-__global__ __launch_bounds__(kBlock) void sddmm_kernel(const int32_t* __restrict__ row_ptr,
+__global__ __launch_bounds__(kBlock) void sddmm_kernel(const int32_t* __restrict__ rb, const int32_t* __restrict__ re,
+                                                       const int32_t* __restrict__ part_row, int skip,
                                                        const int32_t* __restrict__ col, int64_t n_dst,
                                                        const float* __restrict__ a, int64_t lda,
                                                        const float* __restrict__ b, int64_t ldb, int F,
@@ -34,8 +35,11 @@ __global__ __launch_bounds__(kBlock) void sddmm_kernel(const int32_t* __restrict
 {
     constexpr int ROWS_PER_BLOCK = kBlock / G;
     const int lane = threadIdx.x % G, grp = threadIdx.x / G;
-    for (int64_t r = int64_t(blockIdx.x) * ROWS_PER_BLOCK + grp; r < n_dst; r += int64_t(gridDim.x) * ROWS_PER_BLOCK) {
-        const int s = row_ptr[r], e = row_ptr[r + 1];
+    // virtual rows (see HubLists below): part p = positions [rb[p], re[p]) of row part_row[p]; every edge has its own output
+    for (int64_t p = int64_t(blockIdx.x) * ROWS_PER_BLOCK + grp; p < n_dst; p += int64_t(gridDim.x) * ROWS_PER_BLOCK) {
+        const int s = rb[p], e = re[p];
+        if (skip > 0 && e - s > skip) continue;
+        const int64_t r = part_row ? int64_t(part_row[p]) : p;
         const float* ar = a + r * lda;
         for (int i = s; i < e; ++i) {
             const float* br = b + int64_t(col[i]) * ldb;
@@ -59,7 +63,9 @@ __global__ __launch_bounds__(kBlock) void sddmm_kernel(const int32_t* __restrict
 // MASKED (d(max aggregate)/d(edge weight)): a = g / count, and only features j with w[i] * b[col[i], j] == mx[r, j]
 // (the edge attains the row maximum there) enter the dot product.
 template <int G, int CH, bool MASKED>
-__global__ __launch_bounds__(kBlock) void sddmm_fast_kernel(const int32_t* __restrict__ row_ptr,
+__global__ __launch_bounds__(kBlock) void sddmm_fast_kernel(const int32_t* __restrict__ rb,
+                                                            const int32_t* __restrict__ re,
+                                                            const int32_t* __restrict__ part_row, int skip,
                                                             const int32_t* __restrict__ col, int64_t n_dst,
                                                             const float* __restrict__ a, int64_t lda,
                                                             const float* __restrict__ b, int64_t ldb, int F,
@@ -68,8 +74,10 @@ __global__ __launch_bounds__(kBlock) void sddmm_fast_kernel(const int32_t* __res
 {
     constexpr int ROWS_PER_BLOCK = kBlock / G, U = 8;
     const int lane = threadIdx.x % G, grp = threadIdx.x / G;
-    for (int64_t r = int64_t(blockIdx.x) * ROWS_PER_BLOCK + grp; r < n_dst; r += int64_t(gridDim.x) * ROWS_PER_BLOCK) {
-        const int s = row_ptr[r], e = row_ptr[r + 1];
+    for (int64_t p = int64_t(blockIdx.x) * ROWS_PER_BLOCK + grp; p < n_dst; p += int64_t(gridDim.x) * ROWS_PER_BLOCK) {
+        const int s = rb[p], e = re[p];
+        if (skip > 0 && e - s > skip) continue;
+        const int64_t r = part_row ? int64_t(part_row[p]) : p;
         float4 av[CH];
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
@@ -957,9 +965,9 @@ bool gat_bwd_fast_ok(const tfgx_gat_backward_args* p)
 
 using namespace tfgx;
 
-static int sddmm_dispatch(const char* who, const int32_t* row_ptr, const int32_t* col, int64_t n_dst, const float* a,
-                          int64_t lda, const float* b, int64_t ldb, int64_t F, float* out, const float* w,
-                          const float* mx, int64_t ldmx, hipStream_t s)
+static int sddmm_launch(const char* who, const int32_t* rb, const int32_t* re, const int32_t* part_row, int skip,
+                        const int32_t* col, int64_t n_parts, const float* a, int64_t lda, const float* b, int64_t ldb,
+                        int64_t F, float* out, const float* w, const float* mx, int64_t ldmx, hipStream_t s)
 {
     const bool masked = mx != nullptr;
     const bool al = F % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && aligned_to(a, 16) && aligned_to(b, 16) &&
@@ -968,11 +976,11 @@ static int sddmm_dispatch(const char* who, const int32_t* row_ptr, const int32_t
 #define TFGX_SDDMM_GO(G, CH)                                                                                          \
     do {                                                                                                              \
         if (masked)                                                                                                   \
-            sddmm_fast_kernel<G, CH, true><<<grid_for(n_dst, kBlock / G, 1 << 20), kBlock, 0, s>>>(                   \
-                row_ptr, col, n_dst, a, lda, b, ldb, int(F), out, w, mx, ldmx);                                       \
+            sddmm_fast_kernel<G, CH, true><<<grid_for(n_parts, kBlock / G, 1 << 20), kBlock, 0, s>>>(                 \
+                rb, re, part_row, skip, col, n_parts, a, lda, b, ldb, int(F), out, w, mx, ldmx);                      \
         else                                                                                                          \
-            sddmm_fast_kernel<G, CH, false><<<grid_for(n_dst, kBlock / G, 1 << 20), kBlock, 0, s>>>(                  \
-                row_ptr, col, n_dst, a, lda, b, ldb, int(F), out, nullptr, nullptr, 0);                               \
+            sddmm_fast_kernel<G, CH, false><<<grid_for(n_parts, kBlock / G, 1 << 20), kBlock, 0, s>>>(                \
+                rb, re, part_row, skip, col, n_parts, a, lda, b, ldb, int(F), out, nullptr, nullptr, 0);              \
     } while (0)
         if (F <= 32) TFGX_SDDMM_GO(8, 1);
         else if (F <= 64) TFGX_SDDMM_GO(16, 1);
@@ -983,22 +991,44 @@ static int sddmm_dispatch(const char* who, const int32_t* row_ptr, const int32_t
         TFGX_LAUNCH_CHECK(who);
         return TFGX_OK;
     }
-    if (F <= 8) sddmm_kernel<8><<<grid_for(n_dst, kBlock / 8, 1 << 20), kBlock, 0, s>>>(row_ptr, col, n_dst, a, lda, b, ldb, int(F), out, w, mx, ldmx);
-    else if (F <= 32) sddmm_kernel<16><<<grid_for(n_dst, kBlock / 16, 1 << 20), kBlock, 0, s>>>(row_ptr, col, n_dst, a, lda, b, ldb, int(F), out, w, mx, ldmx);
-    else sddmm_kernel<32><<<grid_for(n_dst, kBlock / 32, 1 << 20), kBlock, 0, s>>>(row_ptr, col, n_dst, a, lda, b, ldb, int(F), out, w, mx, ldmx);
+    if (F <= 8) sddmm_kernel<8><<<grid_for(n_parts, kBlock / 8, 1 << 20), kBlock, 0, s>>>(rb, re, part_row, skip, col, n_parts, a, lda, b, ldb, int(F), out, w, mx, ldmx);
+    else if (F <= 32) sddmm_kernel<16><<<grid_for(n_parts, kBlock / 16, 1 << 20), kBlock, 0, s>>>(rb, re, part_row, skip, col, n_parts, a, lda, b, ldb, int(F), out, w, mx, ldmx);
+    else sddmm_kernel<32><<<grid_for(n_parts, kBlock / 32, 1 << 20), kBlock, 0, s>>>(rb, re, part_row, skip, col, n_parts, a, lda, b, ldb, int(F), out, w, mx, ldmx);
     TFGX_LAUNCH_CHECK(who);
     return TFGX_OK;
 }
 
+// every edge owns its output element, so hub rows need no scratch: the plan's rows up to the threshold, then the hub
+// rows' chunks as rows of their own
+static int sddmm_dispatch(const char* who, const int32_t* row_ptr, const int32_t* col, int64_t n_dst, const float* a,
+                          int64_t lda, const float* b, int64_t ldb, int64_t F, float* out, const float* w,
+                          const float* mx, int64_t ldmx, hipStream_t s, const tfgx_hub_lists* hub = nullptr)
+{
+    HubLists hl;
+    const bool chunked = fill_hub(hub, hl);
+    int rc = sddmm_launch(who, row_ptr, row_ptr + 1, nullptr, chunked ? hl.thr : 0, col, n_dst, a, lda, b, ldb, F, out, w, mx,
+                          ldmx, s);
+    if (rc != TFGX_OK || !chunked) return rc;
+    return sddmm_launch(who, hl.chunk_begin, hl.chunk_end, hl.chunk_row, 0, col, hl.n_chunks, a, lda, b, ldb, F, out, w, mx,
+                        ldmx, s);
+}
+
 extern "C" int tfgx_sddmm_f32(const int32_t* row_ptr, const int32_t* col, int64_t n_dst, const float* a, int64_t lda,
                               const float* b, int64_t ldb, int64_t F, float* out, tfgx_stream_t stream)
+{
+    return tfgx_sddmm_hub_f32(row_ptr, col, n_dst, a, lda, b, ldb, F, out, nullptr, stream);
+}
+
+extern "C" int tfgx_sddmm_hub_f32(const int32_t* row_ptr, const int32_t* col, int64_t n_dst, const float* a, int64_t lda,
+                                  const float* b, int64_t ldb, int64_t F, float* out, const tfgx_hub_lists* hub,
+                                  tfgx_stream_t stream)
 {
     TFGX_RANGE();
     TFGX_REQUIRE(n_dst >= 0 && F >= 1 && lda >= F && ldb >= F, "bad size");
     if (n_dst == 0) return TFGX_OK;
     TFGX_REQUIRE(row_ptr && a && b, "null pointer");
     return sddmm_dispatch("sddmm_kernel", row_ptr, col, n_dst, a, lda, b, ldb, F, out, nullptr, nullptr, 0,
-                          as_stream(stream));
+                          as_stream(stream), hub);
 }
 
 extern "C" int tfgx_segment_max_backward_w_f32(const int32_t* row_ptr, const int32_t* col, const float* w, int64_t n_dst,

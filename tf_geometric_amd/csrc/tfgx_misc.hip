@@ -158,7 +158,14 @@ __device__ __forceinline__ int draw_below(uint64_t seed, uint64_t row, uint32_t 
     return static_cast<int>((uint64_t(draw_u32(seed, row, i)) * uint64_t(n)) >> 32);
 }
 
-constexpr int kMaxSampleK = 256;
+constexpr int kSampleLongRow = 64;       // rows with more neighbours / draws than this get a whole wave (coalesced walks)
+
+constexpr int kFloydMax = 32;            // Floyd's O(m^2) duplicate check only for few draws; otherwise one O(d) selection pass
+
+__device__ __forceinline__ bool sample_row_is_long(int d, int m)
+{
+    return (d > kSampleLongRow && m > kFloydMax) || m > kSampleLongRow;
+}
 
 // one thread per destination row; out row r holds cnt[r] = out_ptr[r+1]-out_ptr[r] sampled CSR positions' (col, w)
 __global__ void sample_neighbors_kernel(const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
@@ -172,6 +179,7 @@ __global__ void sample_neighbors_kernel(const int32_t* __restrict__ row_ptr, con
         const int s = row_ptr[r], d = row_ptr[r + 1] - s;
         const int o = out_ptr[r], m = out_ptr[r + 1] - o;
         if (m == 0) continue;
+        if (sample_row_is_long(d, m)) continue;                   // hub rows: sample_neighbors_long_kernel, a wave each
         if (m >= d && !(replace_when_short && m > d)) {          // keep every neighbour, in order (:742-744)
             for (int i = 0; i < d; ++i) {
                 out_col[o + i] = col[s + i];
@@ -187,8 +195,8 @@ __global__ void sample_neighbors_kernel(const int32_t* __restrict__ row_ptr, con
             }
             continue;
         }
-        if (m > kMaxSampleK) {
-            // m < d, many draws (ratio sampling on a hub row): Knuth's selection sampling (Algorithm S) — one pass over
+        if (m > kFloydMax) {
+            // m < d, more than a few draws (ratio sampling): Knuth's selection sampling (Algorithm S) — one pass over
             // the d neighbours, position j is taken with probability (m - taken) / (d - j): uniform without replacement,
             // no scratch, neighbour order kept
             int taken = 0;
@@ -202,7 +210,7 @@ __global__ void sample_neighbors_kernel(const int32_t* __restrict__ row_ptr, con
             continue;
         }
         // m < d: Floyd's algorithm — m distinct positions of [0, d) with uniform probability, no replacement
-        int chosen[kMaxSampleK];
+        int chosen[kFloydMax];
         int c = 0;
         for (int j = d - m; j < d; ++j) {
             int t = draw_below(seed, uint64_t(r), uint32_t(j - (d - m)), j + 1);
@@ -213,6 +221,59 @@ __global__ void sample_neighbors_kernel(const int32_t* __restrict__ row_ptr, con
         for (int i = 0; i < m; ++i) {
             out_col[o + i] = col[s + chosen[i]];
             if (out_w) out_w[o + i] = w ? w[s + chosen[i]] : 1.0f;
+        }
+    }
+}
+
+// Rows with more than 64 neighbours or draws (all of a power-law graph's mass; hubs of 10^4 .. 10^5 neighbours): one WAVE
+// per row instead of one lane — coalesced walks, no divergence between a hub and its wave-mates (R-MAT, ratio = 0.5:
+// 43 ms -> see profiles/r02_skew_cliff_scan.jsonl).  keep-all and with-replacement rows are copied / drawn lane-parallel.
+// m < d: the row's d positions are cut into 64 contiguous strata; with ONE uniform integer U in [0, d) per row, stratum
+// [b0, b1) receives (m*b1 + U)/d - (m*b0 + U)/d of the m samples (integer divisions: never more than it holds, exactly m
+// in total, output offsets in closed form, expectation m * len / d) and draws them by selection sampling (Algorithm S).
+// Neighbour order is kept and EVERY neighbour is included with probability exactly m / d, as with the reference's
+// np.random.choice; the joint draw is systematic across strata rather than a uniform m-subset (lower variance).
+__global__ __launch_bounds__(kBlock) void sample_neighbors_long_kernel(const int32_t* __restrict__ row_ptr,
+                                                                       const int32_t* __restrict__ col,
+                                                                       const float* __restrict__ w, int64_t n_dst,
+                                                                       const int32_t* __restrict__ out_ptr,
+                                                                       int replace_when_short, uint64_t seed,
+                                                                       int32_t* __restrict__ out_col,
+                                                                       float* __restrict__ out_w)
+{
+    constexpr int WV = 64;
+    const int lane = threadIdx.x % WV;
+    int64_t r = (blockIdx.x * int64_t(kBlock) + threadIdx.x) / WV;
+    const int64_t stride = int64_t(gridDim.x) * kBlock / WV;
+    for (; r < n_dst; r += stride) {
+        const int s = row_ptr[r], d = row_ptr[r + 1] - s;
+        const int o = out_ptr[r], m = out_ptr[r + 1] - o;
+        if (m == 0 || !sample_row_is_long(d, m)) continue;
+        if (m >= d && !(replace_when_short && m > d)) {          // keep every neighbour, in order
+            for (int i = lane; i < d; i += WV) {
+                out_col[o + i] = col[s + i];
+                if (out_w) out_w[o + i] = w ? w[s + i] : 1.0f;
+            }
+            continue;
+        }
+        if (m > d) {                                             // padding: m draws WITH replacement (same draws as one lane)
+            for (int i = lane; i < m; i += WV) {
+                const int t = draw_below(seed, uint64_t(r), uint32_t(i), d);
+                out_col[o + i] = col[s + t];
+                if (out_w) out_w[o + i] = w ? w[s + t] : 1.0f;
+            }
+            continue;
+        }
+        const int b0 = int(int64_t(d) * lane / WV), b1 = int(int64_t(d) * (lane + 1) / WV);        // stratum [b0, b1)
+        const int64_t U = draw_below(seed, uint64_t(r), 0xFFFFFFFFu, d);                           // the row's random offset
+        const int o0 = int((int64_t(m) * b0 + U) / d), ml = int((int64_t(m) * b1 + U) / d) - o0;   // its samples
+        int taken = 0;
+        for (int j = b0; j < b1 && taken < ml; ++j) {
+            if (draw_below(seed, uint64_t(r), uint32_t(j), b1 - j) < ml - taken) {
+                out_col[o + o0 + taken] = col[s + j];
+                if (out_w) out_w[o + o0 + taken] = w ? w[s + j] : 1.0f;
+                ++taken;
+            }
         }
     }
 }
@@ -419,6 +480,10 @@ extern "C" int tfgx_sample_neighbors(const int32_t* row_ptr, const int32_t* col,
     sample_neighbors_kernel<<<grid_for(n_dst, kBlock), kBlock, 0, as_stream(stream)>>>(
         row_ptr, col, w, n_dst, out_ptr, replace_when_short, seed, out_col, out_w);
     TFGX_LAUNCH_CHECK("sample_neighbors_kernel");
+    // rows the lane-per-row kernel skipped (hubs): a wave each; a pass over row_ptr / out_ptr when there are none
+    sample_neighbors_long_kernel<<<grid_for(n_dst * 64, kBlock, 1 << 14), kBlock, 0, as_stream(stream)>>>(
+        row_ptr, col, w, n_dst, out_ptr, replace_when_short, seed, out_col, out_w);
+    TFGX_LAUNCH_CHECK("sample_neighbors_long_kernel");
     return TFGX_OK;
 }
 

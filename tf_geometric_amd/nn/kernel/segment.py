@@ -21,8 +21,7 @@ def segment_softmax(data, segment_ids, num_segments):
         return AG.segment_softmax(plan, ids, d)
     out = torch.empty_like(d)
     if E:
-        L.check(lib.tfgx_edge_softmax_f32(L.ptr(plan.row_ptr), L.ptr(plan.perm), L.ptr(d), H, plan.n_dst, L.ptr(out),
-                                          L.stream_ptr()), "tfgx_edge_softmax_f32")
+        L.edge_softmax(plan, d, H, out)
     return out
 
 

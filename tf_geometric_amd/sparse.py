@@ -91,8 +91,7 @@ class SparseMatrix(object):
             return self.with_value(AG.segment_softmax(plan, self.index[0], self.value))
         out = torch.empty_like(self.value)
         if plan.num_edges:
-            L.check(lib.tfgx_edge_softmax_f32(L.ptr(plan.row_ptr), L.ptr(plan.perm), L.ptr(self.value.contiguous()), 1,
-                                              plan.n_dst, L.ptr(out), L.stream_ptr()), "tfgx_edge_softmax_f32")
+            L.edge_softmax(plan, self.value.contiguous(), 1, out)
         return self.with_value(out)
 
     def add_diag(self, weight):
