@@ -682,7 +682,11 @@ class ShardedGraph(object):
         rp_t, dst_t, perm_t = self._transposed_local()
         wt = None if w_t is None else be.permute_rows(w_t, perm_t)
         d_table = be.empty((max(self.n_table, 1), U))
-        be.segment_reduce(rp_t, rp_t[1:], 1, dst_t, wt, self.n_table, g, d_table, L.SUM)
+        if getattr(self, "_tl_hub", None) is None:      # hub SOURCES of the shard: chunked, as the forward's hub rows are
+            hub_fn = getattr(be, "hub_lists", None)
+            self._tl_hub = (hub_fn(rp_t, rp_t[1:], 1, self.n_table, self.num_edges) if hub_fn else None) or False
+        kw = {"hub": self._tl_hub} if self._tl_hub else {}
+        be.segment_reduce(rp_t, rp_t[1:], 1, dst_t, wt, self.n_table, g, d_table, L.SUM, **kw)
         d_own = self.reverse_exchange(d_table, inplace=True)
         if self_coef is not None:
             d_own = d_own + self_coef.unsqueeze(1) * g
