@@ -298,14 +298,14 @@ def static_aggregate(x, plan, cache, op, w_csr=None, self_coef=None):
         return None
     if any(t is not None and t.requires_grad for t in (x, w_csr, self_coef)):
         return None
+    if torch.cuda.is_current_stream_capturing():
+        return None      # a captured graph must contain the aggregation itself: a replay cannot see x's version counter
     ident = lambda t: None if t is None else (t.data_ptr(), t._version, int(t.numel()))      # noqa: E731
     key = (_static_key(x, plan), ident(w_csr), ident(self_coef))
     hit = store.get(op)
     if hit is not None and hit[0] == key:
         STATIC_STATS["agg_hits"] = STATIC_STATS.get("agg_hits", 0) + 1
         return hit[1]
-    if torch.cuda.is_current_stream_capturing():
-        return None
     out = segment_reduce(plan, static_rows(x, plan, cache), op, w_csr=w_csr, self_coef=self_coef)
     store[op] = (key, out, x, w_csr, self_coef)            # the operands stay alive: their addresses cannot be recycled
     return out
