@@ -189,8 +189,12 @@ def _loss_coef(n, u):
     return (np.sin(np.arange(n * u, dtype=np.float64) * 0.37).reshape(n, u) + 1.5).astype(np.float32)
 
 
-def run_training(rank, world, use_gpu, skew, rounds=None, num_splits=None):
+def run_training(rank, world, use_gpu, skew, rounds=None, num_splits=None, hub_threshold=None):
     from tf_geometric_amd.dist.sharded import ShardedGraph
+    import tf_geometric_amd.plan as P
+    # hub_threshold: force the chunked long-row paths of the backward kernels (transposed local pass, GAT / max gradients
+    # on the shard's rectangular plan) on this small graph
+    P.HUB_THRESHOLD, P.HUB_CHUNK = hub_threshold, (None if hub_threshold is None else max(2, hub_threshold // 2))
     ei, x, w, k, b = make_inputs(skew=skew)
     n = x.shape[0]
     if use_gpu:
@@ -266,22 +270,22 @@ def run_training(rank, world, use_gpu, skew, rounds=None, num_splits=None):
     return res
 
 
-def _train_entry(rank, world, port, use_gpu, skew, path, rounds, num_splits):
+def _train_entry(rank, world, port, use_gpu, skew, path, rounds, num_splits, hub_threshold=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if use_gpu:
         torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    res = run_training(rank, world, use_gpu, skew, rounds, num_splits)
+    res = run_training(rank, world, use_gpu, skew, rounds, num_splits, hub_threshold)
     np.save(os.path.join(path, "train{}.npy".format(rank)), np.array([res], dtype=object), allow_pickle=True)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def spawn_training(world, use_gpu, skew, path, port, rounds=None, num_splits=None):
+def spawn_training(world, use_gpu, skew, path, port, rounds=None, num_splits=None, hub_threshold=None):
     import torch.multiprocessing as mp
-    mp.spawn(_train_entry, args=(world, port, use_gpu, skew, path, rounds, num_splits), nprocs=world, join=True)
+    mp.spawn(_train_entry, args=(world, port, use_gpu, skew, path, rounds, num_splits, hub_threshold), nprocs=world, join=True)
     return [np.load(os.path.join(path, "train{}.npy".format(r)), allow_pickle=True)[0] for r in range(world)]
 
 

@@ -55,8 +55,9 @@ def test_edge_balanced_bounds():
     assert list(edge_balanced_bounds(rp, 1)) == [0, 7]
 
 
-@pytest.mark.parametrize("world,skew,rounds", [(2, False, 2), (3, True, 3), (1, True, None)])
-def test_sharded_training_gradients_gloo(tmp_path, world, skew, rounds):
+@pytest.mark.parametrize("world,skew,rounds,hub", [(2, False, 2, None), (3, True, 3, None), (1, True, None, None),
+                                                   (2, True, 2, 8)])
+def test_sharded_training_gradients_gloo(tmp_path, world, skew, rounds, hub):
     """Sharded backward: reverse halo all-to-all-v, owner-side accumulate in fixed peer order, weight-gradient
     all-reduce.  d/dx (per owner), d/dkernel and d/dbias (summed over ranks) must equal single-process float64 autograd
     over the oracle's normalised adjacency — what tf.GradientTape produces in the reference's training loops
@@ -65,7 +66,7 @@ def test_sharded_training_gradients_gloo(tmp_path, world, skew, rounds):
         parts = [dist_worker.run_training(0, 1, False, skew)]
     else:
         port = 29500 + random.randint(4001, 6000)
-        parts = dist_worker.spawn_training(world, False, skew, str(tmp_path), port, rounds=rounds)
+        parts = dist_worker.spawn_training(world, False, skew, str(tmp_path), port, rounds=rounds, hub_threshold=hub)
     ref = dist_worker.training_reference(skew)
     parts = sorted(parts, key=lambda p: p["lo"])
     assert_parity(np.concatenate([p["out"] for p in parts]), ref["out"], what="sharded trainable forward")

@@ -44,17 +44,17 @@ def test_rccl_world1_api_smoke(tfg):
     assert res.returncode == 0 and "RCCL_WORLD1_OK" in text and "True" in text and "False" not in text, text
 
 
-@pytest.mark.parametrize("world,skew", [(1, True), (2, True), (2, False)])
-def test_sharded_training_hip(tfg, tmp_path, world, skew):
+@pytest.mark.parametrize("world,skew,hub", [(1, True, None), (2, True, None), (2, False, None), (2, True, 8)])
+def test_sharded_training_hip(tfg, tmp_path, world, skew, hub):
     """Sharded backward on the HIP kernels (transposed local pass, tfgx_scatter_add_rows_f32 owner-side accumulate,
     MFMA weight gradients) + the reverse exchange and weight-gradient all-reduce over a gloo group sharing cuda:0, and
     the column-chunked halo (bit-identical rows, a quarter of the table)."""
     import numpy as np
     if world == 1:
-        parts = [dist_worker.run_training(0, 1, True, skew, num_splits=4)]
+        parts = [dist_worker.run_training(0, 1, True, skew, num_splits=4, hub_threshold=hub)]
     else:
         port = 37600 + random.randint(0, 2000)
-        parts = dist_worker.spawn_training(2, True, skew, str(tmp_path), port, rounds=3, num_splits=4)
+        parts = dist_worker.spawn_training(2, True, skew, str(tmp_path), port, rounds=3, num_splits=4, hub_threshold=hub)
     ref = dist_worker.training_reference(skew)
     parts = sorted(parts, key=lambda p: p["lo"])
     assert_parity(np.concatenate([p["out"] for p in parts]), ref["out"], what="sharded trainable forward (HIP)")
