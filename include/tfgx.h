@@ -219,6 +219,10 @@ typedef struct tfgx_gat_args {
     int32_t reserved2;
     uint64_t drop_seed;
     int64_t drop_self_base;
+    /* optional walk order: lane group i of the launch processes destination row_order[i] (NULL: i).  On a power-law graph
+       the host passes the rows sorted by in-degree, so that the rows sharing a wave have similar lengths (13-16 % on the
+       whole layer at R-MAT shapes); results do not depend on it.  Ignored by the part / chunk launches. */
+    const int32_t* row_order;
 } tfgx_gat_args;
 
 /* 1 if the item survives dropout at `rate`, else 0: the exact decision every kernel of this library makes for
@@ -354,6 +358,9 @@ typedef struct tfgx_gat_backward_args {
        dsum point into that table with its row stride) turns four gathers into one contiguous burst. */
     int64_t ld_stats_ml;
     int64_t ld_dsum;
+    /* optional walk orders (see tfgx_gat_args.row_order): destinations for the dst pass, sources for the src pass */
+    const int32_t* row_order;
+    const int32_t* row_order_t;
 } tfgx_gat_backward_args;
 
 /* Prepares both backward passes in ONE sweep over the destination rows: dsum[r, h] = <dO[r, h, :], O[r, h, :]> (dense

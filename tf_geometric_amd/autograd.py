@@ -448,6 +448,9 @@ class _GatAttention(torch.autograd.Function):
         a.grad_q, a.ld_grad_q = gq.data_ptr(), A
         a.grad_k, a.ld_grad_k = gk.data_ptr(), A
         a.grad_v, a.ld_grad_v = gv.data_ptr(), W
+        ro, ro_t = plan.row_order(), pt.row_order()        # skewed graphs: degree-ordered walks (results unchanged)
+        a.row_order = 0 if ro is None else ro.data_ptr()
+        a.row_order_t = 0 if ro_t is None else ro_t.data_ptr()
         if ctx.drop[0] > 0.0:      # regenerate the forward's keep mask: same seed, forward-CSR edge positions
             a.drop_rate, a.drop_seed, a.drop_self_base = ctx.drop[0], ctx.drop[1], plan.num_edges
             a.edge_pos_t = t2d.data_ptr()

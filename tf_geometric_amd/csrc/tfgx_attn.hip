@@ -207,6 +207,7 @@ struct GArgs {
     const int32_t* row_end;
     int64_t rp_stride;
     const int32_t* part_row;
+    const int32_t* row_order;   // walk order of the main launch (NULL: identity)
     float* state_acc;     // [n_parts, W]
     float* state_ml;      // [n_parts, 2H]  (m, l) per head
     int32_t hub_threshold;
@@ -258,10 +259,11 @@ __global__ __launch_bounds__(kBlock) void gat_fused_kernel(const GArgs a)
 
     for (int64_t r = int64_t(blockIdx.x) * ROWS_PER_BLOCK + grp; r < a.n_dst;
          r += int64_t(gridDim.x) * ROWS_PER_BLOCK) {
-        const int64_t part = r;
+        const int64_t idx = r;                                           // loop position; restored before the next turn
+        const int64_t part = a.row_order ? int64_t(a.row_order[idx]) : idx;   // degree-ordered walk on skewed graphs
         const int s = a.row_begin[part * a.rp_stride], e = a.row_end[part * a.rp_stride];
         if (a.hub_threshold > 0 && e - s > a.hub_threshold) continue;   // chunked + merged separately
-        if (a.part_row) r = a.part_row[part];
+        r = a.part_row ? int64_t(a.part_row[part]) : part;
         const float* qp = a.q + r * a.ldq + hoff;
         float qreg[D > 0 ? D : 1];
         if constexpr (D > 0) {
@@ -317,7 +319,7 @@ __global__ __launch_bounds__(kBlock) void gat_fused_kernel(const GArgs a)
                     a.state_ml[part * 2 * a.H + 2 * head + 1] = l;
                 }
             }
-            r = part;           // restore the loop variable
+            r = idx;            // restore the loop variable
             continue;
         }
         if (a.add_self_loop) {  // the appended (r, r) edge comes last (graph_utils.py:350-366)
@@ -341,7 +343,7 @@ __global__ __launch_bounds__(kBlock) void gat_fused_kernel(const GArgs a)
             }
             store_vec<VEC>(a.out + r * a.ldo + coff, res);
         }
-        r = part;
+        r = idx;
     }
 }
 
@@ -539,6 +541,7 @@ extern "C" int tfgx_gat_fused_f32(const tfgx_gat_args* p, tfgx_stream_t stream_)
     TFGX_REQUIRE(a.row_end != nullptr && a.rp_stride >= 1, "bad row_begin / row_end / rp_stride");
     a.part_row = nullptr; a.state_acc = p->state_acc; a.state_ml = p->state_ml; a.hub_threshold = 0;
     a.stats_ml = p->stats_ml;
+    a.row_order = (p->state_acc == nullptr && p->row_begin == nullptr) ? p->row_order : nullptr;
     if (p->state_acc) {
         // raw-state launches over arbitrary PARTS (tfgx.h): hub_chunk_row, when given, names the destination (Q row) of
         // every launched part; hub_threshold > 0 skips spans longer than that (their chunks are launched separately)
@@ -578,7 +581,7 @@ extern "C" int tfgx_gat_fused_f32(const tfgx_gat_args* p, tfgx_stream_t stream_)
     GArgs c = a;
     c.row_begin = p->hub_chunk_begin; c.row_end = p->hub_chunk_end; c.rp_stride = 1; c.n_dst = p->n_hub_chunks;
     c.part_row = p->hub_chunk_row; c.state_acc = p->hub_scratch_acc; c.state_ml = p->hub_scratch_ml;
-    c.hub_threshold = 0; c.stats_ml = nullptr;
+    c.hub_threshold = 0; c.stats_ml = nullptr; c.row_order = nullptr;
     rc = launch(c, vec_for(p->hub_scratch_acc, W));
     if (rc != TFGX_OK) return rc;
     GMerge g;

@@ -604,6 +604,7 @@ struct GB {
     const int32_t* row_end;
     const int32_t* part_row;
     int32_t skip;             // > 0: parts longer than this are left to the chunk launch (hub rows)
+    const int32_t* row_order; // walk order of a plain launch (NULL: identity): rows of similar length share a wave
     int64_t n_self;           // rows [0, n_self) of this pass own the appended self-loop (src pass of a rectangular
                               // operator: only sources that are also destinations, i.e. a shard's own rows)
     const float* q; int64_t ldq;
@@ -820,7 +821,8 @@ __global__ __launch_bounds__(kBlock) void gat_backward_fast_kernel(const GB a)
     const int lh = (a.H == 1) ? G : a.dv / VEC;
     const bool head_first = cvalid && (coff % a.dv == 0);
 
-    for (int64_t part = int64_t(blockIdx.x) * ROWS_PER_BLOCK + grp; part < a.n; part += int64_t(gridDim.x) * ROWS_PER_BLOCK) {
+    for (int64_t pi = int64_t(blockIdx.x) * ROWS_PER_BLOCK + grp; pi < a.n; pi += int64_t(gridDim.x) * ROWS_PER_BLOCK) {
+        const int64_t part = a.row_order ? int64_t(a.row_order[pi]) : pi;
         const int s0 = a.row_begin[part], e0 = a.row_end[part];
         if (a.skip > 0 && e0 - s0 > a.skip) continue;             // a hub row: walked chunk-wise by a second launch
         const int64_t row = a.part_row ? int64_t(a.part_row[part]) : part;
@@ -1293,6 +1295,7 @@ static int gat_backward_pass(const tfgx_gat_backward_args* p, GB& a, const tfgx_
                              hipStream_t stream)
 {
     a.row_begin = a.row_ptr; a.row_end = a.row_ptr + 1; a.part_row = nullptr; a.skip = 0;
+    a.row_order = SRC ? p->row_order_t : p->row_order;
     if (!gat_bwd_fast_ok(p)) {
         if (SRC) gat_backward_src_kernel<<<grid_for(a.n * a.H, kBlock), kBlock, 0, stream>>>(a);
         else gat_backward_dst_kernel<<<grid_for(a.n * a.H, kBlock), kBlock, 0, stream>>>(a);
@@ -1307,6 +1310,7 @@ static int gat_backward_pass(const tfgx_gat_backward_args* p, GB& a, const tfgx_
     const int A = a.H * a.d, W = a.H * a.dv;
     GB c = a;
     c.n = hl.n_chunks; c.row_begin = hl.chunk_begin; c.row_end = hl.chunk_end; c.part_row = hl.chunk_row; c.skip = 0;
+    c.row_order = nullptr;
     float* sq = scratch;                                   // [n_chunks, A]: dQ (dst pass) / dK (src pass) partials
     float* sv = scratch + size_t(hl.n_chunks) * size_t(A); // [n_chunks, W]: dV partials (src pass)
     if (SRC) { c.gk = sq; c.ldgk = A; c.gv = sv; c.ldgv = W; }

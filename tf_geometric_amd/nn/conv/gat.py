@@ -100,6 +100,9 @@ def gat_attention(plan, Q, K, V, num_heads, add_self_loop=True, bias=None, act=L
     lib = L.require_gpu()
     a, out, keep = gat_args(Q, K, V, num_heads, plan.n_dst, plan.col, add_self_loop, bias, act, scale_d=scale_d)
     a.row_ptr = plan.row_ptr.data_ptr()
+    order = plan.row_order()                 # skewed graphs: rows of similar length share a wave
+    if order is not None:
+        a.row_order = order.data_ptr()
     if stats_ml is not None:
         a.stats_ml = stats_ml.data_ptr()      # (m, l) per row and head, kept for the backward pass
     if drop_rate > 0.0:

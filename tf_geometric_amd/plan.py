@@ -115,6 +115,19 @@ class CsrPlan(object):
     def in_degree(self):
         return (self.row_ptr[1:] - self.row_ptr[:-1])
 
+    def row_order(self):
+        """Rows sorted by descending length (int32 [n_dst]) when the plan is skewed — longest row more than 8x the mean —
+        else None.  Kernels that give every row a lane group walk the rows in this order so that the rows sharing a wave
+        have similar lengths (GAT layer on R-MAT graphs: 13-16 %); results do not depend on it.  Computed once per plan."""
+        if getattr(self, "_row_order", None) is None:
+            order = False
+            if self.n_dst > 0 and self.num_edges > 0:
+                deg = self.in_degree()
+                if int(deg.max().item()) > 8 * max(self.num_edges / float(self.n_dst), 1.0):
+                    order = torch.argsort(deg, descending=True, stable=True).to(torch.int32).contiguous()
+            self._row_order = order
+        return None if self._row_order is False else self._row_order
+
     def hub_info(self):
         """Chunk lists for destinations with more than hub_threshold in-edges (power-law "hubs"), or None.
         Small control-plane metadata, computed once per plan:
