@@ -658,7 +658,9 @@ def extras(tfg, L, synthetic, x, ei, n, e, f, cache):
         torch.nn.functional.cross_entropy(logits[idx], labels).backward()
         opt.step()
 
+    torch.cuda.reset_peak_memory_stats()
     res["gcn_2layer_train_step_ms"] = _time(full_step, steps=5, warmup=2)
+    res["gcn_2layer_train_step_peak_GB"] = torch.cuda.max_memory_allocated() / 1e9      # graph + plans + activations + workspaces
     # BASELINE configs[3]: GraphSAGE mean / max-pool aggregators (units 256, concat, as demo/demo_graph_sage.py:29-30):
     # one full-batch training step of a 2-layer mean model, and forward + backward of one max-pool layer
     s0, s1 = tfg.layers.MeanGraphSage(256, activation=tfg.relu), tfg.layers.MeanGraphSage(40, activation=None)
