@@ -510,7 +510,7 @@ extern "C" int tfgx_edge_softmax_hub_f32(const int32_t* row_ptr, const int32_t* 
                 hub->chunk_begin, hub->chunk_end, hub->n_chunks, perm, score, int(H), Hp, hub_scratch, out);
         } else {
             // no chunk lists: long rows get a whole 256-thread workgroup each (a pass over row_ptr when there are none)
-            edge_softmax_kernel<kBlock, true><<<grid_for(n_dst, 1, 1 << 14), kBlock, 0, st>>>(row_ptr, perm, score, int(H), Hp,
+            edge_softmax_kernel<kBlock, true><<<grid_for(n_dst, 1, (1 << 14) - 3), kBlock, 0, st>>>(row_ptr, perm, score, int(H), Hp,
                                                                                              n_dst, out, limit);
         }
     }

@@ -481,7 +481,8 @@ extern "C" int tfgx_sample_neighbors(const int32_t* row_ptr, const int32_t* col,
         row_ptr, col, w, n_dst, out_ptr, replace_when_short, seed, out_col, out_w);
     TFGX_LAUNCH_CHECK("sample_neighbors_kernel");
     // rows the lane-per-row kernel skipped (hubs): a wave each; a pass over row_ptr / out_ptr when there are none
-    sample_neighbors_long_kernel<<<grid_for(n_dst * 64, kBlock, 1 << 14), kBlock, 0, as_stream(stream)>>>(
+    // (an ODD grid: with a power-of-two row stride the hubs of an R-MAT graph — ids k * 2^16 — would all land in one wave)
+    sample_neighbors_long_kernel<<<grid_for(n_dst * 64, kBlock, (1 << 14) - 3), kBlock, 0, as_stream(stream)>>>(
         row_ptr, col, w, n_dst, out_ptr, replace_when_short, seed, out_col, out_w);
     TFGX_LAUNCH_CHECK("sample_neighbors_long_kernel");
     return TFGX_OK;
