@@ -174,8 +174,9 @@ def _keep_mask_host(seed, n_items, rate):
     return (x >> np.uint32(8)) >= np.uint32(int(np.float32(rate) * np.float32(16777216.0)))
 
 
-@pytest.mark.parametrize("heads,att,units,rate", [(1, 4, 8, 0.5), (4, 8, 16, 0.6), (2, 32, 8, 0.25), (2, 6, 10, 0.4)])
-def test_gat_attention_dropout_forward_and_grads(tfg, oracle, heads, att, units, rate):
+@pytest.mark.parametrize("heads,att,units,rate,hubs", [(1, 4, 8, 0.5, False), (4, 8, 16, 0.6, False), (2, 32, 8, 0.25, False),
+                                                       (2, 6, 10, 0.4, False), (4, 8, 16, 0.5, True)])
+def test_gat_attention_dropout_forward_and_grads(tfg, oracle, heads, att, units, rate, hubs):
     """Attention dropout (SparseMatrix.dropout after segment_softmax, gat.py:85): out = sum_e a_e keep_e/(1-rate) V.
     The mask is regenerated on the host from (seed, CSR position, head); forward and dQ, dK, dV are compared with torch
     autograd over a float64 restatement that uses that mask.  Covers the tuned and the one-lane-per-row backward."""
@@ -184,7 +185,17 @@ def test_gat_attention_dropout_forward_and_grads(tfg, oracle, heads, att, units,
     from tf_geometric_amd.plan import CsrPlan
     x, ei, w, rng = _graph(oracle, n=300, e=4000, f=5, seed=heads + att)
     n = x.shape[0]
+    import tf_geometric_amd.plan as P
+    old_policy = (P.HUB_THRESHOLD, P.HUB_CHUNK)
+    if hubs:    # a 3000-in-edge destination and a 2500-out-edge source, a low threshold: the backward passes run chunk-wise
+        # (and in degree order) while the keep mask still comes from the edges' absolute CSR positions
+        ei = np.concatenate([np.stack([np.full(3000, 9, np.int32), rng.integers(0, n, 3000, dtype=np.int32)]), ei,
+                             np.stack([rng.integers(0, n, 2500, dtype=np.int32), np.full(2500, 4, np.int32)])], axis=1)
+        P.HUB_THRESHOLD, P.HUB_CHUNK = 64, 48
     plan = CsrPlan.build(L.as_i32(ei), n, n)
+    if hubs:
+        assert plan.hub_info() is not None and plan.transposed().hub_info() is not None and plan.row_order() is not None
+    P.HUB_THRESHOLD, P.HUB_CHUNK = old_policy
     E = plan.num_edges
     seed = (0x1234ABCD << 32) | (77 + heads)
     lib = L.require_gpu()
