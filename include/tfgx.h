@@ -130,6 +130,10 @@ typedef struct tfgx_reduce_args {
        that do not change between launches (the dataset's input features: layer 0 of every model, every epoch). */
     const float* edge_tail;
     int64_t ld_edge_tail;
+    /* optional walk order: lane group i of the launch reduces destination row row_order[i] (NULL: i) — the plan's rows
+       sorted by length on skewed graphs, so that the rows sharing a wave are of similar length; a permutation of
+       [0, n_dst), results do not depend on it */
+    const int32_t* row_order;
 } tfgx_reduce_args;
 
 int tfgx_segment_reduce_f32(const tfgx_reduce_args* args /* host */, tfgx_stream_t stream);

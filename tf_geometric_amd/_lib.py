@@ -41,6 +41,7 @@ class ReduceArgs(ctypes.Structure):
         ("hub_scratch", ctypes.c_void_p),
         ("x_tail", ctypes.c_void_p), ("ld_tail", ctypes.c_int64), ("f_main", ctypes.c_int64),
         ("edge_tail", ctypes.c_void_p), ("ld_edge_tail", ctypes.c_int64),
+        ("row_order", ctypes.c_void_p),
     ]
 
 

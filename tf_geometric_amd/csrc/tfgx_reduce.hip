@@ -57,6 +57,7 @@ struct KArgs {
     const float* x_tail;     // split source rows: columns >= f_main live in x_tail[n_src, ld_tail] (see tfgx.h)
     int64_t ld_tail;
     int32_t f_main;
+    const int32_t* row_order; // optional walk order: lane group i reduces row row_order[i] (skewed plans: degree order)
     const float* edge_tail;  // optional with SPLIT: the tail columns of every edge's SOURCE row, in this plan's edge order
     int64_t ld_edge_tail;    // (streamed next to col / w instead of gathered: one line request fewer per edge)
 };
@@ -131,14 +132,19 @@ __global__ __launch_bounds__(kBlock) void seg_reduce_kernel(const KArgs a)
     // new row starts with its indices in registers instead of two dependent memory round trips.
     const int64_t rstride = int64_t(gridDim.x) * ROWS_PER_BLOCK;
     int64_t r = int64_t(blockIdx.x) * ROWS_PER_BLOCK + grp;
+    // loop position -> destination row: the identity, or the plan's degree order on skewed graphs (rows of similar length
+    // then share a wave; results do not depend on it)
+    auto row_of = [&](int64_t i) -> int64_t { return a.row_order ? int64_t(a.row_order[i]) : i; };
     int s = 0, e = 0, s1 = 0, e1 = 0;
     if (r < a.n_dst) {
-        s = a.row_begin[r * a.rp_stride];
-        e = a.row_end[r * a.rp_stride];
+        const int64_t q = row_of(r);
+        s = a.row_begin[q * a.rp_stride];
+        e = a.row_end[q * a.rp_stride];
     }
     if (r + rstride < a.n_dst) {
-        s1 = a.row_begin[(r + rstride) * a.rp_stride];
-        e1 = a.row_end[(r + rstride) * a.rp_stride];
+        const int64_t q = row_of(r + rstride);
+        s1 = a.row_begin[q * a.rp_stride];
+        e1 = a.row_end[q * a.rp_stride];
     }
     int cj_first = 0;
     float wj_first = 0.0f;
@@ -149,8 +155,9 @@ __global__ __launch_bounds__(kBlock) void seg_reduce_kernel(const KArgs a)
     for (; r < a.n_dst; r += rstride) {
         int s2 = 0, e2 = 0;                                       // header of the row after next
         if (r + 2 * rstride < a.n_dst) {
-            s2 = a.row_begin[(r + 2 * rstride) * a.rp_stride];
-            e2 = a.row_end[(r + 2 * rstride) * a.rp_stride];
+            const int64_t q = row_of(r + 2 * rstride);
+            s2 = a.row_begin[q * a.rp_stride];
+            e2 = a.row_end[q * a.rp_stride];
         }
         int cj_first1 = 0;                                        // first (col, w) batch of the next row
         float wj_first1 = 0.0f;
@@ -164,8 +171,8 @@ __global__ __launch_bounds__(kBlock) void seg_reduce_kernel(const KArgs a)
         float wj_next = wj_first;
         s = s1; e = e1; s1 = s2; e1 = e2; cj_first = cj_first1; wj_first = wj_first1;      // rotate the pipeline
         if (a.hub_threshold > 0 && e_cur - s_cur > a.hub_threshold) continue;   // handled by the chunked hub path
-        seg_reduce_row<VEC, G, CH, IS_MAX, WEIGHTED, SPLIT>(a, r, s_cur, e_cur, cj_next, wj_next, lane, coff, cvalid, xb, xl,
-                                                            xs, xsl, by_edge, init);
+        seg_reduce_row<VEC, G, CH, IS_MAX, WEIGHTED, SPLIT>(a, row_of(r), s_cur, e_cur, cj_next, wj_next, lane, coff, cvalid,
+                                                            xb, xl, xs, xsl, by_edge, init);
     }
 }
 
@@ -494,6 +501,7 @@ extern "C" int tfgx_segment_reduce_f32(const tfgx_reduce_args* p, tfgx_stream_t 
     a.hub_threshold = 0;
     a.x_tail = p->x_tail; a.ld_tail = p->ld_tail; a.f_main = int32_t(p->f_main);
     a.edge_tail = p->edge_tail; a.ld_edge_tail = p->ld_edge_tail;
+    a.row_order = p->row_order;
     TFGX_REQUIRE(p->edge_tail == nullptr ||
                      (p->x_tail != nullptr && p->ld_edge_tail >= p->F - p->f_main && p->ld_edge_tail % 4 == 0 &&
                       aligned_to(p->edge_tail, 16)),
@@ -526,6 +534,7 @@ extern "C" int tfgx_segment_reduce_f32(const tfgx_reduce_args* p, tfgx_stream_t 
     c.n_dst = p->n_hub_chunks; c.out = p->hub_scratch; c.ldo = p->F;
     c.op = is_max ? TFGX_MAX : TFGX_SUM; c.act = TFGX_ACT_NONE; c.accumulate = 0;
     c.self_coef = nullptr; c.bias = nullptr; c.add_x = nullptr; c.mean_count = nullptr; c.hub_threshold = 0;
+    c.row_order = nullptr;
     const bool sok = (p->F % 4 == 0) && aligned_to(p->hub_scratch, 16) && (p->ldx % 4 == 0) && aligned_to(p->x, 16);
     const bool sok2 = (p->F % 2 == 0) && aligned_to(p->hub_scratch, 8) && (p->ldx % 2 == 0) && aligned_to(p->x, 8);
     rc = launch_any(c, sok ? 4 : (sok2 ? 2 : 1), is_max, weighted, stream);
