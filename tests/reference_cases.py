@@ -368,7 +368,10 @@ _add("gcn", _gcn_inputs, _gcn_ref, _gcn_orc, _gcn_hip)
 # ---------------------------------------------------------------------------------------------------------------------
 GAT_CFGS = [dict(H=1, A=4, U=6), dict(H=4, A=8, U=16), dict(H=8, A=8, U=64), dict(H=8, A=64, U=64),
             dict(H=2, A=6, U=10, qact=None, kact=None, act=None), dict(H=4, A=8, U=5, split=False),
-            dict(H=3, A=12, U=9, bias=False)]
+            dict(H=3, A=12, U=9, bias=False),
+            # head geometries that reach the fast kernels zero-padded / in blocks (nn/conv/gat._kernel_widths)
+            dict(H=1, A=1, U=41), dict(H=8, A=256, U=64), dict(H=2, A=2, U=82), dict(H=1, A=8, U=300, act=None),
+            dict(H=4, A=12, U=20), dict(H=4, A=20, U=10, split=False)]
 
 
 def _gat_name(c):
