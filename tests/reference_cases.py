@@ -643,6 +643,7 @@ def _prop_inputs():
              ck=[glorot(rng, 14, 5) for _ in range(3)], cb=small_bias(rng, 5),
              lk=[glorot(rng, 14, 6) for _ in range(3)], lb=[small_bias(rng, 6) for _ in range(3)],
              gin_w=glorot(rng, 14, 8))
+    g.update(kw30=glorot(rng, 14, 30), bw30=small_bias(rng, 30))      # drawn last: earlier arrays keep their values
     return g
 
 
@@ -652,6 +653,7 @@ def _prop_ref(R, g):
     out = {}
     for k in (1, 3):
         out["sgc-k{}".format(k)] = _np(nn.sgc(x, ei, w, k, g["k9"], g["b9"], relu))
+    out["sgc-widening"] = _np(nn.sgc(x, ei, w, 2, g["kw30"], g["bw30"], relu))
     out["tagcn"] = _np(nn.tagcn(x, ei, w, 3, g["tk"], g["tb"], relu))
     out["appnp"] = _np(nn.appnp(x, ei, w, g["ks"], g["bs"], relu, None, k=6, alpha=0.15))
     out["ssgc"] = _np(nn.ssgc(x, ei, w, g["ks"], g["bs"], k=5, alpha=0.2))
@@ -673,6 +675,7 @@ def _prop_orc(o, g):
     out = {}
     for k in (1, 3):
         out["sgc-k{}".format(k)] = o.sgc(x, ei, w, k, g["k9"], g["b9"], "relu")
+    out["sgc-widening"] = o.sgc(x, ei, w, 2, g["kw30"], g["bw30"], "relu")
     out["tagcn"] = o.tagcn(x, ei, w, 3, g["tk"], g["tb"], "relu")
     out["appnp"] = o.appnp(x, ei, w, g["ks"], g["bs"], "relu", None, k=6, alpha=0.15)
     out["ssgc"] = o.ssgc(x, ei, w, g["ks"], g["bs"], k=5, alpha=0.2)
@@ -694,6 +697,7 @@ def _prop_hip(T, g):
     out = {}
     for k in (1, 3):
         out["sgc-k{}".format(k)] = _np(nn.sgc(x, ei, w, k, g["k9"], g["b9"], relu))
+    out["sgc-widening"] = _np(nn.sgc(x, ei, w, 2, g["kw30"], g["bw30"], relu))
     out["tagcn"] = _np(nn.tagcn(x, ei, w, 3, g["tk"], g["tb"], relu))
     out["appnp"] = _np(nn.appnp(x, ei, w, g["ks"], g["bs"], relu, None, k=6, alpha=0.15))
     out["ssgc"] = _np(nn.ssgc(x, ei, w, g["ks"], g["bs"], k=5, alpha=0.2))
