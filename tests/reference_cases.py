@@ -41,13 +41,19 @@ def _add(*a, **k):
 # ---------------------------------------------------------------------------------------------------------------------
 # seeded inputs
 # ---------------------------------------------------------------------------------------------------------------------
-def graph(n, e, f, seed, self_loops=0, isolated=0, weighted=True):
+def graph(n, e, f, seed, self_loops=0, isolated=0, weighted=True, forbid_self_loops=False):
     """Random multigraph: duplicates allowed, ``self_loops`` explicit (i,i) edges, the last ``isolated`` nodes receive
-    no edge (empty segments)."""
+    no edge (empty segments).  ``forbid_self_loops`` also removes the (i,i) pairs the uniform draw produces by chance, so
+    the graph holds NO diagonal entry at all (cases whose result must not depend on how ``SparseMatrix.add_diag`` treats
+    an existing diagonal: add-to vs replace)."""
     rng = np.random.Generator(np.random.PCG64(seed))
     hi = n - isolated
     row = rng.integers(0, hi, size=e, dtype=np.int32)
     col = rng.integers(0, n, size=e, dtype=np.int32)
+    if forbid_self_loops:
+        assert not self_loops
+        col = np.where(col == row, (col + 1) % n, col).astype(np.int32)
+        assert not (col == row).any()
     if self_loops:
         d = rng.integers(0, hi, size=self_loops, dtype=np.int32)
         row, col = np.concatenate([row, d]), np.concatenate([col, d])
@@ -281,6 +287,16 @@ def _norm_hip(T, g):
 _add("gcn_norm_adj", _norm_inputs, _norm_ref, _norm_orc, _norm_hip)
 
 
+def _norm_inputs_nodiag():
+    return graph(70, 500, 3, seed=113, isolated=4, forbid_self_loops=True)
+
+
+_add("gcn_norm_adj_no_diagonal", _norm_inputs_nodiag, _norm_ref, _norm_orc, _norm_hip,
+     note="same 11 configurations on a graph with NO diagonal entry: independent of whether tf_sparse's add_diag adds "
+          "to or replaces an existing diagonal (the one [external] semantic that changes numbers, SURVEY.md 8c; call "
+          "sites nn/conv/gcn.py:72-98)")
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # (a8-a10) gcn functional + SparseMatrix surface — nn/conv/gcn.py:225-290
 # ---------------------------------------------------------------------------------------------------------------------
@@ -361,6 +377,18 @@ def _gcn_hip(T, g):
 
 
 _add("gcn", _gcn_inputs, _gcn_ref, _gcn_orc, _gcn_hip)
+
+
+def _gcn_inputs_nodiag():
+    g = graph(200, 1800, 24, seed=114, isolated=6, forbid_self_loops=True)
+    g["kernel"], g["bias"] = glorot(g["rng"], 24, 10), small_bias(g["rng"], 10)
+    g["wide_kernel"], g["wide_bias"] = glorot(g["rng"], 24, 40), small_bias(g["rng"], 40)
+    g["bias_f"] = small_bias(g["rng"], 24)
+    return g
+
+
+_add("gcn_no_diagonal", _gcn_inputs_nodiag, _gcn_ref, _gcn_orc, _gcn_hip,
+     note="the gcn case on a graph with NO diagonal entry (add_diag reading-independent twin)")
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -556,6 +584,112 @@ def _layer_hip(T, g, golden):
 
 _add("layers", _layer_inputs, _layer_ref, None, _layer_hip,
      note="the hip executor takes the golden dict as third argument (weights come from the reference's own variables)")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[0] and configs[1]: the 2-layer GCN MODEL of demo/demo_gcn.py:18-32 (GCN(16, relu) -> GCN(classes),
+# Dropout between them: identity at inference) at Cora shape and at ogbn-arxiv shape, through the reference's own
+# tfg.layers.GCN with a shared graph cache.  Synthetic inputs per SURVEY.md 8d (no dataset downloads here).
+# ---------------------------------------------------------------------------------------------------------------------
+MODEL_SHAPES = {"model_gcn_cora": dict(n=2708, e=10556, f=1433, hidden=16, classes=7, seed=301, bow=True, rows=None),
+                "model_gcn_arxiv": dict(n=170000, e=1200000, f=128, hidden=256, classes=40, seed=302, bow=False,
+                                        rows=2000)}
+
+
+def directed_pairs(rng, n, e):
+    """E/2 uniform pairs, a == b dropped, emitted [all (a,b) | all (b,a)] (utils/graph_utils.py:186-190)."""
+    a = rng.integers(0, n, size=e // 2, dtype=np.int64)
+    b = rng.integers(0, n, size=e // 2, dtype=np.int64)
+    keep = a != b
+    a, b = a[keep], b[keep]
+    return np.stack([np.concatenate([a, b]), np.concatenate([b, a])]).astype(np.int32)
+
+
+def _model_inputs(name):
+    def make():
+        c = MODEL_SHAPES[name]
+        rng = np.random.Generator(np.random.PCG64(c["seed"]))
+        ei = directed_pairs(rng, c["n"], c["e"])
+        if c["bow"]:        # Cora-like: ~17 active words of 1433 per node, rows normalised to sum 1
+            x = (rng.random((c["n"], c["f"])) < 0.012).astype(np.float32)
+            x = x / np.maximum(x.sum(1, keepdims=True), 1.0)
+        else:
+            x = rng.standard_normal((c["n"], c["f"]), dtype=np.float32)
+        g = dict(n=c["n"], f=c["f"], x=x, ei=ei, w=np.ones(ei.shape[1], np.float32),    # Graph default: data/graph.py:53-56
+                 k0=glorot(rng, c["f"], c["hidden"]), b0=small_bias(rng, c["hidden"]),
+                 k1=glorot(rng, c["hidden"], c["classes"]), b1=small_bias(rng, c["classes"]),
+                 hidden=c["hidden"], classes=c["classes"])
+        g["rows"] = None if c["rows"] is None else np.sort(rng.permutation(c["n"])[:c["rows"]]).astype(np.int32)
+        return g
+    return make
+
+
+def _model_outputs(g, hidden, logits):
+    """What is stored / compared: the full logits at Cora shape; at arxiv shape (27 MB of logits) the sampled rows plus
+    float64 column sums of |.| over ALL rows of both layers' outputs (no cancellation: held to the same 1e-5 relative)."""
+    hidden, logits = _np(hidden), _np(logits)
+    out = {"hidden_col_abs_sum": np.abs(hidden.astype(np.float64)).sum(0),
+           "logits_col_abs_sum": np.abs(logits.astype(np.float64)).sum(0)}
+    if g["rows"] is None:
+        out["logits"] = logits
+    else:
+        out["rows"] = g["rows"]
+        out["logits_rows"] = logits[g["rows"]]
+        out["hidden_rows_head"] = hidden[g["rows"][:100]]
+    return out
+
+
+def _model_ref(R, g):
+    tf, tfg = R.tf, R.tfg
+
+    class GCNModel(tf.keras.Model):                   # demo/demo_gcn.py:18-32, verbatim structure
+
+        def __init__(self, *args, **kwargs):
+            super().__init__(*args, **kwargs)
+            self.gcn0 = tfg.layers.GCN(g["hidden"], activation=tf.nn.relu)
+            self.gcn1 = tfg.layers.GCN(g["classes"])
+            self.dropout = tf.keras.layers.Dropout(0.5)
+
+        def call(self, inputs, training=None, mask=None, cache=None):
+            x, edge_index, edge_weight = inputs
+            h = self.dropout(x, training=training)
+            h = self.gcn0([h, edge_index, edge_weight], cache=cache)
+            self.hidden = h
+            h = self.dropout(h, training=training)
+            h = self.gcn1([h, edge_index, edge_weight], cache=cache)
+            return h
+
+    model = GCNModel()
+    cache = {}
+    inputs = [g["x"], g["ei"], g["w"]]
+    model(inputs, cache=cache)                        # builds the variables and the cached normalised adjacency
+    for layer, k, b in ((model.gcn0, g["k0"], g["b0"]), (model.gcn1, g["k1"], g["b1"])):
+        layer.kernel.assign(k)
+        layer.bias.assign(b)
+    logits = model(inputs, cache=cache)
+    return _model_outputs(g, model.hidden, logits)
+
+
+def _model_orc(o, g):
+    h = o.gcn(g["x"], g["ei"], g["w"], g["k0"], g["b0"], "relu")
+    return _model_outputs(g, h, o.gcn(h, g["ei"], g["w"], g["k1"], g["b1"]))
+
+
+def _model_hip(T, g):
+    gcn0, gcn1 = T.layers.GCN(g["hidden"], activation=T.relu), T.layers.GCN(g["classes"])
+    cache = {}
+    x = T._lib.as_f32(g["x"])
+    gcn0._maybe_build([x])
+    gcn0.set_weights(kernel=g["k0"], bias=g["b0"])
+    h = gcn0([x, g["ei"], g["w"]], cache=cache)
+    gcn1._maybe_build([h])
+    gcn1.set_weights(kernel=g["k1"], bias=g["b1"])
+    return _model_outputs(g, h, gcn1([h, g["ei"], g["w"]], cache=cache))
+
+
+for _name in MODEL_SHAPES:
+    _add(_name, _model_inputs(_name), _model_ref, _model_orc, _model_hip, exact=["rows"],
+         note="BASELINE.json configs[{}]: 2-layer GCN model of demo/demo_gcn.py".format(0 if "cora" in _name else 1))
 
 
 # ---------------------------------------------------------------------------------------------------------------------

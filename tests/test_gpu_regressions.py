@@ -1,0 +1,141 @@
+# coding=utf-8
+"""Regression tests for the round-2 advisor findings: each one reproduces the reported misbehaviour."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_parity
+
+pytestmark = pytest.mark.gpu
+
+
+def _graph(oracle, n, e, f, seed):
+    ei = oracle.synthetic_edges(n, e, seed=seed)
+    rng = np.random.Generator(np.random.PCG64(seed + 1))
+    return rng.standard_normal((n, f)).astype(np.float32), ei, rng
+
+
+def _softmax_np(h):
+    h = h.astype(np.float64)
+    ex = np.exp(h - h.max(1, keepdims=True))
+    return (ex / ex.sum(1, keepdims=True)).astype(np.float32)
+
+
+@pytest.mark.parametrize("units", [41, 7, 43])
+@pytest.mark.parametrize("training", [False, True])
+def test_single_head_gat_row_wise_activation_sees_only_real_columns(tfg, oracle, units, training):
+    """GAT(41, num_heads=1) runs zero-padded to a multiple of four value columns (nn/conv/gat.py).  A ROW-WISE activation
+    (softmax over the class scores — the natural choice for the output layer this path targets) must run on the unpadded
+    result, as the reference applies it last (nn/conv/gat.py:119-120): each padded column would add exp(0) to the
+    denominator."""
+    x, ei, rng = _graph(oracle, 300, 3000, 24, seed=units)
+    wq, wk, wv = oracle.glorot_uniform(rng, 24, 1), oracle.glorot_uniform(rng, 24, 1), oracle.glorot_uniform(rng, 24, units)
+    bq, bk = np.float32([0.1]), np.float32([-0.05])
+    b = (rng.standard_normal(units) * 0.1).astype(np.float32)
+    act = lambda h: torch.softmax(h, dim=-1)       # noqa: E731
+    layer = tfg.layers.GAT(units, attention_units=1, num_heads=1, activation=act)
+    layer._maybe_build([x])
+    layer.set_weights(query_kernel=wq, query_bias=bq, key_kernel=wk, key_bias=bk, kernel=wv, bias=b)
+    if training:
+        layer.trainable(True)
+    got = layer([x, ei])
+    assert tuple(got.shape) == (300, units)
+    ref = oracle.gat(x, ei, wq, bq, "relu", wk, bk, "relu", wv, b, _softmax_np, num_heads=1)
+    assert_parity(got.detach().cpu().numpy(), ref, what="GAT({}) + softmax activation".format(units))
+    assert_parity(got.detach().sum(1).cpu().numpy(), np.ones(300), what="rows sum to one")
+    if training:
+        got.square().sum().backward()
+        assert layer.kernel.grad is not None and tuple(layer.kernel.grad.shape) == (24, units)
+
+
+@pytest.mark.parametrize("f_out", [7, 47, 20])
+def test_k_hop_convolutions_return_dense_tensors(tfg, oracle, f_out):
+    """The line-friendly row stride (F = 7 -> 8, 47 -> 48) is for the links INSIDE a k-hop chain; what the public
+    functions return is a dense [n, F] tensor (.view(-1) works, ld == F for DLPack / C-ABI consumers)."""
+    x, ei, rng = _graph(oracle, 200, 1500, 12, seed=f_out)
+    w = rng.uniform(0.5, 1.5, ei.shape[1]).astype(np.float32)
+    k9 = oracle.glorot_uniform(rng, 12, f_out)
+    outs = {
+        "sgc": tfg.nn.sgc(x, ei, w, 2, k9),
+        "appnp": tfg.nn.appnp(x, ei, w, [k9], [np.zeros(f_out, np.float32)], k=3),
+        "ssgc": tfg.nn.ssgc(x, ei, w, [k9], [np.zeros(f_out, np.float32)], k=3),
+        "tagcn": tfg.nn.tagcn(x, ei, w, 2, oracle.glorot_uniform(rng, 36, f_out)),
+        "chebynet": tfg.nn.chebynet(x, ei, w, 3, [oracle.glorot_uniform(rng, 12, f_out) for _ in range(3)]),
+        "ssgc-plain": tfg.nn.ssgc(rng.standard_normal((200, f_out)).astype(np.float32), ei, None, None, None, k=2),
+    }
+    for name, t in outs.items():
+        assert t.is_contiguous() and t.stride(0) == t.shape[1], name
+        t.view(-1)
+
+
+def test_set_weights_copies_the_callers_tensor(tfg, oracle):
+    """layer.set_weights(kernel=<float32 device tensor>) must not alias it: requires_grad_ / optimizer steps would write
+    into user data."""
+    x, ei, rng = _graph(oracle, 100, 600, 8, seed=3)
+    mine = torch.tensor(oracle.glorot_uniform(rng, 8, 5), device="cuda")
+    keep = mine.clone()
+    layer = tfg.layers.GCN(5)
+    layer._maybe_build([x])
+    layer.trainable(True)
+    layer.set_weights(kernel=mine)
+    assert layer.kernel.data_ptr() != mine.data_ptr() and not mine.requires_grad
+    opt = torch.optim.SGD(layer.parameters(), lr=0.5)
+    layer([x, ei], cache={}).square().sum().backward()
+    opt.step()
+    assert torch.equal(mine, keep) and not torch.equal(layer.kernel.detach(), keep)
+    # by attribute name too (MaxPoolGraphSage: variable "mlp_kernel" lives in attribute neighbor_mlp_kernel)
+    sage = tfg.layers.MaxPoolGraphSage(6)
+    sage._maybe_build([x])
+    new = torch.randn_like(sage.weights["mlp_kernel"])
+    sage.set_weights(mlp_kernel=new)
+    assert torch.equal(sage.neighbor_mlp_kernel, new) and sage.neighbor_mlp_kernel.data_ptr() != new.data_ptr()
+    assert sage.weights["mlp_kernel"] is sage.neighbor_mlp_kernel
+
+
+def test_plan_metadata_is_not_built_inside_a_capture(tfg, oracle):
+    """plan.row_order() / hub_info() synchronise on first use; when the first use happens under hipGraph capture they
+    return None (the launch runs in natural order / inline) instead of breaking the capture."""
+    import bench
+    from tf_geometric_amd.plan import CsrPlan, segment_reduce
+    L = tfg._lib
+    n = 1 << 14
+    ei = bench.rmat_edges(n, 400000, 3, torch.device("cuda"))
+    x = torch.randn(n, 16, device="cuda")
+    eager = segment_reduce(CsrPlan.build(ei, n, n), x, L.SUM)
+    plan = CsrPlan.build(ei, n, n)                      # fresh plan: nothing lazy computed yet
+    out = torch.empty_like(eager)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        segment_reduce(plan, x, L.SUM, out=out)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert_parity(out.cpu().numpy(), eager.cpu().numpy(), what="captured first use of a skewed plan")
+    assert plan.row_order() is not None and plan.hub_info() is not None       # computed by the next eager call
+
+
+def test_dynamic_lambda_max_converges_beyond_the_krylov_window(tfg, oracle):
+    """laplacian_max_eigenvalue: n far above the 96-step Arnoldi window; the Ritz residual is checked (restart when it is
+    not small) and the value agrees with a dense eigen-solve of the same Laplacian (the reference: ARPACK,
+    utils/graph_utils.py:884-909)."""
+    from tf_geometric_amd.nn.conv.propagation import chebynet_norm_edge, laplacian_max_eigenvalue
+    n = 1500
+    rng = np.random.Generator(np.random.PCG64(11))
+    a, b = rng.integers(0, n, 6000), rng.integers(0, n, 6000)
+    keep = a != b
+    lo, hi = np.minimum(a, b)[keep], np.maximum(a, b)[keep]
+    _, first = np.unique(lo * n + hi, return_index=True)
+    lo, hi = lo[first], hi[first]
+    ei = np.stack([np.concatenate([lo, hi]), np.concatenate([hi, lo])]).astype(np.int32)
+    wu = rng.uniform(0.5, 1.5, lo.size).astype(np.float32)
+    w = np.concatenate([wu, wu])
+    for nt in ("sym", "rw", None):
+        got = laplacian_max_eigenvalue(chebynet_norm_edge(ei, n, w, nt), nt)
+        ref = oracle.laplacian_max_eigenvalue(ei, n, w, nt)
+        info = laplacian_max_eigenvalue.last
+        assert info["rel_residual"] <= 1e-6 or info["steps"] >= n, info
+        assert abs(got - ref) <= 1e-4 * abs(ref), (nt, got, ref, info)
+    # a tiny window forces restarts and still converges
+    got = laplacian_max_eigenvalue(chebynet_norm_edge(ei, n, w, "sym"), "sym", steps=12, restarts=40)
+    assert laplacian_max_eigenvalue.last["restarts"] >= 1
+    assert abs(got - oracle.laplacian_max_eigenvalue(ei, n, w, "sym")) <= 1e-4 * abs(got)

@@ -15,6 +15,7 @@ class Layer(object):
         self.built = False
         self.name = name or self.__class__.__name__
         self._weights = {}
+        self._attr_of = {}
         self._gen = None
         self._seed = seed
         self._trainable = False
@@ -44,15 +45,18 @@ class Layer(object):
             # `k` is the VARIABLE name the reference registered with add_weight (what a checkpoint stores); the python
             # attribute may differ (MaxPoolGraphSage: variable "mlp_kernel" lives in self.neighbor_mlp_kernel,
             # layers/conv/graph_sage.py:322-328).  Attribute names are accepted too.
-            attr = None
-            if k in self._weights:
+            attr = self._attr_of.get(k)
+            if attr is None and k in self._weights and self._weights[k] is not None:
                 old = self._weights[k]
-                attr = next((a for a, val in self.__dict__.items() if val is old), None)
+                attr = next((a for a, val in self.__dict__.items() if val is old and a != "_weights"), None)
             if attr is None and hasattr(self, k):
                 attr = k
             if attr is None:
                 raise KeyError("{} has no weight named {}".format(self.name, k))
-            t = L.as_f32(v).contiguous()
+            self._attr_of[k] = attr              # variable name -> python attribute, resolved once
+            # the layer OWNS its weights: a caller's float32 device tensor is copied, never aliased (an optimizer step
+            # or requires_grad_ must not write into user data)
+            t = L.as_f32(v).detach().clone().contiguous()
             if self._trainable:
                 t.requires_grad_(True)
             name = k if k in self._weights else next((n for n, val in self._weights.items()

@@ -12,7 +12,7 @@ import math
 import torch
 
 from ... import _lib as L
-from ...activations import resolve as _resolve_act
+from ...activations import resolve as _resolve_act, relu as relu_act
 from ...plan import CsrPlan, gemm_bias_act, gather_friendly_empty
 from ...sparse import sparse_features, sparse_dense_matmul
 from ... import autograd as AG
@@ -227,9 +227,15 @@ def gat(x, edge_index,
         if bias is not None:
             bf = L.as_f32(bias)
             bias_p = torch.cat([bf, bf.new_zeros(pad)])
+        # only an ELEMENTWISE activation may see the zero columns: the fused code (None / relu) rides into the padded
+        # call, a caller-supplied callable (softmax, log_softmax, a normalisation ...) runs on the unpadded result, as
+        # the reference applies it (gat.py:119-120)
+        act_code, act_post = _resolve_act(activation)
         h = gat(x, edge_index, query_kernel, query_bias, query_activation, key_kernel, key_bias, key_activation,
-                kernel_p, bias_p, activation, 1, split_value_heads, edge_drop_rate, training, cache)
-        return h[:, :U_out].contiguous()
+                kernel_p, bias_p, relu_act if act_code == L.ACT_RELU else None, 1, split_value_heads, edge_drop_rate,
+                training, cache)
+        h = h[:, :U_out].contiguous()
+        return act_post(h) if act_post is not None else h
     xs = sparse_features(x)
     x = xs if xs is not None else L.as_f32(x)
     n = int(x.shape[0])

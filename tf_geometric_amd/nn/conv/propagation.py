@@ -51,10 +51,14 @@ def _features(x, densify=False):
 
 
 def _finish(h, bias, activation):
+    """+ bias, activation — and the PUBLIC result is always a dense [n, F] tensor: the padded row stride of
+    gather_friendly_empty is for the intermediate links of a k-hop chain only (a [:, :F] view of a wider buffer would
+    break .view(-1), DLPack and any consumer assuming ld == F)."""
     act, post = _resolve_act(activation)
     if bias is not None:
         h = h + L.as_f32(bias)
-    return AG.apply_activation(h, act, post)
+    h = AG.apply_activation(h, act, post)
+    return h if h.is_contiguous() else h.contiguous()
 
 
 def _normed(x, edge_index, edge_weight, cache, **norm_kwargs):
@@ -234,7 +238,7 @@ def chebynet_norm_edge(edge_index, num_nodes, edge_weight=None, normalization_ty
     return out
 
 
-def laplacian_max_eigenvalue(lap, normalization_type="sym", steps=96):
+def laplacian_max_eigenvalue(lap, normalization_type="sym", steps=96, tol=1e-6, restarts=6):
     """Largest-magnitude eigenvalue of the Laplacian held in plan form (graph_utils.LaplacianMaxEigenvalue, :884-909,
     which hands scipy's ARPACK a scipy matrix: eigsh for 'sym' / 'rw', eigs for None, k = 1, which = 'LM').
 
@@ -271,32 +275,54 @@ def laplacian_max_eigenvalue(lap, normalization_type="sym", steps=96):
         out = segment_reduce(plan, h.contiguous(), L.SUM, w_csr=lap.w_csr, self_coef=lap.self_coef)
         return out if scale_r is None else out * scale_r
 
-    # Arnoldi (= Lanczos with full re-orthogonalisation when the operator is symmetric): H = V^T L V, upper Hessenberg
+    # Arnoldi (= Lanczos with full re-orthogonalisation when the operator is symmetric): H = V^T L V, upper Hessenberg.
+    # Convergence is CHECKED, as ARPACK checks it: the Ritz pair (theta, V y) of the dominant eigenvalue has residual
+    # |L V y - theta V y| = |b_m * y_m| (last sub-diagonal entry times the last component of the Hessenberg eigenvector);
+    # while that exceeds tol * |theta| the iteration restarts from the Ritz vector (explicit restart), up to `restarts`
+    # times.  `laplacian_max_eigenvalue.last` records (restarts used, relative residual) for the tests.
     m = int(min(steps, n))
     g = torch.Generator(device="cpu")
     g.manual_seed(0)
     v = torch.randn((n, 1), generator=g, dtype=torch.float32).to(dev)
     v = v / v.norm()
-    basis = torch.zeros((n, m), dtype=torch.float32, device=dev)
-    H = np.zeros((m + 1, m), np.float64)
-    k = 0
-    for j in range(m):
-        basis[:, j] = v[:, 0]
-        wv = matvec(v)
-        V = basis[:, :j + 1]
-        h1 = V.t() @ wv
-        wv = wv - V @ h1
-        h2 = V.t() @ wv                                                  # second Gram-Schmidt pass
-        wv = wv - V @ h2
-        H[:j + 1, j] = (h1 + h2)[:, 0].double().cpu().numpy()
-        b_j = float(wv.norm().item())
-        k = j + 1
-        if b_j < 1e-7 or j == m - 1:
+    theta, rel = 2.0, 0.0
+    for attempt in range(restarts + 1):
+        basis = torch.zeros((n, m), dtype=torch.float32, device=dev)
+        H = np.zeros((m + 1, m), np.float64)
+        k, b_last = 0, 0.0
+        for j in range(m):
+            basis[:, j] = v[:, 0]
+            wv = matvec(v)
+            V = basis[:, :j + 1]
+            h1 = V.t() @ wv
+            wv = wv - V @ h1
+            h2 = V.t() @ wv                                                  # second Gram-Schmidt pass
+            wv = wv - V @ h2
+            H[:j + 1, j] = (h1 + h2)[:, 0].double().cpu().numpy()
+            b_j = float(wv.norm().item())
+            k = j + 1
+            b_last = b_j
+            if b_j < 1e-7:
+                b_last = 0.0                                                 # invariant subspace: the Ritz values are exact
+                break
+            if j == m - 1:
+                break
+            H[j + 1, j] = b_j
+            v = wv / b_j
+        ev, evec = np.linalg.eig(H[:k, :k])
+        i = int(np.argmax(np.abs(ev)))
+        theta = float(ev[i].real)
+        y = evec[:, i]
+        rel = abs(b_last * y[k - 1]) / max(abs(theta), 1e-30)
+        if rel <= tol or k >= n:
             break
-        H[j + 1, j] = b_j
-        v = wv / b_j
-    ev = np.linalg.eigvals(H[:k, :k])
-    return float(ev[np.argmax(np.abs(ev))].real)
+        ritz = basis[:, :k] @ torch.as_tensor(np.ascontiguousarray(y.real), dtype=torch.float32, device=dev).unsqueeze(1)
+        nrm = float(ritz.norm().item())
+        if nrm < 1e-20:
+            break
+        v = ritz / nrm
+    laplacian_max_eigenvalue.last = dict(restarts=attempt, rel_residual=float(rel), steps=k)
+    return theta
 
 
 def _csr_to_edge_order(plan, attr_csr):

@@ -120,6 +120,9 @@ class CsrPlan(object):
         else None.  Kernels that give every row a lane group walk the rows in this order so that the rows sharing a wave
         have similar lengths (GAT layer on R-MAT graphs: 13-16 %); results do not depend on it.  Computed once per plan."""
         if getattr(self, "_row_order", None) is None:
+            if torch.cuda.is_current_stream_capturing():
+                return None      # the skew test synchronises (deg.max().item()): never inside a hipGraph capture —
+                                 # results do not depend on the order, and the next eager call computes and keeps it
             order = False
             if self.n_dst > 0 and self.num_edges > 0:
                 deg = self.in_degree()
@@ -133,6 +136,8 @@ class CsrPlan(object):
         Small control-plane metadata, computed once per plan:
         (hub_rows, chunk_ptr, chunk_begin, chunk_end, chunk_row)."""
         if self._hub is None:
+            if torch.cuda.is_current_stream_capturing():
+                return None      # building the lists synchronises; long rows then run inline (same sums, slower)
             thr, chunk = hub_policy(self.num_edges, self.n_dst)
             self.hub_threshold = thr
             self._hub = build_hub_lists(self.row_ptr[:-1], self.row_ptr[1:], thr, chunk) or False
