@@ -622,3 +622,70 @@ def test_hub_rows_in_the_backward_passes(tfg, oracle, threshold):
         assert_parity(xt2.grad.cpu().numpy(), xr2.grad.numpy(), tol=2e-5, what="hub max d/dx")
     finally:
         P.HUB_THRESHOLD, P.HUB_CHUNK = old
+
+
+@pytest.mark.parametrize("op", ["sum", "mean", "max"])
+@pytest.mark.parametrize("weighted", [True, False])
+def test_hip_gradients_match_tf_registered_gradients(tfg, op, weighted):
+    """The HIP backward vs oracle/tf_gradients.py — TensorFlow's REGISTERED gradients (math_grad.py:
+    _UnsortedSegmentSumGrad, _UnsortedSegmentMinOrMaxGrad, _GatherV2Grad ...) chained along the reference's forward lines
+    (nn/kernel/map_reduce.py:45-73), pinned by hand-derived known answers in tests/test_tf_gradient_kats.py.  Graph with
+    duplicated edges and quantised features (many tied maxima) and empty rows."""
+    from oracle import tf_gradients as G
+    rng = np.random.Generator(np.random.PCG64(31))
+    n, e, f = 400, 5000, 24
+    ei = rng.integers(0, n - 20, size=(2, e)).astype(np.int32)
+    ei = np.concatenate([ei, ei[:, :1500]], axis=1)
+    x = (np.round(rng.standard_normal((n, f)) * 2) / 2).astype(np.float32)
+    w = (rng.integers(1, 3, ei.shape[1]) * 0.5).astype(np.float32) if weighted else None
+    g = rng.standard_normal((n, f)).astype(np.float32)
+    xt = torch.tensor(x, device="cuda", requires_grad=True)
+    wt = torch.tensor(w, device="cuda", requires_grad=True) if weighted else None
+    mapper = tfg.nn.gcn_mapper if weighted else tfg.nn.identity_mapper
+    out = tfg.nn.aggregate_neighbors(xt, ei, wt, mapper, getattr(tfg.nn, op + "_reducer"), tfg.nn.sum_updater)
+    out.backward(torch.tensor(g, device="cuda"))
+    ref_out, dx, dw = G.aggregate_neighbors_grad(x, ei, w, op, "sum", g)
+    assert_parity(out.detach().cpu().numpy(), ref_out, what="forward " + op)
+    assert_parity(xt.grad.cpu().numpy(), dx, tol=2e-5, what="d/dx vs TF registered gradients, " + op)
+    if weighted:
+        assert_parity(wt.grad.cpu().numpy(), dw, tol=2e-5, what="d/dw vs TF registered gradients, " + op)
+
+
+def test_hip_segment_softmax_gradient_matches_tf_registered_gradients(tfg):
+    """nn/kernel/segment.py:26-33 under tf.GradientTape: max under stop_gradient, +1e-8 in the denominator."""
+    from oracle import tf_gradients as G
+    rng = np.random.Generator(np.random.PCG64(32))
+    n, e = 200, 3000
+    ids = rng.integers(0, n - 10, size=e).astype(np.int32)
+    for shape in ((e,), (e, 4)):
+        s = (rng.standard_normal(shape) * 3).astype(np.float32)
+        g = rng.standard_normal(shape).astype(np.float32)
+        st = torch.tensor(s, device="cuda", requires_grad=True)
+        score = tfg.nn.segment_softmax(st, ids, n)
+        score.backward(torch.tensor(g, device="cuda"))
+        ref_score, ds = G.segment_softmax_grad(s, ids, n, g)
+        assert_parity(score.detach().cpu().numpy(), ref_score, what="segment_softmax")
+        assert_parity(st.grad.cpu().numpy(), ds, tol=2e-5, what="d segment_softmax / d data vs TF registered gradients")
+
+
+def test_hip_gcn_layer_gradients_match_tf_registered_gradients(tfg, oracle):
+    from oracle import tf_gradients as G
+    x, ei, w, rng = _graph(oracle, seed=9)
+    n, f = x.shape
+    units = 12
+    k = oracle.glorot_uniform(rng, f, units)
+    b = (rng.standard_normal(units) * 0.1).astype(np.float32)
+    layer = tfg.layers.GCN(units, activation=tfg.relu)
+    layer._maybe_build([x])
+    layer.set_weights(kernel=k, bias=b)
+    layer.trainable(True)
+    xt = torch.tensor(x, device="cuda", requires_grad=True)
+    out = layer([xt, ei, w], cache={})
+    g = rng.standard_normal((n, units)).astype(np.float32)
+    out.backward(torch.tensor(g, device="cuda"))
+    idx, nw = oracle.gcn_norm_adj(ei, w, n)
+    ref_out, dx, dk, db = G.gcn_layer_grad(x, idx, nw, k, b, True, g)
+    assert_parity(out.detach().cpu().numpy(), ref_out, what="gcn forward")
+    assert_parity(xt.grad.cpu().numpy(), dx, tol=2e-5, what="gcn d/dx")
+    assert_parity(layer.kernel.grad.cpu().numpy(), dk, tol=2e-5, what="gcn d/dkernel")
+    assert_parity(layer.bias.grad.cpu().numpy(), db, tol=2e-5, what="gcn d/dbias")

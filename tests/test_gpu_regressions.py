@@ -133,7 +133,7 @@ def test_dynamic_lambda_max_converges_beyond_the_krylov_window(tfg, oracle):
         got = laplacian_max_eigenvalue(chebynet_norm_edge(ei, n, w, nt), nt)
         ref = oracle.laplacian_max_eigenvalue(ei, n, w, nt)
         info = laplacian_max_eigenvalue.last
-        assert info["rel_residual"] <= 1e-6 or info["steps"] >= n, info
+        assert info["rel_residual"] <= 1e-5 or info["steps"] >= n, info
         assert abs(got - ref) <= 1e-4 * abs(ref), (nt, got, ref, info)
     # a tiny window forces restarts and still converges
     got = laplacian_max_eigenvalue(chebynet_norm_edge(ei, n, w, "sym"), "sym", steps=12, restarts=40)
