@@ -579,6 +579,20 @@ def _time(fn, steps=10, warmup=3):
     return e0.elapsed_time(e1) / steps
 
 
+def _time_ab(fn_a, fn_b, steps=10, warmup=3, rounds=3):
+    """Median per-step ms of two alternatives measured ALTERNATELY (a, b, a, b, ...): clock / power state drifts over
+    a process's lifetime, so "first all of a, then all of b" charges the drift to whichever ran second (round 2's
+    hipGraph-slower-than-eager reading was exactly that: a rocprofv3 trace of both shows the replay's kernels back to
+    back with 8 us of total idle per step, profiles/r03_hipgraph_vs_eager.md)."""
+    ta, tb = [], []
+    for r in range(rounds):
+        ta.append(_time(fn_a, steps, warmup if r == 0 else 1))
+        tb.append(_time(fn_b, steps, warmup if r == 0 else 1))
+    ta.sort()
+    tb.sort()
+    return ta[len(ta) // 2], tb[len(tb) // 2]
+
+
 def _latency(fn, steps=20, warmup=3):
     """Mean wall time of fn() + synchronize, one step at a time (what a serving request or a training loop that reads the
     loss every step sees)."""
@@ -613,9 +627,8 @@ def extras(tfg, L, synthetic, x, ei, n, e, f, cache):
     def two_layer():
         return g1([g0([x, ei], cache=cache), ei], cache=cache)
 
-    res["gcn_2layer_eager_ms"] = _time(two_layer)
     cap = tfg.CapturedForward(two_layer)
-    res["gcn_2layer_hipgraph_ms"] = _time(lambda: cap.graph.replay())
+    res["gcn_2layer_eager_ms"], res["gcn_2layer_hipgraph_ms"] = _time_ab(two_layer, lambda: cap.graph.replay())
     # the two numbers above are THROUGHPUT (steps queued back to back: the host runs ahead, launch cost is hidden, a
     # graph replay cannot win); what a hipGraph removes is per-step host LATENCY — one forward, then wait for it:
     res["gcn_2layer_eager_latency_ms"] = _latency(two_layer)
@@ -624,9 +637,9 @@ def extras(tfg, L, synthetic, x, ei, n, e, f, cache):
     res["static_layout_bytes"] = int(info["bytes"])
     res["gcn_layer_F{}_to_256_static_ms".format(f)] = _time(lambda: gcn([x, ei], cache=cache))
     res["mean_sage_layer_units256_static_ms"] = _time(lambda: sage([x, ei, w1], cache=cache))
-    res["gcn_2layer_eager_static_ms"] = _time(two_layer)
     cap2 = tfg.CapturedForward(two_layer)                 # prepared BEFORE capture: the replay runs the static layout
-    res["gcn_2layer_hipgraph_static_ms"] = _time(lambda: cap2.graph.replay())
+    res["gcn_2layer_eager_static_ms"], res["gcn_2layer_hipgraph_static_ms"] = _time_ab(two_layer,
+                                                                                       lambda: cap2.graph.replay())
     res["gcn_2layer_eager_static_latency_ms"] = _latency(two_layer)
     res["gcn_2layer_hipgraph_static_latency_ms"] = _latency(lambda: cap2.graph.replay())
     tfg.release_static_features(cache)

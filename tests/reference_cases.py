@@ -760,10 +760,7 @@ _add("graph_utils_laplacian_reindex", _gutil_inputs,
      lambda R, d: _gutil_run(R.tfg.utils.graph_utils, d), None, lambda T, d: _gutil_run(T.utils, d),
      exact=["reindexed", "adj_norm-cache-hit"] + ["laplacian-{}-{}-index".format(nt, t) for nt in ("sym", "rw", None)
                                                   for t in ("sym_graph", "loops")]
-           + ["adj_norm-{}-index".format(a) for a in (False, True)],
-     key_tol={"laplacian-None-loops-w": 2e-5, "laplacian-None-sym_graph-w": 2e-5},
-     note="get_laplacian(None) subtracts a weight from a degree (a sum of ~10 weights): one fp32 rounding of the sum "
-          "order shows at 1e-5 relative to the difference")
+           + ["adj_norm-{}-index".format(a) for a in (False, True)])
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -849,9 +846,12 @@ def _prop_hip(T, g):
     return out
 
 
-_add("propagation_convs", _prop_inputs, _prop_ref, _prop_orc, _prop_hip, tol=2e-5, key_tol={"chebynet-None": 2e-4, "lambda_max-None": 1e-4},
-     note="k-hop chains re-associate k fp32 SpMMs (2e-5); chebynet(normalization_type=None) applies the UN-normalised "
-          "Laplacian twice: terms of magnitude 1e4 cancel, so the fp32 reference itself carries ~1e-4 absolute noise")
+_add("propagation_convs", _prop_inputs, _prop_ref, _prop_orc, _prop_hip, key_tol={"chebynet-None": 2e-4},
+     note="ONE widened output: chebynet(normalization_type=None) applies the UN-normalised Laplacian twice — terms of "
+          "magnitude 1e4 cancel, and the reference's OWN fp32 output is 8x the 1e-5 band away from the float64 value "
+          "(tests/test_oracle_vs_reference.py::test_the_one_widened_tolerance_is_inherent_to_fp32).  Everything else, "
+          "k-hop chains included, is held to the plain band (round 2's blanket 2e-5 was not needed: the HIP path sits at "
+          "<= 0.11 of the band on every other output, profiles/r03_golden_margin.jsonl)")
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -247,39 +247,16 @@ def test_reddit_gat_sampled_rows_match_oracle(tfg, oracle, reddit, attention_uni
     x_np = r["x"].cpu().numpy()
     ref = oracle.gat(x_np, ei_sub, wq, bq, "relu", wk, bk, "relu", wv, b, "relu", num_heads=H)
     rows_np = rows.cpu().numpy()
-    # Band: 1e-5 + 1e-5*|ref|, plus the documented fp32 term: exp() turns the ABSOLUTE rounding error of a
-    # score into RELATIVE error of its weight.  A score is a product of two 602-term fp32 dot products (Q, K: a few ulp
-    # each), so delta_s <= c * eps * |s| with c = 8, and the output moves by at most delta_s_max * sum_e alpha_e |v_e|.
-    # With d_head = 1 (the demo's literal layer) scores reach |s| ~ 25; with d_head = 8 they stay ~ 5.
-    xd = x_np.astype(np.float64)
-    Q = np.maximum(xd @ wq.astype(np.float64) + bq, 0)
-    K = np.maximum(xd @ wk.astype(np.float64) + bk, 0)
-    V = np.abs(xd @ wv.astype(np.float64))
-    d, dv = A // H, U // H
-    ar = np.arange(n, dtype=np.int64)
-    e_dst = np.concatenate([ei_sub[0].astype(np.int64), rows_np])
-    e_src = np.concatenate([ei_sub[1].astype(np.int64), rows_np])        # + the appended self-loop edges
-    pos = np.searchsorted(rows_np, e_dst)
-    extra = np.zeros((rows_np.size, U))
-    for h in range(H):
-        s = (Q[e_dst, h * d:(h + 1) * d] * K[e_src, h * d:(h + 1) * d]).sum(1) / np.sqrt(d)
-        smax = np.full(rows_np.size, -np.inf)
-        np.maximum.at(smax, pos, s)
-        sabs = np.zeros(rows_np.size)
-        np.maximum.at(sabs, pos, np.abs(s))
-        ex = np.exp(s - smax[pos])
-        den = np.zeros(rows_np.size)
-        np.add.at(den, pos, ex)
-        alpha = ex / den[pos]
-        acc = np.zeros((rows_np.size, dv))
-        np.add.at(acc, pos, alpha[:, None] * V[e_src, h * dv:(h + 1) * dv])
-        extra[:, h * dv:(h + 1) * dv] = (8 * 6e-8 * sabs)[:, None] * acc
-    _ = ar
-    refs = ref[rows_np].astype(np.float64)
-    err = np.abs(got.astype(np.float64) - refs)
-    band = 1e-5 + 1e-5 * np.abs(refs) + extra
-    assert (err <= band).all(), "Reddit-shape GAT A={}: max excess {:.3e}".format(A, float((err - band).max()))
-    assert float(extra.max()) < (1e-4 if A == 8 else 5e-5), float(extra.max())   # the widening itself stays small
+    # The PLAIN band of north_star, no widening (round 2 widened it by up to 1e-4 at d_head = 1, where exp() turns the
+    # absolute error of a score — a product of two 602-term fp32 dot products — into relative error of its weight).
+    # What it took: two-level accumulation of long-K projections in the MFMA GEMM (csrc/tfgx_gemm.hip, kTwoLevel);
+    # tools/reddit_gat_attribution.py showed the excess came from the Q / K projections' k-ordered fp32 chain (the same
+    # error hipBLASLt's fp32 GEMM has), not from the attention kernel: profiles/r03_reddit_gat_band.md.
+    assert_parity(got, ref[rows_np], what="Reddit-shape GAT A={} on 400 sampled rows".format(A))
+    # and the reference's OWN formulation in op-for-op fp32 (what a TF-CPU run computes) on the same sub-problem sits in
+    # the same band: neither side needs more than 1e-5 here
+    ref32 = oracle.gat(x_np, ei_sub, wq, bq, "relu", wk, bk, "relu", wv, b, "relu", num_heads=H, acc=np.float32)
+    assert_parity(ref32[rows_np], ref[rows_np], what="fp32 op-for-op reference formulation vs float64")
 
 
 def test_papers_shard_sampled_rows_match_oracle(tfg, oracle):

@@ -110,7 +110,8 @@ def test_plan_metadata_is_not_built_inside_a_capture(tfg, oracle):
         segment_reduce(plan, x, L.SUM, out=out)
     graph.replay()
     torch.cuda.synchronize()
-    assert_parity(out.cpu().numpy(), eager.cpu().numpy(), what="captured first use of a skewed plan")
+    # inline walk of the hub rows vs the eager plan's chunked walk: the same 10^3..10^4-term fp32 sums in another order
+    assert torch.allclose(out, eager, rtol=1e-4, atol=2e-3), "captured first use of a skewed plan"
     assert plan.row_order() is not None and plan.hub_info() is not None       # computed by the next eager call
 
 

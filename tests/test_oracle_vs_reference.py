@@ -140,3 +140,24 @@ def test_num_splits_rule_equals_reference(R):
             if isinstance(want, list):
                 want = [int(v) for v in want]
             assert got == want, (f, k, got, want)
+
+
+def test_the_one_widened_tolerance_is_inherent_to_fp32(oracle, golden):
+    """Every golden comparison uses the plain band 1e-5 + 1e-5*|ref| except propagation_convs::chebynet-None (2e-4).
+    Evidence that this widening is a property of fp32, not of the HIP path: the REFERENCE'S OWN fp32 output (the golden
+    vector) is itself several bands away from the float64-accumulated value of the same formula, while on every other
+    output of the case it sits well inside one band."""
+    case = rc.by_name("propagation_convs")
+    exact = case.orc(oracle, case.inputs())
+    widened = [k for k in exact if case.tol_of(k) != rc.TOL]
+    assert widened == ["chebynet-None"]
+    for k, v in exact.items():
+        ref32 = golden["propagation_convs::" + k].astype(np.float64)
+        v = np.asarray(v, np.float64)
+        ratio = float((np.abs(ref32 - v) / (1e-5 + 1e-5 * np.abs(v))).max())
+        if k in widened:
+            assert ratio > 3.0, (k, ratio)          # measured 9.1: the reference itself leaves the plain band
+        else:
+            assert ratio < 0.5, (k, ratio)
+    assert all(c.tol == rc.TOL for c in rc.CASES)
+    assert sum(len(c.key_tol) for c in rc.CASES) == 1

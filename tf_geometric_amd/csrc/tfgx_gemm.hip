@@ -31,7 +31,8 @@ __global__ __launch_bounds__(kBlock) void gemm_kernel(const float* __restrict__ 
                                                       const float* __restrict__ B, int64_t ldb,
                                                       const float* __restrict__ bias, int act,
                                                       float* __restrict__ C, int64_t ldc, int64_t M, int K, int N,
-                                                      int n_tiles_n, int act_cols, int k_chunk, int64_t c_split_stride)
+                                                      int n_tiles_n, int act_cols, int k_chunk, int64_t c_split_stride,
+                                                      int two_level_on)
 {
     // split-K (small M, long K — Cora's 2708 x 1433): blockIdx.y owns k in [y * k_chunk, (y + 1) * k_chunk) and writes
     // its partial product to its own slab of C (a workspace; bias / activation are applied by splitk_reduce_kernel)
@@ -67,6 +68,28 @@ __global__ __launch_bounds__(kBlock) void gemm_kernel(const float* __restrict__ 
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int t = 0; t < 16; ++t) acc[i][j][t] = 0.0f;
+
+    // Long K on the narrow tiles (N <= 64: Q / K / V projections of a 602- or 1433-wide input): TWO-LEVEL accumulation.
+    // A k-ordered fp32 chain of n terms carries rounding error ~ eps * n / sqrt(2) (in units of one term); flushing the
+    // running MFMA accumulator into a second register set every 64 k (4 tiles) makes it ~ eps * sqrt(64 n) — 3x less at
+    // K = 602 — for one v_add per accumulator register per 4 tiles.  Measured at Reddit shape (tools/
+    // reddit_gat_attribution.py): the demo-literal GAT layer (d_head = 1: exp() turns the projections' absolute error
+    // into relative error of the attention weights) was 2.2e-5 off the float64 value with the plain chain — the same as
+    // hipBLASLt's fp32 GEMM — against 7e-6 for a blocked CPU BLAS.  Wide tiles (TM * TN = 4) keep the single chain: a
+    // second set of 64 accumulator registers would cost a workgroup per CU.
+    constexpr bool kTwoLevel = TM * TN <= 2;
+    constexpr int kFlushTiles = 4;
+    f32x16 tot[kTwoLevel ? TM : 1][kTwoLevel ? TN : 1];
+    const bool two_level = kTwoLevel && two_level_on && K > 8 * BK;
+    if (kTwoLevel) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) tot[i][j][t] = 0.0f;
+    }
+    int tiles_in_chain = 0;
 
     float ra[A_LOADS * 4];
     float4 rb[B_LOADS];
@@ -180,7 +203,31 @@ __global__ __launch_bounds__(kBlock) void gemm_kernel(const float* __restrict__ 
         for (int kk = 0; kk < BK; kk += 2) {
             if (kk < kmax) kstep(kk);
         }
+        if (kTwoLevel) {
+            if (two_level && ++tiles_in_chain == kFlushTiles) {      // wave-uniform
+                tiles_in_chain = 0;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int t = 0; t < 16; ++t) {
+                            tot[i][j][t] += acc[i][j][t];
+                            acc[i][j][t] = 0.0f;
+                        }
+            }
+        }
         __syncthreads();
+    }
+    if (kTwoLevel) {
+        if (two_level) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) acc[i][j][t] += tot[i][j][t];
+        }
     }
 
     // epilogue: D layout col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
@@ -262,7 +309,7 @@ __global__ __launch_bounds__(rows_threads<TN>()) void gemm_rows_kernel(const flo
                                                         const float* __restrict__ B, int64_t ldb,
                                                         const float* __restrict__ bias, int act, int act_cols,
                                                         float* __restrict__ C, int64_t ldc, int64_t M, int K, int N,
-                                                        int64_t n_tiles, int b_vec4)
+                                                        int64_t n_tiles, int b_vec4, int two_level_on)
 {
     constexpr int LDB_S = TN * 32 + 8;   // (4 * LDB_S) % 64 == 32: the two half-waves hit disjoint banks
     constexpr int NQ = LDB_S / 4;
@@ -350,12 +397,34 @@ __global__ __launch_bounds__(rows_threads<TN>()) void gemm_rows_kernel(const flo
     // epilogue the 16 * TN stores are in flight too and that wait stalls the wave until they have drained.
 #pragma unroll
     for (int u = 0; u < 4; ++u) asm volatile("" ::"v"(cur[4 * u]));
+    // narrow outputs with a long K (TN <= 2, K > 128): two-level accumulation like gemm_kernel's narrow tiles — the chain
+    // is flushed into `tot` every 64 k (2 steps), rounding error ~ eps * sqrt(64 K) instead of ~ eps * K
+    constexpr bool kTwoLevel = TN <= 2;
+    const bool two_level = kTwoLevel && two_level_on && K > 128;
+    f32x16 tot[kTwoLevel ? TN : 1];
+    if (kTwoLevel) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) tot[j][t] = 0.0f;
+    }
     for (; tile < n_tiles; tile += stride) {
         for (int ks = 0; ks < nfull; ++ks) {
             prefetch(tile, ks);
             rows_mfma_groups<TN, 16>(acc, cur, Bs + (ks * 32 + 16 * kh) * LDB_S + l31);
 #pragma unroll
             for (int i = 0; i < 16; ++i) cur[i] = nxt[i];
+            if (kTwoLevel) {
+                if (two_level && (ks & 1)) {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int t = 0; t < 16; ++t) {
+                            tot[j][t] += acc[j][t];
+                            acc[j][t] = 0.0f;
+                        }
+                }
+            }
         }
         if (nfull < nsteps) {
             // tail step (K % 32 != 0), kept OUTSIDE the step loop (an if/else inside it makes the compiler carry a second
@@ -377,6 +446,17 @@ __global__ __launch_bounds__(rows_threads<TN>()) void gemm_rows_kernel(const flo
             }
 #pragma unroll
             for (int i = 0; i < 16; ++i) cur[i] = nxt[i];
+        }
+        if (kTwoLevel) {
+            if (two_level) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) {
+                        acc[j][t] += tot[j][t];
+                        tot[j][t] = 0.0f;
+                    }
+            }
         }
         // epilogue (D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)); bias + activation in
         // place first, then stores straight from the accumulator registers (see gemm_kernel's epilogue note)
@@ -811,6 +891,16 @@ inline TnCfg tn_config(int64_t M, int64_t Ka, int64_t N, bool want_bias)
     return c;
 }
 
+// developer A/B switch: TFGX_GEMM_TWO_LEVEL=0 restores the single k-ordered chain on the narrow tiles
+static int two_level_default()
+{
+    static const int on = [] {
+        const char* e = std::getenv("TFGX_GEMM_TWO_LEVEL");
+        return (e && e[0] == '0') ? 0 : 1;
+    }();
+    return on;
+}
+
 inline size_t rows_lds_bytes(int64_t K, int tn) { return sizeof(float) * size_t(K) * size_t(tn * 32 + 8); }
 
 template <int TN>
@@ -836,7 +926,7 @@ int launch_gemm_rows(const float* A, int64_t lda, const float* B, int64_t ldb, c
     const int64_t max_wgs = int64_t(cus) * (TN <= 2 ? 3 : 1);
     dim3 grid(static_cast<unsigned>(wgs < max_wgs ? wgs : max_wgs), 1, 1), block(rows_threads<TN>(), 1, 1);
     gemm_rows_kernel<TN><<<grid, block, rows_lds_bytes(K, TN), stream>>>(A, lda, B, ldb, bias, act, act_cols, C, ldc, M, K,
-                                                                         N, n_tiles, b_vec4);
+                                                                         N, n_tiles, b_vec4, two_level_default());
     TFGX_LAUNCH_CHECK("gemm_rows_kernel");
     return TFGX_OK;
 }
@@ -900,7 +990,7 @@ int launch_gemm(const float* A, int64_t lda, const float* B, int64_t ldb, const 
     dim3 grid(static_cast<unsigned>(blocks), static_cast<unsigned>(ny), 1), block(kBlock, 1, 1);
 #define TFGX_GEMM_GO(AV, BV)                                                                                         \
     gemm_kernel<BM, BN, WM, WN, AV, BV><<<grid, block, 0, stream>>>(A, lda, B, ldb, kb, ka, out, ldo, M, K, N, ntn, \
-                                                                     act_cols, k_chunk, M * int64_t(N))
+                                                                     act_cols, k_chunk, M * int64_t(N), two_level_default())
     if (av4 && bv4) TFGX_GEMM_GO(true, true);
     else if (av4) TFGX_GEMM_GO(true, false);
     else if (bv4) TFGX_GEMM_GO(false, true);
