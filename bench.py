@@ -393,6 +393,11 @@ def main():
                    "partition": "single GPU" if world == 1 else "dst-range x{} + RCCL halo all-to-all-v".format(world)},
         "plan_build_s": plan_s,
     }
+    if world > 1:
+        # which exchange implementation carried the halo rows: "tfgx_dist" = the C ABI of include/tfgx_dist.h (in-process
+        # ncclComm_t, grouped ncclSend / ncclRecv on a second HIP stream) — the product path on RCCL; "torch" only for the
+        # one-GPU plumbing check (TFGX_BENCH_BACKEND=gloo)
+        line["config"]["transport"] = sg.transport.name
 
     if rank == 0 and world > 1:
         # whole job: algorithmic bytes of the full graph over the step time (exchange included) vs N x 8 TB/s
@@ -550,6 +555,7 @@ def shard_diagnostics(sg, table, out, f, L, dist, reps):
     mine = {"rank": sg.rank, "rows": sg.n_own, "edges": sg.num_edges, "own_source_edges": own_edges,
             "halo_rows_received": sg.n_halo, "halo_bytes_received": sg.n_halo * f * 4,
             "rows_sent": int(sum(sg.send_counts)), "bytes_sent": int(sum(sg.send_counts)) * f * 4,
+            "rows_packed": int(sg.send_idx_packed.shape[0]), "peers_sent_whole_block_unpacked": int(sum(sg.dense_send)),
             "exchange_ms": exch, "local_pass_ms": local, "halo_pass_ms": halo,
             "exchange_GBps_received": sg.n_halo * f * 4 / (exch * 1e-3) / 1e9 if exch > 0 else None}
     gathered = [None] * sg.world

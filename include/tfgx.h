@@ -486,7 +486,8 @@ int tfgx_relu_backward_f32(const float* g, int64_t ldg, const float* out, int64_
                            float* gout, int64_t ldgo, tfgx_stream_t stream);
 /* dst[idx[i], :] += src[i, :] for i in [0, M): owner-side accumulate of the reverse halo exchange (gradients of halo rows
    returning to their owners during training).  idx must hold UNIQUE ids within one call (one peer's request list does);
-   peers are applied by the caller in a fixed order, so the sum is deterministic without atomics. */
+   peers are applied by the caller in a fixed order, so the sum is deterministic without atomics.  idx == NULL: the
+   identity list (dst[i, :] += src[i, :]: a peer that requested a contiguous block of rows). */
 int tfgx_scatter_add_rows_f32(float* dst, int64_t ldd, const int32_t* idx, int64_t M, int64_t F, const float* src,
                               int64_t lds, tfgx_stream_t stream);
 /* n_class source classes (own rows + one class per halo exchange ROUND, so the halo pass of round j can run while

@@ -42,11 +42,18 @@ class NumpyBackend(object):
     def permute_rows(self, attr, perm):
         return self.f32(_np(self.f32(attr))[_np(perm)])
 
-    def halo_plan(self, col, own_lo, own_hi, n_global):
+    def halo_plan(self, col, src_lo, src_hi, n_global, n_own, peer_bounds=None, rank=0, dense_pct=0):
+        """tfgx_halo_mark / (dense-peer fill) / tfgx_halo_compact / tfgx_halo_remap_cols restated."""
+        from tf_geometric_amd.dist.sharded import _fill_dense_peers
         c = _np(col)
-        remote = (c < own_lo) | (c >= own_hi)
-        ids = np.unique(c[remote]).astype(np.int32)
-        col_local = np.where(remote, (own_hi - own_lo) + np.searchsorted(ids, c), c - own_lo).astype(np.int32)
+        remote = (c < src_lo) | (c >= src_hi)
+        flags = np.zeros(max(n_global, 1), np.int32)
+        flags[c[remote]] = 1
+        if peer_bounds is not None and dense_pct > 0 and n_global > 0:
+            ft = torch.from_numpy(flags[:n_global])
+            _fill_dense_peers(ft, peer_bounds, rank, dense_pct)
+        ids = np.flatnonzero(flags[:n_global]).astype(np.int32)
+        col_local = np.where(remote, n_own + np.searchsorted(ids, c), c - src_lo).astype(np.int32)
         return torch.from_numpy(ids), torch.from_numpy(col_local)
 
     def split_by_class(self, row_ptr, col_local, w, class_bounds, n_class):

@@ -56,7 +56,8 @@ def pool_weights():
             (rng.standard_normal(20) * 0.2).astype(np.float32), (rng.standard_normal(10) * 0.2).astype(np.float32))
 
 
-def run_checks(rank, world, use_gpu, skew, results, rounds=None, partitioned=False, hub_threshold=None):
+def run_checks(rank, world, use_gpu, skew, results, rounds=None, partitioned=False, hub_threshold=None, self_halo=False,
+               transport=None):
     """Build the shard, run sharded GCN / mean / max / sum and return this rank's rows (as numpy).  hub_threshold: force
     the chunked long-span paths (reduce passes AND the sharded GAT's part lists) on this small graph."""
     from tf_geometric_amd.dist.sharded import ShardedGraph
@@ -71,18 +72,25 @@ def run_checks(rank, world, use_gpu, skew, results, rounds=None, partitioned=Fal
         backend = NumpyBackend()
     group = dist.group.WORLD if dist.is_initialized() else None
 
+    # self_halo (test mode): only the first third of a rank's rows are resident sources, the rest come through the halo
+    # exchange from the rank itself — a world-size-1 run then moves real rows through the transport
+    kw = dict(group=group, backend=backend, rounds=rounds, transport=transport)
+
     def make(weights):
+        sh = (n // world) // 3 if self_halo else None
         if not partitioned:
-            return ShardedGraph.from_global(ei, n, edge_weight=weights, group=group, backend=backend, rounds=rounds)
+            return ShardedGraph.from_global(ei, n, edge_weight=weights, self_halo_rows=sh, **kw)
         # every rank holds a different, interleaved stripe of the edge list (destinations all over the graph)
         part = slice(rank, None, world)
         return ShardedGraph.from_partitioned(ei[:, part], n, edge_weight_part=None if weights is None else weights[part],
-                                             group=group, backend=backend, rounds=rounds)
+                                             self_halo_rows=sh, **kw)
     sg = make(w)
-    assert sg.rounds == (0 if world == 1 else (rounds or 1))
+    assert sg.rounds == (0 if (world == 1 and not self_halo) else (rounds or 1))
     be = sg.backend
     x_own = be.f32(x[sg.own_lo:sg.own_hi])
-    out = {"lo": sg.own_lo, "hi": sg.own_hi, "edges": sg.num_edges, "n_halo": sg.n_halo}
+    out = {"lo": sg.own_lo, "hi": sg.own_hi, "edges": sg.num_edges, "n_halo": sg.n_halo, "transport": sg.transport.name,
+           "dense_send": int(sum(sg.dense_send)), "rows_packed": int(sg.send_idx_packed.shape[0]),
+           "rows_sent": int(sum(sg.send_counts))}
     sg.build_gcn_norm()
     out["gcn"] = sg.gcn(x_own, be.f32(k), bias=be.f32(b), act=1).cpu().numpy()
     out["gcn_nokernel"] = sg.gcn(x_own, None).cpu().numpy()
@@ -114,7 +122,9 @@ def run_checks(rank, world, use_gpu, skew, results, rounds=None, partitioned=Fal
     return out
 
 
-def _entry(rank, world, port, use_gpu, skew, path, rounds=None, partitioned=False, hub_threshold=None):
+def _entry(rank, world, port, use_gpu, skew, path, rounds=None, partitioned=False, hub_threshold=None, self_halo=False,
+           env=None):
+    os.environ.update(env or {})
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -122,15 +132,17 @@ def _entry(rank, world, port, use_gpu, skew, path, rounds=None, partitioned=Fals
         torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     res = {}
-    run_checks(rank, world, use_gpu, skew, res, rounds=rounds, partitioned=partitioned, hub_threshold=hub_threshold)
+    run_checks(rank, world, use_gpu, skew, res, rounds=rounds, partitioned=partitioned, hub_threshold=hub_threshold,
+               self_halo=self_halo)
     np.save(os.path.join(path, "rank{}.npy".format(rank)), np.array([res[rank]], dtype=object), allow_pickle=True)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def spawn(world, use_gpu, skew, path, port, rounds=None, partitioned=False, hub_threshold=None):
+def spawn(world, use_gpu, skew, path, port, rounds=None, partitioned=False, hub_threshold=None, self_halo=False, env=None):
     import torch.multiprocessing as mp
-    mp.spawn(_entry, args=(world, port, use_gpu, skew, path, rounds, partitioned, hub_threshold), nprocs=world, join=True)
+    mp.spawn(_entry, args=(world, port, use_gpu, skew, path, rounds, partitioned, hub_threshold, self_halo, env),
+             nprocs=world, join=True)
     return [np.load(os.path.join(path, "rank{}.npy".format(r)), allow_pickle=True)[0] for r in range(world)]
 
 
@@ -189,7 +201,8 @@ def _loss_coef(n, u):
     return (np.sin(np.arange(n * u, dtype=np.float64) * 0.37).reshape(n, u) + 1.5).astype(np.float32)
 
 
-def run_training(rank, world, use_gpu, skew, rounds=None, num_splits=None, hub_threshold=None):
+def run_training(rank, world, use_gpu, skew, rounds=None, num_splits=None, hub_threshold=None, self_halo=False,
+                 transport=None):
     from tf_geometric_amd.dist.sharded import ShardedGraph
     import tf_geometric_amd.plan as P
     # hub_threshold: force the chunked long-row paths of the backward kernels (transposed local pass, GAT / max gradients
@@ -203,7 +216,8 @@ def run_training(rank, world, use_gpu, skew, rounds=None, num_splits=None, hub_t
         from cpu_backend import NumpyBackend
         backend = NumpyBackend()
     group = dist.group.WORLD if dist.is_initialized() else None
-    sg = ShardedGraph.from_global(ei, n, edge_weight=w, group=group, backend=backend, rounds=rounds)
+    sg = ShardedGraph.from_global(ei, n, edge_weight=w, group=group, backend=backend, rounds=rounds, transport=transport,
+                                  self_halo_rows=(n // world) // 3 if self_halo else None)
     be = sg.backend
     sg.build_gcn_norm()
     x_own = be.f32(x[sg.own_lo:sg.own_hi]).requires_grad_(True)
@@ -270,22 +284,25 @@ def run_training(rank, world, use_gpu, skew, rounds=None, num_splits=None, hub_t
     return res
 
 
-def _train_entry(rank, world, port, use_gpu, skew, path, rounds, num_splits, hub_threshold=None):
+def _train_entry(rank, world, port, use_gpu, skew, path, rounds, num_splits, hub_threshold=None, self_halo=False, env=None):
+    os.environ.update(env or {})
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if use_gpu:
         torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    res = run_training(rank, world, use_gpu, skew, rounds, num_splits, hub_threshold)
+    res = run_training(rank, world, use_gpu, skew, rounds, num_splits, hub_threshold, self_halo=self_halo)
     np.save(os.path.join(path, "train{}.npy".format(rank)), np.array([res], dtype=object), allow_pickle=True)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def spawn_training(world, use_gpu, skew, path, port, rounds=None, num_splits=None, hub_threshold=None):
+def spawn_training(world, use_gpu, skew, path, port, rounds=None, num_splits=None, hub_threshold=None, self_halo=False,
+                   env=None):
     import torch.multiprocessing as mp
-    mp.spawn(_train_entry, args=(world, port, use_gpu, skew, path, rounds, num_splits, hub_threshold), nprocs=world, join=True)
+    mp.spawn(_train_entry, args=(world, port, use_gpu, skew, path, rounds, num_splits, hub_threshold, self_halo, env),
+             nprocs=world, join=True)
     return [np.load(os.path.join(path, "train{}.npy".format(r)), allow_pickle=True)[0] for r in range(world)]
 
 

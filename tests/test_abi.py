@@ -156,7 +156,7 @@ def test_dist_library_exports_every_declared_symbol():
     with open(os.path.join(ROOT, "include", "tfgx_dist.h")) as fh:
         src = re.sub(r"/\*.*?\*/", "", fh.read(), flags=re.S)
     names = sorted(set(re.findall(r"\b(tfgx_[a-z0-9_]+)\s*\(", src)))
-    assert len(names) == 10, names
+    assert len(names) == 16, names
     if not os.path.exists(_build.DIST_LIB):
         _build.build_dist(verbose=False)
     lib = ctypes.CDLL(_build.DIST_LIB)
@@ -165,9 +165,20 @@ def test_dist_library_exports_every_declared_symbol():
     lib.tfgx_dist_last_error.restype = ctypes.c_char_p
     plan = ctypes.c_void_p()
     cnt = (ctypes.c_int64 * 4)(0, 3, 0, 2)
-    assert lib.tfgx_halo_plan_create(2, 5, 2, cnt, cnt, None, ctypes.byref(plan)) == 1      # rank outside world
+    assert lib.tfgx_halo_plan_create(2, 5, 2, cnt, cnt, None, None, ctypes.byref(plan)) == 1      # rank outside world
     assert b"bad world" in lib.tfgx_dist_last_error()
-    assert lib.tfgx_halo_plan_create(2, 0, 2, cnt, cnt, None, ctypes.byref(plan)) == 1      # rows to send, no index list
+    assert lib.tfgx_halo_plan_create(2, 0, 2, cnt, cnt, None, None, ctypes.byref(plan)) == 1      # rows to pack, no index list
+    dense = (ctypes.c_int64 * 4)(-1, 0, -1, 3)          # every non-empty (round, peer) entry is a contiguous block:
+    rc = lib.tfgx_halo_plan_create(2, 0, 2, cnt, cnt, dense, None, ctypes.byref(plan))            # nothing to pack: the
+    assert rc in (0, 4)           # arguments are accepted; without a GPU the plan's hipEventCreate then fails (TFGX_ERR_HIP)
+    if rc == 0:
+        lib.tfgx_halo_plan_rows_packed.restype = lib.tfgx_halo_plan_rows_sent.restype = ctypes.c_int64
+        assert lib.tfgx_halo_plan_rows_packed(plan) == 0 and lib.tfgx_halo_plan_rows_sent(plan) == 5
+        assert lib.tfgx_halo_plan_destroy(plan) == 0
+    else:
+        assert b"hipEventCreate" in lib.tfgx_dist_last_error()
+    assert lib.tfgx_dist_comm_init(0, 0, None, None) == 1 and lib.tfgx_dist_unique_id(None) == 1
+    assert lib.tfgx_alltoallv(None, None, None, None, 4, 2, None, None) == 1
     assert lib.tfgx_halo_exchange_finish(None, 0, None) == 1
     assert lib.tfgx_halo_reverse_start(None, None, 4, None, 0, None, None, None) == 1
     assert lib.tfgx_halo_reverse_finish(None, None, 4, 4, None, None) == 1

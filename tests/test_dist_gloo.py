@@ -109,3 +109,49 @@ def test_sharded_long_spans_are_chunked_gloo(tmp_path, world):
                                   hub_threshold=8)
     assert all(p["gat_used_parts"] for p in parts)
     dist_worker.check_against_reference(parts, True, assert_parity)
+
+
+@pytest.mark.parametrize("pct,expect_dense", [("60", True), ("0", False)])
+def test_dense_peers_skip_the_pack_gloo(tmp_path, pct, expect_dense):
+    """A peer whose block is referenced to >= TFGX_DENSE_PEER_PCT percent is requested WHOLE (its owner sends the block
+    without packing; uniform random graphs at 8 GPUs: every peer).  Same rows as the oracle either way; with the rule on
+    the small uniform test graph takes it (nothing is packed), with it off everything is packed."""
+    port = 29500 + random.randint(9001, 9500)
+    parts = dist_worker.spawn(2, use_gpu=False, skew=False, path=str(tmp_path), port=port, rounds=3,
+                              env={"TFGX_DENSE_PEER_PCT": pct})
+    parts = dist_worker.check_against_reference(parts, False, assert_parity)
+    for p in parts:
+        assert p["rows_sent"] > 0
+        if expect_dense:
+            assert p["dense_send"] == 1 and p["rows_packed"] == 0
+        else:       # rule off: a block still goes unpacked when a peer happens to reference every row of it
+            assert p["rows_packed"] == p["rows_sent"] - p["dense_send"] * (p["hi"] - p["lo"])
+    tr = dist_worker.spawn_training(2, False, False, str(tmp_path), port + 1, rounds=3, env={"TFGX_DENSE_PEER_PCT": pct})
+    ref = dist_worker.training_reference(False)
+    tr = sorted(tr, key=lambda p: p["lo"])
+    assert_parity(np.concatenate([p["dx"] for p in tr]), ref["dx"], tol=2e-5, what="sharded d/dx, dense peers " + pct)
+    dist_worker.check_training_extras(tr, ref, assert_parity)
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_self_halo_mode_moves_own_rows_through_the_exchange(tmp_path, world):
+    """self_halo_rows (the test mode the world-size-1 RCCL run on the GPU box relies on): only a third of a rank's rows
+    are resident sources, the rest arrive through the halo exchange from the rank ITSELF — forward layers and the
+    reverse exchange of the training path give the same rows as the oracle."""
+    if world == 1:
+        res = {}
+        dist_worker.run_checks(0, 1, use_gpu=False, skew=True, results=res, rounds=2, self_halo=True)
+        parts = [res[0]]
+        tr = [dist_worker.run_training(0, 1, False, True, rounds=2, self_halo=True)]
+    else:
+        port = 29500 + random.randint(9501, 9900)
+        parts = dist_worker.spawn(world, use_gpu=False, skew=True, path=str(tmp_path), port=port, rounds=2, self_halo=True)
+        tr = dist_worker.spawn_training(world, False, True, str(tmp_path), port + 1, rounds=2, self_halo=True)
+    parts = dist_worker.check_against_reference(parts, True, assert_parity)
+    assert all(p["n_halo"] > 0 and p["rows_sent"] > 0 for p in parts)
+    ref = dist_worker.training_reference(True)
+    tr = sorted(tr, key=lambda p: p["lo"])
+    assert_parity(np.concatenate([p["out"] for p in tr]), ref["out"], what="self-halo trainable forward")
+    assert_parity(np.concatenate([p["dx"] for p in tr]), ref["dx"], tol=2e-5, what="self-halo d/dx")
+    assert_parity(np.concatenate([p["dx_mean"] for p in tr]), ref["dx_mean"], tol=2e-5, what="self-halo mean d/dx")
+    dist_worker.check_training_extras(tr, ref, assert_parity)

@@ -44,6 +44,46 @@ def test_rccl_world1_api_smoke(tfg):
     assert res.returncode == 0 and "RCCL_WORLD1_OK" in text and "True" in text and "False" not in text, text
 
 
+@pytest.mark.parametrize("partitioned", [False, True])
+def test_sharded_layers_through_the_c_abi_exchange_world1(tfg, partitioned):
+    """The product transport (libtfgx_dist.so: in-process ncclComm_t, grouped ncclSend / ncclRecv on the second HIP stream)
+    carrying real rows on ONE GPU: self-halo test mode, no torch.distributed group at all."""
+    res = {}
+    dist_worker.run_checks(0, 1, use_gpu=True, skew=True, results=res, rounds=3, partitioned=partitioned, self_halo=True)
+    p = res[0]
+    assert p["transport"] == "tfgx_dist" and p["n_halo"] > 0 and p["rows_sent"] > 0 and p["rows_packed"] == p["rows_sent"]
+    dist_worker.check_against_reference([p], True, assert_parity)
+
+
+def test_sharded_training_through_the_c_abi_exchange_world1(tfg):
+    """Reverse exchange (tfgx_halo_reverse_start overlapped with the own-row part of the transposed pass, then
+    tfgx_halo_reverse_finish) and the column-chunked halo (two exchanges in flight) through the product transport."""
+    import numpy as np
+    tr = dist_worker.run_training(0, 1, True, True, rounds=3, num_splits=4, self_halo=True)
+    ref = dist_worker.training_reference(True)
+    assert_parity(tr["out"], ref["out"], what="trainable forward (tfgx_dist)")
+    assert_parity(tr["dx"], ref["dx"], tol=2e-5, what="d/dx (tfgx_dist reverse exchange)")
+    assert_parity(tr["dx_mean"], ref["dx_mean"], tol=2e-5, what="mean d/dx (tfgx_dist)")
+    assert_parity(tr["dk"], ref["dk"], tol=1e-4, what="d/dkernel")
+    dist_worker.check_training_extras([tr], ref, assert_parity)
+    assert np.array_equal(tr["chunked"], tr["whole"])
+
+
+def test_tfgx_dist_world1_under_an_nccl_process_group(tfg):
+    """The same, in a subprocess that first initialises a one-rank "nccl" torch.distributed group (the configuration
+    bench.py --gpus N runs in: torch's group is the control channel, the halo rows travel through tfgx_dist's own
+    communicator) — tests/tfgx_dist_world1.py."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(41600 + random.randint(0, 2000)), RANK="0",
+               WORLD_SIZE="1")
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tfgx_dist_world1.py")
+    res = subprocess.run([sys.executable, script], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    text = res.stdout.decode()
+    assert res.returncode == 0 and "TFGX_DIST_WORLD1_OK" in text, text[-3000:]
+
+
 @pytest.mark.parametrize("world,skew,hub", [(1, True, None), (2, True, None), (2, False, None), (2, True, 8)])
 def test_sharded_training_hip(tfg, tmp_path, world, skew, hub):
     """Sharded backward on the HIP kernels (transposed local pass, tfgx_scatter_add_rows_f32 owner-side accumulate,

@@ -49,6 +49,8 @@ struct tfgx_halo_plan {
     int32_t world, rank, rounds;
     std::vector<int64_t> send_counts, recv_counts;     // [rounds * world]
     std::vector<int64_t> send_off, recv_off;           // row offsets, same indexing (+1 total at the end)
+    std::vector<int64_t> dense_start;                  // [rounds * world]: >= 0 -> contiguous own rows, no pack; -1 packed
+    std::vector<int64_t> pack_off;                     // row offsets into send_idx / send_buf (packed entries only)
     const int32_t* send_idx;                           // device
     std::vector<hipEvent_t> packed, done, rdone;       // per round (rdone: the reverse exchange)
     bool in_flight, reverse_in_flight;
@@ -56,8 +58,77 @@ struct tfgx_halo_plan {
 
 extern "C" const char* tfgx_dist_last_error(void) { return g_err; }
 
+extern "C" int tfgx_dist_unique_id(void* id_out)
+{
+    DIST_REQUIRE(id_out != nullptr, "id_out is null");
+    static_assert(sizeof(ncclUniqueId) <= TFGX_DIST_UNIQUE_ID_BYTES, "ncclUniqueId larger than the documented size");
+    ncclUniqueId id;
+    DIST_NCCL(ncclGetUniqueId(&id));
+    std::memset(id_out, 0, TFGX_DIST_UNIQUE_ID_BYTES);
+    std::memcpy(id_out, &id, sizeof(id));
+    return TFGX_OK;
+}
+
+extern "C" int tfgx_dist_comm_init(int32_t world, int32_t rank, const void* id_bytes, void** comm_out)
+{
+    DIST_REQUIRE(comm_out != nullptr && id_bytes != nullptr, "null pointer");
+    DIST_REQUIRE(world >= 1 && rank >= 0 && rank < world, "bad world / rank");
+    ncclUniqueId id;
+    std::memcpy(&id, id_bytes, sizeof(id));
+    ncclComm_t comm = nullptr;
+    DIST_NCCL(ncclCommInitRank(&comm, world, id, rank));
+    *comm_out = comm;
+    return TFGX_OK;
+}
+
+extern "C" int tfgx_dist_comm_destroy(void* nccl_comm)
+{
+    if (nccl_comm == nullptr) return TFGX_OK;
+    DIST_NCCL(ncclCommDestroy(reinterpret_cast<ncclComm_t>(nccl_comm)));
+    return TFGX_OK;
+}
+
+extern "C" int tfgx_alltoallv(const void* send, const int64_t* send_counts, void* recv, const int64_t* recv_counts,
+                              int64_t elem_bytes, int32_t world, void* nccl_comm, void* stream)
+{
+    DIST_REQUIRE(world >= 1 && elem_bytes >= 1 && send_counts && recv_counts, "bad argument");
+    DIST_REQUIRE(nccl_comm != nullptr, "nccl_comm is null");
+    ncclComm_t comm = reinterpret_cast<ncclComm_t>(nccl_comm);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const char* sp = static_cast<const char*>(send);
+    char* rp = static_cast<char*>(recv);
+    int64_t so = 0, ro = 0;
+    DIST_NCCL(ncclGroupStart());
+    for (int q = 0; q < world; ++q) {
+        DIST_REQUIRE(send_counts[q] >= 0 && recv_counts[q] >= 0, "negative count");
+        if (send_counts[q] > 0) {
+            DIST_REQUIRE(sp != nullptr, "send is null");
+            DIST_NCCL(ncclSend(sp + so * elem_bytes, size_t(send_counts[q]) * size_t(elem_bytes), ncclInt8, q, comm, st));
+        }
+        if (recv_counts[q] > 0) {
+            DIST_REQUIRE(rp != nullptr, "recv is null");
+            DIST_NCCL(ncclRecv(rp + ro * elem_bytes, size_t(recv_counts[q]) * size_t(elem_bytes), ncclInt8, q, comm, st));
+        }
+        so += send_counts[q];
+        ro += recv_counts[q];
+    }
+    DIST_NCCL(ncclGroupEnd());
+    return TFGX_OK;
+}
+
+extern "C" int tfgx_allreduce_sum_i64(int64_t* buf, int64_t count, void* nccl_comm, void* stream)
+{
+    DIST_REQUIRE(count >= 0, "negative count");
+    if (count == 0) return TFGX_OK;
+    DIST_REQUIRE(buf != nullptr && nccl_comm != nullptr, "null pointer");
+    DIST_NCCL(ncclAllReduce(buf, buf, size_t(count), ncclInt64, ncclSum, reinterpret_cast<ncclComm_t>(nccl_comm),
+                            reinterpret_cast<hipStream_t>(stream)));
+    return TFGX_OK;
+}
+
 extern "C" int tfgx_halo_plan_create(int32_t world, int32_t rank, int32_t rounds, const int64_t* send_counts,
-                                     const int64_t* recv_counts, const int32_t* send_idx, tfgx_halo_plan** out)
+                                     const int64_t* recv_counts, const int64_t* send_dense_start,
+                                     const int32_t* send_idx, tfgx_halo_plan** out)
 {
     DIST_REQUIRE(out != nullptr, "out is null");
     DIST_REQUIRE(world >= 1 && rank >= 0 && rank < world && rounds >= 1 && rounds <= 64, "bad world / rank / rounds");
@@ -69,6 +140,8 @@ extern "C" int tfgx_halo_plan_create(int32_t world, int32_t rank, int32_t rounds
     p->recv_counts.assign(recv_counts, recv_counts + n);
     p->send_off.assign(n + 1, 0);
     p->recv_off.assign(n + 1, 0);
+    p->pack_off.assign(n + 1, 0);
+    p->dense_start.assign(n, -1);
     for (size_t i = 0; i < n; ++i) {
         const bool self = int32_t(i % size_t(world)) == rank;
         if (send_counts[i] < 0 || recv_counts[i] < 0 || (self && send_counts[i] != recv_counts[i])) {
@@ -76,12 +149,14 @@ extern "C" int tfgx_halo_plan_create(int32_t world, int32_t rank, int32_t rounds
             set_err("tfgx_halo_plan_create: negative count, or unmatched counts for the rank itself");
             return TFGX_ERR_INVALID_ARG;
         }
+        if (send_dense_start != nullptr && send_dense_start[i] >= 0 && send_counts[i] > 0) p->dense_start[i] = send_dense_start[i];
         p->send_off[i + 1] = p->send_off[i] + send_counts[i];
         p->recv_off[i + 1] = p->recv_off[i] + recv_counts[i];
+        p->pack_off[i + 1] = p->pack_off[i] + (p->dense_start[i] >= 0 ? 0 : send_counts[i]);
     }
-    if (p->send_off[n] > 0 && send_idx == nullptr) {
+    if (p->pack_off[n] > 0 && send_idx == nullptr) {
         delete p;
-        set_err("tfgx_halo_plan_create: send_idx is null but rows are to be sent");
+        set_err("tfgx_halo_plan_create: send_idx is null but rows are to be packed");
         return TFGX_ERR_INVALID_ARG;
     }
     p->packed.assign(rounds, nullptr);
@@ -112,6 +187,7 @@ extern "C" int tfgx_halo_plan_destroy(tfgx_halo_plan* p)
 }
 
 extern "C" int64_t tfgx_halo_plan_rows_sent(const tfgx_halo_plan* p) { return p ? p->send_off.back() : -1; }
+extern "C" int64_t tfgx_halo_plan_rows_packed(const tfgx_halo_plan* p) { return p ? p->pack_off.back() : -1; }
 extern "C" int64_t tfgx_halo_plan_rows_received(const tfgx_halo_plan* p) { return p ? p->recv_off.back() : -1; }
 
 extern "C" int tfgx_halo_exchange_start(tfgx_halo_plan* p, const float* x_own, int64_t ldx, int64_t F, float* halo,
@@ -121,9 +197,11 @@ extern "C" int tfgx_halo_exchange_start(tfgx_halo_plan* p, const float* x_own, i
     DIST_REQUIRE(p != nullptr, "plan is null");
     DIST_REQUIRE(F >= 1 && ldx >= F && ld_halo >= F, "bad F / leading dimension");
     DIST_REQUIRE(ld_halo == F, "the halo table must be dense (ld_halo == F): rows of one peer arrive as one message");
-    const int64_t rows_sent = p->send_off.back(), rows_recv = p->recv_off.back();
-    DIST_REQUIRE(rows_sent == 0 || (x_own && send_buf && send_buf_floats >= size_t(rows_sent) * size_t(F)),
-                 "send buffer too small / null x_own");
+    const int64_t rows_sent = p->send_off.back(), rows_recv = p->recv_off.back(), rows_packed = p->pack_off.back();
+    DIST_REQUIRE(rows_sent == 0 || x_own != nullptr, "null x_own");
+    DIST_REQUIRE(rows_packed == 0 || (send_buf && send_buf_floats >= size_t(rows_packed) * size_t(F)),
+                 "send buffer too small");
+    DIST_REQUIRE(rows_packed == rows_sent || ldx == F, "dense (unpacked) peers are sent straight from x_own: ldx must equal F");
     DIST_REQUIRE(rows_recv == 0 || halo != nullptr, "halo is null");
     DIST_REQUIRE(nccl_comm != nullptr || (rows_sent == 0 && rows_recv == 0), "nccl_comm is null");
     hipStream_t cs = reinterpret_cast<hipStream_t>(compute_stream);
@@ -134,8 +212,8 @@ extern "C" int tfgx_halo_exchange_start(tfgx_halo_plan* p, const float* x_own, i
     }
     for (int j = 0; j < p->rounds; ++j) {
         const size_t base = size_t(j) * size_t(p->world);
-        const int64_t r0 = p->send_off[base], r1 = p->send_off[base + p->world];
-        if (r1 > r0) {   // pack this round's rows (all peers) with ONE gather launch on the compute stream
+        const int64_t r0 = p->pack_off[base], r1 = p->pack_off[base + p->world];
+        if (r1 > r0) {   // pack this round's rows (all packed peers) with ONE gather launch on the compute stream
             const int rc = tfgx_gather_rows_f32(x_own, ldx, p->send_idx + r0, r1 - r0, F, send_buf + r0 * F, F,
                                                 reinterpret_cast<tfgx_stream_t>(cs));
             if (rc != TFGX_OK) {
@@ -149,8 +227,11 @@ extern "C" int tfgx_halo_exchange_start(tfgx_halo_plan* p, const float* x_own, i
             DIST_NCCL(ncclGroupStart());
             for (int q = 0; q < p->world; ++q) {
                 const int64_t sc = p->send_counts[base + q], rc = p->recv_counts[base + q];
-                if (sc > 0)
-                    DIST_NCCL(ncclSend(send_buf + p->send_off[base + q] * F, size_t(sc) * size_t(F), ncclFloat, q, comm, ms));
+                if (sc > 0) {
+                    const int64_t ds = p->dense_start[base + q];
+                    const float* src = ds >= 0 ? x_own + ds * F : send_buf + p->pack_off[base + q] * F;
+                    DIST_NCCL(ncclSend(src, size_t(sc) * size_t(F), ncclFloat, q, comm, ms));
+                }
                 if (rc > 0)
                     DIST_NCCL(ncclRecv(halo + p->recv_off[base + q] * F, size_t(rc) * size_t(F), ncclFloat, q, comm, ms));
             }
@@ -232,8 +313,13 @@ extern "C" int tfgx_halo_reverse_finish(tfgx_halo_plan* p, float* d_own, int64_t
         for (int q = 0; q < p->world; ++q) {
             const int64_t cnt = p->send_counts[base + q], off = p->send_off[base + q];
             if (cnt == 0) continue;
-            const int rc = tfgx_scatter_add_rows_f32(d_own, ldd, p->send_idx + off, cnt, F, back_buf + off * F, F,
-                                                     reinterpret_cast<tfgx_stream_t>(cs));
+            const int64_t ds = p->dense_start[base + q];
+            // dense entry: the returned rows are the contiguous own rows [ds, ds + cnt) (idx = NULL: identity)
+            const int rc = ds >= 0
+                ? tfgx_scatter_add_rows_f32(d_own + ds * ldd, ldd, nullptr, cnt, F, back_buf + off * F, F,
+                                            reinterpret_cast<tfgx_stream_t>(cs))
+                : tfgx_scatter_add_rows_f32(d_own, ldd, p->send_idx + p->pack_off[base + q], cnt, F, back_buf + off * F, F,
+                                            reinterpret_cast<tfgx_stream_t>(cs));
             if (rc != TFGX_OK) {
                 set_err("tfgx_scatter_add_rows_f32: %s", tfgx_last_error());
                 return rc;

@@ -59,7 +59,7 @@ __global__ __launch_bounds__(kBlock) void scatter_add_rows_kernel(float* __restr
     for (; t < total; t += stride) {
         const int64_t i = t / per_row;
         const int j = int(t - i * per_row) * VEC;
-        float* d = dst + int64_t(idx[i]) * ldd + j;
+        float* d = dst + (idx ? int64_t(idx[i]) : i) * ldd + j;      // idx == NULL: rows 0 .. M-1 (a contiguous block)
         const float* sp = src + i * lds + j;
         if constexpr (VEC == 4) {
             float4 a = *reinterpret_cast<float4*>(d);
@@ -382,7 +382,7 @@ extern "C" int tfgx_scatter_add_rows_f32(float* dst, int64_t ldd, const int32_t*
     TFGX_RANGE();
     TFGX_REQUIRE(M >= 0 && F >= 1 && ldd >= F && lds >= F, "bad shape");
     if (M == 0) return TFGX_OK;
-    TFGX_REQUIRE(dst && idx && src, "null pointer");
+    TFGX_REQUIRE(dst && src, "null pointer");
     const bool v4 = (F % 4 == 0) && (ldd % 4 == 0) && (lds % 4 == 0) && aligned_to(dst, 16) && aligned_to(src, 16);
     if (v4)
         scatter_add_rows_kernel<4><<<grid_for(M * (F / 4), kBlock), kBlock, 0, as_stream(stream)>>>(dst, ldd, idx, M,

@@ -61,8 +61,11 @@ class HipBackend(object):
                                                L.stream_ptr()), "tfgx_permute_rows_f32")
         return out
 
-    def halo_plan(self, col, own_lo, own_hi, n_global):
-        """-> (halo_ids sorted int32 [n_halo], col_local int32 [E])."""
+    def halo_plan(self, col, src_lo, src_hi, n_global, n_own, peer_bounds=None, rank=0, dense_pct=0):
+        """-> (halo_ids sorted int32 [n_halo], col_local int32 [E]).  Sources in [src_lo, src_hi) are resident own rows
+        (local index c - src_lo); every other source becomes a halo row at table index n_own + its rank among the halo ids.
+        `peer_bounds` + `dense_pct`: a peer whose block is referenced to at least dense_pct percent is requested WHOLE
+        (flags of its range set before the compaction), so that its owner can send the block without packing."""
         E = int(col.shape[0])
         flags = self.empty(max(n_global, 1), torch.int32)
         pos = self.empty(max(n_global, 1), torch.int32)
@@ -70,12 +73,14 @@ class HipBackend(object):
         n_halo = torch.zeros(1, dtype=torch.int32, device=self.device)
         ws_bytes = self.lib.tfgx_halo_workspace_bytes(n_global)
         ws = self.empty(max(ws_bytes, 1), torch.uint8)
-        L.check(self.lib.tfgx_halo_mark(L.ptr(col), E, own_lo, own_hi, n_global, L.ptr(flags), L.stream_ptr()),
+        L.check(self.lib.tfgx_halo_mark(L.ptr(col), E, src_lo, src_hi, n_global, L.ptr(flags), L.stream_ptr()),
                 "tfgx_halo_mark")
+        if peer_bounds is not None and dense_pct > 0 and n_global > 0:
+            _fill_dense_peers(flags[:n_global], peer_bounds, rank, dense_pct)
         L.check(self.lib.tfgx_halo_compact(L.ptr(flags), n_global, L.ptr(pos), L.ptr(ids), L.ptr(n_halo), L.ptr(ws),
                                            ws_bytes, L.stream_ptr()), "tfgx_halo_compact")
         col_local = self.empty(E, torch.int32)
-        L.check(self.lib.tfgx_halo_remap_cols(L.ptr(col), E, own_lo, own_hi, L.ptr(pos), own_hi - own_lo,
+        L.check(self.lib.tfgx_halo_remap_cols(L.ptr(col), E, src_lo, src_hi, L.ptr(pos), n_own,
                                               L.ptr(col_local), L.stream_ptr()), "tfgx_halo_remap_cols")
         k = int(n_halo.item())
         return ids[:k].clone(), col_local
@@ -222,6 +227,37 @@ class HipBackend(object):
         return out
 
 
+def _fill_dense_peers(flags, peer_bounds, rank, dense_pct):
+    """flags: int32 [n_global] (1 = referenced remote source).  Sets the whole range of every peer (not `rank`) whose
+    block is referenced to at least dense_pct percent; torch ops only, so the numpy test backend shares it."""
+    b = [int(v) for v in peer_bounds]
+    cs = torch.zeros(flags.shape[0] + 1, dtype=torch.int64, device=flags.device)
+    torch.cumsum(flags, 0, out=cs[1:])
+    edges = cs[torch.as_tensor(b, dtype=torch.long, device=flags.device)].tolist()        # world + 1 integers
+    for p in range(len(b) - 1):
+        size, cnt = b[p + 1] - b[p], int(edges[p + 1] - edges[p])
+        if p != rank and size > 0 and 100 * cnt >= dense_pct * size:
+            flags[b[p]:b[p + 1]] = 1
+
+
+def bounds_from_degrees(deg, world):
+    """edge_balanced_bounds on a DEVICE in-degree histogram (int64 [n]): nothing node-sized visits the host.
+    -> (bounds int64 numpy [world+1], row_ptr int64 tensor [n+1])."""
+    n = int(deg.shape[0])
+    rp = torch.zeros(n + 1, dtype=torch.int64, device=deg.device)
+    torch.cumsum(deg, 0, out=rp[1:])
+    E = int(rp[-1].item()) if n else 0
+    bounds = np.zeros(world + 1, dtype=np.int64)
+    bounds[world] = n
+    if world > 1 and E > 0:
+        targets = torch.tensor([(E * k) // world for k in range(1, world)], dtype=torch.int64, device=deg.device)
+        bounds[1:world] = torch.searchsorted(rp, targets, right=False).cpu().numpy()
+    bounds = np.minimum(np.maximum.accumulate(bounds), n)
+    if E == 0:
+        bounds = (np.arange(world + 1, dtype=np.int64) * n) // world
+    return bounds, rp
+
+
 def edge_balanced_bounds(row_ptr_host, world):
     """Split points on the global row_ptr so that each rank gets ~E/world edges. -> int64 [world+1] node ids."""
     rp = np.asarray(row_ptr_host, dtype=np.int64)
@@ -247,120 +283,94 @@ class ShardedGraph(object):
         self.world = 1
 
     # ------------------------------------------------------------------ construction
-    @staticmethod
-    def from_global(edge_index, num_nodes, edge_weight=None, group=None, backend=None, rounds=None):
-        """Every rank passes the SAME global edge_index [2, E] (numpy on the host, or a tensor) and optional
-        edge_weight [E]; each rank counts in-degrees over the whole list (to agree on the split points) but uploads,
-        sorts and keeps only its own E/W slice."""
-        self = ShardedGraph()
+    def _init_common(self, num_nodes, group, backend, transport, self_halo_rows):
+        from .transport import get_transport
         be = self.backend = backend or HipBackend()
         self.group = group
-        self.world = dist.get_world_size(group) if (group is not None or dist.is_initialized()) else 1
-        self.rank = dist.get_rank(group) if (group is not None or dist.is_initialized()) else 0
+        inited = group is not None or dist.is_initialized()
+        self.world = dist.get_world_size(group) if inited else 1
+        self.rank = dist.get_rank(group) if inited else 0
         self.n_global = int(num_nodes)
+        self.transport = transport if (transport is not None and not isinstance(transport, str)) else \
+            get_transport(group, be, transport)
+        # TEST MODE (world-size-1 runs of the real exchange): only the first `self_halo_rows` own rows count as resident
+        # sources; the other own rows are requested through the halo exchange — from this rank itself.  Pack kernel,
+        # RCCL sends / receives, events, per-round waits and the reverse exchange then carry real rows on ONE GPU.
+        self._self_halo_rows = None if self_halo_rows is None else int(self_halo_rows)
+        return be
 
-        # 1. in-degree histogram of the GLOBAL edge list -> global row_ptr (host; N+1 ints) -> edge-balanced bounds.
-        #    Only counting touches all E edges; sorting happens on the rank's own E/W slice (step 3).
-        if isinstance(edge_index, torch.Tensor):
-            ei_all = edge_index.reshape(2, -1)
-            deg = torch.bincount(ei_all[0].long(), minlength=self.n_global).cpu().numpy()
-            if deg.shape[0] != self.n_global or (ei_all.numel() and int(ei_all.min()) < 0):
-                raise L.TfgxError("edge endpoint outside [0, {})".format(self.n_global))
-        else:
-            ei_all = np.asarray(edge_index).reshape(2, -1)
-            if ei_all.size and (ei_all.min() < 0 or ei_all.max() >= self.n_global):
-                raise L.TfgxError("edge endpoint outside [0, {})".format(self.n_global))
-            deg = np.bincount(ei_all[0], minlength=self.n_global)
-        rp_host = np.zeros(self.n_global + 1, dtype=np.int64)
-        np.cumsum(deg, out=rp_host[1:])
-
-        # 2. edge-balanced split points (identical on every rank)
-        self.bounds = edge_balanced_bounds(rp_host, self.world)
+    @staticmethod
+    def from_global(edge_index, num_nodes, edge_weight=None, group=None, backend=None, rounds=None, transport=None,
+                    self_halo_rows=None):
+        """Every rank passes the SAME global edge_index [2, E] (numpy on the host, or a tensor) and optional
+        edge_weight [E]; each rank counts in-degrees over the whole list (to agree on the split points) but sorts and
+        keeps only its own E/W slice.  All edge-sized work runs on the backend's device (torch ops: histogram, prefix sum,
+        mask, compaction)."""
+        self = ShardedGraph()
+        be = self._init_common(num_nodes, group, backend, transport, self_halo_rows)
+        ei_all = be.i32(edge_index).reshape(2, -1)
+        if ei_all.numel() and (int(ei_all.min()) < 0 or int(ei_all.max()) >= self.n_global):
+            raise L.TfgxError("edge endpoint outside [0, {})".format(self.n_global))
+        # 1. in-degree histogram of the GLOBAL edge list -> edge-balanced split points (identical on every rank)
+        deg = torch.bincount(ei_all[0].long(), minlength=self.n_global)
+        self.bounds, rp = bounds_from_degrees(deg, self.world)
         lo, hi = int(self.bounds[self.rank]), int(self.bounds[self.rank + 1])
         self.own_lo, self.own_hi, self.n_own = lo, hi, hi - lo
-        self.num_edges_global = int(rp_host[-1])
-
-        # 3. my edges (destination in [lo, hi)), kept in the caller's relative order, then the stable CSR build of
-        #    that slice alone — the same rows a global stable sort would put in positions [rp[lo], rp[hi])
+        self.num_edges_global = int(rp[-1].item())
+        # 2. my edges (destination in [lo, hi)), kept in the caller's relative order, then the stable CSR build of that
+        #    slice alone — the same rows a global stable sort would put in positions [rp[lo], rp[hi])
         mine = (ei_all[0] >= lo) & (ei_all[0] < hi)
-        if isinstance(edge_index, torch.Tensor):
-            edge_ids = torch.nonzero(mine).flatten()
-            local = torch.stack([ei_all[0][edge_ids] - lo, ei_all[1][edge_ids]])
-            w_local = None if edge_weight is None else be.f32(edge_weight)[edge_ids.to(be.device)]
-        else:
-            edge_ids = np.flatnonzero(mine)
-            local = np.stack([ei_all[0][edge_ids] - lo, ei_all[1][edge_ids]]).astype(np.int32)
-            w_local = None if edge_weight is None else np.asarray(edge_weight, dtype=np.float32)[edge_ids]
-        assert int(local.shape[1]) == int(rp_host[hi] - rp_host[lo])
+        edge_ids = torch.nonzero(mine).flatten()
+        local = torch.stack([ei_all[0][edge_ids] - lo, ei_all[1][edge_ids]]).to(torch.int32)
+        w_local = None if edge_weight is None else be.f32(edge_weight)[edge_ids]
+        assert int(local.shape[1]) == int((rp[hi] - rp[lo]).item())
         self._finish_build(local, w_local, edge_ids, rounds)
         return self
 
     @staticmethod
-    def from_partitioned(edge_index_part, num_nodes, edge_weight_part=None, group=None, backend=None, rounds=None):
+    def from_partitioned(edge_index_part, num_nodes, edge_weight_part=None, group=None, backend=None, rounds=None,
+                         transport=None, self_halo_rows=None):
         """Every rank passes ITS OWN PART of the global edge list (any split: file shards, a generator's stripes —
-        destinations need not be local) as a numpy [2, E_part] array, and optionally that part's weights.  Nothing
-        edge-sized is ever replicated: ranks all-reduce the in-degree histogram (N ints) to agree on the edge-balanced
-        split points, route every edge to the owner of its destination with one all-to-all-v, and from there build
-        exactly what from_global builds.  "This shard's edge order" (self.perm, weights passed later) is the arrival
-        order: parts concatenated by sending rank, each in its own order."""
+        destinations need not be local) as a [2, E_part] array / tensor, and optionally that part's weights.  Nothing
+        edge-sized is ever replicated and nothing edge- or node-sized visits the host: the ranks all-reduce the in-degree
+        histogram on the device to agree on the edge-balanced split points, bucket their edges by destination owner (stable
+        sort on the device) and route them — int32 rows, int32 columns, float32 weights — with one all-to-all-v each through
+        the transport; from there the build is what from_global builds.  "This shard's edge order" (self.perm, weights
+        passed later) is the arrival order: parts concatenated by sending rank, each in its own order."""
         self = ShardedGraph()
-        be = self.backend = backend or HipBackend()
-        self.group = group
-        self.world = dist.get_world_size(group) if (group is not None or dist.is_initialized()) else 1
-        self.rank = dist.get_rank(group) if (group is not None or dist.is_initialized()) else 0
-        self.n_global = int(num_nodes)
-        ei = np.asarray(edge_index_part).reshape(2, -1)
-        if ei.size and (ei.min() < 0 or ei.max() >= self.n_global):
+        be = self._init_common(num_nodes, group, backend, transport, self_halo_rows)
+        t = self.transport
+        ei = be.i32(edge_index_part).reshape(2, -1)
+        if ei.numel() and (int(ei.min()) < 0 or int(ei.max()) >= self.n_global):
             raise L.TfgxError("edge endpoint outside [0, {})".format(self.n_global))
-        w_part = None if edge_weight_part is None else np.asarray(edge_weight_part, dtype=np.float32).reshape(-1)
-        deg = torch.from_numpy(np.bincount(ei[0], minlength=self.n_global).astype(np.int64))
+        w_part = None if edge_weight_part is None else be.f32(edge_weight_part).reshape(-1)
+        deg = torch.bincount(ei[0].long(), minlength=self.n_global)
         if self.world > 1:
-            deg = self._all_reduce_sum_host(deg)
-        rp_host = np.zeros(self.n_global + 1, dtype=np.int64)
-        np.cumsum(deg.numpy(), out=rp_host[1:])
-        self.bounds = edge_balanced_bounds(rp_host, self.world)
+            deg = t.all_reduce_sum_i64(deg.contiguous())
+        self.bounds, rp = bounds_from_degrees(deg, self.world)
         lo, hi = int(self.bounds[self.rank]), int(self.bounds[self.rank + 1])
         self.own_lo, self.own_hi, self.n_own = lo, hi, hi - lo
-        self.num_edges_global = int(rp_host[-1])
+        self.num_edges_global = int(rp[-1].item())
         if self.world > 1:
             # destination owner of every edge of my part; a stable sort by owner keeps each part's own order
-            owner = np.searchsorted(self.bounds, ei[0], side="right") - 1
-            owner = np.minimum(owner, self.world - 1)
-            order = np.argsort(owner, kind="stable")
-            send_counts = np.bincount(owner, minlength=self.world).astype(np.int64)
-            sc = torch.from_numpy(send_counts.copy())
-            rc = torch.empty(self.world, dtype=torch.int64)
-            self._a2a_host(rc, sc, [1] * self.world, [1] * self.world)
-            recv_counts = [int(v) for v in rc.tolist()]
+            cuts = torch.as_tensor(self.bounds[1:-1], dtype=torch.int64, device=ei.device)
+            owner = torch.bucketize(ei[0].long(), cuts, right=True).clamp_(max=self.world - 1)
+            order = torch.argsort(owner, stable=True)
+            send_counts = torch.bincount(owner, minlength=self.world)
             send_list = [int(v) for v in send_counts.tolist()]
-            got = []
-            for arr in (ei[0], ei[1]):
-                out = torch.empty(sum(recv_counts), dtype=torch.int64)
-                self._a2a_host(out, torch.from_numpy(arr[order].astype(np.int64)), recv_counts, send_list)
-                got.append(out.numpy())
-            if w_part is not None:
-                wout = torch.empty(sum(recv_counts), dtype=torch.int64)
-                self._a2a_host(wout, torch.from_numpy(w_part[order].view(np.int32).astype(np.int64)), recv_counts, send_list)
-                w_local = wout.numpy().astype(np.int32).view(np.float32)
-            else:
-                w_local = None
-            rows, cols = got
+            recv_counts = t.all_to_all_v(send_counts.contiguous(), [1] * self.world, [1] * self.world)
+            recv_list = [int(v) for v in recv_counts.tolist()]
+            rows = t.all_to_all_v(ei[0][order], send_list, recv_list)
+            cols = t.all_to_all_v(ei[1][order], send_list, recv_list)
+            w_local = None if w_part is None else t.all_to_all_v(w_part[order], send_list, recv_list)
         else:
-            rows, cols, w_local = ei[0].astype(np.int64), ei[1].astype(np.int64), w_part
-        assert rows.size == 0 or (rows.min() >= lo and rows.max() < hi)
-        local = np.stack([rows - lo, cols]).astype(np.int32)
-        assert int(local.shape[1]) == int(rp_host[hi] - rp_host[lo])
-        self._finish_build(local, w_local, np.arange(local.shape[1], dtype=np.int64), rounds)
+            rows, cols, w_local = ei[0], ei[1], w_part
+        if rows.numel() and (int(rows.min()) < lo or int(rows.max()) >= hi):
+            raise L.TfgxError("edge routed to a rank that does not own its destination")
+        local = torch.stack([rows - lo, cols]).to(torch.int32)
+        assert int(local.shape[1]) == int((rp[hi] - rp[lo]).item())
+        self._finish_build(local, w_local, torch.arange(int(local.shape[1]), device=local.device), rounds)
         return self
-
-    def _all_reduce_sum_host(self, t):
-        """Sum a host int64 tensor over the group (through the GPU when the group is NCCL)."""
-        if dist.get_backend(self.group) == "nccl":
-            d = t.to(self.backend.device)
-            dist.all_reduce(d, group=self.group)
-            return d.cpu()
-        dist.all_reduce(t, group=self.group)
-        return t
 
     def _finish_build(self, local, w_local, edge_ids, rounds):
         """Steps 3b-6 of the shard build from this rank's edges (`local`: [2, E_own], destinations already relative to
@@ -370,11 +380,17 @@ class ShardedGraph(object):
         self.num_edges = int(local.shape[1])
         self.row_ptr, col_slice, perm_local = be.build_csr(be.i32(local), self.n_own, self.n_global)
         w_slice = None if w_local is None else be.permute_rows(w_local, perm_local)
-        ids_dev = be.i32(edge_ids) if not isinstance(edge_ids, torch.Tensor) else edge_ids.to(torch.int32).to(be.device)
+        ids_dev = be.i32(edge_ids)
         self.perm = ids_dev[perm_local.long()].contiguous()     # CSR position -> global edge id (caller's order)
 
-        # 4. halo: remote sources, sorted + de-duplicated; col remapped into [own | halo]
-        self.halo_ids, col_local = be.halo_plan(col_slice, lo, hi, self.n_global)
+        # 4. halo: remote sources, sorted + de-duplicated; col remapped into [own | halo].  A peer whose block is
+        #    referenced to >= TFGX_DENSE_PEER_PCT percent (default 90; uniform random graphs at 8 GPUs: 99.8) is requested
+        #    WHOLE: its owner then sends the block as it is — no pack kernel, no send buffer.
+        self_halo = self._self_halo_rows is not None
+        src_hi = lo + min(max(self._self_halo_rows, 0), self.n_own) if self_halo else hi
+        dense_pct = int(os.environ.get("TFGX_DENSE_PEER_PCT", "90"))
+        self.halo_ids, col_local = be.halo_plan(col_slice, lo, src_hi, self.n_global, self.n_own,
+                                                peer_bounds=self.bounds, rank=self.rank, dense_pct=dense_pct)
         self.n_halo = int(self.halo_ids.shape[0])
         self.n_table = self.n_own + self.n_halo
 
@@ -382,7 +398,7 @@ class ShardedGraph(object):
         #    the halo travels in R all-to-all-v rounds and the edges of round j are reduced while round j+1 flies
         if rounds is None:
             rounds = int(os.environ.get("TFGX_HALO_ROUNDS", "4" if self.n_global // max(self.world, 1) >= 16384 else "1"))
-        self.rounds = max(1, min(int(rounds), 16)) if self.world > 1 else 0
+        self.rounds = max(1, min(int(rounds), 16)) if (self.world > 1 or self_halo) else 0
         self._build_exchange_lists()
         col_local = self._round_major_layout(col_local)
 
@@ -401,74 +417,73 @@ class ShardedGraph(object):
         self.self_coef = None
 
     def _build_exchange_lists(self):
-        be, W = self.backend, self.world
-        halo_host = self.halo_ids.cpu().numpy().astype(np.int64)
-        cuts = np.searchsorted(halo_host, self.bounds, side="left")
+        """Per-peer request counts and id lists, on the device (the halo ids are node-sized: 10^8 at papers100M shape).
+        A peer block requested whole is DENSE: its ids are not exchanged at all (the owner knows them: its own range)."""
+        be, W, t = self.backend, self.world, self.transport
+        dev = self.halo_ids.device
+        cuts = torch.searchsorted(self.halo_ids.long(), torch.as_tensor(self.bounds, dtype=torch.int64, device=dev)).tolist()
         self.recv_counts = [int(cuts[p + 1] - cuts[p]) for p in range(W)]       # rows I receive from p
-        assert self.recv_counts[self.rank] == 0
-        if W == 1:
-            self.send_counts = [0]
-            self.send_idx = be.i32(np.zeros(0, np.int32))
+        assert self.recv_counts[self.rank] == 0 or self._self_halo_rows is not None
+        size = [int(self.bounds[p + 1] - self.bounds[p]) for p in range(W)]
+        dense_recv = [self.recv_counts[p] == size[p] and size[p] > 0 and p != self.rank for p in range(W)]
+        if self.rounds == 0:
+            self.send_counts, self.dense_send = [0] * W, [False] * W
+            self._give_local, self._give_start = be.i32(np.zeros(0, np.int32)), [0] * (W + 1)
             return
-        rc = torch.tensor(self.recv_counts, dtype=torch.int64)
-        sc = torch.empty(W, dtype=torch.int64)
-        self._a2a_host(sc, rc, [1] * W, [1] * W)
-        self.send_counts = [int(v) for v in sc.tolist()]                         # rows p wants from me
-        want = torch.from_numpy(halo_host.astype(np.int64))
-        give = torch.empty(sum(self.send_counts), dtype=torch.int64)
-        self._a2a_host(give, want, self.send_counts, self.recv_counts)
-        give_np = give.numpy()
-        assert ((give_np >= self.own_lo) & (give_np < self.own_hi)).all(), "peer asked for rows I do not own"
-        self.send_idx = be.i32((give_np - self.own_lo).astype(np.int32))
-        self._give_local = (give_np - self.own_lo).astype(np.int32)
+        rc = torch.tensor(self.recv_counts, dtype=torch.int64, device=dev)
+        self.send_counts = [int(v) for v in t.all_to_all_v(rc, [1] * W, [1] * W).tolist()]   # rows p wants from me
+        # a request for exactly n_own rows can only be the whole block [own_lo, own_hi): no list needed, no pack
+        self.dense_send = [self.send_counts[q] == self.n_own and self.n_own > 0 and q != self.rank for q in range(W)]
+        want_counts = [0 if dense_recv[p] else self.recv_counts[p] for p in range(W)]
+        give_counts = [0 if self.dense_send[q] else self.send_counts[q] for q in range(W)]
+        seg = [self.halo_ids[cuts[p]:cuts[p + 1]] for p in range(W) if not dense_recv[p]]
+        want = torch.cat(seg) if seg else self.halo_ids[:0]
+        give = t.all_to_all_v(want.contiguous(), want_counts, give_counts)       # global ids peers want from me
+        if give.numel() and (int(give.min()) < self.own_lo or int(give.max()) >= self.own_hi):
+            raise L.TfgxError("a peer asked for rows this rank does not own")
+        self._give_local = (give - self.own_lo).to(torch.int32).contiguous()
+        self._give_start = [0] + [int(v) for v in np.cumsum(give_counts)]
 
     def _round_major_layout(self, col_local):
         """Cut each peer's halo segment (and the matching send list) into `rounds` contiguous slices and lay the halo
         table out round-major: [round 0: peer 0 slice, peer 1 slice, ... | round 1: ...].  Sender and receiver use the
-        same floor(L*j/R) cut points, so slice j of the list peer q requested is slice j of what q expects."""
+        same floor(L*j/R) cut points, so slice j of the list peer q requested is slice j of what q expects.  Device ops
+        only (W x R small host loops that build index ranges)."""
         be, W, R = self.backend, self.world, self.rounds
-        if W == 1 or R == 0:
+        dev = self.halo_ids.device
+        if R == 0:
             self.round_offset = np.zeros(1, dtype=np.int64)
-            self.round_recv_counts, self.round_send_counts, self.round_send_idx = [], [], []
+            self.round_recv_counts, self.round_send_counts, self.round_send_dense, self.round_send_idx = [], [], [], []
+            self.send_idx_packed = be.i32(np.zeros(0, np.int32))
             return col_local
-        cut = lambda length, j: (length * j) // R
+        cut = lambda length, j: (length * j) // R                                  # noqa: E731
         seg_start = np.concatenate([[0], np.cumsum(self.recv_counts)]).astype(np.int64)   # old halo layout: by peer
         self.round_recv_counts = [[cut(self.recv_counts[p], j + 1) - cut(self.recv_counts[p], j) for p in range(W)]
                                   for j in range(R)]
         self.round_send_counts = [[cut(self.send_counts[p], j + 1) - cut(self.send_counts[p], j) for p in range(W)]
                                   for j in range(R)]
+        # dense (round, peer) entries: the contiguous own rows [cut(n_own, j), cut(n_own, j + 1)); -1 = packed
+        self.round_send_dense = [[cut(self.send_counts[p], j) if self.dense_send[p] else -1 for p in range(W)]
+                                 for j in range(R)]
         self.round_offset = np.concatenate([[0], np.cumsum([sum(c) for c in self.round_recv_counts])]).astype(np.int64)
-        newpos = np.empty(self.n_halo, dtype=np.int32)
-        for j in range(R):
-            base = int(self.round_offset[j])
-            for p in range(W):
-                a, b = int(seg_start[p]) + cut(self.recv_counts[p], j), int(seg_start[p]) + cut(self.recv_counts[p], j + 1)
-                newpos[a:b] = base + np.arange(b - a, dtype=np.int32)
-                base += b - a
-        order = np.argsort(newpos, kind="stable")
-        self.halo_ids = be.i32(self.halo_ids.cpu().numpy()[order])                # halo ids in table order
-        send_start = np.concatenate([[0], np.cumsum(self.send_counts)]).astype(np.int64)
+        pieces = [torch.arange(int(seg_start[p]) + cut(self.recv_counts[p], j), int(seg_start[p]) + cut(self.recv_counts[p], j + 1),
+                               device=dev) for j in range(R) for p in range(W)]
+        order = torch.cat(pieces) if pieces else torch.zeros(0, dtype=torch.int64, device=dev)   # table order -> old position
+        newpos = torch.empty(self.n_halo, dtype=torch.int32, device=dev)
+        newpos[order] = torch.arange(self.n_halo, dtype=torch.int32, device=dev)
+        self.halo_ids = self.halo_ids[order].contiguous()                          # halo ids in table order
         self.round_send_idx = []
         for j in range(R):
-            parts = [self._give_local[int(send_start[p]) + cut(self.send_counts[p], j):
-                                      int(send_start[p]) + cut(self.send_counts[p], j + 1)] for p in range(W)]
-            self.round_send_idx.append(be.i32(np.concatenate(parts) if parts else np.zeros(0, np.int32)))
+            parts = [self._give_local[self._give_start[p] + cut(self.send_counts[p], j):
+                                      self._give_start[p] + cut(self.send_counts[p], j + 1)]
+                     for p in range(W) if not self.dense_send[p]]
+            self.round_send_idx.append(torch.cat(parts).contiguous() if parts else self._give_local[:0])
+        self.send_idx_packed = torch.cat(self.round_send_idx).contiguous() if self.round_send_idx else self._give_local[:0]
         # remap halo columns old position -> round-major position
-        newpos_t = be.i32(newpos)
         cl = col_local.long()
         is_halo = cl >= self.n_own
-        remapped = torch.where(is_halo, self.n_own + newpos_t[(cl - self.n_own).clamp(min=0)].long(), cl)
+        remapped = torch.where(is_halo, self.n_own + newpos[(cl - self.n_own).clamp(min=0)].long(), cl)
         return remapped.to(torch.int32).contiguous()
-
-    def _a2a_host(self, out, inp, out_splits, in_splits):
-        """Small plan-time all-to-all-v of int64 host tensors (through the GPU when the group is NCCL)."""
-        if dist.get_backend(self.group) == "nccl":
-            dev = self.backend.device
-            o = out.to(dev)
-            dist.all_to_all_single(o, inp.to(dev), list(out_splits), list(in_splits), group=self.group)
-            out.copy_(o.cpu())
-        else:
-            dist.all_to_all_single(out, inp, list(out_splits), list(in_splits), group=self.group)
 
     # ------------------------------------------------------------------ source table + exchange
     def alloc_table(self, num_features):
@@ -482,38 +497,15 @@ class ShardedGraph(object):
         return table[self.n_own:]
 
     def exchange_start(self, table):
-        """Pack the rows peers need and start the R all-to-all-v rounds into table[n_own:] (round-major).  Returns a
-        list of per-round handles for exchange_finish().  With NCCL the collectives queue on RCCL's stream and run
-        concurrently with whatever is launched on the current stream afterwards, round 0 completing first."""
-        if self.world == 1:
-            return None
-        be = self.backend
-        F = int(table.shape[1])
-        nccl = dist.get_backend(self.group) == "nccl"
-        handles = []
-        for j in range(self.rounds):
-            send = be.gather_rows(self.own_rows(table), self.round_send_idx[j])
-            halo = table[self.n_own + int(self.round_offset[j]):self.n_own + int(self.round_offset[j + 1])]
-            out_splits, in_splits = list(self.round_recv_counts[j]), list(self.round_send_counts[j])
-            if nccl:
-                work = dist.all_to_all_single(halo, send, out_splits, in_splits, group=self.group, async_op=True)
-                handles.append(["nccl", work, send])
-            else:      # gloo (tests / no-RCCL runs): stage through the host
-                recv_h = torch.empty((int(halo.shape[0]), F), dtype=torch.float32)
-                dist.all_to_all_single(recv_h, send.cpu(), out_splits, in_splits, group=self.group)
-                handles.append(["host", recv_h, halo])
-        return handles
+        """Start the R rounds of the halo exchange into table[n_own:] (round-major) and return a handle for
+        exchange_finish().  Product path (transport "tfgx_dist"): per round one pack launch for the packed peers on the
+        compute stream, then grouped ncclSend / ncclRecv on the transport's communication stream — asynchronous, so the
+        passes launched on the current stream afterwards overlap the transfer, round 0 completing first."""
+        return self.transport.exchange_start(self, table)
 
     def exchange_finish(self, handles, j=None):
-        """Wait for round j (None: all rounds)."""
-        if handles is None:
-            return
-        for h in (handles if j is None else [handles[j]]):
-            if h[0] == "nccl":
-                h[1].wait()           # current stream waits for the RCCL stream
-            elif h[0] == "host":
-                h[2].copy_(h[1])
-            h[0] = "done"
+        """Make the current stream wait for round j (None: all rounds)."""
+        return self.transport.exchange_finish(self, handles, j)
 
     # ------------------------------------------------------------------ aggregation
     def aggregate(self, table, op=L.SUM, w="plan", self_coef=None, bias=None, act=L.ACT_NONE, out=None,
@@ -617,43 +609,30 @@ class ShardedGraph(object):
     def reverse_exchange(self, d_table, inplace=False):
         """Gradient w.r.t. the [own | halo] source table -> gradient w.r.t. this rank's own rows (the backward of the
         halo exchange).  The halo-row gradients travel back along the forward exchange's lists (what I received from p in
-        round j, I send to p; what I sent, I receive), one all-to-all-v per round; returned rows are added into the own
+        round j, I send to p; what I sent, I receive), one grouped exchange per round; returned rows are added into the own
         rows at the forward send indices, peer by peer in rank order and round by round — a fixed order, and one peer's
         list has no repeated row, so the sum is deterministic without atomics (tfgx_scatter_add_rows_f32)."""
-        be = self.backend
-        U = int(d_table.shape[1])
+        d_table = d_table.contiguous()
+        handle = self.transport.reverse_start(self, d_table)
         d_own = d_table[:self.n_own]
         if not inplace:
             d_own = d_own.clone()
-        if self.world == 1:
-            return d_own
-        d_halo = d_table[self.n_own:self.n_table]
-        nccl = dist.get_backend(self.group) == "nccl"
-        for j in range(self.rounds):
-            seg = d_halo[int(self.round_offset[j]):int(self.round_offset[j + 1])].contiguous()
-            n_back = int(sum(self.round_send_counts[j]))
-            back = be.empty((n_back, U))
-            # reverse direction: my forward RECEIVE counts are what I now send, and vice versa
-            out_splits, in_splits = list(self.round_send_counts[j]), list(self.round_recv_counts[j])
-            if nccl:
-                dist.all_to_all_single(back, seg, out_splits, in_splits, group=self.group)
-            else:
-                back_h = torch.empty((n_back, U), dtype=torch.float32)
-                dist.all_to_all_single(back_h, seg.cpu(), out_splits, in_splits, group=self.group)
-                back.copy_(back_h)
-            off = 0
-            for p in range(self.world):            # fixed peer order
-                cnt = int(self.round_send_counts[j][p])
-                if cnt:
-                    be.scatter_add_rows(d_own, self.round_send_idx[j][off:off + cnt], back[off:off + cnt])
-                off += cnt
-        return d_own
+        return self.transport.reverse_finish(self, handle, d_own)
 
-    def halo_table(self, h_own):
+    def halo_table(self, h_own, defer=False):
         """Differentiable [own | halo] source table of own rows `h_own`: forward = the halo exchange, backward =
         reverse_exchange.  Any single-GPU differentiable operator on local_plan() composed with it is the sharded
-        operator WITH its backward (max aggregation, the fused attention)."""
-        return _HaloGather.apply(self, h_own)
+        operator WITH its backward (max aggregation, the fused attention).  defer=True: the exchange is only STARTED
+        (asynchronous on the communication stream); the caller launches whatever row-local work it has and calls
+        halo_table_wait() before the first kernel that reads halo rows."""
+        return _HaloGather.apply(self, h_own, bool(defer))
+
+    def halo_table_wait(self):
+        h = getattr(self, "_deferred_exchange", None)
+        if h is not None:
+            self._deferred_exchange = None
+            with torch.no_grad():          # (the host-staged test transport copies into views made inside the Function)
+                self.exchange_finish(h)
 
     def local_plan(self):
         """This shard as an [n_own x n_table] CSR operator (plan.CsrPlan over row_ptr / col — rows stay contiguous
@@ -682,12 +661,21 @@ class ShardedGraph(object):
         rp_t, dst_t, perm_t = self._transposed_local()
         wt = None if w_t is None else be.permute_rows(w_t, perm_t)
         d_table = be.empty((max(self.n_table, 1), U))
+        n_own, n_halo = self.n_own, self.n_halo
         if getattr(self, "_tl_hub", None) is None:      # hub SOURCES of the shard: chunked, as the forward's hub rows are
             hub_fn = getattr(be, "hub_lists", None)
-            self._tl_hub = (hub_fn(rp_t, rp_t[1:], 1, self.n_table, self.num_edges) if hub_fn else None) or False
-        kw = {"hub": self._tl_hub} if self._tl_hub else {}
-        be.segment_reduce(rp_t, rp_t[1:], 1, dst_t, wt, self.n_table, g, d_table, L.SUM, **kw)
-        d_own = self.reverse_exchange(d_table, inplace=True)
+            self._tl_hub = [(hub_fn(rp_t[a:], rp_t[a + 1:], 1, m, self.num_edges) if (hub_fn and m > 0) else None) or False
+                            for a, m in ((n_own, n_halo), (0, n_own))]
+        # halo rows FIRST: their gradients belong to peers and start travelling (reverse exchange, asynchronous on the
+        # communication stream) while the own rows' part of the transposed pass runs on the compute stream
+        if n_halo > 0:
+            kw = {"hub": self._tl_hub[0]} if self._tl_hub[0] else {}
+            be.segment_reduce(rp_t[n_own:], rp_t[n_own + 1:], 1, dst_t, wt, n_halo, g, d_table[n_own:n_own + n_halo], L.SUM, **kw)
+        handle = self.transport.reverse_start(self, d_table)
+        if n_own > 0:
+            kw = {"hub": self._tl_hub[1]} if self._tl_hub[1] else {}
+            be.segment_reduce(rp_t, rp_t[1:], 1, dst_t, wt, n_own, g, d_table[:n_own], L.SUM, **kw)
+        d_own = self.transport.reverse_finish(self, handle, d_table[:n_own])
         if self_coef is not None:
             d_own = d_own + self_coef.unsqueeze(1) * g
         return d_own
@@ -712,10 +700,11 @@ class ShardedGraph(object):
         backward (reverse_exchange).  query_act / key_act: L.ACT_* codes (as gat()); activation: a callable or None."""
         be = self.backend
         A = int(query_kernel.shape[1])
-        Q = be.linear(x_own, query_kernel, query_bias, query_act)
         K = be.linear(x_own, key_kernel, key_bias, key_act)
         V = be.linear(x_own, kernel)
-        table = self.halo_table(torch.cat([K, V], 1))
+        table = self.halo_table(torch.cat([K, V], 1), defer=True)      # [K | V] rows start travelling ...
+        Q = be.linear(x_own, query_kernel, query_bias, query_act)      # ... while the row-local Q projection runs
+        self.halo_table_wait()
         out = be.gat_attention_autograd(self, Q, table[:, :A], table[:, A:], num_heads)
         if bias is not None:
             out = out + bias
@@ -727,8 +716,15 @@ class ShardedGraph(object):
         SAME activation after the MLP and at the end, as the reference applies it."""
         be = self.backend
         h = be.linear(x_own, neighbor_mlp_kernel, neighbor_mlp_bias, act)
-        reduced = self.aggregate_trainable(h, op, w=None)
-        a, b = be.linear(x_own, self_kernel), be.linear(reduced, neighbor_kernel)
+        if op in (L.SUM, L.MEAN):
+            a = be.linear(x_own, self_kernel)
+            reduced = self.aggregate_trainable(h, op, w=None)
+        else:
+            table = self.halo_table(h, defer=True)                     # the MLP rows start travelling ...
+            a = be.linear(x_own, self_kernel)                          # ... under the row-local self projection
+            self.halo_table_wait()
+            reduced = be.aggregate_autograd(self, table, op, None)
+        b = be.linear(reduced, neighbor_kernel)
         out = torch.cat([a, b], 1) if concat else a + b
         if bias is not None:
             out = out + bias
@@ -752,13 +748,7 @@ class ShardedGraph(object):
         grads = [p.grad for p in params if p.grad is not None]
         if self.world == 1 or not grads:
             return
-        flat = torch.cat([g_.reshape(-1) for g_ in grads])
-        if dist.get_backend(self.group) == "nccl":
-            dist.all_reduce(flat, group=self.group)
-        else:
-            host = flat.cpu()
-            dist.all_reduce(host, group=self.group)
-            flat = host.to(flat.device)
+        flat = self.transport.all_reduce_sum_f32(torch.cat([g_.reshape(-1) for g_ in grads]).contiguous())
         off = 0
         for g_ in grads:
             g_.copy_(flat[off:off + g_.numel()].reshape(g_.shape))
@@ -1005,13 +995,18 @@ class _HaloGather(torch.autograd.Function):
     """own rows -> [own | halo] table (forward: halo exchange; backward: ShardedGraph.reverse_exchange)."""
 
     @staticmethod
-    def forward(ctx, sg, h_own):
+    def forward(ctx, sg, h_own, defer=False):
         ctx.sg = sg
         table = sg.alloc_table(int(h_own.shape[1]))
         sg.own_rows(table).copy_(h_own.detach())
-        sg.exchange_finish(sg.exchange_start(table))
+        handle = sg.exchange_start(table)
+        if defer:
+            sg.halo_table_wait()                       # at most one deferred exchange per shard
+            sg._deferred_exchange = handle
+        else:
+            sg.exchange_finish(handle)
         return table
 
     @staticmethod
     def backward(ctx, g_table):
-        return None, ctx.sg.reverse_exchange(g_table.contiguous())
+        return None, ctx.sg.reverse_exchange(g_table.contiguous()), None
