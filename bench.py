@@ -179,6 +179,16 @@ def cpu_baseline_op_for_op(x_np, ei_np, w_np, self_coef_np, n, f, budget_edges):
 # ----------------------------------------------------------------------------------------------------------------------
 # R-MAT variant: (a,b,c,d) = (0.57,0.19,0.19,0.05), generated on the GPU
 # ----------------------------------------------------------------------------------------------------------------------
+def kernel_source_sha():
+    """sha256[:16] of the headline kernel's sources — the same recipe tools/make_pmc_json.py stamps into profiles/*_pmc.json."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in ("tf_geometric_amd/csrc/tfgx_reduce.hip", "tf_geometric_amd/csrc/tfgx_common.h"):
+        with open(os.path.join(ROOT, rel), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def rmat_edges(n, e, seed, dev):
     """E/2 R-MAT pairs over 2^ceil(log2 n) ids, pairs with an id >= n or a == b dropped, both directions emitted
     [all (a,b) | all (b,a)] like the uniform generator.  int32 [2, ~E] on the device."""
@@ -456,11 +466,19 @@ def main():
         # HBM-side bytes per launch: IMPORTED from the committed rocprofv3 PMC profile of this command (FETCH_SIZE x2 on
         # gfx950 + WRITE_SIZE, separate --pmc passes; see profiles/).  Priced with the PROFILE's own kernel time — it
         # was taken on another box of the pool — never with this run's.
-        for tag in ("r02", "r01"):
+        sha_now = kernel_source_sha()
+        for tag in ("r03", "r02", "r01"):
             pmc_path = os.path.join(ROOT, "profiles", "{}_{}_pmc.json".format(tag, args.workload))
             if os.path.exists(pmc_path):
                 with open(pmc_path) as fh:
                     pmc = json.load(fh)
+                if pmc.get("kernel_source_sha16") != sha_now:
+                    # the profile describes ANOTHER build of the kernel: keep the line, drop the number
+                    line["roofline"]["traffic"] = None
+                    line["roofline"]["traffic_is"] = ("not reported: profiles/{} was measured on kernel sources {} but the "
+                                                      "tree holds {} (re-run tools/profile_round.sh)".format(
+                                                          os.path.basename(pmc_path), pmc.get("kernel_source_sha16"), sha_now))
+                    break
                 line["roofline"]["traffic"] = pmc["traffic_bytes_per_launch"]
                 line["roofline"]["traffic_is"] = "imported from profiles/{} (not measured in this run)".format(
                     os.path.basename(pmc_path))
@@ -495,11 +513,13 @@ def main():
                 "frac_of_hbm_peak_algorithmic": bytes_alg / (ms2 * 1e-3) / HBM_PEAK,
                 "build_ms_once_per_feature_matrix": build_ms, "layout_bytes": int(info["bytes"]),
                 "bit_identical_to_headline_output": bool(torch.equal(out2, res))}
-            for tag in ("r02", "r01"):          # HBM-side bytes of this launch, imported like roofline.traffic
+            for tag in ("r03", "r02", "r01"):   # HBM-side bytes of this launch, imported like roofline.traffic
                 et_path = os.path.join(ROOT, "profiles", "{}_{}_edge_tail_pmc.json".format(tag, args.workload))
                 if os.path.exists(et_path):
                     with open(et_path) as fh:
                         et = json.load(fh)
+                    if et.get("kernel_source_sha16") != kernel_source_sha():
+                        break
                     line["static_feature_layout"]["traffic_imported"] = et["traffic_bytes_per_launch"]
                     line["static_feature_layout"]["traffic_source"] = "profiles/" + os.path.basename(et_path)
                     if et.get("kernel_ms"):

@@ -140,3 +140,29 @@ def test_dynamic_lambda_max_converges_beyond_the_krylov_window(tfg, oracle):
     got = laplacian_max_eigenvalue(chebynet_norm_edge(ei, n, w, "sym"), "sym", steps=12, restarts=40)
     assert laplacian_max_eigenvalue.last["restarts"] >= 1
     assert abs(got - oracle.laplacian_max_eigenvalue(ei, n, w, "sym")) <= 1e-4 * abs(got)
+
+
+def test_gcn_layer_validates_num_splits_at_build_time(tfg, oracle):
+    """layers/conv/gcn.py:21-23 of the reference: build() computes the split and raises for an impossible num_splits
+    (utils/tf_sparse_utils.py:71-90); a valid one does not change the output."""
+    x, ei, rng = _graph(oracle, 120, 900, 10, seed=4)
+    bad = tfg.layers.GCN(9, num_splits=4)                  # 9 columns into 4 parts: ceil = 3 -> only 3 parts
+    with pytest.raises(Exception, match="cannot split H"):
+        bad([x, ei])
+    with pytest.raises(Exception, match="cannot provide both"):
+        tfg.layers.GCN(9, num_splits=3, num_or_size_splits=[3, 3, 3])
+    k = oracle.glorot_uniform(rng, 10, 9)
+    outs = []
+    for kw in (dict(), dict(num_splits=3), dict(num_splits=2), dict(num_or_size_splits=[4, 5])):
+        layer = tfg.layers.GCN(9, use_bias=False, **kw)
+        layer._maybe_build([x])
+        layer.set_weights(kernel=k)
+        outs.append(layer([x, ei]))
+    assert tfg.layers.GCN(9, num_splits=3)._maybe_build([x]) is None
+    lay = tfg.layers.GCN(9, num_splits=2)
+    lay._maybe_build([x])
+    assert lay.num_or_size_splits == [5, 4]
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+    nk = tfg.layers.GCN(9, use_kernel=False, num_splits=5)  # no kernel: the split applies to the F = 10 input columns
+    nk._maybe_build([x])
+    assert nk.num_or_size_splits == 5

@@ -38,6 +38,12 @@ class GCN(Layer):
 
     def build(self, input_shapes):
         num_features = input_shapes[0][-1]
+        if self.num_splits is not None:
+            # as the reference's build (layers/conv/gcn.py:21-23 -> utils/tf_sparse_utils.py:71-90): the split is computed
+            # here and an impossible num_splits raises at build time, not at the first call
+            from ...dist.sharded import compute_num_or_size_splits
+            num_h_features = self.units if self.use_kernel else num_features
+            self.num_or_size_splits = compute_num_or_size_splits(num_h_features, self.num_splits)
         if self.use_kernel:
             self.kernel = self.add_weight("kernel", [num_features, self.units], "glorot_uniform")     # :26-27
         if self.use_bias:

@@ -6,9 +6,24 @@
 FETCH_SIZE / WRITE_SIZE are reported in KiB and summed over the XCDs; on gfx950 FETCH_SIZE tallies a 128-byte request
 as 64 bytes, so it is doubled (MI355X_MICROARCH.md, HBM / rocprofv3 section); WRITE_SIZE is used as reported.
 kernel_ms is the kernel's average duration in the --kernel-trace --stats pass of the SAME command."""
+import hashlib
 import json
+import os
 import sqlite3
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KERNEL_SOURCES = ["tf_geometric_amd/csrc/tfgx_reduce.hip", "tf_geometric_amd/csrc/tfgx_common.h"]
+
+
+def kernel_source_sha():
+    """sha256[:16] of the sources of the measured kernel: bench.py drops an imported `roofline.traffic` whose profile was
+    taken on other sources (the counters describe the binary that ran, not the one in the tree)."""
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def _per_dispatch(db, counter, needle):
@@ -54,6 +69,7 @@ if __name__ == "__main__":
         "traffic_bytes_per_launch": int(fetch_kib * 1024 * 2 + write_kib * 1024),
         "kernel_ms": avg_us / 1e3, "kernel_avg_us_rocprof": avg_us,
         "dispatches": {"fetch_pass": nf, "write_pass": nw, "stats_pass": calls},
+        "kernel_source_sha16": kernel_source_sha(), "kernel_sources": KERNEL_SOURCES,
     }
     with open(out, "w") as fh:
         json.dump(blob, fh, indent=2)
