@@ -123,15 +123,44 @@ __global__ __launch_bounds__(kBlock) void sddmm_fast_kernel(const int32_t* __res
                 }
                 acc[u] = t;
             }
+            if constexpr (G >= 8) {
+                // Reduce the 8 partial dot products across the G lanes with a VALUE-HALVING butterfly: at each of the first
+                // three steps a lane hands half of its values to its partner and keeps (and completes) the other half, so
+                // 4 + 2 + 1 exchanges replace 3 x 8; the remaining log2(G) - 3 steps carry one value.  9 cross-lane
+                // exchanges per 8 edges instead of 40 at G = 32 (each is an LDS-crossbar ds_bpermute: 5 per edge next to the
+                // forward kernel's 2 was what kept this kernel 0.8 ms behind the forward pass at products shape).
+                // Afterwards the lanes whose bits (G/2, G/4, G/8) spell u hold edge u's dot product.
+                constexpr int o1 = G / 2, o2 = G / 4, o3 = G / 8;
+                float a4[4], a2[2];
+                const bool hi1 = (lane & o1) != 0;
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
+                for (int u = 0; u < 4; ++u) {
+                    const float keep = hi1 ? acc[u + 4] : acc[u], send = hi1 ? acc[u] : acc[u + 4];
+                    a4[u] = keep + __shfl_xor(send, o1, G);
+                }
+                const bool hi2 = (lane & o2) != 0;
 #pragma unroll
-                for (int o = G / 2; o > 0; o >>= 1) acc[u] += __shfl_xor(acc[u], o, G);
+                for (int u = 0; u < 2; ++u) {
+                    const float keep = hi2 ? a4[u + 2] : a4[u], send = hi2 ? a4[u] : a4[u + 2];
+                    a2[u] = keep + __shfl_xor(send, o2, G);
+                }
+                const bool hi3 = (lane & o3) != 0;
+                float v = (hi3 ? a2[1] : a2[0]) + __shfl_xor(hi3 ? a2[0] : a2[1], o3, G);
+#pragma unroll
+                for (int o = G / 16; o > 0; o >>= 1) v += __shfl_xor(v, o, G);
+                const int u_mine = (hi1 ? 4 : 0) + (hi2 ? 2 : 0) + (hi3 ? 1 : 0);
+                if ((lane & (o3 - 1)) == 0 && i0 + u_mine < e) out[i0 + u_mine] = v;
+            } else {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+#pragma unroll
+                    for (int o = G / 2; o > 0; o >>= 1) acc[u] += __shfl_xor(acc[u], o, G);
+                }
+                float v = acc[0];
+#pragma unroll
+                for (int u = 1; u < U; ++u) v = (lane == u) ? acc[u] : v;
+                if (lane < U && i0 + lane < e) out[i0 + lane] = v;
             }
-            float v = acc[0];
-#pragma unroll
-            for (int u = 1; u < U; ++u) v = (lane == u) ? acc[u] : v;
-            if (lane < U && i0 + lane < e) out[i0 + lane] = v;
         }
     }
 }
