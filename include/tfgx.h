@@ -134,6 +134,14 @@ typedef struct tfgx_reduce_args {
        sorted by length on skewed graphs, so that the rows sharing a wave are of similar length; a permutation of
        [0, n_dst), results do not depend on it */
     const int32_t* row_order;
+    /* optional, TFGX_MAX only (the TRAINING forward of max aggregation): per output element one uint32 =
+       (number of edges attaining the row maximum, saturating at 65535) << 16 | (CSR position of the FIRST such edge
+       relative to its row's first position; 0xFFFF for an empty row) — what TensorFlow's unsorted_segment_max gradient
+       needs (it divides by the tie count, math_grad._UnsortedSegmentMinOrMaxGrad), produced by the tuned forward walk in
+       the same pass.  Rows must hold fewer than 65536 edges (longer rows are hub rows: hub_threshold must be 0 here);
+       16-byte aligned rows of F <= 256 columns, F % 4 == 0; no accumulate / self_coef / split rows. */
+    uint32_t* track;
+    int64_t ld_track;
 } tfgx_reduce_args;
 
 int tfgx_segment_reduce_f32(const tfgx_reduce_args* args /* host */, tfgx_stream_t stream);
@@ -297,7 +305,9 @@ int tfgx_segment_max_backward_push_f32(const int32_t* row_ptr, const int32_t* co
    gn = g / count; then every SOURCE row walks its out-edges in transposed order (row_ptr_t, dst_t, w_t, and pos_t = the
    forward CSR position of each transposed position, or NULL if identical), reads 4*ceil(F/32) mask bytes per edge and
    gathers gn[dst, j] only where a bit is set (N*F/E columns per edge on average).  One owner per gx element, fixed
-   order: bit-reproducible.  workspace: tfgx_segment_max_backward_mask_workspace_bytes(n_dst, E, F) bytes. */
+   order: bit-reproducible.  workspace: tfgx_segment_max_backward_mask_workspace_bytes(n_dst, E, F) bytes.
+   count == NULL: `argpos` holds the PACKED uint32 array of tfgx_reduce_args.track (tie count << 16 | row-relative
+   position) written by the tuned training forward — one array read instead of two. */
 size_t tfgx_segment_max_backward_mask_workspace_bytes(int64_t n_dst, int64_t E, int64_t F);
 int tfgx_segment_max_backward_mask_f32(const int32_t* row_ptr, const int32_t* col, const float* w /* or NULL */,
                                        int64_t n_dst, int64_t E, const float* x, int64_t ldx, int64_t F, const float* out,

@@ -689,3 +689,51 @@ def test_hip_gcn_layer_gradients_match_tf_registered_gradients(tfg, oracle):
     assert_parity(xt.grad.cpu().numpy(), dx, tol=2e-5, what="gcn d/dx")
     assert_parity(layer.kernel.grad.cpu().numpy(), dk, tol=2e-5, what="gcn d/dkernel")
     assert_parity(layer.bias.grad.cpu().numpy(), db, tol=2e-5, what="gcn d/dbias")
+
+
+@pytest.mark.parametrize("f,weighted", [(100, True), (64, False), (32, True), (256, False), (36, True)])
+def test_tracked_max_forward_equals_the_arg_kernel(tfg, oracle, f, weighted):
+    """tfgx_reduce_args.track (the tuned segment-reduce walk with the tie count and the first maximal edge's position
+    tracked online, packed count << 16 | row-relative position) vs tfgx_segment_max_with_arg_f32: identical maxima,
+    counts and positions — duplicated edges and quantised features (many ties), an empty row; and the mask-form gradient
+    computed from the packed array is bit-identical to the one computed from the two arrays."""
+    from tf_geometric_amd import _lib as L
+    from tf_geometric_amd import autograd as AG
+    from tf_geometric_amd.plan import CsrPlan, segment_reduce, can_track
+    rng = np.random.Generator(np.random.PCG64(f))
+    n = 900
+    ei = oracle.synthetic_edges(n, 12000, seed=f)
+    ei = ei[:, ei[0] != 9]
+    ei = np.concatenate([ei, ei[:, :4000]], axis=1)
+    x = np.round(rng.standard_normal((n, f)).astype(np.float32) * 2) / 2
+    plan = CsrPlan.build(L.as_i32(ei), n, n)
+    xd = L.as_f32(x)
+    w = (torch.randint(1, 3, (plan.num_edges,), device="cuda").float() * 0.5) if weighted else None
+    assert can_track(plan, xd, f)
+    lib = L.require_gpu()
+    out0, cnt0 = torch.empty((n, f), device="cuda"), torch.empty((n, f), device="cuda")
+    arg0 = torch.empty((n, f), dtype=torch.int32, device="cuda")
+    L.check(lib.tfgx_segment_max_with_arg_f32(L.ptr(plan.row_ptr), L.ptr(plan.col), L.ptr(w), n, L.ptr(xd), f, f,
+                                              L.ptr(out0), f, L.ptr(cnt0), f, L.ptr(arg0), f, L.stream_ptr()), "with_arg")
+    out1 = torch.empty((n, f), device="cuda")
+    packed = torch.empty((n, f), dtype=torch.int32, device="cuda")
+    segment_reduce(plan, xd, L.MAX, w_csr=w, out=out1, track=packed)
+    pk = packed.to(torch.int64) & 0xFFFFFFFF
+    cnt1 = (pk >> 16).float()
+    pos1 = torch.where(cnt1 > 0, plan.row_ptr[:-1].long().unsqueeze(1) + (pk & 0xFFFF), torch.full_like(pk, -1))
+    assert torch.equal(out0, out1) and torch.equal(cnt0, cnt1) and torch.equal(arg0.long(), pos1)
+    assert float(cnt1.max()) >= 2 and float(cnt1[9].abs().max()) == 0 and int((pk[9] & 0xFFFF).min()) == 0xFFFF
+    # gradients: the autograd path now takes the packed form; it must equal the two-array mask form bit for bit
+    g = torch.randn(n, f, device="cuda")
+    xt = xd.clone().requires_grad_(True)
+    AG.aggregate(plan, xt, L.MAX, w_csr=w).backward(g)
+    pt, t2d = AG._transposed(plan)
+    w_t = AG._transposed_weights(plan, w, t2d)
+    ws_bytes = lib.tfgx_segment_max_backward_mask_workspace_bytes(n, plan.num_edges, f)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device="cuda")
+    gx = torch.empty((n, f), device="cuda")
+    L.check(lib.tfgx_segment_max_backward_mask_f32(L.ptr(plan.row_ptr), L.ptr(plan.col), L.ptr(w), n, plan.num_edges,
+                                                   L.ptr(xd), f, f, L.ptr(out0), f, L.ptr(g), f, L.ptr(cnt0), f,
+                                                   L.ptr(arg0), f, L.ptr(pt.row_ptr), L.ptr(pt.col), L.ptr(w_t), L.ptr(t2d),
+                                                   n, L.ptr(gx), f, L.ptr(ws), ws_bytes, L.stream_ptr()), "mask (two arrays)")
+    assert torch.equal(xt.grad, gx)

@@ -24,7 +24,7 @@ import math
 import torch
 
 from . import _lib as L
-from .plan import (segment_reduce, gemm_bias_act, gemm_tn, transpose, SplitRows, gather_friendly_empty,
+from .plan import (segment_reduce, can_track, gemm_bias_act, gemm_tn, transpose, SplitRows, gather_friendly_empty,
                    gather_friendly_copy)
 
 
@@ -167,7 +167,16 @@ class _AggregateMax(torch.autograd.Function):
         F = int(x2.shape[1])
         argpos = None
         wd = None if w_csr is None else w_csr.detach()
-        if plan.hub_info() is None:
+        packed = None
+        if _max_mode() == "mask" and can_track(plan, x2, ldx):
+            # the tuned forward walk (8 gathered rows in flight per lane group) with the tie count and the position of the
+            # first maximal edge tracked online and written PACKED (one uint32 per element instead of a float count array
+            # and an int32 position array): what the mask-form backward reads
+            out = torch.empty((plan.n_dst, F), dtype=torch.float32, device=x2.device)
+            packed = torch.empty((plan.n_dst, F), dtype=torch.int32, device=x2.device)
+            segment_reduce(plan, x2, L.MAX, w_csr=wd, out=out, track=packed)
+            count = None
+        elif plan.hub_info() is None:
             # one pass: row maxima AND how many edges attain each (the tie count TF's gradient divides by)
             out = torch.empty((plan.n_dst, F), dtype=torch.float32, device=x2.device)
             count = torch.empty_like(out)
@@ -185,7 +194,7 @@ class _AggregateMax(torch.autograd.Function):
         else:   # skewed graph: the chunked forward keeps long rows off one lane group; count in the backward
             out = segment_reduce(plan, x2, L.MAX, w_csr=wd)
             count = None
-        ctx.plan, ctx.count, ctx.argpos, ctx.mode = plan, count, argpos, _max_mode()
+        ctx.plan, ctx.count, ctx.argpos, ctx.mode, ctx.packed = plan, count, argpos, _max_mode(), packed
         ctx.save_for_backward(x, w_csr, out)
         return out
 
@@ -198,7 +207,11 @@ class _AggregateMax(torch.autograd.Function):
         g2, ldg = L.row_major_2d(g.contiguous())
         F = int(x2.shape[1])
         count = ctx.count
-        if count is None:          # skewed graph: hub rows counted chunk-wise
+        packed = ctx.packed
+
+        def unpack_count():
+            return ((packed.to(torch.int64) & 0xFFFFFFFF) >> 16).to(torch.float32)
+        if count is None and packed is None:          # skewed graph: hub rows counted chunk-wise
             count = torch.empty_like(out)
             hub_c, nc_c = L.hub_lists(plan)
             sc_c = torch.empty(max(nc_c * F, 1), dtype=torch.float32, device=x2.device) if hub_c is not None else None
@@ -209,11 +222,23 @@ class _AggregateMax(torch.autograd.Function):
         gx = None
         if ctx.needs_input_grad[1]:
             gx = torch.empty((int(x2.shape[0]), F), dtype=torch.float32, device=x2.device)   # dense: ld = F below
-            aligned = ctx.argpos is not None and ldg % 4 == 0 and g2.data_ptr() % 16 == 0
+            aligned = (ctx.argpos is not None or packed is not None) and ldg % 4 == 0 and g2.data_ptr() % 16 == 0
             pt_hub, nc_t = L.hub_lists(_transposed(plan)[0])
             if pt_hub is not None:
                 aligned = False        # hub SOURCES: the per-source walks of the mask / push forms would serialise; pull, chunked
-            if aligned and ctx.mode == "mask":
+            if packed is not None and not aligned:
+                count = unpack_count()             # rare fall-back to the pull form: it wants the float count array
+            if aligned and packed is not None:
+                pt, t2d = _transposed(plan)
+                w_t = _transposed_weights(plan, w_csr, t2d)
+                ws_bytes = lib.tfgx_segment_max_backward_mask_workspace_bytes(plan.n_dst, plan.num_edges, F)
+                ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=x2.device)
+                L.check(lib.tfgx_segment_max_backward_mask_f32(
+                    L.ptr(plan.row_ptr), L.ptr(plan.col), L.ptr(None if w_csr is None else w_csr.detach()), plan.n_dst,
+                    plan.num_edges, L.ptr(x2), ldx, F, L.ptr(out), F, L.ptr(g2), ldg, None, F, L.ptr(packed), F,
+                    L.ptr(pt.row_ptr), L.ptr(pt.col), L.ptr(w_t), L.ptr(t2d), int(x2.shape[0]), L.ptr(gx), F, L.ptr(ws),
+                    ws_bytes, L.stream_ptr()), "tfgx_segment_max_backward_mask_f32 (packed)")
+            elif aligned and ctx.mode == "mask":
                 pt, t2d = _transposed(plan)
                 w_t = _transposed_weights(plan, w_csr, t2d)
                 ws_bytes = lib.tfgx_segment_max_backward_mask_workspace_bytes(plan.n_dst, plan.num_edges, F)
@@ -239,6 +264,8 @@ class _AggregateMax(torch.autograd.Function):
                     L.ptr(sc_t), L.stream_ptr()), "tfgx_segment_max_backward_hub_f32")
         gw = None
         if w_csr is not None and ctx.needs_input_grad[2]:
+            if count is None:
+                count = unpack_count()
             gn2 = g2 / count.clamp(min=1.0)          # TF splits the gradient evenly among tied maxima
             gw = torch.empty_like(w_csr)
             L.check(lib.tfgx_segment_max_backward_w_f32(L.ptr(plan.row_ptr), L.ptr(plan.col), L.ptr(w_csr.detach()),

@@ -72,8 +72,16 @@ __global__ __launch_bounds__(kBlock) void sddmm_fast_kernel(const int32_t* __res
                                                             float* __restrict__ out, const float* __restrict__ w,
                                                             const float* __restrict__ mx, int64_t ldmx)
 {
-    constexpr int ROWS_PER_BLOCK = kBlock / G, U = 8;
+    constexpr int ROWS_PER_BLOCK = kBlock / G, U = 8, UL = 8 / CH;      // UL edges (8 float4 row pieces) in flight at a time
     const int lane = threadIdx.x % G, grp = threadIdx.x / G;
+    int joff[CH];
+    bool jvalid[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int j = 4 * (lane + c * G);
+        jvalid[c] = j < F;
+        joff[c] = jvalid[c] ? j : F - 4;
+    }
     for (int64_t p = int64_t(blockIdx.x) * ROWS_PER_BLOCK + grp; p < n_dst; p += int64_t(gridDim.x) * ROWS_PER_BLOCK) {
         const int s = rb[p], e = re[p];
         if (skip > 0 && e - s > skip) continue;
@@ -92,36 +100,61 @@ __global__ __launch_bounds__(kBlock) void sddmm_fast_kernel(const int32_t* __res
                 mv[c] = j < F ? *reinterpret_cast<const float4*>(mx + r * ldmx + j) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
-        for (int i0 = s; i0 < e; i0 += U) {
-            const int mine = (lane < U && i0 + lane < e) ? col[i0 + lane] : 0;   // a valid row for the padded slots
-            const float wmine = (MASKED && lane < U && i0 + lane < e) ? w[i0 + lane] : 0.0f;
+        // (col, w) are read G at a time, one per lane, coalesced, and the NEXT batch is requested while the current one's
+        // rows are being gathered (as the forward kernel does): the index load heads every gather's dependency chain, and
+        // one 8-lane load per 8 edges left a full memory round trip in front of each sub-batch
+        int cj_next = (s + lane < e) ? col[s + lane] : 0;                        // 0: a valid row for the padded slots
+        float wj_next = (MASKED && s + lane < e) ? w[s + lane] : 0.0f;
+        for (int base = s; base < e; base += G) {
+          const int cj = cj_next;
+          const float wj = wj_next;
+          cj_next = 0;
+          wj_next = 0.0f;
+          if (base + G + lane < e) {
+              cj_next = col[base + G + lane];
+              if (MASKED) wj_next = w[base + G + lane];
+          }
+          const int cnt = min(G, e - base);
+          for (int j0 = 0; j0 < cnt; j0 += U) {
+            const int i0 = base + j0;
+            // all U row loads are issued before the first product is formed, from CLAMPED column offsets with no branch
+            // around them: a predicated load makes the compiler drain vmcnt(0) after each one (the previous version of this
+            // loop ran its "8 gathers in flight" strictly one after the other); lanes past F re-read the last valid vector
+            // against a zero a-row
             float acc[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int cu = __shfl(mine, u, G);
-                const float wu = MASKED ? __shfl(wmine, u, G) : 0.0f;
-                const float* br = b + int64_t(cu) * ldb;
-                float t = 0.0f;
+            for (int u0 = 0; u0 < U; u0 += UL) {
+                float4 bv[UL][CH];
+                float wu[UL];
 #pragma unroll
-                for (int c = 0; c < CH; ++c) {
-                    const int j = 4 * (lane + c * G);
-                    if (j < F) {
-                        const float4 bv = *reinterpret_cast<const float4*>(br + j);
+                for (int u = 0; u < UL; ++u) {
+                    const int cu = __shfl(cj, (j0 + u0 + u) & (G - 1), G);
+                    wu[u] = MASKED ? __shfl(wj, (j0 + u0 + u) & (G - 1), G) : 0.0f;
+                    const float* br = b + int64_t(cu) * ldb;
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) bv[u][c] = *reinterpret_cast<const float4*>(br + joff[c]);
+                }
+#pragma unroll
+                for (int u = 0; u < UL; ++u) {
+                    float t = 0.0f;
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) {
+                        const float4 b4 = bv[u][c];
                         if (MASKED) {
                             const float4 m4 = mv[c];
-                            t = (wu * bv.x == m4.x) ? fmaf(av[c].x, bv.x, t) : t;
-                            t = (wu * bv.y == m4.y) ? fmaf(av[c].y, bv.y, t) : t;
-                            t = (wu * bv.z == m4.z) ? fmaf(av[c].z, bv.z, t) : t;
-                            t = (wu * bv.w == m4.w) ? fmaf(av[c].w, bv.w, t) : t;
+                            t = (jvalid[c] && wu[u] * b4.x == m4.x) ? fmaf(av[c].x, b4.x, t) : t;
+                            t = (jvalid[c] && wu[u] * b4.y == m4.y) ? fmaf(av[c].y, b4.y, t) : t;
+                            t = (jvalid[c] && wu[u] * b4.z == m4.z) ? fmaf(av[c].z, b4.z, t) : t;
+                            t = (jvalid[c] && wu[u] * b4.w == m4.w) ? fmaf(av[c].w, b4.w, t) : t;
                         } else {
-                            t = fmaf(av[c].x, bv.x, t);
-                            t = fmaf(av[c].y, bv.y, t);
-                            t = fmaf(av[c].z, bv.z, t);
-                            t = fmaf(av[c].w, bv.w, t);
+                            t = fmaf(av[c].x, b4.x, t);
+                            t = fmaf(av[c].y, b4.y, t);
+                            t = fmaf(av[c].z, b4.z, t);
+                            t = fmaf(av[c].w, b4.w, t);
                         }
                     }
+                    acc[u0 + u] = t;
                 }
-                acc[u] = t;
             }
             if constexpr (G >= 8) {
                 // Reduce the 8 partial dot products across the G lanes with a VALUE-HALVING butterfly: at each of the first
@@ -161,6 +194,7 @@ __global__ __launch_bounds__(kBlock) void sddmm_fast_kernel(const int32_t* __res
                 for (int u = 1; u < U; ++u) v = (lane == u) ? acc[u] : v;
                 if (lane < U && i0 + lane < e) out[i0 + lane] = v;
             }
+          }
         }
     }
 }
@@ -498,10 +532,19 @@ __global__ __launch_bounds__(kBlock) void max_mask_build_kernel(const int32_t* _
         int ap[VEC] = {-1, -1, -1, -1};
         if (rvalid && cvalid) {
             load_vec<VEC>(g + r * ldg + coff, gv);
-            load_vec<VEC>(count + r * ldc + coff, cv);
             load_vec<VEC>(out + r * ldo + coff, ov);
+            if (count != nullptr) {
+                load_vec<VEC>(count + r * ldc + coff, cv);
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) ap[i] = argpos[r * lda + coff + i];
+                for (int i = 0; i < VEC; ++i) ap[i] = argpos[r * lda + coff + i];
+            } else {      // packed form (tfgx_reduce_args.track): count << 16 | position relative to the row start
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    const uint32_t pk = uint32_t(argpos[r * lda + coff + i]);
+                    cv[i] = float(pk >> 16);
+                    ap[i] = (pk >> 16) ? s + int(pk & 0xFFFFu) : -1;
+                }
+            }
             float gnv[VEC];
 #pragma unroll
             for (int i = 0; i < VEC; ++i) gnv[i] = cv[i] > 0.0f ? gv[i] / cv[i] : 0.0f;
@@ -1191,11 +1234,13 @@ extern "C" int tfgx_segment_max_backward_mask_f32(const int32_t* row_ptr, const 
                                                   void* workspace, size_t workspace_bytes, tfgx_stream_t stream_)
 {
     TFGX_RANGE();
+    // count == NULL: `argpos` holds the PACKED uint32 of tfgx_reduce_args.track (tie count << 16 | row-relative position)
+    if (count == nullptr) ldc = F;
     TFGX_REQUIRE(n_dst >= 0 && n_src >= 0 && E >= 0 && F >= 1 && ldx >= F && ldo >= F && ldg >= F && ldc >= F &&
                      lda >= F && ldgx >= F, "bad size");
     if (n_src == 0) return TFGX_OK;
     TFGX_REQUIRE(row_ptr_t && gx, "null pointer");
-    TFGX_REQUIRE(n_dst == 0 || (row_ptr && x && out && g && count && argpos), "null pointer");
+    TFGX_REQUIRE(n_dst == 0 || (row_ptr && x && out && g && argpos), "null pointer");
     TFGX_REQUIRE(E == 0 || (col && dst_t), "null pointer");
     TFGX_REQUIRE((w == nullptr) == (w_t == nullptr), "w and w_t go together");
     TFGX_REQUIRE(F % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && ldg % 4 == 0 && ldc % 4 == 0 && ldgx % 4 == 0 &&

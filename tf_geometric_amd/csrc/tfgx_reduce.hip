@@ -58,6 +58,8 @@ struct KArgs {
     int64_t ld_tail;
     int32_t f_main;
     const int32_t* row_order; // optional walk order: lane group i reduces row row_order[i] (skewed plans: degree order)
+    uint32_t* track;          // TFGX_MAX training forward: (tie count << 16 | position of the first maximal edge in its row)
+    int64_t ld_track;
     const float* edge_tail;  // optional with SPLIT: the tail columns of every edge's SOURCE row, in this plan's edge order
     int64_t ld_edge_tail;    // (streamed next to col / w instead of gathered: one line request fewer per edge)
 };
@@ -72,13 +74,18 @@ struct KArgs {
 #define TFGX_UNROLL_CH4 2
 #endif
 
-template <int VEC, int G, int CH, bool IS_MAX, bool WEIGHTED, bool SPLIT>
+template <int VEC, int G, int CH, bool IS_MAX, bool WEIGHTED, bool SPLIT, bool TRACK>
 __device__ __forceinline__ void seg_reduce_row(const KArgs& a, int64_t r, int s, int e, int cj_next, float wj_next, int lane,
                                                const int (&coff)[CH], const bool (&cvalid)[CH], const float* const (&xb)[CH],
                                                const int64_t (&xl)[CH], const float* const (&xs)[CH],
                                                const int64_t (&xsl)[CH], const bool (&by_edge)[CH], float init);
 
-template <int VEC, int G, int CH, bool IS_MAX, bool WEIGHTED, bool SPLIT = false>
+// TRACK (IS_MAX only; the TRAINING forward of max aggregation): next to the running maximum every lane keeps, per column,
+// how many edges attain it (TF's unsorted_segment_max gradient divides by that count) and the position of the FIRST one
+// inside its row, and the epilogue writes them packed into ONE uint32 per element (count << 16 | position): the mask-form
+// backward reads that instead of a float count array and an int32 position array (rows up to 65535 edges: longer rows are
+// hub rows and take the chunked path, which does not track).
+template <int VEC, int G, int CH, bool IS_MAX, bool WEIGHTED, bool SPLIT = false, bool TRACK = false>
 __global__ __launch_bounds__(kBlock) void seg_reduce_kernel(const KArgs a)
 {
     constexpr int ROWS_PER_BLOCK = kBlock / G;
@@ -171,13 +178,13 @@ __global__ __launch_bounds__(kBlock) void seg_reduce_kernel(const KArgs a)
         float wj_next = wj_first;
         s = s1; e = e1; s1 = s2; e1 = e2; cj_first = cj_first1; wj_first = wj_first1;      // rotate the pipeline
         if (a.hub_threshold > 0 && e_cur - s_cur > a.hub_threshold) continue;   // handled by the chunked hub path
-        seg_reduce_row<VEC, G, CH, IS_MAX, WEIGHTED, SPLIT>(a, row_of(r), s_cur, e_cur, cj_next, wj_next, lane, coff, cvalid,
-                                                            xb, xl, xs, xsl, by_edge, init);
+        seg_reduce_row<VEC, G, CH, IS_MAX, WEIGHTED, SPLIT, TRACK>(a, row_of(r), s_cur, e_cur, cj_next, wj_next, lane, coff,
+                                                                   cvalid, xb, xl, xs, xsl, by_edge, init);
     }
 }
 
 // One destination row [s, e) of the plan, reduced by a group of G lanes (body of seg_reduce_kernel).
-template <int VEC, int G, int CH, bool IS_MAX, bool WEIGHTED, bool SPLIT>
+template <int VEC, int G, int CH, bool IS_MAX, bool WEIGHTED, bool SPLIT, bool TRACK>
 __device__ __forceinline__ void seg_reduce_row(const KArgs& a, int64_t r, int s, int e, int cj_next, float wj_next, int lane,
                                                const int (&coff)[CH], const bool (&cvalid)[CH], const float* const (&xb)[CH],
                                                const int64_t (&xl)[CH], const float* const (&xs)[CH],
@@ -187,10 +194,23 @@ __device__ __forceinline__ void seg_reduce_row(const KArgs& a, int64_t r, int s,
     constexpr int UNROLL = UNROLL_W < G ? UNROLL_W : G;
     {
         float acc[CH][VEC];
+        int tcnt[TRACK ? CH : 1][TRACK ? VEC : 1], tpos[TRACK ? CH : 1][TRACK ? VEC : 1];
 #pragma unroll
         for (int k = 0; k < CH; ++k)
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) acc[k][v] = init;
+            for (int v = 0; v < VEC; ++v) {
+                acc[k][v] = init;
+                if constexpr (TRACK) { tcnt[k][v] = 0; tpos[k][v] = -1; }
+            }
+        // online tie count / first position (identical to the MODE 2 walk of tfgx_backward.hip): a value above the running
+        // maximum restarts the count at 1 and moves the position, an equal one increments the count
+        auto track_step = [&](int k, int v, float m, int p) {
+            if constexpr (TRACK) {
+                const bool gt = m > acc[k][v];
+                tpos[k][v] = (gt || tpos[k][v] < 0) ? p : tpos[k][v];
+                tcnt[k][v] = gt ? 1 : (m == acc[k][v] ? tcnt[k][v] + 1 : tcnt[k][v]);
+            }
+        };
 
         // (col, w) of the NEXT batch are loaded while the current batch's rows are in flight: the index load heads every
         // gather's dependency chain (same-box A/B: 4-6 % at F <= 64, 2 % on a 57 GB table, neutral at F = 100)
@@ -225,6 +245,7 @@ __device__ __forceinline__ void seg_reduce_row(const KArgs& a, int64_t r, int s,
                         for (int v = 0; v < VEC; ++v) {
                             if constexpr (IS_MAX) {
                                 const float m = WEIGHTED ? xv[u][k][v] * ww[u] : xv[u][k][v];
+                                track_step(k, v, m, base + j + u);
                                 acc[k][v] = fmaxf(acc[k][v], m);
                             } else {
                                 acc[k][v] = WEIGHTED ? fmaf(ww[u], xv[u][k][v], acc[k][v]) : acc[k][v] + xv[u][k][v];
@@ -244,6 +265,7 @@ __device__ __forceinline__ void seg_reduce_row(const KArgs& a, int64_t r, int s,
                     for (int v = 0; v < VEC; ++v) {
                         if constexpr (IS_MAX) {
                             const float m = WEIGHTED ? xv[v] * wv : xv[v];
+                            track_step(k, v, m, base + j);
                             acc[k][v] = fmaxf(acc[k][v], m);
                         } else {
                             acc[k][v] = WEIGHTED ? fmaf(wv, xv[v], acc[k][v]) : acc[k][v] + xv[v];
@@ -302,6 +324,20 @@ __device__ __forceinline__ void seg_reduce_row(const KArgs& a, int64_t r, int s,
 #pragma unroll
             for (int v = 0; v < VEC; ++v) res[v] = apply_act(res[v], a.act);
             store_vec<VEC>(op, res);
+            if constexpr (TRACK) {
+                uint32_t pk[VEC];
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    const uint32_t c = uint32_t(tcnt[k][v] < 65535 ? tcnt[k][v] : 65535);
+                    pk[v] = (c << 16) | (tpos[k][v] < 0 ? 0xFFFFu : uint32_t(tpos[k][v] - s) & 0xFFFFu);
+                }
+                uint32_t* tp = a.track + r * a.ld_track + coff[k];
+                if constexpr (VEC == 4) *reinterpret_cast<uint4*>(tp) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                else {
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) tp[v] = pk[v];
+                }
+            }
         }
     }
 }
@@ -342,6 +378,16 @@ int launch_cfg(const KArgs& a, bool is_max, bool weighted, int ny, hipStream_t s
     }
     if (a.x_tail != nullptr) {
         set_error("tfgx_segment_reduce_f32: x_tail needs 16-byte aligned rows and F <= 256");
+        return TFGX_ERR_INVALID_ARG;
+    }
+    if (a.track != nullptr) {
+        if constexpr (VEC == 4 && CH == 1) {
+            if (weighted) seg_reduce_kernel<VEC, G, CH, true, true, false, true><<<grid, block, 0, stream>>>(a);
+            else seg_reduce_kernel<VEC, G, CH, true, false, false, true><<<grid, block, 0, stream>>>(a);
+            TFGX_LAUNCH_CHECK("seg_reduce_kernel<track>");
+            return TFGX_OK;
+        }
+        set_error("tfgx_segment_reduce_f32: track needs 16-byte aligned rows of F <= 256 columns, F % 4 == 0");
         return TFGX_ERR_INVALID_ARG;
     }
     if (is_max) {
@@ -502,6 +548,12 @@ extern "C" int tfgx_segment_reduce_f32(const tfgx_reduce_args* p, tfgx_stream_t 
     a.x_tail = p->x_tail; a.ld_tail = p->ld_tail; a.f_main = int32_t(p->f_main);
     a.edge_tail = p->edge_tail; a.ld_edge_tail = p->ld_edge_tail;
     a.row_order = p->row_order;
+    a.track = p->track; a.ld_track = p->ld_track;
+    if (p->track) {
+        TFGX_REQUIRE(p->op == TFGX_MAX && !p->accumulate && !p->self_coef && !p->x_tail && p->hub_threshold == 0,
+                     "track: plain TFGX_MAX launches only (no accumulate / self_coef / split rows / hub lists)");
+        TFGX_REQUIRE(p->ld_track >= p->F && p->ld_track % 4 == 0 && aligned_to(p->track, 16), "track: bad leading dimension / alignment");
+    }
     TFGX_REQUIRE(p->edge_tail == nullptr ||
                      (p->x_tail != nullptr && p->ld_edge_tail >= p->F - p->f_main && p->ld_edge_tail % 4 == 0 &&
                       aligned_to(p->edge_tail, 16)),
@@ -534,7 +586,7 @@ extern "C" int tfgx_segment_reduce_f32(const tfgx_reduce_args* p, tfgx_stream_t 
     c.n_dst = p->n_hub_chunks; c.out = p->hub_scratch; c.ldo = p->F;
     c.op = is_max ? TFGX_MAX : TFGX_SUM; c.act = TFGX_ACT_NONE; c.accumulate = 0;
     c.self_coef = nullptr; c.bias = nullptr; c.add_x = nullptr; c.mean_count = nullptr; c.hub_threshold = 0;
-    c.row_order = nullptr;
+    c.row_order = nullptr; c.track = nullptr;
     const bool sok = (p->F % 4 == 0) && aligned_to(p->hub_scratch, 16) && (p->ldx % 4 == 0) && aligned_to(p->x, 16);
     const bool sok2 = (p->F % 2 == 0) && aligned_to(p->hub_scratch, 8) && (p->ldx % 2 == 0) && aligned_to(p->x, 8);
     rc = launch_any(c, sok ? 4 : (sok2 ? 2 : 1), is_max, weighted, stream);

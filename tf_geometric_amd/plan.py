@@ -374,10 +374,12 @@ def edge_weight_csr(plan, edge_weight, cache=None):
 
 def segment_reduce(plan, x, op, w_csr=None, out=None, act=L.ACT_NONE, self_coef=None, bias=None, add_x=None,
                    accumulate=False, mean_count=None, row_begin=None, row_end=None, rp_stride=1, col=None,
-                   n_dst=None, describe=False):
+                   n_dst=None, describe=False, track=None):
     """One launch of tfgx_segment_reduce_f32 on `plan` (or on explicit row_begin/row_end/col views of it).
     `x` is a dense [n_src, F] tensor or a SplitRows.  describe=True launches nothing and returns the kernel symbol the
-    dispatcher picks for these arguments (tfgx_segment_reduce_describe)."""
+    dispatcher picks for these arguments (tfgx_segment_reduce_describe).  `track` (TFGX_MAX, training forward): int32
+    [n_dst, F] that receives tie count << 16 | row-relative position of the first maximal edge (tfgx_reduce_args.track;
+    see can_track)."""
     lib = L.require_gpu()
     split = x if isinstance(x, SplitRows) else None
     if split is not None:
@@ -426,7 +428,9 @@ def segment_reduce(plan, x, op, w_csr=None, out=None, act=L.ACT_NONE, self_coef=
         order = plan.row_order()
         if order is not None:
             a.row_order = order.data_ptr()
-    hub = plan.hub_info() if (row_begin is None and row_end is None and col is None) else None
+    if track is not None:
+        a.track, a.ld_track = track.data_ptr(), int(track.stride(0))
+    hub = plan.hub_info() if (row_begin is None and row_end is None and col is None and track is None) else None
     if hub is not None:
         hub_rows, chunk_ptr, chunk_begin, chunk_end, _ = hub
         scratch = torch.empty((int(chunk_begin.shape[0]), F), dtype=torch.float32, device=x.device)
@@ -441,6 +445,15 @@ def segment_reduce(plan, x, op, w_csr=None, out=None, act=L.ACT_NONE, self_coef=
         return buf.value.decode()
     L.check(lib.tfgx_segment_reduce_f32(ctypes.byref(a), L.stream_ptr()), "tfgx_segment_reduce_f32")
     return out
+
+
+def can_track(plan, x2, ldx):
+    """Can the TRAINING forward of max aggregation run on the tuned segment-reduce kernel with packed tie counts / first
+    positions (tfgx_reduce_args.track)?  16-byte aligned rows of 32 <= F <= 256 columns (the dwordx4, one-chunk-per-lane
+    instantiations), no hub rows (hub rows are chunked and do not track) and every row shorter than 65536 edges."""
+    F = int(x2.shape[1])
+    return (F % 4 == 0 and 32 <= F <= 256 and ldx % 4 == 0 and x2.data_ptr() % 16 == 0 and plan.hub_info() is None
+            and int(getattr(plan, "hub_threshold", 1 << 30)) < 65536)
 
 
 def _avg_lines(F, ld):

@@ -1,4 +1,3 @@
 mkdir -p gpurun_out/r03
-python -m pytest tests/test_gpu_backward.py -q -x -k "sddmm or grad_x_and_w or registered" 2>&1 | tail -3
-python tools/bench_sweep.py --only=backward > gpurun_out/r03/backward_a.jsonl 2> gpurun_out/r03/backward_a.err
-cat gpurun_out/r03/backward_a.jsonl | cut -c1-600
+python -m pytest tests/test_gpu_backward.py -q -x -k "sddmm or grad_x_and_w or registered or hub" 2>&1 | tail -3
+python tools/ab_backward_ratios.py 2>/dev/null | tee gpurun_out/r03/backward_ratios.json | cut -c1-600
