@@ -481,7 +481,8 @@ int tfgx_l2_normalize_rows_f32(float* h, int64_t ld, int64_t n, int64_t F, tfgx_
 
 /* ---------------------------------------------------------------------------------------------
  * Destination-range sharding + halo exchange support (no counterpart in the reference).
- *   tfgx_gather_rows_f32   : pack rows x[idx[i], :] -> out[i, :]   (send side of the halo all-to-all-v)
+ *   tfgx_gather_rows_f32   : pack rows x[idx[i], :] -> out[i, :]   (send side of the halo all-to-all-v); idx == NULL:
+ *                            rows 0 .. M-1 (a strided row copy, e.g. own rows into the [own | halo] table)
  *   tfgx_halo_mark         : flags[c] = 1 for every source c of the slice outside [own_lo, own_hi)
  *   tfgx_halo_compact      : halo_ids = sorted ids with flags set; pos[c] = its rank; *n_halo (device int32)
  *   tfgx_halo_remap_cols   : col -> local source-table index: own rows first, then halo rows

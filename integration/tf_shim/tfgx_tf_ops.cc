@@ -207,3 +207,262 @@ class TfgxGemmBiasActOp : public OpKernel {
   int act_;
 };
 REGISTER_KERNEL_BUILDER(Name("TfgxGemmBiasAct").Device(DEVICE_GPU), TfgxGemmBiasActOp);
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Backward ops (round 3; still NEVER LINKED OR RUN — see the header of this file).  The gradients are registered on the
+// Python side, integration/tf_shim/tfgx_tf.py (@tf.RegisterGradient), in terms of the ops of this file:
+//   d/dx of TfgxSegmentReduce (sum / mean)  = TfgxSegmentReduce on the TRANSPOSED plan (TfgxBuildCsrByDst of the swapped
+//                                             edge_index; weights permuted with TfgxPermuteRows)          tfgx.h:263-266
+//   d/dw of TfgxSegmentReduce               = TfgxSddmm(g, x)                                              tfgx_sddmm_f32
+//   d/dkernel, d/dbias of TfgxGemmBiasAct   = TfgxGemmTn(x, g)                                             tfgx_gemm_tn_f32
+//   d/dx of TfgxGemmBiasAct                 = TfgxGemmBiasAct(g, kernel^T)
+//   the ReLU of an epilogue                 = TfgxReluBackward(g, out)                                     tfgx_relu_backward_f32
+// what tf.GradientTape derives for the reference's own composition (demo/demo_gcn.py:68-77).
+// ---------------------------------------------------------------------------------------------------------------------
+REGISTER_OP("TfgxSddmm")
+    .Input("row_ptr: int32")
+    .Input("col: int32")
+    .Input("a: float")          // [N, F] rows indexed by destination (the upstream gradient)
+    .Input("b: float")          // [N, F] rows indexed by source (the layer input)
+    .Output("out: float");      // [E] <a[row(i)], b[col[i]]> per CSR position
+
+class TfgxSddmmOp : public OpKernel {
+ public:
+  explicit TfgxSddmmOp(OpKernelConstruction* c) : OpKernel(c) {}
+  void Compute(OpKernelContext* ctx) override {
+    const Tensor &rp = ctx->input(0), &col = ctx->input(1), &a = ctx->input(2), &b = ctx->input(3);
+    const int64_t n = rp.dim_size(0) - 1, E = col.dim_size(0), F = a.dim_size(1);
+    Tensor* out = nullptr;
+    OP_REQUIRES_OK(ctx, ctx->allocate_output(0, {E}, &out));
+    OP_REQUIRES(ctx, tfgx_sddmm_f32(rp.flat<int32>().data(), col.flat<int32>().data(), n, a.flat<float>().data(), F,
+                                    b.flat<float>().data(), F, F, out->flat<float>().data(), TfStream(ctx)) == 0,
+                errors::Internal(tfgx_last_error()));
+  }
+};
+REGISTER_KERNEL_BUILDER(Name("TfgxSddmm").Device(DEVICE_GPU), TfgxSddmmOp);
+
+REGISTER_OP("TfgxPermuteRows")
+    .Input("src: float")        // [E] or [E, k] in the caller's edge order
+    .Input("perm: int32")       // [E] CSR position -> caller's edge id (TfgxBuildCsrByDst)
+    .Output("dst: float");      // the same rows in CSR order
+
+class TfgxPermuteRowsOp : public OpKernel {
+ public:
+  explicit TfgxPermuteRowsOp(OpKernelConstruction* c) : OpKernel(c) {}
+  void Compute(OpKernelContext* ctx) override {
+    const Tensor &src = ctx->input(0), &perm = ctx->input(1);
+    const int64_t E = perm.dim_size(0), width = src.dims() == 2 ? src.dim_size(1) : 1;
+    Tensor* dst = nullptr;
+    if (src.dims() == 2) OP_REQUIRES_OK(ctx, ctx->allocate_output(0, {E, width}, &dst));
+    else OP_REQUIRES_OK(ctx, ctx->allocate_output(0, {E}, &dst));
+    OP_REQUIRES(ctx, tfgx_permute_rows_f32(src.flat<float>().data(), perm.flat<int32>().data(), E, width,
+                                           dst->flat<float>().data(), TfStream(ctx)) == 0,
+                errors::Internal(tfgx_last_error()));
+  }
+};
+REGISTER_KERNEL_BUILDER(Name("TfgxPermuteRows").Device(DEVICE_GPU), TfgxPermuteRowsOp);
+
+REGISTER_OP("TfgxGemmTn")
+    .Input("x: float")          // [M, K]   the layer input
+    .Input("g: float")          // [M, N]   gradient of the layer output (after the ReLU mask)
+    .Output("dw: float")        // [K, N] = x^T @ g
+    .Output("db: float");       // [N]    = column sums of g
+
+class TfgxGemmTnOp : public OpKernel {
+ public:
+  explicit TfgxGemmTnOp(OpKernelConstruction* c) : OpKernel(c) {}
+  void Compute(OpKernelContext* ctx) override {
+    const Tensor &x = ctx->input(0), &g = ctx->input(1);
+    const int64_t M = x.dim_size(0), K = x.dim_size(1), N = g.dim_size(1);
+    OP_REQUIRES(ctx, g.dim_size(0) == M, errors::InvalidArgument("x and g do not agree on M"));
+    Tensor *dw = nullptr, *db = nullptr, ws;
+    OP_REQUIRES_OK(ctx, ctx->allocate_output(0, {K, N}, &dw));
+    OP_REQUIRES_OK(ctx, ctx->allocate_output(1, {N}, &db));
+    const size_t ws_bytes = tfgx_gemm_tn_workspace_bytes(M, K, N, 1);
+    OP_REQUIRES_OK(ctx, ctx->allocate_temp(DT_UINT8, {static_cast<int64_t>(ws_bytes)}, &ws));
+    OP_REQUIRES(ctx, tfgx_gemm_tn_f32(x.flat<float>().data(), K, g.flat<float>().data(), N, M, K, N,
+                                      dw->flat<float>().data(), N, db->flat<float>().data(), ws.flat<uint8>().data(),
+                                      ws_bytes, TfStream(ctx)) == 0,
+                errors::Internal(tfgx_last_error()));
+  }
+};
+REGISTER_KERNEL_BUILDER(Name("TfgxGemmTn").Device(DEVICE_GPU), TfgxGemmTnOp);
+
+REGISTER_OP("TfgxReluBackward")
+    .Input("g: float")          // [M, N]
+    .Input("out: float")        // [M, N] the forward output whose epilogue applied the ReLU
+    .Output("gout: float");     // g where out > 0, else 0
+
+class TfgxReluBackwardOp : public OpKernel {
+ public:
+  explicit TfgxReluBackwardOp(OpKernelConstruction* c) : OpKernel(c) {}
+  void Compute(OpKernelContext* ctx) override {
+    const Tensor &g = ctx->input(0), &o = ctx->input(1);
+    const int64_t M = g.dim_size(0), N = g.dim_size(1);
+    Tensor* gout = nullptr;
+    OP_REQUIRES_OK(ctx, ctx->allocate_output(0, {M, N}, &gout));
+    OP_REQUIRES(ctx, tfgx_relu_backward_f32(g.flat<float>().data(), N, o.flat<float>().data(), N, M, N,
+                                            gout->flat<float>().data(), N, TfStream(ctx)) == 0,
+                errors::Internal(tfgx_last_error()));
+  }
+};
+REGISTER_KERNEL_BUILDER(Name("TfgxReluBackward").Device(DEVICE_GPU), TfgxReluBackwardOp);
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The sharded path from a TensorFlow host (include/tfgx_dist.h; one process per GPU).  The ncclComm_t is created ONCE per
+// process by the Python side through ctypes (tfgx_dist_unique_id on rank 0 -> the host's control channel -> tfgx_dist_comm_init)
+// and handed to the ops as an int64 scalar in host memory; the exchange description (per-round, per-peer counts; dense
+// starts) are host-memory int64 vectors, the packed send indices a device int32 vector — exactly the arrays
+// tf_geometric_amd.dist.sharded.ShardedGraph builds (round_send_counts / round_recv_counts / round_send_dense /
+// send_idx_packed).  TfgxHaloExchange returns the [own | halo] source table; its gradient is TfgxHaloReverse.
+// (Both wait for every round before returning: overlap with the local-source pass needs the start / finish pair to be
+// two ops with a control dependency in between — left to the host that schedules them.)
+// ---------------------------------------------------------------------------------------------------------------------
+#include "tfgx_dist.h"
+#include <vector>
+
+namespace {
+struct HaloPlanHolder {            // one plan per op instance; rebuilt when the description changes
+  tfgx_halo_plan* plan = nullptr;
+  std::vector<int64_t> key;
+  ~HaloPlanHolder() { tfgx_halo_plan_destroy(plan); }
+  int Get(int32_t world, int32_t rank, int32_t rounds, const Tensor& sc, const Tensor& rc, const Tensor& ds,
+          const int32_t* send_idx, tfgx_halo_plan** out) {
+    const int64_t n = int64_t(world) * rounds;
+    std::vector<int64_t> k;
+    k.push_back(world); k.push_back(rank); k.push_back(rounds); k.push_back(reinterpret_cast<int64_t>(send_idx));
+    for (int64_t i = 0; i < n; ++i) { k.push_back(sc.flat<int64_t>().data()[i]); k.push_back(rc.flat<int64_t>().data()[i]); k.push_back(ds.flat<int64_t>().data()[i]); }
+    if (plan == nullptr || k != key) {
+      tfgx_halo_plan_destroy(plan);
+      plan = nullptr;
+      const int rcode = tfgx_halo_plan_create(world, rank, rounds, sc.flat<int64_t>().data(), rc.flat<int64_t>().data(),
+                                              ds.flat<int64_t>().data(), send_idx, &plan);
+      if (rcode != 0) return rcode;
+      key = k;
+    }
+    *out = plan;
+    return 0;
+  }
+};
+}  // namespace
+
+REGISTER_OP("TfgxHaloExchange")
+    .Input("x_own: float")            // [n_own, F] this rank's rows
+    .Input("send_idx: int32")         // device: packed local row ids, round-major then peer-major
+    .Input("send_counts: int64")      // host [rounds * world]
+    .Input("recv_counts: int64")      // host [rounds * world]
+    .Input("send_dense_start: int64") // host [rounds * world]: >= 0 contiguous own rows (no pack), -1 packed
+    .Input("comm: int64")             // host scalar: the ncclComm_t of tfgx_dist_comm_init
+    .Attr("world: int")
+    .Attr("rank: int")
+    .Attr("rounds: int")
+    .Output("table: float");          // [n_own + rows_received, F] = [own | halo]
+
+class TfgxHaloExchangeOp : public OpKernel {
+ public:
+  explicit TfgxHaloExchangeOp(OpKernelConstruction* c) : OpKernel(c) {
+    OP_REQUIRES_OK(c, c->GetAttr("world", &world_));
+    OP_REQUIRES_OK(c, c->GetAttr("rank", &rank_));
+    OP_REQUIRES_OK(c, c->GetAttr("rounds", &rounds_));
+  }
+  void Compute(OpKernelContext* ctx) override {
+    const Tensor &x = ctx->input(0), &idx = ctx->input(1), &sc = ctx->input(2), &rc = ctx->input(3), &ds = ctx->input(4);
+    void* comm = reinterpret_cast<void*>(ctx->input(5).flat<int64_t>().data()[0]);
+    const int64_t n_own = x.dim_size(0), F = x.dim_size(1);
+    tfgx_halo_plan* plan = nullptr;
+    OP_REQUIRES(ctx, holder_.Get(world_, rank_, rounds_, sc, rc, ds, idx.flat<int32>().data(), &plan) == 0,
+                errors::InvalidArgument(tfgx_dist_last_error()));
+    const int64_t n_halo = tfgx_halo_plan_rows_received(plan), n_pack = tfgx_halo_plan_rows_packed(plan);
+    Tensor *table = nullptr, send_buf;
+    OP_REQUIRES_OK(ctx, ctx->allocate_output(0, {n_own + n_halo, F}, &table));
+    OP_REQUIRES_OK(ctx, ctx->allocate_temp(DT_FLOAT, {n_pack * F + 1}, &send_buf));
+    float* t = table->flat<float>().data();
+    // own rows first (the dense entries of the plan are sent straight from the table: ld == F), then the exchange
+    OP_REQUIRES(ctx, tfgx_gather_rows_f32(x.flat<float>().data(), F, nullptr /* identity */, n_own, F, t, F,
+                                          TfStream(ctx)) == 0,
+                errors::Internal(tfgx_last_error()));
+    OP_REQUIRES(ctx, tfgx_halo_exchange_start(plan, t, F, F, t + n_own * F, F, send_buf.flat<float>().data(),
+                                              static_cast<size_t>(n_pack * F + 1), comm, TfStream(ctx), CommStream()) == 0,
+                errors::Internal(tfgx_dist_last_error()));
+    OP_REQUIRES(ctx, tfgx_halo_exchange_finish(plan, -1, TfStream(ctx)) == 0, errors::Internal(tfgx_dist_last_error()));
+  }
+  static void* CommStream() { return nullptr; }   // the real shim creates ONE hipStream_t per process here (second HIP stream)
+  int world_, rank_, rounds_;
+  HaloPlanHolder holder_;
+};
+REGISTER_KERNEL_BUILDER(Name("TfgxHaloExchange").Device(DEVICE_GPU).HostMemory("send_counts").HostMemory("recv_counts")
+                            .HostMemory("send_dense_start").HostMemory("comm"), TfgxHaloExchangeOp);
+
+REGISTER_OP("TfgxHaloReverse")
+    .Input("d_table: float")          // [n_own + rows_received, F] gradient w.r.t. the [own | halo] table
+    .Input("send_idx: int32")
+    .Input("send_counts: int64")
+    .Input("recv_counts: int64")
+    .Input("send_dense_start: int64")
+    .Input("comm: int64")
+    .Attr("world: int")
+    .Attr("rank: int")
+    .Attr("rounds: int")
+    .Attr("n_own: int")
+    .Output("d_own: float");          // [n_own, F]: own part + what the peers computed for this rank's rows
+
+class TfgxHaloReverseOp : public OpKernel {
+ public:
+  explicit TfgxHaloReverseOp(OpKernelConstruction* c) : OpKernel(c) {
+    OP_REQUIRES_OK(c, c->GetAttr("world", &world_));
+    OP_REQUIRES_OK(c, c->GetAttr("rank", &rank_));
+    OP_REQUIRES_OK(c, c->GetAttr("rounds", &rounds_));
+    OP_REQUIRES_OK(c, c->GetAttr("n_own", &n_own_));
+  }
+  void Compute(OpKernelContext* ctx) override {
+    const Tensor &dt = ctx->input(0), &idx = ctx->input(1), &sc = ctx->input(2), &rc = ctx->input(3), &ds = ctx->input(4);
+    void* comm = reinterpret_cast<void*>(ctx->input(5).flat<int64_t>().data()[0]);
+    const int64_t F = dt.dim_size(1);
+    tfgx_halo_plan* plan = nullptr;
+    OP_REQUIRES(ctx, holder_.Get(world_, rank_, rounds_, sc, rc, ds, idx.flat<int32>().data(), &plan) == 0,
+                errors::InvalidArgument(tfgx_dist_last_error()));
+    const int64_t n_sent = tfgx_halo_plan_rows_sent(plan);
+    Tensor *d_own = nullptr, back;
+    OP_REQUIRES_OK(ctx, ctx->allocate_output(0, {n_own_, F}, &d_own));
+    OP_REQUIRES_OK(ctx, ctx->allocate_temp(DT_FLOAT, {n_sent * F + 1}, &back));
+    const float* d = dt.flat<float>().data();
+    OP_REQUIRES(ctx, tfgx_gather_rows_f32(d, F, nullptr /* identity */, n_own_, F, d_own->flat<float>().data(), F,
+                                          TfStream(ctx)) == 0,
+                errors::Internal(tfgx_last_error()));
+    OP_REQUIRES(ctx, tfgx_halo_reverse_start(plan, d + n_own_ * F, F, back.flat<float>().data(),
+                                             static_cast<size_t>(n_sent * F + 1), comm, TfStream(ctx),
+                                             TfgxHaloExchangeOp::CommStream()) == 0,
+                errors::Internal(tfgx_dist_last_error()));
+    OP_REQUIRES(ctx, tfgx_halo_reverse_finish(plan, d_own->flat<float>().data(), F, F, back.flat<float>().data(),
+                                              TfStream(ctx)) == 0,
+                errors::Internal(tfgx_dist_last_error()));
+  }
+  int world_, rank_, rounds_;
+  int64_t n_own_;
+  HaloPlanHolder holder_;
+};
+REGISTER_KERNEL_BUILDER(Name("TfgxHaloReverse").Device(DEVICE_GPU).HostMemory("send_counts").HostMemory("recv_counts")
+                            .HostMemory("send_dense_start").HostMemory("comm"), TfgxHaloReverseOp);
+
+REGISTER_OP("TfgxAllReduceSum")
+    .Input("x: float")
+    .Input("comm: int64")
+    .Output("out: float");            // sum over the ranks (weight gradients of replicated layers; demo_distributed_gcn.py:52-57)
+
+class TfgxAllReduceSumOp : public OpKernel {
+ public:
+  explicit TfgxAllReduceSumOp(OpKernelConstruction* c) : OpKernel(c) {}
+  void Compute(OpKernelContext* ctx) override {
+    const Tensor& x = ctx->input(0);
+    void* comm = reinterpret_cast<void*>(ctx->input(1).flat<int64_t>().data()[0]);
+    const int64_t n = x.NumElements();
+    Tensor* out = nullptr;
+    OP_REQUIRES_OK(ctx, ctx->allocate_output(0, {n}, &out));
+    OP_REQUIRES(ctx, tfgx_gather_rows_f32(x.flat<float>().data(), n, nullptr /* identity */, 1, n,
+                                          out->flat<float>().data(), n, TfStream(ctx)) == 0,
+                errors::Internal(tfgx_last_error()));
+    OP_REQUIRES(ctx, tfgx_allreduce_sum_f32(out->flat<float>().data(), n, comm, TfStream(ctx)) == 0,
+                errors::Internal(tfgx_dist_last_error()));
+  }
+};
+REGISTER_KERNEL_BUILDER(Name("TfgxAllReduceSum").Device(DEVICE_GPU).HostMemory("comm"), TfgxAllReduceSumOp);

@@ -194,8 +194,22 @@ def test_tf_shim_compiles_against_mock_headers():
                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     assert res.returncode == 0, res.stdout.decode()
     src = open(os.path.join(shim, "tfgx_tf_ops.cc")).read()
-    for op in ("TfgxBuildCsrByDst", "TfgxSegmentReduce", "TfgxGatFused", "TfgxGcnNormEdges", "TfgxGemmBiasAct"):
+    ops = ("TfgxBuildCsrByDst", "TfgxSegmentReduce", "TfgxGatFused", "TfgxGcnNormEdges", "TfgxGemmBiasAct",
+           # round 3: the backward ops and the sharded path
+           "TfgxSddmm", "TfgxPermuteRows", "TfgxGemmTn", "TfgxReluBackward", "TfgxHaloExchange", "TfgxHaloReverse",
+           "TfgxAllReduceSum")
+    for op in ops:
         assert 'REGISTER_OP("{}")'.format(op) in src and 'Name("{}")'.format(op) in src
+    # the Python side (gradient registration, GCN layer over the ops): compiles, and names only ops the library registers
+    import py_compile
+    pyfile = os.path.join(shim, "tfgx_tf.py")
+    py_compile.compile(pyfile, doraise=True)
+    pysrc = open(pyfile).read()
+    snake = {re.sub(r"(?<!^)(?=[A-Z])", "_", op).lower() for op in ops}
+    used = set(re.findall(r"ops\.(tfgx_[a-z_]+)\(", pysrc))
+    assert used and used <= snake, used - snake
+    for grad in ("TfgxSegmentReduce", "TfgxGemmBiasAct", "TfgxHaloExchange"):
+        assert '@tf.RegisterGradient("{}")'.format(grad) in pysrc
 
 
 def test_host_code_under_address_sanitizer():

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(kBlock) void gather_rows_kernel(const float* __rest
     for (; t < total; t += stride) {
         const int64_t i = t / per_row;
         const int j = int(t - i * per_row) * VEC;
-        const float* src = x + int64_t(idx[i]) * ldx + j;
+        const float* src = x + (idx ? int64_t(idx[i]) : i) * ldx + j;      // idx == NULL: rows 0 .. M-1 (strided copy)
         float* dst = out + i * ldo + j;
         if constexpr (VEC == 4) *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(src);
         else *dst = *src;
@@ -318,7 +318,7 @@ extern "C" int tfgx_gather_rows_f32(const float* x, int64_t ldx, const int32_t* 
     TFGX_RANGE();
     TFGX_REQUIRE(M >= 0 && F >= 1 && ldx >= F && ldo >= F, "bad size");
     if (M == 0) return TFGX_OK;
-    TFGX_REQUIRE(x && idx && out, "null pointer");
+    TFGX_REQUIRE(x && out, "null pointer");
     const bool v4 = (F % 4 == 0) && (ldx % 4 == 0) && (ldo % 4 == 0) && aligned_to(x, 16) && aligned_to(out, 16);
     if (v4)
         gather_rows_kernel<4><<<grid_for(M * (F / 4), kBlock), kBlock, 0, as_stream(stream)>>>(x, ldx, idx, M, int(F),
