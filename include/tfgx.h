@@ -151,6 +151,20 @@ int tfgx_segment_reduce_f32(const tfgx_reduce_args* args /* host */, tfgx_stream
    nothing: measurement code (bench.py's roofline.kernel) names the kernel from the dispatch itself. */
 int tfgx_segment_reduce_describe(const tfgx_reduce_args* args /* host */, char* buf, size_t buf_bytes);
 
+/* Aggregation -> projection in ONE launch (the aggregate-then-project layers: GCN when units > F evaluated as
+ * (A_hat x) W, nn/conv/gcn.py:272-288; the neighbour half of mean / sum GraphSAGE, nn/conv/graph_sage.py:34-58):
+ *     C[n_dst, N] = act( reduce(args) @ B[F, N] + bias )
+ * where reduce(args) is exactly what tfgx_segment_reduce_f32 would write for `args` (op TFGX_SUM | TFGX_MEAN; w, self_coef,
+ * mean_count honoured; args->out / ldo / act / bias are NOT used) — but the [n_dst, F] aggregate never visits HBM: 64-row
+ * tiles go registers -> LDS -> v_mfma_f32_32x32x2_f32 against B resident in LDS, bias / activation in the epilogue.
+ * Needs a plain CSR (row_begin = row_ptr, row_end = row_ptr + 1, rp_stride = 1), 16-byte aligned rows, F % 4 == 0,
+ * F <= 128, N <= 256 and B + two tiles within 160 KB of LDS: tfgx_aggregate_gemm_fits(F, N) == 1; no accumulate / add_x /
+ * split rows / hub lists / row_order / track.  Deterministic.  Callers fall back to the two launches otherwise. */
+int tfgx_aggregate_gemm_fits(int64_t F, int64_t N);
+int tfgx_aggregate_gemm_f32(const tfgx_reduce_args* args /* host */, const float* B, int64_t ldb,
+                            const float* bias /* [N] or NULL */, int32_t act, float* C, int64_t ldc, int64_t N,
+                            tfgx_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * GCN normalisation (nn/conv/gcn.py:32-130), on the CSR plan.
  *   tfgx_segment_weight_sum_f32 : deg[r] = sum_{i in row r} w[i] (+ diag)     SparseMatrix.segment_sum(axis=-1) :80

@@ -147,11 +147,15 @@ def test_static_layout_is_replayed_by_a_captured_forward(tfg, products):
     def model():
         return g1([g0([x, p["ei"]], cache=cache), p["ei"]], cache=cache)
 
-    eager_dense = model()
+    from tf_geometric_amd import plan as P
+    fused_dense = model()                     # layer 0 as ONE launch (plan.aggregate_gemm)
+    P.FUSE_AGGREGATE_GEMM = False             # bit-equality is a statement about the two-launch path: the static layout
+    eager_dense = model()                     # feeds tfgx_segment_reduce_f32, which the fused launch replaces
+    P.FUSE_AGGREGATE_GEMM = True
+    assert torch.allclose(fused_dense, eager_dense, rtol=1e-5, atol=1e-5)
     tfg.prepare_static_features(x, p["ei"], cache)
     eager_static = model()
     assert torch.equal(eager_dense, eager_static)
-    from tf_geometric_amd import plan as P
     before = dict(P.STATIC_STATS)
     cap = tfg.CapturedForward(model)
     assert P.STATIC_STATS["hits"] > before["hits"] and P.STATIC_STATS["builds"] == before["builds"]   # used, not rebuilt

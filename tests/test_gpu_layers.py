@@ -360,7 +360,13 @@ def test_static_aggregation_memo_is_opt_in_exact_and_invalidated(tfg, oracle):
     gcn = tfg.layers.GCN(48, activation=tfg.relu)            # 20 < 48: aggregation first
     sage = tfg.layers.MeanGraphSage(64, activation=tfg.relu)   # ku = 32 >= 20: reduce at the input width
     plain_cache = {}
+    fused_gcn, fused_sage = gcn([x, ei, w], cache=plain_cache), sage([x, ei, w], cache=plain_cache)
+    # "same bits" is a statement about the memo against the TWO-LAUNCH plain path (aggregate, then GEMM): the one-launch
+    # fused form of the plain path (plan.aggregate_gemm) multiplies in another k order and agrees to fp32 rounding
+    P.FUSE_AGGREGATE_GEMM = False
     o_gcn, o_sage = gcn([x, ei, w], cache=plain_cache), sage([x, ei, w], cache=plain_cache)
+    assert_parity(fused_gcn.cpu().numpy(), o_gcn.cpu().numpy(), what="fused vs two-launch GCN layer")
+    assert_parity(fused_sage.cpu().numpy(), o_sage.cpu().numpy(), what="fused vs two-launch SAGE layer")
     cache = {}
     tfg.prepare_static_features(x, ei, cache)                 # layout only: no memo
     gcn([x, ei, w], cache=cache)
@@ -389,3 +395,60 @@ def test_static_aggregation_memo_is_opt_in_exact_and_invalidated(tfg, oracle):
         assert torch.equal(fresh, gcn([x.clone(), ei, w], cache={}))
     tfg.release_static_features(cache)
     assert "tfgx_static_aggregated" not in cache
+    P.FUSE_AGGREGATE_GEMM = True
+
+
+@pytest.mark.parametrize("n,e,f,units", [(5000, 60000, 100, 256), (777, 9000, 64, 40), (3000, 30000, 128, 128),
+                                          (130, 900, 36, 7), (64, 300, 4, 1), (10000, 150000, 100, 128), (1000, 0, 8, 16)])
+@pytest.mark.parametrize("mode", ["gcn", "mean", "sum_unweighted"])
+def test_fused_aggregate_gemm_equals_two_launches(tfg, oracle, n, e, f, units, mode):
+    """tfgx_aggregate_gemm_f32 (aggregate -> LDS -> MFMA in one launch) vs tfgx_segment_reduce_f32 + tfgx_gemm_bias_act_f32
+    and vs the float64 oracle: weighted sum with the implicit self-loop (GCN), mean, unweighted sum; tiles that are not
+    full, empty rows, F not a multiple of the lane-group width, one output column."""
+    import torch
+    from tf_geometric_amd import plan as P
+    L = tfg._lib
+    rng = np.random.Generator(np.random.PCG64(n + f))
+    ei = oracle.synthetic_edges(n, e, seed=f) if e else np.zeros((2, 0), np.int32)
+    if e:
+        ei = ei[:, ei[0] % 11 != 3]                                       # rows without in-edges
+    x = rng.standard_normal((n, f), dtype=np.float32)
+    k = oracle.glorot_uniform(rng, f, units)
+    b = (rng.standard_normal(units) * 0.1).astype(np.float32)
+    plan = P.CsrPlan.build(L.as_i32(ei), n, n)
+    xd, kd, bd = L.as_f32(x), L.as_f32(k), L.as_f32(b)
+    w = rng.uniform(0.5, 1.5, ei.shape[1]).astype(np.float32)
+    if mode == "gcn":
+        w_csr, sc, op = plan.edge_attr_to_csr(w), torch.rand(n, device="cuda") + 0.25, L.SUM
+    elif mode == "mean":
+        w_csr, sc, op = plan.edge_attr_to_csr(w), None, L.MEAN
+    else:
+        w_csr, sc, op = None, None, L.SUM
+    assert L.require_gpu().tfgx_aggregate_gemm_fits(f, units) == 1
+    fused = P.aggregate_gemm(plan, xd, op, kd, w_csr=w_csr, self_coef=sc, bias=bd, act=L.ACT_RELU)
+    assert fused is not None and tuple(fused.shape) == (n, units)
+    agg = P.segment_reduce(plan, xd, op, w_csr=w_csr, self_coef=sc)
+    two = P.gemm_bias_act(agg, kd, bias=bd, act=L.ACT_RELU)
+    ref = np.maximum(agg.double().cpu().numpy() @ k.astype(np.float64) + b, 0)
+    assert_parity(fused.cpu().numpy(), ref, what="fused aggregate->gemm vs float64 of the same aggregate")
+    assert_parity(fused.cpu().numpy(), two.cpu().numpy(), what="fused vs two launches")
+    # into a column block of a wider output (GraphSAGE's concat halves) and without bias / activation
+    wide = torch.full((n, units + 5), 7.0, device="cuda")
+    P.aggregate_gemm(plan, xd, op, kd, w_csr=w_csr, self_coef=sc, out=wide[:, 5:])
+    assert_parity(wide[:, 5:].cpu().numpy(), agg.double().cpu().numpy() @ k.astype(np.float64), what="fused into a column block")
+    assert bool((wide[:, :5] == 7.0).all())
+
+
+def test_fused_aggregate_gemm_declines_what_it_cannot_take(tfg, oracle):
+    import torch
+    from tf_geometric_amd import plan as P
+    L = tfg._lib
+    lib = L.require_gpu()
+    assert lib.tfgx_aggregate_gemm_fits(128, 256) == 0 and lib.tfgx_aggregate_gemm_fits(100, 256) == 1
+    assert lib.tfgx_aggregate_gemm_fits(102, 16) == 0 and lib.tfgx_aggregate_gemm_fits(132, 16) == 0
+    assert lib.tfgx_aggregate_gemm_fits(100, 257) == 0
+    ei = oracle.synthetic_edges(500, 4000, seed=1)
+    plan = P.CsrPlan.build(L.as_i32(ei), 500, 500)
+    x = torch.randn(500, 128, device="cuda")
+    assert P.aggregate_gemm(plan, x, L.SUM, torch.randn(128, 256, device="cuda")) is None      # B + tiles exceed 160 KB
+    assert P.aggregate_gemm(plan, x, L.MAX, torch.randn(128, 16, device="cuda")) is None       # max is not linear

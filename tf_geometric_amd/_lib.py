@@ -190,6 +190,8 @@ SIGNATURES = {
     "tfgx_halo_compact": (ctypes.c_int, [_P, _I64, _P, _P, _P, _P, _SZ, _P]),
     "tfgx_halo_remap_cols": (ctypes.c_int, [_P, _I64, _I32, _I32, _P, _I32, _P, _P]),
     "tfgx_split_by_source_class": (ctypes.c_int, [_P, _P, _P, _I64, _I64, _P, _I32, _P, _P, _P, _P]),
+    "tfgx_aggregate_gemm_fits": (ctypes.c_int, [_I64, _I64]),
+    "tfgx_aggregate_gemm_f32": (ctypes.c_int, [ctypes.POINTER(ReduceArgs), _P, _I64, _P, _I32, _P, _I64, _I64, _P]),
 }
 
 _lib = None

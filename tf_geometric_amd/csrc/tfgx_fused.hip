@@ -1,0 +1,336 @@
+// Aggregation -> projection in ONE launch:  C = act( (reduce_{edges of r} w * x[col] (+ self_coef[r] * x[r]) [/ deg]) @ B + bias )
+// for the aggregate-then-project layers — GCN when units > F (nn/conv/gcn.py:272-288 evaluated as (A_hat x) W), mean / sum
+// GraphSAGE's neighbour half (nn/conv/graph_sage.py:34-58) — instead of tfgx_segment_reduce_f32 writing the [N, F] aggregate
+// to HBM and tfgx_gemm_bias_act_f32 reading it back (1.9 GB of round trip at products shape, F = 100).
+//
+// One persistent 1024-thread workgroup per CU (16 waves; the gather walk keeps its rate down to 16 waves per CU:
+// profiles/r03_occupancy_probe.jsonl).  LDS holds ALL of B ([KP][LDW] floats, loaded once) and two tiles of aggregated
+// rows, TRANSPOSED (At[k][m], m = destination row inside the 64-row tile) so that the MFMA A operand is a conflict-free
+// ds_read over consecutive m.
+//   * producers: every wave repeatedly takes the next UNIT (64 / G consecutive destination rows of the current tile: one per
+//     lane group) from an LDS counter, reduces it exactly like seg_reduce_kernel (G lanes per row, 4 columns per lane,
+//     (col, w) batches prefetched, 8 gathered rows in flight, one in-order FMA chain per output element), and stores the row
+//     into the tile.  Units are handed out dynamically, so a wave that drew short rows simply takes more of them;
+//   * consumer: the wave that completes a tile (per-tile arrival counter) multiplies it — 32x32 output blocks with
+//     v_mfma_f32_32x32x2_f32 against B from LDS, bias / activation in the epilogue, rows written straight to C — while the
+//     other 15 waves are already reducing the next tile into the other buffer.  No workgroup barrier after the B load: a
+//     buffer is re-used only after its `done` sequence number says the previous occupant has been multiplied.
+// Deterministic (fixed per-row edge order, fixed k order), fp32 throughout.  Roofline: HBM (the gather), as the unfused
+// aggregation; the MFMA work (2 N F U flops = 0.8 ms of one wave per CU at products shape) rides on otherwise idle pipes.
+#include "tfgx_common.h"
+#include <cstdlib>
+
+namespace tfgx {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kTileRows = 64;
+constexpr int kLda = kTileRows + 1;
+constexpr int kBufs = 2;
+constexpr int kFusedThreads = 1024;
+constexpr int kCtrlInts = 1 + 2 * kBufs;
+
+struct FArgs {
+    const int32_t* row_ptr;
+    const int32_t* col;
+    const float* w;
+    int64_t n_dst;
+    const float* x;
+    int64_t ldx;
+    int32_t F;
+    int32_t op;
+    const float* self_coef;
+    const int32_t* mean_count;
+    const float* B;
+    int64_t ldb;
+    const float* bias;
+    int32_t act;
+    int32_t N;
+    float* C;
+    int64_t ldc;
+    int32_t KP;        // F rounded up to even (the MFMA consumes two k per step)
+    int32_t n_blocks;  // 32-column output blocks, rounded up to a multiple of 4
+    int32_t LDW;       // 32 * n_blocks + 8
+    int64_t n_tiles;
+    int32_t dbg;       // developer experiment: 1 = skip the multiplication and the stores, 2 = skip the stores only
+};
+
+template <int G>
+__device__ __forceinline__ int bcast_i(int v, int j) { return __shfl(v, j, G); }
+template <int G>
+__device__ __forceinline__ float bcast_f(float v, int j) { return __shfl(v, j, G); }
+
+template <int G, bool WEIGHTED>
+__global__ __launch_bounds__(kFusedThreads) void agg_gemm_kernel(const FArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* Ws = lds;                                        // [KP][LDW]
+    float* At = Ws + a.KP * a.LDW;                          // [kBufs][KP][kLda]
+    int* ctrl = reinterpret_cast<int*>(At + kBufs * a.KP * kLda);   // [0] next unit | [1 + b] arrivals of buffer b | [1 + kBufs + b] done seq
+    constexpr int RPW = 64 / G;                             // destination rows per wave step (one per lane group)
+    constexpr int UNITS = kTileRows / RPW;
+    constexpr int UNROLL = 8;
+    const int tid = threadIdx.x, lane64 = tid & 63;
+    const int lane = lane64 % G, grp = lane64 / G;
+
+    for (int i = tid; i < a.KP * a.LDW; i += kFusedThreads) {
+        const int k = i / a.LDW, n = i - k * a.LDW;
+        Ws[i] = (k < a.F && n < a.N) ? a.B[int64_t(k) * a.ldb + n] : 0.0f;
+    }
+    for (int i = tid; i < kBufs * a.KP * kLda; i += kFusedThreads) At[i] = 0.0f;      // rows k >= F stay zero for good
+    if (tid < kCtrlInts) ctrl[tid] = 0;
+    __syncthreads();
+
+    const int64_t my_tiles = a.n_tiles > int64_t(blockIdx.x) ? (a.n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    const int64_t total_units = my_tiles * UNITS;
+    const int c_raw = lane * 4;
+    const bool cvalid = c_raw < a.F;
+    const int coff = cvalid ? c_raw : a.F - 4;              // lanes past F re-read the last valid vector (discarded)
+    const int l31 = lane64 & 31, kh = lane64 >> 5;
+
+    while (true) {
+        int u = 0;
+        if (lane64 == 0) u = atomicAdd(&ctrl[0], 1);
+        u = __builtin_amdgcn_readfirstlane(u);
+        if (u >= total_units) break;
+        const int q = u / UNITS, slot = u - q * UNITS;      // tile sequence number inside this workgroup, unit inside the tile
+        const int buf = q % kBufs;
+        const int64_t tile = int64_t(blockIdx.x) + int64_t(q) * gridDim.x;
+        const int m = slot * RPW + grp;                     // row inside the tile
+        const int64_t r = tile * kTileRows + m;
+
+        // ---- producer: reduce destination row r (seg_reduce_kernel's walk) -------------------------------------------
+        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (r < a.n_dst) {
+            const int s = a.row_ptr[r], e = a.row_ptr[r + 1];
+            int cj_next = 0;
+            float wj_next = 0.0f;
+            if (s + lane < e) {
+                cj_next = a.col[s + lane];
+                if constexpr (WEIGHTED) wj_next = a.w[s + lane];
+            }
+            for (int base = s; base < e; base += G) {
+                const int cj = cj_next;
+                const float wj = wj_next;
+                const int nxt = base + G + lane;
+                if (nxt < e) {
+                    cj_next = a.col[nxt];
+                    if constexpr (WEIGHTED) wj_next = a.w[nxt];
+                }
+                const int cnt = min(G, e - base);
+                int j = 0;
+                for (; j + UNROLL <= cnt; j += UNROLL) {
+                    float xv[UNROLL][4];
+                    float ww[UNROLL];
+#pragma unroll
+                    for (int t = 0; t < UNROLL; ++t) {
+                        const int c = bcast_i<G>(cj, j + t);
+                        if constexpr (WEIGHTED) ww[t] = bcast_f<G>(wj, j + t);
+                        load_vec<4>(a.x + int64_t(c) * a.ldx + coff, xv[t]);
+                    }
+#pragma unroll
+                    for (int t = 0; t < UNROLL; ++t)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) acc[v] = WEIGHTED ? fmaf(ww[t], xv[t][v], acc[v]) : acc[v] + xv[t][v];
+                }
+                for (; j < cnt; ++j) {
+                    const int c = bcast_i<G>(cj, j);
+                    float wv = 1.0f;
+                    if constexpr (WEIGHTED) wv = bcast_f<G>(wj, j);
+                    float xv[4];
+                    load_vec<4>(a.x + int64_t(c) * a.ldx + coff, xv);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) acc[v] = WEIGHTED ? fmaf(wv, xv[v], acc[v]) : acc[v] + xv[v];
+                }
+            }
+            if (a.self_coef) {                               // the implicit (r, r) edge appended after the row's edges
+                const float sc = a.self_coef[r];
+                float xs[4];
+                load_vec<4>(a.x + r * a.ldx + coff, xs);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) acc[v] = fmaf(sc, xs[v], acc[v]);
+            }
+            if (a.op == TFGX_MEAN) {
+                const int cnt = a.mean_count ? a.mean_count[r] : (e - s);
+                const float divisor = float(cnt > 1 ? cnt : 1);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) acc[v] = acc[v] / divisor;
+            }
+        }
+        // ---- hand the row over: wait until the buffer's previous tile (q - kBufs) has been multiplied, store transposed
+        if (q >= kBufs) {
+            volatile int* done = ctrl + 1 + kBufs + buf;
+            while (*done < q - kBufs + 1) __builtin_amdgcn_s_sleep(1);
+            __threadfence_block();
+        }
+        float* ab = At + buf * a.KP * kLda;
+        if (cvalid) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) ab[(coff + v) * kLda + m] = acc[v];
+        }
+        __threadfence_block();
+        int arrived = 0;
+        if (lane64 == 0) arrived = atomicAdd(&ctrl[1 + buf], 1);
+        arrived = __builtin_amdgcn_readfirstlane(arrived);
+        if (arrived != UNITS - 1) continue;
+
+        // ---- consumer: this wave completed tile q -> C[tile rows, :] = act(At^T @ Ws + bias) --------------------------
+        __threadfence_block();
+        for (int mb = 0; mb < (a.dbg == 1 ? 0 : kTileRows / 32); ++mb) {
+            for (int nb0 = 0; nb0 < a.n_blocks; nb0 += 4) {         // n_blocks is a multiple of 4 (zero-padded columns of Ws)
+                f32x16 c4[4];
+#pragma unroll
+                for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) c4[jb][t] = 0.0f;
+                const float* ap = ab + kh * kLda + mb * 32 + l31;
+                const float* bp = Ws + kh * a.LDW + nb0 * 32 + l31;
+                // KU k-pairs per step: all 5 * KU LDS reads of a step are issued before its 4 * KU MFMAs (a read-wait-multiply
+                // chain per MFMA left the single consumer wave at ~2.5x the MFMA time and the producers waiting for buffers)
+                constexpr int KU = 4;
+                const int pairs = a.KP / 2;
+                int pr = 0;
+                for (; pr + KU <= pairs; pr += KU) {
+                    float av[KU], bv[KU][4];
+#pragma unroll
+                    for (int t = 0; t < KU; ++t) {
+                        av[t] = ap[(2 * (pr + t)) * kLda];
+#pragma unroll
+                        for (int jb = 0; jb < 4; ++jb) bv[t][jb] = bp[(2 * (pr + t)) * a.LDW + jb * 32];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);      // left alone the scheduler sinks every read next to its MFMA
+#pragma unroll
+                    for (int t = 0; t < KU; ++t)
+#pragma unroll
+                        for (int jb = 0; jb < 4; ++jb)
+                            c4[jb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t][jb], c4[jb], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                for (; pr < pairs; ++pr) {
+                    const float av = ap[(2 * pr) * kLda];
+                    float bv[4];
+#pragma unroll
+                    for (int jb = 0; jb < 4; ++jb) bv[jb] = bp[(2 * pr) * a.LDW + jb * 32];
+#pragma unroll
+                    for (int jb = 0; jb < 4; ++jb) c4[jb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[jb], c4[jb], 0, 0, 0);
+                }
+                // D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).  Two phases on purpose (as in
+                // tfgx_gemm.hip): bias + activation IN PLACE first, then every store reads its own accumulator register —
+                // results computed into a temporary right before each store make the compiler drain vmcnt(0) between
+                // consecutive stores (measured here: 2.0 ms of the 10.8 ms launch went into 128 serialised stores per tile)
+#pragma unroll
+                for (int jb = 0; jb < 4; ++jb) {
+                    const int gn = (nb0 + jb) * 32 + l31;
+                    const float bv = (a.bias && gn < a.N) ? a.bias[gn] : 0.0f;
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) c4[jb][t] = apply_act(c4[jb][t] + bv, a.act);
+                }
+                const int64_t row0 = (a.dbg == 3 ? (tile & 63) : tile) * kTileRows + mb * 32 + 4 * kh;   // dbg 3: stores land in 4096 rows
+                const bool full = tile * kTileRows + kTileRows <= a.n_dst;
+#pragma unroll
+                for (int jb = 0; jb < 4; ++jb) {
+                    const int gn = (nb0 + jb) * 32 + l31;
+                    if (gn >= a.N || a.dbg == 2) continue;
+                    float* cp = a.C + row0 * a.ldc + gn;
+                    if (full) {
+                        // streaming (non-temporal) stores: the output is written once and not read by this launch; kept out
+                        // of the caches it does not evict source rows the gather still hits there
+                        if (a.dbg != 4) {
+#pragma unroll
+                            for (int t = 0; t < 16; ++t)
+                                __builtin_nontemporal_store(c4[jb][t], cp + int64_t((t & 3) + 8 * (t >> 2)) * a.ldc);
+                        } else {
+#pragma unroll
+                            for (int t = 0; t < 16; ++t) cp[int64_t((t & 3) + 8 * (t >> 2)) * a.ldc] = c4[jb][t];
+                        }
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < 16; ++t) {
+                            const int dr = (t & 3) + 8 * (t >> 2);
+                            if (row0 + dr < a.n_dst) cp[int64_t(dr) * a.ldc] = c4[jb][t];
+                        }
+                    }
+                }
+            }
+        }
+        __threadfence_block();
+        // (every lane stores the same wave-uniform values: no single-lane branch around the hand-over)
+        ctrl[1 + buf] = 0;
+        __threadfence_block();
+        *reinterpret_cast<volatile int*>(ctrl + 1 + kBufs + buf) = q + 1;
+    }
+}
+
+inline size_t fused_lds_bytes(int kp, int ldw) { return sizeof(float) * (size_t(kp) * ldw + size_t(kBufs) * kp * kLda) + sizeof(int) * 16; }
+
+}  // namespace
+}  // namespace tfgx
+
+using namespace tfgx;
+
+// 1 if tfgx_aggregate_gemm_f32 takes rows of F columns projected to N columns (everything resident in 160 KB of LDS)
+extern "C" int tfgx_aggregate_gemm_fits(int64_t F, int64_t N)
+{
+    if (F < 4 || F > 128 || F % 4 != 0 || N < 1 || N > 256) return 0;
+    const int kp = int((F + 1) / 2 * 2), ldw = int((N + 127) / 128) * 128 + 8;
+    return fused_lds_bytes(kp, ldw) <= 160 * 1024 ? 1 : 0;
+}
+
+extern "C" int tfgx_aggregate_gemm_f32(const tfgx_reduce_args* p, const float* B, int64_t ldb, const float* bias, int32_t act,
+                                       float* C, int64_t ldc, int64_t N, tfgx_stream_t stream_)
+{
+    TFGX_RANGE();
+    TFGX_REQUIRE(p != nullptr, "args is null");
+    TFGX_REQUIRE(p->op == TFGX_SUM || p->op == TFGX_MEAN, "sum / mean only");
+    TFGX_REQUIRE(act == TFGX_ACT_NONE || act == TFGX_ACT_RELU, "bad act");
+    TFGX_REQUIRE(tfgx_aggregate_gemm_fits(p->F, N) == 1, "shape not supported (tfgx_aggregate_gemm_fits)");
+    TFGX_REQUIRE(p->n_dst >= 0 && p->n_dst < (int64_t(1) << 31) * kTileRows / 64, "bad n_dst");
+    if (p->n_dst == 0) return TFGX_OK;
+    TFGX_REQUIRE(p->row_begin && p->row_end == p->row_begin + 1 && p->rp_stride == 1, "needs a plain CSR (row_ptr, row_ptr + 1)");
+    TFGX_REQUIRE(p->x && B && C, "null pointer");          // (col may be NULL for a graph without edges)
+    TFGX_REQUIRE(p->ldx >= p->F && p->ldx % 4 == 0 && aligned_to(p->x, 16) && ldb >= N && ldc >= N, "bad leading dimension / alignment");
+    TFGX_REQUIRE(!p->accumulate && !p->add_x && !p->x_tail && p->hub_threshold == 0 && !p->row_order && !p->track,
+                 "plain aggregation only (no accumulate / add_x / split rows / hub lists / row order / track)");
+    FArgs a;
+    a.row_ptr = p->row_begin; a.col = p->col; a.w = p->w; a.n_dst = p->n_dst; a.x = p->x; a.ldx = p->ldx; a.F = int32_t(p->F);
+    a.op = p->op; a.self_coef = p->self_coef; a.mean_count = p->mean_count;
+    a.B = B; a.ldb = ldb; a.bias = bias; a.act = act; a.N = int32_t(N); a.C = C; a.ldc = ldc;
+    a.KP = int32_t((p->F + 1) / 2 * 2);
+    a.n_blocks = int32_t((N + 127) / 128) * 4;          // 32-column blocks, in groups of four (columns >= N are zero in LDS)
+    a.LDW = 32 * a.n_blocks + 8;
+    a.n_tiles = (p->n_dst + kTileRows - 1) / kTileRows;
+    a.dbg = getenv("TFGX_FUSED_DBG") ? atoi(getenv("TFGX_FUSED_DBG")) : 0;
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        TFGX_HIP_CHECK(hipGetDevice(&dev));
+        TFGX_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+        cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const size_t lds_bytes = fused_lds_bytes(a.KP, a.LDW);
+    const int64_t wgs = a.n_tiles < cus ? a.n_tiles : cus;
+    hipStream_t stream = as_stream(stream_);
+    const bool weighted = p->w != nullptr;
+#define TFGX_FUSED_GO(GG, WW)                                                                                        \
+    do {                                                                                                             \
+        static bool attr_set = false;                                                                                \
+        if (!attr_set) {                                                                                             \
+            TFGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(agg_gemm_kernel<GG, WW>),               \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));             \
+            attr_set = true;                                                                                         \
+        }                                                                                                            \
+        agg_gemm_kernel<GG, WW><<<dim3(unsigned(wgs)), dim3(kFusedThreads), lds_bytes, stream>>>(a);                 \
+    } while (0)
+    if (p->F <= 64) {
+        if (weighted) TFGX_FUSED_GO(16, true);
+        else TFGX_FUSED_GO(16, false);
+    } else {
+        if (weighted) TFGX_FUSED_GO(32, true);
+        else TFGX_FUSED_GO(32, false);
+    }
+#undef TFGX_FUSED_GO
+    TFGX_LAUNCH_CHECK("agg_gemm_kernel");
+    return TFGX_OK;
+}

@@ -345,6 +345,18 @@ __device__ __forceinline__ void seg_reduce_row(const KArgs& a, int64_t r, int s,
 // Workgroups per launch: enough to fill 256 CUs x 8 XCDs at full occupancy several times over, few enough that every
 // lane group walks several rows and the row-header pipeline of seg_reduce_kernel has something to overlap.
 // TFGX_REDUCE_GRID_CAP overrides (developer A/B, profiles/r02_ab_grid_cap.jsonl).
+// developer experiment: TFGX_REDUCE_DUMMY_LDS=<bytes> makes every launch reserve that much (unused) dynamic LDS, which caps
+// the workgroups per CU — how does the gather rate depend on the waves in flight? (profiles/r03_occupancy_probe.jsonl)
+inline size_t dummy_lds_bytes()
+{
+    static long v = -1;
+    if (v < 0) {
+        const char* e = getenv("TFGX_REDUCE_DUMMY_LDS");
+        v = (e != nullptr && atol(e) > 0) ? atol(e) : 0;
+    }
+    return size_t(v);
+}
+
 inline int reduce_grid_cap()
 {
     static int cap = 0;
@@ -366,11 +378,11 @@ int launch_cfg(const KArgs& a, bool is_max, bool weighted, int ny, hipStream_t s
     if constexpr (VEC == 4 && CH == 1) {
         if (a.x_tail != nullptr) {   // split rows: sum / mean only (the case that matters: 400-byte rows)
             if (is_max) {
-                if (weighted) seg_reduce_kernel<VEC, G, CH, true, true, true><<<grid, block, 0, stream>>>(a);
-                else seg_reduce_kernel<VEC, G, CH, true, false, true><<<grid, block, 0, stream>>>(a);
+                if (weighted) seg_reduce_kernel<VEC, G, CH, true, true, true><<<grid, block, dummy_lds_bytes(), stream>>>(a);
+                else seg_reduce_kernel<VEC, G, CH, true, false, true><<<grid, block, dummy_lds_bytes(), stream>>>(a);
             } else {
-                if (weighted) seg_reduce_kernel<VEC, G, CH, false, true, true><<<grid, block, 0, stream>>>(a);
-                else seg_reduce_kernel<VEC, G, CH, false, false, true><<<grid, block, 0, stream>>>(a);
+                if (weighted) seg_reduce_kernel<VEC, G, CH, false, true, true><<<grid, block, dummy_lds_bytes(), stream>>>(a);
+                else seg_reduce_kernel<VEC, G, CH, false, false, true><<<grid, block, dummy_lds_bytes(), stream>>>(a);
             }
             TFGX_LAUNCH_CHECK("seg_reduce_kernel<split>");
             return TFGX_OK;
@@ -382,8 +394,8 @@ int launch_cfg(const KArgs& a, bool is_max, bool weighted, int ny, hipStream_t s
     }
     if (a.track != nullptr) {
         if constexpr (VEC == 4 && CH == 1) {
-            if (weighted) seg_reduce_kernel<VEC, G, CH, true, true, false, true><<<grid, block, 0, stream>>>(a);
-            else seg_reduce_kernel<VEC, G, CH, true, false, false, true><<<grid, block, 0, stream>>>(a);
+            if (weighted) seg_reduce_kernel<VEC, G, CH, true, true, false, true><<<grid, block, dummy_lds_bytes(), stream>>>(a);
+            else seg_reduce_kernel<VEC, G, CH, true, false, false, true><<<grid, block, dummy_lds_bytes(), stream>>>(a);
             TFGX_LAUNCH_CHECK("seg_reduce_kernel<track>");
             return TFGX_OK;
         }
@@ -391,11 +403,11 @@ int launch_cfg(const KArgs& a, bool is_max, bool weighted, int ny, hipStream_t s
         return TFGX_ERR_INVALID_ARG;
     }
     if (is_max) {
-        if (weighted) seg_reduce_kernel<VEC, G, CH, true, true><<<grid, block, 0, stream>>>(a);
-        else seg_reduce_kernel<VEC, G, CH, true, false><<<grid, block, 0, stream>>>(a);
+        if (weighted) seg_reduce_kernel<VEC, G, CH, true, true><<<grid, block, dummy_lds_bytes(), stream>>>(a);
+        else seg_reduce_kernel<VEC, G, CH, true, false><<<grid, block, dummy_lds_bytes(), stream>>>(a);
     } else {
-        if (weighted) seg_reduce_kernel<VEC, G, CH, false, true><<<grid, block, 0, stream>>>(a);
-        else seg_reduce_kernel<VEC, G, CH, false, false><<<grid, block, 0, stream>>>(a);
+        if (weighted) seg_reduce_kernel<VEC, G, CH, false, true><<<grid, block, dummy_lds_bytes(), stream>>>(a);
+        else seg_reduce_kernel<VEC, G, CH, false, false><<<grid, block, dummy_lds_bytes(), stream>>>(a);
     }
     TFGX_LAUNCH_CHECK("seg_reduce_kernel");
     return TFGX_OK;

@@ -9,7 +9,8 @@ import torch
 
 from ... import _lib as L
 from ...activations import resolve as _resolve_act
-from ...plan import segment_reduce, gemm_bias_act, static_rows, static_aggregate, gather_friendly_empty
+from ...plan import (segment_reduce, gemm_bias_act, static_rows, static_aggregate, gather_friendly_empty, aggregate_gemm,
+                     SplitRows)
 from ...sparse import SparseMatrix, sparse_features, sparse_dense_matmul
 from ... import autograd as AG
 
@@ -206,7 +207,14 @@ def gcn(x, sparse_adj, kernel, bias=None, activation=None, norm="both", add_self
         # A_hat @ (x @ W) == (A_hat @ x) @ W: gather at the NARROWER width (bytes per edge = 4*min(F, units) + 8),
         # bias + activation move into the GEMM epilogue. Same result up to fp32 re-association (inside 1e-5).
         pre = static_aggregate(x, normed.plan, cache, L.SUM, normed.w_csr, normed.self_coef)       # opt-in memo (layer 0)
-        h = gemm_bias_act(pre if pre is not None else normed.matmul(x, cache=cache), kernel, bias=bias_t, act=act)
+        h = None
+        if pre is None and not isinstance(static_rows(x, normed.plan, cache), SplitRows):
+            # one launch: 64-row tiles of A_hat @ x go registers -> LDS -> MFMA against the kernel held in LDS; the
+            # [N, F] aggregate never visits HBM (tfgx_aggregate_gemm_f32; None when the shape does not fit)
+            h = aggregate_gemm(normed.plan, x, L.SUM, kernel, w_csr=normed.w_csr, self_coef=normed.self_coef, bias=bias_t,
+                               act=act)
+        if h is None:
+            h = gemm_bias_act(pre if pre is not None else normed.matmul(x, cache=cache), kernel, bias=bias_t, act=act)
     else:
         # the GEMM's rows are gathered next: written at a line-friendly stride (plan.gather_friendly_ld)
         h = x if kernel is None else gemm_bias_act(x, kernel, out=gather_friendly_empty(int(x.shape[0]), int(kernel.shape[1]), x.device))     # :266-272

@@ -15,7 +15,7 @@ import torch
 from ... import _lib as L
 from ...activations import resolve as _resolve_act
 from ...plan import (CsrPlan, segment_reduce, gemm_bias_act, l2_normalize_rows_, edge_weight_csr, static_rows,
-                     static_aggregate, gather_friendly_empty)
+                     static_aggregate, static_aggregate_applies, gather_friendly_empty, aggregate_gemm, SplitRows)
 from ...sparse import SparseMatrix
 from .gcn import gcn_norm_adj
 from ... import autograd as AG
@@ -74,6 +74,30 @@ def _neighbor_reduce(x, edge_index, edge_weight, op, cache):
     return x, segment_reduce(plan, static_rows(x, plan, cache), op, w_csr=w_csr)
 
 
+def _concat_fused(x, edge_index, edge_weight, ws, wn, bias, activation, normalize, op, cache):
+    """Inference, concat, aggregation-first (ku >= F): the neighbour half reduce(w * x[col]) @ W_neigh (+ bias, activation)
+    in ONE launch straight into its half of the output (plan.aggregate_gemm: the [N, F] reduce never visits HBM), the self
+    half by the GEMM.  None when the fused kernel does not take the call (shape / static layouts / hub rows)."""
+    n = int(x.shape[0])
+    plan = CsrPlan.from_cache(edge_index, n, n, cache)
+    w_csr = AG.edge_attr_csr(plan, edge_weight, cache)
+    if static_aggregate_applies(x, cache) or isinstance(static_rows(x, plan, cache), SplitRows):
+        return None
+    act, post = _resolve_act(activation)
+    ku_x, ku_n = int(ws.shape[1]), int(wn.shape[1])
+    bias_t = None if bias is None else L.as_f32(bias).contiguous()
+    h = torch.empty((n, ku_x + ku_n), dtype=torch.float32, device=x.device)
+    if aggregate_gemm(plan, x, op, wn, w_csr=w_csr, bias=None if bias_t is None else bias_t[ku_x:].contiguous(), act=act,
+                      out=h[:, ku_x:]) is None:
+        return None
+    gemm_bias_act(x, ws, bias=None if bias_t is None else bias_t[:ku_x], act=act, out=h[:, :ku_x])
+    if post is not None:
+        h = post(h)
+    if normalize:
+        h = l2_normalize_rows_(h.contiguous())
+    return h
+
+
 def _self_neighbor_sage(x, edge_index, edge_weight, self_kernel, neighbor_kernel, bias, activation, concat, normalize,
                         op, cache):
     """mean / sum GraphSAGE (reference :9-115).  Both reducers are linear, so
@@ -86,6 +110,10 @@ def _self_neighbor_sage(x, edge_index, edge_weight, self_kernel, neighbor_kernel
     ws = L.as_f32(self_kernel)
     F, ku_x, ku_n = int(x.shape[1]), int(ws.shape[1]), int(wn.shape[1])
     if not ku_n < F:
+        if concat and not AG.needs_grad(x, edge_weight, ws, wn, bias):
+            h = _concat_fused(x, edge_index, edge_weight, ws, wn, bias, activation, normalize, op, cache)
+            if h is not None:
+                return h
         x, reduced = _neighbor_reduce(x, edge_index, edge_weight, op, cache)
         return _combine(ws, x, wn, reduced, bias, activation, concat, normalize)
     n = int(x.shape[0])
@@ -188,8 +216,10 @@ def gcn_graph_sage(x, edge_index, edge_weight, kernel, bias=None, activation=Non
         z = gemm_bias_act(x, kernel, out=gather_friendly_empty(n, int(kernel.shape[1]), x.device))
         h = normed.matmul(z, bias=None if bias is None else L.as_f32(bias).contiguous(), act=act)
     else:
-        reduced = normed.matmul(x)                                                  # :143-150
-        h = gemm_bias_act(reduced, kernel, bias=bias, act=act)                      # :152-157
+        h = aggregate_gemm(normed.plan, x, L.SUM, kernel, w_csr=normed.w_csr, self_coef=normed.self_coef, bias=bias, act=act)
+        if h is None:
+            reduced = normed.matmul(x)                                              # :143-150
+            h = gemm_bias_act(reduced, kernel, bias=bias, act=act)                  # :152-157
     if post is not None:
         h = post(h)
     if normalize:

@@ -331,6 +331,13 @@ def static_aggregate(x, plan, cache, op, w_csr=None, self_coef=None):
     return out
 
 
+def static_aggregate_applies(x, cache):
+    """Would static_aggregate serve / compute the memo for x?  (No side effects: callers that have a cheaper route for
+    NON-memoised features ask first.)"""
+    store = cache.get(CACHE_KEY_STATIC_AGG) if cache is not None else None
+    return store is not None and _declared_static(x, cache) and not torch.cuda.is_current_stream_capturing()
+
+
 def static_rows(x, plan, cache):
     """`x`, or its prepared SplitRows + edge-resident-tail form when — and only when — the caller opted in for exactly
     this tensor (`prepare_static_features`, or `cache["tfgx_static_features"] = x`).  No heuristics: a tensor that was
@@ -444,6 +451,41 @@ def segment_reduce(plan, x, op, w_csr=None, out=None, act=L.ACT_NONE, self_coef=
         L.check(lib.tfgx_segment_reduce_describe(ctypes.byref(a), buf, 160), "tfgx_segment_reduce_describe")
         return buf.value.decode()
     L.check(lib.tfgx_segment_reduce_f32(ctypes.byref(a), L.stream_ptr()), "tfgx_segment_reduce_f32")
+    return out
+
+
+FUSE_AGGREGATE_GEMM = True      # developer A/B switch (tools/ab_fused_layer.py): False = always two launches
+
+
+def aggregate_gemm(plan, x, op, kernel, w_csr=None, self_coef=None, bias=None, act=L.ACT_NONE, out=None):
+    """act(segment_reduce(plan, x, op, w_csr, self_coef) @ kernel + bias) in ONE launch (tfgx_aggregate_gemm_f32: the
+    aggregate goes registers -> LDS -> MFMA, never through HBM), or None when the fused kernel does not take this call
+    (shape outside tfgx_aggregate_gemm_fits, unaligned rows, a plan with hub rows, hipGraph capture of a first use) —
+    the caller then runs the two launches."""
+    if not FUSE_AGGREGATE_GEMM or op not in (L.SUM, L.MEAN) or isinstance(x, SplitRows):
+        return None
+    lib = L.require_gpu()
+    x2, ldx = L.row_major_2d(x)
+    k2, ldb = L.row_major_2d(L.as_f32(kernel))
+    F, N = int(x2.shape[1]), int(k2.shape[1])
+    if int(k2.shape[0]) != F or not lib.tfgx_aggregate_gemm_fits(F, N) or ldx % 4 != 0 or x2.data_ptr() % 16 != 0:
+        return None
+    if plan.hub_info() is not None:          # long rows are chunked by the unfused path; here a row belongs to one lane group
+        return None
+    n_dst = plan.n_dst
+    if out is None:
+        out = torch.empty((n_dst, N), dtype=torch.float32, device=x2.device)
+    _, ldc = L.row_major_2d(out)
+    a = L.ReduceArgs()
+    a.row_begin, a.row_end, a.rp_stride = plan.row_ptr.data_ptr(), plan.row_ptr[1:].data_ptr(), 1
+    a.col = plan.col.data_ptr()
+    a.w = 0 if w_csr is None else w_csr.data_ptr()
+    a.n_dst, a.x, a.ldx, a.F = n_dst, x2.data_ptr(), ldx, F
+    a.op = op
+    a.self_coef = 0 if self_coef is None else self_coef.data_ptr()
+    bias_t = None if bias is None else L.as_f32(bias).contiguous()
+    L.check(lib.tfgx_aggregate_gemm_f32(ctypes.byref(a), L.ptr(k2), ldb, L.ptr(bias_t), act, L.ptr(out), ldc, N,
+                                        L.stream_ptr()), "tfgx_aggregate_gemm_f32")
     return out
 
 

@@ -1,0 +1,61 @@
+# coding=utf-8
+"""A/B of the fused aggregate->GEMM launch (tfgx_aggregate_gemm_f32) against the two launches it replaces, alternating in
+one process: GCN layer 100 -> 256 (+ bias, ReLU) and the mean-SAGE layer (units 256, concat) at products shape; the
+aggregation alone and the GEMM alone beside them.
+
+    python tools/ab_fused_layer.py > gpurun_out/r03/ab_fused_layer.json
+"""
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import tf_geometric_amd as tfg                          # noqa: E402
+from tf_geometric_amd import synthetic, _lib as L, plan as P     # noqa: E402
+import bench                                            # noqa: E402
+
+which = sys.argv[1] if len(sys.argv) > 1 else "products"
+n, e, f = synthetic.WORKLOADS[which]
+ei = L.as_i32(synthetic.synthetic_edges(n, e, seed=0))
+g = torch.Generator(device="cuda")
+g.manual_seed(1)
+x = torch.randn(n, f, generator=g, device="cuda")
+cache = {}
+gcn = tfg.layers.GCN(256, activation=tfg.relu)
+sage = tfg.layers.MeanGraphSage(256)
+w1 = torch.ones(int(ei.shape[1]), device="cuda")
+gcn([x, ei], cache=cache)
+sage([x, ei, w1], cache=cache)
+from tf_geometric_amd.nn.conv.gcn import gcn_norm_adj   # noqa: E402
+normed = gcn_norm_adj(cache["tfgx_gcn_adj"], cache=cache)
+k = torch.randn(f, 256, device="cuda") * 0.1
+agg_out = torch.empty(n, f, device="cuda")
+
+
+def set_fuse(v):
+    P.FUSE_AGGREGATE_GEMM = v
+
+
+fns = {
+    "gcn_layer_fused": lambda: (set_fuse(True), gcn([x, ei], cache=cache)),
+    "gcn_layer_two_launches": lambda: (set_fuse(False), gcn([x, ei], cache=cache)),
+    "mean_sage_layer_fused": lambda: (set_fuse(True), sage([x, ei, w1], cache=cache)),
+    "mean_sage_layer_two_launches": lambda: (set_fuse(False), sage([x, ei, w1], cache=cache)),
+    "aggregation_alone": lambda: P.segment_reduce(normed.plan, x, L.SUM, w_csr=normed.w_csr, self_coef=normed.self_coef, out=agg_out),
+    "gemm_alone": lambda: P.gemm_bias_act(agg_out, k),
+}
+times = {name: [] for name in fns}
+for rnd in range(4):
+    for name, fn in fns.items():
+        times[name].append(bench._time(fn, steps=10, warmup=3 if rnd == 0 else 1))
+set_fuse(True)
+med = {name: sorted(v)[len(v) // 2] for name, v in times.items()}
+a, b = gcn([x, ei], cache=cache), None
+set_fuse(False)
+b = gcn([x, ei], cache=cache)
+set_fuse(True)
+print(json.dumps({"shape": which, "N": n, "E": int(ei.shape[1]), "F": f, "ms_median_of_4_alternating_rounds": med,
+                  "max_abs_diff_fused_vs_two_launches": float((a - b).abs().max()), "all_rounds_ms": times}))
