@@ -23,6 +23,7 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 
 constexpr int BK = 16;   // 16 keeps load-staging registers low enough for 3 workgroups per CU (BK = 32: 2)
 
@@ -106,7 +107,12 @@ __global__ __launch_bounds__(kBlock) void gemm_kernel(const float* __restrict__ 
                 if (gm < M) {
                     const float* p = A + gm * lda + gk;
                     if (gk + 3 < K) {
-                        v = *reinterpret_cast<const float4*>(p);
+                        // 4-byte alignment is enough for global_load_dwordx4: rows that are not 16-byte aligned (K = 1433,
+                        // 602: lda % 4 != 0) may take this path too — one 16-byte load per lane instead of four dword loads
+                        // (launch_gemm decides; a branch-free clamped-address form of this load was measured and LOST 10-50 %
+                        // to its address arithmetic and selects: profiles/r03_gemm_sweep.jsonl)
+                        const f32x4_a4 t = *reinterpret_cast<const f32x4_a4*>(p);
+                        v = make_float4(t[0], t[1], t[2], t[3]);
                     } else {
                         if (gk < K) v.x = p[0];
                         if (gk + 1 < K) v.y = p[1];
@@ -978,7 +984,12 @@ int launch_gemm(const float* A, int64_t lda, const float* B, int64_t ldb, const 
         set_error("tfgx_gemm_bias_act_f32: too many tiles");
         return TFGX_ERR_INVALID_ARG;
     }
-    const bool av4 = (lda % 4 == 0) && aligned_to(A, 16);
+    // developer A/B: TFGX_GEMM_UNALIGNED_V4=0 restores the dword loads for rows that are not 16-byte aligned
+    static const bool unaligned_v4 = [] { const char* e = std::getenv("TFGX_GEMM_UNALIGNED_V4"); return !(e && e[0] == '0'); }();
+    // measured (same box, TFGX_GEMM_UNALIGNED_V4 = 0 / 1): 173312 x 1433 -> 16: 0.379 -> 0.281 ms; 170000 x 1433 -> 256: 1.235 ->
+    // 1.155; 233000 x 602 -> 64: 0.238 -> 0.214; 100000 x 301 -> 40: 0.073 -> 0.059; but 233000 x 602 -> 16 / 8: 0.188 -> 0.206 /
+    // 0.176 -> 0.205 — narrow outputs of a medium K stay on the dword loads
+    const bool av4 = ((lda % 4 == 0) && aligned_to(A, 16)) || (unaligned_v4 && aligned_to(A, 4) && (N > 32 || K >= 1024));
     const bool bv4 = (ldb % 4 == 0) && aligned_to(B, 16);
     const bool split = split_ws != nullptr && splits > 1;
     const int k_chunk = split ? int((((K + splits - 1) / splits) + 15) / 16 * 16) : K;

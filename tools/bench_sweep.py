@@ -166,7 +166,8 @@ def rmat_section(quick, e):
 
 def gemm_section(n):
     for (m, k, nn) in [(n, 100, 256), (n, 100, 128), (n, 128, 256), (n, 100, 64), (n, 256, 128), (n, 100, 16),
-                       (n, 256, 256), (170000, 128, 256), (170000, 256, 40), (233000, 602, 64), (2708 * 64, 1433, 16)]:
+                       (n, 256, 256), (170000, 128, 256), (170000, 256, 40), (233000, 602, 64), (2708 * 64, 1433, 16),
+                       (233000, 602, 16), (170000, 1433, 256), (100000, 301, 40), (n, 256, 40)]:
         a = torch.randn(m, k, device="cuda")
         b = torch.randn(k, nn, device="cuda") * 0.1
         c = torch.empty(m, nn, device="cuda")
