@@ -605,7 +605,7 @@ def _time(fn, steps=10, warmup=3):
     return e0.elapsed_time(e1) / steps
 
 
-def _time_ab(fn_a, fn_b, steps=10, warmup=3, rounds=3):
+def _time_ab(fn_a, fn_b, steps=20, warmup=3, rounds=5, detail=None):
     """Median per-step ms of two alternatives measured ALTERNATELY (a, b, a, b, ...): clock / power state drifts over
     a process's lifetime, so "first all of a, then all of b" charges the drift to whichever ran second (round 2's
     hipGraph-slower-than-eager reading was exactly that: a rocprofv3 trace of both shows the replay's kernels back to
@@ -614,6 +614,8 @@ def _time_ab(fn_a, fn_b, steps=10, warmup=3, rounds=3):
     for r in range(rounds):
         ta.append(_time(fn_a, steps, warmup if r == 0 else 1))
         tb.append(_time(fn_b, steps, warmup if r == 0 else 1))
+    if detail is not None:           # every round as measured, in order: (a, b) pairs
+        detail["rounds_ms"] = [[round(a, 4), round(b, 4)] for a, b in zip(ta, tb)]
     ta.sort()
     tb.sort()
     return ta[len(ta) // 2], tb[len(tb) // 2]
@@ -654,7 +656,9 @@ def extras(tfg, L, synthetic, x, ei, n, e, f, cache):
         return g1([g0([x, ei], cache=cache), ei], cache=cache)
 
     cap = tfg.CapturedForward(two_layer)
-    res["gcn_2layer_eager_ms"], res["gcn_2layer_hipgraph_ms"] = _time_ab(two_layer, lambda: cap.graph.replay())
+    det = {}
+    res["gcn_2layer_eager_ms"], res["gcn_2layer_hipgraph_ms"] = _time_ab(two_layer, lambda: cap.graph.replay(), detail=det)
+    res["gcn_2layer_eager_vs_hipgraph_rounds_ms"] = det["rounds_ms"]
     # the two numbers above are THROUGHPUT (steps queued back to back: the host runs ahead, launch cost is hidden, a
     # graph replay cannot win); what a hipGraph removes is per-step host LATENCY — one forward, then wait for it:
     res["gcn_2layer_eager_latency_ms"] = _latency(two_layer)
@@ -664,8 +668,10 @@ def extras(tfg, L, synthetic, x, ei, n, e, f, cache):
     res["gcn_layer_F{}_to_256_static_ms".format(f)] = _time(lambda: gcn([x, ei], cache=cache))
     res["mean_sage_layer_units256_static_ms"] = _time(lambda: sage([x, ei, w1], cache=cache))
     cap2 = tfg.CapturedForward(two_layer)                 # prepared BEFORE capture: the replay runs the static layout
+    det = {}
     res["gcn_2layer_eager_static_ms"], res["gcn_2layer_hipgraph_static_ms"] = _time_ab(two_layer,
-                                                                                       lambda: cap2.graph.replay())
+                                                                                       lambda: cap2.graph.replay(), detail=det)
+    res["gcn_2layer_eager_vs_hipgraph_static_rounds_ms"] = det["rounds_ms"]
     res["gcn_2layer_eager_static_latency_ms"] = _latency(two_layer)
     res["gcn_2layer_hipgraph_static_latency_ms"] = _latency(lambda: cap2.graph.replay())
     tfg.release_static_features(cache)

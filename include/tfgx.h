@@ -147,7 +147,7 @@ typedef struct tfgx_reduce_args {
 int tfgx_segment_reduce_f32(const tfgx_reduce_args* args /* host */, tfgx_stream_t stream);
 
 /* The kernel symbol tfgx_segment_reduce_f32 would launch for `args` (template arguments as rocprofv3 prints them:
-   seg_reduce_kernel<VEC, G, CH, IS_MAX, WEIGHTED, SPLIT>), written NUL-terminated into buf.  Host-only, launches
+   seg_reduce_kernel<VEC, G, CH, IS_MAX, WEIGHTED, SPLIT, TRACK>), written NUL-terminated into buf.  Host-only, launches
    nothing: measurement code (bench.py's roofline.kernel) names the kernel from the dispatch itself. */
 int tfgx_segment_reduce_describe(const tfgx_reduce_args* args /* host */, char* buf, size_t buf_bytes);
 

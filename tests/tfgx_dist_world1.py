@@ -43,7 +43,32 @@ dist_worker.check_training_extras([tr], ref, assert_parity)
 assert np.array_equal(tr["chunked"], tr["whole"])            # column-chunked halo: two exchanges in flight on two plans
 print("training through tfgx_dist ok")
 torch.cuda.synchronize()
+from tf_geometric_amd.dist import transport as T               # noqa: E402
 from tf_geometric_amd.dist.transport import close_transports   # noqa: E402
+
+# the agreed safety net of auto mode (world > 1 takes it): the communicator's self-check, and the fallback to torch's own
+# RCCL collectives when the C-ABI transport cannot be brought up on some rank
+from tf_geometric_amd.dist.sharded import HipBackend           # noqa: E402
+chk = T._checked_tfgx_transport(None, HipBackend())
+assert chk.name == "tfgx_dist"
+chk.close()
+
+
+class _Broken(T.TfgxDistTransport):
+    def self_check(self):
+        raise RuntimeError("injected")
+
+
+real, T.TfgxDistTransport = T.TfgxDistTransport, _Broken
+import warnings                                                # noqa: E402
+with warnings.catch_warnings(record=True) as caught:
+    warnings.simplefilter("always")
+    fb = T._checked_tfgx_transport(None, HipBackend())
+T.TfgxDistTransport = real
+assert fb.name.startswith("torch (fallback") and "injected" in fb.fallback_reason and caught, (fb.name, caught)
+got = fb.all_to_all_v(torch.arange(6, dtype=torch.int32, device="cuda").view(3, 2), [3], [3])
+assert got.tolist() == [[0, 1], [2, 3], [4, 5]]
+print("self-check and agreed fallback ok")
 close_transports()
 dist.barrier()
 dist.destroy_process_group()

@@ -532,8 +532,8 @@ extern "C" int tfgx_segment_reduce_describe(const tfgx_reduce_args* p, char* buf
     int G, CH;
     group_shape(int((p->F + vec - 1) / vec), &G, &CH);
     const bool split = p->x_tail != nullptr && vec == 4 && CH == 1;
-    snprintf(buf, buf_bytes, "seg_reduce_kernel<%d, %d, %d, %s, %s, %s>", vec, G, CH, p->op == TFGX_MAX ? "true" : "false",
-             p->w ? "true" : "false", split ? "true" : "false");
+    snprintf(buf, buf_bytes, "seg_reduce_kernel<%d, %d, %d, %s, %s, %s, %s>", vec, G, CH, p->op == TFGX_MAX ? "true" : "false",
+             p->w ? "true" : "false", split ? "true" : "false", p->track ? "true" : "false");
     return TFGX_OK;
 }
 

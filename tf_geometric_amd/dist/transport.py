@@ -117,6 +117,18 @@ class TfgxDistTransport(object):
             self.lib.tfgx_dist_comm_destroy(self.comm)
             self.comm = None
 
+    def self_check(self):
+        """A few hundred bytes through every entry point the plan build uses (tfgx_alltoallv with ragged counts,
+        tfgx_allreduce_sum_i64): raises when any peer's rows arrive wrong.  get_transport runs it once per communicator."""
+        w, r = self.world, self.rank
+        send = torch.cat([torch.full((p + 1, 2), r * 1000 + p, dtype=torch.int32, device=self.device) for p in range(w)])
+        got = self.all_to_all_v(send, [p + 1 for p in range(w)], [r + 1] * w)
+        want = torch.cat([torch.full((r + 1, 2), q * 1000 + r, dtype=torch.int32, device=self.device) for q in range(w)])
+        tot = self.all_reduce_sum_i64(torch.tensor([r + 1, 1], dtype=torch.int64, device=self.device))
+        torch.cuda.synchronize()
+        if not torch.equal(got, want) or tot.tolist() != [w * (w + 1) // 2, w]:
+            raise L.TfgxError("tfgx_dist self-check: rank {} received wrong rows / sums over the RCCL communicator".format(r))
+
     # ---- plan-time exchanges (device tensors, stream-ordered on the current stream)
     def all_reduce_sum_i64(self, t):
         if self.world > 1:
@@ -356,6 +368,7 @@ def get_transport(group, backend, kind=None):
     """One transport (one communicator, one communication stream) per (group, kind).  kind: "tfgx_dist" | "torch" | None
     (auto: the C-ABI RCCL transport for the HIP backend unless the group is gloo; TFGX_DIST_TRANSPORT overrides)."""
     kind = kind or os.environ.get("TFGX_DIST_TRANSPORT")
+    auto = kind is None
     inited = dist.is_available() and dist.is_initialized()
     if kind is None:
         hip = getattr(backend, "name", "") == "hip"
@@ -364,9 +377,43 @@ def get_transport(group, backend, kind=None):
     key = (id(group) if group is not None else 0, kind, inited)
     t = _TRANSPORTS.get(key)
     if t is None:
-        t = TfgxDistTransport(group) if kind == "tfgx_dist" else TorchDistTransport(group, backend)
+        if kind == "tfgx_dist" and auto and inited and dist.get_world_size(group) > 1:
+            t = _checked_tfgx_transport(group, backend)
+        else:
+            t = TfgxDistTransport(group) if kind == "tfgx_dist" else TorchDistTransport(group, backend)
         _TRANSPORTS[key] = t
     return t
+
+
+def _checked_tfgx_transport(group, backend):
+    """Auto mode at world > 1: build the C-ABI transport, push a few rows through it (self_check), and let the ranks
+    AGREE on the outcome over the control channel.  If any rank failed, every rank takes torch.distributed's RCCL
+    collectives instead — same exchange lists, same kernels either side — with a warning and a transport name that says
+    so (bench.py prints it in config.transport).  TFGX_DIST_TRANSPORT=tfgx_dist skips the net and fails loudly."""
+    err, t = None, None
+    try:
+        t = TfgxDistTransport(group)
+        t.self_check()
+    except Exception as ex:          # noqa: BLE001 - anything: a missing library, an RCCL error, wrong rows
+        err = "{}: {}".format(type(ex).__name__, ex)
+    flag = torch.tensor([0 if err else 1], dtype=torch.int32, device=L.device())
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    if int(flag.item()) == 1:
+        return t
+    import warnings
+    msg = "tf_geometric_amd.dist: the tfgx_dist (C ABI) transport failed its self-check on {} ({}); all ranks fall back " \
+          "to torch.distributed collectives on the same RCCL group".format(
+              "this rank" if err else "another rank", err or "see that rank's log")
+    warnings.warn(msg)
+    if t is not None:
+        try:
+            t.close()
+        except Exception:            # noqa: BLE001
+            pass
+    tt = TorchDistTransport(group, backend)
+    tt.name = "torch (fallback: tfgx_dist self-check failed)"
+    tt.fallback_reason = msg
+    return tt
 
 
 def close_transports():

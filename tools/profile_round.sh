@@ -17,10 +17,10 @@ F=$(find "$OUT/fetch" -name "*_results.db" | head -1)
 W=$(find "$OUT/write" -name "*_results.db" | head -1)
 python tools/rocpd_summary.py "$S" > "$OUT/summary_stats.md"
 # per-dispatch rows of the headline kernel: roofline.frac can be re-derived from this small CSV without the raw database
-python tools/kernel_dispatch_csv.py "$S" "seg_reduce_kernel<4, 32, 1, false, true, false>" "$OUT/r03_products_headline_dispatches.csv"
+python tools/kernel_dispatch_csv.py "$S" "seg_reduce_kernel<4, 32, 1, false, true, false, false>" "$OUT/r03_products_headline_dispatches.csv"
 python tools/rocpd_summary.py "$F" "$W" > "$OUT/summary_pmc.md"
-python tools/make_pmc_json.py "$F" "$W" "$S" "seg_reduce_kernel<4, 32, 1, false, true, false>" "$OUT/r03_products_pmc.json" products
-python tools/make_pmc_json.py "$F" "$W" "$S" "seg_reduce_kernel<4, 32, 1, false, true, true>" "$OUT/r03_products_edge_tail_pmc.json" products
+python tools/make_pmc_json.py "$F" "$W" "$S" "seg_reduce_kernel<4, 32, 1, false, true, false, false>" "$OUT/r03_products_pmc.json" products
+python tools/make_pmc_json.py "$F" "$W" "$S" "seg_reduce_kernel<4, 32, 1, false, true, true, false>" "$OUT/r03_products_edge_tail_pmc.json" products
 # the other BASELINE configs: Reddit-shaped GAT and the papers100M-shaped shard, kernel-trace only
 cd /tmp
 rocprofv3 --kernel-trace --stats -d "$OUT/reddit" -- python "$ROOT/tools/bench_sweep.py" --only=reddit > "$OUT/reddit.jsonl" 2> "$OUT/reddit.err"
