@@ -706,6 +706,27 @@ def extras(tfg, L, synthetic, x, ei, n, e, f, cache):
     torch.cuda.reset_peak_memory_stats()
     res["gcn_2layer_train_step_ms"] = _time(full_step, steps=5, warmup=2)
     res["gcn_2layer_train_step_peak_GB"] = torch.cuda.max_memory_allocated() / 1e9      # graph + plans + activations + workspaces
+    # the same step replayed from ONE hipGraph (tfg.CapturedTrainStep: zero-grad, forward, loss, backward, Adam update),
+    # measured alternately with the eager loop on the same capturable optimizer; a step is launch-bound on small graphs
+    # (arxiv shape), kernel-bound at products shape
+    opt_c = torch.optim.Adam(t0l.parameters() + t1l.parameters(), lr=1e-2, capturable=True)
+
+    def loss_c():
+        return torch.nn.functional.cross_entropy(t1l([t0l([x, ei], cache=cache), ei], cache=cache)[idx], labels)
+
+    def full_step_c():
+        opt_c.zero_grad(set_to_none=True)
+        loss_c().backward()
+        opt_c.step()
+
+    cap_step = tfg.CapturedTrainStep(loss_c, opt_c)
+    det = {}
+    res["gcn_2layer_train_step_eager_capturable_ms"], res["gcn_2layer_train_step_hipgraph_ms"] = _time_ab(
+        full_step_c, cap_step, steps=5, warmup=2, rounds=3, detail=det)
+    res["gcn_2layer_train_step_eager_vs_hipgraph_rounds_ms"] = det["rounds_ms"]
+    res["gcn_2layer_train_step_eager_latency_ms"] = _latency(full_step_c, steps=10)
+    res["gcn_2layer_train_step_hipgraph_latency_ms"] = _latency(cap_step, steps=10)
+    del cap_step
     # BASELINE configs[3]: GraphSAGE mean / max-pool aggregators (units 256, concat, as demo/demo_graph_sage.py:29-30):
     # one full-batch training step of a 2-layer mean model, and forward + backward of one max-pool layer
     s0, s1 = tfg.layers.MeanGraphSage(256, activation=tfg.relu), tfg.layers.MeanGraphSage(40, activation=None)

@@ -6,7 +6,7 @@ Same model (GCN(16, relu) -> GCN(num_classes), dropout 0.5, Adam 1e-2, L2 5e-4 o
 signature `[x, edge_index, edge_weight], cache=graph_cache`, same closing "mean forward time" measurement
 (demo/demo_gcn.py:99-105).  tf.GradientTape -> torch.autograd over the kernels' own backward (tf_geometric_amd.autograd).
 
-    python examples/demo_gcn.py [--steps 200]
+    python examples/demo_gcn.py [--steps 200] [--hipgraph]
 """
 import argparse
 import os
@@ -61,7 +61,7 @@ class GCNModel(object):
         return self.gcn0.parameters() + self.gcn1.parameters()
 
 
-def main(steps=200, forward_iters=1000, quiet=False):
+def main(steps=200, forward_iters=1000, quiet=False, hipgraph=False):
     x_np, edge_index, y_np, train_index, valid_index, test_index = cora_shaped()
     num_classes = int(y_np.max()) + 1
     x = tfg._lib.as_f32(x_np)
@@ -72,7 +72,7 @@ def main(steps=200, forward_iters=1000, quiet=False):
     model([x, edge_index, edge_weight], cache=cache)                 # builds weights + plan + normalised adjacency
     model.gcn0.trainable(True)
     model.gcn1.trainable(True)
-    optimizer = torch.optim.Adam(model.parameters(), lr=1e-2)
+    optimizer = torch.optim.Adam(model.parameters(), lr=1e-2, capturable=hipgraph)
     tr, te = torch.as_tensor(train_index, device=x.device), torch.as_tensor(test_index, device=x.device)
 
     def evaluate():
@@ -80,18 +80,37 @@ def main(steps=200, forward_iters=1000, quiet=False):
             logits = model([x, edge_index, edge_weight], cache=cache)
         return float((logits[te].argmax(-1) == y[te]).float().mean())
 
-    acc = evaluate()
-    for step in range(1, steps + 1):
-        optimizer.zero_grad()
+    y_tr = y[tr]
+
+    def compute_loss():
         logits = model([x, edge_index, edge_weight], training=True, cache=cache)
-        loss = torch.nn.functional.cross_entropy(logits[tr], y[tr])
-        loss = loss + 5e-4 * sum(0.5 * (p ** 2).sum() for p in (model.gcn0.kernel, model.gcn1.kernel))
+        loss = torch.nn.functional.cross_entropy(logits[tr], y_tr)
+        return loss + 5e-4 * sum(0.5 * (p ** 2).sum() for p in (model.gcn0.kernel, model.gcn1.kernel))
+
+    def eager_step():
+        optimizer.zero_grad()
+        loss = compute_loss()
         loss.backward()
         optimizer.step()
+        return loss
+
+    # --hipgraph: the whole step (zero-grad, dropout, forward, loss, backward, Adam) replayed from ONE hipGraph — what
+    # tf.function buys the reference's training forward (demo/demo_gcn.py:64-66, "10X faster" :107-109); at this size a
+    # step is ~50 launches of a few microseconds each, i.e. pure launch cost
+    train_step = tfg.CapturedTrainStep(compute_loss, optimizer) if hipgraph else eager_step
+    acc = evaluate()
+    torch.cuda.synchronize()
+    t_train = time.time()
+    for step in range(1, steps + 1):
+        loss = train_step()
         if step % 20 == 0:
             acc = evaluate()
             if not quiet:
                 print("step = {}\tloss = {:.4f}\taccuracy = {:.4f}".format(step, float(loss.detach()), acc))
+    torch.cuda.synchronize()
+    if not quiet and steps:
+        print("mean training step time ({}): {:.6f} seconds".format("hipGraph replay" if hipgraph else "eager",
+                                                                    (time.time() - t_train) / steps))
     mean_forward = None
     if forward_iters:
         with torch.no_grad():
@@ -109,5 +128,6 @@ def main(steps=200, forward_iters=1000, quiet=False):
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--hipgraph", action="store_true", help="replay the whole training step from one hipGraph")
     args = ap.parse_args()
-    main(steps=args.steps)
+    main(steps=args.steps, hipgraph=args.hipgraph)

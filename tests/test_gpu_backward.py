@@ -396,6 +396,8 @@ def test_demo_gcn_trains_on_cora_shaped_graph(tfg):
     import demo_gcn
     acc, _ = demo_gcn.main(steps=60, forward_iters=0, quiet=True)
     assert acc > 0.5, acc
+    acc, _ = demo_gcn.main(steps=60, forward_iters=0, quiet=True, hipgraph=True)     # the whole step (dropout included) replayed
+    assert acc > 0.5, acc
 
 
 def test_demo_gat_trains_with_attention_dropout(tfg):

@@ -166,3 +166,80 @@ def test_gcn_layer_validates_num_splits_at_build_time(tfg, oracle):
     nk = tfg.layers.GCN(9, use_kernel=False, num_splits=5)  # no kernel: the split applies to the F = 10 input columns
     nk._maybe_build([x])
     assert nk.num_or_size_splits == 5
+
+
+def _two_layer(tfg, kind, units, classes):
+    if kind == "gcn":
+        return tfg.layers.GCN(units, activation=tfg.relu), tfg.layers.GCN(classes)
+    if kind == "mean_sage":
+        return tfg.layers.MeanGraphSage(units, activation=tfg.relu), tfg.layers.MeanGraphSage(classes, activation=None)
+    if kind == "max_pool_sage":
+        return tfg.layers.MaxPoolGraphSage(units, activation=tfg.relu), tfg.layers.MaxPoolGraphSage(classes, activation=None)
+    return (tfg.layers.GAT(units, attention_units=8, num_heads=4, activation=tfg.relu),
+            tfg.layers.GAT(classes, attention_units=4, num_heads=1))
+
+
+@pytest.mark.parametrize("kind,opt_name", [("gcn", "adam"), ("gcn", "sgd"), ("mean_sage", "adam"), ("max_pool_sage", "adam"),
+                                           ("gat", "adam")])
+def test_captured_train_step_equals_the_eager_loop(tfg, oracle, kind, opt_name):
+    """tfg.CapturedTrainStep: zero-grad + forward + loss + backward (the kernels' own backward) + optimizer update replayed
+    from ONE hipGraph.  Step k of the replay must leave the weights where step k of the eager loop leaves them — including
+    the constructor's warm-up steps being rolled back (parameters and optimizer state).  The role tf.function plays around
+    the reference's training forward (demo/demo_gcn.py:64-83)."""
+    n, e, f, units, classes = 3000, 24000, 32, 16, 8
+    x_np, ei, rng = _graph(oracle, n, e, f, seed=11)
+    x = tfg._lib.as_f32(x_np)
+    w = np.ones(ei.shape[1], np.float32)
+    labels = torch.as_tensor(rng.integers(0, classes, n), device=x.device)
+    idx = torch.arange(0, n, 3, device=x.device)
+
+    def make():
+        cache = {}
+        l0, l1 = _two_layer(tfg, kind, units, classes)
+        inputs = (lambda h: [h, ei]) if kind in ("gcn", "gat") else (lambda h: [h, ei, w])
+        with torch.no_grad():
+            l1(inputs(l0(inputs(x), cache=cache)), cache=cache)
+        l0.trainable(True)
+        l1.trainable(True)
+        return l0, l1, (lambda: torch.nn.functional.cross_entropy(l1(inputs(l0(inputs(x), cache=cache)), cache=cache)[idx],
+                                                                 labels[idx]))
+
+    a0, a1, loss_a = make()
+    b0, b1, loss_b = make()
+    for la, lb in ((a0, b0), (a1, b1)):
+        lb.set_weights(**{k: v.detach() for k, v in la.weights.items() if v is not None})
+        lb.trainable(True)
+
+    def optimizer(layers):
+        ps = layers[0].parameters() + layers[1].parameters()
+        if opt_name == "adam":
+            return torch.optim.Adam(ps, lr=1e-2, capturable=True)
+        return torch.optim.SGD(ps, lr=5e-2, momentum=0.9)
+
+    opt_a, opt_b = optimizer((a0, a1)), optimizer((b0, b1))
+    losses_a = []
+    for _ in range(6):
+        opt_a.zero_grad(set_to_none=True)
+        la = loss_a()
+        la.backward()
+        opt_a.step()
+        losses_a.append(float(la.detach()))
+    before = [p.detach().clone() for p in b0.parameters() + b1.parameters()]
+    step = tfg.CapturedTrainStep(loss_b, opt_b)
+    for p, q in zip(b0.parameters() + b1.parameters(), before):       # the warm-up left no trace
+        assert torch.equal(p.detach(), q)
+    losses_b = [float(step().detach()) for _ in range(6)]
+    assert losses_a[-1] < losses_a[0]                                  # it trains
+    np.testing.assert_allclose(losses_b, losses_a, rtol=2e-5, atol=1e-6)
+    for p, q in zip(a0.parameters() + a1.parameters(), b0.parameters() + b1.parameters()):
+        assert_parity(q.detach().cpu().numpy(), p.detach().cpu().numpy(), tol=2e-5, what="{} weights after 6 steps".format(kind))
+
+
+def test_captured_train_step_needs_a_capturable_optimizer(tfg, oracle):
+    x_np, ei, rng = _graph(oracle, 200, 1500, 8, seed=3)
+    layer = tfg.layers.GCN(4)
+    x = tfg._lib.as_f32(x_np)
+    layer([x, ei])
+    layer.trainable(True)
+    with pytest.raises(ValueError, match="capturable"):
+        tfg.CapturedTrainStep(lambda: layer([x, ei]).sum(), torch.optim.Adam(layer.parameters(), lr=1e-2))

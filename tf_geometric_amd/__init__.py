@@ -16,6 +16,6 @@ from . import nn
 from . import layers
 from . import dist
 from . import utils
-from .graph_capture import CapturedForward
+from .graph_capture import CapturedForward, CapturedTrainStep
 
 __version__ = "0.1.0"

@@ -848,20 +848,54 @@ inline bool tn_use_direct()
     return v != 0;
 }
 
-// dW[i, n_first + n] = sum over workgroups (in order) of parts[b][i][n]; row Ka -> db
-__global__ void tn_reduce_kernel(const float* __restrict__ parts, int n_parts, int64_t part_stride, int Ka, int ng_cols,
+// dW[i, n_first + n] = sum over workgroups of parts[b][i][n]; row Ka -> db.  64 consecutive output elements per workgroup
+// (one coalesced 256-byte read per part), the parts cut into kTnSlices contiguous ranges summed by different waves with 8
+// loads in flight each, the slice sums folded in slice order through LDS: a fixed order (bit-reproducible), and enough
+// parallelism that the 512 x (Ka + 1) x N floats stream at HBM/MALL rate (one thread per output element walking all
+// 512 parts — the first version — took 118 us for 129 x 256 outputs, as long as the arxiv-shape reduction itself).
+constexpr int kTnSlices = 8;
+__global__ __launch_bounds__(64 * kTnSlices) void tn_reduce_kernel(const float* __restrict__ parts, int n_parts,
+                                 int64_t part_stride, int Ka, int ng_cols,
                                  int n_first, int want_bias, float* __restrict__ dW, int64_t ldw, float* __restrict__ db)
 {
+    __shared__ float part_sum[kTnSlices][64];
     const int rows = Ka + (want_bias ? 1 : 0);
-    int64_t t = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
-    const int64_t total = int64_t(rows) * ng_cols, stride = int64_t(gridDim.x) * blockDim.x;
-    for (; t < total; t += stride) {
-        const int i = int(t / ng_cols), n = int(t % ng_cols);
+    const int64_t total = int64_t(rows) * ng_cols;
+    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int per = (n_parts + kTnSlices - 1) / kTnSlices;
+    const int b0 = min(slice * per, n_parts), b1 = min(b0 + per, n_parts);
+    for (int64_t base = int64_t(blockIdx.x) * 64; base < total; base += int64_t(gridDim.x) * 64) {
+        const int64_t t = base + lane;
+        const int64_t tc = t < total ? t : total - 1;          // clamped: loads stay unconditional
+        const float* p = parts + tc;
         float acc = 0.0f;
-        for (int b = 0; b < n_parts; ++b) acc += parts[int64_t(b) * part_stride + t];
-        if (i < Ka) dW[int64_t(i) * ldw + n_first + n] = acc;
-        else db[n_first + n] = acc;
+        int b = b0;
+        for (; b + 8 <= b1; b += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[int64_t(b + u) * part_stride];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+        for (; b < b1; ++b) acc += p[int64_t(b) * part_stride];
+        part_sum[slice][lane] = acc;
+        __syncthreads();
+        if (slice == 0 && t < total) {
+            float sum = part_sum[0][lane];
+#pragma unroll
+            for (int q = 1; q < kTnSlices; ++q) sum += part_sum[q][lane];
+            const int i = int(t / ng_cols), n = int(t % ng_cols);
+            if (i < Ka) dW[int64_t(i) * ldw + n_first + n] = sum;
+            else db[n_first + n] = sum;
+        }
+        __syncthreads();
     }
+}
+
+inline unsigned tn_reduce_grid(int64_t total)
+{
+    const int64_t g = (total + 63) / 64;
+    return unsigned(g < 1 ? 1 : (g > 8192 ? 8192 : g));
 }
 
 #ifndef TFGX_TN_WGS
@@ -1191,7 +1225,7 @@ extern "C" int tfgx_gemm_tn_gated_f32(const float* X, int64_t ldx, const float* 
         }
 #undef TFGX_TND
         TFGX_LAUNCH_CHECK("gemm_tn_direct_kernel");
-        tn_reduce_kernel<<<grid_for(part_stride, 256), 256, 0, stream>>>(parts, d.wgs, part_stride, int(Ka), int(N), 0,
+        tn_reduce_kernel<<<tn_reduce_grid(part_stride), 64 * kTnSlices, 0, stream>>>(parts, d.wgs, part_stride, int(Ka), int(N), 0,
                                                                         want_bias ? 1 : 0, dW, ldw, db);
         TFGX_LAUNCH_CHECK("tn_reduce_kernel");
         return TFGX_OK;
@@ -1229,7 +1263,7 @@ extern "C" int tfgx_gemm_tn_gated_f32(const float* X, int64_t ldx, const float* 
         else TFGX_TN(8)
 #undef TFGX_TN
         TFGX_LAUNCH_CHECK("gemm_tn_kernel");
-        tn_reduce_kernel<<<grid_for(part_stride, 256), 256, 0, stream>>>(parts, c.wgs, part_stride, int(Ka), ng_cols,
+        tn_reduce_kernel<<<tn_reduce_grid(part_stride), 64 * kTnSlices, 0, stream>>>(parts, c.wgs, part_stride, int(Ka), ng_cols,
                                                                         n_first, want_bias ? 1 : 0, dW, ldw, db);
         TFGX_LAUNCH_CHECK("tn_reduce_kernel");
     }

@@ -40,3 +40,67 @@ class CapturedForward(object):
                 dst.copy_(L.as_f32(src), non_blocking=True)
         self.graph.replay()
         return self.static_output
+
+
+class CapturedTrainStep(object):
+    """One whole training step — zero the gradients, forward, loss, backward through the kernels' own backward
+    (tf_geometric_amd.autograd), optimizer update — captured once into a hipGraph and replayed.
+
+    The reference wraps its forward in tf.function and runs the tape / optimizer around it (demo/demo_gcn.py:64-83); on
+    small graphs a step is launch-bound there and here alike (a 2-layer GCN step at ogbn-arxiv shape is ≈ 40 launches of
+    5-150 us each, issued by Python + autograd).  Every launch of the step sits on the current HIP stream with
+    allocator-owned buffers, so the step is a fixed launch sequence and the replay issues it in one call.
+
+        opt = torch.optim.Adam(params, lr=1e-2, capturable=True)        # the step counter must live on the device
+        step = tfg.CapturedTrainStep(lambda: loss_of(model([x, ei, w], training=True, cache=cache)), opt)
+        for _ in range(epochs):
+            loss = step()               # a device scalar; reading it (float(loss)) is the only synchronisation
+
+    loss_fn() must read its data from tensors that keep their addresses (x, labels, index tensors), over plans that are
+    already cached (run the model once eagerly first).  The warm-up steps this constructor needs (they size the allocator
+    pools, build lazily-built plan metadata and create the optimizer state) are rolled back: parameters and optimizer
+    state are what they were before the constructor ran, so step k of the replay equals step k of the eager loop.
+    """
+
+    def __init__(self, loss_fn, optimizer, warmup=3):
+        L.require_gpu()
+        for g in optimizer.param_groups:
+            if "capturable" in g and not g["capturable"]:
+                raise ValueError("CapturedTrainStep: construct the optimizer with capturable=True (its step counter has "
+                                 "to be a device tensor to be advanced by a replay)")
+        self.optimizer = optimizer
+        params = [p for g in optimizer.param_groups for p in g["params"]]
+        saved_p = [p.detach().clone() for p in params]
+        saved_s = {id(p): {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in st.items()}
+                   for p, st in optimizer.state.items()}
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(int(warmup), 1)):
+                optimizer.zero_grad(set_to_none=True)
+                loss_fn().backward()
+                optimizer.step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        with torch.no_grad():                       # roll the warm-up back, in place (addresses are what gets captured)
+            for p, s in zip(params, saved_p):
+                p.copy_(s)
+            for p, st in optimizer.state.items():
+                before = saved_s.get(id(p), {})
+                for k, v in st.items():
+                    if isinstance(v, torch.Tensor):
+                        if isinstance(before.get(k), torch.Tensor):
+                            v.copy_(before[k])
+                        else:
+                            v.zero_()               # state the warm-up created: Adam's moments / step, SGD's momentum
+        optimizer.zero_grad(set_to_none=True)       # gradients are (re)allocated inside the capture, from the graph's pool
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = loss_fn()
+            self.loss.backward()
+            optimizer.step()
+
+    def __call__(self):
+        self.graph.replay()
+        return self.loss

@@ -9,7 +9,7 @@ import tf_geometric_amd as tfg
 from tf_geometric_amd import synthetic, _lib as L
 
 which = sys.argv[1] if len(sys.argv) > 1 else "gcn"
-n, e, f = synthetic.WORKLOADS["products"]
+n, e, f = synthetic.WORKLOADS[sys.argv[2] if len(sys.argv) > 2 else "products"]
 ei = L.as_i32(synthetic.synthetic_edges(n, e, seed=0))
 x = torch.randn(n, f, device="cuda")
 w1 = torch.ones(int(ei.shape[1]), device="cuda")
