@@ -693,6 +693,153 @@ for _name in MODEL_SHAPES:
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# The other two demo MODELS, end to end through the reference's own layer classes:
+#   * demo/demo_gat.py:18-42 — GAT(64, relu, num_heads=8, attention_units=8) -> GAT(classes, num_heads=1, attention_units=1)
+#     at Cora shape (dropout / edge dropout: identity at inference);
+#   * demo/demo_graph_sage.py:22-60 — MeanGraphSage(256, relu, concat) x 2 over two SAMPLED neighbourhoods (25 / 10 incoming
+#     edges per node, as RandomNeighborSampler.sample(k) hands them over: an edge list plus per-edge weights) -> Dense, at a
+#     PPI-like shape (50 features, 121 labels).  The sampled lists are inputs of the case (drawn once, seeded): the sampler
+#     itself is random by contract and has its own distributional test.
+# ---------------------------------------------------------------------------------------------------------------------
+def _gat_model_inputs():
+    rng = np.random.Generator(np.random.PCG64(311))
+    n, f, classes = 2708, 1433, 7
+    ei = directed_pairs(rng, n, 10556)
+    x = (rng.random((n, f)) < 0.012).astype(np.float32)
+    x = x / np.maximum(x.sum(1, keepdims=True), 1.0)
+    return dict(n=n, f=f, x=x, ei=ei, classes=classes,
+                w0=dict(query_kernel=glorot(rng, f, 8), query_bias=small_bias(rng, 8), key_kernel=glorot(rng, f, 8),
+                        key_bias=small_bias(rng, 8), kernel=glorot(rng, f, 64), bias=small_bias(rng, 64)),
+                w1=dict(query_kernel=glorot(rng, 64, 1), query_bias=small_bias(rng, 1), key_kernel=glorot(rng, 64, 1),
+                        key_bias=small_bias(rng, 1), kernel=glorot(rng, 64, classes), bias=small_bias(rng, classes)))
+
+
+def _gat_model_ref(R, g):
+    tf, tfg = R.tf, R.tfg
+
+    class GATModel(tf.keras.Model):                   # demo/demo_gat.py:18-42, verbatim structure
+
+        def __init__(self, *args, **kwargs):
+            super().__init__(*args, **kwargs)
+            self.gat0 = tfg.layers.GAT(64, activation=tf.nn.relu, num_heads=8, attention_units=8, edge_drop_rate=0.6)
+            self.gat1 = tfg.layers.GAT(g["classes"], num_heads=1, attention_units=1, edge_drop_rate=0.6)
+            self.dropout = tf.keras.layers.Dropout(0.6)
+
+        def call(self, inputs, training=None, mask=None, cache=None):
+            x, edge_index = inputs
+            h = self.dropout(x, training=training)
+            h = self.gat0([h, edge_index], training=training)
+            self.hidden = h
+            h = self.dropout(h, training=training)
+            h = self.gat1([h, edge_index], training=training)
+            return h
+
+    model = GATModel()
+    model([g["x"], g["ei"]])
+    for layer, ws in ((model.gat0, g["w0"]), (model.gat1, g["w1"])):
+        for k, v in ws.items():
+            getattr(layer, k).assign(v)
+    logits = model([g["x"], g["ei"]], training=False)
+    return {"hidden": _np(model.hidden), "logits": _np(logits)}
+
+
+def _gat_model_orc(o, g):
+    a, b = g["w0"], g["w1"]
+    h = o.gat(g["x"], g["ei"], a["query_kernel"], a["query_bias"], "relu", a["key_kernel"], a["key_bias"], "relu",
+              a["kernel"], a["bias"], "relu", num_heads=8)
+    out = o.gat(h, g["ei"], b["query_kernel"], b["query_bias"], "relu", b["key_kernel"], b["key_bias"], "relu",
+                b["kernel"], b["bias"], None, num_heads=1)
+    return {"hidden": h, "logits": out}
+
+
+def _gat_model_hip(T, g):
+    gat0 = T.layers.GAT(64, activation=T.relu, num_heads=8, attention_units=8, edge_drop_rate=0.6)
+    gat1 = T.layers.GAT(g["classes"], num_heads=1, attention_units=1, edge_drop_rate=0.6)
+    x = T._lib.as_f32(g["x"])
+    gat0._maybe_build([x])
+    gat0.set_weights(**g["w0"])
+    h = gat0([x, g["ei"]], training=False)
+    gat1._maybe_build([h])
+    gat1.set_weights(**g["w1"])
+    return {"hidden": _np(h), "logits": _np(gat1([h, g["ei"]], training=False))}
+
+
+_add("model_gat_cora", _gat_model_inputs, _gat_model_ref, _gat_model_orc, _gat_model_hip,
+     note="the 2-layer GAT model of demo/demo_gat.py at Cora shape (8 heads x 8 attention units, then the d_head = 1 output layer)")
+
+
+def _sampled_in_edges(rng, ei, n, k):
+    """At most k incoming edges per destination, drawn without replacement, each weighted 1 / (number kept) — the shape of
+    what RandomNeighborSampler.sample(k) returns (utils/graph_utils.py: sampled edge_index + edge_weight)."""
+    order = np.argsort(ei[0], kind="stable")
+    row, col = ei[0][order], ei[1][order]
+    starts = np.searchsorted(row, np.arange(n + 1))
+    keep_r, keep_c, keep_w = [], [], []
+    for r in range(n):
+        nb = col[starts[r]:starts[r + 1]]
+        if nb.size > k:
+            nb = rng.permutation(nb)[:k]
+        if nb.size:
+            keep_r.append(np.full(nb.size, r, np.int32))
+            keep_c.append(nb.astype(np.int32))
+            keep_w.append(np.full(nb.size, 1.0 / nb.size, np.float32))
+    return np.stack([np.concatenate(keep_r), np.concatenate(keep_c)]), np.concatenate(keep_w)
+
+
+def _sage_model_inputs():
+    rng = np.random.Generator(np.random.PCG64(312))
+    n, f, units, classes = 1500, 50, 256, 121
+    ei = directed_pairs(rng, n, 45000)
+    x = rng.standard_normal((n, f), dtype=np.float32)
+    e25, w25 = _sampled_in_edges(rng, ei, n, 25)
+    e10, w10 = _sampled_in_edges(rng, ei, n, 10)
+    return dict(n=n, f=f, x=x, units=units, classes=classes, e25=e25, w25=w25, e10=e10, w10=w10,
+                s0=dict(self_kernel=glorot(rng, f, units // 2), neighbor_kernel=glorot(rng, f, units // 2),
+                        bias=small_bias(rng, units)),
+                s1=dict(self_kernel=glorot(rng, units, units // 2), neighbor_kernel=glorot(rng, units, units // 2),
+                        bias=small_bias(rng, units)),
+                dk=glorot(rng, units, classes), db=small_bias(rng, classes))
+
+
+def _sage_model_ref(R, g):
+    tf, tfg = R.tf, R.tfg
+    sages = [tfg.layers.MeanGraphSage(units=g["units"], activation=tf.nn.relu, concat=True),       # demo_graph_sage.py:29-30
+             tfg.layers.MeanGraphSage(units=g["units"], activation=tf.nn.relu, concat=True)]
+    lists = [(g["e25"], g["w25"]), (g["e10"], g["w10"])]                                            # :47, :53-55
+    for run in range(2):
+        h = g["x"]
+        for sage, (e_s, w_s), ws in zip(sages, lists, (g["s0"], g["s1"])):
+            if run == 1:
+                for k, v in ws.items():
+                    getattr(sage, k).assign(v)
+            h = sage([h, e_s, w_s], training=False)
+    logits = _np(h) @ g["dk"] + g["db"]              # tf.keras.layers.Dense(num_classes), :44 — a plain affine map
+    return {"hidden": _np(h), "logits": logits.astype(np.float32)}
+
+
+def _sage_model_orc(o, g):
+    h = g["x"]
+    for (e_s, w_s), ws in zip([(g["e25"], g["w25"]), (g["e10"], g["w10"])], (g["s0"], g["s1"])):
+        h = o.mean_graph_sage(h, e_s, w_s, ws["self_kernel"], ws["neighbor_kernel"], ws["bias"], "relu", concat=True)
+    return {"hidden": h, "logits": (h.astype(np.float64) @ g["dk"] + g["db"]).astype(np.float32)}
+
+
+def _sage_model_hip(T, g):
+    h = T._lib.as_f32(g["x"])
+    for (e_s, w_s), ws in zip([(g["e25"], g["w25"]), (g["e10"], g["w10"])], (g["s0"], g["s1"])):
+        sage = T.layers.MeanGraphSage(units=g["units"], activation=T.relu, concat=True)
+        sage._maybe_build([h])
+        sage.set_weights(**ws)
+        h = sage([h, e_s, w_s], training=False)
+    from tf_geometric_amd.plan import gemm_bias_act
+    return {"hidden": _np(h), "logits": _np(gemm_bias_act(h, T._lib.as_f32(g["dk"]), bias=T._lib.as_f32(g["db"])))}
+
+
+_add("model_sage_sampled", _sage_model_inputs, _sage_model_ref, _sage_model_orc, _sage_model_hip,
+     note="the sampled 2-layer MeanGraphSage model of demo/demo_graph_sage.py (25 / 10 sampled in-edges, weights 1 / kept)")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # (f3) edge preprocessing — utils/graph_utils.py:14-212, 252-269 — index work, bit-exact
 # ---------------------------------------------------------------------------------------------------------------------
 def _edge_inputs():
