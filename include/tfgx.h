@@ -139,9 +139,16 @@ typedef struct tfgx_reduce_args {
        relative to its row's first position; 0xFFFF for an empty row) — what TensorFlow's unsorted_segment_max gradient
        needs (it divides by the tie count, math_grad._UnsortedSegmentMinOrMaxGrad), produced by the tuned forward walk in
        the same pass.  Rows must hold fewer than 65536 edges (longer rows are hub rows: hub_threshold must be 0 here);
-       16-byte aligned rows of F <= 256 columns, F % 4 == 0; no accumulate / self_coef / split rows. */
+       16-byte aligned rows of F <= 256 columns, F % 4 == 0; no self_coef / bias / activation / split rows.
+       With accumulate = 1 the launch MERGES into the (out, track) stored by earlier launches over earlier sub-spans of the
+       same rows (a larger maximum replaces count and position, an equal one adds its tie count and keeps the earlier
+       position): a row reduced span by span — the sharded path's own-source pass, then one pass per halo round — ends
+       with the same (out, track) as one launch over the whole row.  track_row_begin (optional, same stride as
+       row_begin): positions are stored relative to track_row_begin[row * rp_stride] (the first position of the WHOLE
+       row) instead of this launch's row_begin. */
     uint32_t* track;
     int64_t ld_track;
+    const int32_t* track_row_begin;
 } tfgx_reduce_args;
 
 int tfgx_segment_reduce_f32(const tfgx_reduce_args* args /* host */, tfgx_stream_t stream);

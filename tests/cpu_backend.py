@@ -99,17 +99,23 @@ class NumpyBackend(object):
         deg = (sg.row_ptr[1:] - sg.row_ptr[:-1]).long()
         return torch.repeat_interleave(torch.arange(sg.n_own), deg)
 
-    def aggregate_autograd(self, sg, table, op, w):
+    def aggregate_autograd(self, sg, table, op, w, handles=None):
         """max over the shard's edges in plain torch (scatter_reduce amax: tied maxima share the gradient evenly, as
         tf.math.unsorted_segment_max's gradient does)."""
         assert op == 2
+        if handles is not None:          # (the HIP backend runs the own-source span under the exchange; here: wait first)
+            with torch.no_grad():
+                sg.exchange_finish(handles)
         rows, col = self._rows_of(sg), sg.col.long()
         msg = table[col] if w is None else table[col] * w.unsqueeze(1)
         out = torch.full((sg.n_own, table.shape[1]), FLT_LOWEST, dtype=table.dtype)
         return out.scatter_reduce(0, rows.unsqueeze(1).expand_as(msg), msg, reduce="amax", include_self=True)
 
-    def gat_attention_autograd(self, sg, Q, K, V, num_heads):
+    def gat_attention_autograd(self, sg, Q, K, V, num_heads, handles=None):
         """nn/conv/gat.py:40-122 over the shard's edges + the appended self-loop (source r = table row r), plain torch."""
+        if handles is not None:
+            with torch.no_grad():
+                sg.exchange_finish(handles)
         n, H = sg.n_own, num_heads
         rows = torch.cat([self._rows_of(sg), torch.arange(n)])
         col = torch.cat([sg.col.long(), torch.arange(n)])

@@ -52,8 +52,9 @@ def pool_weights():
     """(self_kernel, neighbor_mlp_kernel, neighbor_kernel, neighbor_mlp_bias, bias) of MaxPoolGraphSage(10, concat)."""
     from oracle import tfg_oracle as oracle
     rng = np.random.Generator(np.random.PCG64(79))
-    return (oracle.glorot_uniform(rng, 12, 5), oracle.glorot_uniform(rng, 12, 20), oracle.glorot_uniform(rng, 20, 5),
-            (rng.standard_normal(20) * 0.2).astype(np.float32), (rng.standard_normal(10) * 0.2).astype(np.float32))
+    # MLP width 32: wide enough for the tracked span-by-span max forward of the HIP backend (plan.can_track: F >= 32)
+    return (oracle.glorot_uniform(rng, 12, 5), oracle.glorot_uniform(rng, 12, 32), oracle.glorot_uniform(rng, 32, 5),
+            (rng.standard_normal(32) * 0.2).astype(np.float32), (rng.standard_normal(10) * 0.2).astype(np.float32))
 
 
 def run_checks(rank, world, use_gpu, skew, results, rounds=None, partitioned=False, hub_threshold=None, self_halo=False,
@@ -240,6 +241,13 @@ def run_training(rank, world, use_gpu, skew, rounds=None, num_splits=None, hub_t
     mx = sg.aggregate_trainable(x3, 2, w=None)
     (mx * be.f32(_loss_coef(n, x.shape[1])[sg.own_lo:sg.own_hi])).sum().backward()
     res["out_max"], res["dx_max"] = mx.detach().cpu().numpy(), x3.grad.cpu().numpy()
+    # the same max at 36 columns (x tiled three times): wide enough for the HIP backend's tracked span-by-span forward
+    # (own-source span under the exchange, one sub-span per round, merged in the kernel epilogue); every column block must
+    # reproduce the 12-column result
+    xw = be.f32(np.tile(x[sg.own_lo:sg.own_hi], (1, 3))).requires_grad_(True)
+    mw = sg.aggregate_trainable(xw, 2, w=None)
+    (mw * be.f32(np.tile(_loss_coef(n, x.shape[1])[sg.own_lo:sg.own_hi], (1, 3)))).sum().backward()
+    res["out_max_wide"], res["dx_max_wide"] = mw.detach().cpu().numpy(), xw.grad.cpu().numpy()
     gw = [be.f32(a).requires_grad_(True) for a in gat_train_weights()]
     x4 = be.f32(x[sg.own_lo:sg.own_hi]).requires_grad_(True)
     og = sg.gat_trainable(x4, gw[0], gw[1], 1, gw[2], gw[3], 1, gw[4], gw[5], torch.relu, GAT_HEADS)
@@ -272,6 +280,7 @@ def run_training(rank, world, use_gpu, skew, rounds=None, num_splits=None, hub_t
     res["static_sum"], res["static_sum_ref"] = a1.cpu().numpy(), sg.aggregate(t_ref, 0, w=sg.norm_w, self_coef=sg.self_coef).cpu().numpy()
     res["static_mean"], res["static_mean_ref"] = a2.cpu().numpy(), sg.neighbor_reduce(be.f32(x[sg.own_lo:sg.own_hi]), 1).cpu().numpy()
     res["static_exchanges"] = calls["n"]
+    res["counters"] = dict(getattr(sg, "counters", {}))
     if num_splits:
         chunked = sg.aggregate_chunked(be.f32(x[sg.own_lo:sg.own_hi]), num_splits, w=sg.norm_w, self_coef=sg.self_coef,
                                        bias=be.f32(np.arange(x.shape[1], dtype=np.float32) * 0.01), act=1)
@@ -369,6 +378,11 @@ def training_reference(skew):
 def check_training_extras(parts, ref, assert_parity):
     """max aggregation / GAT layer / max-pool SAGE layer of the sharded training path against the float64 reference."""
     parts = sorted(parts, key=lambda p: p["lo"])
+    if "out_max_wide" in parts[0]:
+        assert_parity(np.concatenate([p["out_max_wide"] for p in parts]), np.tile(ref["out_max"], (1, 3)), tol=2e-5,
+                      what="sharded trainable max forward, 36 columns")
+        assert_parity(np.concatenate([p["dx_max_wide"] for p in parts]), np.tile(ref["dx_max"], (1, 3)), tol=1e-4,
+                      what="sharded max d/dx, 36 columns")
     for key in ("max", "gat", "pool"):
         if "out_" + key not in ref:
             continue

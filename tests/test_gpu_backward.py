@@ -739,3 +739,51 @@ def test_tracked_max_forward_equals_the_arg_kernel(tfg, oracle, f, weighted):
                                                    L.ptr(arg0), f, L.ptr(pt.row_ptr), L.ptr(pt.col), L.ptr(w_t), L.ptr(t2d),
                                                    n, L.ptr(gx), f, L.ptr(ws), ws_bytes, L.stream_ptr()), "mask (two arrays)")
     assert torch.equal(xt.grad, gx)
+
+
+@pytest.mark.parametrize("f,weighted,k1", [(100, True, 3), (64, False, 2), (32, True, 4), (256, False, 3)])
+def test_tracked_max_span_by_span_equals_one_launch(tfg, oracle, f, weighted, k1):
+    """tfgx_reduce_args.track with accumulate = 1: a row reduced in k1 launches over consecutive sub-spans (what the sharded
+    path does: own-source edges under the halo exchange, then the sub-span of each round) ends with the SAME maxima and the
+    same packed (tie count, first position) as one launch over the whole row — ties inside and ACROSS sub-spans (quantised
+    features, duplicated edges), empty sub-spans, an empty row; and max_passes on the autograd function reproduces the
+    single-launch gradient bit for bit."""
+    from tf_geometric_amd import _lib as L
+    from tf_geometric_amd import autograd as AG
+    from tf_geometric_amd.plan import CsrPlan, segment_reduce
+    rng = np.random.Generator(np.random.PCG64(1000 + f))
+    n = 700
+    ei = oracle.synthetic_edges(n, 9000, seed=f + 1)
+    ei = ei[:, ei[0] != 5]
+    ei = np.concatenate([ei, ei[:, :3000]], axis=1)
+    x = np.round(rng.standard_normal((n, f)).astype(np.float32) * 2) / 2
+    plan = CsrPlan.build(L.as_i32(ei), n, n)
+    xd = L.as_f32(x)
+    w = (torch.randint(1, 3, (plan.num_edges,), device="cuda").float() * 0.5) if weighted else None
+    rp = plan.row_ptr.long()
+    deg = rp[1:] - rp[:-1]
+    cuts = torch.sort(torch.rand(n, k1 - 1, device="cuda"), dim=1).values        # random cut fractions per row
+    cuts[::7] = 0.0                                                             # some rows: empty leading sub-spans
+    cuts[3::11] = 1.0                                                           # ... or empty trailing ones
+    inner = rp[:-1].unsqueeze(1) + torch.floor(cuts * deg.unsqueeze(1).float()).long()
+    rpk = torch.cat([torch.cat([rp[:-1].unsqueeze(1), inner], 1).reshape(-1), rp[-1:]]).to(torch.int32).contiguous()
+    out1 = torch.empty((n, f), device="cuda")
+    pk1 = torch.empty((n, f), dtype=torch.int32, device="cuda")
+    segment_reduce(plan, xd, L.MAX, w_csr=w, out=out1, track=pk1)
+
+    def passes(x2, w2, out, packed):
+        for k in range(k1):
+            segment_reduce(plan, x2, L.MAX, w_csr=w2, out=out, track=packed, accumulate=k > 0, row_begin=rpk[k:],
+                           row_end=rpk[k + 1:], rp_stride=k1, col=plan.col, n_dst=n, track_row_begin=rpk)
+
+    out2 = torch.empty((n, f), device="cuda")
+    pk2 = torch.full((n, f), 12345, dtype=torch.int32, device="cuda")
+    passes(xd, w, out2, pk2)
+    assert torch.equal(out1, out2)
+    assert torch.equal(pk1, pk2), int((pk1 != pk2).sum())
+    assert int(((pk1.long() & 0xFFFFFFFF) >> 16).max()) >= 2
+    g = torch.randn(n, f, device="cuda")
+    xa, xb = xd.clone().requires_grad_(True), xd.clone().requires_grad_(True)
+    AG.aggregate(plan, xa, L.MAX, w_csr=w).backward(g)
+    AG.aggregate(plan, xb, L.MAX, w_csr=w, max_passes=passes).backward(g)
+    assert torch.equal(xa.grad, xb.grad)

@@ -55,18 +55,24 @@ def test_sharded_layers_through_the_c_abi_exchange_world1(tfg, partitioned):
     dist_worker.check_against_reference([p], True, assert_parity)
 
 
-def test_sharded_training_through_the_c_abi_exchange_world1(tfg):
+@pytest.mark.parametrize("skew", [True, False])
+def test_sharded_training_through_the_c_abi_exchange_world1(tfg, skew):
     """Reverse exchange (tfgx_halo_reverse_start overlapped with the own-row part of the transposed pass, then
     tfgx_halo_reverse_finish) and the column-chunked halo (two exchanges in flight) through the product transport."""
     import numpy as np
-    tr = dist_worker.run_training(0, 1, True, True, rounds=3, num_splits=4, self_halo=True)
-    ref = dist_worker.training_reference(True)
+    tr = dist_worker.run_training(0, 1, True, skew, rounds=3, num_splits=4, self_halo=True)
+    ref = dist_worker.training_reference(skew)
     assert_parity(tr["out"], ref["out"], what="trainable forward (tfgx_dist)")
     assert_parity(tr["dx"], ref["dx"], tol=2e-5, what="d/dx (tfgx_dist reverse exchange)")
     assert_parity(tr["dx_mean"], ref["dx_mean"], tol=2e-5, what="mean d/dx (tfgx_dist)")
     assert_parity(tr["dk"], ref["dk"], tol=1e-4, what="d/dkernel")
     dist_worker.check_training_extras([tr], ref, assert_parity)
     assert np.array_equal(tr["chunked"], tr["whole"])
+    # trainable max / max-pool SAGE / GAT: forwards ran span by span under the exchange (tracked max merged in the kernel
+    # epilogue, GAT states merged with the softmax statistics written for the backward)
+    # (the skewed graph has hub rows: those are chunked and do not track, so its max forward waits for the exchange)
+    assert tr["counters"].get("gat_span_training_forwards", 0) >= 1, tr["counters"]
+    assert skew or tr["counters"].get("max_span_forwards", 0) >= 2, tr["counters"]       # max at 36 columns + max-pool SAGE
 
 
 def test_tfgx_dist_world1_under_an_nccl_process_group(tfg):

@@ -42,7 +42,7 @@ class ReduceArgs(ctypes.Structure):
         ("x_tail", ctypes.c_void_p), ("ld_tail", ctypes.c_int64), ("f_main", ctypes.c_int64),
         ("edge_tail", ctypes.c_void_p), ("ld_edge_tail", ctypes.c_int64),
         ("row_order", ctypes.c_void_p),
-        ("track", ctypes.c_void_p), ("ld_track", ctypes.c_int64),
+        ("track", ctypes.c_void_p), ("ld_track", ctypes.c_int64), ("track_row_begin", ctypes.c_void_p),
     ]
 
 

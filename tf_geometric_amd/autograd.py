@@ -161,14 +161,22 @@ def _max_mode():
 
 class _AggregateMax(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, plan, x, w_csr):
+    def forward(ctx, plan, x, w_csr, passes=None):
+        """`passes` (the sharded path, dist/sharded.py::tracked_max_passes): callable(x2, w, out, packed) that runs the
+        tracked forward as several launches over consecutive sub-spans of every row (merged in the kernel epilogue) —
+        same (out, packed) as the single launch below, so the backward does not know the difference."""
         lib = L.require_gpu()
         x2, ldx = L.row_major_2d(x.detach())
         F = int(x2.shape[1])
         argpos = None
         wd = None if w_csr is None else w_csr.detach()
         packed = None
-        if _max_mode() == "mask" and can_track(plan, x2, ldx):
+        if passes is not None:
+            out = torch.empty((plan.n_dst, F), dtype=torch.float32, device=x2.device)
+            packed = torch.empty((plan.n_dst, F), dtype=torch.int32, device=x2.device)
+            passes(x2, wd, out, packed)
+            count = None
+        elif _max_mode() == "mask" and can_track(plan, x2, ldx):
             # the tuned forward walk (8 gathered rows in flight per lane group) with the tie count and the position of the
             # first maximal edge tracked online and written PACKED (one uint32 per element instead of a float count array
             # and an int32 position array): what the mask-form backward reads
@@ -271,16 +279,16 @@ class _AggregateMax(torch.autograd.Function):
             L.check(lib.tfgx_segment_max_backward_w_f32(L.ptr(plan.row_ptr), L.ptr(plan.col), L.ptr(w_csr.detach()),
                                                         plan.n_dst, L.ptr(x2), ldx, F, L.ptr(out), F, L.ptr(gn2), F,
                                                         L.ptr(gw), L.stream_ptr()), "tfgx_segment_max_backward_w_f32")
-        return None, gx, gw
+        return None, gx, gw, None
 
 
-def aggregate(plan, x, op, w_csr=None, self_coef=None, rows=None, bias=None, act=L.ACT_NONE):
+def aggregate(plan, x, op, w_csr=None, self_coef=None, rows=None, bias=None, act=L.ACT_NONE, max_passes=None):
     """Differentiable gather-scale-segment-reduce (sum / mean / max) on `plan`; sum / mean take the layer's bias and
     ReLU in the kernel epilogue (bias: a tensor that may require grad)."""
     if op == L.MAX:
         if self_coef is not None:
             raise NotImplementedError("max aggregation with an implicit self-loop is inference-only")
-        h = _AggregateMax.apply(plan, x, w_csr)
+        h = _AggregateMax.apply(plan, x, w_csr, max_passes)
         if bias is not None:
             h = h + bias
         return torch.relu(h) if act == L.ACT_RELU else h
@@ -428,11 +436,17 @@ def linear(x, kernel, bias=None, act=L.ACT_NONE, gathered=False):
 
 class _GatAttention(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, plan, num_heads, Q, K, V, drop_rate, drop_seed, scale_d=None):
+    def forward(ctx, plan, num_heads, Q, K, V, drop_rate, drop_seed, scale_d=None, passes=None):
+        """`passes` (the sharded path, dist/sharded.py::_gat_attention_spans): callable(Q, K, V, stats) -> out that runs the
+        forward as span passes + merge under a halo exchange; same (out, stats), so the backward is unchanged."""
         from .nn.conv.gat import gat_attention
         stats = torch.empty((plan.n_dst, 2 * num_heads), dtype=torch.float32, device=V.device)
-        out = gat_attention(plan, Q.detach(), K.detach(), V.detach(), num_heads, True, stats_ml=stats,
-                            drop_rate=drop_rate, drop_seed=drop_seed, scale_d=scale_d)
+        if passes is not None:
+            assert float(drop_rate) == 0.0 and scale_d is None
+            out = passes(Q.detach(), K.detach(), V.detach(), stats)
+        else:
+            out = gat_attention(plan, Q.detach(), K.detach(), V.detach(), num_heads, True, stats_ml=stats,
+                                drop_rate=drop_rate, drop_seed=drop_seed, scale_d=scale_d)
         ctx.plan, ctx.H, ctx.drop = plan, num_heads, (float(drop_rate), int(drop_seed))
         ctx.scale_d = scale_d
         ctx.save_for_backward(Q, K, V, out, stats)
@@ -495,14 +509,14 @@ class _GatAttention(torch.autograd.Function):
         sc_s = torch.empty(max(nc_s * (A + W), 1), dtype=torch.float32, device=dev) if hub_s is not None else None
         L.check(lib.tfgx_gat_backward_src_hub_f32(ctypes.byref(a), None if hub_s is None else ctypes.byref(hub_s),
                                                   L.ptr(sc_s), L.stream_ptr()), "tfgx_gat_backward_src_hub_f32")
-        return None, None, gq, gk, gv, None, None, None
+        return None, None, gq, gk, gv, None, None, None, None
 
 
-def gat_attention(plan, Q, K, V, num_heads, drop_rate=0.0, drop_seed=0, scale_d=None):
+def gat_attention(plan, Q, K, V, num_heads, drop_rate=0.0, drop_seed=0, scale_d=None, passes=None):
     """Differentiable fused attention (self-loop edge appended, as nn/conv/gat.py:43); drop_rate > 0 = training-time
     dropout of the attention weights (gat.py:85).  scale_d: the per-head width the scores are scaled by when Q / K
     arrive zero-padded per head (nn/conv/gat._kernel_widths)."""
-    return _GatAttention.apply(plan, num_heads, Q, K, V, float(drop_rate), int(drop_seed), scale_d)
+    return _GatAttention.apply(plan, num_heads, Q, K, V, float(drop_rate), int(drop_seed), scale_d, passes)
 
 
 def edge_attr_csr(plan, edge_attr, cache=None):

@@ -60,6 +60,7 @@ struct KArgs {
     const int32_t* row_order; // optional walk order: lane group i reduces row row_order[i] (skewed plans: degree order)
     uint32_t* track;          // TFGX_MAX training forward: (tie count << 16 | position of the first maximal edge in its row)
     int64_t ld_track;
+    const int32_t* track_row_begin;   // optional: positions are stored relative to track_row_begin[row * rp_stride]
     const float* edge_tail;  // optional with SPLIT: the tail columns of every edge's SOURCE row, in this plan's edge order
     int64_t ld_edge_tail;    // (streamed next to col / w instead of gathered: one line request fewer per edge)
 };
@@ -289,11 +290,15 @@ __device__ __forceinline__ void seg_reduce_row(const KArgs& a, int64_t r, int s,
 #pragma unroll
             for (int v = 0; v < VEC; ++v) res[v] = acc[k][v];
             float* op = a.out + r * a.ldo + coff[k];
+            float mine[TRACK ? VEC : 1], before[TRACK ? VEC : 1];      // TRACK + accumulate: this pass's maxima / the stored ones
             if (a.accumulate) {
                 float prev[VEC];
                 load_vec<VEC>(op, prev);
 #pragma unroll
-                for (int v = 0; v < VEC; ++v) res[v] = IS_MAX ? fmaxf(prev[v], res[v]) : prev[v] + res[v];
+                for (int v = 0; v < VEC; ++v) {
+                    if constexpr (TRACK) { mine[v] = res[v]; before[v] = prev[v]; }
+                    res[v] = IS_MAX ? fmaxf(prev[v], res[v]) : prev[v] + res[v];
+                }
             }
             if (a.self_coef) {
                 float xself[VEC];
@@ -325,13 +330,38 @@ __device__ __forceinline__ void seg_reduce_row(const KArgs& a, int64_t r, int s,
             for (int v = 0; v < VEC; ++v) res[v] = apply_act(res[v], a.act);
             store_vec<VEC>(op, res);
             if constexpr (TRACK) {
+                // positions are relative to the row's first position: of THIS launch's span, or — when the row is reduced in
+                // several launches over consecutive sub-spans (the sharded path: own-source edges, then one sub-span per
+                // halo round) — of the whole row (track_row_begin)
+                const int s_rel = a.track_row_begin ? a.track_row_begin[r * a.rp_stride] : s;
                 uint32_t pk[VEC];
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) {
                     const uint32_t c = uint32_t(tcnt[k][v] < 65535 ? tcnt[k][v] : 65535);
-                    pk[v] = (c << 16) | (tpos[k][v] < 0 ? 0xFFFFu : uint32_t(tpos[k][v] - s) & 0xFFFFu);
+                    pk[v] = (c << 16) | (tpos[k][v] < 0 ? 0xFFFFu : uint32_t(tpos[k][v] - s_rel) & 0xFFFFu);
                 }
                 uint32_t* tp = a.track + r * a.ld_track + coff[k];
+                if (a.accumulate) {
+                    // merge with what earlier launches stored for this row: a larger maximum replaces (count, position), an
+                    // equal one adds its tie count and keeps the EARLIER position (sub-spans come in position order)
+                    uint32_t old[VEC];
+                    if constexpr (VEC == 4) {
+                        const uint4 o4 = *reinterpret_cast<const uint4*>(tp);
+                        old[0] = o4.x; old[1] = o4.y; old[2] = o4.z; old[3] = o4.w;
+                    } else {
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) old[v] = tp[v];
+                    }
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) {
+                        const uint32_t oc = old[v] >> 16, nc = pk[v] >> 16;
+                        const uint32_t sum = oc + nc < 65535u ? oc + nc : 65535u;
+                        const bool none_before = (old[v] & 0xFFFFu) == 0xFFFFu && oc == 0u;
+                        if (mine[v] > before[v] || none_before) { /* keep pk[v] */ }
+                        else if (mine[v] == before[v] && nc > 0u) pk[v] = (sum << 16) | (old[v] & 0xFFFFu);
+                        else pk[v] = old[v];
+                    }
+                }
                 if constexpr (VEC == 4) *reinterpret_cast<uint4*>(tp) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
                 else {
 #pragma unroll
@@ -560,10 +590,11 @@ extern "C" int tfgx_segment_reduce_f32(const tfgx_reduce_args* p, tfgx_stream_t 
     a.x_tail = p->x_tail; a.ld_tail = p->ld_tail; a.f_main = int32_t(p->f_main);
     a.edge_tail = p->edge_tail; a.ld_edge_tail = p->ld_edge_tail;
     a.row_order = p->row_order;
-    a.track = p->track; a.ld_track = p->ld_track;
+    a.track = p->track; a.ld_track = p->ld_track; a.track_row_begin = p->track_row_begin;
     if (p->track) {
-        TFGX_REQUIRE(p->op == TFGX_MAX && !p->accumulate && !p->self_coef && !p->x_tail && p->hub_threshold == 0,
-                     "track: plain TFGX_MAX launches only (no accumulate / self_coef / split rows / hub lists)");
+        TFGX_REQUIRE(p->op == TFGX_MAX && !p->self_coef && !p->x_tail && p->hub_threshold == 0 && !p->bias && !p->add_x &&
+                         p->act == TFGX_ACT_NONE,
+                     "track: plain TFGX_MAX launches only (no self_coef / bias / activation / split rows / hub lists)");
         TFGX_REQUIRE(p->ld_track >= p->F && p->ld_track % 4 == 0 && aligned_to(p->track, 16), "track: bad leading dimension / alignment");
     }
     TFGX_REQUIRE(p->edge_tail == nullptr ||
@@ -598,7 +629,7 @@ extern "C" int tfgx_segment_reduce_f32(const tfgx_reduce_args* p, tfgx_stream_t 
     c.n_dst = p->n_hub_chunks; c.out = p->hub_scratch; c.ldo = p->F;
     c.op = is_max ? TFGX_MAX : TFGX_SUM; c.act = TFGX_ACT_NONE; c.accumulate = 0;
     c.self_coef = nullptr; c.bias = nullptr; c.add_x = nullptr; c.mean_count = nullptr; c.hub_threshold = 0;
-    c.row_order = nullptr; c.track = nullptr;
+    c.row_order = nullptr; c.track = nullptr; c.track_row_begin = nullptr;
     const bool sok = (p->F % 4 == 0) && aligned_to(p->hub_scratch, 16) && (p->ldx % 4 == 0) && aligned_to(p->x, 16);
     const bool sok2 = (p->F % 2 == 0) && aligned_to(p->hub_scratch, 8) && (p->ldx % 2 == 0) && aligned_to(p->x, 8);
     rc = launch_any(c, sok ? 4 : (sok2 ? 2 : 1), is_max, weighted, stream);

@@ -114,17 +114,31 @@ class HipBackend(object):
         from .. import autograd as AG
         return AG.linear(x, kernel, bias, act)
 
-    def aggregate_autograd(self, sg, table, op, w):
+    def aggregate_autograd(self, sg, table, op, w, handles=None):
         """Differentiable reduce of w * table[col] over the shard's rows, table = [own | halo] (n_own x n_table
-        operator): the single-GPU autograd functions on the shard's rectangular plan."""
+        operator): the single-GPU autograd functions on the shard's rectangular plan.  `handles`: a halo exchange still
+        in flight for `table` (max only) — the forward then runs SPAN BY SPAN, own-source edges under the whole exchange
+        and the sub-span of round j as soon as round j has landed, merging maxima / tie counts / first positions in the
+        kernel epilogue (tfgx_reduce_args.track with accumulate); the backward is the single-GPU one either way."""
         from .. import autograd as AG
-        return AG.aggregate(sg.local_plan(), table, op, w_csr=w)
+        passes = sg.tracked_max_passes(table, handles) if (op == L.MAX and handles is not None) else None
+        if handles is not None and passes is None:
+            with torch.no_grad():
+                sg.exchange_finish(handles)
+        return AG.aggregate(sg.local_plan(), table, op, w_csr=w, max_passes=passes)
 
-    def gat_attention_autograd(self, sg, Q, K, V, num_heads):
+    def gat_attention_autograd(self, sg, Q, K, V, num_heads, handles=None):
         """Differentiable fused attention of own destinations over table sources (self-loop = table row r, own rows
-        come first in the table)."""
+        come first in the table).  `handles`: the exchange of the [K | V] table still in flight — the forward then runs as
+        the inference path does (own-source span under the exchange, halo span after it, states merged; the merge also
+        writes the softmax statistics the backward reads); the backward is the single-GPU one."""
         from .. import autograd as AG
-        return AG.gat_attention(sg.local_plan(), Q, K, V, num_heads)
+        passes = None
+        if handles is not None:
+            def passes(Qd, Kd, Vd, stats):
+                with torch.no_grad():
+                    return sg._gat_attention_spans(Qd, Kd, Vd, num_heads, handles, None, L.ACT_NONE, None, stats=stats)
+        return AG.gat_attention(sg.local_plan(), Q, K, V, num_heads, passes=passes)
 
     def hub_lists(self, row_begin, row_end, rp_stride, n_dst, num_edges):
         """Chunk lists for the long spans of one pass (skewed graphs), or None — see plan.hub_policy."""
@@ -145,7 +159,8 @@ class HipBackend(object):
         return sp.main, sp.tail, gather_rows(sp.tail, col)
 
     def segment_reduce(self, row_begin, row_end, rp_stride, col, w, n_dst, x, out, op, act=L.ACT_NONE,
-                       accumulate=False, self_coef=None, bias=None, mean_count=None, hub=None, split=None):
+                       accumulate=False, self_coef=None, bias=None, mean_count=None, hub=None, split=None, track=None,
+                       track_row_begin=None):
         F_total = int(x.shape[1])
         if split is not None:
             x = split[0]
@@ -167,6 +182,9 @@ class HipBackend(object):
         a.self_coef = 0 if self_coef is None else self_coef.data_ptr()
         a.bias = 0 if bias is None else bias.data_ptr()
         a.mean_count = 0 if mean_count is None else mean_count.data_ptr()
+        if track is not None:
+            a.track, a.ld_track = track.data_ptr(), int(track.stride(0))
+            a.track_row_begin = 0 if track_row_begin is None else track_row_begin.data_ptr()
         if hub is not None:
             thr, hub_rows, chunk_ptr, chunk_begin, chunk_end, _ = hub
             scratch = self.empty((int(chunk_begin.shape[0]), F_total))
@@ -210,18 +228,23 @@ class HipBackend(object):
             a.hub_chunk_row = part_row.data_ptr()
         L.check(self.lib.tfgx_gat_fused_f32(ctypes.byref(a), L.stream_ptr()), "tfgx_gat_fused_f32")
 
-    def gat_merge_parts(self, Q, K, V, num_heads, n_dst, state_acc, state_ml, part_ptr, part_idx, bias, act, out):
+    def gat_merge_parts(self, Q, K, V, num_heads, n_dst, state_acc, state_ml, part_ptr, part_idx, bias, act, out,
+                        stats=None):
         from ..nn.conv.gat import gat_args
         a, out, keep = gat_args(Q, K, V, num_heads, n_dst, self.empty(1, torch.int32), add_self_loop=True, bias=bias,
                                 act=act, out=out)
+        if stats is not None:          # final (m, l) per row and head: what the backward of the attention reads
+            a.stats_ml = stats.data_ptr()
         L.check(self.lib.tfgx_gat_merge_parts_f32(ctypes.byref(a), L.ptr(state_acc), L.ptr(state_ml), L.ptr(part_ptr),
                                                   L.ptr(part_idx), L.stream_ptr()), "tfgx_gat_merge_parts_f32")
         return out
 
-    def gat_merge(self, Q, K, V, num_heads, n_dst, state_acc, state_ml, n_passes, bias, act, out):
+    def gat_merge(self, Q, K, V, num_heads, n_dst, state_acc, state_ml, n_passes, bias, act, out, stats=None):
         from ..nn.conv.gat import gat_args
         a, out, keep = gat_args(Q, K, V, num_heads, n_dst, self.empty(1, torch.int32), add_self_loop=True, bias=bias,
                                 act=act, out=out)
+        if stats is not None:
+            a.stats_ml = stats.data_ptr()
         L.check(self.lib.tfgx_gat_merge_passes_f32(ctypes.byref(a), L.ptr(state_acc), L.ptr(state_ml), n_passes,
                                                    L.stream_ptr()), "tfgx_gat_merge_passes_f32")
         return out
@@ -287,6 +310,7 @@ class ShardedGraph(object):
         from .transport import get_transport
         be = self.backend = backend or HipBackend()
         self.group = group
+        self.counters = {}      # diagnostics: how often the span-by-span training forwards ran (tests assert on them)
         inited = group is not None or dist.is_initialized()
         self.world = dist.get_world_size(group) if inited else 1
         self.rank = dist.get_rank(group) if inited else 0
@@ -634,6 +658,31 @@ class ShardedGraph(object):
             with torch.no_grad():          # (the host-staged test transport copies into views made inside the Function)
                 self.exchange_finish(h)
 
+    def pop_deferred_exchange(self):
+        """The handle of the exchange halo_table(defer=True) started (the caller now owns the waits), or None."""
+        h = getattr(self, "_deferred_exchange", None)
+        self._deferred_exchange = None
+        return h
+
+    def tracked_max_passes(self, table, handles):
+        """The forward of a TRAINABLE max aggregation as one tracked launch per source class (plan.can_track conditions on
+        the table; no chunked long spans), or None when the shard / width does not allow it.  -> callable(x2, w, out, packed)."""
+        from ..plan import can_track
+        x2, ldx = L.row_major_2d(table)
+        if any(h is not None for h in self.hub) or not can_track(self.local_plan(), x2, ldx):
+            return None
+        be, K1, rpk = self.backend, self.n_class, self.rpk
+
+        def run(x2_, w_, out, packed):
+            self.counters["max_span_forwards"] = self.counters.get("max_span_forwards", 0) + 1
+            with torch.no_grad():
+                for k in range(K1):
+                    if k >= 1:
+                        self.exchange_finish(handles, k - 1)      # class k reads the rows of round k - 1
+                    be.segment_reduce(rpk[k:], rpk[k + 1:], K1, self.col, w_, self.n_own, x2_, out, L.MAX,
+                                      accumulate=k > 0, track=packed, track_row_begin=rpk)
+        return run
+
     def local_plan(self):
         """This shard as an [n_own x n_table] CSR operator (plan.CsrPlan over row_ptr / col — rows stay contiguous
         through the per-class partition), with the transposed plan available for the backward passes."""
@@ -690,7 +739,8 @@ class ShardedGraph(object):
         # max (the reducer of max_pool_graph_sage): differentiable halo table, then the single-GPU max aggregation with
         # its tie-sharing gradient on the shard's rectangular plan; halo-row gradients return through reverse_exchange
         w_t = self.w if (isinstance(w, str) and w == "plan") else w
-        return self.backend.aggregate_autograd(self, self.halo_table(h_own), op, w_t)
+        table = self.halo_table(h_own, defer=True)     # the rows start travelling; the own-source span runs under them
+        return self.backend.aggregate_autograd(self, table, op, w_t, handles=self.pop_deferred_exchange())
 
     def gat_trainable(self, x_own, query_kernel, query_bias, query_act, key_kernel, key_bias, key_act, kernel, bias=None,
                       activation=None, num_heads=1):
@@ -704,8 +754,8 @@ class ShardedGraph(object):
         V = be.linear(x_own, kernel)
         table = self.halo_table(torch.cat([K, V], 1), defer=True)      # [K | V] rows start travelling ...
         Q = be.linear(x_own, query_kernel, query_bias, query_act)      # ... while the row-local Q projection runs
-        self.halo_table_wait()
-        out = be.gat_attention_autograd(self, Q, table[:, :A], table[:, A:], num_heads)
+        out = be.gat_attention_autograd(self, Q, table[:, :A], table[:, A:], num_heads,      # ... and the own-source span
+                                        handles=self.pop_deferred_exchange())
         if bias is not None:
             out = out + bias
         return activation(out) if activation is not None else out
@@ -722,8 +772,8 @@ class ShardedGraph(object):
         else:
             table = self.halo_table(h, defer=True)                     # the MLP rows start travelling ...
             a = be.linear(x_own, self_kernel)                          # ... under the row-local self projection
-            self.halo_table_wait()
-            reduced = be.aggregate_autograd(self, table, op, None)
+            reduced = be.aggregate_autograd(self, table, op, None,     # ... and under the own-source span of the max
+                                            handles=self.pop_deferred_exchange())
         b = be.linear(reduced, neighbor_kernel)
         out = torch.cat([a, b], 1) if concat else a + b
         if bias is not None:
@@ -818,11 +868,21 @@ class ShardedGraph(object):
         be.gemm_bias_act(x_own, key_kernel, bias=key_bias, act=key_act, out=self.own_rows(table)[:, :A])
         be.gemm_bias_act(x_own, kernel, out=self.own_rows(table)[:, A:])
         handle = self.exchange_start(table)
-        K, V = table[:, :A], table[:, A:]
+        return self._gat_attention_spans(Q, table[:, :A], table[:, A:], num_heads, handle, bias, act, None)
+
+    def _gat_attention_spans(self, Q, K, V, num_heads, handle, bias, act, out, stats=None):
+        """The attention over this shard's rows as span passes + merge, `handle` = the exchange of the [K | V] table in
+        flight (the own-source span runs under it).  stats: [n_own, 2 H] receives the merged softmax statistics."""
+        be = self.backend
+        U = int(V.shape[1])
         K1, rpk = self.n_class, self.rpk
+        if stats is not None:
+            self.counters["gat_span_training_forwards"] = self.counters.get("gat_span_training_forwards", 0) + 1
         spans = [(rpk, rpk[1:])] + ([(rpk[1:], rpk[K1:])] if K1 > 1 else [])   # own-source span | all halo classes
         plan = self._gat_parts(spans)
-        out = be.empty((self.n_own, U))
+        kw = {} if stats is None else {"stats": stats}
+        if out is None:
+            out = be.empty((self.n_own, U))
         if plan is None:        # near-regular shard: two raw states per row, fixed-stride merge
             s_acc = be.empty((2 * self.n_own, U))
             s_ml = be.empty((2 * self.n_own, 2 * num_heads))
@@ -833,7 +893,7 @@ class ShardedGraph(object):
                 be.gat_pass(rpk[1:], rpk[K1:], K1, self.col, self.n_own, Q, K, V, num_heads, s_acc[self.n_own:],
                             s_ml[self.n_own:])
                 n_passes = 2
-            return be.gat_merge(Q, K, V, num_heads, self.n_own, s_acc, s_ml, n_passes, bias, act, out)
+            return be.gat_merge(Q, K, V, num_heads, self.n_own, s_acc, s_ml, n_passes, bias, act, out, **kw)
         # skewed shard: long spans of either pass are cut into chunks (as single-GPU hub rows are); every row then merges
         # a LIST of parts — whole passes and chunks — named by (part_ptr, part_idx)
         n_states = plan["n_states"]
@@ -854,7 +914,7 @@ class ShardedGraph(object):
         if len(spans) == 1:
             self.exchange_finish(handle)
         return be.gat_merge_parts(Q, K, V, num_heads, self.n_own, s_acc, s_ml, plan["part_ptr"], plan["part_idx"], bias,
-                                  act, out)
+                                  act, out, **kw)
 
     def _gat_parts(self, spans):
         """Part lists for the sharded GAT on a skewed shard, or None when no span of either pass is long.  State rows:

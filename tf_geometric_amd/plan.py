@@ -381,12 +381,13 @@ def edge_weight_csr(plan, edge_weight, cache=None):
 
 def segment_reduce(plan, x, op, w_csr=None, out=None, act=L.ACT_NONE, self_coef=None, bias=None, add_x=None,
                    accumulate=False, mean_count=None, row_begin=None, row_end=None, rp_stride=1, col=None,
-                   n_dst=None, describe=False, track=None):
+                   n_dst=None, describe=False, track=None, track_row_begin=None):
     """One launch of tfgx_segment_reduce_f32 on `plan` (or on explicit row_begin/row_end/col views of it).
     `x` is a dense [n_src, F] tensor or a SplitRows.  describe=True launches nothing and returns the kernel symbol the
     dispatcher picks for these arguments (tfgx_segment_reduce_describe).  `track` (TFGX_MAX, training forward): int32
     [n_dst, F] that receives tie count << 16 | row-relative position of the first maximal edge (tfgx_reduce_args.track;
-    see can_track)."""
+    see can_track); with accumulate=True the launch merges into the (out, track) earlier launches stored for earlier
+    sub-spans of the same rows (track_row_begin: the first position of the whole row)."""
     lib = L.require_gpu()
     split = x if isinstance(x, SplitRows) else None
     if split is not None:
@@ -437,6 +438,8 @@ def segment_reduce(plan, x, op, w_csr=None, out=None, act=L.ACT_NONE, self_coef=
             a.row_order = order.data_ptr()
     if track is not None:
         a.track, a.ld_track = track.data_ptr(), int(track.stride(0))
+        if track_row_begin is not None:      # positions relative to the WHOLE row when it is reduced span by span
+            a.track_row_begin = track_row_begin.data_ptr()
     hub = plan.hub_info() if (row_begin is None and row_end is None and col is None and track is None) else None
     if hub is not None:
         hub_rows, chunk_ptr, chunk_begin, chunk_end, _ = hub
