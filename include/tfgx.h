@@ -166,7 +166,9 @@ int tfgx_segment_reduce_describe(const tfgx_reduce_args* args /* host */, char* 
  * tiles go registers -> LDS -> v_mfma_f32_32x32x2_f32 against B resident in LDS, bias / activation in the epilogue.
  * Needs a plain CSR (row_begin = row_ptr, row_end = row_ptr + 1, rp_stride = 1), 16-byte aligned rows, F % 4 == 0,
  * F <= 128, N <= 256 and B + two tiles within 160 KB of LDS: tfgx_aggregate_gemm_fits(F, N) == 1; no accumulate / add_x /
- * split rows / hub lists / row_order / track.  Deterministic.  Callers fall back to the two launches otherwise. */
+ * split rows / row_order / track.  Hub lists (hub_threshold, hub_rows, hub_chunk_*, hub_scratch) are honoured: the chunks
+ * are reduced into hub_scratch by a launch of the ordinary kernel first, and a long row's lane group folds its chunk
+ * partials in chunk order instead of walking the edges.  Deterministic.  Callers fall back to the two launches otherwise. */
 int tfgx_aggregate_gemm_fits(int64_t F, int64_t N);
 int tfgx_aggregate_gemm_f32(const tfgx_reduce_args* args /* host */, const float* B, int64_t ldb,
                             const float* bias /* [N] or NULL */, int32_t act, float* C, int64_t ldc, int64_t N,

@@ -452,3 +452,42 @@ def test_fused_aggregate_gemm_declines_what_it_cannot_take(tfg, oracle):
     x = torch.randn(500, 128, device="cuda")
     assert P.aggregate_gemm(plan, x, L.SUM, torch.randn(128, 256, device="cuda")) is None      # B + tiles exceed 160 KB
     assert P.aggregate_gemm(plan, x, L.MAX, torch.randn(128, 16, device="cuda")) is None       # max is not linear
+
+
+@pytest.mark.parametrize("mode", ["gcn", "mean"])
+@pytest.mark.parametrize("f,units,thr", [(100, 256, 64), (64, 40, 16), (36, 128, 128)])
+def test_fused_aggregate_gemm_on_a_graph_with_hub_rows(tfg, oracle, mode, f, units, thr):
+    """Power-law graphs: rows longer than the plan's hub threshold are cut into chunks, reduced chunk by chunk by a launch of
+    the ordinary kernel, and folded in chunk order by the row's lane group inside the fused launch — same rows as the two
+    launches (whose hub path folds the same partials in the same order) and as the float64 product."""
+    import torch
+    from tf_geometric_amd import plan as P
+    L = tfg._lib
+    rng = np.random.Generator(np.random.PCG64(f + thr))
+    n = 4000
+    ei = oracle.synthetic_edges(n, 40000, seed=thr)
+    hubs = np.stack([rng.integers(0, 25, size=30000, dtype=np.int32),            # 25 destinations with ~1200 extra in-edges
+                     rng.integers(0, n, size=30000, dtype=np.int32)])
+    ei = np.concatenate([ei, hubs], axis=1)
+    x = rng.standard_normal((n, f), dtype=np.float32)
+    k, b = oracle.glorot_uniform(rng, f, units), (rng.standard_normal(units) * 0.1).astype(np.float32)
+    old = (P.HUB_THRESHOLD, P.HUB_CHUNK, P.FUSE_ON_SKEWED_WIDE)
+    P.HUB_THRESHOLD, P.HUB_CHUNK, P.FUSE_ON_SKEWED_WIDE = thr, max(8, thr // 2), True     # (wide outputs too: kernel test)
+    try:
+        plan = P.CsrPlan.build(L.as_i32(ei), n, n)
+        hub = plan.hub_info()
+        assert hub is not None and int(hub[0].shape[0]) >= 25
+        xd, kd, bd = L.as_f32(x), L.as_f32(k), L.as_f32(b)
+        # (weights ~ 1 / hub degree: a 1200-term row stays O(1), so the 1e-5 band tests the kernel, not fp32 at magnitude 100)
+        w_csr = plan.edge_attr_to_csr(rng.uniform(0.5, 1.5, ei.shape[1]).astype(np.float32) / (40.0 if mode == "gcn" else 1.0))
+        sc = L.as_f32(rng.uniform(0.25, 1.25, n).astype(np.float32)) if mode == "gcn" else None
+        op = L.SUM if mode == "gcn" else L.MEAN
+        fused = P.aggregate_gemm(plan, xd, op, kd, w_csr=w_csr, self_coef=sc, bias=bd, act=L.ACT_RELU)
+        assert fused is not None
+        agg = P.segment_reduce(plan, xd, op, w_csr=w_csr, self_coef=sc)
+        two = P.gemm_bias_act(agg, kd, bias=bd, act=L.ACT_RELU)
+    finally:
+        P.HUB_THRESHOLD, P.HUB_CHUNK, P.FUSE_ON_SKEWED_WIDE = old
+    ref = np.maximum(agg.double().cpu().numpy() @ k.astype(np.float64) + b, 0)
+    assert_parity(fused.cpu().numpy(), ref, what="fused with hub rows vs float64 of the same aggregate")
+    assert_parity(fused.cpu().numpy(), two.cpu().numpy(), what="fused with hub rows vs two launches")

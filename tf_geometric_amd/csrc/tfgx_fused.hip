@@ -54,6 +54,17 @@ struct FArgs {
     int32_t LDW;       // 32 * n_blocks + 8
     int64_t n_tiles;
     int32_t dbg;       // developer experiment: 1 = skip the multiplication and the stores, 2 = skip the stores only
+    // power-law graphs: rows longer than hub_threshold were cut into chunks and reduced chunk by chunk into hub_scratch by a
+    // launch of the ordinary kernel BEFORE this one; their lane group folds the chunk partials in chunk order instead of
+    // walking the edges (what hub_finalize_kernel does in the unfused path)
+    int32_t hub_threshold;
+    int32_t n_hub;
+    const int32_t* hub_rows;        // ascending
+    const int32_t* hub_chunk_ptr;
+    const float* hub_scratch;       // [chunks, F]
+    // skewed plans: slot i of the launch reduces destination row row_order[i] (the plan's rows sorted by length), so the 64
+    // rows of a tile are of similar length and no lane group holds a tile back; NULL: i
+    const int32_t* row_order;
 };
 
 template <int G>
@@ -68,6 +79,7 @@ __global__ __launch_bounds__(kFusedThreads) void agg_gemm_kernel(const FArgs a)
     float* Ws = lds;                                        // [KP][LDW]
     float* At = Ws + a.KP * a.LDW;                          // [kBufs][KP][kLda]
     int* ctrl = reinterpret_cast<int*>(At + kBufs * a.KP * kLda);   // [0] next unit | [1 + b] arrivals of buffer b | [1 + kBufs + b] done seq
+    int* rowid = ctrl + 16;                                 // [kBufs][kTileRows]: the destination row of each tile slot (row_order)
     constexpr int RPW = 64 / G;                             // destination rows per wave step (one per lane group)
     constexpr int UNITS = kTileRows / RPW;
     constexpr int UNROLL = 8;
@@ -98,19 +110,35 @@ __global__ __launch_bounds__(kFusedThreads) void agg_gemm_kernel(const FArgs a)
         const int buf = q % kBufs;
         const int64_t tile = int64_t(blockIdx.x) + int64_t(q) * gridDim.x;
         const int m = slot * RPW + grp;                     // row inside the tile
-        const int64_t r = tile * kTileRows + m;
+        const int64_t ri = tile * kTileRows + m;
+        const int64_t r = (a.row_order != nullptr && ri < a.n_dst) ? int64_t(a.row_order[ri]) : ri;
 
         // ---- producer: reduce destination row r (seg_reduce_kernel's walk) -------------------------------------------
         float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         if (r < a.n_dst) {
             const int s = a.row_ptr[r], e = a.row_ptr[r + 1];
+            const bool hub = a.hub_threshold > 0 && e - s > a.hub_threshold;      // uniform inside the lane group
             int cj_next = 0;
             float wj_next = 0.0f;
-            if (s + lane < e) {
+            if (!hub && s + lane < e) {
                 cj_next = a.col[s + lane];
                 if constexpr (WEIGHTED) wj_next = a.w[s + lane];
             }
-            for (int base = s; base < e; base += G) {
+            if (hub) {
+                int lo = 0, hi = a.n_hub - 1;                 // r is in the list: find its slot
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (a.hub_rows[mid] < int32_t(r)) lo = mid + 1;
+                    else hi = mid;
+                }
+                for (int c = a.hub_chunk_ptr[lo]; c < a.hub_chunk_ptr[lo + 1]; ++c) {
+                    float pv[4];
+                    load_vec<4>(a.hub_scratch + int64_t(c) * a.F + coff, pv);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) acc[v] += pv[v];
+                }
+            }
+            for (int base = s; base < (hub ? s : e); base += G) {
                 const int cj = cj_next;
                 const float wj = wj_next;
                 const int nxt = base + G + lane;
@@ -169,6 +197,7 @@ __global__ __launch_bounds__(kFusedThreads) void agg_gemm_kernel(const FArgs a)
 #pragma unroll
             for (int v = 0; v < 4; ++v) ab[(coff + v) * kLda + m] = acc[v];
         }
+        if (a.row_order != nullptr && lane == 0) rowid[buf * kTileRows + m] = ri < a.n_dst ? int(r) : -1;
         __threadfence_block();
         int arrived = 0;
         if (lane64 == 0) arrived = atomicAdd(&ctrl[1 + buf], 1);
@@ -228,6 +257,21 @@ __global__ __launch_bounds__(kFusedThreads) void agg_gemm_kernel(const FArgs a)
                 }
                 const int64_t row0 = (a.dbg == 3 ? (tile & 63) : tile) * kTileRows + mb * 32 + 4 * kh;   // dbg 3: stores land in 4096 rows
                 const bool full = tile * kTileRows + kTileRows <= a.n_dst;
+                if (a.row_order != nullptr) {
+                    // walk order: tile slot -> destination row through the ids the producers left in LDS
+                    const int* rid = rowid + buf * kTileRows + mb * 32 + 4 * kh;
+#pragma unroll
+                    for (int jb = 0; jb < 4; ++jb) {
+                        const int gn = (nb0 + jb) * 32 + l31;
+                        if (gn >= a.N || a.dbg == 2) continue;
+#pragma unroll
+                        for (int t = 0; t < 16; ++t) {
+                            const int rr = rid[(t & 3) + 8 * (t >> 2)];
+                            if (rr >= 0) __builtin_nontemporal_store(c4[jb][t], a.C + int64_t(rr) * a.ldc + gn);
+                        }
+                    }
+                    continue;
+                }
 #pragma unroll
                 for (int jb = 0; jb < 4; ++jb) {
                     const int gn = (nb0 + jb) * 32 + l31;
@@ -262,7 +306,10 @@ __global__ __launch_bounds__(kFusedThreads) void agg_gemm_kernel(const FArgs a)
     }
 }
 
-inline size_t fused_lds_bytes(int kp, int ldw) { return sizeof(float) * (size_t(kp) * ldw + size_t(kBufs) * kp * kLda) + sizeof(int) * 16; }
+inline size_t fused_lds_bytes(int kp, int ldw)
+{
+    return sizeof(float) * (size_t(kp) * ldw + size_t(kBufs) * kp * kLda) + sizeof(int) * (16 + kBufs * kTileRows);
+}
 
 }  // namespace
 }  // namespace tfgx
@@ -290,9 +337,30 @@ extern "C" int tfgx_aggregate_gemm_f32(const tfgx_reduce_args* p, const float* B
     TFGX_REQUIRE(p->row_begin && p->row_end == p->row_begin + 1 && p->rp_stride == 1, "needs a plain CSR (row_ptr, row_ptr + 1)");
     TFGX_REQUIRE(p->x && B && C, "null pointer");          // (col may be NULL for a graph without edges)
     TFGX_REQUIRE(p->ldx >= p->F && p->ldx % 4 == 0 && aligned_to(p->x, 16) && ldb >= N && ldc >= N, "bad leading dimension / alignment");
-    TFGX_REQUIRE(!p->accumulate && !p->add_x && !p->x_tail && p->hub_threshold == 0 && !p->row_order && !p->track,
-                 "plain aggregation only (no accumulate / add_x / split rows / hub lists / row order / track)");
+    TFGX_REQUIRE(!p->accumulate && !p->add_x && !p->x_tail && !p->track,
+                 "plain aggregation only (no accumulate / add_x / split rows / track)");
+    const bool use_hub = p->hub_threshold > 0 && p->n_hub_rows > 0;
+    if (use_hub) {
+        TFGX_REQUIRE(p->hub_rows && p->hub_chunk_ptr && p->hub_chunk_begin && p->hub_chunk_end && p->hub_scratch &&
+                         p->n_hub_chunks > 0 && p->n_hub_rows < (int64_t(1) << 31),
+                     "hub rows given without chunk lists / scratch");
+        // chunk partials first: every chunk is reduced like an ordinary row into hub_scratch (the unfused path's step 2)
+        tfgx_reduce_args c = *p;
+        c.row_begin = p->hub_chunk_begin; c.row_end = p->hub_chunk_end; c.rp_stride = 1;
+        c.n_dst = p->n_hub_chunks; c.out = p->hub_scratch; c.ldo = p->F;
+        c.op = TFGX_SUM; c.act = TFGX_ACT_NONE; c.accumulate = 0;
+        c.self_coef = nullptr; c.bias = nullptr; c.add_x = nullptr; c.mean_count = nullptr;
+        c.hub_threshold = 0; c.hub_rows = nullptr; c.hub_chunk_ptr = nullptr; c.hub_chunk_begin = nullptr;
+        c.hub_chunk_end = nullptr; c.n_hub_rows = 0; c.n_hub_chunks = 0; c.hub_scratch = nullptr;
+        c.row_order = nullptr;          // (a walk order names DESTINATION rows; the chunk launch walks chunks)
+        const int rc = tfgx_segment_reduce_f32(&c, stream_);
+        if (rc != TFGX_OK) return rc;
+    }
     FArgs a;
+    a.hub_threshold = use_hub ? p->hub_threshold : 0;
+    a.n_hub = use_hub ? int32_t(p->n_hub_rows) : 0;
+    a.hub_rows = p->hub_rows; a.hub_chunk_ptr = p->hub_chunk_ptr; a.hub_scratch = p->hub_scratch;
+    a.row_order = p->row_order;
     a.row_ptr = p->row_begin; a.col = p->col; a.w = p->w; a.n_dst = p->n_dst; a.x = p->x; a.ldx = p->ldx; a.F = int32_t(p->F);
     a.op = p->op; a.self_coef = p->self_coef; a.mean_count = p->mean_count;
     a.B = B; a.ldb = ldb; a.bias = bias; a.act = act; a.N = int32_t(N); a.C = C; a.ldc = ldc;

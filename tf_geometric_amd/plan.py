@@ -460,10 +460,13 @@ def segment_reduce(plan, x, op, w_csr=None, out=None, act=L.ACT_NONE, self_coef=
 FUSE_AGGREGATE_GEMM = True      # developer A/B switch (tools/ab_fused_layer.py): False = always two launches
 
 
+FUSE_ON_SKEWED_WIDE = False      # developer A/B: take the fused launch on skewed plans for outputs wider than 128 columns too
+
+
 def aggregate_gemm(plan, x, op, kernel, w_csr=None, self_coef=None, bias=None, act=L.ACT_NONE, out=None):
     """act(segment_reduce(plan, x, op, w_csr, self_coef) @ kernel + bias) in ONE launch (tfgx_aggregate_gemm_f32: the
     aggregate goes registers -> LDS -> MFMA, never through HBM), or None when the fused kernel does not take this call
-    (shape outside tfgx_aggregate_gemm_fits, unaligned rows, a plan with hub rows, hipGraph capture of a first use) —
+    (shape outside tfgx_aggregate_gemm_fits, unaligned rows) —
     the caller then runs the two launches."""
     if not FUSE_AGGREGATE_GEMM or op not in (L.SUM, L.MEAN) or isinstance(x, SplitRows):
         return None
@@ -473,7 +476,12 @@ def aggregate_gemm(plan, x, op, kernel, w_csr=None, self_coef=None, bias=None, a
     F, N = int(x2.shape[1]), int(k2.shape[1])
     if int(k2.shape[0]) != F or not lib.tfgx_aggregate_gemm_fits(F, N) or ldx % 4 != 0 or x2.data_ptr() % 16 != 0:
         return None
-    if plan.hub_info() is not None:          # long rows are chunked by the unfused path; here a row belongs to one lane group
+    hub = plan.hub_info()      # long rows: chunk partials by a launch of the ordinary kernel, folded by the row's lane group
+    order = plan.row_order()   # skewed plans: tiles of similar-length rows (degree order), results unchanged
+    if (hub is not None or order is not None) and N > 128 and not FUSE_ON_SKEWED_WIDE:
+        # measured on the R-MAT graph of bench.py (products size, tools/ab_fused_layer.py products rmat): the fused launch
+        # wins with a 128-column output (mean SAGE half: 10.31 vs 10.57 ms) and loses with 256 columns (GCN 100 -> 256: 11.75
+        # vs 10.77 ms: one consumer wave per tile scatters 64 KB of rows in walk order) — wide outputs take the two launches
         return None
     n_dst = plan.n_dst
     if out is None:
@@ -486,6 +494,16 @@ def aggregate_gemm(plan, x, op, kernel, w_csr=None, self_coef=None, bias=None, a
     a.n_dst, a.x, a.ldx, a.F = n_dst, x2.data_ptr(), ldx, F
     a.op = op
     a.self_coef = 0 if self_coef is None else self_coef.data_ptr()
+    if order is not None:
+        a.row_order = order.data_ptr()
+    if hub is not None:
+        hub_rows, chunk_ptr, chunk_begin, chunk_end, _ = hub
+        scratch = torch.empty((int(chunk_begin.shape[0]), F), dtype=torch.float32, device=x2.device)
+        a.hub_threshold = plan.hub_threshold
+        a.hub_rows, a.hub_chunk_ptr = hub_rows.data_ptr(), chunk_ptr.data_ptr()
+        a.hub_chunk_begin, a.hub_chunk_end = chunk_begin.data_ptr(), chunk_end.data_ptr()
+        a.n_hub_rows, a.n_hub_chunks = int(hub_rows.shape[0]), int(chunk_begin.shape[0])
+        a.hub_scratch = scratch.data_ptr()
     bias_t = None if bias is None else L.as_f32(bias).contiguous()
     L.check(lib.tfgx_aggregate_gemm_f32(ctypes.byref(a), L.ptr(k2), ldb, L.ptr(bias_t), act, L.ptr(out), ldc, N,
                                         L.stream_ptr()), "tfgx_aggregate_gemm_f32")

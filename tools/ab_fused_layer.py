@@ -18,8 +18,9 @@ from tf_geometric_amd import synthetic, _lib as L, plan as P     # noqa: E402
 import bench                                            # noqa: E402
 
 which = sys.argv[1] if len(sys.argv) > 1 else "products"
+graph = sys.argv[2] if len(sys.argv) > 2 else "uniform"          # "rmat": power-law in-degrees (hub rows, chunked)
 n, e, f = synthetic.WORKLOADS[which]
-ei = L.as_i32(synthetic.synthetic_edges(n, e, seed=0))
+ei = bench.rmat_edges(n, e, 7, torch.device("cuda")) if graph == "rmat" else L.as_i32(synthetic.synthetic_edges(n, e, seed=0))
 g = torch.Generator(device="cuda")
 g.manual_seed(1)
 x = torch.randn(n, f, generator=g, device="cuda")
@@ -33,6 +34,9 @@ from tf_geometric_amd.nn.conv.gcn import gcn_norm_adj   # noqa: E402
 normed = gcn_norm_adj(cache["tfgx_gcn_adj"], cache=cache)
 k = torch.randn(f, 256, device="cuda") * 0.1
 agg_out = torch.empty(n, f, device="cuda")
+
+
+P.FUSE_ON_SKEWED_WIDE = True          # (the A/B measures the fused launch wherever it can run)
 
 
 def set_fuse(v):
@@ -57,5 +61,5 @@ a, b = gcn([x, ei], cache=cache), None
 set_fuse(False)
 b = gcn([x, ei], cache=cache)
 set_fuse(True)
-print(json.dumps({"shape": which, "N": n, "E": int(ei.shape[1]), "F": f, "ms_median_of_4_alternating_rounds": med,
+print(json.dumps({"shape": which, "graph": graph, "N": n, "E": int(ei.shape[1]), "F": f, "ms_median_of_4_alternating_rounds": med,
                   "max_abs_diff_fused_vs_two_launches": float((a - b).abs().max()), "all_rounds_ms": times}))
