@@ -21,6 +21,13 @@ python tools/kernel_dispatch_csv.py "$S" "seg_reduce_kernel<4, 32, 1, false, tru
 python tools/rocpd_summary.py "$F" "$W" > "$OUT/summary_pmc.md"
 python tools/make_pmc_json.py "$F" "$W" "$S" "seg_reduce_kernel<4, 32, 1, false, true, false, false>" "$OUT/r03_products_pmc.json" products
 python tools/make_pmc_json.py "$F" "$W" "$S" "seg_reduce_kernel<4, 32, 1, false, true, true, false>" "$OUT/r03_products_edge_tail_pmc.json" products
+# the fused aggregate -> GEMM launch against the two launches it replaces: HBM-side bytes per kernel (separate PMC passes)
+cd /tmp
+rocprofv3 --pmc FETCH_SIZE -d "$OUT/fused_fetch" -- python "$ROOT/tools/fused_layer_pmc.py" > /dev/null 2> "$OUT/fused_fetch.err"
+rocprofv3 --pmc WRITE_SIZE -d "$OUT/fused_write" -- python "$ROOT/tools/fused_layer_pmc.py" > /dev/null 2> "$OUT/fused_write.err"
+cd "$ROOT"
+python tools/rocpd_summary.py "$(find "$OUT/fused_fetch" -name "*_results.db" | head -1)" "$(find "$OUT/fused_write" -name "*_results.db" | head -1)" > "$OUT/summary_fused_pmc.md"
+rm -rf "$OUT/fused_fetch" "$OUT/fused_write"
 # the other BASELINE configs: Reddit-shaped GAT and the papers100M-shaped shard, kernel-trace only
 cd /tmp
 rocprofv3 --kernel-trace --stats -d "$OUT/reddit" -- python "$ROOT/tools/bench_sweep.py" --only=reddit > "$OUT/reddit.jsonl" 2> "$OUT/reddit.err"
