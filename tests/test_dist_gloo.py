@@ -10,7 +10,7 @@ from conftest import assert_parity
 import dist_worker
 
 
-@pytest.mark.parametrize("world,skew,rounds", [(2, False, None), (2, True, 3), (3, True, 4), (2, False, 16)])
+@pytest.mark.parametrize("world,skew,rounds", [(2, False, None), (2, True, 3), (3, True, 4), (2, False, 16), (8, False, None)])
 def test_sharded_matches_oracle_gloo(tmp_path, world, skew, rounds):
     """rounds = number of all-to-all-v rounds the halo travels in (pipelined with the per-round reduce passes)."""
     port = 29500 + random.randint(0, 2000)
@@ -56,7 +56,7 @@ def test_edge_balanced_bounds():
 
 
 @pytest.mark.parametrize("world,skew,rounds,hub", [(2, False, 2, None), (3, True, 3, None), (1, True, None, None),
-                                                   (2, True, 2, 8)])
+                                                   (2, True, 2, 8), (8, False, 4, None)])
 def test_sharded_training_gradients_gloo(tmp_path, world, skew, rounds, hub):
     """Sharded backward: reverse halo all-to-all-v, owner-side accumulate in fixed peer order, weight-gradient
     all-reduce.  d/dx (per owner), d/dkernel and d/dbias (summed over ranks) must equal single-process float64 autograd
