@@ -339,6 +339,17 @@ int tfgx_segment_max_backward_mask_f32(const int32_t* row_ptr, const int32_t* co
                                        const float* w_t /* or NULL */, const int32_t* pos_t /* or NULL */, int64_t n_src,
                                        float* gx, int64_t ldgx, void* workspace, size_t workspace_bytes,
                                        tfgx_stream_t stream);
+/* The same in PHASES (the sharded path sends the halo rows' gradients back while the own rows' are still computed):
+   phases bit 0 = build gn and the masks into `workspace` (reads the forward arrays; row_ptr_t / gx unused), bit 1 = apply
+   them to a WINDOW of source rows: row_ptr_t points at the window's first row, n_src = rows in the window, gx at the
+   window's first output row; n_dst, E, F and the workspace must be the ones of the build call.  3 = both (the call above). */
+int tfgx_segment_max_backward_mask_phases_f32(const int32_t* row_ptr, const int32_t* col, const float* w /* or NULL */,
+                                              int64_t n_dst, int64_t E, const float* x, int64_t ldx, int64_t F,
+                                              const float* out, int64_t ldo, const float* g, int64_t ldg,
+                                              const float* count, int64_t ldc, const int32_t* argpos, int64_t lda,
+                                              const int32_t* row_ptr_t, const int32_t* dst_t, const float* w_t /* or NULL */,
+                                              const int32_t* pos_t /* or NULL */, int64_t n_src, float* gx, int64_t ldgx,
+                                              void* workspace, size_t workspace_bytes, int32_t phases, tfgx_stream_t stream);
 int tfgx_segment_max_backward_f32(const int32_t* row_ptr_t, const int32_t* dst_t, const float* w_t /* or NULL */,
                                   int64_t n_src, const float* x, int64_t ldx, int64_t F, const float* out, int64_t ldo,
                                   const float* g, int64_t ldg, const float* count, int64_t ldc, float* gx, int64_t ldgx,

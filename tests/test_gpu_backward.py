@@ -787,3 +787,14 @@ def test_tracked_max_span_by_span_equals_one_launch(tfg, oracle, f, weighted, k1
     AG.aggregate(plan, xa, L.MAX, w_csr=w).backward(g)
     AG.aggregate(plan, xb, L.MAX, w_csr=w, max_passes=passes).backward(g)
     assert torch.equal(xa.grad, xb.grad)
+    # halo-first backward (tfgx_segment_max_backward_mask_phases_f32): masks built once, applied to the source rows
+    # [n_first, n) first — the hook sees their final gradients (and, in the sharded path, sends them on their way) — then
+    # to [0, n_first): the same gradient bit for bit
+    seen = {}
+
+    def hook(gx):
+        seen["tail"] = gx[n // 3:].clone()
+    passes.halo_first = (n // 3, hook)
+    xc = xd.clone().requires_grad_(True)
+    AG.aggregate(plan, xc, L.MAX, w_csr=w, max_passes=passes).backward(g)
+    assert torch.equal(xa.grad, xc.grad) and torch.equal(seen["tail"], xa.grad[n // 3:])

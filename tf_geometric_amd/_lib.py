@@ -142,6 +142,9 @@ SIGNATURES = {
     "tfgx_segment_max_backward_mask_workspace_bytes": (_SZ, [_I64, _I64, _I64]),
     "tfgx_segment_max_backward_mask_f32": (ctypes.c_int, [_P, _P, _P, _I64, _I64, _P, _I64, _I64, _P, _I64, _P, _I64, _P,
                                                           _I64, _P, _I64, _P, _P, _P, _P, _I64, _P, _I64, _P, _SZ, _P]),
+    "tfgx_segment_max_backward_mask_phases_f32": (ctypes.c_int, [_P, _P, _P, _I64, _I64, _P, _I64, _I64, _P, _I64, _P, _I64, _P,
+                                                                 _I64, _P, _I64, _P, _P, _P, _P, _I64, _P, _I64, _P, _SZ,
+                                                                 ctypes.c_int32, _P]),
     "tfgx_segment_max_backward_push_f32": (ctypes.c_int, [_P, _P, _P, _I64, _I64, _P, _I64, _I64, _P, _I64, _P, _I64, _P,
                                                           _I64, _P, _I64, _P, _I64, _P]),
     "tfgx_segment_max_backward_w_f32": (ctypes.c_int, [_P, _P, _P, _I64, _P, _I64, _I64, _P, _I64, _P, _I64, _P, _P]),

@@ -176,6 +176,7 @@ class _AggregateMax(torch.autograd.Function):
             packed = torch.empty((plan.n_dst, F), dtype=torch.int32, device=x2.device)
             passes(x2, wd, out, packed)
             count = None
+            ctx.halo_first = getattr(passes, "halo_first", None)     # (n_own, callable(gx)): see backward
         elif _max_mode() == "mask" and can_track(plan, x2, ldx):
             # the tuned forward walk (8 gathered rows in flight per lane group) with the tie count and the position of the
             # first maximal edge tracked online and written PACKED (one uint32 per element instead of a float count array
@@ -203,6 +204,8 @@ class _AggregateMax(torch.autograd.Function):
             out = segment_reduce(plan, x2, L.MAX, w_csr=wd)
             count = None
         ctx.plan, ctx.count, ctx.argpos, ctx.mode, ctx.packed = plan, count, argpos, _max_mode(), packed
+        if passes is None:
+            ctx.halo_first = None
         ctx.save_for_backward(x, w_csr, out)
         return out
 
@@ -241,11 +244,24 @@ class _AggregateMax(torch.autograd.Function):
                 w_t = _transposed_weights(plan, w_csr, t2d)
                 ws_bytes = lib.tfgx_segment_max_backward_mask_workspace_bytes(plan.n_dst, plan.num_edges, F)
                 ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=x2.device)
-                L.check(lib.tfgx_segment_max_backward_mask_f32(
-                    L.ptr(plan.row_ptr), L.ptr(plan.col), L.ptr(None if w_csr is None else w_csr.detach()), plan.n_dst,
-                    plan.num_edges, L.ptr(x2), ldx, F, L.ptr(out), F, L.ptr(g2), ldg, None, F, L.ptr(packed), F,
-                    L.ptr(pt.row_ptr), L.ptr(pt.col), L.ptr(w_t), L.ptr(t2d), int(x2.shape[0]), L.ptr(gx), F, L.ptr(ws),
-                    ws_bytes, L.stream_ptr()), "tfgx_segment_max_backward_mask_f32 (packed)")
+                n_table = int(x2.shape[0])
+
+                def run(phases, lo, hi):       # masks built / applied to source rows [lo, hi) of the table
+                    L.check(lib.tfgx_segment_max_backward_mask_phases_f32(
+                        L.ptr(plan.row_ptr), L.ptr(plan.col), L.ptr(None if w_csr is None else w_csr.detach()), plan.n_dst,
+                        plan.num_edges, L.ptr(x2), ldx, F, L.ptr(out), F, L.ptr(g2), ldg, None, F, L.ptr(packed), F,
+                        pt.row_ptr.data_ptr() + 4 * lo, L.ptr(pt.col), L.ptr(w_t), L.ptr(t2d), hi - lo,
+                        gx.data_ptr() + 4 * F * lo, F, L.ptr(ws), ws_bytes, phases, L.stream_ptr()),
+                        "tfgx_segment_max_backward_mask_phases_f32 (packed)")
+                hf = getattr(ctx, "halo_first", None)
+                if hf is not None and 0 < hf[0] < n_table:
+                    # sharded table [own | halo]: the halo rows' gradients belong to peers — compute them first and let them
+                    # travel (reverse exchange on the communication stream) while the own rows' part runs
+                    run(3, hf[0], n_table)
+                    hf[1](gx)
+                    run(2, 0, hf[0])
+                else:
+                    run(3, 0, n_table)
             elif aligned and ctx.mode == "mask":
                 pt, t2d = _transposed(plan)
                 w_t = _transposed_weights(plan, w_csr, t2d)

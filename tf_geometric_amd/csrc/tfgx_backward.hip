@@ -1233,15 +1233,31 @@ extern "C" int tfgx_segment_max_backward_mask_f32(const int32_t* row_ptr, const 
                                                   const int32_t* pos_t, int64_t n_src, float* gx, int64_t ldgx,
                                                   void* workspace, size_t workspace_bytes, tfgx_stream_t stream_)
 {
+    return tfgx_segment_max_backward_mask_phases_f32(row_ptr, col, w, n_dst, E, x, ldx, F, out, ldo, g, ldg, count, ldc, argpos,
+                                                     lda, row_ptr_t, dst_t, w_t, pos_t, n_src, gx, ldgx, workspace,
+                                                     workspace_bytes, 3, stream_);
+}
+
+extern "C" int tfgx_segment_max_backward_mask_phases_f32(const int32_t* row_ptr, const int32_t* col, const float* w,
+                                                         int64_t n_dst, int64_t E, const float* x, int64_t ldx, int64_t F,
+                                                         const float* out, int64_t ldo, const float* g, int64_t ldg,
+                                                         const float* count, int64_t ldc, const int32_t* argpos, int64_t lda,
+                                                         const int32_t* row_ptr_t, const int32_t* dst_t, const float* w_t,
+                                                         const int32_t* pos_t, int64_t n_src, float* gx, int64_t ldgx,
+                                                         void* workspace, size_t workspace_bytes, int32_t phases,
+                                                         tfgx_stream_t stream_)
+{
     TFGX_RANGE();
+    TFGX_REQUIRE(phases >= 1 && phases <= 3, "phases: bit 0 = build the masks, bit 1 = apply them to a window of source rows");
+    const bool do_build = (phases & 1) != 0, do_apply = (phases & 2) != 0;
     // count == NULL: `argpos` holds the PACKED uint32 of tfgx_reduce_args.track (tie count << 16 | row-relative position)
     if (count == nullptr) ldc = F;
     TFGX_REQUIRE(n_dst >= 0 && n_src >= 0 && E >= 0 && F >= 1 && ldx >= F && ldo >= F && ldg >= F && ldc >= F &&
                      lda >= F && ldgx >= F, "bad size");
-    if (n_src == 0) return TFGX_OK;
-    TFGX_REQUIRE(row_ptr_t && gx, "null pointer");
-    TFGX_REQUIRE(n_dst == 0 || (row_ptr && x && out && g && argpos), "null pointer");
-    TFGX_REQUIRE(E == 0 || (col && dst_t), "null pointer");
+    if (n_src == 0 && !do_build) return TFGX_OK;
+    TFGX_REQUIRE(!do_apply || n_src == 0 || (row_ptr_t && gx), "null pointer");
+    TFGX_REQUIRE(!do_build || n_dst == 0 || (row_ptr && x && out && g && argpos), "null pointer");
+    TFGX_REQUIRE(E == 0 || ((!do_build || col) && (!do_apply || dst_t)), "null pointer");
     TFGX_REQUIRE((w == nullptr) == (w_t == nullptr), "w and w_t go together");
     TFGX_REQUIRE(F % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && ldg % 4 == 0 && ldc % 4 == 0 && ldgx % 4 == 0 &&
                      aligned_to(x, 16) && aligned_to(out, 16) && aligned_to(g, 16) && aligned_to(count, 16) &&
@@ -1259,14 +1275,16 @@ extern "C" int tfgx_segment_max_backward_mask_f32(const int32_t* row_ptr, const 
 #define TFGX_MASK(GG)                                                                                                  \
     {                                                                                                                  \
         const int ny = (lanes + GG - 1) / GG;                                                                          \
-        if (n_dst > 0) {                                                                                               \
+        if (do_build && n_dst > 0) {                                                                                   \
             dim3 ga(grid_for(n_dst, kBlock / GG, 1 << 20), ny, 1);                                                     \
             max_mask_build_kernel<GG><<<ga, kBlock, 0, stream>>>(row_ptr, col, w, n_dst, x, ldx, int(F), out, ldo, g,  \
                                                                  ldg, count, ldc, argpos, lda, gn, mask, MW);         \
         }                                                                                                              \
-        dim3 gb(grid_for(n_src, kBlock / GG, 1 << 20), ny, 1);                                                         \
-        max_backward_mask_apply_kernel<GG><<<gb, kBlock, 0, stream>>>(row_ptr_t, dst_t, w_t, pos_t, n_src, int(F), gn, \
-                                                                      mask, MW, gx, ldgx);                            \
+        if (do_apply && n_src > 0) {                                                                                   \
+            dim3 gb(grid_for(n_src, kBlock / GG, 1 << 20), ny, 1);                                                     \
+            max_backward_mask_apply_kernel<GG><<<gb, kBlock, 0, stream>>>(row_ptr_t, dst_t, w_t, pos_t, n_src, int(F), \
+                                                                          gn, mask, MW, gx, ldgx);                    \
+        }                                                                                                              \
     }
     if (lanes <= 8) TFGX_MASK(8)
     else if (lanes <= 16) TFGX_MASK(16)

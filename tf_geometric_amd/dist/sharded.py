@@ -630,14 +630,14 @@ class ShardedGraph(object):
             self._tl = be.build_csr(torch.stack([self.col, rows]), max(self.n_table, 1), max(self.n_own, 1))
         return self._tl
 
-    def reverse_exchange(self, d_table, inplace=False):
+    def reverse_exchange(self, d_table, inplace=False, started=None):
         """Gradient w.r.t. the [own | halo] source table -> gradient w.r.t. this rank's own rows (the backward of the
         halo exchange).  The halo-row gradients travel back along the forward exchange's lists (what I received from p in
         round j, I send to p; what I sent, I receive), one grouped exchange per round; returned rows are added into the own
         rows at the forward send indices, peer by peer in rank order and round by round — a fixed order, and one peer's
         list has no repeated row, so the sum is deterministic without atomics (tfgx_scatter_add_rows_f32)."""
         d_table = d_table.contiguous()
-        handle = self.transport.reverse_start(self, d_table)
+        handle = started if started is not None else self.transport.reverse_start(self, d_table)
         d_own = d_table[:self.n_own]
         if not inplace:
             d_own = d_own.clone()
@@ -673,6 +673,14 @@ class ShardedGraph(object):
             return None
         be, K1, rpk = self.backend, self.n_class, self.rpk
 
+        token = int(table.data_ptr())
+
+        def start_reverse(gx):
+            # called by the max backward once the halo rows of d(table) are final: they start travelling now; the
+            # _HaloGather node of THIS table (matched by its storage) finishes the exchange instead of starting one
+            self.counters["max_halo_first_backwards"] = self.counters.get("max_halo_first_backwards", 0) + 1
+            self._early_reverse = (token, self.transport.reverse_start(self, gx), gx)
+
         def run(x2_, w_, out, packed):
             self.counters["max_span_forwards"] = self.counters.get("max_span_forwards", 0) + 1
             with torch.no_grad():
@@ -681,6 +689,7 @@ class ShardedGraph(object):
                         self.exchange_finish(handles, k - 1)      # class k reads the rows of round k - 1
                     be.segment_reduce(rpk[k:], rpk[k + 1:], K1, self.col, w_, self.n_own, x2_, out, L.MAX,
                                       accumulate=k > 0, track=packed, track_row_begin=rpk)
+        run.halo_first = (self.n_own, start_reverse)
         return run
 
     def local_plan(self):
@@ -1058,6 +1067,7 @@ class _HaloGather(torch.autograd.Function):
     def forward(ctx, sg, h_own, defer=False):
         ctx.sg = sg
         table = sg.alloc_table(int(h_own.shape[1]))
+        ctx.table_ptr = int(table.data_ptr())
         sg.own_rows(table).copy_(h_own.detach())
         handle = sg.exchange_start(table)
         if defer:
@@ -1069,4 +1079,13 @@ class _HaloGather(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_table):
-        return None, ctx.sg.reverse_exchange(g_table.contiguous()), None
+        sg = ctx.sg
+        early = getattr(sg, "_early_reverse", None)
+        if early is not None and early[0] == ctx.table_ptr:
+            # the consumer of this table (trainable max) already sent the halo rows of THIS gradient on their way
+            sg._early_reverse = None
+            if g_table.data_ptr() != early[2].data_ptr():
+                raise RuntimeError("sharded max backward: the table gradient was replaced after its halo rows started "
+                                   "travelling (the table has more than one consumer?)")
+            return None, sg.reverse_exchange(g_table, started=early[1]), None
+        return None, sg.reverse_exchange(g_table.contiguous()), None
