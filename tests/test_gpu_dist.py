@@ -72,6 +72,7 @@ def test_sharded_training_through_the_c_abi_exchange_world1(tfg, skew):
     # epilogue, GAT states merged with the softmax statistics written for the backward)
     # (the skewed graph has hub rows: those are chunked and do not track, so its max forward waits for the exchange)
     assert tr["counters"].get("gat_span_training_forwards", 0) >= 1, tr["counters"]
+    assert skew or tr["counters"].get("gat_halo_first_backwards", 0) >= 1, tr["counters"]   # (hub sources: one pass)
     assert skew or tr["counters"].get("max_span_forwards", 0) >= 2, tr["counters"]       # max at 36 columns + max-pool SAGE
     assert skew or tr["counters"].get("max_halo_first_backwards", 0) >= 2, tr["counters"]   # ... and their halo-first backward
 

@@ -457,6 +457,7 @@ class _GatAttention(torch.autograd.Function):
         forward as span passes + merge under a halo exchange; same (out, stats), so the backward is unchanged."""
         from .nn.conv.gat import gat_attention
         stats = torch.empty((plan.n_dst, 2 * num_heads), dtype=torch.float32, device=V.device)
+        ctx.halo_first = getattr(passes, "halo_first", None)        # (n_own, callable(d[K | V] table)): see backward
         if passes is not None:
             assert float(drop_rate) == 0.0 and scale_d is None
             out = passes(Q.detach(), K.detach(), V.detach(), stats)
@@ -492,8 +493,17 @@ class _GatAttention(torch.autograd.Function):
         # dense outputs (K2 / V2 may be column slices of a wider table — the sharded [K | V] halo table)
         dev = g2.device
         gq = torch.empty((n, A), dtype=torch.float32, device=dev)
-        gk = torch.empty((int(K2.shape[0]), A), dtype=torch.float32, device=dev)
-        gv = torch.empty((int(V2.shape[0]), W), dtype=torch.float32, device=dev)
+        hf = getattr(ctx, "halo_first", None)
+        n_tab = int(K2.shape[0])
+        if hf is not None and int(V2.shape[0]) == n_tab:
+            # sharded [K | V] table: d[K | V] in ONE buffer (its halo rows travel back as one exchange), gk / gv are its column
+            # blocks — what autograd's slice backward would assemble anyway
+            gkv = torch.empty((n_tab, A + W), dtype=torch.float32, device=dev)
+            gk, gv = gkv[:, :A], gkv[:, A:]
+        else:
+            hf, gkv = None, None
+            gk = torch.empty((n_tab, A), dtype=torch.float32, device=dev)
+            gv = torch.empty((int(V2.shape[0]), W), dtype=torch.float32, device=dev)
         a = L.GatBackwardArgs()
         a.row_ptr, a.col, a.n_dst = plan.row_ptr.data_ptr(), plan.col.data_ptr(), n
         a.row_ptr_t, a.dst_t, a.n_src = pt.row_ptr.data_ptr(), pt.col.data_ptr(), pt.n_dst
@@ -503,8 +513,8 @@ class _GatAttention(torch.autograd.Function):
         a.H, a.d, a.dv, a.add_self_loop = H, A // H, W // H, 1
         a.scale = math.sqrt(float(A // H if ctx.scale_d is None else ctx.scale_d))
         a.grad_q, a.ld_grad_q = gq.data_ptr(), A
-        a.grad_k, a.ld_grad_k = gk.data_ptr(), A
-        a.grad_v, a.ld_grad_v = gv.data_ptr(), W
+        a.grad_k, a.ld_grad_k = gk.data_ptr(), int(gk.stride(0))
+        a.grad_v, a.ld_grad_v = gv.data_ptr(), int(gv.stride(0))
         ro, ro_t = plan.row_order(), pt.row_order()        # skewed graphs: degree-ordered walks (results unchanged)
         a.row_order = 0 if ro is None else ro.data_ptr()
         a.row_order_t = 0 if ro_t is None else ro_t.data_ptr()
@@ -523,8 +533,27 @@ class _GatAttention(torch.autograd.Function):
         a.dsum, a.ld_dsum = pack.data_ptr() + 4 * (W + A + 2 * H), P
         hub_s, nc_s = L.hub_lists(pt)
         sc_s = torch.empty(max(nc_s * (A + W), 1), dtype=torch.float32, device=dev) if hub_s is not None else None
-        L.check(lib.tfgx_gat_backward_src_hub_f32(ctypes.byref(a), None if hub_s is None else ctypes.byref(hub_s),
-                                                  L.ptr(sc_s), L.stream_ptr()), "tfgx_gat_backward_src_hub_f32")
+        if hf is not None and hub_s is None and 0 < hf[0] < n_tab:
+            # halo rows of the table first (sources that are no destinations: no self-loop, window-relative row indices:
+            # the K / V / gradient pointers move with the window), their gradients start travelling, then the own rows
+            n_own = int(hf[0])
+            full = (a.row_ptr_t, a.n_src, a.k, a.v, a.grad_k, a.grad_v, a.add_self_loop, a.row_order_t)
+            a.row_ptr_t = pt.row_ptr.data_ptr() + 4 * n_own
+            a.n_src = n_tab - n_own
+            a.k, a.v = K2.data_ptr() + 4 * ldk * n_own, V2.data_ptr() + 4 * ldv * n_own
+            a.grad_k = gk.data_ptr() + 4 * int(gk.stride(0)) * n_own
+            a.grad_v = gv.data_ptr() + 4 * int(gv.stride(0)) * n_own
+            a.add_self_loop, a.row_order_t = 0, 0
+            L.check(lib.tfgx_gat_backward_src_hub_f32(ctypes.byref(a), None, None, L.stream_ptr()),
+                    "tfgx_gat_backward_src_hub_f32 (halo rows)")
+            hf[1](gkv)
+            a.row_ptr_t, a.n_src, a.k, a.v, a.grad_k, a.grad_v, a.add_self_loop, a.row_order_t = full
+            a.n_src, a.row_order_t = n_own, 0
+            L.check(lib.tfgx_gat_backward_src_hub_f32(ctypes.byref(a), None, None, L.stream_ptr()),
+                    "tfgx_gat_backward_src_hub_f32 (own rows)")
+        else:
+            L.check(lib.tfgx_gat_backward_src_hub_f32(ctypes.byref(a), None if hub_s is None else ctypes.byref(hub_s),
+                                                      L.ptr(sc_s), L.stream_ptr()), "tfgx_gat_backward_src_hub_f32")
         return None, None, gq, gk, gv, None, None, None, None
 
 

@@ -138,6 +138,16 @@ class HipBackend(object):
             def passes(Qd, Kd, Vd, stats):
                 with torch.no_grad():
                     return sg._gat_attention_spans(Qd, Kd, Vd, num_heads, handles, None, L.ACT_NONE, None, stats=stats)
+            base = getattr(K, "_base", None)
+            if base is not None and getattr(V, "_base", None) is base and K.data_ptr() == base.data_ptr():
+                # K and V are the column blocks of ONE halo table: the backward writes d[K | V] into one buffer and sends
+                # its halo rows back before it computes the own rows (matched to the table's exchange node by its storage)
+                token = int(base.data_ptr())
+
+                def start_reverse(gkv):
+                    sg.counters["gat_halo_first_backwards"] = sg.counters.get("gat_halo_first_backwards", 0) + 1
+                    sg._early_reverse = (token, sg.transport.reverse_start(sg, gkv), None)
+                passes.halo_first = (sg.n_own, start_reverse)
         return AG.gat_attention(sg.local_plan(), Q, K, V, num_heads, passes=passes)
 
     def hub_lists(self, row_begin, row_end, rp_stride, n_dst, num_edges):
@@ -1084,7 +1094,7 @@ class _HaloGather(torch.autograd.Function):
         if early is not None and early[0] == ctx.table_ptr:
             # the consumer of this table (trainable max) already sent the halo rows of THIS gradient on their way
             sg._early_reverse = None
-            if g_table.data_ptr() != early[2].data_ptr():
+            if early[2] is not None and g_table.data_ptr() != early[2].data_ptr():
                 raise RuntimeError("sharded max backward: the table gradient was replaced after its halo rows started "
                                    "travelling (the table has more than one consumer?)")
             return None, sg.reverse_exchange(g_table, started=early[1]), None
