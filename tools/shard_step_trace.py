@@ -26,13 +26,26 @@ sg = ShardedGraph.from_global(ei, n, rounds=R, self_halo_rows=n // W)
 table = sg.alloc_table(f)
 sg.own_rows(table).copy_(torch.randn(n, f, device="cuda"))
 out = torch.empty(sg.n_own, f, device="cuda")
+mode = sys.argv[1] if len(sys.argv) > 1 else "forward"              # "train": forward + backward (reverse exchange) per step
+x_own = torch.randn(n, f, device="cuda", requires_grad=True)
+g_out = torch.randn(sg.n_own, f, device="cuda")
+
+
+def step():
+    if mode == "train":
+        x_own.grad = None
+        sg.aggregate_trainable(x_own, L.SUM, w=None).backward(g_out)
+    else:
+        sg.aggregate(table, L.SUM, w=None, out=out)
+
+
 for _ in range(3):
-    sg.aggregate(table, L.SUM, w=None, out=out)
+    step()
 torch.cuda.synchronize()
 import time                                                           # noqa: E402
 time.sleep(0.3)                                                       # an idle gap: trace_overlap.py cuts phases at it
 for _ in range(5):
-    sg.aggregate(table, L.SUM, w=None, out=out)
+    step()
 torch.cuda.synchronize()
 from tf_geometric_amd.dist.transport import close_transports         # noqa: E402
 close_transports()

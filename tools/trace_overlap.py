@@ -26,7 +26,7 @@ ph = rows[cut:]
 
 
 def is_comm(name):
-    return "nccl" in name.lower() or "rccl" in name.lower() or "halo_pack" in name or "pack_rows" in name
+    return "nccl" in name.lower() or "rccl" in name.lower()
 
 
 def union(iv):
