@@ -53,6 +53,7 @@ struct tfgx_halo_plan {
     std::vector<int64_t> pack_off;                     // row offsets into send_idx / send_buf (packed entries only)
     const int32_t* send_idx;                           // device
     std::vector<hipEvent_t> packed, done, rdone;       // per round (rdone: the reverse exchange)
+    int reverse_rounds_started = 0;                    // tfgx_halo_reverse_start_round bookkeeping
     bool in_flight, reverse_in_flight;
 };
 
@@ -258,11 +259,14 @@ extern "C" int tfgx_halo_exchange_finish(tfgx_halo_plan* p, int32_t round, void*
 }
 
 // ---- backward of the exchange: halo-row gradients return to their owners along the same lists, reversed
-extern "C" int tfgx_halo_reverse_start(tfgx_halo_plan* p, const float* d_halo, int64_t F, float* back_buf,
-                                       size_t back_buf_floats, void* nccl_comm, void* compute_stream, void* comm_stream)
+extern "C" int tfgx_halo_reverse_start_round(tfgx_halo_plan* p, int32_t round, const float* d_halo, int64_t F,
+                                             float* back_buf, size_t back_buf_floats, void* nccl_comm,
+                                             void* compute_stream, void* comm_stream)
 {
     DIST_REQUIRE(p != nullptr, "plan is null");
     DIST_REQUIRE(F >= 1, "bad F");
+    DIST_REQUIRE(round >= 0 && round < p->rounds, "bad round");
+    DIST_REQUIRE(round == p->reverse_rounds_started, "reverse rounds are started in order 0, 1, ..., R - 1");
     const int64_t rows_sent = p->send_off.back(), rows_recv = p->recv_off.back();
     DIST_REQUIRE(rows_recv == 0 || d_halo != nullptr, "d_halo is null");
     DIST_REQUIRE(rows_sent == 0 || (back_buf && back_buf_floats >= size_t(rows_sent) * size_t(F)), "back_buf too small");
@@ -270,29 +274,46 @@ extern "C" int tfgx_halo_reverse_start(tfgx_halo_plan* p, const float* d_halo, i
     hipStream_t cs = reinterpret_cast<hipStream_t>(compute_stream);
     hipStream_t ms = reinterpret_cast<hipStream_t>(comm_stream);
     ncclComm_t comm = reinterpret_cast<ncclComm_t>(nccl_comm);
-    if (p->reverse_in_flight) {   // a previous reverse exchange may still be writing back_buf
+    if (round == 0 && p->reverse_in_flight) {   // a previous reverse exchange may still be writing back_buf
         for (int j = 0; j < p->rounds; ++j) DIST_HIP(hipStreamWaitEvent(cs, p->rdone[j], 0));
+        p->reverse_in_flight = false;
     }
-    // d_halo is produced on the compute stream (the transposed local pass): order the sends after it
-    DIST_HIP(hipEventRecord(p->packed[0], cs));
-    DIST_HIP(hipStreamWaitEvent(ms, p->packed[0], 0));
-    for (int j = 0; j < p->rounds; ++j) {
-        const size_t base = size_t(j) * size_t(p->world);
-        if (nccl_comm != nullptr) {
-            DIST_NCCL(ncclGroupStart());
-            for (int q = 0; q < p->world; ++q) {
-                // what I RECEIVED from q in the forward exchange is what I now SEND to q, and vice versa
-                const int64_t sc = p->recv_counts[base + q], rc = p->send_counts[base + q];
-                if (sc > 0)
-                    DIST_NCCL(ncclSend(d_halo + p->recv_off[base + q] * F, size_t(sc) * size_t(F), ncclFloat, q, comm, ms));
-                if (rc > 0)
-                    DIST_NCCL(ncclRecv(back_buf + p->send_off[base + q] * F, size_t(rc) * size_t(F), ncclFloat, q, comm, ms));
-            }
-            DIST_NCCL(ncclGroupEnd());
+    // round `round`'s rows of d_halo are produced on the compute stream (that window of the transposed local pass): order
+    // the sends after it — later windows may still be running while this round is on the wire
+    DIST_HIP(hipEventRecord(p->packed[round], cs));
+    DIST_HIP(hipStreamWaitEvent(ms, p->packed[round], 0));
+    const size_t base = size_t(round) * size_t(p->world);
+    if (nccl_comm != nullptr) {
+        DIST_NCCL(ncclGroupStart());
+        for (int q = 0; q < p->world; ++q) {
+            // what I RECEIVED from q in the forward exchange is what I now SEND to q, and vice versa
+            const int64_t sc = p->recv_counts[base + q], rc = p->send_counts[base + q];
+            if (sc > 0)
+                DIST_NCCL(ncclSend(d_halo + p->recv_off[base + q] * F, size_t(sc) * size_t(F), ncclFloat, q, comm, ms));
+            if (rc > 0)
+                DIST_NCCL(ncclRecv(back_buf + p->send_off[base + q] * F, size_t(rc) * size_t(F), ncclFloat, q, comm, ms));
         }
-        DIST_HIP(hipEventRecord(p->rdone[j], ms));
+        DIST_NCCL(ncclGroupEnd());
     }
-    p->reverse_in_flight = true;
+    DIST_HIP(hipEventRecord(p->rdone[round], ms));
+    if (++p->reverse_rounds_started == p->rounds) {
+        p->reverse_rounds_started = 0;
+        p->reverse_in_flight = true;
+    }
+    return TFGX_OK;
+}
+
+extern "C" int tfgx_halo_reverse_start(tfgx_halo_plan* p, const float* d_halo, int64_t F, float* back_buf,
+                                       size_t back_buf_floats, void* nccl_comm, void* compute_stream, void* comm_stream)
+{
+    DIST_REQUIRE(p != nullptr, "plan is null");
+    DIST_REQUIRE(p->reverse_rounds_started == 0, "a round-by-round reverse exchange is half started");
+    for (int j = 0; j < p->rounds; ++j) {
+        const int rc = tfgx_halo_reverse_start_round(p, j, d_halo, F, back_buf, back_buf_floats, nccl_comm, compute_stream,
+                                                     comm_stream);
+        if (rc != TFGX_OK) return rc;
+    }
+    if (p->rounds == 0) p->reverse_in_flight = true;
     return TFGX_OK;
 }
 

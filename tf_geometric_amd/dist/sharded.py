@@ -735,11 +735,20 @@ class ShardedGraph(object):
             self._tl_hub = [(hub_fn(rp_t[a:], rp_t[a + 1:], 1, m, self.num_edges) if (hub_fn and m > 0) else None) or False
                             for a, m in ((n_own, n_halo), (0, n_own))]
         # halo rows FIRST: their gradients belong to peers and start travelling (reverse exchange, asynchronous on the
-        # communication stream) while the own rows' part of the transposed pass runs on the compute stream
-        if n_halo > 0:
-            kw = {"hub": self._tl_hub[0]} if self._tl_hub[0] else {}
-            be.segment_reduce(rp_t[n_own:], rp_t[n_own + 1:], 1, dst_t, wt, n_halo, g, d_table[n_own:n_own + n_halo], L.SUM, **kw)
-        handle = self.transport.reverse_start(self, d_table)
+        # communication stream) while the rest of the transposed pass runs on the compute stream — round by round (the halo
+        # table is round-major): round j's window, then round j's sends, so each round is on the wire under the windows that
+        # follow; hub sources in the halo (chunk lists span the whole halo range) keep one window and one start
+        if n_halo > 0 and self._tl_hub[0]:
+            be.segment_reduce(rp_t[n_own:], rp_t[n_own + 1:], 1, dst_t, wt, n_halo, g, d_table[n_own:n_own + n_halo], L.SUM,
+                              hub=self._tl_hub[0])
+            handle = self.transport.reverse_start(self, d_table)
+        else:
+            handle = None
+            for j in range(self.rounds):
+                lo, hi = n_own + int(self.round_offset[j]), n_own + int(self.round_offset[j + 1])
+                if hi > lo:
+                    be.segment_reduce(rp_t[lo:], rp_t[lo + 1:], 1, dst_t, wt, hi - lo, g, d_table[lo:hi], L.SUM)
+                handle = self.transport.reverse_start_round(self, d_table, j, handle)
         if n_own > 0:
             kw = {"hub": self._tl_hub[1]} if self._tl_hub[1] else {}
             be.segment_reduce(rp_t, rp_t[1:], 1, dst_t, wt, n_own, g, d_table[:n_own], L.SUM, **kw)

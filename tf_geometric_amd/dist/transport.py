@@ -46,6 +46,7 @@ _DIST_SIGNATURES = {
     "tfgx_halo_exchange_start": (ctypes.c_int, [_P, _P, _I64, _I64, _P, _I64, _P, _SZ, _P, _P, _P]),
     "tfgx_halo_exchange_finish": (ctypes.c_int, [_P, _I32, _P]),
     "tfgx_halo_reverse_start": (ctypes.c_int, [_P, _P, _I64, _P, _SZ, _P, _P, _P]),
+    "tfgx_halo_reverse_start_round": (ctypes.c_int, [_P, _I32, _P, _I64, _P, _SZ, _P, _P, _P]),
     "tfgx_halo_reverse_finish": (ctypes.c_int, [_P, _P, _I64, _I64, _P, _P]),
 }
 _dist_lib = None
@@ -226,6 +227,27 @@ class TfgxDistTransport(object):
                 "tfgx_halo_reverse_start")
         return [plan, back, d_table]
 
+    def reverse_start_round(self, sg, d_table, j, handle=None):
+        """Round j (0, 1, ..., R - 1 in order) of the reverse exchange, posted after whatever wrote round j's rows of
+        d_table[n_own:] on the current stream — the caller computes the transposed pass window by window.  -> handle (pass it
+        to the next round and to reverse_finish)."""
+        if sg.rounds == 0 or sg.n_halo + sum(sg.send_counts) == 0:
+            return None
+        plan = self._plans(sg)[2]
+        U = int(d_table.shape[1])
+        if handle is None:
+            assert d_table.is_contiguous()
+            back = torch.empty((max(sg._xrows_sent, 1), U), dtype=torch.float32, device=self.device)
+            back.record_stream(self.comm_stream)
+            d_table.record_stream(self.comm_stream)
+            handle = [plan, back, d_table]
+        d_halo = d_table[sg.n_own:]
+        _dcheck(self.lib.tfgx_halo_reverse_start_round(plan, int(j), L.ptr(d_halo), U, L.ptr(handle[1]),
+                                                       int(handle[1].numel()), self._comm(), L.stream_ptr(),
+                                                       ctypes.c_void_p(self.comm_stream.cuda_stream)),
+                "tfgx_halo_reverse_start_round")
+        return handle
+
     def reverse_finish(self, sg, handle, d_own):
         if handle is None:
             return d_own
@@ -326,25 +348,33 @@ class TorchDistTransport(object):
     def reverse_start(self, sg, d_table):
         if sg.rounds == 0:
             return None
+        backs = None
+        for j in range(sg.rounds):
+            backs = self.reverse_start_round(sg, d_table, j, backs)
+        return backs
+
+    def reverse_start_round(self, sg, d_table, j, handle=None):
+        if sg.rounds == 0:
+            return None
         be = sg.backend
         U = int(d_table.shape[1])
         d_halo = d_table[sg.n_own:sg.n_table]
-        backs = []
-        for j in range(sg.rounds):
-            seg = d_halo[int(sg.round_offset[j]):int(sg.round_offset[j + 1])].contiguous()
-            n_back = int(sum(sg.round_send_counts[j]))
-            out_splits, in_splits = list(sg.round_send_counts[j]), list(sg.round_recv_counts[j])
-            if self.world == 1:
-                back = seg.clone()
-            elif self.nccl:
-                back = be.empty((n_back, U))
-                dist.all_to_all_single(back, seg, out_splits, in_splits, group=self.group)
-            else:
-                back_h = torch.empty((n_back, U), dtype=torch.float32)
-                dist.all_to_all_single(back_h, seg.cpu(), out_splits, in_splits, group=self.group)
-                back = be.empty((n_back, U))
-                back.copy_(back_h)
-            backs.append(back)
+        backs = [] if handle is None else handle
+        assert len(backs) == j, "reverse rounds are started in order"
+        seg = d_halo[int(sg.round_offset[j]):int(sg.round_offset[j + 1])].contiguous()
+        n_back = int(sum(sg.round_send_counts[j]))
+        out_splits, in_splits = list(sg.round_send_counts[j]), list(sg.round_recv_counts[j])
+        if self.world == 1:
+            back = seg.clone()
+        elif self.nccl:
+            back = be.empty((n_back, U))
+            dist.all_to_all_single(back, seg, out_splits, in_splits, group=self.group)
+        else:
+            back_h = torch.empty((n_back, U), dtype=torch.float32)
+            dist.all_to_all_single(back_h, seg.cpu(), out_splits, in_splits, group=self.group)
+            back = be.empty((n_back, U))
+            back.copy_(back_h)
+        backs.append(back)
         return backs
 
     def reverse_finish(self, sg, backs, d_own):
