@@ -792,9 +792,10 @@ def test_tracked_max_span_by_span_equals_one_launch(tfg, oracle, f, weighted, k1
     # to [0, n_first): the same gradient bit for bit
     seen = {}
 
-    def hook(gx):
-        seen["tail"] = gx[n // 3:].clone()
-    passes.halo_first = (n // 3, hook)
+    def hook(j, gx):
+        seen[j] = gx[n // 3 + j * 100:(n if j == 1 else n // 3 + 100)].clone()
+    passes.halo_first = (n // 3, [(n // 3, n // 3 + 100), (n // 3 + 100, n)], hook)     # two windows, as two exchange rounds
     xc = xd.clone().requires_grad_(True)
     AG.aggregate(plan, xc, L.MAX, w_csr=w, max_passes=passes).backward(g)
-    assert torch.equal(xa.grad, xc.grad) and torch.equal(seen["tail"], xa.grad[n // 3:])
+    assert torch.equal(xa.grad, xc.grad)
+    assert torch.equal(seen[0], xa.grad[n // 3:n // 3 + 100]) and torch.equal(seen[1], xa.grad[n // 3 + 100:])

@@ -176,7 +176,7 @@ class _AggregateMax(torch.autograd.Function):
             packed = torch.empty((plan.n_dst, F), dtype=torch.int32, device=x2.device)
             passes(x2, wd, out, packed)
             count = None
-            ctx.halo_first = getattr(passes, "halo_first", None)     # (n_own, callable(gx)): see backward
+            ctx.halo_first = getattr(passes, "halo_first", None)     # (n_own, [(lo, hi) per round], callable(j, gx)): see backward
         elif _max_mode() == "mask" and can_track(plan, x2, ldx):
             # the tuned forward walk (8 gathered rows in flight per lane group) with the tie count and the position of the
             # first maximal edge tracked online and written PACKED (one uint32 per element instead of a float count array
@@ -255,10 +255,14 @@ class _AggregateMax(torch.autograd.Function):
                         "tfgx_segment_max_backward_mask_phases_f32 (packed)")
                 hf = getattr(ctx, "halo_first", None)
                 if hf is not None and 0 < hf[0] < n_table:
-                    # sharded table [own | halo]: the halo rows' gradients belong to peers — compute them first and let them
-                    # travel (reverse exchange on the communication stream) while the own rows' part runs
-                    run(3, hf[0], n_table)
-                    hf[1](gx)
+                    # sharded table [own | halo]: the halo rows' gradients belong to peers — compute them first, window by
+                    # window (one per exchange round), and let each window travel (reverse exchange on the communication
+                    # stream) while the following windows and the own rows' part run
+                    run(1, 0, 0)                                   # masks + g / count, once
+                    for j, (lo, hi) in enumerate(hf[1]):
+                        if hi > lo:
+                            run(2, lo, hi)
+                        hf[2](j, gx)
                     run(2, 0, hf[0])
                 else:
                     run(3, 0, n_table)
@@ -457,7 +461,7 @@ class _GatAttention(torch.autograd.Function):
         forward as span passes + merge under a halo exchange; same (out, stats), so the backward is unchanged."""
         from .nn.conv.gat import gat_attention
         stats = torch.empty((plan.n_dst, 2 * num_heads), dtype=torch.float32, device=V.device)
-        ctx.halo_first = getattr(passes, "halo_first", None)        # (n_own, callable(d[K | V] table)): see backward
+        ctx.halo_first = getattr(passes, "halo_first", None)   # (n_own, [(lo, hi) per round], callable(j, d[K | V])): see backward
         if passes is not None:
             assert float(drop_rate) == 0.0 and scale_d is None
             out = passes(Q.detach(), K.detach(), V.detach(), stats)
@@ -538,15 +542,17 @@ class _GatAttention(torch.autograd.Function):
             # the K / V / gradient pointers move with the window), their gradients start travelling, then the own rows
             n_own = int(hf[0])
             full = (a.row_ptr_t, a.n_src, a.k, a.v, a.grad_k, a.grad_v, a.add_self_loop, a.row_order_t)
-            a.row_ptr_t = pt.row_ptr.data_ptr() + 4 * n_own
-            a.n_src = n_tab - n_own
-            a.k, a.v = K2.data_ptr() + 4 * ldk * n_own, V2.data_ptr() + 4 * ldv * n_own
-            a.grad_k = gk.data_ptr() + 4 * int(gk.stride(0)) * n_own
-            a.grad_v = gv.data_ptr() + 4 * int(gv.stride(0)) * n_own
             a.add_self_loop, a.row_order_t = 0, 0
-            L.check(lib.tfgx_gat_backward_src_hub_f32(ctypes.byref(a), None, None, L.stream_ptr()),
-                    "tfgx_gat_backward_src_hub_f32 (halo rows)")
-            hf[1](gkv)
+            for j, (lo, hi) in enumerate(hf[1]):               # one window per exchange round (the halo rows are round-major)
+                if hi > lo:
+                    a.row_ptr_t = pt.row_ptr.data_ptr() + 4 * lo
+                    a.n_src = hi - lo
+                    a.k, a.v = K2.data_ptr() + 4 * ldk * lo, V2.data_ptr() + 4 * ldv * lo
+                    a.grad_k = gk.data_ptr() + 4 * int(gk.stride(0)) * lo
+                    a.grad_v = gv.data_ptr() + 4 * int(gv.stride(0)) * lo
+                    L.check(lib.tfgx_gat_backward_src_hub_f32(ctypes.byref(a), None, None, L.stream_ptr()),
+                            "tfgx_gat_backward_src_hub_f32 (halo rows)")
+                hf[2](j, gkv)
             a.row_ptr_t, a.n_src, a.k, a.v, a.grad_k, a.grad_v, a.add_self_loop, a.row_order_t = full
             a.n_src, a.row_order_t = n_own, 0
             L.check(lib.tfgx_gat_backward_src_hub_f32(ctypes.byref(a), None, None, L.stream_ptr()),

@@ -143,11 +143,8 @@ class HipBackend(object):
                 # K and V are the column blocks of ONE halo table: the backward writes d[K | V] into one buffer and sends
                 # its halo rows back before it computes the own rows (matched to the table's exchange node by its storage)
                 token = int(base.data_ptr())
-
-                def start_reverse(gkv):
-                    sg.counters["gat_halo_first_backwards"] = sg.counters.get("gat_halo_first_backwards", 0) + 1
-                    sg._early_reverse = (token, sg.transport.reverse_start(sg, gkv), None)
-                passes.halo_first = (sg.n_own, start_reverse)
+                passes.halo_first = (sg.n_own, sg.halo_round_windows(),
+                                     sg._early_reverse_rounds(token, "gat_halo_first_backwards", check_ptr=False))
         return AG.gat_attention(sg.local_plan(), Q, K, V, num_heads, passes=passes)
 
     def hub_lists(self, row_begin, row_end, rp_stride, n_dst, num_edges):
@@ -685,11 +682,7 @@ class ShardedGraph(object):
 
         token = int(table.data_ptr())
 
-        def start_reverse(gx):
-            # called by the max backward once the halo rows of d(table) are final: they start travelling now; the
-            # _HaloGather node of THIS table (matched by its storage) finishes the exchange instead of starting one
-            self.counters["max_halo_first_backwards"] = self.counters.get("max_halo_first_backwards", 0) + 1
-            self._early_reverse = (token, self.transport.reverse_start(self, gx), gx)
+        start_reverse = self._early_reverse_rounds(token, "max_halo_first_backwards", check_ptr=True)
 
         def run(x2_, w_, out, packed):
             self.counters["max_span_forwards"] = self.counters.get("max_span_forwards", 0) + 1
@@ -699,8 +692,28 @@ class ShardedGraph(object):
                         self.exchange_finish(handles, k - 1)      # class k reads the rows of round k - 1
                     be.segment_reduce(rpk[k:], rpk[k + 1:], K1, self.col, w_, self.n_own, x2_, out, L.MAX,
                                       accumulate=k > 0, track=packed, track_row_begin=rpk)
-        run.halo_first = (self.n_own, start_reverse)
+        run.halo_first = (self.n_own, self.halo_round_windows(), start_reverse)
         return run
+
+    def halo_round_windows(self):
+        """Table-row windows [lo, hi) of the halo rows, one per exchange round (the halo part of the table is round-major)."""
+        return [(self.n_own + int(self.round_offset[j]), self.n_own + int(self.round_offset[j + 1]))
+                for j in range(self.rounds)]
+
+    def _early_reverse_rounds(self, token, counter, check_ptr):
+        """callable(j, d_table) for the backward of a trainable aggregation on the [own | halo] table: called once per round,
+        in order, as soon as round j's rows of d_table are final — they start travelling (tfgx_halo_reverse_start_round); after
+        the last round the _HaloGather node of THIS table (matched by its storage `token`) finds the exchange started and only
+        finishes it."""
+        state = {"handle": None}
+
+        def start_round(j, d_table):
+            state["handle"] = self.transport.reverse_start_round(self, d_table, j, state["handle"])
+            if j == self.rounds - 1:
+                self.counters[counter] = self.counters.get(counter, 0) + 1
+                self._early_reverse = (token, state["handle"], d_table if check_ptr else None)
+                state["handle"] = None
+        return start_round
 
     def local_plan(self):
         """This shard as an [n_own x n_table] CSR operator (plan.CsrPlan over row_ptr / col — rows stay contiguous
