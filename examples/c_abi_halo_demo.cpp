@@ -108,7 +108,9 @@ int main()
         HK(hipMemcpy(d_dhalo, dh.data(), dh.size() * 4, hipMemcpyHostToDevice));
         HK(hipMemset(d_down, 0, n_own * F * 4));
         HK(hipDeviceSynchronize());
-        CK(tfgx_halo_reverse_start(p2, d_dhalo, F, d_back, size_t(457) * F, comm, compute, comms));
+        // round by round (a host that computes the halo gradients window by window posts each round as soon as it is ready)
+        for (int j = 0; j < rounds; ++j)
+            CK(tfgx_halo_reverse_start_round(p2, j, d_dhalo, F, d_back, size_t(457) * F, comm, compute, comms));
         CK(tfgx_halo_reverse_finish(p2, d_down, F, F, d_back, compute));
         HK(hipStreamSynchronize(compute));
         HK(hipMemcpy(down.data(), d_down, down.size() * 4, hipMemcpyDeviceToHost));
