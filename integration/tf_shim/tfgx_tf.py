@@ -84,7 +84,8 @@ def _register_gradients(tf, ops):
         raise NotImplementedError("second-order gradients are not provided")
 
 
-def gcn_layer(x, edge_index, edge_weight, kernel, bias, num_nodes, activation_is_relu=False, cache=None):
+def gcn_layer(x, edge_index, edge_weight, kernel, bias, num_nodes, activation_is_relu=False, cache=None,
+              inference_only=False):
     """tfg.layers.GCN.call on the ops (norm='both', renorm=True: the layer's defaults, layers/conv/gcn.py:32-40).
     `cache`: the dict the reference keeps its normalised adjacency in (nn/conv/gcn.py:125-128); here it keeps the plan."""
     import tensorflow as tf
@@ -99,6 +100,13 @@ def gcn_layer(x, edge_index, edge_weight, kernel, bias, num_nodes, activation_is
             cache["tfgx_plan"] = plan
     row_ptr, col, w_norm, self_coef = plan
     empty = tf.zeros([0], tf.float32)
+    f_in, units = int(x.shape[-1]), int(kernel.shape[-1])
+    fits = units > f_in and f_in % 4 == 0 and f_in <= 128 and units <= 256 and \
+        4 * (f_in * (-(-units // 128) * 128 + 8) + 2 * f_in * 65) + 576 <= 160 * 1024           # tfgx_aggregate_gemm_fits
+    if fits and inference_only:
+        # (A_hat x) W in ONE launch: the aggregate never visits HBM (inference: the op registers no gradient)
+        return ops.tfgx_aggregate_gemm(row_ptr=row_ptr, col=col, w=w_norm, x=x, self_coef=self_coef, kernel=kernel,
+                                       bias=empty if bias is None else bias, op=0, act=1 if activation_is_relu else 0)
     h = ops.tfgx_gemm_bias_act(x=x, kernel=kernel, bias=empty, act=0)            # gcn.py:272
     return ops.tfgx_segment_reduce(row_ptr=row_ptr, col=col, w=w_norm, x=h, self_coef=self_coef,
                                    bias=empty if bias is None else bias, op=0, act=1 if activation_is_relu else 0)

@@ -208,6 +208,58 @@ class TfgxGemmBiasActOp : public OpKernel {
 };
 REGISTER_KERNEL_BUILDER(Name("TfgxGemmBiasAct").Device(DEVICE_GPU), TfgxGemmBiasActOp);
 
+// The aggregate-then-project layers in ONE launch (tfgx_aggregate_gemm_f32: GCN with units > F evaluated as (A_hat x) W,
+// nn/conv/gcn.py:272-288; the neighbour half of mean / sum GraphSAGE, nn/conv/graph_sage.py:34-58).  Inference only: its
+// gradient would need the [N, F] aggregate the fusion avoids writing, so tfgx_tf.py uses it outside a GradientTape and
+// falls back to TfgxSegmentReduce + TfgxGemmBiasAct when tfgx_aggregate_gemm_fits says no.
+REGISTER_OP("TfgxAggregateGemm")
+    .Input("row_ptr: int32")
+    .Input("col: int32")
+    .Input("w: float")          // [E] in CSR order, or [0]
+    .Input("x: float")          // [N_src, F]
+    .Input("self_coef: float")  // [N] or [0]
+    .Input("kernel: float")     // [F, U]
+    .Input("bias: float")       // [U] or [0]
+    .Attr("op: int")            // 0 sum, 1 mean
+    .Attr("act: int = 0")
+    .Output("out: float");      // [N, U]
+
+class TfgxAggregateGemmOp : public OpKernel {
+ public:
+  explicit TfgxAggregateGemmOp(OpKernelConstruction* c) : OpKernel(c) {
+    OP_REQUIRES_OK(c, c->GetAttr("op", &op_));
+    OP_REQUIRES_OK(c, c->GetAttr("act", &act_));
+  }
+  void Compute(OpKernelContext* ctx) override {
+    const Tensor &rp = ctx->input(0), &col = ctx->input(1), &w = ctx->input(2), &x = ctx->input(3);
+    const Tensor &sc = ctx->input(4), &k = ctx->input(5), &bias = ctx->input(6);
+    const int64_t n = rp.dim_size(0) - 1, F = x.dim_size(1), U = k.dim_size(1);
+    OP_REQUIRES(ctx, k.dim_size(0) == F, errors::InvalidArgument("x and kernel do not agree on F"));
+    OP_REQUIRES(ctx, tfgx_aggregate_gemm_fits(F, U) == 1,
+                errors::InvalidArgument("shape outside tfgx_aggregate_gemm_fits: use TfgxSegmentReduce + TfgxGemmBiasAct"));
+    Tensor* out = nullptr;
+    OP_REQUIRES_OK(ctx, ctx->allocate_output(0, {n, U}, &out));
+    tfgx_reduce_args a = {};
+    a.row_begin = rp.flat<int32>().data();
+    a.row_end = a.row_begin + 1;
+    a.rp_stride = 1;
+    a.col = col.flat<int32>().data();
+    a.w = w.NumElements() ? w.flat<float>().data() : nullptr;
+    a.n_dst = n;
+    a.x = x.flat<float>().data();
+    a.ldx = F;
+    a.F = F;
+    a.op = op_;
+    a.self_coef = sc.NumElements() ? sc.flat<float>().data() : nullptr;
+    OP_REQUIRES(ctx, tfgx_aggregate_gemm_f32(&a, k.flat<float>().data(), U,
+                                             bias.NumElements() ? bias.flat<float>().data() : nullptr, act_,
+                                             out->flat<float>().data(), U, U, TfStream(ctx)) == 0,
+                errors::Internal(tfgx_last_error()));
+  }
+  int op_, act_;
+};
+REGISTER_KERNEL_BUILDER(Name("TfgxAggregateGemm").Device(DEVICE_GPU), TfgxAggregateGemmOp);
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Backward ops (round 3; still NEVER LINKED OR RUN — see the header of this file).  The gradients are registered on the
 // Python side, integration/tf_shim/tfgx_tf.py (@tf.RegisterGradient), in terms of the ops of this file:

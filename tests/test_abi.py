@@ -195,7 +195,7 @@ def test_tf_shim_compiles_against_mock_headers():
                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     assert res.returncode == 0, res.stdout.decode()
     src = open(os.path.join(shim, "tfgx_tf_ops.cc")).read()
-    ops = ("TfgxBuildCsrByDst", "TfgxSegmentReduce", "TfgxGatFused", "TfgxGcnNormEdges", "TfgxGemmBiasAct",
+    ops = ("TfgxBuildCsrByDst", "TfgxSegmentReduce", "TfgxGatFused", "TfgxGcnNormEdges", "TfgxGemmBiasAct", "TfgxAggregateGemm",
            # round 3: the backward ops and the sharded path
            "TfgxSddmm", "TfgxPermuteRows", "TfgxGemmTn", "TfgxReluBackward", "TfgxHaloExchange", "TfgxHaloReverse",
            "TfgxAllReduceSum")
