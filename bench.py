@@ -322,6 +322,14 @@ def main():
         out = torch.empty((n, f), dtype=torch.float32, device=x.device)
         torch.cuda.synchronize()
         plan_s = time.perf_counter() - t0
+        # the same again with the edge list already on the device and the code objects loaded: what a second graph costs
+        # (plan_build_s above includes the host -> device copies of 1 GB of edges + 1 GB of features and first-use set-up)
+        t1 = time.perf_counter()
+        adj2 = tfg.SparseMatrix(ei, None, [n, n])
+        normed2 = gcn_norm_adj(adj2, cache={})
+        torch.cuda.synchronize()
+        plan_rebuild_s = time.perf_counter() - t1
+        del adj2, normed2
         from tf_geometric_amd.plan import segment_reduce
 
         def step():
@@ -403,6 +411,8 @@ def main():
                    "partition": "single GPU" if world == 1 else "dst-range x{} + RCCL halo all-to-all-v".format(world)},
         "plan_build_s": plan_s,
     }
+    if world == 1:
+        line["plan_rebuild_on_device_s"] = plan_rebuild_s
     if world > 1:
         # which exchange implementation carried the halo rows: "tfgx_dist" = the C ABI of include/tfgx_dist.h (in-process
         # ncclComm_t, grouped ncclSend / ncclRecv on a second HIP stream) — the product path on RCCL; "torch" only for the
