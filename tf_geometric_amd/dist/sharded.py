@@ -1100,6 +1100,9 @@ class _HaloGather(torch.autograd.Function):
         ctx.sg = sg
         table = sg.alloc_table(int(h_own.shape[1]))
         ctx.table_ptr = int(table.data_ptr())
+        early = getattr(sg, "_early_reverse", None)
+        if early is not None and early[0] == ctx.table_ptr:
+            sg._early_reverse = None       # a stale entry of an earlier table at this address (its backward was abandoned)
         sg.own_rows(table).copy_(h_own.detach())
         handle = sg.exchange_start(table)
         if defer:
