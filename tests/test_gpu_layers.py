@@ -471,8 +471,8 @@ def test_fused_aggregate_gemm_on_a_graph_with_hub_rows(tfg, oracle, mode, f, uni
     ei = np.concatenate([ei, hubs], axis=1)
     x = rng.standard_normal((n, f), dtype=np.float32)
     k, b = oracle.glorot_uniform(rng, f, units), (rng.standard_normal(units) * 0.1).astype(np.float32)
-    old = (P.HUB_THRESHOLD, P.HUB_CHUNK, P.FUSE_ON_SKEWED_WIDE)
-    P.HUB_THRESHOLD, P.HUB_CHUNK, P.FUSE_ON_SKEWED_WIDE = thr, max(8, thr // 2), True     # (wide outputs too: kernel test)
+    old = (P.HUB_THRESHOLD, P.HUB_CHUNK)
+    P.HUB_THRESHOLD, P.HUB_CHUNK = thr, max(8, thr // 2)
     try:
         plan = P.CsrPlan.build(L.as_i32(ei), n, n)
         hub = plan.hub_info()
@@ -487,7 +487,7 @@ def test_fused_aggregate_gemm_on_a_graph_with_hub_rows(tfg, oracle, mode, f, uni
         agg = P.segment_reduce(plan, xd, op, w_csr=w_csr, self_coef=sc)
         two = P.gemm_bias_act(agg, kd, bias=bd, act=L.ACT_RELU)
     finally:
-        P.HUB_THRESHOLD, P.HUB_CHUNK, P.FUSE_ON_SKEWED_WIDE = old
+        P.HUB_THRESHOLD, P.HUB_CHUNK = old
     ref = np.maximum(agg.double().cpu().numpy() @ k.astype(np.float64) + b, 0)
     assert_parity(fused.cpu().numpy(), ref, what="fused with hub rows vs float64 of the same aggregate")
     assert_parity(fused.cpu().numpy(), two.cpu().numpy(), what="fused with hub rows vs two launches")

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(kFusedThreads) void agg_gemm_kernel(const FArgs a)
         Ws[i] = (k < a.F && n < a.N) ? a.B[int64_t(k) * a.ldb + n] : 0.0f;
     }
     for (int i = tid; i < kBufs * a.KP * kLda; i += kFusedThreads) At[i] = 0.0f;      // rows k >= F stay zero for good
-    if (tid < kCtrlInts) ctrl[tid] = 0;
+    if (tid < 16) ctrl[tid] = 0;                            // ([6 + b]: finished halves of buffer b's tile)
     __syncthreads();
 
     const int64_t my_tiles = a.n_tiles > int64_t(blockIdx.x) ? (a.n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
@@ -202,12 +202,22 @@ __global__ __launch_bounds__(kFusedThreads) void agg_gemm_kernel(const FArgs a)
         int arrived = 0;
         if (lane64 == 0) arrived = atomicAdd(&ctrl[1 + buf], 1);
         arrived = __builtin_amdgcn_readfirstlane(arrived);
-        if (arrived != UNITS - 1) continue;
+        const int njobs = 2 * (a.n_blocks / 4);              // (32-row half) x (128-column group) blocks of the tile: 2 or 4
+        if (arrived < UNITS - njobs) continue;
 
-        // ---- consumer: this wave completed tile q -> C[tile rows, :] = act(At^T @ Ws + bias) --------------------------
+        // ---- consumers: the last arrivers of tile q each multiply ONE 32-row x 128-column block of it (the last one at once,
+        // the ones before it as soon as the tile is complete) -> C[tile rows, :] = act(At^T @ Ws + bias).  Two or four waves
+        // per tile: on tiles of short rows (the tail of a power-law graph in walk order) the producers are done in less than
+        // one wave's multiplication time, and a single consumer wave was what the launch waited for
+        const int job = UNITS - 1 - arrived;                 // the last arriver takes block 0, the one before it block 1, ...
+        if (job > 0) {
+            volatile int* arr = ctrl + 1 + buf;
+            while (*arr < UNITS) __builtin_amdgcn_s_sleep(1);
+        }
         __threadfence_block();
-        for (int mb = 0; mb < (a.dbg == 1 ? 0 : kTileRows / 32); ++mb) {
-            for (int nb0 = 0; nb0 < a.n_blocks; nb0 += 4) {         // n_blocks is a multiple of 4 (zero-padded columns of Ws)
+        const int half = job & 1, nb_first = (job >> 1) * 4;
+        for (int mb = half; mb < (a.dbg == 1 ? 0 : half + 1); ++mb) {
+            for (int nb0 = nb_first; nb0 < nb_first + 4; nb0 += 4) {     // n_blocks is a multiple of 4 (zero-padded columns of Ws)
                 f32x16 c4[4];
 #pragma unroll
                 for (int jb = 0; jb < 4; ++jb)
@@ -299,10 +309,17 @@ __global__ __launch_bounds__(kFusedThreads) void agg_gemm_kernel(const FArgs a)
             }
         }
         __threadfence_block();
-        // (every lane stores the same wave-uniform values: no single-lane branch around the hand-over)
-        ctrl[1 + buf] = 0;
-        __threadfence_block();
-        *reinterpret_cast<volatile int*>(ctrl + 1 + kBufs + buf) = q + 1;
+        int fin = 0;
+        if (lane64 == 0) fin = atomicAdd(&ctrl[6 + buf], 1);
+        fin = __builtin_amdgcn_readfirstlane(fin);
+        if (fin == njobs - 1) {
+            // the last block to finish hands the buffer back (wave-uniform branch; every lane stores the same values: no
+            // single-lane branch around the hand-over)
+            ctrl[1 + buf] = 0;
+            ctrl[6 + buf] = 0;
+            __threadfence_block();
+            *reinterpret_cast<volatile int*>(ctrl + 1 + kBufs + buf) = q + 1;
+        }
     }
 }
 

@@ -460,9 +460,6 @@ def segment_reduce(plan, x, op, w_csr=None, out=None, act=L.ACT_NONE, self_coef=
 FUSE_AGGREGATE_GEMM = True      # developer A/B switch (tools/ab_fused_layer.py): False = always two launches
 
 
-FUSE_ON_SKEWED_WIDE = False      # developer A/B: take the fused launch on skewed plans for outputs wider than 128 columns too
-
-
 def aggregate_gemm(plan, x, op, kernel, w_csr=None, self_coef=None, bias=None, act=L.ACT_NONE, out=None):
     """act(segment_reduce(plan, x, op, w_csr, self_coef) @ kernel + bias) in ONE launch (tfgx_aggregate_gemm_f32: the
     aggregate goes registers -> LDS -> MFMA, never through HBM), or None when the fused kernel does not take this call
@@ -478,11 +475,6 @@ def aggregate_gemm(plan, x, op, kernel, w_csr=None, self_coef=None, bias=None, a
         return None
     hub = plan.hub_info()      # long rows: chunk partials by a launch of the ordinary kernel, folded by the row's lane group
     order = plan.row_order()   # skewed plans: tiles of similar-length rows (degree order), results unchanged
-    if (hub is not None or order is not None) and N > 128 and not FUSE_ON_SKEWED_WIDE:
-        # measured on the R-MAT graph of bench.py (products size, tools/ab_fused_layer.py products rmat): the fused launch
-        # wins with a 128-column output (mean SAGE half: 10.31 vs 10.57 ms) and loses with 256 columns (GCN 100 -> 256: 11.75
-        # vs 10.77 ms: one consumer wave per tile scatters 64 KB of rows in walk order) — wide outputs take the two launches
-        return None
     n_dst = plan.n_dst
     if out is None:
         out = torch.empty((n_dst, N), dtype=torch.float32, device=x2.device)

@@ -36,9 +36,6 @@ k = torch.randn(f, 256, device="cuda") * 0.1
 agg_out = torch.empty(n, f, device="cuda")
 
 
-P.FUSE_ON_SKEWED_WIDE = True          # (the A/B measures the fused launch wherever it can run)
-
-
 def set_fuse(v):
     P.FUSE_AGGREGATE_GEMM = v
 
