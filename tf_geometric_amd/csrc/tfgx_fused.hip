@@ -11,9 +11,9 @@
 //     lane group) from an LDS counter, reduces it exactly like seg_reduce_kernel (G lanes per row, 4 columns per lane,
 //     (col, w) batches prefetched, 8 gathered rows in flight, one in-order FMA chain per output element), and stores the row
 //     into the tile.  Units are handed out dynamically, so a wave that drew short rows simply takes more of them;
-//   * consumer: the wave that completes a tile (per-tile arrival counter) multiplies it — 32x32 output blocks with
-//     v_mfma_f32_32x32x2_f32 against B from LDS, bias / activation in the epilogue, rows written straight to C — while the
-//     other 15 waves are already reducing the next tile into the other buffer.  No workgroup barrier after the B load: a
+//   * consumers: the last waves to arrive at a tile (per-tile arrival counter) each multiply one 32-row x 64-column block of
+//     it — v_mfma_f32_32x32x2_f32 against B from LDS, bias / activation in the epilogue, rows written straight to C — while
+//     the other waves are already reducing the next tile into the other buffer.  No workgroup barrier after the B load: a
 //     buffer is re-used only after its `done` sequence number says the previous occupant has been multiplied.
 // Deterministic (fixed per-row edge order, fixed k order), fp32 throughout.  Roofline: HBM (the gather), as the unfused
 // aggregation; the MFMA work (2 N F U flops = 0.8 ms of one wave per CU at products shape) rides on otherwise idle pipes.
@@ -30,6 +30,9 @@ constexpr int kLda = kTileRows + 1;
 constexpr int kBufs = 2;
 constexpr int kFusedThreads = 1024;
 constexpr int kCtrlInts = 1 + 2 * kBufs;
+#ifndef TFGX_FUSED_JB
+#define TFGX_FUSED_JB 2
+#endif
 
 struct FArgs {
     const int32_t* row_ptr;
@@ -202,12 +205,13 @@ __global__ __launch_bounds__(kFusedThreads) void agg_gemm_kernel(const FArgs a)
         int arrived = 0;
         if (lane64 == 0) arrived = atomicAdd(&ctrl[1 + buf], 1);
         arrived = __builtin_amdgcn_readfirstlane(arrived);
-        const int njobs = 2 * (a.n_blocks / 4);              // (32-row half) x (128-column group) blocks of the tile: 2 or 4
+        constexpr int JB = TFGX_FUSED_JB;                    // 32-column blocks per consumer job
+        const int njobs = 2 * (a.n_blocks / JB);
         if (arrived < UNITS - njobs) continue;
 
-        // ---- consumers: the last arrivers of tile q each multiply ONE 32-row x 128-column block of it (the last one at once,
-        // the ones before it as soon as the tile is complete) -> C[tile rows, :] = act(At^T @ Ws + bias).  Two or four waves
-        // per tile: on tiles of short rows (the tail of a power-law graph in walk order) the producers are done in less than
+        // ---- consumers: the last arrivers of tile q each multiply ONE 32-row x (32 JB)-column block of it (the last one at
+        // once, the ones before it as soon as the tile is complete) -> C[tile rows, :] = act(At^T @ Ws + bias).  Up to eight
+        // waves per tile (JB = 2 measured best: 4 halves the jobs, 1 loses the shared A operand): on tiles of short rows (the tail of a power-law graph in walk order) the producers are done in less than
         // one wave's multiplication time, and a single consumer wave was what the launch waited for
         const int job = UNITS - 1 - arrived;                 // the last arriver takes block 0, the one before it block 1, ...
         if (job > 0) {
@@ -215,51 +219,51 @@ __global__ __launch_bounds__(kFusedThreads) void agg_gemm_kernel(const FArgs a)
             while (*arr < UNITS) __builtin_amdgcn_s_sleep(1);
         }
         __threadfence_block();
-        const int half = job & 1, nb_first = (job >> 1) * 4;
+        const int half = job & 1, nb_first = (job >> 1) * JB;
         for (int mb = half; mb < (a.dbg == 1 ? 0 : half + 1); ++mb) {
-            for (int nb0 = nb_first; nb0 < nb_first + 4; nb0 += 4) {     // n_blocks is a multiple of 4 (zero-padded columns of Ws)
-                f32x16 c4[4];
+            for (int nb0 = nb_first; nb0 < nb_first + JB; nb0 += JB) {     // n_blocks is a multiple of 4 (zero-padded columns of Ws)
+                f32x16 c4[JB];
 #pragma unroll
-                for (int jb = 0; jb < 4; ++jb)
+                for (int jb = 0; jb < JB; ++jb)
 #pragma unroll
                     for (int t = 0; t < 16; ++t) c4[jb][t] = 0.0f;
                 const float* ap = ab + kh * kLda + mb * 32 + l31;
                 const float* bp = Ws + kh * a.LDW + nb0 * 32 + l31;
-                // KU k-pairs per step: all 5 * KU LDS reads of a step are issued before its 4 * KU MFMAs (a read-wait-multiply
+                // KU k-pairs per step: all (1 + JB) * KU LDS reads of a step are issued before its JB * KU MFMAs (a read-wait-multiply
                 // chain per MFMA left the single consumer wave at ~2.5x the MFMA time and the producers waiting for buffers)
                 constexpr int KU = 4;
                 const int pairs = a.KP / 2;
                 int pr = 0;
                 for (; pr + KU <= pairs; pr += KU) {
-                    float av[KU], bv[KU][4];
+                    float av[KU], bv[KU][JB];
 #pragma unroll
                     for (int t = 0; t < KU; ++t) {
                         av[t] = ap[(2 * (pr + t)) * kLda];
 #pragma unroll
-                        for (int jb = 0; jb < 4; ++jb) bv[t][jb] = bp[(2 * (pr + t)) * a.LDW + jb * 32];
+                        for (int jb = 0; jb < JB; ++jb) bv[t][jb] = bp[(2 * (pr + t)) * a.LDW + jb * 32];
                     }
                     __builtin_amdgcn_sched_barrier(0);      // left alone the scheduler sinks every read next to its MFMA
 #pragma unroll
                     for (int t = 0; t < KU; ++t)
 #pragma unroll
-                        for (int jb = 0; jb < 4; ++jb)
+                        for (int jb = 0; jb < JB; ++jb)
                             c4[jb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t][jb], c4[jb], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 for (; pr < pairs; ++pr) {
                     const float av = ap[(2 * pr) * kLda];
-                    float bv[4];
+                    float bv[JB];
 #pragma unroll
-                    for (int jb = 0; jb < 4; ++jb) bv[jb] = bp[(2 * pr) * a.LDW + jb * 32];
+                    for (int jb = 0; jb < JB; ++jb) bv[jb] = bp[(2 * pr) * a.LDW + jb * 32];
 #pragma unroll
-                    for (int jb = 0; jb < 4; ++jb) c4[jb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[jb], c4[jb], 0, 0, 0);
+                    for (int jb = 0; jb < JB; ++jb) c4[jb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[jb], c4[jb], 0, 0, 0);
                 }
                 // D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).  Two phases on purpose (as in
                 // tfgx_gemm.hip): bias + activation IN PLACE first, then every store reads its own accumulator register —
                 // results computed into a temporary right before each store make the compiler drain vmcnt(0) between
                 // consecutive stores (measured here: 2.0 ms of the 10.8 ms launch went into 128 serialised stores per tile)
 #pragma unroll
-                for (int jb = 0; jb < 4; ++jb) {
+                for (int jb = 0; jb < JB; ++jb) {
                     const int gn = (nb0 + jb) * 32 + l31;
                     const float bv = (a.bias && gn < a.N) ? a.bias[gn] : 0.0f;
 #pragma unroll
@@ -271,7 +275,7 @@ __global__ __launch_bounds__(kFusedThreads) void agg_gemm_kernel(const FArgs a)
                     // walk order: tile slot -> destination row through the ids the producers left in LDS
                     const int* rid = rowid + buf * kTileRows + mb * 32 + 4 * kh;
 #pragma unroll
-                    for (int jb = 0; jb < 4; ++jb) {
+                    for (int jb = 0; jb < JB; ++jb) {
                         const int gn = (nb0 + jb) * 32 + l31;
                         if (gn >= a.N || a.dbg == 2) continue;
 #pragma unroll
@@ -283,7 +287,7 @@ __global__ __launch_bounds__(kFusedThreads) void agg_gemm_kernel(const FArgs a)
                     continue;
                 }
 #pragma unroll
-                for (int jb = 0; jb < 4; ++jb) {
+                for (int jb = 0; jb < JB; ++jb) {
                     const int gn = (nb0 + jb) * 32 + l31;
                     if (gn >= a.N || a.dbg == 2) continue;
                     float* cp = a.C + row0 * a.ldc + gn;
