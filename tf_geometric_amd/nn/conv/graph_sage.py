@@ -244,8 +244,29 @@ def _pool_graph_sage(x, edge_index, edge_weight, self_kernel, neighbor_mlp_kerne
     h = gemm_bias_act(x, neighbor_mlp_kernel, bias=neighbor_mlp_bias, act=act)      # :199-204 per node (weight == 1)
     if post is not None:
         h = post(h)
+    wn, ws = L.as_f32(neighbor_kernel), L.as_f32(self_kernel)
+    ku_x, ku_n = int(ws.shape[1]), int(wn.shape[1])
+    if op == L.MEAN and ku_n < int(h.shape[1]):
+        # the mean is linear: mean_j(h_j) @ W_neigh == mean_j(h_j @ W_neigh) (:206-208) — project the MLP rows to the
+        # (4x narrower) output width first and gather THOSE: 4 * ku instead of 16 * ku bytes per edge, bias + activation in
+        # the aggregation's epilogue, the result straight into its half of the output (as _self_neighbor_sage does for
+        # mean / sum GraphSAGE).  max_pool cannot: max does not commute with the projection
+        bias_t = None if bias is None else L.as_f32(bias).contiguous()
+        z = gemm_bias_act(h, wn, out=gather_friendly_empty(n, ku_n, x.device))
+        if concat:
+            out = torch.empty((n, ku_x + ku_n), dtype=torch.float32, device=x.device)
+            gemm_bias_act(x, ws, bias=None if bias_t is None else bias_t[:ku_x], act=act, out=out[:, :ku_x])
+            segment_reduce(plan, z, L.MEAN, out=out[:, ku_x:], act=act,
+                           bias=None if bias_t is None else bias_t[ku_x:].contiguous())
+        else:
+            out = segment_reduce(plan, z, L.MEAN, add_x=gemm_bias_act(x, ws), bias=bias_t, act=act)
+        if post is not None:
+            out = post(out)
+        if normalize:
+            out = l2_normalize_rows_(out.contiguous())
+        return out
     reduced = segment_reduce(plan, h, op)                                            # :206 / :269
-    return _combine(L.as_f32(self_kernel), x, L.as_f32(neighbor_kernel), reduced, bias, activation, concat, normalize)
+    return _combine(ws, x, wn, reduced, bias, activation, concat, normalize)
 
 
 def mean_pool_graph_sage(x, edge_index, edge_weight, self_kernel, neighbor_mlp_kernel, neighbor_kernel,
