@@ -111,6 +111,10 @@ def run_checks(rank, world, use_gpu, skew, results, rounds=None, partitioned=Fal
                                         op=0).cpu().numpy()
     out["sage_max_pool"] = sg.pool_graph_sage(x_own, be.f32(ks), be.f32(kmlp), be.f32(kn2), be.f32(bmlp),
                                               bias=be.f32(b10), act=1).cpu().numpy()
+    out["sage_mean_pool"] = sg.pool_graph_sage(x_own, be.f32(ks), be.f32(kmlp), be.f32(kn2), be.f32(bmlp),
+                                               bias=be.f32(b10), act=1, op=1).cpu().numpy()       # projects before it gathers
+    out["sage_mean_pool_add"] = sg.pool_graph_sage(x_own, be.f32(ks), be.f32(kmlp), be.f32(kn2), be.f32(bmlp),
+                                                   bias=be.f32(b10[:5]), act=1, op=1, concat=False).cpu().numpy()
     sg2 = make(None)
     sg2.build_gcn_norm(norm="left", improved=True)
     out["gcn_left_improved_unweighted"] = sg2.gcn(x_own, be.f32(k)).cpu().numpy()
@@ -175,6 +179,8 @@ def _sage_reference(oracle, x, ei, w):
         "sage_mean": oracle.mean_graph_sage(x, ei, w, ks, kn, b10, "relu"),
         "sage_sum_add": oracle.sum_graph_sage(x, ei, w, ks, kn, b10[:5], None, concat=False),
         "sage_max_pool": oracle.max_pool_graph_sage(x, ei, w, ks, kmlp, kn2, bmlp, b10, "relu"),
+        "sage_mean_pool": oracle.mean_pool_graph_sage(x, ei, w, ks, kmlp, kn2, bmlp, b10, "relu"),
+        "sage_mean_pool_add": oracle.mean_pool_graph_sage(x, ei, w, ks, kmlp, kn2, bmlp, b10[:5], "relu", concat=False),
     }
 
 

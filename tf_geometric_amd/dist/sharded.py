@@ -807,6 +807,14 @@ class ShardedGraph(object):
         SAME activation after the MLP and at the end, as the reference applies it."""
         be = self.backend
         h = be.linear(x_own, neighbor_mlp_kernel, neighbor_mlp_bias, act)
+        if op in (L.SUM, L.MEAN) and int(neighbor_kernel.shape[1]) < int(h.shape[1]):
+            # linear reducer: project first, ku-wide rows travel (forward) and ku-wide gradients come back (backward)
+            a = be.linear(x_own, self_kernel)
+            b = self.aggregate_trainable(be.linear(h, neighbor_kernel), op, w=None)
+            out = torch.cat([a, b], 1) if concat else a + b
+            if bias is not None:
+                out = out + bias
+            return torch.relu(out) if act == L.ACT_RELU else out
         if op in (L.SUM, L.MEAN):
             a = be.linear(x_own, self_kernel)
             reduced = self.aggregate_trainable(h, op, w=None)
@@ -1055,7 +1063,24 @@ class ShardedGraph(object):
         the per-edge MLP act(x[col] @ W + b) is a per-NODE GEMM (as on one GPU): it runs on the owner and its output
         rows are what the halo exchange carries."""
         be = self.backend
-        table = self.alloc_table(int(neighbor_mlp_kernel.shape[1]))
+        ku_x, ku_n, width = int(self_kernel.shape[1]), int(neighbor_kernel.shape[1]), int(neighbor_mlp_kernel.shape[1])
+        if op == L.MEAN and ku_n < width:
+            # the mean is linear: mean_j(h_j) @ W_neigh == mean_j(h_j @ W_neigh) (graph_sage.py:206-208) — both GEMMs run on
+            # the owner and only ku-wide rows travel and are gathered (a quarter of the MLP width)
+            hmlp = be.gemm_bias_act(x_own, neighbor_mlp_kernel, bias=neighbor_mlp_bias, act=act)
+            table = self.alloc_table(ku_n)
+            be.gemm_bias_act(hmlp, neighbor_kernel, out=self.own_rows(table))
+            if concat:
+                h = be.empty((self.n_own, ku_x + ku_n))
+                be.gemm_bias_act(x_own, self_kernel, bias=None if bias is None else bias[:ku_x], act=act, out=h[:, :ku_x])
+                h[:, ku_x:] = self.aggregate(table, L.MEAN, w=None, bias=None if bias is None else bias[ku_x:].contiguous(),
+                                             act=act)
+                return h
+            h = be.gemm_bias_act(x_own, self_kernel) + self.aggregate(table, L.MEAN, w=None)
+            if bias is not None:
+                h = h + bias
+            return torch.relu(h) if act == L.ACT_RELU else h
+        table = self.alloc_table(width)
         be.gemm_bias_act(x_own, neighbor_mlp_kernel, bias=neighbor_mlp_bias, act=act, out=self.own_rows(table))
         reduced = self.aggregate(table, op, w=None)
         return self._sage_combine(x_own, reduced, self_kernel, neighbor_kernel, bias, act, concat)
