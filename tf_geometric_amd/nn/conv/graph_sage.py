@@ -14,7 +14,7 @@ import torch
 
 from ... import _lib as L
 from ...activations import resolve as _resolve_act
-from ...plan import (CsrPlan, segment_reduce, gemm_bias_act, l2_normalize_rows_, edge_weight_csr, static_rows,
+from ...plan import (CsrPlan, segment_reduce, gemm_bias_act, l2_normalize_rows_, static_rows,
                      static_aggregate, static_aggregate_applies, gather_friendly_empty, aggregate_gemm, SplitRows)
 from ...sparse import SparseMatrix
 from .gcn import gcn_norm_adj

@@ -9,7 +9,7 @@ tensors -> segment-reduce kernel over the explicit messages.
 import torch
 
 from ... import _lib as L
-from ...plan import CsrPlan, segment_reduce, gather_rows, edge_weight_csr
+from ...plan import CsrPlan, segment_reduce
 from ... import autograd as AG
 
 

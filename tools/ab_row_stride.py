@@ -1,6 +1,6 @@
 import sys, json, torch
 sys.path.insert(0, ".")
-import tf_geometric_amd as tfg
+import tf_geometric_amd as tfg  # noqa: F401 (loads the library)
 from tf_geometric_amd import synthetic, _lib as L
 from tf_geometric_amd.plan import CsrPlan, segment_reduce
 n, e, f = synthetic.WORKLOADS["products"]
