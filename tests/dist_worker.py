@@ -261,6 +261,14 @@ def run_training(rank, world, use_gpu, skew, rounds=None, num_splits=None, hub_t
     sg.all_reduce_gradients(gw)
     res["out_gat"], res["dx_gat"] = og.detach().cpu().numpy(), x4.grad.cpu().numpy()
     res["dw_gat"] = [t.grad.cpu().numpy() for t in gw]
+    # mean-pool GraphSAGE (trainable): the mean is linear, so both projections run on the owner and ku-wide rows travel
+    mw_ = [be.f32(a).requires_grad_(True) for a in pool_weights()]
+    x6 = be.f32(x[sg.own_lo:sg.own_hi]).requires_grad_(True)
+    om = sg.pool_graph_sage_trainable(x6, mw_[0], mw_[1], mw_[2], mw_[3], mw_[4], act=1, concat=True, op=1)
+    (om * be.f32(_loss_coef(n, om.shape[1])[sg.own_lo:sg.own_hi])).sum().backward()
+    sg.all_reduce_gradients(mw_)
+    res["out_meanpool"], res["dx_meanpool"] = om.detach().cpu().numpy(), x6.grad.cpu().numpy()
+    res["dw_meanpool"] = [t.grad.cpu().numpy() for t in mw_]
     if not skew:     # (the skewed graph has rows without in-edges: their float-lowest maxima overflow the next GEMM in fp32)
         pw = [be.f32(a).requires_grad_(True) for a in pool_weights()]
         x5 = be.f32(x[sg.own_lo:sg.own_hi]).requires_grad_(True)
@@ -371,6 +379,15 @@ def training_reference(skew):
     og = torch.relu(og.reshape(n, H * dv) + gw[5])
     (og * torch.from_numpy(_loss_coef(n, og.shape[1]).astype(np.float64))).sum().backward()
     ref["out_gat"], ref["dx_gat"], ref["dw_gat"] = og.detach().numpy(), x4.grad.numpy(), [t.grad.numpy() for t in gw]
+    mw_ = [torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in pool_weights()]
+    x6 = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    hm6 = torch.relu(x6 @ mw_[1] + mw_[3])
+    cnt = torch.zeros(n, dtype=torch.float64).index_add_(0, rows, torch.ones(rows.shape[0], dtype=torch.float64)).clamp(min=1)
+    mean6 = torch.zeros((n, hm6.shape[1]), dtype=torch.float64).index_add(0, rows, hm6[cols]) / cnt.unsqueeze(1)
+    om = torch.relu(torch.cat([x6 @ mw_[0], mean6 @ mw_[2]], 1) + mw_[4])
+    (om * torch.from_numpy(_loss_coef(n, om.shape[1]).astype(np.float64))).sum().backward()
+    ref["out_meanpool"], ref["dx_meanpool"] = om.detach().numpy(), x6.grad.numpy()
+    ref["dw_meanpool"] = [t.grad.numpy() for t in mw_]
     if not skew:
         pw = [torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in pool_weights()]
         x5 = torch.tensor(x, dtype=torch.float64, requires_grad=True)
@@ -389,7 +406,7 @@ def check_training_extras(parts, ref, assert_parity):
                       what="sharded trainable max forward, 36 columns")
         assert_parity(np.concatenate([p["dx_max_wide"] for p in parts]), np.tile(ref["dx_max"], (1, 3)), tol=1e-4,
                       what="sharded max d/dx, 36 columns")
-    for key in ("max", "gat", "pool"):
+    for key in ("max", "gat", "pool", "meanpool"):
         if "out_" + key not in ref:
             continue
         assert_parity(np.concatenate([p["out_" + key] for p in parts]), ref["out_" + key], tol=2e-5,
