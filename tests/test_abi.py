@@ -84,6 +84,11 @@ def test_argument_validation_without_gpu():
     assert b"act_cols" in lib.tfgx_last_error()
     assert lib.tfgx_segment_max_with_count_f32(None, None, None, 4, None, 2, 8, None, 8, None, 8, None) == 1
     assert lib.tfgx_segment_max_backward_w_f32(None, None, None, 4, None, 8, 8, None, 8, None, 4, None, None) == 1
+    # phases outside {1, 2, 3}; and a fused aggregate -> GEMM shape that does not fit LDS is refused on the host
+    assert lib.tfgx_segment_max_backward_mask_phases_f32(None, None, None, 4, 8, None, 8, 8, None, 8, None, 8, None, 8, None, 8,
+                                                         None, None, None, None, 4, None, 8, None, 0, 0, None) == 1
+    assert lib.tfgx_aggregate_gemm_fits(128, 256) == 0 and lib.tfgx_aggregate_gemm_fits(100, 256) == 1
+    assert lib.tfgx_aggregate_gemm_fits(102, 16) == 0 and lib.tfgx_aggregate_gemm_fits(100, 257) == 0
     g = _lib.GatArgs()
     g.H, g.d, g.dv, g.n_dst, g.scale, g.drop_rate = 2, 4, 4, 3, 2.0, 1.5
     assert lib.tfgx_gat_fused_f32(ctypes.byref(g), None) == 1
