@@ -258,18 +258,47 @@ def rmat_line(tfg, L, n, e, f, x, steps, warmup, seed):
 
 
 # ----------------------------------------------------------------------------------------------------------------------
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks here (what
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...`
+    does) and become that launcher — rank 0 of the children prints the one JSON line on this process's stdout."""
+    import socket
+    with socket.socket() as sock:                 # a free rendezvous port on the loopback interface
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
 def main():
     args = parse_args()
+    # ONE JSON line on stdout, nothing else: the C++ layers underneath (gloo's "[Gloo] Rank 0 is connected to ..." banner,
+    # RCCL's version banner) print to fd 1, so fd 1 is pointed at stderr for the whole run and the line is written to the
+    # saved descriptor at the end
+    sys.stdout.flush()
+    line_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world and world > 1:
         raise SystemExit("--gpus {} but WORLD_SIZE={}".format(args.gpus, world))
     if args.gpus > 1 and world == 1:
-        raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node {} bench.py --gpus {}".format(
-            args.gpus, args.gpus))
+        os.dup2(line_fd, 1)                       # the children inherit the real stdout
+        self_launch(args)                         # does not return
     assert torch.cuda.is_available(), "bench.py needs a GPU"
-    torch.cuda.set_device(local_rank % torch.cuda.device_count())
+    n_dev = torch.cuda.device_count()
+    # N > 1: one rank per GPU, halo rows over the repo's own RCCL communicator (transport "tfgx_dist", asked for BY NAME:
+    # if any rank cannot bring it up every rank exits non-zero — a scaling line is never carried by anything else).
+    # The one exception is the single-GPU plumbing check of this code path, which must be requested explicitly:
+    # TFGX_BENCH_BACKEND=gloo puts all ranks on the visible device(s) and stages rows through the host (transport "torch").
+    plumbing = os.environ.get("TFGX_BENCH_BACKEND", "") == "gloo"
+    if world > 1 and n_dev < world and not plumbing:
+        raise SystemExit("bench.py --gpus {}: only {} GPU(s) visible; RCCL needs one device per rank (for a plumbing check "
+                         "of the N > 1 code path on fewer GPUs set TFGX_BENCH_BACKEND=gloo)".format(world, n_dev))
+    torch.cuda.set_device(local_rank % n_dev)
 
     import tf_geometric_amd as tfg
     from tf_geometric_amd import synthetic
@@ -278,27 +307,31 @@ def main():
 
     L.require_gpu()
     n, e_req, f = synthetic.WORKLOADS[args.workload]
-    ei_np = synthetic.synthetic_edges(n, e_req, seed=args.seed)      # deterministic: every rank derives the same list
-    e = int(ei_np.shape[1])
     diag = None
+    gen_s = None
 
     if world > 1:
         import torch.distributed as dist
-        # RCCL ("nccl") always, except for the single-GPU plumbing check of this code path
-        # (TFGX_BENCH_BACKEND=gloo with all ranks on one device; rows are then staged through the host)
-        dist.init_process_group(os.environ.get("TFGX_BENCH_BACKEND", "nccl"))
+        # CONTROL PLANE = a gloo group (rendezvous, the 128-byte ncclUniqueId, barriers, the max-over-ranks of the timings):
+        # host tensors only.  DATA PLANE = tfgx_dist's ncclComm_t: the only RCCL communicator in the process.
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        dist.init_process_group("gloo")
         from tf_geometric_amd.dist.sharded import ShardedGraph
         t0 = time.perf_counter()
-        # every rank keeps only ITS stripe of the edge list (what a per-rank file shard / generator stripe would be);
-        # from_partitioned routes each edge to its destination's owner — nothing edge-sized is replicated on a GPU
-        lo_e, hi_e = (e * rank) // world, (e * (rank + 1)) // world
-        stripe = np.ascontiguousarray(ei_np[:, lo_e:hi_e])
-        del ei_np
-        sg = ShardedGraph.from_partitioned(stripe, n, group=dist.group.WORLD)
+        # every rank GENERATES only its stripe of the edge list (block-seeded generator: the union over the ranks is the same
+        # edge multiset at every N) and from_partitioned routes each edge to its destination's owner — nothing edge-sized
+        # is replicated on a host or on a GPU
+        stripe = synthetic.synthetic_edge_stripe(n, e_req, seed=args.seed, stripe=rank, num_stripes=world)
+        gen_s = time.perf_counter() - t0
+        cnt = torch.tensor([int(stripe.shape[1])], dtype=torch.int64)
+        dist.all_reduce(cnt)
+        e = int(cnt.item())
+        sg = ShardedGraph.from_partitioned(stripe, n, group=dist.group.WORLD,
+                                           transport="torch" if plumbing else "tfgx_dist")
         del stripe
         sg.build_gcn_norm()
         table = sg.alloc_table(f)                       # [own rows | halo rows]; own rows resident before timing
-        x_own = synthetic.synthetic_features(n, f, seed=args.seed + 1)[sg.own_lo:sg.own_hi]
+        x_own = synthetic.synthetic_feature_rows(n, f, seed=args.seed + 1, row_lo=sg.own_lo, row_hi=sg.own_hi)
         sg.own_rows(table).copy_(L.as_f32(x_own))
         del x_own
         out = torch.empty((sg.n_own, f), dtype=torch.float32, device=table.device)
@@ -310,25 +343,43 @@ def main():
 
         def barrier():
             dist.barrier()
+
+        def max_over_ranks(v):
+            t = torch.tensor([v], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
     else:
-        x_np = synthetic.synthetic_features(n, f, seed=args.seed + 1)
+        t0 = time.perf_counter()
+        ei_np = synthetic.synthetic_edge_stripe(n, e_req, seed=args.seed)     # all blocks: the same graph the N > 1 runs shard
+        e = int(ei_np.shape[1])
+        x_np = synthetic.synthetic_feature_rows(n, f, seed=args.seed + 1)
+        gen_s = time.perf_counter() - t0
         t0 = time.perf_counter()
         ei = L.as_i32(ei_np)
+        x = L.as_f32(x_np)
+        torch.cuda.synchronize()
+        h2d_s = time.perf_counter() - t0
+        t0 = time.perf_counter()
         adj = tfg.SparseMatrix(ei, None, [n, n])
         cache = {}
         normed = gcn_norm_adj(adj, cache=cache)
         cache["tfgx_csr_plan"] = adj.plan           # one CSR plan per graph, shared by every layer given this cache
-        x = L.as_f32(x_np)
         out = torch.empty((n, f), dtype=torch.float32, device=x.device)
         torch.cuda.synchronize()
         plan_s = time.perf_counter() - t0
-        # the same again with the edge list already on the device and the code objects loaded: what a second graph costs
-        # (plan_build_s above includes the host -> device copies of 1 GB of edges + 1 GB of features and first-use set-up)
+        # the same again with the code objects loaded and the allocator warm: what a second graph costs, split with HIP
+        # events into the CSR build (sort by destination) and the normalisation
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         t1 = time.perf_counter()
+        ev[0].record()
         adj2 = tfg.SparseMatrix(ei, None, [n, n])
+        _ = adj2.plan
+        ev[1].record()
         normed2 = gcn_norm_adj(adj2, cache={})
+        ev[2].record()
         torch.cuda.synchronize()
         plan_rebuild_s = time.perf_counter() - t1
+        plan_rebuild_split = {"csr_build_ms_events": ev[0].elapsed_time(ev[1]), "gcn_norm_ms_events": ev[1].elapsed_time(ev[2])}
         del adj2, normed2
         from tf_geometric_amd.plan import segment_reduce
 
@@ -369,24 +420,18 @@ def main():
 
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([wall], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
-        t = torch.tensor([ev_ms], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        ev_ms = float(t.item())
+        wall = max_over_ranks(wall)
+        ev_ms = max_over_ranks(ev_ms)
         diag = shard_diagnostics(sg, table, out, f, L, dist, max(3, min(args.steps, 10)))
         # beside the headline (which exchanges the halo every step, as any hidden layer must): layer 0 with its input
         # features declared static — halo exchanged once, shard table in the edge-resident-tail layout, no exchange per step
         st = sg.prepare_static_features(sg.own_rows(table))
         dist.barrier()
-        ms_static = _event_time(lambda: sg.aggregate_static(st, L.SUM, w=sg.norm_w, self_coef=sg.self_coef, out=out),
-                                max(3, min(args.steps, 10)), 2)
-        t = torch.tensor([ms_static], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ms_static = max_over_ranks(_event_time(
+            lambda: sg.aggregate_static(st, L.SUM, w=sg.norm_w, self_coef=sg.self_coef, out=out), max(3, min(args.steps, 10)), 2))
         static_shard = {"what": "layer 0 after ShardedGraph.prepare_static_features: halo exchanged once, no exchange per "
                                 "step, shard table in the static layout where the width calls for it",
-                        "step_ms_max_over_ranks": float(t.item()), "edges_per_s": e / (float(t.item()) * 1e-3),
+                        "step_ms_max_over_ranks": ms_static, "edges_per_s": e / (ms_static * 1e-3),
                         "bytes_rank0": int(st["bytes"]), "layout_rank0": "edge_tail" if st["split"] is not None else "dense"}
         del st
 
@@ -410,14 +455,32 @@ def main():
                    "nodes": n, "edges": e, "features": f, "edges_aggregated": e_agg,
                    "partition": "single GPU" if world == 1 else "dst-range x{} + RCCL halo all-to-all-v".format(world)},
         "plan_build_s": plan_s,
+        "plan_build_s_is": ("first CSR plan + GCN normalisation of this process on device-resident edges: includes code-object "
+                            "loads and first allocations (host perf_counter around a synchronize); inputs generated in "
+                            "input_generation_s and copied in h2d_copy_s, both outside it") if world == 1 else
+                           ("this rank's stripe generation + from_partitioned (degree all-reduce, edge routing all-to-all-v, "
+                            "CSR + halo plan) + GCN normalisation + own feature rows to the device (host perf_counter)"),
+        "input_generation_s": gen_s,
     }
     if world == 1:
+        line["h2d_copy_s"] = h2d_s
         line["plan_rebuild_on_device_s"] = plan_rebuild_s
+        line["plan_rebuild_split"] = plan_rebuild_split
     if world > 1:
         # which exchange implementation carried the halo rows: "tfgx_dist" = the C ABI of include/tfgx_dist.h (in-process
-        # ncclComm_t, grouped ncclSend / ncclRecv on a second HIP stream) — the product path on RCCL; "torch" only for the
-        # one-GPU plumbing check (TFGX_BENCH_BACKEND=gloo)
+        # ncclComm_t, grouped ncclSend / ncclRecv on a second HIP stream) — the product path on RCCL, and the only thing a
+        # scaling line may be carried by; "torch" only in the explicitly requested one-GPU plumbing check.
+        # rccl_ranks = ncclCommCount of that communicator (0: no RCCL communicator, plumbing mode).
         line["config"]["transport"] = sg.transport.name
+        line["config"]["control_plane"] = "gloo (host tensors: rendezvous, barriers, max-over-ranks)"
+        line["config"]["rccl_ranks"] = sg.transport.comm_info()[0] if hasattr(sg.transport, "comm_info") else 0
+        line["config"]["devices_visible"] = n_dev
+        if plumbing:
+            line["config"]["plumbing_check"] = ("TFGX_BENCH_BACKEND=gloo: {} ranks on {} device(s), rows staged through the "
+                                                "host — exercises the N > 1 code path, NOT a scaling number".format(world, n_dev))
+        elif line["config"]["rccl_ranks"] != world or sg.transport.name != "tfgx_dist":
+            raise SystemExit("bench.py: the halo exchange is not on a {}-rank tfgx_dist communicator ({}, {} ranks)".format(
+                world, sg.transport.name, line["config"]["rccl_ranks"]))
 
     if rank == 0 and world > 1:
         # whole job: algorithmic bytes of the full graph over the step time (exchange included) vs N x 8 TB/s
@@ -502,11 +565,20 @@ def main():
         # The same pass with the features declared static (tfg.prepare_static_features: SplitRows + edge-resident tail
         # columns) — what layer 0 of a model runs in every epoch once the caller has opted in.  Reported
         # NEXT TO the headline, never as it: the layout is derived from the feature values (build_ms, extra bytes).
+        # build cost, two readings: the FIRST call on the host clock (includes a fresh 2.9 GB hipMalloc through torch's
+        # allocator — 5 to 60 ms depending on the box) and a second build, allocator warm, between HIP events (the kernels)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         info = tfg.prepare_static_features(x, normed.plan, cache)
         torch.cuda.synchronize()
-        build_ms = (time.perf_counter() - t1) * 1e3
+        build_first_ms = (time.perf_counter() - t1) * 1e3
+        tfg.release_static_features(cache)
+        b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        b0.record()
+        info = tfg.prepare_static_features(x, normed.plan, cache)
+        b1.record()
+        torch.cuda.synchronize()
+        build_ms = b0.elapsed_time(b1)
         if info["layout"] == "edge_tail":
             from tf_geometric_amd.plan import static_rows
             rows = static_rows(x, normed.plan, cache)
@@ -521,7 +593,9 @@ def main():
                                          out=out2, describe=True),
                 "kernel_ms": ms2, "edges_per_s": e / (ms2 * 1e-3),
                 "frac_of_hbm_peak_algorithmic": bytes_alg / (ms2 * 1e-3) / HBM_PEAK,
-                "build_ms_once_per_feature_matrix": build_ms, "layout_bytes": int(info["bytes"]),
+                "build_ms_once_per_feature_matrix": build_ms,
+                "build_ms_is": "HIP events around a second build (allocator warm): the layout kernels themselves",
+                "build_first_call_ms_host_clock": build_first_ms, "layout_bytes": int(info["bytes"]),
                 "bit_identical_to_headline_output": bool(torch.equal(out2, res))}
             for tag in ("r03", "r02", "r01"):   # HBM-side bytes of this launch, imported like roofline.traffic
                 et_path = os.path.join(ROOT, "profiles", "{}_{}_edge_tail_pmc.json".format(tag, args.workload))
@@ -555,7 +629,8 @@ def main():
     if args.extras and world == 1 and rank == 0:
         line["extras"] = extras(tfg, L, synthetic, x, ei, n, e, f, cache)
     if rank == 0:
-        print(json.dumps(line))
+        sys.stdout.flush()
+        os.write(line_fd, (json.dumps(line) + "\n").encode())
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()

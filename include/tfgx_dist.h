@@ -33,6 +33,10 @@ const char* tfgx_dist_last_error(void);
 int tfgx_dist_unique_id(void* id_out /* TFGX_DIST_UNIQUE_ID_BYTES */);
 int tfgx_dist_comm_init(int32_t world, int32_t rank, const void* id, void** comm_out);
 int tfgx_dist_comm_destroy(void* nccl_comm);
+/* What the communicator itself reports: ncclCommCount / ncclCommUserRank / ncclCommCuDevice.  bench.py prints world_out as
+ * `rccl_ranks`, so a scaling line states how many ranks the RCCL communicator that carried the halo rows really had
+ * (any pointer may be NULL). */
+int tfgx_dist_comm_info(void* nccl_comm, int32_t* world_out, int32_t* rank_out, int32_t* device_out);
 
 /* Plan-time personalised exchange of raw device bytes (edge routing of ShardedGraph.from_partitioned, halo request
  * lists): peer q receives send[send_off_q ...], counts in ELEMENTS of elem_bytes each (host arrays of `world` entries,

@@ -417,3 +417,41 @@ def check_training_extras(parts, ref, assert_parity):
             for p in parts:
                 for i, (got, want) in enumerate(zip(p["dw_" + key], ref["dw_" + key])):
                     assert_parity(got, want, tol=2e-4, what="all-reduced {} weight gradient {}".format(key, i))
+
+
+def _agree_entry(rank, world, port, path, fail_rank):
+    """tests/test_dist_gloo.py::test_strict_transport_failure_is_agreed: the strict C-ABI transport on a gloo control
+    group.  fail_rank None: nothing is patched (on a box without a GPU every rank fails its local preconditions);
+    fail_rank r: only rank r's library load fails.  Every rank must raise TfgxDistUnavailable — nobody waits in RCCL."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tf_geometric_amd.dist import transport as T
+    from tf_geometric_amd import _lib as L
+    if fail_rank is not None:
+        class _FakeLib(object):                       # the preconditions "pass" everywhere except on fail_rank
+            pass
+
+        def fake_load():
+            if rank == fail_rank:
+                raise L.TfgxError("injected: libtfgx_dist.so missing on this rank")
+            return _FakeLib()
+        T.load_dist_library = fake_load
+        L.require_gpu = lambda: None
+        L.device = lambda: torch.device("cpu")
+        torch.cuda.Stream = lambda device=None: None
+    msg = None
+    try:
+        T.get_transport(None, None, "tfgx_dist")
+    except T.TfgxDistUnavailable as ex:
+        msg = str(ex)
+    with open(os.path.join(path, "agree{}.txt".format(rank)), "w") as fh:
+        fh.write(msg or "NO ERROR")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def spawn_agree(world, path, port, fail_rank):
+    import torch.multiprocessing as mp
+    mp.spawn(_agree_entry, args=(world, port, path, fail_rank), nprocs=world, join=True)
+    return [open(os.path.join(path, "agree{}.txt".format(r))).read() for r in range(world)]

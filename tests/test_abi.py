@@ -161,7 +161,7 @@ def test_dist_library_exports_every_declared_symbol():
     with open(os.path.join(ROOT, "include", "tfgx_dist.h")) as fh:
         src = re.sub(r"/\*.*?\*/", "", fh.read(), flags=re.S)
     names = sorted(set(re.findall(r"\b(tfgx_[a-z0-9_]+)\s*\(", src)))
-    assert len(names) == 17, names
+    assert len(names) == 18, names
     if not os.path.exists(_build.DIST_LIB):
         _build.build_dist(verbose=False)
     lib = ctypes.CDLL(_build.DIST_LIB)
@@ -183,6 +183,7 @@ def test_dist_library_exports_every_declared_symbol():
     else:
         assert b"hipEventCreate" in lib.tfgx_dist_last_error()
     assert lib.tfgx_dist_comm_init(0, 0, None, None) == 1 and lib.tfgx_dist_unique_id(None) == 1
+    assert lib.tfgx_dist_comm_info(None, None, None, None) == 1
     assert lib.tfgx_alltoallv(None, None, None, None, 4, 2, None, None) == 1
     assert lib.tfgx_halo_exchange_finish(None, 0, None) == 1
     assert lib.tfgx_halo_reverse_start(None, None, 4, None, 0, None, None, None) == 1

@@ -155,3 +155,20 @@ def test_self_halo_mode_moves_own_rows_through_the_exchange(tmp_path, world):
     assert_parity(np.concatenate([p["dx"] for p in tr]), ref["dx"], tol=2e-5, what="self-halo d/dx")
     assert_parity(np.concatenate([p["dx_mean"] for p in tr]), ref["dx_mean"], tol=2e-5, what="self-halo mean d/dx")
     dist_worker.check_training_extras(tr, ref, assert_parity)
+
+
+@pytest.mark.parametrize("fail_rank", [None, 1])
+def test_strict_transport_failure_is_agreed(tmp_path, fail_rank):
+    """transport="tfgx_dist" (what bench.py --gpus N asks for by name) never degrades and never hangs: the ranks agree on
+    their local preconditions over the control channel BEFORE any RCCL call, so a failure on one rank (fail_rank = 1: its
+    library load is made to fail) or on all of them (this box has no GPU) raises TfgxDistUnavailable on every rank."""
+    import torch
+    if fail_rank is None and torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU (every rank then fails require_gpu)")
+    port = 29500 + random.randint(4001, 6000)
+    msgs = dist_worker.spawn_agree(2, str(tmp_path), port, fail_rank)
+    assert all("failed on" in m and "of 2 ranks" in m for m in msgs), msgs
+    if fail_rank is not None:
+        assert all("1 of 2 ranks" in m and "rank 1: TfgxError: injected" in m for m in msgs), msgs
+    else:
+        assert all("2 of 2 ranks" in m for m in msgs), msgs

@@ -1,0 +1,69 @@
+# coding=utf-8
+"""bench.py as the driver runs it: the PLAIN command (`python3 bench.py --gpus N ...`, no launcher around it)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _run(argv, env=None, timeout=900):
+    e = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "TFGX_BENCH_BACKEND"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=e, stdout=subprocess.PIPE,
+                          stderr=subprocess.PIPE, timeout=timeout)
+
+
+def _json_line(res):
+    lines = res.stdout.decode().splitlines()          # stdout carries the ONE JSON line and nothing else (no gloo / RCCL banners)
+    assert len(lines) == 1 and lines[0].startswith("{"), (res.stdout.decode()[-2000:], res.stderr.decode()[-3000:])
+    return json.loads(lines[0])
+
+
+def test_plain_command_starts_its_own_ranks(tfg):
+    """`python3 bench.py --gpus 2` with WORLD_SIZE unset launches its two ranks itself (torch.distributed.run on
+    127.0.0.1) and rank 0 prints the one JSON line.  On a one-GPU box the exchange cannot be on RCCL (two ranks per device
+    are refused), so this is the explicitly requested plumbing mode: gloo control plane, rows staged through the host,
+    and the line says so."""
+    import torch
+    res = _run(["--gpus", "2", "--workload", "tiny", "--steps", "3", "--warmup", "1"], env={"TFGX_BENCH_BACKEND": "gloo"})
+    assert res.returncode == 0, res.stderr.decode()[-3000:]
+    line = _json_line(res)
+    cfg = line["config"]
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["value"] > 0 and line["scaling"] == "strong"
+    assert cfg["transport"] == "torch" and cfg["rccl_ranks"] == 0 and "plumbing_check" in cfg
+    assert cfg["devices_visible"] == torch.cuda.device_count()
+    ranks = line["roofline"]["per_rank"]
+    assert [d["rank"] for d in ranks] == [0, 1] and sum(d["edges"] for d in ranks) == cfg["edges"]
+    assert all(d["halo_rows_received"] > 0 and d["exchange_GBps_received"] > 0 for d in ranks)
+
+
+def test_more_ranks_than_gpus_is_refused_loudly(tfg):
+    """Without the plumbing switch a rank count above the visible GPUs must fail (non-zero, a message that says why):
+    a scaling line is only ever carried by the tfgx_dist RCCL communicator, one device per rank."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("box has a GPU per rank")
+    res = _run(["--gpus", "2", "--workload", "tiny", "--steps", "2", "--warmup", "1"], timeout=600)
+    assert res.returncode != 0
+    assert "RCCL needs one device per rank" in res.stderr.decode(), res.stderr.decode()[-2000:]
+    assert not [ln for ln in res.stdout.decode().splitlines() if ln.startswith("{")]
+
+
+def test_single_gpu_line_shape(tfg):
+    """N = 1 on a small workload: the contract keys, the roofline / cpu_baseline objects, parity of the timed output."""
+    res = _run(["--workload", "tiny", "--steps", "3", "--warmup", "1"])
+    assert res.returncode == 0, res.stderr.decode()[-3000:]
+    line = _json_line(res)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["n_gpus"] == 1 and line["dtype"] == "f32" and line["roofline"]["bound"] == "hbm"
+    assert 0 < line["roofline"]["frac"] < 1.0 and line["cpu_baseline"]["kind"] == "port"
+    assert line["parity_vs_cpu_port_max_abs_err"] < 1e-4

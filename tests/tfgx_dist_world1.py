@@ -51,8 +51,8 @@ from tf_geometric_amd.dist.transport import close_transports   # noqa: E402
 # the agreed safety net of auto mode (world > 1 takes it): the communicator's self-check, and the fallback to torch's own
 # RCCL collectives when the C-ABI transport cannot be brought up on some rank
 from tf_geometric_amd.dist.sharded import HipBackend           # noqa: E402
-chk = T._checked_tfgx_transport(None, HipBackend())
-assert chk.name == "tfgx_dist"
+chk = T._bring_up_tfgx(None, HipBackend(), auto=False)
+assert chk.name == "tfgx_dist" and chk.comm_info()[:2] == (1, 0), chk.comm_info()       # ncclCommCount / UserRank
 chk.close()
 
 
@@ -65,7 +65,12 @@ real, T.TfgxDistTransport = T.TfgxDistTransport, _Broken
 import warnings                                                # noqa: E402
 with warnings.catch_warnings(record=True) as caught:
     warnings.simplefilter("always")
-    fb = T._checked_tfgx_transport(None, HipBackend())
+    fb = T._bring_up_tfgx(None, HipBackend(), auto=True)
+    try:                                  # asked for by name (bench.py, TFGX_DIST_TRANSPORT): no net, it raises
+        T._bring_up_tfgx(None, HipBackend(), auto=False)
+        raise AssertionError("strict mode fell back")
+    except T.TfgxDistUnavailable as ex:
+        assert "injected" in str(ex)
 T.TfgxDistTransport = real
 assert fb.name.startswith("torch (fallback") and "injected" in fb.fallback_reason and caught, (fb.name, caught)
 got = fb.all_to_all_v(torch.arange(6, dtype=torch.int32, device="cuda").view(3, 2), [3], [3])

@@ -89,6 +89,26 @@ extern "C" int tfgx_dist_comm_destroy(void* nccl_comm)
     return TFGX_OK;
 }
 
+extern "C" int tfgx_dist_comm_info(void* nccl_comm, int32_t* world_out, int32_t* rank_out, int32_t* device_out)
+{
+    DIST_REQUIRE(nccl_comm != nullptr, "nccl_comm is null");
+    ncclComm_t comm = reinterpret_cast<ncclComm_t>(nccl_comm);
+    int v = 0;
+    if (world_out) {
+        DIST_NCCL(ncclCommCount(comm, &v));
+        *world_out = v;
+    }
+    if (rank_out) {
+        DIST_NCCL(ncclCommUserRank(comm, &v));
+        *rank_out = v;
+    }
+    if (device_out) {
+        DIST_NCCL(ncclCommCuDevice(comm, &v));
+        *device_out = v;
+    }
+    return TFGX_OK;
+}
+
 extern "C" int tfgx_alltoallv(const void* send, const int64_t* send_counts, void* recv, const int64_t* recv_counts,
                               int64_t elem_bytes, int32_t world, void* nccl_comm, void* stream)
 {

@@ -4,9 +4,12 @@
 // to HBM and tfgx_gemm_bias_act_f32 reading it back (1.9 GB of round trip at products shape, F = 100).
 //
 // One persistent 1024-thread workgroup per CU (16 waves; the gather walk keeps its rate down to 16 waves per CU:
-// profiles/r03_occupancy_probe.jsonl).  LDS holds ALL of B ([KP][LDW] floats, loaded once) and two tiles of aggregated
+// profiles/r03_occupancy_probe.jsonl).  LDS holds B ([KP][LDW] floats, loaded once) and two tiles of aggregated
 // rows, TRANSPOSED (At[k][m], m = destination row inside the 64-row tile) so that the MFMA A operand is a conflict-free
-// ds_read over consecutive m.
+// ds_read over consecutive m.  When all of B does not fit beside the two tiles (F = 128 -> 256: 135 KB + 66 KB > 160 KB)
+// only its first NL columns (a multiple of 64) are resident; the consumer jobs of the remaining columns read their B
+// operand straight from global memory — 128-byte row segments of a <= 128 KB matrix that every workgroup re-reads for every
+// tile, i.e. L2 hits — with 8 k-pairs (16 loads) in flight per wave.
 //   * producers: every wave repeatedly takes the next UNIT (64 / G consecutive destination rows of the current tile: one per
 //     lane group) from an LDS counter, reduces it exactly like seg_reduce_kernel (G lanes per row, 4 columns per lane,
 //     (col, w) batches prefetched, 8 gathered rows in flight, one in-order FMA chain per output element), and stores the row
@@ -56,7 +59,10 @@ struct FArgs {
     int32_t n_blocks;  // 32-column output blocks, rounded up to a multiple of 4
     int32_t LDW;       // 32 * n_blocks + 8
     int64_t n_tiles;
-    int32_t dbg;       // developer experiment: 1 = skip the multiplication and the stores, 2 = skip the stores only
+    int32_t NL;        // columns of B resident in LDS (multiple of 64; LDW = NL + 8); columns >= NL: B operand from global
+    float* agg;        // optional side output (training forward): the aggregated rows themselves, [n_dst, ld_agg], or NULL
+    int64_t ld_agg;
+    int32_t dbg;       // developer experiment (-DTFGX_FUSED_DEBUG builds only): 1 = skip the multiplication and the stores, 2 = skip the stores only
     // power-law graphs: rows longer than hub_threshold were cut into chunks and reduced chunk by chunk into hub_scratch by a
     // launch of the ordinary kernel BEFORE this one; their lane group folds the chunk partials in chunk order instead of
     // walking the edges (what hub_finalize_kernel does in the unfused path)
@@ -68,7 +74,14 @@ struct FArgs {
     // skewed plans: slot i of the launch reduces destination row row_order[i] (the plan's rows sorted by length), so the 64
     // rows of a tile are of similar length and no lane group holds a tile back; NULL: i
     const int32_t* row_order;
+    const int32_t* hub_order_slot;  // optional: slot of row row_order[i] in hub_rows, i < n_hub (rows sorted by length: hubs first)
 };
+
+#ifdef TFGX_FUSED_DEBUG
+#define TFGX_FUSED_DBG_IS(v) (a.dbg == (v))
+#else
+#define TFGX_FUSED_DBG_IS(v) false
+#endif
 
 template <int G>
 __device__ __forceinline__ int bcast_i(int v, int j) { return __shfl(v, j, G); }
@@ -91,7 +104,7 @@ __global__ __launch_bounds__(kFusedThreads) void agg_gemm_kernel(const FArgs a)
 
     for (int i = tid; i < a.KP * a.LDW; i += kFusedThreads) {
         const int k = i / a.LDW, n = i - k * a.LDW;
-        Ws[i] = (k < a.F && n < a.N) ? a.B[int64_t(k) * a.ldb + n] : 0.0f;
+        Ws[i] = (k < a.F && n < a.N && n < a.NL) ? a.B[int64_t(k) * a.ldb + n] : 0.0f;
     }
     for (int i = tid; i < kBufs * a.KP * kLda; i += kFusedThreads) At[i] = 0.0f;      // rows k >= F stay zero for good
     if (tid < 16) ctrl[tid] = 0;                            // ([6 + b]: finished halves of buffer b's tile)
@@ -128,11 +141,17 @@ __global__ __launch_bounds__(kFusedThreads) void agg_gemm_kernel(const FArgs a)
                 if constexpr (WEIGHTED) wj_next = a.w[s + lane];
             }
             if (hub) {
-                int lo = 0, hi = a.n_hub - 1;                 // r is in the list: find its slot
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    if (a.hub_rows[mid] < int32_t(r)) lo = mid + 1;
-                    else hi = mid;
+                // r is in the list: its slot.  Walk order by length puts the hub rows first, and the plan then hands over
+                // their slots (one load, checked); otherwise a binary search
+                int lo = (a.hub_order_slot != nullptr && a.row_order != nullptr && ri < a.n_hub) ? a.hub_order_slot[ri] : -1;
+                if (lo < 0 || lo >= a.n_hub || a.hub_rows[lo] != int32_t(r)) {
+                    int hi = a.n_hub - 1;
+                    lo = 0;
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        if (a.hub_rows[mid] < int32_t(r)) lo = mid + 1;
+                        else hi = mid;
+                    }
                 }
                 for (int c = a.hub_chunk_ptr[lo]; c < a.hub_chunk_ptr[lo + 1]; ++c) {
                     float pv[4];
@@ -189,6 +208,8 @@ __global__ __launch_bounds__(kFusedThreads) void agg_gemm_kernel(const FArgs a)
                 for (int v = 0; v < 4; ++v) acc[v] = acc[v] / divisor;
             }
         }
+        if (a.agg != nullptr && cvalid && r < a.n_dst)        // training forward: the weight gradient needs the aggregate
+            store_vec<4>(a.agg + r * a.ld_agg + coff, acc);
         // ---- hand the row over: wait until the buffer's previous tile (q - kBufs) has been multiplied, store transposed
         if (q >= kBufs) {
             volatile int* done = ctrl + 1 + kBufs + buf;
@@ -220,7 +241,7 @@ __global__ __launch_bounds__(kFusedThreads) void agg_gemm_kernel(const FArgs a)
         }
         __threadfence_block();
         const int half = job & 1, nb_first = (job >> 1) * JB;
-        for (int mb = half; mb < (a.dbg == 1 ? 0 : half + 1); ++mb) {
+        for (int mb = half; mb < (TFGX_FUSED_DBG_IS(1) ? 0 : half + 1); ++mb) {
             for (int nb0 = nb_first; nb0 < nb_first + JB; nb0 += JB) {     // n_blocks is a multiple of 4 (zero-padded columns of Ws)
                 f32x16 c4[JB];
 #pragma unroll
@@ -228,35 +249,74 @@ __global__ __launch_bounds__(kFusedThreads) void agg_gemm_kernel(const FArgs a)
 #pragma unroll
                     for (int t = 0; t < 16; ++t) c4[jb][t] = 0.0f;
                 const float* ap = ab + kh * kLda + mb * 32 + l31;
-                const float* bp = Ws + kh * a.LDW + nb0 * 32 + l31;
-                // KU k-pairs per step: all (1 + JB) * KU LDS reads of a step are issued before its JB * KU MFMAs (a read-wait-multiply
-                // chain per MFMA left the single consumer wave at ~2.5x the MFMA time and the producers waiting for buffers)
-                constexpr int KU = 4;
                 const int pairs = a.KP / 2;
                 int pr = 0;
-                for (; pr + KU <= pairs; pr += KU) {
-                    float av[KU], bv[KU][JB];
+                if (nb0 * 32 < a.NL) {
+                    // B resident in LDS.  KU k-pairs per step: all (1 + JB) * KU LDS reads of a step are issued before its
+                    // JB * KU MFMAs (a read-wait-multiply chain per MFMA left the single consumer wave at ~2.5x the MFMA time
+                    // and the producers waiting for buffers)
+                    const float* bp = Ws + kh * a.LDW + nb0 * 32 + l31;
+                    constexpr int KU = 4;
+                    for (; pr + KU <= pairs; pr += KU) {
+                        float av[KU], bv[KU][JB];
 #pragma unroll
-                    for (int t = 0; t < KU; ++t) {
-                        av[t] = ap[(2 * (pr + t)) * kLda];
+                        for (int t = 0; t < KU; ++t) {
+                            av[t] = ap[(2 * (pr + t)) * kLda];
 #pragma unroll
-                        for (int jb = 0; jb < JB; ++jb) bv[t][jb] = bp[(2 * (pr + t)) * a.LDW + jb * 32];
+                            for (int jb = 0; jb < JB; ++jb) bv[t][jb] = bp[(2 * (pr + t)) * a.LDW + jb * 32];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);      // left alone the scheduler sinks every read next to its MFMA
+#pragma unroll
+                        for (int t = 0; t < KU; ++t)
+#pragma unroll
+                            for (int jb = 0; jb < JB; ++jb)
+                                c4[jb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t][jb], c4[jb], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-                    __builtin_amdgcn_sched_barrier(0);      // left alone the scheduler sinks every read next to its MFMA
+                    for (; pr < pairs; ++pr) {
+                        const float av = ap[(2 * pr) * kLda];
+                        float bv[JB];
 #pragma unroll
-                    for (int t = 0; t < KU; ++t)
+                        for (int jb = 0; jb < JB; ++jb) bv[jb] = bp[(2 * pr) * a.LDW + jb * 32];
 #pragma unroll
-                        for (int jb = 0; jb < JB; ++jb)
-                            c4[jb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t][jb], c4[jb], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                for (; pr < pairs; ++pr) {
-                    const float av = ap[(2 * pr) * kLda];
-                    float bv[JB];
+                        for (int jb = 0; jb < JB; ++jb) c4[jb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[jb], c4[jb], 0, 0, 0);
+                    }
+                } else {
+                    // B columns past the resident ones: the operand comes from global memory (L2: every workgroup re-reads the
+                    // same <= 128 KB for every tile).  Lane (l31, kh) reads B[2 pr + kh][col]: two 128-byte row segments per
+                    // load; KG k-pairs = JB * KG loads in flight per wave before the first MFMA of the step.  Columns >= N read
+                    // column N - 1 (never stored).
+                    const float* gp[JB];
 #pragma unroll
-                    for (int jb = 0; jb < JB; ++jb) bv[jb] = bp[(2 * pr) * a.LDW + jb * 32];
+                    for (int jb = 0; jb < JB; ++jb) {
+                        const int gn = (nb0 + jb) * 32 + l31;
+                        gp[jb] = a.B + int64_t(kh) * a.ldb + (gn < a.N ? gn : a.N - 1);
+                    }
+                    constexpr int KG = 8;
+                    for (; pr + KG <= pairs; pr += KG) {
+                        float av[KG], bv[KG][JB];
 #pragma unroll
-                    for (int jb = 0; jb < JB; ++jb) c4[jb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[jb], c4[jb], 0, 0, 0);
+                        for (int t = 0; t < KG; ++t)
+#pragma unroll
+                            for (int jb = 0; jb < JB; ++jb) bv[t][jb] = gp[jb][int64_t(2 * (pr + t)) * a.ldb];
+#pragma unroll
+                        for (int t = 0; t < KG; ++t) av[t] = ap[(2 * (pr + t)) * kLda];
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int t = 0; t < KG; ++t)
+#pragma unroll
+                            for (int jb = 0; jb < JB; ++jb)
+                                c4[jb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t][jb], c4[jb], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    for (; pr < pairs; ++pr) {
+                        const float av = ap[(2 * pr) * kLda];
+                        float bv[JB];
+#pragma unroll
+                        for (int jb = 0; jb < JB; ++jb) bv[jb] = (2 * pr + kh < a.F) ? gp[jb][int64_t(2 * pr) * a.ldb] : 0.0f;
+#pragma unroll
+                        for (int jb = 0; jb < JB; ++jb) c4[jb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[jb], c4[jb], 0, 0, 0);
+                    }
                 }
                 // D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).  Two phases on purpose (as in
                 // tfgx_gemm.hip): bias + activation IN PLACE first, then every store reads its own accumulator register —
@@ -269,7 +329,7 @@ __global__ __launch_bounds__(kFusedThreads) void agg_gemm_kernel(const FArgs a)
 #pragma unroll
                     for (int t = 0; t < 16; ++t) c4[jb][t] = apply_act(c4[jb][t] + bv, a.act);
                 }
-                const int64_t row0 = (a.dbg == 3 ? (tile & 63) : tile) * kTileRows + mb * 32 + 4 * kh;   // dbg 3: stores land in 4096 rows
+                const int64_t row0 = (TFGX_FUSED_DBG_IS(3) ? (tile & 63) : tile) * kTileRows + mb * 32 + 4 * kh;   // dbg 3: stores land in 4096 rows
                 const bool full = tile * kTileRows + kTileRows <= a.n_dst;
                 if (a.row_order != nullptr) {
                     // walk order: tile slot -> destination row through the ids the producers left in LDS
@@ -277,7 +337,7 @@ __global__ __launch_bounds__(kFusedThreads) void agg_gemm_kernel(const FArgs a)
 #pragma unroll
                     for (int jb = 0; jb < JB; ++jb) {
                         const int gn = (nb0 + jb) * 32 + l31;
-                        if (gn >= a.N || a.dbg == 2) continue;
+                        if (gn >= a.N || TFGX_FUSED_DBG_IS(2)) continue;
 #pragma unroll
                         for (int t = 0; t < 16; ++t) {
                             const int rr = rid[(t & 3) + 8 * (t >> 2)];
@@ -289,12 +349,12 @@ __global__ __launch_bounds__(kFusedThreads) void agg_gemm_kernel(const FArgs a)
 #pragma unroll
                 for (int jb = 0; jb < JB; ++jb) {
                     const int gn = (nb0 + jb) * 32 + l31;
-                    if (gn >= a.N || a.dbg == 2) continue;
+                    if (gn >= a.N || TFGX_FUSED_DBG_IS(2)) continue;
                     float* cp = a.C + row0 * a.ldc + gn;
                     if (full) {
                         // streaming (non-temporal) stores: the output is written once and not read by this launch; kept out
                         // of the caches it does not evict source rows the gather still hits there
-                        if (a.dbg != 4) {
+                        if (!TFGX_FUSED_DBG_IS(4)) {
 #pragma unroll
                             for (int t = 0; t < 16; ++t)
                                 __builtin_nontemporal_store(c4[jb][t], cp + int64_t((t & 3) + 8 * (t >> 2)) * a.ldc);
@@ -332,17 +392,29 @@ inline size_t fused_lds_bytes(int kp, int ldw)
     return sizeof(float) * (size_t(kp) * ldw + size_t(kBufs) * kp * kLda) + sizeof(int) * (16 + kBufs * kTileRows);
 }
 
+constexpr size_t kFusedLdsLimit = 160 * 1024;
+
+// Columns of B kept in LDS for a [kp, np] projection (np = N rounded up to 128): all of them when B and the two tiles fit,
+// else the largest multiple of 64 (one consumer job = 64 columns) that does; 0 = not even 64 columns fit.
+inline int fused_resident_cols(int kp, int np)
+{
+    for (int nl = np; nl >= 64; nl -= 64)
+        if (fused_lds_bytes(kp, nl + 8) <= kFusedLdsLimit) return nl;
+    return 0;
+}
+
 }  // namespace
 }  // namespace tfgx
 
 using namespace tfgx;
 
-// 1 if tfgx_aggregate_gemm_f32 takes rows of F columns projected to N columns (everything resident in 160 KB of LDS)
+// 1 if tfgx_aggregate_gemm_f32 takes rows of F columns projected to N columns: the two tiles and at least 64 columns of B
+// resident in 160 KB of LDS (columns that do not fit are read from global memory / L2 by their consumer jobs)
 extern "C" int tfgx_aggregate_gemm_fits(int64_t F, int64_t N)
 {
     if (F < 4 || F > 128 || F % 4 != 0 || N < 1 || N > 256) return 0;
-    const int kp = int((F + 1) / 2 * 2), ldw = int((N + 127) / 128) * 128 + 8;
-    return fused_lds_bytes(kp, ldw) <= 160 * 1024 ? 1 : 0;
+    const int kp = int((F + 1) / 2 * 2), np = int((N + 127) / 128) * 128;
+    return fused_resident_cols(kp, np) > 0 ? 1 : 0;
 }
 
 extern "C" int tfgx_aggregate_gemm_f32(const tfgx_reduce_args* p, const float* B, int64_t ldb, const float* bias, int32_t act,
@@ -360,6 +432,8 @@ extern "C" int tfgx_aggregate_gemm_f32(const tfgx_reduce_args* p, const float* B
     TFGX_REQUIRE(p->ldx >= p->F && p->ldx % 4 == 0 && aligned_to(p->x, 16) && ldb >= N && ldc >= N, "bad leading dimension / alignment");
     TFGX_REQUIRE(!p->accumulate && !p->add_x && !p->x_tail && !p->track,
                  "plain aggregation only (no accumulate / add_x / split rows / track)");
+    TFGX_REQUIRE(p->out == nullptr || (p->ldo >= p->F && p->ldo % 4 == 0 && aligned_to(p->out, 16)),
+                 "side output of the aggregate: rows of >= F floats, 16-byte aligned");
     const bool use_hub = p->hub_threshold > 0 && p->n_hub_rows > 0;
     if (use_hub) {
         TFGX_REQUIRE(p->hub_rows && p->hub_chunk_ptr && p->hub_chunk_begin && p->hub_chunk_end && p->hub_scratch &&
@@ -374,6 +448,7 @@ extern "C" int tfgx_aggregate_gemm_f32(const tfgx_reduce_args* p, const float* B
         c.hub_threshold = 0; c.hub_rows = nullptr; c.hub_chunk_ptr = nullptr; c.hub_chunk_begin = nullptr;
         c.hub_chunk_end = nullptr; c.n_hub_rows = 0; c.n_hub_chunks = 0; c.hub_scratch = nullptr;
         c.row_order = nullptr;          // (a walk order names DESTINATION rows; the chunk launch walks chunks)
+        c.hub_order_slot = nullptr;
         const int rc = tfgx_segment_reduce_f32(&c, stream_);
         if (rc != TFGX_OK) return rc;
     }
@@ -385,30 +460,42 @@ extern "C" int tfgx_aggregate_gemm_f32(const tfgx_reduce_args* p, const float* B
     a.row_ptr = p->row_begin; a.col = p->col; a.w = p->w; a.n_dst = p->n_dst; a.x = p->x; a.ldx = p->ldx; a.F = int32_t(p->F);
     a.op = p->op; a.self_coef = p->self_coef; a.mean_count = p->mean_count;
     a.B = B; a.ldb = ldb; a.bias = bias; a.act = act; a.N = int32_t(N); a.C = C; a.ldc = ldc;
+    a.hub_order_slot = use_hub ? p->hub_order_slot : nullptr;
+    a.agg = p->out; a.ld_agg = p->ldo;
     a.KP = int32_t((p->F + 1) / 2 * 2);
     a.n_blocks = int32_t((N + 127) / 128) * 4;          // 32-column blocks, in groups of four (columns >= N are zero in LDS)
-    a.LDW = 32 * a.n_blocks + 8;
+    a.NL = fused_resident_cols(a.KP, 32 * a.n_blocks);
+    a.LDW = a.NL + 8;
     a.n_tiles = (p->n_dst + kTileRows - 1) / kTileRows;
+#ifdef TFGX_FUSED_DEBUG
     a.dbg = getenv("TFGX_FUSED_DBG") ? atoi(getenv("TFGX_FUSED_DBG")) : 0;
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
+    if (a.dbg) fprintf(stderr, "tfgx_aggregate_gemm_f32: DEBUG MODE %d — results are not valid\n", a.dbg);
+#else
+    a.dbg = 0;
+#endif
+    // per DEVICE (one process may drive several): compute-unit count, and the dynamic-LDS attribute of each instantiation
+    constexpr int kMaxDev = 64;
+    static int cus_of[kMaxDev] = {0};
+    int dev = 0;
+    TFGX_HIP_CHECK(hipGetDevice(&dev));
+    TFGX_REQUIRE(dev >= 0 && dev < kMaxDev, "device ordinal out of range");
+    if (cus_of[dev] == 0) {
         hipDeviceProp_t prop;
-        TFGX_HIP_CHECK(hipGetDevice(&dev));
         TFGX_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-        cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        cus_of[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
+    const int cus = cus_of[dev];
     const size_t lds_bytes = fused_lds_bytes(a.KP, a.LDW);
     const int64_t wgs = a.n_tiles < cus ? a.n_tiles : cus;
     hipStream_t stream = as_stream(stream_);
     const bool weighted = p->w != nullptr;
 #define TFGX_FUSED_GO(GG, WW)                                                                                        \
     do {                                                                                                             \
-        static bool attr_set = false;                                                                                \
-        if (!attr_set) {                                                                                             \
+        static bool attr_set[kMaxDev] = {false};                                                                     \
+        if (!attr_set[dev]) {                                                                                        \
             TFGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(agg_gemm_kernel<GG, WW>),               \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));             \
-            attr_set = true;                                                                                         \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, int(kFusedLdsLimit)));    \
+            attr_set[dev] = true;                                                                                    \
         }                                                                                                            \
         agg_gemm_kernel<GG, WW><<<dim3(unsigned(wgs)), dim3(kFusedThreads), lds_bytes, stream>>>(a);                 \
     } while (0)

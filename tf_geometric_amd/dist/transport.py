@@ -35,6 +35,7 @@ _DIST_SIGNATURES = {
     "tfgx_dist_unique_id": (ctypes.c_int, [_P]),
     "tfgx_dist_comm_init": (ctypes.c_int, [_I32, _I32, _P, ctypes.POINTER(_P)]),
     "tfgx_dist_comm_destroy": (ctypes.c_int, [_P]),
+    "tfgx_dist_comm_info": (ctypes.c_int, [_P, ctypes.POINTER(_I32), ctypes.POINTER(_I32), ctypes.POINTER(_I32)]),
     "tfgx_alltoallv": (ctypes.c_int, [_P, _P, _P, _P, _I64, _I32, _P, _P]),
     "tfgx_allreduce_sum_i64": (ctypes.c_int, [_P, _I64, _P, _P]),
     "tfgx_allreduce_sum_f32": (ctypes.c_int, [_P, _I64, _P, _P]),
@@ -80,37 +81,90 @@ def _flat(rows):
     return [int(v) for r in rows for v in r]
 
 
+class TfgxDistUnavailable(L.TfgxError):
+    """Raised ON EVERY RANK of the group when any rank could not bring the C-ABI transport up (the ranks agree over the
+    control channel before and after each collective bootstrap step, so nobody is left waiting inside RCCL)."""
+
+
 class TfgxDistTransport(object):
     name = "tfgx_dist"
 
     def __init__(self, group=None):
-        self.lib = load_dist_library()
-        L.require_gpu()
         self.group = group
         inited = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(group) if inited else 1
         self.rank = dist.get_rank(group) if inited else 0
-        self.device = L.device()
         self.comm = None
-        self.comm_stream = torch.cuda.Stream(device=self.device)       # north_star's "second HIP stream"
         self._bufs = {}
+        # local preconditions first; nothing collective has run yet, so a rank that fails here can still tell the others
+        err = None
+        try:
+            self.lib = load_dist_library()
+            L.require_gpu()
+            self.device = L.device()
+            self.comm_stream = torch.cuda.Stream(device=self.device)       # north_star's "second HIP stream"
+        except Exception as ex:          # noqa: BLE001 - a missing library, no GPU, ...
+            err = "{}: {}".format(type(ex).__name__, ex)
+        self._agree(err, "loading lib/libtfgx_dist.so")
         if self.world > 1:
             self._comm()          # collective: every rank of the group constructs its transport at the same point
 
+    def _agree(self, err, stage):
+        """Every rank reports its local outcome of `stage` over the CONTROL channel (torch.distributed object collective:
+        works on gloo and on nccl groups); if any rank failed, EVERY rank raises TfgxDistUnavailable naming the ranks.
+        No RCCL call of this transport is in flight while the ranks agree."""
+        if self.world == 1:
+            if err:
+                raise TfgxDistUnavailable("tfgx_dist: {} failed: {}".format(stage, err))
+            return
+        box = [None] * self.world
+        dist.all_gather_object(box, err, group=self.group)
+        bad = ["rank {}: {}".format(r, e) for r, e in enumerate(box) if e]
+        if bad:
+            raise TfgxDistUnavailable("tfgx_dist: {} failed on {} of {} ranks ({})".format(stage, len(bad), self.world,
+                                                                                        "; ".join(bad)))
+
     def _comm(self):
         if self.comm is None:
-            uid = ctypes.create_string_buffer(UNIQUE_ID_BYTES)
+            uid, err = ctypes.create_string_buffer(UNIQUE_ID_BYTES), None
             if self.rank == 0:
-                _dcheck(self.lib.tfgx_dist_unique_id(uid), "tfgx_dist_unique_id")
+                try:
+                    _dcheck(self.lib.tfgx_dist_unique_id(uid), "tfgx_dist_unique_id")
+                except Exception as ex:          # noqa: BLE001
+                    err = "{}: {}".format(type(ex).__name__, ex)
+            self._agree(err, "ncclGetUniqueId")
             if self.world > 1:
                 box = [bytes(uid.raw)]
                 src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
                 dist.broadcast_object_list(box, src=src, group=self.group)      # control channel: 128 bytes
                 uid = ctypes.create_string_buffer(box[0], UNIQUE_ID_BYTES)
             comm = ctypes.c_void_p()
-            _dcheck(self.lib.tfgx_dist_comm_init(self.world, self.rank, uid, ctypes.byref(comm)), "tfgx_dist_comm_init")
+            try:
+                _dcheck(self.lib.tfgx_dist_comm_init(self.world, self.rank, uid, ctypes.byref(comm)), "tfgx_dist_comm_init")
+            except Exception as ex:              # noqa: BLE001
+                err = "{}: {}".format(type(ex).__name__, ex)
+            self._agree(err, "ncclCommInitRank")
             self.comm = comm
         return self.comm
+
+    def comm_info(self):
+        """(ranks, rank, device) as the ncclComm_t itself reports them (ncclCommCount / UserRank / CuDevice); a transport
+        of a 1-process job has no communicator: (1, 0, current device)."""
+        if self.comm is None:
+            return 1, 0, int(torch.cuda.current_device())
+        w, r, d = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+        _dcheck(self.lib.tfgx_dist_comm_info(self.comm, ctypes.byref(w), ctypes.byref(r), ctypes.byref(d)),
+                "tfgx_dist_comm_info")
+        return int(w.value), int(r.value), int(d.value)
+
+    def checked_self_check(self):
+        """self_check, then the ranks agree on its outcome (a rank that received wrong rows raises alone otherwise)."""
+        err = None
+        try:
+            self.self_check()
+        except Exception as ex:                  # noqa: BLE001
+            err = "{}: {}".format(type(ex).__name__, ex)
+        self._agree(err, "the self-check (rows through tfgx_alltoallv / tfgx_allreduce_sum_i64)")
 
     def close(self):
         if self.comm is not None:
@@ -395,8 +449,15 @@ _TRANSPORTS = {}
 
 
 def get_transport(group, backend, kind=None):
-    """One transport (one communicator, one communication stream) per (group, kind).  kind: "tfgx_dist" | "torch" | None
-    (auto: the C-ABI RCCL transport for the HIP backend unless the group is gloo; TFGX_DIST_TRANSPORT overrides)."""
+    """One transport (one communicator, one communication stream) per (group, kind).
+
+    kind "tfgx_dist": the C-ABI RCCL transport, STRICT — if any rank cannot bring it up, every rank raises
+                      TfgxDistUnavailable (bench.py and the examples ask for it by name: a scaling line must never be
+                      carried by something else).  Works over any control group (nccl or gloo).
+    kind "torch":     torch.distributed collectives (host-staged on a gloo group) — CPU tests, two ranks on one GPU.
+    kind None:        TFGX_DIST_TRANSPORT if set (strict, as above); otherwise AUTO: tfgx_dist for the HIP backend on
+                      an nccl group — falling back, on every rank together and with a warning, to torch collectives if
+                      the ranks agree that it is unavailable — and torch for gloo groups / the numpy test backend."""
     kind = kind or os.environ.get("TFGX_DIST_TRANSPORT")
     auto = kind is None
     inited = dist.is_available() and dist.is_initialized()
@@ -404,44 +465,45 @@ def get_transport(group, backend, kind=None):
         hip = getattr(backend, "name", "") == "hip"
         gloo = inited and dist.get_backend(group) != "nccl"
         kind = "tfgx_dist" if (hip and not gloo) else "torch"
+    if kind not in ("tfgx_dist", "torch"):
+        raise L.TfgxError("unknown transport kind {!r} (tfgx_dist | torch)".format(kind))
     key = (id(group) if group is not None else 0, kind, inited)
     t = _TRANSPORTS.get(key)
     if t is None:
-        if kind == "tfgx_dist" and auto and inited and dist.get_world_size(group) > 1:
-            t = _checked_tfgx_transport(group, backend)
+        multi = inited and dist.get_world_size(group) > 1
+        if kind == "torch":
+            t = TorchDistTransport(group, backend)
+        elif not multi:
+            t = TfgxDistTransport(group)
         else:
-            t = TfgxDistTransport(group) if kind == "tfgx_dist" else TorchDistTransport(group, backend)
+            t = _bring_up_tfgx(group, backend, auto)
         _TRANSPORTS[key] = t
     return t
 
 
-def _checked_tfgx_transport(group, backend):
-    """Auto mode at world > 1: build the C-ABI transport, push a few rows through it (self_check), and let the ranks
-    AGREE on the outcome over the control channel.  If any rank failed, every rank takes torch.distributed's RCCL
-    collectives instead — same exchange lists, same kernels either side — with a warning and a transport name that says
-    so (bench.py prints it in config.transport).  TFGX_DIST_TRANSPORT=tfgx_dist skips the net and fails loudly."""
-    err, t = None, None
+def _bring_up_tfgx(group, backend, auto):
+    """The C-ABI transport of a multi-rank group: bootstrap (the ranks agree before and after every collective step),
+    then a few rows through every plan-time entry point, agreed again.  Strict (auto=False): TfgxDistUnavailable on every
+    rank when any rank failed.  AUTO: every rank takes _torch_fallback instead."""
     try:
         t = TfgxDistTransport(group)
-        t.self_check()
-    except Exception as ex:          # noqa: BLE001 - anything: a missing library, an RCCL error, wrong rows
-        err = "{}: {}".format(type(ex).__name__, ex)
-    flag = torch.tensor([0 if err else 1], dtype=torch.int32, device=L.device())
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-    if int(flag.item()) == 1:
+        t.checked_self_check()
         return t
+    except TfgxDistUnavailable as ex:            # raised on every rank (see TfgxDistTransport._agree)
+        if not auto:
+            raise
+        return _torch_fallback(group, backend, str(ex))
+
+
+def _torch_fallback(group, backend, reason):
+    """AUTO mode only, all ranks together: torch.distributed's collectives on the same group — same exchange lists, same
+    kernels either side — with a warning and a transport name that says so."""
     import warnings
-    msg = "tf_geometric_amd.dist: the tfgx_dist (C ABI) transport failed its self-check on {} ({}); all ranks fall back " \
-          "to torch.distributed collectives on the same RCCL group".format(
-              "this rank" if err else "another rank", err or "see that rank's log")
+    msg = "tf_geometric_amd.dist: {}; all ranks fall back to torch.distributed collectives on the same group " \
+          "(pass transport='tfgx_dist' or set TFGX_DIST_TRANSPORT=tfgx_dist to fail instead)".format(reason)
     warnings.warn(msg)
-    if t is not None:
-        try:
-            t.close()
-        except Exception:            # noqa: BLE001
-            pass
     tt = TorchDistTransport(group, backend)
-    tt.name = "torch (fallback: tfgx_dist self-check failed)"
+    tt.name = "torch (fallback: tfgx_dist unavailable)"
     tt.fallback_reason = msg
     return tt
 

@@ -16,6 +16,54 @@ def synthetic_edges(num_nodes, num_edges, seed=0):
     return np.stack([np.concatenate([a, b]), np.concatenate([b, a])]).astype(np.int32)
 
 
+PAIR_BLOCK = 1 << 20          # pairs per independently seeded block of synthetic_edge_stripe
+ROW_BLOCK = 1 << 16           # rows per independently seeded block of synthetic_feature_rows
+
+
+def _pair_block(num_nodes, count, seed, k):
+    rng = np.random.Generator(np.random.PCG64(np.random.SeedSequence([int(seed), int(k)])))
+    a = rng.integers(0, num_nodes, size=count, dtype=np.int32)
+    b = rng.integers(0, num_nodes, size=count, dtype=np.int32)
+    keep = a != b
+    return a[keep], b[keep]
+
+
+def synthetic_edge_stripe(num_nodes, num_edges, seed=0, stripe=0, num_stripes=1):
+    """The same family of graphs as synthetic_edges (E/2 uniform pairs, self pairs dropped, both directions emitted), but
+    drawn in blocks of PAIR_BLOCK pairs, block k from its own stream SeedSequence([seed, k]) — so stripe `stripe` of
+    `num_stripes` (a contiguous range of blocks) can be generated ALONE: rank r of an N-GPU job builds only its E/N edges,
+    and the union over the stripes is the same edge multiset for every num_stripes (bench.py: the same graph at every N).
+    A stripe is [all (a,b) of its blocks | all (b,a) of its blocks]; with num_stripes = 1 that is synthetic_edges'
+    layout.  int32 [2, ~E/num_stripes]."""
+    half = num_edges // 2
+    n_blocks = -(-half // PAIR_BLOCK) if half else 0
+    lo, hi = (n_blocks * stripe) // num_stripes, (n_blocks * (stripe + 1)) // num_stripes
+    blocks = [_pair_block(num_nodes, min(PAIR_BLOCK, half - k * PAIR_BLOCK), seed, k) for k in range(lo, hi)]
+    tot = sum(int(a.shape[0]) for a, _ in blocks)
+    out = np.empty((2, 2 * tot), dtype=np.int32)           # filled in place: one pass over the 1 GB at products size
+    pos = 0
+    for a, b in blocks:
+        m = int(a.shape[0])
+        out[0, pos:pos + m], out[1, pos:pos + m] = a, b
+        out[0, tot + pos:tot + pos + m], out[1, tot + pos:tot + pos + m] = b, a
+        pos += m
+    return out
+
+
+def synthetic_feature_rows(num_nodes, num_features, seed=1, row_lo=0, row_hi=None):
+    """Rows [row_lo, row_hi) of a standard-normal [N, F] float32 matrix drawn in blocks of ROW_BLOCK rows (block k from
+    SeedSequence([seed, k])): any row range costs only its own blocks, and every rank sees the same matrix."""
+    row_hi = num_nodes if row_hi is None else row_hi
+    out = np.empty((max(row_hi - row_lo, 0), num_features), dtype=np.float32)
+    for k in range(row_lo // ROW_BLOCK, -(-row_hi // ROW_BLOCK) if row_hi > row_lo else 0):
+        b0, b1 = k * ROW_BLOCK, min((k + 1) * ROW_BLOCK, num_nodes)
+        rng = np.random.Generator(np.random.PCG64(np.random.SeedSequence([int(seed), int(k)])))
+        blk = rng.standard_normal((b1 - b0, num_features), dtype=np.float32)
+        s0, s1 = max(b0, row_lo), min(b1, row_hi)
+        out[s0 - row_lo:s1 - row_lo] = blk[s0 - b0:s1 - b0]
+    return out
+
+
 def synthetic_features(num_nodes, num_features, seed=1):
     rng = np.random.Generator(np.random.PCG64(seed))
     return rng.standard_normal((num_nodes, num_features), dtype=np.float32)
