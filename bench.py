@@ -189,36 +189,6 @@ def kernel_source_sha():
     return h.hexdigest()[:16]
 
 
-def rmat_edges(n, e, seed, dev):
-    """E/2 R-MAT pairs over 2^ceil(log2 n) ids, pairs with an id >= n or a == b dropped, both directions emitted
-    [all (a,b) | all (b,a)] like the uniform generator.  int32 [2, ~E] on the device."""
-    k = max(1, int(np.ceil(np.log2(max(n, 2)))))
-    half = e // 2
-    g = torch.Generator(device=dev)
-    g.manual_seed(seed)
-    got_a, got_b, have = [], [], 0
-    a_, b_, c_ = 0.57, 0.19, 0.19
-    for _ in range(8):
-        m = int((half - have) * 1.7) + 1024
-        src = torch.zeros(m, dtype=torch.int64, device=dev)
-        dst = torch.zeros(m, dtype=torch.int64, device=dev)
-        for _lvl in range(k):
-            r = torch.rand(m, generator=g, device=dev)
-            sbit = r >= (a_ + b_)
-            dbit = ((r >= a_) & (r < a_ + b_)) | (r >= a_ + b_ + c_)
-            src = src * 2 + sbit
-            dst = dst * 2 + dbit
-        keep = (src < n) & (dst < n) & (src != dst)
-        got_a.append(src[keep])
-        got_b.append(dst[keep])
-        have += int(keep.sum().item())
-        if have >= half:
-            break
-    a = torch.cat(got_a)[:half].to(torch.int32)
-    b = torch.cat(got_b)[:half].to(torch.int32)
-    return torch.stack([torch.cat([a, b]), torch.cat([b, a])]).contiguous()
-
-
 def _event_time(fn, steps, warmup):
     for _ in range(warmup):
         fn()
@@ -234,6 +204,7 @@ def _event_time(fn, steps, warmup):
 def rmat_line(tfg, L, n, e, f, x, steps, warmup, seed):
     from tf_geometric_amd.nn.conv.gcn import gcn_norm_adj
     from tf_geometric_amd.plan import segment_reduce
+    from tf_geometric_amd.synthetic import rmat_edges
     ei = rmat_edges(n, e, seed, x.device)
     e_r = int(ei.shape[1])
     torch.cuda.synchronize()

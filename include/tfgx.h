@@ -43,7 +43,11 @@ enum { TFGX_SUM = 0, TFGX_MEAN = 1, TFGX_MAX = 2 };
 enum { TFGX_ACT_NONE = 0, TFGX_ACT_RELU = 1 };
 enum { TFGX_NORM_BOTH = 0, TFGX_NORM_LEFT = 1, TFGX_NORM_RIGHT = 2 };
 
-int tfgx_version(void);
+/* ABI version of this header: bumped whenever an entry point's signature or a struct's layout changes (a host built
+ * against another value must refuse to run: tf_geometric_amd/_lib.py does).  100 = rounds 1-3; 110 = round 4
+ * (tfgx_reduce_args.hub_order_slot; tfgx_aggregate_gemm_f32 honours args->out as a side output of the aggregate). */
+#define TFGX_ABI_VERSION 110
+int tfgx_version(void);            /* the TFGX_ABI_VERSION the library was built with */
 const char* tfgx_last_error(void); /* host string, thread-local, valid until the next failing call */
 
 /* ---------------------------------------------------------------------------------------------
@@ -149,6 +153,10 @@ typedef struct tfgx_reduce_args {
     uint32_t* track;
     int64_t ld_track;
     const int32_t* track_row_begin;
+    /* optional, read by tfgx_aggregate_gemm_f32 only, with row_order and hub lists: hub_order_slot[i] = index into hub_rows of
+       destination row row_order[i], for i < n_hub_rows (a walk order sorted by descending length puts the hub rows first).
+       Checked against hub_rows before use; NULL or a mismatch costs a binary search per hub row instead of one load. */
+    const int32_t* hub_order_slot;
 } tfgx_reduce_args;
 
 int tfgx_segment_reduce_f32(const tfgx_reduce_args* args /* host */, tfgx_stream_t stream);
@@ -162,11 +170,14 @@ int tfgx_segment_reduce_describe(const tfgx_reduce_args* args /* host */, char* 
  * (A_hat x) W, nn/conv/gcn.py:272-288; the neighbour half of mean / sum GraphSAGE, nn/conv/graph_sage.py:34-58):
  *     C[n_dst, N] = act( reduce(args) @ B[F, N] + bias )
  * where reduce(args) is exactly what tfgx_segment_reduce_f32 would write for `args` (op TFGX_SUM | TFGX_MEAN; w, self_coef,
- * mean_count honoured; args->out / ldo / act / bias are NOT used) — but the [n_dst, F] aggregate never visits HBM: 64-row
- * tiles go registers -> LDS -> v_mfma_f32_32x32x2_f32 against B resident in LDS, bias / activation in the epilogue.
+ * mean_count honoured; args->act / bias are NOT used) — but the [n_dst, F] aggregate is not read back from HBM: 64-row
+ * tiles go registers -> LDS -> v_mfma_f32_32x32x2_f32 against B, bias / activation in the epilogue.  B is resident in LDS as
+ * far as it fits beside the two tiles (all of it up to F = 100 -> 256; its first 128 columns at F = 128 -> 256); the
+ * consumer jobs of the remaining columns read their B operand from global memory (L2-resident: <= 128 KB re-read per tile).
+ * args->out: NULL, or [n_dst, ldo] (16-byte aligned rows) that ALSO receives the aggregate itself — the training forward,
+ * whose weight gradient needs it; the projection still takes it from LDS.
  * Needs a plain CSR (row_begin = row_ptr, row_end = row_ptr + 1, rp_stride = 1), 16-byte aligned rows, F % 4 == 0,
- * F <= 128, N <= 256 and B + two tiles within 160 KB of LDS: tfgx_aggregate_gemm_fits(F, N) == 1; no accumulate / add_x /
- * split rows / row_order / track.  Hub lists (hub_threshold, hub_rows, hub_chunk_*, hub_scratch) are honoured: the chunks
+ * F <= 128, N <= 256: tfgx_aggregate_gemm_fits(F, N) == 1; no accumulate / add_x / split rows / track.  Hub lists (hub_threshold, hub_rows, hub_chunk_*, hub_scratch) are honoured: the chunks
  * are reduced into hub_scratch by a launch of the ordinary kernel first, and a long row's lane group folds its chunk
  * partials in chunk order instead of walking the edges.  Deterministic.  Callers fall back to the two launches otherwise. */
 int tfgx_aggregate_gemm_fits(int64_t F, int64_t N);

@@ -209,9 +209,13 @@ def _remove_inf_and_nan(x):
 
 
 def gcn_norm_adj(edge_index, edge_weight, num_nodes, norm="both", add_self_loop=True, sym=True,
-                 renorm=True, improved=False, acc=np.float64):
+                 renorm=True, improved=False, acc=np.float64, row_deg=None):
     """nn/conv/gcn.py:32-130 for a square adjacency (non-square forbids add_self_loop/sym, :65-69).
-    Returns (index [2,E'], value [E'] float32) of the normalised adjacency, self-loops appended."""
+    Returns (index [2,E'], value [E'] float32) of the normalised adjacency, self-loops appended.
+    row_deg (test infrastructure for CUT-OUT sub-problems of a big graph, tests/test_gpu_fullsize.py): the row sums the
+    reference would compute at :80 on the WHOLE graph (diagonal included where the mode adds it first), given for the
+    nodes of the sub-problem — a source node's degree depends on in-edges the cut-out does not hold.  norm="both", sym=True
+    only; every other line runs unchanged on the sub-problem's edges."""
     ei = np.asarray(edge_index, dtype=np.int32).reshape(2, -1)
     E = ei.shape[1]
     w = np.ones([E], dtype=np.float32) if edge_weight is None else np.asarray(edge_weight, dtype=np.float32)
@@ -223,6 +227,9 @@ def gcn_norm_adj(edge_index, edge_weight, num_nodes, norm="both", add_self_loop=
         return ei2, w2
 
     def row_sum(ei_, w_):
+        if row_deg is not None:
+            assert norm == "both" and sym and np.shape(row_deg) == (N,)
+            return np.asarray(row_deg, dtype=acc)
         return unsorted_segment_sum(w_.astype(acc), ei_[0], N, acc=acc)
 
     def col_sum(ei_, w_):
@@ -270,11 +277,13 @@ def matmul(a, b, acc=np.float64):
 
 
 def gcn(x, edge_index, edge_weight, kernel, bias=None, activation=None, norm="both", add_self_loop=True,
-        sym=True, renorm=True, improved=False, acc=np.float64):
-    """nn/conv/gcn.py:225-290 (inference: dropout is identity, num_or_size_splits does not change the result)."""
+        sym=True, renorm=True, improved=False, acc=np.float64, row_deg=None):
+    """nn/conv/gcn.py:225-290 (inference: dropout is identity, num_or_size_splits does not change the result).
+    row_deg: see gcn_norm_adj (cut-out sub-problems only)."""
     x = np.asarray(x, dtype=np.float32)
     N = x.shape[0]
-    ei, nw = gcn_norm_adj(edge_index, edge_weight, N, norm, add_self_loop, sym, renorm, improved, acc=acc)  # :260
+    ei, nw = gcn_norm_adj(edge_index, edge_weight, N, norm, add_self_loop, sym, renorm, improved, acc=acc,
+                          row_deg=row_deg)                                 # :260
     h = x if kernel is None else matmul(x, kernel, acc)                   # :266-272
     h = spmm(ei, nw, (N, N), h, acc=acc)                                   # :280
     if bias is not None:

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), "libtfgx.so does not export {}".format(name)
     assert set(names) == set(_lib.SIGNATURES), "ctypes table and header disagree: {}".format(
         set(names) ^ set(_lib.SIGNATURES))
-    assert lib.tfgx_version() >= 100
+    assert lib.tfgx_version() == 110          # include/tfgx.h TFGX_ABI_VERSION == _lib.ABI_VERSION
 
 
 def test_structs_match_header_layout(tmp_path):
@@ -87,7 +87,7 @@ def test_argument_validation_without_gpu():
     # phases outside {1, 2, 3}; and a fused aggregate -> GEMM shape that does not fit LDS is refused on the host
     assert lib.tfgx_segment_max_backward_mask_phases_f32(None, None, None, 4, 8, None, 8, 8, None, 8, None, 8, None, 8, None, 8,
                                                          None, None, None, None, 4, None, 8, None, 0, 0, None) == 1
-    assert lib.tfgx_aggregate_gemm_fits(128, 256) == 0 and lib.tfgx_aggregate_gemm_fits(100, 256) == 1
+    assert lib.tfgx_aggregate_gemm_fits(128, 256) == 1 and lib.tfgx_aggregate_gemm_fits(100, 256) == 1
     assert lib.tfgx_aggregate_gemm_fits(102, 16) == 0 and lib.tfgx_aggregate_gemm_fits(100, 257) == 0
     g = _lib.GatArgs()
     g.H, g.d, g.dv, g.n_dst, g.scale, g.drop_rate = 2, 4, 4, 3, 2.0, 1.5

@@ -388,6 +388,58 @@ def test_mean_sum_sage_layer_grads_fused_epilogues(tfg, oracle, cls, f, units, c
         assert_parity(getattr(layer, k).grad.cpu().numpy(), r[k].grad.numpy(), tol=2e-4, what=cls + " d/d" + k)
 
 
+@pytest.mark.parametrize("kind,f,units", [("gcn", 12, 24), ("gcn", 100, 256), ("gcn", 128, 256), ("MeanGraphSage", 12, 32),
+                                           ("SumGraphSage", 100, 256), ("MeanGraphSage", 128, 512)])
+@pytest.mark.parametrize("x_grad", [True, False])
+def test_training_forward_takes_the_fused_launch(tfg, oracle, kind, f, units, x_grad):
+    """The aggregate-then-project layers TRAIN through tfgx_aggregate_gemm_f32 too (autograd._AggregateProject /
+    _SageWide): one forward launch, the aggregate written beside it for the weight gradient (FUSED_STATS says so), and
+    output + every gradient vs float64 autograd over the reference's formula (gcn.py:272-288, graph_sage.py:34-58) —
+    including F = 128 -> 256, where half of the kernel is read from global memory.  x_grad False = layer 0 (data input)."""
+    from tf_geometric_amd import plan as P
+    x, ei, w, rng = _graph(oracle, n=700, e=9000, f=f, seed=31)
+    n = x.shape[0]
+    ei = ei[:, ei[0] != 7]
+    w = w[:ei.shape[1]]
+    gout = torch.tensor(rng.standard_normal((n, units)).astype(np.float32), device="cuda")
+    xt = torch.tensor(x, device="cuda", requires_grad=x_grad)
+    xr = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    before = dict(P.FUSED_STATS)
+    if kind == "gcn":
+        layer = tfg.layers.GCN(units, activation=tfg.relu)
+        layer._maybe_build([x])
+        ws = {"kernel": oracle.glorot_uniform(rng, f, units), "bias": (rng.standard_normal(units) * 0.1).astype(np.float32)}
+        layer.set_weights(**ws)
+        layer.trainable(True)
+        out = layer([xt, ei, w], cache={})
+        r = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in ws.items()}
+        idx, nw = oracle.gcn_norm_adj(ei, w, n)
+        A = torch.zeros(n, n, dtype=torch.float64).index_put((torch.from_numpy(idx[0]).long(), torch.from_numpy(idx[1]).long()),
+                                                             torch.from_numpy(nw).double(), accumulate=True)
+        ref = torch.relu(A @ (xr @ r["kernel"]) + r["bias"])
+    else:
+        layer = getattr(tfg.layers, kind)(units, activation=tfg.relu, concat=True)
+        layer._maybe_build([x])
+        ku = units // 2
+        ws = {"self_kernel": oracle.glorot_uniform(rng, f, ku), "neighbor_kernel": oracle.glorot_uniform(rng, f, ku),
+              "bias": (rng.standard_normal(units) * 0.3).astype(np.float32)}
+        layer.set_weights(**ws)
+        layer.trainable(True)
+        out = layer([xt, ei, w], cache={})
+        r = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in ws.items()}
+        red = _ref_aggregate(xr, ei, torch.tensor(w, dtype=torch.float64), "mean" if kind.startswith("Mean") else "sum", n)
+        ref = torch.relu(torch.cat([xr @ r["self_kernel"], red @ r["neighbor_kernel"]], 1) + r["bias"])
+    assert P.FUSED_STATS["launches"] == before["launches"] + 1
+    assert P.FUSED_STATS["with_side_output"] == before["with_side_output"] + 1      # the kernel's gradient needs the aggregate
+    out.backward(gout)
+    ref.backward(gout.double().cpu())
+    assert_parity(out.detach().cpu().numpy(), ref.detach().numpy(), what=kind + " fused training forward")
+    if x_grad:
+        assert_parity(xt.grad.cpu().numpy(), xr.grad.numpy(), tol=5e-5, what=kind + " d/dx")
+    for k in ws:
+        assert_parity(getattr(layer, k).grad.cpu().numpy(), r[k].grad.numpy(), tol=2e-4, what=kind + " d/d" + k)
+
+
 def test_demo_gcn_trains_on_cora_shaped_graph(tfg):
     """examples/demo_gcn.py (counterpart of the reference's demo/demo_gcn.py): accuracy far above 1/7 chance."""
     import os

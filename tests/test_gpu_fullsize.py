@@ -317,3 +317,107 @@ def test_products_shard_static_features_use_the_edge_tail_layout(tfg, products):
     fast = sg.aggregate_static(st, L.SUM, w=sg.norm_w, self_coef=sg.self_coef)
     assert torch.equal(plain, fast)
     assert torch.equal(sg.aggregate(table, L.MEAN), sg.aggregate_static(st, L.MEAN))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Whole LAYERS at BASELINE configs[3]'s shape (products: N = 2.4 M, E = 123 M, F = 100, units = 256, concat — the reference's
+# demo/demo_graph_sage.py:29-30) through the routes a drop-in user gets — the fused aggregate -> projection launch for GCN and
+# mean GraphSAGE, the per-node-MLP + max reduce for max-pool GraphSAGE — on the uniform graph AND on the R-MAT graph (hub
+# rows, degree-ordered walk), sampled rows vs the ORACLE's layer functions run on the cut-out sub-problem.
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def products_rmat(tfg):
+    from tf_geometric_amd import synthetic
+    from tf_geometric_amd.plan import CsrPlan
+    n, e, f = synthetic.WORKLOADS["products"]
+    ei = synthetic.rmat_edges(n, e, 7, torch.device("cuda"))
+    g = torch.Generator(device="cuda")
+    g.manual_seed(11)
+    x = torch.randn(n, f, generator=g, device="cuda")
+    w = torch.rand(int(ei.shape[1]), generator=g, device="cuda") + 0.5
+    plan = CsrPlan.build(ei, n, n)
+    return dict(n=n, f=f, ei=ei, x=x, w=w, plan=plan)
+
+
+def _layer_rows(p, count, seed, hub_rows=0, max_hub_degree=20000, longest=True):
+    """Sorted sample of destination rows: `count` uniform ones plus, on skewed plans, `hub_rows` rows from the plan's hub
+    list (longer than the hub threshold: reduced chunk by chunk) and, with `longest`, the longest row of the graph."""
+    rows = _sample_rows(p["n"], count, seed)
+    hub = p["plan"].hub_info()
+    if hub_rows and hub is not None:
+        deg = p["plan"].in_degree()
+        cand = hub[0].long()
+        cand = cand[deg[cand] <= max_hub_degree]
+        g = torch.Generator(device="cpu")
+        g.manual_seed(seed + 1)
+        pick = cand[torch.randperm(int(cand.shape[0]), generator=g)[:hub_rows].cuda()]
+        rows = torch.unique(torch.cat([rows, pick] + ([deg.argmax().reshape(1)] if longest else [])))
+    return rows
+
+
+def _cut_out(p, rows):
+    """Sub-problem of the sampled rows: nodes = rows + every source of their in-edges (global ids, sorted); edges renumbered
+    into it, per-row edge order kept.  -> (nodes (GPU), ei_sub numpy int32, edge positions (GPU), local index of each row)."""
+    import numpy as np
+    ei = p["ei"]
+    pos = torch.nonzero(torch.isin(ei[0].long(), rows)).squeeze(1)
+    nodes = torch.unique(torch.cat([rows, ei[1, pos].long()]))
+    sub = torch.stack([torch.searchsorted(nodes, ei[0, pos].long()), torch.searchsorted(nodes, ei[1, pos].long())])
+    return nodes, sub.cpu().numpy().astype(np.int32), pos, torch.searchsorted(nodes, rows).cpu().numpy()
+
+
+@pytest.mark.parametrize("graph", ["uniform", "rmat"])
+@pytest.mark.parametrize("kind", ["GCN", "MeanGraphSage", "MaxPoolGraphSage"])
+def test_products_layers_sampled_rows_match_oracle(tfg, oracle, products, products_rmat, graph, kind):
+    import numpy as np
+    from conftest import assert_parity
+    from tf_geometric_amd import plan as P
+    p = products if graph == "uniform" else products_rmat
+    n, f, units = p["n"], p["f"], 256
+    rng = np.random.Generator(np.random.PCG64(60 + len(kind)))
+    cache = {"tfgx_csr_plan": p["plan"]}
+    heavy = kind == "MaxPoolGraphSage"                    # the reference's per-EDGE MLP: [E_sub, 512] float64 in the oracle
+    rows = _layer_rows(p, 600 if heavy else 2000, seed=8, hub_rows=(10 if heavy else 100) if graph == "rmat" else 0,
+                       max_hub_degree=3000 if heavy else 20000, longest=not heavy)
+    nodes, ei_sub, pos, local = _cut_out(p, rows)
+    x_sub, w_sub = p["x"][nodes].cpu().numpy(), p["w"][pos].cpu().numpy()
+    before = dict(P.FUSED_STATS)
+    if kind == "GCN":
+        k, b = oracle.glorot_uniform(rng, f, units), (rng.standard_normal(units) * 0.1).astype(np.float32)
+        layer = tfg.layers.GCN(units, activation=tfg.relu)
+        layer._maybe_build([p["x"]])
+        layer.set_weights(kernel=k, bias=b)
+        got = layer([p["x"], p["ei"], p["w"]], cache=cache)[rows].cpu().numpy()
+        # row sums of A + I over the WHOLE graph (gcn.py:77,80), in float64 by torch — independent of the HIP plan
+        deg = torch.zeros(n, dtype=torch.float64, device="cuda").index_add_(0, p["ei"][0].long(), p["w"].double()) + 1.0
+        ref = oracle.gcn(x_sub, ei_sub, w_sub, k, b, "relu", row_deg=deg[nodes].cpu().numpy())[local]
+        assert P.FUSED_STATS["launches"] == before["launches"] + 1          # ONE launch: tfgx_aggregate_gemm_f32
+    elif kind == "MeanGraphSage":
+        ws, wn = oracle.glorot_uniform(rng, f, units // 2), oracle.glorot_uniform(rng, f, units // 2)
+        b = (rng.standard_normal(units) * 0.1).astype(np.float32)
+        layer = tfg.layers.MeanGraphSage(units, activation=tfg.relu, concat=True)
+        layer._maybe_build([p["x"]])
+        layer.set_weights(self_kernel=ws, neighbor_kernel=wn, bias=b)
+        got = layer([p["x"], p["ei"], p["w"]], cache=cache)[rows].cpu().numpy()
+        ref = oracle.mean_graph_sage(x_sub, ei_sub, w_sub, ws, wn, b, "relu", concat=True)[local]
+        assert P.FUSED_STATS["launches"] == before["launches"] + 1          # the neighbour half: one fused launch
+    else:
+        ku = units // 2
+        ws, wm, wn = (oracle.glorot_uniform(rng, f, ku), oracle.glorot_uniform(rng, f, 4 * ku),
+                      oracle.glorot_uniform(rng, 4 * ku, ku))
+        bm, b = (rng.standard_normal(4 * ku) * 0.1).astype(np.float32), (rng.standard_normal(units) * 0.1).astype(np.float32)
+        layer = tfg.layers.MaxPoolGraphSage(units, activation=tfg.relu, concat=True)
+        layer._maybe_build([p["x"]])
+        layer.set_weights(self_kernel=ws, mlp_kernel=wm, mlp_bias=bm, neighs_kernel=wn, bias=b)
+        got = layer([p["x"], p["ei"], p["w"]], cache=cache)[rows].cpu().numpy()
+        ref = oracle.max_pool_graph_sage(x_sub, ei_sub, w_sub, ws, wm, wn, bm, b, "relu", concat=True)[local]
+        # a row without in-edges keeps float32 lowest through the next GEMM (graph_sage.py:263-266): 512 products of -3.4e38
+        # summed in float32 overflow or not depending on the summation ORDER (the float64-accumulating oracle and any fp32
+        # GEMM, TensorFlow's included, disagree on which columns end up +-inf) — so on those rows only the self half
+        # (x @ W_self, finite) is compared; rows with neighbours are compared in full
+        has = (p["plan"].in_degree()[rows] > 0).cpu().numpy()
+        if (~has).any():
+            assert_parity(got[~has][:, :ku], ref[~has][:, :ku], what="max-pool SAGE self half of rows without in-edges")
+        got, ref = got[has], ref[has]
+    assert ei_sub.shape[1] > 1000 and got.shape[0] > 400
+    assert_parity(got, ref, what="products-shape {} ({} graph) layer on sampled rows".format(kind, graph))

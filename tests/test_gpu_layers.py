@@ -399,7 +399,9 @@ def test_static_aggregation_memo_is_opt_in_exact_and_invalidated(tfg, oracle):
 
 
 @pytest.mark.parametrize("n,e,f,units", [(5000, 60000, 100, 256), (777, 9000, 64, 40), (3000, 30000, 128, 128),
-                                          (130, 900, 36, 7), (64, 300, 4, 1), (10000, 150000, 100, 128), (1000, 0, 8, 16)])
+                                          (130, 900, 36, 7), (64, 300, 4, 1), (10000, 150000, 100, 128), (1000, 0, 8, 16),
+                                          (6000, 70000, 128, 256), (1500, 20000, 128, 200), (900, 8000, 104, 129),
+                                          (2100, 30000, 124, 256)])
 @pytest.mark.parametrize("mode", ["gcn", "mean", "sum_unweighted"])
 def test_fused_aggregate_gemm_equals_two_launches(tfg, oracle, n, e, f, units, mode):
     """tfgx_aggregate_gemm_f32 (aggregate -> LDS -> MFMA in one launch) vs tfgx_segment_reduce_f32 + tfgx_gemm_bias_act_f32
@@ -429,14 +431,30 @@ def test_fused_aggregate_gemm_equals_two_launches(tfg, oracle, n, e, f, units, m
     assert fused is not None and tuple(fused.shape) == (n, units)
     agg = P.segment_reduce(plan, xd, op, w_csr=w_csr, self_coef=sc)
     two = P.gemm_bias_act(agg, kd, bias=bd, act=L.ACT_RELU)
-    ref = np.maximum(agg.double().cpu().numpy() @ k.astype(np.float64) + b, 0)
-    assert_parity(fused.cpu().numpy(), ref, what="fused aggregate->gemm vs float64 of the same aggregate")
+    # reference side: the oracle's aggregate (float64 accumulation over the caller's edge list, stored as float32 as the
+    # reference stores it), float64 projection
+    if ei.shape[1]:
+        red = oracle.mean_reducer if mode == "mean" else oracle.sum_reducer
+        agg_ref = oracle.aggregate_neighbors(x, ei, None if mode == "sum_unweighted" else w,
+                                             oracle.identity_mapper if mode == "sum_unweighted" else oracle.gcn_mapper, red,
+                                             oracle.identity_updater, num_nodes=n).astype(np.float64)
+    else:
+        agg_ref = np.zeros((n, f))
+    if sc is not None:
+        agg_ref = agg_ref + sc.double().cpu().numpy()[:, None] * x.astype(np.float64)
+    assert_parity(agg.cpu().numpy(), agg_ref, what="two-launch aggregate vs oracle")
+    ref = np.maximum(agg_ref @ k.astype(np.float64) + b, 0)
+    assert_parity(fused.cpu().numpy(), ref, what="fused aggregate->gemm vs the oracle's aggregate projected in float64")
     assert_parity(fused.cpu().numpy(), two.cpu().numpy(), what="fused vs two launches")
     # into a column block of a wider output (GraphSAGE's concat halves) and without bias / activation
     wide = torch.full((n, units + 5), 7.0, device="cuda")
     P.aggregate_gemm(plan, xd, op, kd, w_csr=w_csr, self_coef=sc, out=wide[:, 5:])
-    assert_parity(wide[:, 5:].cpu().numpy(), agg.double().cpu().numpy() @ k.astype(np.float64), what="fused into a column block")
+    assert_parity(wide[:, 5:].cpu().numpy(), agg_ref @ k.astype(np.float64), what="fused into a column block")
     assert bool((wide[:, :5] == 7.0).all())
+    # training forward: the aggregate itself as a side output — the bits tfgx_segment_reduce_f32 writes — same projection
+    side = torch.full((n, f), float("nan"), device="cuda")
+    again = P.aggregate_gemm(plan, xd, op, kd, w_csr=w_csr, self_coef=sc, bias=bd, act=L.ACT_RELU, agg_out=side)
+    assert torch.equal(side, agg) and torch.equal(again, fused)
 
 
 def test_fused_aggregate_gemm_declines_what_it_cannot_take(tfg, oracle):
@@ -444,13 +462,14 @@ def test_fused_aggregate_gemm_declines_what_it_cannot_take(tfg, oracle):
     from tf_geometric_amd import plan as P
     L = tfg._lib
     lib = L.require_gpu()
-    assert lib.tfgx_aggregate_gemm_fits(128, 256) == 0 and lib.tfgx_aggregate_gemm_fits(100, 256) == 1
+    assert lib.tfgx_aggregate_gemm_fits(128, 256) == 1 and lib.tfgx_aggregate_gemm_fits(100, 256) == 1   # (B partly resident)
     assert lib.tfgx_aggregate_gemm_fits(102, 16) == 0 and lib.tfgx_aggregate_gemm_fits(132, 16) == 0
     assert lib.tfgx_aggregate_gemm_fits(100, 257) == 0
     ei = oracle.synthetic_edges(500, 4000, seed=1)
     plan = P.CsrPlan.build(L.as_i32(ei), 500, 500)
     x = torch.randn(500, 128, device="cuda")
-    assert P.aggregate_gemm(plan, x, L.SUM, torch.randn(128, 256, device="cuda")) is None      # B + tiles exceed 160 KB
+    assert P.aggregate_gemm(plan, x, L.SUM, torch.randn(128, 300, device="cuda")) is None      # more than 256 output columns
+    assert P.aggregate_gemm(plan, x[:, :126], L.SUM, torch.randn(126, 16, device="cuda")) is None   # F % 4 != 0
     assert P.aggregate_gemm(plan, x, L.MAX, torch.randn(128, 16, device="cuda")) is None       # max is not linear
 
 

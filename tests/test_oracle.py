@@ -235,3 +235,23 @@ def test_topk_pool_known_answers(oracle):
         oracle.topk_pool(src, sc)
     with pytest.raises(Exception):
         oracle.topk_pool(src, sc, k=1, ratio=0.5)
+
+
+def test_gcn_on_a_cut_out_with_whole_graph_degrees_equals_the_whole_graph_rows(oracle):
+    """oracle.gcn(..., row_deg=...) — the form tests/test_gpu_fullsize.py runs on sub-problems cut out of a 123 M-edge graph:
+    sampled destination rows + their in-edges + the row sums of the WHOLE graph for the nodes involved reproduce the whole
+    graph's output rows (bitwise: same edges in the same order per row, same degrees)."""
+    rng = np.random.Generator(np.random.PCG64(90))
+    n, f, u = 500, 9, 6
+    ei = oracle.synthetic_edges(n, 6000, seed=90)
+    w = rng.uniform(0.5, 1.5, ei.shape[1]).astype(np.float32)
+    x = rng.standard_normal((n, f)).astype(np.float32)
+    k, b = oracle.glorot_uniform(rng, f, u), rng.standard_normal(u).astype(np.float32)
+    whole = oracle.gcn(x, ei, w, k, b, "relu")
+    rows = np.sort(rng.permutation(n)[:40])
+    keep = np.isin(ei[0], rows)
+    nodes = np.unique(np.concatenate([rows, ei[1][keep]]))
+    sub = np.stack([np.searchsorted(nodes, ei[0][keep]), np.searchsorted(nodes, ei[1][keep])]).astype(np.int32)
+    deg = oracle.unsorted_segment_sum(w.astype(np.float64), ei[0], n) + 1.0          # rows of A + I (gcn.py:77,80)
+    part = oracle.gcn(x[nodes], sub, w[keep], k, b, "relu", row_deg=deg[nodes])
+    assert np.array_equal(part[np.searchsorted(nodes, rows)], whole[rows])

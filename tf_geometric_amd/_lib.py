@@ -26,6 +26,9 @@ class TfgxError(RuntimeError):
     pass
 
 
+ABI_VERSION = 110      # include/tfgx.h TFGX_ABI_VERSION: struct layouts / signatures bound below
+
+
 class ReduceArgs(ctypes.Structure):
     """struct tfgx_reduce_args (include/tfgx.h)."""
     _fields_ = [
@@ -43,6 +46,7 @@ class ReduceArgs(ctypes.Structure):
         ("edge_tail", ctypes.c_void_p), ("ld_edge_tail", ctypes.c_int64),
         ("row_order", ctypes.c_void_p),
         ("track", ctypes.c_void_p), ("ld_track", ctypes.c_int64), ("track_row_begin", ctypes.c_void_p),
+        ("hub_order_slot", ctypes.c_void_p),
     ]
 
 
@@ -220,6 +224,9 @@ def load_library():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    if lib.tfgx_version() != ABI_VERSION:
+        raise TfgxError("tf_geometric_amd: {} was built for ABI {} but this package binds ABI {} (include/tfgx.h "
+                        "TFGX_ABI_VERSION): rebuild with __graft_entry__.build()".format(LIB_PATH, lib.tfgx_version(), ABI_VERSION))
     _lib = lib
     return lib
 

@@ -25,7 +25,7 @@ import torch
 
 from . import _lib as L
 from .plan import (segment_reduce, can_track, gemm_bias_act, gemm_tn, transpose, SplitRows, gather_friendly_empty,
-                   gather_friendly_copy)
+                   gather_friendly_copy, aggregate_gemm, aggregate_gemm_applies)
 
 
 def needs_grad(*tensors):
@@ -124,27 +124,141 @@ class _Aggregate(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        lib = L.require_gpu()
         plan = ctx.plan
         x, w_csr, self_coef, bias, out = ctx.saved_tensors
         g = relu_backward(g, out) if ctx.act == L.ACT_RELU else g.contiguous()
         gb = g.sum(0) if (bias is not None and ctx.needs_input_grad[6]) else None
-        gx = gw = gs = None
-        if ctx.mean and (ctx.needs_input_grad[3] or ctx.needs_input_grad[4]) and not ctx.needs_input_grad[2]:
-            g = g / plan.in_degree().clamp(min=1).to(g.dtype).unsqueeze(1)
-        if ctx.needs_input_grad[2]:
-            gx, g = _aggregate_grad_x(plan, ctx.mean, g, w_csr, self_coef)
-        if w_csr is not None and ctx.needs_input_grad[3]:
-            gw = torch.empty_like(w_csr)
-            g2, ldg = L.row_major_2d(g)
-            x2, ldx = L.row_major_2d(x.detach())
-            hub_w, _ = L.hub_lists(plan)           # hub destinations: their edges are walked chunk-wise
-            L.check(lib.tfgx_sddmm_hub_f32(L.ptr(plan.row_ptr), L.ptr(plan.col), plan.n_dst, L.ptr(g2), ldg, L.ptr(x2), ldx,
-                                           int(x2.shape[1]), L.ptr(gw), None if hub_w is None else ctypes.byref(hub_w),
-                                           L.stream_ptr()), "tfgx_sddmm_hub_f32")
-        if self_coef is not None and ctx.needs_input_grad[4]:
-            gs = (x.detach() * g).sum(1)
+        gx, gw, gs = _aggregate_backward(plan, ctx.mean, x, w_csr, self_coef, g, ctx.needs_input_grad[2],
+                                         ctx.needs_input_grad[3], ctx.needs_input_grad[4])
         return None, None, gx, gw, gs, None, gb, None
+
+
+def _aggregate_backward(plan, mean, x, w_csr, self_coef, g, need_x, need_w, need_s):
+    """(d/dx, d/dw_csr, d/dself_coef) of (1/cnt) (sum_i w_i x[col_i] + self_coef x) given g = d/d(aggregate)."""
+    lib = L.require_gpu()
+    gx = gw = gs = None
+    need_w = need_w and w_csr is not None
+    need_s = need_s and self_coef is not None
+    if mean and (need_w or need_s) and not need_x:
+        g = g / plan.in_degree().clamp(min=1).to(g.dtype).unsqueeze(1)
+    if need_x:
+        gx, g = _aggregate_grad_x(plan, mean, g, w_csr, self_coef)
+    if need_w:
+        gw = torch.empty_like(w_csr)
+        g2, ldg = L.row_major_2d(g)
+        x2, ldx = L.row_major_2d(x.detach())
+        hub_w, _ = L.hub_lists(plan)           # hub destinations: their edges are walked chunk-wise
+        L.check(lib.tfgx_sddmm_hub_f32(L.ptr(plan.row_ptr), L.ptr(plan.col), plan.n_dst, L.ptr(g2), ldg, L.ptr(x2), ldx,
+                                       int(x2.shape[1]), L.ptr(gw), None if hub_w is None else ctypes.byref(hub_w),
+                                       L.stream_ptr()), "tfgx_sddmm_hub_f32")
+    if need_s:
+        gs = (x.detach() * g).sum(1)
+    return gx, gw, gs
+
+
+class _AggregateProject(torch.autograd.Function):
+    """out = act( reduce(plan, x, w, self_coef) @ kernel + bias ) — the aggregate-then-project layers (GCN with units > F,
+    the neighbour half of mean / sum GraphSAGE) in ONE forward launch (tfgx_aggregate_gemm_f32).  When the kernel needs a
+    gradient the launch also writes the aggregate itself (side output: d/dkernel = aggregate^T @ g); the projection still
+    reads it from LDS, so the training forward saves the GEMM's read-back of the [N, F] aggregate."""
+
+    @staticmethod
+    def forward(ctx, plan, mean, x, w_csr, self_coef, kernel, bias, act):
+        n, F = plan.n_dst, int(x.shape[1])
+        need_agg = ctx.needs_input_grad[5]
+        agg = torch.empty((n, F), dtype=torch.float32, device=x.device) if need_agg else None
+        out = aggregate_gemm(plan, x.detach(), L.MEAN if mean else L.SUM, kernel.detach(),
+                             w_csr=None if w_csr is None else w_csr.detach(),
+                             self_coef=None if self_coef is None else self_coef.detach(),
+                             bias=None if bias is None else bias.detach(), act=act, agg_out=agg)
+        if out is None:
+            raise L.TfgxError("_AggregateProject: the fused launch declined (ask plan.aggregate_gemm_applies first)")
+        ctx.plan, ctx.mean, ctx.act = plan, mean, act
+        ctx.save_for_backward(x, w_csr, self_coef, kernel, bias, agg, out if act == L.ACT_RELU else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w_csr, self_coef, kernel, bias, agg, out = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        g = relu_backward(g, out) if ctx.act == L.ACT_RELU else g.contiguous()
+        want_b = bias is not None and need[6]
+        gk = gb = None
+        if need[5] or want_b:
+            if agg is not None:
+                gk, gb = gemm_tn(agg, g, want_bias=want_b)
+                if not need[5]:
+                    gk = None
+            else:
+                gb = g.sum(0)
+        gx = gw = gs = None
+        if need[2] or need[3] or need[4]:
+            g_agg = gemm_bias_act(g, transpose(kernel.detach()))          # d/d(aggregate) = g @ kernel^T
+            gx, gw, gs = _aggregate_backward(ctx.plan, ctx.mean, x, w_csr, self_coef, g_agg, need[2], need[3], need[4])
+        return None, None, gx, gw, gs, gk, gb, None
+
+
+def aggregate_project(plan, x, op, kernel, w_csr=None, self_coef=None, bias=None, act=L.ACT_NONE):
+    """Differentiable act(reduce(plan, x) @ kernel + bias) on the fused launch, or None when it does not take the shape
+    (the caller then composes aggregate + linear)."""
+    if op not in (L.SUM, L.MEAN) or not aggregate_gemm_applies(x, kernel, op):
+        return None
+    return _AggregateProject.apply(plan, op == L.MEAN, x, w_csr, self_coef, L.as_f32(kernel),
+                                   None if bias is None else L.as_f32(bias), act)
+
+
+class _SageWide(torch.autograd.Function):
+    """h = act([x @ ks | reduce(w * x[col]) @ kn] + bias): mean / sum GraphSAGE, concat form, aggregation first (ku >= F:
+    nn/conv/graph_sage.py:34-58 with demo_graph_sage.py:29-30's units=256).  The neighbour half is ONE launch
+    (tfgx_aggregate_gemm_f32 straight into its half of h, aggregate written beside it for d/dkn), the self half the GEMM."""
+
+    @staticmethod
+    def forward(ctx, plan, mean, x, ks, kn, w_csr, bias, act):
+        n, F, na, nb = int(x.shape[0]), int(x.shape[1]), int(ks.shape[1]), int(kn.shape[1])
+        h = torch.empty((n, na + nb), dtype=torch.float32, device=x.device)
+        bd = None if bias is None else bias.detach().contiguous()
+        agg = torch.empty((n, F), dtype=torch.float32, device=x.device) if ctx.needs_input_grad[4] else None
+        got = aggregate_gemm(plan, x.detach(), L.MEAN if mean else L.SUM, kn.detach(),
+                             w_csr=None if w_csr is None else w_csr.detach(),
+                             bias=None if bd is None else bd[na:].contiguous(), act=act, out=h[:, na:], agg_out=agg)
+        if got is None:
+            raise L.TfgxError("_SageWide: the fused launch declined (ask plan.aggregate_gemm_applies first)")
+        gemm_bias_act(x.detach(), ks.detach(), bias=None if bd is None else bd[:na], act=act, out=h[:, :na])
+        ctx.plan, ctx.mean, ctx.act, ctx.na = plan, mean, act, na
+        ctx.save_for_backward(x, ks, kn, w_csr, bias, agg, h if act == L.ACT_RELU else None)
+        return h
+
+    @staticmethod
+    def backward(ctx, g):
+        x, ks, kn, w_csr, bias, agg, h = ctx.saved_tensors
+        plan, na, need = ctx.plan, ctx.na, ctx.needs_input_grad
+        g = relu_backward(g, h) if ctx.act == L.ACT_RELU else g.contiguous()
+        want_b = bias is not None and need[6]
+        gs, gn = g[:, :na], g[:, na:]
+        gx, gks, gba = _linear_grads(x, ks, gs, need[2], need[3], want_b)
+        gkn = gbb = None
+        if need[4] or want_b:
+            if agg is not None:
+                gkn, gbb = gemm_tn(agg, gn, want_bias=want_b)
+                if not need[4]:
+                    gkn = None
+            else:
+                gbb = gn.sum(0)
+        if need[2]:
+            g_agg = gemm_bias_act(gn, transpose(kn.detach()))
+            gx2, _, _ = _aggregate_backward(plan, ctx.mean, x, w_csr, None, g_agg, True, False, False)
+            gx = gx + gx2
+        gb = torch.cat([gba, gbb]) if want_b else None
+        return None, None, gx, gks, gkn, None, gb, None
+
+
+def sage_wide(plan, op, x, ks, kn, w_csr=None, bias=None, act=L.ACT_NONE):
+    """Differentiable mean / sum GraphSAGE layer body (concat form, aggregation first) with the neighbour half on the fused
+    launch, or None when it does not take the shape.  Edge weights are constants here (trainable ones take the un-fused route)."""
+    if op not in (L.SUM, L.MEAN) or not aggregate_gemm_applies(x, kn, op):
+        return None
+    return _SageWide.apply(plan, op == L.MEAN, x, L.as_f32(ks), L.as_f32(kn), w_csr,
+                           None if bias is None else L.as_f32(bias), act)
 
 
 # Gradient of max aggregation (tf.math.unsorted_segment_max, ties share evenly):

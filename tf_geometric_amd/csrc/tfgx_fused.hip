@@ -32,7 +32,6 @@ constexpr int kTileRows = 64;
 constexpr int kLda = kTileRows + 1;
 constexpr int kBufs = 2;
 constexpr int kFusedThreads = 1024;
-constexpr int kCtrlInts = 1 + 2 * kBufs;
 #ifndef TFGX_FUSED_JB
 #define TFGX_FUSED_JB 2
 #endif

@@ -175,7 +175,7 @@ __global__ void emit_unique(const int64_t* __restrict__ keys_s, const int32_t* _
 
 using namespace tfgx;
 
-extern "C" int tfgx_version(void) { return 100; }
+extern "C" int tfgx_version(void) { return TFGX_ABI_VERSION; }
 
 extern "C" const char* tfgx_last_error(void) { return g_err; }
 

@@ -197,8 +197,16 @@ def gcn(x, sparse_adj, kernel, bias=None, activation=None, norm="both", add_self
         bias_t = None if bias is None else L.as_f32(bias)
         if narrow_first:
             pre = static_aggregate(h, normed.plan, cache, L.SUM, normed.w_csr, normed.self_coef)   # opt-in memo (layer 0)
-            h = pre if pre is not None else AG.aggregate(normed.plan, h, L.SUM, normed.w_csr, normed.self_coef, rows=rows)
-            h = AG.linear(h, kernel, bias_t, act)
+            fused = None
+            if pre is None and not isinstance(rows, SplitRows):
+                # ONE forward launch (tfgx_aggregate_gemm_f32); the aggregate is written beside it only because the
+                # kernel's gradient needs it — the projection reads it from LDS (None: shape does not fit)
+                fused = AG.aggregate_project(normed.plan, h, L.SUM, kernel, normed.w_csr, normed.self_coef, bias_t, act)
+            if fused is not None:
+                h = fused
+            else:
+                h = pre if pre is not None else AG.aggregate(normed.plan, h, L.SUM, normed.w_csr, normed.self_coef, rows=rows)
+                h = AG.linear(h, kernel, bias_t, act)
         else:
             h = AG.aggregate(normed.plan, h, L.SUM, normed.w_csr, normed.self_coef, rows=rows, bias=bias_t, act=act)
         return post(h) if post is not None else h

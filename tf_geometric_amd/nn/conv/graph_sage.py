@@ -98,6 +98,25 @@ def _concat_fused(x, edge_index, edge_weight, ws, wn, bias, activation, normaliz
     return h
 
 
+def _concat_fused_training(x, edge_index, edge_weight, ws, wn, bias, activation, normalize, op, cache):
+    """The same layer body with gradients (autograd.sage_wide): the neighbour half's forward is still one launch; the
+    aggregate is written beside it when d/dW_neigh is wanted.  None when the fused kernel does not take the call."""
+    n = int(x.shape[0])
+    plan = CsrPlan.from_cache(edge_index, n, n, cache)
+    if static_aggregate_applies(x, cache) or isinstance(static_rows(x, plan, cache), SplitRows):
+        return None
+    w_csr = AG.edge_attr_csr(plan, edge_weight, cache)
+    act, post = _resolve_act(activation)
+    h = AG.sage_wide(plan, op, x, ws, wn, w_csr, bias, act)
+    if h is None:
+        return None
+    if post is not None:
+        h = post(h)
+    if normalize:
+        h = h * torch.rsqrt(torch.clamp((h * h).sum(-1, keepdim=True), min=1e-12))
+    return h
+
+
 def _self_neighbor_sage(x, edge_index, edge_weight, self_kernel, neighbor_kernel, bias, activation, concat, normalize,
                         op, cache):
     """mean / sum GraphSAGE (reference :9-115).  Both reducers are linear, so
@@ -112,6 +131,10 @@ def _self_neighbor_sage(x, edge_index, edge_weight, self_kernel, neighbor_kernel
     if not ku_n < F:
         if concat and not AG.needs_grad(x, edge_weight, ws, wn, bias):
             h = _concat_fused(x, edge_index, edge_weight, ws, wn, bias, activation, normalize, op, cache)
+            if h is not None:
+                return h
+        if concat and not AG.needs_grad(edge_weight):
+            h = _concat_fused_training(x, edge_index, edge_weight, ws, wn, bias, activation, normalize, op, cache)
             if h is not None:
                 return h
         x, reduced = _neighbor_reduce(x, edge_index, edge_weight, op, cache)

@@ -143,6 +143,18 @@ class CsrPlan(object):
             self._hub = build_hub_lists(self.row_ptr[:-1], self.row_ptr[1:], thr, chunk) or False
         return self._hub or None
 
+    def hub_order_slot(self):
+        """int32 [n_hub]: the slot in hub_rows of walk-order entry i (row_order sorts by descending length, so its first
+        n_hub entries ARE the hub rows) — tfgx_reduce_args.hub_order_slot; None without hub rows / walk order."""
+        if getattr(self, "_hub_order_slot", None) is None:
+            hub, order = self.hub_info(), self.row_order()
+            slot = False
+            if hub is not None and order is not None:
+                n_hub = int(hub[0].shape[0])
+                slot = torch.searchsorted(hub[0], order[:n_hub].contiguous()).to(torch.int32).contiguous()
+            self._hub_order_slot = slot
+        return None if self._hub_order_slot is False else self._hub_order_slot
+
 
 def build_hub_lists(span_begin, span_end, threshold, chunk):
     """Cut every span [begin[r], end[r]) longer than `threshold` into chunks of `chunk` CSR positions.
@@ -281,6 +293,7 @@ def prepare_static_features(x, edge_index, cache, num_nodes=None, cache_aggregat
     n = int(x.shape[0]) if num_nodes is None else int(num_nodes)
     plan = edge_index if isinstance(edge_index, CsrPlan) else CsrPlan.from_cache(edge_index, n, int(x.shape[0]), cache)
     cache[CACHE_KEY_STATIC] = x
+    cache.pop(CACHE_KEY_STATIC_AUTO, None)          # an explicit declaration: rebuilt on a version bump, never dropped
     if cache_aggregation:
         cache[CACHE_KEY_STATIC_AGG] = {}
     else:
@@ -292,7 +305,8 @@ def prepare_static_features(x, edge_index, cache, num_nodes=None, cache_aggregat
 
 
 def release_static_features(cache):
-    """Undo prepare_static_features: frees the layout; later aggregations read x itself."""
+    """Undo prepare_static_features (or an automatic promotion): frees the layout; later aggregations read x itself."""
+    cache.pop(CACHE_KEY_STATIC_AUTO, None)
     cache.pop(CACHE_KEY_STATIC, None)
     cache.pop(CACHE_KEY_STATIC_ROWS, None)
     cache.pop(CACHE_KEY_STATIC_AGG, None)
@@ -338,16 +352,75 @@ def static_aggregate_applies(x, cache):
     return store is not None and _declared_static(x, cache) and not torch.cuda.is_current_stream_capturing()
 
 
+# AUTOMATIC promotion to the static layout (round 4): a drop-in user never calls prepare_static_features — the
+# reference's own epoch loop (demo/demo_gcn.py:68-77) passes the SAME feature tensor to layer 0 in every step.  When a layer
+# meets the same tensor again (same live storage, same torch version counter, same plan) after it has already been
+# aggregated once, and the layout would remove over-fetch (SplitRows.wanted) and fits the budget, the layout is built then
+# and used from that call on — under exactly the contract prepare_static_features states: a torch-visible write (version
+# counter) drops it again (a tensor that changes every step is never promoted); writes that bypass the counter (x.data,
+# foreign pointers) are not seen.  TFGX_STATIC_LAYOUT=explicit (or plan.AUTO_STATIC_LAYOUT = False) turns promotion off;
+# TFGX_STATIC_LAYOUT_BUDGET = bytes the layout may take (default: 10 % of the HBM free at that moment).
+import os as _os
+import weakref as _weakref
+
+AUTO_STATIC_LAYOUT = _os.environ.get("TFGX_STATIC_LAYOUT", "auto") != "explicit"
+CACHE_KEY_STATIC_SEEN = "tfgx_static_seen"        # {data_ptr: (weakref(x), key, launch counter at first sight)}
+CACHE_KEY_STATIC_AUTO = "tfgx_static_auto"        # True while the opt-in in this cache was made by the promotion
+_AGG_LAUNCHES = [0]                                # aggregation launches so far (segment_reduce / aggregate_gemm)
+
+
+def static_layout_budget_bytes():
+    env = _os.environ.get("TFGX_STATIC_LAYOUT_BUDGET")
+    if env is not None:
+        return int(float(env))
+    free, _ = torch.cuda.mem_get_info()
+    return free // 10
+
+
+def _auto_promote(x, plan, cache):
+    """Second sighting of the same tensor (see above) -> declare it static in `cache`; True when promoted."""
+    if (not AUTO_STATIC_LAYOUT or x.dim() != 2 or not x.is_contiguous() or x.requires_grad or x.dtype != torch.float32
+            or not x.is_cuda or not SplitRows.wanted(int(x.shape[0]), int(x.shape[1]))
+            or torch.cuda.is_current_stream_capturing()):
+        return False
+    seen = cache.setdefault(CACHE_KEY_STATIC_SEEN, {})
+    key = _static_key(x, plan)
+    # "the same tensor" = the same live STORAGE (layers see a fresh .detach() view of the caller's tensor on every call;
+    # torch keeps one Python object per storage while it is alive, so a weak reference tells a tensor that was freed and
+    # whose address the allocator handed out again — a hidden activation of the next step — from the caller's matrix)
+    store = x.untyped_storage()
+    hit = seen.get(x.data_ptr())
+    if hit is None or hit[0]() is not store or hit[1] != key:
+        if len(seen) >= 8:
+            seen.clear()
+        seen[x.data_ptr()] = (_weakref.ref(store), key, _AGG_LAUNCHES[0])
+        return False
+    if _AGG_LAUNCHES[0] == hit[2]:
+        return False                                   # still the first layer call (it looks the tensor up more than once)
+    F = int(x.shape[1])
+    need = 4 * (int(x.shape[0]) * F + plan.num_edges * (F % 32))
+    if need > static_layout_budget_bytes():
+        return False
+    seen.pop(x.data_ptr(), None)
+    cache[CACHE_KEY_STATIC] = x
+    cache[CACHE_KEY_STATIC_AUTO] = True
+    STATIC_STATS["auto_promotions"] = STATIC_STATS.get("auto_promotions", 0) + 1
+    return True
+
+
 def static_rows(x, plan, cache):
-    """`x`, or its prepared SplitRows + edge-resident-tail form when — and only when — the caller opted in for exactly
-    this tensor (`prepare_static_features`, or `cache["tfgx_static_features"] = x`).  No heuristics: a tensor that was
-    not declared static is always read as it is.  A torch-visible change of x (version counter) rebuilds the layout
-    outside hipGraph capture and falls back to x inside it (building allocates)."""
+    """`x`, or its SplitRows + edge-resident-tail form when this tensor is the graph's static feature matrix: declared by
+    the caller (`prepare_static_features`, or `cache["tfgx_static_features"] = x`) or promoted automatically on its second
+    aggregation (see AUTO_STATIC_LAYOUT above).  A torch-visible change of x (version counter) rebuilds a DECLARED layout
+    outside hipGraph capture and falls back to x inside it (building allocates); an automatically promoted one is dropped."""
     if cache is None or not isinstance(x, torch.Tensor):
         return x
     opt = cache.get(CACHE_KEY_STATIC, None)
     if opt is None or opt is False or not isinstance(opt, torch.Tensor):
-        return x
+        if opt is None and _auto_promote(x, plan, cache):
+            opt = x
+        else:
+            return x
     # "the same tensor": same storage window (views made by .detach() / as_f32 share it); opt is kept alive by the
     # cache entry, so the address cannot have been recycled
     if opt.data_ptr() != x.data_ptr() or opt.shape != x.shape or opt.dtype != x.dtype or opt.stride() != x.stride():
@@ -358,6 +431,12 @@ def static_rows(x, plan, cache):
             STATIC_STATS["hits"] += 1
         return x if hit[1] is None else hit[1]
     if torch.cuda.is_current_stream_capturing() or x.dim() != 2 or not x.is_contiguous():
+        return x
+    if hit is not None and cache.get(CACHE_KEY_STATIC_AUTO):
+        # promoted automatically and now written to: not static after all — drop the layout, start counting again
+        release_static_features(cache)
+        STATIC_STATS["auto_demotions"] = STATIC_STATS.get("auto_demotions", 0) + 1
+        _auto_promote(x, plan, cache)
         return x
     rows, _ = _build_static_rows(x, plan, cache)
     return x if rows is None else rows
@@ -454,17 +533,33 @@ def segment_reduce(plan, x, op, w_csr=None, out=None, act=L.ACT_NONE, self_coef=
         L.check(lib.tfgx_segment_reduce_describe(ctypes.byref(a), buf, 160), "tfgx_segment_reduce_describe")
         return buf.value.decode()
     L.check(lib.tfgx_segment_reduce_f32(ctypes.byref(a), L.stream_ptr()), "tfgx_segment_reduce_f32")
+    _AGG_LAUNCHES[0] += 1
     return out
 
 
 FUSE_AGGREGATE_GEMM = True      # developer A/B switch (tools/ab_fused_layer.py): False = always two launches
 
 
-def aggregate_gemm(plan, x, op, kernel, w_csr=None, self_coef=None, bias=None, act=L.ACT_NONE, out=None):
+FUSED_STATS = {"launches": 0, "with_side_output": 0}      # diagnostics (tests assert the route taken)
+
+
+def aggregate_gemm_applies(x, kernel, op=L.SUM):
+    """Would aggregate_gemm take this call?  (No launch; callers that must choose their autograd route ask first.)"""
+    if not FUSE_AGGREGATE_GEMM or op not in (L.SUM, L.MEAN) or isinstance(x, SplitRows) or kernel is None:
+        return False
+    lib = L.require_gpu()
+    x2, ldx = L.row_major_2d(x)
+    F, N = int(x2.shape[1]), int(kernel.shape[1])
+    return bool(int(kernel.shape[0]) == F and lib.tfgx_aggregate_gemm_fits(F, N) and ldx % 4 == 0
+                and x2.data_ptr() % 16 == 0)
+
+
+def aggregate_gemm(plan, x, op, kernel, w_csr=None, self_coef=None, bias=None, act=L.ACT_NONE, out=None, agg_out=None):
     """act(segment_reduce(plan, x, op, w_csr, self_coef) @ kernel + bias) in ONE launch (tfgx_aggregate_gemm_f32: the
-    aggregate goes registers -> LDS -> MFMA, never through HBM), or None when the fused kernel does not take this call
-    (shape outside tfgx_aggregate_gemm_fits, unaligned rows) —
-    the caller then runs the two launches."""
+    aggregate goes registers -> LDS -> MFMA and is never read back from HBM), or None when the fused kernel does not take
+    this call (shape outside tfgx_aggregate_gemm_fits, unaligned rows) — the caller then runs the two launches.
+    agg_out: optional dense [n_dst, F] tensor that ALSO receives the aggregate itself (the training forward: the weight
+    gradient needs it)."""
     if not FUSE_AGGREGATE_GEMM or op not in (L.SUM, L.MEAN) or isinstance(x, SplitRows):
         return None
     lib = L.require_gpu()
@@ -496,6 +591,16 @@ def aggregate_gemm(plan, x, op, kernel, w_csr=None, self_coef=None, bias=None, a
         a.hub_chunk_begin, a.hub_chunk_end = chunk_begin.data_ptr(), chunk_end.data_ptr()
         a.n_hub_rows, a.n_hub_chunks = int(hub_rows.shape[0]), int(chunk_begin.shape[0])
         a.hub_scratch = scratch.data_ptr()
+        slot = plan.hub_order_slot()
+        if slot is not None:
+            a.hub_order_slot = slot.data_ptr()
+    if agg_out is not None:
+        ao, ldo = L.row_major_2d(agg_out)
+        assert ao is agg_out and tuple(agg_out.shape) == (n_dst, F) and ldo % 4 == 0 and agg_out.data_ptr() % 16 == 0
+        a.out, a.ldo = agg_out.data_ptr(), ldo
+        FUSED_STATS["with_side_output"] += 1
+    FUSED_STATS["launches"] += 1
+    _AGG_LAUNCHES[0] += 1
     bias_t = None if bias is None else L.as_f32(bias).contiguous()
     L.check(lib.tfgx_aggregate_gemm_f32(ctypes.byref(a), L.ptr(k2), ldb, L.ptr(bias_t), act, L.ptr(out), ldc, N,
                                         L.stream_ptr()), "tfgx_aggregate_gemm_f32")

@@ -80,6 +80,38 @@ def glorot_uniform(fan_in, fan_out, seed=3):
     return rng.uniform(-limit, limit, size=(fan_in, fan_out)).astype(np.float32)
 
 
+# R-MAT variant of SURVEY.md §8d: (a,b,c,d) = (0.57,0.19,0.19,0.05), generated on the GPU (torch; imported lazily)
+def rmat_edges(n, e, seed, dev):
+    """E/2 R-MAT pairs over 2^ceil(log2 n) ids, pairs with an id >= n or a == b dropped, both directions emitted
+    [all (a,b) | all (b,a)] like the uniform generator.  int32 [2, ~E] on the device."""
+    import torch
+    k = max(1, int(np.ceil(np.log2(max(n, 2)))))
+    half = e // 2
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    got_a, got_b, have = [], [], 0
+    a_, b_, c_ = 0.57, 0.19, 0.19
+    for _ in range(8):
+        m = int((half - have) * 1.7) + 1024
+        src = torch.zeros(m, dtype=torch.int64, device=dev)
+        dst = torch.zeros(m, dtype=torch.int64, device=dev)
+        for _lvl in range(k):
+            r = torch.rand(m, generator=g, device=dev)
+            sbit = r >= (a_ + b_)
+            dbit = ((r >= a_) & (r < a_ + b_)) | (r >= a_ + b_ + c_)
+            src = src * 2 + sbit
+            dst = dst * 2 + dbit
+        keep = (src < n) & (dst < n) & (src != dst)
+        got_a.append(src[keep])
+        got_b.append(dst[keep])
+        have += int(keep.sum().item())
+        if have >= half:
+            break
+    a = torch.cat(got_a)[:half].to(torch.int32)
+    b = torch.cat(got_b)[:half].to(torch.int32)
+    return torch.stack([torch.cat([a, b]), torch.cat([b, a])]).contiguous()
+
+
 WORKLOADS = {
     # name: (nodes, edges, features)  — BASELINE.json configs
     "products": (2400000, 123000000, 100),   # ogbn-products-shaped: north-star target (segment-sum, 1 GPU)

@@ -3,7 +3,10 @@
 one process: GCN layer 100 -> 256 (+ bias, ReLU) and the mean-SAGE layer (units 256, concat) at products shape; the
 aggregation alone and the GEMM alone beside them.
 
-    python tools/ab_fused_layer.py > gpurun_out/r03/ab_fused_layer.json
+    python tools/ab_fused_layer.py [products|arxiv] [uniform|rmat] [F]  > gpurun_out/r04/ab_fused_layer.json
+F overrides the workload's feature width (128: BASELINE configs C2 / C5 — half of the 128 x 256 kernel is read from L2).
+Also times ONE TRAINING step of the GCN layer (forward through the fused launch with the aggregate as a side output,
+backward) against the un-fused training route.
 """
 import json
 import os
@@ -20,7 +23,9 @@ import bench                                            # noqa: E402
 which = sys.argv[1] if len(sys.argv) > 1 else "products"
 graph = sys.argv[2] if len(sys.argv) > 2 else "uniform"          # "rmat": power-law in-degrees (hub rows, chunked)
 n, e, f = synthetic.WORKLOADS[which]
-ei = bench.rmat_edges(n, e, 7, torch.device("cuda")) if graph == "rmat" else L.as_i32(synthetic.synthetic_edges(n, e, seed=0))
+if len(sys.argv) > 3:
+    f = int(sys.argv[3])
+ei = synthetic.rmat_edges(n, e, 7, torch.device("cuda")) if graph == "rmat" else L.as_i32(synthetic.synthetic_edges(n, e, seed=0))
 g = torch.Generator(device="cuda")
 g.manual_seed(1)
 x = torch.randn(n, f, generator=g, device="cuda")
@@ -48,6 +53,20 @@ fns = {
     "aggregation_alone": lambda: P.segment_reduce(normed.plan, x, L.SUM, w_csr=normed.w_csr, self_coef=normed.self_coef, out=agg_out),
     "gemm_alone": lambda: P.gemm_bias_act(agg_out, k),
 }
+gt = tfg.layers.GCN(256, activation=tfg.relu)
+gt._maybe_build([x])
+gt.trainable(True)
+
+
+def train_step(fuse):
+    set_fuse(fuse)
+    for p_ in gt.parameters():
+        p_.grad = None
+    gt([x, ei], cache=cache).sum().backward()
+
+
+fns["gcn_layer_fwd_bwd_fused_forward"] = lambda: train_step(True)
+fns["gcn_layer_fwd_bwd_two_launch_forward"] = lambda: train_step(False)
 times = {name: [] for name in fns}
 for rnd in range(4):
     for name, fn in fns.items():
