@@ -45,7 +45,8 @@ enum { TFGX_NORM_BOTH = 0, TFGX_NORM_LEFT = 1, TFGX_NORM_RIGHT = 2 };
 
 /* ABI version of this header: bumped whenever an entry point's signature or a struct's layout changes (a host built
  * against another value must refuse to run: tf_geometric_amd/_lib.py does).  100 = rounds 1-3; 110 = round 4
- * (tfgx_reduce_args.hub_order_slot; tfgx_aggregate_gemm_f32 honours args->out as a side output of the aggregate). */
+ * (tfgx_reduce_args.hub_order_slot; tfgx_aggregate_gemm_f32 honours args->out as a side output of the aggregate;
+ * tfgx_gat_args / tfgx_gat_backward_args .drop_seed_dev). */
 #define TFGX_ABI_VERSION 110
 int tfgx_version(void);            /* the TFGX_ABI_VERSION the library was built with */
 const char* tfgx_last_error(void); /* host string, thread-local, valid until the next failing call */
@@ -269,6 +270,10 @@ typedef struct tfgx_gat_args {
        the host passes the rows sorted by in-degree, so that the rows sharing a wave have similar lengths (13-16 % on the
        whole layer at R-MAT shapes); results do not depend on it.  Ignored by the part / chunk launches. */
     const int32_t* row_order;
+    /* optional, with drop_rate > 0: the seed is read from this DEVICE location by the kernel instead of drop_seed — for
+       launches captured into a hipGraph, whose arguments are frozen: the captured step advances the value on the device, so
+       every replay draws a new mask (forward and backward of one step read the same location). */
+    const uint64_t* drop_seed_dev;
 } tfgx_gat_args;
 
 /* 1 if the item survives dropout at `rate`, else 0: the exact decision every kernel of this library makes for
@@ -420,6 +425,7 @@ typedef struct tfgx_gat_backward_args {
     /* optional walk orders (see tfgx_gat_args.row_order): destinations for the dst pass, sources for the src pass */
     const int32_t* row_order;
     const int32_t* row_order_t;
+    const uint64_t* drop_seed_dev;                /* see tfgx_gat_args.drop_seed_dev (same location as the forward) */
 } tfgx_gat_backward_args;
 
 /* Prepares both backward passes in ONE sweep over the destination rows: dsum[r, h] = <dO[r, h, :], O[r, h, :]> (dense

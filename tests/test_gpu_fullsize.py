@@ -96,24 +96,29 @@ def test_reddit_shaped_gat_partition_of_unity_and_bounds(tfg):
     assert float((uni - ref).abs().max()) < 2e-5
 
 
-def test_products_static_feature_layout_is_explicit_opt_in(tfg, products):
-    """The static-feature layout (SplitRows + edge-resident tail) is built ONLY after the caller
-    declares the tensor static (prepare_static_features / cache["tfgx_static_features"] = x): without the opt-in
-    nothing is derived from feature values, so a write that bypasses torch's version counter (x.data) can never
-    return stale results; with it, outputs are bit-identical, a torch-visible in-place update rebuilds the layout, and
-    release_static_features returns to the plain path."""
+def test_products_static_feature_layout_explicit_mode_and_opt_in(tfg, products):
+    """TFGX_STATIC_LAYOUT=explicit (plan.AUTO_STATIC_LAYOUT = False): the static-feature layout (SplitRows + edge-resident
+    tail) is built ONLY after the caller declares the tensor static (prepare_static_features /
+    cache["tfgx_static_features"] = x): nothing is derived from feature values otherwise, so a write that bypasses torch's
+    version counter (x.data) can never return stale results; with the opt-in, outputs are bit-identical, a torch-visible
+    in-place update rebuilds the layout, and release_static_features returns to the plain path."""
+    from tf_geometric_amd import plan as P
     from tf_geometric_amd.plan import SplitRows
     p = products
     x = p["x"].clone()
     cache = {"tfgx_csr_plan": p["plan"]}
     layer = tfg.layers.GCN(1, use_kernel=False, use_bias=False)
-    o1 = layer([x, p["ei"], p["w"]], cache=cache)
-    for _ in range(3):                                               # no heuristic: repeated calls build nothing
-        assert torch.equal(layer([x, p["ei"], p["w"]], cache=cache), o1)
-    assert "tfgx_static_rows" not in cache and "tfgx_static_features" not in cache
-    x.data.mul_(2.0)                                                 # bypasses the version counter
-    assert torch.equal(layer([x, p["ei"], p["w"]], cache=cache), o1 * 2.0)      # not stale: nothing was cached
-    x.data.mul_(0.5)
+    P.AUTO_STATIC_LAYOUT = False
+    try:
+        o1 = layer([x, p["ei"], p["w"]], cache=cache)
+        for _ in range(3):                                               # explicit mode: repeated calls build nothing
+            assert torch.equal(layer([x, p["ei"], p["w"]], cache=cache), o1)
+        assert "tfgx_static_rows" not in cache and "tfgx_static_features" not in cache
+        x.data.mul_(2.0)                                                 # bypasses the version counter
+        assert torch.equal(layer([x, p["ei"], p["w"]], cache=cache), o1 * 2.0)      # not stale: nothing was cached
+        x.data.mul_(0.5)
+    finally:
+        P.AUTO_STATIC_LAYOUT = True
     info = tfg.prepare_static_features(x, p["ei"], cache)
     assert info["layout"] == "edge_tail" and info["f_main"] == 96 and info["f_tail"] == 4
     assert info["bytes"] == 4 * (p["n"] * 100 + p["plan"].num_edges * 4)
@@ -124,16 +129,72 @@ def test_products_static_feature_layout_is_explicit_opt_in(tfg, products):
     assert torch.equal(o1, o2) and torch.equal(o1, o3)
     other = x.clone()                                                # a different tensor is never touched by the opt-in
     assert torch.equal(layer([other, p["ei"], p["w"]], cache=cache), o1) and cache["tfgx_static_rows"][1] is rows
-    x.mul_(2.0)                                                      # torch-visible update: layout rebuilt, not stale
+    x.mul_(2.0)                                                      # torch-visible update: DECLARED layout rebuilt, not stale
     o4 = layer([x, p["ei"], p["w"]], cache=cache)
     assert torch.equal(o4, o1 * 2.0) and cache["tfgx_static_rows"][1] is not rows
     sage = tfg.layers.MeanGraphSage(8)
     s1 = sage([x, p["ei"], p["w"]], cache=cache)
     tfg.release_static_features(cache)
     assert "tfgx_static_rows" not in cache
-    assert torch.equal(sage([x, p["ei"], p["w"]], cache=cache), s1) and "tfgx_static_rows" not in cache
     lazy = {"tfgx_csr_plan": p["plan"], "tfgx_static_features": x}   # the other spelling: built on first eager use
     assert torch.equal(layer([x, p["ei"], p["w"]], cache=lazy), o4) and lazy["tfgx_static_rows"][1] is not None
+    assert torch.equal(sage([x, p["ei"], p["w"]], cache=lazy), s1)
+
+
+def test_products_static_layout_is_promoted_automatically_on_the_second_call(tfg, products):
+    """The drop-in user's epoch loop (demo/demo_gcn.py:68-77: the SAME feature tensor into layer 0 every step, no API of this
+    package called): the first call reads x as it is; the second call meets the same live storage at the same version ->
+    the layout is built there (within TFGX_STATIC_LAYOUT_BUDGET) and used from then on, bit-identical outputs.  A
+    torch-visible write drops it (a tensor that changes every step is never promoted); a tensor that merely lands on a
+    recycled ADDRESS (a hidden activation of the next step) is not mistaken for it."""
+    import os
+    from tf_geometric_amd import plan as P
+    p = products
+    x = p["x"].clone()
+    cache = {"tfgx_csr_plan": p["plan"]}
+    layer = tfg.layers.GCN(1, use_kernel=False, use_bias=False)
+    st = lambda k: P.STATIC_STATS.get(k, 0)                           # noqa: E731
+    promos, demos, hits = st("auto_promotions"), st("auto_demotions"), st("hits")
+    o1 = layer([x, p["ei"], p["w"]], cache=cache)
+    assert "tfgx_static_rows" not in cache and st("auto_promotions") == promos          # first sighting: plain
+    o2 = layer([x, p["ei"], p["w"]], cache=cache)                     # second call: promoted here
+    assert st("auto_promotions") == promos + 1 and cache["tfgx_static_rows"][1] is not None and torch.equal(o1, o2)
+    o3 = layer([x.detach(), p["ei"], p["w"]], cache=cache)
+    assert torch.equal(o1, o3) and st("hits") >= hits + 1 and st("auto_promotions") == promos + 1
+    # a whole 2-layer model sharing the cache keeps hitting it (hidden activations never displace the entry)
+    gcn = tfg.layers.GCN(128, activation=tfg.relu)
+    a = gcn([x, p["ei"], p["w"]], cache=cache)
+    h0 = st("hits")
+    b = gcn([x, p["ei"], p["w"]], cache=cache)
+    assert torch.equal(a, b) and st("hits") > h0
+    x.mul_(2.0)                                                       # torch-visible write: dropped, this call reads x itself
+    o4 = layer([x, p["ei"], p["w"]], cache=cache)
+    assert torch.equal(o4, o1 * 2.0) and "tfgx_static_rows" not in cache and st("auto_demotions") == demos + 1
+    x.mul_(0.5)                                                       # ... and changes again before the next call:
+    o5 = layer([x, p["ei"], p["w"]], cache=cache)                     # version moved -> still not promoted
+    assert torch.equal(o5, o1) and "tfgx_static_rows" not in cache
+    o6 = layer([x, p["ei"], p["w"]], cache=cache)                     # unchanged since the last call -> promoted again
+    assert torch.equal(o6, o1) and cache["tfgx_static_rows"][1] is not None and st("auto_promotions") == promos + 2
+    tfg.release_static_features(cache)
+    # budget: a layout of 2.9 GB is not built when the budget says 1 GB
+    os.environ["TFGX_STATIC_LAYOUT_BUDGET"] = "1e9"
+    try:
+        c2 = {"tfgx_csr_plan": p["plan"]}
+        for _ in range(3):
+            assert torch.equal(layer([x, p["ei"], p["w"]], cache=c2), o1)
+        assert "tfgx_static_rows" not in c2
+    finally:
+        del os.environ["TFGX_STATIC_LAYOUT_BUDGET"]
+    # recycled address: two different tensors that happen to get the same block, one after the other
+    c3 = {"tfgx_csr_plan": p["plan"]}
+    t1 = x.clone()
+    ptr = t1.data_ptr()
+    layer([t1, p["ei"], p["w"]], cache=c3)
+    del t1
+    t2 = x * 3.0
+    same_block = t2.data_ptr() == ptr
+    o7 = layer([t2, p["ei"], p["w"]], cache=c3)
+    assert torch.allclose(o7, o1 * 3.0, rtol=1e-5, atol=1e-5) and "tfgx_static_rows" not in c3, same_block
 
 
 def test_static_layout_is_replayed_by_a_captured_forward(tfg, products):
@@ -421,3 +482,20 @@ def test_products_layers_sampled_rows_match_oracle(tfg, oracle, products, produc
         got, ref = got[has], ref[has]
     assert ei_sub.shape[1] > 1000 and got.shape[0] > 400
     assert_parity(got, ref, what="products-shape {} ({} graph) layer on sampled rows".format(kind, graph))
+
+
+def test_demo_gcn_products_shape_runs_the_static_layout_from_the_second_step(tfg):
+    """examples/demo_gcn.py --shape products: the reference's epoch loop (demo/demo_gcn.py:68-77) at products shape through
+    the layer signature alone — step 1 reads x as it is, step 2 promotes, later steps run layer 0 on the edge-tail layout
+    and are faster than step 1."""
+    import importlib.util
+    import os
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("demo_gcn", os.path.join(ROOT, "examples", "demo_gcn.py"))
+    demo = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(demo)
+    log = demo.main_products(steps=5, quiet=True)
+    assert [r["static_layout"] for r in log] == ["none", "edge_tail", "edge_tail", "edge_tail", "edge_tail"], log
+    assert log[-1]["auto_promotions"] == log[0]["auto_promotions"] + 1
+    assert min(r["layer0_forward_ms"] for r in log[2:]) < log[0]["layer0_forward_ms"], log
+    assert log[-1]["loss"] < log[0]["loss"]

@@ -243,3 +243,55 @@ def test_captured_train_step_needs_a_capturable_optimizer(tfg, oracle):
     layer.trainable(True)
     with pytest.raises(ValueError, match="capturable"):
         tfg.CapturedTrainStep(lambda: layer([x, ei]).sum(), torch.optim.Adam(layer.parameters(), lr=1e-2))
+
+
+def test_captured_gat_attention_dropout_draws_a_new_mask_on_every_replay(tfg, oracle):
+    """a dropout seed passed BY VALUE is frozen into a hipGraph — every replay of a captured step then
+    drops the same edges.  Under capture the seed lives on the device (nn/conv/gat.new_drop_seed: the captured sequence
+    advances the per-device seed stream and snapshots it per layer call; kernels read tfgx_gat_args.drop_seed_dev), so
+    (1) replays differ from one another, (2) each replay equals the EAGER layer run with that replay's seed value, and
+    (3) a captured training step of a GAT with edge_drop_rate > 0 sees a different loss on replays with frozen weights."""
+    from tf_geometric_amd.nn.conv import gat as G
+    from tf_geometric_amd.plan import CsrPlan
+    n, e, H = 2000, 30000, 2
+    x_np, ei, rng = _graph(oracle, n, e, 16, seed=13)
+    plan = CsrPlan.build(tfg._lib.as_i32(ei), n, n)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    Q, K, V = (torch.randn(n, 8, generator=g, device="cuda") for _ in range(3))
+    G.new_drop_seed(Q.device)                                   # eager use creates the device seed stream
+    state = G._seed_state(Q.device)
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        G.gat_attention(plan, Q, K, V, H, drop_rate=0.5, drop_seed=G.new_drop_seed(Q.device))
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    with torch.cuda.graph(graph):
+        seed_t = G.new_drop_seed(Q.device)
+        assert isinstance(seed_t, torch.Tensor)                  # under capture: a device tensor, not a frozen integer
+        out = G.gat_attention(plan, Q, K, V, H, drop_rate=0.5, drop_seed=seed_t)
+    outs, seeds = [], []
+    for _ in range(3):
+        graph.replay()
+        torch.cuda.synchronize()
+        outs.append(out.clone())
+        seeds.append(int(seed_t.item()))
+    assert len(set(seeds)) == 3 and int(state.item()) == seeds[-1]
+    assert not torch.equal(outs[0], outs[1]) and not torch.equal(outs[1], outs[2])
+    for o, s in zip(outs, seeds):                                # the eager launch with the same seed BY VALUE: same mask
+        assert torch.equal(o, G.gat_attention(plan, Q, K, V, H, drop_rate=0.5, drop_seed=s & 0xFFFFFFFFFFFFFFFF))
+    # a whole captured training step, weights frozen (lr = 0): the loss moves between replays because the mask does, and the
+    # backward of each replay regenerates ITS forward's mask (gradients finite, loss finite)
+    x = tfg._lib.as_f32(x_np)
+    layer = tfg.layers.GAT(8, attention_units=8, num_heads=H, edge_drop_rate=0.6)
+    cache = {}
+    with torch.no_grad():
+        layer([x, ei], cache=cache)
+    layer.trainable(True)
+    opt = torch.optim.SGD(layer.parameters(), lr=0.0)
+    step = tfg.CapturedTrainStep(lambda: (layer([x, ei], training=True, cache=cache) ** 2).mean(), opt)
+    losses = [float(step().detach()) for _ in range(4)]
+    assert len(set(losses)) == 4 and all(np.isfinite(losses))
+    assert all(torch.isfinite(p.grad).all() for p in layer.parameters())

@@ -48,6 +48,7 @@ def build(force=False, verbose=True):
         subprocess.check_call(cmd)
     build_dist(force=force or bool(jobs), verbose=verbose)
     build_c_abi_demo(force=force or bool(jobs), verbose=verbose)
+    build_tf_shim_mock(force=force or bool(jobs), verbose=verbose)
     return LIB_PATH
 
 
@@ -96,6 +97,32 @@ def build_c_abi_demo(force=False, verbose=True):
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
     return DEMO_BIN
+
+
+SHIM_DIR = os.path.join(_HERE, "..", "integration", "tf_shim")
+SHIM_MOCK_BIN = os.path.join(LIB_DIR, "tf_shim_mock_driver")
+
+
+def build_tf_shim_mock(force=False, verbose=True):
+    """lib/tf_shim_mock_driver: integration/tf_shim/tfgx_tf_ops.cc (the tf.load_op_library binding) LINKED against the mock
+    TensorFlow runtime of integration/tf_shim/mock/ and libtfgx.so / libtfgx_dist.so, with a script-driven main — every
+    Compute() body of the shim runs on the GPU in tests/test_gpu_tf_shim.py.  (TensorFlow itself is not in the image.)"""
+    srcs = [os.path.join(SHIM_DIR, "tfgx_tf_ops.cc"), os.path.join(SHIM_DIR, "mock", "mock_runtime.cc"),
+            os.path.join(SHIM_DIR, "mock", "mock_driver.cc")]
+    if not all(os.path.exists(s) for s in srcs):
+        return None
+    fw = os.path.join(SHIM_DIR, "mock", "tensorflow", "core", "framework")
+    deps = srcs + [os.path.join(SHIM_DIR, "mock", "mock_runtime.h"), os.path.join(fw, "op.h"), os.path.join(fw, "op_kernel.h"),
+                   LIB_PATH, DIST_LIB]
+    if force or any(_newer(d, SHIM_MOCK_BIN) for d in deps):
+        inc = os.path.join(_HERE, "..", "include")
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O2", "-std=c++17", "-I", inc, "-I", os.path.join(SHIM_DIR, "mock")] + srcs + \
+              ["-L", LIB_DIR, "-ltfgx_dist", "-ltfgx", "-L", os.path.join(ROCM, "lib"), "-lrccl", "-Wl,-rpath,$ORIGIN",
+               "-o", SHIM_MOCK_BIN]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return SHIM_MOCK_BIN
 
 
 if __name__ == "__main__":

@@ -71,6 +71,7 @@ class GatArgs(ctypes.Structure):
         ("drop_rate", ctypes.c_float), ("reserved2", ctypes.c_int32), ("drop_seed", ctypes.c_uint64),
         ("drop_self_base", ctypes.c_int64),
         ("row_order", ctypes.c_void_p),
+        ("drop_seed_dev", ctypes.c_void_p),
     ]
 
 
@@ -127,6 +128,7 @@ class GatBackwardArgs(ctypes.Structure):
         ("drop_self_base", ctypes.c_int64), ("edge_pos_t", ctypes.c_void_p),
         ("ld_stats_ml", ctypes.c_int64), ("ld_dsum", ctypes.c_int64),
         ("row_order", ctypes.c_void_p), ("row_order_t", ctypes.c_void_p),
+        ("drop_seed_dev", ctypes.c_void_p),
     ]
 
 

@@ -582,7 +582,7 @@ class _GatAttention(torch.autograd.Function):
         else:
             out = gat_attention(plan, Q.detach(), K.detach(), V.detach(), num_heads, True, stats_ml=stats,
                                 drop_rate=drop_rate, drop_seed=drop_seed, scale_d=scale_d)
-        ctx.plan, ctx.H, ctx.drop = plan, num_heads, (float(drop_rate), int(drop_seed))
+        ctx.plan, ctx.H, ctx.drop = plan, num_heads, (float(drop_rate), drop_seed)      # (seed: host int or device tensor)
         ctx.scale_d = scale_d
         ctx.save_for_backward(Q, K, V, out, stats)
         return out
@@ -637,7 +637,8 @@ class _GatAttention(torch.autograd.Function):
         a.row_order = 0 if ro is None else ro.data_ptr()
         a.row_order_t = 0 if ro_t is None else ro_t.data_ptr()
         if ctx.drop[0] > 0.0:      # regenerate the forward's keep mask: same seed, forward-CSR edge positions
-            a.drop_rate, a.drop_seed, a.drop_self_base = ctx.drop[0], ctx.drop[1], plan.num_edges
+            from .nn.conv.gat import _set_drop
+            _set_drop(a, ctx.drop[0], ctx.drop[1], plan.num_edges)
             a.edge_pos_t = t2d.data_ptr()
         # power-law graphs: rows too long for one lane group are walked chunk-wise (the plans' hub lists) and their chunk
         # partials added in order — dQ over the forward plan's hub destinations, dK / dV over the transposed plan's hub sources
@@ -681,7 +682,8 @@ def gat_attention(plan, Q, K, V, num_heads, drop_rate=0.0, drop_seed=0, scale_d=
     """Differentiable fused attention (self-loop edge appended, as nn/conv/gat.py:43); drop_rate > 0 = training-time
     dropout of the attention weights (gat.py:85).  scale_d: the per-head width the scores are scaled by when Q / K
     arrive zero-padded per head (nn/conv/gat._kernel_widths)."""
-    return _GatAttention.apply(plan, num_heads, Q, K, V, float(drop_rate), int(drop_seed), scale_d, passes)
+    return _GatAttention.apply(plan, num_heads, Q, K, V, float(drop_rate),
+                               drop_seed if isinstance(drop_seed, torch.Tensor) else int(drop_seed), scale_d, passes)
 
 
 def edge_attr_csr(plan, edge_attr, cache=None):

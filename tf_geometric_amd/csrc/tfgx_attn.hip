@@ -551,7 +551,7 @@ extern "C" int tfgx_gat_fused_f32(const tfgx_gat_args* p, tfgx_stream_t stream_)
     TFGX_REQUIRE(p->drop_rate >= 0.0f && p->drop_rate < 1.0f, "drop_rate outside [0, 1)");
     TFGX_REQUIRE(p->drop_rate == 0.0f || (p->state_acc == nullptr && !(p->hub_threshold > 0 && p->n_hub_rows > 0)),
                  "attention dropout cannot be combined with the raw-state / hub options");
-    a.drop = make_drop(p->drop_rate, p->drop_seed, p->drop_self_base);
+    a.drop = make_drop(p->drop_rate, p->drop_seed, p->drop_self_base, p->drop_seed_dev);
     TFGX_REQUIRE((p->state_acc == nullptr) == (p->state_ml == nullptr), "state_acc and state_ml go together");
     const bool use_hub = p->hub_threshold > 0 && p->n_hub_rows > 0 && p->state_acc == nullptr;
     if (use_hub) {

@@ -1346,7 +1346,7 @@ static int fill_gb(const tfgx_gat_backward_args* p, GB& a)
     a.gq = p->grad_q; a.ldgq = p->ld_grad_q; a.gk = p->grad_k; a.ldgk = p->ld_grad_k;
     a.gv = p->grad_v; a.ldgv = p->ld_grad_v;
     TFGX_REQUIRE(p->drop_rate >= 0.0f && p->drop_rate < 1.0f, "drop_rate outside [0, 1)");
-    a.drop = make_drop(p->drop_rate, p->drop_seed, p->drop_self_base);
+    a.drop = make_drop(p->drop_rate, p->drop_seed, p->drop_self_base, p->drop_seed_dev);
     a.pos = nullptr;
     return TFGX_OK;
 }

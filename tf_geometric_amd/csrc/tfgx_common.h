@@ -114,22 +114,30 @@ struct DropCfg {
     float keep_scale;   // 1 / (1 - rate)
     uint64_t seed;
     int64_t self_base;
+    const uint64_t* seed_dev;   // non-NULL: the seed is READ FROM DEVICE MEMORY by the kernel (hipGraph replays: the step's
+                                // own captured seed-advance kernel leaves a fresh value there before every replayed launch)
 };
 
-inline DropCfg make_drop(float rate, uint64_t seed, int64_t self_base)
+inline DropCfg make_drop(float rate, uint64_t seed, int64_t self_base, const uint64_t* seed_dev = nullptr)
 {
     DropCfg c;
     c.thr = rate > 0.0f ? static_cast<uint32_t>(rate * 16777216.0f) : 0u;
     c.keep_scale = rate > 0.0f ? 1.0f / (1.0f - rate) : 1.0f;
     c.seed = seed;
     c.self_base = self_base;
+    c.seed_dev = rate > 0.0f ? seed_dev : nullptr;
     return c;
 }
 
 __host__ __device__ inline float drop_scale(const DropCfg& c, uint32_t item)
 {
     if (c.thr == 0u) return 1.0f;
-    return (drop_hash(c.seed, item) >> 8) >= c.thr ? c.keep_scale : 0.0f;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint64_t seed = c.seed_dev != nullptr ? *c.seed_dev : c.seed;     // wave-uniform address: one scalar load, cached
+#else
+    const uint64_t seed = c.seed;
+#endif
+    return (drop_hash(seed, item) >> 8) >= c.thr ? c.keep_scale : 0.0f;
 }
 
 inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }

@@ -152,7 +152,19 @@ __global__ __launch_bounds__(kFusedThreads) void agg_gemm_kernel(const FArgs a)
                         else hi = mid;
                     }
                 }
-                for (int c = a.hub_chunk_ptr[lo]; c < a.hub_chunk_ptr[lo + 1]; ++c) {
+                // chunk partials in chunk order, eight loads in flight (thousands of chunks on the longest rows)
+                int c = a.hub_chunk_ptr[lo];
+                const int c_end = a.hub_chunk_ptr[lo + 1];
+                for (; c + UNROLL <= c_end; c += UNROLL) {
+                    float pv[UNROLL][4];
+#pragma unroll
+                    for (int t = 0; t < UNROLL; ++t) load_vec<4>(a.hub_scratch + int64_t(c + t) * a.F + coff, pv[t]);
+#pragma unroll
+                    for (int t = 0; t < UNROLL; ++t)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) acc[v] += pv[t][v];
+                }
+                for (; c < c_end; ++c) {
                     float pv[4];
                     load_vec<4>(a.hub_scratch + int64_t(c) * a.F + coff, pv);
 #pragma unroll

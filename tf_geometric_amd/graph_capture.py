@@ -60,6 +60,11 @@ class CapturedTrainStep(object):
     already cached (run the model once eagerly first).  The warm-up steps this constructor needs (they size the allocator
     pools, build lazily-built plan metadata and create the optimizer state) are rolled back: parameters and optimizer
     state are what they were before the constructor ran, so step k of the replay equals step k of the eager loop.
+
+    Randomness: torch's dropout / rand_like draw from a device-side Philox offset that a replay advances, and the attention
+    dropout of GAT layers reads its seed from a device tensor the captured sequence advances (nn/conv/gat.new_drop_seed) —
+    every replay draws fresh masks.  (A by-value seed would be frozen into the graph; tests/test_gpu_regressions.py holds
+    the replays to differ and to match the eager layer run with each replay's seed.)
     """
 
     def __init__(self, loss_fn, optimizer, warmup=3):

@@ -85,10 +85,46 @@ def gat_args(Q, K, V, num_heads, n_dst, col, add_self_loop=True, bias=None, act=
     return a, out, (Q, K, V)
 
 
-def new_drop_seed():
-    """A fresh 64-bit dropout seed from torch's host generator (torch.manual_seed makes training runs repeatable)."""
+_SEED_STATE = {}          # device index -> int64[1] device tensor: the seed stream hipGraph-captured steps draw from
+_SEED_STRIDE = -7046029254386353131      # 0x9E3779B97F4A7C15 as int64 (odd: the stream visits all 2^64 values)
+
+
+def _seed_state(device):
+    """Created EAGERLY (never inside a capture: a captured fill would reset it on every replay), from torch's host generator."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    st = _SEED_STATE.get(key)
+    if st is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise L.TfgxError("attention dropout inside a hipGraph capture needs the device seed stream to exist before the "
+                              "capture starts: run the step once eagerly first (CapturedTrainStep's warm-up does)")
+        hi, lo = torch.randint(0, 2 ** 31 - 1, (2,)).tolist()
+        st = torch.tensor([(int(hi) << 32) | int(lo)], dtype=torch.int64, device=device)
+        _SEED_STATE[key] = st
+    return st
+
+
+def new_drop_seed(device=None):
+    """A fresh 64-bit dropout seed.  Eager launches: a host integer from torch's host generator (torch.manual_seed makes
+    training runs repeatable), passed by value.  While the current stream is being CAPTURED into a hipGraph a by-value seed
+    would be frozen into the graph — every replay would drop the same edges — so the seed is a DEVICE tensor there: the
+    captured sequence advances the per-device seed stream in place (an add kernel, replayed with the step) and snapshots it
+    for this layer call; forward and backward kernels read the snapshot (tfgx_gat_args.drop_seed_dev)."""
+    if device is not None:
+        state = _seed_state(device)              # exists before any capture (the eager warm-up steps create it)
+        if torch.cuda.is_current_stream_capturing():
+            state.add_(_SEED_STRIDE)
+            return state.clone()
     hi, lo = torch.randint(0, 2 ** 31 - 1, (2,)).tolist()
     return (int(hi) << 32) | int(lo)
+
+
+def _set_drop(a, drop_rate, drop_seed, self_base):
+    """drop_seed: host int, or an int64[1] device tensor (see new_drop_seed)."""
+    a.drop_rate, a.drop_self_base = float(drop_rate), int(self_base)
+    if isinstance(drop_seed, torch.Tensor):
+        a.drop_seed, a.drop_seed_dev = 0, drop_seed.data_ptr()
+    else:
+        a.drop_seed = int(drop_seed) & 0xFFFFFFFFFFFFFFFF
 
 
 def gat_attention(plan, Q, K, V, num_heads, add_self_loop=True, bias=None, act=L.ACT_NONE, stats_ml=None,
@@ -106,7 +142,7 @@ def gat_attention(plan, Q, K, V, num_heads, add_self_loop=True, bias=None, act=L
     if stats_ml is not None:
         a.stats_ml = stats_ml.data_ptr()      # (m, l) per row and head, kept for the backward pass
     if drop_rate > 0.0:
-        a.drop_rate, a.drop_seed, a.drop_self_base = float(drop_rate), int(drop_seed), plan.num_edges
+        _set_drop(a, drop_rate, drop_seed, plan.num_edges)
     hub = plan.hub_info() if drop_rate <= 0.0 else None      # the chunk-merge path has no dropout; long rows run inline
     if hub is not None:
         hub_rows, chunk_ptr, chunk_begin, chunk_end, chunk_row = hub
@@ -174,7 +210,7 @@ def _gat_train(x, plan, wq, bq, qact, wk, bk, kact, kernel, bias, activation, nu
                                                       else AG.linear(x, kernel, gathered=True))
     d, dv = int(Q.shape[1]) // num_heads, int(V.shape[1]) // num_heads
     d2, dv2 = _kernel_widths(d, dv, num_heads)
-    seed = new_drop_seed() if drop_rate > 0.0 else 0
+    seed = new_drop_seed(V.device) if drop_rate > 0.0 else 0
     Qp, Kp = _pad_heads(Q, num_heads, d2), _pad_heads(K, num_heads, d2)
     if num_heads == 1 and dv > 256:
         # one head wider than the backward kernels' 64 lanes x 4 columns: the attention weights do not depend on the

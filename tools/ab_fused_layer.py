@@ -41,6 +41,9 @@ k = torch.randn(f, 256, device="cuda") * 0.1
 agg_out = torch.empty(n, f, device="cuda")
 
 
+P.AUTO_STATIC_LAYOUT = False      # A/B of the launches on x as it is (no promotion to the static layout mid-measurement)
+
+
 def set_fuse(v):
     P.FUSE_AGGREGATE_GEMM = v
 
