@@ -93,7 +93,8 @@ int tfgx_halo_reverse_start(tfgx_halo_plan* plan, const float* d_halo, int64_t F
 /* The same round by round: round `round` (0, 1, ..., R - 1, in this order) is posted after whatever wrote ITS rows of d_halo
  * (the halo table is round-major: rows [recv_off[round * world], recv_off[(round + 1) * world])) on compute_stream, so the
  * caller runs the transposed pass window by window and every round travels while the later windows are computed.
- * finish() as above, after all R rounds were started. */
+ * finish() as above, after all R rounds were started.  Starting round 0 while an earlier sequence is half started abandons
+ * that sequence (its posted rounds are waited for) and begins a new one. */
 int tfgx_halo_reverse_start_round(tfgx_halo_plan* plan, int32_t round, const float* d_halo, int64_t F, float* back_buf,
                                   size_t back_buf_floats, void* nccl_comm, void* compute_stream, void* comm_stream);
 int tfgx_halo_reverse_finish(tfgx_halo_plan* plan, float* d_own, int64_t ldd, int64_t F, const float* back_buf,

@@ -7,6 +7,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+os.environ.setdefault("TFGX_DIST_DEBUG_CHECKS", "1")     # the early-halo-send consistency check of dist/sharded.py (synchronises)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:

@@ -79,10 +79,9 @@ def test_plan_rejects_out_of_range_ids_like_tf_cpu(tfg):
 def test_plan_and_hub_lists_on_rmat(tfg):
     """R-MAT (0.57, 0.19, 0.19, 0.05): hub destinations take the chunked path; the chunk lists must tile every hub row's
     CSR span exactly, in order, with the plan's policy — and with a forced small threshold."""
-    import bench
-    from tf_geometric_amd import plan as P
+    from tf_geometric_amd import plan as P, synthetic
     n, e = 1 << 16, 2000000
-    ei_t = bench.rmat_edges(n, e, 7, torch.device("cuda"))
+    ei_t = synthetic.rmat_edges(n, e, 7, torch.device("cuda"))
     ei = ei_t.cpu().numpy()
     plan = P.CsrPlan.build(ei_t, n, n)
     _check(plan, ei, n)

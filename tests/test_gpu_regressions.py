@@ -95,11 +95,11 @@ def test_set_weights_copies_the_callers_tensor(tfg, oracle):
 def test_plan_metadata_is_not_built_inside_a_capture(tfg, oracle):
     """plan.row_order() / hub_info() synchronise on first use; when the first use happens under hipGraph capture they
     return None (the launch runs in natural order / inline) instead of breaking the capture."""
-    import bench
+    from tf_geometric_amd import synthetic
     from tf_geometric_amd.plan import CsrPlan, segment_reduce
     L = tfg._lib
     n = 1 << 14
-    ei = bench.rmat_edges(n, 400000, 3, torch.device("cuda"))
+    ei = synthetic.rmat_edges(n, 400000, 3, torch.device("cuda"))
     x = torch.randn(n, 16, device="cuda")
     eager = segment_reduce(CsrPlan.build(ei, n, n), x, L.SUM)
     plan = CsrPlan.build(ei, n, n)                      # fresh plan: nothing lazy computed yet

@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libtfgx.so")
+LIB_PATH = os.environ.get("TFGX_LIB_PATH") or os.path.join(_HERE, "lib", "libtfgx.so")   # (override: developer A/B of kernel builds)
 
 SUM, MEAN, MAX = 0, 1, 2
 ACT_NONE, ACT_RELU = 0, 1

@@ -286,6 +286,14 @@ extern "C" int tfgx_halo_reverse_start_round(tfgx_halo_plan* p, int32_t round, c
     DIST_REQUIRE(p != nullptr, "plan is null");
     DIST_REQUIRE(F >= 1, "bad F");
     DIST_REQUIRE(round >= 0 && round < p->rounds, "bad round");
+    hipStream_t cs0 = reinterpret_cast<hipStream_t>(compute_stream);
+    if (round == 0 && p->reverse_rounds_started != 0) {
+        // a round-by-round sequence was ABANDONED half way (an exception in the host's backward pass): starting round 0
+        // again begins a new sequence instead of leaving the plan unusable.  The rounds already posted are waited for (they
+        // write the caller's previous back_buf).  (With peers this only helps if every rank abandoned the same sequence.)
+        for (int j = 0; j < p->reverse_rounds_started; ++j) DIST_HIP(hipStreamWaitEvent(cs0, p->rdone[j], 0));
+        p->reverse_rounds_started = 0;
+    }
     DIST_REQUIRE(round == p->reverse_rounds_started, "reverse rounds are started in order 0, 1, ..., R - 1");
     const int64_t rows_sent = p->send_off.back(), rows_recv = p->recv_off.back();
     DIST_REQUIRE(rows_recv == 0 || d_halo != nullptr, "d_halo is null");

@@ -26,6 +26,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 
 constexpr int BK = 16;   // 16 keeps load-staging registers low enough for 3 workgroups per CU (BK = 32: 2)
+#ifndef TFGX_ROWS_NT_STORE
+#define TFGX_ROWS_NT_STORE 0      // developer A/B: streaming stores of the row kernel's output tiles
+#endif
+#ifndef TFGX_ROWS_NT_LOAD
+#define TFGX_ROWS_NT_LOAD 0       // developer A/B: streaming loads of the A rows
+#endif
 
 template <int BM, int BN, int WM, int WN, bool AV4, bool BV4>
 __global__ __launch_bounds__(kBlock) void gemm_kernel(const float* __restrict__ A, int64_t lda,
@@ -326,21 +332,40 @@ __global__ __launch_bounds__(rows_threads<TN>()) void gemm_rows_kernel(const flo
     const int l31 = lane & 31, kh = lane >> 5;
 
     constexpr int NT = rows_threads<TN>();
-    for (int f = tid; f < K * NQ; f += NT) {
-        const int k = f / NQ, n4 = (f - k * NQ) * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k < K) {
-            const float* p = B + int64_t(k) * ldb + n4;
-            if (b_vec4 && n4 + 3 < N) {
-                v = *reinterpret_cast<const float4*>(p);
-            } else {
-                if (n4 < N) v.x = p[0];
-                if (n4 + 1 < N) v.y = p[1];
-                if (n4 + 2 < N) v.z = p[2];
-                if (n4 + 3 < N) v.w = p[3];
+#ifndef TFGX_ROWS_B_BATCH
+#define TFGX_ROWS_B_BATCH 8
+#endif
+    // B -> LDS, TFGX_ROWS_B_BATCH loads in flight per thread before the first LDS store: with one load per iteration the
+    // prologue was a chain of ~17 L2 round trips (128 x 256 floats over 512 threads) — a quarter of the whole launch at
+    // ogbn-arxiv size (170 k rows)
+    constexpr int BB = TFGX_ROWS_B_BATCH;
+    for (int f0 = tid; f0 < K * NQ; f0 += NT * BB) {
+        float4 v[BB];
+#pragma unroll
+        for (int u = 0; u < BB; ++u) {
+            const int f = f0 + u * NT;
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (f < K * NQ) {
+                const int k = f / NQ, n4 = (f - k * NQ) * 4;
+                const float* p = B + int64_t(k) * ldb + n4;
+                if (b_vec4 && n4 + 3 < N) {
+                    v[u] = *reinterpret_cast<const float4*>(p);
+                } else {
+                    if (n4 < N) v[u].x = p[0];
+                    if (n4 + 1 < N) v[u].y = p[1];
+                    if (n4 + 2 < N) v[u].z = p[2];
+                    if (n4 + 3 < N) v[u].w = p[3];
+                }
             }
         }
-        *reinterpret_cast<float4*>(&Bs[k * LDB_S + n4]) = v;
+#pragma unroll
+        for (int u = 0; u < BB; ++u) {
+            const int f = f0 + u * NT;
+            if (f < K * NQ) {
+                const int k = f / NQ, n4 = (f - k * NQ) * 4;
+                *reinterpret_cast<float4*>(&Bs[k * LDB_S + n4]) = v[u];
+            }
+        }
     }
     __syncthreads();
 
@@ -365,7 +390,11 @@ __global__ __launch_bounds__(rows_threads<TN>()) void gemm_rows_kernel(const flo
         const float* p = A + gm * lda;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
+#if TFGX_ROWS_NT_LOAD
+            const f32x4_a8 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_a8*>(p + min(kb + 4 * u, K - 4)));
+#else
             const f32x4_a8 v = *reinterpret_cast<const f32x4_a8*>(p + min(kb + 4 * u, K - 4));
+#endif
             r[4 * u + 0] = v[0];
             r[4 * u + 1] = v[1];
             r[4 * u + 2] = v[2];
@@ -480,7 +509,13 @@ __global__ __launch_bounds__(rows_threads<TN>()) void gemm_rows_kernel(const flo
                 if (gn < N) {
                     float* cp = C + r0 * ldc + gn;
 #pragma unroll
-                    for (int t = 0; t < 16; ++t) cp[int64_t((t & 3) + 8 * (t >> 2)) * ldc] = acc[j][t];
+                    for (int t = 0; t < 16; ++t) {
+#if TFGX_ROWS_NT_STORE
+                        __builtin_nontemporal_store(acc[j][t], cp + int64_t((t & 3) + 8 * (t >> 2)) * ldc);
+#else
+                        cp[int64_t((t & 3) + 8 * (t >> 2)) * ldc] = acc[j][t];
+#endif
+                    }
                 }
             }
         } else {
@@ -947,23 +982,31 @@ template <int TN>
 int launch_gemm_rows(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, int act, float* C,
                      int64_t ldc, int64_t M, int K, int N, int act_cols, hipStream_t stream)
 {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
+    // per DEVICE (one process may drive several GPUs): compute-unit count + the kernel's dynamic-LDS attribute
+    constexpr int kMaxDev = 64;
+    static int cus_of[kMaxDev] = {0};
+    int dev = 0;
+    TFGX_HIP_CHECK(hipGetDevice(&dev));
+    TFGX_REQUIRE(dev >= 0 && dev < kMaxDev, "device ordinal out of range");
+    if (cus_of[dev] == 0) {
         hipDeviceProp_t prop;
-        TFGX_HIP_CHECK(hipGetDevice(&dev));
         TFGX_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
         TFGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_rows_kernel<TN>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        cus_of[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
+    const int cus = cus_of[dev];
     const int64_t n_tiles = (M + 31) / 32;
     constexpr int kWaves = rows_threads<TN>() / 64;
     const int64_t wgs = (n_tiles + kWaves - 1) / kWaves;
     const int b_vec4 = (ldb % 4 == 0) && aligned_to(B, 16);
     // narrow outputs (TN <= 2) are A-streaming kernels with few registers and a small B: several workgroups per CU
     // keep more row loads in flight than one workgroup's single-step prefetch can
-    const int64_t max_wgs = int64_t(cus) * (TN <= 2 ? 3 : 1);
+    static const int mult_env = [] {          // developer A/B: TFGX_ROWS_WGS_MULT = workgroups per CU of the row kernel
+        const char* e = std::getenv("TFGX_ROWS_WGS_MULT");
+        return (e && atoi(e) > 0) ? atoi(e) : 0;
+    }();
+    const int64_t max_wgs = int64_t(cus) * (mult_env > 0 ? mult_env : (TN <= 2 ? 3 : 1));
     dim3 grid(static_cast<unsigned>(wgs < max_wgs ? wgs : max_wgs), 1, 1), block(rows_threads<TN>(), 1, 1);
     gemm_rows_kernel<TN><<<grid, block, rows_lds_bytes(K, TN), stream>>>(A, lda, B, ldb, bias, act, act_cols, C, ldc, M, K,
                                                                          N, n_tiles, b_vec4, two_level_default());
@@ -1247,11 +1290,14 @@ extern "C" int tfgx_gemm_tn_gated_f32(const float* X, int64_t ldx, const float* 
         const int64_t part_stride = int64_t(Ka + (want_bias ? 1 : 0)) * ng_cols;
 #define TFGX_TN(TPW)                                                                                                    \
     {                                                                                                                   \
-        static bool attr_set = false;                                                                                   \
-        if (!attr_set) {                                                                                                \
+        static bool attr_set[64] = {false};      /* per device: one process may drive several GPUs */                  \
+        int dev_ = 0;                                                                                                   \
+        TFGX_HIP_CHECK(hipGetDevice(&dev_));                                                                            \
+        TFGX_REQUIRE(dev_ >= 0 && dev_ < 64, "device ordinal out of range");                                            \
+        if (!attr_set[dev_]) {                                                                                          \
             TFGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_kernel<TPW>),                      \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                \
-            attr_set = true;                                                                                            \
+            attr_set[dev_] = true;                                                                                      \
         }                                                                                                               \
         gemm_tn_kernel<TPW><<<c.wgs, kTnThreads, lds, stream>>>(X, ldx, G, ldg, M, int(Ka), int(N), n_first, ng_cols,    \
                                                                 c.R, c.ka_pad, ng_pad, want_bias ? 1 : 0, parts,        \

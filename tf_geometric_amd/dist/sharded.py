@@ -303,6 +303,9 @@ def edge_balanced_bounds(row_ptr_host, world):
     return bounds
 
 
+_DEBUG_CHECKS = os.environ.get("TFGX_DIST_DEBUG_CHECKS", "0") != "0"     # extra consistency checks that synchronise
+
+
 class ShardedGraph(object):
     """One rank's shard: destination rows [own_lo, own_hi) of a global graph, plus its halo plan."""
 
@@ -335,25 +338,49 @@ class ShardedGraph(object):
                     self_halo_rows=None):
         """Every rank passes the SAME global edge_index [2, E] (numpy on the host, or a tensor) and optional
         edge_weight [E]; each rank counts in-degrees over the whole list (to agree on the split points) but sorts and
-        keeps only its own E/W slice.  All edge-sized work runs on the backend's device (torch ops: histogram, prefix sum,
-        mask, compaction)."""
+        keeps only its own E/W slice.  The edge-sized work runs on the backend's device (torch ops: histogram, prefix sum,
+        mask, compaction), chunk by chunk."""
         self = ShardedGraph()
         be = self._init_common(num_nodes, group, backend, transport, self_halo_rows)
-        ei_all = be.i32(edge_index).reshape(2, -1)
-        if ei_all.numel() and (int(ei_all.min()) < 0 or int(ei_all.max()) >= self.n_global):
-            raise L.TfgxError("edge endpoint outside [0, {})".format(self.n_global))
+        # The global list is walked in CHUNKS of 2^26 edges: a host array is copied chunk by chunk (never whole), and the
+        # int64 / bool temporaries of the histogram and of the ownership mask are chunk-sized — device memory stays
+        # O(E / world + chunk) instead of ~30 bytes per GLOBAL edge (papers100M: 1.6e9 edges).  from_partitioned is the
+        # constructor that does not replicate the list at all.
+        host = not isinstance(edge_index, torch.Tensor)
+        ei_src = np.asarray(edge_index).reshape(2, -1) if host else edge_index.reshape(2, -1)
+        E = int(ei_src.shape[1])
+        step = int(os.environ.get("TFGX_FROM_GLOBAL_CHUNK", str(1 << 26)))
+        chunks = [(c0, min(c0 + step, E)) for c0 in range(0, E, step)] or [(0, 0)]
+        piece = lambda c0, c1: be.i32(np.ascontiguousarray(ei_src[:, c0:c1]) if host else ei_src[:, c0:c1]).reshape(2, -1)   # noqa: E731
         # 1. in-degree histogram of the GLOBAL edge list -> edge-balanced split points (identical on every rank)
-        deg = torch.bincount(ei_all[0].long(), minlength=self.n_global)
+        deg = None
+        for c0, c1 in chunks:
+            ei_c = piece(c0, c1)
+            if ei_c.numel() and (int(ei_c.min()) < 0 or int(ei_c.max()) >= self.n_global):
+                raise L.TfgxError("edge endpoint outside [0, {})".format(self.n_global))
+            d = torch.bincount(ei_c[0].long(), minlength=self.n_global)
+            deg = d if deg is None else deg.add_(d)
         self.bounds, rp = bounds_from_degrees(deg, self.world)
         lo, hi = int(self.bounds[self.rank]), int(self.bounds[self.rank + 1])
         self.own_lo, self.own_hi, self.n_own = lo, hi, hi - lo
         self.num_edges_global = int(rp[-1].item())
         # 2. my edges (destination in [lo, hi)), kept in the caller's relative order, then the stable CSR build of that
         #    slice alone — the same rows a global stable sort would put in positions [rp[lo], rp[hi])
-        mine = (ei_all[0] >= lo) & (ei_all[0] < hi)
-        edge_ids = torch.nonzero(mine).flatten()
-        local = torch.stack([ei_all[0][edge_ids] - lo, ei_all[1][edge_ids]]).to(torch.int32)
-        w_local = None if edge_weight is None else be.f32(edge_weight)[edge_ids]
+        ids, rows, cols = [], [], []
+        for c0, c1 in chunks:
+            ei_c = piece(c0, c1)
+            pos = torch.nonzero((ei_c[0] >= lo) & (ei_c[0] < hi)).flatten()
+            ids.append(pos + c0)
+            rows.append(ei_c[0][pos] - lo)
+            cols.append(ei_c[1][pos])
+        edge_ids = torch.cat(ids)
+        local = torch.stack([torch.cat(rows), torch.cat(cols)]).to(torch.int32)
+        if edge_weight is None:
+            w_local = None
+        elif isinstance(edge_weight, torch.Tensor):
+            w_local = be.f32(edge_weight)[edge_ids]
+        else:                    # host weights: only this rank's entries go to the device
+            w_local = be.f32(np.asarray(edge_weight, dtype=np.float32)[edge_ids.cpu().numpy()])
         assert int(local.shape[1]) == int((rp[hi] - rp[lo]).item())
         self._finish_build(local, w_local, edge_ids, rounds)
         return self
@@ -711,7 +738,8 @@ class ShardedGraph(object):
             state["handle"] = self.transport.reverse_start_round(self, d_table, j, state["handle"])
             if j == self.rounds - 1:
                 self.counters[counter] = self.counters.get(counter, 0) + 1
-                self._early_reverse = (token, state["handle"], d_table if check_ptr else None)
+                self._early_reverse = (token, state["handle"], d_table if check_ptr else None,
+                                       None if check_ptr else d_table)
                 state["handle"] = None
         return start_round
 
@@ -1147,5 +1175,13 @@ class _HaloGather(torch.autograd.Function):
             if early[2] is not None and g_table.data_ptr() != early[2].data_ptr():
                 raise RuntimeError("sharded max backward: the table gradient was replaced after its halo rows started "
                                    "travelling (the table has more than one consumer?)")
+            if early[3] is not None and _DEBUG_CHECKS:
+                # GAT halo-first backward (autograd assembles this gradient from the [K | V] slices, so the pointer differs):
+                # the halo rows that already travelled must BE the halo rows of the final gradient — they are not if the
+                # table had a second consumer.  A device comparison + host read: debug mode only (TFGX_DIST_DEBUG_CHECKS=1;
+                # the multi-process tests run with it)
+                if not torch.equal(g_table[sg.n_own:], early[3][sg.n_own:]):
+                    raise RuntimeError("sharded GAT backward: the halo rows sent early differ from the table gradient's "
+                                       "(the [K | V] table has more than one consumer?)")
             return None, sg.reverse_exchange(g_table, started=early[1]), None
         return None, sg.reverse_exchange(g_table.contiguous()), None

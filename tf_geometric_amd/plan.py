@@ -240,7 +240,7 @@ class SplitRows(object):
 
 
 USE_ROW_ORDER = True      # degree-ordered row walk of the segment-reduce kernel on skewed plans (developer A/B switch)
-ROW_ORDER_MAX_F = 64      # ... applied up to this width (wider rows: measured neutral to harmful, see segment_reduce)
+ROW_ORDER_MAX_F = 128     # ... applied up to this width (same-box A/B on R-MAT graphs, profiles/r04_ab_row_order.jsonl: see segment_reduce)
 
 CACHE_KEY_STATIC = "tfgx_static_features"      # user opt-in: cache[CACHE_KEY_STATIC] = the static feature tensor
 CACHE_KEY_STATIC_ROWS = "tfgx_static_rows"      # the layout built for it: (key, SplitRows | None, x, plan, bytes)
@@ -511,8 +511,10 @@ def segment_reduce(plan, x, op, w_csr=None, out=None, act=L.ACT_NONE, self_coef=
         if split.edge_tail is not None and split.edge_plan is plan and col is None:
             a.edge_tail, a.ld_edge_tail = split.edge_tail.data_ptr(), int(split.edge_tail.shape[1])
     if row_begin is None and row_end is None and col is None and n_dst == plan.n_dst and USE_ROW_ORDER and F <= ROW_ORDER_MAX_F:
-        # skewed plans, narrow rows (four or more rows per wave): degree-ordered walk.  Same-box A/B on R-MAT graphs:
-        # F = 20: -7 .. -16 %, F = 64: -4 .. -11 %; F = 100: 0 .. +2 %, F = 256: +5 .. +9 % (hence the width limit)
+        # skewed plans: degree-ordered walk (the rows sharing a wave have similar lengths).  Same-box A/B on R-MAT graphs:
+        # F = 20: -7 .. -16 %, F = 64: -4 .. -11 % (round 2); round 4, after the hub finalize stopped being a latency chain
+        # (profiles/r04_ab_row_order.jsonl, 2.4 M / 123 M and 2^21 / 61 M edges): F = 100: -10 / -11 %, F = 128: -3 / -5 %,
+        # F = 256: -2 .. +1 % (one row per wave there: nothing to balance) — hence the width limit
         order = plan.row_order()
         if order is not None:
             a.row_order = order.data_ptr()

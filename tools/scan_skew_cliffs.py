@@ -29,7 +29,7 @@ def t(fn, k=3):
     return a.elapsed_time(b) / k
 
 
-graphs = {"uniform": L.as_i32(synthetic.synthetic_edges(n, e, seed=0)), "rmat": bench.rmat_edges(n, e, 0, torch.device("cuda"))}
+graphs = {"uniform": L.as_i32(synthetic.synthetic_edges(n, e, seed=0)), "rmat": synthetic.rmat_edges(n, e, 0, torch.device("cuda"))}
 for gname, ei in graphs.items():
     E = int(ei.shape[1])
     deg = torch.bincount(ei[0].long(), minlength=n)

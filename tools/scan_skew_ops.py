@@ -25,7 +25,7 @@ def t(fn, k=3):
     return (time.perf_counter() - t0) * 1e3 / k
 
 
-graphs = {"uniform": L.as_i32(synthetic.synthetic_edges(n, e, seed=0)), "rmat": bench.rmat_edges(n, e, 0, torch.device("cuda"))}
+graphs = {"uniform": L.as_i32(synthetic.synthetic_edges(n, e, seed=0)), "rmat": synthetic.rmat_edges(n, e, 0, torch.device("cuda"))}
 for gname, ei in graphs.items():
     E = int(ei.shape[1])
     w = torch.rand(E, device="cuda") + 0.5
