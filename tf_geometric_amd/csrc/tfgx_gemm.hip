@@ -1000,13 +1000,15 @@ int launch_gemm_rows(const float* A, int64_t lda, const float* B, int64_t ldb, c
     constexpr int kWaves = rows_threads<TN>() / 64;
     const int64_t wgs = (n_tiles + kWaves - 1) / kWaves;
     const int b_vec4 = (ldb % 4 == 0) && aligned_to(B, 16);
-    // narrow outputs (TN <= 2) are A-streaming kernels with few registers and a small B: several workgroups per CU
-    // keep more row loads in flight than one workgroup's single-step prefetch can
+    // one persistent workgroup per CU.  (Rounds 2-3 ran the narrow outputs, TN <= 2, with up to three per CU; the round-4
+    // same-box sweep — TFGX_ROWS_WGS_MULT, profiles/r04_gemm_sweep.jsonl — has one per CU equal or faster on every narrow
+    // shape: 2.4 M x 100 -> 16: 0.298 -> 0.265 ms, 170 k x 256 -> 40: 0.071 -> 0.063 (every workgroup stages B in LDS for
+    // only a handful of tiles there), 2.4 M x 100 -> 64 and 2.4 M x 256 -> 40 unchanged)
     static const int mult_env = [] {          // developer A/B: TFGX_ROWS_WGS_MULT = workgroups per CU of the row kernel
         const char* e = std::getenv("TFGX_ROWS_WGS_MULT");
         return (e && atoi(e) > 0) ? atoi(e) : 0;
     }();
-    const int64_t max_wgs = int64_t(cus) * (mult_env > 0 ? mult_env : (TN <= 2 ? 3 : 1));
+    const int64_t max_wgs = int64_t(cus) * (mult_env > 0 ? mult_env : 1);
     dim3 grid(static_cast<unsigned>(wgs < max_wgs ? wgs : max_wgs), 1, 1), block(rows_threads<TN>(), 1, 1);
     gemm_rows_kernel<TN><<<grid, block, rows_lds_bytes(K, TN), stream>>>(A, lda, B, ldb, bias, act, act_cols, C, ldc, M, K,
                                                                          N, n_tiles, b_vec4, two_level_default());

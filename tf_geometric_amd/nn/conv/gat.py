@@ -97,7 +97,11 @@ def _seed_state(device):
         if torch.cuda.is_current_stream_capturing():
             raise L.TfgxError("attention dropout inside a hipGraph capture needs the device seed stream to exist before the "
                               "capture starts: run the step once eagerly first (CapturedTrainStep's warm-up does)")
-        hi, lo = torch.randint(0, 2 ** 31 - 1, (2,)).tolist()
+        # a private generator keyed by torch's seed: repeatable under torch.manual_seed, and the GLOBAL host stream — which
+        # the eager by-value seeds are drawn from — is not advanced by creating the device stream
+        g = torch.Generator()
+        g.manual_seed(torch.initial_seed() % (2 ** 63))
+        hi, lo = torch.randint(0, 2 ** 31 - 1, (2,), generator=g).tolist()
         st = torch.tensor([(int(hi) << 32) | int(lo)], dtype=torch.int64, device=device)
         _SEED_STATE[key] = st
     return st
