@@ -29,6 +29,15 @@ constexpr int BK = 16;   // 16 keeps load-staging registers low enough for 3 wor
 #ifndef TFGX_ROWS_NT_STORE
 #define TFGX_ROWS_NT_STORE 0      // developer A/B: streaming stores of the row kernel's output tiles
 #endif
+#ifndef TFGX_ROWS_EXPERIMENT
+#define TFGX_ROWS_EXPERIMENT 0    // developer experiments on the row kernel's epilogue (1: no stores, 2: stores into a small window) — results INVALID
+#endif
+#ifndef TFGX_ROWS_VEC_STORE
+#define TFGX_ROWS_VEC_STORE 1     // 16-byte epilogue stores of the row kernel through a quad transpose of the accumulators
+#endif
+#ifndef TFGX_ROWS_STAGGER
+#define TFGX_ROWS_STAGGER 0
+#endif
 #ifndef TFGX_ROWS_NT_LOAD
 #define TFGX_ROWS_NT_LOAD 0       // developer A/B: streaming loads of the A rows
 #endif
@@ -288,6 +297,27 @@ __global__ __launch_bounds__(kBlock) void gemm_kernel(const float* __restrict__ 
 // the current step's 16 x TN MFMAs, B operands are double-buffered in registers one MFMA group ahead, and because
 // waves drift apart the store epilogue of one wave overlaps the MFMAs of the other wave on its SIMD.
 // Arithmetic: fp32 FMA chain per output element in the k order above (a permutation of 0..K-1).
+// 4 x 4 transpose between the four lanes of a quad and four registers: lane i (= lane & 3) enters with r[k] = M[k][i] and
+// leaves with r[0..3] = M[i][0..3] — two butterfly stages over DPP quad permutes (xor 1, then xor 2).  The MFMA D layout puts
+// ONE output column in a lane (rows in registers); after this a lane holds four consecutive columns of one row and the
+// epilogue stores 16 bytes per lane: 32 store instructions per 32 x 256 tile instead of 128.
+__device__ __forceinline__ void quad_transpose4(float (&r)[4], int lane)
+{
+    const bool odd = lane & 1, hi = lane & 2;
+#pragma unroll
+    for (int k = 0; k < 4; k += 2) {
+        const float send = odd ? r[k] : r[k + 1];
+        const float recv = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, send), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+        r[k] = odd ? recv : r[k];
+        r[k + 1] = odd ? r[k + 1] : recv;
+    }
+    const float sa = hi ? r[0] : r[2], sb = hi ? r[1] : r[3];
+    const float ra = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, sa), 0x4E, 0xF, 0xF, true));          // quad_perm [2,3,0,1]
+    const float rb = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, sb), 0x4E, 0xF, 0xF, true));
+    const float o0 = hi ? ra : r[0], o1 = hi ? rb : r[1], o2 = hi ? r[2] : ra, o3 = hi ? r[3] : rb;
+    r[0] = o0; r[1] = o1; r[2] = o2; r[3] = o3;
+}
+
 // NG consecutive MFMA groups of gemm_rows_kernel (one group = one k pair x TN accumulators; a full step is 16 groups),
 // B operands read from LDS one group ahead.  The sched_barriers pin that order: left alone, the scheduler sinks every
 // ds_read next to its MFMA (fewest live registers), which puts a full LDS round trip in front of each group.
@@ -421,11 +451,27 @@ __global__ __launch_bounds__(rows_threads<TN>()) void gemm_rows_kernel(const flo
         load_a(nxt, same ? t : t + stride, same ? ks + 1 : 0);
     };
 
+#if TFGX_ROWS_VEC_STORE
+    // wave-uniform.  Wide outputs only: same-box A/B (profiles/r04_gemm_sweep.jsonl) 2.4 M x 100 -> 256: 1.349 -> 1.290 ms,
+    // 170 k x 128 -> 256: 0.140 -> 0.128; at TN <= 4 (100 -> 128 / 64) the transposes cost more than the 4x fewer store
+    // instructions give back (+3 .. 4 %), so narrow outputs keep the per-column stores
+    const bool vec_store = TN >= 5 && (N % 4 == 0) && (ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
+#endif
     float bv[TN];   // this lane's bias values, loaded once (a per-tile load would put a memory round trip in every epilogue)
 #pragma unroll
     for (int j = 0; j < TN; ++j) bv[j] = (bias && j * 32 + l31 < N) ? bias[j * 32 + l31] : 0.0f;
 
     int64_t tile = int64_t(blockIdx.x) * (NT / 64) + wave;
+#if TFGX_ROWS_STAGGER
+    // The two waves of a SIMD (wave w and w + 4) would otherwise run in lock step — every wave of the chip multiplies a tile,
+    // then every wave stores one: a write burst the MFMA pipes idle through (measured: the same kernel without its stores
+    // 0.98 ms, with them 1.27 ms at 2.4 M x 100 -> 256, although 2.46 GB of output is 0.36 ms of pure write time).  The upper
+    // half of the workgroup starts half a tile late, once: from then on one wave of a SIMD stores while the other multiplies.
+    if (wave >= NT / 128) {
+        const int naps = (K * TN * 16) / 8128 + 1;          // half a tile of MFMA time (K/2 * TN * 64 cycles / 2) in s_sleep(127) units
+        for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
     if (tile < n_tiles) load_a(cur, tile, 0);
     // Consume the first A registers here so their wait sits in front of the loop.  Otherwise every step carries a
     // "first iteration" vmcnt wait; harmless in steady state (only the 4 prefetch loads are in flight), but right after an
@@ -501,12 +547,40 @@ __global__ __launch_bounds__(rows_threads<TN>()) void gemm_rows_kernel(const flo
 #pragma unroll
             for (int t = 0; t < 16; ++t) acc[j][t] = apply_act(acc[j][t] + bv[j], a_j);
         }
+#if TFGX_ROWS_EXPERIMENT == 2
+        const int64_t r0 = (tile & 127) * 32 + 4 * kh;      // experiment: every tile's stores land in the same 4096 rows (cache-resident)
+#else
         const int64_t r0 = tile * 32 + 4 * kh;
+#endif
+#if TFGX_ROWS_VEC_STORE
+        if (vec_store && tile * 32 + 32 <= M) {
+            // 16-byte stores: quad-transposed accumulators (see quad_transpose4).  Register group g = t >> 2 holds rows
+            // 8 g + (t & 3) + 4 kh; after the transpose lane i of a quad owns row 8 g + i + 4 kh, columns 4 q .. 4 q + 3
+            const int qi = lane & 3, qc = (l31 >> 2) * 4;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float r4[4] = {acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
+                    quad_transpose4(r4, lane);
+                    const int gn = j * 32 + qc;
+                    if (gn < N) {                      // N % 4 == 0 on this path: the four columns are valid together
+                        float* cp = C + (tile * 32 + 8 * g + qi + 4 * kh) * ldc + gn;
+                        *reinterpret_cast<f32x4*>(cp) = f32x4{r4[0], r4[1], r4[2], r4[3]};
+                    }
+                }
+            }
+        } else
+#endif
         if (tile * 32 + 32 <= M) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int gn = j * 32 + l31;
+#if TFGX_ROWS_EXPERIMENT == 1
+                if (gn < N && acc[j][0] == 1.2345e30f) {          // experiment: (practically) no stores at all
+#else
                 if (gn < N) {
+#endif
                     float* cp = C + r0 * ldc + gn;
 #pragma unroll
                     for (int t = 0; t < 16; ++t) {

@@ -19,6 +19,8 @@ SHAPES = [(2400000, 100, 256), (2400000, 100, 128), (2400000, 128, 256), (240000
           (2400000, 100, 16), (2400000, 256, 256), (170000, 128, 256), (170000, 256, 40), (233000, 602, 64),
           (173312, 1433, 16), (233000, 602, 16), (170000, 1433, 256), (100000, 301, 40), (2400000, 256, 40)]
 tag = sys.argv[1] if len(sys.argv) > 1 else "tree"
+if os.environ.get("GEMM_AB_SHAPES"):      # "M,K,N;M,K,N;..."
+    SHAPES = [tuple(int(v) for v in s.split(",")) for s in os.environ["GEMM_AB_SHAPES"].split(";")]
 
 
 def t(fn, steps, warmup):
