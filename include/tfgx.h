@@ -178,7 +178,8 @@ int tfgx_segment_reduce_describe(const tfgx_reduce_args* args /* host */, char* 
  * args->out: NULL, or [n_dst, ldo] (16-byte aligned rows) that ALSO receives the aggregate itself — the training forward,
  * whose weight gradient needs it; the projection still takes it from LDS.
  * Needs a plain CSR (row_begin = row_ptr, row_end = row_ptr + 1, rp_stride = 1), 16-byte aligned rows, F % 4 == 0,
- * F <= 128, N <= 256: tfgx_aggregate_gemm_fits(F, N) == 1; no accumulate / add_x / split rows / track.  Hub lists (hub_threshold, hub_rows, hub_chunk_*, hub_scratch) are honoured: the chunks
+ * F <= 128, N <= 256: tfgx_aggregate_gemm_fits(F, N) == 1; no accumulate / add_x / track.  Split source rows (x_tail / f_main /
+ * edge_tail: the static feature layout) are honoured exactly as by tfgx_segment_reduce_f32.  Hub lists (hub_threshold, hub_rows, hub_chunk_*, hub_scratch) are honoured: the chunks
  * are reduced into hub_scratch by a launch of the ordinary kernel first, and a long row's lane group folds its chunk
  * partials in chunk order instead of walking the edges.  Deterministic.  Callers fall back to the two launches otherwise. */
 int tfgx_aggregate_gemm_fits(int64_t F, int64_t N);

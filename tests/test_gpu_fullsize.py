@@ -215,13 +215,13 @@ def test_static_layout_is_replayed_by_a_captured_forward(tfg, products):
     P.FUSE_AGGREGATE_GEMM = True
     assert torch.allclose(fused_dense, eager_dense, rtol=1e-5, atol=1e-5)
     tfg.prepare_static_features(x, p["ei"], cache)
-    eager_static = model()
-    assert torch.equal(eager_dense, eager_static)
+    eager_static = model()                    # layer 0: the fused launch on the static layout (round 4) — same chains, same
+    assert torch.equal(fused_dense, eager_static)      # projection order as the fused launch on the dense table: same bits
     before = dict(P.STATIC_STATS)
     cap = tfg.CapturedForward(model)
     assert P.STATIC_STATS["hits"] > before["hits"] and P.STATIC_STATS["builds"] == before["builds"]   # used, not rebuilt
     out = cap()
-    assert torch.equal(out, eager_dense)
+    assert torch.equal(out, eager_static)
     tfg.release_static_features(cache)
 
 

@@ -455,6 +455,15 @@ def test_fused_aggregate_gemm_equals_two_launches(tfg, oracle, n, e, f, units, m
     side = torch.full((n, f), float("nan"), device="cuda")
     again = P.aggregate_gemm(plan, xd, op, kd, w_csr=w_csr, self_coef=sc, bias=bd, act=L.ACT_RELU, agg_out=side)
     assert torch.equal(side, agg) and torch.equal(again, fused)
+    # the static feature layout as the source (main rows of whole lines + node tails, then the per-edge tail stream): the
+    # same FMA chain per element, the same projection order -> bit-identical to the launch on the dense table
+    if f > 32 and f % 32 and ei.shape[1]:
+        rows = P.SplitRows.from_dense(xd)
+        assert torch.equal(P.aggregate_gemm(plan, rows, op, kd, w_csr=w_csr, self_coef=sc, bias=bd, act=L.ACT_RELU), fused)
+        rows.with_edge_tail(plan)
+        side2 = torch.empty_like(side)
+        tail = P.aggregate_gemm(plan, rows, op, kd, w_csr=w_csr, self_coef=sc, bias=bd, act=L.ACT_RELU, agg_out=side2)
+        assert torch.equal(tail, fused) and torch.equal(side2, agg)
 
 
 def test_fused_aggregate_gemm_declines_what_it_cannot_take(tfg, oracle):

@@ -163,11 +163,12 @@ class _AggregateProject(torch.autograd.Function):
     reads it from LDS, so the training forward saves the GEMM's read-back of the [N, F] aggregate."""
 
     @staticmethod
-    def forward(ctx, plan, mean, x, w_csr, self_coef, kernel, bias, act):
+    def forward(ctx, plan, mean, x, w_csr, self_coef, kernel, bias, act, rows=None):
+        """`rows`: x in the static feature layout (plan.static_rows) — same values, same aggregate bits."""
         n, F = plan.n_dst, int(x.shape[1])
         need_agg = ctx.needs_input_grad[5]
         agg = torch.empty((n, F), dtype=torch.float32, device=x.device) if need_agg else None
-        out = aggregate_gemm(plan, x.detach(), L.MEAN if mean else L.SUM, kernel.detach(),
+        out = aggregate_gemm(plan, x.detach() if rows is None else rows, L.MEAN if mean else L.SUM, kernel.detach(),
                              w_csr=None if w_csr is None else w_csr.detach(),
                              self_coef=None if self_coef is None else self_coef.detach(),
                              bias=None if bias is None else bias.detach(), act=act, agg_out=agg)
@@ -195,16 +196,17 @@ class _AggregateProject(torch.autograd.Function):
         if need[2] or need[3] or need[4]:
             g_agg = gemm_bias_act(g, transpose(kernel.detach()))          # d/d(aggregate) = g @ kernel^T
             gx, gw, gs = _aggregate_backward(ctx.plan, ctx.mean, x, w_csr, self_coef, g_agg, need[2], need[3], need[4])
-        return None, None, gx, gw, gs, gk, gb, None
+        return None, None, gx, gw, gs, gk, gb, None, None
 
 
-def aggregate_project(plan, x, op, kernel, w_csr=None, self_coef=None, bias=None, act=L.ACT_NONE):
+def aggregate_project(plan, x, op, kernel, w_csr=None, self_coef=None, bias=None, act=L.ACT_NONE, rows=None):
     """Differentiable act(reduce(plan, x) @ kernel + bias) on the fused launch, or None when it does not take the shape
-    (the caller then composes aggregate + linear)."""
-    if op not in (L.SUM, L.MEAN) or not aggregate_gemm_applies(x, kernel, op):
+    (the caller then composes aggregate + linear).  rows: x's static layout (plan.static_rows) or None / x itself."""
+    rows = rows if isinstance(rows, SplitRows) else None
+    if op not in (L.SUM, L.MEAN) or not aggregate_gemm_applies(x if rows is None else rows, kernel, op):
         return None
     return _AggregateProject.apply(plan, op == L.MEAN, x, w_csr, self_coef, L.as_f32(kernel),
-                                   None if bias is None else L.as_f32(bias), act)
+                                   None if bias is None else L.as_f32(bias), act, rows)
 
 
 class _SageWide(torch.autograd.Function):
@@ -213,12 +215,12 @@ class _SageWide(torch.autograd.Function):
     (tfgx_aggregate_gemm_f32 straight into its half of h, aggregate written beside it for d/dkn), the self half the GEMM."""
 
     @staticmethod
-    def forward(ctx, plan, mean, x, ks, kn, w_csr, bias, act):
+    def forward(ctx, plan, mean, x, ks, kn, w_csr, bias, act, rows=None):
         n, F, na, nb = int(x.shape[0]), int(x.shape[1]), int(ks.shape[1]), int(kn.shape[1])
         h = torch.empty((n, na + nb), dtype=torch.float32, device=x.device)
         bd = None if bias is None else bias.detach().contiguous()
         agg = torch.empty((n, F), dtype=torch.float32, device=x.device) if ctx.needs_input_grad[4] else None
-        got = aggregate_gemm(plan, x.detach(), L.MEAN if mean else L.SUM, kn.detach(),
+        got = aggregate_gemm(plan, x.detach() if rows is None else rows, L.MEAN if mean else L.SUM, kn.detach(),
                              w_csr=None if w_csr is None else w_csr.detach(),
                              bias=None if bd is None else bd[na:].contiguous(), act=act, out=h[:, na:], agg_out=agg)
         if got is None:
@@ -249,16 +251,18 @@ class _SageWide(torch.autograd.Function):
             gx2, _, _ = _aggregate_backward(plan, ctx.mean, x, w_csr, None, g_agg, True, False, False)
             gx = gx + gx2
         gb = torch.cat([gba, gbb]) if want_b else None
-        return None, None, gx, gks, gkn, None, gb, None
+        return None, None, gx, gks, gkn, None, gb, None, None
 
 
-def sage_wide(plan, op, x, ks, kn, w_csr=None, bias=None, act=L.ACT_NONE):
+def sage_wide(plan, op, x, ks, kn, w_csr=None, bias=None, act=L.ACT_NONE, rows=None):
     """Differentiable mean / sum GraphSAGE layer body (concat form, aggregation first) with the neighbour half on the fused
-    launch, or None when it does not take the shape.  Edge weights are constants here (trainable ones take the un-fused route)."""
-    if op not in (L.SUM, L.MEAN) or not aggregate_gemm_applies(x, kn, op):
+    launch, or None when it does not take the shape.  Edge weights are constants here (trainable ones take the un-fused route).
+    rows: x's static layout (plan.static_rows) or None / x itself."""
+    rows = rows if isinstance(rows, SplitRows) else None
+    if op not in (L.SUM, L.MEAN) or not aggregate_gemm_applies(x if rows is None else rows, kn, op):
         return None
     return _SageWide.apply(plan, op == L.MEAN, x, L.as_f32(ks), L.as_f32(kn), w_csr,
-                           None if bias is None else L.as_f32(bias), act)
+                           None if bias is None else L.as_f32(bias), act, rows)
 
 
 # Gradient of max aggregation (tf.math.unsorted_segment_max, ties share evenly):

@@ -74,6 +74,13 @@ struct FArgs {
     // rows of a tile are of similar length and no lane group holds a tile back; NULL: i
     const int32_t* row_order;
     const int32_t* hub_order_slot;  // optional: slot of row row_order[i] in hub_rows, i < n_hub (rows sorted by length: hubs first)
+    // optional split source rows (the static feature layout, tfgx_reduce_args.x_tail / edge_tail): x holds columns [0, f_main),
+    // x_tail columns [f_main, F) per NODE, edge_tail the same tail columns per EDGE of this plan (streamed next to col / w)
+    const float* x_tail;
+    int64_t ld_tail;
+    int32_t f_main;
+    const float* edge_tail;
+    int64_t ld_edge_tail;
 };
 
 #ifdef TFGX_FUSED_DEBUG
@@ -115,6 +122,22 @@ __global__ __launch_bounds__(kFusedThreads) void agg_gemm_kernel(const FArgs a)
     const bool cvalid = c_raw < a.F;
     const int coff = cvalid ? c_raw : a.F - 4;              // lanes past F re-read the last valid vector (discarded)
     const int l31 = lane64 & 31, kh = lane64 >> 5;
+    // per-lane source base / stride (seg_reduce_kernel's SPLIT scheme): one array normally; with split rows the lanes that own
+    // columns >= f_main read the node-tail array — or, for gathered rows, the per-EDGE tail stream (indexed by CSR position)
+    const float* xb = a.x + coff;           // gathered rows
+    int64_t xl = a.ldx;
+    const float* xsb = xb;                  // a NODE's own row (the self-loop term)
+    int64_t xsl = xl;
+    bool by_edge = false;
+    if (a.x_tail != nullptr && coff >= a.f_main) {
+        xb = xsb = a.x_tail + (coff - a.f_main);
+        xl = xsl = a.ld_tail;
+        if (a.edge_tail != nullptr) {
+            xb = a.edge_tail + (coff - a.f_main);
+            xl = a.ld_edge_tail;
+            by_edge = true;
+        }
+    }
 
     while (true) {
         int u = 0;
@@ -188,7 +211,7 @@ __global__ __launch_bounds__(kFusedThreads) void agg_gemm_kernel(const FArgs a)
                     for (int t = 0; t < UNROLL; ++t) {
                         const int c = bcast_i<G>(cj, j + t);
                         if constexpr (WEIGHTED) ww[t] = bcast_f<G>(wj, j + t);
-                        load_vec<4>(a.x + int64_t(c) * a.ldx + coff, xv[t]);
+                        load_vec<4>(xb + (by_edge ? int64_t(base + j + t) : int64_t(c)) * xl, xv[t]);
                     }
 #pragma unroll
                     for (int t = 0; t < UNROLL; ++t)
@@ -200,7 +223,7 @@ __global__ __launch_bounds__(kFusedThreads) void agg_gemm_kernel(const FArgs a)
                     float wv = 1.0f;
                     if constexpr (WEIGHTED) wv = bcast_f<G>(wj, j);
                     float xv[4];
-                    load_vec<4>(a.x + int64_t(c) * a.ldx + coff, xv);
+                    load_vec<4>(xb + (by_edge ? int64_t(base + j) : int64_t(c)) * xl, xv);
 #pragma unroll
                     for (int v = 0; v < 4; ++v) acc[v] = WEIGHTED ? fmaf(wv, xv[v], acc[v]) : acc[v] + xv[v];
                 }
@@ -208,7 +231,7 @@ __global__ __launch_bounds__(kFusedThreads) void agg_gemm_kernel(const FArgs a)
             if (a.self_coef) {                               // the implicit (r, r) edge appended after the row's edges
                 const float sc = a.self_coef[r];
                 float xs[4];
-                load_vec<4>(a.x + r * a.ldx + coff, xs);
+                load_vec<4>(xsb + r * xsl, xs);
 #pragma unroll
                 for (int v = 0; v < 4; ++v) acc[v] = fmaf(sc, xs[v], acc[v]);
             }
@@ -440,9 +463,17 @@ extern "C" int tfgx_aggregate_gemm_f32(const tfgx_reduce_args* p, const float* B
     if (p->n_dst == 0) return TFGX_OK;
     TFGX_REQUIRE(p->row_begin && p->row_end == p->row_begin + 1 && p->rp_stride == 1, "needs a plain CSR (row_ptr, row_ptr + 1)");
     TFGX_REQUIRE(p->x && B && C, "null pointer");          // (col may be NULL for a graph without edges)
-    TFGX_REQUIRE(p->ldx >= p->F && p->ldx % 4 == 0 && aligned_to(p->x, 16) && ldb >= N && ldc >= N, "bad leading dimension / alignment");
-    TFGX_REQUIRE(!p->accumulate && !p->add_x && !p->x_tail && !p->track,
-                 "plain aggregation only (no accumulate / add_x / split rows / track)");
+    TFGX_REQUIRE(p->ldx >= (p->x_tail ? p->f_main : p->F) && p->ldx % 4 == 0 && aligned_to(p->x, 16) && ldb >= N && ldc >= N,
+                 "bad leading dimension / alignment");
+    TFGX_REQUIRE(!p->accumulate && !p->add_x && !p->track, "plain aggregation only (no accumulate / add_x / track)");
+    if (p->x_tail) {      // split source rows (static feature layout): whole-line main rows + 16-byte aligned tails
+        TFGX_REQUIRE(p->f_main >= 4 && p->f_main % 4 == 0 && p->f_main < p->F && p->ldx >= p->f_main && p->ld_tail >= p->F - p->f_main &&
+                         p->ld_tail % 4 == 0 && aligned_to(p->x_tail, 16),
+                     "split rows: bad f_main / ld_tail / alignment");
+        TFGX_REQUIRE(p->edge_tail == nullptr || (p->ld_edge_tail >= p->F - p->f_main && p->ld_edge_tail % 4 == 0 &&
+                                                 aligned_to(p->edge_tail, 16)),
+                     "split rows: bad edge_tail stride / alignment");
+    }
     TFGX_REQUIRE(p->out == nullptr || (p->ldo >= p->F && p->ldo % 4 == 0 && aligned_to(p->out, 16)),
                  "side output of the aggregate: rows of >= F floats, 16-byte aligned");
     const bool use_hub = p->hub_threshold > 0 && p->n_hub_rows > 0;
@@ -472,6 +503,8 @@ extern "C" int tfgx_aggregate_gemm_f32(const tfgx_reduce_args* p, const float* B
     a.op = p->op; a.self_coef = p->self_coef; a.mean_count = p->mean_count;
     a.B = B; a.ldb = ldb; a.bias = bias; a.act = act; a.N = int32_t(N); a.C = C; a.ldc = ldc;
     a.hub_order_slot = use_hub ? p->hub_order_slot : nullptr;
+    a.x_tail = p->x_tail; a.ld_tail = p->ld_tail; a.f_main = int32_t(p->x_tail ? p->f_main : p->F);
+    a.edge_tail = p->x_tail ? p->edge_tail : nullptr; a.ld_edge_tail = p->ld_edge_tail;
     a.agg = p->out; a.ld_agg = p->ldo;
     a.KP = int32_t((p->F + 1) / 2 * 2);
     a.n_blocks = int32_t((N + 127) / 128) * 4;          // 32-column blocks, in groups of four (columns >= N are zero in LDS)

@@ -198,10 +198,12 @@ def gcn(x, sparse_adj, kernel, bias=None, activation=None, norm="both", add_self
         if narrow_first:
             pre = static_aggregate(h, normed.plan, cache, L.SUM, normed.w_csr, normed.self_coef)   # opt-in memo (layer 0)
             fused = None
-            if pre is None and not isinstance(rows, SplitRows):
-                # ONE forward launch (tfgx_aggregate_gemm_f32); the aggregate is written beside it only because the
-                # kernel's gradient needs it — the projection reads it from LDS (None: shape does not fit)
-                fused = AG.aggregate_project(normed.plan, h, L.SUM, kernel, normed.w_csr, normed.self_coef, bias_t, act)
+            if pre is None:
+                # ONE forward launch (tfgx_aggregate_gemm_f32), on the static feature layout when x has one; the aggregate is
+                # written beside it only because the kernel's gradient needs it — the projection reads it from LDS (None: shape
+                # does not fit)
+                fused = AG.aggregate_project(normed.plan, h, L.SUM, kernel, normed.w_csr, normed.self_coef, bias_t, act,
+                                             rows=rows)
             if fused is not None:
                 h = fused
             else:
@@ -216,11 +218,12 @@ def gcn(x, sparse_adj, kernel, bias=None, activation=None, norm="both", add_self
         # bias + activation move into the GEMM epilogue. Same result up to fp32 re-association (inside 1e-5).
         pre = static_aggregate(x, normed.plan, cache, L.SUM, normed.w_csr, normed.self_coef)       # opt-in memo (layer 0)
         h = None
-        if pre is None and not isinstance(static_rows(x, normed.plan, cache), SplitRows):
+        if pre is None:
             # one launch: 64-row tiles of A_hat @ x go registers -> LDS -> MFMA against the kernel held in LDS; the
-            # [N, F] aggregate never visits HBM (tfgx_aggregate_gemm_f32; None when the shape does not fit)
-            h = aggregate_gemm(normed.plan, x, L.SUM, kernel, w_csr=normed.w_csr, self_coef=normed.self_coef, bias=bias_t,
-                               act=act)
+            # [N, F] aggregate never visits HBM (tfgx_aggregate_gemm_f32; None when the shape does not fit).  Source rows: x
+            # itself, or its static layout (declared, or promoted on this tensor's second sighting: plan.static_rows)
+            h = aggregate_gemm(normed.plan, static_rows(x, normed.plan, cache), L.SUM, kernel, w_csr=normed.w_csr,
+                               self_coef=normed.self_coef, bias=bias_t, act=act)
         if h is None:
             h = gemm_bias_act(pre if pre is not None else normed.matmul(x, cache=cache), kernel, bias=bias_t, act=act)
     else:

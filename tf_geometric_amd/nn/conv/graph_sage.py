@@ -81,14 +81,14 @@ def _concat_fused(x, edge_index, edge_weight, ws, wn, bias, activation, normaliz
     n = int(x.shape[0])
     plan = CsrPlan.from_cache(edge_index, n, n, cache)
     w_csr = AG.edge_attr_csr(plan, edge_weight, cache)
-    if static_aggregate_applies(x, cache) or isinstance(static_rows(x, plan, cache), SplitRows):
+    if static_aggregate_applies(x, cache):
         return None
     act, post = _resolve_act(activation)
     ku_x, ku_n = int(ws.shape[1]), int(wn.shape[1])
     bias_t = None if bias is None else L.as_f32(bias).contiguous()
     h = torch.empty((n, ku_x + ku_n), dtype=torch.float32, device=x.device)
-    if aggregate_gemm(plan, x, op, wn, w_csr=w_csr, bias=None if bias_t is None else bias_t[ku_x:].contiguous(), act=act,
-                      out=h[:, ku_x:]) is None:
+    if aggregate_gemm(plan, static_rows(x, plan, cache), op, wn, w_csr=w_csr,
+                      bias=None if bias_t is None else bias_t[ku_x:].contiguous(), act=act, out=h[:, ku_x:]) is None:
         return None
     gemm_bias_act(x, ws, bias=None if bias_t is None else bias_t[:ku_x], act=act, out=h[:, :ku_x])
     if post is not None:
@@ -103,11 +103,11 @@ def _concat_fused_training(x, edge_index, edge_weight, ws, wn, bias, activation,
     aggregate is written beside it when d/dW_neigh is wanted.  None when the fused kernel does not take the call."""
     n = int(x.shape[0])
     plan = CsrPlan.from_cache(edge_index, n, n, cache)
-    if static_aggregate_applies(x, cache) or isinstance(static_rows(x, plan, cache), SplitRows):
+    if static_aggregate_applies(x, cache):
         return None
     w_csr = AG.edge_attr_csr(plan, edge_weight, cache)
     act, post = _resolve_act(activation)
-    h = AG.sage_wide(plan, op, x, ws, wn, w_csr, bias, act)
+    h = AG.sage_wide(plan, op, x, ws, wn, w_csr, bias, act, rows=static_rows(x, plan, cache))
     if h is None:
         return None
     if post is not None:

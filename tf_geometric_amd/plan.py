@@ -547,12 +547,13 @@ FUSED_STATS = {"launches": 0, "with_side_output": 0}      # diagnostics (tests a
 
 
 def aggregate_gemm_applies(x, kernel, op=L.SUM):
-    """Would aggregate_gemm take this call?  (No launch; callers that must choose their autograd route ask first.)"""
-    if not FUSE_AGGREGATE_GEMM or op not in (L.SUM, L.MEAN) or isinstance(x, SplitRows) or kernel is None:
+    """Would aggregate_gemm take this call?  (No launch; callers that must choose their autograd route ask first.)
+    x: a dense table or a SplitRows (the static feature layout)."""
+    if not FUSE_AGGREGATE_GEMM or op not in (L.SUM, L.MEAN) or kernel is None:
         return False
     lib = L.require_gpu()
-    x2, ldx = L.row_major_2d(x)
-    F, N = int(x2.shape[1]), int(kernel.shape[1])
+    x2, ldx = L.row_major_2d(x.main if isinstance(x, SplitRows) else x)
+    F, N = (x.shape[1] if isinstance(x, SplitRows) else int(x2.shape[1])), int(kernel.shape[1])
     return bool(int(kernel.shape[0]) == F and lib.tfgx_aggregate_gemm_fits(F, N) and ldx % 4 == 0
                 and x2.data_ptr() % 16 == 0)
 
@@ -563,12 +564,13 @@ def aggregate_gemm(plan, x, op, kernel, w_csr=None, self_coef=None, bias=None, a
     this call (shape outside tfgx_aggregate_gemm_fits, unaligned rows) — the caller then runs the two launches.
     agg_out: optional dense [n_dst, F] tensor that ALSO receives the aggregate itself (the training forward: the weight
     gradient needs it)."""
-    if not FUSE_AGGREGATE_GEMM or op not in (L.SUM, L.MEAN) or isinstance(x, SplitRows):
+    if not FUSE_AGGREGATE_GEMM or op not in (L.SUM, L.MEAN):
         return None
     lib = L.require_gpu()
-    x2, ldx = L.row_major_2d(x)
+    split = x if isinstance(x, SplitRows) else None       # static feature layout: main / tail / per-edge tail (as segment_reduce)
+    x2, ldx = L.row_major_2d(split.main if split is not None else x)
     k2, ldb = L.row_major_2d(L.as_f32(kernel))
-    F, N = int(x2.shape[1]), int(k2.shape[1])
+    F, N = (split.shape[1] if split is not None else int(x2.shape[1])), int(k2.shape[1])
     if int(k2.shape[0]) != F or not lib.tfgx_aggregate_gemm_fits(F, N) or ldx % 4 != 0 or x2.data_ptr() % 16 != 0:
         return None
     hub = plan.hub_info()      # long rows: chunk partials by a launch of the ordinary kernel, folded by the row's lane group
@@ -584,6 +586,10 @@ def aggregate_gemm(plan, x, op, kernel, w_csr=None, self_coef=None, bias=None, a
     a.n_dst, a.x, a.ldx, a.F = n_dst, x2.data_ptr(), ldx, F
     a.op = op
     a.self_coef = 0 if self_coef is None else self_coef.data_ptr()
+    if split is not None:
+        a.x_tail, a.ld_tail, a.f_main = split.tail.data_ptr(), int(split.tail.shape[1]), int(split.main.shape[1])
+        if split.edge_tail is not None and split.edge_plan is plan:
+            a.edge_tail, a.ld_edge_tail = split.edge_tail.data_ptr(), int(split.edge_tail.shape[1])
     if order is not None:
         a.row_order = order.data_ptr()
     if hub is not None:
