@@ -851,3 +851,42 @@ def test_tracked_max_span_by_span_equals_one_launch(tfg, oracle, f, weighted, k1
     AG.aggregate(plan, xc, L.MAX, w_csr=w, max_passes=passes).backward(g)
     assert torch.equal(xa.grad, xc.grad)
     assert torch.equal(seen[0], xa.grad[n // 3:n // 3 + 100]) and torch.equal(seen[1], xa.grad[n // 3 + 100:])
+
+
+@pytest.mark.parametrize("kind", ["gcn", "MeanGraphSage"])
+def test_training_on_the_promoted_static_layout_gives_the_same_bits(tfg, oracle, kind):
+    """A layer's second call with the same unchanged feature tensor promotes it to the static layout (plan.static_rows);
+    the TRAINING forward then runs the fused launch on split rows + the per-edge tail stream.  Same FMA chains, same
+    projection order: output and every gradient are bit-identical to the run on the plain table.  (The promotion is
+    restricted to matrices far larger than the caches; the size test is lifted here to exercise the route at test size.)"""
+    from tf_geometric_amd import plan as P
+    x, ei, w, rng = _graph(oracle, n=3000, e=40000, f=100, seed=41)
+    n, units = x.shape[0], 256
+    xt = tfg._lib.as_f32(x)
+    gout = torch.tensor(rng.standard_normal((n, units)).astype(np.float32), device="cuda")
+    layer = tfg.layers.GCN(units, activation=tfg.relu) if kind == "gcn" else getattr(tfg.layers, kind)(units, activation=tfg.relu)
+    layer._maybe_build([x])
+    layer.trainable(True)
+
+    def run(cache):
+        for p_ in layer.parameters():
+            p_.grad = None
+        out = layer([xt, ei, w], cache=cache)
+        out.backward(gout)
+        return out.detach().clone(), [p_.grad.clone() for p_ in layer.parameters()]
+
+    wanted = P.SplitRows.wanted
+    P.SplitRows.wanted = staticmethod(lambda n_, F: F % 4 == 0 and 32 < F <= 128 and F % 32 != 0)
+    try:
+        cache = {}
+        o1, g1 = run(cache)                                  # first sighting: the plain table
+        assert cache.get("tfgx_static_rows") is None
+        before = dict(P.FUSED_STATS)
+        o2, g2 = run(cache)                                  # second call: promoted, fused launch on the split rows
+        assert cache["tfgx_static_rows"][1] is not None and cache["tfgx_static_rows"][1].edge_tail is not None
+        assert P.FUSED_STATS["launches"] == before["launches"] + 1 and P.FUSED_STATS["with_side_output"] == before["with_side_output"] + 1
+    finally:
+        P.SplitRows.wanted = wanted
+    assert torch.equal(o1, o2)
+    for a, b in zip(g1, g2):
+        assert torch.equal(a, b)
