@@ -324,6 +324,39 @@ def test_reddit_gat_sampled_rows_match_oracle(tfg, oracle, reddit, attention_uni
     assert_parity(ref32[rows_np], ref[rows_np], what="fp32 op-for-op reference formulation vs float64")
 
 
+def test_reddit_rmat_gat_sampled_rows_match_oracle(tfg, oracle):
+    """The same layer on a Reddit-sized R-MAT graph (power-law in-degrees: rows beyond the plan's hub threshold take the
+    chunk-cooperative softmax path, the rest the degree-ordered walk): 300 random rows + 20 hub rows vs oracle.gat."""
+    import numpy as np
+    from conftest import assert_parity
+    from tf_geometric_amd import synthetic
+    from tf_geometric_amd.plan import CsrPlan
+    n, e, f = synthetic.WORKLOADS["reddit"]
+    ei = synthetic.rmat_edges(n, e, 13, torch.device("cuda"))
+    g = torch.Generator(device="cuda")
+    g.manual_seed(19)
+    x = torch.randn(n, f, generator=g, device="cuda")
+    plan = CsrPlan.build(ei, n, n)
+    hub = plan.hub_info()
+    assert hub is not None and int(hub[0].shape[0]) > 100                      # the graph does exercise the hub path
+    rng = np.random.Generator(np.random.PCG64(48))
+    A, U, H = 8, 64, 8
+    wq, wk, wv = oracle.glorot_uniform(rng, f, A), oracle.glorot_uniform(rng, f, A), oracle.glorot_uniform(rng, f, U)
+    bq, bk = (rng.standard_normal(A) * 0.1).astype(np.float32), (rng.standard_normal(A) * 0.1).astype(np.float32)
+    b = (rng.standard_normal(U) * 0.1).astype(np.float32)
+    layer = tfg.layers.GAT(U, attention_units=A, num_heads=H, activation=tfg.relu)
+    layer._maybe_build([x])
+    layer.set_weights(query_kernel=wq, query_bias=bq, key_kernel=wk, key_bias=bk, kernel=wv, bias=b)
+    p = dict(n=n, plan=plan)
+    rows = _layer_rows(p, 300, seed=9, hub_rows=20, max_hub_degree=20000, longest=False)
+    got = layer([x, ei], cache={"tfgx_csr_plan": plan})[rows].cpu().numpy()
+    ei_sub = ei[:, torch.isin(ei[0].long(), rows)].cpu().numpy()
+    deg = plan.in_degree()[rows]
+    assert int((deg > plan.hub_threshold).sum()) >= 10 and ei_sub.shape[1] > 20000
+    ref = oracle.gat(x.cpu().numpy(), ei_sub, wq, bq, "relu", wk, bk, "relu", wv, b, "relu", num_heads=H)
+    assert_parity(got, ref[rows.cpu().numpy()], what="Reddit-sized R-MAT GAT (hub rows sampled) on sampled rows")
+
+
 def test_papers_shard_sampled_rows_match_oracle(tfg, oracle):
     """BASELINE configs[4], ONE of the 8 destination shards of the papers100M shape: 13.9 M destination rows, 200 M
     in-edges, sources anywhere among 111 M nodes (the 56.8 GB source table is resident: own rows + halo).  Weighted sum

@@ -21,6 +21,7 @@
 // Deterministic (fixed per-row edge order, fixed k order), fp32 throughout.  Roofline: HBM (the gather), as the unfused
 // aggregation; the MFMA work (2 N F U flops = 0.8 ms of one wave per CU at products shape) rides on otherwise idle pipes.
 #include "tfgx_common.h"
+#include "tfgx_mfma.h"
 #include <cstdlib>
 
 namespace tfgx {
@@ -32,6 +33,9 @@ constexpr int kTileRows = 64;
 constexpr int kLda = kTileRows + 1;
 constexpr int kBufs = 2;
 constexpr int kFusedThreads = 1024;
+#ifndef TFGX_FUSED_VEC_STORE
+#define TFGX_FUSED_VEC_STORE 1
+#endif
 #ifndef TFGX_FUSED_JB
 #define TFGX_FUSED_JB 2
 #endif
@@ -122,6 +126,10 @@ __global__ __launch_bounds__(kFusedThreads) void agg_gemm_kernel(const FArgs a)
     const bool cvalid = c_raw < a.F;
     const int coff = cvalid ? c_raw : a.F - 4;              // lanes past F re-read the last valid vector (discarded)
     const int l31 = lane64 & 31, kh = lane64 >> 5;
+#if TFGX_FUSED_VEC_STORE
+    const bool vec_store = (a.N % 4 == 0) && (a.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.C) & 15) == 0) &&
+                           a.row_order == nullptr;      // wave-uniform (walk order scatters a tile's rows: per-row ids, scalar path)
+#endif
     // per-lane source base / stride (seg_reduce_kernel's SPLIT scheme): one array normally; with split rows the lanes that own
     // columns >= f_main read the node-tail array — or, for gathered rows, the per-EDGE tail stream (indexed by CSR position)
     const float* xb = a.x + coff;           // gathered rows
@@ -380,6 +388,28 @@ __global__ __launch_bounds__(kFusedThreads) void agg_gemm_kernel(const FArgs a)
                     }
                     continue;
                 }
+#if TFGX_FUSED_VEC_STORE
+                if (full && vec_store) {
+                    // 16-byte stores through a quad transpose of the accumulators (tfgx_mfma.h): 8 instead of 32 store
+                    // instructions per job; lane i of a quad ends with row 8 g + i + 4 kh, columns 4 q .. 4 q + 3
+                    const int qi = lane64 & 3, qc = (l31 >> 2) * 4;
+#pragma unroll
+                    for (int jb = 0; jb < JB; ++jb) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            float r4[4] = {c4[jb][4 * g], c4[jb][4 * g + 1], c4[jb][4 * g + 2], c4[jb][4 * g + 3]};
+                            quad_transpose4(r4, lane64);
+                            const int gn = (nb0 + jb) * 32 + qc;
+                            if (gn < a.N) {
+                                float* cp = a.C + (tile * kTileRows + mb * 32 + 8 * g + qi + 4 * kh) * a.ldc + gn;
+                                typedef float f32x4s __attribute__((ext_vector_type(4)));
+                                __builtin_nontemporal_store(f32x4s{r4[0], r4[1], r4[2], r4[3]}, reinterpret_cast<f32x4s*>(cp));
+                            }
+                        }
+                    }
+                    continue;
+                }
+#endif
 #pragma unroll
                 for (int jb = 0; jb < JB; ++jb) {
                     const int gn = (nb0 + jb) * 32 + l31;

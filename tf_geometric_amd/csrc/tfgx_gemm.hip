@@ -16,6 +16,7 @@
 //    consecutive m; B is staged as Bs[k][n].  Global loads for tile t+1 are issued before the MFMAs of tile t
 //    (register staging), LDS is single-buffered.  Optional split-K over blockIdx.y for small M with a long K.
 #include "tfgx_common.h"
+#include "tfgx_mfma.h"
 #include <cstdlib>
 
 namespace tfgx {
@@ -297,27 +298,6 @@ __global__ __launch_bounds__(kBlock) void gemm_kernel(const float* __restrict__ 
 // the current step's 16 x TN MFMAs, B operands are double-buffered in registers one MFMA group ahead, and because
 // waves drift apart the store epilogue of one wave overlaps the MFMAs of the other wave on its SIMD.
 // Arithmetic: fp32 FMA chain per output element in the k order above (a permutation of 0..K-1).
-// 4 x 4 transpose between the four lanes of a quad and four registers: lane i (= lane & 3) enters with r[k] = M[k][i] and
-// leaves with r[0..3] = M[i][0..3] — two butterfly stages over DPP quad permutes (xor 1, then xor 2).  The MFMA D layout puts
-// ONE output column in a lane (rows in registers); after this a lane holds four consecutive columns of one row and the
-// epilogue stores 16 bytes per lane: 32 store instructions per 32 x 256 tile instead of 128.
-__device__ __forceinline__ void quad_transpose4(float (&r)[4], int lane)
-{
-    const bool odd = lane & 1, hi = lane & 2;
-#pragma unroll
-    for (int k = 0; k < 4; k += 2) {
-        const float send = odd ? r[k] : r[k + 1];
-        const float recv = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, send), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
-        r[k] = odd ? recv : r[k];
-        r[k + 1] = odd ? r[k + 1] : recv;
-    }
-    const float sa = hi ? r[0] : r[2], sb = hi ? r[1] : r[3];
-    const float ra = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, sa), 0x4E, 0xF, 0xF, true));          // quad_perm [2,3,0,1]
-    const float rb = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, sb), 0x4E, 0xF, 0xF, true));
-    const float o0 = hi ? ra : r[0], o1 = hi ? rb : r[1], o2 = hi ? r[2] : ra, o3 = hi ? r[3] : rb;
-    r[0] = o0; r[1] = o1; r[2] = o2; r[3] = o3;
-}
-
 // NG consecutive MFMA groups of gemm_rows_kernel (one group = one k pair x TN accumulators; a full step is 16 groups),
 // B operands read from LDS one group ahead.  The sched_barriers pin that order: left alone, the scheduler sinks every
 // ds_read next to its MFMA (fewest live registers), which puts a full LDS round trip in front of each group.
