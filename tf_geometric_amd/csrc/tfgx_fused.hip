@@ -127,8 +127,7 @@ __global__ __launch_bounds__(kFusedThreads) void agg_gemm_kernel(const FArgs a)
     const int coff = cvalid ? c_raw : a.F - 4;              // lanes past F re-read the last valid vector (discarded)
     const int l31 = lane64 & 31, kh = lane64 >> 5;
 #if TFGX_FUSED_VEC_STORE
-    const bool vec_store = (a.N % 4 == 0) && (a.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.C) & 15) == 0) &&
-                           a.row_order == nullptr;      // wave-uniform (walk order scatters a tile's rows: per-row ids, scalar path)
+    const bool vec_store = (a.N % 4 == 0) && (a.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.C) & 15) == 0);   // wave-uniform
 #endif
     // per-lane source base / stride (seg_reduce_kernel's SPLIT scheme): one array normally; with split rows the lanes that own
     // columns >= f_main read the node-tail array — or, for gathered rows, the per-EDGE tail stream (indexed by CSR position)
@@ -389,7 +388,7 @@ __global__ __launch_bounds__(kFusedThreads) void agg_gemm_kernel(const FArgs a)
                     continue;
                 }
 #if TFGX_FUSED_VEC_STORE
-                if (full && vec_store) {
+                if (vec_store && (full || a.row_order != nullptr)) {
                     // 16-byte stores through a quad transpose of the accumulators (tfgx_mfma.h): 8 instead of 32 store
                     // instructions per job; lane i of a quad ends with row 8 g + i + 4 kh, columns 4 q .. 4 q + 3
                     const int qi = lane64 & 3, qc = (l31 >> 2) * 4;
@@ -400,8 +399,11 @@ __global__ __launch_bounds__(kFusedThreads) void agg_gemm_kernel(const FArgs a)
                             float r4[4] = {c4[jb][4 * g], c4[jb][4 * g + 1], c4[jb][4 * g + 2], c4[jb][4 * g + 3]};
                             quad_transpose4(r4, lane64);
                             const int gn = (nb0 + jb) * 32 + qc;
-                            if (gn < a.N) {
-                                float* cp = a.C + (tile * kTileRows + mb * 32 + 8 * g + qi + 4 * kh) * a.ldc + gn;
+                            // walk order: the tile slot's destination row comes from the ids the producers left in LDS (-1: past the end)
+                            const int64_t rr = a.row_order != nullptr ? int64_t(rowid[buf * kTileRows + mb * 32 + 8 * g + qi + 4 * kh])
+                                                                      : tile * kTileRows + mb * 32 + 8 * g + qi + 4 * kh;
+                            if (gn < a.N && rr >= 0) {
+                                float* cp = a.C + rr * a.ldc + gn;
                                 typedef float f32x4s __attribute__((ext_vector_type(4)));
                                 __builtin_nontemporal_store(f32x4s{r4[0], r4[1], r4[2], r4[3]}, reinterpret_cast<f32x4s*>(cp));
                             }
