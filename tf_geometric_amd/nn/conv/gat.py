@@ -85,13 +85,15 @@ def gat_args(Q, K, V, num_heads, n_dst, col, add_self_loop=True, bias=None, act=
     return a, out, (Q, K, V)
 
 
-_SEED_STATE = {}          # device index -> int64[1] device tensor: the seed stream hipGraph-captured steps draw from
+_SEED_STATE = {}          # (device index, torch seed) -> int64[1] device tensor: the seed stream hipGraph-captured steps draw from
 _SEED_STRIDE = -7046029254386353131      # 0x9E3779B97F4A7C15 as int64 (odd: the stream visits all 2^64 values)
 
 
 def _seed_state(device):
     """Created EAGERLY (never inside a capture: a captured fill would reset it on every replay), from torch's host generator."""
-    key = device.index if device.index is not None else torch.cuda.current_device()
+    # one stream per (device, torch seed): torch.manual_seed(s) before a capture makes the captured masks repeatable; streams
+    # of earlier seeds stay alive (a captured graph keeps reading the one it was captured with)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.initial_seed())
     st = _SEED_STATE.get(key)
     if st is None:
         if torch.cuda.is_current_stream_capturing():
