@@ -13,6 +13,9 @@ import tf_geometric_amd as tfg                                   # noqa: E402
 from tf_geometric_amd import synthetic, _lib as L, plan as P     # noqa: E402
 
 n, e, f = synthetic.WORKLOADS["products"]
+if len(sys.argv) > 1:                      # feature width override (128: half of the kernel streamed from L2, round 4)
+    f = int(sys.argv[1])
+P.AUTO_STATIC_LAYOUT = False               # the plain table in every call (no promotion on the layer's second call)
 ei = L.as_i32(synthetic.synthetic_edges(n, e, seed=0))
 x = torch.randn(n, f, device="cuda")
 cache = {}
