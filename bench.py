@@ -266,9 +266,6 @@ def main():
     # The one exception is the single-GPU plumbing check of this code path, which must be requested explicitly:
     # TFGX_BENCH_BACKEND=gloo puts all ranks on the visible device(s) and stages rows through the host (transport "torch").
     plumbing = os.environ.get("TFGX_BENCH_BACKEND", "") == "gloo"
-    if world > 1 and n_dev < world and not plumbing:
-        raise SystemExit("bench.py --gpus {}: only {} GPU(s) visible; RCCL needs one device per rank (for a plumbing check "
-                         "of the N > 1 code path on fewer GPUs set TFGX_BENCH_BACKEND=gloo)".format(world, n_dev))
     torch.cuda.set_device(local_rank % n_dev)
 
     import tf_geometric_amd as tfg
@@ -287,6 +284,16 @@ def main():
         # host tensors only.  DATA PLANE = tfgx_dist's ncclComm_t: the only RCCL communicator in the process.
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         dist.init_process_group("gloo")
+        # one physical device per rank?  (ranks may each see all GPUs, or one each through *_VISIBLE_DEVICES: compare PCI ids)
+        props = torch.cuda.get_device_properties(torch.cuda.current_device())
+        mine = "{}:{:04x}:{:02x}:{:02x}".format(os.uname().nodename, getattr(props, "pci_domain_id", 0),
+                                               getattr(props, "pci_bus_id", local_rank % n_dev), getattr(props, "pci_device_id", 0))
+        devs = [None] * world
+        dist.all_gather_object(devs, mine)
+        if len(set(devs)) < world and not plumbing:
+            raise SystemExit("bench.py --gpus {}: {} distinct GPU(s) behind the {} ranks; RCCL needs one device per rank (for a "
+                             "plumbing check of the N > 1 code path on fewer GPUs set TFGX_BENCH_BACKEND=gloo)".format(
+                                 world, len(set(devs)), world))
         from tf_geometric_amd.dist.sharded import ShardedGraph
         t0 = time.perf_counter()
         # every rank GENERATES only its stripe of the edge list (block-seeded generator: the union over the ranks is the same
