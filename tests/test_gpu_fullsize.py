@@ -175,6 +175,13 @@ def test_products_static_layout_is_promoted_automatically_on_the_second_call(tfg
     assert torch.equal(o5, o1) and "tfgx_static_rows" not in cache
     o6 = layer([x, p["ei"], p["w"]], cache=cache)                     # unchanged since the last call -> promoted again
     assert torch.equal(o6, o1) and cache["tfgx_static_rows"][1] is not None and st("auto_promotions") == promos + 2
+    # the caller moves on to ANOTHER feature matrix: seen twice, it takes the promoted tensor's place (the old layout is freed)
+    y = x * 0.5
+    oy = layer([y, p["ei"], p["w"]], cache=cache)
+    assert cache["tfgx_static_features"].data_ptr() == x.data_ptr()                  # first sighting of y: x still holds the slot
+    oy2 = layer([y, p["ei"], p["w"]], cache=cache)
+    assert torch.equal(oy, oy2) and torch.equal(oy, o1 * 0.5)
+    assert cache["tfgx_static_features"].data_ptr() == y.data_ptr() and cache["tfgx_static_rows"][1] is not None
     tfg.release_static_features(cache)
     # budget: a layout of 2.9 GB is not built when the budget says 1 GB
     os.environ["TFGX_STATIC_LAYOUT_BUDGET"] = "1e9"

@@ -417,15 +417,20 @@ def static_rows(x, plan, cache):
     if cache is None or not isinstance(x, torch.Tensor):
         return x
     opt = cache.get(CACHE_KEY_STATIC, None)
-    if opt is None or opt is False or not isinstance(opt, torch.Tensor):
-        if opt is None and _auto_promote(x, plan, cache):
-            opt = x
-        else:
-            return x
+    auto = bool(cache.get(CACHE_KEY_STATIC_AUTO))
     # "the same tensor": same storage window (views made by .detach() / as_f32 share it); opt is kept alive by the
     # cache entry, so the address cannot have been recycled
-    if opt.data_ptr() != x.data_ptr() or opt.shape != x.shape or opt.dtype != x.dtype or opt.stride() != x.stride():
-        return x
+    same = isinstance(opt, torch.Tensor) and (opt.data_ptr() == x.data_ptr() and opt.shape == x.shape and
+                                              opt.dtype == x.dtype and opt.stride() == x.stride())
+    if not same:
+        # no static tensor yet — or an AUTOMATICALLY promoted one that is not this tensor: a candidate seen twice takes its
+        # place (the caller moved on to another feature matrix; the old layout must not be kept alive for ever).  A tensor
+        # the caller DECLARED static is never displaced.
+        if (opt is None or (auto and isinstance(opt, torch.Tensor))) and _auto_promote(x, plan, cache):
+            cache.pop(CACHE_KEY_STATIC_ROWS, None)
+            cache.pop(CACHE_KEY_STATIC_AGG, None)
+        else:
+            return x
     hit = cache.get(CACHE_KEY_STATIC_ROWS)
     if hit is not None and hit[0] == _static_key(x, plan):
         if hit[1] is not None:
