@@ -1,7 +1,8 @@
 # coding=utf-8
-"""Python side of the tf.load_op_library route (BASELINE.json north_star) — A SKETCH, NEVER IMPORTED OR RUN HERE:
-TensorFlow is absent from this image.  tests/test_abi.py compiles this file (py_compile) and checks that every op it
-names is registered by tfgx_tf_ops.cc; nothing more can be verified without TensorFlow.
+"""Python side of the tf.load_op_library route (BASELINE.json north_star) — NEVER IMPORTED OR RUN HERE: TensorFlow is absent
+from this image.  tests/test_abi.py compiles this file (py_compile) and checks that every op it names is registered by
+tfgx_tf_ops.cc; the ops themselves ARE executed — against the mock runtime of integration/tf_shim/mock/, in the pipelines
+this file composes (tests/test_gpu_tf_shim.py) — but nothing here can run without TensorFlow.
 
 What it holds, for a maintainer with a TensorFlow-ROCm build:
   * `load()`                      tf.load_op_library(libtfgx_tf_ops.so) (built by build_tf_shim.sh)
@@ -71,6 +72,28 @@ def _register_gradients(tf, ops):
         dx = ops.tfgx_gemm_bias_act(x=g, kernel=tf.transpose(kernel), bias=tf.zeros([0], g.dtype), act=0)
         return [dx, dw, tf.cond(tf.size(bias) > 0, lambda: db, lambda: tf.zeros([0], g.dtype))]
 
+    @tf.RegisterGradient("TfgxAggregateGemm")
+    def _aggregate_gemm_grad(op, g, g_agg_unused):
+        # out = act(aggregate @ kernel + bias), aggregate = reduce(x) returned as the op's second output (want_aggregate=True)
+        row_ptr, col, w, x, self_coef, kernel, bias = op.inputs
+        if not op.get_attr("want_aggregate"):
+            raise NotImplementedError("TfgxAggregateGemm under a GradientTape needs want_aggregate=True")
+        if op.get_attr("act") == 1:
+            g = ops.tfgx_relu_backward(g=g, out=op.outputs[0])
+        empty = tf.zeros([0], g.dtype)
+        dw, db = ops.tfgx_gemm_tn(x=op.outputs[1], g=g)                         # aggregate^T @ g, column sums of g
+        d_agg = ops.tfgx_gemm_bias_act(x=g, kernel=tf.transpose(kernel), bias=empty, act=0)
+        n = tf.shape(x)[0]
+        if op.get_attr("op") == 1:
+            d_agg = d_agg / tf.cast(tf.maximum(row_ptr[1:] - row_ptr[:-1], 1), g.dtype)[:, None]
+        row_ptr_t, dst_t, perm_t = _transposed_plan(tf, ops, row_ptr, col, None, n)
+        has_w = tf.size(w) > 0
+        w_t = tf.cond(has_w, lambda: ops.tfgx_permute_rows(src=w, perm=perm_t), lambda: empty)
+        gx = ops.tfgx_segment_reduce(row_ptr=row_ptr_t, col=dst_t, w=w_t, x=d_agg, self_coef=self_coef, bias=empty, op=0, act=0)
+        gw = tf.cond(has_w, lambda: ops.tfgx_sddmm(row_ptr=row_ptr, col=col, a=d_agg, b=x), lambda: empty)
+        g_sc = tf.cond(tf.size(self_coef) > 0, lambda: tf.reduce_sum(d_agg * x, axis=1), lambda: empty)
+        return [None, None, gw, gx, g_sc, dw, tf.cond(tf.size(bias) > 0, lambda: db, lambda: empty)]
+
     @tf.RegisterGradient("TfgxHaloExchange")
     def _halo_grad(op, g_table):
         x_own, send_idx, sc, rc, ds, comm = op.inputs
@@ -101,12 +124,13 @@ def gcn_layer(x, edge_index, edge_weight, kernel, bias, num_nodes, activation_is
     row_ptr, col, w_norm, self_coef = plan
     empty = tf.zeros([0], tf.float32)
     f_in, units = int(x.shape[-1]), int(kernel.shape[-1])
-    fits = units > f_in and f_in % 4 == 0 and f_in <= 128 and units <= 256 and \
-        4 * (f_in * (-(-units // 128) * 128 + 8) + 2 * f_in * 65) + 576 <= 160 * 1024           # tfgx_aggregate_gemm_fits
-    if fits and inference_only:
-        # (A_hat x) W in ONE launch: the aggregate never visits HBM (inference: the op registers no gradient)
-        return ops.tfgx_aggregate_gemm(row_ptr=row_ptr, col=col, w=w_norm, x=x, self_coef=self_coef, kernel=kernel,
-                                       bias=empty if bias is None else bias, op=0, act=1 if activation_is_relu else 0)
+    fits = units > f_in and f_in % 4 == 0 and 4 <= f_in <= 128 and units <= 256      # tfgx_aggregate_gemm_fits (ABI 110)
+    if fits:
+        # (A_hat x) W in ONE launch; under a GradientTape the same launch also returns the aggregate (d/dkernel needs it)
+        out, _ = ops.tfgx_aggregate_gemm(row_ptr=row_ptr, col=col, w=w_norm, x=x, self_coef=self_coef, kernel=kernel,
+                                         bias=empty if bias is None else bias, op=0, act=1 if activation_is_relu else 0,
+                                         want_aggregate=not inference_only)
+        return out
     h = ops.tfgx_gemm_bias_act(x=x, kernel=kernel, bias=empty, act=0)            # gcn.py:272
     return ops.tfgx_segment_reduce(row_ptr=row_ptr, col=col, w=w_norm, x=h, self_coef=self_coef,
                                    bias=empty if bias is None else bias, op=0, act=1 if activation_is_relu else 0)

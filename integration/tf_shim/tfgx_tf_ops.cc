@@ -209,9 +209,10 @@ class TfgxGemmBiasActOp : public OpKernel {
 REGISTER_KERNEL_BUILDER(Name("TfgxGemmBiasAct").Device(DEVICE_GPU), TfgxGemmBiasActOp);
 
 // The aggregate-then-project layers in ONE launch (tfgx_aggregate_gemm_f32: GCN with units > F evaluated as (A_hat x) W,
-// nn/conv/gcn.py:272-288; the neighbour half of mean / sum GraphSAGE, nn/conv/graph_sage.py:34-58).  Inference only: its
-// gradient would need the [N, F] aggregate the fusion avoids writing, so tfgx_tf.py uses it outside a GradientTape and
-// falls back to TfgxSegmentReduce + TfgxGemmBiasAct when tfgx_aggregate_gemm_fits says no.
+// nn/conv/gcn.py:272-288; the neighbour half of mean / sum GraphSAGE, nn/conv/graph_sage.py:34-58).  want_aggregate = true
+// (under a GradientTape: d/dkernel = aggregate^T @ g) also returns the [N, F] aggregate — written by the same launch beside
+// the projection, which still reads it from LDS; false returns an empty second output.  tfgx_tf.py falls back to
+// TfgxSegmentReduce + TfgxGemmBiasAct when tfgx_aggregate_gemm_fits says no.
 REGISTER_OP("TfgxAggregateGemm")
     .Input("row_ptr: int32")
     .Input("col: int32")
@@ -222,13 +223,16 @@ REGISTER_OP("TfgxAggregateGemm")
     .Input("bias: float")       // [U] or [0]
     .Attr("op: int")            // 0 sum, 1 mean
     .Attr("act: int = 0")
-    .Output("out: float");      // [N, U]
+    .Attr("want_aggregate: bool = false")
+    .Output("out: float")       // [N, U]
+    .Output("aggregate: float");// [N, F] (want_aggregate) or [0]
 
 class TfgxAggregateGemmOp : public OpKernel {
  public:
   explicit TfgxAggregateGemmOp(OpKernelConstruction* c) : OpKernel(c) {
     OP_REQUIRES_OK(c, c->GetAttr("op", &op_));
     OP_REQUIRES_OK(c, c->GetAttr("act", &act_));
+    OP_REQUIRES_OK(c, c->GetAttr("want_aggregate", &want_agg_));
   }
   void Compute(OpKernelContext* ctx) override {
     const Tensor &rp = ctx->input(0), &col = ctx->input(1), &w = ctx->input(2), &x = ctx->input(3);
@@ -237,8 +241,10 @@ class TfgxAggregateGemmOp : public OpKernel {
     OP_REQUIRES(ctx, k.dim_size(0) == F, errors::InvalidArgument("x and kernel do not agree on F"));
     OP_REQUIRES(ctx, tfgx_aggregate_gemm_fits(F, U) == 1,
                 errors::InvalidArgument("shape outside tfgx_aggregate_gemm_fits: use TfgxSegmentReduce + TfgxGemmBiasAct"));
-    Tensor* out = nullptr;
+    Tensor *out = nullptr, *agg = nullptr;
     OP_REQUIRES_OK(ctx, ctx->allocate_output(0, {n, U}, &out));
+    if (want_agg_) OP_REQUIRES_OK(ctx, ctx->allocate_output(1, {n, F}, &agg));
+    else OP_REQUIRES_OK(ctx, ctx->allocate_output(1, {0}, &agg));
     tfgx_reduce_args a = {};
     a.row_begin = rp.flat<int32>().data();
     a.row_end = a.row_begin + 1;
@@ -251,12 +257,17 @@ class TfgxAggregateGemmOp : public OpKernel {
     a.F = F;
     a.op = op_;
     a.self_coef = sc.NumElements() ? sc.flat<float>().data() : nullptr;
+    if (want_agg_) {                                   // side output of the same launch (tfgx.h: args->out)
+      a.out = agg->flat<float>().data();
+      a.ldo = F;
+    }
     OP_REQUIRES(ctx, tfgx_aggregate_gemm_f32(&a, k.flat<float>().data(), U,
                                              bias.NumElements() ? bias.flat<float>().data() : nullptr, act_,
                                              out->flat<float>().data(), U, U, TfStream(ctx)) == 0,
                 errors::Internal(tfgx_last_error()));
   }
   int op_, act_;
+  bool want_agg_;
 };
 REGISTER_KERNEL_BUILDER(Name("TfgxAggregateGemm").Device(DEVICE_GPU), TfgxAggregateGemmOp);
 

@@ -89,13 +89,15 @@ def test_gcn_layer_through_the_shim_ops_matches_the_reference(tfg, tmp_path):
         s.op("TfgxSegmentReduce", ["row_ptr", "col", "wn%d" % i, "h", "sc%d" % i, "bias"], ["o%d" % i], op=0, act=1)
         s.save("o%d" % i)
     # units > F: the aggregate-then-project route in ONE op, and as two ops
-    s.op("TfgxAggregateGemm", ["row_ptr", "col", "wn0", "x", "sc0", "wide_kernel", "wide_bias"], ["wide_fused"], op=0, act=1)
+    s.op("TfgxAggregateGemm", ["row_ptr", "col", "wn0", "x", "sc0", "wide_kernel", "wide_bias"], ["wide_fused", "no_agg"], op=0, act=1)
+    s.op("TfgxAggregateGemm", ["row_ptr", "col", "wn0", "x", "sc0", "wide_kernel", "wide_bias"], ["wide_fused_t", "wide_agg"],
+         op=0, act=1, want_aggregate=True)                 # the training form: the aggregate as the second output
     s.op("TfgxSegmentReduce", ["row_ptr", "col", "wn0", "x", "sc0", "none"], ["agg"], op=0)
     s.op("TfgxGemmBiasAct", ["agg", "wide_kernel", "wide_bias"], ["wide_two"], act=1)
     s.op("TfgxSegmentReduce", ["row_ptr", "col", "wn0", "h", "sc0", "none"], ["plain"], op=0)      # no bias, no activation
     s.op("TfgxGcnNormEdges", ["row_ptr", "col", "none"], ["wn_u", "sc_u"])                          # unweighted graph (w = ones)
     s.op("TfgxSegmentReduce", ["row_ptr", "col", "wn_u", "h", "sc_u", "none"], ["unweighted"], op=0)
-    for name in ("wide_fused", "wide_two", "plain", "unweighted"):
+    for name in ("wide_fused", "wide_two", "plain", "unweighted", "wide_fused_t", "wide_agg", "agg", "no_agg"):
         s.save(name)
     s.save("row_ptr", np.int32)
     s.save("col", np.int32)
@@ -106,6 +108,8 @@ def test_gcn_layer_through_the_shim_ops_matches_the_reference(tfg, tmp_path):
         assert_parity(out["o%d" % i], golden[key], what="shim ops vs reference " + key)
     assert_parity(out["wide_fused"], golden["gcn::wide"], what="TfgxAggregateGemm vs reference gcn::wide")
     assert_parity(out["wide_two"], golden["gcn::wide"], what="TfgxSegmentReduce + TfgxGemmBiasAct vs reference gcn::wide")
+    assert np.array_equal(out["wide_fused_t"], out["wide_fused"]) and np.array_equal(out["wide_agg"], out["agg"])
+    assert out["no_agg"].size == 0 and out["wide_agg"].shape == (n, f)
     assert_parity(out["plain"], golden["gcn::no_bias_no_act"], what="shim ops vs reference gcn::no_bias_no_act")
     assert_parity(out["unweighted"], golden["gcn::unweighted"], what="shim ops vs reference gcn::unweighted")
     # the plan the op built: stable sort of the edges by destination, bit for bit
