@@ -392,21 +392,32 @@ __global__ __launch_bounds__(kFusedThreads) void agg_gemm_kernel(const FArgs a)
                     // 16-byte stores through a quad transpose of the accumulators (tfgx_mfma.h): 8 instead of 32 store
                     // instructions per job; lane i of a quad ends with row 8 g + i + 4 kh, columns 4 q .. 4 q + 3
                     const int qi = lane64 & 3, qc = (l31 >> 2) * 4;
+                    typedef float f32x4s __attribute__((ext_vector_type(4)));
+                    // destination rows of this lane's four register groups (g): natural order = ONE multiply + adds; walk
+                    // order = the ids the producers left in LDS (-1: past the end)
+                    int64_t roff[4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int slot = mb * 32 + 8 * g + qi + 4 * kh;
+                        const int64_t rr = a.row_order != nullptr ? int64_t(rowid[buf * kTileRows + slot]) : tile * kTileRows + slot;
+                        roff[g] = rr >= 0 ? rr * a.ldc : int64_t(-1);
+                    }
 #pragma unroll
                     for (int jb = 0; jb < JB; ++jb) {
+                        float r4[4][4];
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            float r4[4] = {c4[jb][4 * g], c4[jb][4 * g + 1], c4[jb][4 * g + 2], c4[jb][4 * g + 3]};
-                            quad_transpose4(r4, lane64);
-                            const int gn = (nb0 + jb) * 32 + qc;
-                            // walk order: the tile slot's destination row comes from the ids the producers left in LDS (-1: past the end)
-                            const int64_t rr = a.row_order != nullptr ? int64_t(rowid[buf * kTileRows + mb * 32 + 8 * g + qi + 4 * kh])
-                                                                      : tile * kTileRows + mb * 32 + 8 * g + qi + 4 * kh;
-                            if (gn < a.N && rr >= 0) {
-                                float* cp = a.C + rr * a.ldc + gn;
-                                typedef float f32x4s __attribute__((ext_vector_type(4)));
-                                __builtin_nontemporal_store(f32x4s{r4[0], r4[1], r4[2], r4[3]}, reinterpret_cast<f32x4s*>(cp));
-                            }
+                        for (int g = 0; g < 4; ++g) {          // (every lane takes part in the quad permutes)
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) r4[g][k] = c4[jb][4 * g + k];
+                            quad_transpose4(r4[g], lane64);
+                        }
+                        const int gn = (nb0 + jb) * 32 + qc;
+                        if (gn < a.N) {
+#pragma unroll
+                            for (int g = 0; g < 4; ++g)
+                                if (roff[g] >= 0)
+                                    __builtin_nontemporal_store(f32x4s{r4[g][0], r4[g][1], r4[g][2], r4[g][3]},
+                                                                reinterpret_cast<f32x4s*>(a.C + roff[g] + gn));
                         }
                     }
                     continue;

@@ -537,17 +537,22 @@ __global__ __launch_bounds__(rows_threads<TN>()) void gemm_rows_kernel(const flo
             // 16-byte stores: quad-transposed accumulators (see quad_transpose4).  Register group g = t >> 2 holds rows
             // 8 g + (t & 3) + 4 kh; after the transpose lane i of a quad owns row 8 g + i + 4 kh, columns 4 q .. 4 q + 3
             const int qi = lane & 3, qc = (l31 >> 2) * 4;
+            float* const cb = C + (tile * 32 + qi + 4 * kh) * ldc + qc;      // ONE 64-bit multiply per tile; the rest are adds
+            const int64_t ldc8 = 8 * ldc;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
+                float r4[4][4];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    float r4[4] = {acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
-                    quad_transpose4(r4, lane);
-                    const int gn = j * 32 + qc;
-                    if (gn < N) {                      // N % 4 == 0 on this path: the four columns are valid together
-                        float* cp = C + (tile * 32 + 8 * g + qi + 4 * kh) * ldc + gn;
-                        *reinterpret_cast<f32x4*>(cp) = f32x4{r4[0], r4[1], r4[2], r4[3]};
-                    }
+                for (int g = 0; g < 4; ++g) {                  // every lane takes part in the quad permutes (no branch around them)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) r4[g][k] = acc[j][4 * g + k];
+                    quad_transpose4(r4[g], lane);
+                }
+                if (j * 32 + qc < N) {                         // N % 4 == 0 on this path: the four columns are valid together
+                    float* cj = cb + j * 32;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        *reinterpret_cast<f32x4*>(cj + g * ldc8) = f32x4{r4[g][0], r4[g][1], r4[g][2], r4[g][3]};
                 }
             }
         } else
