@@ -138,3 +138,72 @@ def test_fuzz_gemm(tfg, oracle, seed):
         c = n if act_cols is None else act_cols
         ref[:, :c] = np.maximum(ref[:, :c], 0)
     assert_parity(got, ref.astype(np.float32), tol=2e-5, what="fuzz gemm seed {} {}x{}x{}".format(seed, m, k, n))
+
+
+@pytest.mark.parametrize("seed", range(32 * _SCALE))
+def test_fuzz_fused_aggregate_gemm(tfg, oracle, seed):
+    """tfgx_aggregate_gemm_f32 across its whole envelope, drawn at random: F in 4..128 (step 4), N in 1..256 (kernel fully or
+    partly resident in LDS), sum / mean, weights, self-loop term, bias / ReLU, output into a column block, the aggregate as a
+    side output, split source rows with and without the per-edge tail stream, forced hub chunking and the degree-ordered walk
+    — against the float64 restatement and, bit for bit, against its own launch on the dense table."""
+    from tf_geometric_amd import plan as P
+    L = tfg._lib
+    rng = np.random.Generator(np.random.PCG64(4000 + seed))
+    n = int(rng.integers(1, 1500))
+    e = int(rng.integers(0, 20000))
+    f = 4 * int(rng.integers(1, 33))
+    units = int(rng.choice([1, 7, 16, 40, 64, 65, 100, 128, 129, 192, 200, 256]))
+    ei = _random_graph(rng, n, e)
+    x = rng.standard_normal((n, f)).astype(np.float32)
+    k = (rng.standard_normal((f, units)) / np.sqrt(f)).astype(np.float32)
+    mean = rng.random() < 0.4
+    weighted = rng.random() < 0.6
+    w = rng.uniform(-1.5, 1.5, size=e).astype(np.float32) if weighted else None
+    sc = rng.uniform(0.1, 1.0, size=n).astype(np.float32) if (rng.random() < 0.5 and not mean) else None
+    bias = rng.standard_normal(units).astype(np.float32) if rng.random() < 0.5 else None
+    act = int(rng.integers(0, 2))
+    hub = rng.random() < 0.4
+    if hub:
+        P.HUB_THRESHOLD, P.HUB_CHUNK = int(rng.choice([8, 32, 100])), int(rng.choice([8, 16, 64]))
+    try:
+        plan = P.CsrPlan.build(L.as_i32(ei), n, n)
+        xd, kd = L.as_f32(x), L.as_f32(k)
+        w_csr = None if w is None else plan.edge_attr_to_csr(w)
+        scd = None if sc is None else L.as_f32(sc)
+        bd = None if bias is None else L.as_f32(bias)
+        op = L.MEAN if mean else L.SUM
+        assert L.require_gpu().tfgx_aggregate_gemm_fits(f, units) == 1
+        side = torch.full((n, f), float("nan"), device="cuda")
+        wide = torch.full((n, units + 3), 5.0, device="cuda")
+        got = P.aggregate_gemm(plan, xd, op, kd, w_csr=w_csr, self_coef=scd, bias=bd, act=act, out=wide[:, 3:], agg_out=side)
+        assert got is not None and bool((wide[:, :3] == 5.0).all())
+        got = got.clone()
+        # float64 restatement
+        msg = x[ei[1]].astype(np.float64) * (w[:, None] if w is not None else 1.0)
+        agg = np.zeros((n, f))
+        np.add.at(agg, ei[0], msg)
+        if sc is not None:
+            agg += sc[:, None].astype(np.float64) * x
+        if mean:
+            agg /= np.maximum(np.bincount(ei[0], minlength=n), 1)[:, None]
+        ref = agg @ k.astype(np.float64)
+        if bias is not None:
+            ref = ref + bias
+        if act:
+            ref = np.maximum(ref, 0)
+        scale = max(1.0, float(np.abs(msg).sum(0).max()) if e else 1.0)
+        tol = 2e-5 * scale ** 0.5
+        what = "fuzz fused seed {} n={} e={} f={} units={} mean={} hub={}".format(seed, n, e, f, units, mean, hub)
+        assert_parity(side.cpu().numpy(), agg.astype(np.float32), tol=tol, what=what + " (side output)")
+        assert_parity(got.cpu().numpy(), ref.astype(np.float32), tol=tol * max(1.0, float(np.abs(k).sum(0).max())), what=what)
+        # the aggregate written beside the projection = the bits of the stand-alone kernel
+        assert torch.equal(side, P.segment_reduce(plan, xd, op, w_csr=w_csr, self_coef=scd))
+        # split source rows (static layout), then with the per-edge tail stream: bit-identical
+        if f > 32 and f % 32:
+            rows = P.SplitRows.from_dense(xd)
+            assert torch.equal(P.aggregate_gemm(plan, rows, op, kd, w_csr=w_csr, self_coef=scd, bias=bd, act=act), got), what
+            if e:
+                rows.with_edge_tail(plan)
+                assert torch.equal(P.aggregate_gemm(plan, rows, op, kd, w_csr=w_csr, self_coef=scd, bias=bd, act=act), got), what
+    finally:
+        P.HUB_THRESHOLD, P.HUB_CHUNK = None, None

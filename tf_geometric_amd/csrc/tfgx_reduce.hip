@@ -525,8 +525,9 @@ __global__ __launch_bounds__(kBlock) void hub_finalize_kernel(const HubArgs h)
             // split source rows: columns >= f_main of a NODE's row live in x_tail (ldx is then f_main-wide)
             const float xv = (a.x_tail != nullptr && j >= a.f_main) ? a.x_tail[r * a.ld_tail + (j - a.f_main)]
                                                                     : a.x[r * a.ldx + j];
-            const float sv = a.self_coef[r] * xv;
-            res = is_max ? fmaxf(res, sv) : res + sv;
+            // sum / mean: ONE fused multiply-add, like the implicit edge of a row that is walked whole (and like the fused
+            // launch's fold of a hub row) — a hub row's bits do not depend on which launch reduced it
+            res = is_max ? fmaxf(res, a.self_coef[r] * xv) : fmaf(a.self_coef[r], xv, res);
         }
         if (a.op == TFGX_MEAN) {
             const int cnt = a.mean_count ? a.mean_count[r]
