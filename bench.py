@@ -431,7 +431,8 @@ def main():
         "config": {"workload": "{}-shaped GCN propagation A_hat@h (weighted segment-sum + implicit self-loops): "
                                "N={} E={} F={}".format(args.workload, n, e, f),
                    "nodes": n, "edges": e, "features": f, "edges_aggregated": e_agg,
-                   "partition": "single GPU" if world == 1 else "dst-range x{} + RCCL halo all-to-all-v".format(world)},
+                   "partition": "single GPU" if world == 1 else
+                                "dst-range x{} + {} halo all-to-all-v".format(world, "HOST-STAGED (plumbing check)" if plumbing else "RCCL")},
         "plan_build_s": plan_s,
         "plan_build_s_is": ("first CSR plan + GCN normalisation of this process on device-resident edges: includes code-object "
                             "loads and first allocations (host perf_counter around a synchronize); inputs generated in "
