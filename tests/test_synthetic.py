@@ -31,3 +31,30 @@ def test_feature_rows_are_the_same_matrix_from_any_row_range():
     for lo, hi in ((0, 10), (S.ROW_BLOCK - 3, S.ROW_BLOCK + 3), (2 * S.ROW_BLOCK, n), (n - 1, n), (7, 7)):
         assert np.array_equal(S.synthetic_feature_rows(n, f, seed=9, row_lo=lo, row_hi=hi), x[lo:hi])
     assert abs(float(x.mean())) < 0.01 and abs(float(x.std()) - 1.0) < 0.01
+
+
+def test_bench_plain_command_builds_its_own_launcher_line(monkeypatch):
+    """`python3 bench.py --gpus N` without a launcher around it re-executes itself under torch.distributed.run on the loopback
+    interface with its own arguments (no GPU needed to check the command line)."""
+    import os
+    import sys
+    import bench
+    seen = {}
+
+    def fake_execv(exe, argv):
+        seen["exe"], seen["argv"] = exe, list(argv)
+        raise SystemExit(0)
+
+    monkeypatch.setattr(os, "execv", fake_execv)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7", "--warmup", "2"])
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    try:
+        bench.main()
+    except SystemExit:
+        pass
+    a = seen["argv"]
+    assert seen["exe"] == sys.executable and a[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nnodes=1" in a and a[a.index("--nproc-per-node") + 1] == "4" and a[a.index("--master-addr") + 1] == "127.0.0.1"
+    assert 1024 < int(a[a.index("--master-port") + 1]) < 65536
+    assert a[-6:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"] and a[-7].endswith("bench.py")
