@@ -46,8 +46,8 @@ enum { TFGX_NORM_BOTH = 0, TFGX_NORM_LEFT = 1, TFGX_NORM_RIGHT = 2 };
 /* ABI version of this header: bumped whenever an entry point's signature or a struct's layout changes (a host built
  * against another value must refuse to run: tf_geometric_amd/_lib.py does).  100 = rounds 1-3; 110 = round 4
  * (tfgx_reduce_args.hub_order_slot; tfgx_aggregate_gemm_f32 honours args->out as a side output of the aggregate;
- * tfgx_gat_args / tfgx_gat_backward_args .drop_seed_dev). */
-#define TFGX_ABI_VERSION 110
+ * tfgx_gat_args / tfgx_gat_backward_args .drop_seed_dev); 111 = + tfgx_column_sum_f32. */
+#define TFGX_ABI_VERSION 111
 int tfgx_version(void);            /* the TFGX_ABI_VERSION the library was built with */
 const char* tfgx_last_error(void); /* host string, thread-local, valid until the next failing call */
 
@@ -547,6 +547,12 @@ int tfgx_gather_rows_f32(const float* x, int64_t ldx, const int32_t* idx, int64_
    tfgx_segment_reduce_f32 epilogues (tf.nn.relu under a GradientTape, demo/demo_gcn.py:68-77).  gout may alias g. */
 int tfgx_relu_backward_f32(const float* g, int64_t ldg, const float* out, int64_t ldo, int64_t M, int64_t N,
                            float* gout, int64_t ldgo, tfgx_stream_t stream);
+/* out[c] = sum_m g[m, c] (g [M, N], row stride ldg): the bias gradient where the bias rode in an aggregation epilogue
+   (tf.GradientTape's reduce_sum over the node axis, demo/demo_gcn.py:68-77).  Deterministic (fixed two-phase order).
+   workspace: tfgx_column_sum_workspace_bytes(M, N) bytes of device scratch. */
+size_t tfgx_column_sum_workspace_bytes(int64_t M, int64_t N);
+int tfgx_column_sum_f32(const float* g, int64_t ldg, int64_t M, int64_t N, float* out, void* workspace,
+                        size_t workspace_bytes, tfgx_stream_t stream);
 /* dst[idx[i], :] += src[i, :] for i in [0, M): owner-side accumulate of the reverse halo exchange (gradients of halo rows
    returning to their owners during training).  idx must hold UNIQUE ids within one call (one peer's request list does);
    peers are applied by the caller in a fixed order, so the sum is deterministic without atomics.  idx == NULL: the

@@ -890,3 +890,19 @@ def test_training_on_the_promoted_static_layout_gives_the_same_bits(tfg, oracle,
     assert torch.equal(o1, o2)
     for a, b in zip(g1, g2):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("m,n", [(1, 1), (5, 47), (70001, 47), (300000, 41), (4099, 256), (100003, 7), (2500, 1030), (0, 9)])
+def test_column_sums_kernel(tfg, m, n):
+    """tfgx_column_sum_f32 (the bias gradient where the bias rode in an aggregation epilogue) vs float64; strided input;
+    deterministic.  Odd widths are the point: torch's g.sum(0) runs a [2.4 M, 47] gradient at 24 GB/s."""
+    from tf_geometric_amd.plan import column_sums
+    g = torch.Generator(device="cuda")
+    g.manual_seed(m + n)
+    wide = torch.randn(m, n + 3, generator=g, device="cuda")
+    x = wide[:, 1:n + 1]                                      # row stride n + 3
+    got = column_sums(x)
+    assert got.shape == (n,) and torch.equal(got, column_sums(x))
+    ref = x.double().sum(0)
+    scale = max(1.0, float(m) ** 0.5)
+    assert float((got.double() - ref).abs().max()) <= 2e-6 * scale * max(1.0, float(x.abs().max()) if m else 1.0)

@@ -26,7 +26,7 @@ class TfgxError(RuntimeError):
     pass
 
 
-ABI_VERSION = 110      # include/tfgx.h TFGX_ABI_VERSION: struct layouts / signatures bound below
+ABI_VERSION = 111      # include/tfgx.h TFGX_ABI_VERSION: struct layouts / signatures bound below
 
 
 class ReduceArgs(ctypes.Structure):
@@ -136,6 +136,8 @@ class GatBackwardArgs(ctypes.Structure):
 _I64, _I32, _F32, _P, _SZ = ctypes.c_int64, ctypes.c_int32, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
 SIGNATURES = {
     "tfgx_version": (ctypes.c_int, []),
+    "tfgx_column_sum_workspace_bytes": (_SZ, [_I64, _I64]),
+    "tfgx_column_sum_f32": (ctypes.c_int, [_P, _I64, _I64, _I64, _P, _P, _SZ, _P]),
     "tfgx_last_error": (ctypes.c_char_p, []),
     "tfgx_csr_plan_workspace_bytes": (_SZ, [_I64, _I64]),
     "tfgx_build_csr_by_dst": (ctypes.c_int, [_P, _P, _I64, _I64, _I64, _P, _P, _P, _P, _SZ, _P]),

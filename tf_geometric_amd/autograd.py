@@ -25,7 +25,7 @@ import torch
 
 from . import _lib as L
 from .plan import (segment_reduce, can_track, gemm_bias_act, gemm_tn, transpose, SplitRows, gather_friendly_empty,
-                   gather_friendly_copy, aggregate_gemm, aggregate_gemm_applies)
+                   gather_friendly_copy, aggregate_gemm, aggregate_gemm_applies, column_sums)
 
 
 def needs_grad(*tensors):
@@ -127,7 +127,7 @@ class _Aggregate(torch.autograd.Function):
         plan = ctx.plan
         x, w_csr, self_coef, bias, out = ctx.saved_tensors
         g = relu_backward(g, out) if ctx.act == L.ACT_RELU else g.contiguous()
-        gb = g.sum(0) if (bias is not None and ctx.needs_input_grad[6]) else None
+        gb = column_sums(g) if (bias is not None and ctx.needs_input_grad[6]) else None
         gx, gw, gs = _aggregate_backward(plan, ctx.mean, x, w_csr, self_coef, g, ctx.needs_input_grad[2],
                                          ctx.needs_input_grad[3], ctx.needs_input_grad[4])
         return None, None, gx, gw, gs, None, gb, None
@@ -191,7 +191,7 @@ class _AggregateProject(torch.autograd.Function):
                 if not need[5]:
                     gk = None
             else:
-                gb = g.sum(0)
+                gb = column_sums(g)
         gx = gw = gs = None
         if need[2] or need[3] or need[4]:
             g_agg = gemm_bias_act(g, transpose(kernel.detach()))          # d/d(aggregate) = g @ kernel^T
@@ -245,7 +245,7 @@ class _SageWide(torch.autograd.Function):
                 if not need[4]:
                     gkn = None
             else:
-                gbb = gn.sum(0)
+                gbb = column_sums(gn)
         if need[2]:
             g_agg = gemm_bias_act(gn, transpose(kn.detach()))
             gx2, _, _ = _aggregate_backward(plan, ctx.mean, x, w_csr, None, g_agg, True, False, False)
@@ -518,7 +518,7 @@ class _SageNarrow(torch.autograd.Function):
         else:
             D[:, :na] = g[:, :na]
             gn.copy_(g[:, na:])
-        gbb = gn.sum(0) if want_b else None
+        gbb = column_sums(gn) if want_b else None
         if ctx.mean:
             gn.div_(plan.in_degree().clamp(min=1).to(gn.dtype).unsqueeze(1))
         pt, t2d = _transposed(plan)

@@ -744,6 +744,19 @@ def gemm_tn(x, g, want_bias=False, gate=None):
     return dW, db
 
 
+def column_sums(g):
+    """g.sum(0) of a [M, N] float32 matrix on the two-phase kernel (tfgx_column_sum_f32): deterministic, and at HBM rate for
+    every width (torch's reduction runs a [2.4 M, 47] gradient — ogbn-products' 47 classes — at 24 GB/s: 18.7 ms per step)."""
+    lib = L.require_gpu()
+    g2, ldg = L.row_major_2d(L.as_f32(g))
+    M, N = int(g2.shape[0]), int(g2.shape[1])
+    out = torch.empty(N, dtype=torch.float32, device=g2.device)
+    ws_bytes = lib.tfgx_column_sum_workspace_bytes(M, N)
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=g2.device)
+    L.check(lib.tfgx_column_sum_f32(L.ptr(g2), ldg, M, N, L.ptr(out), L.ptr(ws), ws_bytes, L.stream_ptr()), "tfgx_column_sum_f32")
+    return out
+
+
 def transpose(a):
     """a^T as a new row-major tensor (tfgx_transpose_f32)."""
     lib = L.require_gpu()
