@@ -306,6 +306,15 @@ def edge_balanced_bounds(row_ptr_host, world):
 _DEBUG_CHECKS = os.environ.get("TFGX_DIST_DEBUG_CHECKS", "0") != "0"     # extra consistency checks that synchronise
 
 
+def _bias_add(out, bias):
+    """out + bias of the trainable layers: on the GPU the bias gradient is the column-sum kernel, not torch's g.sum(0)
+    (autograd.bias_add); CPU tensors of the numpy test backend take the plain add."""
+    if out.is_cuda:
+        from .. import autograd as AG
+        return AG.bias_add(out, bias)
+    return out + bias
+
+
 class ShardedGraph(object):
     """One rank's shard: destination rows [own_lo, own_hi) of a global graph, plus its halo plan."""
 
@@ -826,7 +835,7 @@ class ShardedGraph(object):
         out = be.gat_attention_autograd(self, Q, table[:, :A], table[:, A:], num_heads,      # ... and the own-source span
                                         handles=self.pop_deferred_exchange())
         if bias is not None:
-            out = out + bias
+            out = _bias_add(out, bias)
         return activation(out) if activation is not None else out
 
     def pool_graph_sage_trainable(self, x_own, self_kernel, neighbor_mlp_kernel, neighbor_kernel, neighbor_mlp_bias=None,
@@ -841,7 +850,7 @@ class ShardedGraph(object):
             b = self.aggregate_trainable(be.linear(h, neighbor_kernel), op, w=None)
             out = torch.cat([a, b], 1) if concat else a + b
             if bias is not None:
-                out = out + bias
+                out = _bias_add(out, bias)
             return torch.relu(out) if act == L.ACT_RELU else out
         if op in (L.SUM, L.MEAN):
             a = be.linear(x_own, self_kernel)
@@ -854,7 +863,7 @@ class ShardedGraph(object):
         b = be.linear(reduced, neighbor_kernel)
         out = torch.cat([a, b], 1) if concat else a + b
         if bias is not None:
-            out = out + bias
+            out = _bias_add(out, bias)
         return torch.relu(out) if act == L.ACT_RELU else out
 
     def gcn_trainable(self, x_own, kernel, bias=None, activation=None):
@@ -866,7 +875,7 @@ class ShardedGraph(object):
         h = x_own if kernel is None else self.backend.linear(x_own, kernel)
         out = self.aggregate_trainable(h, L.SUM, w=self.norm_w, self_coef=self.self_coef)
         if bias is not None:
-            out = out + bias
+            out = _bias_add(out, bias)
         return activation(out) if activation is not None else out
 
     def all_reduce_gradients(self, params):

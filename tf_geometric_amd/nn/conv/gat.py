@@ -232,7 +232,7 @@ def _gat_train(x, plan, wq, bq, qact, wk, bk, kact, kernel, bias, activation, nu
         U = int(V.shape[1]) // num_heads
         h = h.view(h.shape[0], num_heads, U).sum(1) / num_heads
     if bias is not None:
-        h = h + L.as_f32(bias)
+        h = AG.bias_add(h, bias)
     code, post = _resolve_act(activation)
     return AG.apply_activation(h, code, post)
 

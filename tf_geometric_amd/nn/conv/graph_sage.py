@@ -34,7 +34,7 @@ def _combine(from_x_kernel, x, from_neigh_kernel, reduced, bias, activation, con
         else:
             h = AG.linear(x, from_x_kernel) + AG.linear(reduced, from_neigh_kernel)
             if bias is not None:
-                h = h + L.as_f32(bias)
+                h = AG.bias_add(h, bias)
             h = AG.apply_activation(h, act, post)
         if normalize:
             h = h * torch.rsqrt(torch.clamp((h * h).sum(-1, keepdim=True), min=1e-12))
@@ -159,7 +159,7 @@ def _self_neighbor_sage(x, edge_index, edge_weight, self_kernel, neighbor_kernel
         else:
             h = AG.linear(x, ws) + AG.aggregate(plan, AG.linear(x, wn, gathered=True), op, w_csr)
             if bias is not None:
-                h = h + L.as_f32(bias)
+                h = AG.bias_add(h, bias)
             h = AG.apply_activation(h, act, post)
         if normalize:
             h = h * torch.rsqrt(torch.clamp((h * h).sum(-1, keepdim=True), min=1e-12))

@@ -56,7 +56,7 @@ def _finish(h, bias, activation):
     break .view(-1), DLPack and any consumer assuming ld == F)."""
     act, post = _resolve_act(activation)
     if bias is not None:
-        h = h + L.as_f32(bias)
+        h = AG.bias_add(h, bias)
     h = AG.apply_activation(h, act, post)
     return h if h.is_contiguous() else h.contiguous()
 
