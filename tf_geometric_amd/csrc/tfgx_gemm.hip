@@ -301,30 +301,47 @@ __global__ __launch_bounds__(kBlock) void gemm_kernel(const float* __restrict__ 
 // NG consecutive MFMA groups of gemm_rows_kernel (one group = one k pair x TN accumulators; a full step is 16 groups),
 // B operands read from LDS one group ahead.  The sched_barriers pin that order: left alone, the scheduler sinks every
 // ds_read next to its MFMA (fewest live registers), which puts a full LDS round trip in front of each group.
+#ifndef TFGX_ROWS_LDS_AHEAD
+#define TFGX_ROWS_LDS_AHEAD 1      // developer A/B: how many MFMA groups ahead the B operands are read from LDS (1 or 2)
+#endif
 template <int TN, int NG>
 __device__ __forceinline__ void rows_mfma_groups(f32x16 (&acc)[TN], const float* a, const float* b_s)
 {
     constexpr int LDB_S = TN * 32 + 8;
-    float bb[2][TN];
+    constexpr int AH = TFGX_ROWS_LDS_AHEAD, NB = AH + 1;
+    float bb[NB][TN];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) bb[0][j] = b_s[j * 32];
+    for (int p = 0; p < AH; ++p)
+        if (p < NG) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bb[p][j] = b_s[p * LDB_S + j * 32];
+        }
 #pragma unroll
     for (int i = 0; i < NG; ++i) {
-        if (i + 1 < NG) {
+        if (i + AH < NG) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bb[(i + 1) & 1][j] = b_s[(i + 1) * LDB_S + j * 32];
+            for (int j = 0; j < TN; ++j) bb[(i + AH) % NB][j] = b_s[(i + AH) * LDB_S + j * 32];
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[i & 1][j], acc[j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[i % NB][j], acc[j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     }
 }
 
 // threads per workgroup: 8 waves, 2 per SIMD, <= 256 registers each (TN = 8 needs 218).  12 waves for the TN <= 4
 // kernels (< 170 registers) measured 2 % slower than 8.
+#ifndef TFGX_ROWS_THREADS_NARROW
+#define TFGX_ROWS_THREADS_NARROW 512   // developer A/B: workgroup size of the TN <= 4 kernels
+#endif
 template <int TN>
-constexpr int rows_threads() { return 512; }
+#ifndef TFGX_ROWS_THREADS_WIDE
+#define TFGX_ROWS_THREADS_WIDE 512
+#endif
+#ifndef TFGX_ROWS_PRIO
+#define TFGX_ROWS_PRIO 0               // developer A/B: 1 = the second wave of each SIMD yields the MFMA port (static s_setprio)
+#endif
+constexpr int rows_threads() { return TN <= 4 ? TFGX_ROWS_THREADS_NARROW : TFGX_ROWS_THREADS_WIDE; }
 
 template <int TN>
 __global__ __launch_bounds__(rows_threads<TN>()) void gemm_rows_kernel(const float* __restrict__ A, int64_t lda,
@@ -393,7 +410,13 @@ __global__ __launch_bounds__(rows_threads<TN>()) void gemm_rows_kernel(const flo
     // values that are never stored; the tail step accounts for its own clamped vector.
     typedef float f32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
     const int half_t = (K - nfull * 32) >> 1;
+#ifndef TFGX_ROWS_PF2
+#define TFGX_ROWS_PF2 0                // developer A/B: A rows prefetched two steps ahead instead of one
+#endif
     float cur[16], nxt[16];
+#if TFGX_ROWS_PF2
+    float nx2[16];
+#endif
     auto load_a = [&](float (&r)[16], int64_t t, int ks) {
         const int64_t gm = min(t * 32 + l31, M - 1);
         const int kb = ks * 32 + (ks < nfull ? 16 : half_t) * kh;
@@ -426,9 +449,27 @@ __global__ __launch_bounds__(rows_threads<TN>()) void gemm_rows_kernel(const flo
     };
     zero_acc();
     // branch-free on purpose (see load_a): past the last tile the row clamp turns this into a harmless re-read
-    auto prefetch = [&](int64_t t, int ks) {
+    auto adv = [&](int64_t& t, int& ks) {
         const bool same = ks + 1 < nsteps;
-        load_a(nxt, same ? t : t + stride, same ? ks + 1 : 0);
+        t = same ? t : t + stride;
+        ks = same ? ks + 1 : 0;
+    };
+    auto prefetch = [&](int64_t t, int ks) {
+        adv(t, ks);
+#if TFGX_ROWS_PF2
+        adv(t, ks);
+        load_a(nx2, t, ks);
+#else
+        load_a(nxt, t, ks);
+#endif
+    };
+    auto rotate = [&]() {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) cur[i] = nxt[i];
+#if TFGX_ROWS_PF2
+#pragma unroll
+        for (int i = 0; i < 16; ++i) nxt[i] = nx2[i];
+#endif
     };
 
 #if TFGX_ROWS_VEC_STORE
@@ -442,6 +483,9 @@ __global__ __launch_bounds__(rows_threads<TN>()) void gemm_rows_kernel(const flo
     for (int j = 0; j < TN; ++j) bv[j] = (bias && j * 32 + l31 < N) ? bias[j * 32 + l31] : 0.0f;
 
     int64_t tile = int64_t(blockIdx.x) * (NT / 64) + wave;
+#if TFGX_ROWS_PRIO == 1
+    if (wave < 4) __builtin_amdgcn_s_setprio(1);
+#endif
 #if TFGX_ROWS_STAGGER
     // The two waves of a SIMD (wave w and w + 4) would otherwise run in lock step — every wave of the chip multiplies a tile,
     // then every wave stores one: a write burst the MFMA pipes idle through (measured: the same kernel without its stores
@@ -453,6 +497,14 @@ __global__ __launch_bounds__(rows_threads<TN>()) void gemm_rows_kernel(const flo
     }
 #endif
     if (tile < n_tiles) load_a(cur, tile, 0);
+#if TFGX_ROWS_PF2
+    if (tile < n_tiles) {
+        int64_t t1 = tile;
+        int k1 = 0;
+        adv(t1, k1);
+        load_a(nxt, t1, k1);
+    }
+#endif
     // Consume the first A registers here so their wait sits in front of the loop.  Otherwise every step carries a
     // "first iteration" vmcnt wait; harmless in steady state (only the 4 prefetch loads are in flight), but right after an
     // epilogue the 16 * TN stores are in flight too and that wait stalls the wave until they have drained.
@@ -473,8 +525,7 @@ __global__ __launch_bounds__(rows_threads<TN>()) void gemm_rows_kernel(const flo
         for (int ks = 0; ks < nfull; ++ks) {
             prefetch(tile, ks);
             rows_mfma_groups<TN, 16>(acc, cur, Bs + (ks * 32 + 16 * kh) * LDB_S + l31);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) cur[i] = nxt[i];
+            rotate();
             if (kTwoLevel) {
                 if (two_level && (ks & 1)) {
 #pragma unroll
@@ -505,8 +556,7 @@ __global__ __launch_bounds__(rows_threads<TN>()) void gemm_rows_kernel(const flo
                     rows_mfma_groups<TN, 2>(acc, a, b_s + 2 * q * LDB_S);
                 }
             }
-#pragma unroll
-            for (int i = 0; i < 16; ++i) cur[i] = nxt[i];
+            rotate();
         }
         if (kTwoLevel) {
             if (two_level) {
