@@ -334,13 +334,13 @@ __device__ __forceinline__ void rows_mfma_groups(f32x16 (&acc)[TN], const float*
 #ifndef TFGX_ROWS_THREADS_NARROW
 #define TFGX_ROWS_THREADS_NARROW 512   // developer A/B: workgroup size of the TN <= 4 kernels
 #endif
-template <int TN>
 #ifndef TFGX_ROWS_THREADS_WIDE
 #define TFGX_ROWS_THREADS_WIDE 512
 #endif
 #ifndef TFGX_ROWS_PRIO
-#define TFGX_ROWS_PRIO 0               // developer A/B: 1 = the second wave of each SIMD yields the MFMA port (static s_setprio)
+#define TFGX_ROWS_PRIO 0               // developer A/B: 1 = the first wave of each SIMD holds the MFMA port (static s_setprio)
 #endif
+template <int TN>
 constexpr int rows_threads() { return TN <= 4 ? TFGX_ROWS_THREADS_NARROW : TFGX_ROWS_THREADS_WIDE; }
 
 template <int TN>
