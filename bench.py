@@ -400,18 +400,30 @@ def main():
         import torch.distributed as dist
         wall = max_over_ranks(wall)
         ev_ms = max_over_ranks(ev_ms)
-        diag = shard_diagnostics(sg, table, out, f, L, dist, max(3, min(args.steps, 10)))
+        # everything below is commentary beside the headline: a failure in it (the same code on every rank, so the same
+        # failure on every rank) is reported inside the line instead of costing the run its number
+        diag, static_shard = None, None
+        try:
+            diag = shard_diagnostics(sg, table, out, f, L, dist, max(3, min(args.steps, 10)))
+        except Exception as ex:                                         # noqa: BLE001
+            static_shard = {"error": "shard_diagnostics: {!r}".format(ex)}
         # beside the headline (which exchanges the halo every step, as any hidden layer must): layer 0 with its input
         # features declared static — halo exchanged once, shard table in the edge-resident-tail layout, no exchange per step
-        st = sg.prepare_static_features(sg.own_rows(table))
-        dist.barrier()
-        ms_static = max_over_ranks(_event_time(
-            lambda: sg.aggregate_static(st, L.SUM, w=sg.norm_w, self_coef=sg.self_coef, out=out), max(3, min(args.steps, 10)), 2))
-        static_shard = {"what": "layer 0 after ShardedGraph.prepare_static_features: halo exchanged once, no exchange per "
-                                "step, shard table in the static layout where the width calls for it",
-                        "step_ms_max_over_ranks": ms_static, "edges_per_s": e / (ms_static * 1e-3),
-                        "bytes_rank0": int(st["bytes"]), "layout_rank0": "edge_tail" if st["split"] is not None else "dense"}
-        del st
+        if diag is not None:
+            try:
+                st = sg.prepare_static_features(sg.own_rows(table))
+                dist.barrier()
+                ms_static = max_over_ranks(_event_time(
+                    lambda: sg.aggregate_static(st, L.SUM, w=sg.norm_w, self_coef=sg.self_coef, out=out),
+                    max(3, min(args.steps, 10)), 2))
+                static_shard = {"what": "layer 0 after ShardedGraph.prepare_static_features: halo exchanged once, no exchange "
+                                        "per step, shard table in the static layout where the width calls for it",
+                                "step_ms_max_over_ranks": ms_static, "edges_per_s": e / (ms_static * 1e-3),
+                                "bytes_rank0": int(st["bytes"]),
+                                "layout_rank0": "edge_tail" if st["split"] is not None else "dense"}
+                del st
+            except Exception as ex:                                     # noqa: BLE001
+                static_shard = {"error": "static feature layout: {!r}".format(ex)}
 
     ms_per_step = wall * 1e3 / args.steps
     e_agg = e + n
@@ -465,9 +477,11 @@ def main():
         # whole job: algorithmic bytes of the full graph over the step time (exchange included) vs N x 8 TB/s
         bytes_alg = b_alg(e_agg, n, f, weighted=True)
         achieved = bytes_alg / (ms_per_step * 1e-3)
-        slow = max(diag, key=lambda d: d["exchange_ms"] + d["local_pass_ms"] + d["halo_pass_ms"])
-        serial = slow["exchange_ms"] + slow["local_pass_ms"] + slow["halo_pass_ms"]
-        hideable = min(slow["exchange_ms"], slow["local_pass_ms"] + slow["halo_pass_ms"])
+        serial, hideable = 0.0, 0.0
+        if diag:
+            slow = max(diag, key=lambda d: d["exchange_ms"] + d["local_pass_ms"] + d["halo_pass_ms"])
+            serial = slow["exchange_ms"] + slow["local_pass_ms"] + slow["halo_pass_ms"]
+            hideable = min(slow["exchange_ms"], slow["local_pass_ms"] + slow["halo_pass_ms"])
         line["roofline"] = {"bound": "hbm", "kernel": "seg_reduce_kernel (local-source pass + {} halo-round passes) "
                                                       "+ RCCL all-to-all-v in {} rounds".format(sg.rounds, sg.rounds),
                             "achieved": achieved / 1e9, "peak": world * HBM_PEAK / 1e9, "unit": "GB/s",
