@@ -85,6 +85,8 @@ def relu_backward(g, out, into=None):
     assert r2 is res, "relu_backward: `into` must have dense rows"
     L.check(lib.tfgx_relu_backward_f32(L.ptr(g2), ldg, L.ptr(o2), ldo, M, N, L.ptr(res), ldr, L.stream_ptr()),
             "tfgx_relu_backward_f32")
+    if into is not None:
+        torch.autograd.graph.increment_version(into)
     return res
 
 

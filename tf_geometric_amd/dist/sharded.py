@@ -568,7 +568,10 @@ class ShardedGraph(object):
         exchange_finish().  Product path (transport "tfgx_dist"): per round one pack launch for the packed peers on the
         compute stream, then grouped ncclSend / ncclRecv on the transport's communication stream — asynchronous, so the
         passes launched on the current stream afterwards overlap the transfer, round 0 completing first."""
-        return self.transport.exchange_start(self, table)
+        handles = self.transport.exchange_start(self, table)
+        if isinstance(table, torch.Tensor) and not table.requires_grad:
+            torch.autograd.graph.increment_version(table)      # halo rows arrive through raw pointers (RCCL / pack kernels)
+        return handles
 
     def exchange_finish(self, handles, j=None):
         """Make the current stream wait for round j (None: all rounds)."""

@@ -23,9 +23,13 @@ class CapturedForward(object):
         L.require_gpu()
         self.static_inputs = [L.as_f32(t).clone() if isinstance(t, torch.Tensor) or hasattr(t, "shape") else t
                               for t in example_inputs]
+        from .plan import no_auto_promotion
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side), torch.no_grad():
+        # the static input buffers are rewritten before every replay: the warm-up's repeated calls on them must not be read as
+        # "the same features again" (plan.static_rows' automatic promotion); tensors `fn` closes over are covered by the rule
+        # that a captured sequence only ever uses a layout the caller DECLARED (prepare_static_features)
+        with torch.cuda.stream(side), torch.no_grad(), no_auto_promotion():
             for _ in range(warmup):                # builds / fetches cached plans, sizes the allocator pools
                 fn(*self.static_inputs)
         torch.cuda.current_stream().wait_stream(side)

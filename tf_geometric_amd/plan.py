@@ -370,6 +370,31 @@ CACHE_KEY_STATIC_AUTO = "tfgx_static_auto"        # True while the opt-in in thi
 _AGG_LAUNCHES = [0]                                # aggregation launches so far (segment_reduce / aggregate_gemm)
 
 
+_AUTO_SUPPRESSED = [0]                             # > 0 inside no_auto_promotion()
+
+
+class no_auto_promotion(object):
+    """Context: no tensor is promoted while it is active (CapturedForward's warm-up: its static INPUT buffers are rewritten
+    before every replay — the opposite of static features)."""
+
+    def __enter__(self):
+        _AUTO_SUPPRESSED[0] += 1
+        return self
+
+    def __exit__(self, *exc):
+        _AUTO_SUPPRESSED[0] -= 1
+        return False
+
+
+def written_by_kernel(t):
+    """Tell torch that a launch of this library wrote into `t` through its raw pointer (a caller-provided `out=`): bumps the
+    tensor's version counter, which every contents-keyed memo here (static layout, CSR-ordered edge weights, transposed
+    weights) relies on."""
+    if isinstance(t, torch.Tensor):
+        torch.autograd.graph.increment_version(t)
+    return t
+
+
 def static_layout_budget_bytes():
     env = _os.environ.get("TFGX_STATIC_LAYOUT_BUDGET")
     if env is not None:
@@ -380,7 +405,7 @@ def static_layout_budget_bytes():
 
 def _auto_promote(x, plan, cache):
     """Second sighting of the same tensor (see above) -> declare it static in `cache`; True when promoted."""
-    if (not AUTO_STATIC_LAYOUT or x.dim() != 2 or not x.is_contiguous() or x.requires_grad or x.dtype != torch.float32
+    if (not AUTO_STATIC_LAYOUT or _AUTO_SUPPRESSED[0] > 0 or x.dim() != 2 or not x.is_contiguous() or x.requires_grad or x.dtype != torch.float32
             or not x.is_cuda or not SplitRows.wanted(int(x.shape[0]), int(x.shape[1]))
             or torch.cuda.is_current_stream_capturing()):
         return False
@@ -418,6 +443,11 @@ def static_rows(x, plan, cache):
         return x
     opt = cache.get(CACHE_KEY_STATIC, None)
     auto = bool(cache.get(CACHE_KEY_STATIC_AUTO))
+    if auto and torch.cuda.is_current_stream_capturing():
+        # a hipGraph replay cannot see x's version counter: only a layout the caller DECLARED (prepare_static_features: "x is
+        # not written to") may be baked into a captured sequence — a promoted one is this library's guess, and the static
+        # buffers of a captured model are exactly the tensors callers overwrite between replays
+        return x
     # "the same tensor": same storage window (views made by .detach() / as_f32 share it); opt is kept alive by the
     # cache entry, so the address cannot have been recycled
     same = isinstance(opt, torch.Tensor) and (opt.data_ptr() == x.data_ptr() and opt.shape == x.shape and
@@ -482,6 +512,7 @@ def segment_reduce(plan, x, op, w_csr=None, out=None, act=L.ACT_NONE, self_coef=
         x, ldx = L.row_major_2d(x)
         F = int(x.shape[1])
     n_dst = plan.n_dst if n_dst is None else int(n_dst)
+    given = out is not None
     if out is None:
         out = torch.empty((n_dst, F), dtype=torch.float32, device=x.device)
     out2, ldo = L.row_major_2d(out)
@@ -542,6 +573,10 @@ def segment_reduce(plan, x, op, w_csr=None, out=None, act=L.ACT_NONE, self_coef=
         return buf.value.decode()
     L.check(lib.tfgx_segment_reduce_f32(ctypes.byref(a), L.stream_ptr()), "tfgx_segment_reduce_f32")
     _AGG_LAUNCHES[0] += 1
+    if given:
+        written_by_kernel(out)
+    if track is not None:
+        written_by_kernel(track)
     return out
 
 
@@ -581,6 +616,7 @@ def aggregate_gemm(plan, x, op, kernel, w_csr=None, self_coef=None, bias=None, a
     hub = plan.hub_info()      # long rows: chunk partials by a launch of the ordinary kernel, folded by the row's lane group
     order = plan.row_order()   # skewed plans: tiles of similar-length rows (degree order), results unchanged
     n_dst = plan.n_dst
+    given = out is not None
     if out is None:
         out = torch.empty((n_dst, N), dtype=torch.float32, device=x2.device)
     _, ldc = L.row_major_2d(out)
@@ -618,6 +654,9 @@ def aggregate_gemm(plan, x, op, kernel, w_csr=None, self_coef=None, bias=None, a
     bias_t = None if bias is None else L.as_f32(bias).contiguous()
     L.check(lib.tfgx_aggregate_gemm_f32(ctypes.byref(a), L.ptr(k2), ldb, L.ptr(bias_t), act, L.ptr(out), ldc, N,
                                         L.stream_ptr()), "tfgx_aggregate_gemm_f32")
+    if given:
+        written_by_kernel(out)
+    written_by_kernel(agg_out)
     return out
 
 
@@ -686,6 +725,7 @@ def gemm_bias_act(a, b, bias=None, act=L.ACT_NONE, out=None, act_cols=None):
     if int(b.shape[0]) != K:
         raise ValueError("matmul shape mismatch: {} @ {}".format(tuple(a.shape), tuple(b.shape)))
     N = int(b.shape[1])
+    given = out is not None
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=a.device)
     _, ldc = L.row_major_2d(out)
@@ -695,6 +735,8 @@ def gemm_bias_act(a, b, bias=None, act=L.ACT_NONE, out=None, act_cols=None):
     L.check(lib.tfgx_gemm_bias_act_cols_ws_f32(L.ptr(a), lda, L.ptr(b), ldb, L.ptr(bias_t), act,
                                                N if act_cols is None else int(act_cols), L.ptr(out), ldc, M, K, N,
                                                L.ptr(ws), ws_bytes, L.stream_ptr()), "tfgx_gemm_bias_act_cols_ws_f32")
+    if given:
+        written_by_kernel(out)
     return out
 
 
@@ -712,11 +754,14 @@ def gather_rows(x, idx, out=None):
     x, ldx = L.row_major_2d(x)
     idx = L.as_i32(idx)
     M, F = int(idx.shape[0]), int(x.shape[1])
+    given = out is not None
     if out is None:
         out = torch.empty((M, F), dtype=torch.float32, device=x.device)
     _, ldo = L.row_major_2d(out)
     L.check(lib.tfgx_gather_rows_f32(L.ptr(x), ldx, L.ptr(idx), M, F, L.ptr(out), ldo, L.stream_ptr()),
             "tfgx_gather_rows_f32")
+    if given:
+        written_by_kernel(out)
     return out
 
 
