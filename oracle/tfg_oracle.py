@@ -109,6 +109,42 @@ def unsorted_segment_max(data, segment_ids, num_segments):
     return out[:, 0] if squeeze else out
 
 
+def sorted_segment(kind, data, segment_ids, acc=np.float64):
+    """tf.math.segment_sum / segment_mean / segment_max / segment_min (the callables nn/kernel/segment.py:5 is handed at
+    nn/kernel/map_reduce.py:35 and nn/pool/common_pool.py:28,36): ids ascending, output rows = last id + 1, a segment id
+    that does not occur yields 0 (TensorFlow's documented value — unlike the unsorted max / min, which hold lowest / max)."""
+    data2, squeeze = _as2d(data)
+    ids = np.asarray(segment_ids).astype(np.int64)
+    if ids.size and (np.diff(ids) < 0).any():
+        raise ValueError("segment ids are not increasing")
+    n = int(ids[-1]) + 1 if ids.size else 0
+    out = np.zeros((n, data2.shape[1]), dtype=np.float32)
+    if ids.size:
+        starts = np.flatnonzero(np.concatenate(([True], ids[1:] != ids[:-1])))
+        if kind in ("sum", "mean"):
+            red = np.add.reduceat(data2.astype(acc), starts, axis=0)
+            if kind == "mean":
+                red = red / np.diff(np.concatenate((starts, [ids.size])))[:, None]
+        else:
+            red = (np.maximum if kind == "max" else np.minimum).reduceat(data2.astype(np.float32), starts, axis=0)
+        out[ids[starts]] = red.astype(np.float32)
+    return out[:, 0] if squeeze else out
+
+
+def segment_op_with_pad(segment_op, data, segment_ids, num_segments):
+    """nn/kernel/segment.py:5-23 line by line; segment_op(sorted_data, sorted_ids) is a sorted segment op, e.g.
+    functools.partial(sorted_segment, "max")."""
+    data = np.asarray(data)
+    segment_ids = np.asarray(segment_ids)
+    sort_index = np.argsort(segment_ids, kind="stable")                    # :7
+    sorted_segment_ids = segment_ids[sort_index]                           # :8
+    sorted_data = data[sort_index]                                         # :9
+    reduced_data = segment_op(sorted_data, sorted_segment_ids)             # :11
+    num_paddings = num_segments - reduced_data.shape[0]                    # :12
+    pads = np.zeros((num_paddings,) + data.shape[1:], dtype=reduced_data.dtype)    # :14-18
+    return np.concatenate([reduced_data, pads], axis=0)                    # :19-23
+
+
 def segment_softmax(data, segment_ids, num_segments, acc=np.float64):
     """nn/kernel/segment.py:26-33 line by line."""
     data = np.asarray(data, dtype=np.float32)

@@ -1029,6 +1029,40 @@ _add("pooling", _pool_inputs, lambda R, g: _pool_run(R.tfg.nn, g), None, lambda 
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# segment_op_with_pad — nn/kernel/segment.py:5-23 (the TF1 route of max_reducer / max_pool / min_pool: a SORTED segment op
+# on rows sorted by id, zero rows appended up to num_segments)
+# ---------------------------------------------------------------------------------------------------------------------
+def _pad_inputs():
+    rng = np.random.Generator(np.random.PCG64(120))
+    ids = rng.integers(0, 40, size=900, dtype=np.int32)             # unsorted; ids 7 and 23 never occur, 40..44 are padding
+    ids[ids == 7] = 8
+    ids[ids == 23] = 22
+    x = rng.standard_normal((900, 6), dtype=np.float32)
+    x[::37] = x[1::37][:x[::37].shape[0]]                            # ties
+    return dict(x=x, ids=ids, v=rng.standard_normal(900).astype(np.float32))
+
+
+def _pad_run(pad, op_of, g):
+    out = {}
+    for kind in ("sum", "mean", "max", "min"):
+        out[kind] = _np(pad(op_of(kind), g["x"], g["ids"], 45))
+        out[kind + "-1d"] = _np(pad(op_of(kind), g["v"], g["ids"], 41))
+    return out
+
+
+def _pad_orc(o, g):
+    import functools
+    return _pad_run(o.segment_op_with_pad, lambda k: functools.partial(o.sorted_segment, k), g)
+
+
+_add("segment_op_with_pad", _pad_inputs,
+     lambda R, g: _pad_run(R.tfg.nn.kernel.segment.segment_op_with_pad, lambda k: getattr(R.tf.math, "segment_" + k), g),
+     _pad_orc,
+     lambda T, g: _pad_run(T.nn.kernel.segment.segment_op_with_pad, lambda k: getattr(T.nn.kernel.segment, "segment_" + k), g),
+     exact=["max", "min", "max-1d", "min-1d"])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # fuzz: the core hot-path functions on six more seeded graphs each (sizes, widths, head counts, normalisation configs
 # and graph irregularities vary with the seed) — reference outputs in the same golden file
 # ---------------------------------------------------------------------------------------------------------------------

@@ -2,6 +2,7 @@
 """GPU parity: HIP gather-scale-segment-reduce (through the C ABI) vs the CPU oracle, same seeded inputs."""
 import numpy as np
 import pytest
+import torch
 
 from conftest import assert_parity
 
@@ -549,3 +550,38 @@ def test_segment_softmax_hub_rows(tfg, oracle, heads):
             assert_parity(got, ref, tol=2e-6, what="segment_softmax hub thr={}".format(thr))
     finally:
         P.HUB_THRESHOLD, P.HUB_CHUNK = old
+
+
+def test_segment_op_with_pad_routes_gradient_and_refusals(tfg, oracle):
+    """nn/kernel/segment.py:5-23.  This module's own sorted segment ops take ONE launch on the unsorted rows; any other
+    callable is run as the reference runs it (sort, gather, op, pad) — same values; gradients flow through the kernel's own
+    backward; ids >= num_segments and unsorted ids handed to a sorted op are refused."""
+    import functools
+    seg = tfg.nn.kernel.segment
+    rng = np.random.Generator(np.random.PCG64(91))
+    ids = rng.integers(0, 50, size=2000).astype(np.int32)
+    ids[ids == 13] = 14
+    x = rng.standard_normal((2000, 7), dtype=np.float32)
+    for kind in ("sum", "mean", "max", "min"):
+        op = getattr(seg, "segment_" + kind)
+        fast = seg.segment_op_with_pad(op, x, ids, 60)
+        slow = seg.segment_op_with_pad(lambda d, i, op=op: op(d, i), x, ids, 60)        # a plain callable: the reference's route
+        ref = oracle.segment_op_with_pad(functools.partial(oracle.sorted_segment, kind), x, ids, 60)
+        assert tuple(fast.shape) == (60, 7)
+        assert_parity(fast.cpu().numpy(), ref, what="segment_op_with_pad " + kind)
+        if kind in ("max", "min"):
+            assert np.array_equal(fast.cpu().numpy(), ref) and torch.equal(fast, slow)
+        else:
+            assert_parity(slow.cpu().numpy(), ref, what="segment_op_with_pad generic " + kind)
+    xd = torch.tensor(x, device="cuda", requires_grad=True)
+    seg.segment_op_with_pad(seg.segment_sum, xd, ids, 60).sum().backward()
+    assert torch.equal(xd.grad, torch.ones_like(xd))
+    xd.grad = None
+    seg.segment_op_with_pad(seg.segment_max, xd, ids, 60)[:, 0].sum().backward()
+    g0 = xd.grad[:, 0].cpu().numpy()
+    assert g0.sum() == len(np.unique(ids)) and (xd.grad[:, 1:] == 0).all()
+    with pytest.raises(ValueError):
+        seg.segment_op_with_pad(seg.segment_sum, x, ids, 49)
+    with pytest.raises(ValueError):
+        seg.segment_max(x, ids)                                                          # ids not ascending
+    assert tuple(seg.segment_max(x[:0], ids[:0]).shape) == (0, 7)

@@ -295,3 +295,22 @@ def test_captured_gat_attention_dropout_draws_a_new_mask_on_every_replay(tfg, or
     losses = [float(step().detach()) for _ in range(4)]
     assert len(set(losses)) == 4 and all(np.isfinite(losses))
     assert all(torch.isfinite(p.grad).all() for p in layer.parameters())
+
+
+def test_edge_weights_written_in_place_are_seen(tfg, oracle):
+    """The CSR-ordered copy of the caller's edge weights is memoised per cache on the array object; a torch in-place write to
+    that tensor (its version counter) must invalidate it, like a new tensor does."""
+    rng = np.random.Generator(np.random.PCG64(77))
+    n, e, f = 300, 2400, 20
+    ei = rng.integers(0, n, size=(2, e)).astype(np.int32)
+    x = rng.standard_normal((n, f), dtype=np.float32)
+    w = (rng.random(e, dtype=np.float32) + 0.5)
+    layer = tfg.layers.MeanGraphSage(8, activation=None)
+    eid, xd, wd = torch.as_tensor(ei, device="cuda"), torch.as_tensor(x, device="cuda"), torch.as_tensor(w, device="cuda")
+    cache = {}
+    a = layer([xd, eid, wd], cache=cache).clone()
+    flip = torch.as_tensor(rng.random(e, dtype=np.float32) + 0.25, device="cuda")
+    wd.mul_(flip)                                                    # same tensor object, new contents
+    b = layer([xd, eid, wd], cache=cache)
+    fresh = layer([xd, eid, wd.clone()], cache={})
+    assert torch.equal(b, fresh) and not torch.equal(a, b)

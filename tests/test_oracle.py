@@ -255,3 +255,21 @@ def test_gcn_on_a_cut_out_with_whole_graph_degrees_equals_the_whole_graph_rows(o
     deg = oracle.unsorted_segment_sum(w.astype(np.float64), ei[0], n) + 1.0          # rows of A + I (gcn.py:77,80)
     part = oracle.gcn(x[nodes], sub, w[keep], k, b, "relu", row_deg=deg[nodes])
     assert np.array_equal(part[np.searchsorted(nodes, rows)], whole[rows])
+
+
+def test_kat_sorted_segment_ops_and_pad(oracle):
+    """tf.math.segment_* documented example (c = [[1,2,3,4],[4,3,2,1],[5,6,7,8]], ids [0,0,1]) and the rule that an id which
+    does not occur yields 0; segment_op_with_pad (nn/kernel/segment.py:5-23) sorts, reduces and appends zero rows."""
+    import functools
+    c = np.array([[1, 2, 3, 4], [4, 3, 2, 1], [5, 6, 7, 8]], dtype=np.float32)
+    ids = np.array([0, 0, 1])
+    assert np.array_equal(oracle.sorted_segment("sum", c, ids), [[5, 5, 5, 5], [5, 6, 7, 8]])
+    assert np.array_equal(oracle.sorted_segment("mean", c, ids), [[2.5, 2.5, 2.5, 2.5], [5, 6, 7, 8]])
+    assert np.array_equal(oracle.sorted_segment("max", c, ids), [[4, 3, 3, 4], [5, 6, 7, 8]])
+    assert np.array_equal(oracle.sorted_segment("min", c, ids), [[1, 2, 2, 1], [5, 6, 7, 8]])
+    gap = oracle.sorted_segment("max", -c, np.array([0, 2, 2]))                 # id 1 never occurs: 0, not lowest
+    assert np.array_equal(gap, [[-1, -2, -3, -4], [0, 0, 0, 0], [-4, -3, -2, -1]])
+    with pytest.raises(ValueError):
+        oracle.sorted_segment("sum", c, np.array([1, 0, 1]))
+    out = oracle.segment_op_with_pad(functools.partial(oracle.sorted_segment, "max"), -c, np.array([2, 0, 2]), 5)
+    assert np.array_equal(out, [[-4, -3, -2, -1], [0, 0, 0, 0], [-1, -2, -3, -4], [0, 0, 0, 0], [0, 0, 0, 0]])

@@ -32,3 +32,74 @@ def segment_count(index, num_segments=None):
         num_segments = int(ids.max().item()) + 1
     plan = CsrPlan.build(torch.stack([ids, torch.zeros_like(ids)]), int(num_segments), 1)
     return plan.in_degree().to(ids.dtype)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The TF1 route of the reference's max reducer / max-min readouts (nn/kernel/map_reduce.py:31-36, nn/pool/common_pool.py:
+# 24-37): `segment_op_with_pad(tf.math.segment_max, data, ids, n)`.  The callables it is handed are TensorFlow's SORTED
+# segment ops; their counterparts here are segment_sum / segment_mean / segment_max / segment_min below.
+# ---------------------------------------------------------------------------------------------------------------------
+def _rows(data):
+    d = L.as_f32(data)
+    return (d.reshape(-1, 1), True) if d.dim() == 1 else (d.reshape(int(d.shape[0]), -1), False)
+
+
+def _segment(data, segment_ids, num_segments, op):
+    """One launch of the segment-reduce kernel over rows grouped by id; a segment without rows holds 0 (the sorted TF ops'
+    documented value for an empty segment — NOT float32 lowest, which is what the unsorted max holds)."""
+    d = L.as_f32(data)
+    d2, squeeze = _rows(d)
+    ids = L.as_i32(segment_ids)
+    n_rows = int(ids.shape[0])
+    if int(d2.shape[0]) != n_rows:
+        raise ValueError("segment op: data has {} rows, segment_ids {}".format(int(d2.shape[0]), n_rows))
+    n = int(num_segments)
+    from ...plan import segment_reduce
+    plan = CsrPlan.build(torch.stack([ids, torch.arange(n_rows, dtype=torch.int32, device=ids.device)]), n, max(n_rows, 1))
+    kind, flip = {"sum": (L.SUM, False), "mean": (L.MEAN, False), "max": (L.MAX, False), "min": (L.MAX, True)}[op]
+    src = -d2 if flip else d2
+    out = AG.aggregate(plan, src, kind) if AG.needs_grad(src) else segment_reduce(plan, src, kind)
+    if flip:
+        out = -out
+    if kind == L.MAX:
+        out = torch.where((plan.in_degree() == 0).unsqueeze(-1), torch.zeros((), dtype=out.dtype, device=out.device), out)
+    return out.reshape(n) if squeeze else out.reshape((n,) + tuple(d.shape[1:]))
+
+
+def _sorted_segment_op(op):
+    def segment_op(data, segment_ids, name=None):
+        """tf.math.segment_{} : ids ascending, output rows = last id + 1, an id that does not occur yields 0."""
+        ids = L.as_i32(segment_ids)
+        if int(ids.shape[0]) == 0:
+            d = L.as_f32(data)
+            return torch.zeros((0,) + tuple(d.shape[1:]), dtype=torch.float32, device=d.device)
+        if bool((ids[1:] < ids[:-1]).any().item()):
+            raise ValueError("segment ids are not increasing")            # TF: InvalidArgumentError
+        return _segment(data, ids, int(ids[-1].item()) + 1, op)
+    segment_op.__doc__ = segment_op.__doc__.format(op)
+    segment_op.__name__ = "segment_" + op
+    segment_op._tfgx_segment_kind = op
+    return segment_op
+
+
+segment_sum, segment_mean = _sorted_segment_op("sum"), _sorted_segment_op("mean")
+segment_max, segment_min = _sorted_segment_op("max"), _sorted_segment_op("min")
+
+
+def segment_op_with_pad(segment_op, data, segment_ids, num_segments):
+    """Reference: nn/kernel/segment.py:5-23 — sort the rows by segment id, apply a SORTED segment op (it returns last id + 1
+    rows), pad with zero rows up to num_segments.  For this module's own segment_sum / mean / max / min that is ONE launch of
+    the segment-reduce kernel on the unsorted rows (no sort, no gather, no concat); any other callable
+    (sorted_data, sorted_ids) -> [<= num_segments, ...] is run as the reference runs it."""
+    n = int(num_segments)
+    kind = getattr(segment_op, "_tfgx_segment_kind", None)
+    ids = L.as_i32(segment_ids)
+    if kind is not None:
+        if int(ids.shape[0]) and int(ids.max().item()) >= n:
+            raise ValueError("segment_op_with_pad: segment id {} >= num_segments {}".format(int(ids.max().item()), n))
+        return _segment(data, ids, n, kind)
+    d = L.as_f32(data)
+    order = torch.argsort(ids.long(), stable=True)                                       # :7
+    reduced = segment_op(d[order], ids[order])                                           # :8-11
+    pads = torch.zeros((n - int(reduced.shape[0]),) + tuple(d.shape[1:]), dtype=reduced.dtype, device=reduced.device)   # :12-18
+    return torch.cat([reduced, pads], dim=0)                                             # :19-23

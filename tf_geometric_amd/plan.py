@@ -484,13 +484,14 @@ def edge_weight_csr(plan, edge_weight, cache=None):
     graph, inputs not mutated in place — nn/conv/gcn.py:125-128)."""
     if edge_weight is None:
         return None
+    ver = edge_weight._version if isinstance(edge_weight, torch.Tensor) else None     # a torch in-place write is seen
     if cache is not None:
         hit = cache.get("tfgx_edge_weight_csr")
-        if hit is not None and hit[0] is edge_weight and hit[2] is plan:
+        if hit is not None and hit[0] is edge_weight and hit[2] is plan and hit[3] == ver:
             return hit[1]
     w_csr = plan.edge_attr_to_csr(edge_weight)
     if cache is not None:
-        cache["tfgx_edge_weight_csr"] = (edge_weight, w_csr, plan)
+        cache["tfgx_edge_weight_csr"] = (edge_weight, w_csr, plan, ver)
     return w_csr
 
 
