@@ -84,7 +84,8 @@ class CapturedTrainStep(object):
                    for p, st in optimizer.state.items()}
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
+        from .plan import no_auto_promotion
+        with torch.cuda.stream(side), no_auto_promotion():      # a layout promoted here could never be replayed (static_rows)
             for _ in range(max(int(warmup), 1)):
                 optimizer.zero_grad(set_to_none=True)
                 loss_fn().backward()
