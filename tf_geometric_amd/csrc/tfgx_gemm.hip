@@ -486,7 +486,20 @@ __global__ __launch_bounds__(rows_threads<TN>()) void gemm_rows_kernel(const flo
 #if TFGX_ROWS_PRIO == 1
     if (wave < 4) __builtin_amdgcn_s_setprio(1);
 #endif
-#if TFGX_ROWS_STAGGER
+#if TFGX_ROWS_STAGGER == 2 || TFGX_ROWS_STAGGER == 3
+    // The two waves of a SIMD leave the barrier together, run the same instruction stream and share the MFMA port turn by
+    // turn — so they stay in phase for the whole launch: both compute addresses and issue loads at the top of a k-step at the
+    // same time (the port idles), then both multiply.  Delay the second wave of each SIMD ONCE by half a k-step of MFMA time
+    // (2: 16 * TN groups of 64 cycles; 3: a quarter): the phase difference persists, one wave's step overhead and epilogue
+    // then fall under the other's MFMAs.
+    if (wave >= NT / 128) {
+        constexpr int units = (TFGX_ROWS_STAGGER == 2 ? 16 : 8) * TN;     // s_sleep counts 64-cycle units, immediate <= 127
+#pragma unroll
+        for (int i = 0; i < units / 32; ++i) __builtin_amdgcn_s_sleep(32);
+        if (units % 32 >= 16) __builtin_amdgcn_s_sleep(16);
+        if (units % 16 >= 8) __builtin_amdgcn_s_sleep(8);
+    }
+#elif TFGX_ROWS_STAGGER
     // The two waves of a SIMD (wave w and w + 4) would otherwise run in lock step — every wave of the chip multiplies a tile,
     // then every wave stores one: a write burst the MFMA pipes idle through (measured: the same kernel without its stores
     // 0.98 ms, with them 1.27 ms at 2.4 M x 100 -> 256, although 2.46 GB of output is 0.36 ms of pure write time).  The upper
