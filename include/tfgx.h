@@ -476,9 +476,13 @@ int tfgx_gemm_bias_act_cols_f32(const float* A, int64_t lda, const float* B, int
                                 int32_t act, int64_t act_cols, float* C, int64_t ldc, int64_t M, int64_t K, int64_t N,
                                 tfgx_stream_t stream);
 
-/* same, with a caller-lent workspace of tfgx_gemm_workspace_bytes(M, K, N) bytes (0 for most shapes): small-M / long-K
-   products (Cora: 2708 x 1433 x 16) are cut along K over the idle CUs, the partial products are summed in split order
-   (deterministic) together with bias and activation.  workspace == NULL behaves like tfgx_gemm_bias_act_cols_f32. */
+/* same, with a caller-lent workspace of tfgx_gemm_workspace_bytes(M, K, N) bytes: small-M / long-K products (Cora:
+   2708 x 1433 x 16) are cut along K over the idle CUs, the partial products are summed in split order (deterministic)
+   together with bias and activation; tall products on the row-streaming kernel (M >= 2^18) keep their tile counters
+   there (~2 KB, zeroed in stream order by the call): the kernel's waves then CLAIM their 32-row tiles instead of walking
+   a fixed map — same values in every element (a tile's arithmetic does not depend on which wave runs it), 1-4 % less
+   time.  The workspace must belong to this call until it has completed on `stream`.  workspace == NULL behaves like
+   tfgx_gemm_bias_act_cols_f32. */
 size_t tfgx_gemm_workspace_bytes(int64_t M, int64_t K, int64_t N);
 int tfgx_gemm_bias_act_cols_ws_f32(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias,
                                    int32_t act, int64_t act_cols, float* C, int64_t ldc, int64_t M, int64_t K, int64_t N,

@@ -79,7 +79,8 @@ def test_argument_validation_without_gpu():
     assert lib.tfgx_segment_topk(None, None, 5, 3, 1, 0.0, None, None, None, 0, None) == 1 and b"out_count" in lib.tfgx_last_error()
     assert lib.tfgx_segment_topk_workspace_bytes(1000, 10) > 1000 * 24 and lib.tfgx_segment_topk_workspace_bytes(-1, 1) == 0
     assert lib.tfgx_gemm_workspace_bytes(2708, 1433, 256) >= 2 * 4 * 2708 * 256      # small M, long K: split-K
-    assert lib.tfgx_gemm_workspace_bytes(2400000, 100, 256) == 0                      # plenty of tiles: no split
+    assert 0 < lib.tfgx_gemm_workspace_bytes(2400000, 100, 256) <= 4096               # plenty of tiles: no split, only the row kernel's tile counters
+    assert lib.tfgx_gemm_workspace_bytes(170000, 128, 256) == 0                       # short launches keep the fixed tile map
     assert lib.tfgx_gemm_bias_act_cols_ws_f32(None, 4, None, 4, None, 0, 9, None, 4, 2, 4, 4, None, 0, None) == 1
     assert b"act_cols" in lib.tfgx_last_error()
     assert lib.tfgx_segment_max_with_count_f32(None, None, None, 4, None, 2, 8, None, 8, None, 8, None) == 1

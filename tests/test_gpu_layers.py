@@ -519,3 +519,29 @@ def test_fused_aggregate_gemm_on_a_graph_with_hub_rows(tfg, oracle, mode, f, uni
     ref = np.maximum(agg.double().cpu().numpy() @ k.astype(np.float64) + b, 0)
     assert_parity(fused.cpu().numpy(), ref, what="fused with hub rows vs float64 of the same aggregate")
     assert_parity(fused.cpu().numpy(), two.cpu().numpy(), what="fused with hub rows vs two launches")
+
+
+@pytest.mark.parametrize("m,k,n", [(300001, 100, 256), (280000, 256, 256), (262144, 128, 96), (270000, 36, 40)])
+def test_gemm_dynamic_tile_order_changes_no_bit(tfg, oracle, m, k, n):
+    """Tall products (M >= 2^18) given a workspace run the row kernel with CLAIMED tiles (per-pool device counters in the
+    workspace) instead of the fixed tile -> wave map of the workspace-less entry point: a tile's arithmetic does not depend on
+    the wave that runs it, so the two launches agree in every bit; and both sit in the oracle's band."""
+    import torch
+    from tf_geometric_amd import _lib as L
+    from tf_geometric_amd.plan import gemm_bias_act
+    lib = L.require_gpu()
+    assert lib.tfgx_gemm_workspace_bytes(m, k, n) > 0
+    rng = np.random.Generator(np.random.PCG64(m + n))
+    a = torch.as_tensor(rng.standard_normal((m, k), dtype=np.float32), device="cuda")
+    b = torch.as_tensor(oracle.glorot_uniform(rng, k, n), device="cuda")
+    bias = torch.as_tensor((rng.standard_normal(n) * 0.1).astype(np.float32), device="cuda")
+    dyn = gemm_bias_act(a, b, bias=bias, act=1)                                     # workspace lent: claimed tiles
+    fixed = torch.empty_like(dyn)
+    L.check(lib.tfgx_gemm_bias_act_f32(L.ptr(a), k, L.ptr(b), n, L.ptr(bias), 1, L.ptr(fixed), n, m, k, n, L.stream_ptr()),
+            "tfgx_gemm_bias_act_f32")
+    assert torch.equal(dyn, fixed)
+    rows = rng.choice(m, size=4000, replace=False)
+    ref = np.maximum(oracle.matmul(a[rows].cpu().numpy(), b.cpu().numpy()) + bias.cpu().numpy(), 0)
+    assert_parity(dyn[rows].cpu().numpy(), ref, what="dynamic-order gemm {}x{}x{}".format(m, k, n))
+    again = gemm_bias_act(a, b, bias=bias, act=1)                                   # and run to run
+    assert torch.equal(dyn, again)

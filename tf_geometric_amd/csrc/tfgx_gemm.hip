@@ -304,6 +304,12 @@ __global__ __launch_bounds__(kBlock) void gemm_kernel(const float* __restrict__ 
 #ifndef TFGX_ROWS_LDS_AHEAD
 #define TFGX_ROWS_LDS_AHEAD 1      // developer A/B: how many MFMA groups ahead the B operands are read from LDS (1 or 2)
 #endif
+constexpr int kRowsCounterStride = 32;          // uints between the per-slot tile counters (one 128-byte line each)
+constexpr int kRowsCounterSlots = 16;           // >= waves per workgroup of any row kernel
+#if TFGX_ROWS_EXPERIMENT == 3
+__device__ uint64_t g_rows_dbg[12];
+__device__ uint64_t g_rows_wave[4096 * 4];   // per wave of the LAST launch: loop start tick, loop end tick, tiles, hw id     // loop cycles, loop 100 MHz ticks, tiles, waves, max / min loop ticks of a wave, prologue ticks, max end tick - min start tick
+#endif
 template <int TN, int NG>
 __device__ __forceinline__ void rows_mfma_groups(f32x16 (&acc)[TN], const float* a, const float* b_s)
 {
@@ -348,7 +354,8 @@ __global__ __launch_bounds__(rows_threads<TN>()) void gemm_rows_kernel(const flo
                                                         const float* __restrict__ B, int64_t ldb,
                                                         const float* __restrict__ bias, int act, int act_cols,
                                                         float* __restrict__ C, int64_t ldc, int64_t M, int K, int N,
-                                                        int64_t n_tiles, int b_vec4, int two_level_on)
+                                                        int64_t n_tiles, int b_vec4, int two_level_on,
+                                                        unsigned int* __restrict__ tile_counter)
 {
     constexpr int LDB_S = TN * 32 + 8;   // (4 * LDB_S) % 64 == 32: the two half-waves hit disjoint banks
     constexpr int NQ = LDB_S / 4;
@@ -357,6 +364,9 @@ __global__ __launch_bounds__(rows_threads<TN>()) void gemm_rows_kernel(const flo
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int l31 = lane & 31, kh = lane >> 5;
+#if TFGX_ROWS_EXPERIMENT == 3
+    const uint64_t dbg_wk = wall_clock64();
+#endif
 
     constexpr int NT = rows_threads<TN>();
 #ifndef TFGX_ROWS_B_BATCH
@@ -449,9 +459,27 @@ __global__ __launch_bounds__(rows_threads<TN>()) void gemm_rows_kernel(const flo
     };
     zero_acc();
     // branch-free on purpose (see load_a): past the last tile the row clamp turns this into a harmless re-read
+    // DYNAMIC tile order (tile_counter != nullptr): every wave claims its tiles from one device counter, one tile ahead — the
+    // claim is ISSUED at the top of a tile and its value first READ at that tile's last k-step, where the next tile's A rows
+    // are prefetched.  In-kernel clocks (TFGX_ROWS_EXPERIMENT=3, tools/rows_clock_probe.py) show the waves of one launch
+    // spending 1087 .. 1512 us (mean 1300) over the same 36-37 tiles of 2.4 M x 128 -> 256: with a fixed tile -> wave map
+    // the launch lasts as long as its slowest wave.
+    unsigned int next_raw = 0;                 // lane 0: the claimed index of the next tile (valid once the atomic has returned)
+    // kRowsCounterSlots pools (counters kRowsCounterStride uints = 128 bytes apart), pool p owning the tiles = p (mod pools):
+    // a returning atomic on ONE address costs ~12 ns (measured: 4096 initial claims = 50 us), so a single counter would
+    // serialise 75 000 claims into 0.9 ms.  A pool is shared by BOTH waves of a SIMD (wave & 3) of a quarter of the
+    // workgroups (spread over all XCDs): the SIMD's older wave wins the MFMA port whenever both are ready and runs ~25 % faster than the younger one
+    // for the whole launch (per-slot pools left the spread as it was) — in a shared pool it simply takes more tiles.
+    const int pool = ((int(blockIdx.x) >> 3) & 3) * 4 + (wave & 3);      // blockIdx >> 3: workgroups i .. i + 7 sit on the 8 XCDs, so every pool spans all of them
+    auto claim = [&]() {
+        if (lane == 0) next_raw = atomicAdd(tile_counter + kRowsCounterStride * pool, 1u);
+    };
+    auto next_of = [&](int64_t t) -> int64_t {
+        return tile_counter ? int64_t(uint32_t(__builtin_amdgcn_readfirstlane(int(next_raw)))) * kRowsCounterSlots + pool : t + stride;
+    };
     auto adv = [&](int64_t& t, int& ks) {
         const bool same = ks + 1 < nsteps;
-        t = same ? t : t + stride;
+        t = same ? t : next_of(t);
         ks = same ? ks + 1 : 0;
     };
     auto prefetch = [&](int64_t t, int ks) {
@@ -483,6 +511,11 @@ __global__ __launch_bounds__(rows_threads<TN>()) void gemm_rows_kernel(const flo
     for (int j = 0; j < TN; ++j) bv[j] = (bias && j * 32 + l31 < N) ? bias[j * 32 + l31] : 0.0f;
 
     int64_t tile = int64_t(blockIdx.x) * (NT / 64) + wave;
+    if (tile_counter) {
+        claim();
+        tile = next_of(0);
+        claim();
+    }
 #if TFGX_ROWS_PRIO == 1
     if (wave < 4) __builtin_amdgcn_s_setprio(1);
 #endif
@@ -534,7 +567,16 @@ __global__ __launch_bounds__(rows_threads<TN>()) void gemm_rows_kernel(const flo
 #pragma unroll
             for (int t = 0; t < 16; ++t) tot[j][t] = 0.0f;
     }
-    for (; tile < n_tiles; tile += stride) {
+#if TFGX_ROWS_EXPERIMENT == 3
+    // instrumented build (results valid, timing perturbed by four scalar reads per wave): shader-clock cycles and constant
+    // 100 MHz ticks spent inside the tile loop, summed over waves -> tfgx_debug_rows_stats
+    const uint64_t dbg_c0 = __builtin_readcyclecounter(), dbg_w0 = wall_clock64();
+    uint64_t dbg_tiles = 0;
+#endif
+    while (tile < n_tiles) {
+#if TFGX_ROWS_EXPERIMENT == 3
+        ++dbg_tiles;
+#endif
         for (int ks = 0; ks < nfull; ++ks) {
             prefetch(tile, ks);
             rows_mfma_groups<TN, 16>(acc, cur, Bs + (ks * 32 + 16 * kh) * LDB_S + l31);
@@ -655,7 +697,35 @@ __global__ __launch_bounds__(rows_threads<TN>()) void gemm_rows_kernel(const flo
             }
         }
         zero_acc();
+        tile = next_of(tile);                  // dynamic: the claim issued a tile ago
+        if (tile_counter) claim();             // ... and the one for the tile after the next
     }
+#if TFGX_ROWS_EXPERIMENT == 3
+    if (lane == 0 && dbg_tiles) {
+        atomicAdd(reinterpret_cast<unsigned long long*>(&g_rows_dbg[0]), (unsigned long long)(__builtin_readcyclecounter() - dbg_c0));
+        atomicAdd(reinterpret_cast<unsigned long long*>(&g_rows_dbg[1]), (unsigned long long)(wall_clock64() - dbg_w0));
+        atomicAdd(reinterpret_cast<unsigned long long*>(&g_rows_dbg[2]), (unsigned long long)dbg_tiles);
+        atomicAdd(reinterpret_cast<unsigned long long*>(&g_rows_dbg[3]), 1ull);
+        const unsigned long long w1 = wall_clock64();
+        atomicMax(reinterpret_cast<unsigned long long*>(&g_rows_dbg[4]), (unsigned long long)(w1 - dbg_w0));
+        atomicMin(reinterpret_cast<unsigned long long*>(&g_rows_dbg[5]), (unsigned long long)(w1 - dbg_w0));
+        atomicAdd(reinterpret_cast<unsigned long long*>(&g_rows_dbg[6]), (unsigned long long)(dbg_w0 - dbg_wk));
+        atomicMax(reinterpret_cast<unsigned long long*>(&g_rows_dbg[7]), (unsigned long long)(w1 - dbg_wk));
+        atomicMin(reinterpret_cast<unsigned long long*>(&g_rows_dbg[8]), (unsigned long long)dbg_wk);      // earliest / latest kernel entry
+        atomicMax(reinterpret_cast<unsigned long long*>(&g_rows_dbg[9]), (unsigned long long)dbg_wk);
+        {
+            const int gw = int(blockIdx.x) * (NT / 64) + wave;
+            if (gw < 4096) {
+                g_rows_wave[4 * gw + 0] = dbg_w0;
+                g_rows_wave[4 * gw + 1] = w1;
+                g_rows_wave[4 * gw + 2] = dbg_tiles;
+                g_rows_wave[4 * gw + 3] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));   // HW_REG_XCC_ID
+            }
+        }
+        atomicMin(reinterpret_cast<unsigned long long*>(&g_rows_dbg[10]), w1);                              // earliest / latest loop end
+        atomicMax(reinterpret_cast<unsigned long long*>(&g_rows_dbg[11]), w1);
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1098,11 +1168,34 @@ static int two_level_default()
     return on;
 }
 
+// Dynamic tile order of the row kernel (see gemm_rows_kernel): its pool counters live in the CALLER's workspace
+// (tfgx_gemm_bias_act_cols_ws_f32) — a buffer that belongs to one call in flight by construction — and are zeroed in stream
+// order before the launch.  Without a workspace (or for launches too short to gain: a memset node costs ~2 us) the kernel
+// walks its fixed tile -> wave map.  TFGX_ROWS_DYNAMIC=0 turns it off (developer A/B), =2 removes the size threshold (tests).
+constexpr size_t kRowsCounterBytes = sizeof(unsigned int) * kRowsCounterStride * kRowsCounterSlots;
+inline int rows_dynamic_mode()
+{
+    static const int mode = [] { const char* e = std::getenv("TFGX_ROWS_DYNAMIC"); return e ? atoi(e) : 1; }();
+    return mode;
+}
+inline bool rows_dynamic_wanted(int64_t M)
+{
+    const int mode = rows_dynamic_mode();
+    return mode == 2 || (mode == 1 && M >= (int64_t(1) << 18));
+}
+inline unsigned int* rows_tile_counter(int64_t M, void* workspace, size_t workspace_bytes)
+{
+    if (!rows_dynamic_wanted(M) || workspace == nullptr) return nullptr;
+    const uintptr_t p = (reinterpret_cast<uintptr_t>(workspace) + 127) & ~uintptr_t(127);
+    if (p + kRowsCounterBytes > reinterpret_cast<uintptr_t>(workspace) + workspace_bytes) return nullptr;
+    return reinterpret_cast<unsigned int*>(p);
+}
+
 inline size_t rows_lds_bytes(int64_t K, int tn) { return sizeof(float) * size_t(K) * size_t(tn * 32 + 8); }
 
 template <int TN>
 int launch_gemm_rows(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, int act, float* C,
-                     int64_t ldc, int64_t M, int K, int N, int act_cols, hipStream_t stream)
+                     int64_t ldc, int64_t M, int K, int N, int act_cols, hipStream_t stream, unsigned int* tile_counter)
 {
     // per DEVICE (one process may drive several GPUs): compute-unit count + the kernel's dynamic-LDS attribute
     constexpr int kMaxDev = 64;
@@ -1132,8 +1225,10 @@ int launch_gemm_rows(const float* A, int64_t lda, const float* B, int64_t ldb, c
     }();
     const int64_t max_wgs = int64_t(cus) * (mult_env > 0 ? mult_env : 1);
     dim3 grid(static_cast<unsigned>(wgs < max_wgs ? wgs : max_wgs), 1, 1), block(rows_threads<TN>(), 1, 1);
+    if (tile_counter)
+        TFGX_HIP_CHECK(hipMemsetAsync(tile_counter, 0, kRowsCounterBytes, stream));
     gemm_rows_kernel<TN><<<grid, block, rows_lds_bytes(K, TN), stream>>>(A, lda, B, ldb, bias, act, act_cols, C, ldc, M, K,
-                                                                         N, n_tiles, b_vec4, two_level_default());
+                                                                         N, n_tiles, b_vec4, two_level_default(), tile_counter);
     TFGX_LAUNCH_CHECK("gemm_rows_kernel");
     return TFGX_OK;
 }
@@ -1227,11 +1322,36 @@ static inline int64_t generic_tiles(int64_t M, int64_t N)
     return ((M + bm - 1) / bm) * ((N + bn - 1) / bn);
 }
 
+#if TFGX_ROWS_EXPERIMENT == 3
+// developer build only: read and clear the row kernel's in-kernel clocks (see gemm_rows_kernel)
+extern "C" int tfgx_debug_rows_stats(uint64_t* out4)
+{
+    uint64_t z[12] = {0, 0, 0, 0, 0, ~0ull, 0, 0, ~0ull, 0, ~0ull, 0};
+    TFGX_HIP_CHECK(hipDeviceSynchronize());
+    TFGX_HIP_CHECK(hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_rows_dbg), sizeof(z)));
+    TFGX_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_rows_dbg), z, sizeof(z)));
+    return TFGX_OK;
+}
+#endif
+
+#if TFGX_ROWS_EXPERIMENT == 3
+extern "C" int tfgx_debug_rows_waves(uint64_t* out, int n_waves)
+{
+    TFGX_HIP_CHECK(hipDeviceSynchronize());
+    TFGX_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rows_wave), sizeof(uint64_t) * 4 * size_t(n_waves)));
+    return TFGX_OK;
+}
+#endif
+
 extern "C" size_t tfgx_gemm_workspace_bytes(int64_t M, int64_t K, int64_t N)
 {
     if (M <= 0 || K <= 0 || N <= 0) return 0;
     const int s = splitk_factor(generic_tiles(M, N), K);
-    return s > 1 ? sizeof(float) * size_t(s) * size_t(M) * size_t(N) : 0;
+    if (s > 1) return sizeof(float) * size_t(s) * size_t(M) * size_t(N);
+    // the row kernel's tile counters (alignment slack included); whether the row kernel runs also depends on the pointers,
+    // so this is an upper bound for shapes it can take
+    const bool rows_shape = N <= 512 && K >= 32 && K % 4 == 0 && M >= 128 * 256;
+    return (rows_shape && rows_dynamic_wanted(M)) ? kRowsCounterBytes + 128 : 0;
 }
 
 extern "C" int tfgx_gemm_bias_act_cols_ws_f32(const float* A, int64_t lda, const float* B, int64_t ldb,
@@ -1267,15 +1387,16 @@ extern "C" int tfgx_gemm_bias_act_cols_ws_f32(const float* A, int64_t lda, const
     if (N > 128 && N <= 512 && N % 128 == 0 && !rows_ok(A, lda, M, K, N) && rows_ok(A, lda, M, K, 128)) {
         for (int64_t n0 = 0; n0 < N; n0 += 128) {
             const int64_t ac_slice = act_cols > n0 ? (act_cols - n0 < 128 ? act_cols - n0 : 128) : 0;
-            const int rc = tfgx_gemm_bias_act_cols_f32(A, lda, B + n0, ldb, bias ? bias + n0 : nullptr, act, ac_slice,
-                                                       C + n0, ldc, M, K, 128, stream_);
+            const int rc = tfgx_gemm_bias_act_cols_ws_f32(A, lda, B + n0, ldb, bias ? bias + n0 : nullptr, act, ac_slice,
+                                                          C + n0, ldc, M, K, 128, workspace, workspace_bytes, stream_);
             if (rc != TFGX_OK) return rc;
         }
         return TFGX_OK;
     }
     if (rows_ok(A, lda, M, K, N)) {
+        unsigned int* ctr = rows_tile_counter(M, workspace, workspace_bytes);
 #define TFGX_ROWS_CASE(T) \
-    case T: return launch_gemm_rows<T>(A, lda, B, ldb, bias, act, C, ldc, M, int(K), int(N), ac, stream)
+    case T: return launch_gemm_rows<T>(A, lda, B, ldb, bias, act, C, ldc, M, int(K), int(N), ac, stream, ctr)
         switch ((N + 31) / 32) {
             TFGX_ROWS_CASE(1);
             TFGX_ROWS_CASE(2);

@@ -731,7 +731,7 @@ def gemm_bias_act(a, b, bias=None, act=L.ACT_NONE, out=None, act_cols=None):
         out = torch.empty((M, N), dtype=torch.float32, device=a.device)
     _, ldc = L.row_major_2d(out)
     bias_t = None if bias is None else L.as_f32(bias).contiguous()
-    ws_bytes = lib.tfgx_gemm_workspace_bytes(M, K, N)       # > 0 only for small-M / long-K shapes (split-K)
+    ws_bytes = lib.tfgx_gemm_workspace_bytes(M, K, N)       # split-K partials (small M, long K) or the row kernel's tile counters (tall M)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device) if ws_bytes else None
     L.check(lib.tfgx_gemm_bias_act_cols_ws_f32(L.ptr(a), lda, L.ptr(b), ldb, L.ptr(bias_t), act,
                                                N if act_cols is None else int(act_cols), L.ptr(out), ldc, M, K, N,
