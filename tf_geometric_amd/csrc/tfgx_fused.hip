@@ -98,9 +98,15 @@ __device__ __forceinline__ int bcast_i(int v, int j) { return __shfl(v, j, G); }
 template <int G>
 __device__ __forceinline__ float bcast_f(float v, int j) { return __shfl(v, j, G); }
 
+#ifdef TFGX_FUSED_DEBUG
+__device__ uint64_t g_fused_wave_end[4096 * 2];     // per wave of the last launch: entry tick, exit tick (100 MHz)
+#endif
 template <int G, bool WEIGHTED>
 __global__ __launch_bounds__(kFusedThreads) void agg_gemm_kernel(const FArgs a)
 {
+#ifdef TFGX_FUSED_DEBUG
+    const uint64_t dbg_t0 = wall_clock64();
+#endif
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* Ws = lds;                                        // [KP][LDW]
     float* At = Ws + a.KP * a.LDW;                          // [kBufs][KP][kLda]
@@ -462,6 +468,15 @@ __global__ __launch_bounds__(kFusedThreads) void agg_gemm_kernel(const FArgs a)
             *reinterpret_cast<volatile int*>(ctrl + 1 + kBufs + buf) = q + 1;
         }
     }
+#ifdef TFGX_FUSED_DEBUG
+    if ((threadIdx.x & 63) == 0) {
+        const int gw = int(blockIdx.x) * (kFusedThreads / 64) + int(threadIdx.x >> 6);
+        if (gw < 4096) {
+            g_fused_wave_end[2 * gw] = dbg_t0;
+            g_fused_wave_end[2 * gw + 1] = wall_clock64();
+        }
+    }
+#endif
 }
 
 inline size_t fused_lds_bytes(int kp, int ldw)
@@ -487,6 +502,15 @@ using namespace tfgx;
 
 // 1 if tfgx_aggregate_gemm_f32 takes rows of F columns projected to N columns: the two tiles and at least 64 columns of B
 // resident in 160 KB of LDS (columns that do not fit are read from global memory / L2 by their consumer jobs)
+#ifdef TFGX_FUSED_DEBUG
+extern "C" int tfgx_debug_fused_waves(uint64_t* out, int n_waves)
+{
+    TFGX_HIP_CHECK(hipDeviceSynchronize());
+    TFGX_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(tfgx::g_fused_wave_end), sizeof(uint64_t) * 2 * size_t(n_waves)));
+    return TFGX_OK;
+}
+#endif
+
 extern "C" int tfgx_aggregate_gemm_fits(int64_t F, int64_t N)
 {
     if (F < 4 || F > 128 || F % 4 != 0 || N < 1 || N > 256) return 0;
