@@ -9,8 +9,7 @@ import torch
 
 from ... import _lib as L
 from ...activations import resolve as _resolve_act
-from ...plan import (segment_reduce, gemm_bias_act, static_rows, static_aggregate, gather_friendly_empty, aggregate_gemm,
-                     SplitRows)
+from ...plan import segment_reduce, gemm_bias_act, static_rows, static_aggregate, gather_friendly_empty, aggregate_gemm
 from ...sparse import SparseMatrix, sparse_features, sparse_dense_matmul
 from ... import autograd as AG
 

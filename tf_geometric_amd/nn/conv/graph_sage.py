@@ -15,7 +15,7 @@ import torch
 from ... import _lib as L
 from ...activations import resolve as _resolve_act
 from ...plan import (CsrPlan, segment_reduce, gemm_bias_act, l2_normalize_rows_, static_rows,
-                     static_aggregate, static_aggregate_applies, gather_friendly_empty, aggregate_gemm, SplitRows)
+                     static_aggregate, static_aggregate_applies, gather_friendly_empty, aggregate_gemm)
 from ...sparse import SparseMatrix
 from .gcn import gcn_norm_adj
 from ... import autograd as AG

@@ -7,7 +7,6 @@ import os
 import sys
 import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
 import torch
 import tf_geometric_amd as tfg
 from tf_geometric_amd import synthetic, _lib as L

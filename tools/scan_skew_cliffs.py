@@ -9,7 +9,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import tf_geometric_amd as tfg
 from tf_geometric_amd import synthetic, _lib as L
-import bench
 
 n, e, f = 1 << 20, 30000000, 64
 
