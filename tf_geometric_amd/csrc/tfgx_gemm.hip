@@ -34,7 +34,10 @@ constexpr int BK = 16;   // 16 keeps load-staging registers low enough for 3 wor
 #define TFGX_ROWS_EXPERIMENT 0    // developer experiments on the row kernel's epilogue (1: no stores, 2: stores into a small window) — results INVALID
 #endif
 #ifndef TFGX_ROWS_VEC_STORE
-#define TFGX_ROWS_VEC_STORE 1     // 16-byte epilogue stores of the row kernel through a quad transpose of the accumulators
+#define TFGX_ROWS_VEC_STORE 0     // 16-byte epilogue stores through a quad transpose of the accumulators: +4..9 % while every store carried
+                                  // its own 64-bit address arithmetic; once the addresses moved off the vector ALU the 65 VALU ops per
+                                  // 32 x 32 block of the transpose cost more than 96 fewer store instructions save (2.4 M x 100 -> 256:
+                                  // 1.20 -> 1.155 ms, 170 k x 128 -> 256: 0.121 -> 0.113 without it) — kept as a switch
 #endif
 #ifndef TFGX_ROWS_STAGGER
 #define TFGX_ROWS_STAGGER 0
@@ -307,7 +310,7 @@ __global__ __launch_bounds__(kBlock) void gemm_kernel(const float* __restrict__ 
 constexpr int kRowsCounterStride = 32;          // uints between the per-slot tile counters (one 128-byte line each)
 constexpr int kRowsCounterSlots = 16;           // >= waves per workgroup of any row kernel
 #if TFGX_ROWS_EXPERIMENT == 3
-__device__ uint64_t g_rows_dbg[12];
+__device__ uint64_t g_rows_dbg[16];     // [12]: cycles inside the MFMA groups of full steps, [13]: cycles in epilogues
 __device__ uint64_t g_rows_wave[4096 * 4];   // per wave of the LAST launch: loop start tick, loop end tick, tiles, hw id     // loop cycles, loop 100 MHz ticks, tiles, waves, max / min loop ticks of a wave, prologue ticks, max end tick - min start tick
 #endif
 template <int TN, int NG>
@@ -427,21 +430,40 @@ __global__ __launch_bounds__(rows_threads<TN>()) void gemm_rows_kernel(const flo
 #if TFGX_ROWS_PF2
     float nx2[16];
 #endif
+    // ADDRESSES.  In-kernel clocks (TFGX_ROWS_EXPERIMENT=3: cycles inside the MFMA groups / in the epilogue / elsewhere)
+    // showed a wave spending a third of every tile OUTSIDE its MFMA groups, at ~38 cycles per VALU instruction: while the other
+    // wave of the SIMD streams MFMAs, a vector ALU instruction gets an issue slot only now and then, and when both waves are
+    // in such a stretch the MFMA port idles.  So the per-step and per-store address arithmetic is kept off the vector ALU:
+    // every global address is  (wave-uniform 64-bit base, SALU)  +  (per-lane 32-bit byte offset, computed ONCE)  +  immediate
+    // — the saddr form of global_load / global_store.  The tile index is made provably uniform with readfirstlane.
+    const uint32_t a_off_full = uint32_t((int64_t(l31) * lda + 16 * kh) * 4);
+    const int64_t last_tile = n_tiles - 1;
+    const uint32_t a_off_last = uint32_t((min(int64_t(l31), M - 1 - last_tile * 32) * lda + 16 * kh) * 4);   // rows clamped to M - 1
     auto load_a = [&](float (&r)[16], int64_t t, int ks) {
-        const int64_t gm = min(t * 32 + l31, M - 1);
-        const int kb = ks * 32 + (ks < nfull ? 16 : half_t) * kh;
-        const float* p = A + gm * lda;
+        const int64_t tc = t < last_tile ? t : last_tile;        // past the end: a harmless re-read of the last tile (uniform)
+        if (ks < nfull) {                                        // uniform
+            const char* base = reinterpret_cast<const char*>(A + tc * 32 * lda + ks * 32);
+            const uint32_t off = tc == last_tile ? a_off_last : a_off_full;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-#if TFGX_ROWS_NT_LOAD
-            const f32x4_a8 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_a8*>(p + min(kb + 4 * u, K - 4)));
-#else
-            const f32x4_a8 v = *reinterpret_cast<const f32x4_a8*>(p + min(kb + 4 * u, K - 4));
-#endif
-            r[4 * u + 0] = v[0];
-            r[4 * u + 1] = v[1];
-            r[4 * u + 2] = v[2];
-            r[4 * u + 3] = v[3];
+            for (int u = 0; u < 4; ++u) {
+                const f32x4_a8 v = *reinterpret_cast<const f32x4_a8*>(base + off + 16 * u);
+                r[4 * u + 0] = v[0];
+                r[4 * u + 1] = v[1];
+                r[4 * u + 2] = v[2];
+                r[4 * u + 3] = v[3];
+            }
+        } else {                                                 // the tail step (K % 32 != 0), once per tile: per-lane clamps
+            const int64_t gm = min(tc * 32 + l31, M - 1);
+            const int kb = ks * 32 + half_t * kh;
+            const float* p = A + gm * lda;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const f32x4_a8 v = *reinterpret_cast<const f32x4_a8*>(p + min(kb + 4 * u, K - 4));
+                r[4 * u + 0] = v[0];
+                r[4 * u + 1] = v[1];
+                r[4 * u + 2] = v[2];
+                r[4 * u + 3] = v[3];
+            }
         }
     };
 
@@ -475,7 +497,9 @@ __global__ __launch_bounds__(rows_threads<TN>()) void gemm_rows_kernel(const flo
         if (lane == 0) next_raw = atomicAdd(tile_counter + kRowsCounterStride * pool, 1u);
     };
     auto next_of = [&](int64_t t) -> int64_t {
-        return tile_counter ? int64_t(uint32_t(__builtin_amdgcn_readfirstlane(int(next_raw)))) * kRowsCounterSlots + pool : t + stride;
+        return tile_counter ? int64_t(uint32_t(__builtin_amdgcn_readfirstlane(int(next_raw)))) * kRowsCounterSlots +
+                                  __builtin_amdgcn_readfirstlane(pool)
+                            : t + stride;
     };
     auto adv = [&](int64_t& t, int& ks) {
         const bool same = ks + 1 < nsteps;
@@ -506,11 +530,13 @@ __global__ __launch_bounds__(rows_threads<TN>()) void gemm_rows_kernel(const flo
     // instructions give back (+3 .. 4 %), so narrow outputs keep the per-column stores
     const bool vec_store = TN >= 5 && (N % 4 == 0) && (ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
 #endif
+    const uint32_t c_off = uint32_t((int64_t(4 * kh) * ldc + l31) * 4);                               // per-column stores: row 4 kh, column l31
+    const uint32_t c_off_vec = uint32_t((int64_t((lane & 3) + 4 * kh) * ldc + (l31 >> 2) * 4) * 4);   // 16-byte stores: row (lane & 3) + 4 kh
     float bv[TN];   // this lane's bias values, loaded once (a per-tile load would put a memory round trip in every epilogue)
 #pragma unroll
     for (int j = 0; j < TN; ++j) bv[j] = (bias && j * 32 + l31 < N) ? bias[j * 32 + l31] : 0.0f;
 
-    int64_t tile = int64_t(blockIdx.x) * (NT / 64) + wave;
+    int64_t tile = int64_t(blockIdx.x) * (NT / 64) + __builtin_amdgcn_readfirstlane(wave);
     if (tile_counter) {
         claim();
         tile = next_of(0);
@@ -571,7 +597,7 @@ __global__ __launch_bounds__(rows_threads<TN>()) void gemm_rows_kernel(const flo
     // instrumented build (results valid, timing perturbed by four scalar reads per wave): shader-clock cycles and constant
     // 100 MHz ticks spent inside the tile loop, summed over waves -> tfgx_debug_rows_stats
     const uint64_t dbg_c0 = __builtin_readcyclecounter(), dbg_w0 = wall_clock64();
-    uint64_t dbg_tiles = 0;
+    uint64_t dbg_tiles = 0, dbg_mf = 0, dbg_ep = 0;
 #endif
     while (tile < n_tiles) {
 #if TFGX_ROWS_EXPERIMENT == 3
@@ -579,7 +605,13 @@ __global__ __launch_bounds__(rows_threads<TN>()) void gemm_rows_kernel(const flo
 #endif
         for (int ks = 0; ks < nfull; ++ks) {
             prefetch(tile, ks);
+#if TFGX_ROWS_EXPERIMENT == 3
+            const uint64_t dbg_a = __builtin_readcyclecounter();
+#endif
             rows_mfma_groups<TN, 16>(acc, cur, Bs + (ks * 32 + 16 * kh) * LDB_S + l31);
+#if TFGX_ROWS_EXPERIMENT == 3
+            dbg_mf += __builtin_readcyclecounter() - dbg_a;
+#endif
             rotate();
             if (kTwoLevel) {
                 if (two_level && (ks & 1)) {
@@ -624,13 +656,18 @@ __global__ __launch_bounds__(rows_threads<TN>()) void gemm_rows_kernel(const flo
                     }
             }
         }
+#if TFGX_ROWS_EXPERIMENT == 3
+        const uint64_t dbg_e0 = __builtin_readcyclecounter();
+#endif
         // epilogue (D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)); bias + activation in
         // place first, then stores straight from the accumulator registers (see gemm_kernel's epilogue note)
+        if (bias != nullptr || act != TFGX_ACT_NONE) {           // uniform: a plain x @ W (the h = x W of a GCN layer) skips 32 TN VALU ops
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int a_j = j * 32 + l31 < act_cols ? act : TFGX_ACT_NONE;
+            for (int j = 0; j < TN; ++j) {
+                const int a_j = j * 32 + l31 < act_cols ? act : TFGX_ACT_NONE;
 #pragma unroll
-            for (int t = 0; t < 16; ++t) acc[j][t] = apply_act(acc[j][t] + bv[j], a_j);
+                for (int t = 0; t < 16; ++t) acc[j][t] = apply_act(acc[j][t] + bv[j], a_j);
+            }
         }
 #if TFGX_ROWS_EXPERIMENT == 2
         const int64_t r0 = (tile & 127) * 32 + 4 * kh;      // experiment: every tile's stores land in the same 4096 rows (cache-resident)
@@ -641,9 +678,9 @@ __global__ __launch_bounds__(rows_threads<TN>()) void gemm_rows_kernel(const flo
         if (vec_store && tile * 32 + 32 <= M) {
             // 16-byte stores: quad-transposed accumulators (see quad_transpose4).  Register group g = t >> 2 holds rows
             // 8 g + (t & 3) + 4 kh; after the transpose lane i of a quad owns row 8 g + i + 4 kh, columns 4 q .. 4 q + 3
-            const int qi = lane & 3, qc = (l31 >> 2) * 4;
-            float* const cb = C + (tile * 32 + qi + 4 * kh) * ldc + qc;      // ONE 64-bit multiply per tile; the rest are adds
-            const int64_t ldc8 = 8 * ldc;
+            const int qc = (l31 >> 2) * 4;
+            char* const cb = reinterpret_cast<char*>(C + tile * 32 * ldc);     // uniform; row 8 g is a scalar add, column block j an immediate
+            const int64_t ldc8b = 32 * ldc;                                     // 8 rows in bytes
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 float r4[4][4];
@@ -654,10 +691,9 @@ __global__ __launch_bounds__(rows_threads<TN>()) void gemm_rows_kernel(const flo
                     quad_transpose4(r4[g], lane);
                 }
                 if (j * 32 + qc < N) {                         // N % 4 == 0 on this path: the four columns are valid together
-                    float* cj = cb + j * 32;
 #pragma unroll
                     for (int g = 0; g < 4; ++g)
-                        *reinterpret_cast<f32x4*>(cj + g * ldc8) = f32x4{r4[g][0], r4[g][1], r4[g][2], r4[g][3]};
+                        *reinterpret_cast<f32x4*>(cb + g * ldc8b + c_off_vec + j * 128) = f32x4{r4[g][0], r4[g][1], r4[g][2], r4[g][3]};
                 }
             }
         } else
@@ -671,15 +707,10 @@ __global__ __launch_bounds__(rows_threads<TN>()) void gemm_rows_kernel(const flo
 #else
                 if (gn < N) {
 #endif
-                    float* cp = C + r0 * ldc + gn;
+                    char* const cb = reinterpret_cast<char*>(C + (r0 - 4 * kh) * ldc);      // uniform (r0 - 4 kh = the tile's first row)
 #pragma unroll
-                    for (int t = 0; t < 16; ++t) {
-#if TFGX_ROWS_NT_STORE
-                        __builtin_nontemporal_store(acc[j][t], cp + int64_t((t & 3) + 8 * (t >> 2)) * ldc);
-#else
-                        cp[int64_t((t & 3) + 8 * (t >> 2)) * ldc] = acc[j][t];
-#endif
-                    }
+                    for (int t = 0; t < 16; ++t)
+                        *reinterpret_cast<float*>(cb + int64_t((t & 3) + 8 * (t >> 2)) * ldc * 4 + c_off + j * 128) = acc[j][t];
                 }
             }
         } else {
@@ -697,6 +728,9 @@ __global__ __launch_bounds__(rows_threads<TN>()) void gemm_rows_kernel(const flo
             }
         }
         zero_acc();
+#if TFGX_ROWS_EXPERIMENT == 3
+        dbg_ep += __builtin_readcyclecounter() - dbg_e0;
+#endif
         tile = next_of(tile);                  // dynamic: the claim issued a tile ago
         if (tile_counter) claim();             // ... and the one for the tile after the next
     }
@@ -705,6 +739,8 @@ __global__ __launch_bounds__(rows_threads<TN>()) void gemm_rows_kernel(const flo
         atomicAdd(reinterpret_cast<unsigned long long*>(&g_rows_dbg[0]), (unsigned long long)(__builtin_readcyclecounter() - dbg_c0));
         atomicAdd(reinterpret_cast<unsigned long long*>(&g_rows_dbg[1]), (unsigned long long)(wall_clock64() - dbg_w0));
         atomicAdd(reinterpret_cast<unsigned long long*>(&g_rows_dbg[2]), (unsigned long long)dbg_tiles);
+        atomicAdd(reinterpret_cast<unsigned long long*>(&g_rows_dbg[12]), (unsigned long long)dbg_mf);
+        atomicAdd(reinterpret_cast<unsigned long long*>(&g_rows_dbg[13]), (unsigned long long)dbg_ep);
         atomicAdd(reinterpret_cast<unsigned long long*>(&g_rows_dbg[3]), 1ull);
         const unsigned long long w1 = wall_clock64();
         atomicMax(reinterpret_cast<unsigned long long*>(&g_rows_dbg[4]), (unsigned long long)(w1 - dbg_w0));
@@ -1238,6 +1274,7 @@ int launch_gemm_rows(const float* A, int64_t lda, const float* B, int64_t ldb, c
 inline bool rows_ok(const float* A, int64_t lda, int64_t M, int64_t K, int64_t N)
 {
     if (N < 1 || N > 256 || K < 32 || K % 4 != 0 || lda % 4 != 0 || !aligned_to(A, 16) || M < 128 * 256) return false;
+    if (lda >= (int64_t(1) << 25)) return false;          // per-lane byte offsets of the kernel are 32-bit (32 rows x lda x 4)
     return rows_lds_bytes(K, int((N + 31) / 32)) <= 160 * 1024;
 }
 
@@ -1326,7 +1363,7 @@ static inline int64_t generic_tiles(int64_t M, int64_t N)
 // developer build only: read and clear the row kernel's in-kernel clocks (see gemm_rows_kernel)
 extern "C" int tfgx_debug_rows_stats(uint64_t* out4)
 {
-    uint64_t z[12] = {0, 0, 0, 0, 0, ~0ull, 0, 0, ~0ull, 0, ~0ull, 0};
+    uint64_t z[16] = {0, 0, 0, 0, 0, ~0ull, 0, 0, ~0ull, 0, ~0ull, 0, 0, 0, 0, 0};
     TFGX_HIP_CHECK(hipDeviceSynchronize());
     TFGX_HIP_CHECK(hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_rows_dbg), sizeof(z)));
     TFGX_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_rows_dbg), z, sizeof(z)));
@@ -1384,7 +1421,8 @@ extern "C" int tfgx_gemm_bias_act_cols_ws_f32(const float* A, int64_t lda, const
     const int ac = int(act_cols);
     // K * N too large for LDS but a column slice fits (hidden -> hidden, 256 -> 256): run the row-streaming kernel once
     // per slice of 128 columns.  A is streamed once per slice; at these widths the MFMA time still dominates.
-    if (N > 128 && N <= 512 && N % 128 == 0 && !rows_ok(A, lda, M, K, N) && rows_ok(A, lda, M, K, 128)) {
+    const bool ldc_ok = ldc < (int64_t(1) << 25);          // same for the stores (36 rows x ldc x 4)
+    if (ldc_ok && N > 128 && N <= 512 && N % 128 == 0 && !rows_ok(A, lda, M, K, N) && rows_ok(A, lda, M, K, 128)) {
         for (int64_t n0 = 0; n0 < N; n0 += 128) {
             const int64_t ac_slice = act_cols > n0 ? (act_cols - n0 < 128 ? act_cols - n0 : 128) : 0;
             const int rc = tfgx_gemm_bias_act_cols_ws_f32(A, lda, B + n0, ldb, bias ? bias + n0 : nullptr, act, ac_slice,
@@ -1393,7 +1431,7 @@ extern "C" int tfgx_gemm_bias_act_cols_ws_f32(const float* A, int64_t lda, const
         }
         return TFGX_OK;
     }
-    if (rows_ok(A, lda, M, K, N)) {
+    if (ldc_ok && rows_ok(A, lda, M, K, N)) {
         unsigned int* ctr = rows_tile_counter(M, workspace, workspace_bytes);
 #define TFGX_ROWS_CASE(T) \
     case T: return launch_gemm_rows<T>(A, lda, B, ldb, bias, act, C, ldc, M, int(K), int(N), ac, stream, ctr)

@@ -21,7 +21,7 @@ lib = L.require_gpu()
 fn = lib.tfgx_debug_rows_stats
 fn.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
 fn.restype = ctypes.c_int
-buf = (ctypes.c_uint64 * 12)()
+buf = (ctypes.c_uint64 * 16)()
 g = torch.Generator(device="cuda")
 g.manual_seed(0)
 for M, K, N in [(2400000, 256, 128), (2400000, 100, 128), (2400000, 128, 256), (2400000, 100, 256), (2400000, 256, 40)]:
@@ -39,7 +39,7 @@ for M, K, N in [(2400000, 256, 128), (2400000, 100, 128), (2400000, 128, 256), (
     e1.record()
     torch.cuda.synchronize()
     fn(buf)
-    cyc, ticks, tiles, waves, tmax, tmin, tpro, tspan, k0, k1, e0_, e1_ = [int(v) for v in buf]
+    cyc, ticks, tiles, waves, tmax, tmin, tpro, tspan, k0, k1, e0_, e1_, cmf, cep = [int(v) for v in buf][:14]
     tn = (N + 31) // 32
     groups = (K // 32) * 16 + (K % 32) // 2
     ideal = groups * tn * 64
@@ -50,4 +50,7 @@ for M, K, N in [(2400000, 256, 128), (2400000, 100, 128), (2400000, 128, 256), (
                       "loop_us_avg_min_max": [ticks / waves / 100.0, tmin / 100.0, tmax / 100.0], "prologue_us_avg": tpro / waves / 100.0,
                       "wave_start_to_end_us_max": tspan / 100.0,
                       "kernel_entry_skew_us": (k1 - k0) / 100.0, "loop_end_skew_us": (e1_ - e0_) / 100.0,
-                      "first_entry_to_last_end_us": (e1_ - k0) / 100.0}), flush=True)
+                      "first_entry_to_last_end_us": (e1_ - k0) / 100.0,
+                      "cycles_per_tile_in_full_step_mfma_groups": cmf / tiles, "cycles_per_tile_in_epilogue": cep / tiles,
+                      "cycles_per_tile_elsewhere": (cyc - cmf - cep) / tiles,
+                      "cycles_per_mfma_inside_groups_per_wave": cmf / tiles / ((K // 32) * 16 * tn)}), flush=True)
