@@ -313,8 +313,29 @@ constexpr int kRowsCounterSlots = 16;           // >= waves per workgroup of any
 __device__ uint64_t g_rows_dbg[16];     // [12]: cycles inside the MFMA groups of full steps, [13]: cycles in epilogues
 __device__ uint64_t g_rows_wave[4096 * 4];   // per wave of the LAST launch: loop start tick, loop end tick, tiles, hw id     // loop cycles, loop 100 MHz ticks, tiles, waves, max / min loop ticks of a wave, prologue ticks, max end tick - min start tick
 #endif
-template <int TN, int NG>
-__device__ __forceinline__ void rows_mfma_groups(f32x16 (&acc)[TN], const float* a, const float* b_s)
+// One LDS dword as ONE ds_read_b32 with a 16-bit immediate offset.  A plain load lets the backend pair neighbours into
+// ds_read2_b32, whose two 8-bit offsets reach only 1020 bytes: the 16 B rows of a k-step lie 9 KB apart, so it paid a
+// v_add_u32 per pair — 13 vector-ALU instructions per step that the MFMA stream of the SIMD's other wave starves.  A relaxed
+// wavefront-scope atomic load is never merged and costs nothing else (no fence, same instruction).
+#ifndef TFGX_ROWS_LDS_SINGLE
+#define TFGX_ROWS_LDS_SINGLE 1     // developer A/B: 0 = plain loads (the backend pairs them into ds_read2_b32 + v_add_u32)
+#endif
+#ifndef TFGX_ROWS_ZERO_FIRST
+#define TFGX_ROWS_ZERO_FIRST 1     // developer A/B: 0 = accumulators zeroed with v_mov before every tile
+#endif
+__device__ __forceinline__ float lds_read_f32(const float* p)
+{
+#if TFGX_ROWS_LDS_SINGLE
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#else
+    return *p;
+#endif
+}
+
+// ZERO_FIRST: the first group multiplies into a literal zero (the MFMA's C operand as an inline constant) — a tile's first
+// step then needs no zeroed accumulators (16 TN v_mov per tile otherwise).
+template <int TN, int NG, bool ZERO_FIRST = false, class AOF>
+__device__ __forceinline__ void rows_mfma_groups(f32x16 (&acc)[TN], AOF a_of, const float* b_s)
 {
     constexpr int LDB_S = TN * 32 + 8;
     constexpr int AH = TFGX_ROWS_LDS_AHEAD, NB = AH + 1;
@@ -323,17 +344,24 @@ __device__ __forceinline__ void rows_mfma_groups(f32x16 (&acc)[TN], const float*
     for (int p = 0; p < AH; ++p)
         if (p < NG) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bb[p][j] = b_s[p * LDB_S + j * 32];
+            for (int j = 0; j < TN; ++j) bb[p][j] = lds_read_f32(b_s + p * LDB_S + j * 32);
         }
 #pragma unroll
     for (int i = 0; i < NG; ++i) {
         if (i + AH < NG) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bb[(i + AH) % NB][j] = b_s[(i + AH) * LDB_S + j * 32];
+            for (int j = 0; j < TN; ++j) bb[(i + AH) % NB][j] = lds_read_f32(b_s + (i + AH) * LDB_S + j * 32);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[i % NB][j], acc[j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j) {
+            if (ZERO_FIRST && TFGX_ROWS_ZERO_FIRST && i == 0) {
+                const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_of(i), bb[i % NB][j], zero, 0, 0, 0);
+            } else {
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_of(i), bb[i % NB][j], acc[j], 0, 0, 0);
+            }
+        }
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -423,54 +451,75 @@ __global__ __launch_bounds__(rows_threads<TN>()) void gemm_rows_kernel(const flo
     // values that are never stored; the tail step accounts for its own clamped vector.
     typedef float f32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
     const int half_t = (K - nfull * 32) >> 1;
-#ifndef TFGX_ROWS_PF2
-#define TFGX_ROWS_PF2 0                // developer A/B: A rows prefetched two steps ahead instead of one
-#endif
-    float cur[16], nxt[16];
-#if TFGX_ROWS_PF2
-    float nx2[16];
-#endif
+    // the A registers of a step, kept as the four 16-byte vectors they are loaded as: the per-step hand-over (cur = nxt) then
+    // costs 8 64-bit moves instead of 16 v_mov_b32 (every vector-ALU instruction here waits ~38 cycles for an issue slot)
+    f32x4 cur[4], nxt[4];
     // ADDRESSES.  In-kernel clocks (TFGX_ROWS_EXPERIMENT=3: cycles inside the MFMA groups / in the epilogue / elsewhere)
     // showed a wave spending a third of every tile OUTSIDE its MFMA groups, at ~38 cycles per VALU instruction: while the other
     // wave of the SIMD streams MFMAs, a vector ALU instruction gets an issue slot only now and then, and when both waves are
     // in such a stretch the MFMA port idles.  So the per-step and per-store address arithmetic is kept off the vector ALU:
     // every global address is  (wave-uniform 64-bit base, SALU)  +  (per-lane 32-bit byte offset, computed ONCE)  +  immediate
     // — the saddr form of global_load / global_store.  The tile index is made provably uniform with readfirstlane.
-    const uint32_t a_off_full = uint32_t((int64_t(l31) * lda + 16 * kh) * 4);
+    // (implemented with RAW BUFFER loads / stores: a 128-bit resource descriptor in SGPRs — base and extent, rebuilt per tile
+    // with scalar instructions — a per-lane 32-bit byte offset computed ONCE per launch, a scalar offset and an immediate.
+    // Reads past the descriptor's extent return 0 and touch no memory: rows >= M of the last tile and the prefetch past the
+    // last tile need no clamps.)
+    constexpr int kRsrcFlags = 0x00020000;                       // raw buffer, dword data format (gfx9 family): the stores' descriptor
+#ifndef TFGX_ROWS_BUFFER_LOADS
+#define TFGX_ROWS_BUFFER_LOADS 0   // developer A/B: 1 = A rows through raw buffer loads too.  Same-box A/B: K = 100 / 128 gain 1-2 %,
+                                   // K = 256 loses 4-10 % (2.4 M x 256 -> 40: 0.717 -> 0.790 ms) — global loads in saddr form stay
+#endif
+    const uint32_t a_voff = uint32_t((int64_t(l31) * lda + 16 * kh) * 4);
     const int64_t last_tile = n_tiles - 1;
-    const uint32_t a_off_last = uint32_t((min(int64_t(l31), M - 1 - last_tile * 32) * lda + 16 * kh) * 4);   // rows clamped to M - 1
-    auto load_a = [&](float (&r)[16], int64_t t, int ks) {
-        const int64_t tc = t < last_tile ? t : last_tile;        // past the end: a harmless re-read of the last tile (uniform)
-        if (ks < nfull) {                                        // uniform
-            const char* base = reinterpret_cast<const char*>(A + tc * 32 * lda + ks * 32);
-            const uint32_t off = tc == last_tile ? a_off_last : a_off_full;
+    const uint32_t a_voff_last = uint32_t((min(int64_t(l31), M - 1 - last_tile * 32) * lda + 16 * kh) * 4);   // rows clamped to M - 1
+#if TFGX_ROWS_BUFFER_LOADS
+    // the tail step (K % 32 != 0): the half-waves split the K % 32 remaining k, vectors clamped to stay inside the row
+    uint32_t a_voff_tail[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const f32x4_a8 v = *reinterpret_cast<const f32x4_a8*>(base + off + 16 * u);
-                r[4 * u + 0] = v[0];
-                r[4 * u + 1] = v[1];
-                r[4 * u + 2] = v[2];
-                r[4 * u + 3] = v[3];
-            }
-        } else {                                                 // the tail step (K % 32 != 0), once per tile: per-lane clamps
+    for (int u = 0; u < 4; ++u) a_voff_tail[u] = uint32_t((int64_t(l31) * lda + min(nfull * 32 + half_t * kh + 4 * u, K - 4)) * 4);
+#endif
+    auto load_a = [&](f32x4 (&r)[4], int64_t t, int ks) {
+#if TFGX_ROWS_BUFFER_LOADS
+        // reads past the descriptor's extent return 0 and touch no memory: rows >= M of the last tile and the prefetch past the
+        // last tile need no clamps
+        const int64_t rows_left = M - t * 32;                                    // <= 0 past the last tile
+        const int64_t bytes = rows_left > 0 ? rows_left * lda * 4 : 0;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(A + (rows_left > 0 ? t : 0) * 32 * lda), 0, int(bytes < 0x7fffffff ? bytes : 0x7fffffff), kRsrcFlags);
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+        if (ks < nfull) {                                                        // uniform
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                r[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, a_voff + 16 * u, ks * 128, 0));
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                r[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, a_voff_tail[u], 0, 0));
+        }
+#else
+        // global loads in saddr form: (uniform 64-bit base) + (per-lane 32-bit byte offset) + immediate.  Past the end the last
+        // tile is re-read (harmless); its rows >= M are clamped to M - 1 through the per-lane offset (values never stored)
+        const int64_t tc = t < last_tile ? t : last_tile;                        // uniform
+        if (ks < nfull) {                                                        // uniform
+            const char* base = reinterpret_cast<const char*>(A + tc * 32 * lda + ks * 32);
+            const uint32_t off = tc == last_tile ? a_voff_last : a_voff;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) r[u] = *reinterpret_cast<const f32x4_a8*>(base + off + 16 * u);
+        } else {
+            // the tail step, once per tile: per-lane 64-bit addresses with their clamps (written differently from the branch
+            // above ON PURPOSE: two branches of the same shape get merged into one per-lane address computation, and the
+            // full steps lose the saddr form)
             const int64_t gm = min(tc * 32 + l31, M - 1);
             const int kb = ks * 32 + half_t * kh;
             const float* p = A + gm * lda;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const f32x4_a8 v = *reinterpret_cast<const f32x4_a8*>(p + min(kb + 4 * u, K - 4));
-                r[4 * u + 0] = v[0];
-                r[4 * u + 1] = v[1];
-                r[4 * u + 2] = v[2];
-                r[4 * u + 3] = v[3];
-            }
+            for (int u = 0; u < 4; ++u) r[u] = *reinterpret_cast<const f32x4_a8*>(p + min(kb + 4 * u, K - 4));
         }
+#endif
     };
 
-    // zero_acc: the empty asm makes the zeroed accumulators opaque register values.  Without it the compiler treats
-    // them as constants, keeps a second, permanently zero accumulator set alive across the tile loop and writes the
-    // first MFMA of each tile into a different register set (twice the accumulator registers, spills at TN = 8).
-    f32x16 acc[TN];
+    f32x16 acc[TN];       // never zeroed: a tile's first MFMA group takes a literal zero as its C operand (ZERO_FIRST)
+#if !TFGX_ROWS_ZERO_FIRST
     auto zero_acc = [&]() {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -480,6 +529,7 @@ __global__ __launch_bounds__(rows_threads<TN>()) void gemm_rows_kernel(const flo
         }
     };
     zero_acc();
+#endif
     // branch-free on purpose (see load_a): past the last tile the row clamp turns this into a harmless re-read
     // DYNAMIC tile order (tile_counter != nullptr): every wave claims its tiles from one device counter, one tile ahead — the
     // claim is ISSUED at the top of a tile and its value first READ at that tile's last k-step, where the next tile's A rows
@@ -508,20 +558,11 @@ __global__ __launch_bounds__(rows_threads<TN>()) void gemm_rows_kernel(const flo
     };
     auto prefetch = [&](int64_t t, int ks) {
         adv(t, ks);
-#if TFGX_ROWS_PF2
-        adv(t, ks);
-        load_a(nx2, t, ks);
-#else
         load_a(nxt, t, ks);
-#endif
     };
     auto rotate = [&]() {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) cur[i] = nxt[i];
-#if TFGX_ROWS_PF2
-#pragma unroll
-        for (int i = 0; i < 16; ++i) nxt[i] = nx2[i];
-#endif
+        for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
     };
 
 #if TFGX_ROWS_VEC_STORE
@@ -569,19 +610,11 @@ __global__ __launch_bounds__(rows_threads<TN>()) void gemm_rows_kernel(const flo
     }
 #endif
     if (tile < n_tiles) load_a(cur, tile, 0);
-#if TFGX_ROWS_PF2
-    if (tile < n_tiles) {
-        int64_t t1 = tile;
-        int k1 = 0;
-        adv(t1, k1);
-        load_a(nxt, t1, k1);
-    }
-#endif
     // Consume the first A registers here so their wait sits in front of the loop.  Otherwise every step carries a
     // "first iteration" vmcnt wait; harmless in steady state (only the 4 prefetch loads are in flight), but right after an
     // epilogue the 16 * TN stores are in flight too and that wait stalls the wave until they have drained.
 #pragma unroll
-    for (int u = 0; u < 4; ++u) asm volatile("" ::"v"(cur[4 * u]));
+    for (int u = 0; u < 4; ++u) asm volatile("" ::"v"(cur[u]));
     // narrow outputs with a long K (TN <= 2, K > 128): two-level accumulation like gemm_kernel's narrow tiles — the chain
     // is flushed into `tot` every 64 k (2 steps), rounding error ~ eps * sqrt(64 K) instead of ~ eps * K
     constexpr bool kTwoLevel = TN <= 2;
@@ -597,22 +630,43 @@ __global__ __launch_bounds__(rows_threads<TN>()) void gemm_rows_kernel(const flo
     // instrumented build (results valid, timing perturbed by four scalar reads per wave): shader-clock cycles and constant
     // 100 MHz ticks spent inside the tile loop, summed over waves -> tfgx_debug_rows_stats
     const uint64_t dbg_c0 = __builtin_readcyclecounter(), dbg_w0 = wall_clock64();
-    uint64_t dbg_tiles = 0, dbg_mf = 0, dbg_ep = 0;
+    uint64_t dbg_tiles = 0, dbg_mf = 0, dbg_ep = 0, dbg_h0 = 0, dbg_h1 = 0;
 #endif
     while (tile < n_tiles) {
 #if TFGX_ROWS_EXPERIMENT == 3
         ++dbg_tiles;
 #endif
-        for (int ks = 0; ks < nfull; ++ks) {
+        {   // the tile's first step (K >= 32: there always is one) starts the accumulators from a literal zero
+            prefetch(tile, 0);
+#if TFGX_ROWS_EXPERIMENT == 3
+            const uint64_t dbg_a = __builtin_readcyclecounter();
+#endif
+            rows_mfma_groups<TN, 16, true>(acc, [&](int i) { return cur[i >> 2][i & 3]; }, Bs + 16 * kh * LDB_S + l31);
+#if TFGX_ROWS_EXPERIMENT == 3
+            const uint64_t dbg_b = __builtin_readcyclecounter();
+            dbg_mf += dbg_b - dbg_a;
+#endif
+            rotate();
+#if TFGX_ROWS_EXPERIMENT == 3
+            asm volatile("" ::"v"(cur[0]), "v"(cur[1]), "v"(cur[2]), "v"(cur[3]));
+            dbg_h0 += __builtin_readcyclecounter() - dbg_b;          // hand-over after the tile's FIRST step (loads issued after the stores)
+#endif
+        }
+        for (int ks = 1; ks < nfull; ++ks) {
             prefetch(tile, ks);
 #if TFGX_ROWS_EXPERIMENT == 3
             const uint64_t dbg_a = __builtin_readcyclecounter();
 #endif
-            rows_mfma_groups<TN, 16>(acc, cur, Bs + (ks * 32 + 16 * kh) * LDB_S + l31);
+            rows_mfma_groups<TN, 16>(acc, [&](int i) { return cur[i >> 2][i & 3]; }, Bs + (ks * 32 + 16 * kh) * LDB_S + l31);
 #if TFGX_ROWS_EXPERIMENT == 3
-            dbg_mf += __builtin_readcyclecounter() - dbg_a;
+            const uint64_t dbg_b = __builtin_readcyclecounter();
+            dbg_mf += dbg_b - dbg_a;
 #endif
             rotate();
+#if TFGX_ROWS_EXPERIMENT == 3
+            asm volatile("" ::"v"(cur[0]), "v"(cur[1]), "v"(cur[2]), "v"(cur[3]));
+            dbg_h1 += __builtin_readcyclecounter() - dbg_b;          // hand-over after the other steps
+#endif
             if (kTwoLevel) {
                 if (two_level && (ks & 1)) {
 #pragma unroll
@@ -635,12 +689,13 @@ __global__ __launch_bounds__(rows_threads<TN>()) void gemm_rows_kernel(const flo
                 if (2 * q < half_t) {
                     // When T/2 % 4 == 2 the kh = 1 half's last vector would start at K - 2; load_a clamped it to K - 4,
                     // so the two values it needs sit in elements 2, 3 instead of 0, 1.
-                    float a[2] = {cur[2 * q], cur[2 * q + 1]};
+                    auto c = [&](int i) { return cur[i >> 2][i & 3]; };
+                    float a[2] = {c(2 * q), c(2 * q + 1)};
                     if (q % 2 == 0 && kh == 1 && 2 * q + 2 == half_t) {
-                        a[0] = cur[2 * q + 2];
-                        a[1] = cur[2 * q + 3];
+                        a[0] = c(2 * q + 2);
+                        a[1] = c(2 * q + 3);
                     }
-                    rows_mfma_groups<TN, 2>(acc, a, b_s + 2 * q * LDB_S);
+                    rows_mfma_groups<TN, 2>(acc, [&](int i) { return a[i]; }, b_s + 2 * q * LDB_S);
                 }
             }
             rotate();
@@ -699,6 +754,8 @@ __global__ __launch_bounds__(rows_threads<TN>()) void gemm_rows_kernel(const flo
         } else
 #endif
         if (tile * 32 + 32 <= M) {
+            // a FULL tile: 36 rows x ldc x 4 bytes from the tile's first row (the descriptor's extent; no store relies on it)
+            const __amdgpu_buffer_rsrc_t c_rs = __builtin_amdgcn_make_buffer_rsrc(C + tile * 32 * ldc, 0, int(36 * ldc * 4), kRsrcFlags);
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int gn = j * 32 + l31;
@@ -707,10 +764,12 @@ __global__ __launch_bounds__(rows_threads<TN>()) void gemm_rows_kernel(const flo
 #else
                 if (gn < N) {
 #endif
-                    char* const cb = reinterpret_cast<char*>(C + (r0 - 4 * kh) * ldc);      // uniform (r0 - 4 kh = the tile's first row)
 #pragma unroll
-                    for (int t = 0; t < 16; ++t)
-                        *reinterpret_cast<float*>(cb + int64_t((t & 3) + 8 * (t >> 2)) * ldc * 4 + c_off + j * 128) = acc[j][t];
+                    for (int t = 0; t < 16; ++t) {
+                        const float val = acc[j][t];
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, val), c_rs, c_off + j * 128,
+                                                              int(((t & 3) + 8 * (t >> 2)) * ldc * 4), 0);
+                    }
                 }
             }
         } else {
@@ -727,7 +786,9 @@ __global__ __launch_bounds__(rows_threads<TN>()) void gemm_rows_kernel(const flo
                 }
             }
         }
+#if !TFGX_ROWS_ZERO_FIRST
         zero_acc();
+#endif
 #if TFGX_ROWS_EXPERIMENT == 3
         dbg_ep += __builtin_readcyclecounter() - dbg_e0;
 #endif
@@ -741,6 +802,8 @@ __global__ __launch_bounds__(rows_threads<TN>()) void gemm_rows_kernel(const flo
         atomicAdd(reinterpret_cast<unsigned long long*>(&g_rows_dbg[2]), (unsigned long long)dbg_tiles);
         atomicAdd(reinterpret_cast<unsigned long long*>(&g_rows_dbg[12]), (unsigned long long)dbg_mf);
         atomicAdd(reinterpret_cast<unsigned long long*>(&g_rows_dbg[13]), (unsigned long long)dbg_ep);
+        atomicAdd(reinterpret_cast<unsigned long long*>(&g_rows_dbg[14]), (unsigned long long)dbg_h0);
+        atomicAdd(reinterpret_cast<unsigned long long*>(&g_rows_dbg[15]), (unsigned long long)dbg_h1);
         atomicAdd(reinterpret_cast<unsigned long long*>(&g_rows_dbg[3]), 1ull);
         const unsigned long long w1 = wall_clock64();
         atomicMax(reinterpret_cast<unsigned long long*>(&g_rows_dbg[4]), (unsigned long long)(w1 - dbg_w0));

@@ -39,7 +39,7 @@ for M, K, N in [(2400000, 256, 128), (2400000, 100, 128), (2400000, 128, 256), (
     e1.record()
     torch.cuda.synchronize()
     fn(buf)
-    cyc, ticks, tiles, waves, tmax, tmin, tpro, tspan, k0, k1, e0_, e1_, cmf, cep = [int(v) for v in buf][:14]
+    cyc, ticks, tiles, waves, tmax, tmin, tpro, tspan, k0, k1, e0_, e1_, cmf, cep, cw0, cw1 = [int(v) for v in buf][:16]
     tn = (N + 31) // 32
     groups = (K // 32) * 16 + (K % 32) // 2
     ideal = groups * tn * 64
@@ -53,4 +53,5 @@ for M, K, N in [(2400000, 256, 128), (2400000, 100, 128), (2400000, 128, 256), (
                       "first_entry_to_last_end_us": (e1_ - k0) / 100.0,
                       "cycles_per_tile_in_full_step_mfma_groups": cmf / tiles, "cycles_per_tile_in_epilogue": cep / tiles,
                       "cycles_per_tile_elsewhere": (cyc - cmf - cep) / tiles,
+                      "cycles_per_tile_handover_after_first_step": cw0 / tiles, "cycles_per_tile_handover_other_steps": cw1 / tiles,
                       "cycles_per_mfma_inside_groups_per_wave": cmf / tiles / ((K // 32) * 16 * tn)}), flush=True)
