@@ -87,6 +87,9 @@ struct FArgs {
     int64_t ld_edge_tail;
 };
 
+#ifndef TFGX_FUSED_PRIO
+#define TFGX_FUSED_PRIO 0
+#endif
 #ifdef TFGX_FUSED_DEBUG
 #define TFGX_FUSED_DBG_IS(v) (a.dbg == (v))
 #else
@@ -126,6 +129,9 @@ __global__ __launch_bounds__(kFusedThreads) void agg_gemm_kernel(const FArgs a)
     if (tid < 16) ctrl[tid] = 0;                            // ([6 + b]: finished halves of buffer b's tile)
     __syncthreads();
 
+#if TFGX_FUSED_PRIO
+    __builtin_amdgcn_s_setprio(TFGX_FUSED_PRIO);    // developer A/B: producers (gather + FMA) above the consumers' MFMA stream
+#endif
     const int64_t my_tiles = a.n_tiles > int64_t(blockIdx.x) ? (a.n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
     const int64_t total_units = my_tiles * UNITS;
     const int c_raw = lane * 4;
@@ -287,6 +293,9 @@ __global__ __launch_bounds__(kFusedThreads) void agg_gemm_kernel(const FArgs a)
             while (*arr < UNITS) __builtin_amdgcn_s_sleep(1);
         }
         __threadfence_block();
+#if TFGX_FUSED_PRIO
+        __builtin_amdgcn_s_setprio(0);       // multiply at LOW priority: the producers' vector-ALU work on this SIMD goes first
+#endif
         const int half = job & 1, nb_first = (job >> 1) * JB;
         for (int mb = half; mb < (TFGX_FUSED_DBG_IS(1) ? 0 : half + 1); ++mb) {
             for (int nb0 = nb_first; nb0 < nb_first + JB; nb0 += JB) {     // n_blocks is a multiple of 4 (zero-padded columns of Ws)
@@ -456,6 +465,9 @@ __global__ __launch_bounds__(kFusedThreads) void agg_gemm_kernel(const FArgs a)
             }
         }
         __threadfence_block();
+#if TFGX_FUSED_PRIO
+        __builtin_amdgcn_s_setprio(TFGX_FUSED_PRIO);
+#endif
         int fin = 0;
         if (lane64 == 0) fin = atomicAdd(&ctrl[6 + buf], 1);
         fin = __builtin_amdgcn_readfirstlane(fin);
