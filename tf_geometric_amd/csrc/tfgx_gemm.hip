@@ -1037,23 +1037,65 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
         float a[U][TM], b[U][TN];
     };
     constexpr int BR = KS * U;                    // node rows per batch
-    auto load = [&](Ops& o, int64_t r) {          // full batch: rows r .. r + BR - 1 all < r_end
+    // OPERAND LOADS (end of round 4).  Every operand used to be a predicated per-lane load (`valid ? p[col] : fill`) behind
+    // its own 64-bit address arithmetic: a branch and ~3 vector-ALU instructions per load — and a vector-ALU instruction
+    // waits ~38 cycles for an issue slot beside an MFMA stream (see gemm_rows_kernel).  Now: RAW BUFFER loads.  One
+    // descriptor per operand matrix and batch (scalar: base = first row of the batch, extent = the rows of the batch that
+    // exist), one per-lane byte offset per (u, tile) computed ONCE per launch — 0xffffffff for a column past the matrix, so
+    // that lane reads 0 without touching memory, exactly like a row past r_end.  No predication, no per-load arithmetic, and
+    // the ragged last batch runs the same code as the full ones.
+    constexpr int kFlags = 0x00020000;
+    uint32_t off_a[U][TM], off_b[U][TN];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) off_a[u][i] = (mval[i] && mtile[i]) ? uint32_t((int64_t(KS * u + kk) * ldx + mcol[i]) * 4) : 0xffffffffu;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) off_b[u][j] = (nval[j] && ntile[j]) ? uint32_t((int64_t(KS * u + kk) * ldg + ncol[j]) * 4) : 0xffffffffu;
+    }
+    uint32_t off_g[GATED ? U : 1][GATED ? TN : 1];
+    if constexpr (GATED) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                off_g[u][j] = (nval[j] && ntile[j]) ? uint32_t((int64_t(KS * u + kk) * ldgate + ncol[j]) * 4) : 0xffffffffu;
+    }
+    // the virtual all-ones column Ka of X (row Ka of the product = the bias gradient) lives in ONE of this wave's tiles, if any
+    int ib = -1;
+    if (want_bias) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+            if (mtile[i] && (mt0 + i) == Ka / S) ib = i;                 // uniform
+    }
+    const bool fill_lane = want_bias && lc == Ka % S;                    // the lane that owns column Ka inside tile ib
+    auto load = [&](Ops& o, int64_t r) {          // rows r .. min(r + BR, r_end) - 1; the rest of the batch reads zeros
+        const int64_t rows = r_end - r < BR ? r_end - r : BR;           // uniform, >= 1
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X + r * ldx), 0, int(rows * ldx * 4), kFlags);
+        const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(G + r * ldg), 0, int(rows * ldg * 4), kFlags);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const float* xr = X + (r + KS * u + kk) * ldx;
-            const float* gr = G + (r + KS * u + kk) * ldg;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) o.a[u][i] = mval[i] ? xr[mcol[i]] : mfill[i];
+            for (int i = 0; i < TM; ++i) o.a[u][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, off_a[u][i], 0, 0));
 #pragma unroll
-            for (int j = 0; j < TN; ++j) o.b[u][j] = nval[j] ? gr[ncol[j]] : 0.0f;
-            if constexpr (GATED) {
-                const float* tr = gate + (r + KS * u + kk) * ldgate;
+            for (int j = 0; j < TN; ++j) o.b[u][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, off_b[u][j], 0, 0));
+        }
+        if constexpr (GATED) {
+            const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gate + r * ldgate), 0, int(rows * ldgate * 4), kFlags);
+#pragma unroll
+            for (int u = 0; u < U; ++u)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    const float t = nval[j] ? tr[ncol[j]] : 0.0f;
+                    const float t = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rt, off_g[u][j], 0, 0));
                     o.b[u][j] = t > 0.0f ? o.b[u][j] : 0.0f;
                 }
-            }
+        }
+        if (ib >= 0) {                                                   // uniform; one tile of one wave per row group
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    if (i == ib) o.a[u][i] = fill_lane ? ((KS * u + kk < rows) ? 1.0f : 0.0f) : o.a[u][i];   // (that lane's real column is past Ka: it read 0)
         }
     };
     auto mul = [&](const Ops& o) {
@@ -1065,39 +1107,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
                 for (int j = 0; j < TN; ++j)
                     if (mtile[i] && ntile[j]) acc[i][j] = T::mfma(o.a[u][i], o.b[u][j], acc[i][j]);
     };
-    int64_t r = r_begin;
-    if (r + BR <= r_end) {
+    if (r_begin < r_end) {
         Ops cur;
-        load(cur, r);
-        for (; r + 2 * BR <= r_end; r += BR) {
+        load(cur, r_begin);
+        for (int64_t r = r_begin; r + BR < r_end; r += BR) {
             Ops nxt;
             load(nxt, r + BR);
             mul(cur);
             cur = nxt;
         }
         mul(cur);
-        r += BR;
-    }
-    for (; r < r_end; r += KS) {                   // tail: one k-step at a time, rows past r_end contribute zeros
-        const int64_t row = r + kk;
-        const bool rv = row < r_end;
-        float a[TM], b[TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) a[i] = rv ? (mval[i] ? X[row * ldx + mcol[i]] : mfill[i]) : 0.0f;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) b[j] = (rv && nval[j]) ? G[row * ldg + ncol[j]] : 0.0f;
-        if constexpr (GATED) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const float t = (rv && nval[j]) ? gate[row * ldgate + ncol[j]] : 0.0f;
-                b[j] = t > 0.0f ? b[j] : 0.0f;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                if (mtile[i] && ntile[j]) acc[i][j] = T::mfma(a[i], b[j], acc[i][j]);
     }
     // partial of this workgroup: [rows_out][N]; D layout: col = lane % S, row = TnTile::out_row(register, lane / S)
     float* out = parts + int64_t(blockIdx.x) * part_stride;
