@@ -71,6 +71,8 @@ import os as _os
 # gradient first.  Same-box A/B at products shape: a wash (GCN step 25.84 / 26.06 vs 25.62 / 26.15 ms, mean SAGE 27.49 /
 # 27.67 vs 27.52 / 27.99 ms) — the kernel reads the gate where the copy was written and re-read — so it stays off.
 GATED_WEIGHT_GRADIENTS = _os.environ.get("TFGX_GATED_WGRAD", "0") != "0"
+# ... and in the fused aggregate -> project layer (round 4, after the weight-gradient kernel's operand loads were rewritten):
+GATED_AGGREGATE_PROJECT = _os.environ.get("TFGX_GATED_AGGPROJ", "1") != "0"
 
 
 def relu_backward(g, out, into=None):
@@ -184,12 +186,18 @@ class _AggregateProject(torch.autograd.Function):
     def backward(ctx, g):
         x, w_csr, self_coef, kernel, bias, agg, out = ctx.saved_tensors
         need = ctx.needs_input_grad
-        g = relu_backward(g, out) if ctx.act == L.ACT_RELU else g.contiguous()
         want_b = bias is not None and need[6]
+        # layer 0 (nothing upstream wants a gradient): the ReLU mask is applied INSIDE the weight-gradient reduction (gate = the
+        # layer's output) and the masked gradient is never written — one 3 x [N, units] pass less (1.45 ms at products shape;
+        # the gated kernel costs 0.05 ms more than the plain one since its operands moved to raw buffer loads)
+        gated = (ctx.act == L.ACT_RELU and agg is not None and (need[5] or want_b)
+                 and not (need[2] or need[3] or need[4]) and GATED_AGGREGATE_PROJECT)
+        if not gated:
+            g = relu_backward(g, out) if ctx.act == L.ACT_RELU else g.contiguous()
         gk = gb = None
         if need[5] or want_b:
             if agg is not None:
-                gk, gb = gemm_tn(agg, g, want_bias=want_b)
+                gk, gb = gemm_tn(agg, g.contiguous() if gated else g, want_bias=want_b, gate=out if gated else None)
                 if not need[5]:
                     gk = None
             else:
@@ -236,14 +244,16 @@ class _SageWide(torch.autograd.Function):
     def backward(ctx, g):
         x, ks, kn, w_csr, bias, agg, h = ctx.saved_tensors
         plan, na, need = ctx.plan, ctx.na, ctx.needs_input_grad
-        g = relu_backward(g, h) if ctx.act == L.ACT_RELU else g.contiguous()
         want_b = bias is not None and need[6]
+        # layer 0 (x carries no gradient): both weight-gradient reductions apply the ReLU mask themselves (see _AggregateProject)
+        gated = ctx.act == L.ACT_RELU and not need[2] and agg is not None and GATED_AGGREGATE_PROJECT
+        g = g.contiguous() if (gated or ctx.act != L.ACT_RELU) else relu_backward(g, h)
         gs, gn = g[:, :na], g[:, na:]
-        gx, gks, gba = _linear_grads(x, ks, gs, need[2], need[3], want_b)
+        gx, gks, gba = _linear_grads(x, ks, gs, need[2], need[3], want_b, gate=h[:, :na] if gated else None)
         gkn = gbb = None
         if need[4] or want_b:
             if agg is not None:
-                gkn, gbb = gemm_tn(agg, gn, want_bias=want_b)
+                gkn, gbb = gemm_tn(agg, gn, want_bias=want_b, gate=h[:, na:] if gated else None)
                 if not need[4]:
                     gkn = None
             else:
