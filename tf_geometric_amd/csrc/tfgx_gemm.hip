@@ -445,10 +445,9 @@ __global__ __launch_bounds__(rows_threads<TN>()) void gemm_rows_kernel(const flo
     // Tail step (T = K % 32 left, a multiple of 4): the two half-waves split it evenly, k = 32 nfull + kh T/2 + i for
     // i < T/2, so a tail costs T/2 fully used MFMA groups; T/2 may be only 8-byte aligned, hence the aligned(8) vector
     // type (global_load_dwordx4 itself has no 16-byte requirement).
-    // Loads are unconditional from clamped addresses (row <= M - 1, k <= K - 4): with no branch around a load the
-    // compiler knows how many are in flight and the next step's loads stay outstanding while the current step's
-    // registers are used (a predicated load forces vmcnt(0), which serialises the prefetch).  Rows >= M compute
-    // values that are never stored; the tail step accounts for its own clamped vector.
+    // No load is PREDICATED (an exec-masked load makes the waitcnt pass lose count and drain vmcnt(0), which serialises the
+    // prefetch); the only branches around loads are wave-uniform.  Rows >= M of the last tile are clamped to row M - 1 through
+    // the per-lane offset (their values are never stored), vectors of the tail step to k <= K - 4 (accounted for there).
     typedef float f32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
     const int half_t = (K - nfull * 32) >> 1;
     // the A registers of a step, kept as the four 16-byte vectors they are loaded as: the per-step hand-over (cur = nxt) then
