@@ -18,6 +18,7 @@
 #include "tfgx_common.h"
 #include "tfgx_mfma.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace tfgx {
 namespace {
@@ -618,13 +619,7 @@ __global__ __launch_bounds__(rows_threads<TN>()) void gemm_rows_kernel(const flo
     // is flushed into `tot` every 64 k (2 steps), rounding error ~ eps * sqrt(64 K) instead of ~ eps * K
     constexpr bool kTwoLevel = TN <= 2;
     const bool two_level = kTwoLevel && two_level_on && K > 128;
-    f32x16 tot[kTwoLevel ? TN : 1];
-    if (kTwoLevel) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int t = 0; t < 16; ++t) tot[j][t] = 0.0f;
-    }
+    f32x16 tot[kTwoLevel ? TN : 1];       // (assigned by the first fold of every tile)
 #if TFGX_ROWS_EXPERIMENT == 3
     // instrumented build (results valid, timing perturbed by four scalar reads per wave): shader-clock cycles and constant
     // 100 MHz ticks spent inside the tile loop, summed over waves -> tfgx_debug_rows_stats
@@ -635,28 +630,15 @@ __global__ __launch_bounds__(rows_threads<TN>()) void gemm_rows_kernel(const flo
 #if TFGX_ROWS_EXPERIMENT == 3
         ++dbg_tiles;
 #endif
-        {   // the tile's first step (K >= 32: there always is one) starts the accumulators from a literal zero
-            prefetch(tile, 0);
-#if TFGX_ROWS_EXPERIMENT == 3
-            const uint64_t dbg_a = __builtin_readcyclecounter();
-#endif
-            rows_mfma_groups<TN, 16, true>(acc, [&](int i) { return cur[i >> 2][i & 3]; }, Bs + 16 * kh * LDB_S + l31);
-#if TFGX_ROWS_EXPERIMENT == 3
-            const uint64_t dbg_b = __builtin_readcyclecounter();
-            dbg_mf += dbg_b - dbg_a;
-#endif
-            rotate();
-#if TFGX_ROWS_EXPERIMENT == 3
-            asm volatile("" ::"v"(cur[0]), "v"(cur[1]), "v"(cur[2]), "v"(cur[3]));
-            dbg_h0 += __builtin_readcyclecounter() - dbg_b;          // hand-over after the tile's FIRST step (loads issued after the stores)
-#endif
-        }
-        for (int ks = 1; ks < nfull; ++ks) {
+        // one k-step: prefetch the next step's A rows, 16 MFMA groups on the current ones, hand the registers over.
+        // zf (std::true_type / false_type): the step STARTS an accumulation chain — its first group multiplies into a literal 0
+        auto step = [&](auto zf, int ks) {
             prefetch(tile, ks);
 #if TFGX_ROWS_EXPERIMENT == 3
             const uint64_t dbg_a = __builtin_readcyclecounter();
 #endif
-            rows_mfma_groups<TN, 16>(acc, [&](int i) { return cur[i >> 2][i & 3]; }, Bs + (ks * 32 + 16 * kh) * LDB_S + l31);
+            rows_mfma_groups<TN, 16, decltype(zf)::value>(acc, [&](int i) { return cur[i >> 2][i & 3]; },
+                                                         Bs + (ks * 32 + 16 * kh) * LDB_S + l31);
 #if TFGX_ROWS_EXPERIMENT == 3
             const uint64_t dbg_b = __builtin_readcyclecounter();
             dbg_mf += dbg_b - dbg_a;
@@ -664,23 +646,12 @@ __global__ __launch_bounds__(rows_threads<TN>()) void gemm_rows_kernel(const flo
             rotate();
 #if TFGX_ROWS_EXPERIMENT == 3
             asm volatile("" ::"v"(cur[0]), "v"(cur[1]), "v"(cur[2]), "v"(cur[3]));
-            dbg_h1 += __builtin_readcyclecounter() - dbg_b;          // hand-over after the other steps
+            (ks == 0 ? dbg_h0 : dbg_h1) += __builtin_readcyclecounter() - dbg_b;     // hand-over after the first / the other steps
 #endif
-            if (kTwoLevel) {
-                if (two_level && (ks & 1)) {
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-#pragma unroll
-                        for (int t = 0; t < 16; ++t) {
-                            tot[j][t] += acc[j][t];
-                            acc[j][t] = 0.0f;
-                        }
-                }
-            }
-        }
-        if (nfull < nsteps) {
-            // tail step (K % 32 != 0), kept OUTSIDE the step loop (an if/else inside it makes the compiler carry a second
-            // accumulator set): half_t groups in pairs, skipped wave-uniformly past the end
+        };
+        // tail step (K % 32 != 0), kept OUTSIDE the step loop (an if/else inside it makes the compiler carry a second
+        // accumulator set): half_t groups in pairs, skipped wave-uniformly past the end
+        auto tail_step = [&](auto zf) {
             prefetch(tile, nfull);
             const float* b_s = Bs + (nfull * 32 + half_t * kh) * LDB_S + l31;
 #pragma unroll
@@ -694,21 +665,52 @@ __global__ __launch_bounds__(rows_threads<TN>()) void gemm_rows_kernel(const flo
                         a[0] = c(2 * q + 2);
                         a[1] = c(2 * q + 3);
                     }
-                    rows_mfma_groups<TN, 2>(acc, [&](int i) { return a[i]; }, b_s + 2 * q * LDB_S);
+                    if (q == 0) rows_mfma_groups<TN, 2, decltype(zf)::value>(acc, [&](int i) { return a[i]; }, b_s);
+                    else rows_mfma_groups<TN, 2>(acc, [&](int i) { return a[i]; }, b_s + 2 * q * LDB_S);
                 }
             }
             rotate();
-        }
-        if (kTwoLevel) {
-            if (two_level) {
+        };
+        const bool has_tail = nfull < nsteps;
+        if (kTwoLevel && two_level) {
+            // narrow outputs of a long K (K > 128, so nfull >= 4): chains of TWO k-steps (64 k), each started from a literal
+            // zero and folded into `tot` with one v_add per register — no accumulator is ever zeroed with the vector ALU
+            // (the first fold is a copy); an odd last step and / or the tail form the last chain
+            step(std::true_type{}, 0);
+            step(std::false_type{}, 1);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) tot[j] = acc[j];
+            int ks = 2;
+            for (; ks + 1 < nfull; ks += 2) {
+                step(std::true_type{}, ks);
+                step(std::false_type{}, ks + 1);
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
-                    for (int t = 0; t < 16; ++t) {
-                        acc[j][t] += tot[j][t];
-                        tot[j][t] = 0.0f;
-                    }
+                    for (int t = 0; t < 16; ++t) tot[j][t] += acc[j][t];
             }
+            bool chain = false;                                     // uniform: does `acc` hold a chain not yet in `tot`?
+            if (ks < nfull) {
+                step(std::true_type{}, ks);
+                chain = true;
+                if (has_tail) tail_step(std::false_type{});
+            } else if (has_tail) {
+                tail_step(std::true_type{});
+                chain = true;
+            }
+            if (chain) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) acc[j][t] += tot[j][t];
+            } else {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[j] = tot[j];
+            }
+        } else {
+            step(std::true_type{}, 0);                              // K >= 32: there always is a first step
+            for (int ks = 1; ks < nfull; ++ks) step(std::false_type{}, ks);
+            if (has_tail) tail_step(std::false_type{});
         }
 #if TFGX_ROWS_EXPERIMENT == 3
         const uint64_t dbg_e0 = __builtin_readcyclecounter();
