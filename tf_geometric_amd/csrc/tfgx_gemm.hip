@@ -28,23 +28,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 
 constexpr int BK = 16;   // 16 keeps load-staging registers low enough for 3 workgroups per CU (BK = 32: 2)
-#ifndef TFGX_ROWS_NT_STORE
-#define TFGX_ROWS_NT_STORE 0      // developer A/B: streaming stores of the row kernel's output tiles
-#endif
 #ifndef TFGX_ROWS_EXPERIMENT
-#define TFGX_ROWS_EXPERIMENT 0    // developer experiments on the row kernel's epilogue (1: no stores, 2: stores into a small window) — results INVALID
+#define TFGX_ROWS_EXPERIMENT 0    // 3 = instrumented build: per-wave clocks of the tile loop and its phases (tfgx_debug_rows_stats / _waves)
 #endif
 #ifndef TFGX_ROWS_VEC_STORE
 #define TFGX_ROWS_VEC_STORE 0     // 16-byte epilogue stores through a quad transpose of the accumulators: +4..9 % while every store carried
                                   // its own 64-bit address arithmetic; once the addresses moved off the vector ALU the 65 VALU ops per
                                   // 32 x 32 block of the transpose cost more than 96 fewer store instructions save (2.4 M x 100 -> 256:
                                   // 1.20 -> 1.155 ms, 170 k x 128 -> 256: 0.121 -> 0.113 without it) — kept as a switch
-#endif
-#ifndef TFGX_ROWS_STAGGER
-#define TFGX_ROWS_STAGGER 0
-#endif
-#ifndef TFGX_ROWS_NT_LOAD
-#define TFGX_ROWS_NT_LOAD 0       // developer A/B: streaming loads of the A rows
 #endif
 
 template <int BM, int BN, int WM, int WN, bool AV4, bool BV4>
@@ -375,9 +366,6 @@ __device__ __forceinline__ void rows_mfma_groups(f32x16 (&acc)[TN], AOF a_of, co
 #ifndef TFGX_ROWS_THREADS_WIDE
 #define TFGX_ROWS_THREADS_WIDE 512
 #endif
-#ifndef TFGX_ROWS_PRIO
-#define TFGX_ROWS_PRIO 0               // developer A/B: 1 = the first wave of each SIMD holds the MFMA port (static s_setprio)
-#endif
 template <int TN>
 constexpr int rows_threads() { return TN <= 4 ? TFGX_ROWS_THREADS_NARROW : TFGX_ROWS_THREADS_WIDE; }
 
@@ -583,32 +571,6 @@ __global__ __launch_bounds__(rows_threads<TN>()) void gemm_rows_kernel(const flo
         tile = next_of(0);
         claim();
     }
-#if TFGX_ROWS_PRIO == 1
-    if (wave < 4) __builtin_amdgcn_s_setprio(1);
-#endif
-#if TFGX_ROWS_STAGGER == 2 || TFGX_ROWS_STAGGER == 3
-    // The two waves of a SIMD leave the barrier together, run the same instruction stream and share the MFMA port turn by
-    // turn — so they stay in phase for the whole launch: both compute addresses and issue loads at the top of a k-step at the
-    // same time (the port idles), then both multiply.  Delay the second wave of each SIMD ONCE by half a k-step of MFMA time
-    // (2: 16 * TN groups of 64 cycles; 3: a quarter): the phase difference persists, one wave's step overhead and epilogue
-    // then fall under the other's MFMAs.
-    if (wave >= NT / 128) {
-        constexpr int units = (TFGX_ROWS_STAGGER == 2 ? 16 : 8) * TN;     // s_sleep counts 64-cycle units, immediate <= 127
-#pragma unroll
-        for (int i = 0; i < units / 32; ++i) __builtin_amdgcn_s_sleep(32);
-        if (units % 32 >= 16) __builtin_amdgcn_s_sleep(16);
-        if (units % 16 >= 8) __builtin_amdgcn_s_sleep(8);
-    }
-#elif TFGX_ROWS_STAGGER
-    // The two waves of a SIMD (wave w and w + 4) would otherwise run in lock step — every wave of the chip multiplies a tile,
-    // then every wave stores one: a write burst the MFMA pipes idle through (measured: the same kernel without its stores
-    // 0.98 ms, with them 1.27 ms at 2.4 M x 100 -> 256, although 2.46 GB of output is 0.36 ms of pure write time).  The upper
-    // half of the workgroup starts half a tile late, once: from then on one wave of a SIMD stores while the other multiplies.
-    if (wave >= NT / 128) {
-        const int naps = (K * TN * 16) / 8128 + 1;          // half a tile of MFMA time (K/2 * TN * 64 cycles / 2) in s_sleep(127) units
-        for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-#endif
     if (tile < n_tiles) load_a(cur, tile, 0);
     // Consume the first A registers here so their wait sits in front of the loop.  Otherwise every step carries a
     // "first iteration" vmcnt wait; harmless in steady state (only the 4 prefetch loads are in flight), but right after an
@@ -725,11 +687,7 @@ __global__ __launch_bounds__(rows_threads<TN>()) void gemm_rows_kernel(const flo
                 for (int t = 0; t < 16; ++t) acc[j][t] = apply_act(acc[j][t] + bv[j], a_j);
             }
         }
-#if TFGX_ROWS_EXPERIMENT == 2
-        const int64_t r0 = (tile & 127) * 32 + 4 * kh;      // experiment: every tile's stores land in the same 4096 rows (cache-resident)
-#else
         const int64_t r0 = tile * 32 + 4 * kh;
-#endif
 #if TFGX_ROWS_VEC_STORE
         if (vec_store && tile * 32 + 32 <= M) {
             // 16-byte stores: quad-transposed accumulators (see quad_transpose4).  Register group g = t >> 2 holds rows
@@ -760,11 +718,7 @@ __global__ __launch_bounds__(rows_threads<TN>()) void gemm_rows_kernel(const flo
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int gn = j * 32 + l31;
-#if TFGX_ROWS_EXPERIMENT == 1
-                if (gn < N && acc[j][0] == 1.2345e30f) {          // experiment: (practically) no stores at all
-#else
                 if (gn < N) {
-#endif
 #pragma unroll
                     for (int t = 0; t < 16; ++t) {
                         const float val = acc[j][t];
