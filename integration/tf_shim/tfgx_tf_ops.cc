@@ -199,9 +199,15 @@ class TfgxGemmBiasActOp : public OpKernel {
     OP_REQUIRES(ctx, k.dim_size(0) == K, errors::InvalidArgument("x and kernel do not agree on K"));
     Tensor* out = nullptr;
     OP_REQUIRES_OK(ctx, ctx->allocate_output(0, {M, N}, &out));
-    OP_REQUIRES(ctx, tfgx_gemm_bias_act_f32(x.flat<float>().data(), K, k.flat<float>().data(), N,
-                                            b.NumElements() ? b.flat<float>().data() : nullptr, act_,
-                                            out->flat<float>().data(), N, M, K, N, TfStream(ctx)) == 0,
+    // the workspace: split-K partials (small M, long K) or the row kernel's tile counters (tall M); a temp of THIS op call
+    Tensor ws;
+    const size_t ws_bytes = tfgx_gemm_workspace_bytes(M, K, N);
+    OP_REQUIRES_OK(ctx, ctx->allocate_temp(DT_UINT8, {static_cast<int64_t>(ws_bytes)}, &ws));
+    OP_REQUIRES(ctx, tfgx_gemm_bias_act_cols_ws_f32(x.flat<float>().data(), K, k.flat<float>().data(), N,
+                                                    b.NumElements() ? b.flat<float>().data() : nullptr, act_, N,
+                                                    out->flat<float>().data(), N, M, K, N,
+                                                    ws_bytes ? static_cast<void*>(ws.flat<uint8_t>().data()) : nullptr, ws_bytes,
+                                                    TfStream(ctx)) == 0,
                 errors::Internal(tfgx_last_error()));
   }
   int act_;
