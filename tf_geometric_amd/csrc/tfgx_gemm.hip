@@ -447,11 +447,11 @@ __global__ __launch_bounds__(rows_threads<TN>()) void gemm_rows_kernel(const flo
     // wave of the SIMD streams MFMAs, a vector ALU instruction gets an issue slot only now and then, and when both waves are
     // in such a stretch the MFMA port idles.  So the per-step and per-store address arithmetic is kept off the vector ALU:
     // every global address is  (wave-uniform 64-bit base, SALU)  +  (per-lane 32-bit byte offset, computed ONCE)  +  immediate
-    // — the saddr form of global_load / global_store.  The tile index is made provably uniform with readfirstlane.
-    // (implemented with RAW BUFFER loads / stores: a 128-bit resource descriptor in SGPRs — base and extent, rebuilt per tile
-    // with scalar instructions — a per-lane 32-bit byte offset computed ONCE per launch, a scalar offset and an immediate.
-    // Reads past the descriptor's extent return 0 and touch no memory: rows >= M of the last tile and the prefetch past the
-    // last tile need no clamps.)
+    // The tile index is made provably uniform with readfirstlane.  LOADS of the A rows: global loads on a uniform base pointer;
+    // STORES of full tiles: raw buffer stores (a 128-bit resource descriptor in SGPRs rebuilt per tile with scalar instructions,
+    // the per-lane offset as voffset, the row as a scalar offset, the column block as an immediate).  Raw buffer LOADS — whose
+    // out-of-extent reads return 0, so the last tile and the prefetch past it would need no clamps — measured slower at
+    // K = 256 and are a compile-time switch.
     constexpr int kRsrcFlags = 0x00020000;                       // raw buffer, dword data format (gfx9 family): the stores' descriptor
 #ifndef TFGX_ROWS_BUFFER_LOADS
 #define TFGX_ROWS_BUFFER_LOADS 0   // developer A/B: 1 = A rows through raw buffer loads too.  Same-box A/B: K = 100 / 128 gain 1-2 %,
@@ -518,7 +518,6 @@ __global__ __launch_bounds__(rows_threads<TN>()) void gemm_rows_kernel(const flo
     };
     zero_acc();
 #endif
-    // branch-free on purpose (see load_a): past the last tile the row clamp turns this into a harmless re-read
     // DYNAMIC tile order (tile_counter != nullptr): every wave claims its tiles from one device counter, one tile ahead — the
     // claim is ISSUED at the top of a tile and its value first READ at that tile's last k-step, where the next tile's A rows
     // are prefetched.  In-kernel clocks (TFGX_ROWS_EXPERIMENT=3, tools/rows_clock_probe.py) show the waves of one launch
