@@ -34,10 +34,16 @@ import ctypes
 import json
 import os
 import sys
+import threading
 import time
 
-import numpy as np
-import torch
+# Multi-process GPU work on the MI355X boxes needs dmabuf IPC (the host driver has no legacy IPC mode): without it RCCL's
+# bring-up fails inside hipIpcGetMemHandle.  The ROCr runtime reads the variable at its initialisation, so it is defaulted
+# before torch is imported; the ranks self_launch() starts inherit it.  (tf_geometric_amd.dist does the same at import.)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np          # noqa: E402
+import torch                # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -54,6 +60,7 @@ def parse_args():
     p.add_argument("--workload", default="products")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-rmat", action="store_true")
+    p.add_argument("--no-configs", action="store_true", help="skip the block that times BASELINE configs[1..3] beside the headline")
     p.add_argument("--extras", action="store_true", help="also time GEMM+aggregation layers (GCN/SAGE/GAT)")
     p.add_argument("--seed", type=int, default=0)
     return p.parse_args()
@@ -82,6 +89,63 @@ def usable_cores():
         except (OSError, ValueError):
             pass
     return cores
+
+
+class Watchdog(object):
+    """One timer thread per rank.  Every phase of the run is announced with stage(name, limit_s); when a phase makes no
+    progress within its limit the thread reports and ends the process (exit code 3): ONE JSON line carrying
+    "error" on the saved stdout descriptor (N > 1: the first rank whose timer fires), every rank a sentence on stderr.  A blocked ncclCommInitRank, grouped exchange
+    or gloo barrier cannot be interrupted from Python any other way, and without this the driver would see nothing but its
+    own 1800 s timeout.  Limits: TFGX_BENCH_WATCHDOG_S (default 120 s per phase; the phases that generate / sort / time
+    on the host get a multiple of it)."""
+
+    def __init__(self, line_fd, rank, world):
+        self.line_fd, self.rank, self.world = line_fd, rank, world
+        self.base = float(os.environ.get("TFGX_BENCH_WATCHDOG_S", "120"))
+        self.name, self.limit, self.t0 = "start", self.base, time.monotonic()
+        self.history = []
+        self._stop = False
+        self._thread = threading.Thread(target=self._run, name="bench-watchdog", daemon=True)
+        self._thread.start()
+
+    def stage(self, name, factor=1.0):
+        now = time.monotonic()
+        self.history.append((self.name, round(now - self.t0, 3)))
+        self.name, self.limit, self.t0 = name, self.base * factor, now
+
+    def stop(self):
+        self.stage("done")
+        self._stop = True
+
+    def _run(self):
+        while not self._stop:
+            time.sleep(0.5)
+            waited = time.monotonic() - self.t0
+            if not self._stop and waited > self.limit:
+                msg = "bench.py watchdog: rank {} of {} made no progress in phase '{}' for {:.0f} s (limit {:.0f} s)".format(
+                    self.rank, self.world, self.name, waited, self.limit)
+                try:
+                    sys.stderr.write(msg + "; phases so far: {}\n".format(self.history))
+                    sys.stderr.flush()
+                    # exactly ONE line on stdout: the first rank whose timer fires writes it (the launcher ends the other
+                    # ranks as soon as one exits, so waiting for rank 0 could lose the reason).  The ranks of a job are
+                    # children of one launcher process: an O_EXCL file named after it elects the writer.
+                    first = True
+                    if self.world > 1:
+                        import tempfile
+                        lock = os.path.join(tempfile.gettempdir(), "tfgx_bench_error_{}.lock".format(os.getppid()))
+                        try:
+                            os.close(os.open(lock, os.O_CREAT | os.O_EXCL | os.O_WRONLY))
+                        except FileExistsError:
+                            first = False
+                    if first:
+                        line = {"metric": "aggregated edges/sec + achieved HBM GB/s, GCN layer", "value": None,
+                                "unit": "edges/s", "n_gpus": self.world, "error": msg, "phase": self.name, "reported_by_rank": self.rank,
+                                "phases_completed": self.history,
+                                "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}
+                        os.write(self.line_fd, (json.dumps(line) + "\n").encode())
+                finally:
+                    os._exit(3)
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -259,6 +323,16 @@ def main():
     if args.gpus > 1 and world == 1:
         os.dup2(line_fd, 1)                       # the children inherit the real stdout
         self_launch(args)                         # does not return
+    wd = Watchdog(line_fd, rank, world)
+    hang_at = os.environ.get("TFGX_BENCH_TEST_HANG", "")      # tests only: block inside the named phase, as a stuck collective would
+
+    def maybe_hang(phase):
+        if hang_at and hang_at == phase and (os.environ.get("TFGX_BENCH_TEST_HANG_RANK", str(rank)) == str(rank)):
+            wd.stage("TEST HANG in '{}'".format(phase))
+            time.sleep(10 ** 6)
+
+    maybe_hang("start")
+    wd.stage("HIP initialisation")
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     n_dev = torch.cuda.device_count()
     # N > 1: one rank per GPU, halo rows over the repo's own RCCL communicator (transport "tfgx_dist", asked for BY NAME:
@@ -283,7 +357,9 @@ def main():
         # CONTROL PLANE = a gloo group (rendezvous, the 128-byte ncclUniqueId, barriers, the max-over-ranks of the timings):
         # host tensors only.  DATA PLANE = tfgx_dist's ncclComm_t: the only RCCL communicator in the process.
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        wd.stage("gloo rendezvous (control plane)")
         dist.init_process_group("gloo")
+        wd.stage("device census over the control plane")
         # one physical device per rank?  (ranks may each see all GPUs, or one each through *_VISIBLE_DEVICES: compare PCI ids)
         props = torch.cuda.get_device_properties(torch.cuda.current_device())
         mine = "{}:{:04x}:{:02x}:{:02x}".format(os.uname().nodename, getattr(props, "pci_domain_id", 0),
@@ -294,7 +370,15 @@ def main():
             raise SystemExit("bench.py --gpus {}: {} distinct GPU(s) behind the {} ranks; RCCL needs one device per rank (for a "
                              "plumbing check of the N > 1 code path on fewer GPUs set TFGX_BENCH_BACKEND=gloo)".format(
                                  world, len(set(devs)), world))
-        from tf_geometric_amd.dist.sharded import ShardedGraph
+        from tf_geometric_amd.dist.sharded import ShardedGraph, HipBackend
+        from tf_geometric_amd.dist.transport import get_transport, ipc_mode_note
+        # the data plane first, as a phase of its own: a hang inside ncclCommInitRank or the first grouped send / receive is
+        # then reported BY NAME by the watchdog within its limit
+        wd.stage("RCCL bring-up over tfgx_dist (ncclGetUniqueId, ncclCommInitRank, self-check rows)" if not plumbing
+                 else "host-staged transport (plumbing mode)")
+        maybe_hang("bring-up")
+        transport = get_transport(dist.group.WORLD, HipBackend(), "torch" if plumbing else "tfgx_dist")
+        wd.stage("stripe generation (host)", 3)
         t0 = time.perf_counter()
         # every rank GENERATES only its stripe of the edge list (block-seeded generator: the union over the ranks is the same
         # edge multiset at every N) and from_partitioned routes each edge to its destination's owner — nothing edge-sized
@@ -304,10 +388,12 @@ def main():
         cnt = torch.tensor([int(stripe.shape[1])], dtype=torch.int64)
         dist.all_reduce(cnt)
         e = int(cnt.item())
-        sg = ShardedGraph.from_partitioned(stripe, n, group=dist.group.WORLD,
-                                           transport="torch" if plumbing else "tfgx_dist")
+        wd.stage("shard plan: degree all-reduce, edge routing all-to-all-v, CSR + halo plan", 3)
+        sg = ShardedGraph.from_partitioned(stripe, n, group=dist.group.WORLD, transport=transport)
         del stripe
+        wd.stage("sharded GCN normalisation (one 1-column halo exchange)")
         sg.build_gcn_norm()
+        wd.stage("own feature rows (host generation + copy)", 3)
         table = sg.alloc_table(f)                       # [own rows | halo rows]; own rows resident before timing
         x_own = synthetic.synthetic_feature_rows(n, f, seed=args.seed + 1, row_lo=sg.own_lo, row_hi=sg.own_hi)
         sg.own_rows(table).copy_(L.as_f32(x_own))
@@ -327,11 +413,13 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             return float(t.item())
     else:
+        wd.stage("input generation (host)", 3)
         t0 = time.perf_counter()
         ei_np = synthetic.synthetic_edge_stripe(n, e_req, seed=args.seed)     # all blocks: the same graph the N > 1 runs shard
         e = int(ei_np.shape[1])
         x_np = synthetic.synthetic_feature_rows(n, f, seed=args.seed + 1)
         gen_s = time.perf_counter() - t0
+        wd.stage("host -> device copies, CSR plan, GCN normalisation")
         t0 = time.perf_counter()
         ei = L.as_i32(ei_np)
         x = L.as_f32(x_np)
@@ -368,7 +456,11 @@ def main():
             pass
 
     cold_ms = None
+    wd.stage("first step (N > 1: first halo exchange on the RCCL communicator + the per-round passes)")
+    maybe_hang("first-step")
     for i in range(args.warmup):
+        if i == 1:
+            wd.stage("warm-up steps")
         if i == 0:          # the very first launch after plan build: cold caches / TLBs, code object load
             c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             c0.record()
@@ -378,8 +470,10 @@ def main():
             torch.cuda.synchronize()
             cold_ms = c0.elapsed_time(c1)
     torch.cuda.synchronize()
+    wd.stage("barrier in front of the timed loop")
     barrier()
     torch.cuda.synchronize()
+    wd.stage("timed loop ({} steps)".format(args.steps), 2)
     import gc
     gc.collect()
     gc.disable()            # as timeit does: a full cyclic collection of a torch process is a 40 ms host pause
@@ -398,6 +492,7 @@ def main():
 
     if world > 1:
         import torch.distributed as dist
+        wd.stage("max over ranks + per-rank diagnostics (exchange / passes alone)", 2)
         wall = max_over_ranks(wall)
         ev_ms = max_over_ranks(ev_ms)
         # everything below is commentary beside the headline: a failure in it (the same code on every rank, so the same
@@ -410,6 +505,7 @@ def main():
         # beside the headline (which exchanges the halo every step, as any hidden layer must): layer 0 with its input
         # features declared static — halo exchanged once, shard table in the edge-resident-tail layout, no exchange per step
         if diag is not None:
+            wd.stage("static shard layout (halo exchanged once)", 2)
             try:
                 st = sg.prepare_static_features(sg.own_rows(table))
                 dist.barrier()
@@ -425,6 +521,7 @@ def main():
             except Exception as ex:                                     # noqa: BLE001
                 static_shard = {"error": "static feature layout: {!r}".format(ex)}
 
+    wd.stage("commentary beside the headline (static layout, R-MAT, CPU legs, configs)", 5)
     ms_per_step = wall * 1e3 / args.steps
     e_agg = e + n
     line = {
@@ -466,6 +563,9 @@ def main():
         line["config"]["control_plane"] = "gloo (host tensors: rendezvous, barriers, max-over-ranks)"
         line["config"]["rccl_ranks"] = sg.transport.comm_info()[0] if hasattr(sg.transport, "comm_info") else 0
         line["config"]["devices_visible"] = n_dev
+        line["config"]["HSA_ENABLE_IPC_MODE_LEGACY"] = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")
+        if ipc_mode_note():
+            line["config"]["ipc_mode_note"] = ipc_mode_note()
         if plumbing:
             line["config"]["plumbing_check"] = ("TFGX_BENCH_BACKEND=gloo: {} ranks on {} device(s), rows staged through the "
                                                 "host — exercises the N > 1 code path, NOT a scaling number".format(world, n_dev))
@@ -641,8 +741,14 @@ def main():
             line["cpu_baseline_op_for_op"] = base2
             line["parity_vs_cpu_op_for_op_max_abs_err"] = float(np.abs(res[:cpu_out2.shape[0]].cpu().numpy() - cpu_out2).max())
             line["speedup_vs_cpu_op_for_op"] = line["value"] / base2["value"]
+    if world == 1 and rank == 0 and not args.no_configs and n >= 100000:
+        wd.stage("configs block (C2 arxiv GCN, C3 Reddit GAT, C4 GraphSAGE, GEMM)", 5)
+        line["configs"] = baseline_configs(tfg, L, synthetic, x, ei, n, e, f, cache, args.seed)
     if args.extras and world == 1 and rank == 0:
+        wd.stage("extras", 10)
         line["extras"] = extras(tfg, L, synthetic, x, ei, n, e, f, cache)
+    line["watchdog"] = {"limit_s_per_phase": wd.base, "phases_s": wd.history + [(wd.name, round(time.monotonic() - wd.t0, 3))]}
+    wd.stop()
     if rank == 0:
         sys.stdout.flush()
         os.write(line_fd, (json.dumps(line) + "\n").encode())
@@ -732,6 +838,189 @@ def _latency(fn, steps=20, warmup=3):
         fn()
         torch.cuda.synchronize()
     return (time.perf_counter() - t0) * 1e3 / steps
+
+
+def _fwd_bwd(layer, inputs, cache):
+    def run():
+        for p_ in layer.parameters():
+            p_.grad = None
+        layer(inputs, cache=cache).sum().backward()
+    return run
+
+
+def _entry(res, key, fn):
+    """One entry of the configs block; a failure is reported inside the line, never at the cost of the headline."""
+    try:
+        res[key] = fn()
+    except Exception as ex:                                            # noqa: BLE001
+        res[key] = {"error": "{}: {}".format(type(ex).__name__, ex)}
+    torch.cuda.synchronize()
+
+
+def baseline_configs(tfg, L, synthetic, x, ei, n, e, f, cache, seed):
+    """The OTHER BASELINE.json configs inside the driver-timed line — bounded (tens of seconds), after the
+    timed loop, every entry with its time (HIP events, steps queued back to back), the kernel the dispatcher picks for the
+    dominant launch and that launch's algorithmic fraction of the HBM peak (SURVEY.md §8d's B_alg).  Shapes:
+    C2 demo/demo_gcn.py:22-23 on the arxiv-shaped graph (hidden 256, 40 classes); C3 demo/demo_gat.py:22 on the Reddit-shaped
+    graph; C4 demo/demo_graph_sage.py:29-30 (units 256, concat) on the products-shaped graph this run already holds.
+    The automatic static-layout promotion is OFF in here: every key times the tensors as they are."""
+    from tf_geometric_amd import plan as P
+    from tf_geometric_amd.plan import CsrPlan, segment_reduce, gemm_bias_act
+    from tf_geometric_amd.nn.conv.gat import gat_attention
+    res = {"what": "BASELINE.json configs[1..3] beside the headline: ms = HIP events over back-to-back launches; frac = "
+                   "algorithmic bytes of the named launch / its ms / 8 TB/s; promotion of static layouts switched off"}
+    auto = P.AUTO_STATIC_LAYOUT
+    P.AUTO_STATIC_LAYOUT = False
+    dev = x.device
+    t_start = time.perf_counter()
+
+    # ---- C4: GraphSAGE mean / max-pool aggregators at the contract shape (units 256, concat) on the products-shaped graph
+    w1 = torch.ones(e, dtype=torch.float32, device=dev)
+    plan = CsrPlan.from_cache(ei, n, n, cache)
+
+    def c4_mean():
+        lay = tfg.layers.MeanGraphSage(256, activation=tfg.relu)
+        before = P.FUSED_STATS["launches"]
+        ms = _time(lambda: lay([x, ei, w1], cache=cache), steps=8, warmup=2)
+        fused = P.FUSED_STATS["launches"] > before
+        ms_agg = _time(lambda: segment_reduce(plan, x, L.MEAN, w_csr=w1), steps=8, warmup=2)
+        tl = tfg.layers.MeanGraphSage(256, activation=tfg.relu)
+        tl._maybe_build([x])
+        tl.trainable(True)
+        ms_t = _time(_fwd_bwd(tl, [x, ei, w1], cache), steps=4, warmup=2)
+        balg = b_alg(e, n, f)
+        return {"layer": "MeanGraphSage(256, concat=True) on [N={}, F={}], E={}".format(n, f, e),
+                "forward_ms": ms, "fwd_bwd_ms": ms_t,
+                "dominant_launch": ("tfgx_aggregate_gemm_f32 -> agg_gemm_kernel<32, true> (mean of w*x[col] at the INPUT width "
+                                    "F={}, projected to 128 columns in the same launch)".format(f)) if fused else
+                                   "tfgx_segment_reduce_f32 + tfgx_gemm_bias_act_f32",
+                "aggregation_alone_kernel": segment_reduce(plan, x, L.MEAN, w_csr=w1, describe=True),
+                "aggregation_alone_ms": ms_agg, "algorithmic_bytes": balg,
+                "frac_of_hbm_peak_aggregation_alone": balg / (ms_agg * 1e-3) / HBM_PEAK,
+                "frac_of_hbm_peak_whole_layer": balg / (ms * 1e-3) / HBM_PEAK}
+
+    def c4_maxpool():
+        lay = tfg.layers.MaxPoolGraphSage(256, activation=tfg.relu)
+        ms = _time(lambda: lay([x, ei, w1], cache=cache), steps=4, warmup=2)
+        # the launch that dominates it, alone: the max reduce over the [N, 4 * ku = 512] per-node MLP rows
+        h = torch.relu_(gemm_bias_act(x, lay.neighbor_mlp_kernel.detach()))
+        width = int(h.shape[1])
+        out = torch.empty_like(h)
+        ms_red = _time(lambda: segment_reduce(plan, h, L.MAX, out=out), steps=4, warmup=2)
+        balg = b_alg(e, n, width, weighted=False)
+        kname = segment_reduce(plan, h, L.MAX, out=out, describe=True)
+        del h, out
+        tl = tfg.layers.MaxPoolGraphSage(256, activation=tfg.relu)
+        tl._maybe_build([x])
+        tl.trainable(True)
+        ms_t = _time(_fwd_bwd(tl, [x, ei, w1], cache), steps=3, warmup=2)
+        return {"layer": "MaxPoolGraphSage(256, concat=True): per-node MLP {} -> {} (+ ReLU), max over in-edges at {} columns, "
+                         "512 -> 128 and {} -> 128 projections".format(f, width, width, f),
+                "forward_ms": ms, "fwd_bwd_ms": ms_t, "reduce_alone_kernel": kname, "reduce_alone_ms": ms_red,
+                "reduce_columns": width, "algorithmic_bytes": balg,
+                "frac_of_hbm_peak_reduce_alone": balg / (ms_red * 1e-3) / HBM_PEAK,
+                "reduce_edges_per_s": e / (ms_red * 1e-3)}
+
+    def width_sweep():
+        rows = []
+        wsum = torch.rand(e, device=dev) + 0.5
+        sc = torch.rand(n, device=dev)
+        for width in (128, 192, 256, 384, 512):
+            xw = torch.randn(n, width, device=dev)
+            ow = torch.empty_like(xw)
+            ms = _time(lambda: segment_reduce(plan, xw, L.SUM, w_csr=wsum, self_coef=sc, out=ow), steps=5, warmup=2)
+            balg = b_alg(e + n, n, width)
+            rows.append({"F": width, "kernel": segment_reduce(plan, xw, L.SUM, w_csr=wsum, self_coef=sc, out=ow, describe=True),
+                         "ms": ms, "frac_of_hbm_peak_algorithmic": balg / (ms * 1e-3) / HBM_PEAK,
+                         "G_row_lines_per_s": (e + n) * (width * 4 / 128.0) / (ms * 1e-3) / 1e9})
+            del xw, ow
+        return {"what": "the headline launch (weighted sum + implicit self-loops) on the same graph at wider rows", "rows": rows}
+
+    _entry(res, "C4_mean_sage_256_concat", c4_mean)
+    _entry(res, "C4_maxpool_sage_256_concat", c4_maxpool)
+    _entry(res, "C4_width_sweep", width_sweep)
+    del w1
+
+    # ---- dense x @ W beside torch.matmul (hipBLASLt), alternating
+    def gemm_pair(m, k, nn, xin=None):
+        a = xin if xin is not None else torch.randn(m, k, device=dev)
+        b = L.as_f32(synthetic.glorot_uniform(k, nn))
+        c = torch.empty((m, nn), dtype=torch.float32, device=dev)
+        ours, lib = _time_ab(lambda: gemm_bias_act(a, b, out=c), lambda: torch.matmul(a, b, out=c), steps=10, warmup=3, rounds=3)
+        return {"shape": "{} x {} -> {}".format(m, k, nn), "ms": ours, "torch_matmul_ms": lib, "ratio_ours_over_torch": ours / lib,
+                "tflops_fp32": 2.0 * m * k * nn / (ours * 1e-3) / 1e12, "entry": "tfgx_gemm_bias_act_f32 (fp32 MFMA)"}
+
+    _entry(res, "gemm_products_100_to_256", lambda: gemm_pair(n, f, 256, x if f == 100 else None))
+    _entry(res, "gemm_arxiv_128_to_256", lambda: gemm_pair(170000, 128, 256))
+
+    # ---- C2: 2-layer GCN 128 -> 256 -> 40 on the arxiv-shaped graph: forward and one full-batch training step
+    def c2():
+        na, ea, fa = synthetic.WORKLOADS["arxiv"]
+        eia = L.as_i32(synthetic.synthetic_edge_stripe(na, ea, seed=seed))
+        xa = L.as_f32(synthetic.synthetic_feature_rows(na, fa, seed=seed + 1))
+        ca = {}
+        g0, g1 = tfg.layers.GCN(256, activation=tfg.relu), tfg.layers.GCN(40)
+        before = P.FUSED_STATS["launches"]
+        fwd = lambda: g1([g0([xa, eia], cache=ca), eia], cache=ca)          # noqa: E731
+        ms_f = _time(fwd, steps=20, warmup=5)
+        fused = P.FUSED_STATS["launches"] > before
+        g0.trainable(True)
+        g1.trainable(True)
+        opt = torch.optim.Adam(g0.parameters() + g1.parameters(), lr=1e-2)
+        idx = torch.arange(0, na, 10, device=dev)
+        labels = torch.randint(0, 40, (int(idx.shape[0]),), device=dev)
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            torch.nn.functional.cross_entropy(fwd()[idx], labels).backward()
+            opt.step()
+
+        ms_s = _time(step, steps=10, warmup=3)
+        ea_real = int(eia.shape[1])
+        planA = CsrPlan.from_cache(eia, na, na, ca)
+        balg0 = b_alg(ea_real + na, na, fa)           # layer 0 aggregates at the input width (128), layer 1 at 40
+        return {"model": "GCN(256, relu) -> GCN(40) on N={} E={} F={} (demo/demo_gcn.py:18-32)".format(na, ea_real, fa),
+                "forward_ms": ms_f, "train_step_ms": ms_s,
+                "dominant_launch": "tfgx_aggregate_gemm_f32 -> agg_gemm_kernel<32, true> (A_hat x at 128 columns, x W fused)" if fused
+                                   else "tfgx_segment_reduce_f32 + tfgx_gemm_bias_act_f32",
+                "layer1_aggregation_kernel": segment_reduce(planA, torch.empty((na, 40), device=dev), L.SUM,
+                                                            w_csr=torch.empty(ea_real, device=dev), describe=True),
+                "algorithmic_bytes_layer0_aggregation": balg0,
+                "frac_of_hbm_peak_forward": (balg0 + b_alg(ea_real + na, na, 40)) / (ms_f * 1e-3) / HBM_PEAK,
+                "note": "the 87 MB feature table lives in the Infinity Cache: the fraction is algorithmic bytes over time, not HBM traffic"}
+
+    _entry(res, "C2_arxiv_gcn_2layer", c2)
+
+    # ---- C3: demo/demo_gat.py:22 literal layer on the Reddit-shaped graph: forward, forward + backward, attention alone
+    def c3():
+        nr, er, fr = synthetic.WORKLOADS["reddit"]
+        eir = L.as_i32(synthetic.synthetic_edge_stripe(nr, er, seed=seed + 3))
+        er_real = int(eir.shape[1])
+        xr = torch.randn(nr, fr, device=dev)
+        cr = {}
+        H, A, U = 8, 8, 64
+        lay = tfg.layers.GAT(U, attention_units=A, num_heads=H, activation=tfg.relu)
+        ms_f = _time(lambda: lay([xr, eir], cache=cr), steps=8, warmup=2)
+        planR = CsrPlan.from_cache(eir, nr, nr, cr)
+        Q, K, V = (torch.randn(nr, A, device=dev), torch.randn(nr, A, device=dev), torch.randn(nr, U, device=dev))
+        ms_att = _time(lambda: gat_attention(planR, Q, K, V, H), steps=8, warmup=2)
+        tl = tfg.layers.GAT(U, attention_units=A, num_heads=H, activation=tfg.relu)
+        tl._maybe_build([xr])
+        tl.trainable(True)
+        ms_t = _time(_fwd_bwd(tl, [xr, eir], cr), steps=4, warmup=2)
+        e_agg = er_real + nr
+        balg = e_agg * (4 * A + 4 * U + 4) + nr * 4 * (A + U) + 4 * (nr + 1)
+        return {"layer": "GAT(64, num_heads=8, attention_units=8) on N={} E={} F={}".format(nr, er_real, fr),
+                "forward_ms": ms_f, "fwd_bwd_ms": ms_t, "fwd_bwd_over_forward": ms_t / ms_f,
+                "dominant_launch": "tfgx_gat_fused_f32 -> gat_fused_kernel (scores + online softmax + value sum, one pass per row)",
+                "attention_alone_ms": ms_att, "algorithmic_bytes_attention": balg,
+                "frac_of_hbm_peak_attention_alone": balg / (ms_att * 1e-3) / HBM_PEAK,
+                "edges_per_s_layer": er_real / (ms_f * 1e-3)}
+
+    _entry(res, "C3_reddit_gat_H8_A8", c3)
+    P.AUTO_STATIC_LAYOUT = auto
+    res["wall_s"] = time.perf_counter() - t_start
+    return res
 
 
 def extras(tfg, L, synthetic, x, ei, n, e, f, cache):

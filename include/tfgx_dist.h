@@ -28,11 +28,19 @@ const char* tfgx_dist_last_error(void);
 /* Communicator bootstrap for hosts that do not already own an ncclComm_t (the Python host: torch.distributed does not hand
  * out its communicator).  Rank 0 calls tfgx_dist_unique_id (ncclGetUniqueId) and broadcasts the TFGX_DIST_UNIQUE_ID_BYTES
  * bytes over whatever control channel the host has (the torch.distributed store / a gloo group / MPI); every rank then
- * calls tfgx_dist_comm_init (ncclCommInitRank on the CURRENT HIP device).  *comm_out is an ncclComm_t. */
+ * calls tfgx_dist_comm_init (ncclCommInitRank on the CURRENT HIP device).  *comm_out is an ncclComm_t.
+ * ENVIRONMENT: the MI355X host driver supports dmabuf IPC only — the host process must have HSA_ENABLE_IPC_MODE_LEGACY=0 in
+ * its environment BEFORE its first HIP call (the ROCr runtime reads it at initialisation; the Python host defaults it at
+ * import of tf_geometric_amd.dist, bench.py before importing torch); without it a multi-rank ncclCommInitRank fails inside
+ * hipIpcGetMemHandle. */
 #define TFGX_DIST_UNIQUE_ID_BYTES 128
 int tfgx_dist_unique_id(void* id_out /* TFGX_DIST_UNIQUE_ID_BYTES */);
 int tfgx_dist_comm_init(int32_t world, int32_t rank, const void* id, void** comm_out);
 int tfgx_dist_comm_destroy(void* nccl_comm);
+/* ncclCommAbort: tears the communicator down WITHOUT waiting for the peers (ncclCommDestroy may wait for outstanding
+ * operations).  For the failure paths of a bring-up — a rank whose peers reported a failed ncclCommInitRank / self-check
+ * must not block inside a collective teardown. */
+int tfgx_dist_comm_abort(void* nccl_comm);
 /* What the communicator itself reports: ncclCommCount / ncclCommUserRank / ncclCommCuDevice.  bench.py prints world_out as
  * `rccl_ranks`, so a scaling line states how many ranks the RCCL communicator that carried the halo rows really had
  * (any pointer may be NULL). */

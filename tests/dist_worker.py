@@ -145,6 +145,15 @@ def _entry(rank, world, port, use_gpu, skew, path, rounds=None, partitioned=Fals
     dist.destroy_process_group()
 
 
+def free_port():
+    """A rendezvous port the kernel just handed out as free (bound to port 0 on the loopback interface, as bench.py's
+    self_launch does) — never a number drawn blindly from the ephemeral range, where any other socket may already live."""
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
 def spawn(world, use_gpu, skew, path, port, rounds=None, partitioned=False, hub_threshold=None, self_halo=False, env=None):
     import torch.multiprocessing as mp
     mp.spawn(_entry, args=(world, port, use_gpu, skew, path, rounds, partitioned, hub_threshold, self_halo, env),

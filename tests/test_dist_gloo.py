@@ -1,7 +1,6 @@
 # coding=utf-8
 """N>1 path on CPU: world_size-2 (and 3) gloo process groups drive tf_geometric_amd.dist.sharded with the numpy test
 backend; the concatenated per-rank rows must equal the single-graph oracle."""
-import random
 
 import numpy as np
 import pytest
@@ -13,7 +12,7 @@ import dist_worker
 @pytest.mark.parametrize("world,skew,rounds", [(2, False, None), (2, True, 3), (3, True, 4), (2, False, 16), (8, False, None)])
 def test_sharded_matches_oracle_gloo(tmp_path, world, skew, rounds):
     """rounds = number of all-to-all-v rounds the halo travels in (pipelined with the per-round reduce passes)."""
-    port = 29500 + random.randint(0, 2000)
+    port = dist_worker.free_port()
     parts = dist_worker.spawn(world, use_gpu=False, skew=skew, path=str(tmp_path), port=port, rounds=rounds)
     parts = dist_worker.check_against_reference(parts, skew, assert_parity)
     edges = [p["edges"] for p in parts]
@@ -26,7 +25,7 @@ def test_sharded_matches_oracle_gloo(tmp_path, world, skew, rounds):
 def test_from_partitioned_matches_oracle_gloo(tmp_path, world, skew, rounds):
     """ShardedGraph.from_partitioned: every rank starts from its own stripe of the edge list (nothing edge-sized is
     replicated); after the degree all-reduce and the edge all-to-all-v the shards give the same layer outputs."""
-    port = 29500 + random.randint(2001, 4000)
+    port = dist_worker.free_port()
     parts = dist_worker.spawn(world, use_gpu=False, skew=skew, path=str(tmp_path), port=port, rounds=rounds,
                               partitioned=True)
     parts = dist_worker.check_against_reference(parts, skew, assert_parity)
@@ -65,7 +64,7 @@ def test_sharded_training_gradients_gloo(tmp_path, world, skew, rounds, hub):
     if world == 1:
         parts = [dist_worker.run_training(0, 1, False, skew)]
     else:
-        port = 29500 + random.randint(4001, 6000)
+        port = dist_worker.free_port()
         parts = dist_worker.spawn_training(world, False, skew, str(tmp_path), port, rounds=rounds, hub_threshold=hub)
     ref = dist_worker.training_reference(skew)
     parts = sorted(parts, key=lambda p: p["lo"])
@@ -87,7 +86,7 @@ def test_sharded_training_gradients_gloo(tmp_path, world, skew, rounds, hub):
 def test_column_chunked_halo_bounds_the_table_gloo(tmp_path):
     """aggregate_chunked(num_splits) (the reference's num_splits, utils/tf_sparse_utils.py:71-90): same rows as the
     unchunked pass, with a source table num_splits times smaller."""
-    port = 29500 + random.randint(6001, 8000)
+    port = dist_worker.free_port()
     parts = dist_worker.spawn_training(2, False, True, str(tmp_path), port, rounds=2, num_splits=4)   # F = 12 -> four 3-column chunks
     for p in parts:
         assert np.array_equal(p["chunked"], p["whole"])
@@ -104,7 +103,7 @@ def test_sharded_long_spans_are_chunked_gloo(tmp_path, world):
         dist_worker.run_checks(0, 1, use_gpu=False, skew=True, results=res, hub_threshold=8)
         parts = [res[0]]
     else:
-        port = 29500 + random.randint(8001, 9000)
+        port = dist_worker.free_port()
         parts = dist_worker.spawn(world, use_gpu=False, skew=True, path=str(tmp_path), port=port, rounds=2,
                                   hub_threshold=8)
     assert all(p["gat_used_parts"] for p in parts)
@@ -116,7 +115,7 @@ def test_dense_peers_skip_the_pack_gloo(tmp_path, pct, expect_dense):
     """A peer whose block is referenced to >= TFGX_DENSE_PEER_PCT percent is requested WHOLE (its owner sends the block
     without packing; uniform random graphs at 8 GPUs: every peer).  Same rows as the oracle either way; with the rule on
     the small uniform test graph takes it (nothing is packed), with it off everything is packed."""
-    port = 29500 + random.randint(9001, 9500)
+    port = dist_worker.free_port()
     parts = dist_worker.spawn(2, use_gpu=False, skew=False, path=str(tmp_path), port=port, rounds=3,
                               env={"TFGX_DENSE_PEER_PCT": pct})
     parts = dist_worker.check_against_reference(parts, False, assert_parity)
@@ -126,7 +125,7 @@ def test_dense_peers_skip_the_pack_gloo(tmp_path, pct, expect_dense):
             assert p["dense_send"] == 1 and p["rows_packed"] == 0
         else:       # rule off: a block still goes unpacked when a peer happens to reference every row of it
             assert p["rows_packed"] == p["rows_sent"] - p["dense_send"] * (p["hi"] - p["lo"])
-    tr = dist_worker.spawn_training(2, False, False, str(tmp_path), port + 1, rounds=3, env={"TFGX_DENSE_PEER_PCT": pct})
+    tr = dist_worker.spawn_training(2, False, False, str(tmp_path), dist_worker.free_port(), rounds=3, env={"TFGX_DENSE_PEER_PCT": pct})
     ref = dist_worker.training_reference(False)
     tr = sorted(tr, key=lambda p: p["lo"])
     assert_parity(np.concatenate([p["dx"] for p in tr]), ref["dx"], tol=2e-5, what="sharded d/dx, dense peers " + pct)
@@ -144,9 +143,9 @@ def test_self_halo_mode_moves_own_rows_through_the_exchange(tmp_path, world):
         parts = [res[0]]
         tr = [dist_worker.run_training(0, 1, False, True, rounds=2, self_halo=True)]
     else:
-        port = 29500 + random.randint(9501, 9900)
+        port = dist_worker.free_port()
         parts = dist_worker.spawn(world, use_gpu=False, skew=True, path=str(tmp_path), port=port, rounds=2, self_halo=True)
-        tr = dist_worker.spawn_training(world, False, True, str(tmp_path), port + 1, rounds=2, self_halo=True)
+        tr = dist_worker.spawn_training(world, False, True, str(tmp_path), dist_worker.free_port(), rounds=2, self_halo=True)
     parts = dist_worker.check_against_reference(parts, True, assert_parity)
     assert all(p["n_halo"] > 0 and p["rows_sent"] > 0 for p in parts)
     ref = dist_worker.training_reference(True)
@@ -165,7 +164,7 @@ def test_strict_transport_failure_is_agreed(tmp_path, fail_rank):
     import torch
     if fail_rank is None and torch.cuda.is_available():
         pytest.skip("needs a box without a GPU (every rank then fails require_gpu)")
-    port = 29500 + random.randint(4001, 6000)
+    port = dist_worker.free_port()
     msgs = dist_worker.spawn_agree(2, str(tmp_path), port, fail_rank)
     assert all("failed on" in m and "of 2 ranks" in m for m in msgs), msgs
     if fail_rank is not None:

@@ -67,3 +67,33 @@ def test_single_gpu_line_shape(tfg):
     assert line["n_gpus"] == 1 and line["dtype"] == "f32" and line["roofline"]["bound"] == "hbm"
     assert 0 < line["roofline"]["frac"] < 1.0 and line["cpu_baseline"]["kind"] == "port"
     assert line["parity_vs_cpu_port_max_abs_err"] < 1e-4
+
+
+def test_watchdog_turns_a_hang_in_the_first_exchange_into_a_reason(tfg):
+    """A rank stuck inside its first step (what a blocked grouped ncclSend / ncclRecv looks like from Python) must end the
+    run within the watchdog's limit: exit code != 0, ONE JSON line with "error" naming the phase on stdout — not the
+    driver's 1800 s timeout with nothing to read."""
+    res = _run(["--gpus", "2", "--workload", "tiny", "--steps", "2", "--warmup", "1"],
+               env={"TFGX_BENCH_BACKEND": "gloo", "TFGX_BENCH_TEST_HANG": "first-step", "TFGX_BENCH_TEST_HANG_RANK": "1",
+                    "TFGX_BENCH_WATCHDOG_S": "20"}, timeout=600)
+    assert res.returncode != 0
+    lines = [ln for ln in res.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, (res.stdout.decode()[-2000:], res.stderr.decode()[-3000:])
+    line = json.loads(lines[0])
+    assert line["value"] is None and "made no progress" in line["error"] and line["n_gpus"] == 2
+    assert "made no progress in phase" in res.stderr.decode()  # whichever rank's timer fires first reports (the stuck one, or its peer waiting for it)
+
+
+def test_products_shaped_eight_rank_plumbing_run(tfg):
+    """The products-shaped graph through the `--gpus 8` code path on ONE GPU (host-staged transport, explicitly requested):
+    eight stripes generated, routed and sharded, every peer dense, one line with eight per-rank records.  Not a scaling
+    number — the plumbing the driver's 8-GPU run goes through, at the driver's own shape."""
+    res = _run(["--gpus", "8", "--steps", "2", "--warmup", "1"], env={"TFGX_BENCH_BACKEND": "gloo"}, timeout=1500)
+    assert res.returncode == 0, res.stderr.decode()[-3000:]
+    line = _json_line(res)
+    cfg = line["config"]
+    assert line["n_gpus"] == 8 and cfg["nodes"] == 2400000 and cfg["transport"] == "torch" and "plumbing_check" in cfg
+    ranks = line["roofline"]["per_rank"]
+    assert [d["rank"] for d in ranks] == list(range(8)) and sum(d["edges"] for d in ranks) == cfg["edges"]
+    assert max(d["edges"] for d in ranks) <= 1.05 * cfg["edges"] / 8           # edge-balanced destination ranges
+    assert cfg["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

@@ -2,7 +2,6 @@
 """Sharded path with the HIP backend on the GPU box: world_size 1 in-process, and world_size 2 as two processes that
 share cuda:0 with a gloo group (rows staged through the host) — the kernels and the plan code are the product's,
 only the transport differs from the RCCL path the 8-GPU bench uses."""
-import random
 
 import pytest
 
@@ -20,13 +19,13 @@ def test_sharded_world1_hip(tfg):
 
 @pytest.mark.parametrize("skew,rounds", [(False, None), (True, 4)])
 def test_sharded_world2_hip_gloo_transport(tfg, tmp_path, skew, rounds):
-    port = 31500 + random.randint(0, 2000)
+    port = dist_worker.free_port()
     parts = dist_worker.spawn(2, use_gpu=True, skew=skew, path=str(tmp_path), port=port, rounds=rounds)
     dist_worker.check_against_reference(parts, skew, assert_parity)
 
 
 def test_from_partitioned_world2_hip_gloo_transport(tfg, tmp_path):
-    port = 33600 + random.randint(0, 2000)
+    port = dist_worker.free_port()
     parts = dist_worker.spawn(2, use_gpu=True, skew=True, path=str(tmp_path), port=port, rounds=3, partitioned=True)
     dist_worker.check_against_reference(parts, True, assert_parity)
 
@@ -36,7 +35,7 @@ def test_rccl_world1_api_smoke(tfg):
     import os
     import subprocess
     import sys
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(35600 + random.randint(0, 2000)), RANK="0",
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(dist_worker.free_port()), RANK="0",
                WORLD_SIZE="1")
     script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_world1_smoke.py")
     res = subprocess.run([sys.executable, script], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
@@ -84,7 +83,7 @@ def test_tfgx_dist_world1_under_an_nccl_process_group(tfg):
     import os
     import subprocess
     import sys
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(41600 + random.randint(0, 2000)), RANK="0",
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(dist_worker.free_port()), RANK="0",
                WORLD_SIZE="1")
     script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tfgx_dist_world1.py")
     res = subprocess.run([sys.executable, script], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
@@ -101,7 +100,7 @@ def test_sharded_training_hip(tfg, tmp_path, world, skew, hub):
     if world == 1:
         parts = [dist_worker.run_training(0, 1, True, skew, num_splits=4, hub_threshold=hub)]
     else:
-        port = 37600 + random.randint(0, 2000)
+        port = dist_worker.free_port()
         parts = dist_worker.spawn_training(2, True, skew, str(tmp_path), port, rounds=3, num_splits=4, hub_threshold=hub)
     ref = dist_worker.training_reference(skew)
     parts = sorted(parts, key=lambda p: p["lo"])
@@ -129,7 +128,7 @@ def test_sharded_long_spans_are_chunked_hip(tfg, tmp_path, world):
         dist_worker.run_checks(0, 1, use_gpu=True, skew=True, results=res, hub_threshold=8)
         parts = [res[0]]
     else:
-        port = 39600 + random.randint(0, 2000)
+        port = dist_worker.free_port()
         parts = dist_worker.spawn(2, use_gpu=True, skew=True, path=str(tmp_path), port=port, rounds=2, hub_threshold=8)
     assert all(p["gat_used_parts"] for p in parts)
     dist_worker.check_against_reference(parts, True, assert_parity)
@@ -145,7 +144,7 @@ def test_demo_sharded_gcn_trains(tfg, self_halo):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(43600 + random.randint(0, 2000)), RANK="0",
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(dist_worker.free_port()), RANK="0",
                WORLD_SIZE="1", TFGX_DEMO_SELF_HALO=self_halo)
     res = subprocess.run([sys.executable, os.path.join(root, "examples", "demo_sharded_gcn.py"), "--steps", "40",
                           "--nodes", "30000", "--edges", "600000"], env=env, stdout=subprocess.PIPE,

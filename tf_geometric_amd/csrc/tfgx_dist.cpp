@@ -89,6 +89,13 @@ extern "C" int tfgx_dist_comm_destroy(void* nccl_comm)
     return TFGX_OK;
 }
 
+extern "C" int tfgx_dist_comm_abort(void* nccl_comm)
+{
+    if (nccl_comm == nullptr) return TFGX_OK;
+    DIST_NCCL(ncclCommAbort(reinterpret_cast<ncclComm_t>(nccl_comm)));
+    return TFGX_OK;
+}
+
 extern "C" int tfgx_dist_comm_info(void* nccl_comm, int32_t* world_out, int32_t* rank_out, int32_t* device_out)
 {
     DIST_REQUIRE(nccl_comm != nullptr, "nccl_comm is null");

@@ -35,6 +35,7 @@ _DIST_SIGNATURES = {
     "tfgx_dist_unique_id": (ctypes.c_int, [_P]),
     "tfgx_dist_comm_init": (ctypes.c_int, [_I32, _I32, _P, ctypes.POINTER(_P)]),
     "tfgx_dist_comm_destroy": (ctypes.c_int, [_P]),
+    "tfgx_dist_comm_abort": (ctypes.c_int, [_P]),
     "tfgx_dist_comm_info": (ctypes.c_int, [_P, ctypes.POINTER(_I32), ctypes.POINTER(_I32), ctypes.POINTER(_I32)]),
     "tfgx_alltoallv": (ctypes.c_int, [_P, _P, _P, _P, _I64, _I32, _P, _P]),
     "tfgx_allreduce_sum_i64": (ctypes.c_int, [_P, _I64, _P, _P]),
@@ -79,6 +80,16 @@ def _i64_array(values):
 
 def _flat(rows):
     return [int(v) for r in rows for v in r]
+
+
+def ipc_mode_note():
+    """What this process runs with for cross-process device memory (see dist/__init__.py): None when
+    HSA_ENABLE_IPC_MODE_LEGACY=0 is in the environment, otherwise a sentence for error messages / the bench line."""
+    v = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")
+    if v == "0":
+        return None
+    return ("HSA_ENABLE_IPC_MODE_LEGACY={} in this process (the MI355X host driver supports dmabuf IPC only: export "
+            "HSA_ENABLE_IPC_MODE_LEGACY=0 before the first HIP call)".format("unset" if v is None else repr(v)))
 
 
 class TfgxDistUnavailable(L.TfgxError):
@@ -143,8 +154,14 @@ class TfgxDistTransport(object):
                 _dcheck(self.lib.tfgx_dist_comm_init(self.world, self.rank, uid, ctypes.byref(comm)), "tfgx_dist_comm_init")
             except Exception as ex:              # noqa: BLE001
                 err = "{}: {}".format(type(ex).__name__, ex)
-            self._agree(err, "ncclCommInitRank")
-            self.comm = comm
+                if ipc_mode_note():
+                    err += " [" + ipc_mode_note() + "]"
+            self.comm = comm if err is None else None
+            try:
+                self._agree(err, "ncclCommInitRank")
+            except TfgxDistUnavailable:
+                self.close(abort=True)           # this rank's communicator came up, a peer's did not: never wait for it
+                raise
         return self.comm
 
     def comm_info(self):
@@ -166,10 +183,15 @@ class TfgxDistTransport(object):
             err = "{}: {}".format(type(ex).__name__, ex)
         self._agree(err, "the self-check (rows through tfgx_alltoallv / tfgx_allreduce_sum_i64)")
 
-    def close(self):
+    def close(self, abort=False):
+        """Destroys the communicator (ncclCommDestroy after a device synchronise); abort=True is the failure path's
+        ncclCommAbort, which does not wait for peers that may never arrive."""
         if self.comm is not None:
-            torch.cuda.synchronize()
-            self.lib.tfgx_dist_comm_destroy(self.comm)
+            if abort:
+                self.lib.tfgx_dist_comm_abort(self.comm)
+            else:
+                torch.cuda.synchronize()
+                self.lib.tfgx_dist_comm_destroy(self.comm)
             self.comm = None
 
     def self_check(self):
@@ -485,11 +507,19 @@ def _bring_up_tfgx(group, backend, auto):
     """The C-ABI transport of a multi-rank group: bootstrap (the ranks agree before and after every collective step),
     then a few rows through every plan-time entry point, agreed again.  Strict (auto=False): TfgxDistUnavailable on every
     rank when any rank failed.  AUTO: every rank takes _torch_fallback instead."""
+    t = None
     try:
         t = TfgxDistTransport(group)
         t.checked_self_check()
         return t
     except TfgxDistUnavailable as ex:            # raised on every rank (see TfgxDistTransport._agree)
+        # a communicator that came up but failed its self-check must not linger beside whatever carries the rows instead
+        # (strict mode: beside nothing — the caller exits): every rank destroys it, best effort, before going on
+        if t is not None:
+            try:
+                t.close(abort=True)
+            except Exception:                    # noqa: BLE001 - the communicator is already suspect
+                pass
         if not auto:
             raise
         return _torch_fallback(group, backend, str(ex))
