@@ -46,8 +46,8 @@ enum { TFGX_NORM_BOTH = 0, TFGX_NORM_LEFT = 1, TFGX_NORM_RIGHT = 2 };
 /* ABI version of this header: bumped whenever an entry point's signature or a struct's layout changes (a host built
  * against another value must refuse to run: tf_geometric_amd/_lib.py does).  100 = rounds 1-3; 110 = round 4
  * (tfgx_reduce_args.hub_order_slot; tfgx_aggregate_gemm_f32 honours args->out as a side output of the aggregate;
- * tfgx_gat_args / tfgx_gat_backward_args .drop_seed_dev); 111 = + tfgx_column_sum_f32. */
-#define TFGX_ABI_VERSION 111
+ * tfgx_gat_args / tfgx_gat_backward_args .drop_seed_dev); 111 = + tfgx_column_sum_f32; 112 = round 5 (+ tfgx_split_rows_verify_f32). */
+#define TFGX_ABI_VERSION 112
 int tfgx_version(void);            /* the TFGX_ABI_VERSION the library was built with */
 const char* tfgx_last_error(void); /* host string, thread-local, valid until the next failing call */
 
@@ -531,6 +531,15 @@ int tfgx_segment_topk(const int32_t* segment, const float* score, int64_t n, int
 /* x[n, F] -> x_main[n, f_main] + x_tail[n, F - f_main] in one pass (the split source layout of tfgx_reduce_args) */
 int tfgx_split_rows_f32(const float* x, int64_t ldx, int64_t n, int64_t F, int64_t f_main, float* x_main,
                         int64_t ld_main, float* x_tail, int64_t ld_tail, tfgx_stream_t stream);
+
+/* Is the split layout still a copy of x?  Compares `samples` rows of x bit for bit with x_main / x_tail — rows 0 and n - 1
+   always, the rest drawn from (seed, i); samples >= n compares every row — and leaves 1 in *mismatch (device int32; zeroed
+   first) when any bit differs.  The host runs this before it serves a layout it built on its OWN initiative (automatic
+   promotion of a tensor seen twice): a write that bypassed torch's version counter then demotes the layout instead of being
+   aggregated from a stale copy.  (The reference never caches feature values: nn/conv/gcn.py:125-128 caches the adjacency.) */
+int tfgx_split_rows_verify_f32(const float* x, int64_t ldx, int64_t n, int64_t F, int64_t f_main, const float* x_main,
+                               int64_t ld_main, const float* x_tail, int64_t ld_tail, int64_t samples, uint64_t seed,
+                               int32_t* mismatch /* device */, tfgx_stream_t stream);
 
 /* h = h * rsqrt(max(sum(h^2), 1e-12)) per row, in place (tf.nn.l2_normalize, graph_sage.py:58) */
 int tfgx_l2_normalize_rows_f32(float* h, int64_t ld, int64_t n, int64_t F, tfgx_stream_t stream);

@@ -585,3 +585,18 @@ def test_segment_op_with_pad_routes_gradient_and_refusals(tfg, oracle):
     with pytest.raises(ValueError):
         seg.segment_max(x, ids)                                                          # ids not ascending
     assert tuple(seg.segment_max(x[:0], ids[:0]).shape) == (0, 7)
+    # integer data keeps its dtype (segment.py:12-18 pads with dtype=reduced_data.dtype) and stays exact, or is refused
+    counts = rng.integers(0, 1000, size=(2000, 3)).astype(np.int64)
+    got = seg.segment_op_with_pad(seg.segment_sum, counts, ids, 60)
+    want = np.zeros((60, 3), dtype=np.int64)
+    np.add.at(want, ids, counts)
+    assert got.dtype == torch.int64 and np.array_equal(got.cpu().numpy(), want)
+    assert seg.segment_max(np.sort(ids), np.sort(ids)).dtype == torch.int32
+    with pytest.raises(TypeError):
+        seg.segment_op_with_pad(seg.segment_sum, counts * 100000, ids, 60)               # sums beyond 2^24: not exact in float32
+    with pytest.raises(TypeError):
+        seg.segment_op_with_pad(seg.segment_mean, counts, ids, 60)
+    bad = ids.copy()
+    bad[5] = -1
+    with pytest.raises(ValueError):
+        seg.segment_op_with_pad(seg.segment_sum, x, bad, 60)                             # negative id: TF raises InvalidArgumentError

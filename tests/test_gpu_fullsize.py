@@ -204,6 +204,77 @@ def test_products_static_layout_is_promoted_automatically_on_the_second_call(tfg
     assert torch.allclose(o7, o1 * 3.0, rtol=1e-5, atol=1e-5) and "tfgx_static_rows" not in c3, same_block
 
 
+def test_a_promoted_layout_is_not_served_after_a_write_the_version_counter_missed(tfg, products):
+    """The automatic promotion copies feature VALUES the caller never promised to leave alone (the reference caches the
+    adjacency, never features: nn/conv/gcn.py:125-128), and torch's counter does not see every write.  Before a promoted
+    layout is served, sampled rows are compared with x on the device: a bulk write through `x.data` and a raw-pointer kernel
+    write (this library's own gather kernel aimed at x, no version bump) both demote the layout — the call returns the FRESH
+    aggregation; a declared layout (prepare_static_features) is the caller's contract and is not re-checked."""
+    import os
+    import ctypes
+    from tf_geometric_amd import plan as P, _lib as L
+    p = products
+    x = p["x"].clone()
+    cache = {"tfgx_csr_plan": p["plan"]}
+    layer = tfg.layers.GCN(1, use_kernel=False, use_bias=False)
+    st = lambda k: P.STATIC_STATS.get(k, 0)                           # noqa: E731
+    o1 = layer([x, p["ei"], p["w"]], cache=cache)
+    o2 = layer([x, p["ei"], p["w"]], cache=cache)                     # promoted here
+    assert cache["tfgx_static_rows"][1] is not None and torch.equal(o1, o2)
+    caught, checks = st("stale_copies_caught"), st("verifications")
+    o3 = layer([x, p["ei"], p["w"]], cache=cache)                     # served from the layout after a clean check
+    assert torch.equal(o1, o3) and st("verifications") == checks + 1 and st("stale_copies_caught") == caught
+    # (a) a write through .data: same storage, same version counter
+    v = x._version
+    x.data.mul_(2.0)
+    assert x._version == v
+    o4 = layer([x, p["ei"], p["w"]], cache=cache)
+    assert torch.equal(o4, o1 * 2.0) and st("stale_copies_caught") == caught + 1 and "tfgx_static_rows" not in cache
+    o5 = layer([x, p["ei"], p["w"]], cache=cache)                     # a storage caught once is never promoted again in this cache
+    o6 = layer([x, p["ei"], p["w"]], cache=cache)
+    assert torch.equal(o5, o4) and torch.equal(o6, o4) and "tfgx_static_rows" not in cache
+    # (b) a raw-pointer kernel of a "foreign" library writes the whole table (tfgx_gather_rows_f32 through ctypes: rows of
+    # the original features back into x) — no torch op touches x
+    x = p["x"] * 2.0
+    cache = {"tfgx_csr_plan": p["plan"]}
+    for _ in range(2):
+        layer([x, p["ei"], p["w"]], cache=cache)
+    assert cache["tfgx_static_rows"][1] is not None
+    lib = L.load_library()
+    n, f = int(x.shape[0]), int(x.shape[1])
+    idx = torch.arange(n, dtype=torch.int32, device=x.device)
+    v = x._version
+    L.check(lib.tfgx_gather_rows_f32(L.ptr(p["x"]), f, L.ptr(idx), n, f, L.ptr(x), f, L.stream_ptr()), "tfgx_gather_rows_f32")
+    assert x._version == v
+    o7 = layer([x, p["ei"], p["w"]], cache=cache)
+    assert torch.equal(o7, o1) and st("stale_copies_caught") == caught + 2
+    # (c) a write to a FEW rows is caught by the exhaustive setting at once (the default samples 4096 rows per call)
+    x = p["x"].clone()
+    cache = {"tfgx_csr_plan": p["plan"]}
+    for _ in range(2):
+        layer([x, p["ei"], p["w"]], cache=cache)
+    assert cache["tfgx_static_rows"][1] is not None
+    os.environ["TFGX_STATIC_VERIFY_ROWS"] = "all"
+    try:
+        x.data[123457, 3] += 1.0
+        o8 = layer([x, p["ei"], p["w"]], cache=cache)
+        assert st("stale_copies_caught") == caught + 3 and not torch.equal(o8, o1)
+        P.AUTO_STATIC_LAYOUT = False
+        try:
+            assert torch.equal(o8, layer([x, p["ei"], p["w"]], cache={"tfgx_csr_plan": p["plan"]}))      # == the plain path on the new values
+        finally:
+            P.AUTO_STATIC_LAYOUT = True
+    finally:
+        del os.environ["TFGX_STATIC_VERIFY_ROWS"]
+    # (d) declared layouts are not re-checked (the caller's contract), and the check can be switched off
+    tfg.release_static_features(cache)
+    tfg.prepare_static_features(x, p["plan"], cache)
+    checks = st("verifications")
+    layer([x, p["ei"], p["w"]], cache=cache)
+    assert st("verifications") == checks
+    tfg.release_static_features(cache)
+
+
 def test_a_promoted_layout_is_never_baked_into_a_capture(tfg, products):
     """hipGraph replays cannot see a version counter, and the static buffers of a captured model are exactly the tensors
     callers overwrite between replays: (i) CapturedForward's warm-up calls on its input buffer must not promote it, (ii) a

@@ -483,11 +483,13 @@ def test_fused_aggregate_gemm_declines_what_it_cannot_take(tfg, oracle):
 
 
 @pytest.mark.parametrize("mode", ["gcn", "mean"])
-@pytest.mark.parametrize("f,units,thr", [(100, 256, 64), (64, 40, 16), (36, 128, 128)])
+@pytest.mark.parametrize("f,units,thr", [(100, 256, 64), (64, 40, 16), (36, 128, 128), (100, 41, 64)])
 def test_fused_aggregate_gemm_on_a_graph_with_hub_rows(tfg, oracle, mode, f, units, thr):
     """Power-law graphs: rows longer than the plan's hub threshold are cut into chunks, reduced chunk by chunk by a launch of
     the ordinary kernel, and folded in chunk order by the row's lane group inside the fused launch — same rows as the two
-    launches (whose hub path folds the same partials in the same order) and as the float64 product."""
+    launches (whose hub path folds the same partials in the same order) and as the float64 product.  The plan is walked in
+    degree order and n = 4000 leaves a ragged last tile: units % 4 == 0 takes the 16-byte transposed stores with the row
+    ids from LDS, units = 41 the per-column stores."""
     import torch
     from tf_geometric_amd import plan as P
     L = tfg._lib

@@ -26,7 +26,7 @@ class TfgxError(RuntimeError):
     pass
 
 
-ABI_VERSION = 111      # include/tfgx.h TFGX_ABI_VERSION: struct layouts / signatures bound below
+ABI_VERSION = 112      # include/tfgx.h TFGX_ABI_VERSION: struct layouts / signatures bound below
 
 
 class ReduceArgs(ctypes.Structure):
@@ -195,6 +195,7 @@ SIGNATURES = {
     "tfgx_l2_normalize_rows_f32": (ctypes.c_int, [_P, _I64, _I64, _I64, _P]),
     "tfgx_sample_neighbors": (ctypes.c_int, [_P, _P, _P, _I64, _P, _I32, _I32, ctypes.c_uint64, _P, _P, _P]),
     "tfgx_split_rows_f32": (ctypes.c_int, [_P, _I64, _I64, _I64, _I64, _P, _I64, _P, _I64, _P]),
+    "tfgx_split_rows_verify_f32": (ctypes.c_int, [_P, _I64, _I64, _I64, _I64, _P, _I64, _P, _I64, _I64, ctypes.c_uint64, _P, _P]),
     "tfgx_gather_rows_f32": (ctypes.c_int, [_P, _I64, _P, _I64, _I64, _P, _I64, _P]),
     "tfgx_halo_workspace_bytes": (_SZ, [_I64]),
     "tfgx_halo_mark": (ctypes.c_int, [_P, _I64, _I32, _I32, _I64, _P, _P]),

@@ -138,9 +138,8 @@ __global__ __launch_bounds__(kFusedThreads) void agg_gemm_kernel(const FArgs a)
     const bool cvalid = c_raw < a.F;
     const int coff = cvalid ? c_raw : a.F - 4;              // lanes past F re-read the last valid vector (discarded)
     const int l31 = lane64 & 31, kh = lane64 >> 5;
-#if TFGX_FUSED_VEC_STORE
-    const bool vec_store = (a.N % 4 == 0) && (a.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.C) & 15) == 0);   // wave-uniform
-#endif
+    const bool vec_store = TFGX_FUSED_VEC_STORE && (a.N % 4 == 0) && (a.ldc % 4 == 0) &&
+                           ((reinterpret_cast<uintptr_t>(a.C) & 15) == 0);                                      // wave-uniform
     // per-lane source base / stride (seg_reduce_kernel's SPLIT scheme): one array normally; with split rows the lanes that own
     // columns >= f_main read the node-tail array — or, for gathered rows, the per-EDGE tail stream (indexed by CSR position)
     const float* xb = a.x + coff;           // gathered rows
@@ -387,7 +386,7 @@ __global__ __launch_bounds__(kFusedThreads) void agg_gemm_kernel(const FArgs a)
                 }
                 const int64_t row0 = (TFGX_FUSED_DBG_IS(3) ? (tile & 63) : tile) * kTileRows + mb * 32 + 4 * kh;   // dbg 3: stores land in 4096 rows
                 const bool full = tile * kTileRows + kTileRows <= a.n_dst;
-                if (a.row_order != nullptr) {
+                if (a.row_order != nullptr && !vec_store) {     // walk order without 16-byte stores (odd N / unaligned C)
                     // walk order: tile slot -> destination row through the ids the producers left in LDS
                     const int* rid = rowid + buf * kTileRows + mb * 32 + 4 * kh;
 #pragma unroll

@@ -1297,6 +1297,12 @@ int launch_gemm_rows(const float* A, int64_t lda, const float* B, int64_t ldb, c
     }();
     const int64_t max_wgs = int64_t(cus) * (mult_env > 0 ? mult_env : 1);
     dim3 grid(static_cast<unsigned>(wgs < max_wgs ? wgs : max_wgs), 1, 1), block(rows_threads<TN>(), 1, 1);
+    // claimed tiles: pool p (16 of them: ((blockIdx >> 3) & 3) * 4 + (wave & 3)) owns the tiles = p (mod 16) and is drained only
+    // by waves whose own pool id is p, so every pool needs a claimant: at least 4 waves per workgroup and workgroups
+    // 0, 8, 16, 24 present.  Smaller launches (few CUs, few tiles) take the fixed tile map instead — a pool without a
+    // claimant would leave its tiles of C unwritten.
+    static_assert(rows_threads<TN>() / 64 >= 4, "the claimed tile order needs all four (wave & 3) pool slots per workgroup");
+    if (grid.x < 32) tile_counter = nullptr;
     if (tile_counter)
         TFGX_HIP_CHECK(hipMemsetAsync(tile_counter, 0, kRowsCounterBytes, stream));
     gemm_rows_kernel<TN><<<grid, block, rows_lds_bytes(K, TN), stream>>>(A, lda, B, ldb, bias, act, act_cols, C, ldc, M, K,

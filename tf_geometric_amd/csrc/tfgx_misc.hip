@@ -296,6 +296,34 @@ __global__ __launch_bounds__(kBlock) void split_rows_kernel(const float* __restr
     }
 }
 
+// the split layout against the table it was built from, on a SAMPLE of rows (rows 0 and n - 1 always, the others drawn from
+// (seed, i)): any bit that differs raises *mismatch.  One thread per (sampled row, 4 columns).
+__global__ __launch_bounds__(kBlock) void split_rows_verify_kernel(const float* __restrict__ x, int64_t ldx, int64_t n, int F,
+                                                                   int f_main, const float* __restrict__ xm, int64_t ldm,
+                                                                   const float* __restrict__ xt, int64_t ldt, int64_t samples,
+                                                                   uint64_t seed, int32_t* __restrict__ mismatch)
+{
+    const int per_row = F / 4;
+    int64_t t = blockIdx.x * int64_t(kBlock) + threadIdx.x;
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    const int64_t total = samples * per_row;
+    bool bad = false;
+    for (; t < total; t += stride) {
+        const int64_t k = t / per_row;
+        const int j = int(t - k * per_row) * 4;
+        int64_t i;
+        if (samples >= n) i = k;                                   // full comparison
+        else if (k == 0) i = 0;
+        else if (k == 1) i = n - 1;
+        else i = int64_t((uint64_t(drop_hash(seed, uint32_t(k))) << 16 ^ drop_hash(seed ^ 0x9E3779B97F4A7C15ull, uint32_t(k))) % uint64_t(n));
+        const uint4 a = *reinterpret_cast<const uint4*>(x + i * ldx + j);
+        const uint4 b = j < f_main ? *reinterpret_cast<const uint4*>(xm + i * ldm + j)
+                                   : *reinterpret_cast<const uint4*>(xt + i * ldt + (j - f_main));
+        bad = bad || a.x != b.x || a.y != b.y || a.z != b.z || a.w != b.w;
+    }
+    if (bad) atomicOr(mismatch, 1);
+}
+
 }  // namespace
 }  // namespace tfgx
 
@@ -464,6 +492,27 @@ extern "C" int tfgx_split_rows_f32(const float* x, int64_t ldx, int64_t n, int64
     split_rows_kernel<<<grid_for(n * (F / 4), kBlock), kBlock, 0, as_stream(stream)>>>(x, ldx, n, int(F), int(f_main),
                                                                                      x_main, ld_main, x_tail, ld_tail);
     TFGX_LAUNCH_CHECK("split_rows_kernel");
+    return TFGX_OK;
+}
+
+extern "C" int tfgx_split_rows_verify_f32(const float* x, int64_t ldx, int64_t n, int64_t F, int64_t f_main, const float* x_main,
+                                          int64_t ld_main, const float* x_tail, int64_t ld_tail, int64_t samples, uint64_t seed,
+                                          int32_t* mismatch, tfgx_stream_t stream)
+{
+    TFGX_RANGE();
+    TFGX_REQUIRE(n >= 0 && F >= 8 && F % 4 == 0 && f_main > 0 && f_main < F && f_main % 4 == 0, "bad F / f_main");
+    TFGX_REQUIRE(mismatch != nullptr, "null pointer");
+    TFGX_HIP_CHECK(hipMemsetAsync(mismatch, 0, sizeof(int32_t), as_stream(stream)));
+    if (n == 0 || samples <= 0) return TFGX_OK;
+    TFGX_REQUIRE(x && x_main && x_tail, "null pointer");
+    TFGX_REQUIRE(ldx >= F && ldx % 4 == 0 && ld_main >= f_main && ld_main % 4 == 0 && ld_tail >= F - f_main &&
+                     ld_tail % 4 == 0 && aligned_to(x, 16) && aligned_to(x_main, 16) && aligned_to(x_tail, 16),
+                 "rows must be 16-byte aligned");
+    if (samples > n) samples = n;
+    if (samples < n && samples < 2) samples = 2;
+    split_rows_verify_kernel<<<grid_for(samples * (F / 4), kBlock), kBlock, 0, as_stream(stream)>>>(
+        x, ldx, n, int(F), int(f_main), x_main, ld_main, x_tail, ld_tail, samples, seed, mismatch);
+    TFGX_LAUNCH_CHECK("split_rows_verify_kernel");
     return TFGX_OK;
 }
 

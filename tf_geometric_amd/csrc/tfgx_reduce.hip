@@ -13,6 +13,14 @@
 // source row is read as one contiguous 4*F-byte burst.  The walk is unrolled by UNROLL edges so that
 // UNROLL independent loads are in flight per lane before the first FMA.  Accumulation is a single
 // in-order FMA chain per output element: deterministic, no atomics, original edge order per row.
+//
+// WIDE rows (round 5, F >= 128 with 16-byte rows): the row is NOT read as one burst.  It is cut into column blocks of
+// 64 columns (256 bytes; 128 columns at F = 256) on blockIdx.y: every launch pass gathers one block of every source row, the
+// blocks of a row are requested far apart in time.  Same-box A/B over every placement (tools/wide_row_ab.cpp,
+// profiles/r05_wide_row_ab*.jsonl): one 1 KB / 2 KB burst per row 20.0 / 43.5 ms at F = 256 / 512, the same blocks
+// requested at the same time by sibling waves (same workgroup, or workgroups on the same XCD) no better — the blocks on
+// grid.y 18.5 / 37.1 ms; EA read latency 2175 -> 1640 cycles, DRAM-credit stalls per request 0.38 -> 0.11 (pmc passes in
+// profiles/r05_wide_pmc.md).  The (col, w) stream is re-read per block (8 bytes against 256).
 #include "tfgx_common.h"
 #include <cfloat>
 #include <cstdio>
@@ -68,6 +76,9 @@ struct KArgs {
 #ifndef TFGX_REDUCE_GRID_CAP_DEFAULT
 #define TFGX_REDUCE_GRID_CAP_DEFAULT (1 << 20)
 #endif
+#ifndef TFGX_REDUCE_MASKED_TAIL
+#define TFGX_REDUCE_MASKED_TAIL 1
+#endif
 #ifndef TFGX_UNROLL_CH2
 #define TFGX_UNROLL_CH2 4
 #endif
@@ -75,7 +86,7 @@ struct KArgs {
 #define TFGX_UNROLL_CH4 2
 #endif
 
-template <int VEC, int G, int CH, bool IS_MAX, bool WEIGHTED, bool SPLIT, bool TRACK>
+template <int VEC, int G, int CH, bool IS_MAX, bool WEIGHTED, bool SPLIT, bool TRACK, int U>
 __device__ __forceinline__ void seg_reduce_row(const KArgs& a, int64_t r, int s, int e, int cj_next, float wj_next, int lane,
                                                const int (&coff)[CH], const bool (&cvalid)[CH], const float* const (&xb)[CH],
                                                const int64_t (&xl)[CH], const float* const (&xs)[CH],
@@ -86,7 +97,8 @@ __device__ __forceinline__ void seg_reduce_row(const KArgs& a, int64_t r, int s,
 // inside its row, and the epilogue writes them packed into ONE uint32 per element (count << 16 | position): the mask-form
 // backward reads that instead of a float count array and an int32 position array (rows up to 65535 edges: longer rows are
 // hub rows and take the chunked path, which does not track).
-template <int VEC, int G, int CH, bool IS_MAX, bool WEIGHTED, bool SPLIT = false, bool TRACK = false>
+// U: edges per batch (0 = the default for the group shape: 8, 4 / 2 with several column chunks per lane).
+template <int VEC, int G, int CH, bool IS_MAX, bool WEIGHTED, bool SPLIT = false, bool TRACK = false, int U = 0>
 __global__ __launch_bounds__(kBlock) void seg_reduce_kernel(const KArgs a)
 {
     constexpr int ROWS_PER_BLOCK = kBlock / G;
@@ -179,19 +191,19 @@ __global__ __launch_bounds__(kBlock) void seg_reduce_kernel(const KArgs a)
         float wj_next = wj_first;
         s = s1; e = e1; s1 = s2; e1 = e2; cj_first = cj_first1; wj_first = wj_first1;      // rotate the pipeline
         if (a.hub_threshold > 0 && e_cur - s_cur > a.hub_threshold) continue;   // handled by the chunked hub path
-        seg_reduce_row<VEC, G, CH, IS_MAX, WEIGHTED, SPLIT, TRACK>(a, row_of(r), s_cur, e_cur, cj_next, wj_next, lane, coff,
-                                                                   cvalid, xb, xl, xs, xsl, by_edge, init);
+        seg_reduce_row<VEC, G, CH, IS_MAX, WEIGHTED, SPLIT, TRACK, U>(a, row_of(r), s_cur, e_cur, cj_next, wj_next, lane, coff,
+                                                                      cvalid, xb, xl, xs, xsl, by_edge, init);
     }
 }
 
 // One destination row [s, e) of the plan, reduced by a group of G lanes (body of seg_reduce_kernel).
-template <int VEC, int G, int CH, bool IS_MAX, bool WEIGHTED, bool SPLIT, bool TRACK>
+template <int VEC, int G, int CH, bool IS_MAX, bool WEIGHTED, bool SPLIT, bool TRACK, int U>
 __device__ __forceinline__ void seg_reduce_row(const KArgs& a, int64_t r, int s, int e, int cj_next, float wj_next, int lane,
                                                const int (&coff)[CH], const bool (&cvalid)[CH], const float* const (&xb)[CH],
                                                const int64_t (&xl)[CH], const float* const (&xs)[CH],
                                                const int64_t (&xsl)[CH], const bool (&by_edge)[CH], float init)
 {
-    constexpr int UNROLL_W = (CH >= 4) ? TFGX_UNROLL_CH4 : (CH == 2 ? TFGX_UNROLL_CH2 : 8);
+    constexpr int UNROLL_W = U > 0 ? U : ((CH >= 4) ? TFGX_UNROLL_CH4 : (CH == 2 ? TFGX_UNROLL_CH2 : 8));
     constexpr int UNROLL = UNROLL_W < G ? UNROLL_W : G;
     {
         float acc[CH][VEC];
@@ -253,7 +265,8 @@ __device__ __forceinline__ void seg_reduce_row(const KArgs& a, int64_t r, int s,
                             }
                         }
             }
-            for (; j < cnt; ++j) {
+#if !TFGX_REDUCE_MASKED_TAIL
+            for (; j < cnt; ++j) {          // developer A/B (-DTFGX_REDUCE_MASKED_TAIL=0): the round 1-4 remainder, one dependent load per edge
                 const int c = bcast_i<G>(cj, j);
                 float wv = 1.0f;
                 if constexpr (WEIGHTED) wv = bcast_f<G>(wj, j);
@@ -274,6 +287,47 @@ __device__ __forceinline__ void seg_reduce_row(const KArgs& a, int64_t r, int s,
                     }
                 }
             }
+#else
+            if (j < cnt) {
+                // the last, partial batch as ONE batch (round 5): the loads of the missing slots repeat the last edge's
+                // (clamped index: the same lines, an L1 hit), the arithmetic of a missing slot is dropped by a SELECT — a
+                // branch there lets the compiler sink the slot's load into it and wait for it alone.  Until round 4 the
+                // remainder ran one dependent load per edge: up to UNROLL - 1 round trips per row, all of a short row's.
+                float xv[UNROLL][CH][VEC];
+                float ww[UNROLL];
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) {
+                    const int idx = min(j + u, cnt - 1);
+                    const int c = bcast_i<G>(cj, idx);
+                    if constexpr (WEIGHTED) ww[u] = bcast_f<G>(wj, idx);
+#pragma unroll
+                    for (int k = 0; k < CH; ++k) {
+                        if constexpr (SPLIT) load_vec<VEC>(xb[k] + (by_edge[k] ? int64_t(base + idx) : int64_t(c)) * xl[k], xv[u][k]);
+                        else load_vec<VEC>(a.x + int64_t(c) * a.ldx + coff[k], xv[u][k]);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) {
+                    const bool live = j + u < cnt;
+#pragma unroll
+                    for (int k = 0; k < CH; ++k)
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) {
+                            if constexpr (IS_MAX) {
+                                const float m = WEIGHTED ? xv[u][k][v] * ww[u] : xv[u][k][v];
+                                if constexpr (TRACK) {
+                                    if (live) track_step(k, v, m, base + j + u);
+                                }
+                                const float t = fmaxf(acc[k][v], m);
+                                acc[k][v] = live ? t : acc[k][v];
+                            } else {
+                                const float t = WEIGHTED ? fmaf(ww[u], xv[u][k][v], acc[k][v]) : acc[k][v] + xv[u][k][v];
+                                acc[k][v] = live ? t : acc[k][v];
+                            }
+                        }
+                }
+            }
+#endif
         }
 
         // ---- epilogue (per destination row) ----
@@ -397,7 +451,18 @@ inline int reduce_grid_cap()
     return cap;
 }
 
-template <int VEC, int G, int CH>
+// developer A/B: TFGX_REDUCE_WIDE_BLOCKS=0 runs wide rows as one burst per row again (the round 1-4 shapes)
+inline bool wide_blocks_enabled()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("TFGX_REDUCE_WIDE_BLOCKS");
+        v = (e != nullptr && atoi(e) == 0) ? 0 : 1;
+    }
+    return v != 0;
+}
+
+template <int VEC, int G, int CH, int U = 0>
 int launch_cfg(const KArgs& a, bool is_max, bool weighted, int ny, hipStream_t stream)
 {
     constexpr int ROWS_PER_BLOCK = kBlock / G;
@@ -408,11 +473,11 @@ int launch_cfg(const KArgs& a, bool is_max, bool weighted, int ny, hipStream_t s
     if constexpr (VEC == 4 && CH == 1) {
         if (a.x_tail != nullptr) {   // split rows: sum / mean only (the case that matters: 400-byte rows)
             if (is_max) {
-                if (weighted) seg_reduce_kernel<VEC, G, CH, true, true, true><<<grid, block, dummy_lds_bytes(), stream>>>(a);
-                else seg_reduce_kernel<VEC, G, CH, true, false, true><<<grid, block, dummy_lds_bytes(), stream>>>(a);
+                if (weighted) seg_reduce_kernel<VEC, G, CH, true, true, true, false, U><<<grid, block, dummy_lds_bytes(), stream>>>(a);
+                else seg_reduce_kernel<VEC, G, CH, true, false, true, false, U><<<grid, block, dummy_lds_bytes(), stream>>>(a);
             } else {
-                if (weighted) seg_reduce_kernel<VEC, G, CH, false, true, true><<<grid, block, dummy_lds_bytes(), stream>>>(a);
-                else seg_reduce_kernel<VEC, G, CH, false, false, true><<<grid, block, dummy_lds_bytes(), stream>>>(a);
+                if (weighted) seg_reduce_kernel<VEC, G, CH, false, true, true, false, U><<<grid, block, dummy_lds_bytes(), stream>>>(a);
+                else seg_reduce_kernel<VEC, G, CH, false, false, true, false, U><<<grid, block, dummy_lds_bytes(), stream>>>(a);
             }
             TFGX_LAUNCH_CHECK("seg_reduce_kernel<split>");
             return TFGX_OK;
@@ -424,8 +489,8 @@ int launch_cfg(const KArgs& a, bool is_max, bool weighted, int ny, hipStream_t s
     }
     if (a.track != nullptr) {
         if constexpr (VEC == 4 && CH == 1) {
-            if (weighted) seg_reduce_kernel<VEC, G, CH, true, true, false, true><<<grid, block, dummy_lds_bytes(), stream>>>(a);
-            else seg_reduce_kernel<VEC, G, CH, true, false, false, true><<<grid, block, dummy_lds_bytes(), stream>>>(a);
+            if (weighted) seg_reduce_kernel<VEC, G, CH, true, true, false, true, U><<<grid, block, dummy_lds_bytes(), stream>>>(a);
+            else seg_reduce_kernel<VEC, G, CH, true, false, false, true, U><<<grid, block, dummy_lds_bytes(), stream>>>(a);
             TFGX_LAUNCH_CHECK("seg_reduce_kernel<track>");
             return TFGX_OK;
         }
@@ -433,37 +498,51 @@ int launch_cfg(const KArgs& a, bool is_max, bool weighted, int ny, hipStream_t s
         return TFGX_ERR_INVALID_ARG;
     }
     if (is_max) {
-        if (weighted) seg_reduce_kernel<VEC, G, CH, true, true><<<grid, block, dummy_lds_bytes(), stream>>>(a);
-        else seg_reduce_kernel<VEC, G, CH, true, false><<<grid, block, dummy_lds_bytes(), stream>>>(a);
+        if (weighted) seg_reduce_kernel<VEC, G, CH, true, true, false, false, U><<<grid, block, dummy_lds_bytes(), stream>>>(a);
+        else seg_reduce_kernel<VEC, G, CH, true, false, false, false, U><<<grid, block, dummy_lds_bytes(), stream>>>(a);
     } else {
-        if (weighted) seg_reduce_kernel<VEC, G, CH, false, true><<<grid, block, dummy_lds_bytes(), stream>>>(a);
-        else seg_reduce_kernel<VEC, G, CH, false, false><<<grid, block, dummy_lds_bytes(), stream>>>(a);
+        if (weighted) seg_reduce_kernel<VEC, G, CH, false, true, false, false, U><<<grid, block, dummy_lds_bytes(), stream>>>(a);
+        else seg_reduce_kernel<VEC, G, CH, false, false, false, false, U><<<grid, block, dummy_lds_bytes(), stream>>>(a);
     }
     TFGX_LAUNCH_CHECK("seg_reduce_kernel");
     return TFGX_OK;
 }
 
-// lanes needed to cover one row with one chunk each -> (G, CH): the ONE place the group shape is decided
-// (launch_vec dispatches on it, tfgx_segment_reduce_describe reports it)
-inline void group_shape(int lanes, int* G, int* CH)
+// Group shape of a launch: lanes per row G, column chunks per lane CH, column blocks on grid.y NY, edges per batch U
+// (0 = default) — the ONE place it is decided (launch_vec dispatches on it, tfgx_segment_reduce_describe reports it).
+struct GroupShape { int G, CH, NY, U; };
+
+inline GroupShape group_shape(const KArgs& a, int vec)
 {
-    *CH = 1;
-    if (lanes <= 4) *G = 4;
-    else if (lanes <= 8) *G = 8;
-    else if (lanes <= 16) *G = 16;
-    else if (lanes <= 32) *G = 32;
-    else if (lanes <= 64) *G = 64;
-    else if (lanes <= 128) { *G = 64; *CH = 2; }
-    else { *G = 64; *CH = 4; }      // wider rows: column blocks of 64*VEC*4 on grid.y
+    const int lanes = (a.F + vec - 1) / vec;
+    // wide rows made of whole 128-byte lines (F >= 128, F % 32 == 0, line-aligned table, no split layout): column blocks of
+    // 64 columns (two lines per gathered piece) on grid.y, 16 pieces in flight per lane — see the head of this file.  Rows
+    // that are NOT whole lines keep the single burst: every block boundary inside a line would cost one more line request.
+    // F = 256 runs as two 128-column blocks (same-box A/B: 18.5 ms against 19.3 for four blocks, 20.0 for one burst).
+    if (vec == 4 && a.F >= 128 && a.F % 32 == 0 && a.ldx % 32 == 0 && aligned_to(a.x, 128) && a.x_tail == nullptr && wide_blocks_enabled()) {
+        const int g = a.F == 256 ? 32 : 16;
+        return GroupShape{g, 1, (lanes + g - 1) / g, 16};
+    }
+    if (lanes <= 4) return GroupShape{4, 1, 1, 0};
+    if (lanes <= 8) return GroupShape{8, 1, 1, 0};
+    if (lanes <= 16) return GroupShape{16, 1, 1, 0};
+    if (lanes <= 32) return GroupShape{32, 1, 1, 0};
+    if (lanes <= 64) return GroupShape{64, 1, 1, 0};
+    if (lanes <= 128) return GroupShape{64, 2, 1, 0};
+    const int per = 64 * 4;      // wider rows: column blocks of 64 lanes x 4 chunks on grid.y (col / w re-read per block)
+    return GroupShape{64, 4, (lanes + per - 1) / per, 0};
 }
 
 template <int VEC>
 int launch_vec(const KArgs& a, bool is_max, bool weighted, hipStream_t stream)
 {
-    int G, CH;
-    group_shape((a.F + VEC - 1) / VEC, &G, &CH);
-    if (CH == 1) {
-        switch (G) {
+    const GroupShape g = group_shape(a, VEC);
+    if constexpr (VEC == 4) {
+        if (g.U == 16 && g.G == 16) return launch_cfg<4, 16, 1, 16>(a, is_max, weighted, g.NY, stream);
+        if (g.U == 16 && g.G == 32) return launch_cfg<4, 32, 1, 16>(a, is_max, weighted, g.NY, stream);
+    }
+    if (g.CH == 1) {
+        switch (g.G) {
             case 4: return launch_cfg<VEC, 4, 1>(a, is_max, weighted, 1, stream);
             case 8: return launch_cfg<VEC, 8, 1>(a, is_max, weighted, 1, stream);
             case 16: return launch_cfg<VEC, 16, 1>(a, is_max, weighted, 1, stream);
@@ -471,10 +550,8 @@ int launch_vec(const KArgs& a, bool is_max, bool weighted, hipStream_t stream)
             default: return launch_cfg<VEC, 64, 1>(a, is_max, weighted, 1, stream);
         }
     }
-    if (CH == 2) return launch_cfg<VEC, 64, 2>(a, is_max, weighted, 1, stream);
-    // col/w are re-read per column block: 8 B vs >= 1 KiB of x
-    const int per = 64 * VEC * 4;
-    return launch_cfg<VEC, 64, 4>(a, is_max, weighted, (a.F + per - 1) / per, stream);
+    if (g.CH == 2) return launch_cfg<VEC, 64, 2>(a, is_max, weighted, 1, stream);
+    return launch_cfg<VEC, 64, 4>(a, is_max, weighted, g.NY, stream);
 }
 
 // Hub rows (in-degree > hub_threshold): the row is cut into chunks of consecutive edges, every chunk is reduced like
@@ -574,11 +651,12 @@ extern "C" int tfgx_segment_reduce_describe(const tfgx_reduce_args* p, char* buf
 {
     TFGX_REQUIRE(p != nullptr && buf != nullptr && buf_bytes > 0, "null argument");
     const int vec = vector_width(p);
-    int G, CH;
-    group_shape(int((p->F + vec - 1) / vec), &G, &CH);
-    const bool split = p->x_tail != nullptr && vec == 4 && CH == 1;
-    snprintf(buf, buf_bytes, "seg_reduce_kernel<%d, %d, %d, %s, %s, %s, %s>", vec, G, CH, p->op == TFGX_MAX ? "true" : "false",
-             p->w ? "true" : "false", split ? "true" : "false", p->track ? "true" : "false");
+    KArgs a;
+    a.F = int32_t(p->F); a.ldx = p->ldx; a.x = p->x; a.x_tail = p->x_tail;
+    const GroupShape g = group_shape(a, vec);
+    const bool split = p->x_tail != nullptr && vec == 4 && g.CH == 1;
+    snprintf(buf, buf_bytes, "seg_reduce_kernel<%d, %d, %d, %s, %s, %s, %s, %d>", vec, g.G, g.CH, p->op == TFGX_MAX ? "true" : "false",
+             p->w ? "true" : "false", split ? "true" : "false", p->track ? "true" : "false", g.U);
     return TFGX_OK;
 }
 

@@ -44,9 +44,22 @@ def _rows(data):
     return (d.reshape(-1, 1), True) if d.dim() == 1 else (d.reshape(int(d.shape[0]), -1), False)
 
 
+def _integer_dtype(data):
+    """torch integer dtype of `data` (a torch tensor or anything numpy understands), None for floating point."""
+    if isinstance(data, torch.Tensor):
+        return None if data.dtype.is_floating_point else (data.dtype if data.dtype != torch.bool else torch.int32)
+    import numpy as np
+    kind = np.asarray(data).dtype.kind
+    if kind in "iub":
+        return {1: torch.int8, 2: torch.int16, 4: torch.int32, 8: torch.int64}.get(np.asarray(data).dtype.itemsize, torch.int64) \
+            if kind == "i" else (torch.int64 if kind == "u" else torch.int32)
+    return None
+
+
 def _segment(data, segment_ids, num_segments, op):
     """One launch of the segment-reduce kernel over rows grouped by id; a segment without rows holds 0 (the sorted TF ops'
     documented value for an empty segment — NOT float32 lowest, which is what the unsorted max holds)."""
+    int_dtype = _integer_dtype(data)              # the sorted TF ops (and segment_op_with_pad's pads) keep the data dtype
     d = L.as_f32(data)
     d2, squeeze = _rows(d)
     ids = L.as_i32(segment_ids)
@@ -54,6 +67,8 @@ def _segment(data, segment_ids, num_segments, op):
     if int(d2.shape[0]) != n_rows:
         raise ValueError("segment op: data has {} rows, segment_ids {}".format(int(d2.shape[0]), n_rows))
     n = int(num_segments)
+    if n_rows and int(ids.min().item()) < 0:
+        raise ValueError("segment op: negative segment id {}".format(int(ids.min().item())))      # TF: InvalidArgumentError
     from ...plan import segment_reduce
     plan = CsrPlan.build(torch.stack([ids, torch.arange(n_rows, dtype=torch.int32, device=ids.device)]), n, max(n_rows, 1))
     kind, flip = {"sum": (L.SUM, False), "mean": (L.MEAN, False), "max": (L.MAX, False), "min": (L.MAX, True)}[op]
@@ -63,6 +78,16 @@ def _segment(data, segment_ids, num_segments, op):
         out = -out
     if kind == L.MAX:
         out = torch.where((plan.in_degree() == 0).unsqueeze(-1), torch.zeros((), dtype=out.dtype, device=out.device), out)
+    if int_dtype is not None:
+        # integer data (counts, ids): the kernel computes in float32, which is exact only below 2^24 — checked, not assumed
+        if op == "mean":
+            raise TypeError("segment_mean of integer data is not supported (float32 kernel): cast to float32 first")
+        terms = int(plan.in_degree().max().item()) if (n_rows and op == "sum") else 1
+        bound = (float(d2.abs().max().item()) if n_rows else 0.0) * max(terms, 1)
+        if bound >= 2.0 ** 24:
+            raise TypeError("segment_{} of {} data: |value| x segment length reaches {:.3g} >= 2^24, beyond what the float32 "
+                            "kernel represents exactly".format(op, int_dtype, bound))
+        out = out.to(int_dtype)
     return out.reshape(n) if squeeze else out.reshape((n,) + tuple(d.shape[1:]))
 
 
@@ -72,7 +97,7 @@ def _sorted_segment_op(op):
         ids = L.as_i32(segment_ids)
         if int(ids.shape[0]) == 0:
             d = L.as_f32(data)
-            return torch.zeros((0,) + tuple(d.shape[1:]), dtype=torch.float32, device=d.device)
+            return torch.zeros((0,) + tuple(d.shape[1:]), dtype=_integer_dtype(data) or torch.float32, device=d.device)
         if bool((ids[1:] < ids[:-1]).any().item()):
             raise ValueError("segment ids are not increasing")            # TF: InvalidArgumentError
         return _segment(data, ids, int(ids[-1].item()) + 1, op)

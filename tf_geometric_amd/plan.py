@@ -367,6 +367,7 @@ import weakref as _weakref
 AUTO_STATIC_LAYOUT = _os.environ.get("TFGX_STATIC_LAYOUT", "auto") != "explicit"
 CACHE_KEY_STATIC_SEEN = "tfgx_static_seen"        # {data_ptr: (weakref(x), key, launch counter at first sight)}
 CACHE_KEY_STATIC_AUTO = "tfgx_static_auto"        # True while the opt-in in this cache was made by the promotion
+CACHE_KEY_STATIC_DISTRUST = "tfgx_static_distrust"  # weakref(storage) whose promoted copy went stale behind the version counter
 _AGG_LAUNCHES = [0]                                # aggregation launches so far (segment_reduce / aggregate_gemm)
 
 
@@ -409,6 +410,9 @@ def _auto_promote(x, plan, cache):
             or not x.is_cuda or not SplitRows.wanted(int(x.shape[0]), int(x.shape[1]))
             or torch.cuda.is_current_stream_capturing()):
         return False
+    bad = cache.get(CACHE_KEY_STATIC_DISTRUST)
+    if bad is not None and bad() is x.untyped_storage():
+        return False                                   # caught once with a write the version counter missed (static_rows)
     seen = cache.setdefault(CACHE_KEY_STATIC_SEEN, {})
     key = _static_key(x, plan)
     # "the same tensor" = the same live STORAGE (layers see a fresh .detach() view of the caller's tensor on every call;
@@ -431,7 +435,49 @@ def _auto_promote(x, plan, cache):
     cache[CACHE_KEY_STATIC] = x
     cache[CACHE_KEY_STATIC_AUTO] = True
     STATIC_STATS["auto_promotions"] = STATIC_STATS.get("auto_promotions", 0) + 1
+    STATIC_STATS["auto_promoted_bytes"] = need
+    import logging
+    logging.getLogger("tf_geometric_amd").info(
+        "static feature layout: tensor [%d, %d] seen unchanged twice -> split + edge-tail copy of %.2f GB held in the graph's "
+        "cache (TFGX_STATIC_LAYOUT=explicit turns this off; tfg.release_static_features(cache) frees it)",
+        int(x.shape[0]), F, need / 1e9)
     return True
+
+
+# FAIL-SAFE of the automatic promotion (round 5): a layout this library built on its own initiative is a COPY of feature values
+# the caller never promised to leave alone, and torch's version counter does not see every write (x.data.copy_, DLPack, a
+# foreign kernel, the tf.load_op_library route).  Before such a layout is served, a sample of its rows is compared bit for bit
+# with x on the device (tfgx_split_rows_verify_f32: rows 0 and n - 1 and TFGX_STATIC_VERIFY_ROWS - 2 rows drawn afresh for every
+# call — 4096 by default, "all" compares every row); a mismatch demotes the layout and the call reads x itself.  A bulk
+# rewrite of the table is caught on the first call after it, a write to a few rows as soon as a draw covers one of them
+# (every row with TFGX_STATIC_VERIFY_ROWS=all, at the cost of one more pass over x); layouts the caller DECLARED
+# (prepare_static_features) are the caller's contract and are not re-checked.  Costs one small launch and one 4-byte read-back
+# per served call (~20 us beside a 7 ms aggregation at products shape: automatic_promotion.ms_per_call in the bench line).
+_VERIFY_CALLS = [0]
+
+
+def _verify_rows_setting():
+    v = _os.environ.get("TFGX_STATIC_VERIFY_ROWS", "4096")
+    return -1 if v == "all" else max(int(v), 0)
+
+
+def _promoted_layout_is_current(x, rows):
+    """True when the sampled rows of the promoted layout `rows` still equal x (always True with the check switched off)."""
+    samples = _verify_rows_setting()
+    if samples == 0:
+        return True
+    n, F = int(x.shape[0]), int(x.shape[1])
+    if samples < 0:
+        samples = n
+    lib = L.require_gpu()
+    flag = torch.empty(1, dtype=torch.int32, device=x.device)
+    _VERIFY_CALLS[0] += 1
+    L.check(lib.tfgx_split_rows_verify_f32(L.ptr(x), int(x.stride(0)), n, F, int(rows.main.shape[1]), L.ptr(rows.main), int(rows.main.stride(0)),
+                                           L.ptr(rows.tail), int(rows.tail.stride(0)), samples,
+                                           (0x5DEECE66D * _VERIFY_CALLS[0] + 11) & 0xFFFFFFFFFFFFFFFF, L.ptr(flag), L.stream_ptr()),
+            "tfgx_split_rows_verify_f32")
+    STATIC_STATS["verifications"] = STATIC_STATS.get("verifications", 0) + 1
+    return int(flag.item()) == 0
 
 
 def static_rows(x, plan, cache):
@@ -463,6 +509,15 @@ def static_rows(x, plan, cache):
             return x
     hit = cache.get(CACHE_KEY_STATIC_ROWS)
     if hit is not None and hit[0] == _static_key(x, plan):
+        if hit[1] is not None and cache.get(CACHE_KEY_STATIC_AUTO) and not _promoted_layout_is_current(x, hit[1]):
+            # written to behind the version counter: the promoted copy is stale — drop it, read x, start counting again
+            release_static_features(cache)
+            STATIC_STATS["auto_demotions"] = STATIC_STATS.get("auto_demotions", 0) + 1
+            STATIC_STATS["stale_copies_caught"] = STATIC_STATS.get("stale_copies_caught", 0) + 1
+            # its owner writes behind the version counter: "seen unchanged twice" cannot be established for this storage any
+            # more — it is never promoted again in this cache (an explicit prepare_static_features still works)
+            cache[CACHE_KEY_STATIC_DISTRUST] = _weakref.ref(x.untyped_storage())
+            return x
         if hit[1] is not None:
             STATIC_STATS["hits"] += 1
         return x if hit[1] is None else hit[1]
