@@ -46,7 +46,7 @@ enum { TFGX_NORM_BOTH = 0, TFGX_NORM_LEFT = 1, TFGX_NORM_RIGHT = 2 };
 /* ABI version of this header: bumped whenever an entry point's signature or a struct's layout changes (a host built
  * against another value must refuse to run: tf_geometric_amd/_lib.py does).  100 = rounds 1-3; 110 = round 4
  * (tfgx_reduce_args.hub_order_slot; tfgx_aggregate_gemm_f32 honours args->out as a side output of the aggregate;
- * tfgx_gat_args / tfgx_gat_backward_args .drop_seed_dev); 111 = + tfgx_column_sum_f32; 112 = round 5 (+ tfgx_split_rows_verify_f32). */
+ * tfgx_gat_args / tfgx_gat_backward_args .drop_seed_dev); 111 = + tfgx_column_sum_f32; 112 = round 5 (+ tfgx_split_rows_verify_f32, tfgx_reduce_args.wide_blocks). */
 #define TFGX_ABI_VERSION 112
 int tfgx_version(void);            /* the TFGX_ABI_VERSION the library was built with */
 const char* tfgx_last_error(void); /* host string, thread-local, valid until the next failing call */
@@ -158,6 +158,13 @@ typedef struct tfgx_reduce_args {
        destination row row_order[i], for i < n_hub_rows (a walk order sorted by descending length puts the hub rows first).
        Checked against hub_rows before use; NULL or a mismatch costs a binary search per hub row instead of one load. */
     const int32_t* hub_order_slot;
+    /* Wide rows (F >= 128 made of whole 128-byte lines; tfgx_segment_reduce_f32 only): 0 = the library's policy — column blocks
+       of 64 columns on grid.y, every pass gathering one block of every source row (round 5: +7 ... +17 % at F = 128 ... 512 on
+       the uniform products-shaped graph) —, 1 = blocks wherever the layout allows, -1 = one burst per source row (what a host
+       passes for a power-law plan at widths that are not a power of two: its walk is mostly short rows, whose start-up is
+       paid once per pass).  Results do not depend on it. */
+    int32_t wide_blocks;
+    int32_t reserved_r5;
 } tfgx_reduce_args;
 
 int tfgx_segment_reduce_f32(const tfgx_reduce_args* args /* host */, tfgx_stream_t stream);

@@ -745,7 +745,7 @@ def test_hip_gcn_layer_gradients_match_tf_registered_gradients(tfg, oracle):
     assert_parity(layer.bias.grad.cpu().numpy(), db, tol=2e-5, what="gcn d/dbias")
 
 
-@pytest.mark.parametrize("f,weighted", [(100, True), (64, False), (32, True), (256, False), (36, True)])
+@pytest.mark.parametrize("f,weighted", [(100, True), (64, False), (32, True), (256, False), (36, True), (512, False), (384, True)])
 def test_tracked_max_forward_equals_the_arg_kernel(tfg, oracle, f, weighted):
     """tfgx_reduce_args.track (the tuned segment-reduce walk with the tie count and the first maximal edge's position
     tracked online, packed count << 16 | row-relative position) vs tfgx_segment_max_with_arg_f32: identical maxima,

@@ -47,6 +47,7 @@ class ReduceArgs(ctypes.Structure):
         ("row_order", ctypes.c_void_p),
         ("track", ctypes.c_void_p), ("ld_track", ctypes.c_int64), ("track_row_begin", ctypes.c_void_p),
         ("hub_order_slot", ctypes.c_void_p),
+        ("wide_blocks", ctypes.c_int32), ("reserved_r5", ctypes.c_int32),
     ]
 
 

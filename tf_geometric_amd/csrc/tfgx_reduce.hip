@@ -71,6 +71,7 @@ struct KArgs {
     const int32_t* track_row_begin;   // optional: positions are stored relative to track_row_begin[row * rp_stride]
     const float* edge_tail;  // optional with SPLIT: the tail columns of every edge's SOURCE row, in this plan's edge order
     int64_t ld_edge_tail;    // (streamed next to col / w instead of gathered: one line request fewer per edge)
+    int32_t wide_blocks;     // tfgx_reduce_args.wide_blocks: 0 = library policy, 1 = column blocks, -1 = one burst per row
 };
 
 #ifndef TFGX_REDUCE_GRID_CAP_DEFAULT
@@ -105,6 +106,11 @@ __global__ __launch_bounds__(kBlock) void seg_reduce_kernel(const KArgs a)
     constexpr int COLS_PER_PASS = G * VEC * CH;
     const int lane = threadIdx.x % G;
     const int grp = threadIdx.x / G;
+    // column blocks on grid.y (wide rows): the launch works through the passes in order, so at any moment every workgroup
+    // gathers the SAME column block of its source rows — the table a pass touches is 1 / gridDim.y of the whole (a 614 MB stripe
+    // of a 4.9 GB table at F = 512).  That is what the gain comes from: the same blocks ROTATED over the workgroups
+    // ((blockIdx.x + blockIdx.y) mod gridDim.y, all stripes live at once) run no faster than one burst per row
+    // (profiles/r05_ab_wide_blocks_modes_uniform.jsonl: 40.0 vs 47.8 vs 46.1 ms at F = 512).
     const int colbase = a.col0 + blockIdx.y * COLS_PER_PASS;
 
     // column offsets of this lane; lanes past F re-read the last valid vector (branch-free, discarded)
@@ -265,7 +271,10 @@ __device__ __forceinline__ void seg_reduce_row(const KArgs& a, int64_t r, int s,
                             }
                         }
             }
-#if !TFGX_REDUCE_MASKED_TAIL
+            // (narrow rows, G < 16, keep the one-load-per-edge remainder: they are bound by instruction issue, and the
+            // repeated loads of the masked batch cost 4 % at F = 32 — profiles/r05_ab_masked_tail.jsonl)
+            constexpr bool kMaskedTail = TFGX_REDUCE_MASKED_TAIL && G >= 16;
+            if constexpr (!kMaskedTail) {
             for (; j < cnt; ++j) {          // developer A/B (-DTFGX_REDUCE_MASKED_TAIL=0): the round 1-4 remainder, one dependent load per edge
                 const int c = bcast_i<G>(cj, j);
                 float wv = 1.0f;
@@ -287,7 +296,7 @@ __device__ __forceinline__ void seg_reduce_row(const KArgs& a, int64_t r, int s,
                     }
                 }
             }
-#else
+            } else {
             if (j < cnt) {
                 // the last, partial batch as ONE batch (round 5): the loads of the missing slots repeat the last edge's
                 // (clamped index: the same lines, an L1 hit), the arithmetic of a missing slot is dropped by a SELECT — a
@@ -327,7 +336,7 @@ __device__ __forceinline__ void seg_reduce_row(const KArgs& a, int64_t r, int s,
                         }
                 }
             }
-#endif
+            }
         }
 
         // ---- epilogue (per destination row) ----
@@ -461,6 +470,15 @@ inline bool wide_blocks_enabled()
     }
     return v != 0;
 }
+inline int wide_g256()              // developer A/B: lanes per row at F = 256 (two 128-column blocks or four 64-column ones)
+{
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("TFGX_REDUCE_WIDE_G256");
+        v = (e != nullptr && atoi(e) == 16) ? 16 : 32;
+    }
+    return v;
+}
 
 template <int VEC, int G, int CH, int U = 0>
 int launch_cfg(const KArgs& a, bool is_max, bool weighted, int ny, hipStream_t stream)
@@ -494,7 +512,7 @@ int launch_cfg(const KArgs& a, bool is_max, bool weighted, int ny, hipStream_t s
             TFGX_LAUNCH_CHECK("seg_reduce_kernel<track>");
             return TFGX_OK;
         }
-        set_error("tfgx_segment_reduce_f32: track needs 16-byte aligned rows of F <= 256 columns, F % 4 == 0");
+        set_error("tfgx_segment_reduce_f32: track needs 16-byte aligned rows, F % 4 == 0, of F <= 256 columns or of whole 128-byte lines");
         return TFGX_ERR_INVALID_ARG;
     }
     if (is_max) {
@@ -519,8 +537,12 @@ inline GroupShape group_shape(const KArgs& a, int vec)
     // 64 columns (two lines per gathered piece) on grid.y, 16 pieces in flight per lane — see the head of this file.  Rows
     // that are NOT whole lines keep the single burst: every block boundary inside a line would cost one more line request.
     // F = 256 runs as two 128-column blocks (same-box A/B: 18.5 ms against 19.3 for four blocks, 20.0 for one burst).
-    if (vec == 4 && a.F >= 128 && a.F % 32 == 0 && a.ldx % 32 == 0 && aligned_to(a.x, 128) && a.x_tail == nullptr && wide_blocks_enabled()) {
-        const int g = a.F == 256 ? 32 : 16;
+    // The caller's hint (tfgx_reduce_args.wide_blocks) can switch the blocks off (-1): on a power-law plan the walk is mostly
+    // short rows, whose per-row start-up is paid once per pass, and the hot source rows already hit in the caches with one
+    // burst per row (R-MAT at products size, F = 192 / 224: 13.4 / 15.7 ms with bursts against 14.6 / 18.0 with blocks).
+    if (vec == 4 && a.F >= 128 && a.F % 32 == 0 && a.ldx % 32 == 0 && aligned_to(a.x, 128) && a.x_tail == nullptr &&
+        a.wide_blocks >= 0 && (a.wide_blocks > 0 || wide_blocks_enabled())) {
+        const int g = a.F == 256 ? wide_g256() : 16;
         return GroupShape{g, 1, (lanes + g - 1) / g, 16};
     }
     if (lanes <= 4) return GroupShape{4, 1, 1, 0};
@@ -652,7 +674,7 @@ extern "C" int tfgx_segment_reduce_describe(const tfgx_reduce_args* p, char* buf
     TFGX_REQUIRE(p != nullptr && buf != nullptr && buf_bytes > 0, "null argument");
     const int vec = vector_width(p);
     KArgs a;
-    a.F = int32_t(p->F); a.ldx = p->ldx; a.x = p->x; a.x_tail = p->x_tail;
+    a.F = int32_t(p->F); a.ldx = p->ldx; a.x = p->x; a.x_tail = p->x_tail; a.wide_blocks = p->wide_blocks;
     const GroupShape g = group_shape(a, vec);
     const bool split = p->x_tail != nullptr && vec == 4 && g.CH == 1;
     snprintf(buf, buf_bytes, "seg_reduce_kernel<%d, %d, %d, %s, %s, %s, %s, %d>", vec, g.G, g.CH, p->op == TFGX_MAX ? "true" : "false",
@@ -682,6 +704,7 @@ extern "C" int tfgx_segment_reduce_f32(const tfgx_reduce_args* p, tfgx_stream_t 
     a.hub_threshold = 0;
     a.x_tail = p->x_tail; a.ld_tail = p->ld_tail; a.f_main = int32_t(p->f_main);
     a.edge_tail = p->edge_tail; a.ld_edge_tail = p->ld_edge_tail;
+    a.wide_blocks = p->wide_blocks;
     a.row_order = p->row_order;
     a.track = p->track; a.ld_track = p->ld_track; a.track_row_begin = p->track_row_begin;
     if (p->track) {

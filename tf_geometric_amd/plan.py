@@ -623,6 +623,13 @@ def segment_reduce(plan, x, op, w_csr=None, out=None, act=L.ACT_NONE, self_coef=
         a.hub_chunk_begin, a.hub_chunk_end = chunk_begin.data_ptr(), chunk_end.data_ptr()
         a.n_hub_rows, a.n_hub_chunks = int(hub_rows.shape[0]), int(chunk_begin.shape[0])
         a.hub_scratch = scratch.data_ptr()
+    if hub is not None and F & (F - 1) != 0:
+        # power-law plan (hub lists present), row stride not a power of two: one burst per source row (tfgx.h wide_blocks).
+        # Same-box A/B on the products-sized R-MAT graph (profiles/r05_ab_wide_blocks_modes_rmat.jsonl): F = 192 / 224
+        # 13.4 / 15.7 ms with bursts against 14.6 / 18.0 with column blocks (mostly short rows: the start-up of a row is
+        # paid once per pass, and the hot source rows already hit in the caches); at F = 128 / 512, where a power-of-two
+        # stride folds the hot rows onto few cache sets, the blocks win (11.2 -> 9.4 ms, 50.8 -> 48.1) and stay on.
+        a.wide_blocks = -1
     if describe:
         buf = ctypes.create_string_buffer(160)
         L.check(lib.tfgx_segment_reduce_describe(ctypes.byref(a), buf, 160), "tfgx_segment_reduce_describe")
@@ -718,10 +725,13 @@ def aggregate_gemm(plan, x, op, kernel, w_csr=None, self_coef=None, bias=None, a
 
 def can_track(plan, x2, ldx):
     """Can the TRAINING forward of max aggregation run on the tuned segment-reduce kernel with packed tie counts / first
-    positions (tfgx_reduce_args.track)?  16-byte aligned rows of 32 <= F <= 256 columns (the dwordx4, one-chunk-per-lane
-    instantiations), no hub rows (hub rows are chunked and do not track) and every row shorter than 65536 edges."""
+    positions (tfgx_reduce_args.track)?  16-byte aligned rows of 32 <= F <= 256 columns — or wider line-aligned rows — (the
+    dwordx4, one-chunk-per-lane instantiations), no hub rows (hub rows are chunked and do not track) and every row shorter than 65536 edges."""
     F = int(x2.shape[1])
-    return (F % 4 == 0 and 32 <= F <= 256 and ldx % 4 == 0 and x2.data_ptr() % 16 == 0 and plan.hub_info() is None
+    # one 16-byte chunk per lane: rows up to 256 columns, or — round 5 — any wider row made of whole 128-byte lines, which the
+    # kernel walks in 64-column blocks on grid.y (tfgx_reduce.hip group_shape; TFGX_REDUCE_WIDE_BLOCKS=0 switches them off)
+    wide = (F % 32 == 0 and ldx % 32 == 0 and x2.data_ptr() % 128 == 0 and _os.environ.get("TFGX_REDUCE_WIDE_BLOCKS", "2") != "0")
+    return (F % 4 == 0 and F >= 32 and (F <= 256 or wide) and ldx % 4 == 0 and x2.data_ptr() % 16 == 0 and plan.hub_info() is None
             and int(getattr(plan, "hub_threshold", 1 << 30)) < 65536)
 
 

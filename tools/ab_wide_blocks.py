@@ -22,9 +22,10 @@ ei = L.as_i32(synthetic.synthetic_edge_stripe(n, e, seed=0)) if graph == "unifor
 E = int(ei.shape[1])
 plan = P.CsrPlan.build(ei, n, n)
 plan.hub_info()
+torch.manual_seed(11)                      # the same operands in every process: the checksums of two settings must agree
 w = torch.rand(E, device=dev) + 0.5
 sc = torch.rand(n, device=dev)
-tag = {"wide_blocks": os.environ.get("TFGX_REDUCE_WIDE_BLOCKS", "1"), "lib": os.path.basename(os.path.dirname(os.environ.get("TFGX_LIB_PATH", "lib/x")))}
+tag = {"wide_blocks": os.environ.get("TFGX_REDUCE_WIDE_BLOCKS", "2"), "g256": os.environ.get("TFGX_REDUCE_WIDE_G256", "32"), "lib": os.path.basename(os.path.dirname(os.environ.get("TFGX_LIB_PATH", "lib/x")))}
 
 
 def timeit(fn, steps=6, warmup=2):
