@@ -46,7 +46,7 @@ enum { TFGX_NORM_BOTH = 0, TFGX_NORM_LEFT = 1, TFGX_NORM_RIGHT = 2 };
 /* ABI version of this header: bumped whenever an entry point's signature or a struct's layout changes (a host built
  * against another value must refuse to run: tf_geometric_amd/_lib.py does).  100 = rounds 1-3; 110 = round 4
  * (tfgx_reduce_args.hub_order_slot; tfgx_aggregate_gemm_f32 honours args->out as a side output of the aggregate;
- * tfgx_gat_args / tfgx_gat_backward_args .drop_seed_dev); 111 = + tfgx_column_sum_f32; 112 = round 5 (+ tfgx_split_rows_verify_f32, tfgx_reduce_args.wide_blocks). */
+ * tfgx_gat_args / tfgx_gat_backward_args .drop_seed_dev); 111 = + tfgx_column_sum_f32; 112 = round 5 (+ tfgx_split_rows_verify_f32, tfgx_reduce_args.wide_blocks, tfgx_gat_args.state_in_*, tfgx_gat_backward_args.span_*). */
 #define TFGX_ABI_VERSION 112
 int tfgx_version(void);            /* the TFGX_ABI_VERSION the library was built with */
 const char* tfgx_last_error(void); /* host string, thread-local, valid until the next failing call */
@@ -282,6 +282,15 @@ typedef struct tfgx_gat_args {
        launches captured into a hipGraph, whose arguments are frozen: the captured step advances the value on the device, so
        every replay draws a new mask (forward and backward of one step read the same location). */
     const uint64_t* drop_seed_dev;
+    /* optional (round 5): RESUME.  The walk of every launched part starts from the raw state stored here — (acc, m, l) as
+       state_acc / state_ml hold them, same indexing — instead of the empty state, and ends as usual: with state_acc set the
+       updated raw state is written (it must not alias the state read), without it the row is finished (self-loop, normalise,
+       bias, activation, stats_ml).  Chaining KB launches over the SOURCE BLOCKS of a plan whose rows are partitioned by
+       source range (row_begin / row_end / rp_stride = KB) makes every launch gather K / V rows of one block only: on a dense
+       graph (Reddit shape: 489 in-edges per node, 67 MB of K | V rows) a block fits the L2 of every XCD and the layer's
+       attention runs 1.5x faster.  Not combinable with drop_rate > 0 or the hub lists. */
+    const float* state_in_acc;     /* [n_parts, H*dv] */
+    const float* state_in_ml;      /* [n_parts, 2*H]  */
 } tfgx_gat_args;
 
 /* 1 if the item survives dropout at `rate`, else 0: the exact decision every kernel of this library makes for
@@ -434,6 +443,18 @@ typedef struct tfgx_gat_backward_args {
     const int32_t* row_order;
     const int32_t* row_order_t;
     const uint64_t* drop_seed_dev;                /* see tfgx_gat_args.drop_seed_dev (same location as the forward) */
+    /* optional (round 5): ONE BLOCK of a source-blocked pass.  Row p of the pass being called (destination for the dst pass,
+       source for the src pass) walks positions [span_begin[p * span_stride], span_end[p * span_stride]) of the col / dst_t
+       array handed in — a plan whose rows are partitioned by the range of the OTHER endpoint (CsrPlan.source_blocks) —; with
+       accumulate = 1 the gradients of the pass are ADDED to the stored ones (blocks are launched in order, so the sum is
+       deterministic); add_self_loop is set by the caller on the last block only.  Every launch then gathers rows of one
+       block, which the L2 of every XCD serves (see tfgx_gat_args.state_in_acc).  Fast-kernel head geometries, no attention
+       dropout, no hub lists.  NULL span_begin = the plain pass over row_ptr / row_ptr_t. */
+    const int32_t* span_begin;
+    const int32_t* span_end;
+    int64_t span_stride;
+    int32_t accumulate;
+    int32_t reserved3;
 } tfgx_gat_backward_args;
 
 /* Prepares both backward passes in ONE sweep over the destination rows: dsum[r, h] = <dO[r, h, :], O[r, h, :]> (dense

@@ -324,6 +324,40 @@ def test_gat_layer_grads(tfg, oracle, heads, att, units):
         assert_parity(getattr(layer, k).grad.cpu().numpy(), r[k].grad.numpy(), tol=2e-4, what="gat d/d" + k)
 
 
+def test_gat_layer_grads_in_source_blocks(tfg, oracle):
+    """Training forward in chained source-block launches, destination pass (dQ) in source blocks and source pass (dK, dV) in
+    destination blocks with the gradients accumulated block by block: outputs and every gradient against float64 autograd."""
+    from tf_geometric_amd.nn.conv import gat as G
+    x, ei, w, rng = _graph(oracle, n=300, e=20000, f=9, seed=31)
+    n, f = x.shape
+    heads, att, units = 4, 8, 16
+    layer = tfg.layers.GAT(units, attention_units=att, activation=tfg.relu, num_heads=heads)
+    layer._maybe_build([x])
+    ws = dict(query_kernel=oracle.glorot_uniform(rng, f, att), key_kernel=oracle.glorot_uniform(rng, f, att),
+              kernel=oracle.glorot_uniform(rng, f, units), query_bias=(rng.standard_normal(att) * 0.3).astype(np.float32),
+              key_bias=(rng.standard_normal(att) * 0.3).astype(np.float32), bias=(rng.standard_normal(units) * 0.1).astype(np.float32))
+    layer.set_weights(**ws)
+    layer.trainable(True)
+    xt = torch.tensor(x, device="cuda", requires_grad=True)
+    before, bw_before = G.SOURCE_BLOCK_STATS["launches"], G.SOURCE_BLOCK_STATS.get("backward_launches", 0)
+    G.SOURCE_BLOCKS = 5
+    try:
+        out = layer([xt, ei])
+        gout = torch.tensor(rng.standard_normal((n, units)).astype(np.float32), device="cuda")
+        out.backward(gout)
+    finally:
+        G.SOURCE_BLOCKS = None
+    assert G.SOURCE_BLOCK_STATS["launches"] == before + 5 and G.SOURCE_BLOCK_STATS.get("backward_launches", 0) >= bw_before + 10
+    r = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in ws.items()}
+    xr = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    ref = _ref_gat(xr, ei, r["query_kernel"], r["query_bias"], r["key_kernel"], r["key_bias"], r["kernel"], r["bias"], heads, n)
+    ref.backward(gout.double().cpu())
+    assert_parity(out.detach().cpu().numpy(), ref.detach().numpy(), what="gat forward (source blocks)")
+    assert_parity(xt.grad.cpu().numpy(), xr.grad.numpy(), tol=5e-5, what="gat d/dx (source blocks)")
+    for k in ws:
+        assert_parity(getattr(layer, k).grad.cpu().numpy(), r[k].grad.numpy(), tol=2e-4, what="gat d/d" + k)
+
+
 @pytest.mark.parametrize("cls", ["MeanGraphSage", "SumGraphSage", "MaxPoolGraphSage", "MeanPoolGraphSage", "GCNGraphSage"])
 def test_sage_layers_train_step_decreases_loss(tfg, oracle, cls):
     """Every GraphSAGE variant is differentiable end to end: a few SGD steps reduce a regression loss."""

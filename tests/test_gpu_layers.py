@@ -88,6 +88,41 @@ def test_gat_layer(tfg, oracle, heads, att, units, split):
     assert_parity(got, ref, what="GAT H={} A={} U={} split={}".format(heads, att, units, split))
 
 
+@pytest.mark.parametrize("heads,att,units,kb", [(8, 8, 64, 4), (8, 64, 64, 3), (1, 1, 44, 2), (4, 16, 20, 7), (2, 6, 10, 5)])
+def test_gat_source_blocks_equal_the_oracle(tfg, oracle, heads, att, units, kb):
+    """Dense graphs run the fused attention as KB chained launches over SOURCE BLOCKS (each launch gathers K / V rows of one
+    block; the raw online-softmax state is handed from launch to launch, the last one appends the self-loop edge): the same
+    layer output as the reference within the plain band — only the order in which a row's edges enter its softmax sums
+    changes — for every head geometry class, with empty (row, block) spans, isolated nodes and explicit self-loops."""
+    from tf_geometric_amd.nn.conv import gat as G
+    x, ei, w, rng = _graph(oracle, 600, 30000, 30, seed=heads + att + kb)
+    ei = ei[:, (ei[0] != 17) & (ei[0] != 333)]                                           # two rows without in-edges
+    ei = np.concatenate([ei, np.stack([np.arange(20, dtype=np.int32)] * 2)], axis=1)     # explicit self-loops are kept
+    layer = tfg.layers.GAT(units, attention_units=att, activation=tfg.relu, num_heads=heads)
+    layer._maybe_build([x])
+    wq, wk = oracle.glorot_uniform(rng, 30, att), oracle.glorot_uniform(rng, 30, att)
+    bq, bk = (rng.standard_normal(att) * 0.2).astype(np.float32), (rng.standard_normal(att) * 0.2).astype(np.float32)
+    wv, b = oracle.glorot_uniform(rng, 30, units), (rng.standard_normal(units) * 0.1).astype(np.float32)
+    layer.set_weights(query_kernel=wq, query_bias=bq, key_kernel=wk, key_bias=bk, kernel=wv, bias=b)
+    ref = oracle.gat(x, ei, wq, bq, "relu", wk, bk, "relu", wv, b, "relu", num_heads=heads)
+    one = layer([x, ei]).cpu().numpy()
+    before = G.SOURCE_BLOCK_STATS["launches"]
+    G.SOURCE_BLOCKS = kb
+    try:
+        got = layer([x, ei], cache={}).cpu().numpy()
+    finally:
+        G.SOURCE_BLOCKS = None
+    assert G.SOURCE_BLOCK_STATS["launches"] == before + kb
+    assert_parity(got, ref, what="GAT in {} source blocks H={} A={} U={}".format(kb, heads, att, units))
+    assert_parity(got, one, what="source blocks vs one pass")
+    # the policy: Reddit-like density and table size -> blocks; products-like density -> one pass
+    class _P(object):
+        def __init__(self, n, e):
+            self.n_dst, self.n_src, self.num_edges = n, n, e
+    assert G.source_block_count(_P(233000, 114000000), 8, 64) == 8 and G.source_block_count(_P(2400000, 123000000), 8, 64) == 1
+    assert G.source_block_count(_P(600, 30000), 8, 64) == 1
+
+
 def test_gat_large_scores_online_softmax(tfg, oracle):
     """Scores spanning about +-25 force many running-max rescales; existing self-loops are kept (duplicates).
     A score s carries an fp32 rounding error of ~|s|*1e-7 which exp() turns into the same RELATIVE error of the

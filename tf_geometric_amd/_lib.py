@@ -73,6 +73,7 @@ class GatArgs(ctypes.Structure):
         ("drop_self_base", ctypes.c_int64),
         ("row_order", ctypes.c_void_p),
         ("drop_seed_dev", ctypes.c_void_p),
+        ("state_in_acc", ctypes.c_void_p), ("state_in_ml", ctypes.c_void_p),
     ]
 
 
@@ -130,6 +131,8 @@ class GatBackwardArgs(ctypes.Structure):
         ("ld_stats_ml", ctypes.c_int64), ("ld_dsum", ctypes.c_int64),
         ("row_order", ctypes.c_void_p), ("row_order_t", ctypes.c_void_p),
         ("drop_seed_dev", ctypes.c_void_p),
+        ("span_begin", ctypes.c_void_p), ("span_end", ctypes.c_void_p), ("span_stride", ctypes.c_int64),
+        ("accumulate", ctypes.c_int32), ("reserved3", ctypes.c_int32),
     ]
 
 

@@ -660,8 +660,29 @@ class _GatAttention(torch.autograd.Function):
         # partials added in order — dQ over the forward plan's hub destinations, dK / dV over the transposed plan's hub sources
         hub_d, nc_d = L.hub_lists(plan)
         sc_d = torch.empty(max(nc_d * A, 1), dtype=torch.float32, device=dev) if hub_d is not None else None
-        L.check(lib.tfgx_gat_backward_dst_hub_f32(ctypes.byref(a), None if hub_d is None else ctypes.byref(hub_d),
-                                                  L.ptr(sc_d), L.stream_ptr()), "tfgx_gat_backward_dst_hub_f32")
+        # dense graphs: both passes in chained launches over the blocks of the OTHER endpoint (nn/conv/gat.source_block_count:
+        # each launch gathers rows of one block, served by the L2 of every XCD; gradients accumulate block by block)
+        from .nn.conv.gat import source_block_count, SOURCE_BLOCK_STATS
+        d_h, dv_h = A // H, W // H
+        blocks_ok = (ctx.drop[0] <= 0.0 and hf is None and hub_d is None and ro is None and ro_t is None and
+                     d_h in (1, 2, 4, 8, 16, 32) and dv_h % 4 == 0 and dv_h // 4 <= 64 and
+                     (((dv_h // 4) & (dv_h // 4 - 1)) == 0 or H == 1) and ldv % 4 == 0 and ldg % 4 == 0 and
+                     V2.data_ptr() % 16 == 0 and g2.data_ptr() % 16 == 0)
+        kb_d = source_block_count(plan, A, W) if blocks_ok else 1
+        blk_d = plan.source_blocks(kb_d) if kb_d >= 2 else None
+        if blk_d is not None:
+            rpk, col_k = blk_d
+            for b in range(kb_d):
+                a.col = col_k.data_ptr()
+                a.span_begin, a.span_end, a.span_stride = rpk[b:].data_ptr(), rpk[b + 1:].data_ptr(), kb_d
+                a.accumulate, a.add_self_loop = (1 if b else 0), (1 if b == kb_d - 1 else 0)
+                L.check(lib.tfgx_gat_backward_dst_hub_f32(ctypes.byref(a), None, None, L.stream_ptr()),
+                        "tfgx_gat_backward_dst_hub_f32 (source block)")
+            a.col, a.span_begin, a.span_end, a.span_stride, a.accumulate, a.add_self_loop = plan.col.data_ptr(), 0, 0, 0, 0, 1
+            SOURCE_BLOCK_STATS["backward_launches"] = SOURCE_BLOCK_STATS.get("backward_launches", 0) + kb_d
+        else:
+            L.check(lib.tfgx_gat_backward_dst_hub_f32(ctypes.byref(a), None if hub_d is None else ctypes.byref(hub_d),
+                                                      L.ptr(sc_d), L.stream_ptr()), "tfgx_gat_backward_dst_hub_f32")
         a.grad_out, a.ld_grad_out = pack.data_ptr(), P
         a.q, a.ldq = pack.data_ptr() + 4 * W, P
         a.stats_ml, a.ld_stats_ml = pack.data_ptr() + 4 * (W + A), P
@@ -689,8 +710,21 @@ class _GatAttention(torch.autograd.Function):
             L.check(lib.tfgx_gat_backward_src_hub_f32(ctypes.byref(a), None, None, L.stream_ptr()),
                     "tfgx_gat_backward_src_hub_f32 (own rows)")
         else:
-            L.check(lib.tfgx_gat_backward_src_hub_f32(ctypes.byref(a), None if hub_s is None else ctypes.byref(hub_s),
-                                                      L.ptr(sc_s), L.stream_ptr()), "tfgx_gat_backward_src_hub_f32")
+            # the source pass gathers the packed DESTINATION rows (P floats each): blocks of destinations
+            kb_s = source_block_count(pt, P, 0) if (blocks_ok and hub_s is None and gv.stride(0) % 4 == 0) else 1
+            blk_s = pt.source_blocks(kb_s) if kb_s >= 2 else None
+            if blk_s is not None:
+                rpk_t, dst_k = blk_s
+                for b in range(kb_s):
+                    a.dst_t = dst_k.data_ptr()
+                    a.span_begin, a.span_end, a.span_stride = rpk_t[b:].data_ptr(), rpk_t[b + 1:].data_ptr(), kb_s
+                    a.accumulate, a.add_self_loop = (1 if b else 0), (1 if b == kb_s - 1 else 0)
+                    L.check(lib.tfgx_gat_backward_src_hub_f32(ctypes.byref(a), None, None, L.stream_ptr()),
+                            "tfgx_gat_backward_src_hub_f32 (destination block)")
+                SOURCE_BLOCK_STATS["backward_launches"] = SOURCE_BLOCK_STATS.get("backward_launches", 0) + kb_s
+            else:
+                L.check(lib.tfgx_gat_backward_src_hub_f32(ctypes.byref(a), None if hub_s is None else ctypes.byref(hub_s),
+                                                          L.ptr(sc_s), L.stream_ptr()), "tfgx_gat_backward_src_hub_f32")
         return None, None, gq, gk, gv, None, None, None, None
 
 

@@ -210,6 +210,8 @@ struct GArgs {
     const int32_t* row_order;   // walk order of the main launch (NULL: identity)
     float* state_acc;     // [n_parts, W]
     float* state_ml;      // [n_parts, 2H]  (m, l) per head
+    const float* state_in_acc;   // optional: the walk of part p RESUMES from this stored state instead of (0, -FLT_MAX, 0) —
+    const float* state_in_ml;    // source-blocked passes chained through the state (tfgx_gat_args.state_in_acc)
     int32_t hub_threshold;
     float* stats_ml;      // [n_dst, 2H] final (m, l) for the backward pass, or NULL
     DropCfg drop;         // attention dropout (training): acc += p * keep_scale_or_0 * V; the denominator is untouched
@@ -274,6 +276,11 @@ __global__ __launch_bounds__(kBlock) void gat_fused_kernel(const GArgs a)
         float acc[VEC];
 #pragma unroll
         for (int i = 0; i < VEC; ++i) acc[i] = 0.0f;
+        if (a.state_in_acc) {   // resume the online softmax where the previous pass over this part left it
+            load_vec<VEC>(a.state_in_acc + part * a.W + coff, acc);
+            m = a.state_in_ml[part * 2 * a.H + 2 * head];
+            l = a.state_in_ml[part * 2 * a.H + 2 * head + 1];
+        }
 
         auto step = [&](float sc, const float (&vv)[VEC], int64_t pos) {
             const float mn = fmaxf(m, sc);
@@ -540,6 +547,12 @@ extern "C" int tfgx_gat_fused_f32(const tfgx_gat_args* p, tfgx_stream_t stream_)
     a.rp_stride = p->row_begin ? p->rp_stride : 1;
     TFGX_REQUIRE(a.row_end != nullptr && a.rp_stride >= 1, "bad row_begin / row_end / rp_stride");
     a.part_row = nullptr; a.state_acc = p->state_acc; a.state_ml = p->state_ml; a.hub_threshold = 0;
+    a.state_in_acc = p->state_in_acc; a.state_in_ml = p->state_in_ml;
+    TFGX_REQUIRE((p->state_in_acc == nullptr) == (p->state_in_ml == nullptr), "state_in_acc and state_in_ml go together");
+    TFGX_REQUIRE(p->state_in_acc == nullptr || (p->state_in_acc != p->state_acc && p->state_in_ml != p->state_ml),
+                 "the resumed state must not alias the state being written");
+    TFGX_REQUIRE(p->state_in_acc == nullptr || (p->drop_rate == 0.0f && !(p->hub_threshold > 0 && p->n_hub_rows > 0 && p->state_acc == nullptr)),
+                 "state_in cannot be combined with attention dropout or the hub lists");
     a.stats_ml = p->stats_ml;
     a.row_order = (p->state_acc == nullptr && p->row_begin == nullptr) ? p->row_order : nullptr;
     if (p->state_acc) {

@@ -672,8 +672,10 @@ struct GB {
     const int32_t* row_ptr;   // forward plan (by destination) or transposed plan (by source)
     const int32_t* other;     // col (sources) for the dst pass; destinations for the src pass
     int64_t n;                // rows (or parts) of this launch
-    const int32_t* row_begin; // part p spans [row_begin[p], row_end[p]) of row part_row[p] (NULL: p); plain launch: row_ptr, row_ptr+1
+    const int32_t* row_begin; // part p spans [row_begin[p * rp_stride], row_end[p * rp_stride]) of row part_row[p] (NULL: p); plain launch: row_ptr, row_ptr+1
     const int32_t* row_end;
+    int64_t rp_stride;        // 1, or KB for one block of a source-blocked plan (tfgx_gat_backward_args.span_*)
+    int32_t accumulate;       // 1: add to the gradients already stored (later blocks of a source-blocked pass)
     const int32_t* part_row;
     int32_t skip;             // > 0: parts longer than this are left to the chunk launch (hub rows)
     const int32_t* row_order; // walk order of a plain launch (NULL: identity): rows of similar length share a wave
@@ -895,7 +897,7 @@ __global__ __launch_bounds__(kBlock) void gat_backward_fast_kernel(const GB a)
 
     for (int64_t pi = int64_t(blockIdx.x) * ROWS_PER_BLOCK + grp; pi < a.n; pi += int64_t(gridDim.x) * ROWS_PER_BLOCK) {
         const int64_t part = a.row_order ? int64_t(a.row_order[pi]) : pi;
-        const int s0 = a.row_begin[part], e0 = a.row_end[part];
+        const int s0 = a.row_begin[part * a.rp_stride], e0 = a.row_end[part * a.rp_stride];
         if (a.skip > 0 && e0 - s0 > a.skip) continue;             // a hub row: walked chunk-wise by a second launch
         const int64_t row = a.part_row ? int64_t(a.part_row[part]) : part;
         // "mine": the row this group owns (destination r for the dst pass, source c for the src pass)
@@ -982,12 +984,21 @@ __global__ __launch_bounds__(kBlock) void gat_backward_fast_kernel(const GB a)
         if (a.add_self_loop && row < a.n_self && (a.part_row == nullptr || e0 == a.row_ptr[row + 1]))
             edge(row, drop_scale(a.drop, uint32_t((a.drop.self_base + row) * a.H + head)));
         if (SRC) {
-            if (cvalid) store_vec<VEC>(a.gv + part * a.ldgv + coff, acc_v);
+            if (cvalid) {
+                float* gvp = a.gv + part * a.ldgv + coff;
+                if (a.accumulate) {                                 // blocks are applied in order: previous blocks + this one
+                    float prev[VEC];
+                    load_vec<VEC>(gvp, prev);
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) acc_v[i] = prev[i] + acc_v[i];
+                }
+                store_vec<VEC>(gvp, acc_v);
+            }
         }
         if (head_first) {
             float* dst = (SRC ? a.gk + part * a.ldgk : a.gq + part * a.ldgq) + head * a.d;
 #pragma unroll
-            for (int t = 0; t < D; ++t) dst[t] = acc_qk[t];
+            for (int t = 0; t < D; ++t) dst[t] = a.accumulate ? dst[t] + acc_qk[t] : acc_qk[t];
         }
     }
 }
@@ -1386,8 +1397,17 @@ template <bool SRC>
 static int gat_backward_pass(const tfgx_gat_backward_args* p, GB& a, const tfgx_hub_lists* hub, float* scratch,
                              hipStream_t stream)
 {
-    a.row_begin = a.row_ptr; a.row_end = a.row_ptr + 1; a.part_row = nullptr; a.skip = 0;
+    a.row_begin = a.row_ptr; a.row_end = a.row_ptr + 1; a.part_row = nullptr; a.skip = 0; a.rp_stride = 1; a.accumulate = 0;
     a.row_order = SRC ? p->row_order_t : p->row_order;
+    if (p->span_begin != nullptr) {
+        // one block of a source-blocked pass (tfgx.h): explicit spans, gradients accumulated over the blocks in launch order
+        TFGX_REQUIRE(p->span_end != nullptr && p->span_stride >= 1, "span_begin needs span_end and span_stride >= 1");
+        TFGX_REQUIRE(gat_bwd_fast_ok(p) && p->drop_rate == 0.0f && hub == nullptr,
+                     "span passes: fast-kernel head geometry only, no attention dropout, no hub lists");
+        a.row_begin = p->span_begin; a.row_end = p->span_end; a.rp_stride = p->span_stride; a.accumulate = p->accumulate ? 1 : 0;
+        a.row_order = nullptr;
+        return launch_gat_bwd<SRC>(a, stream);
+    }
     if (!gat_bwd_fast_ok(p)) {
         if (SRC) gat_backward_src_kernel<<<grid_for(a.n * a.H, kBlock), kBlock, 0, stream>>>(a);
         else gat_backward_dst_kernel<<<grid_for(a.n * a.H, kBlock), kBlock, 0, stream>>>(a);

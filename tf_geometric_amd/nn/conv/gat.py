@@ -133,6 +133,59 @@ def _set_drop(a, drop_rate, drop_seed, self_base):
         a.drop_seed = int(drop_seed) & 0xFFFFFFFFFFFFFFFF
 
 
+SOURCE_BLOCKS = None      # developer A/B: None = the policy below, 0 / 1 = always one pass, k >= 2 = always k source blocks
+SOURCE_BLOCK_BYTES = 8 << 20          # K | V rows gathered per pass (same-box sweep at the Reddit shape: 8.4 MB blocks — KB = 8 —
+SOURCE_BLOCK_MIN_EDGES = 32           # beat 16.8 / 4.2 / 2.1 MB; at least this many edges per (row, block) on average
+SOURCE_BLOCK_STATS = {"launches": 0}  # diagnostics (tests assert the route taken)
+
+
+def source_block_count(plan, A, W):
+    """How many source blocks the fused attention runs in (1 = one pass).  Dense graphs only: the K | V table
+    (n_src x (A + W) floats) must be several blocks large and every (row, block) must still hold a few dozen edges —
+    Reddit shape (233 k nodes, 489 in-edges each, A = 8, W = 64): 8 blocks; products shape (51 in-edges): 1."""
+    if SOURCE_BLOCKS is not None:
+        return max(int(SOURCE_BLOCKS), 1)
+    if plan.n_dst == 0 or plan.num_edges == 0:
+        return 1
+    table = plan.n_src * (int(A) + int(W)) * 4
+    kb = min(int(round(table / float(SOURCE_BLOCK_BYTES))), int(plan.num_edges / float(plan.n_dst) / SOURCE_BLOCK_MIN_EDGES), 16)
+    return kb if kb >= 2 else 1
+
+
+def _gat_attention_source_blocks(plan, blocks, KB, Q, K, V, num_heads, add_self_loop, bias, act, stats_ml, scale_d):
+    """KB chained launches of tfgx_gat_fused_f32, launch b over the edges whose source lies in block b: the raw online-softmax
+    state of every row is handed from launch to launch (tfgx_gat_args.state_in_*), the last launch appends the self-loop
+    edge and finishes the rows.  Every launch gathers K / V rows of ONE block, which the L2 of every XCD then serves
+    (Reddit shape: 5.8 -> 3.5 ms).  The result differs from the one-pass kernel only by the order in which a row's edges
+    enter its softmax sums (by source block, original order inside a block)."""
+    lib = L.require_gpu()
+    rpk, col_k = blocks
+    n, W = plan.n_dst, int(V.shape[1])
+    dev = V.device
+    bufs = [(torch.empty((n, W), dtype=torch.float32, device=dev), torch.empty((n, 2 * num_heads), dtype=torch.float32, device=dev))
+            for _ in range(2 if KB > 2 else 1)]
+    out = None
+    prev = None
+    for b in range(KB):
+        last = b == KB - 1
+        a, o, keep = gat_args(Q, K, V, num_heads, n, col_k, add_self_loop if last else False, bias if last else None,
+                              act if last else L.ACT_NONE, scale_d=scale_d, out=None if last else bufs[b % len(bufs)][0])
+        a.row_begin, a.row_end, a.rp_stride = rpk[b:].data_ptr(), rpk[b + 1:].data_ptr(), KB
+        if prev is not None:
+            a.state_in_acc, a.state_in_ml = prev[0].data_ptr(), prev[1].data_ptr()
+        if last:
+            out = o
+            if stats_ml is not None:
+                a.stats_ml = stats_ml.data_ptr()
+        else:
+            cur = bufs[b % len(bufs)]
+            a.state_acc, a.state_ml = cur[0].data_ptr(), cur[1].data_ptr()
+            prev = cur
+        L.check(lib.tfgx_gat_fused_f32(ctypes.byref(a), L.stream_ptr()), "tfgx_gat_fused_f32")
+    SOURCE_BLOCK_STATS["launches"] += KB
+    return out
+
+
 def gat_attention(plan, Q, K, V, num_heads, add_self_loop=True, bias=None, act=L.ACT_NONE, stats_ml=None,
                   drop_rate=0.0, drop_seed=0, scale_d=None):
     """Fused SDDMM + edge softmax + SpMM over `plan` (tfgx_gat_fused_f32). Q:[n_dst,A] K:[n_src,A] V:[n_src,W].
@@ -140,6 +193,11 @@ def gat_attention(plan, Q, K, V, num_heads, add_self_loop=True, bias=None, act=L
     drop_rate > 0 (training): the softmax weights are dropped / rescaled inside the kernel (gat.py:85); the keep
     decision is a function of (drop_seed, CSR position, head), positions [E, E+n) being the appended self-loops."""
     lib = L.require_gpu()
+    if drop_rate <= 0.0 and plan.row_order() is None and plan.hub_info() is None:
+        KB = source_block_count(plan, int(Q.shape[1]), int(V.shape[1]))
+        blocks = plan.source_blocks(KB) if KB >= 2 else None
+        if blocks is not None:
+            return _gat_attention_source_blocks(plan, blocks, KB, Q, K, V, num_heads, add_self_loop, bias, act, stats_ml, scale_d)
     a, out, keep = gat_args(Q, K, V, num_heads, plan.n_dst, plan.col, add_self_loop, bias, act, scale_d=scale_d)
     a.row_ptr = plan.row_ptr.data_ptr()
     order = plan.row_order()                 # skewed graphs: rows of similar length share a wave

@@ -143,6 +143,30 @@ class CsrPlan(object):
             self._hub = build_hub_lists(self.row_ptr[:-1], self.row_ptr[1:], thr, chunk) or False
         return self._hub or None
 
+    def source_blocks(self, num_blocks):
+        """The plan with every destination row's edges stably partitioned by SOURCE BLOCK (block b = sources
+        [b * ceil(n_src / KB), (b + 1) * ...)): (rpk int32 [n_dst * KB + 1], col_k int32 [E]) — row r's edges
+        from block b sit at positions [rpk[r * KB + b], rpk[r * KB + b + 1]) of col_k (a row's edges keep their order inside a block).  KB chained
+        launches over the blocks (row_begin = rpk + b, row_end = rpk + b + 1, rp_stride = KB) each gather rows of one block
+        only (nn/conv/gat.py: dense graphs whose K | V table fits the L2 block by block).  Built once per (plan, KB) with
+        device sorts; E * 12 bytes while building, E * 4 + n_dst * KB * 4 kept."""
+        KB = int(num_blocks)
+        memo = self.__dict__.setdefault("_source_blocks", {})
+        if KB not in memo:
+            if torch.cuda.is_current_stream_capturing():
+                return None
+            dev = self.col.device
+            blk = max(-(-self.n_src // KB), 1)
+            rows = torch.repeat_interleave(torch.arange(self.n_dst, device=dev, dtype=torch.int64), self.in_degree().long())
+            key = rows * KB + torch.div(self.col.long(), blk, rounding_mode="floor")
+            del rows
+            order = torch.argsort(key, stable=True)
+            rpk = torch.zeros(self.n_dst * KB + 1, dtype=torch.int32, device=dev)
+            rpk[1:] = torch.cumsum(torch.bincount(key, minlength=self.n_dst * KB), 0).to(torch.int32)
+            del key
+            memo[KB] = (rpk, self.col[order].contiguous())
+        return memo[KB]
+
     def hub_order_slot(self):
         """int32 [n_hub]: the slot in hub_rows of walk-order entry i (row_order sorts by descending length, so its first
         n_hub entries ARE the hub rows) — tfgx_reduce_args.hub_order_slot; None without hub rows / walk order."""

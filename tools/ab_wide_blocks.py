@@ -41,9 +41,11 @@ def timeit(fn, steps=6, warmup=2):
     return e0.elapsed_time(e1) / steps
 
 
+pad = int(os.environ.get("AB_LD_PAD", "0"))          # AB_LD_PAD=32: the table's rows start (F + 32) floats apart (a view of a wider array)
+tag["ld_pad"] = pad
 for f in widths:
-    x = torch.randn(n, f, device=dev)
-    out = torch.empty_like(x)
+    x = torch.randn(n, f + pad, device=dev)[:, :f] if pad else torch.randn(n, f, device=dev)
+    out = torch.empty((n, f), dtype=torch.float32, device=dev)
     for name, op, ww, s in (("sum_w_self", L.SUM, w, sc), ("max", L.MAX, None, None)):
         if name == "max" and f not in (100, 256, 512):
             continue

@@ -30,6 +30,11 @@ elif variant == "rmat_row_order":
     P.ROW_ORDER_MAX_F = 256
 ei = L.as_i32(synthetic.synthetic_edge_stripe(n, e, seed=0)) if variant == "uniform" else synthetic.rmat_edges(n, e, 7, dev)
 x = L.as_f32(synthetic.synthetic_feature_rows(n, f, seed=1))
+_pad = int(os.environ.get("RMAT_LD_PAD", "0"))       # rows (F + pad) floats apart: is it the power-of-two row stride?
+if _pad:
+    _wide = torch.empty((n, f + _pad), dtype=torch.float32, device=dev)
+    _wide[:, :f] = x
+    x = _wide[:, :f]
 normed = gcn_norm_adj(tfg.SparseMatrix(ei, None, [n, n]), sym=True)
 plan = normed.plan
 hub = plan.hub_info()
