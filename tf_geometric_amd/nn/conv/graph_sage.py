@@ -260,11 +260,14 @@ def _pool_graph_sage(x, edge_index, edge_weight, self_kernel, neighbor_mlp_kerne
     plan = CsrPlan.from_cache(edge_index, n, n, cache)
     act, post = _resolve_act(activation)
     if AG.needs_grad(x, neighbor_mlp_kernel, neighbor_mlp_bias, self_kernel, neighbor_kernel, bias):
-        h = AG.apply_activation(AG.linear(x, neighbor_mlp_kernel, neighbor_mlp_bias, act), L.ACT_NONE, post)
+        h = AG.apply_activation(AG.linear(x, neighbor_mlp_kernel, neighbor_mlp_bias, act, gathered=True), L.ACT_NONE, post)
         reduced = AG.aggregate(plan, h, op)
         return _combine(L.as_f32(self_kernel), x, L.as_f32(neighbor_kernel), reduced, bias, activation, concat,
                         normalize)
-    h = gemm_bias_act(x, neighbor_mlp_kernel, bias=neighbor_mlp_bias, act=act)      # :199-204 per node (weight == 1)
+    # :199-204 per node (weight == 1).  The [N, 4 * ku] MLP rows are gathered next: written at a gather-friendly stride (units
+    # 256 -> 512 columns -> rows 544 floats apart: a 2 KB row stride costs the max reduce 20 %, plan.pow2_row_stride)
+    h = gemm_bias_act(x, neighbor_mlp_kernel, bias=neighbor_mlp_bias, act=act,
+                      out=gather_friendly_empty(n, int(neighbor_mlp_kernel.shape[1]), x.device))
     if post is not None:
         h = post(h)
     wn, ws = L.as_f32(neighbor_kernel), L.as_f32(self_kernel)

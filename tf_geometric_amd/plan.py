@@ -574,6 +574,37 @@ def edge_weight_csr(plan, edge_weight, cache=None):
     return w_csr
 
 
+RELAY_POW2_TABLES = True     # developer A/B switch
+
+
+def relaid_for_gather(x, ldx, plan_is_skewed):
+    """A caller's dense [n, F] table whose row stride is a power of two (pow2_row_stride) -> the same rows 32 floats further
+    apart, when one strided copy (read + write of the table) costs less than it saves: strides of 2 KB and more on any graph
+    (uniform products graph, F = 512: 43.8 -> 36.7 ms for a 2 ms copy), 512 bytes and more on a power-law plan (R-MAT, F = 256:
+    25.6 -> 19.3 ms for 1 ms).  Only tables beyond the caches (> 512 MB) and only when the copy fits half of the free memory
+    (inside a hipGraph capture the copy is one more captured launch).  Returns (x, ldx) unchanged otherwise.  The copy lives
+    for this call only: nothing is cached, nothing can go stale."""
+    F = int(x.shape[1])
+    if not (RELAY_POW2_TABLES and ldx == F and pow2_row_stride(F) and (F >= 512 or plan_is_skewed)):
+        return x, ldx
+    n = int(x.shape[0])
+    need = 4 * n * (F + 32)
+    if 4 * n * F <= (512 << 20):
+        return x, ldx
+    if not torch.cuda.is_current_stream_capturing():
+        free, _ = torch.cuda.mem_get_info()
+        if need > free // 2:
+            return x, ldx
+    wide = torch.empty((n, F + 32), dtype=torch.float32, device=x.device)
+    L.check(L.require_gpu().tfgx_gather_rows_f32(L.ptr(x), ldx, None, n, F, L.ptr(wide), F + 32, L.stream_ptr()),
+            "tfgx_gather_rows_f32 (strided row copy)")
+    RELAY_STATS["copies"] += 1
+    return wide[:, :F], F + 32
+
+
+RELAY_STATS = {"copies": 0}
+
+
 def segment_reduce(plan, x, op, w_csr=None, out=None, act=L.ACT_NONE, self_coef=None, bias=None, add_x=None,
                    accumulate=False, mean_count=None, row_begin=None, row_end=None, rp_stride=1, col=None,
                    n_dst=None, describe=False, track=None, track_row_begin=None):
@@ -591,6 +622,8 @@ def segment_reduce(plan, x, op, w_csr=None, out=None, act=L.ACT_NONE, self_coef=
     else:
         x, ldx = L.row_major_2d(x)
         F = int(x.shape[1])
+        if not describe and row_begin is None and row_end is None and col is None:
+            x, ldx = relaid_for_gather(x, ldx, plan.hub_info() is not None)
     n_dst = plan.n_dst if n_dst is None else int(n_dst)
     given = out is not None
     if out is None:
@@ -647,6 +680,12 @@ def segment_reduce(plan, x, op, w_csr=None, out=None, act=L.ACT_NONE, self_coef=
         a.hub_chunk_begin, a.hub_chunk_end = chunk_begin.data_ptr(), chunk_end.data_ptr()
         a.n_hub_rows, a.n_hub_chunks = int(hub_rows.shape[0]), int(chunk_begin.shape[0])
         a.hub_scratch = scratch.data_ptr()
+    rows_launched = max(n_dst, 1)
+    if hub is None and plan.num_edges < 32 * rows_launched and row_begin is None and col is None:
+        # short rows (fewer than 32 edges per row on average): a row's start-up — header loads, the first index batch, the
+        # self-loop row — is paid once per column pass.  One shard of the papers100M-shaped graph (13.9 M rows x 14.4 edges,
+        # F = 128, 57 GB table): 19.2 ms with one burst per row against 22.2 with two column passes (profiles/r05_papers_shard.jsonl)
+        a.wide_blocks = -1
     if hub is not None and F & (F - 1) != 0:
         # power-law plan (hub lists present), row stride not a power of two: one burst per source row (tfgx.h wide_blocks).
         # Same-box A/B on the products-sized R-MAT graph (profiles/r05_ab_wide_blocks_modes_rmat.jsonl): F = 192 / 224
@@ -702,6 +741,8 @@ def aggregate_gemm(plan, x, op, kernel, w_csr=None, self_coef=None, bias=None, a
         return None
     hub = plan.hub_info()      # long rows: chunk partials by a launch of the ordinary kernel, folded by the row's lane group
     order = plan.row_order()   # skewed plans: tiles of similar-length rows (degree order), results unchanged
+    if split is None:
+        x2, ldx = relaid_for_gather(x2, ldx, hub is not None)      # F = 128 at a 512-byte row stride on a power-law plan
     n_dst = plan.n_dst
     given = out is not None
     if out is None:
@@ -772,8 +813,8 @@ def gather_friendly_ld(F):
     at the part's line-request ceiling, so a row that straddles an extra line costs exactly that much.  Candidates: F
     itself, the next power of two (F <= 32), the next multiple of 16 and of 32 floats; the one with the fewest lines per
     row on average wins, ties go to the smaller stride.  20 -> 32 (1.5 -> 1 line: 3.32 -> 2.36 ms per products-shaped
-    pass), 47 -> 48 (2.44 -> 2: 5.14 -> 4.35 ms), 44 -> 48 (2.25 -> 2), 172 -> 176 (6.25 -> 6); 40, 64, 100, 128 stay
-    dense (F = 100 touches 4 lines at any stride; padding it to 112 / 128 LOSES 3-9 % to the larger footprint).
+    pass), 47 -> 48 (2.44 -> 2: 5.14 -> 4.35 ms), 44 -> 48 (2.25 -> 2), 172 -> 176 (6.25 -> 6); 40, 64, 100 stay
+    dense; 128 / 256 / 512 ... get one more line per row (160 / 288 / 544: pow2_row_stride) (F = 100 touches 4 lines at any stride; padding it to 112 / 128 LOSES 3-9 % to the larger footprint).
     Same-box A/B: tools/ab_row_stride.py, profiles/r02_ab_row_stride.jsonl."""
     F = int(F)
     if F <= 0:
@@ -782,7 +823,21 @@ def gather_friendly_ld(F):
     if F <= 32:
         cands.append(1 << (F - 1).bit_length())
     best = min(sorted(set(cands)), key=lambda ld: (round(_avg_lines(F, ld), 6), ld))
+    if pow2_row_stride(best):
+        best += 32          # never a power-of-two row stride of 512 bytes or more: see pow2_row_stride
     return best
+
+
+def pow2_row_stride(ld):
+    """Is a row stride of `ld` floats a power of two of at least 512 bytes?  Rows that far apart put the same column of every
+    row on the same few memory channels / cache sets.  Round 5, same box, products-sized graphs (profiles/r05_ab_ld_pad.jsonl:
+    ld = F against ld = F + 32): on the R-MAT graph, whose hot source rows are what the aliasing folds together, F = 128
+    10.2 -> 7.7 ms, F = 256 25.6 -> 19.3, F = 512 49.3 -> 40.0; on the uniform graph F = 512 43.8 -> 36.7 ms (F = 128 / 256:
+    9.20 -> 9.03 / 20.8 -> 20.9).  L2 hit rates barely move (17.7 -> 19.9 % at F = 256, profiles/r05_rmat_stride_pmc.md): the
+    conflict is beyond L2.  Tables this package lays out avoid such strides (gather_friendly_ld); a caller's table that has
+    one is re-laid out on the fly where that pays (relaid_for_gather)."""
+    ld = int(ld)
+    return ld >= 128 and (ld & (ld - 1)) == 0
 
 
 def gather_friendly_empty(n, F, device):
