@@ -903,9 +903,10 @@ def baseline_configs(tfg, L, synthetic, x, ei, n, e, f, cache, seed):
         lay = tfg.layers.MaxPoolGraphSage(256, activation=tfg.relu)
         ms = _time(lambda: lay([x, ei, w1], cache=cache), steps=4, warmup=2)
         # the launch that dominates it, alone: the max reduce over the [N, 4 * ku = 512] per-node MLP rows
-        h = torch.relu_(gemm_bias_act(x, lay.neighbor_mlp_kernel.detach()))
-        width = int(h.shape[1])
-        out = torch.empty_like(h)
+        # (as the layer lays them out: rows at plan.gather_friendly_ld — 544 floats apart, never a 2 KB power-of-two stride)
+        width = int(lay.neighbor_mlp_kernel.shape[1])
+        h = gemm_bias_act(x, lay.neighbor_mlp_kernel.detach(), act=L.ACT_RELU, out=P.gather_friendly_empty(n, width, dev))
+        out = torch.empty((n, width), dtype=torch.float32, device=dev)
         ms_red = _time(lambda: segment_reduce(plan, h, L.MAX, out=out), steps=4, warmup=2)
         balg = b_alg(e, n, width, weighted=False)
         kname = segment_reduce(plan, h, L.MAX, out=out, describe=True)
@@ -917,7 +918,7 @@ def baseline_configs(tfg, L, synthetic, x, ei, n, e, f, cache, seed):
         return {"layer": "MaxPoolGraphSage(256, concat=True): per-node MLP {} -> {} (+ ReLU), max over in-edges at {} columns, "
                          "512 -> 128 and {} -> 128 projections".format(f, width, width, f),
                 "forward_ms": ms, "fwd_bwd_ms": ms_t, "reduce_alone_kernel": kname, "reduce_alone_ms": ms_red,
-                "reduce_columns": width, "algorithmic_bytes": balg,
+                "reduce_columns": width, "row_stride_floats": P.gather_friendly_ld(width), "algorithmic_bytes": balg,
                 "frac_of_hbm_peak_reduce_alone": balg / (ms_red * 1e-3) / HBM_PEAK,
                 "reduce_edges_per_s": e / (ms_red * 1e-3)}
 

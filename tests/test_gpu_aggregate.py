@@ -600,3 +600,51 @@ def test_segment_op_with_pad_routes_gradient_and_refusals(tfg, oracle):
     bad[5] = -1
     with pytest.raises(ValueError):
         seg.segment_op_with_pad(seg.segment_sum, x, bad, 60)                             # negative id: TF raises InvalidArgumentError
+
+
+@pytest.mark.parametrize("f", [128, 160, 192, 256, 384, 512, 1024])
+def test_wide_rows_in_column_blocks_are_bit_identical_to_one_burst(tfg, oracle, f):
+    """Wide rows made of whole 128-byte lines are gathered in 64-column blocks on grid.y (128 columns at F = 256), 16 pieces in
+    flight per lane, the last partial batch as one masked batch: every output element keeps its own in-order FMA chain, so
+    the launch equals the one-burst-per-row launch BIT FOR BIT (sum, mean with the self-loop term and an epilogue, max) and
+    sits in the oracle's band; a table whose rows are not line-aligned keeps the burst."""
+    from tf_geometric_amd import plan as P
+    L = tfg._lib
+    rng = np.random.Generator(np.random.PCG64(f))
+    n, e = 1500, 90000
+    ei = oracle.synthetic_edges(n, e, seed=f)
+    ei = ei[:, (ei[0] != 5) & (ei[0] != 1499)]                      # empty rows: the first block and the last
+    x = rng.standard_normal((n, f), dtype=np.float32)
+    w = rng.uniform(0.5, 1.5, ei.shape[1]).astype(np.float32)
+    plan = P.CsrPlan.build(L.as_i32(ei), n, n)
+    xd, wd = L.as_f32(x), plan.edge_attr_to_csr(L.as_f32(w))
+    sc = L.as_f32(rng.uniform(0.1, 0.9, n).astype(np.float32))
+    bias = L.as_f32(rng.standard_normal(f).astype(np.float32))
+    name = P.segment_reduce(plan, xd, L.SUM, w_csr=wd, describe=True)
+    assert name.endswith(", 16>") and ("<4, 16, 1," in name or (f == 256 and "<4, 32, 1," in name)), name
+    assert P.segment_reduce(plan, xd, L.SUM, w_csr=wd, describe=True, wide_blocks=-1).endswith(", 0>")
+    for op, kw in ((L.SUM, dict(w_csr=wd, self_coef=sc, bias=bias, act=L.ACT_RELU)), (L.MEAN, dict(w_csr=wd)), (L.MAX, dict())):
+        blocks = P.segment_reduce(plan, xd, op, wide_blocks=1, **kw)
+        burst = P.segment_reduce(plan, xd, op, wide_blocks=-1, **kw)
+        assert torch.equal(blocks, burst)
+    got = P.segment_reduce(plan, xd, L.SUM, w_csr=wd).cpu().numpy()
+    ref = oracle.aggregate_neighbors(x, ei, w, oracle.gcn_mapper, oracle.sum_reducer, oracle.identity_updater)
+    assert_parity(got, ref, what="wide rows F={}".format(f))
+    gotm = P.segment_reduce(plan, xd, L.MAX).cpu().numpy()
+    refm = oracle.aggregate_neighbors(x, ei, None, oracle.identity_mapper, oracle.max_reducer, oracle.identity_updater)
+    assert np.array_equal(gotm, refm)
+    # rows 4 floats further apart are no longer whole lines: one burst per row, same values
+    wide = torch.empty((n, f + 4), device="cuda")
+    wide[:, :f] = xd
+    assert P.segment_reduce(plan, wide[:, :f], L.SUM, w_csr=wd, describe=True).endswith(", 0>")
+    assert torch.equal(P.segment_reduce(plan, wide[:, :f], L.SUM, w_csr=wd), P.segment_reduce(plan, xd, L.SUM, w_csr=wd, wide_blocks=-1))
+
+
+def test_power_of_two_row_strides_are_avoided(tfg):
+    """plan.gather_friendly_ld never hands out a power-of-two row stride of 512 bytes or more (hot rows of a power-law graph,
+    and every row at 2 KB, fold onto the same memory channels: profiles/r05_ab_ld_pad.jsonl), and keeps the strides that were
+    already line-friendly."""
+    from tf_geometric_amd import plan as P
+    assert [P.gather_friendly_ld(v) for v in (20, 47, 64, 100, 128, 160, 256, 512, 1024)] == [32, 48, 64, 100, 160, 160, 288, 544, 1056]
+    t = P.gather_friendly_empty(10, 256, "cuda")
+    assert tuple(t.shape) == (10, 256) and t.stride(0) == 288

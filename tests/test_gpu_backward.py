@@ -790,8 +790,8 @@ def test_tracked_max_forward_equals_the_arg_kernel(tfg, oracle, f, weighted):
     from tf_geometric_amd.plan import CsrPlan, segment_reduce, can_track
     rng = np.random.Generator(np.random.PCG64(f))
     n = 900
-    ei = oracle.synthetic_edges(n, 12000, seed=f)
-    ei = ei[:, ei[0] != 9]
+    ei = oracle.synthetic_edges(n, 12000 if f <= 256 else 40000, seed=f)      # rows wider than 256 columns track through the
+    ei = ei[:, ei[0] != 9]                                                     # column-block walk, which dense plans take
     ei = np.concatenate([ei, ei[:, :4000]], axis=1)
     x = np.round(rng.standard_normal((n, f)).astype(np.float32) * 2) / 2
     plan = CsrPlan.build(L.as_i32(ei), n, n)

@@ -607,7 +607,7 @@ RELAY_STATS = {"copies": 0}
 
 def segment_reduce(plan, x, op, w_csr=None, out=None, act=L.ACT_NONE, self_coef=None, bias=None, add_x=None,
                    accumulate=False, mean_count=None, row_begin=None, row_end=None, rp_stride=1, col=None,
-                   n_dst=None, describe=False, track=None, track_row_begin=None):
+                   n_dst=None, describe=False, track=None, track_row_begin=None, wide_blocks=None):
     """One launch of tfgx_segment_reduce_f32 on `plan` (or on explicit row_begin/row_end/col views of it).
     `x` is a dense [n_src, F] tensor or a SplitRows.  describe=True launches nothing and returns the kernel symbol the
     dispatcher picks for these arguments (tfgx_segment_reduce_describe).  `track` (TFGX_MAX, training forward): int32
@@ -693,6 +693,8 @@ def segment_reduce(plan, x, op, w_csr=None, out=None, act=L.ACT_NONE, self_coef=
         # paid once per pass, and the hot source rows already hit in the caches); at F = 128 / 512, where a power-of-two
         # stride folds the hot rows onto few cache sets, the blocks win (11.2 -> 9.4 ms, 50.8 -> 48.1) and stay on.
         a.wide_blocks = -1
+    if wide_blocks is not None:          # tests / A-B tools: +1 column blocks wherever the layout allows, -1 one burst per row
+        a.wide_blocks = int(wide_blocks)
     if describe:
         buf = ctypes.create_string_buffer(160)
         L.check(lib.tfgx_segment_reduce_describe(ctypes.byref(a), buf, 160), "tfgx_segment_reduce_describe")
@@ -795,7 +797,8 @@ def can_track(plan, x2, ldx):
     F = int(x2.shape[1])
     # one 16-byte chunk per lane: rows up to 256 columns, or — round 5 — any wider row made of whole 128-byte lines, which the
     # kernel walks in 64-column blocks on grid.y (tfgx_reduce.hip group_shape; TFGX_REDUCE_WIDE_BLOCKS=0 switches them off)
-    wide = (F % 32 == 0 and ldx % 32 == 0 and x2.data_ptr() % 128 == 0 and _os.environ.get("TFGX_REDUCE_WIDE_BLOCKS", "2") != "0")
+    wide = (F % 32 == 0 and ldx % 32 == 0 and x2.data_ptr() % 128 == 0 and _os.environ.get("TFGX_REDUCE_WIDE_BLOCKS", "1") != "0"
+            and plan.num_edges >= 32 * max(plan.n_dst, 1))          # (segment_reduce runs sparse plans as one burst per row)
     return (F % 4 == 0 and F >= 32 and (F <= 256 or wide) and ldx % 4 == 0 and x2.data_ptr() % 16 == 0 and plan.hub_info() is None
             and int(getattr(plan, "hub_threshold", 1 << 30)) < 65536)
 
