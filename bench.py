@@ -633,7 +633,7 @@ def main():
         # gfx950 + WRITE_SIZE, separate --pmc passes; see profiles/).  Priced with the PROFILE's own kernel time — it
         # was taken on another box of the pool — never with this run's.
         sha_now = kernel_source_sha()
-        for tag in ("r04", "r03", "r02", "r01"):
+        for tag in ("r05", "r04", "r03", "r02", "r01"):
             pmc_path = os.path.join(ROOT, "profiles", "{}_{}_pmc.json".format(tag, args.workload))
             if os.path.exists(pmc_path):
                 with open(pmc_path) as fh:
@@ -690,7 +690,7 @@ def main():
                 "build_ms_is": "HIP events around a second build (allocator warm): the layout kernels themselves",
                 "build_first_call_ms_host_clock": build_first_ms, "layout_bytes": int(info["bytes"]),
                 "bit_identical_to_headline_output": bool(torch.equal(out2, res))}
-            for tag in ("r04", "r03", "r02", "r01"):   # HBM-side bytes of this launch, imported like roofline.traffic
+            for tag in ("r05", "r04", "r03", "r02", "r01"):   # HBM-side bytes of this launch, imported like roofline.traffic
                 et_path = os.path.join(ROOT, "profiles", "{}_{}_edge_tail_pmc.json".format(tag, args.workload))
                 if os.path.exists(et_path):
                     with open(et_path) as fh:

@@ -309,6 +309,33 @@ def test_gemm_streaming_kernel(tfg, oracle, m, k, n):
     assert_parity(got2, ref2, what="stream gemm act_cols")
 
 
+@pytest.mark.parametrize("m,k,n", [(33000, 1433, 16), (40007, 602, 8), (32768, 301, 7), (50001, 1024, 16), (33000, 257, 1),
+                                   (36000, 1900, 12), (32769, 272, 16)])
+def test_gemm_long_k_narrow_output_kernel(tfg, oracle, m, k, n):
+    """Long K, at most 16 output columns, rows that are not 16-byte aligned (Cora-width 1433 -> 16, GAT's 602 -> 8): the
+    persistent gemm_skinny_kernel — B resident in LDS, A streamed straight into the 16 x 16 x 4 MFMA layout, two-level sum.
+    Every K tail class (K % 16 in 0 / 1 / 9 / 10 / 12 / 13), ragged M, bias / ReLU / column-limited activation; also a view
+    of A with a leading dimension (rows even further from any alignment)."""
+    from tf_geometric_amd.plan import gemm_bias_act
+    rng = np.random.Generator(np.random.PCG64(m + k))
+    a = rng.standard_normal((m, k), dtype=np.float32)
+    b = oracle.glorot_uniform(rng, k, n)
+    bias = (rng.standard_normal(n) * 0.1).astype(np.float32)
+    got = gemm_bias_act(a, b, bias=bias, act=1).cpu().numpy()
+    ref = np.maximum(oracle.matmul(a, b) + bias, 0)
+    assert_parity(got, ref, what="long-K gemm {}x{}x{}".format(m, k, n))
+    if n > 1:
+        got2 = gemm_bias_act(a, b, act=1, act_cols=n // 2).cpu().numpy()
+        ref2 = oracle.matmul(a, b)
+        ref2[:, :n // 2] = np.maximum(ref2[:, :n // 2], 0)
+        assert_parity(got2, ref2, what="long-K gemm act_cols")
+    import torch
+    wide = torch.zeros((m, k + 3), device="cuda")
+    wide[:, :k] = torch.from_numpy(a).cuda()
+    got3 = gemm_bias_act(wide[:, :k], b).cpu().numpy()
+    assert_parity(got3, oracle.matmul(a, b), what="long-K gemm on a strided view")
+
+
 def test_gcn_sparse_node_features(tfg, oracle):
     """gcn.py:269-270: sparse x (bag-of-words rows) -> x @ W as a segment-sum over the kernel rows; SparseMatrix and
     torch sparse COO inputs, forward parity with the dense path and the kernel gradient."""

@@ -511,7 +511,7 @@ __global__ __launch_bounds__(kBlock) void max_mask_build_kernel(const int32_t* _
                                                                 const float* __restrict__ g, int64_t ldg,
                                                                 const float* __restrict__ count, int64_t ldc,
                                                                 const int32_t* __restrict__ argpos, int64_t lda,
-                                                                float* __restrict__ gn, uint32_t* __restrict__ mask,
+                                                                float* __restrict__ gn, int64_t ldgn, uint32_t* __restrict__ mask,
                                                                 int MW)
 {
     constexpr int VEC = 4;
@@ -548,7 +548,7 @@ __global__ __launch_bounds__(kBlock) void max_mask_build_kernel(const int32_t* _
             float gnv[VEC];
 #pragma unroll
             for (int i = 0; i < VEC; ++i) gnv[i] = cv[i] > 0.0f ? gv[i] / cv[i] : 0.0f;
-            store_vec<VEC>(gn + r * int64_t(F) + coff, gnv);
+            store_vec<VEC>(gn + r * ldgn + coff, gnv);
         }
         bool tie = false;
 #pragma unroll
@@ -595,7 +595,7 @@ __global__ __launch_bounds__(kBlock) void max_backward_mask_apply_kernel(const i
                                                                          const float* __restrict__ w_t,
                                                                          const int32_t* __restrict__ pos_t,
                                                                          int64_t n_src, int F,
-                                                                         const float* __restrict__ gn,
+                                                                         const float* __restrict__ gn, int64_t ldgn,
                                                                          const uint32_t* __restrict__ mask, int MW,
                                                                          float* __restrict__ gx, int64_t ldgx)
 {
@@ -637,7 +637,7 @@ __global__ __launch_bounds__(kBlock) void max_backward_mask_apply_kernel(const i
                 float val[U][VEC];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    const float* gp = gn + rr[u] * int64_t(F) + coff;
+                    const float* gp = gn + rr[u] * ldgn + coff;
 #pragma unroll
                     for (int i = 0; i < VEC; ++i) {
                         val[u][i] = 0.0f;
@@ -1228,10 +1228,14 @@ extern "C" int tfgx_segment_max_backward_push_f32(const int32_t* row_ptr, const 
     return TFGX_OK;
 }
 
+// row stride of the gn table inside the mask workspace: never a power of two of 512 bytes or more (the apply pass gathers
+// single elements of gn rows: the same column of every row would sit on the same few memory channels — plan.pow2_row_stride)
+static inline int64_t mask_gn_ld(int64_t F) { return (F >= 128 && (F & (F - 1)) == 0) ? F + 32 : F; }
+
 extern "C" size_t tfgx_segment_max_backward_mask_workspace_bytes(int64_t n_dst, int64_t E, int64_t F)
 {
     if (n_dst < 0 || E < 0 || F < 1) return 0;
-    const size_t gn = sizeof(float) * size_t(n_dst) * size_t(F);
+    const size_t gn = sizeof(float) * size_t(n_dst) * size_t(mask_gn_ld(F));
     const size_t mk = sizeof(uint32_t) * size_t(E) * size_t((F + 31) / 32);
     return (gn + 255) / 256 * 256 + mk + 256;
 }
@@ -1280,7 +1284,8 @@ extern "C" int tfgx_segment_max_backward_mask_phases_f32(const int32_t* row_ptr,
     hipStream_t stream = as_stream(stream_);
     const int MW = int((F + 31) / 32);
     float* gn = static_cast<float*>(workspace);
-    const size_t gn_bytes = (sizeof(float) * size_t(n_dst) * size_t(F) + 255) / 256 * 256;
+    const int64_t ldgn = mask_gn_ld(F);
+    const size_t gn_bytes = (sizeof(float) * size_t(n_dst) * size_t(ldgn) + 255) / 256 * 256;
     uint32_t* mask = reinterpret_cast<uint32_t*>(static_cast<char*>(workspace) + gn_bytes);
     const int lanes = int((F + 3) / 4);
 #define TFGX_MASK(GG)                                                                                                  \
@@ -1289,12 +1294,12 @@ extern "C" int tfgx_segment_max_backward_mask_phases_f32(const int32_t* row_ptr,
         if (do_build && n_dst > 0) {                                                                                   \
             dim3 ga(grid_for(n_dst, kBlock / GG, 1 << 20), ny, 1);                                                     \
             max_mask_build_kernel<GG><<<ga, kBlock, 0, stream>>>(row_ptr, col, w, n_dst, x, ldx, int(F), out, ldo, g,  \
-                                                                 ldg, count, ldc, argpos, lda, gn, mask, MW);         \
+                                                                 ldg, count, ldc, argpos, lda, gn, ldgn, mask, MW);   \
         }                                                                                                              \
         if (do_apply && n_src > 0) {                                                                                   \
             dim3 gb(grid_for(n_src, kBlock / GG, 1 << 20), ny, 1);                                                     \
             max_backward_mask_apply_kernel<GG><<<gb, kBlock, 0, stream>>>(row_ptr_t, dst_t, w_t, pos_t, n_src, int(F), \
-                                                                          gn, mask, MW, gx, ldgx);                    \
+                                                                          gn, ldgn, mask, MW, gx, ldgx);              \
         }                                                                                                              \
     }
     if (lanes <= 8) TFGX_MASK(8)
