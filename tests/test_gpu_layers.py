@@ -310,10 +310,12 @@ def test_gemm_streaming_kernel(tfg, oracle, m, k, n):
 
 
 @pytest.mark.parametrize("m,k,n", [(33000, 1433, 16), (40007, 602, 8), (32768, 301, 7), (50001, 1024, 16), (33000, 257, 1),
-                                   (36000, 1900, 12), (32769, 272, 16)])
+                                   (36000, 1900, 12), (32769, 272, 16), (40000, 301, 40), (33000, 1433, 32), (35000, 602, 41),
+                                   (33333, 67, 48), (34000, 777, 17)])
 def test_gemm_long_k_narrow_output_kernel(tfg, oracle, m, k, n):
-    """Long K, at most 16 output columns, rows that are not 16-byte aligned (Cora-width 1433 -> 16, GAT's 602 -> 8): the
-    persistent gemm_skinny_kernel — B resident in LDS, A streamed straight into the 16 x 16 x 4 MFMA layout, two-level sum.
+    """Narrow outputs (N <= 48: one to three 16-column MFMA tiles) of rows that are not 16-byte aligned (Cora-width 1433 -> 16,
+    GAT's 602 -> 8 / 41): the persistent gemm_skinny_kernel — B resident in LDS, A streamed straight into the 16 x 16 x 4 MFMA
+    layout, two-level sum.
     Every K tail class (K % 16 in 0 / 1 / 9 / 10 / 12 / 13), ragged M, bias / ReLU / column-limited activation; also a view
     of A with a leading dimension (rows even further from any alignment)."""
     from tf_geometric_amd.plan import gemm_bias_act

@@ -1321,36 +1321,43 @@ inline bool rows_ok(const float* A, int64_t lda, int64_t M, int64_t K, int64_t N
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Long K, at most 16 output columns (round 5; Cora-width first layers 1433 -> 16, GAT's Q / K projections 602 -> 8 / 16): the
-// product is a stream over A — 993 MB at 173 k x 1433 against 11 MB of output — that the LDS-staged kernel ran at 3.6 TB/s
-// (two barriers per 16 k, half of every 32-column MFMA tile multiplying padding).  Here a persistent 1024-thread workgroup per
-// CU keeps ALL of B in LDS (K x 16 floats, row pitch 20: the four k-groups of a wave land on disjoint banks) and every wave
-// streams its own 16 rows of A straight into the operand layout of v_mfma_f32_16x16x4_f32 — lane (m = lane & 15, kq = lane >> 4)
-// loads the 16 bytes A[m][k0 + 4 kq .. + 3] (4-byte alignment is enough for global_load_dwordx4, so K = 1433 needs no
-// special path) and the i-th MFMA of the step multiplies k = k0 + 4 kq + i against LDS row k of B: any pairing of k's is a
-// valid product as long as A and B agree.  Eight steps (8 x 64 contiguous bytes per row) are in flight per lane before the
-// first MFMA; no barrier after the B load.  Arithmetic: one fp32 chain per output element in that k order, flushed into a
-// second accumulator every 64 k (the two-level sum of the narrow tiles above: error ~ eps * sqrt(64 n) instead of eps * n).
-constexpr int kSkinnyPitch = 20;
+// Narrow outputs (N <= 48) of a K that need not be aligned (round 5; Cora-width first layers 1433 -> 16, GAT's Q / K
+// projections 602 -> 8 / 16, hidden -> classes 256 -> 40): the product is a stream over A — 993 MB at 173 k x 1433 against
+// 11 MB of output — that the LDS-staged kernel ran at 3.6 TB/s (two barriers per 16 k, half of every 32-column MFMA tile
+// multiplying padding).  Here a persistent 1024-thread workgroup per CU keeps ALL of B in LDS (K x 16 NT floats, row pitch
+// 16 NT + 4: the four k-groups of a wave land on disjoint banks) and every wave streams its own 16 rows of A straight into the
+// operand layout of v_mfma_f32_16x16x4_f32 — lane (m = lane & 15, kq = lane >> 4) loads the 16 bytes A[m][k0 + 4 kq .. + 3]
+// (4-byte alignment is enough for global_load_dwordx4, so K = 1433 needs no special path) and the i-th MFMA group of the step
+// multiplies k = k0 + 4 kq + i against LDS row k of B: any pairing of k's is a valid product as long as A and B agree.  Eight
+// steps (8 x 64 contiguous bytes per row) are in flight per lane before the first MFMA; no barrier after the B load.
+// Arithmetic: one fp32 chain per output element in that k order, flushed into a second accumulator every 64 k (the two-level
+// sum of the narrow tiles above: error ~ eps * sqrt(64 n) instead of eps * n).
 constexpr int kSkinnyThreads = 1024;
-inline size_t skinny_lds_bytes(int64_t K) { return sizeof(float) * size_t((K + 15) / 16 * 16) * kSkinnyPitch; }
+inline int skinny_tiles(int64_t N) { return int((N + 15) / 16); }
+inline size_t skinny_lds_bytes(int64_t K, int nt) { return sizeof(float) * size_t((K + 15) / 16 * 16) * size_t(16 * nt + 4); }
+inline int skinny_mode()      // TFGX_GEMM_SKINNY: 0 = off, 1 = where the row-streaming kernel cannot go, 2 = every N <= 48 (developer A/B)
+{
+    static const int v = [] { const char* e = std::getenv("TFGX_GEMM_SKINNY"); return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1; }();
+    return v;
+}
 inline bool skinny_ok(const float* A, int64_t lda, int64_t M, int64_t K, int64_t N)
 {
-    static const bool on = [] { const char* e = std::getenv("TFGX_GEMM_SKINNY"); return !(e && e[0] == '0'); }();
-    return on && N <= 16 && K >= 256 && M >= 32768 && aligned_to(A, 4) && lda < (int64_t(1) << 28) && skinny_lds_bytes(K) <= 150 * 1024;
+    return skinny_mode() != 0 && N <= 48 && K >= 64 && M >= 32768 && aligned_to(A, 4) && lda < (int64_t(1) << 28) &&
+           skinny_lds_bytes(K, skinny_tiles(N)) <= 150 * 1024;
 }
 
+template <int NT>
 __global__ __launch_bounds__(kSkinnyThreads) void gemm_skinny_kernel(const float* __restrict__ A, int64_t lda,
                                                                      const float* __restrict__ B, int64_t ldb,
                                                                      const float* __restrict__ bias, int act, int act_cols,
                                                                      float* __restrict__ C, int64_t ldc, int64_t M, int K, int N,
                                                                      int64_t n_tiles, int two_level)
 {
-    extern __shared__ __attribute__((aligned(16))) float Bsk[];      // [Kp][kSkinnyPitch], rows >= K and columns >= N are zero
-    constexpr int P = kSkinnyPitch;
+    extern __shared__ __attribute__((aligned(16))) float Bsk[];      // [Kp][P], rows >= K and columns >= N are zero
+    constexpr int P = 16 * NT + 4;
     const int Kp = (K + 15) / 16 * 16;
-    for (int idx = threadIdx.x; idx < Kp * 16; idx += kSkinnyThreads) {
-        const int k = idx >> 4, n = idx & 15;
+    for (int idx = threadIdx.x; idx < Kp * 16 * NT; idx += kSkinnyThreads) {
+        const int k = idx / (16 * NT), n = idx % (16 * NT);
         Bsk[k * P + n] = (k < K && n < N) ? B[int64_t(k) * ldb + n] : 0.0f;
     }
     __syncthreads();
@@ -1358,12 +1365,14 @@ __global__ __launch_bounds__(kSkinnyThreads) void gemm_skinny_kernel(const float
     const int m = lane & 15, kq = lane >> 4;
     constexpr int WAVES = kSkinnyThreads / 64;
     const int full = K / 16;                  // steps whose 16 k are all inside the row
-    const float* bp0 = Bsk + 4 * kq * P + m;  // B[k0 + 4 kq + i][n = lane & 15] = bp0[(k0 + i) * P]
+    const float* bp0 = Bsk + 4 * kq * P + m;  // B[k0 + 4 kq + i][16 t + (lane & 15)] = bp0[(k0 + i) * P + 16 t]
     constexpr int U = 8;
     for (int64_t tile = int64_t(blockIdx.x) * WAVES + wave; tile < n_tiles; tile += int64_t(gridDim.x) * WAVES) {
         const int64_t row = tile * 16 + m;
         const float* ap = A + (row < M ? row : M - 1) * lda + 4 * kq;      // rows past M re-read the last row (never stored)
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, tot = {0.f, 0.f, 0.f, 0.f};
+        f32x4 acc[NT], tot[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { acc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; tot[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         int s = 0;
         for (; s + U <= full; s += U) {
             f32x4_a4 a[U];
@@ -1374,10 +1383,13 @@ __global__ __launch_bounds__(kSkinnyThreads) void gemm_skinny_kernel(const float
             for (int u = 0; u < U; ++u) {
                 const float* bp = bp0 + 16 * (s + u) * P;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i], bp[i * P], acc, 0, 0, 0);
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i], bp[i * P + 16 * t], acc[t], 0, 0, 0);
                 if ((u & 3) == 3 && two_level) {       // every 64 k (wave-uniform)
-                    tot += acc;
-                    acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) { tot[t] += acc[t]; acc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
                 }
             }
         }
@@ -1385,7 +1397,9 @@ __global__ __launch_bounds__(kSkinnyThreads) void gemm_skinny_kernel(const float
             const f32x4_a4 a1 = *reinterpret_cast<const f32x4_a4*>(ap + 16 * s);
             const float* bp = bp0 + 16 * s * P;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i], bp[i * P], acc, 0, 0, 0);
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i], bp[i * P + 16 * t], acc[t], 0, 0, 0);
         }
         if (full * 16 < K) {                   // the last, partial step: elements past the row's end are read as zero
             const int k0 = full * 16 + 4 * kq;
@@ -1393,23 +1407,29 @@ __global__ __launch_bounds__(kSkinnyThreads) void gemm_skinny_kernel(const float
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float av = (k0 + i < K) ? ap[16 * full + i] : 0.0f;
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bp[i * P], acc, 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bp[i * P + 16 * t], acc[t], 0, 0, 0);
             }
         }
-        if (two_level) acc += tot;
-        // D layout: column n = lane & 15, rows 4 * (lane >> 4) + i
-        if (m < N) {
-            const float bv = bias ? bias[m] : 0.0f;
-            const int a_j = m < act_cols ? act : TFGX_ACT_NONE;
+        // D layout: column 16 t + (lane & 15), rows 4 * (lane >> 4) + i
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int64_t r = tile * 16 + 4 * kq + i;
-                if (r < M) C[r * ldc + m] = apply_act(acc[i] + bv, a_j);
+        for (int t = 0; t < NT; ++t) {
+            if (two_level) acc[t] += tot[t];
+            const int cn = 16 * t + m;
+            if (cn < N) {
+                const float bv = bias ? bias[cn] : 0.0f;
+                const int a_j = cn < act_cols ? act : TFGX_ACT_NONE;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int64_t r = tile * 16 + 4 * kq + i;
+                    if (r < M) C[r * ldc + cn] = apply_act(acc[t][i] + bv, a_j);
+                }
             }
         }
     }
 }
 
+template <int NT>
 int launch_gemm_skinny(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, int act, float* C,
                        int64_t ldc, int64_t M, int K, int N, int act_cols, hipStream_t stream)
 {
@@ -1421,15 +1441,15 @@ int launch_gemm_skinny(const float* A, int64_t lda, const float* B, int64_t ldb,
     if (cus_of[dev] == 0) {
         hipDeviceProp_t prop;
         TFGX_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-        TFGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_skinny_kernel),
+        TFGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_skinny_kernel<NT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         cus_of[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     const int64_t n_tiles = (M + 15) / 16;
     const int64_t wgs = (n_tiles + (kSkinnyThreads / 64) - 1) / (kSkinnyThreads / 64);
     dim3 grid(static_cast<unsigned>(wgs < cus_of[dev] ? wgs : cus_of[dev]), 1, 1), block(kSkinnyThreads, 1, 1);
-    gemm_skinny_kernel<<<grid, block, skinny_lds_bytes(K), stream>>>(A, lda, B, ldb, bias, act, act_cols, C, ldc, M, K, N,
-                                                                    n_tiles, two_level_default());
+    gemm_skinny_kernel<NT><<<grid, block, skinny_lds_bytes(K, NT), stream>>>(A, lda, B, ldb, bias, act, act_cols, C, ldc, M, K, N,
+                                                                            n_tiles, two_level_default());
     TFGX_LAUNCH_CHECK("gemm_skinny_kernel");
     return TFGX_OK;
 }
@@ -1587,8 +1607,13 @@ extern "C" int tfgx_gemm_bias_act_cols_ws_f32(const float* A, int64_t lda, const
         }
         return TFGX_OK;
     }
-    if (skinny_ok(A, lda, M, K, N) && !rows_ok(A, lda, M, K, N))
-        return launch_gemm_skinny(A, lda, B, ldb, bias, act, C, ldc, M, int(K), int(N), ac, stream);
+    if (skinny_ok(A, lda, M, K, N) && (skinny_mode() == 2 || !rows_ok(A, lda, M, K, N))) {
+        switch (skinny_tiles(N)) {
+            case 1: return launch_gemm_skinny<1>(A, lda, B, ldb, bias, act, C, ldc, M, int(K), int(N), ac, stream);
+            case 2: return launch_gemm_skinny<2>(A, lda, B, ldb, bias, act, C, ldc, M, int(K), int(N), ac, stream);
+            default: return launch_gemm_skinny<3>(A, lda, B, ldb, bias, act, C, ldc, M, int(K), int(N), ac, stream);
+        }
+    }
     if (ldc_ok && rows_ok(A, lda, M, K, N)) {
         unsigned int* ctr = rows_tile_counter(M, workspace, workspace_bytes);
 #define TFGX_ROWS_CASE(T) \

@@ -1,6 +1,6 @@
 # coding=utf-8
-"""Long-K / narrow-output products beside torch.matmul (hipBLASLt), one setting of TFGX_GEMM_SKINNY per process (0 = the
-LDS-staged generic kernel of rounds 1-4, 1 = gemm_skinny_kernel).  One JSON line per shape."""
+"""Narrow-output products beside torch.matmul (hipBLASLt), one setting of TFGX_GEMM_SKINNY per process (0 = the kernels of
+rounds 1-4, 1 = gemm_skinny_kernel where the row-streaming kernel cannot go, 2 = gemm_skinny_kernel for every N <= 48).  One JSON line per shape."""
 import json
 import os
 import sys
@@ -26,7 +26,9 @@ def timeit(fn, steps=20, warmup=5):
 
 
 torch.manual_seed(0)
-for (m, k, n) in [(173312, 1433, 16), (233000, 602, 16), (233000, 602, 8), (170000, 1433, 8), (2400000, 301, 16), (100000, 1433, 16)]:
+SHAPES = [(173312, 1433, 16), (233000, 602, 16), (233000, 602, 8), (2400000, 100, 16), (2400000, 100, 40), (2400000, 256, 40),
+          (170000, 256, 40), (2400000, 128, 40), (233000, 602, 41), (2400000, 256, 47), (2400000, 100, 32)]
+for (m, k, n) in SHAPES:
     a = torch.randn(m, k, device="cuda")
     b = torch.randn(k, n, device="cuda") * 0.1
     c = torch.empty(m, n, device="cuda")
