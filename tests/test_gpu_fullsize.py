@@ -627,15 +627,19 @@ def test_products_layers_sampled_rows_match_oracle(tfg, oracle, products, produc
         has = (p["plan"].in_degree()[rows] > 0).cpu().numpy()
         if (~has).any():
             assert_parity(got[~has][:, :ku], ref[~has][:, :ku], what="max-pool SAGE self half of rows without in-edges")
-            # the neighbour half of those rows is relu(sum_k (-3.4e38) * W[k, j] + b): every one of the 512 terms is ~ 1e37 and
-            # both signs occur in every column, so the float32 sum is +inf, -inf or nan depending on the order alone — what CAN
-            # be held is the form of the result: 0 (relu of -inf), +inf or nan, never a finite non-zero number, exactly what
-            # the same expression gives in op-for-op float32 on the CPU (oracle with acc = float32), and the same on every call
+            # the neighbour half of those rows is relu(sum_k (-3.4e38) * W[k, j] + b): 512 terms of ~ 1e37 with both signs in
+            # every column — a random walk of ~ 4e38 against a float32 range of 3.4e38 — so the float32 sum is +inf, -inf, nan or a
+            # huge finite number depending on the ORDER of the additions alone.  What can be held: the result is a ReLU output
+            # (never negative), the same on every call, and where neither this GEMM nor the op-for-op float32 expression on
+            # the CPU (oracle with acc = float32) overflowed on the way, the two agree (the terms are the same; cancellation
+            # of ~ 1e3 x the result amplifies the rounding of two different orders to ~ 1e-4)
             nb = got[~has][:, ku:]
-            assert ((nb == 0) | np.isposinf(nb) | np.isnan(nb)).all()
+            assert (np.isnan(nb) | (nb >= 0)).all()
             ref32 = oracle.max_pool_graph_sage(x_sub, ei_sub, w_sub, ws, wm, wn, bm, b, "relu", concat=True, acc=np.float32)[local]
             nb32 = ref32[~has][:, ku:]
-            assert ((nb32 == 0) | np.isposinf(nb32) | np.isnan(nb32)).all()
+            both = np.isfinite(nb) & np.isfinite(nb32) & (np.maximum(np.abs(nb), np.abs(nb32)) > 1e30)
+            if both.any():
+                assert (np.abs(nb[both] - nb32[both]) <= 1e-2 * np.maximum(np.abs(nb[both]), np.abs(nb32[both]))).all()
             again = layer([p["x"], p["ei"], p["w"]], cache=cache)[rows].cpu().numpy()[~has][:, ku:]
             assert np.array_equal(nb, again, equal_nan=True)
         got, ref = got[has], ref[has]
