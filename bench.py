@@ -28,6 +28,12 @@ Prints ONE JSON line (rank 0).
   rmat          the same launch on an R-MAT graph of the same size (skewed in-degrees, hub path) — beside the uniform
                 graph, never instead of it.
   static_feature_layout   the same launch with the features in the opt-in static layout (tfg.prepare_static_features).
+  configs       (N = 1, round 5) the OTHER BASELINE.json configs, bounded to seconds: C2 arxiv-shaped 2-layer GCN forward +
+                training step, C3 Reddit-shaped GAT(64, H8, A8) forward / forward + backward / attention alone, C4
+                GraphSAGE(256, concat) mean and max-pool layers with the dominant reduce broken out, the width sweep
+                F = 128 ... 512, two GEMMs beside torch.matmul — each with ms, the dispatched kernel and an algorithmic fraction.
+  watchdog      phase times of the run; a phase that makes no progress for TFGX_BENCH_WATCHDOG_S seconds (default 120) ends the
+                process with ONE JSON line carrying "error" and exit code 3 (every rank runs one).
 """
 import argparse
 import ctypes

@@ -681,6 +681,10 @@ def segment_reduce(plan, x, op, w_csr=None, out=None, act=L.ACT_NONE, self_coef=
         a.n_hub_rows, a.n_hub_chunks = int(hub_rows.shape[0]), int(chunk_begin.shape[0])
         a.hub_scratch = scratch.data_ptr()
     rows_launched = max(n_dst, 1)
+    if row_begin is not None or row_end is not None or col is not None:
+        # explicit spans (the sharded path's per-class passes: a row's own-source edges, then one sub-span per halo round —
+        # a handful of edges per row and pass): one burst per row, as before round 5
+        a.wide_blocks = -1
     if hub is None and plan.num_edges < 32 * rows_launched and row_begin is None and col is None:
         # short rows (fewer than 32 edges per row on average): a row's start-up — header loads, the first index batch, the
         # self-loop row — is paid once per column pass.  One shard of the papers100M-shaped graph (13.9 M rows x 14.4 edges,
