@@ -690,8 +690,9 @@ def segment_reduce(plan, x, op, w_csr=None, out=None, act=L.ACT_NONE, self_coef=
         # self-loop row — is paid once per column pass.  One shard of the papers100M-shaped graph (13.9 M rows x 14.4 edges,
         # F = 128, 57 GB table): 19.2 ms with one burst per row against 22.2 with two column passes (profiles/r05_papers_shard.jsonl)
         a.wide_blocks = -1
-    if hub is not None and F & (F - 1) != 0:
-        # power-law plan (hub lists present), row stride not a power of two: one burst per source row (tfgx.h wide_blocks).
+    if hub is not None and not pow2_row_stride(ldx):
+        # power-law plan (hub lists present), row stride not a power of two — the table's own, or after relaid_for_gather moved
+        # its rows 128 bytes further apart: one burst per source row (tfgx.h wide_blocks).
         # Same-box A/B on the products-sized R-MAT graph (profiles/r05_ab_wide_blocks_modes_rmat.jsonl): F = 192 / 224
         # 13.4 / 15.7 ms with bursts against 14.6 / 18.0 with column blocks (mostly short rows: the start-up of a row is
         # paid once per pass, and the hot source rows already hit in the caches); at F = 128 / 512, where a power-of-two
