@@ -577,7 +577,7 @@ def edge_weight_csr(plan, edge_weight, cache=None):
 RELAY_POW2_TABLES = True     # developer A/B switch
 
 
-def relaid_for_gather(x, ldx, plan_is_skewed):
+def relaid_for_gather(x, ldx, plan_is_skewed, dry_run=False):
     """A caller's dense [n, F] table whose row stride is a power of two (pow2_row_stride) -> the same rows 32 floats further
     apart, when one strided copy (read + write of the table) costs less than it saves: strides of 2 KB and more on any graph
     (uniform products graph, F = 512: 43.8 -> 36.7 ms for a 2 ms copy), 512 bytes and more on a power-law plan (R-MAT, F = 256:
@@ -595,6 +595,8 @@ def relaid_for_gather(x, ldx, plan_is_skewed):
         free, _ = torch.cuda.mem_get_info()
         if need > free // 2:
             return x, ldx
+    if dry_run:                      # describe: which kernel WOULD run (no copy is made)
+        return x, F + 32
     wide = torch.empty((n, F + 32), dtype=torch.float32, device=x.device)
     L.check(L.require_gpu().tfgx_gather_rows_f32(L.ptr(x), ldx, None, n, F, L.ptr(wide), F + 32, L.stream_ptr()),
             "tfgx_gather_rows_f32 (strided row copy)")
@@ -622,8 +624,8 @@ def segment_reduce(plan, x, op, w_csr=None, out=None, act=L.ACT_NONE, self_coef=
     else:
         x, ldx = L.row_major_2d(x)
         F = int(x.shape[1])
-        if not describe and row_begin is None and row_end is None and col is None:
-            x, ldx = relaid_for_gather(x, ldx, plan.hub_info() is not None)
+        if row_begin is None and row_end is None and col is None:
+            x, ldx = relaid_for_gather(x, ldx, plan.hub_info() is not None, dry_run=describe)
     n_dst = plan.n_dst if n_dst is None else int(n_dst)
     given = out is not None
     if out is None:
@@ -714,6 +716,7 @@ def segment_reduce(plan, x, op, w_csr=None, out=None, act=L.ACT_NONE, self_coef=
 
 
 FUSE_AGGREGATE_GEMM = True      # developer A/B switch (tools/ab_fused_layer.py): False = always two launches
+TFGX_FUSE_WIDE = False          # developer A/B switch: True = the fused launch also at F = 128 on large dense tables (round 4's route)
 
 
 FUSED_STATS = {"launches": 0, "with_side_output": 0}      # diagnostics (tests assert the route taken)
@@ -748,6 +751,14 @@ def aggregate_gemm(plan, x, op, kernel, w_csr=None, self_coef=None, bias=None, a
         return None
     hub = plan.hub_info()      # long rows: chunk partials by a launch of the ordinary kernel, folded by the row's lane group
     order = plan.row_order()   # skewed plans: tiles of similar-length rows (degree order), results unchanged
+    if (split is None and agg_out is None and hub is None and F >= 128 and F % 32 == 0 and ldx % 32 == 0 and x2.data_ptr() % 128 == 0
+            and plan.num_edges >= 32 * max(plan.n_dst, 1) and 4 * int(x2.shape[0]) * F > (512 << 20) and not TFGX_FUSE_WIDE):
+        # round 5: at F = 128 the stand-alone aggregation gathers in column blocks (10.2 -> 9.2 ms at products shape), which this
+        # launch's producers do not; on a large dense table the two launches are now ahead at inference — same-box A/B
+        # (profiles/r05_ab_fused_layer_F128.json): GCN layer 128 -> 256 11.05 fused vs 10.53, mean GraphSAGE 10.86 vs 10.40.
+        # The TRAINING forward keeps the fused launch (its side output saves the aggregate's read-back: 14.66 vs 15.14), and so
+        # do small graphs (arxiv shape: the table is cache-resident, 0.238 vs 0.259 ms).
+        return None
     if split is None:
         x2, ldx = relaid_for_gather(x2, ldx, hub is not None)      # F = 128 at a 512-byte row stride on a power-law plan
     n_dst = plan.n_dst
