@@ -250,7 +250,10 @@ template <int VEC, int G, int D>
 __global__ __launch_bounds__(kBlock) void gat_fused_kernel(const GArgs a)
 {
     constexpr int ROWS_PER_BLOCK = kBlock / G;
-    constexpr int UNROLL = 4;
+#ifndef TFGX_GAT_UNROLL_NARROW
+#define TFGX_GAT_UNROLL_NARROW 4      // developer A/B: edges in flight per lane group when a head's K slice is <= 4 floats
+#endif
+    constexpr int UNROLL = (D > 0 && D <= 4) ? TFGX_GAT_UNROLL_NARROW : 4;
     const int lane = threadIdx.x % G;
     const int grp = threadIdx.x / G;
     const int c_raw = (blockIdx.y * G + lane) * VEC;

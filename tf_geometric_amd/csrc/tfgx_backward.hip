@@ -962,7 +962,10 @@ __global__ __launch_bounds__(kBlock) void gat_backward_fast_kernel(const GB a)
             edge_load(o, in);
             edge_apply(in, keep);
         };
-        constexpr int U = (D <= 4) ? 4 : (D <= 16 ? 2 : 1);
+#ifndef TFGX_GAT_BWD_UNROLL_NARROW
+#define TFGX_GAT_BWD_UNROLL_NARROW 4  // developer A/B
+#endif
+        constexpr int U = (D <= 4) ? TFGX_GAT_BWD_UNROLL_NARROW : (D <= 16 ? 2 : 1);
         for (int base = s0; base < e0; base += G) {
             const int idx = base + lane;
             const int oj = (idx < e0) ? a.other[idx] : 0;
