@@ -95,7 +95,20 @@ __global__ __launch_bounds__(kBlock) void gcn_norm_kernel(const int32_t* __restr
         const int s = row_ptr[r], e = row_ptr[r + 1];
         if (mode == TFGX_NORM_BOTH) {
             const float dr = inv_pow(row_deg[r], true);
-            for (int i = s + first; i < e; i += step) {
+            int i = s + first;
+            // (four independent col -> degree chains per lane: a long row — the hubs of a power-law graph cluster in a few
+            // workgroups — is bound by the latency of that dependent gather)
+            for (; i + 3 * step < e; i += 4 * step) {
+                int c4[4];
+                float d4[4], w4[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { c4[u] = col[i + u * step]; w4[u] = w ? w[i + u * step] : 1.0f; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) d4[u] = cdeg[c4[u]];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) w_out[i + u * step] = dr * w4[u] * inv_pow(d4[u], true);
+            }
+            for (; i < e; i += step) {
                 const float wi = w ? w[i] : 1.0f;
                 w_out[i] = dr * wi * inv_pow(cdeg[col[i]], true);   // (D^-1/2 A) D^-1/2, left product first (:94)
             }
