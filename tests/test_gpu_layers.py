@@ -611,3 +611,43 @@ def test_gemm_dynamic_tile_order_changes_no_bit(tfg, oracle, m, k, n):
     assert_parity(dyn[rows].cpu().numpy(), ref, what="dynamic-order gemm {}x{}x{}".format(m, k, n))
     again = gemm_bias_act(a, b, bias=bias, act=1)                                   # and run to run
     assert torch.equal(dyn, again)
+
+
+def test_layer_losses_collect_the_regularisers_as_keras_does(tfg, oracle):
+    """kernel_regularizer goes to every glorot-initialised matrix, bias_regularizer to every zero-initialised vector
+    (layers/conv/gcn.py:26-30, gat.py:64-83, graph_sage.py:55-61); `layer.losses` holds one term per regularised weight,
+    follows set_weights, and is differentiable on a trainable layer (the demos' hand-written L2 term, demo_gcn.py:60-66)."""
+    import torch
+    x, ei, w, rng = _graph(oracle, 300, 2000, 20, seed=8)
+    l2 = lambda t: 5e-4 * (t * t).sum() / 2            # noqa: E731
+    l1 = lambda t: 1e-3 * t.abs().sum()                # noqa: E731
+
+    gcn = tfg.layers.GCN(8, kernel_regularizer=l2, bias_regularizer=l1)
+    assert gcn.losses == []                            # nothing built yet
+    gcn._maybe_build([x])
+    kernel = oracle.glorot_uniform(rng, 20, 8)
+    bias = (rng.standard_normal(8) * 0.1).astype(np.float32)
+    gcn.set_weights(kernel=kernel, bias=bias)
+    got = sorted(float(t) for t in gcn.losses)
+    want = sorted([5e-4 * float((kernel.astype(np.float64) ** 2).sum()) / 2, 1e-3 * float(np.abs(bias).sum())])
+    assert np.allclose(got, want, rtol=1e-5)
+    assert tfg.layers.GCN(8)([x, ei, w]) is not None and tfg.layers.GCN(8).losses == []    # no regulariser, no term
+
+    gat = tfg.layers.GAT(8, num_heads=2, kernel_regularizer=l2)
+    gat._maybe_build([x])
+    assert len(gat.losses) == 3                        # query_kernel, key_kernel, kernel; the biases take none here
+    sage = tfg.layers.MaxPoolGraphSage(8, kernel_regularizer=l2, bias_regularizer=l1)
+    sage._maybe_build([x])
+    assert len(sage.losses) == len([t for t in sage.weights.values() if t is not None])
+
+    gcn.trainable(True)
+    out = gcn([x, ei, w])
+    loss = (out * out).mean() + sum(gcn.losses)
+    loss.backward()
+    gk = gcn.kernel.grad.clone()
+    gcn.kernel.grad = None
+    gcn.bias.grad = None
+    (gcn([x, ei, w]) ** 2).mean().backward()
+    extra = (gk - gcn.kernel.grad).cpu().numpy()       # d/dW of 5e-4 * |W|^2 / 2 = 5e-4 * W
+    assert np.allclose(extra, 5e-4 * kernel, atol=1e-7)
+    assert torch.isfinite(gcn.bias.grad).all()

@@ -15,6 +15,7 @@ class Layer(object):
         self.built = False
         self.name = name or self.__class__.__name__
         self._weights = {}
+        self._init_of = {}
         self._attr_of = {}
         self._gen = None
         self._seed = seed
@@ -37,6 +38,7 @@ class Layer(object):
         else:
             raise ValueError("unknown initializer {}".format(initializer))
         self._weights[name] = w
+        self._init_of[name] = initializer
         return w
 
     def set_weights(self, **named):
@@ -67,6 +69,23 @@ class Layer(object):
     @property
     def weights(self):
         return dict(self._weights)
+
+    @property
+    def losses(self):
+        """Regularisation terms, as keras collects them in `layer.losses`: the reference hands `kernel_regularizer` to every
+        glorot-initialised matrix and `bias_regularizer` to every zero-initialised vector it registers (e.g.
+        layers/conv/gcn.py:26-30, layers/conv/gat.py:64-83, layers/conv/graph_sage.py:55-61); scalars (GIN's eps,
+        layers/conv/gin.py:23) take none.  One term per regularised weight, evaluated on the CURRENT weights; differentiable
+        when the layer is trainable."""
+        out = []
+        for name, w in self._weights.items():
+            if w is None or w.dim() == 0:
+                continue
+            kind = "bias_regularizer" if self._init_of.get(name) == "zeros" else "kernel_regularizer"
+            reg = getattr(self, kind, None)
+            if reg is not None:
+                out.append(reg(w))
+        return out
 
     def parameters(self):
         """The layer's weight tensors (for torch.optim); call trainable(True) first to track gradients."""

@@ -16,8 +16,8 @@ class GAT(Layer):
     split_value_heads=True: V [F, units] is cut into heads and the heads are concatenated;
     False: V is [F, units * num_heads] and the heads are averaged.
     query_activation / key_activation default to relu as in the reference; edge_drop_rate is the dropout rate of
-    the attention weights (active only under training=True).  kernel_regularizer / bias_regularizer are accepted for
-    signature compatibility and stored (the training loop owns the loss)."""
+    the attention weights (active only under training=True).  kernel_regularizer / bias_regularizer feed `layer.losses`
+    (one term per regularised weight, as keras collects them; the training loop adds them to its loss)."""
 
     def __init__(self, units, attention_units=None, activation=None, use_bias=True, num_heads=1,
                  split_value_heads=True, query_activation=relu, key_activation=relu, edge_drop_rate=0.0,

@@ -38,6 +38,7 @@ class SGC(Layer):
     def __init__(self, units, k=1, activation=None, use_bias=True, renorm=True, improved=False,
                  kernel_regularizer=None, bias_regularizer=None, *args, **kwargs):
         super().__init__(*args, **kwargs)
+        self.kernel_regularizer, self.bias_regularizer = kernel_regularizer, bias_regularizer
         self.units, self.k, self.activation, self.use_bias = units, k, activation, use_bias
         self.renorm, self.improved = renorm, improved
         self.kernel = self.bias = None
@@ -59,6 +60,7 @@ class TAGCN(Layer):
     def __init__(self, units, k=3, activation=None, use_bias=True, renorm=False, improved=False,
                  kernel_regularizer=None, bias_regularizer=None, *args, **kwargs):
         super().__init__(*args, **kwargs)
+        self.kernel_regularizer, self.bias_regularizer = kernel_regularizer, bias_regularizer
         assert k > 0                                                     # layers/conv/tagcn.py:34
         self.units, self.k, self.activation, self.use_bias = units, k, activation, use_bias
         self.renorm, self.improved = renorm, improved
@@ -80,6 +82,7 @@ class _MlpPropagation(Layer):
                  last_dense_drop_rate=0.0, edge_drop_rate=0.0, kernel_regularizer=None, bias_regularizer=None,
                  *args, **kwargs):
         super().__init__(*args, **kwargs)
+        self.kernel_regularizer, self.bias_regularizer = kernel_regularizer, bias_regularizer
         self.units_list = units_list
         self.dense_activation, self.activation = dense_activation, activation
         self.k, self.alpha = k, alpha
@@ -138,6 +141,7 @@ class ChebyNet(Layer):
     def __init__(self, units, k, activation=None, use_bias=True, normalization_type="sym",
                  use_dynamic_lambda_max=False, kernel_regularizer=None, bias_regularizer=None, *args, **kwargs):
         super().__init__(*args, **kwargs)
+        self.kernel_regularizer, self.bias_regularizer = kernel_regularizer, bias_regularizer
         assert k >= 1                                                     # layers/conv/chebynet.py:38-39
         assert normalization_type in [None, "sym", "rw"]
         self.units, self.k, self.activation, self.use_bias = units, k, activation, use_bias
@@ -172,6 +176,7 @@ class LEConv(Layer):
     def __init__(self, units, activation=None, self_use_bias=True, aggr_self_use_bias=True,
                  aggr_neighbor_use_bias=False, kernel_regularizer=None, bias_regularizer=None, *args, **kwargs):
         super().__init__(*args, **kwargs)
+        self.kernel_regularizer, self.bias_regularizer = kernel_regularizer, bias_regularizer
         self.units, self.activation = units, activation
         self.self_use_bias, self.aggr_self_use_bias, self.aggr_neighbor_use_bias = \
             self_use_bias, aggr_self_use_bias, aggr_neighbor_use_bias
