@@ -38,7 +38,7 @@ constexpr int BK = 16;   // 16 keeps load-staging registers low enough for 3 wor
                                   // 1.20 -> 1.155 ms, 170 k x 128 -> 256: 0.121 -> 0.113 without it) — kept as a switch
 #endif
 
-template <int BM, int BN, int WM, int WN, bool AV4, bool BV4>
+template <int BM, int BN, int WM, int WN, bool AV4, bool BV4, bool AHEAD>
 __global__ __launch_bounds__(kBlock) void gemm_kernel(const float* __restrict__ A, int64_t lda,
                                                       const float* __restrict__ B, int64_t ldb,
                                                       const float* __restrict__ bias, int act,
@@ -214,11 +214,50 @@ __global__ __launch_bounds__(kBlock) void gemm_kernel(const float* __restrict__ 
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         };
-        // unrolled, so the LDS reads of step kk+1 issue under the MFMAs of step kk; the zero-padded tail of the last
-        // tile is skipped by a wave-uniform guard per step (one accumulator copy, no second loop body)
+        if constexpr (AHEAD) {
+            // Long K on the wide wave tiles (the host picks this instantiation from K >= 256 and a 64 x 64 wave tile): one
+            // straight-line block per tile, the operands of step kk + 2 read from LDS BEFORE the MFMAs of step kk are issued.  In the guarded form below every step is a
+            // basic block of its own — ds_read, s_waitcnt lgkmcnt(0), 4 MFMAs — and the LDS round trip of a step starts only
+            // after the previous step's last MFMA has been issued (+3.5 % at 170 k x 1433 -> 256 and 233 k x 602 -> 256,
+            // profiles/r05_gemm_generic_ab.jsonl).  The padded tail of the last tile is multiplied, not skipped: A and B are
+            // both zero-filled past K, so it adds +0 to every accumulator (same bits; at K = 101 the 11 wasted k of 112 cost
+            // 4 %, which is why short K keeps the guards).  The sched_barriers pin the order: left alone the scheduler sinks
+            // each read next to its MFMA again.  A guarded second body for the last tile inside this loop made the compiler
+            // keep two accumulator sets (128 AGPRs).
+            (void)kmax;
+            auto fetch = [&](int kk, float (&a)[TM], float (&b)[TN]) {
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            if (kk < kmax) kstep(kk);
+                for (int i = 0; i < TM; ++i) a[i] = As[(kk + kh) * LDA_S + wm * WM + i * 32 + l31];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[j] = Bs[(kk + kh) * LDB_S + wn * WN + j * 32 + l31];
+            };
+            auto mfmas = [&](const float (&a)[TM], const float (&b)[TN]) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            };
+            float a0[TM], b0[TN], a1[TM], b1[TN];
+            fetch(0, a0, b0);
+#pragma unroll
+            for (int kk = 0; kk < BK; kk += 4) {
+                fetch(kk + 2, a1, b1);
+                __builtin_amdgcn_sched_barrier(0);
+                mfmas(a0, b0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kk + 4 < BK) fetch(kk + 4, a0, b0);
+                __builtin_amdgcn_sched_barrier(0);
+                mfmas(a1, b1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            // the zero-padded tail of the last tile is skipped by a wave-uniform guard per step (one accumulator copy, no
+            // second loop body)
+#pragma unroll
+            for (int kk = 0; kk < BK; kk += 2) {
+                if (kk < kmax) kstep(kk);
+            }
         }
         if (kTwoLevel) {
             if (two_level && ++tiles_in_chain == kFlushTiles) {      // wave-uniform
@@ -1508,9 +1547,21 @@ int launch_gemm(const float* A, int64_t lda, const float* B, int64_t ldb, const 
     const float* kb = split ? nullptr : bias;
     const int ka = split ? TFGX_ACT_NONE : act;
     dim3 grid(static_cast<unsigned>(blocks), static_cast<unsigned>(ny), 1), block(kBlock, 1, 1);
-#define TFGX_GEMM_GO(AV, BV)                                                                                         \
-    gemm_kernel<BM, BN, WM, WN, AV, BV><<<grid, block, 0, stream>>>(A, lda, B, ldb, kb, ka, out, ldo, M, K, N, ntn, \
-                                                                     act_cols, k_chunk, M * int64_t(N), two_level_default())
+    // developer A/B: TFGX_GEMM_LDS_AHEAD=0 keeps the per-step operand reads at every K
+    static const bool lds_ahead = [] { const char* e = std::getenv("TFGX_GEMM_LDS_AHEAD"); return !(e && e[0] == '0'); }();
+    // wide wave tiles only (4 MFMAs per step): on the 32 x 64 / 64 x 32 wave tiles (2 MFMAs per 3 operand reads) the pinned
+    // order LOST 8 % (233 k x 602 -> 64: 0.225 -> 0.244 ms, 170 k x 1433 -> 64: 0.385 -> 0.402)
+    constexpr bool kWideWaveTile = (WM / 32) * (WN / 32) >= 4;
+    const bool ahead = kWideWaveTile && lds_ahead && k_chunk >= 256;
+#define TFGX_GEMM_GO(AV, BV)                                                                                              \
+    do {                                                                                                                  \
+        if (ahead)                                                                                                        \
+            gemm_kernel<BM, BN, WM, WN, AV, BV, kWideWaveTile><<<grid, block, 0, stream>>>(                               \
+                A, lda, B, ldb, kb, ka, out, ldo, M, K, N, ntn, act_cols, k_chunk, M * int64_t(N), two_level_default());  \
+        else                                                                                                              \
+            gemm_kernel<BM, BN, WM, WN, AV, BV, false><<<grid, block, 0, stream>>>(                                       \
+                A, lda, B, ldb, kb, ka, out, ldo, M, K, N, ntn, act_cols, k_chunk, M * int64_t(N), two_level_default());  \
+    } while (0)
     if (av4 && bv4) TFGX_GEMM_GO(true, true);
     else if (av4) TFGX_GEMM_GO(true, false);
     else if (bv4) TFGX_GEMM_GO(false, true);
