@@ -31,6 +31,9 @@ constexpr int BK = 16;   // 16 keeps load-staging registers low enough for 3 wor
 #ifndef TFGX_ROWS_EXPERIMENT
 #define TFGX_ROWS_EXPERIMENT 0    // 3 = instrumented build: per-wave clocks of the tile loop and its phases (tfgx_debug_rows_stats / _waves)
 #endif
+#ifndef TFGX_GEMM_PREFETCH_TILES
+#define TFGX_GEMM_PREFETCH_TILES 1   // developer A/B: 2 = gemm_kernel's long-K instantiation keeps two tiles of global loads in flight
+#endif
 #ifndef TFGX_ROWS_VEC_STORE
 #define TFGX_ROWS_VEC_STORE 0     // 16-byte epilogue stores through a quad transpose of the accumulators: +4..9 % while every store carried
                                   // its own 64-bit address arithmetic; once the addresses moved off the vector ALU the 65 VALU ops per
@@ -103,10 +106,10 @@ __global__ __launch_bounds__(kBlock) void gemm_kernel(const float* __restrict__ 
     }
     int tiles_in_chain = 0;
 
-    float ra[A_LOADS * 4];
-    float4 rb[B_LOADS];
+    typedef float RegsA[A_LOADS * 4];
+    typedef float4 RegsB[B_LOADS];
 
-    auto load_tiles = [&](int k0) {
+    auto load_tiles = [&](int k0, RegsA& ra, RegsB& rb) {
         if (AV4) {
 #pragma unroll
             for (int i = 0; i < A_LOADS; ++i) {
@@ -169,7 +172,7 @@ __global__ __launch_bounds__(kBlock) void gemm_kernel(const float* __restrict__ 
         }
     };
 
-    auto store_tiles = [&]() {
+    auto store_tiles = [&](const RegsA& ra, const RegsB& rb) {
         if (AV4) {
 #pragma unroll
             for (int i = 0; i < A_LOADS; ++i) {
@@ -195,11 +198,11 @@ __global__ __launch_bounds__(kBlock) void gemm_kernel(const float* __restrict__ 
         }
     };
 
-    load_tiles(0);
-    for (int k0 = 0; k0 < K; k0 += BK) {
-        store_tiles();
+    // one BK-deep tile: registers -> LDS, barrier, the global loads of tile k_next into the SAME registers, multiply, barrier
+    auto one_tile = [&](int k0, int k_next, RegsA& ra, RegsB& rb) {
+        store_tiles(ra, rb);
         __syncthreads();
-        if (k0 + BK < K) load_tiles(k0 + BK);
+        if (k_next < K) load_tiles(k_next, ra, rb);
         const int kh = lane >> 5, l31 = lane & 31;
         const int kmax = min(BK, K - k0);   // the zero-padded tail of the last tile is skipped, not multiplied
         auto kstep = [&](int kk) {
@@ -274,6 +277,23 @@ __global__ __launch_bounds__(kBlock) void gemm_kernel(const float* __restrict__ 
             }
         }
         __syncthreads();
+    };
+    if constexpr (AHEAD && TFGX_GEMM_PREFETCH_TILES == 2) {
+        // two register stages: the loads of tile t + 2 are issued when tile t starts multiplying, so they have two tiles of
+        // MFMA time (not one) to come back from HBM before store_tiles waits for them
+        RegsA ra0, ra1;
+        RegsB rb0, rb1;
+        load_tiles(0, ra0, rb0);
+        if (BK < K) load_tiles(BK, ra1, rb1);
+        for (int k0 = 0; k0 < K; k0 += 2 * BK) {
+            one_tile(k0, k0 + 2 * BK, ra0, rb0);
+            if (k0 + BK < K) one_tile(k0 + BK, k0 + 3 * BK, ra1, rb1);
+        }
+    } else {
+        RegsA ra;
+        RegsB rb;
+        load_tiles(0, ra, rb);
+        for (int k0 = 0; k0 < K; k0 += BK) one_tile(k0, k0 + BK, ra, rb);
     }
     if (kTwoLevel) {
         if (two_level) {
