@@ -14,7 +14,8 @@
 //  * gemm_kernel (everything else): BM x BN tile per 256-thread workgroup (4 waves), BK = 16.  A is staged transposed
 //    in LDS (As[k][m]) so the MFMA A operand (lane l: A[m = l&31][k = l>>5]) is a conflict-free ds_read_b32 over
 //    consecutive m; B is staged as Bs[k][n].  Global loads for tile t+1 are issued before the MFMAs of tile t
-//    (register staging), LDS is single-buffered.  Optional split-K over blockIdx.y for small M with a long K.
+//    (register staging), LDS is single-buffered.  On long K (>= 256) the 64 x 64 wave tile reads the LDS operands of k step
+//    kk + 2 before the MFMAs of step kk (template flag AHEAD).  Optional split-K over blockIdx.y for small M with a long K.
 #include "tfgx_common.h"
 #include "tfgx_mfma.h"
 #include <cstdlib>
