@@ -250,6 +250,9 @@ template <int VEC, int G, int D>
 __global__ __launch_bounds__(kBlock) void gat_fused_kernel(const GArgs a)
 {
     constexpr int ROWS_PER_BLOCK = kBlock / G;
+#ifndef TFGX_GAT_COL_AHEAD
+#define TFGX_GAT_COL_AHEAD 1          // developer A/B: 0 = every batch loads its own source ids right before its gathers
+#endif
 #ifndef TFGX_GAT_UNROLL_NARROW
 #define TFGX_GAT_UNROLL_NARROW 4      // developer A/B: edges in flight per lane group when a head's K slice is <= 4 floats
 #endif
@@ -296,9 +299,19 @@ __global__ __launch_bounds__(kBlock) void gat_fused_kernel(const GArgs a)
             m = mn;
         };
 
+#if TFGX_GAT_COL_AHEAD
+        // the source ids of the NEXT batch of G edges are loaded before this batch's gathers are issued: in a source-blocked
+        // pass a row has ~60 edges per block (4 batches), and each batch's id load sat in front of its gathers
+        int cj_next = (s + lane < e) ? a.col[s + lane] : 0;
+#endif
         for (int base = s; base < e; base += G) {
+#if TFGX_GAT_COL_AHEAD
+            const int cj = cj_next;
+            cj_next = (base + G + lane < e) ? a.col[base + G + lane] : 0;
+#else
             const int mine = base + lane;
             const int cj = (mine < e) ? a.col[mine] : 0;
+#endif
             const int cnt = min(G, e - base);
             int j = 0;
             for (; j + UNROLL <= cnt; j += UNROLL) {

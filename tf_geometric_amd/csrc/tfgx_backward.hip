@@ -966,9 +966,21 @@ __global__ __launch_bounds__(kBlock) void gat_backward_fast_kernel(const GB a)
 #define TFGX_GAT_BWD_UNROLL_NARROW 4  // developer A/B
 #endif
         constexpr int U = (D <= 4) ? TFGX_GAT_BWD_UNROLL_NARROW : (D <= 16 ? 2 : 1);
+#ifndef TFGX_GAT_BWD_COL_AHEAD
+#define TFGX_GAT_BWD_COL_AHEAD 1      // developer A/B: 0 = every batch loads its own neighbour ids right before its gathers
+#endif
+#if TFGX_GAT_BWD_COL_AHEAD
+        // as in gat_fused_kernel: the neighbour ids of the NEXT batch are loaded before this batch's gathers are issued
+        int oj_next = (s0 + lane < e0) ? a.other[s0 + lane] : 0;
+#endif
         for (int base = s0; base < e0; base += G) {
             const int idx = base + lane;
+#if TFGX_GAT_BWD_COL_AHEAD
+            const int oj = oj_next;
+            oj_next = (idx + G < e0) ? a.other[idx + G] : 0;
+#else
             const int oj = (idx < e0) ? a.other[idx] : 0;
+#endif
             const int pj = (a.drop.thr != 0u && a.pos && idx < e0) ? a.pos[idx] : idx;   // forward-CSR position
             const int cnt = min(G, e0 - base);
             int j = 0;
