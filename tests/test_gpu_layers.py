@@ -119,7 +119,7 @@ def test_gat_source_blocks_equal_the_oracle(tfg, oracle, heads, att, units, kb):
     class _P(object):
         def __init__(self, n, e):
             self.n_dst, self.n_src, self.num_edges = n, n, e
-    assert G.source_block_count(_P(233000, 114000000), 8, 64) == 8 and G.source_block_count(_P(2400000, 123000000), 8, 64) == 1
+    assert G.source_block_count(_P(233000, 114000000), 8, 64) == 11 and G.source_block_count(_P(2400000, 123000000), 8, 64) == 1
     assert G.source_block_count(_P(600, 30000), 8, 64) == 1
 
 

@@ -15,6 +15,11 @@
 // (m, l, acc[VEC]) is lane-private and no cross-lane traffic is needed beyond the col broadcast.
 #include "tfgx_common.h"
 #include <cfloat>
+#include <cmath>
+#include <type_traits>
+#ifndef TFGX_GAT_POW2_SCALE
+#define TFGX_GAT_POW2_SCALE 1         // developer A/B: 0 = the attention kernels always DIVIDE the score by scale
+#endif
 
 namespace tfgx {
 namespace {
@@ -196,6 +201,7 @@ struct GArgs {
     int32_t H, d, dv, W;  // W = H*dv
     int32_t add_self_loop;
     float scale;
+    float inv_scale;      // 1 / scale when scale is a power of two (then dot * inv_scale == dot / scale bit for bit), else 0
     int32_t act;
     const float* bias;
     int32_t kvec;         // 1: K/Q head slices are 16-byte aligned and d % 4 == 0
@@ -216,6 +222,20 @@ struct GArgs {
     float* stats_ml;      // [n_dst, 2H] final (m, l) for the backward pass, or NULL
     DropCfg drop;         // attention dropout (training): acc += p * keep_scale_or_0 * V; the denominator is untouched
 };
+
+// 1 / s when s is a power of two with a normal reciprocal: x * (1 / s) and x / s are then the same correctly rounded value
+inline float exact_inverse_or_zero(float s)
+{
+#if TFGX_GAT_POW2_SCALE
+    int e = 0;
+    if (!(s > 0.0f) || std::frexp(s, &e) != 0.5f) return 0.0f;
+    const float inv = 1.0f / s;
+    return (inv >= FLT_MIN && inv <= FLT_MAX) ? inv : 0.0f;
+#else
+    (void)s;
+    return 0.0f;
+#endif
+}
 
 // D > 0: compile-time head width (Q slice lives in registers); D == 0: runtime d, Q re-read (cache-hot)
 template <int D>
@@ -246,10 +266,14 @@ __device__ __forceinline__ float head_dot(const float (&qreg)[D > 0 ? D : 1], co
     return s;
 }
 
-template <int VEC, int G, int D>
-__global__ __launch_bounds__(kBlock) void gat_fused_kernel(const GArgs a)
+// POW2: a.inv_scale is the exact inverse of a power-of-two scale (instantiated for d = 1, 4, 16, where sqrt(d) is one)
+template <int VEC, int G, int D, bool POW2 = false>
+__global__ __launch_bounds__(kBlock, (D > 0 && D <= 8) ? 5 : 1) void gat_fused_kernel(const GArgs a)
 {
     constexpr int ROWS_PER_BLOCK = kBlock / G;
+#ifndef TFGX_GAT_ONE_EXP
+#define TFGX_GAT_ONE_EXP 1            // developer A/B: 0 = two exponentials per edge (exp(m - mn), exp(sc - mn))
+#endif
 #ifndef TFGX_GAT_COL_AHEAD
 #define TFGX_GAT_COL_AHEAD 1          // developer A/B: 0 = every batch loads its own source ids right before its gathers
 #endif
@@ -289,49 +313,79 @@ __global__ __launch_bounds__(kBlock) void gat_fused_kernel(const GArgs a)
         }
 
         auto step = [&](float sc, const float (&vv)[VEC], int64_t pos) {
+#if TFGX_GAT_ONE_EXP
+            // mn = max(m, sc): one of exp(m - mn), exp(sc - mn) is exp(0) = 1, the other exp(-|sc - m|) — ONE exponential per
+            // edge (the loop is bound by vector-ALU issue, not by its gathers: ~55 instructions per edge, 25 of them the two
+            // expf).  Same bits as the two-exponential form: m - sc == -(sc - m) exactly; the `x - x` terms keep its NaN for an
+            // infinite score or running maximum (exp(inf - inf)), and are +0 otherwise.
+            const float dlt = sc - m;
+            const bool up = dlt > 0.0f;                  // sc is the new running maximum (false for NaN, as fmaxf keeps m)
+            const float ex = expf(up ? -dlt : dlt);
+            const float corr = up ? ex : 1.0f + (m - m);
+            const float p = up ? 1.0f + (sc - sc) : ex;
+            const float mn = up ? sc : m;
+#else
             const float mn = fmaxf(m, sc);
             const float corr = expf(m - mn);
             const float p = expf(sc - mn);
+#endif
             l = fmaf(l, corr, p);
             const float pk = p * drop_scale(a.drop, uint32_t(pos * a.H + head));
 #pragma unroll
             for (int i = 0; i < VEC; ++i) acc[i] = fmaf(acc[i], corr, pk * vv[i]);
             m = mn;
         };
+        // element offset of a gathered row as ONE 32 x 32 -> 64-bit multiply (v_mad_u64_u32): ids are non-negative int32 and
+        // the leading dimensions fit 32 bits (checked at the entry point).  `int64_t(c) * a.ldk` made the compiler emulate a
+        // 64 x 64-bit product — v_ashrrev, 2 v_mul_lo_u32, v_mad_u64_u32, v_add3 per address, three of them quarter-rate:
+        // 40 % of this loop's vector-ALU time for its two addresses per edge.
+        const uint32_t ldk32 = uint32_t(a.ldk), ldv32 = uint32_t(a.ldv);
+        auto row_off = [](int c, uint32_t ld) { return uint64_t(uint32_t(c)) * ld; };
+        // score = <q, k> / scale (gat.py:79); a power-of-two scale (sqrt(d) for d = 1, 4, 16, 64) divides exactly by a multiply
+        auto scaled = [&](auto pow2, float dot) {
+            if constexpr (decltype(pow2)::value) return dot * a.inv_scale;
+            else return dot / a.scale;
+        };
 
+        // the scale's kind is a template parameter: a run-time branch on it would sit between the gathers of a batch and split
+        // them into one basic block each (measured: attention 3.45 -> 4.06 ms in 8 source blocks), and two copies of the walk
+        // inside one kernel cost 9 registers and with them the fifth wave per SIMD (one-pass walk on sparse graphs: + 3-5 %)
+        constexpr std::bool_constant<POW2> pow2{};
+        {
 #if TFGX_GAT_COL_AHEAD
-        // the source ids of the NEXT batch of G edges are loaded before this batch's gathers are issued: in a source-blocked
-        // pass a row has ~60 edges per block (4 batches), and each batch's id load sat in front of its gathers
-        int cj_next = (s + lane < e) ? a.col[s + lane] : 0;
+            // the source ids of the NEXT batch of G edges are loaded before this batch's gathers are issued: in a source-blocked
+            // pass a row has ~60 edges per block (4 batches), and each batch's id load sat in front of its gathers
+            int cj_next = (s + lane < e) ? a.col[s + lane] : 0;
 #endif
-        for (int base = s; base < e; base += G) {
+            for (int base = s; base < e; base += G) {
 #if TFGX_GAT_COL_AHEAD
-            const int cj = cj_next;
-            cj_next = (base + G + lane < e) ? a.col[base + G + lane] : 0;
+                const int cj = cj_next;
+                cj_next = (base + G + lane < e) ? a.col[base + G + lane] : 0;
 #else
-            const int mine = base + lane;
-            const int cj = (mine < e) ? a.col[mine] : 0;
+                const int mine = base + lane;
+                const int cj = (mine < e) ? a.col[mine] : 0;
 #endif
-            const int cnt = min(G, e - base);
-            int j = 0;
-            for (; j + UNROLL <= cnt; j += UNROLL) {
-                float sc[UNROLL];
-                float vv[UNROLL][VEC];
+                const int cnt = min(G, e - base);
+                int j = 0;
+                for (; j + UNROLL <= cnt; j += UNROLL) {
+                    float sc[UNROLL];
+                    float vv[UNROLL][VEC];
 #pragma unroll
-                for (int u = 0; u < UNROLL; ++u) {
-                    const int c = __shfl(cj, j + u, G);
-                    sc[u] = head_dot<D>(qreg, qp, a.k + int64_t(c) * a.ldk + hoff, a.d, a.kvec) / a.scale;
-                    load_vec<VEC>(a.v + int64_t(c) * a.ldv + coff, vv[u]);
+                    for (int u = 0; u < UNROLL; ++u) {
+                        const int c = __shfl(cj, j + u, G);
+                        sc[u] = scaled(pow2, head_dot<D>(qreg, qp, a.k + row_off(c, ldk32) + hoff, a.d, a.kvec));
+                        load_vec<VEC>(a.v + row_off(c, ldv32) + coff, vv[u]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < UNROLL; ++u) step(sc[u], vv[u], base + j + u);
                 }
-#pragma unroll
-                for (int u = 0; u < UNROLL; ++u) step(sc[u], vv[u], base + j + u);
-            }
-            for (; j < cnt; ++j) {
-                const int c = __shfl(cj, j, G);
-                const float sc = head_dot<D>(qreg, qp, a.k + int64_t(c) * a.ldk + hoff, a.d, a.kvec) / a.scale;
-                float vv[VEC];
-                load_vec<VEC>(a.v + int64_t(c) * a.ldv + coff, vv);
-                step(sc, vv, base + j);
+                for (; j < cnt; ++j) {
+                    const int c = __shfl(cj, j, G);
+                    const float sc = scaled(pow2, head_dot<D>(qreg, qp, a.k + row_off(c, ldk32) + hoff, a.d, a.kvec));
+                    float vv[VEC];
+                    load_vec<VEC>(a.v + row_off(c, ldv32) + coff, vv);
+                    step(sc, vv, base + j);
+                }
             }
         }
         if (a.state_acc) {      // raw state of this part; the self-loop edge is added by the merge
@@ -346,7 +400,8 @@ __global__ __launch_bounds__(kBlock) void gat_fused_kernel(const GArgs a)
             continue;
         }
         if (a.add_self_loop) {  // the appended (r, r) edge comes last (graph_utils.py:350-366)
-            const float sc = head_dot<D>(qreg, qp, a.k + r * a.ldk + hoff, a.d, a.kvec) / a.scale;
+            const float dot = head_dot<D>(qreg, qp, a.k + r * a.ldk + hoff, a.d, a.kvec);
+            const float sc = scaled(pow2, dot);
             float vv[VEC];
             load_vec<VEC>(a.v + r * a.ldv + coff, vv);
             step(sc, vv, a.drop.self_base + r);
@@ -449,12 +504,19 @@ int launch_gat_d(const GArgs& a, hipStream_t stream)
     constexpr int ROWS_PER_BLOCK = kBlock / G;
     dim3 grid(grid_for(a.n_dst, ROWS_PER_BLOCK, 1 << 20), (a.W + G * VEC - 1) / (G * VEC), 1);
     dim3 block(kBlock, 1, 1);
+    const bool pow2 = a.inv_scale != 0.0f;      // only d = 1, 4, 16 have the multiply instantiated; every other d divides
     switch (a.d) {
-        case 1: gat_fused_kernel<VEC, G, 1><<<grid, block, 0, stream>>>(a); break;
+#define TFGX_GAT_POW2_CASE(D_)                                                                   \
+    case D_:                                                                                     \
+        if (pow2) gat_fused_kernel<VEC, G, D_, true><<<grid, block, 0, stream>>>(a);              \
+        else gat_fused_kernel<VEC, G, D_, false><<<grid, block, 0, stream>>>(a);                  \
+        break
+        TFGX_GAT_POW2_CASE(1);
         case 2: gat_fused_kernel<VEC, G, 2><<<grid, block, 0, stream>>>(a); break;
-        case 4: gat_fused_kernel<VEC, G, 4><<<grid, block, 0, stream>>>(a); break;
+        TFGX_GAT_POW2_CASE(4);
         case 8: gat_fused_kernel<VEC, G, 8><<<grid, block, 0, stream>>>(a); break;
-        case 16: gat_fused_kernel<VEC, G, 16><<<grid, block, 0, stream>>>(a); break;
+        TFGX_GAT_POW2_CASE(16);
+#undef TFGX_GAT_POW2_CASE
         case 32: gat_fused_kernel<VEC, G, 32><<<grid, block, 0, stream>>>(a); break;
         default: gat_fused_kernel<VEC, G, 0><<<grid, block, 0, stream>>>(a); break;
     }
@@ -552,11 +614,13 @@ extern "C" int tfgx_gat_fused_f32(const tfgx_gat_args* p, tfgx_stream_t stream_)
     const int64_t W = int64_t(p->H) * p->dv, A = int64_t(p->H) * p->d;
     TFGX_REQUIRE(p->ldq >= A && p->ldk >= A && p->ldv >= W && (p->state_acc || p->ldo >= W),
                  "leading dimension too small");
+    TFGX_REQUIRE(p->ldk < (int64_t(1) << 31) && p->ldv < (int64_t(1) << 31), "ldk / ldv must be below 2^31 elements");
     GArgs a;
     a.row_ptr = p->row_ptr; a.col = p->col; a.n_dst = p->n_dst;
     a.q = p->q; a.ldq = p->ldq; a.k = p->k; a.ldk = p->ldk; a.v = p->v; a.ldv = p->ldv;
     a.out = p->out; a.ldo = p->ldo; a.H = p->H; a.d = p->d; a.dv = p->dv; a.W = int32_t(W);
     a.add_self_loop = p->add_self_loop; a.scale = p->scale; a.act = p->act; a.bias = p->bias;
+    a.inv_scale = exact_inverse_or_zero(p->scale);
     a.kvec = (p->d % 4 == 0) && (p->ldk % 4 == 0) && aligned_to(p->k, 16);
     a.row_begin = p->row_begin ? p->row_begin : p->row_ptr;
     a.row_end = p->row_begin ? p->row_end : p->row_ptr + 1;

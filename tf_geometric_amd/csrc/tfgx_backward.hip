@@ -18,7 +18,12 @@
 // one-lane-per-output fallback for layouts the tuned one does not cover.
 #include "tfgx_common.h"
 #include <cfloat>
+#include <cmath>
 #include <cstring>
+#include <type_traits>
+#ifndef TFGX_GAT_BWD_POW2_SCALE
+#define TFGX_GAT_BWD_POW2_SCALE 1     // developer A/B: 0 = the attention backward always DIVIDES by scale
+#endif
 
 namespace tfgx {
 namespace {
@@ -690,6 +695,7 @@ struct GB {
     int64_t ldml, lddsum;            // row strides of ml / dsum (2H / H unless the caller packed the per-row data)
     int32_t H, d, dv, add_self_loop;
     float scale;
+    float inv_scale;                 // 1 / scale when scale is a power of two (x * inv_scale == x / scale bit for bit), else 0
     float* gq; int64_t ldgq;
     float* gk; int64_t ldgk;
     float* gv; int64_t ldgv;
@@ -879,7 +885,8 @@ __global__ __launch_bounds__(kBlock) void gat_pack_dst_vec4_kernel(const float* 
     }
 }
 
-template <int G, int D, bool SRC>
+// POW2: a.inv_scale is the exact inverse of a power-of-two scale (instantiated for d = 1, 4, 16, where sqrt(d) is one)
+template <int G, int D, bool SRC, bool POW2 = false>
 __global__ __launch_bounds__(kBlock) void gat_backward_fast_kernel(const GB a)
 {
     constexpr int VEC = 4;
@@ -924,22 +931,32 @@ __global__ __launch_bounds__(kBlock) void gat_backward_fast_kernel(const GB a)
             float v[VEC];
             float m, l, dd;
         };
-        auto edge_load = [&](int64_t o, EdgeIn& in) {   // o: the other endpoint (source c / destination r)
-            const float* pq = (SRC ? a.q + o * a.ldq : a.k + o * a.ldk) + head * a.d;
+        // element offsets of the gathered rows as ONE 32 x 32 -> 64-bit multiply each (v_mad_u64_u32): ids are non-negative int32
+        // and the leading dimensions fit 32 bits (checked at the entry point); an int64 id times an int64 stride made the
+        // compiler emulate a 64 x 64-bit product per address (see gat_fused_kernel)
+        const uint32_t ld_qk32 = uint32_t(SRC ? a.ldq : a.ldk), ld_v32 = uint32_t(SRC ? a.ldgo : a.ldv);
+        const uint32_t ldml32 = uint32_t(a.ldml), lddsum32 = uint32_t(a.lddsum);
+        auto edge_load = [&](int o_, EdgeIn& in) {   // o: the other endpoint (source c / destination r)
+            const uint64_t o = uint64_t(uint32_t(o_));
+            const float* pq = (SRC ? a.q : a.k) + o * ld_qk32 + head * a.d;
 #pragma unroll
             for (int t = 0; t < D; ++t) in.qk[t] = pq[t];
-            load_vec<VEC>((SRC ? a.go + o * a.ldgo : a.v + o * a.ldv) + coff, in.v);
+            load_vec<VEC>((SRC ? a.go : a.v) + o * ld_v32 + coff, in.v);
             if (SRC) {
-                in.m = a.ml[o * a.ldml + 2 * head];
-                in.l = a.ml[o * a.ldml + 2 * head + 1];
-                in.dd = a.dsum[o * a.lddsum + head];
+                in.m = a.ml[o * ldml32 + 2 * head];
+                in.l = a.ml[o * ldml32 + 2 * head + 1];
+                in.dd = a.dsum[o * lddsum32 + head];
             }
         };
-        auto edge_apply = [&](const EdgeIn& in, float keep) {
+        // pow2 (std::bool_constant<POW2>): the score and ds are divided by the scale with a multiply by its exact inverse — a
+        // template parameter of the kernel, so that no branch sits between a batch's gathers and no second copy of the walk
+        // costs registers
+        auto edge_apply = [&](const EdgeIn& in, float keep, auto pow2) {
             float sc = 0.0f;
 #pragma unroll
             for (int t = 0; t < D; ++t) sc = fmaf(mine_qk[t], in.qk[t], sc);
-            sc = sc / a.scale;
+            if constexpr (decltype(pow2)::value) sc = sc * a.inv_scale;
+            else sc = sc / a.scale;
             float part = 0.0f;
 #pragma unroll
             for (int i = 0; i < VEC; ++i) part = fmaf(mine_v[i], in.v[i], part);   // <dO, V> over this lane's columns
@@ -948,7 +965,9 @@ __global__ __launch_bounds__(kBlock) void gat_backward_fast_kernel(const GB a)
             const float linv = SRC ? 1.0f / (in.l + 1e-8f) : linv_r;
             const float dd = SRC ? in.dd : d_r;
             const float alpha = expf(sc - m) * linv;
-            const float ds = alpha * (keep * da - dd) / a.scale;
+            float ds = alpha * (keep * da - dd);
+            if constexpr (decltype(pow2)::value) ds = ds * a.inv_scale;
+            else ds = ds / a.scale;
 #pragma unroll
             for (int t = 0; t < D; ++t) acc_qk[t] = fmaf(ds, in.qk[t], acc_qk[t]);
             if (SRC) {
@@ -957,10 +976,10 @@ __global__ __launch_bounds__(kBlock) void gat_backward_fast_kernel(const GB a)
                 for (int i = 0; i < VEC; ++i) acc_v[i] = fmaf(ak, in.v[i], acc_v[i]);
             }
         };
-        auto edge = [&](int64_t o, float keep) {
+        auto edge = [&](int o, float keep, auto pow2) {
             EdgeIn in;
             edge_load(o, in);
-            edge_apply(in, keep);
+            edge_apply(in, keep, pow2);
         };
 #ifndef TFGX_GAT_BWD_UNROLL_NARROW
 #define TFGX_GAT_BWD_UNROLL_NARROW 4  // developer A/B
@@ -969,35 +988,38 @@ __global__ __launch_bounds__(kBlock) void gat_backward_fast_kernel(const GB a)
 #ifndef TFGX_GAT_BWD_COL_AHEAD
 #define TFGX_GAT_BWD_COL_AHEAD 1      // developer A/B: 0 = every batch loads its own neighbour ids right before its gathers
 #endif
+        constexpr std::bool_constant<POW2> pow2{};
+        {
 #if TFGX_GAT_BWD_COL_AHEAD
-        // as in gat_fused_kernel: the neighbour ids of the NEXT batch are loaded before this batch's gathers are issued
-        int oj_next = (s0 + lane < e0) ? a.other[s0 + lane] : 0;
+            // as in gat_fused_kernel: the neighbour ids of the NEXT batch are loaded before this batch's gathers are issued
+            int oj_next = (s0 + lane < e0) ? a.other[s0 + lane] : 0;
 #endif
-        for (int base = s0; base < e0; base += G) {
-            const int idx = base + lane;
+            for (int base = s0; base < e0; base += G) {
+                const int idx = base + lane;
 #if TFGX_GAT_BWD_COL_AHEAD
-            const int oj = oj_next;
-            oj_next = (idx + G < e0) ? a.other[idx + G] : 0;
+                const int oj = oj_next;
+                oj_next = (idx + G < e0) ? a.other[idx + G] : 0;
 #else
-            const int oj = (idx < e0) ? a.other[idx] : 0;
+                const int oj = (idx < e0) ? a.other[idx] : 0;
 #endif
-            const int pj = (a.drop.thr != 0u && a.pos && idx < e0) ? a.pos[idx] : idx;   // forward-CSR position
-            const int cnt = min(G, e0 - base);
-            int j = 0;
-            for (; j + U <= cnt; j += U) {
-                EdgeIn in[U];
+                const int pj = (a.drop.thr != 0u && a.pos && idx < e0) ? a.pos[idx] : idx;   // forward-CSR position
+                const int cnt = min(G, e0 - base);
+                int j = 0;
+                for (; j + U <= cnt; j += U) {
+                    EdgeIn in[U];
 #pragma unroll
-                for (int u = 0; u < U; ++u) edge_load(int64_t(__shfl(oj, j + u, G)), in[u]);
+                    for (int u = 0; u < U; ++u) edge_load(__shfl(oj, j + u, G), in[u]);
 #pragma unroll
-                for (int u = 0; u < U; ++u)
-                    edge_apply(in[u], drop_scale(a.drop, uint32_t(int64_t(__shfl(pj, j + u, G)) * a.H + head)));
+                    for (int u = 0; u < U; ++u)
+                        edge_apply(in[u], drop_scale(a.drop, uint32_t(int64_t(__shfl(pj, j + u, G)) * a.H + head)), pow2);
+                }
+                for (; j < cnt; ++j)
+                    edge(__shfl(oj, j, G), drop_scale(a.drop, uint32_t(int64_t(__shfl(pj, j, G)) * a.H + head)), pow2);
             }
-            for (; j < cnt; ++j)
-                edge(int64_t(__shfl(oj, j, G)), drop_scale(a.drop, uint32_t(int64_t(__shfl(pj, j, G)) * a.H + head)));
+            // the appended self-loop belongs to the row's LAST part (chunk launches: the chunk that ends where the row ends)
+            if (a.add_self_loop && row < a.n_self && (a.part_row == nullptr || e0 == a.row_ptr[row + 1]))
+                edge(int(row), drop_scale(a.drop, uint32_t((a.drop.self_base + row) * a.H + head)), pow2);
         }
-        // the appended self-loop belongs to the row's LAST part (chunk launches: the chunk that ends where the row ends)
-        if (a.add_self_loop && row < a.n_self && (a.part_row == nullptr || e0 == a.row_ptr[row + 1]))
-            edge(row, drop_scale(a.drop, uint32_t((a.drop.self_base + row) * a.H + head)));
         if (SRC) {
             if (cvalid) {
                 float* gvp = a.gv + part * a.ldgv + coff;
@@ -1024,12 +1046,19 @@ int launch_gat_bwd_d(const GB& a, hipStream_t stream)
     constexpr int ROWS_PER_BLOCK = kBlock / G;
     const int W = a.H * a.dv;
     dim3 grid(grid_for(a.n, ROWS_PER_BLOCK, 1 << 20), (W + G * 4 - 1) / (G * 4), 1), block(kBlock, 1, 1);
+    const bool pow2 = a.inv_scale != 0.0f;      // only d = 1, 4, 16 have the multiply instantiated; every other d divides
     switch (a.d) {
-        case 1: gat_backward_fast_kernel<G, 1, SRC><<<grid, block, 0, stream>>>(a); break;
+#define TFGX_GAT_BWD_POW2_CASE(D_)                                                                   \
+    case D_:                                                                                         \
+        if (pow2) gat_backward_fast_kernel<G, D_, SRC, true><<<grid, block, 0, stream>>>(a);          \
+        else gat_backward_fast_kernel<G, D_, SRC, false><<<grid, block, 0, stream>>>(a);              \
+        break
+        TFGX_GAT_BWD_POW2_CASE(1);
         case 2: gat_backward_fast_kernel<G, 2, SRC><<<grid, block, 0, stream>>>(a); break;
-        case 4: gat_backward_fast_kernel<G, 4, SRC><<<grid, block, 0, stream>>>(a); break;
+        TFGX_GAT_BWD_POW2_CASE(4);
         case 8: gat_backward_fast_kernel<G, 8, SRC><<<grid, block, 0, stream>>>(a); break;
-        case 16: gat_backward_fast_kernel<G, 16, SRC><<<grid, block, 0, stream>>>(a); break;
+        TFGX_GAT_BWD_POW2_CASE(16);
+#undef TFGX_GAT_BWD_POW2_CASE
         default: gat_backward_fast_kernel<G, 32, SRC><<<grid, block, 0, stream>>>(a); break;
     }
     TFGX_LAUNCH_CHECK("gat_backward_fast_kernel");
@@ -1373,7 +1402,17 @@ static int fill_gb(const tfgx_gat_backward_args* p, GB& a)
     a.ldml = p->ld_stats_ml > 0 ? p->ld_stats_ml : 2 * int64_t(p->H);
     a.lddsum = p->ld_dsum > 0 ? p->ld_dsum : int64_t(p->H);
     TFGX_REQUIRE(a.ldml >= 2 * p->H && a.lddsum >= p->H, "ld_stats_ml / ld_dsum too small");
+    {
+        const int64_t lim = int64_t(1) << 31;     // the kernels form row offsets from 32-bit strides
+        TFGX_REQUIRE(a.ldq < lim && a.ldk < lim && a.ldv < lim && a.ldgo < lim && a.ldml < lim && a.lddsum < lim,
+                     "leading dimensions must be below 2^31 elements");
+    }
     a.H = p->H; a.d = p->d; a.dv = p->dv; a.add_self_loop = p->add_self_loop; a.scale = p->scale;
+    {   // a power-of-two scale (sqrt(d) for d = 1, 4, 16, 64) divides exactly by a multiply (see tfgx_attn.hip)
+        int e2 = 0;
+        const float inv = 1.0f / p->scale;
+        a.inv_scale = (TFGX_GAT_BWD_POW2_SCALE && std::frexp(p->scale, &e2) == 0.5f && inv >= FLT_MIN && inv <= FLT_MAX) ? inv : 0.0f;
+    }
     a.gq = p->grad_q; a.ldgq = p->ld_grad_q; a.gk = p->grad_k; a.ldgk = p->ld_grad_k;
     a.gv = p->grad_v; a.ldgv = p->ld_grad_v;
     TFGX_REQUIRE(p->drop_rate >= 0.0f && p->drop_rate < 1.0f, "drop_rate outside [0, 1)");

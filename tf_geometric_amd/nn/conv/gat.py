@@ -54,7 +54,11 @@ def _project_qkv(x, wq, bq, qact, wk, bk, kact, wv):
         w_qk = torch.cat([L.as_f32(wq, dev), L.as_f32(wk, dev)], dim=1).contiguous()
         b_qk = None if bq is None else torch.cat([L.as_f32(bq, dev).reshape(-1), L.as_f32(bk, dev).reshape(-1)])
         qk = gemm_bias_act(x, w_qk, bias=b_qk, act=qa)
-        return qk[:, :A], qk[:, A:], _values(x, wv)
+        # K rows narrower than a 128-byte line are gathered per edge: inside [Q | K] a line holds half as many of them, and
+        # the attention kernel (no longer hidden behind its own vector-ALU work) ran 3.62 instead of 3.09 ms at the Reddit
+        # shape (tools/gat_layer_attention_probe.py) — a copy of [n, A] floats costs ~10 us
+        K = qk[:, A:].contiguous() if A <= 16 else qk[:, A:]
+        return qk[:, :A], K, _values(x, wv)
     return _linear(x, wq, bq, qact), _linear(x, wk, bk, kact), _values(x, wv)
 
 
@@ -134,15 +138,17 @@ def _set_drop(a, drop_rate, drop_seed, self_base):
 
 
 SOURCE_BLOCKS = None      # developer A/B: None = the policy below, 0 / 1 = always one pass, k >= 2 = always k source blocks
-SOURCE_BLOCK_BYTES = 8 << 20          # K | V rows gathered per pass (same-box sweep at the Reddit shape: 8.4 MB blocks — KB = 8 —
-SOURCE_BLOCK_MIN_EDGES = 32           # beat 16.8 / 4.2 / 2.1 MB; at least this many edges per (row, block) on average
+SOURCE_BLOCK_BYTES = 6 << 20          # K | V rows gathered per pass.  Reddit shape (67 MB table), tools/gat_kb_sweep.py: KB = 4 / 6 / 8 /
+SOURCE_BLOCK_MIN_EDGES = 32           # 10 / 12 / 14 / 16 / 20 / 24 -> 4.14 / 3.50 / 2.98 / 2.77 / 2.77 / 2.80 / 2.83 / 2.93 / 3.09 ms (the
+                                      # optimum was KB = 8 while the kernel was bound by its own vector-ALU work); and at least this
+                                      # many edges per (row, block) on average
 SOURCE_BLOCK_STATS = {"launches": 0}  # diagnostics (tests assert the route taken)
 
 
 def source_block_count(plan, A, W):
     """How many source blocks the fused attention runs in (1 = one pass).  Dense graphs only: the K | V table
     (n_src x (A + W) floats) must be several blocks large and every (row, block) must still hold a few dozen edges —
-    Reddit shape (233 k nodes, 489 in-edges each, A = 8, W = 64): 8 blocks; products shape (51 in-edges): 1."""
+    Reddit shape (233 k nodes, 489 in-edges each, A = 8, W = 64): 11 blocks; products shape (51 in-edges): 1."""
     if SOURCE_BLOCKS is not None:
         return max(int(SOURCE_BLOCKS), 1)
     if plan.n_dst == 0 or plan.num_edges == 0:
