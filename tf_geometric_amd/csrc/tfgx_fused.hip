@@ -156,6 +156,11 @@ __global__ __launch_bounds__(kFusedThreads) void agg_gemm_kernel(const FArgs a)
             by_edge = true;
         }
     }
+    // element offset of a gathered row as ONE 32 x 32 -> 64-bit multiply (v_mad_u64_u32): ids / CSR positions are non-negative
+    // int32 and the strides fit 32 bits (checked at the entry point); int64 x int64 is emulated with three quarter-rate
+    // multiplies per address — vector-ALU work the MFMA half of this kernel competes with
+    const uint32_t xl32 = uint32_t(xl);
+    auto row_off = [&](int i) { return uint64_t(uint32_t(i)) * xl32; };
 
     while (true) {
         int u = 0;
@@ -229,7 +234,7 @@ __global__ __launch_bounds__(kFusedThreads) void agg_gemm_kernel(const FArgs a)
                     for (int t = 0; t < UNROLL; ++t) {
                         const int c = bcast_i<G>(cj, j + t);
                         if constexpr (WEIGHTED) ww[t] = bcast_f<G>(wj, j + t);
-                        load_vec<4>(xb + (by_edge ? int64_t(base + j + t) : int64_t(c)) * xl, xv[t]);
+                        load_vec<4>(xb + row_off(by_edge ? base + j + t : c), xv[t]);
                     }
 #pragma unroll
                     for (int t = 0; t < UNROLL; ++t)
@@ -241,7 +246,7 @@ __global__ __launch_bounds__(kFusedThreads) void agg_gemm_kernel(const FArgs a)
                     float wv = 1.0f;
                     if constexpr (WEIGHTED) wv = bcast_f<G>(wj, j);
                     float xv[4];
-                    load_vec<4>(xb + (by_edge ? int64_t(base + j) : int64_t(c)) * xl, xv);
+                    load_vec<4>(xb + row_off(by_edge ? base + j : c), xv);
 #pragma unroll
                     for (int v = 0; v < 4; ++v) acc[v] = WEIGHTED ? fmaf(wv, xv[v], acc[v]) : acc[v] + xv[v];
                 }
@@ -544,6 +549,8 @@ extern "C" int tfgx_aggregate_gemm_f32(const tfgx_reduce_args* p, const float* B
     TFGX_REQUIRE(p->ldx >= (p->x_tail ? p->f_main : p->F) && p->ldx % 4 == 0 && aligned_to(p->x, 16) && ldb >= N && ldc >= N,
                  "bad leading dimension / alignment");
     TFGX_REQUIRE(!p->accumulate && !p->add_x && !p->track, "plain aggregation only (no accumulate / add_x / track)");
+    TFGX_REQUIRE(p->ldx < (int64_t(1) << 31) && p->ld_tail < (int64_t(1) << 31) && p->ld_edge_tail < (int64_t(1) << 31),
+                 "leading dimensions must be below 2^31 elements");
     if (p->x_tail) {      // split source rows (static feature layout): whole-line main rows + 16-byte aligned tails
         TFGX_REQUIRE(p->f_main >= 4 && p->f_main % 4 == 0 && p->f_main < p->F && p->ldx >= p->f_main && p->ld_tail >= p->F - p->f_main &&
                          p->ld_tail % 4 == 0 && aligned_to(p->x_tail, 16),
