@@ -21,6 +21,9 @@
 #include <cmath>
 #include <cstring>
 #include <type_traits>
+#ifndef TFGX_GAT_BWD_DPP_SUM
+#define TFGX_GAT_BWD_DPP_SUM 1        // developer A/B: 0 = the per-head <dO, V> reduction as a loop of ds_bpermute shuffles
+#endif
 #ifndef TFGX_GAT_BWD_POW2_SCALE
 #define TFGX_GAT_BWD_POW2_SCALE 1     // developer A/B: 0 = the attention backward always DIVIDES by scale
 #endif
@@ -801,11 +804,35 @@ __device__ __forceinline__ float dot_d(const float (&a)[D], const float* __restr
     return s;
 }
 
+// Sum of v over the lh lanes of a head (lh a power of two, the lanes aligned at a multiple of lh; lh == G for a single head).
+// Inside one DPP row (16 lanes) the steps are data-parallel-primitive adds — row_mirror, row_half_mirror, quad_perm [2,3,0,1],
+// quad_perm [1,0,3,2]: each pairs every lane with one of the other half of its 16 / 8 / 4 / 2 lanes — behind wave-uniform
+// branches instead of a loop: the loop form (ds_bpermute + s_waitcnt lgkmcnt(0) + branch per step, per edge) put an LDS round
+// trip into every edge's dependent chain and cut the four unrolled edges of a batch into separate basic blocks.
+template <int CTRL>
+__device__ __forceinline__ float dpp_lane_f32(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+
 template <int G>
 __device__ __forceinline__ float head_sum(float v, int lh)
 {
+#if TFGX_GAT_BWD_DPP_SUM
+    if constexpr (G > 16) {
+        for (int o = lh >> 1; o >= 16; o >>= 1) v += __shfl_xor(v, o, G);     // steps that cross DPP rows (one wide head)
+    }
+    // (wave-uniform branches, not selects: the kernel is bound by vector-ALU issue, and masked steps that add 0 cost three
+    //  instructions each — measured 10.45 against 10.10 ms for the shuffle loop at lh = 2)
+    if constexpr (G >= 16) { if (lh >= 16) v += dpp_lane_f32<0x140>(v); }
+    if constexpr (G >= 8) { if (lh >= 8) v += dpp_lane_f32<0x141>(v); }
+    if (lh >= 4) v += dpp_lane_f32<0x4E>(v);
+    if (lh >= 2) v += dpp_lane_f32<0xB1>(v);
+    return v;
+#else
     for (int o = lh >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, G);
     return v;
+#endif
 }
 
 // One pass that prepares the GAT source pass's packed destination rows (see tfgx_gat_backward_args.ld_stats_ml):
