@@ -662,3 +662,197 @@ def test_demo_gcn_products_shape_runs_the_static_layout_from_the_second_step(tfg
     assert log[-1]["auto_promotions"] == log[0]["auto_promotions"] + 1
     assert min(r["layer0_forward_ms"] for r in log[2:]) < log[0]["layer0_forward_ms"], log
     assert log[-1]["loss"] < log[0]["loss"]
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# BACKWARD at BASELINE.json's shapes ("the timed code must be the tested code").  bench.py times
+# forward + backward of the Reddit-shape GAT and of both products-shape GraphSAGE layers through routes a size POLICY picks
+# (source / destination blocks of the attention, the 512-column tracked max + mask build / apply, the fused aggregate ->
+# project training forward, hub chunks on R-MAT) — none of which a 3000-node gradient test reaches.  Here the WHOLE layer
+# runs forward + backward on the full graph with a dense random upstream gradient, and EVERY gradient (d/dx of all N rows,
+# every weight and bias) is held against float64 torch autograd over the reference's composition on the same full graph
+# (tests/f64_layers.py: edge-sized float64 intermediates walked in column / head chunks on the GPU).  Then the same layer is
+# run in the form bench.py times (layer 0: only the weights carry gradients) and must give the same weight gradients.
+# ----------------------------------------------------------------------------------------------------------------------
+GRAD_REPORT = []          # (what, worst |d| - tol |ref| in units of tol): printed with -s; kept for tools/fullsize_backward_report.py
+
+
+def _grad_check(got, ref, tol, what, scale="element"):
+    """|got - ref| <= tol * (S + |ref|) with S = 1 (conftest.assert_parity's band, element by element) or, for results that
+    are LONG float32 sums — a weight gradient sums one product per node (233 k ... 2.4 M terms), d/dx of a power-law hub
+    source sums one term per out-edge (up to 330 k) — S = 1 + the largest |ref| of the matrix ("matrix") / of the element's row
+    ("row"): the rounding error of a long sum scales with the magnitude of its terms, not with where the terms happen to
+    cancel, so an element whose true value is near zero cannot be held to 1e-5 of ITSELF."""
+    got, ref = got.detach().double(), ref.detach().double()
+    if scale == "matrix":
+        S = 1.0 + ref.abs().max()
+    elif scale == "row":
+        S = 1.0 + ref.abs().amax(dim=1, keepdim=True)
+    else:
+        S = torch.ones((), dtype=torch.float64, device=ref.device)
+    worst = float(((got - ref).abs() / (S + ref.abs())).max())
+    GRAD_REPORT.append((what, worst, float(ref.abs().max())))
+    print("  {:<72s} worst |d| / ({} + |ref|) = {:.3e}   max |ref| = {:.3e}   (tol {:.0e})".format(
+        what, {"element": "1", "row": "1 + max|ref_row|", "matrix": "1 + max|ref|"}[scale], worst, float(ref.abs().max()), tol))
+    assert bool(torch.isfinite(got).all()), what + ": non-finite values"
+    assert worst <= tol, "{}: parity violated, worst normalised error {:.3e} > {:.1e}".format(what, worst, tol)
+
+
+def _upstream(n, units, seed):
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    return torch.randn(n, units, generator=g, device="cuda")
+
+
+def _trainable_layer(tfg, cls, units, x, weights, **kw):
+    layer = getattr(tfg.layers, cls)(units, activation=tfg.relu, **kw)
+    layer._maybe_build([x])
+    layer.set_weights(**weights)
+    layer.trainable(True)
+    return layer
+
+
+def _run_backward(layer, inputs, cache, G, x_grad):
+    for t in layer.parameters():
+        t.grad = None
+    x = inputs[0].detach().clone().requires_grad_(x_grad)
+    out = layer([x] + list(inputs[1:]), cache=cache)
+    out.backward(G)
+    grads = {k: v.grad for k, v in layer.weights.items() if v is not None}
+    grads["x"] = x.grad
+    return out.detach(), grads
+
+
+# north_star's 1e-5 throughout; what it is relative to is _grad_check's `scale`
+_TOL = 1e-5
+
+
+@pytest.mark.parametrize("graph", ["uniform", "rmat"])
+@pytest.mark.parametrize("attention_units", [8, 64])
+def test_reddit_gat_backward_matches_float64_autograd(tfg, oracle, reddit, graph, attention_units):
+    """BASELINE configs[2]: GAT(64, num_heads=8, attention_units=8) (demo/demo_gat.py:22) and the A = 64 variant, one training
+    step's forward + backward on the 114 M-edge graph.  Uniform graph: the block policy must be the route (forward in source
+    blocks, dQ pass in source blocks, dK / dV pass in destination blocks); R-MAT graph of the same size: hub chunks and
+    degree-ordered walks in all three passes."""
+    import numpy as np
+    import f64_layers as R
+    from tf_geometric_amd import synthetic
+    from tf_geometric_amd.nn.conv import gat as G_
+    from tf_geometric_amd.plan import CsrPlan
+    r = reddit
+    n, f = r["n"], r["f"]
+    A, U, H = attention_units, 64, 8
+    if graph == "uniform":
+        ei = r["ei"]
+    else:
+        if attention_units != 8:
+            pytest.skip("R-MAT: the demo's literal layer only")
+        ei = synthetic.rmat_edges(n, synthetic.WORKLOADS["reddit"][1], 13, torch.device("cuda"))
+    rng = np.random.Generator(np.random.PCG64(140 + A))
+    ws = dict(query_kernel=oracle.glorot_uniform(rng, f, A), key_kernel=oracle.glorot_uniform(rng, f, A),
+              kernel=oracle.glorot_uniform(rng, f, U), query_bias=(rng.standard_normal(A) * 0.1).astype(np.float32),
+              key_bias=(rng.standard_normal(A) * 0.1).astype(np.float32), bias=(rng.standard_normal(U) * 0.1).astype(np.float32))
+    # input rows whose Q / K pre-activation sits on the ReLU kink are drawn again (f64_layers docstring)
+    x, redrawn = R.redraw_kink_rows(r["x"], [(ws["query_kernel"], ws["query_bias"]), (ws["key_kernel"], ws["key_bias"])])
+    ref_out, ref, Gup = R.gat_layer(x, ei, ws["query_kernel"], ws["query_bias"], ws["key_kernel"], ws["key_bias"], ws["kernel"],
+                                    ws["bias"], H, _upstream(n, U, seed=21))
+    print("  rows of x redrawn off the Q / K kink: {}; upstream entries zeroed at the output kink: {}".format(
+        redrawn, int((Gup == 0).sum())))
+    layer = _trainable_layer(tfg, "GAT", U, x, ws, attention_units=A, num_heads=H)
+    cache = {}
+    plan = CsrPlan.from_cache(ei, n, n, cache)
+    fw, bw = G_.SOURCE_BLOCK_STATS["launches"], G_.SOURCE_BLOCK_STATS.get("backward_launches", 0)
+    out, grads = _run_backward(layer, [x, ei], cache, Gup, x_grad=True)
+    if graph == "uniform":
+        kb = G_.source_block_count(plan, A, U)
+        assert kb >= 2 and G_.SOURCE_BLOCK_STATS["launches"] == fw + kb                       # forward in source blocks
+        assert G_.SOURCE_BLOCK_STATS["backward_launches"] >= bw + kb + 2                      # dQ in source blocks + dK / dV in destination blocks
+    else:
+        assert plan.hub_info() is not None and G_.SOURCE_BLOCK_STATS["launches"] == fw        # hub route, no blocks
+    tag = "Reddit-shape GAT A={} ({}) ".format(A, graph)
+    # forward over ALL 14.9 M outputs.  The sampled-row test above holds 400 rows to the plain 1e-5; over every row the tail of
+    # the float32 score error (d_head = 1: exp() of a product of two 602-term float32 dot products) reaches further, for ANY
+    # float32 evaluation — the reference's own formulation evaluated op for op in float32 is measured beside it
+    ref32 = R.gat_forward(x, ei, ws["query_kernel"], ws["query_bias"], ws["key_kernel"], ws["key_bias"], ws["kernel"],
+                          ws["bias"], H, dtype=torch.float32)
+    band = lambda t: ((t.double() - ref_out).abs() - 1e-5 * ref_out.abs())            # noqa: E731
+    ours, theirs = band(out), band(ref32)
+    print("  forward, all rows: worst beyond-band {:.2e} ({} of {} elements outside 1e-5); float32 op-for-op reference "
+          "formulation: {:.2e} ({} outside)".format(float(ours.max()), int((ours > 1e-5).sum()), ours.numel(),
+                                                    float(theirs.max()), int((theirs > 1e-5).sum())))
+    _grad_check(out, ref_out, 3e-5, tag + "forward, all rows")
+    assert int((ours > 1e-5).sum()) <= max(2 * int((theirs > 1e-5).sum()), 20)
+    del ref32, ours, theirs
+    # the same composition differentiated op for op in float32 (what a TF-CPU run computes), same upstream gradient
+    _, g32, _ = R.gat_layer(x, ei, ws["query_kernel"], ws["query_bias"], ws["key_kernel"], ws["key_bias"], ws["kernel"],
+                            ws["bias"], H, Gup, kink_margin=None, dtype=torch.float32)
+    rowscale = lambda t, r: float(((t.double() - r).abs() / (1.0 + r.abs().amax(1, keepdim=True) + r.abs())).max())   # noqa: E731
+    print("  d/dx, row-scaled error: ours {:.3e}; float32 op-for-op autograd of the reference formulation {:.3e}".format(
+        rowscale(grads["x"], ref["x"]), rowscale(g32["x"], ref["x"])))
+    del g32
+    _grad_check(grads["x"], ref["x"], _TOL, tag + "d/dx, all rows", scale="row")
+    for k in ws:
+        _grad_check(grads[k], ref[k], _TOL, tag + "d/d" + k, scale="matrix")
+    # the form bench.py times (configs.C3_*.fwd_bwd_ms): layer 0, x carries no gradient — same weight gradients, same bits
+    out0, grads0 = _run_backward(layer, [x, ei], cache, Gup, x_grad=False)
+    assert torch.equal(out0, out) and grads0["x"] is None
+    for k in ws:
+        assert torch.equal(grads0[k], grads[k]), k
+    del ref, ref_out
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("graph", ["uniform", "rmat"])
+@pytest.mark.parametrize("kind", ["GCN", "MeanGraphSage", "MaxPoolGraphSage"])
+def test_products_layers_backward_matches_float64_autograd(tfg, oracle, products, products_rmat, graph, kind):
+    """BASELINE configs[3] (products shape, units = 256, concat: demo/demo_graph_sage.py:29-30): GCN(256), MeanGraphSage(256),
+    MaxPoolGraphSage(256), forward + backward on the full 123 M-edge graph, uniform and R-MAT (hub rows: chunked transposed
+    aggregation, chunk-wise max counting), all gradients vs float64 autograd; then the layer-0 form bench.py times."""
+    import numpy as np
+    import f64_layers as R
+    from tf_geometric_amd import plan as P
+    p = products if graph == "uniform" else products_rmat
+    n, f, units = p["n"], p["f"], 256
+    ku = units // 2
+    rng = np.random.Generator(np.random.PCG64(160 + len(kind)))
+    cache = {"tfgx_csr_plan": p["plan"]}
+    G0 = _upstream(n, units, seed=22)
+    has = torch.ones(n, dtype=torch.bool, device="cuda")
+    if kind == "GCN":
+        ws = dict(kernel=oracle.glorot_uniform(rng, f, units), bias=(rng.standard_normal(units) * 0.1).astype(np.float32))
+        ref_out, ref, Gup = R.gcn_layer(p["x"], p["ei"], p["w"], ws["kernel"], ws["bias"], G0)
+    elif kind == "MeanGraphSage":
+        ws = dict(self_kernel=oracle.glorot_uniform(rng, f, ku), neighbor_kernel=oracle.glorot_uniform(rng, f, ku),
+                  bias=(rng.standard_normal(units) * 0.1).astype(np.float32))
+        ref_out, ref, Gup = R.mean_sage_layer(p["x"], p["ei"], p["w"], ws["self_kernel"], ws["neighbor_kernel"], ws["bias"], G0)
+    else:
+        ws = dict(self_kernel=oracle.glorot_uniform(rng, f, ku), mlp_kernel=oracle.glorot_uniform(rng, f, 4 * ku),
+                  mlp_bias=(rng.standard_normal(4 * ku) * 0.1).astype(np.float32),
+                  neighs_kernel=oracle.glorot_uniform(rng, 4 * ku, ku), bias=(rng.standard_normal(units) * 0.1).astype(np.float32))
+        ref_out, ref, Gup, ambiguous = R.max_pool_sage_layer(p["x"], p["ei"], ws["self_kernel"], ws["mlp_kernel"], ws["mlp_bias"],
+                                                             ws["neighs_kernel"], ws["bias"], G0)
+        has = p["plan"].in_degree() > 0
+        print("  rows without upstream gradient (no in-edges, or a pooling decision inside the float32 margin): {} of {}".format(
+            int(ambiguous.sum()), n))
+        assert int(ambiguous.sum()) < n // 2
+    del G0
+    torch.cuda.empty_cache()
+    layer = _trainable_layer(tfg, kind, units, p["x"], ws, **({} if kind == "GCN" else {"concat": True}))
+    fused = P.FUSED_STATS["launches"]
+    out, grads = _run_backward(layer, [p["x"], p["ei"], p["w"]], cache, Gup, x_grad=True)
+    if kind != "MaxPoolGraphSage":
+        assert P.FUSED_STATS["launches"] == fused + 1                  # the training forward took the fused aggregate -> project launch
+    tag = "products-shape {} ({}) ".format(kind, graph)
+    _grad_check(out[has], ref_out[has], _TOL, tag + "forward, all rows")
+    _grad_check(grads["x"], ref["x"], _TOL, tag + "d/dx, all rows", scale="row")
+    for k in ws:
+        _grad_check(grads[k], ref[k], _TOL, tag + "d/d" + k, scale="matrix")
+    # the form bench.py times (configs.C4_*.fwd_bwd_ms): x carries no gradient (ReLU masks applied inside the weight-gradient
+    # reductions, no transposed aggregation) — the same weight gradients within the same band
+    out0, grads0 = _run_backward(layer, [p["x"], p["ei"], p["w"]], cache, Gup, x_grad=False)
+    assert grads0["x"] is None
+    _grad_check(out0[has], ref_out[has], _TOL, tag + "forward (layer-0 form)")
+    for k in ws:
+        _grad_check(grads0[k], ref[k], _TOL, tag + "d/d{} (layer-0 form)".format(k), scale="matrix")
+    del ref, ref_out
+    torch.cuda.empty_cache()

@@ -267,8 +267,14 @@ __device__ __forceinline__ float head_dot(const float (&qreg)[D > 0 ? D : 1], co
 }
 
 // POW2: a.inv_scale is the exact inverse of a power-of-two scale (instantiated for d = 1, 4, 16, where sqrt(d) is one)
+#ifndef TFGX_GAT_D8_WAVES
+#define TFGX_GAT_D8_WAVES 5           // waves per SIMD the d_head = 8 walk is compiled for.  At 5 (96 VGPRs) the compiler spills ONE
+#endif                                // 64-bit kernel-invariant pointer: stored before the row loop, reloaded once per ROW in the state /
+                                      // output epilogue (ISA read: no scratch access inside the edge loops).  At 4 (98 VGPRs, no scratch) the
+                                      // Reddit-shape A = 64 attention runs 6.45 instead of 5.77 ms, the one-pass walk at products density
+                                      // 10.27 instead of 9.89 ms (same box, profiles/r06_gat_d8_waves.jsonl): the fifth wave is worth more
 template <int VEC, int G, int D, bool POW2 = false>
-__global__ __launch_bounds__(kBlock, (D > 0 && D <= 8) ? 5 : 1) void gat_fused_kernel(const GArgs a)
+__global__ __launch_bounds__(kBlock, (D > 0 && D <= 4) ? 5 : (D == 8 ? TFGX_GAT_D8_WAVES : 1)) void gat_fused_kernel(const GArgs a)
 {
     constexpr int ROWS_PER_BLOCK = kBlock / G;
 #ifndef TFGX_GAT_ONE_EXP
@@ -302,7 +308,17 @@ __global__ __launch_bounds__(kBlock, (D > 0 && D <= 8) ? 5 : 1) void gat_fused_k
 #pragma unroll
             for (int t = 0; t < D; ++t) qreg[t] = qp[t];
         }
-        float m = -FLT_MAX, l = 0.0f;
+        // `l` is the softmax denominator WITHOUT the running maximum's own term exp(0) = 1: sum over the OTHER edges of
+        // exp(score - m).  A peaked row (one score 15 above the rest) has l_full = 1.025: kept whole, every later term of
+        // ~5e-5 is rounded to the 1.2e-7 grid of [1, 2) IN THE SAME DIRECTION (a small positive term added to a value that
+        // sits on the grid) — 500 such additions left l_full 1.3e-5 off (measured, Reddit shape, d_head = 1; float32
+        // evaluated op for op: 2e-7), which is exactly the forward's 3.9e-5 tail and, through sum_e alpha_e != 1, 20 x
+        // that in dQ.  Without the 1 the sum lives on the grid of its own (small) magnitude; the 1 is added where the
+        // denominator is used.  l_full = l + (m > -FLT_MAX): m leaves -FLT_MAX exactly when a running maximum exists.
+        // Second level: a row whose runner-up is close to its maximum still holds l ~ 1 (measured: 6.6e-6 off), so the
+        // terms of one batch of G edges are summed in `ls` first and folded into l once per batch — the big accumulator
+        // takes deg / G additions instead of deg (one multiply per edge more: both levels shrink when the maximum moves).
+        float m = -FLT_MAX, l = 0.0f, ls = 0.0f;
         float acc[VEC];
 #pragma unroll
         for (int i = 0; i < VEC; ++i) acc[i] = 0.0f;
@@ -310,7 +326,9 @@ __global__ __launch_bounds__(kBlock, (D > 0 && D <= 8) ? 5 : 1) void gat_fused_k
             load_vec<VEC>(a.state_in_acc + part * a.W + coff, acc);
             m = a.state_in_ml[part * 2 * a.H + 2 * head];
             l = a.state_in_ml[part * 2 * a.H + 2 * head + 1];
+            l -= (m > -FLT_MAX) ? 1.0f : 0.0f;                        // stored whole (exact: 1 is a multiple of ulp(l_full))
         }
+        auto l_full = [&]() { return (l + ls) + ((m > -FLT_MAX) ? 1.0f : 0.0f); };
 
         auto step = [&](float sc, const float (&vv)[VEC], int64_t pos) {
 #if TFGX_GAT_ONE_EXP
@@ -324,12 +342,17 @@ __global__ __launch_bounds__(kBlock, (D > 0 && D <= 8) ? 5 : 1) void gat_fused_k
             const float corr = up ? ex : 1.0f + (m - m);
             const float p = up ? 1.0f + (sc - sc) : ex;
             const float mn = up ? sc : m;
+            // the denominator without the maximum's 1 (see above).  sc takes over: the old maximum becomes an ordinary term
+            // exp(m - sc) = ex and the others shrink by it, (l + 1) * ex = fmaf(l, ex, ex); otherwise l + ex — ONE expression
+            ls = fmaf(ls, corr, ex);
+            l *= corr;
 #else
             const float mn = fmaxf(m, sc);
             const float corr = expf(m - mn);
             const float p = expf(sc - mn);
+            ls = fmaf(ls, corr, sc > m ? corr : p);
+            l *= corr;
 #endif
-            l = fmaf(l, corr, p);
             const float pk = p * drop_scale(a.drop, uint32_t(pos * a.H + head));
 #pragma unroll
             for (int i = 0; i < VEC; ++i) acc[i] = fmaf(acc[i], corr, pk * vv[i]);
@@ -386,6 +409,8 @@ __global__ __launch_bounds__(kBlock, (D > 0 && D <= 8) ? 5 : 1) void gat_fused_k
                     load_vec<VEC>(a.v + row_off(c, ldv32) + coff, vv);
                     step(sc, vv, base + j);
                 }
+                l += ls;                 // fold the batch (see the declaration of l)
+                ls = 0.0f;
             }
         }
         if (a.state_acc) {      // raw state of this part; the self-loop edge is added by the merge
@@ -393,7 +418,7 @@ __global__ __launch_bounds__(kBlock, (D > 0 && D <= 8) ? 5 : 1) void gat_fused_k
                 store_vec<VEC>(a.state_acc + part * a.W + coff, acc);
                 if (coff % a.dv == 0) {
                     a.state_ml[part * 2 * a.H + 2 * head] = m;
-                    a.state_ml[part * 2 * a.H + 2 * head + 1] = l;
+                    a.state_ml[part * 2 * a.H + 2 * head + 1] = l_full();
                 }
             }
             r = idx;            // restore the loop variable
@@ -408,10 +433,10 @@ __global__ __launch_bounds__(kBlock, (D > 0 && D <= 8) ? 5 : 1) void gat_fused_k
         }
         if (a.stats_ml && cvalid && (coff % a.dv == 0)) {
             a.stats_ml[r * 2 * a.H + 2 * head] = m;
-            a.stats_ml[r * 2 * a.H + 2 * head + 1] = l;
+            a.stats_ml[r * 2 * a.H + 2 * head + 1] = l_full();
         }
         if (cvalid) {
-            const float den = l + 1e-8f;   // segment.py:30
+            const float den = l_full() + 1e-8f;   // segment.py:30
             float res[VEC];
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
