@@ -41,3 +41,23 @@ def test_ipc_mode_is_defaulted_where_the_multi_rank_paths_live():
             "print(os.environ['HSA_ENABLE_IPC_MODE_LEGACY']); print(t.ipc_mode_note())")
     out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, stdout=subprocess.PIPE, check=True).stdout.decode().splitlines()
     assert out[0] == "1" and "dmabuf" in out[1]
+
+
+def test_a_stale_error_lock_of_an_earlier_job_does_not_silence_the_watchdog(tmp_path):
+    """the rank that writes the error line is elected with an O_EXCL file.  Named after the launcher's pid alone, a
+    file left by an earlier job whose launcher had the same (recycled) pid made every rank of a later job stand back: exit 3
+    and NO line.  The name now carries the launcher's start time and the rendezvous port; a stale file of the old form, or of
+    another job, changes nothing."""
+    me = os.getpid()                                   # the launcher of the rank started below
+    stale = [tmp_path / "tfgx_bench_error_{}.lock".format(me), tmp_path / "tfgx_bench_error_{}_0_29400.lock".format(me)]
+    for p in stale:
+        p.write_text("")
+    env = {"TFGX_BENCH_TEST_HANG": "start", "TFGX_BENCH_WATCHDOG_S": "1", "RANK": "1", "LOCAL_RANK": "1", "WORLD_SIZE": "2",
+           "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29400", "TMPDIR": str(tmp_path)}
+    res = _run(["--workload", "tiny", "--gpus", "2"], env)
+    assert res.returncode == 3, (res.returncode, res.stderr.decode()[-2000:])
+    lines = res.stdout.decode().splitlines()
+    assert len(lines) == 1 and json.loads(lines[0])["reported_by_rank"] == 1
+    # the SAME job's second rank (same launcher, same port) finds the first one's file and stays quiet
+    res2 = _run(["--workload", "tiny", "--gpus", "2"], dict(env, RANK="0", LOCAL_RANK="0"))
+    assert res2.returncode == 3 and res2.stdout.decode().strip() == ""

@@ -97,3 +97,36 @@ def test_products_shaped_eight_rank_plumbing_run(tfg):
     assert [d["rank"] for d in ranks] == list(range(8)) and sum(d["edges"] for d in ranks) == cfg["edges"]
     assert max(d["edges"] for d in ranks) <= 1.05 * cfg["edges"] / 8           # edge-balanced destination ranges
     assert cfg["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_default_line_configs_carry_a_real_roof_each(tfg):
+    """The driver's default command (bounded here: fewer steps, no CPU legs, no R-MAT line): every BASELINE config sits in the
+    `configs` block with a `roofline` object against the resource that bounds it — HBM for the tables far beyond the caches
+    (C4, C5), the L2s for the source-blocked attention (C3, both attention widths), the Infinity Cache's probed line rate for
+    the arxiv-shaped table (C2) — and NO fraction anywhere in the line exceeds 1 (VERDICT r5 missing #4 / #5: a `frac` above 1
+    means the roof is wrong)."""
+    res = _run(["--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-rmat"], timeout=1200)
+    assert res.returncode == 0, res.stderr.decode()[-3000:]
+    line = _json_line(res)
+    cfgs = line["configs"]
+    want = {"C2_arxiv_gcn_2layer": "mall", "C3_reddit_gat_H8_A8": "l2", "C3_reddit_gat_H8_A64": "l2",
+            "C4_mean_sage_256_concat": "hbm", "C4_maxpool_sage_256_concat": "hbm", "C5_papers100M_one_shard_of_8": "hbm"}
+    for key, bound in want.items():
+        assert key in cfgs and "error" not in cfgs[key] and "skipped" not in cfgs[key], (key, cfgs.get(key))
+        r = cfgs[key]["roofline"]
+        assert r["bound"] == bound and r["peak"] and 0.0 < r["frac"] <= 1.0, (key, r)
+    fracs = []
+
+    def walk(node, path):
+        if isinstance(node, dict):
+            for k, v in node.items():
+                assert "frac_of_hbm_peak" not in k, path + "/" + k
+                if k.startswith("frac") and isinstance(v, (int, float)):
+                    fracs.append((path + "/" + k, v))
+                walk(v, path + "/" + k)
+        elif isinstance(node, list):
+            for i, v in enumerate(node):
+                walk(v, "{}[{}]".format(path, i))
+    walk(line, "")
+    assert fracs and all(0.0 <= v <= 1.0 for _, v in fracs), [f for f in fracs if not 0.0 <= f[1] <= 1.0]
+    assert cfgs["C3_reddit_gat_H8_A8"]["fwd_bwd_ms"] > cfgs["C3_reddit_gat_H8_A8"]["forward_ms"] > 0

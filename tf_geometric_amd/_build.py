@@ -47,6 +47,7 @@ def build(force=False, verbose=True):
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
     build_dist(force=force or bool(jobs), verbose=verbose)
+    build_line_rate_probe(force=force, verbose=verbose)
     build_c_abi_demo(force=force or bool(jobs), verbose=verbose)
     build_tf_shim_mock(force=force or bool(jobs), verbose=verbose)
     return LIB_PATH
@@ -79,6 +80,24 @@ def build_dist(force=False, verbose=True):
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
     return DIST_LIB
+
+
+PROBE_SRC = os.path.join(_HERE, "..", "tools", "line_rate_probe.cpp")
+PROBE_BIN = os.path.join(LIB_DIR, "line_rate_probe")
+
+
+def build_line_rate_probe(force=False, verbose=True):
+    """lib/line_rate_probe: the random-line-rate probe (tools/line_rate_probe.cpp — a measurement utility, no part of the
+    library).  bench.py runs it on the SAME box for the roofs of the cache-resident configs: random aligned spans served by
+    a table of the size the timed kernel gathers from (an L2-sized source block, an Infinity-Cache-sized feature table)."""
+    if not os.path.exists(PROBE_SRC):
+        return None
+    if force or _newer(PROBE_SRC, PROBE_BIN):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O3", PROBE_SRC, "-o", PROBE_BIN]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return PROBE_BIN
 
 
 DEMO_SRC = os.path.join(_HERE, "..", "examples", "c_abi_demo.cpp")

@@ -113,7 +113,8 @@ static void run(const float* table, int64_t table_bytes, int lines, bool aligned
 int main(int argc, char** argv)
 {
     const int64_t table_bytes = int64_t(argc > 1 ? std::atoll(argv[1]) : 4096) << 20;   // MiB, default 4 GiB
-    const int64_t n_spans = 64 << 20;
+    const bool quick = argc > 2 && std::strcmp(argv[2], "quick") == 0;    // bench.py: aligned spans only, a quarter of the spans
+    const int64_t n_spans = quick ? (16 << 20) : (64 << 20);
     float *table, *out;
     HIP_OK(hipMalloc(reinterpret_cast<void**>(&table), table_bytes));
     HIP_OK(hipMemset(table, 0, table_bytes));
@@ -130,7 +131,7 @@ int main(int argc, char** argv)
     HIP_OK(hipEventElapsedTime(&ms, e0, e1));
     std::printf("{\"probe\": \"sequential_read\", \"bytes\": %lld, \"ms\": %.4f, \"TBps\": %.3f, \"G_lines_per_s\": %.2f}\n",
                 (long long)table_bytes, ms / 5, table_bytes / (ms / 5) / 1e9, table_bytes / 128.0 / (ms / 5) / 1e6);
-    for (int aligned = 1; aligned >= 0; --aligned) {
+    for (int aligned = 1; aligned >= (quick ? 1 : 0); --aligned) {
         run<8>(table, table_bytes, 1, aligned, n_spans, out);
         run<16>(table, table_bytes, 2, aligned, n_spans, out);
         run<32>(table, table_bytes, 3, aligned, n_spans / 2, out);   // G = 32 lanes, lanes 24..31 re-read inside the span
