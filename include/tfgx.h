@@ -46,8 +46,9 @@ enum { TFGX_NORM_BOTH = 0, TFGX_NORM_LEFT = 1, TFGX_NORM_RIGHT = 2 };
 /* ABI version of this header: bumped whenever an entry point's signature or a struct's layout changes (a host built
  * against another value must refuse to run: tf_geometric_amd/_lib.py does).  100 = rounds 1-3; 110 = round 4
  * (tfgx_reduce_args.hub_order_slot; tfgx_aggregate_gemm_f32 honours args->out as a side output of the aggregate;
- * tfgx_gat_args / tfgx_gat_backward_args .drop_seed_dev); 111 = + tfgx_column_sum_f32; 112 = round 5 (+ tfgx_split_rows_verify_f32, tfgx_reduce_args.wide_blocks, tfgx_gat_args.state_in_*, tfgx_gat_backward_args.span_*). */
-#define TFGX_ABI_VERSION 112
+ * tfgx_gat_args / tfgx_gat_backward_args .drop_seed_dev); 111 = + tfgx_column_sum_f32; 112 = round 5 (+ tfgx_split_rows_verify_f32, tfgx_reduce_args.wide_blocks, tfgx_gat_args.state_in_*, tfgx_gat_backward_args.span_*);
+ * 113 = round 6 (+ tfgx_gat_backward_args.head_pack / ld_head_pack, tfgx_gat_pack_dst_heads_f32). */
+#define TFGX_ABI_VERSION 113
 int tfgx_version(void);            /* the TFGX_ABI_VERSION the library was built with */
 const char* tfgx_last_error(void); /* host string, thread-local, valid until the next failing call */
 
@@ -455,6 +456,14 @@ typedef struct tfgx_gat_backward_args {
     int64_t span_stride;
     int32_t accumulate;
     int32_t reserved3;
+    /* optional (round 6, ABI 113), src pass: the per-head scalars of every DESTINATION in one contiguous block per head,
+       head_pack[r * ld_head_pack + h * B + ...] = [ Q[r,h,0..d) | m | 1 / (l + 1e-8) | D | zero pad ], B = roundup4(d + 3)
+       floats (tfgx_gat_pack_dst_heads_f32 writes it behind dO in the packed table).  With it the pass issues, per edge and
+       lane, the dO load and B / 4 16-byte loads of that block — three line requests where q / stats_ml / dsum as separate
+       pointers cost five (the L2s serve ~145 G requests/s: the pass went 3.9 -> 2.9 ms at Reddit shape).  q / stats_ml /
+       dsum stay mandatory: the one-lane kernels of odd head geometries read them. */
+    const float* head_pack;
+    int64_t ld_head_pack;
 } tfgx_gat_backward_args;
 
 /* Prepares both backward passes in ONE sweep over the destination rows: dsum[r, h] = <dO[r, h, :], O[r, h, :]> (dense
@@ -463,6 +472,12 @@ typedef struct tfgx_gat_backward_args {
 int tfgx_gat_pack_dst_f32(const float* grad_out, int64_t ld_grad_out, const float* out, int64_t ldo, const float* q,
                           int64_t ldq, const float* stats_ml /* [n_dst, 2H] */, int64_t n_dst, int32_t H, int32_t d,
                           int32_t dv, float* pack, int64_t ld_pack, float* dsum /* [n_dst, H] */, tfgx_stream_t stream);
+/* the same sweep, head-block form: pack[r] = [ dO (H*dv) | pad to 4 floats | per head: Q (d), m, 1 / (l + 1e-8), D, pad to
+   roundup4(d + 3) ] with ld_pack >= roundup4(H*dv) + H*roundup4(d + 3); grad_out = pack, head_pack = pack + roundup4(H*dv), both
+   with row stride ld_pack (a multiple of 4, pack 16-byte aligned), is what tfgx_gat_backward_args.head_pack expects. */
+int tfgx_gat_pack_dst_heads_f32(const float* grad_out, int64_t ld_grad_out, const float* out, int64_t ldo, const float* q,
+                                int64_t ldq, const float* stats_ml /* [n_dst, 2H] */, int64_t n_dst, int32_t H, int32_t d,
+                                int32_t dv, float* pack, int64_t ld_pack, float* dsum /* [n_dst, H] */, tfgx_stream_t stream);
 int tfgx_gat_backward_dst_f32(const tfgx_gat_backward_args* args /* host */, tfgx_stream_t stream);
 int tfgx_gat_backward_src_f32(const tfgx_gat_backward_args* args /* host */, tfgx_stream_t stream);
 /* the same passes on a graph with hub rows: `hub` = chunk lists of the forward plan (dst pass) / of the transposed plan

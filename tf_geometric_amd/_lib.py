@@ -26,7 +26,7 @@ class TfgxError(RuntimeError):
     pass
 
 
-ABI_VERSION = 112      # include/tfgx.h TFGX_ABI_VERSION: struct layouts / signatures bound below
+ABI_VERSION = 113      # include/tfgx.h TFGX_ABI_VERSION: struct layouts / signatures bound below
 
 
 class ReduceArgs(ctypes.Structure):
@@ -133,6 +133,7 @@ class GatBackwardArgs(ctypes.Structure):
         ("drop_seed_dev", ctypes.c_void_p),
         ("span_begin", ctypes.c_void_p), ("span_end", ctypes.c_void_p), ("span_stride", ctypes.c_int64),
         ("accumulate", ctypes.c_int32), ("reserved3", ctypes.c_int32),
+        ("head_pack", ctypes.c_void_p), ("ld_head_pack", ctypes.c_int64),
     ]
 
 
@@ -169,6 +170,7 @@ SIGNATURES = {
     "tfgx_dropout_keep": (ctypes.c_int32, [ctypes.c_uint64, ctypes.c_uint32, _F32]),
     "tfgx_permute_rows_f32": (ctypes.c_int, [_P, _P, _I64, _I64, _P, _P]),
     "tfgx_gat_pack_dst_f32": (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _I64, _P, _P]),
+    "tfgx_gat_pack_dst_heads_f32": (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _I64, _P, _P]),
     "tfgx_relu_backward_f32": (ctypes.c_int, [_P, _I64, _P, _I64, _I64, _I64, _P, _I64, _P]),
     "tfgx_scatter_add_rows_f32": (ctypes.c_int, [_P, _I64, _P, _I64, _I64, _P, _I64, _P]),
     "tfgx_segment_reduce_f32": (ctypes.c_int, [ctypes.POINTER(ReduceArgs), _P]),

@@ -584,6 +584,58 @@ def linear(x, kernel, bias=None, act=L.ACT_NONE, gathered=False):
     return _Linear.apply(x, L.as_f32(kernel), None if bias is None else L.as_f32(bias), act, gathered)
 
 
+class _ProjectQKV(torch.autograd.Function):
+    """Q = act(x Wq + bq), K = act(x Wk + bk), V = x W (nn/conv/gat.py:52-70) as ONE differentiable operator: the forward reads
+    x twice ([Q | K] in one GEMM when they share the activation, V in a second one with its gather-friendly stride), the
+    backward ONCE — the masked dQ, dK and dV are laid side by side in one [n, 2A + U] matrix D, so that all three weight
+    gradients and both bias gradients come from one reduction over x (x^T D) and d/dx from one GEMM (D [Wq | Wk | W]^T).
+    Three separate linear layers read the 561 MB Reddit-shaped x six times per training step; this reads it three times."""
+
+    @staticmethod
+    def forward(ctx, x, wq, bq, wk, bk, wv, act):
+        n, A, U = int(x.shape[0]), int(wq.shape[1]), int(wv.shape[1])
+        xd = x.detach()
+        w_qk = torch.cat([wq.detach(), wk.detach()], dim=1).contiguous()
+        b_qk = None if bq is None else torch.cat([bq.detach().reshape(-1), bk.detach().reshape(-1)])
+        qk = gemm_bias_act(xd, w_qk, bias=b_qk, act=act)
+        V = gemm_bias_act(xd, wv.detach(), out=gather_friendly_empty(n, U, x.device))
+        # K rows narrower than a 128-byte line are gathered per edge: inside [Q | K] a line holds half as many of them
+        # (nn/conv/gat._project_qkv); a copy of [n, A] floats costs ~10 us
+        K = qk[:, A:].contiguous() if A <= 16 else qk[:, A:]
+        ctx.act, ctx.A = act, A
+        ctx.save_for_backward(x, wq, wk, wv, bq, qk if act == L.ACT_RELU else None)
+        return qk[:, :A], K, V
+
+    @staticmethod
+    def backward(ctx, gQ, gK, gV):
+        x, wq, wk, wv, bq, qk = ctx.saved_tensors
+        A, U, n = ctx.A, int(wv.shape[1]), int(x.shape[0])
+        need = ctx.needs_input_grad
+        D = torch.empty((n, 2 * A + U), dtype=torch.float32, device=x.device)
+        if ctx.act == L.ACT_RELU:
+            relu_backward(gQ, qk[:, :A], into=D[:, :A])
+            relu_backward(gK, qk[:, A:], into=D[:, A:2 * A])
+        else:
+            D[:, :A] = gQ
+            D[:, A:2 * A] = gK
+        D[:, 2 * A:] = gV
+        gwq = gwk = gwv = gbq = gbk = gx = None
+        if need[1] or need[2] or need[3] or need[4] or need[5]:
+            gW, gb = gemm_tn(x.detach(), D, want_bias=bq is not None and (need[2] or need[4]))
+            gwq, gwk, gwv = gW[:, :A], gW[:, A:2 * A], gW[:, 2 * A:]
+            if gb is not None:
+                gbq, gbk = gb[:A], gb[A:2 * A]
+        if need[0]:
+            gx = gemm_bias_act(D, transpose(torch.cat([wq.detach(), wk.detach(), wv.detach()], dim=1)))
+        return gx, gwq, gbq, gwk, gbk, gwv, None
+
+
+def project_qkv(x, wq, bq, wk, bk, wv, act):
+    """Differentiable (Q, K, V) of a GAT layer on dense features; Q and K share the (fused-code) activation `act`."""
+    f = L.as_f32
+    return _ProjectQKV.apply(x, f(wq), None if bq is None else f(bq), f(wk), None if bk is None else f(bk), f(wv), act)
+
+
 class _GatAttention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, plan, num_heads, Q, K, V, drop_rate, drop_seed, scale_d=None, passes=None):
@@ -616,13 +668,18 @@ class _GatAttention(torch.autograd.Function):
         # one sweep over the destination rows: D = <dO, O> per head AND the packed rows the source pass gathers — per
         # edge it needs the DESTINATION's dO, Q, (m, l) and D; interleaved into one row per destination, padded to whole
         # 128-byte lines, that is one burst of P*4 bytes per edge instead of four gathers (H=8, A=8, U=64: 96 floats =
-        # 3 lines instead of 5)
-        P = -(-(W + A + 3 * H) // 32) * 32
+        # 3 lines instead of 5).  Round 6: behind dO the row holds ONE block per head, [Q | m | 1 / (l + 1e-8) | D | pad] in
+        # roundup4(d + 3) floats — every lane of a head then fetches its scalars with 16-byte loads of the same bytes: three
+        # line REQUESTS per edge instead of five (tfgx_gat_backward_args.head_pack)
+        HB = -(-(A // H + 3) // 4) * 4
+        W4 = -(-W // 4) * 4                                      # the head blocks start on a 16-byte boundary of the row
+        P = -(-(W4 + H * HB) // 32) * 32
         pack = torch.empty((n, P), dtype=torch.float32, device=g2.device)
         dsum = torch.empty((n, H), dtype=torch.float32, device=g2.device)
         out2, ldo = L.row_major_2d(out)
-        L.check(lib.tfgx_gat_pack_dst_f32(L.ptr(g2), ldg, L.ptr(out2), ldo, L.ptr(Q2), ldq, L.ptr(stats), n, H, A // H,
-                                          W // H, L.ptr(pack), P, L.ptr(dsum), L.stream_ptr()), "tfgx_gat_pack_dst_f32")
+        L.check(lib.tfgx_gat_pack_dst_heads_f32(L.ptr(g2), ldg, L.ptr(out2), ldo, L.ptr(Q2), ldq, L.ptr(stats), n, H, A // H,
+                                                W // H, L.ptr(pack), P, L.ptr(dsum), L.stream_ptr()),
+                "tfgx_gat_pack_dst_heads_f32")
         pt, t2d = _transposed(plan)
         # dense outputs (K2 / V2 may be column slices of a wider table — the sharded [K | V] halo table)
         dev = g2.device
@@ -663,6 +720,7 @@ class _GatAttention(torch.autograd.Function):
         # dense graphs: both passes in chained launches over the blocks of the OTHER endpoint (nn/conv/gat.source_block_count:
         # each launch gathers rows of one block, served by the L2 of every XCD; gradients accumulate block by block)
         from .nn.conv.gat import source_block_count, SOURCE_BLOCK_STATS
+        from .nn.conv import gat as G_
         d_h, dv_h = A // H, W // H
         blocks_ok = (ctx.drop[0] <= 0.0 and hf is None and hub_d is None and ro is None and ro_t is None and
                      d_h in (1, 2, 4, 8, 16, 32) and dv_h % 4 == 0 and dv_h // 4 <= 64 and
@@ -683,10 +741,8 @@ class _GatAttention(torch.autograd.Function):
         else:
             L.check(lib.tfgx_gat_backward_dst_hub_f32(ctypes.byref(a), None if hub_d is None else ctypes.byref(hub_d),
                                                       L.ptr(sc_d), L.stream_ptr()), "tfgx_gat_backward_dst_hub_f32")
-        a.grad_out, a.ld_grad_out = pack.data_ptr(), P
-        a.q, a.ldq = pack.data_ptr() + 4 * W, P
-        a.stats_ml, a.ld_stats_ml = pack.data_ptr() + 4 * (W + A), P
-        a.dsum, a.ld_dsum = pack.data_ptr() + 4 * (W + A + 2 * H), P
+        a.grad_out, a.ld_grad_out = pack.data_ptr(), P            # dO out of the packed rows; Q / (m, l) / D stay the dense arrays
+        a.head_pack, a.ld_head_pack = pack.data_ptr() + 4 * W4, P  # (read by the one-lane kernels of odd head geometries only)
         hub_s, nc_s = L.hub_lists(pt)
         sc_s = torch.empty(max(nc_s * (A + W), 1), dtype=torch.float32, device=dev) if hub_s is not None else None
         if hf is not None and hub_s is None and 0 < hf[0] < n_tab:
@@ -712,6 +768,8 @@ class _GatAttention(torch.autograd.Function):
         else:
             # the source pass gathers the packed DESTINATION rows (P floats each): blocks of destinations
             kb_s = source_block_count(pt, P, 0) if (blocks_ok and hub_s is None and gv.stride(0) % 4 == 0) else 1
+            if kb_s >= 2 and G_.DESTINATION_BLOCKS is not None:
+                kb_s = max(int(G_.DESTINATION_BLOCKS), 1)       # developer A/B (tools/r06/sweep_gat_bwd_blocks.py)
             blk_s = pt.source_blocks(kb_s) if kb_s >= 2 else None
             if blk_s is not None:
                 rpk_t, dst_k = blk_s

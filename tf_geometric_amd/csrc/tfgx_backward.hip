@@ -704,7 +704,11 @@ struct GB {
     float* gv; int64_t ldgv;
     DropCfg drop;                    // the forward's attention dropout (keep mask regenerated from the edge position)
     const int32_t* pos;              // src pass: forward-CSR position of each transposed position (NULL: identity)
+    const float* hp; int64_t ldhp;   // src pass, optional: per destination r and head h ONE block of roundup4(d + 3) floats
+                                     // [Q[r,h,0..d) | m | 1 / (l + 1e-8) | D | pad] at hp[r * ldhp + h * block] (tfgx_gat_pack_dst_heads_f32)
 };
+
+constexpr int head_block(int d) { return (d + 3 + 3) / 4 * 4; }
 
 // keep_scale_or_0 of edge (position p of this pass, destination r when it is the appended self-loop) for head h
 __device__ __forceinline__ float edge_keep(const GB& a, int64_t p, bool self_loop, int64_t r, int h)
@@ -835,6 +839,45 @@ __device__ __forceinline__ float head_sum(float v, int lh)
 #endif
 }
 
+// the same sum for U values at once: the wave-uniform branches are taken once per BATCH of edges instead of once per edge
+// (ISA of the source pass, round 6: four branch blocks per edge, every one a v_cndmask / v_cmp / s_andn2 / s_cbranch group —
+// a quarter of the walk's instructions)
+template <int G, int U>
+__device__ __forceinline__ void head_sum_batch(float (&v)[U], int lh)
+{
+#if TFGX_GAT_BWD_DPP_SUM
+    if constexpr (G > 16) {
+        for (int o = lh >> 1; o >= 16; o >>= 1) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] += __shfl_xor(v[u], o, G);
+        }
+    }
+    if constexpr (G >= 16) {
+        if (lh >= 16) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] += dpp_lane_f32<0x140>(v[u]);
+        }
+    }
+    if constexpr (G >= 8) {
+        if (lh >= 8) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] += dpp_lane_f32<0x141>(v[u]);
+        }
+    }
+    if (lh >= 4) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] += dpp_lane_f32<0x4E>(v[u]);
+    }
+    if (lh >= 2) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] += dpp_lane_f32<0xB1>(v[u]);
+    }
+#else
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = head_sum<G>(v[u], lh);
+#endif
+}
+
 // One pass that prepares the GAT source pass's packed destination rows (see tfgx_gat_backward_args.ld_stats_ml):
 //   pack[r] = [ dO[r, 0..W) | Q[r, 0..A) | (m, l)[r, 0..2H) | D[r, 0..H) ],  D[r, h] = <dO[r, h, :], O[r, h, :]>
 // and the dense dsum[r, h] the destination pass reads.  Replaces a reduction and four strided copies.
@@ -912,8 +955,50 @@ __global__ __launch_bounds__(kBlock) void gat_pack_dst_vec4_kernel(const float* 
     }
 }
 
+// The head-block form of the packed table (round 6): pack[r] = [ dO[r, 0..W) | pad to 4 floats | per head h: Q[r,h,0..d), m, 1/(l + 1e-8), D, pad ].
+// The source pass of round 5 read, per edge and lane group, dO (one 16-byte load per lane) and Q / (m, l) / D as THREE more
+// load instructions that all fall into the row's last 128-byte line: five line requests per edge where three lines are
+// touched — and the pass ran at 143 G requests/s, the rate at which the L2s serve requests, not lines.  With a head's scalars
+// contiguous, every lane of the head loads the same 16 (d = 1) ... 48 bytes with dwordx4 loads: three requests per edge.
+// One thread per 4 floats of the row; D = <dO, O> is summed per head first (one lane per head, dv sequential terms: the pass is
+// 0.1 ms of a 10 ms step).
+__global__ __launch_bounds__(kBlock) void gat_pack_dst_heads_kernel(const float* __restrict__ go, int64_t ldgo,
+                                                                    const float* __restrict__ o, int64_t ldo,
+                                                                    const float* __restrict__ q, int64_t ldq,
+                                                                    const float* __restrict__ ml, int64_t n, int H, int d, int dv,
+                                                                    float* __restrict__ pack, int64_t P,
+                                                                    float* __restrict__ dsum)
+{
+    const int W = H * dv, hb = head_block(d);
+    const int per_row = (W + 3) / 4 + H;                 // copies of dO in fours, then one work item per head
+    int64_t t = blockIdx.x * int64_t(kBlock) + threadIdx.x;
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    for (; t < n * per_row; t += stride) {
+        const int64_t r = t / per_row;
+        const int k = int(t - r * per_row);
+        float* pr = pack + r * P;
+        if (k < (W + 3) / 4) {
+            for (int c = 4 * k; c < 4 * k + 4 && c < W; ++c) pr[c] = go[r * ldgo + c];
+        } else {
+            const int h = k - (W + 3) / 4;
+            const float* gp = go + r * ldgo + h * dv;
+            const float* op = o + r * ldo + h * dv;
+            float acc = 0.0f;
+            for (int i = 0; i < dv; ++i) acc = fmaf(gp[i], op[i], acc);
+            dsum[r * H + h] = acc;
+            float* hp = pr + (W + 3) / 4 * 4 + h * hb;        // the head blocks start on a 16-byte boundary of the row
+            for (int u = 0; u < d; ++u) hp[u] = q[r * ldq + h * d + u];
+            hp[d] = ml[r * 2 * H + 2 * h];
+            hp[d + 1] = 1.0f / (ml[r * 2 * H + 2 * h + 1] + 1e-8f);
+            hp[d + 2] = acc;
+            for (int u = d + 3; u < hb; ++u) hp[u] = 0.0f;
+        }
+    }
+}
+
 // POW2: a.inv_scale is the exact inverse of a power-of-two scale (instantiated for d = 1, 4, 16, where sqrt(d) is one)
-template <int G, int D, bool SRC, bool POW2 = false>
+// HP (src pass only): the per-head scalars of the gathered destination come from a.hp (head blocks, see above)
+template <int G, int D, bool SRC, bool POW2 = false, bool HP = false>
 __global__ __launch_bounds__(kBlock) void gat_backward_fast_kernel(const GB a)
 {
     constexpr int VEC = 4;
@@ -963,8 +1048,24 @@ __global__ __launch_bounds__(kBlock) void gat_backward_fast_kernel(const GB a)
         // compiler emulate a 64 x 64-bit product per address (see gat_fused_kernel)
         const uint32_t ld_qk32 = uint32_t(SRC ? a.ldq : a.ldk), ld_v32 = uint32_t(SRC ? a.ldgo : a.ldv);
         const uint32_t ldml32 = uint32_t(a.ldml), lddsum32 = uint32_t(a.lddsum);
+        const uint32_t ldhp32 = uint32_t(a.ldhp);
         auto edge_load = [&](int o_, EdgeIn& in) {   // o: the other endpoint (source c / destination r)
             const uint64_t o = uint64_t(uint32_t(o_));
+            if constexpr (SRC && HP) {
+                // the head's block [Q | m | 1 / (l + 1e-8) | D | pad]: 16-byte loads, the same bytes for every lane of the head
+                constexpr int HB = head_block(D);
+                float hb[HB];
+                const float* ph = a.hp + o * ldhp32 + head * HB;
+#pragma unroll
+                for (int t = 0; t < HB; t += 4) load_vec<4>(ph + t, *reinterpret_cast<float (*)[4]>(&hb[t]));
+#pragma unroll
+                for (int t = 0; t < D; ++t) in.qk[t] = hb[t];
+                in.m = hb[D];
+                in.l = hb[D + 1];          // already the reciprocal
+                in.dd = hb[D + 2];
+                load_vec<VEC>(a.go + o * ld_v32 + coff, in.v);
+                return;
+            }
             const float* pq = (SRC ? a.q : a.k) + o * ld_qk32 + head * a.d;
 #pragma unroll
             for (int t = 0; t < D; ++t) in.qk[t] = pq[t];
@@ -978,18 +1079,24 @@ __global__ __launch_bounds__(kBlock) void gat_backward_fast_kernel(const GB a)
         // pow2 (std::bool_constant<POW2>): the score and ds are divided by the scale with a multiply by its exact inverse — a
         // template parameter of the kernel, so that no branch sits between a batch's gathers and no second copy of the walk
         // costs registers
-        auto edge_apply = [&](const EdgeIn& in, float keep, auto pow2) {
-            float sc = 0.0f;
+        // an edge's arithmetic in three steps, so that a batch can run the step in the middle — the sum of <dO, V> over the lanes
+        // of a head, and the dropout mask — once for all its edges (head_sum_batch)
+        auto edge_scores = [&](const EdgeIn& in, float& sc, float& part, auto pow2) {
+            sc = 0.0f;
 #pragma unroll
             for (int t = 0; t < D; ++t) sc = fmaf(mine_qk[t], in.qk[t], sc);
             if constexpr (decltype(pow2)::value) sc = sc * a.inv_scale;
             else sc = sc / a.scale;
-            float part = 0.0f;
+            part = 0.0f;
 #pragma unroll
             for (int i = 0; i < VEC; ++i) part = fmaf(mine_v[i], in.v[i], part);   // <dO, V> over this lane's columns
-            const float da = head_sum<G>(cvalid ? part : 0.0f, lh);
+            part = cvalid ? part : 0.0f;
+        };
+        auto edge_finish = [&](const EdgeIn& in, float sc, float da, float keep, auto pow2) {
             const float m = SRC ? in.m : m_r;
-            const float linv = SRC ? 1.0f / (in.l + 1e-8f) : linv_r;
+            // 1 / (l + 1e-8): the destination pass divides once per row; per EDGE (source pass) the correctly rounded division
+            // is ten instructions of a walk bound by vector-ALU issue — v_rcp_f32 (1 ulp) there
+            const float linv = SRC ? (HP ? in.l : __builtin_amdgcn_rcpf(in.l + 1e-8f)) : linv_r;
             const float dd = SRC ? in.dd : d_r;
             const float alpha = expf(sc - m) * linv;
             float ds = alpha * (keep * da - dd);
@@ -1006,7 +1113,9 @@ __global__ __launch_bounds__(kBlock) void gat_backward_fast_kernel(const GB a)
         auto edge = [&](int o, float keep, auto pow2) {
             EdgeIn in;
             edge_load(o, in);
-            edge_apply(in, keep, pow2);
+            float sc, part;
+            edge_scores(in, sc, part, pow2);
+            edge_finish(in, sc, head_sum<G>(part, lh), keep, pow2);
         };
 #ifndef TFGX_GAT_BWD_UNROLL_NARROW
 #define TFGX_GAT_BWD_UNROLL_NARROW 4  // developer A/B
@@ -1036,9 +1145,19 @@ __global__ __launch_bounds__(kBlock) void gat_backward_fast_kernel(const GB a)
                     EdgeIn in[U];
 #pragma unroll
                     for (int u = 0; u < U; ++u) edge_load(__shfl(oj, j + u, G), in[u]);
+                    float sc[U], da[U], keep[U];
 #pragma unroll
-                    for (int u = 0; u < U; ++u)
-                        edge_apply(in[u], drop_scale(a.drop, uint32_t(int64_t(__shfl(pj, j + u, G)) * a.H + head)), pow2);
+                    for (int u = 0; u < U; ++u) edge_scores(in[u], sc[u], da[u], pow2);
+                    head_sum_batch<G, U>(da, lh);
+                    if (a.drop.thr != 0u) {        // wave-uniform: ONE branch per batch, nothing of the mask otherwise
+#pragma unroll
+                        for (int u = 0; u < U; ++u) keep[u] = drop_scale(a.drop, uint32_t(int64_t(__shfl(pj, j + u, G)) * a.H + head));
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < U; ++u) keep[u] = 1.0f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) edge_finish(in[u], sc[u], da[u], keep[u], pow2);
                 }
                 for (; j < cnt; ++j)
                     edge(__shfl(oj, j, G), drop_scale(a.drop, uint32_t(int64_t(__shfl(pj, j, G)) * a.H + head)), pow2);
@@ -1074,6 +1193,26 @@ int launch_gat_bwd_d(const GB& a, hipStream_t stream)
     const int W = a.H * a.dv;
     dim3 grid(grid_for(a.n, ROWS_PER_BLOCK, 1 << 20), (W + G * 4 - 1) / (G * 4), 1), block(kBlock, 1, 1);
     const bool pow2 = a.inv_scale != 0.0f;      // only d = 1, 4, 16 have the multiply instantiated; every other d divides
+    if constexpr (SRC) {
+        if (a.hp != nullptr) {      // head blocks (tfgx_gat_pack_dst_heads_f32): 16-byte aligned by the entry point's checks
+            switch (a.d) {
+#define TFGX_GAT_BWD_HP_CASE(D_)                                                                       \
+    case D_:                                                                                         \
+        if (pow2) gat_backward_fast_kernel<G, D_, true, true, true><<<grid, block, 0, stream>>>(a);   \
+        else gat_backward_fast_kernel<G, D_, true, false, true><<<grid, block, 0, stream>>>(a);       \
+        break
+                TFGX_GAT_BWD_HP_CASE(1);
+                case 2: gat_backward_fast_kernel<G, 2, true, false, true><<<grid, block, 0, stream>>>(a); break;
+                TFGX_GAT_BWD_HP_CASE(4);
+                case 8: gat_backward_fast_kernel<G, 8, true, false, true><<<grid, block, 0, stream>>>(a); break;
+                TFGX_GAT_BWD_HP_CASE(16);
+#undef TFGX_GAT_BWD_HP_CASE
+                default: gat_backward_fast_kernel<G, 32, true, false, true><<<grid, block, 0, stream>>>(a); break;
+            }
+            TFGX_LAUNCH_CHECK("gat_backward_fast_kernel (head blocks)");
+            return TFGX_OK;
+        }
+    }
     switch (a.d) {
 #define TFGX_GAT_BWD_POW2_CASE(D_)                                                                   \
     case D_:                                                                                         \
@@ -1445,6 +1584,33 @@ static int fill_gb(const tfgx_gat_backward_args* p, GB& a)
     TFGX_REQUIRE(p->drop_rate >= 0.0f && p->drop_rate < 1.0f, "drop_rate outside [0, 1)");
     a.drop = make_drop(p->drop_rate, p->drop_seed, p->drop_self_base, p->drop_seed_dev);
     a.pos = nullptr;
+    a.hp = nullptr; a.ldhp = 0;
+    if (p->head_pack != nullptr) {
+        const int64_t need = int64_t(p->H) * head_block(p->d);
+        TFGX_REQUIRE(p->ld_head_pack >= need && p->ld_head_pack % 4 == 0 && aligned_to(p->head_pack, 16) &&
+                     p->ld_head_pack < (int64_t(1) << 31),
+                     "head_pack: rows of H * roundup4(d + 3) floats, 16-byte aligned, row stride a multiple of 4 below 2^31");
+        a.hp = p->head_pack; a.ldhp = p->ld_head_pack;
+    }
+    return TFGX_OK;
+}
+
+extern "C" int tfgx_gat_pack_dst_heads_f32(const float* grad_out, int64_t ld_grad_out, const float* out, int64_t ldo,
+                                           const float* q, int64_t ldq, const float* stats_ml, int64_t n_dst, int32_t H,
+                                           int32_t d, int32_t dv, float* pack, int64_t ld_pack, float* dsum,
+                                           tfgx_stream_t stream)
+{
+    TFGX_RANGE();
+    TFGX_REQUIRE(n_dst >= 0 && H >= 1 && d >= 1 && dv >= 1, "bad size");
+    const int64_t W = int64_t(H) * dv, A = int64_t(H) * d;
+    TFGX_REQUIRE(ld_grad_out >= W && ldo >= W && ldq >= A && ld_pack >= (W + 3) / 4 * 4 + int64_t(H) * head_block(d),
+                 "leading dimension too small (ld_pack >= roundup4(H * dv) + H * roundup4(d + 3))");
+    if (n_dst == 0) return TFGX_OK;
+    TFGX_REQUIRE(grad_out && out && q && stats_ml && pack && dsum, "null pointer");
+    const int per_row = int((W + 3) / 4) + H;
+    gat_pack_dst_heads_kernel<<<grid_for(n_dst * per_row, kBlock), kBlock, 0, as_stream(stream)>>>(
+        grad_out, ld_grad_out, out, ldo, q, ldq, stats_ml, n_dst, H, d, dv, pack, ld_pack, dsum);
+    TFGX_LAUNCH_CHECK("gat_pack_dst_heads_kernel");
     return TFGX_OK;
 }
 

@@ -143,6 +143,7 @@ SOURCE_BLOCK_MIN_EDGES = 32           # 10 / 12 / 14 / 16 / 20 / 24 -> 4.14 / 3.
                                       # optimum was KB = 8 while the kernel was bound by its own vector-ALU work); and at least this
                                       # many edges per (row, block) on average
 SOURCE_BLOCK_STATS = {"launches": 0}  # diagnostics (tests assert the route taken)
+DESTINATION_BLOCKS = None             # developer A/B: the number of destination blocks of the backward's source pass (None = the policy)
 
 
 def source_block_count(plan, A, W):
@@ -276,8 +277,15 @@ def _gat_train(x, plan, wq, bq, qact, wk, bk, kact, kernel, bias, activation, nu
         if xs is not None:
             return AG.apply_activation(sparse_dense_matmul(xs, w, bias=b, act=code), L.ACT_NONE, post)
         return AG.apply_activation(AG.linear(x, w, b, code), L.ACT_NONE, post)
-    Q, K, V = lin(wq, bq, qact), lin(wk, bk, kact), (sparse_dense_matmul(xs, kernel) if xs is not None
-                                                      else AG.linear(x, kernel, gathered=True))
+    qa, qpost = _resolve_act(qact)
+    ka, kpost = _resolve_act(kact)
+    if (xs is None and qa == ka and qpost is None and kpost is None and (bq is None) == (bk is None)
+            and int(wq.shape[1]) == int(wk.shape[1])):
+        # one operator for the three projections: x is read twice in the forward and ONCE in the backward (autograd._ProjectQKV)
+        Q, K, V = AG.project_qkv(x, wq, bq, wk, bk, kernel, qa)
+    else:
+        Q, K, V = lin(wq, bq, qact), lin(wk, bk, kact), (sparse_dense_matmul(xs, kernel) if xs is not None
+                                                          else AG.linear(x, kernel, gathered=True))
     d, dv = int(Q.shape[1]) // num_heads, int(V.shape[1]) // num_heads
     d2, dv2 = _kernel_widths(d, dv, num_heads)
     seed = new_drop_seed(V.device) if drop_rate > 0.0 else 0
