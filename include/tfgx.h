@@ -47,7 +47,8 @@ enum { TFGX_NORM_BOTH = 0, TFGX_NORM_LEFT = 1, TFGX_NORM_RIGHT = 2 };
  * against another value must refuse to run: tf_geometric_amd/_lib.py does).  100 = rounds 1-3; 110 = round 4
  * (tfgx_reduce_args.hub_order_slot; tfgx_aggregate_gemm_f32 honours args->out as a side output of the aggregate;
  * tfgx_gat_args / tfgx_gat_backward_args .drop_seed_dev); 111 = + tfgx_column_sum_f32; 112 = round 5 (+ tfgx_split_rows_verify_f32, tfgx_reduce_args.wide_blocks, tfgx_gat_args.state_in_*, tfgx_gat_backward_args.span_*);
- * 113 = round 6 (+ tfgx_gat_backward_args.head_pack / ld_head_pack, tfgx_gat_pack_dst_heads_f32). */
+ * 113 = round 6 (+ tfgx_gat_backward_args.head_pack / ld_head_pack, tfgx_gat_pack_dst_heads_f32,
+ * tfgx_pool_mlp_max_wgrad_*). */
 #define TFGX_ABI_VERSION 113
 int tfgx_version(void);            /* the TFGX_ABI_VERSION the library was built with */
 const char* tfgx_last_error(void); /* host string, thread-local, valid until the next failing call */
@@ -389,6 +390,24 @@ int tfgx_segment_max_backward_f32(const int32_t* row_ptr_t, const int32_t* dst_t
                                   const float* g, int64_t ldg, const float* count, int64_t ldc, float* gx, int64_t ldgx,
                                   int64_t n_dst, float* gn_scratch /* [n_dst, F] workspace or NULL (slow path) */,
                                   tfgx_stream_t stream);
+
+/* Max-pool GraphSAGE, layer 0 (round 6, ABI 113): the weight / bias gradient of the pooling MLP h = relu(x W + b) under
+   red[r, :] = max over in-edges of h[col, :] (tf_geometric/nn/conv/graph_sage.py:260-269) WITHOUT materialising dh:
+       dW[k, j] = sum_r [red[r, j] > 0] g[r, j] / count[r, j] * x[w, k] summed over the sources w that attain the maximum,
+       db[j]    = the same with x = 1
+   destination-major: the x rows of a destination's in-edges are staged in LDS once (the forward's own gather) and every
+   (feature, column) accumulator is a register of one thread for the whole launch — deterministic, no atomics.  `packed` is the
+   tracked forward's (count << 16 | position) array (tfgx_reduce_args.track), `h` is read only where a maximum is tied.
+   Replaces tfgx_segment_max_backward_mask_f32 + the ReLU-mask pass + tfgx_gemm_tn_f32 when NO gradient w.r.t. x is wanted.
+   Shapes: F_in a multiple of 4 in [4, 124], Fp in {128, 256, 512} (tfgx_pool_mlp_max_wgrad_applies), rows shorter than 65536
+   edges (the packed format's bound). */
+int tfgx_pool_mlp_max_wgrad_applies(int64_t F_in, int64_t Fp);
+size_t tfgx_pool_mlp_max_wgrad_workspace_bytes(int64_t n_dst, int64_t F_in, int64_t Fp);
+int tfgx_pool_mlp_max_wgrad_f32(const int32_t* row_ptr, const int32_t* col, int64_t n_dst, const float* x, int64_t ldx,
+                                int64_t F_in, const float* h, int64_t ldh, const float* red, int64_t ldr,
+                                const int32_t* packed, int64_t ldp, const float* g, int64_t ldg, int64_t Fp, float* dW,
+                                int64_t lddw, float* db /* [Fp] or NULL */, void* workspace, size_t workspace_bytes,
+                                tfgx_stream_t stream);
 
 /* Chunk lists of the rows of a plan that are too long for one lane group ("hubs" of a power-law graph), as the host
    builds them once per plan (the same lists tfgx_reduce_args / tfgx_gat_args carry for the forward): rows with more

@@ -940,3 +940,65 @@ def test_column_sums_kernel(tfg, m, n):
     ref = x.double().sum(0)
     scale = max(1.0, float(m) ** 0.5)
     assert float((got.double() - ref).abs().max()) <= 2e-6 * scale * max(1.0, float(x.abs().max()) if m else 1.0)
+
+
+@pytest.mark.parametrize("f_in,units,n,e,long_rows", [(100, 256, 3000, 150000, False), (4, 64, 500, 6000, True),
+                                                      (124, 128, 800, 30000, True), (36, 256, 700, 9000, False)])
+def test_pool_mlp_max_weight_gradient_from_destination_rows(tfg, oracle, f_in, units, n, e, long_rows):
+    """MaxPoolGraphSage, layer-0 form (x carries no gradient): the MLP + max operator whose backward goes from the destination
+    rows straight to dW / db (tfgx_pool_mlp_max_wgrad_f32) against (i) the composed form (winner masks -> dh -> ReLU mask ->
+    x^T dh) and (ii) float64 autograd with TensorFlow's tie rule.  Quantised features and duplicated edges (tied maxima between
+    DIFFERENT sources and between copies of one edge), rows without in-edges, rows longer than the 96-edge LDS chunk."""
+    from tf_geometric_amd import _lib as L, autograd as AG
+    rng = np.random.Generator(np.random.PCG64(f_in + units))
+    ei = oracle.synthetic_edges(n, e, seed=f_in)
+    ei = ei[:, ei[0] != 7]                                              # row 7: no in-edges
+    ei = np.concatenate([ei, ei[:, :e // 8]], axis=1)                   # duplicated edges
+    if long_rows:
+        extra = np.stack([np.full(700, 5, np.int32), rng.integers(0, n, 700).astype(np.int32)])
+        ei = np.concatenate([ei, extra, np.stack([np.full(97, 11, np.int32), rng.integers(0, n, 97).astype(np.int32)])], axis=1)
+    x = (np.round(rng.standard_normal((n, f_in)) * 2) / 2).astype(np.float32)          # quantised: exact ties between sources
+    w1 = np.ones(ei.shape[1], np.float32)
+    ku = units // 2
+    ws = dict(self_kernel=oracle.glorot_uniform(rng, f_in, ku),
+              mlp_kernel=(np.round(oracle.glorot_uniform(rng, f_in, 4 * ku) * 8) / 8).astype(np.float32),
+              mlp_bias=(np.round(rng.standard_normal(4 * ku)) * 0.25).astype(np.float32),
+              neighs_kernel=oracle.glorot_uniform(rng, 4 * ku, ku), bias=(rng.standard_normal(units) * 0.1).astype(np.float32))
+    gout = torch.tensor(rng.standard_normal((n, units)).astype(np.float32), device="cuda")
+    gout[7] = 0.0                        # the row without in-edges pools float32 lowest: no gradient through its overflow
+
+    def run(fused):
+        AG.POOL_MLP_MAX_FUSED = fused
+        try:
+            layer = tfg.layers.MaxPoolGraphSage(units, activation=tfg.relu, concat=True)
+            layer._maybe_build([x])
+            layer.set_weights(**ws)
+            layer.trainable(True)
+            out = layer([L.as_f32(x), ei, w1], cache={})
+            out.backward(gout)
+            return out.detach(), {k: v.grad.clone() for k, v in layer.weights.items()}
+        finally:
+            AG.POOL_MLP_MAX_FUSED = True
+    lib = L.require_gpu()
+    assert lib.tfgx_pool_mlp_max_wgrad_applies(f_in, 4 * ku)
+    out_f, g_f = run(True)
+    out_c, g_c = run(False)
+    assert torch.equal(out_f, out_c)
+    for k in ws:
+        scale = float(g_c[k].abs().max()) + 1.0
+        assert float((g_f[k] - g_c[k]).abs().max()) <= 2e-5 * scale, k
+    # float64 autograd, ties shared evenly (math_grad._UnsortedSegmentMinOrMaxGrad)
+    row, col = torch.from_numpy(ei[0]).long(), torch.from_numpy(ei[1]).long()
+    t = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in ws.items()}
+    xr = torch.tensor(x, dtype=torch.float64)
+    h = torch.relu(xr @ t["mlp_kernel"] + t["mlp_bias"])
+    red = torch.full((n, 4 * ku), -3.4028234663852886e38, dtype=torch.float64).scatter_reduce(
+        0, row[:, None].expand(-1, 4 * ku), h[col], "amax", include_self=True)
+    ref = torch.relu(torch.cat([xr @ t["self_kernel"], red @ t["neighs_kernel"]], dim=1) + t["bias"])
+    keep = torch.ones(n, dtype=torch.bool)
+    keep[7] = False
+    ref.backward(gout.double().cpu())
+    assert_parity(out_f[keep].cpu().numpy(), ref.detach()[keep].numpy(), what="max-pool layer forward")
+    for k in ("mlp_kernel", "mlp_bias"):
+        scale = float(t[k].grad.abs().max()) + 1.0
+        assert float((g_f[k].double().cpu() - t[k].grad).abs().max()) <= 2e-5 * scale, k

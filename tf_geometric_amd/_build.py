@@ -11,7 +11,7 @@ LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libtfgx.so")
 OBJ_DIR = os.path.join(LIB_DIR, "obj")
 SOURCES = ["tfgx_plan.hip", "tfgx_reduce.hip", "tfgx_norm.hip", "tfgx_attn.hip", "tfgx_gemm.hip", "tfgx_misc.hip", "tfgx_backward.hip",
-           "tfgx_topk.hip", "tfgx_fused.hip"]
+           "tfgx_topk.hip", "tfgx_fused.hip", "tfgx_poolgrad.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + \
     os.environ.get("TFGX_EXTRA_HIPCC_FLAGS", "").split()      # developer A/B switches (e.g. -DTFGX_PREFETCH_INDEX=0)

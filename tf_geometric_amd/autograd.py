@@ -432,6 +432,82 @@ class _AggregateMax(torch.autograd.Function):
         return None, gx, gw, None
 
 
+POOL_MLP_MAX_FUSED = _os.environ.get("TFGX_POOL_MLP_MAX_FUSED", "1") != "0"     # developer A/B
+
+
+def pool_mlp_max_applies(plan, x, kernel):
+    """Can the pooling MLP + max of max-pool GraphSAGE run as autograd._PoolMlpMax with the destination-major weight
+    gradient (tfgx_pool_mlp_max_wgrad_f32)?  Dense float32 features that carry NO gradient (layer 0 of a model), shapes the
+    kernel is instantiated for, and a plan whose rows the tracked forward can take."""
+    if not POOL_MLP_MAX_FUSED or not isinstance(x, torch.Tensor) or x.requires_grad or not torch.is_grad_enabled():
+        return False
+    lib = L.require_gpu()
+    F_in, Fp = int(x.shape[1]), int(kernel.shape[1])
+    if not lib.tfgx_pool_mlp_max_wgrad_applies(F_in, Fp):
+        return False
+    x2, ldx = L.row_major_2d(x)
+    if ldx % 4 != 0 or x2.data_ptr() % 16 != 0 or plan.n_dst != plan.n_src:
+        return False
+    from .plan import gather_friendly_ld
+    return _max_mode() == "mask" and can_track(plan, _FutureRows(Fp), gather_friendly_ld(Fp))
+
+
+class _FutureRows(object):
+    """What plan.can_track looks at, for the [n, F] hidden rows that do not exist yet: their width and (torch's allocations are
+    256-byte aligned) an aligned address."""
+
+    def __init__(self, F):
+        self.shape = (0, F)
+
+    def data_ptr(self):
+        return 0
+
+
+class _PoolMlpMax(torch.autograd.Function):
+    """red = max over in-edges of relu(x W + b)[col] — the pooling MLP and the max of max-pool GraphSAGE
+    (nn/conv/graph_sage.py:260-269) as ONE operator for features that carry no gradient.  Forward: the MFMA GEMM (bias + ReLU
+    in its epilogue, rows at the gather-friendly stride) and the tracked max.  Backward: dW, db straight from the destination
+    rows (tfgx_pool_mlp_max_wgrad_f32) — the gradient of the hidden rows, the per-edge winner masks, the ReLU-mask pass and the
+    reduction x^T dh of the composed form are never computed."""
+
+    @staticmethod
+    def forward(ctx, plan, x, kernel, bias):
+        n, Fp = int(x.shape[0]), int(kernel.shape[1])
+        h = gemm_bias_act(x.detach(), kernel.detach(), bias=None if bias is None else bias.detach(), act=L.ACT_RELU,
+                          out=gather_friendly_empty(n, Fp, x.device))
+        red = torch.empty((plan.n_dst, Fp), dtype=torch.float32, device=x.device)
+        packed = torch.empty((plan.n_dst, Fp), dtype=torch.int32, device=x.device)
+        segment_reduce(plan, h, L.MAX, out=red, track=packed)
+        ctx.plan = plan
+        ctx.save_for_backward(x, h, red, packed, bias)
+        return red
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = L.require_gpu()
+        plan = ctx.plan
+        x, h, red, packed, bias = ctx.saved_tensors
+        x2, ldx = L.row_major_2d(x.detach())
+        h2, ldh = L.row_major_2d(h)
+        g2, ldg = L.row_major_2d(g.contiguous())
+        F_in, Fp = int(x2.shape[1]), int(h2.shape[1])
+        dW = torch.empty((F_in, Fp), dtype=torch.float32, device=x2.device)
+        db = torch.empty(Fp, dtype=torch.float32, device=x2.device) if bias is not None else None
+        ws_bytes = lib.tfgx_pool_mlp_max_wgrad_workspace_bytes(plan.n_dst, F_in, Fp)
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=x2.device)
+        L.check(lib.tfgx_pool_mlp_max_wgrad_f32(L.ptr(plan.row_ptr), L.ptr(plan.col), plan.n_dst, L.ptr(x2), ldx, F_in,
+                                                L.ptr(h2), ldh, L.ptr(red), Fp, L.ptr(packed), Fp, L.ptr(g2), ldg, Fp,
+                                                L.ptr(dW), Fp, L.ptr(db), L.ptr(ws), ws_bytes, L.stream_ptr()),
+                "tfgx_pool_mlp_max_wgrad_f32")
+        need = ctx.needs_input_grad
+        return None, None, (dW if need[2] else None), (db if (bias is not None and need[3]) else None)
+
+
+def pool_mlp_max(plan, x, kernel, bias):
+    """max over in-edges of relu(x @ kernel + bias)[col]; differentiable w.r.t. kernel and bias only (ask pool_mlp_max_applies)."""
+    return _PoolMlpMax.apply(plan, L.as_f32(x), L.as_f32(kernel), None if bias is None else L.as_f32(bias))
+
+
 def aggregate(plan, x, op, w_csr=None, self_coef=None, rows=None, bias=None, act=L.ACT_NONE, max_passes=None):
     """Differentiable gather-scale-segment-reduce (sum / mean / max) on `plan`; sum / mean take the layer's bias and
     ReLU in the kernel epilogue (bias: a tensor that may require grad)."""

@@ -1,0 +1,325 @@
+// Weight gradient of the max-pool GraphSAGE aggregator's MLP WITHOUT the gradient of its hidden rows (round 6).
+//
+//   reference (nn/conv/graph_sage.py:228-287):  h = relu(x W_mlp + b_mlp)  [N, Fp];  red[r, j] = max_{e: row_e = r} h[col_e, j]
+//   layer 0 of a model (x is data: no d/dx wanted) needs, of this part,
+//       dW_mlp[k, j] = sum_c x[c, k] dh[c, j] [h[c, j] > 0],   db_mlp[j] = sum_c dh[c, j] [h[c, j] > 0],
+//       dh[c, j]     = sum_{r: c wins (r, j)} g[r, j] / count[r, j]            (tf.math.unsorted_segment_max's registered gradient)
+//   The composition materialises dh [N, Fp]: per-edge winner masks (E x Fp bits), a source-major gather of ~N Fp scattered
+//   4-byte elements (one 128-byte line request each: 1.23 G requests at products shape, 24.8 ms), a ReLU-mask pass and the
+//   reduction x^T dh — 39.8 of the layer's 94 ms.  Exchanging the sums,
+//       dW_mlp[:, j] = sum_r  gn[r, j] * x[w(r, j), :],   gn = [red > 0] g / count,  w(r, j) = the source that attains the maximum,
+//   the sum runs DESTINATION-major: a workgroup stages the x rows of a destination's in-edges in LDS (the forward's own gather:
+//   one 400-byte burst per edge) and every (column, feature) accumulator lives in a register of ONE thread for the whole
+//   launch — no atomics, a fixed summation order, one partial [F_in + 1, Fp] per workgroup folded by a second kernel.
+//
+//   pool_wgrad_kernel     one workgroup per CU, ONE THREAD PER COLUMN j, its F_in + 1 accumulators dW[0..F_in, j] (feature F_in is
+//                         the constant 1: db) in registers.  The thread fetches its own (position, gn) pair straight from the
+//                         tracked forward's packed (count << 16 | position) array — no broadcast of anything — and reads the
+//                         winner's staged row X[p_j][0..F_in] from LDS with immediate offsets: 2 instructions per multiply-add.
+//                         (ds_read_b128: 256 bytes per clock).  Rows are staged XS = KMAX + 4 floats apart with XS / 4 ODD: the 16
+//                         lanes one LDS cycle serves read different rows at the same features, and p -> p XS / 4 mod 16 is a
+//                         bijection, so up to 16 distinct winners sit in distinct bank groups (equal winners are a broadcast).  Per (row, chunk of <= 96 edges) the x rows of the NEXT chunk are in flight
+//                         (ids one chunk further ahead) while this one is consumed.  A column with tied maxima walks the chunk
+//                         exactly (every tied edge receives g / count)
+//   pool_wgrad_reduce     dW / db = the workgroups' partials added in workgroup order
+#include "tfgx_common.h"
+
+namespace tfgx {
+namespace {
+
+#ifndef TFGX_POOL_EXPERIMENT
+#define TFGX_POOL_EXPERIMENT 0      // developer A/B, TIMING ONLY (wrong results): 1 = no LDS reads / FMAs, 2 = no gather of x rows
+#endif
+constexpr int kPoolChunk = 96;      // edges staged at a time, at most (products shape: in-degree 51 +- 7)
+constexpr int kPoolSlots = 4;       // 16-byte loads per thread and chunk: a chunk holds min(96, 4 * threads / (F_in / 4)) edges
+
+struct PoolArgs {
+    const int32_t* row_ptr;
+    const int32_t* col;
+    int64_t n_dst;
+    const float* x; int64_t ldx; int32_t F_in;
+    const float* h; int64_t ldh;
+    const float* red; int64_t ldr;
+    const int32_t* packed; int64_t ldp;
+    const float* g; int64_t ldg;
+    int32_t Fp;
+    float* partial;          // [gridDim.x, F_in + 1, Fp]
+    int64_t rows_per_block;
+};
+
+typedef float float2v __attribute__((ext_vector_type(2)));
+constexpr int kPoolRpTile = 8192;   // rows whose row_ptr entries sit in LDS at a time (the item bookkeeping never waits for HBM)
+
+template <int KMAX>       // accumulators per thread: F_in + 1 <= KMAX
+__global__ __launch_bounds__(512, 1) void pool_wgrad_kernel(const PoolArgs a)
+{
+    constexpr int XS = KMAX + 4;                 // floats between staged rows: 16-byte aligned, XS / 4 ODD (KMAX % 8 == 0) — see the header
+    static_assert(KMAX % 8 == 0, "KMAX must be a multiple of 8");
+    extern __shared__ float smem[];
+    float* const Xs = smem;                                                   // [2][kPoolChunk][XS]
+    int* const Cs = reinterpret_cast<int*>(smem + 2 * kPoolChunk * XS);       // [2][kPoolChunk] source ids of the staged rows
+    int* const Rp = Cs + 2 * kPoolChunk;                                      // [kPoolRpTile + 1] row_ptr of the current row tile
+    const int tid = threadIdx.x, nthr = blockDim.x;                           // nthr == Fp: thread tid owns column tid
+    const int j = tid;
+    const int Q4 = a.F_in / 4;                      // 16-byte pieces per x row
+    const int CH = min(kPoolChunk, (kPoolSlots * nthr) / Q4);                // edges per chunk: every piece has a slot
+    const int64_t blk_begin = int64_t(blockIdx.x) * a.rows_per_block;
+    const int64_t blk_end = min(a.n_dst, blk_begin + a.rows_per_block);
+
+    float2v acc[KMAX / 2];                       // pairs of accumulators: v_pk_fma_f32 does two multiply-adds per issue slot
+#pragma unroll
+    for (int k = 0; k < KMAX / 2; ++k) acc[k] = float2v{0.0f, 0.0f};
+
+    // slot u of this thread: piece q (16 bytes) of edge e of the chunk
+    int slot_e[kPoolSlots];
+#pragma unroll
+    for (int u = 0; u < kPoolSlots; ++u) slot_e[u] = (tid + u * nthr) / Q4;
+    auto slot_q = [&](int u) { return tid + u * nthr - slot_e[u] * Q4; };
+
+    for (int64_t r_begin = blk_begin; r_begin < blk_end; r_begin += kPoolRpTile) {
+        const int64_t r_end = min(blk_end, r_begin + kPoolRpTile);
+        __syncthreads();
+        for (int i = tid; i <= int(r_end - r_begin); i += nthr) Rp[i] = a.row_ptr[r_begin + i];
+        __syncthreads();
+        // a work item: edges [s, s + len) of row `row`, the chunk starting `off` edges into the row; row == r_end: none left
+        struct Item { int64_t row; int s; int len; int off; };
+        auto first_item = [&](int64_t r) {
+            Item it;
+            for (; r < r_end; ++r) {
+                const int s = __builtin_amdgcn_readfirstlane(Rp[r - r_begin]), e = __builtin_amdgcn_readfirstlane(Rp[r - r_begin + 1]);
+                if (e > s) { it.row = r; it.s = s; it.len = min(e - s, CH); it.off = 0; return it; }
+            }
+            it.row = r_end; it.s = 0; it.len = 0; it.off = 0;
+            return it;
+        };
+        auto next_item = [&](const Item& cur) {
+            if (cur.row >= r_end) return cur;
+            const int e = __builtin_amdgcn_readfirstlane(Rp[cur.row - r_begin + 1]);
+            if (cur.s + cur.len < e) {
+                Item it;
+                it.row = cur.row; it.s = cur.s + cur.len; it.len = min(e - it.s, CH); it.off = cur.off + cur.len;
+                return it;
+            }
+            return first_item(cur.row + 1);
+        };
+        auto load_ids = [&](const Item& it, int (&ids)[kPoolSlots]) {
+#pragma unroll
+            for (int u = 0; u < kPoolSlots; ++u) ids[u] = (slot_e[u] < it.len) ? a.col[it.s + slot_e[u]] : 0;
+        };
+        auto load_x = [&](const Item& it, const int (&ids)[kPoolSlots], float4 (&xv)[kPoolSlots]) {
+#pragma unroll
+            for (int u = 0; u < kPoolSlots; ++u) {
+                xv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (slot_e[u] < it.len && TFGX_POOL_EXPERIMENT != 2)
+                    xv[u] = *reinterpret_cast<const float4*>(a.x + uint64_t(uint32_t(ids[u])) * uint64_t(a.ldx) + 4 * slot_q(u));
+            }
+        };
+        auto commit = [&](const Item& it, int buf, const int (&ids)[kPoolSlots], const float4 (&xv)[kPoolSlots]) {
+            float* Xb = Xs + buf * kPoolChunk * XS;
+            int* Cb = Cs + buf * kPoolChunk;
+#pragma unroll
+            for (int u = 0; u < kPoolSlots; ++u) {
+                if (slot_e[u] < it.len) {
+                    *reinterpret_cast<float4*>(Xb + slot_e[u] * XS + 4 * slot_q(u)) = xv[u];
+                    if (slot_q(u) == 0) {
+                        Cb[slot_e[u]] = ids[u];
+                        Xb[slot_e[u] * XS + a.F_in] = 1.0f;               // the constant feature: its accumulator is the bias gradient
+                    }
+                }
+            }
+        };
+        // (position of the winner inside its row, gn) of this thread's column for row r, straight from the tracked forward's
+        // packed array: gn = g where the maximum is unique and positive (ReLU under the max: a maximum of 0 passes nothing); a
+        // tied maximum (count > 1) is walked exactly below (pos = -1, gn = g / count)
+        struct Pair { int pos; float gn; float rv; };
+        auto load_pair = [&](const Item& it) {
+            Pair o;
+            o.pos = 0; o.gn = 0.0f; o.rv = 0.0f;
+            if (it.row < r_end) {
+                const uint32_t pk = uint32_t(a.packed[it.row * a.ldp + j]);
+                const float rv = a.red[it.row * a.ldr + j];
+                const float gv = a.g[it.row * a.ldg + j];
+                const uint32_t cnt = pk >> 16;
+                if (cnt > 0u && rv > 0.0f) {
+                    if (cnt == 1u) { o.pos = int(pk & 0xFFFFu); o.gn = gv; }
+                    else { o.pos = -1; o.gn = gv / float(cnt); o.rv = rv; }
+                }
+            }
+            return o;
+        };
+
+        // software pipeline, two chunks deep: while chunk i is consumed from LDS, the x rows of chunk i + 1 are in registers
+        // (loaded during chunk i - 1, written to the other buffer after the compute) and those of chunk i + 2 are in flight;
+        // the source ids run one chunk further ahead still.  (Three register bundles trading roles in a loop unrolled by three —
+        // no register rotation at the end of a step — measured SLOWER: 28.5 vs 25.8 ms at products shape.)
+        Item it0 = first_item(r_begin);
+        Item it1 = next_item(it0);
+        Item it2 = next_item(it1);
+        int ids1[kPoolSlots], ids2[kPoolSlots], ids3[kPoolSlots];
+        float4 x1[kPoolSlots], x2[kPoolSlots];
+        {
+            int ids0[kPoolSlots];
+            float4 x0[kPoolSlots];
+            load_ids(it0, ids0);
+            load_ids(it1, ids1);
+            load_ids(it2, ids2);
+            load_x(it0, ids0, x0);
+            load_x(it1, ids1, x1);
+            commit(it0, 0, ids0, x0);
+        }
+        Pair pr = load_pair(it0);
+        __syncthreads();
+        int buf = 0;
+        while (it0.row < r_end) {
+            const Item it3 = next_item(it2);
+            load_x(it2, ids2, x2);              // two chunks ahead
+            load_ids(it3, ids3);
+            const Pair pr_n = load_pair(it1);
+            {
+                const float* Xb = Xs + buf * kPoolChunk * XS;
+                const int rel = pr.pos - it0.off;
+                const bool in = pr.pos >= 0 && uint32_t(rel) < uint32_t(it0.len);       // the winner is staged in this chunk
+                const float gv = in ? pr.gn : 0.0f;
+                const float2v g2 = {gv, gv};
+                const float* xr = Xb + (in ? rel : 0) * XS;
+#pragma unroll
+                for (int k = 0; k < (TFGX_POOL_EXPERIMENT == 1 ? 4 : KMAX); k += 4) {      // ds_read_b128 (immediate offsets), 2 x v_pk_fma_f32
+                    const float4 v = *reinterpret_cast<const float4*>(xr + k);
+                    const float2v lo = {v.x, v.y}, hi = {v.z, v.w};
+                    acc[k / 2] = __builtin_elementwise_fma(g2, lo, acc[k / 2]);
+                    acc[k / 2 + 1] = __builtin_elementwise_fma(g2, hi, acc[k / 2 + 1]);
+                }
+                if (pr.pos < 0) {
+                    // tied maximum in this column: every edge of the chunk that attains it receives g / count (duplicate edges,
+                    // exact ties of quantised features); the hidden rows are consulted, as the mask form does
+                    const int* Cb = Cs + buf * kPoolChunk;
+                    const float2v t2 = {pr.gn, pr.gn};
+                    for (int i = 0; i < it0.len; ++i) {
+                        if (a.h[int64_t(Cb[i]) * a.ldh + j] == pr.rv) {
+                            const float* xt = Xb + i * XS;
+#pragma unroll
+                            for (int k = 0; k < KMAX; k += 2) {
+                                const float2v v = {xt[k], xt[k + 1]};
+                                acc[k / 2] = __builtin_elementwise_fma(t2, v, acc[k / 2]);
+                            }
+                        }
+                    }
+                }
+            }
+            commit(it1, buf ^ 1, ids1, x1);
+            __syncthreads();
+            buf ^= 1;
+            it0 = it1; it1 = it2; it2 = it3;
+            pr = pr_n;
+#pragma unroll
+            for (int u = 0; u < kPoolSlots; ++u) { ids1[u] = ids2[u]; ids2[u] = ids3[u]; x1[u] = x2[u]; }
+        }
+    }
+    float* out = a.partial + int64_t(blockIdx.x) * (a.F_in + 1) * a.Fp;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+        if (k <= a.F_in) out[int64_t(k) * a.Fp + j] = (k & 1) ? acc[k / 2].y : acc[k / 2].x;
+}
+
+__global__ __launch_bounds__(kBlock) void pool_wgrad_reduce_kernel(const float* __restrict__ partial, int n_blocks, int F_in,
+                                                                   int Fp, float* __restrict__ dW, int64_t lddw,
+                                                                   float* __restrict__ db)
+{
+    const int64_t total = int64_t(F_in + 1) * Fp;
+    int64_t t = blockIdx.x * int64_t(kBlock) + threadIdx.x;
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    for (; t < total; t += stride) {
+        float s = 0.0f;
+        for (int b = 0; b < n_blocks; ++b) s += partial[int64_t(b) * total + t];
+        const int k = int(t / Fp), j = int(t - int64_t(k) * Fp);
+        if (k < F_in) dW[int64_t(k) * lddw + j] = s;
+        else if (db != nullptr) db[j] = s;
+    }
+}
+
+int pool_grid()
+{
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
+inline size_t pool_lds_bytes(int kmax)
+{
+    return size_t(2) * kPoolChunk * size_t(kmax + 4) * sizeof(float) + size_t(2) * kPoolChunk * sizeof(int) + size_t(kPoolRpTile + 1) * sizeof(int);
+}
+
+inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
+
+}  // namespace
+}  // namespace tfgx
+
+using namespace tfgx;
+
+extern "C" int tfgx_pool_mlp_max_wgrad_applies(int64_t F_in, int64_t Fp)
+{
+    return (F_in % 4 == 0 && F_in >= 4 && F_in <= 124 && (Fp == 128 || Fp == 256 || Fp == 512)) ? 1 : 0;
+}
+
+extern "C" size_t tfgx_pool_mlp_max_wgrad_workspace_bytes(int64_t n_dst, int64_t F_in, int64_t Fp)
+{
+    if (n_dst < 0 || F_in < 1 || Fp < 1) return 0;
+    (void)n_dst;
+    return align256(size_t(1024) * size_t(F_in + 1) * size_t(Fp) * sizeof(float));      // partials of up to 1024 workgroups
+}
+
+extern "C" int tfgx_pool_mlp_max_wgrad_f32(const int32_t* row_ptr, const int32_t* col, int64_t n_dst, const float* x,
+                                           int64_t ldx, int64_t F_in, const float* h, int64_t ldh, const float* red,
+                                           int64_t ldr, const int32_t* packed, int64_t ldp, const float* g, int64_t ldg,
+                                           int64_t Fp, float* dW, int64_t lddw, float* db, void* workspace,
+                                           size_t workspace_bytes, tfgx_stream_t stream)
+{
+    TFGX_RANGE();
+    TFGX_REQUIRE(n_dst >= 0 && tfgx_pool_mlp_max_wgrad_applies(F_in, Fp),
+                 "F_in a multiple of 4 in [4, 124] and Fp in {128, 256, 512} (tfgx_pool_mlp_max_wgrad_applies)");
+    TFGX_REQUIRE(row_ptr && col && x && h && red && packed && g && dW && workspace, "null pointer");
+    TFGX_REQUIRE(ldx >= F_in && ldx % 4 == 0 && aligned_to(x, 16) && ldx < (int64_t(1) << 31), "x: 16-byte aligned rows, ldx % 4 == 0");
+    TFGX_REQUIRE(ldh >= Fp && ldr >= Fp && ldp >= Fp && ldg >= Fp && lddw >= Fp, "leading dimension too small");
+    TFGX_REQUIRE(workspace_bytes >= tfgx_pool_mlp_max_wgrad_workspace_bytes(n_dst, F_in, Fp), "workspace too small");
+    hipStream_t st = as_stream(stream);
+    float* partial = static_cast<float*>(workspace);
+    if (n_dst == 0) {
+        TFGX_HIP_CHECK(hipMemset2DAsync(dW, sizeof(float) * size_t(lddw), 0, sizeof(float) * size_t(Fp), size_t(F_in), st));
+        if (db) TFGX_HIP_CHECK(hipMemsetAsync(db, 0, sizeof(float) * size_t(Fp), st));
+        return TFGX_OK;
+    }
+    PoolArgs a;
+    a.row_ptr = row_ptr; a.col = col; a.n_dst = n_dst; a.x = x; a.ldx = ldx; a.F_in = int(F_in); a.h = h; a.ldh = ldh;
+    a.red = red; a.ldr = ldr; a.packed = packed; a.ldp = ldp; a.g = g; a.ldg = ldg; a.Fp = int(Fp);
+    a.partial = partial;
+    int grid = pool_grid();
+    if (grid > 1024) grid = 1024;
+    if (int64_t(grid) > n_dst) grid = int(n_dst);
+    a.rows_per_block = (n_dst + grid - 1) / grid;
+    grid = int((n_dst + a.rows_per_block - 1) / a.rows_per_block);
+#define TFGX_POOL_LAUNCH(KMAX_)                                                                                       \
+    {                                                                                                                 \
+        static bool attr_set = false;                                                                                 \
+        if (!attr_set) {                                                                                              \
+            TFGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pool_wgrad_kernel<KMAX_>),             \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, int(pool_lds_bytes(KMAX_)))); \
+            attr_set = true;                                                                                          \
+        }                                                                                                             \
+        pool_wgrad_kernel<KMAX_><<<grid, int(Fp), pool_lds_bytes(KMAX_), st>>>(a);                                    \
+    }
+    if (F_in + 1 <= 8) TFGX_POOL_LAUNCH(8)
+    else if (F_in + 1 <= 40) TFGX_POOL_LAUNCH(40)
+    else if (F_in + 1 <= 72) TFGX_POOL_LAUNCH(72)
+    else if (F_in + 1 <= 104) TFGX_POOL_LAUNCH(104)
+    else TFGX_POOL_LAUNCH(128)
+#undef TFGX_POOL_LAUNCH
+    TFGX_LAUNCH_CHECK("pool_wgrad_kernel");
+    pool_wgrad_reduce_kernel<<<grid_for((F_in + 1) * Fp, kBlock), kBlock, 0, st>>>(partial, grid, int(F_in), int(Fp), dW, lddw, db);
+    TFGX_LAUNCH_CHECK("pool_wgrad_reduce_kernel");
+    return TFGX_OK;
+}

@@ -260,8 +260,14 @@ def _pool_graph_sage(x, edge_index, edge_weight, self_kernel, neighbor_mlp_kerne
     plan = CsrPlan.from_cache(edge_index, n, n, cache)
     act, post = _resolve_act(activation)
     if AG.needs_grad(x, neighbor_mlp_kernel, neighbor_mlp_bias, self_kernel, neighbor_kernel, bias):
-        h = AG.apply_activation(AG.linear(x, neighbor_mlp_kernel, neighbor_mlp_bias, act, gathered=True), L.ACT_NONE, post)
-        reduced = AG.aggregate(plan, h, op)
+        if (op == L.MAX and act == L.ACT_RELU and post is None and AG.needs_grad(neighbor_mlp_kernel, neighbor_mlp_bias)
+                and AG.pool_mlp_max_applies(plan, x, neighbor_mlp_kernel)):
+            # layer 0 (x is data): MLP + max as one operator whose backward goes from the destination rows straight to the
+            # weight gradient — no gradient of the [N, 4 ku] hidden rows (autograd._PoolMlpMax)
+            reduced = AG.pool_mlp_max(plan, x, neighbor_mlp_kernel, neighbor_mlp_bias)
+        else:
+            h = AG.apply_activation(AG.linear(x, neighbor_mlp_kernel, neighbor_mlp_bias, act, gathered=True), L.ACT_NONE, post)
+            reduced = AG.aggregate(plan, h, op)
         return _combine(L.as_f32(self_kernel), x, L.as_f32(neighbor_kernel), reduced, bias, activation, concat,
                         normalize)
     # :199-204 per node (weight == 1).  The [N, 4 * ku] MLP rows are gathered next: written at a gather-friendly stride (units
