@@ -648,3 +648,43 @@ def test_power_of_two_row_strides_are_avoided(tfg):
     assert [P.gather_friendly_ld(v) for v in (20, 47, 64, 100, 128, 160, 256, 512, 1024)] == [32, 48, 64, 100, 160, 160, 288, 544, 1056]
     t = P.gather_friendly_empty(10, 256, "cuda")
     assert tuple(t.shape) == (10, 256) and t.stride(0) == 288
+
+
+def test_relaid_copy_of_a_power_of_two_stride_table_is_memoised_and_fails_safe(tfg):
+    """VERDICT r5 item 7 / ADVICE: a caller's table with a 2 KB row stride is gathered from a copy whose rows sit 128 bytes
+    further apart (plan.relaid_for_gather); the copy used to be made on EVERY call.  It is memoised per table now: the second
+    call with the same tensor copies nothing, a torch-visible write re-copies, and a write behind the version counter is
+    caught by the sampled-row comparison the promoted layouts use — the call returns the fresh aggregation."""
+    import torch
+    from tf_geometric_amd import _lib as L, plan as P, synthetic
+    n, e, F = 300000, 4000000, 512            # 614 MB table: beyond the 512 MB floor of the re-layout
+    ei = L.as_i32(synthetic.synthetic_edges(n, e, seed=4))
+    plan = P.CsrPlan.build(ei, n, n)
+    x = torch.randn(n, F, device="cuda")
+    P.release_relaid_copies()
+    st = lambda k: P.RELAY_STATS.get(k, 0)                             # noqa: E731
+    copies, hits, caught = st("copies"), st("hits"), st("stale_copies_caught")
+    o1 = P.segment_reduce(plan, x, L.SUM)
+    assert st("copies") == copies + 1
+    o2 = P.segment_reduce(plan, x, L.SUM)
+    assert st("copies") == copies + 1 and st("hits") == hits + 1 and torch.equal(o1, o2)          # no second copy
+    P.RELAY_POW2_TABLES = False
+    try:
+        assert torch.equal(P.segment_reduce(plan, x, L.SUM), o1)       # same bits as the table itself
+    finally:
+        P.RELAY_POW2_TABLES = True
+    x.mul_(2.0)                                                         # torch-visible write: copied again
+    o3 = P.segment_reduce(plan, x, L.SUM)
+    assert st("copies") == copies + 2 and torch.equal(o3, o1 * 2.0)
+    v = x._version
+    x.data.mul_(0.5)                                                    # behind the version counter
+    assert x._version == v
+    o4 = P.segment_reduce(plan, x, L.SUM)
+    assert torch.equal(o4, o1) and st("stale_copies_caught") == caught + 1 and st("copies") == copies + 3
+    # inside a hipGraph capture nothing is served from the memo: a replay re-copies, so it sees the table change
+    out = torch.empty_like(o1)
+    cap = tfg.CapturedForward(lambda: P.segment_reduce(plan, x, L.SUM, out=out))
+    assert torch.equal(cap(), o1)
+    x.copy_(x * 2.0)                                                    # (a power of two: exact)
+    assert torch.equal(cap(), o1 * 2.0)
+    P.release_relaid_copies()

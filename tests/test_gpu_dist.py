@@ -155,3 +155,34 @@ def test_demo_sharded_gcn_trains(tfg, self_halo):
     acc = float(last.split("test accuracy = ")[1].split()[0])
     assert acc > 0.5, last
     assert ("transport tfgx_dist" in last) if self_halo == "1" else True
+
+
+def test_sharded_span_passes_gather_one_burst_per_row(tfg):
+    """plan.segment_reduce switched explicit-span launches (a row's own-source edges, then one sub-span per halo
+    round — a handful of edges per row and pass) to one burst per gathered row, but the sharded backend filled its own
+    ReduceArgs and left the kernel's 64-column blocks on: the row start-up was paid once per block.  ONE policy now
+    (plan.wide_blocks_hint) — the dispatcher's choice for the same wide rows, whole rows vs class sub-spans."""
+    import torch
+    from tf_geometric_amd import _lib as L, synthetic
+    from tf_geometric_amd.dist.sharded import HipBackend
+    from tf_geometric_amd.plan import CsrPlan, wide_blocks_hint
+    n, e, F = 40000, 3200000, 256
+    ei = L.as_i32(synthetic.synthetic_edges(n, e, seed=2))
+    plan = CsrPlan.build(ei, n, n)
+    be = HipBackend()
+    x = torch.randn(n, F + 32, device="cuda")[:, :F]          # line-aligned rows, not a power-of-two stride
+    out = torch.empty(n, F, device="cuda")
+    whole = be.segment_reduce(plan.row_ptr, plan.row_ptr[1:], 1, plan.col, None, n, x, out, L.SUM, describe=True)
+    # two classes: [row_ptr_k[2 r], row_ptr_k[2 r + 1]) own-source edges, [.. + 1, .. + 2) halo edges (here: split in the middle)
+    mid = (plan.row_ptr[:-1] + plan.row_ptr[1:]) // 2
+    rpk = torch.stack([plan.row_ptr[:-1], mid], dim=1).reshape(-1)
+    rpk = torch.cat([rpk, plan.row_ptr[-1:]]).contiguous()
+    spans = be.segment_reduce(rpk, rpk[1:], 2, plan.col, None, n, x, out, L.SUM, describe=True)
+    assert whole.endswith(", 16>") and spans.endswith(", 0>"), (whole, spans)
+    assert wide_blocks_hint(True, False, F + 32, e, n) == -1 and wide_blocks_hint(False, False, F + 32, e, n) == 0
+    assert wide_blocks_hint(False, False, F + 32, 14 * n, n) == -1 and wide_blocks_hint(False, True, F + 32, e, n) == -1
+    # and the numbers agree: the two class passes accumulated == the whole-row pass
+    ref = be.segment_reduce(plan.row_ptr, plan.row_ptr[1:], 1, plan.col, None, n, x, torch.empty_like(out), L.SUM)
+    got = be.segment_reduce(rpk, rpk[1:], 2, plan.col, None, n, x, torch.empty_like(out), L.SUM)
+    got = be.segment_reduce(rpk[1:], rpk[2:], 2, plan.col, None, n, x, got, L.SUM, accumulate=True)
+    assert torch.allclose(got, ref, rtol=1e-5, atol=1e-4)

@@ -167,7 +167,7 @@ class HipBackend(object):
 
     def segment_reduce(self, row_begin, row_end, rp_stride, col, w, n_dst, x, out, op, act=L.ACT_NONE,
                        accumulate=False, self_coef=None, bias=None, mean_count=None, hub=None, split=None, track=None,
-                       track_row_begin=None):
+                       track_row_begin=None, describe=False):
         F_total = int(x.shape[1])
         if split is not None:
             x = split[0]
@@ -200,6 +200,15 @@ class HipBackend(object):
             a.hub_chunk_begin, a.hub_chunk_end = chunk_begin.data_ptr(), chunk_end.data_ptr()
             a.n_hub_rows, a.n_hub_chunks = int(hub_rows.shape[0]), int(chunk_begin.shape[0])
             a.hub_scratch = scratch.data_ptr()
+        # the per-class passes of a shard are span launches (a row's own-source edges, then one sub-span per halo round): the
+        # one policy of plan.wide_blocks_hint (this path used to leave the kernel's column blocks on)
+        from ..plan import wide_blocks_hint
+        a.wide_blocks = wide_blocks_hint(explicit_spans=rp_stride > 1, has_hub_lists=hub is not None, ldx=ldx,
+                                         num_edges=int(col.shape[0]) // max(int(rp_stride), 1), n_rows=n_dst)
+        if describe:
+            buf = ctypes.create_string_buffer(160)
+            L.check(self.lib.tfgx_segment_reduce_describe(ctypes.byref(a), buf, 160), "tfgx_segment_reduce_describe")
+            return buf.value.decode()
         L.check(self.lib.tfgx_segment_reduce_f32(ctypes.byref(a), L.stream_ptr()), "tfgx_segment_reduce_f32")
         return out
 

@@ -581,9 +581,15 @@ def relaid_for_gather(x, ldx, plan_is_skewed, dry_run=False):
     """A caller's dense [n, F] table whose row stride is a power of two (pow2_row_stride) -> the same rows 32 floats further
     apart, when one strided copy (read + write of the table) costs less than it saves: strides of 2 KB and more on any graph
     (uniform products graph, F = 512: 43.8 -> 36.7 ms for a 2 ms copy), 512 bytes and more on a power-law plan (R-MAT, F = 256:
-    25.6 -> 19.3 ms for 1 ms).  Only tables beyond the caches (> 512 MB) and only when the copy fits half of the free memory
-    (inside a hipGraph capture the copy is one more captured launch).  Returns (x, ldx) unchanged otherwise.  The copy lives
-    for this call only: nothing is cached, nothing can go stale."""
+    25.6 -> 19.3 ms for 1 ms).  Only tables beyond the caches (> 512 MB) and only when the copy fits half of the free memory.
+    Returns (x, ldx) unchanged otherwise.
+
+    Round 6: the copy is MEMOISED per table (storage window + torch version counter; the two most recent tables) — a model
+    that aggregates the same hidden table in several launches, or the same input every step, pays the 1-2 ms copy and its
+    allocation once.  It is a copy of values the caller never promised to leave alone, so it is served under the fail-safe of
+    the promoted static layouts: before every use sampled rows (TFGX_STATIC_VERIFY_ROWS) are compared bit for bit with x on
+    the device; a write the version counter missed drops the copy and the call re-copies.  Inside a hipGraph capture nothing
+    is memoised or served from the memo (a replay could not see the table change): the copy is one more captured launch."""
     F = int(x.shape[1])
     if not (RELAY_POW2_TABLES and ldx == F and pow2_row_stride(F) and (F >= 512 or plan_is_skewed)):
         return x, ldx
@@ -591,20 +597,84 @@ def relaid_for_gather(x, ldx, plan_is_skewed, dry_run=False):
     need = 4 * n * (F + 32)
     if 4 * n * F <= (512 << 20):
         return x, ldx
-    if not torch.cuda.is_current_stream_capturing():
-        free, _ = torch.cuda.mem_get_info()
-        if need > free // 2:
-            return x, ldx
+    capturing = torch.cuda.is_current_stream_capturing()
+    key = (x.data_ptr(), n, F)
+    hit = None if capturing else _RELAID.get(key)
+    if hit is not None:
+        storage_ref, version, wide = hit
+        if storage_ref() is not None and version == x._version and _relaid_copy_is_current(x, wide, F):
+            if not dry_run:
+                RELAY_STATS["hits"] = RELAY_STATS.get("hits", 0) + 1
+            return wide[:, :F], F + 32
+        _RELAID.pop(key, None)
+        if storage_ref() is not None and version == x._version:
+            RELAY_STATS["stale_copies_caught"] = RELAY_STATS.get("stale_copies_caught", 0) + 1
+        del wide, hit
+    free, _ = torch.cuda.mem_get_info()          # (legal during a capture: no stream operation)
+    if need > free // 2:
+        return x, ldx
     if dry_run:                      # describe: which kernel WOULD run (no copy is made)
         return x, F + 32
     wide = torch.empty((n, F + 32), dtype=torch.float32, device=x.device)
     L.check(L.require_gpu().tfgx_gather_rows_f32(L.ptr(x), ldx, None, n, F, L.ptr(wide), F + 32, L.stream_ptr()),
             "tfgx_gather_rows_f32 (strided row copy)")
     RELAY_STATS["copies"] += 1
+    if not capturing:
+        while len(_RELAID) >= 2:                 # the two most recent tables
+            _RELAID.pop(next(iter(_RELAID)))
+        _RELAID[key] = (_weakref.ref(x.untyped_storage()), x._version, wide)
     return wide[:, :F], F + 32
 
 
 RELAY_STATS = {"copies": 0}
+_RELAID = {}      # (data_ptr, n, F) -> (weakref to the table's storage, its version counter at copy time, the re-laid copy)
+
+
+def _relaid_copy_is_current(x, wide, F):
+    """Sampled rows of the memoised copy against x, bit for bit (the promoted layouts' check, tfgx_split_rows_verify_f32, on
+    the two column halves of the copy)."""
+    samples = _verify_rows_setting()
+    if samples == 0:
+        return True
+    n = int(x.shape[0])
+    if samples < 0:
+        samples = n
+    half = (F // 2) // 4 * 4
+    lib = L.require_gpu()
+    flag = torch.empty(1, dtype=torch.int32, device=x.device)
+    _VERIFY_CALLS[0] += 1
+    L.check(lib.tfgx_split_rows_verify_f32(L.ptr(x), int(x.stride(0)), n, F, half, L.ptr(wide), int(wide.stride(0)),
+                                           wide.data_ptr() + 4 * half, int(wide.stride(0)), samples,
+                                           (0x5DEECE66D * _VERIFY_CALLS[0] + 11) & 0xFFFFFFFFFFFFFFFF, L.ptr(flag), L.stream_ptr()),
+            "tfgx_split_rows_verify_f32 (re-laid copy)")
+    return int(flag.item()) == 0
+
+
+def release_relaid_copies():
+    """Drop the memoised re-laid tables (relaid_for_gather)."""
+    _RELAID.clear()
+
+
+def wide_blocks_hint(explicit_spans, has_hub_lists, ldx, num_edges, n_rows):
+    """tfgx_reduce_args.wide_blocks for one launch: 0 = the kernel's own choice (wide line-aligned rows gathered in 64-column
+    blocks), -1 = one burst per gathered row.  ONE policy for every caller that fills a ReduceArgs
+    (plan.segment_reduce and the sharded backend, dist/sharded.py — ADVICE r5: the sharded passes used to miss it):
+      * explicit spans (a row's own-source edges, then one sub-span per halo round: a handful of edges per row and pass) and
+        short rows (fewer than 32 edges per launched row on average): a row's start-up — header loads, the first index batch,
+        the self-loop row — is paid once per column pass.  One shard of the papers100M-shaped graph (13.9 M rows x 14.4 edges,
+        F = 128, 57 GB table): 19.2 ms with one burst per row against 22.2 with two column passes (profiles/r05_papers_shard.jsonl)
+      * a power-law plan (hub lists) whose row stride is not a power of two — the table's own, or after relaid_for_gather moved
+        its rows 128 bytes further apart: same-box A/B on the products-sized R-MAT graph
+        (profiles/r05_ab_wide_blocks_modes_rmat.jsonl): F = 192 / 224 13.4 / 15.7 ms with bursts against 14.6 / 18.0 with column
+        blocks (mostly short rows, and the hot source rows already hit in the caches); at F = 128 / 512, where a power-of-two
+        stride folds the hot rows onto few cache sets, the blocks win (11.2 -> 9.4 ms, 50.8 -> 48.1) and stay on."""
+    if explicit_spans:
+        return -1
+    if not has_hub_lists and num_edges < 32 * max(int(n_rows), 1):
+        return -1
+    if has_hub_lists and not pow2_row_stride(ldx):
+        return -1
+    return 0
 
 
 def segment_reduce(plan, x, op, w_csr=None, out=None, act=L.ACT_NONE, self_coef=None, bias=None, add_x=None,
@@ -682,24 +752,8 @@ def segment_reduce(plan, x, op, w_csr=None, out=None, act=L.ACT_NONE, self_coef=
         a.hub_chunk_begin, a.hub_chunk_end = chunk_begin.data_ptr(), chunk_end.data_ptr()
         a.n_hub_rows, a.n_hub_chunks = int(hub_rows.shape[0]), int(chunk_begin.shape[0])
         a.hub_scratch = scratch.data_ptr()
-    rows_launched = max(n_dst, 1)
-    if row_begin is not None or row_end is not None or col is not None:
-        # explicit spans (the sharded path's per-class passes: a row's own-source edges, then one sub-span per halo round —
-        # a handful of edges per row and pass): one burst per row, as before round 5
-        a.wide_blocks = -1
-    if hub is None and plan.num_edges < 32 * rows_launched and row_begin is None and col is None:
-        # short rows (fewer than 32 edges per row on average): a row's start-up — header loads, the first index batch, the
-        # self-loop row — is paid once per column pass.  One shard of the papers100M-shaped graph (13.9 M rows x 14.4 edges,
-        # F = 128, 57 GB table): 19.2 ms with one burst per row against 22.2 with two column passes (profiles/r05_papers_shard.jsonl)
-        a.wide_blocks = -1
-    if hub is not None and not pow2_row_stride(ldx):
-        # power-law plan (hub lists present), row stride not a power of two — the table's own, or after relaid_for_gather moved
-        # its rows 128 bytes further apart: one burst per source row (tfgx.h wide_blocks).
-        # Same-box A/B on the products-sized R-MAT graph (profiles/r05_ab_wide_blocks_modes_rmat.jsonl): F = 192 / 224
-        # 13.4 / 15.7 ms with bursts against 14.6 / 18.0 with column blocks (mostly short rows: the start-up of a row is
-        # paid once per pass, and the hot source rows already hit in the caches); at F = 128 / 512, where a power-of-two
-        # stride folds the hot rows onto few cache sets, the blocks win (11.2 -> 9.4 ms, 50.8 -> 48.1) and stay on.
-        a.wide_blocks = -1
+    a.wide_blocks = wide_blocks_hint(explicit_spans=row_begin is not None or row_end is not None or col is not None,
+                                     has_hub_lists=hub is not None, ldx=ldx, num_edges=plan.num_edges, n_rows=n_dst)
     if wide_blocks is not None:          # tests / A-B tools: +1 column blocks wherever the layout allows, -1 one burst per row
         a.wide_blocks = int(wide_blocks)
     if describe:
