@@ -1,7 +1,7 @@
 #!/bin/bash
 # where does pool_wgrad_kernel's time go: variants built on the box (timing only; results are wrong for 1 and 2)
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
-for v in 1 2 0; do
+for v in ${POOL_VARIANTS:-1 2 0}; do
   TFGX_EXTRA_HIPCC_FLAGS="-DTFGX_POOL_EXPERIMENT=$v" python -c "
 import os
 from tf_geometric_amd import _build
