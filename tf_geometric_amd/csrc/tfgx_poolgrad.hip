@@ -28,7 +28,7 @@ namespace tfgx {
 namespace {
 
 #ifndef TFGX_POOL_EXPERIMENT
-#define TFGX_POOL_EXPERIMENT 0      // developer A/B, TIMING ONLY (wrong results): 1 = no LDS reads / FMAs, 3 = no pair loads
+#define TFGX_POOL_EXPERIMENT 0      // developer A/B, TIMING ONLY (wrong results): 1 = no LDS reads / FMAs, 2 = no gather of x rows
 #endif
 constexpr int kPoolChunk = 96;      // edges staged at a time, at most (products shape: in-degree 51 +- 7)
 constexpr int kPoolSlots = 4;       // 16-byte loads per thread and chunk: a chunk holds min(96, 4 * threads / (F_in / 4)) edges
@@ -76,9 +76,6 @@ __global__ __launch_bounds__(512, 1) void pool_wgrad_kernel(const PoolArgs a)
     for (int u = 0; u < kPoolSlots; ++u) slot_e[u] = (tid + u * nthr) / Q4;
     auto slot_q = [&](int u) { return tid + u * nthr - slot_e[u] * Q4; };
 
-    // the constant feature (its accumulator is the bias gradient): column F_in of every staged row, written once — the
-    // chunk stores above never touch it (F_in is a multiple of 4: the 16-byte pieces end at F_in)
-    for (int i = tid; i < 2 * kPoolChunk; i += nthr) Xs[i * XS + a.F_in] = 1.0f;
     for (int64_t r_begin = blk_begin; r_begin < blk_end; r_begin += kPoolRpTile) {
         const int64_t r_end = min(blk_end, r_begin + kPoolRpTile);
         __syncthreads();
@@ -107,14 +104,14 @@ __global__ __launch_bounds__(512, 1) void pool_wgrad_kernel(const PoolArgs a)
         };
         auto load_ids = [&](const Item& it, int (&ids)[kPoolSlots]) {
 #pragma unroll
-            // (no branch per slot: a slot past the chunk's last edge re-reads that edge — same cache lines — and later stages its row
-            //  into an LDS row no winner position points at; twelve divergent branch blocks per chunk were a quarter of the loop)
-            for (int u = 0; u < kPoolSlots; ++u) ids[u] = a.col[it.s + min(slot_e[u], max(it.len - 1, 0))];
+            for (int u = 0; u < kPoolSlots; ++u) ids[u] = (slot_e[u] < it.len) ? a.col[it.s + slot_e[u]] : 0;
         };
         auto load_x = [&](const Item& it, const int (&ids)[kPoolSlots], float4 (&xv)[kPoolSlots]) {
 #pragma unroll
             for (int u = 0; u < kPoolSlots; ++u) {
-                xv[u] = *reinterpret_cast<const float4*>(a.x + uint64_t(uint32_t(ids[u])) * uint64_t(a.ldx) + 4 * slot_q(u));
+                xv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (slot_e[u] < it.len && TFGX_POOL_EXPERIMENT != 2)
+                    xv[u] = *reinterpret_cast<const float4*>(a.x + uint64_t(uint32_t(ids[u])) * uint64_t(a.ldx) + 4 * slot_q(u));
             }
         };
         auto commit = [&](const Item& it, int buf, const int (&ids)[kPoolSlots], const float4 (&xv)[kPoolSlots]) {
@@ -122,9 +119,12 @@ __global__ __launch_bounds__(512, 1) void pool_wgrad_kernel(const PoolArgs a)
             int* Cb = Cs + buf * kPoolChunk;
 #pragma unroll
             for (int u = 0; u < kPoolSlots; ++u) {
-                if (slot_e[u] < kPoolChunk) {                               // (a buffer bound, not the chunk's length)
+                if (slot_e[u] < it.len) {
                     *reinterpret_cast<float4*>(Xb + slot_e[u] * XS + 4 * slot_q(u)) = xv[u];
-                    if (slot_q(u) == 0) Cb[slot_e[u]] = ids[u];
+                    if (slot_q(u) == 0) {
+                        Cb[slot_e[u]] = ids[u];
+                        Xb[slot_e[u] * XS + a.F_in] = 1.0f;               // the constant feature: its accumulator is the bias gradient
+                    }
                 }
             }
         };
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(512, 1) void pool_wgrad_kernel(const PoolArgs a)
         auto load_pair = [&](const Item& it) {
             Pair o;
             o.pos = 0; o.gn = 0.0f; o.rv = 0.0f;
-            if (it.row < r_end && TFGX_POOL_EXPERIMENT != 3) {
+            if (it.row < r_end) {
                 const uint32_t pk = uint32_t(a.packed[it.row * a.ldp + j]);
                 const float rv = a.red[it.row * a.ldr + j];
                 const float gv = a.g[it.row * a.ldg + j];
