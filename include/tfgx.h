@@ -402,10 +402,16 @@ int tfgx_segment_max_backward_f32(const int32_t* row_ptr_t, const int32_t* dst_t
    Shapes: F_in a multiple of 4 in [4, 124], Fp in {128, 256, 512} (tfgx_pool_mlp_max_wgrad_applies), rows shorter than 65536
    edges (the packed format's bound). */
 int tfgx_pool_mlp_max_wgrad_applies(int64_t F_in, int64_t Fp);
+/* once per graph and (F_in, Fp): the launch's work items (rows cut into chunks of edges that fit the LDS stage, workgroup by
+   workgroup) into a caller-owned device buffer; E = row_ptr[n_dst] */
+size_t tfgx_pool_mlp_max_wgrad_plan_bytes(int64_t n_dst, int64_t E, int64_t F_in, int64_t Fp);
+int tfgx_pool_mlp_max_wgrad_plan(const int32_t* row_ptr, int64_t n_dst, int64_t E, int64_t F_in, int64_t Fp, void* plan_buf,
+                                 size_t plan_bytes, tfgx_stream_t stream);
 size_t tfgx_pool_mlp_max_wgrad_workspace_bytes(int64_t n_dst, int64_t F_in, int64_t Fp);
-int tfgx_pool_mlp_max_wgrad_f32(const int32_t* row_ptr, const int32_t* col, int64_t n_dst, const float* x, int64_t ldx,
+int tfgx_pool_mlp_max_wgrad_f32(const int32_t* row_ptr, const int32_t* col, int64_t n_dst, int64_t E, const float* x, int64_t ldx,
                                 int64_t F_in, const float* h, int64_t ldh, const float* red, int64_t ldr,
-                                const int32_t* packed, int64_t ldp, const float* g, int64_t ldg, int64_t Fp, float* dW,
+                                const int32_t* packed, int64_t ldp, const float* g, int64_t ldg, int64_t Fp,
+                                const void* plan_buf /* tfgx_pool_mlp_max_wgrad_plan of the same row_ptr, F_in, Fp */, float* dW,
                                 int64_t lddw, float* db /* [Fp] or NULL */, void* workspace, size_t workspace_bytes,
                                 tfgx_stream_t stream);
 

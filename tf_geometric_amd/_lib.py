@@ -154,9 +154,11 @@ SIGNATURES = {
     "tfgx_segment_max_with_arg_f32": (ctypes.c_int, [_P, _P, _P, _I64, _P, _I64, _I64, _P, _I64, _P, _I64, _P, _I64, _P]),
     "tfgx_segment_max_backward_mask_workspace_bytes": (_SZ, [_I64, _I64, _I64]),
     "tfgx_pool_mlp_max_wgrad_applies": (ctypes.c_int, [_I64, _I64]),
+    "tfgx_pool_mlp_max_wgrad_plan_bytes": (_SZ, [_I64, _I64, _I64, _I64]),
+    "tfgx_pool_mlp_max_wgrad_plan": (ctypes.c_int, [_P, _I64, _I64, _I64, _I64, _P, _SZ, _P]),
     "tfgx_pool_mlp_max_wgrad_workspace_bytes": (_SZ, [_I64, _I64, _I64]),
-    "tfgx_pool_mlp_max_wgrad_f32": (ctypes.c_int, [_P, _P, _I64, _P, _I64, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _I64,
-                                                   _P, _I64, _P, _P, _SZ, _P]),
+    "tfgx_pool_mlp_max_wgrad_f32": (ctypes.c_int, [_P, _P, _I64, _I64, _P, _I64, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _I64,
+                                                   _P, _P, _I64, _P, _P, _SZ, _P]),
     "tfgx_segment_max_backward_mask_f32": (ctypes.c_int, [_P, _P, _P, _I64, _I64, _P, _I64, _I64, _P, _I64, _P, _I64, _P,
                                                           _I64, _P, _I64, _P, _P, _P, _P, _I64, _P, _I64, _P, _SZ, _P]),
     "tfgx_segment_max_backward_mask_phases_f32": (ctypes.c_int, [_P, _P, _P, _I64, _I64, _P, _I64, _I64, _P, _I64, _P, _I64, _P,

@@ -493,11 +493,20 @@ class _PoolMlpMax(torch.autograd.Function):
         F_in, Fp = int(x2.shape[1]), int(h2.shape[1])
         dW = torch.empty((F_in, Fp), dtype=torch.float32, device=x2.device)
         db = torch.empty(Fp, dtype=torch.float32, device=x2.device) if bias is not None else None
+        # the launch's work items depend on the graph and on (F_in, Fp) alone: built once, kept on the plan
+        items = plan.__dict__.setdefault("_pool_wgrad_items", {})
+        key = (F_in, Fp)
+        if key not in items:
+            nb = lib.tfgx_pool_mlp_max_wgrad_plan_bytes(plan.n_dst, plan.num_edges, F_in, Fp)
+            buf = torch.empty(max(nb, 1), dtype=torch.uint8, device=x2.device)
+            L.check(lib.tfgx_pool_mlp_max_wgrad_plan(L.ptr(plan.row_ptr), plan.n_dst, plan.num_edges, F_in, Fp, L.ptr(buf), nb,
+                                                     L.stream_ptr()), "tfgx_pool_mlp_max_wgrad_plan")
+            items[key] = buf
         ws_bytes = lib.tfgx_pool_mlp_max_wgrad_workspace_bytes(plan.n_dst, F_in, Fp)
         ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=x2.device)
-        L.check(lib.tfgx_pool_mlp_max_wgrad_f32(L.ptr(plan.row_ptr), L.ptr(plan.col), plan.n_dst, L.ptr(x2), ldx, F_in,
+        L.check(lib.tfgx_pool_mlp_max_wgrad_f32(L.ptr(plan.row_ptr), L.ptr(plan.col), plan.n_dst, plan.num_edges, L.ptr(x2), ldx, F_in,
                                                 L.ptr(h2), ldh, L.ptr(red), Fp, L.ptr(packed), Fp, L.ptr(g2), ldg, Fp,
-                                                L.ptr(dW), Fp, L.ptr(db), L.ptr(ws), ws_bytes, L.stream_ptr()),
+                                                L.ptr(items[key]), L.ptr(dW), Fp, L.ptr(db), L.ptr(ws), ws_bytes, L.stream_ptr()),
                 "tfgx_pool_mlp_max_wgrad_f32")
         need = ctx.needs_input_grad
         return None, None, (dW if need[2] else None), (db if (bias is not None and need[3]) else None)

@@ -45,10 +45,51 @@ struct PoolArgs {
     int32_t Fp;
     float* partial;          // [gridDim.x, F_in + 1, Fp]
     int64_t rows_per_block;
+    int32_t chunk;           // edges per work item, at most
+    const int4* items;       // work items (row, first CSR position, edges, offset of the chunk inside its row), block by block
+    const int32_t* item_ptr; // [gridDim.x + 1] item range of every workgroup
 };
 
+// Work items of the main kernel: the rows of a workgroup's range with at least one in-edge, cut into chunks of at most `chunk`
+// edges — written once by these two small kernels, so that the main loop reads its next items as plain 16-byte loads issued
+// steps ahead instead of walking row_ptr (round 6: the scalar walk — LDS read, s_waitcnt, v_readfirstlane, a data-dependent
+// loop over empty rows — sat in front of every step's loads).
+__global__ void pool_item_count_kernel(const int32_t* __restrict__ row_ptr, int64_t n_dst, int64_t rows_per_block, int chunk,
+                                       int32_t* __restrict__ counts)
+{
+    const int64_t b = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+    const int64_t r0 = b * rows_per_block;
+    if (r0 >= n_dst) return;
+    const int64_t r1 = min(n_dst, r0 + rows_per_block);
+    int c = 0;
+    for (int64_t r = r0; r < r1; ++r) c += (row_ptr[r + 1] - row_ptr[r] + chunk - 1) / chunk;
+    counts[b] = c;
+}
+
+__global__ void pool_item_scan_kernel(const int32_t* __restrict__ counts, int n_blocks, int32_t* __restrict__ item_ptr)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        int acc = 0;
+        for (int b = 0; b < n_blocks; ++b) { item_ptr[b] = acc; acc += counts[b]; }
+        item_ptr[n_blocks] = acc;
+    }
+}
+
+__global__ void pool_item_fill_kernel(const int32_t* __restrict__ row_ptr, int64_t n_dst, int64_t rows_per_block, int chunk,
+                                      const int32_t* __restrict__ item_ptr, int4* __restrict__ items)
+{
+    const int64_t b = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+    const int64_t r0 = b * rows_per_block;
+    if (r0 >= n_dst) return;
+    const int64_t r1 = min(n_dst, r0 + rows_per_block);
+    int4* out = items + item_ptr[b];
+    for (int64_t r = r0; r < r1; ++r) {
+        const int s = row_ptr[r], e = row_ptr[r + 1];
+        for (int p = s; p < e; p += chunk) *out++ = make_int4(int(r), p, min(chunk, e - p), p - s);
+    }
+}
+
 typedef float float2v __attribute__((ext_vector_type(2)));
-constexpr int kPoolRpTile = 8192;   // rows whose row_ptr entries sit in LDS at a time (the item bookkeeping never waits for HBM)
 
 template <int KMAX>       // accumulators per thread: F_in + 1 <= KMAX
 __global__ __launch_bounds__(512, 1) void pool_wgrad_kernel(const PoolArgs a)
@@ -58,13 +99,9 @@ __global__ __launch_bounds__(512, 1) void pool_wgrad_kernel(const PoolArgs a)
     extern __shared__ float smem[];
     float* const Xs = smem;                                                   // [2][kPoolChunk][XS]
     int* const Cs = reinterpret_cast<int*>(smem + 2 * kPoolChunk * XS);       // [2][kPoolChunk] source ids of the staged rows
-    int* const Rp = Cs + 2 * kPoolChunk;                                      // [kPoolRpTile + 1] row_ptr of the current row tile
     const int tid = threadIdx.x, nthr = blockDim.x;                           // nthr == Fp: thread tid owns column tid
     const int j = tid;
     const int Q4 = a.F_in / 4;                      // 16-byte pieces per x row
-    const int CH = min(kPoolChunk, (kPoolSlots * nthr) / Q4);                // edges per chunk: every piece has a slot
-    const int64_t blk_begin = int64_t(blockIdx.x) * a.rows_per_block;
-    const int64_t blk_end = min(a.n_dst, blk_begin + a.rows_per_block);
 
     float2v acc[KMAX / 2];                       // pairs of accumulators: v_pk_fma_f32 does two multiply-adds per issue slot
 #pragma unroll
@@ -76,31 +113,22 @@ __global__ __launch_bounds__(512, 1) void pool_wgrad_kernel(const PoolArgs a)
     for (int u = 0; u < kPoolSlots; ++u) slot_e[u] = (tid + u * nthr) / Q4;
     auto slot_q = [&](int u) { return tid + u * nthr - slot_e[u] * Q4; };
 
-    for (int64_t r_begin = blk_begin; r_begin < blk_end; r_begin += kPoolRpTile) {
-        const int64_t r_end = min(blk_end, r_begin + kPoolRpTile);
-        __syncthreads();
-        for (int i = tid; i <= int(r_end - r_begin); i += nthr) Rp[i] = a.row_ptr[r_begin + i];
-        __syncthreads();
+    {
+        const int64_t r_end = a.n_dst;          // (item.row == r_end: no item)
         // a work item: edges [s, s + len) of row `row`, the chunk starting `off` edges into the row; row == r_end: none left
         struct Item { int64_t row; int s; int len; int off; };
-        auto first_item = [&](int64_t r) {
-            Item it;
-            for (; r < r_end; ++r) {
-                const int s = __builtin_amdgcn_readfirstlane(Rp[r - r_begin]), e = __builtin_amdgcn_readfirstlane(Rp[r - r_begin + 1]);
-                if (e > s) { it.row = r; it.s = s; it.len = min(e - s, CH); it.off = 0; return it; }
-            }
-            it.row = r_end; it.s = 0; it.len = 0; it.off = 0;
-            return it;
+        const int item_begin = a.item_ptr[blockIdx.x], item_end = a.item_ptr[blockIdx.x + 1];
+        auto fetch = [&](int i) {                // the raw 16 bytes of item i (a load every thread issues: one request per wave)
+            return (i < item_end) ? a.items[i] : make_int4(-1, 0, 0, 0);
         };
-        auto next_item = [&](const Item& cur) {
-            if (cur.row >= r_end) return cur;
-            const int e = __builtin_amdgcn_readfirstlane(Rp[cur.row - r_begin + 1]);
-            if (cur.s + cur.len < e) {
-                Item it;
-                it.row = cur.row; it.s = cur.s + cur.len; it.len = min(e - it.s, CH); it.off = cur.off + cur.len;
-                return it;
-            }
-            return first_item(cur.row + 1);
+        auto decode = [&](const int4& v) {
+            Item it;
+            const int row = __builtin_amdgcn_readfirstlane(v.x);
+            it.row = row < 0 ? r_end : int64_t(row);
+            it.s = __builtin_amdgcn_readfirstlane(v.y);
+            it.len = __builtin_amdgcn_readfirstlane(v.z);
+            it.off = __builtin_amdgcn_readfirstlane(v.w);
+            return it;
         };
         auto load_ids = [&](const Item& it, int (&ids)[kPoolSlots]) {
 #pragma unroll
@@ -152,9 +180,11 @@ __global__ __launch_bounds__(512, 1) void pool_wgrad_kernel(const PoolArgs a)
         // (loaded during chunk i - 1, written to the other buffer after the compute) and those of chunk i + 2 are in flight;
         // the source ids run one chunk further ahead still.  (Three register bundles trading roles in a loop unrolled by three —
         // no register rotation at the end of a step — measured SLOWER: 28.5 vs 25.8 ms at products shape.)
-        Item it0 = first_item(r_begin);
-        Item it1 = next_item(it0);
-        Item it2 = next_item(it1);
+        int inext = item_begin + 3;
+        Item it0 = decode(fetch(item_begin));
+        Item it1 = decode(fetch(item_begin + 1));
+        Item it2 = decode(fetch(item_begin + 2));
+        int4 raw3 = fetch(inext);                // decoded one step later: the load has a whole step to arrive
         int ids1[kPoolSlots], ids2[kPoolSlots], ids3[kPoolSlots];
         float4 x1[kPoolSlots], x2[kPoolSlots];
         {
@@ -171,7 +201,8 @@ __global__ __launch_bounds__(512, 1) void pool_wgrad_kernel(const PoolArgs a)
         __syncthreads();
         int buf = 0;
         while (it0.row < r_end) {
-            const Item it3 = next_item(it2);
+            const Item it3 = decode(raw3);
+            raw3 = fetch(++inext);
             load_x(it2, ids2, x2);              // two chunks ahead
             load_ids(it3, ids3);
             const Pair pr_n = load_pair(it1);
@@ -251,7 +282,7 @@ int pool_grid()
 
 inline size_t pool_lds_bytes(int kmax)
 {
-    return size_t(2) * kPoolChunk * size_t(kmax + 4) * sizeof(float) + size_t(2) * kPoolChunk * sizeof(int) + size_t(kPoolRpTile + 1) * sizeof(int);
+    return size_t(2) * kPoolChunk * size_t(kmax + 4) * sizeof(float) + size_t(2) * kPoolChunk * sizeof(int);
 }
 
 inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
@@ -266,23 +297,74 @@ extern "C" int tfgx_pool_mlp_max_wgrad_applies(int64_t F_in, int64_t Fp)
     return (F_in % 4 == 0 && F_in >= 4 && F_in <= 124 && (Fp == 128 || Fp == 256 || Fp == 512)) ? 1 : 0;
 }
 
-extern "C" size_t tfgx_pool_mlp_max_wgrad_workspace_bytes(int64_t n_dst, int64_t F_in, int64_t Fp)
+static int pool_chunk(int64_t F_in, int64_t Fp)      // edges per work item: every 16-byte piece of a chunk has a load slot
 {
-    if (n_dst < 0 || F_in < 1 || Fp < 1) return 0;
-    (void)n_dst;
-    return align256(size_t(1024) * size_t(F_in + 1) * size_t(Fp) * sizeof(float));      // partials of up to 1024 workgroups
+    const int64_t c = (kPoolSlots * Fp) / (F_in / 4);
+    return int(c < kPoolChunk ? c : kPoolChunk);
 }
 
-extern "C" int tfgx_pool_mlp_max_wgrad_f32(const int32_t* row_ptr, const int32_t* col, int64_t n_dst, const float* x,
-                                           int64_t ldx, int64_t F_in, const float* h, int64_t ldh, const float* red,
-                                           int64_t ldr, const int32_t* packed, int64_t ldp, const float* g, int64_t ldg,
-                                           int64_t Fp, float* dW, int64_t lddw, float* db, void* workspace,
-                                           size_t workspace_bytes, tfgx_stream_t stream)
+static size_t pool_partial_bytes(int64_t F_in, int64_t Fp) { return align256(size_t(1024) * size_t(F_in + 1) * size_t(Fp) * sizeof(float)); }
+static size_t pool_item_capacity(int64_t n_dst, int64_t E, int64_t F_in, int64_t Fp) { return size_t(n_dst) + size_t(E) / size_t(pool_chunk(F_in, Fp)) + 1; }
+
+// ---- the work-item table: a function of the plan and of (F_in, Fp) alone — built once per graph, kept by the caller
+struct PoolPlanHeader {
+    int32_t magic, grid, chunk, reserved;
+    int64_t rows_per_block, n_dst, E, F_in, Fp;
+};
+constexpr int32_t kPoolMagic = 0x706f6f6c;
+static size_t pool_plan_items_offset() { return align256(sizeof(PoolPlanHeader)) + align256(sizeof(int32_t) * 2 * 1032); }
+
+extern "C" size_t tfgx_pool_mlp_max_wgrad_plan_bytes(int64_t n_dst, int64_t E, int64_t F_in, int64_t Fp)
+{
+    if (n_dst < 0 || E < 0 || !tfgx_pool_mlp_max_wgrad_applies(F_in, Fp)) return 0;
+    return pool_plan_items_offset() + align256(sizeof(int4) * pool_item_capacity(n_dst, E, F_in, Fp));
+}
+
+extern "C" int tfgx_pool_mlp_max_wgrad_plan(const int32_t* row_ptr, int64_t n_dst, int64_t E, int64_t F_in, int64_t Fp,
+                                            void* plan_buf, size_t plan_bytes, tfgx_stream_t stream)
 {
     TFGX_RANGE();
-    TFGX_REQUIRE(n_dst >= 0 && tfgx_pool_mlp_max_wgrad_applies(F_in, Fp),
+    TFGX_REQUIRE(n_dst >= 0 && E >= 0 && tfgx_pool_mlp_max_wgrad_applies(F_in, Fp), "bad size (tfgx_pool_mlp_max_wgrad_applies)");
+    TFGX_REQUIRE(plan_buf != nullptr && plan_bytes >= tfgx_pool_mlp_max_wgrad_plan_bytes(n_dst, E, F_in, Fp), "plan buffer too small");
+    TFGX_REQUIRE(n_dst == 0 || row_ptr != nullptr, "null pointer");
+    hipStream_t st = as_stream(stream);
+    PoolPlanHeader h;
+    h.magic = kPoolMagic; h.reserved = 0; h.n_dst = n_dst; h.E = E; h.F_in = F_in; h.Fp = Fp;
+    h.chunk = pool_chunk(F_in, Fp);
+    int grid = pool_grid();
+    if (grid > 1024) grid = 1024;
+    if (int64_t(grid) > n_dst) grid = int(n_dst > 0 ? n_dst : 1);
+    h.rows_per_block = n_dst > 0 ? (n_dst + grid - 1) / grid : 1;
+    h.grid = n_dst > 0 ? int((n_dst + h.rows_per_block - 1) / h.rows_per_block) : 0;
+    char* base = static_cast<char*>(plan_buf);
+    // (the header's fields are functions of (device, n_dst, F_in, Fp) and are recomputed by the launch: nothing is copied)
+    if (n_dst == 0) return TFGX_OK;
+    int32_t* counts = reinterpret_cast<int32_t*>(base + align256(sizeof(PoolPlanHeader)));
+    int32_t* item_ptr = counts + 1032;
+    int4* items = reinterpret_cast<int4*>(base + pool_plan_items_offset());
+    pool_item_count_kernel<<<(h.grid + 63) / 64, 64, 0, st>>>(row_ptr, n_dst, h.rows_per_block, h.chunk, counts);
+    pool_item_scan_kernel<<<1, 64, 0, st>>>(counts, h.grid, item_ptr);
+    pool_item_fill_kernel<<<(h.grid + 63) / 64, 64, 0, st>>>(row_ptr, n_dst, h.rows_per_block, h.chunk, item_ptr, items);
+    TFGX_LAUNCH_CHECK("pool_item_*_kernel");
+    return TFGX_OK;
+}
+
+extern "C" size_t tfgx_pool_mlp_max_wgrad_workspace_bytes(int64_t n_dst, int64_t F_in, int64_t Fp)
+{
+    if (n_dst < 0 || !tfgx_pool_mlp_max_wgrad_applies(F_in, Fp)) return 0;
+    return pool_partial_bytes(F_in, Fp);                      // partials of up to 1024 workgroups
+}
+
+extern "C" int tfgx_pool_mlp_max_wgrad_f32(const int32_t* row_ptr, const int32_t* col, int64_t n_dst, int64_t E, const float* x,
+                                           int64_t ldx, int64_t F_in, const float* h, int64_t ldh, const float* red,
+                                           int64_t ldr, const int32_t* packed, int64_t ldp, const float* g, int64_t ldg,
+                                           int64_t Fp, const void* plan_buf, float* dW, int64_t lddw, float* db,
+                                           void* workspace, size_t workspace_bytes, tfgx_stream_t stream)
+{
+    TFGX_RANGE();
+    TFGX_REQUIRE(n_dst >= 0 && E >= 0 && tfgx_pool_mlp_max_wgrad_applies(F_in, Fp),
                  "F_in a multiple of 4 in [4, 124] and Fp in {128, 256, 512} (tfgx_pool_mlp_max_wgrad_applies)");
-    TFGX_REQUIRE(row_ptr && col && x && h && red && packed && g && dW && workspace, "null pointer");
+    TFGX_REQUIRE(row_ptr && col && x && h && red && packed && g && dW && workspace && plan_buf, "null pointer");
     TFGX_REQUIRE(ldx >= F_in && ldx % 4 == 0 && aligned_to(x, 16) && ldx < (int64_t(1) << 31), "x: 16-byte aligned rows, ldx % 4 == 0");
     TFGX_REQUIRE(ldh >= Fp && ldr >= Fp && ldp >= Fp && ldg >= Fp && lddw >= Fp, "leading dimension too small");
     TFGX_REQUIRE(workspace_bytes >= tfgx_pool_mlp_max_wgrad_workspace_bytes(n_dst, F_in, Fp), "workspace too small");
@@ -293,6 +375,7 @@ extern "C" int tfgx_pool_mlp_max_wgrad_f32(const int32_t* row_ptr, const int32_t
         if (db) TFGX_HIP_CHECK(hipMemsetAsync(db, 0, sizeof(float) * size_t(Fp), st));
         return TFGX_OK;
     }
+    // grid / rows per workgroup / chunk are functions of (device, n_dst, F_in, Fp): recomputed here exactly as the plan call did
     PoolArgs a;
     a.row_ptr = row_ptr; a.col = col; a.n_dst = n_dst; a.x = x; a.ldx = ldx; a.F_in = int(F_in); a.h = h; a.ldh = ldh;
     a.red = red; a.ldr = ldr; a.packed = packed; a.ldp = ldp; a.g = g; a.ldg = ldg; a.Fp = int(Fp);
@@ -302,6 +385,10 @@ extern "C" int tfgx_pool_mlp_max_wgrad_f32(const int32_t* row_ptr, const int32_t
     if (int64_t(grid) > n_dst) grid = int(n_dst);
     a.rows_per_block = (n_dst + grid - 1) / grid;
     grid = int((n_dst + a.rows_per_block - 1) / a.rows_per_block);
+    const char* base = static_cast<const char*>(plan_buf);
+    a.chunk = pool_chunk(F_in, Fp);
+    a.item_ptr = reinterpret_cast<const int32_t*>(base + align256(sizeof(PoolPlanHeader))) + 1032;
+    a.items = reinterpret_cast<const int4*>(base + pool_plan_items_offset());
 #define TFGX_POOL_LAUNCH(KMAX_)                                                                                       \
     {                                                                                                                 \
         static bool attr_set = false;                                                                                 \
