@@ -179,7 +179,8 @@ __global__ __launch_bounds__(512, 1) void pool_wgrad_kernel(const PoolArgs a)
         // software pipeline, two chunks deep: while chunk i is consumed from LDS, the x rows of chunk i + 1 are in registers
         // (loaded during chunk i - 1, written to the other buffer after the compute) and those of chunk i + 2 are in flight;
         // the source ids run one chunk further ahead still.  (Three register bundles trading roles in a loop unrolled by three —
-        // no register rotation at the end of a step — measured SLOWER: 28.5 vs 25.8 ms at products shape.)
+        // no register rotation at the end of a step — measured SLOWER: 28.5 vs 25.8 ms at products shape; two rows per step
+        // — 128-edge spans, 7 load slots, one barrier for two work items — 24.0 vs 24.4 ms at 255 VGPRs: not kept.)
         int inext = item_begin + 3;
         Item it0 = decode(fetch(item_begin));
         Item it1 = decode(fetch(item_begin + 1));
