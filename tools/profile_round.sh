@@ -1,6 +1,7 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (via gpurun): rocprofv3 kernel-trace/stats pass + separate PMC passes of bench.py, summaries into
 # gpurun_out/prof_<TAG>/ (TFGX_ROUND, default r06).  --pmc is never combined with any trace domain other than --kernel-trace (pool rule).
+# (bench.py starts tools/line_rate_probe as child processes: rocprofv3 writes one database per process — the LARGEST is the bench itself)
 set -u
 ROOT="$(pwd)"
 TAG="${TFGX_ROUND:-r06}"          # names of the artefacts: profiles/<TAG>_*
@@ -16,9 +17,9 @@ B="python $ROOT/bench.py --no-cpu-baseline --no-rmat --no-configs"
 rocprofv3 --pmc FETCH_SIZE -d "$OUT/fetch" -- $B --steps 3 --warmup 1 > /dev/null 2> "$OUT/fetch.err"
 rocprofv3 --pmc WRITE_SIZE -d "$OUT/write" -- $B --steps 3 --warmup 1 > /dev/null 2> "$OUT/write.err"
 cd "$ROOT"
-S=$(find "$OUT/stats" -name "*_results.db" | head -1)
-F=$(find "$OUT/fetch" -name "*_results.db" | head -1)
-W=$(find "$OUT/write" -name "*_results.db" | head -1)
+S=$(find "$OUT/stats" -name "*_results.db" -printf "%s %p\n" | sort -nr | head -1 | cut -d" " -f2-)
+F=$(find "$OUT/fetch" -name "*_results.db" -printf "%s %p\n" | sort -nr | head -1 | cut -d" " -f2-)
+W=$(find "$OUT/write" -name "*_results.db" -printf "%s %p\n" | sort -nr | head -1 | cut -d" " -f2-)
 python tools/rocpd_summary.py "$S" > "$OUT/summary_stats.md"
 python tools/kernel_dispatch_csv.py "$S" "$HEAD" "$OUT/${TAG}_products_headline_dispatches.csv"
 python tools/rocpd_summary.py "$F" "$W" > "$OUT/summary_pmc.md"
@@ -27,7 +28,7 @@ python tools/rocpd_summary.py "$F" "$W" > "$OUT/summary_pmc.md"
 cd /tmp
 rocprofv3 --kernel-trace --stats -d "$OUT/stats2" -- $B --steps 20 --warmup 5 > /dev/null 2> "$OUT/stats2.err"
 cd "$ROOT"
-S2=$(find "$OUT/stats2" -name "*_results.db" | head -1)
+S2=$(find "$OUT/stats2" -name "*_results.db" -printf "%s %p\n" | sort -nr | head -1 | cut -d" " -f2-)
 python tools/make_pmc_json.py "$F" "$W" "$S2" "$HEAD" "$OUT/${TAG}_products_pmc.json" products
 python tools/make_pmc_json.py "$F" "$W" "$S2" "$TAIL" "$OUT/${TAG}_products_edge_tail_pmc.json" products
 rm -rf "$OUT/stats" "$OUT/stats2" "$OUT/fetch" "$OUT/write"

@@ -4,7 +4,7 @@ cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
 for which in "$@"; do
   d=/tmp/prof_$which; rm -rf $d
   rocprofv3 --kernel-trace --stats -d $d -o r -- python tools/r06/profile_layer_fwd_bwd.py $which 5 > /tmp/prof_$which.log 2>&1
-  db=$(find $d -name "*.db" | head -1)
+  db=$(find $d -name "*.db" -printf "%s %p\n" | sort -nr | head -1 | cut -d" " -f2-)
   python tools/rocpd_summary.py $db > gpurun_out/r06_trace_$which.md
   head -32 gpurun_out/r06_trace_$which.md | cut -c1-200
 done
