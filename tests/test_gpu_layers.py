@@ -651,3 +651,20 @@ def test_layer_losses_collect_the_regularisers_as_keras_does(tfg, oracle):
     extra = (gk - gcn.kernel.grad).cpu().numpy()       # d/dW of 5e-4 * |W|^2 / 2 = 5e-4 * W
     assert np.allclose(extra, 5e-4 * kernel, atol=1e-7)
     assert torch.isfinite(gcn.bias.grad).all()
+
+
+@pytest.mark.parametrize("m,k,n,act_cols", [(5000, 602, 160, 160), (4100, 301, 144, 130), (4096, 257, 288, 100), (6000, 1433, 192, 192)])
+def test_gemm_short_column_remainder_runs_as_a_second_product(tfg, oracle, m, k, n, act_cols):
+    """N = q * 128 + r with r <= 64 on a long, unaligned K (round 6): the first q * 128 columns and the remainder are two
+    launches (no half-empty last tile column); bias, ReLU and the column-limited activation land in the right columns."""
+    from tf_geometric_amd.plan import gemm_bias_act
+    rng = np.random.Generator(np.random.PCG64(m + n))
+    a = rng.standard_normal((m, k), dtype=np.float32)
+    b = oracle.glorot_uniform(rng, k, n)
+    bias = (rng.standard_normal(n) * 0.1).astype(np.float32)
+    got = gemm_bias_act(a, b, bias=bias, act=1, act_cols=act_cols).cpu().numpy()
+    ref = oracle.matmul(a, b) + bias
+    ref[:, :act_cols] = np.maximum(ref[:, :act_cols], 0)
+    assert_parity(got, ref, what="gemm {}x{}x{} (act_cols {})".format(m, k, n, act_cols))
+    if act_cols < n:
+        assert (got[:, act_cols:] < 0).any()

@@ -1702,6 +1702,19 @@ extern "C" int tfgx_gemm_bias_act_cols_ws_f32(const float* A, int64_t lda, const
         }
 #undef TFGX_ROWS_CASE
     }
+    // N = q * 128 + r with a SHORT remainder (r <= 64: 160, 144, 288 ...): the 128-column tiles would multiply a last tile column
+    // that is 50 % or more padding (N = 160: 3/8 of all MFMA work).  The first q * 128 columns and the remainder are two products
+    // — A is streamed once more, the remainder on a 32- / 64-column tile: 233 k x 602 -> 160 0.66 -> 0.51 ms (hipBLASLt 0.48).
+    // Long K only: on a short K the second pass over A costs what the padding did.
+    if (N > 128 && N % 128 != 0 && N % 128 <= 64 && K >= 256 && M >= 4096) {
+        const int64_t n_main = N - N % 128;
+        int rc = tfgx_gemm_bias_act_cols_ws_f32(A, lda, B, ldb, bias, act, act_cols < n_main ? act_cols : n_main, C, ldc, M, K,
+                                                n_main, workspace, workspace_bytes, stream_);
+        if (rc != TFGX_OK) return rc;
+        return tfgx_gemm_bias_act_cols_ws_f32(A, lda, B + n_main, ldb, bias ? bias + n_main : nullptr, act,
+                                              act_cols > n_main ? act_cols - n_main : 0, C + n_main, ldc, M, K, N - n_main,
+                                              workspace, workspace_bytes, stream_);
+    }
     // small M with a long K leaves most CUs idle: split K over blockIdx.y when the caller lent a workspace
     int splits = splitk_factor(generic_tiles(M, N), K);
     float* ws = static_cast<float*>(workspace);
