@@ -67,8 +67,17 @@ __global__ __launch_bounds__(kBlock) void gemm_kernel(const float* __restrict__ 
     constexpr int B_THREADS_PER_ROW = BN / 4;
     constexpr int LDA_S = BM + 1, LDB_S = BN + 4;   // +1: spreads the transposed A stores over banks
 
-    __shared__ __attribute__((aligned(16))) float As[BK * LDA_S];
-    __shared__ __attribute__((aligned(16))) float Bs[BK * LDB_S];
+#ifndef TFGX_GEMM_DOUBLE_LDS
+#define TFGX_GEMM_DOUBLE_LDS 0       // developer A/B: 1 = two LDS stages, ONE barrier per k tile.  Measured and dropped (round 6, same
+#endif                               // box, alternating with hipBLASLt): 170 k x 1433 -> 256 1.103 -> 1.140 ms, 233 k x 602 -> 128
+                                     // 0.367 -> 0.382, 2.4 M x 101 -> 256 1.578 -> 1.673 — 3-6 % slower on every shape of the sweep
+    // two LDS stages: tile t + 1 is written into the other stage at the START of step t (its global loads were issued a whole
+    // step earlier), so a step is store -> loads of t + 2 -> MFMAs of t -> one barrier instead of two
+    constexpr int STAGES = TFGX_GEMM_DOUBLE_LDS ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) float As_all[STAGES * BK * LDA_S];
+    __shared__ __attribute__((aligned(16))) float Bs_all[STAGES * BK * LDB_S];
+    float* As = As_all;
+    float* Bs = Bs_all;
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
@@ -200,10 +209,13 @@ __global__ __launch_bounds__(kBlock) void gemm_kernel(const float* __restrict__ 
     };
 
     // one BK-deep tile: registers -> LDS, barrier, the global loads of tile k_next into the SAME registers, multiply, barrier
-    auto one_tile = [&](int k0, int k_next, RegsA& ra, RegsB& rb) {
-        store_tiles(ra, rb);
-        __syncthreads();
-        if (k_next < K) load_tiles(k_next, ra, rb);
+    // (DOUBLE: the tile is already in the current stage; only the multiply and the closing barrier)
+    auto one_tile = [&](int k0, int k_next, RegsA& ra, RegsB& rb, auto dbl) {
+        if constexpr (!decltype(dbl)::value) {
+            store_tiles(ra, rb);
+            __syncthreads();
+            if (k_next < K) load_tiles(k_next, ra, rb);
+        }
         const int kh = lane >> 5, l31 = lane & 31;
         const int kmax = min(BK, K - k0);   // the zero-padded tail of the last tile is skipped, not multiplied
         auto kstep = [&](int kk) {
@@ -279,7 +291,27 @@ __global__ __launch_bounds__(kBlock) void gemm_kernel(const float* __restrict__ 
         }
         __syncthreads();
     };
-    if constexpr (AHEAD && TFGX_GEMM_PREFETCH_TILES == 2) {
+    if constexpr (STAGES == 2) {
+        RegsA ra;
+        RegsB rb;
+        load_tiles(0, ra, rb);
+        store_tiles(ra, rb);                      // stage 0
+        __syncthreads();
+        if (BK < K) load_tiles(BK, ra, rb);
+        int stage = 0;
+        for (int k0 = 0; k0 < K; k0 += BK) {
+            if (k0 + BK < K) {                    // tile t + 1 into the other stage (last read two steps ago, a barrier since)
+                As = As_all + (stage ^ 1) * BK * LDA_S;
+                Bs = Bs_all + (stage ^ 1) * BK * LDB_S;
+                store_tiles(ra, rb);
+            }
+            if (k0 + 2 * BK < K) load_tiles(k0 + 2 * BK, ra, rb);
+            As = As_all + stage * BK * LDA_S;
+            Bs = Bs_all + stage * BK * LDB_S;
+            one_tile(k0, k0 + BK, ra, rb, std::true_type{});
+            stage ^= 1;
+        }
+    } else if constexpr (AHEAD && TFGX_GEMM_PREFETCH_TILES == 2) {
         // two register stages: the loads of tile t + 2 are issued when tile t starts multiplying, so they have two tiles of
         // MFMA time (not one) to come back from HBM before store_tiles waits for them
         RegsA ra0, ra1;
@@ -287,14 +319,14 @@ __global__ __launch_bounds__(kBlock) void gemm_kernel(const float* __restrict__ 
         load_tiles(0, ra0, rb0);
         if (BK < K) load_tiles(BK, ra1, rb1);
         for (int k0 = 0; k0 < K; k0 += 2 * BK) {
-            one_tile(k0, k0 + 2 * BK, ra0, rb0);
-            if (k0 + BK < K) one_tile(k0 + BK, k0 + 3 * BK, ra1, rb1);
+            one_tile(k0, k0 + 2 * BK, ra0, rb0, std::false_type{});
+            if (k0 + BK < K) one_tile(k0 + BK, k0 + 3 * BK, ra1, rb1, std::false_type{});
         }
     } else {
         RegsA ra;
         RegsB rb;
         load_tiles(0, ra, rb);
-        for (int k0 = 0; k0 < K; k0 += BK) one_tile(k0, k0 + BK, ra, rb);
+        for (int k0 = 0; k0 < K; k0 += BK) one_tile(k0, k0 + BK, ra, rb, std::false_type{});
     }
     if (kTwoLevel) {
         if (two_level) {
