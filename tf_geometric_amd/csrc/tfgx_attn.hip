@@ -273,9 +273,22 @@ __device__ __forceinline__ float head_dot(const float (&qreg)[D > 0 ? D : 1], co
                                       // output epilogue (ISA read: no scratch access inside the edge loops).  At 4 (98 VGPRs, no scratch) the
                                       // Reddit-shape A = 64 attention runs 6.45 instead of 5.77 ms, the one-pass walk at products density
                                       // 10.27 instead of 9.89 ms (same box, profiles/r06_gat_d8_waves.jsonl): the fifth wave is worth more
-template <int VEC, int G, int D, bool POW2 = false>
+// KS ("K split", round 6; d == dv in {8, 16}, 16-byte aligned K rows): the d floats of a head's K / Q slice are DISTRIBUTED over
+// the head's d / 4 lanes — lane `sub` of the head holds floats [4 sub, 4 sub + 4) — instead of every lane of the head loading
+// the whole slice.  One dwordx4 per lane then covers the K row contiguously: at A = 64 (8 heads x 8) ONE load instruction
+// touches the row's 2 lines, where two instructions each touched both (4 line REQUESTS for 2 lines; the L2s serve requests,
+// not lines — see tfgx_backward.hip's head blocks).  The score is the sum of the lanes' partial dots (one or two DPP adds).
+template <int CTRL>
+__device__ __forceinline__ float attn_dpp_f32(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+
+template <int VEC, int G, int D, bool POW2 = false, bool KS = false>
 __global__ __launch_bounds__(kBlock, (D > 0 && D <= 4) ? 5 : (D == 8 ? TFGX_GAT_D8_WAVES : 1)) void gat_fused_kernel(const GArgs a)
 {
+    static_assert(!KS || (VEC == 4 && (D == 8 || D == 16)), "KS: d == dv in {8, 16}, 4 columns per lane");
+    constexpr int DL = KS ? 4 : D;                 // floats of the head's slice this lane holds
     constexpr int ROWS_PER_BLOCK = kBlock / G;
 #ifndef TFGX_GAT_ONE_EXP
 #define TFGX_GAT_ONE_EXP 1            // developer A/B: 0 = two exponentials per edge (exp(m - mn), exp(sc - mn))
@@ -293,7 +306,15 @@ __global__ __launch_bounds__(kBlock, (D > 0 && D <= 4) ? 5 : (D == 8 ? TFGX_GAT_
     const bool cvalid = c_raw < a.W;
     const int coff = cvalid ? c_raw : (a.W - VEC);
     const int head = coff / a.dv;
-    const int hoff = head * a.d;
+    const int hoff = head * a.d + (KS ? (coff - head * a.dv) : 0);        // KS: this lane's 4 floats of the slice (d == dv)
+    // the score of an edge from this lane's (partial) dot product
+    auto lane_sum = [](float s) {
+        if constexpr (KS) {
+            s += attn_dpp_f32<0xB1>(s);                                     // quad_perm [1,0,3,2]: the other lane of the pair
+            if constexpr (D == 16) s += attn_dpp_f32<0x4E>(s);             // quad_perm [2,3,0,1]: the other pair of the quad
+        }
+        return s;
+    };
 
     for (int64_t r = int64_t(blockIdx.x) * ROWS_PER_BLOCK + grp; r < a.n_dst;
          r += int64_t(gridDim.x) * ROWS_PER_BLOCK) {
@@ -303,10 +324,10 @@ __global__ __launch_bounds__(kBlock, (D > 0 && D <= 4) ? 5 : (D == 8 ? TFGX_GAT_
         if (a.hub_threshold > 0 && e - s > a.hub_threshold) continue;   // chunked + merged separately
         r = a.part_row ? int64_t(a.part_row[part]) : part;
         const float* qp = a.q + r * a.ldq + hoff;
-        float qreg[D > 0 ? D : 1];
+        float qreg[DL > 0 ? DL : 1];
         if constexpr (D > 0) {
 #pragma unroll
-            for (int t = 0; t < D; ++t) qreg[t] = qp[t];
+            for (int t = 0; t < DL; ++t) qreg[t] = qp[t];
         }
         // `l` is the softmax denominator WITHOUT the running maximum's own term exp(0) = 1: sum over the OTHER edges of
         // exp(score - m).  A peaked row (one score 15 above the rest) has l_full = 1.025: kept whole, every later term of
@@ -396,7 +417,7 @@ __global__ __launch_bounds__(kBlock, (D > 0 && D <= 4) ? 5 : (D == 8 ? TFGX_GAT_
 #pragma unroll
                     for (int u = 0; u < UNROLL; ++u) {
                         const int c = __shfl(cj, j + u, G);
-                        sc[u] = scaled(pow2, head_dot<D>(qreg, qp, a.k + row_off(c, ldk32) + hoff, a.d, a.kvec));
+                        sc[u] = scaled(pow2, lane_sum(head_dot<DL>(qreg, qp, a.k + row_off(c, ldk32) + hoff, a.d, a.kvec)));
                         load_vec<VEC>(a.v + row_off(c, ldv32) + coff, vv[u]);
                     }
 #pragma unroll
@@ -404,7 +425,7 @@ __global__ __launch_bounds__(kBlock, (D > 0 && D <= 4) ? 5 : (D == 8 ? TFGX_GAT_
                 }
                 for (; j < cnt; ++j) {
                     const int c = __shfl(cj, j, G);
-                    const float sc = scaled(pow2, head_dot<D>(qreg, qp, a.k + row_off(c, ldk32) + hoff, a.d, a.kvec));
+                    const float sc = scaled(pow2, lane_sum(head_dot<DL>(qreg, qp, a.k + row_off(c, ldk32) + hoff, a.d, a.kvec)));
                     float vv[VEC];
                     load_vec<VEC>(a.v + row_off(c, ldv32) + coff, vv);
                     step(sc, vv, base + j);
@@ -425,7 +446,7 @@ __global__ __launch_bounds__(kBlock, (D > 0 && D <= 4) ? 5 : (D == 8 ? TFGX_GAT_
             continue;
         }
         if (a.add_self_loop) {  // the appended (r, r) edge comes last (graph_utils.py:350-366)
-            const float dot = head_dot<D>(qreg, qp, a.k + r * a.ldk + hoff, a.d, a.kvec);
+            const float dot = lane_sum(head_dot<DL>(qreg, qp, a.k + r * a.ldk + hoff, a.d, a.kvec));
             const float sc = scaled(pow2, dot);
             float vv[VEC];
             load_vec<VEC>(a.v + r * a.ldv + coff, vv);
@@ -523,6 +544,16 @@ __global__ __launch_bounds__(kBlock) void gat_merge_kernel(const GMerge g)
     }
 }
 
+inline bool gat_k_split()           // developer A/B: TFGX_GAT_K_SPLIT=0 -> every lane of a head loads the head's whole K slice
+{
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("TFGX_GAT_K_SPLIT");
+        v = (e != nullptr && atoi(e) == 0) ? 0 : 1;
+    }
+    return v != 0;
+}
+
 template <int VEC, int G>
 int launch_gat_d(const GArgs& a, hipStream_t stream)
 {
@@ -530,6 +561,7 @@ int launch_gat_d(const GArgs& a, hipStream_t stream)
     dim3 grid(grid_for(a.n_dst, ROWS_PER_BLOCK, 1 << 20), (a.W + G * VEC - 1) / (G * VEC), 1);
     dim3 block(kBlock, 1, 1);
     const bool pow2 = a.inv_scale != 0.0f;      // only d = 1, 4, 16 have the multiply instantiated; every other d divides
+    const bool ks = gat_k_split() && a.d == a.dv && a.kvec && (a.d == 8 || a.d == 16) && (a.W / 4) % (a.d / 4) == 0;
     switch (a.d) {
 #define TFGX_GAT_POW2_CASE(D_)                                                                   \
     case D_:                                                                                     \
@@ -539,8 +571,19 @@ int launch_gat_d(const GArgs& a, hipStream_t stream)
         TFGX_GAT_POW2_CASE(1);
         case 2: gat_fused_kernel<VEC, G, 2><<<grid, block, 0, stream>>>(a); break;
         TFGX_GAT_POW2_CASE(4);
-        case 8: gat_fused_kernel<VEC, G, 8><<<grid, block, 0, stream>>>(a); break;
-        TFGX_GAT_POW2_CASE(16);
+        case 8:
+            if constexpr (VEC == 4) {
+                if (ks) { gat_fused_kernel<VEC, G, 8, false, true><<<grid, block, 0, stream>>>(a); break; }
+            }
+            gat_fused_kernel<VEC, G, 8><<<grid, block, 0, stream>>>(a);
+            break;
+        case 16:
+            if constexpr (VEC == 4) {
+                if (ks && pow2) { gat_fused_kernel<VEC, G, 16, true, true><<<grid, block, 0, stream>>>(a); break; }
+            }
+            if (pow2) gat_fused_kernel<VEC, G, 16, true><<<grid, block, 0, stream>>>(a);
+            else gat_fused_kernel<VEC, G, 16, false><<<grid, block, 0, stream>>>(a);
+            break;
 #undef TFGX_GAT_POW2_CASE
         case 32: gat_fused_kernel<VEC, G, 32><<<grid, block, 0, stream>>>(a); break;
         default: gat_fused_kernel<VEC, G, 0><<<grid, block, 0, stream>>>(a); break;
