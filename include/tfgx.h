@@ -48,8 +48,9 @@ enum { TFGX_NORM_BOTH = 0, TFGX_NORM_LEFT = 1, TFGX_NORM_RIGHT = 2 };
  * (tfgx_reduce_args.hub_order_slot; tfgx_aggregate_gemm_f32 honours args->out as a side output of the aggregate;
  * tfgx_gat_args / tfgx_gat_backward_args .drop_seed_dev); 111 = + tfgx_column_sum_f32; 112 = round 5 (+ tfgx_split_rows_verify_f32, tfgx_reduce_args.wide_blocks, tfgx_gat_args.state_in_*, tfgx_gat_backward_args.span_*);
  * 113 = round 6 (+ tfgx_gat_backward_args.head_pack / ld_head_pack, tfgx_gat_pack_dst_heads_f32,
- * tfgx_pool_mlp_max_wgrad_*). */
-#define TFGX_ABI_VERSION 113
+ * tfgx_pool_mlp_max_wgrad_*); 114 = + tfgx_gat_args.qgrad_t / qgrad_s / state_t / state_s / state_in_t / state_in_s,
+ * tfgx_gat_query_grad_d1_f32. */
+#define TFGX_ABI_VERSION 114
 int tfgx_version(void);            /* the TFGX_ABI_VERSION the library was built with */
 const char* tfgx_last_error(void); /* host string, thread-local, valid until the next failing call */
 
@@ -293,6 +294,23 @@ typedef struct tfgx_gat_args {
        attention runs 1.5x faster.  Not combinable with drop_rate > 0 or the hub lists. */
     const float* state_in_acc;     /* [n_parts, H*dv] */
     const float* state_in_ml;      /* [n_parts, 2*H]  */
+    /* optional (round 6, ABI 114; d == 1 only — the demo's literal layer GAT(units, num_heads=8, attention_units=8),
+       demo/demo_gat.py:22): the sums the QUERY gradient needs, accumulated by the same walk out of the K and V values it
+       holds anyway:
+         qgrad_t[r, h*dv + j] = sum_e a_e keep_e K[c_e, h] V[c_e, h*dv + j]        qgrad_s[r, h] = sum_e a_e K[c_e, h]
+       so that dQ[r, h] = sum_e a_e (keep_e <dO[r,h,:], V[c_e,h,:]> - D[r,h]) K[c_e, h] / scale
+                        = (<dO[r,h,:], qgrad_t[r,h,:]> - D[r,h] qgrad_s[r,h]) / scale          (tfgx_gat_query_grad_d1_f32)
+       is a per-ROW expression and the backward's destination pass (tfgx_gat_backward_dst_*: a second walk over every edge
+       that gathers K and V again) is not run.  A finishing launch writes both (dense rows, 16-byte aligned); a raw-state
+       launch (state_acc != NULL) carries the un-normalised sums in state_t / state_s and a resumed one reads
+       state_in_t / state_in_s — same indexing as state_acc / [n_parts, H].  All NULL = not computed.  Needs dv % 4 == 0 and
+       16-byte aligned V / out rows; not combinable with the hub lists. */
+    float* qgrad_t;                /* [n_dst, H*dv] */
+    float* qgrad_s;                /* [n_dst, H] */
+    float* state_t;                /* [n_parts, H*dv] */
+    float* state_s;                /* [n_parts, H] */
+    const float* state_in_t;       /* [n_parts, H*dv] */
+    const float* state_in_s;       /* [n_parts, H] */
 } tfgx_gat_args;
 
 /* 1 if the item survives dropout at `rate`, else 0: the exact decision every kernel of this library makes for
@@ -503,6 +521,12 @@ int tfgx_gat_pack_dst_f32(const float* grad_out, int64_t ld_grad_out, const floa
 int tfgx_gat_pack_dst_heads_f32(const float* grad_out, int64_t ld_grad_out, const float* out, int64_t ldo, const float* q,
                                 int64_t ldq, const float* stats_ml /* [n_dst, 2H] */, int64_t n_dst, int32_t H, int32_t d,
                                 int32_t dv, float* pack, int64_t ld_pack, float* dsum /* [n_dst, H] */, tfgx_stream_t stream);
+/* d == 1 (ABI 114): dQ out of the forward's sums (tfgx_gat_args.qgrad_t / qgrad_s) instead of the destination pass:
+   grad_q[r, h] = (<grad_out[r, h, :], qgrad_t[r, h, :]> - dsum[r, h] * qgrad_s[r, h]) / scale, dsum = <dO, O> per head as
+   tfgx_gat_pack_dst*_f32 writes it.  Replaces the dQ the reference's tape derives from gat.py:73-89. */
+int tfgx_gat_query_grad_d1_f32(const float* grad_out, int64_t ld_grad_out, const float* qgrad_t, int64_t ld_t,
+                               const float* qgrad_s /* [n_dst, H] */, const float* dsum /* [n_dst, H] */, int64_t n_dst,
+                               int32_t H, int32_t dv, float scale, float* grad_q, int64_t ld_grad_q, tfgx_stream_t stream);
 int tfgx_gat_backward_dst_f32(const tfgx_gat_backward_args* args /* host */, tfgx_stream_t stream);
 int tfgx_gat_backward_src_f32(const tfgx_gat_backward_args* args /* host */, tfgx_stream_t stream);
 /* the same passes on a graph with hub rows: `hub` = chunk lists of the forward plan (dst pass) / of the transposed plan

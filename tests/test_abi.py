@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), "libtfgx.so does not export {}".format(name)
     assert set(names) == set(_lib.SIGNATURES), "ctypes table and header disagree: {}".format(
         set(names) ^ set(_lib.SIGNATURES))
-    assert lib.tfgx_version() == 113          # include/tfgx.h TFGX_ABI_VERSION == _lib.ABI_VERSION
+    assert lib.tfgx_version() == 114          # include/tfgx.h TFGX_ABI_VERSION == _lib.ABI_VERSION
 
 
 def test_structs_match_header_layout(tmp_path):

@@ -324,6 +324,59 @@ def test_gat_layer_grads(tfg, oracle, heads, att, units):
         assert_parity(getattr(layer, k).grad.cpu().numpy(), r[k].grad.numpy(), tol=2e-4, what="gat d/d" + k)
 
 
+@pytest.mark.parametrize("blocks", [None, 5])
+@pytest.mark.parametrize("drop", [0.0, 0.4])
+def test_gat_query_gradient_from_the_forward_sums(tfg, oracle, blocks, drop):
+    """One attention unit per head (the demo's literal layer): the training forward accumulates T = sum a k V and S = sum a k,
+    dQ = (<dO, T> - D S) / scale per row — against the destination pass (the same inputs with the route switched off: the
+    forward must be bit-identical, dQ equal to rounding) and against float64 autograd."""
+    from tf_geometric_amd.nn.conv import gat as G
+    from tf_geometric_amd import autograd as AG
+    from tf_geometric_amd.plan import CsrPlan
+    if blocks is not None and drop > 0.0:
+        pytest.skip("source blocks run without attention dropout")
+    rng = np.random.default_rng(77)
+    n, e, H, dv = 500, 30000, 8, 8
+    ei = np.stack([rng.integers(0, n, e), rng.integers(0, n, e)]).astype(np.int32)
+    plan = CsrPlan.from_cache(ei, n, n, {})
+    Qn, Kn, Vn = (rng.standard_normal((n, H)).astype(np.float32) * 1.5, rng.standard_normal((n, H)).astype(np.float32) * 1.5,
+                  rng.standard_normal((n, H * dv)).astype(np.float32))
+    gout = torch.tensor(rng.standard_normal((n, H * dv)).astype(np.float32), device="cuda")
+
+    def run(on):
+        Q, K, V = (torch.tensor(t, device="cuda", requires_grad=True) for t in (Qn, Kn, Vn))
+        before = G.SOURCE_BLOCK_STATS.get("query_sum_backwards", 0)
+        G.QUERY_GRAD_SUMS, G.SOURCE_BLOCKS = on, blocks
+        try:
+            out = AG.gat_attention(plan, Q, K, V, H, drop_rate=drop, drop_seed=1234)
+            out.backward(gout)
+        finally:
+            G.QUERY_GRAD_SUMS, G.SOURCE_BLOCKS = True, None
+        assert G.SOURCE_BLOCK_STATS.get("query_sum_backwards", 0) == before + (1 if on else 0)
+        return out.detach(), Q.grad, K.grad, V.grad
+
+    o1, q1, k1, v1 = run(True)
+    o0, q0, k0, v0 = run(False)
+    assert torch.equal(o1, o0) and torch.equal(k1, k0) and torch.equal(v1, v0)
+    scale = float(q0.abs().max())
+    # two float32 evaluations of the same sums in different association (measured beside float64, tools/r06/diag_query_sums.py:
+    # 1.6e-5 / 1.1e-5 off at this shape, whose softmaxes are peaked — scores of std 2 — and whose largest |dQ| is 5)
+    assert float((q1 - q0).abs().max()) <= 5e-6 * max(scale, 1.0), (float((q1 - q0).abs().max()), scale)
+    if drop == 0.0:      # float64 autograd of the reference's formulation (gat.py:73-89 with the self-loop appended)
+        Q, K, V = (torch.tensor(t, dtype=torch.float64, requires_grad=True) for t in (Qn, Kn, Vn))
+        row = torch.cat([torch.tensor(ei[0]).long(), torch.arange(n)])
+        col = torch.cat([torch.tensor(ei[1]).long(), torch.arange(n)])
+        s = Q[row] * K[col]                                                     # d = 1: scale sqrt(1)
+        mx = torch.full((n, H), -float("inf"), dtype=torch.float64).scatter_reduce(0, row[:, None].expand(-1, H), s.detach(), "amax")
+        ex = torch.exp(s - mx[row])
+        den = torch.zeros((n, H), dtype=torch.float64).index_add(0, row, ex) + 1e-8
+        alpha = ex / den[row]
+        out = torch.zeros((n, H, dv), dtype=torch.float64).index_add(0, row, alpha[:, :, None] * V[col].reshape(-1, H, dv))
+        out.reshape(n, H * dv).backward(gout.double().cpu())
+        assert_parity(o1.cpu().numpy(), out.detach().reshape(n, H * dv).numpy(), what="attention forward")
+        assert_parity(q1.cpu().numpy(), Q.grad.numpy(), tol=2e-5, what="dQ from the forward sums")
+
+
 def test_gat_layer_grads_in_source_blocks(tfg, oracle):
     """Training forward in chained source-block launches, destination pass (dQ) in source blocks and source pass (dK, dV) in
     destination blocks with the gradients accumulated block by block: outputs and every gradient against float64 autograd."""

@@ -762,13 +762,20 @@ def test_reddit_gat_backward_matches_float64_autograd(tfg, oracle, reddit, graph
     cache = {}
     plan = CsrPlan.from_cache(ei, n, n, cache)
     fw, bw = G_.SOURCE_BLOCK_STATS["launches"], G_.SOURCE_BLOCK_STATS.get("backward_launches", 0)
+    qs = G_.SOURCE_BLOCK_STATS.get("query_sum_backwards", 0)
     out, grads = _run_backward(layer, [x, ei], cache, Gup, x_grad=True)
     if graph == "uniform":
         kb = G_.source_block_count(plan, A, U)
         assert kb >= 2 and G_.SOURCE_BLOCK_STATS["launches"] == fw + kb                       # forward in source blocks
-        assert G_.SOURCE_BLOCK_STATS["backward_launches"] >= bw + kb + 2                      # dQ in source blocks + dK / dV in destination blocks
+        if A == H:     # one attention unit per head: dQ out of the forward's sums, dK / dV in destination blocks
+            assert G_.SOURCE_BLOCK_STATS.get("query_sum_backwards", 0) == qs + 1
+            assert G_.SOURCE_BLOCK_STATS["backward_launches"] >= bw + 2
+        else:          # dQ in source blocks + dK / dV in destination blocks
+            assert G_.SOURCE_BLOCK_STATS.get("query_sum_backwards", 0) == qs
+            assert G_.SOURCE_BLOCK_STATS["backward_launches"] >= bw + kb + 2
     else:
         assert plan.hub_info() is not None and G_.SOURCE_BLOCK_STATS["launches"] == fw        # hub route, no blocks
+        assert G_.SOURCE_BLOCK_STATS.get("query_sum_backwards", 0) == qs                      # ... and dQ from the destination pass
     tag = "Reddit-shape GAT A={} ({}) ".format(A, graph)
     # forward over ALL 14.9 M outputs.  The sampled-row test above holds 400 rows to the plain 1e-5; over every row the tail of
     # the float32 score error (d_head = 1: exp() of a product of two 602-term float32 dot products) reaches further, for ANY

@@ -26,7 +26,7 @@ class TfgxError(RuntimeError):
     pass
 
 
-ABI_VERSION = 113      # include/tfgx.h TFGX_ABI_VERSION: struct layouts / signatures bound below
+ABI_VERSION = 114      # include/tfgx.h TFGX_ABI_VERSION: struct layouts / signatures bound below
 
 
 class ReduceArgs(ctypes.Structure):
@@ -74,6 +74,8 @@ class GatArgs(ctypes.Structure):
         ("row_order", ctypes.c_void_p),
         ("drop_seed_dev", ctypes.c_void_p),
         ("state_in_acc", ctypes.c_void_p), ("state_in_ml", ctypes.c_void_p),
+        ("qgrad_t", ctypes.c_void_p), ("qgrad_s", ctypes.c_void_p), ("state_t", ctypes.c_void_p), ("state_s", ctypes.c_void_p),
+        ("state_in_t", ctypes.c_void_p), ("state_in_s", ctypes.c_void_p),
     ]
 
 
@@ -176,6 +178,7 @@ SIGNATURES = {
     "tfgx_dropout_keep": (ctypes.c_int32, [ctypes.c_uint64, ctypes.c_uint32, _F32]),
     "tfgx_permute_rows_f32": (ctypes.c_int, [_P, _P, _I64, _I64, _P, _P]),
     "tfgx_gat_pack_dst_f32": (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _I64, _P, _P]),
+    "tfgx_gat_query_grad_d1_f32": (ctypes.c_int, [_P, _I64, _P, _I64, _P, _P, _I64, _I32, _I32, ctypes.c_float, _P, _I64, _P]),
     "tfgx_gat_pack_dst_heads_f32": (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _I64, _P, _P]),
     "tfgx_relu_backward_f32": (ctypes.c_int, [_P, _I64, _P, _I64, _I64, _I64, _P, _I64, _P]),
     "tfgx_scatter_add_rows_f32": (ctypes.c_int, [_P, _I64, _P, _I64, _I64, _P, _I64, _P]),

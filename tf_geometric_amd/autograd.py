@@ -726,25 +726,34 @@ class _GatAttention(torch.autograd.Function):
     def forward(ctx, plan, num_heads, Q, K, V, drop_rate, drop_seed, scale_d=None, passes=None):
         """`passes` (the sharded path, dist/sharded.py::_gat_attention_spans): callable(Q, K, V, stats) -> out that runs the
         forward as span passes + merge under a halo exchange; same (out, stats), so the backward is unchanged."""
-        from .nn.conv.gat import gat_attention
+        from .nn.conv.gat import gat_attention, query_sums_apply, SOURCE_BLOCK_STATS
         stats = torch.empty((plan.n_dst, 2 * num_heads), dtype=torch.float32, device=V.device)
         ctx.halo_first = getattr(passes, "halo_first", None)   # (n_own, [(lo, hi) per round], callable(j, d[K | V])): see backward
+        qsums = None
         if passes is not None:
             assert float(drop_rate) == 0.0 and scale_d is None
             out = passes(Q.detach(), K.detach(), V.detach(), stats)
         else:
+            # one attention unit per head (the demo's literal layer): the walk also accumulates the two sums dQ is a per-row
+            # expression of (tfgx_gat_args.qgrad_t) — the backward then runs no destination pass
+            if ctx.needs_input_grad[2] and query_sums_apply(plan, Q, V, num_heads, float(drop_rate)):
+                qsums = (torch.empty((plan.n_dst, int(V.shape[1])), dtype=torch.float32, device=V.device),
+                         torch.empty((plan.n_dst, num_heads), dtype=torch.float32, device=V.device))
+                SOURCE_BLOCK_STATS["query_sum_forwards"] = SOURCE_BLOCK_STATS.get("query_sum_forwards", 0) + 1
             out = gat_attention(plan, Q.detach(), K.detach(), V.detach(), num_heads, True, stats_ml=stats,
-                                drop_rate=drop_rate, drop_seed=drop_seed, scale_d=scale_d)
+                                drop_rate=drop_rate, drop_seed=drop_seed, scale_d=scale_d, qsums=qsums)
         ctx.plan, ctx.H, ctx.drop = plan, num_heads, (float(drop_rate), drop_seed)      # (seed: host int or device tensor)
         ctx.scale_d = scale_d
-        ctx.save_for_backward(Q, K, V, out, stats)
+        ctx.has_qsums = qsums is not None
+        ctx.save_for_backward(Q, K, V, out, stats, *(qsums or ()))
         return out
 
     @staticmethod
     def backward(ctx, g):
         lib = L.require_gpu()
         plan, H = ctx.plan, ctx.H
-        Q, K, V, out, stats = ctx.saved_tensors
+        Q, K, V, out, stats = ctx.saved_tensors[:5]
+        qsums = ctx.saved_tensors[5:7] if ctx.has_qsums else None
         Q2, ldq = L.row_major_2d(Q.detach())
         K2, ldk = L.row_major_2d(K.detach())
         V2, ldv = L.row_major_2d(V.detach())
@@ -813,7 +822,12 @@ class _GatAttention(torch.autograd.Function):
                      V2.data_ptr() % 16 == 0 and g2.data_ptr() % 16 == 0)
         kb_d = source_block_count(plan, A, W) if blocks_ok else 1
         blk_d = plan.source_blocks(kb_d) if kb_d >= 2 else None
-        if blk_d is not None:
+        if qsums is not None:
+            # dQ from the forward's sums: (<dO, T> - D S) / scale per (row, head) — no walk over the edges
+            L.check(lib.tfgx_gat_query_grad_d1_f32(L.ptr(g2), ldg, L.ptr(qsums[0]), W, L.ptr(qsums[1]), L.ptr(dsum), n, H, W // H,
+                                                   a.scale, L.ptr(gq), A, L.stream_ptr()), "tfgx_gat_query_grad_d1_f32")
+            SOURCE_BLOCK_STATS["query_sum_backwards"] = SOURCE_BLOCK_STATS.get("query_sum_backwards", 0) + 1
+        elif blk_d is not None:
             rpk, col_k = blk_d
             for b in range(kb_d):
                 a.col = col_k.data_ptr()

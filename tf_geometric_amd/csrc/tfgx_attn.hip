@@ -221,6 +221,13 @@ struct GArgs {
     int32_t hub_threshold;
     float* stats_ml;      // [n_dst, 2H] final (m, l) for the backward pass, or NULL
     DropCfg drop;         // attention dropout (training): acc += p * keep_scale_or_0 * V; the denominator is untouched
+    // QG kernels only (tfgx_gat_args.qgrad_t): the query gradient's sums, final (normalised) or as raw state
+    float* qg_t;          // [n_dst, W]
+    float* qg_s;          // [n_dst, H]
+    float* state_t;       // [n_parts, W]
+    float* state_s;       // [n_parts, H]
+    const float* state_in_t;
+    const float* state_in_s;
 };
 
 // 1 / s when s is a power of two with a normal reciprocal: x * (1 / s) and x / s are then the same correctly rounded value
@@ -284,10 +291,16 @@ __device__ __forceinline__ float attn_dpp_f32(float v)
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
 }
 
-template <int VEC, int G, int D, bool POW2 = false, bool KS = false>
-__global__ __launch_bounds__(kBlock, (D > 0 && D <= 4) ? 5 : (D == 8 ? TFGX_GAT_D8_WAVES : 1)) void gat_fused_kernel(const GArgs a)
+// QG ("query gradient", round 6; d == 1 — the demo's literal layer, attention_units == num_heads): the walk also accumulates
+//   T[r, cols] = sum_e a_e keep_e K[c_e, h] V[c_e, cols]        S[r, h] = sum_e a_e K[c_e, h]
+// from the K and V values it has in registers anyway.  dQ[r, h] = sum_e ds_e K[c_e, h] / scale with ds_e = a_e (keep_e <dO, V_e> - D)
+// is then (<dO[r, h, :], T[r, h, :]> - D[r, h] S[r, h]) / scale, a per-ROW expression: the backward's destination pass — a second
+// walk over every edge that gathers K and V again, 2.55 of the Reddit-shaped layer's 9.7 ms — is not run (tfgx_gat_query_grad_d1_f32).
+template <int VEC, int G, int D, bool POW2 = false, bool KS = false, bool QG = false>
+__global__ __launch_bounds__(kBlock, (D > 0 && D <= 4) ? (QG ? 4 : 5) : (D == 8 ? TFGX_GAT_D8_WAVES : 1)) void gat_fused_kernel(const GArgs a)
 {
     static_assert(!KS || (VEC == 4 && (D == 8 || D == 16)), "KS: d == dv in {8, 16}, 4 columns per lane");
+    static_assert(!QG || (D == 1 && VEC == 4), "QG: one attention unit per head, 4 columns per lane");
     constexpr int DL = KS ? 4 : D;                 // floats of the head's slice this lane holds
     constexpr int ROWS_PER_BLOCK = kBlock / G;
 #ifndef TFGX_GAT_ONE_EXP
@@ -343,15 +356,22 @@ __global__ __launch_bounds__(kBlock, (D > 0 && D <= 4) ? 5 : (D == 8 ? TFGX_GAT_
         float acc[VEC];
 #pragma unroll
         for (int i = 0; i < VEC; ++i) acc[i] = 0.0f;
+        float acc_t[QG ? VEC : 1], s_k = 0.0f;       // QG: the raw T columns of this lane and the head's raw S
+#pragma unroll
+        for (int i = 0; i < (QG ? VEC : 1); ++i) acc_t[i] = 0.0f;
         if (a.state_in_acc) {   // resume the online softmax where the previous pass over this part left it
             load_vec<VEC>(a.state_in_acc + part * a.W + coff, acc);
             m = a.state_in_ml[part * 2 * a.H + 2 * head];
             l = a.state_in_ml[part * 2 * a.H + 2 * head + 1];
             l -= (m > -FLT_MAX) ? 1.0f : 0.0f;                        // stored whole (exact: 1 is a multiple of ulp(l_full))
+            if constexpr (QG) {
+                load_vec<VEC>(a.state_in_t + part * a.W + coff, acc_t);
+                s_k = a.state_in_s[part * a.H + head];
+            }
         }
         auto l_full = [&]() { return (l + ls) + ((m > -FLT_MAX) ? 1.0f : 0.0f); };
 
-        auto step = [&](float sc, const float (&vv)[VEC], int64_t pos) {
+        auto step = [&](float sc, const float (&vv)[VEC], int64_t pos, float kj = 0.0f) {
 #if TFGX_GAT_ONE_EXP
             // mn = max(m, sc): one of exp(m - mn), exp(sc - mn) is exp(0) = 1, the other exp(-|sc - m|) — ONE exponential per
             // edge (the loop is bound by vector-ALU issue, not by its gathers: ~55 instructions per edge, 25 of them the two
@@ -377,7 +397,22 @@ __global__ __launch_bounds__(kBlock, (D > 0 && D <= 4) ? 5 : (D == 8 ? TFGX_GAT_
             const float pk = p * drop_scale(a.drop, uint32_t(pos * a.H + head));
 #pragma unroll
             for (int i = 0; i < VEC; ++i) acc[i] = fmaf(acc[i], corr, pk * vv[i]);
+            if constexpr (QG) {
+                const float pkk = pk * kj;
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) acc_t[i] = fmaf(acc_t[i], corr, pkk * vv[i]);
+                s_k = fmaf(s_k, corr, p * kj);
+            }
             m = mn;
+        };
+        // one edge's score; QG (d == 1): the K value itself is kept for the sums above (q * k, the same product head_dot forms)
+        auto score_of = [&](const float* kp, float& kj) {
+            if constexpr (QG) {
+                kj = kp[0];
+                return qreg[0] * kj;
+            } else {
+                return lane_sum(head_dot<DL>(qreg, qp, kp, a.d, a.kvec));
+            }
         };
         // element offset of a gathered row as ONE 32 x 32 -> 64-bit multiply (v_mad_u64_u32): ids are non-negative int32 and
         // the leading dimensions fit 32 bits (checked at the entry point).  `int64_t(c) * a.ldk` made the compiler emulate a
@@ -412,23 +447,24 @@ __global__ __launch_bounds__(kBlock, (D > 0 && D <= 4) ? 5 : (D == 8 ? TFGX_GAT_
                 const int cnt = min(G, e - base);
                 int j = 0;
                 for (; j + UNROLL <= cnt; j += UNROLL) {
-                    float sc[UNROLL];
+                    float sc[UNROLL], kj[UNROLL];
                     float vv[UNROLL][VEC];
 #pragma unroll
                     for (int u = 0; u < UNROLL; ++u) {
                         const int c = __shfl(cj, j + u, G);
-                        sc[u] = scaled(pow2, lane_sum(head_dot<DL>(qreg, qp, a.k + row_off(c, ldk32) + hoff, a.d, a.kvec)));
+                        sc[u] = scaled(pow2, score_of(a.k + row_off(c, ldk32) + hoff, kj[u]));
                         load_vec<VEC>(a.v + row_off(c, ldv32) + coff, vv[u]);
                     }
 #pragma unroll
-                    for (int u = 0; u < UNROLL; ++u) step(sc[u], vv[u], base + j + u);
+                    for (int u = 0; u < UNROLL; ++u) step(sc[u], vv[u], base + j + u, kj[u]);
                 }
                 for (; j < cnt; ++j) {
                     const int c = __shfl(cj, j, G);
-                    const float sc = scaled(pow2, lane_sum(head_dot<DL>(qreg, qp, a.k + row_off(c, ldk32) + hoff, a.d, a.kvec)));
+                    float kj;
+                    const float sc = scaled(pow2, score_of(a.k + row_off(c, ldk32) + hoff, kj));
                     float vv[VEC];
                     load_vec<VEC>(a.v + row_off(c, ldv32) + coff, vv);
-                    step(sc, vv, base + j);
+                    step(sc, vv, base + j, kj);
                 }
                 l += ls;                 // fold the batch (see the declaration of l)
                 ls = 0.0f;
@@ -441,16 +477,21 @@ __global__ __launch_bounds__(kBlock, (D > 0 && D <= 4) ? 5 : (D == 8 ? TFGX_GAT_
                     a.state_ml[part * 2 * a.H + 2 * head] = m;
                     a.state_ml[part * 2 * a.H + 2 * head + 1] = l_full();
                 }
+                if constexpr (QG) {
+                    store_vec<VEC>(a.state_t + part * a.W + coff, acc_t);
+                    if (coff % a.dv == 0) a.state_s[part * a.H + head] = s_k;
+                }
             }
             r = idx;            // restore the loop variable
             continue;
         }
         if (a.add_self_loop) {  // the appended (r, r) edge comes last (graph_utils.py:350-366)
-            const float dot = lane_sum(head_dot<DL>(qreg, qp, a.k + r * a.ldk + hoff, a.d, a.kvec));
+            float kj;
+            const float dot = score_of(a.k + r * a.ldk + hoff, kj);
             const float sc = scaled(pow2, dot);
             float vv[VEC];
             load_vec<VEC>(a.v + r * a.ldv + coff, vv);
-            step(sc, vv, a.drop.self_base + r);
+            step(sc, vv, a.drop.self_base + r, kj);
         }
         if (a.stats_ml && cvalid && (coff % a.dv == 0)) {
             a.stats_ml[r * 2 * a.H + 2 * head] = m;
@@ -466,6 +507,13 @@ __global__ __launch_bounds__(kBlock, (D > 0 && D <= 4) ? 5 : (D == 8 ? TFGX_GAT_
                 res[i] = apply_act(o, a.act);
             }
             store_vec<VEC>(a.out + r * a.ldo + coff, res);
+            if constexpr (QG) {
+                float t_[VEC];
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) t_[i] = acc_t[i] / den;
+                store_vec<VEC>(a.qg_t + r * a.W + coff, t_);
+                if (coff % a.dv == 0) a.qg_s[r * a.H + head] = s_k / den;
+            }
         }
         r = idx;
     }
@@ -562,6 +610,16 @@ int launch_gat_d(const GArgs& a, hipStream_t stream)
     dim3 block(kBlock, 1, 1);
     const bool pow2 = a.inv_scale != 0.0f;      // only d = 1, 4, 16 have the multiply instantiated; every other d divides
     const bool ks = gat_k_split() && a.d == a.dv && a.kvec && (a.d == 8 || a.d == 16) && (a.W / 4) % (a.d / 4) == 0;
+    if (a.qg_t != nullptr || a.state_t != nullptr) {         // the entry point has checked d == 1 and VEC == 4
+        if constexpr (VEC == 4) {
+            if (pow2) gat_fused_kernel<VEC, G, 1, true, false, true><<<grid, block, 0, stream>>>(a);
+            else gat_fused_kernel<VEC, G, 1, false, false, true><<<grid, block, 0, stream>>>(a);
+            TFGX_LAUNCH_CHECK("gat_fused_kernel (query-gradient sums)");
+            return TFGX_OK;
+        } else {
+            return TFGX_ERR_INVALID_ARG;
+        }
+    }
     switch (a.d) {
 #define TFGX_GAT_POW2_CASE(D_)                                                                   \
     case D_:                                                                                     \
@@ -702,6 +760,23 @@ extern "C" int tfgx_gat_fused_f32(const tfgx_gat_args* p, tfgx_stream_t stream_)
     TFGX_REQUIRE(p->state_in_acc == nullptr || (p->drop_rate == 0.0f && !(p->hub_threshold > 0 && p->n_hub_rows > 0 && p->state_acc == nullptr)),
                  "state_in cannot be combined with attention dropout or the hub lists");
     a.stats_ml = p->stats_ml;
+    a.qg_t = p->qgrad_t; a.qg_s = p->qgrad_s; a.state_t = p->state_t; a.state_s = p->state_s;
+    a.state_in_t = p->state_in_t; a.state_in_s = p->state_in_s;
+    const bool qg = p->qgrad_t || p->qgrad_s || p->state_t || p->state_s || p->state_in_t || p->state_in_s;
+    if (qg) {
+        TFGX_REQUIRE(p->d == 1, "the query-gradient sums (qgrad_t / state_t) exist for d == 1 only");
+        TFGX_REQUIRE(!(p->hub_threshold > 0 && p->n_hub_rows > 0 && p->state_acc == nullptr),
+                     "the query-gradient sums cannot be combined with the hub lists");
+        if (p->state_acc) TFGX_REQUIRE(p->state_t && p->state_s && !p->qgrad_t && !p->qgrad_s,
+                                       "a raw-state launch carries the sums in state_t / state_s");
+        else TFGX_REQUIRE(p->qgrad_t && p->qgrad_s && !p->state_t && !p->state_s, "a finishing launch writes qgrad_t and qgrad_s");
+        TFGX_REQUIRE((p->state_in_acc != nullptr) == (p->state_in_t != nullptr) && (p->state_in_t != nullptr) == (p->state_in_s != nullptr),
+                     "state_in_t / state_in_s go with state_in_acc");
+        TFGX_REQUIRE(p->state_in_t == nullptr || (p->state_in_t != p->state_t && p->state_in_s != p->state_s),
+                     "the resumed sums must not alias the sums being written");
+        TFGX_REQUIRE(aligned_to(p->qgrad_t, 16) && aligned_to(p->state_t, 16) && aligned_to(p->state_in_t, 16),
+                     "qgrad_t / state_t must be 16-byte aligned");
+    }
     a.row_order = (p->state_acc == nullptr && p->row_begin == nullptr) ? p->row_order : nullptr;
     if (p->state_acc) {
         // raw-state launches over arbitrary PARTS (tfgx.h): hub_chunk_row, when given, names the destination (Q row) of
@@ -735,7 +810,9 @@ extern "C" int tfgx_gat_fused_f32(const tfgx_gat_args* p, tfgx_stream_t stream_)
         if (vec == 2) return launch_gat<2>(g, stream);
         return launch_gat<1>(g, stream);
     };
-    int rc = launch(a, p->state_acc ? vec_for(p->state_acc, W) : vec_for(p->out, p->ldo));
+    const int vec_main = p->state_acc ? vec_for(p->state_acc, W) : vec_for(p->out, p->ldo);
+    TFGX_REQUIRE(!qg || vec_main == 4, "the query-gradient sums need dv % 4 == 0 and 16-byte aligned V / out rows");
+    int rc = launch(a, vec_main);
     if (rc != TFGX_OK || !use_hub) return rc;
 
     // hub rows: raw state per chunk, then ordered merge (+ self loop, bias, activation)

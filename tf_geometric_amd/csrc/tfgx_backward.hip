@@ -996,6 +996,27 @@ __global__ __launch_bounds__(kBlock) void gat_pack_dst_heads_kernel(const float*
     }
 }
 
+// d == 1: dQ[r, h] = (<dO[r, h, :], T[r, h, :]> - D[r, h] S[r, h]) / scale from the sums the forward walk accumulated
+// (gat_fused_kernel's QG mode) — one thread per (row, head), sequential dv-term dot as D itself is formed.
+__global__ __launch_bounds__(kBlock) void gat_query_grad_d1_kernel(const float* __restrict__ go, int64_t ldgo,
+                                                                   const float* __restrict__ t, int64_t ldt,
+                                                                   const float* __restrict__ s, const float* __restrict__ dsum,
+                                                                   int64_t n, int H, int dv, float scale,
+                                                                   float* __restrict__ gq, int64_t ldgq)
+{
+    int64_t i = blockIdx.x * int64_t(kBlock) + threadIdx.x;
+    const int64_t stride = int64_t(gridDim.x) * kBlock;
+    for (; i < n * H; i += stride) {
+        const int64_t r = i / H;
+        const int h = int(i - r * H);
+        const float* gp = go + r * ldgo + h * dv;
+        const float* tp = t + r * ldt + h * dv;
+        float acc = 0.0f;
+        for (int j = 0; j < dv; ++j) acc = fmaf(gp[j], tp[j], acc);
+        gq[r * ldgq + h] = fmaf(-dsum[i], s[i], acc) / scale;
+    }
+}
+
 // POW2: a.inv_scale is the exact inverse of a power-of-two scale (instantiated for d = 1, 4, 16, where sqrt(d) is one)
 // HP (src pass only): the per-head scalars of the gathered destination come from a.hp (head blocks, see above)
 template <int G, int D, bool SRC, bool POW2 = false, bool HP = false>
@@ -1592,6 +1613,21 @@ static int fill_gb(const tfgx_gat_backward_args* p, GB& a)
                      "head_pack: rows of H * roundup4(d + 3) floats, 16-byte aligned, row stride a multiple of 4 below 2^31");
         a.hp = p->head_pack; a.ldhp = p->ld_head_pack;
     }
+    return TFGX_OK;
+}
+
+extern "C" int tfgx_gat_query_grad_d1_f32(const float* grad_out, int64_t ld_grad_out, const float* qgrad_t, int64_t ld_t,
+                                          const float* qgrad_s, const float* dsum, int64_t n_dst, int32_t H, int32_t dv,
+                                          float scale, float* grad_q, int64_t ld_grad_q, tfgx_stream_t stream)
+{
+    TFGX_RANGE();
+    TFGX_REQUIRE(n_dst >= 0 && H >= 1 && dv >= 1 && scale > 0.0f, "bad n_dst / H / dv / scale");
+    if (n_dst == 0) return TFGX_OK;
+    TFGX_REQUIRE(grad_out && qgrad_t && qgrad_s && dsum && grad_q, "null pointer");
+    TFGX_REQUIRE(ld_grad_out >= int64_t(H) * dv && ld_t >= int64_t(H) * dv && ld_grad_q >= H, "leading dimension too small");
+    gat_query_grad_d1_kernel<<<grid_for(n_dst * H, kBlock), kBlock, 0, as_stream(stream)>>>(
+        grad_out, ld_grad_out, qgrad_t, ld_t, qgrad_s, dsum, n_dst, H, dv, scale, grad_q, ld_grad_q);
+    TFGX_LAUNCH_CHECK("gat_query_grad_d1_kernel");
     return TFGX_OK;
 }
 

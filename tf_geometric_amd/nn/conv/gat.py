@@ -8,6 +8,7 @@ vector (:79) are never materialised; the N self-loop edges of add_self_loop_edge
 """
 import ctypes
 import math
+import os
 
 import torch
 
@@ -159,7 +160,7 @@ def source_block_count(plan, A, W):
     return kb if kb >= 2 else 1
 
 
-def _gat_attention_source_blocks(plan, blocks, KB, Q, K, V, num_heads, add_self_loop, bias, act, stats_ml, scale_d):
+def _gat_attention_source_blocks(plan, blocks, KB, Q, K, V, num_heads, add_self_loop, bias, act, stats_ml, scale_d, qsums=None):
     """KB chained launches of tfgx_gat_fused_f32, launch b over the edges whose source lies in block b: the raw online-softmax
     state of every row is handed from launch to launch (tfgx_gat_args.state_in_*), the last launch appends the self-loop
     edge and finishes the rows.  Every launch gathers K / V rows of ONE block, which the L2 of every XCD then serves
@@ -171,8 +172,11 @@ def _gat_attention_source_blocks(plan, blocks, KB, Q, K, V, num_heads, add_self_
     dev = V.device
     bufs = [(torch.empty((n, W), dtype=torch.float32, device=dev), torch.empty((n, 2 * num_heads), dtype=torch.float32, device=dev))
             for _ in range(2 if KB > 2 else 1)]
+    # the query gradient's sums (tfgx_gat_args.qgrad_t) travel with the state
+    tbufs = [(torch.empty((n, W), dtype=torch.float32, device=dev), torch.empty((n, num_heads), dtype=torch.float32, device=dev))
+             for _ in bufs] if qsums is not None else None
     out = None
-    prev = None
+    prev = prev_t = None
     for b in range(KB):
         last = b == KB - 1
         a, o, keep = gat_args(Q, K, V, num_heads, n, col_k, add_self_loop if last else False, bias if last else None,
@@ -180,21 +184,43 @@ def _gat_attention_source_blocks(plan, blocks, KB, Q, K, V, num_heads, add_self_
         a.row_begin, a.row_end, a.rp_stride = rpk[b:].data_ptr(), rpk[b + 1:].data_ptr(), KB
         if prev is not None:
             a.state_in_acc, a.state_in_ml = prev[0].data_ptr(), prev[1].data_ptr()
+            if qsums is not None:
+                a.state_in_t, a.state_in_s = prev_t[0].data_ptr(), prev_t[1].data_ptr()
         if last:
             out = o
             if stats_ml is not None:
                 a.stats_ml = stats_ml.data_ptr()
+            if qsums is not None:
+                a.qgrad_t, a.qgrad_s = qsums[0].data_ptr(), qsums[1].data_ptr()
         else:
             cur = bufs[b % len(bufs)]
             a.state_acc, a.state_ml = cur[0].data_ptr(), cur[1].data_ptr()
             prev = cur
+            if qsums is not None:
+                prev_t = tbufs[b % len(bufs)]
+                a.state_t, a.state_s = prev_t[0].data_ptr(), prev_t[1].data_ptr()
         L.check(lib.tfgx_gat_fused_f32(ctypes.byref(a), L.stream_ptr()), "tfgx_gat_fused_f32")
     SOURCE_BLOCK_STATS["launches"] += KB
     return out
 
 
+QUERY_GRAD_SUMS = os.environ.get("TFGX_GAT_QUERY_SUMS", "1") != "0"   # developer A/B: 0 = dQ always from the backward's destination pass
+
+
+def query_sums_apply(plan, Q, V, num_heads, drop_rate=0.0):
+    """True when the training forward can accumulate the query gradient's sums (tfgx_gat_args.qgrad_t: one attention unit
+    per head, 4-column lanes, no hub lists) — the backward then needs no destination pass."""
+    A, W = int(Q.shape[1]), int(V.shape[1])
+    if not QUERY_GRAD_SUMS or A != num_heads or W % num_heads or (W // num_heads) % 4 or plan.n_dst == 0:
+        return False
+    if drop_rate <= 0.0 and plan.hub_info() is not None:
+        return False
+    V2, ldv = L.row_major_2d(V)
+    return ldv % 4 == 0 and V2.data_ptr() % 16 == 0
+
+
 def gat_attention(plan, Q, K, V, num_heads, add_self_loop=True, bias=None, act=L.ACT_NONE, stats_ml=None,
-                  drop_rate=0.0, drop_seed=0, scale_d=None):
+                  drop_rate=0.0, drop_seed=0, scale_d=None, qsums=None):
     """Fused SDDMM + edge softmax + SpMM over `plan` (tfgx_gat_fused_f32). Q:[n_dst,A] K:[n_src,A] V:[n_src,W].
     Destinations with very many in-edges (plan.hub_info()) are processed chunk-wise and merged.
     drop_rate > 0 (training): the softmax weights are dropped / rescaled inside the kernel (gat.py:85); the keep
@@ -204,7 +230,8 @@ def gat_attention(plan, Q, K, V, num_heads, add_self_loop=True, bias=None, act=L
         KB = source_block_count(plan, int(Q.shape[1]), int(V.shape[1]))
         blocks = plan.source_blocks(KB) if KB >= 2 else None
         if blocks is not None:
-            return _gat_attention_source_blocks(plan, blocks, KB, Q, K, V, num_heads, add_self_loop, bias, act, stats_ml, scale_d)
+            return _gat_attention_source_blocks(plan, blocks, KB, Q, K, V, num_heads, add_self_loop, bias, act, stats_ml, scale_d,
+                                                qsums)
     a, out, keep = gat_args(Q, K, V, num_heads, plan.n_dst, plan.col, add_self_loop, bias, act, scale_d=scale_d)
     a.row_ptr = plan.row_ptr.data_ptr()
     order = plan.row_order()                 # skewed graphs: rows of similar length share a wave
@@ -212,6 +239,8 @@ def gat_attention(plan, Q, K, V, num_heads, add_self_loop=True, bias=None, act=L
         a.row_order = order.data_ptr()
     if stats_ml is not None:
         a.stats_ml = stats_ml.data_ptr()      # (m, l) per row and head, kept for the backward pass
+    if qsums is not None:                     # (T, S): see query_sums_apply
+        a.qgrad_t, a.qgrad_s = qsums[0].data_ptr(), qsums[1].data_ptr()
     if drop_rate > 0.0:
         _set_drop(a, drop_rate, drop_seed, plan.num_edges)
     hub = plan.hub_info() if drop_rate <= 0.0 else None      # the chunk-merge path has no dropout; long rows run inline
