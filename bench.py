@@ -1128,6 +1128,9 @@ def baseline_configs(tfg, L, synthetic, x, ei, n, e, f, cache, seed):
         probe = line_rate_probe(block_mib)
         return {"layer": "GAT(64, num_heads=8, attention_units={}) on N={} E={} F={}".format(A, nr, er_real, fr),
                 "forward_ms": ms_f, "fwd_bwd_ms": ms_t, "fwd_bwd_over_forward": ms_t / ms_f,
+                "backward": ("dQ per row from the sums the training forward accumulates (tfgx_gat_args.qgrad_t: one attention unit "
+                             "per head), dK / dV in one source pass over destination blocks" if A == H else
+                             "dQ in a destination pass over source blocks, dK / dV in a source pass over destination blocks"),
                 "dominant_launch": "tfgx_gat_fused_f32 -> gat_fused_kernel (scores + online softmax + value sum), {} chained "
                                    "launches over source blocks of {:.1f} MiB".format(kb, block_mib),
                 "attention_alone_ms": ms_att,

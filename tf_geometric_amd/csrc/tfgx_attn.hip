@@ -296,8 +296,24 @@ __device__ __forceinline__ float attn_dpp_f32(float v)
 // from the K and V values it has in registers anyway.  dQ[r, h] = sum_e ds_e K[c_e, h] / scale with ds_e = a_e (keep_e <dO, V_e> - D)
 // is then (<dO[r, h, :], T[r, h, :]> - D[r, h] S[r, h]) / scale, a per-ROW expression: the backward's destination pass — a second
 // walk over every edge that gathers K and V again, 2.55 of the Reddit-shaped layer's 9.7 ms — is not run (tfgx_gat_query_grad_d1_f32).
+#ifndef TFGX_GAT_STATE_NT
+#define TFGX_GAT_STATE_NT 0           // developer A/B: 0 = the chained raw state is loaded / stored like any other row
+#endif
+#if TFGX_GAT_STATE_NT
+#define TFGX_STATE_LOAD load_vec_nt
+#define TFGX_STATE_STORE store_vec_nt
+#else
+#define TFGX_STATE_LOAD load_vec
+#define TFGX_STATE_STORE store_vec
+#endif
+#ifndef TFGX_GAT_QG_EXPERIMENT
+#define TFGX_GAT_QG_EXPERIMENT 0      // TIMING ONLY (wrong sums): 1 = the sums are not carried through the chained state, 2 = not accumulated
+#endif
+#ifndef TFGX_GAT_QG_WAVES
+#define TFGX_GAT_QG_WAVES 4           // developer A/B: waves per SIMD the QG kernels are compiled for (110 VGPRs as written)
+#endif
 template <int VEC, int G, int D, bool POW2 = false, bool KS = false, bool QG = false>
-__global__ __launch_bounds__(kBlock, (D > 0 && D <= 4) ? (QG ? 4 : 5) : (D == 8 ? TFGX_GAT_D8_WAVES : 1)) void gat_fused_kernel(const GArgs a)
+__global__ __launch_bounds__(kBlock, (D > 0 && D <= 4) ? (QG ? TFGX_GAT_QG_WAVES : 5) : (D == 8 ? TFGX_GAT_D8_WAVES : 1)) void gat_fused_kernel(const GArgs a)
 {
     static_assert(!KS || (VEC == 4 && (D == 8 || D == 16)), "KS: d == dv in {8, 16}, 4 columns per lane");
     static_assert(!QG || (D == 1 && VEC == 4), "QG: one attention unit per head, 4 columns per lane");
@@ -312,7 +328,10 @@ __global__ __launch_bounds__(kBlock, (D > 0 && D <= 4) ? (QG ? 4 : 5) : (D == 8 
 #ifndef TFGX_GAT_UNROLL_NARROW
 #define TFGX_GAT_UNROLL_NARROW 4      // developer A/B: edges in flight per lane group when a head's K slice is <= 4 floats
 #endif
-    constexpr int UNROLL = (D > 0 && D <= 4) ? TFGX_GAT_UNROLL_NARROW : 4;
+#ifndef TFGX_GAT_QG_UNROLL
+#define TFGX_GAT_QG_UNROLL 4          // developer A/B: edges in flight per lane group in the QG kernels
+#endif
+    constexpr int UNROLL = QG ? TFGX_GAT_QG_UNROLL : ((D > 0 && D <= 4) ? TFGX_GAT_UNROLL_NARROW : 4);
     const int lane = threadIdx.x % G;
     const int grp = threadIdx.x / G;
     const int c_raw = (blockIdx.y * G + lane) * VEC;
@@ -360,12 +379,12 @@ __global__ __launch_bounds__(kBlock, (D > 0 && D <= 4) ? (QG ? 4 : 5) : (D == 8 
 #pragma unroll
         for (int i = 0; i < (QG ? VEC : 1); ++i) acc_t[i] = 0.0f;
         if (a.state_in_acc) {   // resume the online softmax where the previous pass over this part left it
-            load_vec<VEC>(a.state_in_acc + part * a.W + coff, acc);
+            TFGX_STATE_LOAD<VEC>(a.state_in_acc + part * a.W + coff, acc);
             m = a.state_in_ml[part * 2 * a.H + 2 * head];
             l = a.state_in_ml[part * 2 * a.H + 2 * head + 1];
             l -= (m > -FLT_MAX) ? 1.0f : 0.0f;                        // stored whole (exact: 1 is a multiple of ulp(l_full))
-            if constexpr (QG) {
-                load_vec<VEC>(a.state_in_t + part * a.W + coff, acc_t);
+            if constexpr (QG && TFGX_GAT_QG_EXPERIMENT != 1) {
+                TFGX_STATE_LOAD<VEC>(a.state_in_t + part * a.W + coff, acc_t);
                 s_k = a.state_in_s[part * a.H + head];
             }
         }
@@ -397,7 +416,7 @@ __global__ __launch_bounds__(kBlock, (D > 0 && D <= 4) ? (QG ? 4 : 5) : (D == 8 
             const float pk = p * drop_scale(a.drop, uint32_t(pos * a.H + head));
 #pragma unroll
             for (int i = 0; i < VEC; ++i) acc[i] = fmaf(acc[i], corr, pk * vv[i]);
-            if constexpr (QG) {
+            if constexpr (QG && TFGX_GAT_QG_EXPERIMENT != 2) {
                 const float pkk = pk * kj;
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) acc_t[i] = fmaf(acc_t[i], corr, pkk * vv[i]);
@@ -447,16 +466,20 @@ __global__ __launch_bounds__(kBlock, (D > 0 && D <= 4) ? (QG ? 4 : 5) : (D == 8 
                 const int cnt = min(G, e - base);
                 int j = 0;
                 for (; j + UNROLL <= cnt; j += UNROLL) {
-                    float sc[UNROLL], kj[UNROLL];
+                    float sc[UNROLL], kj[QG ? UNROLL : 1];
                     float vv[UNROLL][VEC];
 #pragma unroll
                     for (int u = 0; u < UNROLL; ++u) {
                         const int c = __shfl(cj, j + u, G);
-                        sc[u] = scaled(pow2, score_of(a.k + row_off(c, ldk32) + hoff, kj[u]));
+                        if constexpr (QG) kj[u] = a.k[row_off(c, ldk32) + hoff];    // the score is formed where it is used: one
+                        else sc[u] = scaled(pow2, score_of(a.k + row_off(c, ldk32) + hoff, kj[0]));   // live register per edge, not two
                         load_vec<VEC>(a.v + row_off(c, ldv32) + coff, vv[u]);
                     }
 #pragma unroll
-                    for (int u = 0; u < UNROLL; ++u) step(sc[u], vv[u], base + j + u, kj[u]);
+                    for (int u = 0; u < UNROLL; ++u) {
+                        if constexpr (QG) step(scaled(pow2, qreg[0] * kj[u]), vv[u], base + j + u, kj[u]);
+                        else step(sc[u], vv[u], base + j + u);
+                    }
                 }
                 for (; j < cnt; ++j) {
                     const int c = __shfl(cj, j, G);
@@ -472,13 +495,13 @@ __global__ __launch_bounds__(kBlock, (D > 0 && D <= 4) ? (QG ? 4 : 5) : (D == 8 
         }
         if (a.state_acc) {      // raw state of this part; the self-loop edge is added by the merge
             if (cvalid) {
-                store_vec<VEC>(a.state_acc + part * a.W + coff, acc);
+                TFGX_STATE_STORE<VEC>(a.state_acc + part * a.W + coff, acc);
                 if (coff % a.dv == 0) {
                     a.state_ml[part * 2 * a.H + 2 * head] = m;
                     a.state_ml[part * 2 * a.H + 2 * head + 1] = l_full();
                 }
-                if constexpr (QG) {
-                    store_vec<VEC>(a.state_t + part * a.W + coff, acc_t);
+                if constexpr (QG && TFGX_GAT_QG_EXPERIMENT != 1) {
+                    TFGX_STATE_STORE<VEC>(a.state_t + part * a.W + coff, acc_t);
                     if (coff % a.dv == 0) a.state_s[part * a.H + head] = s_k;
                 }
             }

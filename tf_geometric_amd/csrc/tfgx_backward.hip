@@ -1019,8 +1019,11 @@ __global__ __launch_bounds__(kBlock) void gat_query_grad_d1_kernel(const float* 
 
 // POW2: a.inv_scale is the exact inverse of a power-of-two scale (instantiated for d = 1, 4, 16, where sqrt(d) is one)
 // HP (src pass only): the per-head scalars of the gathered destination come from a.hp (head blocks, see above)
+#ifndef TFGX_GAT_BWD_SRC_WAVES
+#define TFGX_GAT_BWD_SRC_WAVES 1      // developer A/B: waves per SIMD the head-block source pass of narrow heads is compiled for
+#endif
 template <int G, int D, bool SRC, bool POW2 = false, bool HP = false>
-__global__ __launch_bounds__(kBlock) void gat_backward_fast_kernel(const GB a)
+__global__ __launch_bounds__(kBlock, (SRC && HP && D <= 4) ? TFGX_GAT_BWD_SRC_WAVES : 1) void gat_backward_fast_kernel(const GB a)
 {
     constexpr int VEC = 4;
     constexpr int ROWS_PER_BLOCK = kBlock / G;
@@ -1190,13 +1193,25 @@ __global__ __launch_bounds__(kBlock) void gat_backward_fast_kernel(const GB a)
         if (SRC) {
             if (cvalid) {
                 float* gvp = a.gv + part * a.ldgv + coff;
+#ifndef TFGX_GAT_BWD_ACC_NT
+#define TFGX_GAT_BWD_ACC_NT 0         // developer A/B: 0 = the block-by-block gradient accumulation uses plain loads / stores
+#endif
                 if (a.accumulate) {                                 // blocks are applied in order: previous blocks + this one
                     float prev[VEC];
+#if TFGX_GAT_BWD_ACC_NT
+                    load_vec_nt<VEC>(gvp, prev);                    // streamed once per launch: kept out of the gathered rows' way
+#else
                     load_vec<VEC>(gvp, prev);
+#endif
 #pragma unroll
                     for (int i = 0; i < VEC; ++i) acc_v[i] = prev[i] + acc_v[i];
                 }
+#if TFGX_GAT_BWD_ACC_NT
+                if (a.rp_stride > 1) store_vec_nt<VEC>(gvp, acc_v);
+                else store_vec<VEC>(gvp, acc_v);
+#else
                 store_vec<VEC>(gvp, acc_v);
+#endif
             }
         }
         if (head_first) {

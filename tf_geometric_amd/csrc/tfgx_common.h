@@ -94,6 +94,32 @@ __device__ __forceinline__ void store_vec(float* p, const float (&v)[VEC])
     *reinterpret_cast<T*>(p) = t;
 }
 
+// Streamed-once rows (the raw softmax state chained between source-block launches, gradients accumulated block by block): loaded /
+// stored NON-TEMPORALLY, so that they do not displace the gathered rows the launch keeps in the L2s.
+typedef float tfgx_f32x4 __attribute__((ext_vector_type(4)));
+typedef float tfgx_f32x2 __attribute__((ext_vector_type(2)));
+template <int VEC>
+__device__ __forceinline__ void load_vec_nt(const float* p, float (&v)[VEC])
+{
+    if constexpr (VEC == 1) { v[0] = __builtin_nontemporal_load(p); }
+    if constexpr (VEC == 2) { const tfgx_f32x2 t = __builtin_nontemporal_load(reinterpret_cast<const tfgx_f32x2*>(p)); v[0] = t[0]; v[1] = t[1]; }
+    if constexpr (VEC == 4) {
+        const tfgx_f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const tfgx_f32x4*>(p));
+        v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+    }
+}
+
+template <int VEC>
+__device__ __forceinline__ void store_vec_nt(float* p, const float (&v)[VEC])
+{
+    if constexpr (VEC == 1) { __builtin_nontemporal_store(v[0], p); }
+    if constexpr (VEC == 2) { tfgx_f32x2 t; t[0] = v[0]; t[1] = v[1]; __builtin_nontemporal_store(t, reinterpret_cast<tfgx_f32x2*>(p)); }
+    if constexpr (VEC == 4) {
+        tfgx_f32x4 t; t[0] = v[0]; t[1] = v[1]; t[2] = v[2]; t[3] = v[3];
+        __builtin_nontemporal_store(t, reinterpret_cast<tfgx_f32x4*>(p));
+    }
+}
+
 // ---- dropout decisions: a pure function of (seed, item), so the forward kernel, both backward kernels and the host
 // (tfgx_dropout_keep, used by the tests) regenerate the same mask.  murmur3 finaliser over item ^ seed_lo, mixed with
 // seed_hi between the two multiplies; keep <=> top 24 bits >= rate * 2^24.
