@@ -27,6 +27,9 @@
 namespace tfgx {
 namespace {
 
+#ifndef TFGX_POOL_LOAD_ORDER
+#define TFGX_POOL_LOAD_ORDER 1        // developer A/B: 0 = the gathers of a step are issued before its id / scalar loads
+#endif
 #ifndef TFGX_POOL_EXPERIMENT
 #define TFGX_POOL_EXPERIMENT 0      // developer A/B, TIMING ONLY (wrong results): 1 = no LDS reads / FMAs, 2 = no gather of x rows
 #endif
@@ -90,6 +93,7 @@ __global__ void pool_item_fill_kernel(const int32_t* __restrict__ row_ptr, int64
 }
 
 typedef float float2v __attribute__((ext_vector_type(2)));
+typedef float float4v __attribute__((ext_vector_type(4)));   // (arrays of HIP's float4 struct were left in scratch once their loads lost their branches)
 
 template <int KMAX>       // accumulators per thread: F_in + 1 <= KMAX
 __global__ __launch_bounds__(512, 1) void pool_wgrad_kernel(const PoolArgs a)
@@ -118,10 +122,10 @@ __global__ __launch_bounds__(512, 1) void pool_wgrad_kernel(const PoolArgs a)
         // a work item: edges [s, s + len) of row `row`, the chunk starting `off` edges into the row; row == r_end: none left
         struct Item { int64_t row; int s; int len; int off; };
         const int item_begin = a.item_ptr[blockIdx.x], item_end = a.item_ptr[blockIdx.x + 1];
-        auto fetch = [&](int i) {                // the raw 16 bytes of item i (a load every thread issues: one request per wave)
+        auto fetch = [&](int i) __attribute__((always_inline)) {                // the raw 16 bytes of item i (a load every thread issues: one request per wave)
             return (i < item_end) ? a.items[i] : make_int4(-1, 0, 0, 0);
         };
-        auto decode = [&](const int4& v) {
+        auto decode = [&](const int4& v) __attribute__((always_inline)) {
             Item it;
             const int row = __builtin_amdgcn_readfirstlane(v.x);
             it.row = row < 0 ? r_end : int64_t(row);
@@ -130,25 +134,32 @@ __global__ __launch_bounds__(512, 1) void pool_wgrad_kernel(const PoolArgs a)
             it.off = __builtin_amdgcn_readfirstlane(v.w);
             return it;
         };
-        auto load_ids = [&](const Item& it, int (&ids)[kPoolSlots]) {
+        // NO LOAD OF THE LOOP IS PREDICATED.  A load under a per-lane branch (`if (slot < len) v = p[..]`) is an exec-masked block
+        // of its own, and the compiler's wait-count pass then drains vmcnt(0) at the next use of ANY loaded value — the ISA of the
+        // predicated form waited for the gathers of chunk i + 2 in the middle of step i, right after issuing them: one chunk in
+        // flight, every step a full gather latency.  Slots past the chunk's end load the chunk's LAST edge again (same addresses
+        // as a live slot: no new lines), rows past the end load row n_dst - 1; the values are discarded by selects.
+        auto load_ids = [&](const Item& it, int (&ids)[kPoolSlots]) __attribute__((always_inline)) {
 #pragma unroll
-            for (int u = 0; u < kPoolSlots; ++u) ids[u] = (slot_e[u] < it.len) ? a.col[it.s + slot_e[u]] : 0;
+            for (int u = 0; u < kPoolSlots; ++u) ids[u] = a.col[it.s + max(min(slot_e[u], it.len - 1), 0)];
         };
-        auto load_x = [&](const Item& it, const int (&ids)[kPoolSlots], float4 (&xv)[kPoolSlots]) {
+        auto load_x = [&](const Item& it, const int (&ids)[kPoolSlots], float4v (&xv)[kPoolSlots]) __attribute__((always_inline)) {
+            (void)it;
 #pragma unroll
             for (int u = 0; u < kPoolSlots; ++u) {
-                xv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (slot_e[u] < it.len && TFGX_POOL_EXPERIMENT != 2)
-                    xv[u] = *reinterpret_cast<const float4*>(a.x + uint64_t(uint32_t(ids[u])) * uint64_t(a.ldx) + 4 * slot_q(u));
+                if (TFGX_POOL_EXPERIMENT != 2)
+                    xv[u] = *reinterpret_cast<const float4v*>(a.x + uint64_t(uint32_t(ids[u])) * uint64_t(a.ldx) + 4 * slot_q(u));
+                else
+                    xv[u] = float4v{0.f, 0.f, 0.f, 0.f};
             }
         };
-        auto commit = [&](const Item& it, int buf, const int (&ids)[kPoolSlots], const float4 (&xv)[kPoolSlots]) {
+        auto commit = [&](const Item& it, int buf, const int (&ids)[kPoolSlots], const float4v (&xv)[kPoolSlots]) __attribute__((always_inline)) {
             float* Xb = Xs + buf * kPoolChunk * XS;
             int* Cb = Cs + buf * kPoolChunk;
 #pragma unroll
             for (int u = 0; u < kPoolSlots; ++u) {
                 if (slot_e[u] < it.len) {
-                    *reinterpret_cast<float4*>(Xb + slot_e[u] * XS + 4 * slot_q(u)) = xv[u];
+                    *reinterpret_cast<float4v*>(Xb + slot_e[u] * XS + 4 * slot_q(u)) = xv[u];
                     if (slot_q(u) == 0) {
                         Cb[slot_e[u]] = ids[u];
                         Xb[slot_e[u] * XS + a.F_in] = 1.0f;               // the constant feature: its accumulator is the bias gradient
@@ -160,19 +171,26 @@ __global__ __launch_bounds__(512, 1) void pool_wgrad_kernel(const PoolArgs a)
         // packed array: gn = g where the maximum is unique and positive (ReLU under the max: a maximum of 0 passes nothing); a
         // tied maximum (count > 1) is walked exactly below (pos = -1, gn = g / count)
         struct Pair { int pos; float gn; float rv; };
-        auto load_pair = [&](const Item& it) {
+        struct RawPair { uint32_t pk; float rv; float gv; bool row_ok; };
+        // the row's three scalars are LOADED a step before they are used and DECODED at the use (decoding at the load made the
+        // step wait for them at once, and with them for every load issued before)
+        auto load_pair = [&](const Item& it) __attribute__((always_inline)) {
+            RawPair o;
+            const int64_t row = min(it.row, r_end - 1);                    // three unconditional loads (see above)
+            o.pk = uint32_t(a.packed[row * a.ldp + j]);
+            o.rv = a.red[row * a.ldr + j];
+            o.gv = a.g[row * a.ldg + j];
+            o.row_ok = it.row < r_end;
+            return o;
+        };
+        auto decode_pair = [&](const RawPair& w) __attribute__((always_inline)) {
             Pair o;
-            o.pos = 0; o.gn = 0.0f; o.rv = 0.0f;
-            if (it.row < r_end) {
-                const uint32_t pk = uint32_t(a.packed[it.row * a.ldp + j]);
-                const float rv = a.red[it.row * a.ldr + j];
-                const float gv = a.g[it.row * a.ldg + j];
-                const uint32_t cnt = pk >> 16;
-                if (cnt > 0u && rv > 0.0f) {
-                    if (cnt == 1u) { o.pos = int(pk & 0xFFFFu); o.gn = gv; }
-                    else { o.pos = -1; o.gn = gv / float(cnt); o.rv = rv; }
-                }
-            }
+            const uint32_t cnt = w.pk >> 16;
+            const bool live = w.row_ok && cnt > 0u && w.rv > 0.0f;
+            const bool tied = live && cnt > 1u;
+            o.pos = live ? (tied ? -1 : int(w.pk & 0xFFFFu)) : 0;
+            o.gn = live ? (tied ? w.gv / float(cnt) : w.gv) : 0.0f;
+            o.rv = tied ? w.rv : 0.0f;
             return o;
         };
 
@@ -187,10 +205,10 @@ __global__ __launch_bounds__(512, 1) void pool_wgrad_kernel(const PoolArgs a)
         Item it2 = decode(fetch(item_begin + 2));
         int4 raw3 = fetch(inext);                // decoded one step later: the load has a whole step to arrive
         int ids1[kPoolSlots], ids2[kPoolSlots], ids3[kPoolSlots];
-        float4 x1[kPoolSlots], x2[kPoolSlots];
+        float4v x1[kPoolSlots], x2[kPoolSlots];
         {
             int ids0[kPoolSlots];
-            float4 x0[kPoolSlots];
+            float4v x0[kPoolSlots];
             load_ids(it0, ids0);
             load_ids(it1, ids1);
             load_ids(it2, ids2);
@@ -198,16 +216,29 @@ __global__ __launch_bounds__(512, 1) void pool_wgrad_kernel(const PoolArgs a)
             load_x(it1, ids1, x1);
             commit(it0, 0, ids0, x0);
         }
-        Pair pr = load_pair(it0);
+        RawPair prw = load_pair(it0);
         __syncthreads();
         int buf = 0;
         while (it0.row < r_end) {
             const Item it3 = decode(raw3);
             raw3 = fetch(++inext);
+#if TFGX_POOL_LOAD_ORDER
+            // PROGRAM ORDER of the step's loads: vector-memory loads return in order (vmcnt), so whatever a later step waits for also
+            // waits for every load issued before it.  The x gathers of chunk i + 2 go LAST: the ids of chunk i + 3 and the (packed,
+            // red, g) scalars of row i + 1 — which the next step needs at its start — are then never queued behind a random gather
+            // (they were: every step began by waiting for the previous step's gathers, one chunk in flight at a time)
+            load_ids(it3, ids3);
+            const RawPair prw_n = load_pair(it1);
+            __builtin_amdgcn_sched_barrier(0);
+            load_x(it2, ids2, x2);              // two chunks ahead
+            __builtin_amdgcn_sched_barrier(0);
+#else
             load_x(it2, ids2, x2);              // two chunks ahead
             load_ids(it3, ids3);
-            const Pair pr_n = load_pair(it1);
+            const RawPair prw_n = load_pair(it1);
+#endif
             {
+                const Pair pr = decode_pair(prw);
                 const float* Xb = Xs + buf * kPoolChunk * XS;
                 const int rel = pr.pos - it0.off;
                 const bool in = pr.pos >= 0 && uint32_t(rel) < uint32_t(it0.len);       // the winner is staged in this chunk
@@ -242,7 +273,7 @@ __global__ __launch_bounds__(512, 1) void pool_wgrad_kernel(const PoolArgs a)
             __syncthreads();
             buf ^= 1;
             it0 = it1; it1 = it2; it2 = it3;
-            pr = pr_n;
+            prw = prw_n;
 #pragma unroll
             for (int u = 0; u < kPoolSlots; ++u) { ids1[u] = ids2[u]; ids2[u] = ids3[u]; x1[u] = x2[u]; }
         }

@@ -14,5 +14,5 @@ d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 print(d["ms_per_step"], d["roofline"]["frac"])
 for k, v in d.get("configs", {}).items():
     if isinstance(v, dict):
-        print(k, {a: round(b, 3) for a, b in v.items() if a.endswith("_ms")}, (v.get("roofline") or {}).get("bound"), (v.get("roofline") or {}).get("frac"))
+        print(k, {a: round(b, 3) for a, b in v.items() if a.endswith("_ms") and isinstance(b, (int, float))}, (v.get("roofline") or {}).get("bound"), (v.get("roofline") or {}).get("frac"))
 PY

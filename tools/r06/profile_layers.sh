@@ -8,3 +8,10 @@ for which in "$@"; do
   python tools/rocpd_summary.py $db > gpurun_out/r06_trace_$which.md
   head -32 gpurun_out/r06_trace_$which.md | cut -c1-200
 done
+# launch sequence of the last step(s): TFGX_SEQ=<n dispatches> bash tools/r06/profile_layers.sh maxpool
+if [ -n "${TFGX_SEQ:-}" ]; then
+  for which in "$@"; do
+    db=$(find /tmp/prof_$which -name "*.db" -printf "%s %p\n" | sort -nr | head -1 | cut -d" " -f2-)
+    python tools/rocpd_sequence.py $db $TFGX_SEQ > gpurun_out/r06_sequence_$which.md
+  done
+fi
