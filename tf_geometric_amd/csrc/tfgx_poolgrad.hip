@@ -27,6 +27,9 @@
 namespace tfgx {
 namespace {
 
+#ifndef TFGX_POOL_DEPTH
+#define TFGX_POOL_DEPTH 2             // developer A/B: chunks of gathered x rows in flight (2 or 3)
+#endif
 #ifndef TFGX_POOL_LOAD_ORDER
 #define TFGX_POOL_LOAD_ORDER 1        // developer A/B: 0 = the gathers of a step are issued before its id / scalar loads
 #endif
@@ -199,6 +202,40 @@ __global__ __launch_bounds__(512, 1) void pool_wgrad_kernel(const PoolArgs a)
         // the source ids run one chunk further ahead still.  (Three register bundles trading roles in a loop unrolled by three —
         // no register rotation at the end of a step — measured SLOWER: 28.5 vs 25.8 ms at products shape; two rows per step
         // — 128-edge spans, 7 load slots, one barrier for two work items — 24.0 vs 24.4 ms at 255 VGPRs: not kept.)
+#if TFGX_POOL_DEPTH == 3
+        // three chunks deep: the gathers of chunk i + 3 are issued in step i and written to LDS at the end of step i + 1
+        int inext = item_begin + 4;
+        Item it0 = decode(fetch(item_begin));
+        Item it1 = decode(fetch(item_begin + 1));
+        Item it2 = decode(fetch(item_begin + 2));
+        Item it3 = decode(fetch(item_begin + 3));
+        int4 raw4 = fetch(inext);
+        int ids1[kPoolSlots], ids2[kPoolSlots], ids3[kPoolSlots], ids4[kPoolSlots];
+        float4v x1[kPoolSlots], x2[kPoolSlots], x3[kPoolSlots];
+        {
+            int ids0[kPoolSlots];
+            float4v x0[kPoolSlots];
+            load_ids(it0, ids0);
+            load_ids(it1, ids1);
+            load_ids(it2, ids2);
+            load_ids(it3, ids3);
+            load_x(it0, ids0, x0);
+            load_x(it1, ids1, x1);
+            load_x(it2, ids2, x2);
+            commit(it0, 0, ids0, x0);
+        }
+        RawPair prw = load_pair(it0);
+        __syncthreads();
+        int buf = 0;
+        while (it0.row < r_end) {
+            const Item it4 = decode(raw4);
+            raw4 = fetch(++inext);
+            load_ids(it4, ids4);
+            const RawPair prw_n = load_pair(it1);
+            __builtin_amdgcn_sched_barrier(0);
+            load_x(it3, ids3, x3);              // three chunks ahead
+            __builtin_amdgcn_sched_barrier(0);
+#else
         int inext = item_begin + 3;
         Item it0 = decode(fetch(item_begin));
         Item it1 = decode(fetch(item_begin + 1));
@@ -222,7 +259,9 @@ __global__ __launch_bounds__(512, 1) void pool_wgrad_kernel(const PoolArgs a)
         while (it0.row < r_end) {
             const Item it3 = decode(raw3);
             raw3 = fetch(++inext);
-#if TFGX_POOL_LOAD_ORDER
+#endif
+#if TFGX_POOL_DEPTH == 3
+#elif TFGX_POOL_LOAD_ORDER
             // PROGRAM ORDER of the step's loads: vector-memory loads return in order (vmcnt), so whatever a later step waits for also
             // waits for every load issued before it.  The x gathers of chunk i + 2 go LAST: the ids of chunk i + 3 and the (packed,
             // red, g) scalars of row i + 1 — which the next step needs at its start — are then never queued behind a random gather
@@ -272,10 +311,16 @@ __global__ __launch_bounds__(512, 1) void pool_wgrad_kernel(const PoolArgs a)
             commit(it1, buf ^ 1, ids1, x1);
             __syncthreads();
             buf ^= 1;
-            it0 = it1; it1 = it2; it2 = it3;
             prw = prw_n;
+#if TFGX_POOL_DEPTH == 3
+            it0 = it1; it1 = it2; it2 = it3; it3 = it4;
+#pragma unroll
+            for (int u = 0; u < kPoolSlots; ++u) { ids1[u] = ids2[u]; ids2[u] = ids3[u]; ids3[u] = ids4[u]; x1[u] = x2[u]; x2[u] = x3[u]; }
+#else
+            it0 = it1; it1 = it2; it2 = it3;
 #pragma unroll
             for (int u = 0; u < kPoolSlots; ++u) { ids1[u] = ids2[u]; ids2[u] = ids3[u]; x1[u] = x2[u]; }
+#endif
         }
     }
     float* out = a.partial + int64_t(blockIdx.x) * (a.F_in + 1) * a.Fp;

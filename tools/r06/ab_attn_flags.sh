@@ -12,11 +12,12 @@ from tf_geometric_amd import _build
 os.utime(os.path.join(_build.CSRC, '$src'))
 _build.build(verbose=False)" 2>&1 | grep -v warning | tail -2
 }
-python tools/r06/time_gat.py base_a >> $out
+T="${TFGX_AB_SCRIPT:-tools/r06/time_gat.py}"
+python $T base_a >> $out
 rebuild "$flags"
-python tools/r06/time_gat.py "$tag" >> $out
+python $T "$tag" >> $out
 rebuild ""
-python tools/r06/time_gat.py base_b >> $out
+python $T base_b >> $out
 python - $out <<'PY'
 import json, sys
 for l in open(sys.argv[1]):
