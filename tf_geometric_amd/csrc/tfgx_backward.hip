@@ -1144,7 +1144,10 @@ __global__ __launch_bounds__(kBlock, (SRC && HP && D <= 4) ? TFGX_GAT_BWD_SRC_WA
 #ifndef TFGX_GAT_BWD_UNROLL_NARROW
 #define TFGX_GAT_BWD_UNROLL_NARROW 4  // developer A/B
 #endif
-        constexpr int U = (D <= 4) ? TFGX_GAT_BWD_UNROLL_NARROW : (D <= 16 ? 2 : 1);
+#ifndef TFGX_GAT_BWD_UNROLL_MID
+#define TFGX_GAT_BWD_UNROLL_MID 2     // developer A/B: edges in flight per lane group for d_head 8 / 16
+#endif
+        constexpr int U = (D <= 4) ? TFGX_GAT_BWD_UNROLL_NARROW : (D <= 16 ? TFGX_GAT_BWD_UNROLL_MID : 1);
 #ifndef TFGX_GAT_BWD_COL_AHEAD
 #define TFGX_GAT_BWD_COL_AHEAD 1      // developer A/B: 0 = every batch loads its own neighbour ids right before its gathers
 #endif

@@ -36,4 +36,12 @@ def fb():
 res = {"tag": sys.argv[1] if len(sys.argv) > 1 else "", "maxpool_fwd_bwd_ms": ev(fb)}
 with torch.no_grad():
     res["maxpool_forward_ms"] = ev(lambda: layer([x, ei, w1], cache=cache))
+if len(sys.argv) > 2 and sys.argv[2] == "hidden":        # the hidden-layer form: x carries a gradient too (winner masks, source-major apply)
+    xg = x.clone().requires_grad_(True)
+    def fb2():
+        for p_ in layer.parameters():
+            p_.grad = None
+        xg.grad = None
+        layer([xg, ei, w1], cache=cache).backward(g)
+    res["maxpool_hidden_layer_fwd_bwd_ms"] = ev(fb2)
 print(json.dumps(res))
