@@ -1060,15 +1060,6 @@ def baseline_configs(tfg, L, synthetic, x, ei, n, e, f, cache, seed):
             opt.step()
 
         ms_s = _time(step, steps=10, warmup=3)
-        # the same step replayed from ONE hipGraph (tfg.CapturedTrainStep): at this size a step is ~40 launches of 5-150 us
-        ms_cap = None
-        try:
-            opt_c = torch.optim.Adam(g0.parameters() + g1.parameters(), lr=1e-2, capturable=True)
-            cap_step = tfg.CapturedTrainStep(lambda: torch.nn.functional.cross_entropy(fwd()[idx], labels), opt_c)
-            ms_cap = _time(cap_step, steps=10, warmup=3)
-            del cap_step, opt_c
-        except Exception as ex:      # reported, never fatal for the line
-            ms_cap = "failed: {}".format(ex)
         ea_real = int(eia.shape[1])
         planA = CsrPlan.from_cache(eia, na, na, ca)
         balg0 = b_alg(ea_real + na, na, fa)           # layer 0 aggregates at the input width (128), layer 1 at 40
@@ -1086,7 +1077,7 @@ def baseline_configs(tfg, L, synthetic, x, ei, n, e, f, cache, seed):
         probe = line_rate_probe(table_mib)
         peak = probe.get(512)
         return {"model": "GCN(256, relu) -> GCN(40) on N={} E={} F={} (demo/demo_gcn.py:18-32)".format(na, ea_real, fa),
-                "forward_ms": ms_f, "train_step_ms": ms_s, "train_step_hipgraph_replay_ms": ms_cap,
+                "forward_ms": ms_f, "train_step_ms": ms_s,
                 "dominant_launch": "tfgx_aggregate_gemm_f32 -> agg_gemm_kernel<32, true> (A_hat x at 128 columns, x W fused)" if fused
                                    else "tfgx_segment_reduce_f32 + tfgx_gemm_bias_act_f32",
                 "layer1_aggregation_kernel": segment_reduce(planA, torch.empty((na, 40), device=dev), L.SUM,
