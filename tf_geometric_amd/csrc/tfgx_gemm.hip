@@ -1187,6 +1187,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
 struct TnDirectCfg {
     int S, WM, TM, TN, m_groups, n_groups, wgs;
     int64_t rows_per_wg;
+    double cost;          // multiplies on the critical path (the configuration search's figure of merit)
 };
 
 inline int tn_env(const char* name, int dflt)
@@ -1221,6 +1222,7 @@ inline TnDirectCfg tn_direct_config(int64_t M, int64_t Ka, int64_t N, bool want_
             }
         }
     }
+    best.cost = best_cost;
     const int groups = best.m_groups * best.n_groups;
     int wgs = (w_env > 0 ? w_env : 512) / groups;
     if (wgs < 32) wgs = 32;
@@ -1231,6 +1233,20 @@ inline TnDirectCfg tn_direct_config(int64_t M, int64_t Ka, int64_t N, bool want_
     best.wgs = int((M + rows - 1) / rows);
     if (best.wgs < 1) best.wgs = 1;
     return best;
+}
+
+// The bias gradient rides in the reduction as a virtual all-ones column Ka of X (row Ka of the product).  When Ka is a multiple of
+// the tile size that one row opens a whole new row of tiles — Ka = 512, N = 128: 33 tile rows instead of 32, a second group of
+// waves on grid.y that re-reads G and multiplies 15/16 empty tiles: 4.16 ms against 2.68 without the bias (products shape,
+// tools/r06/tn_strides.py).  Then the column sums are taken by the two-phase column-sum kernel instead (one more read of G: 0.25 ms).
+inline bool tn_bias_by_column_sum(int64_t M, int64_t Ka, int64_t N, bool want_bias, bool gated)
+{
+    static const int on = tn_env("TFGX_TN_SPLIT_BIAS", 1);      // developer A/B
+    if (!want_bias || gated || !on) return false;
+    if (M * N < (int64_t(1) << 26)) return false;               // small gradients: two more launches cost what the tile row does
+    // the ones column opens a new row of 16-row tiles exactly when Ka is a multiple of 16 (the search's cost figure — multiplies
+    // on the critical path — rates that row at +9 %; measured it is +55 %: the extra group of waves also re-reads G)
+    return Ka % 16 == 0;
 }
 
 inline bool tn_use_direct()
@@ -1770,8 +1786,16 @@ extern "C" size_t tfgx_gemm_tn_workspace_bytes(int64_t M, int64_t Ka, int64_t N,
 {
     if (M <= 0 || Ka <= 0 || N <= 0) return 0;
     if (tn_use_direct()) {
+        // (gated calls never split: they get the larger of the two figures)
         const TnDirectCfg d = tn_direct_config(M, Ka, N, want_bias != 0);
-        return sizeof(float) * size_t(Ka + (want_bias ? 1 : 0)) * size_t(N) * size_t(d.wgs);
+        size_t bytes = sizeof(float) * size_t(Ka + (want_bias ? 1 : 0)) * size_t(N) * size_t(d.wgs);
+        if (tn_bias_by_column_sum(M, Ka, N, want_bias != 0, false)) {
+            const TnDirectCfg d0 = tn_direct_config(M, Ka, N, false);
+            const size_t split = (sizeof(float) * size_t(Ka) * size_t(N) * size_t(d0.wgs) + 255) / 256 * 256 +
+                                 tfgx_column_sum_workspace_bytes(M, N);
+            bytes = split > bytes ? split : bytes;
+        }
+        return bytes;
     }
     if (Ka > 2016) return 0;
     const TnCfg c = tn_config(M, Ka, N, want_bias != 0);
@@ -1802,8 +1826,20 @@ extern "C" int tfgx_gemm_tn_gated_f32(const float* X, int64_t ldx, const float* 
         return TFGX_OK;
     }
     TFGX_REQUIRE(X && G && ldx >= Ka && ldg >= N, "null pointer / leading dimension too small");
-    const bool want_bias = db != nullptr;
+    bool want_bias = db != nullptr;
     if (tn_use_direct()) {
+        if (tn_bias_by_column_sum(M, Ka, N, want_bias, gate != nullptr)) {
+            // db by the column-sum kernel out of the tail of the workspace, dW by the reduction without the ones column
+            const TnDirectCfg d0 = tn_direct_config(M, Ka, N, false);
+            const size_t parts_bytes = (sizeof(float) * size_t(Ka) * size_t(N) * size_t(d0.wgs) + 255) / 256 * 256;
+            const size_t cs_bytes = tfgx_column_sum_workspace_bytes(M, N);
+            TFGX_REQUIRE(workspace != nullptr && workspace_bytes >= parts_bytes + cs_bytes, "workspace too small (tfgx_gemm_tn_workspace_bytes)");
+            const int rc = tfgx_column_sum_f32(G, ldg, M, N, db, static_cast<char*>(workspace) + parts_bytes, cs_bytes, stream_);
+            if (rc != TFGX_OK) return rc;
+            want_bias = false;
+            db = nullptr;
+            workspace_bytes = parts_bytes;
+        }
         const TnDirectCfg d = tn_direct_config(M, Ka, N, want_bias);
         const int64_t part_stride = int64_t(Ka + (want_bias ? 1 : 0)) * N;
         TFGX_REQUIRE(workspace != nullptr && workspace_bytes >= sizeof(float) * size_t(part_stride) * size_t(d.wgs),
