@@ -970,6 +970,8 @@ __global__ __launch_bounds__(kBlock) void gat_pack_dst_heads_kernel(const float*
                                                                     float* __restrict__ dsum)
 {
     const int W = H * dv, hb = head_block(d);
+    const bool vec = (dv % 4 == 0) && (ldgo % 4 == 0) && (ldo % 4 == 0) && (P % 4 == 0) &&
+                     ((reinterpret_cast<uintptr_t>(go) | reinterpret_cast<uintptr_t>(o) | reinterpret_cast<uintptr_t>(pack)) & 15) == 0;
     const int per_row = (W + 3) / 4 + H;                 // copies of dO in fours, then one work item per head
     int64_t t = blockIdx.x * int64_t(kBlock) + threadIdx.x;
     const int64_t stride = int64_t(gridDim.x) * kBlock;
@@ -978,13 +980,29 @@ __global__ __launch_bounds__(kBlock) void gat_pack_dst_heads_kernel(const float*
         const int k = int(t - r * per_row);
         float* pr = pack + r * P;
         if (k < (W + 3) / 4) {
-            for (int c = 4 * k; c < 4 * k + 4 && c < W; ++c) pr[c] = go[r * ldgo + c];
+            if (vec) {                                   // whole 16-byte pieces (W % 4 == 0, aligned rows)
+                float t4[4];
+                load_vec<4>(go + r * ldgo + 4 * k, t4);
+                store_vec<4>(pr + 4 * k, t4);
+            } else {
+                for (int c = 4 * k; c < 4 * k + 4 && c < W; ++c) pr[c] = go[r * ldgo + c];
+            }
         } else {
             const int h = k - (W + 3) / 4;
             const float* gp = go + r * ldgo + h * dv;
             const float* op = o + r * ldo + h * dv;
             float acc = 0.0f;
-            for (int i = 0; i < dv; ++i) acc = fmaf(gp[i], op[i], acc);
+            if (vec) {                                   // same terms in the same order, 16-byte loads
+                for (int i = 0; i < dv; i += 4) {
+                    float g4[4], o4[4];
+                    load_vec<4>(gp + i, g4);
+                    load_vec<4>(op + i, o4);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc = fmaf(g4[t], o4[t], acc);
+                }
+            } else {
+                for (int i = 0; i < dv; ++i) acc = fmaf(gp[i], op[i], acc);
+            }
             dsum[r * H + h] = acc;
             float* hp = pr + (W + 3) / 4 * 4 + h * hb;        // the head blocks start on a 16-byte boundary of the row
             for (int u = 0; u < d; ++u) hp[u] = q[r * ldq + h * d + u];
@@ -1006,13 +1024,25 @@ __global__ __launch_bounds__(kBlock) void gat_query_grad_d1_kernel(const float* 
 {
     int64_t i = blockIdx.x * int64_t(kBlock) + threadIdx.x;
     const int64_t stride = int64_t(gridDim.x) * kBlock;
+    const bool vec = (dv % 4 == 0) && (ldgo % 4 == 0) && (ldt % 4 == 0) &&
+                     ((reinterpret_cast<uintptr_t>(go) | reinterpret_cast<uintptr_t>(t)) & 15) == 0;
     for (; i < n * H; i += stride) {
         const int64_t r = i / H;
         const int h = int(i - r * H);
         const float* gp = go + r * ldgo + h * dv;
         const float* tp = t + r * ldt + h * dv;
         float acc = 0.0f;
-        for (int j = 0; j < dv; ++j) acc = fmaf(gp[j], tp[j], acc);
+        if (vec) {
+            for (int j = 0; j < dv; j += 4) {
+                float g4[4], t4[4];
+                load_vec<4>(gp + j, g4);
+                load_vec<4>(tp + j, t4);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc = fmaf(g4[u], t4[u], acc);
+            }
+        } else {
+            for (int j = 0; j < dv; ++j) acc = fmaf(gp[j], tp[j], acc);
+        }
         gq[r * ldgq + h] = fmaf(-dsum[i], s[i], acc) / scale;
     }
 }
