@@ -37,7 +37,10 @@ namespace {
 #define TFGX_POOL_EXPERIMENT 0      // developer A/B, TIMING ONLY (wrong results): 1 = no LDS reads / FMAs, 2 = no gather of x rows
 #endif
 constexpr int kPoolChunk = 96;      // edges staged at a time, at most (products shape: in-degree 51 +- 7)
-constexpr int kPoolSlots = 4;       // 16-byte loads per thread and chunk: a chunk holds min(96, 4 * threads / (F_in / 4)) edges
+#ifndef TFGX_POOL_SLOTS
+#define TFGX_POOL_SLOTS 4             // developer A/B
+#endif
+constexpr int kPoolSlots = TFGX_POOL_SLOTS;       // 16-byte loads per thread and chunk: a chunk holds min(96, 4 * threads / (F_in / 4)) edges
 
 struct PoolArgs {
     const int32_t* row_ptr;
