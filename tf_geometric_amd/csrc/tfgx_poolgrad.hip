@@ -18,8 +18,9 @@
 //                         winner's staged row X[p_j][0..F_in] from LDS with immediate offsets: 2 instructions per multiply-add.
 //                         (ds_read_b128: 256 bytes per clock).  Rows are staged XS = KMAX + 4 floats apart with XS / 4 ODD: the 16
 //                         lanes one LDS cycle serves read different rows at the same features, and p -> p XS / 4 mod 16 is a
-//                         bijection, so up to 16 distinct winners sit in distinct bank groups (equal winners are a broadcast).  Per (row, chunk of <= 96 edges) the x rows of the NEXT chunk are in flight
-//                         (ids one chunk further ahead) while this one is consumed.  A column with tied maxima walks the chunk
+//                         bijection, so up to 16 distinct winners sit in distinct bank groups (equal winners are a broadcast).  Per (row, chunk of <= 96 edges) the x rows of the next TWO chunks
+//                         are in flight (ids one chunk further ahead) while this one is consumed — which holds only because no load
+//                         of the loop is predicated (see load_ids): the exec-masked form drained vmcnt(0) in every step.  A column with tied maxima walks the chunk
 //                         exactly (every tied edge receives g / count)
 //   pool_wgrad_reduce     dW / db = the workgroups' partials added in workgroup order
 #include "tfgx_common.h"
