@@ -324,9 +324,10 @@ def test_gat_layer_grads(tfg, oracle, heads, att, units):
         assert_parity(getattr(layer, k).grad.cpu().numpy(), r[k].grad.numpy(), tol=2e-4, what="gat d/d" + k)
 
 
+@pytest.mark.parametrize("skewed", [False, True])
 @pytest.mark.parametrize("blocks", [None, 5])
 @pytest.mark.parametrize("drop", [0.0, 0.4])
-def test_gat_query_gradient_from_the_forward_sums(tfg, oracle, blocks, drop):
+def test_gat_query_gradient_from_the_forward_sums(tfg, oracle, blocks, drop, skewed):
     """One attention unit per head (the demo's literal layer): the training forward accumulates T = sum a k V and S = sum a k,
     dQ = (<dO, T> - D S) / scale per row — against the destination pass (the same inputs with the route switched off: the
     forward must be bit-identical, dQ equal to rounding) and against float64 autograd."""
@@ -335,10 +336,15 @@ def test_gat_query_gradient_from_the_forward_sums(tfg, oracle, blocks, drop):
     from tf_geometric_amd.plan import CsrPlan
     if blocks is not None and drop > 0.0:
         pytest.skip("source blocks run without attention dropout")
+    if skewed and (drop == 0.0 or blocks is not None):
+        pytest.skip("long rows run inline (degree-ordered walk) only under attention dropout; without it they are hub chunks")
     rng = np.random.default_rng(77)
     n, e, H, dv = 500, 30000, 8, 8
     ei = np.stack([rng.integers(0, n, e), rng.integers(0, n, e)]).astype(np.int32)
+    if skewed:        # five destinations with 900 in-edges each: the plan walks its rows in degree order
+        ei = np.concatenate([ei, np.stack([np.repeat(np.arange(5), 900), rng.integers(0, n, 4500)]).astype(np.int32)], axis=1)
     plan = CsrPlan.from_cache(ei, n, n, {})
+    assert (plan.row_order() is not None) == skewed
     Qn, Kn, Vn = (rng.standard_normal((n, H)).astype(np.float32) * 1.5, rng.standard_normal((n, H)).astype(np.float32) * 1.5,
                   rng.standard_normal((n, H * dv)).astype(np.float32))
     gout = torch.tensor(rng.standard_normal((n, H * dv)).astype(np.float32), device="cuda")
