@@ -314,3 +314,25 @@ def test_edge_weights_written_in_place_are_seen(tfg, oracle):
     b = layer([xd, eid, wd], cache=cache)
     fresh = layer([xd, eid, wd.clone()], cache={})
     assert torch.equal(b, fresh) and not torch.equal(a, b)
+
+
+def test_max_pool_sage_layer0_backward_on_a_graph_without_edges(tfg):
+    """The destination-major weight gradient of the pooling MLP (tfgx_pool_mlp_max_wgrad_f32) loads unconditionally inside its row
+    loop: a graph with NO edge must not reach that loop — every pooled value is float32 lowest, nothing passes the ReLU, the
+    MLP's gradients are exact zeros and the self half trains as usual."""
+    import numpy as np
+    n, f = 300, 100
+    x = torch.randn(n, f, device="cuda")
+    ei = np.zeros((2, 0), np.int32)
+    layer = tfg.layers.MaxPoolGraphSage(256, activation=tfg.relu, concat=True)
+    layer._maybe_build([x])
+    layer.trainable(True)
+    out = layer([x, ei, np.zeros(0, np.float32)], cache={})
+    g = torch.randn(n, 256, device="cuda")
+    g[:, 128:] = 0.0                      # the neighbour half pooled float32 lowest: no gradient through its overflow
+    out.backward(g)
+    grads = {k: v.grad for k, v in layer.weights.items()}
+    assert all(v is None or bool(torch.isfinite(v).all()) for v in grads.values())
+    for k in ("mlp_kernel", "mlp_bias"):
+        assert grads[k] is None or float(grads[k].abs().max()) == 0.0
+    assert float(grads["self_kernel"].abs().max()) > 0.0

@@ -451,7 +451,8 @@ extern "C" int tfgx_pool_mlp_max_wgrad_f32(const int32_t* row_ptr, const int32_t
     TFGX_REQUIRE(workspace_bytes >= tfgx_pool_mlp_max_wgrad_workspace_bytes(n_dst, F_in, Fp), "workspace too small");
     hipStream_t st = as_stream(stream);
     float* partial = static_cast<float*>(workspace);
-    if (n_dst == 0) {
+    if (n_dst == 0 || E == 0) {      // (no edge: every maximum is float lowest, nothing passes the ReLU — and the row loop's
+                                     //  unconditional loads need col[0] to exist)
         TFGX_HIP_CHECK(hipMemset2DAsync(dW, sizeof(float) * size_t(lddw), 0, sizeof(float) * size_t(Fp), size_t(F_in), st));
         if (db) TFGX_HIP_CHECK(hipMemsetAsync(db, 0, sizeof(float) * size_t(Fp), st));
         return TFGX_OK;
